@@ -1,0 +1,143 @@
+"""CPU: pins the oracle (oracle/mmd_oracle.py) to the golden vectors produced by the genuine reference
+(tools/make_golden.py).  Runs without a GPU and without /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mmd_amd import synth
+from oracle import mmd_oracle as O
+import cases
+from cases import GOLDEN, H, D, rel_l2
+
+
+def test_g1_schedule_tables_bit_exact():
+    g = np.load(os.path.join(GOLDEN, "g1_schedules.npz"))
+    for T in (25, 50, 100):
+        tb = O.schedule_tables(T)
+        for k in O.SCHEDULE_KEYS:
+            assert np.array_equal(tb[k].numpy(), g[f"T{T}.{k}"]), (T, k)
+
+
+def test_g2_unet_forward():
+    g = np.load(os.path.join(GOLDEN, "g2_unet.npz"))
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(int(g["weights_seed"])))
+    x = torch.from_numpy(synth.synth_noise(int(g["x_seed"]), (4, H, D)))
+    for t in g["ts"]:
+        eps = O.unet_forward(sd, x, torch.full((4,), int(t), dtype=torch.long))
+        assert rel_l2(eps, g[f"eps_t{t}"]) < 1e-6
+
+
+@pytest.mark.parametrize("env_id", ["EnvEmpty2D", "EnvHighways2D", "EnvConveyor2D", "EnvDropRegion2D"])
+def test_g3_sdf_grid(env_id):
+    g = np.load(os.path.join(GOLDEN, "g3_sdf.npz"))
+    sdf, grad = O.build_sdf_grid(env_id)
+    assert tuple(sdf.shape) == tuple(g[f"{env_id}.shape"])
+    idx = g[f"{env_id}.idx"]
+    assert np.array_equal(sdf.numpy()[idx[:, 0], idx[:, 1]], g[f"{env_id}.sdf"])
+    assert np.array_equal(grad.numpy()[idx[:, 0], idx[:, 1]], g[f"{env_id}.grad"])
+    assert abs(sdf.double().sum().item() - float(g[f"{env_id}.sum_sdf"])) < 1e-6
+    assert abs(grad.double().abs().sum().item() - float(g[f"{env_id}.sum_abs_grad"])) < 1e-6
+
+
+def test_g4_guide_terms():
+    g = np.load(os.path.join(GOLDEN, "g4_guide_terms.npz"))
+    x = torch.from_numpy(synth.synth_noise(int(g["x_seed"]), (8, H, D))) * float(g["x_scale"])
+    gp = cases.guide_params("EnvHighways2D")
+    _, _, soft, hard = cases.highways_case()
+    _, terms = O.guide_grad(x, gp, [soft, hard], return_terms=True)
+    for name, term in zip(("obj", "ws", "gp", "cons_soft", "cons_hard"), terms):
+        ref = torch.from_numpy(g[f"term_{name}"])
+        assert float((term - ref).abs().max()) <= 1e-6, name
+    # the GP term must be non-trivial, the object term must touch some points on Highways
+    assert float(torch.from_numpy(g["term_gp"]).abs().max()) > 0.1
+    assert float(torch.from_numpy(g["term_obj"]).abs().max()) > 0.1
+    assert float(torch.from_numpy(g["term_cons_soft"]).abs().max()) > 0.1
+
+
+def test_g5_full_guide():
+    g = np.load(os.path.join(GOLDEN, "g5_guide.npz"))
+    gp = cases.guide_params("EnvHighways2D")
+    _, _, soft, hard = cases.highways_case()
+    x = torch.from_numpy(synth.synth_noise(7, (8, H, D))) * 0.6
+    assert float((O.guide_grad(x, gp, [soft, hard]) - torch.from_numpy(g["highways_B8"])).abs().max()) <= 1e-7
+    x2 = torch.from_numpy(synth.synth_noise(8, (8, H, D))) * 1.1
+    assert float((O.guide_grad(x2, gp, [soft, hard]) - torch.from_numpy(g["highways_B8_wide"])).abs().max()) <= 1e-7
+    # the always-clip variant (what the HIP kernel implements) agrees here because the batch exceeds 1+1e-4
+    assert float((O.guide_grad(x2, gp, [soft, hard], clip_mode="always")
+                  - torch.from_numpy(g["highways_B8_wide"])).abs().max()) <= 1e-7
+    # dense, autograd, reference-shaped evaluation agrees with the closed form
+    assert float((O.guide_grad_dense_autograd(x, gp, [soft, hard]) - torch.from_numpy(g["highways_B8"])).abs().max()) <= 1e-6
+    gpe = cases.guide_params("EnvEmpty2D")
+    starts, goals = synth.start_goal_circle(32, 0.8)
+    grp = cases.soft_group(synth.straight_line_paths(starts, goals, H), 0)
+    assert grp.q.shape[0] == 31 * 63
+    x3 = torch.from_numpy(synth.synth_noise(9, (4, H, D))) * 0.5
+    assert float((O.guide_grad(x3, gpe, [grp]) - torch.from_numpy(g["empty32_B4"])).abs().max()) <= 1e-7
+
+
+@pytest.mark.parametrize("name", cases.SAMPLE_CASES)
+def test_g6_run_inference(name):
+    g = np.load(os.path.join(GOLDEN, f"g6_sample_{name}.npz"))
+    case = cases.sample_case(name)
+    chain = cases.oracle_run_inference(case)
+    assert chain.shape[0] == case["T"] + 2
+    rows = g["rows"]
+    ref = torch.from_numpy(g["chain_rows"])
+    for k, r in enumerate(rows):
+        assert rel_l2(chain[r], ref[k]) < 1e-4, (name, int(r), rel_l2(chain[r], ref[k]))
+    assert rel_l2(chain[-1], ref[-1]) < 1e-4
+
+
+def test_g7_run_local_inference():
+    g = np.load(os.path.join(GOLDEN, "g7_local.npz"))
+    T, B = 50, 8
+    starts, goals, soft, hard = cases.highways_case()
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    tb = O.schedule_tables(T)
+    gp = cases.guide_params("EnvHighways2D")
+    a = np.linspace(0, 1, H, dtype=np.float32)[None, :, None]
+    pos = starts[3][None, None] * (1 - a) + goals[3][None, None] * a
+    seed = np.concatenate([np.repeat(pos, B, 0), np.zeros((B, H, 2), np.float32)], -1)
+    seed = torch.from_numpy((seed + 0.02 * synth.synth_noise(23, (B, H, D))).astype(np.float32))
+    qn = torch.from_numpy(synth.synth_noise(24, (B, H, D)))
+    steps = torch.from_numpy(synth.synth_noise(25, (4, B, H, D)))
+    x0 = O.q_sample(tb, seed, 3, qn)
+    chain = O.p_sample_loop(sd, tb, x0, cases.hard_conds_for(starts[3], goals[3]), 3, steps,
+                            guide=lambda x: O.guide_grad(x, gp, [soft, hard]), n_guide_steps=20, t_start_guide=25,
+                            noise_std_extra=0.5, n_diffusion_steps_without_noise=1)
+    ref = torch.from_numpy(g["chain"])
+    assert chain.shape == ref.shape == (5, B, H, D)
+    for r in range(5):
+        assert rel_l2(chain[r], ref[r]) < 1e-5, r
+
+
+def test_g8_ensemble():
+    g = np.load(os.path.join(GOLDEN, "g8_ensemble.npz"))
+    T, B = 25, 4
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    tb = O.schedule_tables(T)
+    gp = cases.guide_params("EnvEmptyNoWait2D", cutoff=0.01)
+    transforms = {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])}
+    s = cases.hard_conds_for([-0.7, 0.3], [0, 0])[0]
+    gl = cases.hard_conds_for([0.6, -0.4], [0, 0])[0]
+    hard = {0: {0: s}, 1: {H - 1: gl}}
+    cross = {(0, 1): (H - 1, 0)}
+    cons = {0: [cases.hard_group([[0.2, 0.1]], [[30, 36]])], 1: [cases.hard_group([[-0.3, -0.1]], [[10, 14]])]}
+    x = {m: O.apply_hard_conditioning(torch.from_numpy(synth.synth_noise(26 + m, (B, H, D))), hard[m]) for m in (0, 1)}
+    steps = torch.from_numpy(synth.synth_noise(28, (T + 1, 2, B, H, D)))
+    x = O.apply_cross_conditioning(x, cross, transforms)
+    k = 0
+    mid = {}
+    for i in reversed(range(-1, T)):
+        for m in (0, 1):
+            x[m] = O.ddpm_sample_step(sd, tb, x[m], hard[m], i, guide=lambda y, m=m: O.guide_grad(y, gp, cons[m]),
+                                      n_guide_steps=20, t_start_guide=13, noise=steps[k, m], noise_std_extra=0.5)
+            x[m] = O.apply_hard_conditioning(x[m], hard[m])
+            x = O.apply_cross_conditioning(x, cross, transforms)
+        k += 1
+        if k == T // 2 + 1:
+            mid = {m: x[m].clone() for m in (0, 1)}
+    assert rel_l2(mid[0], g["chain0_mid"]) < 1e-4 and rel_l2(mid[1], g["chain1_mid"]) < 1e-4
+    assert rel_l2(x[0], g["final0"]) < 1e-4 and rel_l2(x[1], g["final1"]) < 1e-4

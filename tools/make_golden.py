@@ -1,0 +1,295 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the GENUINE reference (imported from
+/root/reference; build container only -- SURVEY.md §8c).  Inputs are regenerated from numpy-PCG64 seeds by
+`mmd_amd.synth`; only seeds/parameters and the reference's OUTPUTS are stored.  No reference code is stored.
+
+    python tools/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixtures:
+  g1_schedules.npz     12 diffusion buffers for T in {25,50,100}
+  g2_unet.npz          TemporalUnet eps for B=4 at t in {0,37,99}
+  g3_sdf.npz           per map: float64 checksums of the 400x400 SDF grid + 4096 sampled (value, grad) cells
+  g4_guide_terms.npz   clipped per-term guide gradients (objects, ws-boundary, GP, constraints) on Highways, B=8
+  g5_guide.npz         full guide(x): Highways+constraints (B=8), Empty + 31x63 soft constraints (B=4)
+  g6_sample_*.npz      run_inference chains with injected noise
+  g7_local.npz         run_local_inference (3 noising / 3 denoising steps)
+  g8_ensemble.npz      2-tile DiffusionsEnsemble.run_inference
+"""
+import os
+import sys
+from math import ceil
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+from ref_harness import (make_model, make_guide, make_cost_constraint, make_task, injected_noise, quiet,   # noqa: E402
+                         ddpm_sample_fn, TENSOR_ARGS)
+from mmd_amd import synth                                                                                 # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+MINS, MAXS = synth.NORM_MINS, synth.NORM_MAXS
+H, D = 64, 4
+RADIUS_SOFT = 0.05 * 2.4        # mmd_params.py:52
+
+
+def normalize(x):
+    return 2 * (x - MINS) / (MAXS - MINS) - 1
+
+
+def hard_conds_for(start, goal):
+    """dataset.get_hard_conditions(..., normalize=True) (mmd/datasets/trajectories.py:216-239)."""
+    s = normalize(np.concatenate([start, np.zeros(2, np.float32)]).astype(np.float32))
+    g = normalize(np.concatenate([goal, np.zeros(2, np.float32)]).astype(np.float32))
+    return {0: torch.from_numpy(s.astype(np.float32)), H - 1: torch.from_numpy(g.astype(np.float32))}
+
+
+def soft_points(paths, agent):
+    """cbs.py:468-508 for equal start times."""
+    q, tr = [], []
+    for j in range(paths.shape[0]):
+        if j == agent:
+            continue
+        for t in range(1, H):
+            q.append(paths[j, t])
+            tr.append((t, t + 1))
+    return np.array(q, np.float32), np.array(tr, np.int64), np.full(len(q), RADIUS_SOFT, np.float32)
+
+
+def g1():
+    out = {}
+    sd = synth.synth_unet_state_dict(0)
+    for T in (25, 50, 100):
+        with quiet():
+            m = make_model(sd, T)
+        for k, v in m.state_dict().items():
+            if not k.startswith("model."):
+                out[f"T{T}.{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_schedules.npz"), **out)
+
+
+def g2():
+    sd = synth.synth_unet_state_dict(0)
+    with quiet():
+        m = make_model(sd, 100)
+    x = torch.from_numpy(synth.synth_noise(5, (4, H, D)))
+    out = {"weights_seed": 0, "x_seed": 5, "ts": np.array([0, 37, 99])}
+    for t in (0, 37, 99):
+        with torch.no_grad():
+            out[f"eps_t{t}"] = m.model(x, torch.full((4,), t, dtype=torch.long), None).numpy()
+    np.savez_compressed(os.path.join(OUT, "g2_unet.npz"), **out)
+
+
+def g3():
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(33))
+    for env_id in ("EnvEmpty2D", "EnvHighways2D", "EnvConveyor2D", "EnvDropRegion2D"):
+        with quiet():
+            env, robot, task = make_task(env_id)
+        g = env.grid_map_sdf_obj_fixed
+        sdf, grad = g.sdf_tensor.numpy(), g.grad_sdf_tensor.numpy()
+        idx = rng.integers(0, 400, size=(4096, 2))
+        out[f"{env_id}.shape"] = np.array(sdf.shape)
+        out[f"{env_id}.sum_sdf"] = np.float64(sdf.astype(np.float64).sum())
+        out[f"{env_id}.sum_abs_grad"] = np.float64(np.abs(grad.astype(np.float64)).sum())
+        out[f"{env_id}.idx"] = idx
+        out[f"{env_id}.sdf"] = sdf[idx[:, 0], idx[:, 1]]
+        out[f"{env_id}.grad"] = grad[idx[:, 0], idx[:, 1]]
+    np.savez_compressed(os.path.join(OUT, "g3_sdf.npz"), **out)
+
+
+def highways_case(agent=3, n_agents=10):
+    starts, goals = synth.start_goal_circle(n_agents, 0.45)
+    paths = synth.straight_line_paths(starts, goals, H)
+    q, tr, r = soft_points(paths, agent)
+    hard_q = np.array([[0.1, 0.2]], np.float32)
+    hard_tr = np.array([[20, 27]], np.int64)
+    hard_r = np.array([RADIUS_SOFT], np.float32)
+    return starts, goals, (q, tr, r), (hard_q, hard_tr, hard_r)
+
+
+def g4_g5():
+    x = torch.from_numpy(synth.synth_noise(7, (8, H, D))) * 0.6
+    _, _, soft, hard = highways_case()
+    out = {"x_seed": 7, "x_scale": 0.6}
+    for name, which in (("obj", ("obj",)), ("ws", ("ws",)), ("gp", ("gp",)), ("cons", ())):
+        with quiet():
+            guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS, which=which, w_coll=1.0, w_smooth=1.0)
+        if name == "cons":
+            guide.add_extra_costs([make_cost_constraint(robot, *soft, True), make_cost_constraint(robot, *hard, False)],
+                                  [1.0, 0.0])
+            out["term_cons_soft"] = (-guide(x)).numpy()
+            guide.reset_extra_costs()
+            guide.add_extra_costs([make_cost_constraint(robot, *hard, False)], [1.0])
+            out["term_cons_hard"] = (-guide(x)).numpy()
+        else:
+            out[f"term_{name}"] = (-guide(x)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g4_guide_terms.npz"), **out)
+
+    out = {}
+    with quiet():
+        guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS)
+    guide.add_extra_costs([make_cost_constraint(robot, *soft, True), make_cost_constraint(robot, *hard, False)],
+                          [2e-2, 2e-1])
+    out["highways_B8"] = guide(x).numpy()
+    # values beyond +-1 exercise the data-dependent clip of LimitsNormalizer.unnormalize
+    x2 = torch.from_numpy(synth.synth_noise(8, (8, H, D))) * 1.1
+    out["highways_B8_wide"] = guide(x2).numpy()
+    guide.reset_extra_costs()
+    with quiet():
+        guide, robot, task, env = make_guide("EnvEmpty2D", MINS, MAXS)
+    starts, goals = synth.start_goal_circle(32, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    q, tr, r = soft_points(paths, 0)
+    guide.add_extra_costs([make_cost_constraint(robot, q, tr, r, True)], [2e-2])
+    x3 = torch.from_numpy(synth.synth_noise(9, (4, H, D))) * 0.5
+    out["empty32_B4"] = guide(x3).numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_guide.npz"), **out)
+
+
+CHAIN_ROWS = lambda T: sorted({0, 1, 2, T // 2, T // 2 + 1, T // 2 + 2, T - 1, T, T + 1})   # noqa: E731
+
+
+def run_ref_inference(env_id, T, B, start, goal, cons, seed_xT, seed_steps, weights_seed=0, cutoff=0.05,
+                      n_guide_steps=20, use_guide=True):
+    sd = synth.synth_unet_state_dict(weights_seed)
+    with quiet():
+        model = make_model(sd, T)
+        guide, robot, task, env = make_guide(env_id, MINS, MAXS, cutoff_margin=cutoff)
+    costs, ws = [], []
+    for (q, tr, r, soft) in cons:
+        costs.append(make_cost_constraint(robot, q, tr, r, soft))
+        ws.append(2e-2 if soft else 2e-1)                              # mpd.py:409-412, mmd_params.py:42-43
+    guide.add_extra_costs(costs, ws)
+    xT = synth.synth_noise(seed_xT, (B, H, D))
+    steps = synth.synth_noise(seed_steps, (T + 1, B, H, D))
+    with quiet(), injected_noise([xT] + list(steps)) as q:
+        chain = model.run_inference(
+            None, hard_conds_for(start, goal), n_samples=B, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn,
+            guide=guide if use_guide else None, n_guide_steps=n_guide_steps, t_start_guide=ceil(0.5 * T),
+            noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=1)
+        assert len(q) == 0
+    guide.reset_extra_costs()
+    return chain.numpy()          # [T+2, B, H, D]
+
+
+def g6():
+    # (a) config 2 shape: Empty, 6 robots on a circle, robot 0, soft constraints from the 5 others, T=50
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    q, tr, r = soft_points(paths, 0)
+    chain = run_ref_inference("EnvEmpty2D", 50, 8, starts[0], goals[0], [(q, tr, r, True)], 11, 12)
+    rows = CHAIN_ROWS(50)
+    np.savez_compressed(os.path.join(OUT, "g6_sample_empty_T50.npz"), rows=np.array(rows), chain_rows=chain[rows],
+                        meta=np.array([50, 8, 6, 0, 11, 12]))
+    # (b) config 3 shape: Highways, 10 robots small circle, robot 3, soft + one hard constraint, T=100
+    starts, goals, soft, hard = highways_case()
+    chain = run_ref_inference("EnvHighways2D", 100, 8, starts[3], goals[3], [(*soft, True), (*hard, False)], 13, 14)
+    rows = CHAIN_ROWS(100)
+    np.savez_compressed(os.path.join(OUT, "g6_sample_highways_T100.npz"), rows=np.array(rows), chain_rows=chain[rows],
+                        meta=np.array([100, 8, 10, 3, 13, 14]))
+    # (c) released-checkpoint step count: Empty, no constraints, T=25
+    chain = run_ref_inference("EnvEmpty2D", 25, 4, starts[0], goals[0], [], 15, 16)
+    rows = CHAIN_ROWS(25)
+    np.savez_compressed(os.path.join(OUT, "g6_sample_empty_T25_nocons.npz"), rows=np.array(rows),
+                        chain_rows=chain[rows], meta=np.array([25, 4, 10, 0, 15, 16]))
+    # (d) config 0: single robot, 1 sample, T=50
+    chain = run_ref_inference("EnvEmpty2D", 50, 1, np.array([-0.8, 0], np.float32), np.array([0.8, 0], np.float32),
+                              [], 17, 18)
+    np.savez_compressed(os.path.join(OUT, "g6_sample_cfg0_T50_B1.npz"), rows=np.arange(52), chain_rows=chain,
+                        meta=np.array([50, 1, 1, 0, 17, 18]))
+    # (e) north-star per-robot shape, short: Empty, 32 robots, robot 5, 31x63 soft points, T=25, B=4
+    starts, goals = synth.start_goal_circle(32, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    q, tr, r = soft_points(paths, 5)
+    chain = run_ref_inference("EnvEmpty2D", 25, 4, starts[5], goals[5], [(q, tr, r, True)], 19, 20)
+    rows = CHAIN_ROWS(25)
+    np.savez_compressed(os.path.join(OUT, "g6_sample_empty32_T25.npz"), rows=np.array(rows), chain_rows=chain[rows],
+                        meta=np.array([25, 4, 32, 5, 19, 20]))
+    # (f) Conveyor map (config 5 shape, one robot's shard): 8 robots on the boundary, robot 2, T=50
+    starts, goals = synth.start_goal_boundary(8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    q, tr, r = soft_points(paths, 2)
+    chain = run_ref_inference("EnvConveyor2D", 50, 4, starts[2], goals[2], [(q, tr, r, True)], 21, 22)
+    rows = CHAIN_ROWS(50)
+    np.savez_compressed(os.path.join(OUT, "g6_sample_conveyor_T50.npz"), rows=np.array(rows), chain_rows=chain[rows],
+                        meta=np.array([50, 4, 8, 2, 21, 22]))
+
+
+def g7():
+    """run_local_inference (diffusion_model_base.py:353-421): noise the seed batch 3 steps, denoise 3 (+1)."""
+    T, B = 50, 8
+    sd = synth.synth_unet_state_dict(0)
+    starts, goals, soft, hard = highways_case()
+    with quiet():
+        model = make_model(sd, T)
+        guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS)
+    guide.add_extra_costs([make_cost_constraint(robot, *soft, True), make_cost_constraint(robot, *hard, False)],
+                          [2e-2, 2e-1])
+    # seed trajectories: straight line + small noise, UN-normalised as the caller passes them (cbs.py:424)
+    a = np.linspace(0, 1, H, dtype=np.float32)[None, :, None]
+    pos = starts[3][None, None] * (1 - a) + goals[3][None, None] * a
+    seed = np.concatenate([np.repeat(pos, B, 0), np.zeros((B, H, 2), np.float32)], -1)
+    seed = (seed + 0.02 * synth.synth_noise(23, (B, H, D))).astype(np.float32)
+    qn = synth.synth_noise(24, (B, H, D))
+    steps = synth.synth_noise(25, (4, B, H, D))
+    with quiet(), injected_noise([qn] + list(steps)) as q:
+        chain = model.run_local_inference(
+            torch.from_numpy(seed), 3, 3, None, hard_conds_for(starts[3], goals[3]), n_samples=B, horizon=H,
+            return_chain=True, sample_fn=ddpm_sample_fn, guide=guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+            noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=1)
+        assert len(q) == 0
+    np.savez_compressed(os.path.join(OUT, "g7_local.npz"), chain=chain.numpy(), meta=np.array([T, B, 10, 3, 23, 24, 25]))
+
+
+def g8():
+    """2-tile DiffusionsEnsemble.p_sample_loop (diffusion_ensemble.py:55-106): tiles at x-offsets 0 and 2, the end of
+    tile 0 cross-conditioned onto the start of tile 1 (sample_functions.py:17-31)."""
+    from mmd.models.diffusion_models.diffusion_ensemble import DiffusionsEnsemble
+    T, B = 25, 4
+    sd = synth.synth_unet_state_dict(0)
+    with quiet():
+        models = {0: make_model(sd, T), 1: make_model(sd, T)}
+        guides = {}
+        for m in (0, 1):
+            # separate guide objects (own extra-cost lists) over the same map; MPDEnsemble uses cutoff 0.01
+            guides[m], robot, task, env = make_guide("EnvEmptyNoWait2D", MINS, MAXS, cutoff_margin=0.01)
+    transforms = {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])}
+    ens = DiffusionsEnsemble(models, transforms)
+    start = np.array([-0.7, 0.3], np.float32)
+    goal = np.array([0.6, -0.4], np.float32)          # in tile 1's local frame
+    s = hard_conds_for(start, start)[0]
+    g = hard_conds_for(goal, goal)[0]
+    hard_conds = {0: {0: s.repeat(B, 1)}, 1: {H - 1: g.repeat(B, 1)}}
+    cross_conds = {(0, 1): (H - 1, 0)}
+    # one soft constraint point per tile so that the guides differ
+    cons = {0: (np.array([[0.2, 0.1]], np.float32), np.array([[30, 36]]), np.array([RADIUS_SOFT], np.float32)),
+            1: (np.array([[-0.3, -0.1]], np.float32), np.array([[10, 14]]), np.array([RADIUS_SOFT], np.float32))}
+    for m in (0, 1):
+        guides[m].add_extra_costs([make_cost_constraint(robot, *cons[m], False)], [2e-1])
+    x0 = [synth.synth_noise(26 + m, (B, H, D)) for m in (0, 1)]
+    steps = synth.synth_noise(28, (T + 1, 2, B, H, D))
+    draws = list(x0) + [steps[k, m] for k in range(T + 1) for m in (0, 1)]
+    sample_kwargs = {m: dict(guide=guides[m], n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                             noise_std_extra_schedule_fn=lambda x: 0.5) for m in (0, 1)}
+    with quiet(), injected_noise(draws) as q:
+        x, chains = ens.p_sample_loop((B, H, D), hard_conds, cross_conds, n_diffusion_steps=T, return_chain=True,
+                                      sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=1,
+                                      sample_kwargs=sample_kwargs)
+        assert len(q) == 0
+    np.savez_compressed(os.path.join(OUT, "g8_ensemble.npz"), final0=x[0].numpy(), final1=x[1].numpy(),
+                        chain0_mid=chains[0][:, T // 2 + 1].numpy(), chain1_mid=chains[1][:, T // 2 + 1].numpy(),
+                        meta=np.array([T, B, 26, 27, 28]))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8"]
+    for name in todo:
+        print("generating", name, flush=True)
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8}[name]()
+    print("done")
