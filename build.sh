@@ -1,0 +1,8 @@
+#!/bin/bash
+# Build libmmd_amd.so for gfx950 (cross-compiles without a GPU).  Usage: ./build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+mkdir -p mmd_amd/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+  mmd_amd/csrc/unet.hip mmd_amd/csrc/guide.hip mmd_amd/csrc/api.hip -o mmd_amd/lib/libmmd_amd.so "$@"
+echo "built mmd_amd/lib/libmmd_amd.so"

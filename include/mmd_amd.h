@@ -1,0 +1,177 @@
+/*
+ * mmd_amd.h -- C ABI of libmmd_amd.so: the MI355X (gfx950) guided-diffusion trajectory sampler that drops in
+ * behind yoraish/mmd's MPD / MPDEnsemble planners.
+ *
+ * The reference has no FFI layer (it is pure Python); the boundary a maintainer would bind is the
+ * "inner" call contract of the planner.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference checkout).  All pointers suffixed _dev are device (HIP) pointers to contiguous
+ * fp32 / int32 data; everything else is host memory.  `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Every function returns 0 on success and a non-zero code on failure; mmd_last_error() gives the text.
+ * No global state besides the last-error string; entry points are re-entrant per (handle, stream).
+ *
+ * Trajectory tensors are [n_traj, H, D] fp32 with D = 4 (x, y, vx, vy) and H = 64 support points, in the
+ * NORMALISED space of the diffusion model; n_traj = n_robots * samples_per_robot, robot-major.
+ */
+#ifndef MMD_AMD_H
+#define MMD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMD_AMD_ABI_VERSION 1
+#define MMD_STATE_DIM 4
+#define MMD_HORIZON 64
+
+typedef struct mmd_unet_s* mmd_unet_t; /* opaque: packed TemporalUnet weights + time-embedding table on device */
+
+int mmd_abi_version(void);
+const char* mmd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * TemporalUnet  (replaces mmd/models/diffusion_models/temporal_unet.py:23-174 `TemporalUnet.__init__/forward`,
+ * layers mmd/models/layers/layers.py:232-358)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Number of parameter tensors, and the element count of tensor i, in the reference's state_dict order for
+ * TemporalUnet(state_dim=4, n_support_points=64, unet_input_dim, dim_mults=(1,2,4)).
+ * Only unet_input_dim == 32 with 3 levels is instantiated in this build; others return an error. */
+int mmd_unet_num_tensors(int unet_input_dim, int n_levels);
+int64_t mmd_unet_tensor_numel(int unet_input_dim, int n_levels, int index);
+
+/* Build the device-side model from HOST fp32 tensors given in state_dict order (the values of
+ * `{k: v for k, v in diffusion_model.state_dict().items() if k.startswith('model.')}`; replaces
+ * `diffusion_model.load_state_dict(...)`, mmd/planners/single_agent/mpd.py:167-172).  `numels[i]` is checked
+ * against mmd_unet_tensor_numel.  Also precomputes, on the GPU, the time-embedding projections of every integer
+ * diffusion step t in [0, n_diffusion_steps) (TimeEncoder + the 12 cond_mlp heads; t is identical across the
+ * batch, mmd/models/diffusion_models/diffusion_model_base.py:27-29). */
+int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_diffusion_steps,
+                    const float* const* tensors, const int64_t* numels, int n_tensors, void* stream);
+int mmd_unet_destroy(mmd_unet_t unet);
+
+/* Scratch (activations) needed by mmd_unet_forward for n_traj trajectories; allocate it with the host framework. */
+size_t mmd_unet_workspace_bytes(mmd_unet_t unet, int n_traj);
+
+/* eps = model(x, t, context=None)  (temporal_unet.py:121; called from p_mean_variance,
+ * diffusion_model_base.py:152).  t is one integer for the whole batch. */
+int mmd_unet_forward(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj, void* workspace_dev,
+                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Guide  (replaces GuideManagerTrajectoriesWithVelocity.forward, mmd/models/diffusion_models/guides.py:180-226,
+ * with the cost terms of deps/motion_planning_baselines/mp_baselines/planners/costs/cost_functions.py:149-193,
+ * :275-326, :505-542 and the SDF fields of deps/torch_robotics/.../distance_fields.py:333-367,
+ * environments/grid_map_sdf.py:84-114)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+typedef struct mmd_guide_desc {
+  /* LimitsNormalizer (mmd/datasets/normalization.py:145-168): x_u = (clip(x,-1,1)+1)/2*(max-min)+min.
+   * The clip is applied unconditionally (the reference clips only if the batch leaves [-1-1e-4, 1+1e-4]). */
+  float norm_min[MMD_STATE_DIM];
+  float norm_max[MMD_STATE_DIM];
+  /* SDF grids of the fixed objects: GridMapSDF (grid_map_sdf.py:9-114).  Cell (ix,iy) holds float4
+   * (sdf, d sdf/dx, d sdf/dy, 0); layout [n_maps][n_grids][nx][ny][4]; index = floor((p-lo)/(hi-lo)*n) clamped. */
+  float limits_lo[2];
+  float limits_hi[2];
+  int32_t grid_nx, grid_ny, n_grids, n_maps;
+  const float* sdf_grids_dev;
+  const int32_t* robot_map_dev;      /* [n_robots] map index per robot, or NULL (all robots use map 0) */
+  /* workspace boundaries (tasks.py:75-86, already scaled by 1.08) */
+  float ws_min[2];
+  float ws_max[2];
+  float margin;                      /* 1.1 * robot radius + obstacle cutoff margin (distance_fields.py:117) */
+  float dt;                          /* trajectory_duration / n_support_points (mpd.py:140) */
+  float sigma_gp;                    /* 1.0 (mpd.py:237) */
+  float weight_collision;            /* weight_grad_cost_collision  (mmd_params.py:40) */
+  float weight_smoothness;           /* weight_grad_cost_smoothness (mmd_params.py:41) */
+  float max_grad_norm;               /* 1.0 (guides.py:154) */
+  /* Constraints: one group per CostConstraint (= per MultiPointConstraint, mmd/common/constraints.py:46-85),
+   * stored time-bucketed (ELL): slot j of a group holds, for every time step t, at most one active point
+   * float4 (qx, qy, radius, 0) with radius < 0 meaning "no point".  cons_ell_dev is [n_slots][H][4];
+   * group g owns slots [grp_slot_off[g], grp_slot_off[g+1]); robot r owns groups
+   * [robot_grp_off[r], robot_grp_off[r+1]).  Build it with mmd_pack_constraints or
+   * mmd_soft_constraints_from_paths.  NULL pointers = no constraints. */
+  const float* cons_ell_dev;
+  const int32_t* grp_slot_off_dev;
+  const float* grp_weight_dev;
+  const int32_t* robot_grp_off_dev;
+} mmd_guide_desc;
+
+/* Host helper: time-bucket one robot's constraint groups.  For group g (n_pts[g] points): q [n,2], t_range [n,2]
+ * as [t0, t1) (exclusive end, cost_functions.py:305), radius [n].  Writes the ELL block into `ell_out`
+ * ([max_slots][H][4], host) and returns the number of slots used by each group in slots_out[g]; returns an error
+ * if max_slots is too small.  With ell_out == NULL only slots_out is filled (sizing pass).  (Replaces the per-call CostConstraint construction, mpd.py:329-342.) */
+int mmd_pack_constraints(int n_groups, const int32_t* n_pts, const float* const* q, const float* const* t_range,
+                         const float* const* radius, int horizon, float* ell_out, int max_slots,
+                         int32_t* slots_out);
+
+/* Device helper: all-pairs soft constraints from the robots' current best paths (replaces
+ * CBS.create_soft_constraints_from_other_agents_paths, mmd/planners/multi_agent/cbs.py:468-508, for equal start
+ * times).  paths_dev [n_all, H, 2] un-normalised positions of ALL robots (after the all-gather); this rank owns
+ * robots [robot0, robot0 + n_local).  Writes one group of (n_all-1) slots per local robot into ell_out_dev
+ * ([n_local*(n_all-1)][H][4]) plus the three offset/weight arrays (sizes n_local+1, n_local, n_local+1). */
+int mmd_soft_constraints_from_paths(const float* paths_dev, int n_all, int robot0, int n_local, int horizon,
+                                    float radius, float weight, float* ell_out_dev, int32_t* grp_slot_off_dev,
+                                    float* grp_weight_dev, int32_t* robot_grp_off_dev, void* stream);
+
+/* n_steps x { x += guide(x); apply_hard_conditioning }  (guide_gradient_steps,
+ * mmd/models/diffusion_models/sample_functions.py:89-107).  hard_dev [n_robots][2][4]: normalised start / goal
+ * state of each robot; hard_mask bit0 = row 0 is conditioned, bit1 = row H-1 is conditioned. */
+int mmd_guide_steps(const mmd_guide_desc* g, float* x_dev, const float* hard_dev, int hard_mask, int n_robots,
+                    int samples_per_robot, int n_steps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * DDPM sampling  (replaces ddpm_sample_fn, sample_functions.py:40-86, and GaussianDiffusionModel.p_sample_loop /
+ * run_inference / run_local_inference, diffusion_model_base.py:162-211, :320-421)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+typedef struct mmd_sampler_desc {
+  int32_t n_diffusion_steps;                /* T of the schedule tables */
+  /* [T] host tables (GaussianDiffusionModel buffers, diffusion_model_base.py:83-105) */
+  const float* sqrt_recip_alphas_cumprod;
+  const float* sqrt_recipm1_alphas_cumprod;
+  const float* posterior_mean_coef1;
+  const float* posterior_mean_coef2;
+  const float* posterior_log_variance_clipped;
+  int32_t n_guide_steps;                    /* 20 (mmd_params.py:38) */
+  int32_t t_start_guide;                    /* guide iff loop index i < t_start_guide (sample_functions.py:63) */
+  float noise_std_extra;                    /* 0.5 (mpd.py:303) */
+  int32_t hard_mask;                        /* as in mmd_guide_steps */
+} mmd_sampler_desc;
+
+/* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop (UNet activations + the eps buffer). */
+size_t mmd_sampler_workspace_bytes(mmd_unet_t unet, int n_traj);
+
+/* One ddpm_sample_fn call + the apply_hard_conditioning that follows it in p_sample_loop
+ * (diffusion_model_base.py:199-203): x <- step(x) for loop index i (i < 0 means t = 0, no noise).
+ * guide may be NULL (no guidance).  noise_dev [n_traj,H,4] is the injected randn_like draw, or NULL to draw it
+ * in-kernel from Philox4x32-10 keyed by (seed, draw_index). */
+int mmd_ddpm_step(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_desc* guide, float* x_dev,
+                  const float* hard_dev, int n_robots, int samples_per_robot, int i, const float* noise_dev,
+                  uint64_t seed, uint32_t draw_index, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* The whole loop: for i = n_steps-1 ... -n_steps_without_noise.  x_dev holds x_T (or the warm start; NULL noise
+ * + init_noise != 0 draws x_T in-kernel) on entry and the final sample on exit.  chain_dev, if not NULL, receives
+ * [n_steps + n_steps_without_noise + 1][n_traj,H,4] (chain[0] = conditioned x_T).  step_noise_dev, if not NULL, is
+ * [n_steps + n_steps_without_noise][n_traj,H,4] injected draws in loop order. */
+int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_desc* guide, float* x_dev,
+                      const float* hard_dev, int n_robots, int samples_per_robot, int n_steps,
+                      int n_steps_without_noise, int init_noise, const float* step_noise_dev, uint64_t seed,
+                      float* chain_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* q_sample (diffusion_model_base.py:425-433): x = a * x_start + b * noise (noise injected or Philox). */
+int mmd_q_sample(float* x_dev, const float* x_start_dev, const float* noise_dev, float sqrt_alphas_cumprod_t,
+                 float sqrt_one_minus_alphas_cumprod_t, uint64_t seed, uint32_t draw_index, int n_traj, void* stream);
+
+/* apply_cross_conditioning for one (m1, m2) tile pair (sample_functions.py:17-31): row ind1 of x1 := min(row ind2
+ * of x2 + rel, boundary); then row ind2 of x2 := max(row ind1 of x1 - rel, -boundary); rel / boundary are [4] host. */
+int mmd_cross_condition(float* x1_dev, float* x2_dev, int ind1, int ind2, const float* rel, const float* boundary,
+                        int n_traj, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMD_AMD_H */

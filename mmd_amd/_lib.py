@@ -1,0 +1,103 @@
+"""ctypes binding of libmmd_amd.so (include/mmd_amd.h).  There is NO fallback: if the HIP library is missing the
+import of any compute entry point raises, and on a GPU box every op fails loudly rather than running on the CPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmmd_amd.so")
+ABI_VERSION = 1
+
+
+class GuideDesc(C.Structure):
+    _fields_ = [
+        ("norm_min", C.c_float * 4), ("norm_max", C.c_float * 4),
+        ("limits_lo", C.c_float * 2), ("limits_hi", C.c_float * 2),
+        ("grid_nx", C.c_int32), ("grid_ny", C.c_int32), ("n_grids", C.c_int32), ("n_maps", C.c_int32),
+        ("sdf_grids_dev", C.c_void_p), ("robot_map_dev", C.c_void_p),
+        ("ws_min", C.c_float * 2), ("ws_max", C.c_float * 2),
+        ("margin", C.c_float), ("dt", C.c_float), ("sigma_gp", C.c_float),
+        ("weight_collision", C.c_float), ("weight_smoothness", C.c_float), ("max_grad_norm", C.c_float),
+        ("cons_ell_dev", C.c_void_p), ("grp_slot_off_dev", C.c_void_p), ("grp_weight_dev", C.c_void_p),
+        ("robot_grp_off_dev", C.c_void_p),
+    ]
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [
+        ("n_diffusion_steps", C.c_int32),
+        ("sqrt_recip_alphas_cumprod", C.POINTER(C.c_float)),
+        ("sqrt_recipm1_alphas_cumprod", C.POINTER(C.c_float)),
+        ("posterior_mean_coef1", C.POINTER(C.c_float)),
+        ("posterior_mean_coef2", C.POINTER(C.c_float)),
+        ("posterior_log_variance_clipped", C.POINTER(C.c_float)),
+        ("n_guide_steps", C.c_int32), ("t_start_guide", C.c_int32),
+        ("noise_std_extra", C.c_float), ("hard_mask", C.c_int32),
+    ]
+
+
+_SIGNATURES = {
+    "mmd_abi_version": (C.c_int, []),
+    "mmd_last_error": (C.c_char_p, []),
+    "mmd_unet_num_tensors": (C.c_int, [C.c_int, C.c_int]),
+    "mmd_unet_tensor_numel": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "mmd_unet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    "mmd_unet_destroy": (C.c_int, [C.c_void_p]),
+    "mmd_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "mmd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
+    "mmd_pack_constraints": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
+    "mmd_soft_constraints_from_paths": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmd_guide_steps": (C.c_int, [C.POINTER(GuideDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p]),
+    "mmd_sampler_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "mmd_ddpm_step": (C.c_int, [C.c_void_p, C.POINTER(SamplerDesc), C.POINTER(GuideDesc), C.c_void_p, C.c_void_p,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_size_t,
+                                C.c_void_p]),
+    "mmd_p_sample_loop": (C.c_int, [C.c_void_p, C.POINTER(SamplerDesc), C.POINTER(GuideDesc), C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mmd_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint32,
+                               C.c_int, C.c_void_p]),
+    "mmd_cross_condition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load():
+    """Load (once) and return the CDLL; raises ImportError with the build hint if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: the HIP extension is required (run ./build.sh or "
+                              f"`python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if lib.mmd_abi_version() != ABI_VERSION:
+            raise ImportError(f"libmmd_amd.so ABI {lib.mmd_abi_version()} != expected {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libmmd_amd: " + load().mmd_last_error().decode())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t, name="tensor"):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous float32 CUDA(HIP) tensor")
+    return C.c_void_p(t.data_ptr())

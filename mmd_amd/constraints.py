@@ -1,0 +1,105 @@
+"""Constraint types (mirror of reference mmd/common/constraints.py:46-85 and the CostConstraint holder,
+deps/motion_planning_baselines/mp_baselines/planners/costs/cost_functions.py:275-295) and their packing into the
+time-bucketed ELL table the guide kernel reads (include/mmd_amd.h: mmd_guide_desc.cons_ell_dev)."""
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+VERTEX_CONSTRAINT_RADIUS = 0.05 * 2.4        # mmd/config/mmd_params.py:52
+H = 64
+
+
+class MultiPointConstraint:
+    """Same fields and accessors as the reference class (mmd/common/constraints.py:46-85)."""
+
+    def __init__(self, q_l: List[torch.Tensor], t_range_l: List[Tuple[int, int]], radius_l: List[float] = None,
+                 is_soft: bool = False):
+        self.q_l = q_l
+        self.t_range_l = t_range_l
+        self.radius_l = [VERTEX_CONSTRAINT_RADIUS] * len(q_l) if radius_l is None else radius_l
+        self.is_soft = is_soft
+
+    def get_q_l(self):
+        return self.q_l
+
+    def get_t_range_l(self):
+        return self.t_range_l
+
+    def get_radius_l(self):
+        return self.radius_l
+
+    def get_is_soft(self):
+        return self.is_soft
+
+    def get_copy(self):
+        return MultiPointConstraint(list(self.q_l), list(self.t_range_l), list(self.radius_l), self.is_soft)
+
+
+class CostConstraint:
+    """Parameter holder with the reference constructor signature (cost_functions.py:282-295).  One instance = one
+    guide cost term = one ELL group (own gradient clip and weight)."""
+
+    def __init__(self, robot=None, n_support_points=H, q_l=None, traj_range_l=None, radius_l=None, is_soft=False,
+                 **kwargs):
+        self.n_support_points = n_support_points
+        self.qs = np.stack([np.asarray(torch.as_tensor(q).detach().cpu(), dtype=np.float32).reshape(-1)[:2]
+                            for q in q_l]).astype(np.float32).reshape(-1, 2)
+        self.traj_ranges = np.asarray(traj_range_l, dtype=np.float32).reshape(-1, 2)
+        self.radii = np.asarray(radius_l, dtype=np.float32).reshape(-1)
+        self.is_soft = is_soft
+
+
+def pack_constraints(per_robot_groups: Sequence[Sequence[Tuple[CostConstraint, float]]], device):
+    """per_robot_groups[r] = [(CostConstraint, weight), ...].  Returns device tensors
+    (ell [n_slots,H,4] f32, grp_slot_off [G+1] i32, grp_weight [G] f32, robot_grp_off [R+1] i32) or None if empty."""
+    lib = _lib.load()
+    flat = [gw for groups in per_robot_groups for gw in groups]
+    if not flat:
+        return None
+    G = len(flat)
+    n_pts = (C.c_int32 * G)(*[g.qs.shape[0] for g, _ in flat])
+    keep = []
+
+    def ptr_array(arrs):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in arrs]
+        keep.append(arrs)
+        return (C.c_void_p * G)(*[a.ctypes.data for a in arrs])
+
+    q = ptr_array([g.qs for g, _ in flat])
+    tr = ptr_array([g.traj_ranges for g, _ in flat])
+    rad = ptr_array([g.radii for g, _ in flat])
+    slots = (C.c_int32 * G)()
+    _lib.check(lib.mmd_pack_constraints(G, n_pts, q, tr, rad, H, None, 0, slots))
+    total = int(sum(slots))
+    ell = np.zeros((max(total, 1), H, 4), dtype=np.float32)
+    ell[..., 2] = -1.0
+    _lib.check(lib.mmd_pack_constraints(G, n_pts, q, tr, rad, H, ell.ctypes.data, max(total, 1), slots))
+    grp_slot_off = np.zeros(G + 1, dtype=np.int32)
+    grp_slot_off[1:] = np.cumsum(np.array(list(slots), dtype=np.int64))
+    robot_grp_off = np.zeros(len(per_robot_groups) + 1, dtype=np.int32)
+    robot_grp_off[1:] = np.cumsum([len(g) for g in per_robot_groups])
+    weights = np.array([w for _, w in flat], dtype=np.float32)
+    return (torch.from_numpy(ell).to(device), torch.from_numpy(grp_slot_off).to(device),
+            torch.from_numpy(weights).to(device), torch.from_numpy(robot_grp_off).to(device))
+
+
+def soft_constraints_from_paths(paths: torch.Tensor, robot0: int, n_local: int, radius=VERTEX_CONSTRAINT_RADIUS,
+                                weight=2e-2):
+    """Device-side all-pairs soft constraints (replaces cbs.py:468-508 for equal start times).  paths [N,H,2]
+    un-normalised best-path positions of ALL robots on this device; returns the 4 constraint tensors for local
+    robots [robot0, robot0+n_local)."""
+    lib = _lib.load()
+    n_all = paths.shape[0]
+    dev = paths.device
+    ell = torch.empty((n_local * (n_all - 1), H, 4), dtype=torch.float32, device=dev)
+    gso = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
+    gw = torch.empty(n_local, dtype=torch.float32, device=dev)
+    rgo = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
+    _lib.check(lib.mmd_soft_constraints_from_paths(_lib.require_gpu(paths, "paths"), n_all, robot0, n_local, H,
+                                                   float(radius), float(weight), ell.data_ptr(), gso.data_ptr(),
+                                                   gw.data_ptr(), rgo.data_ptr(), _lib.current_stream_ptr()))
+    return ell, gso, gw, rgo

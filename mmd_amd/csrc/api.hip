@@ -1,0 +1,111 @@
+// Sampling-loop orchestration and ABI bookkeeping of libmmd_amd.so.
+//
+// p_sample_loop (diffusion_model_base.py:162-211) = per outer step: 29 UNet kernels (unet.hip) + ONE fused kernel
+// doing posterior mean, the n_guide_steps guide iterations, noise and hard conditioning (guide.hip).  Everything is
+// enqueued on the caller's stream with no host synchronisation: the reference's per-step `.item()`-style syncs
+// (sample_functions.py:53,63; normalization.py:161) do not exist here because the branches depend only on the
+// loop index, which the host knows.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/mmd_amd.h"
+#include "common.h"
+#include "guide_dev.h"
+
+namespace mmd {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static int make_step(const mmd_sampler_desc* s, int i, bool guided, StepDev& sd) {
+  const int t = i < 0 ? 0 : i;                                    // sample_functions.py:53-54
+  MMD_REQUIRE(t < s->n_diffusion_steps, "loop index %d outside the %d-step schedule", i, s->n_diffusion_steps);
+  sd.a_t = s->sqrt_recip_alphas_cumprod[t];
+  sd.b_t = s->sqrt_recipm1_alphas_cumprod[t];
+  sd.c1 = s->posterior_mean_coef1[t];
+  sd.c2 = s->posterior_mean_coef2[t];
+  sd.sigma = expf(0.5f * s->posterior_log_variance_clipped[t]);   // model_std, sample_functions.py:60
+  sd.noise_std_extra = s->noise_std_extra;
+  sd.do_model = 1;
+  sd.do_guide = guided && i < s->t_start_guide ? 1 : 0;           // sample_functions.py:63
+  sd.do_noise = t == 0 ? 0 : 1;                                   // noise[t == 0] = 0, sample_functions.py:76
+  sd.n_guide_steps = s->n_guide_steps;
+  sd.hard_mask = s->hard_mask;
+  return 0;
+}
+
+}  // namespace mmd
+
+using namespace mmd;
+
+extern "C" {
+
+int mmd_abi_version(void) { return MMD_AMD_ABI_VERSION; }
+const char* mmd_last_error(void) { return g_err; }
+
+size_t mmd_sampler_workspace_bytes(mmd_unet_t unet, int n_traj) {
+  return mmd_unet_workspace_bytes(unet, n_traj) + (size_t)(n_traj > 0 ? n_traj : 0) * H * D * sizeof(float);
+}
+
+int mmd_ddpm_step(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_desc* guide, float* x_dev,
+                  const float* hard_dev, int n_robots, int samples_per_robot, int i, const float* noise_dev,
+                  uint64_t seed, uint32_t draw_index, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  MMD_REQUIRE(unet && s && x_dev && hard_dev && workspace_dev, "mmd_ddpm_step: NULL argument");
+  const int n = n_robots * samples_per_robot;
+  MMD_REQUIRE(n >= 1, "mmd_ddpm_step: empty batch");
+  MMD_REQUIRE(workspace_bytes >= mmd_sampler_workspace_bytes(unet, n), "mmd_ddpm_step: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t uws = mmd_unet_workspace_bytes(unet, n);
+  float* eps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace_dev) + uws);
+  StepDev sd{};
+  if (int rc = make_step(s, i, guide != nullptr, sd)) return rc;
+  sd.seed = seed; sd.draw = draw_index;
+  GuideDev g{};
+  if (sd.do_guide)
+    if (int rc = fill_guide(guide, g)) return rc;
+  if (int rc = mmd_unet_forward(unet, x_dev, i < 0 ? 0 : i, eps, n, workspace_dev, uws, stream)) return rc;
+  launch_step(g, sd, x_dev, eps, noise_dev, nullptr, hard_dev, n, samples_per_robot, st);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_desc* guide, float* x_dev,
+                      const float* hard_dev, int n_robots, int samples_per_robot, int n_steps,
+                      int n_steps_without_noise, int init_noise, const float* step_noise_dev, uint64_t seed,
+                      float* chain_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  MMD_REQUIRE(unet && s && x_dev && hard_dev && workspace_dev, "mmd_p_sample_loop: NULL argument");
+  const int n = n_robots * samples_per_robot;
+  MMD_REQUIRE(n >= 1, "mmd_p_sample_loop: empty batch");
+  MMD_REQUIRE(n_steps >= 0 && n_steps <= s->n_diffusion_steps && n_steps_without_noise >= 0, "bad step counts");
+  MMD_REQUIRE(workspace_bytes >= mmd_sampler_workspace_bytes(unet, n), "mmd_p_sample_loop: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t uws = mmd_unet_workspace_bytes(unet, n);
+  float* eps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace_dev) + uws);
+  const size_t traj_floats = (size_t)n * H * D;
+  GuideDev g{};
+  if (guide)
+    if (int rc = fill_guide(guide, g)) return rc;
+  launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed, n, samples_per_robot, st);
+  int k = 0;
+  for (int i = n_steps - 1; i >= -n_steps_without_noise; --i, ++k) {
+    StepDev sd{};
+    if (int rc = make_step(s, i, guide != nullptr, sd)) return rc;
+    sd.seed = seed; sd.draw = (unsigned int)k;
+    if (int rc = mmd_unet_forward(unet, x_dev, i < 0 ? 0 : i, eps, n, workspace_dev, uws, stream)) return rc;
+    launch_step(g, sd, x_dev, eps, step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr,
+                chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr, hard_dev, n, samples_per_robot, st);
+  }
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,394 @@
+// Cost-guidance gradient + DDPM step algebra for gfx950.
+//
+// One wavefront per trajectory, lane = support point t (H = 64 = wave width): a trajectory's 1 KiB is one fully
+// coalesced 16-byte-per-lane load, the GP-prior stencil talks to lanes t-1 / t+1 through wave shuffles, and all
+// n_guide_steps inner iterations of guide_gradient_steps (sample_functions.py:89-107) run in registers.  The SDF
+// grid is an L2-resident float4 texture (sdf, dsdf/dx, dsdf/dy, 0) so a point costs one 16-byte gather.  A
+// workgroup is 4 waves = 4 trajectories of the same robot, so the robot's constraint groups are block-uniform and
+// the time-bucketed (ELL) constraint table [slot][t] is read coalesced across lanes.
+//
+// Closed-form gradients (no autograd), term by term as GuideManagerTrajectoriesWithVelocity.forward does
+// (guides.py:180-226): per cost -> clip by norm over the 4 state dims with +1e-6 inside (guides.py:247-253) -> zero
+// rows 0 and H-1 -> weight -> sum -> negate.  The gradient is taken w.r.t. the UN-normalised trajectory and added to
+// the NORMALISED one (sample_functions.py:104), as the reference does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mmd_amd.h"
+#include "common.h"
+#include "guide_dev.h"
+
+namespace mmd {
+
+// ---- Philox4x32-10 + Box-Muller -------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0;
+    const unsigned int n1 = (unsigned int)p1;
+    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+    const unsigned int n3 = (unsigned int)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__device__ __forceinline__ float4 normal4(unsigned long long seed, unsigned int draw, unsigned int point) {
+  unsigned int c[4] = {point, draw, 0u, 0u};
+  philox4x32(c, (unsigned int)seed, (unsigned int)(seed >> 32));
+  const float s = 2.3283064365386963e-10f;   // 2^-32
+  const float u0 = ((float)c[0] + 0.5f) * s, u1 = ((float)c[1] + 0.5f) * s;
+  const float u2 = ((float)c[2] + 0.5f) * s, u3 = ((float)c[3] + 0.5f) * s;
+  const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+}
+
+// clip_grad_by_norm (guides.py:247-253): scale = clip(||g + 1e-6||, 0, max) / ||g + 1e-6||
+__device__ __forceinline__ float clip_scale(float gx, float gy, float gz, float gw, float max_norm) {
+  const float ax = gx + 1e-6f, ay = gy + 1e-6f, az = gz + 1e-6f, aw = gw + 1e-6f;
+  const float n = sqrtf(ax * ax + ay * ay + az * az + aw * aw);
+  return fminf(fmaxf(n, 0.f), max_norm) / n;
+}
+
+__device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t, const float4* __restrict__ grid,
+                                             int grp0, int grp1) {
+  // LimitsNormalizer.unnormalize (normalization.py:157-168), clip applied unconditionally
+  float xu[4];
+  const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float v = fminf(fmaxf(xv[d], -1.f), 1.f);
+    v = (v + 1.f) / 2.f;
+    xu[d] = v * g.nscale[d] + g.nmin[d];
+  }
+  const float px = xu[0], py = xu[1], vx = xu[2], vy = xu[3];
+  const bool interior = t > 0 && t < H - 1;   // rows 0 and H-1 are zeroed for every term (guides.py:217-218)
+  float tx = 0.f, ty = 0.f, tz = 0.f, tw = 0.f;
+
+  // --- CostCollision over the SDF grids: d/dp max_k relu(margin - sdf_k(p))  (t >= 1; field_factor.py range [1,None])
+  {
+    int ix = (int)floorf((px - g.lo[0]) / g.dim[0] * (float)g.nx);
+    int iy = (int)floorf((py - g.lo[1]) / g.dim[1] * (float)g.ny);
+    ix = min(max(ix, 0), g.nx - 1);
+    iy = min(max(iy, 0), g.ny - 1);
+    float best = 0.f, gx = 0.f, gy = 0.f;
+    for (int k = 0; k < g.n_grids; ++k) {
+      const float4 c = grid[((size_t)k * g.nx + ix) * g.ny + iy];
+      const float v = fmaxf(g.margin - c.x, 0.f);
+      if (v > best) { best = v; gx = -c.y; gy = -c.z; }
+    }
+    const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
+    if (interior) { tx += g.w_coll * (sc * gx); ty += g.w_coll * (sc * gy); }
+  }
+  // --- CostCollision over the workspace boundaries (distance_fields.py:354-367)
+  {
+    const float d0 = px - g.ws_min[0], d1 = py - g.ws_min[1], d2 = g.ws_max[0] - px, d3 = g.ws_max[1] - py;
+    float best = fmaxf(g.margin - d0, 0.f), gx = -1.f, gy = 0.f;
+    float v = fmaxf(g.margin - d1, 0.f);
+    if (v > best) { best = v; gx = 0.f; gy = -1.f; }
+    v = fmaxf(g.margin - d2, 0.f);
+    if (v > best) { best = v; gx = 1.f; gy = 0.f; }
+    v = fmaxf(g.margin - d3, 0.f);
+    if (v > best) { best = v; gx = 0.f; gy = 1.f; }
+    if (!(best > 0.f)) { gx = 0.f; gy = 0.f; }
+    const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
+    if (interior) { tx += g.w_coll * (sc * gx); ty += g.w_coll * (sc * gy); }
+  }
+  // --- CostGPTrajectory (cost_functions.py:532-542, gp_factor.py): e_t = s_{t+1} - Phi s_t, w_t = 2 Q^-1 e_t,
+  //     g_t = w_{t-1} - Phi^T w_t
+  {
+    const float npx = __shfl_down(px, 1), npy = __shfl_down(py, 1);
+    const float nvx = __shfl_down(vx, 1), nvy = __shfl_down(vy, 1);
+    float wpx = 0.f, wpy = 0.f, wvx = 0.f, wvy = 0.f;
+    if (t < H - 1) {
+      const float epx = npx - (px + g.dt * vx), epy = npy - (py + g.dt * vy);
+      const float evx = nvx - vx, evy = nvy - vy;
+      wpx = 2.f * (g.m1 * epx + g.m2 * evx);
+      wpy = 2.f * (g.m1 * epy + g.m2 * evy);
+      wvx = 2.f * (g.m2 * epx + g.m3 * evx);
+      wvy = 2.f * (g.m2 * epy + g.m3 * evy);
+    }
+    float lpx = __shfl_up(wpx, 1), lpy = __shfl_up(wpy, 1), lvx = __shfl_up(wvx, 1), lvy = __shfl_up(wvy, 1);
+    if (t == 0) { lpx = lpy = lvx = lvy = 0.f; }
+    const float gx = lpx - wpx, gy = lpy - wpy;
+    const float gz = lvx - (g.dt * wpx + wvx), gw = lvy - (g.dt * wpy + wvy);
+    const float sc = clip_scale(gx, gy, gz, gw, g.max_norm);
+    if (interior) {
+      tx += g.w_smooth * (sc * gx); ty += g.w_smooth * (sc * gy);
+      tz += g.w_smooth * (sc * gz); tw += g.w_smooth * (sc * gw);
+    }
+  }
+  // --- CostConstraint groups (cost_functions.py:297-326): -sum_{active, ||d|| <= R} d / ||d||
+  for (int grp = grp0; grp < grp1; ++grp) {
+    const int s0 = g.grp_slot_off[grp], s1 = g.grp_slot_off[grp + 1];
+    float gx = 0.f, gy = 0.f;
+    for (int s = s0; s < s1; ++s) {
+      const float4 c = g.cons[(size_t)s * H + t];
+      const float dx = px - c.x, dy = py - c.y;
+      const float dist = sqrtf(dx * dx + dy * dy);
+      if (c.z >= 0.f && !(dist > c.z)) { gx -= dx / dist; gy -= dy / dist; }
+    }
+    const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
+    const float w = g.grp_weight[grp];
+    if (interior) { tx += w * (sc * gx); ty += w * (sc * gy); }
+  }
+  return make_float4(-tx, -ty, -tz, -tw);
+}
+
+// One ddpm_sample_fn (sample_functions.py:40-86) + the apply_hard_conditioning after it, for one trajectory per wave.
+__global__ __launch_bounds__(256) void ddpm_guide_kernel(GuideDev g, StepDev s, float4* __restrict__ x,
+                                                         const float4* __restrict__ eps,
+                                                         const float4* __restrict__ noise, float4* __restrict__ chain,
+                                                         const float4* __restrict__ hard, int n_traj,
+                                                         int samples_per_robot) {
+  const int t = threadIdx.x & 63;
+  const int traj = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (traj >= n_traj) return;
+  const int robot = traj / samples_per_robot;
+  const size_t idx = (size_t)traj * H + t;
+  float4 v = x[idx];
+
+  if (s.do_model) {
+    // p_mean_variance (diffusion_model_base.py:148-160): x0 = a x - b eps; clamp; mean = c1 x0 + c2 x
+    const float4 e = eps[idx];
+    float4 x0;
+    x0.x = fminf(fmaxf(s.a_t * v.x - s.b_t * e.x, -1.f), 1.f);
+    x0.y = fminf(fmaxf(s.a_t * v.y - s.b_t * e.y, -1.f), 1.f);
+    x0.z = fminf(fmaxf(s.a_t * v.z - s.b_t * e.z, -1.f), 1.f);
+    x0.w = fminf(fmaxf(s.a_t * v.w - s.b_t * e.w, -1.f), 1.f);
+    v.x = s.c1 * x0.x + s.c2 * v.x;
+    v.y = s.c1 * x0.y + s.c2 * v.y;
+    v.z = s.c1 * x0.z + s.c2 * v.z;
+    v.w = s.c1 * x0.w + s.c2 * v.w;
+  }
+
+  const float4 hs = hard[robot * 2 + 0], hg = hard[robot * 2 + 1];
+  const bool is_start = (s.hard_mask & 1) && t == 0;
+  const bool is_goal = (s.hard_mask & 2) && t == H - 1;
+
+  if (s.do_guide) {
+    const int map = g.robot_map ? g.robot_map[robot] : 0;
+    const float4* grid = g.grids + (size_t)map * g.n_grids * g.nx * g.ny;
+    int grp0 = 0, grp1 = 0;
+    if (g.robot_grp_off) { grp0 = g.robot_grp_off[robot]; grp1 = g.robot_grp_off[robot + 1]; }
+    for (int it = 0; it < s.n_guide_steps; ++it) {
+      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1);
+      v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w;
+      if (is_start) v = hs;
+      if (is_goal) v = hg;
+    }
+  }
+
+  if (s.do_noise) {
+    float4 z = noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned int)idx);
+    // x + model_std * noise * noise_std  (sample_functions.py:86)
+    v.x += s.sigma * z.x * s.noise_std_extra;
+    v.y += s.sigma * z.y * s.noise_std_extra;
+    v.z += s.sigma * z.z * s.noise_std_extra;
+    v.w += s.sigma * z.w * s.noise_std_extra;
+  }
+  if (is_start) v = hs;
+  if (is_goal) v = hg;
+  x[idx] = v;
+  if (chain) chain[idx] = v;
+}
+
+// x <- conditioned init: optional Philox draw of x_T, apply_hard_conditioning, optional chain[0] write
+__global__ void init_kernel(float4* __restrict__ x, float4* __restrict__ chain, const float4* __restrict__ hard,
+                            int hard_mask, int draw_noise, unsigned long long seed, int n_traj, int samples_per_robot) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n_traj * H) return;
+  const int t = idx % H;
+  const int robot = (idx / H) / samples_per_robot;
+  float4 v = draw_noise ? normal4(seed, 0xFFFFFFFFu, (unsigned int)idx) : x[idx];
+  if ((hard_mask & 1) && t == 0) v = hard[robot * 2];
+  if ((hard_mask & 2) && t == H - 1) v = hard[robot * 2 + 1];
+  x[idx] = v;
+  if (chain) chain[idx] = v;
+}
+
+__global__ void q_sample_kernel(float4* __restrict__ x, const float4* __restrict__ x0, const float4* __restrict__ noise,
+                                float a, float b, unsigned long long seed, unsigned int draw, size_t n_pts) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_pts) return;
+  const float4 z = noise ? noise[idx] : normal4(seed, draw, (unsigned int)idx);
+  const float4 s = x0[idx];
+  x[idx] = make_float4(a * s.x + b * z.x, a * s.y + b * z.y, a * s.z + b * z.z, a * s.w + b * z.w);
+}
+
+__global__ void cross_condition_kernel(float4* __restrict__ x1, float4* __restrict__ x2, int ind1, int ind2,
+                                       float4 rel, float4 bnd, int n_traj) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_traj) return;
+  const float4 v2 = x2[(size_t)b * H + ind2];
+  float4 v1;
+  v1.x = fminf(v2.x + rel.x, bnd.x); v1.y = fminf(v2.y + rel.y, bnd.y);
+  v1.z = fminf(v2.z + rel.z, bnd.z); v1.w = fminf(v2.w + rel.w, bnd.w);
+  x1[(size_t)b * H + ind1] = v1;
+  float4 w;
+  w.x = fmaxf(v1.x - rel.x, -bnd.x); w.y = fmaxf(v1.y - rel.y, -bnd.y);
+  w.z = fmaxf(v1.z - rel.z, -bnd.z); w.w = fmaxf(v1.w - rel.w, -bnd.w);
+  x2[(size_t)b * H + ind2] = w;
+}
+
+// all-pairs soft constraints from best paths (cbs.py:468-508): slot j of local robot i = other robot j (+1 past i)
+__global__ void soft_cons_kernel(const float2* __restrict__ paths, int n_all, int robot0, int n_local, float radius,
+                                 float weight, float4* __restrict__ ell, int* __restrict__ grp_slot_off,
+                                 float* __restrict__ grp_weight, int* __restrict__ robot_grp_off) {
+  const int slots = n_all - 1;
+  const size_t tot = (size_t)n_local * slots * H;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+    const int t = idx % H;
+    const int j = (idx / H) % slots;
+    const int i = idx / ((size_t)H * slots);
+    const int other = j + (j >= robot0 + i ? 1 : 0);
+    const float2 p = paths[(size_t)other * H + t];
+    ell[idx] = make_float4(p.x, p.y, t >= 1 ? radius : -1.f, 0.f);   // constraints cover t in [1, H-1]
+  }
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid <= n_local) {
+    grp_slot_off[tid] = tid * slots;
+    robot_grp_off[tid] = tid;
+    if (tid < n_local) grp_weight[tid] = weight;
+  }
+}
+
+int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
+  MMD_REQUIRE(d->sdf_grids_dev && d->n_grids >= 1 && d->grid_nx >= 1 && d->grid_ny >= 1, "guide: SDF grid missing");
+  for (int k = 0; k < 4; ++k) { g.nmin[k] = d->norm_min[k]; g.nscale[k] = d->norm_max[k] - d->norm_min[k]; }
+  for (int k = 0; k < 2; ++k) {
+    g.lo[k] = d->limits_lo[k];
+    g.dim[k] = fabsf(d->limits_hi[k] - d->limits_lo[k]);
+    g.inv_dim[k] = 1.f / g.dim[k];
+    g.ws_min[k] = d->ws_min[k]; g.ws_max[k] = d->ws_max[k];
+  }
+  g.nx = d->grid_nx; g.ny = d->grid_ny; g.n_grids = d->n_grids;
+  g.grids = reinterpret_cast<const float4*>(d->sdf_grids_dev);
+  g.robot_map = d->robot_map_dev;
+  g.margin = d->margin; g.dt = d->dt; g.w_coll = d->weight_collision; g.w_smooth = d->weight_smoothness;
+  g.max_norm = d->max_grad_norm;
+  const double dt = d->dt, qc = 1.0 / ((double)d->sigma_gp * d->sigma_gp);
+  g.m1 = (float)(12.0 / (dt * dt * dt) * qc);
+  g.m2 = (float)(-6.0 / (dt * dt) * qc);
+  g.m3 = (float)(4.0 / dt * qc);
+  g.cons = reinterpret_cast<const float4*>(d->cons_ell_dev);
+  g.grp_slot_off = d->grp_slot_off_dev; g.grp_weight = d->grp_weight_dev; g.robot_grp_off = d->robot_grp_off_dev;
+  if (!g.cons || !g.grp_slot_off || !g.grp_weight) g.robot_grp_off = nullptr;
+  return 0;
+}
+
+int launch_step(const GuideDev& g, const StepDev& s, float* x, const float* eps, const float* noise, float* chain,
+                const float* hard, int n_traj, int spr, hipStream_t st) {
+  hipLaunchKernelGGL(ddpm_guide_kernel, dim3((n_traj + 3) / 4), dim3(256), 0, st, g, s, (float4*)x, (const float4*)eps,
+                     (const float4*)noise, (float4*)chain, (const float4*)hard, n_traj, spr);
+  return 0;
+}
+
+int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed, int n_traj,
+                int spr, hipStream_t st) {
+  const size_t n = (size_t)n_traj * H;
+  hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float4*)x, (float4*)chain,
+                     (const float4*)hard, hard_mask, draw, seed, n_traj, spr);
+  return 0;
+}
+
+}  // namespace mmd
+
+using namespace mmd;
+
+extern "C" {
+
+int mmd_pack_constraints(int n_groups, const int32_t* n_pts, const float* const* q, const float* const* t_range,
+                         const float* const* radius, int horizon, float* ell_out, int max_slots, int32_t* slots_out) {
+  MMD_REQUIRE(horizon == H, "mmd_pack_constraints: horizon must be %d", H);
+  int used = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    // a point is active at integer t iff t >= t0 and t < t1 (float ranges, cost_functions.py:304-305)
+    std::vector<int> fill(H, 0);
+    for (int c = 0; c < n_pts[g]; ++c) {
+      const int t0 = (int)ceilf(t_range[g][2 * c]), t1 = (int)ceilf(t_range[g][2 * c + 1]);
+      for (int t = t0 < 0 ? 0 : t0; t < t1 && t < H; ++t) ++fill[t];
+    }
+    int slots = 0;
+    for (int t = 0; t < H; ++t) slots = fill[t] > slots ? fill[t] : slots;
+    slots_out[g] = slots;
+    if (!ell_out) { used += slots; continue; }      // sizing pass
+    MMD_REQUIRE(used + slots <= max_slots, "mmd_pack_constraints: need more than %d slots", max_slots);
+    for (int s = 0; s < slots; ++s)
+      for (int t = 0; t < H; ++t) {
+        float* e = ell_out + ((size_t)(used + s) * H + t) * 4;
+        e[0] = 0.f; e[1] = 0.f; e[2] = -1.f; e[3] = 0.f;
+      }
+    std::fill(fill.begin(), fill.end(), 0);
+    for (int c = 0; c < n_pts[g]; ++c) {
+      const int t0 = (int)ceilf(t_range[g][2 * c]), t1 = (int)ceilf(t_range[g][2 * c + 1]);
+      for (int t = t0 < 0 ? 0 : t0; t < t1 && t < H; ++t) {
+        float* e = ell_out + ((size_t)(used + fill[t]) * H + t) * 4;
+        e[0] = q[g][2 * c]; e[1] = q[g][2 * c + 1]; e[2] = radius[g][c];
+        ++fill[t];
+      }
+    }
+    used += slots;
+  }
+  return 0;
+}
+
+int mmd_soft_constraints_from_paths(const float* paths_dev, int n_all, int robot0, int n_local, int horizon,
+                                    float radius, float weight, float* ell_out_dev, int32_t* grp_slot_off_dev,
+                                    float* grp_weight_dev, int32_t* robot_grp_off_dev, void* stream) {
+  MMD_REQUIRE(horizon == H, "horizon must be %d", H);
+  MMD_REQUIRE(n_all >= 2 && n_local >= 1 && robot0 >= 0 && robot0 + n_local <= n_all, "bad robot range");
+  const size_t tot = (size_t)n_local * (n_all - 1) * H;
+  int grid = (int)((tot + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (grid * 256 < n_local + 1) grid = (n_local + 1 + 255) / 256;
+  hipLaunchKernelGGL(soft_cons_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float2*)paths_dev, n_all,
+                     robot0, n_local, radius, weight, (float4*)ell_out_dev, grp_slot_off_dev, grp_weight_dev,
+                     robot_grp_off_dev);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int mmd_guide_steps(const mmd_guide_desc* d, float* x_dev, const float* hard_dev, int hard_mask, int n_robots,
+                    int samples_per_robot, int n_steps, void* stream) {
+  MMD_REQUIRE(d && x_dev && hard_dev, "mmd_guide_steps: NULL argument");
+  GuideDev g{};
+  if (int rc = fill_guide(d, g)) return rc;
+  StepDev s{};
+  s.do_guide = 1; s.n_guide_steps = n_steps; s.hard_mask = hard_mask;
+  launch_step(g, s, x_dev, nullptr, nullptr, nullptr, hard_dev, n_robots * samples_per_robot, samples_per_robot,
+              (hipStream_t)stream);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int mmd_q_sample(float* x_dev, const float* x_start_dev, const float* noise_dev, float a, float b, uint64_t seed,
+                 uint32_t draw_index, int n_traj, void* stream) {
+  const size_t n = (size_t)n_traj * H;
+  hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (float4*)x_dev, (const float4*)x_start_dev, (const float4*)noise_dev, a, b,
+                     (unsigned long long)seed, draw_index, n);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int mmd_cross_condition(float* x1_dev, float* x2_dev, int ind1, int ind2, const float* rel, const float* boundary,
+                        int n_traj, void* stream) {
+  MMD_REQUIRE(ind1 >= 0 && ind1 < H && ind2 >= 0 && ind2 < H, "row index out of range");
+  hipLaunchKernelGGL(cross_condition_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (float4*)x1_dev, (float4*)x2_dev, ind1, ind2, make_float4(rel[0], rel[1], rel[2], rel[3]),
+                     make_float4(boundary[0], boundary[1], boundary[2], boundary[3]), n_traj);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

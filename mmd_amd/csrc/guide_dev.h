@@ -1,0 +1,42 @@
+// Device-side parameter blocks of the guide / DDPM-step kernel, shared by guide.hip and api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/mmd_amd.h"
+
+namespace mmd {
+
+struct GuideDev {
+  float nmin[4], nscale[4];          // x_u = ((clip(x)+1)/2) * nscale + nmin,  nscale = max - min
+  float lo[2], inv_dim[2];           // grid index = floor((p - lo) * inv_dim?  -- see sdf_cell: kept as division
+  float dim[2];
+  int nx, ny, n_grids;
+  const float4* grids;               // [n_maps][n_grids][nx][ny]
+  const int* robot_map;
+  float ws_min[2], ws_max[2];
+  float margin, dt, w_coll, w_smooth, max_norm;
+  float m1, m2, m3;                  // GP prior Q^-1 blocks: 12/dt^3, -6/dt^2, 4/dt  (x 1/sigma^2)
+  const float4* cons;                // [n_slots][H]
+  const int* grp_slot_off;
+  const float* grp_weight;
+  const int* robot_grp_off;
+};
+
+struct StepDev {
+  float a_t, b_t, c1, c2;            // sqrt_recip_alphas_cumprod[t], sqrt_recipm1[t], posterior_mean_coef1/2[t]
+  float sigma;                       // exp(0.5 * posterior_log_variance_clipped[t])
+  float noise_std_extra;
+  int do_model, do_guide, do_noise;  // do_model = 0: guide-only launch (mmd_guide_steps)
+  int n_guide_steps;
+  int hard_mask;
+  unsigned long long seed;
+  unsigned int draw;
+};
+
+int fill_guide(const mmd_guide_desc* d, GuideDev& g);
+int launch_step(const GuideDev& g, const StepDev& s, float* x, const float* eps, const float* noise, float* chain,
+                const float* hard, int n_traj, int spr, hipStream_t st);
+int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed, int n_traj,
+                int spr, hipStream_t st);
+
+}  // namespace mmd

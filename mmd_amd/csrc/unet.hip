@@ -1,0 +1,751 @@
+// TemporalUnet forward for gfx950 (MI355X): every Conv1d / ConvTranspose1d of the reference network
+// (mmd/models/diffusion_models/temporal_unet.py:121-174, mmd/models/layers/layers.py:261-358) is an implicit-im2col
+// GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32), with GroupNorm + Mish + time-bias / residual fused
+// into the epilogue.
+//
+// Layout.  Activations are channels-last [n_traj, L, C] fp32 in HBM, so the trajectory tensor [n, 64, 4] needs no
+// transpose on either side.  A workgroup (4 waves) owns SPB whole samples: it stages their [L+4, C_in] slabs (zero
+// halo) into LDS once, then every wave runs its K loop (taps x channels) with no further barrier -- the five taps
+// are row-shifted views of the same slab, so the input is read from HBM once, not five times.  A wave owns whole
+// samples x a 32-channel slice (RW = 32*MT_W rows x 32 cols): the GroupNorm groups (C_out/8 channels) and samples
+// never straddle waves, so the statistics are pure in-register + cross-lane reductions.  Weights are pre-packed
+// on the host in MFMA B-fragment order so a lane fetches 4 consecutive k-steps with one 16-byte load straight from
+// L2 (no LDS staging: a B element is used by at most two m-tiles).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mmd_amd.h"
+#include "common.h"
+
+namespace mmd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { MODE_CONV5 = 0, MODE_DOWN = 1, MODE_UP = 2 };
+enum { EPI_PLAIN = 0, EPI_GN_TB = 1, EPI_GN_RES = 2, EPI_GN_FINAL = 3 };
+enum { RES_NONE = 0, RES_IDENT = 1, RES_CONV = 2 };
+
+struct ConvArgs {
+  const float* in0;      // [n, LIN, C0]
+  const float* in1;      // [n, LIN, C1] (second half of a channel concat) or null
+  float* out;            // [n, LOUT, COUT]   (EPI_GN_FINAL: [n, 64, 4])
+  const float4* wpk;     // packed B fragments (UP: parity 0 then parity 1)
+  const float* bias;     // [COUT]
+  const float* gamma;    // [COUT] GroupNorm weight
+  const float* beta;     // [COUT] GroupNorm bias
+  const float* tbias;    // [COUT] time-embedding projection for the current t (EPI_GN_TB)
+  const float* res0;     // residual source (RES_IDENT: [n, L, COUT]; RES_CONV: [n, L, RC0])
+  const float* res1;     // second half of the residual concat or null
+  const float4* res_wpk; // packed 1x1 residual conv (RES_CONV) / final 1x1 conv (EPI_GN_FINAL)
+  const float* res_bias; // [COUT] / [4]
+  int n;                 // number of trajectories
+};
+
+template <int C0_, int C1_, int COUT_, int LIN_, int MODE_, int MT_W_, int EPI_, int RES_, int RC0_, int RC1_>
+struct Cfg {
+  static constexpr int C0 = C0_, C1 = C1_, COUT = COUT_, LIN = LIN_, MODE = MODE_, MT_W = MT_W_, EPI = EPI_;
+  static constexpr int RES = RES_, RC0 = RC0_, RC1 = RC1_;
+  static constexpr int CIN = C0 + C1;
+  static constexpr int CINP = (CIN + 7) / 8 * 8;         // K per tap, multiple of 8 (4 k-pairs per 16-byte B load)
+  static constexpr int SSTR = CINP + 1;                  // odd row stride: A-fragment reads are bank-conflict free
+  static constexpr int WN = COUT / 32;                   // waves along channels
+  static constexpr int WM = 4 / WN;                      // waves along samples
+  static constexpr int LROWS = MODE == MODE_DOWN ? LIN / 2 : LIN;   // GEMM rows per sample
+  static constexpr int LOUT = MODE == MODE_DOWN ? LIN / 2 : (MODE == MODE_UP ? LIN * 2 : LIN);
+  static constexpr int RW = 32 * MT_W;                   // GEMM rows per wave
+  static constexpr int SW = RW / LROWS;                  // samples per wave
+  static constexpr int SPB = WM * SW;                    // samples per workgroup
+  static constexpr int SROWS = LIN + 4;                  // slab rows per sample (2-row zero halo each side)
+  static constexpr int SLAB = SPB * SROWS * SSTR;        // floats
+  static constexpr int NTAPS = MODE == MODE_CONV5 ? 5 : (MODE == MODE_DOWN ? 3 : 2);
+  static constexpr int RC = RC0 + RC1;
+  static constexpr int RCP = (RC + 7) / 8 * 8;
+  static constexpr int RSTR = RCP + 1;
+  static constexpr int RSLAB = RES == RES_CONV ? SPB * LIN * RSTR : 0;
+  static constexpr int YSLAB = EPI == EPI_GN_FINAL ? 4 * RW * 33 : 0;
+  static constexpr int LDS_FLOATS = (SLAB + RSLAB) > YSLAB ? (SLAB + RSLAB) : YSLAB;
+  static constexpr int CPG = COUT / 8;                   // channels per GroupNorm group (8 groups for 32/64/128)
+  static_assert(COUT % 32 == 0 && (WN == 1 || WN == 2 || WN == 4), "COUT must be 32, 64 or 128");
+  static_assert(RW % LROWS == 0 && SW >= 1, "a wave must own whole samples");
+  static_assert(LROWS >= 16, "sample index must be a function of (mt, reg>>3)");
+};
+
+// Mish(y) = y * tanh(softplus(y)) = y * n / (n + 2), n = e^y (e^y + 2)   (torch.nn.Mish; softplus threshold 20)
+__device__ __forceinline__ float mish(float y) {
+  if (y > 20.f) return y;
+  float e = __expf(y);
+  float n = e * (e + 2.f);
+  return y * __fdividef(n, n + 2.f);
+}
+
+// Stage SPB samples' [LIN, C] rows (channels-last, optionally a concat of two tensors) into an LDS slab
+// [SPB][ROWS][STR] at row offset ROFF; samples >= n are zero filled.
+template <int C0, int C1, int CP, int LIN, int ROWS, int ROFF, int STR, int SPB>
+__device__ __forceinline__ void stage_slab(float* slab, const float* __restrict__ in0, const float* __restrict__ in1,
+                                           int n0, int n) {
+  constexpr int C = C0 + C1;
+  const int tid = threadIdx.x;
+  if constexpr (C % 4 == 0) {
+    constexpr int C4 = C / 4;
+    constexpr int TOT = SPB * LIN * C4;
+    for (int idx = tid; idx < TOT; idx += 256) {
+      int c4 = idx % C4;
+      int l = (idx / C4) % LIN;
+      int s = idx / (C4 * LIN);
+      int c = c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 + s < n) {
+        if (c < C0)
+          v = *reinterpret_cast<const float4*>(in0 + ((size_t)(n0 + s) * LIN + l) * C0 + c);
+        else
+          v = *reinterpret_cast<const float4*>(in1 + ((size_t)(n0 + s) * LIN + l) * C1 + (c - C0));
+      }
+      float* d = slab + (s * ROWS + l + ROFF) * STR + c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  // zero the channel padding (C..CP) -- only the 4-channel input layer has any
+  if constexpr (CP > C) {
+    constexpr int PADC = CP - C;
+    constexpr int TOT = SPB * LIN * PADC;
+    for (int idx = tid; idx < TOT; idx += 256) {
+      int c = C + idx % PADC;
+      int l = (idx / PADC) % LIN;
+      int s = idx / (PADC * LIN);
+      slab[(s * ROWS + l + ROFF) * STR + c] = 0.f;
+    }
+  }
+  // zero halo rows
+  if constexpr (ROFF > 0) {
+    constexpr int HR = ROWS - LIN;   // halo rows per sample
+    constexpr int TOT = SPB * HR * CP;
+    for (int idx = tid; idx < TOT; idx += 256) {
+      int c = idx % CP;
+      int hr = (idx / CP) % HR;
+      int s = idx / (CP * HR);
+      int row = hr < ROFF ? hr : LIN + hr;
+      slab[(s * ROWS + row) * STR + c] = 0.f;
+    }
+  }
+}
+
+// acc[mt] += A(slab rows, taps x CP channels) * B(packed).  abase[mt] is the lane's slab offset of (row, k=lane>>5)
+// for tap 0; tap t reads STR floats further.  wp points at this lane's float4 of the first k-group.
+template <int NTAPS, int CP, int STR, int MT_W>
+__device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W],
+                                          const float4* __restrict__ wp) {
+  constexpr int GPT = CP / 8;   // k-groups (of 4 k-pairs) per tap
+  float4 bnext = wp[0];
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap) {
+#pragma unroll 4
+    for (int cg = 0; cg < GPT; ++cg) {
+      const float4 b = bnext;
+      const int g = tap * GPT + cg;
+      if (g + 1 < NTAPS * GPT) bnext = wp[(size_t)(g + 1) * 64];
+      const float bq[4] = {b.x, b.y, b.z, b.w};
+      float a[4][MT_W];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT_W; ++mt) a[q][mt] = slab[abase[mt] + tap * STR + cg * 8 + q * 2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT_W; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][mt], bq[q], acc[mt], 0, 0, 0);
+    }
+  }
+}
+
+// sum over the CPG lanes of a GroupNorm group and over both half-waves (rows r and r+4 live in lanes l and l+32)
+template <int CPG>
+__device__ __forceinline__ float group_allreduce(float v) {
+#pragma unroll
+  for (int m = 1; m < CPG; m <<= 1) v += __shfl_xor(v, m);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// GroupNorm (biased variance, eps 1e-5, two-pass in registers) + affine + Mish on a wave tile.
+template <int COUT, int LROWS, int MT_W>
+__device__ __forceinline__ void gn_mish(f32x16 (&acc)[MT_W], float gamma, float beta) {
+  constexpr int CPG = COUT / 8;
+  constexpr int RW = 32 * MT_W;
+  constexpr int SW = RW / LROWS;                 // samples per wave
+  constexpr float inv_n = 1.f / (float)(LROWS * CPG);
+  float mean[SW], rstd[SW];
+  // element (mt, reg) belongs to sample (mt*32 + 8*(reg>>2)) / LROWS
+#pragma unroll
+  for (int s = 0; s < SW; ++s) {
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((mt * 32 + 8 * (r >> 2)) / LROWS == s) sum += acc[mt][r];
+    mean[s] = group_allreduce<CPG>(sum) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((mt * 32 + 8 * (r >> 2)) / LROWS == s) {
+          float d = acc[mt][r] - mean[s];
+          sq += d * d;
+        }
+    rstd[s] = rsqrtf(group_allreduce<CPG>(sq) * inv_n + 1e-5f);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int s = (mt * 32 + 8 * (r >> 2)) / LROWS;
+      float y = (acc[mt][r] - mean[s]) * rstd[s] * gamma + beta;
+      acc[mt][r] = mish(y);
+    }
+}
+
+template <class CF>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[CF::LDS_FLOATS];
+  float* slab = lds;
+  float* rslab = lds + CF::SLAB;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / CF::WN, wn = wave % CF::WN;
+  const int n0 = blockIdx.x * CF::SPB;
+  const int col = wn * 32 + (lane & 31);
+  const int hi = lane >> 5;
+
+  stage_slab<CF::C0, CF::C1, CF::CINP, CF::LIN, CF::SROWS, 2, CF::SSTR, CF::SPB>(slab, a.in0, a.in1, n0, a.n);
+  if constexpr (CF::RES == RES_CONV)
+    stage_slab<CF::RC0, CF::RC1, CF::RCP, CF::LIN, CF::LIN, 0, CF::RSTR, CF::SPB>(rslab, a.res0, a.res1, n0, a.n);
+  __syncthreads();
+
+  // this lane's A rows: tile row i = lane&31 of m-tile mt  ->  (sample, position)
+  constexpr int RSTEP = CF::MODE == MODE_DOWN ? 2 : 1;
+  int srow[CF::MT_W];      // wave-local sample of the lane's A row
+  int lrow[CF::MT_W];      // position within the sample
+#pragma unroll
+  for (int mt = 0; mt < CF::MT_W; ++mt) {
+    const int r = mt * 32 + (lane & 31);
+    srow[mt] = wm * CF::SW + r / CF::LROWS;
+    lrow[mt] = r % CF::LROWS;
+  }
+  constexpr int G = CF::NTAPS * CF::CINP / 8;   // 16-byte B groups per n-tile
+  const float bias = a.bias[col];
+
+  constexpr int NPASS = CF::MODE == MODE_UP ? 2 : 1;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    f32x16 acc[CF::MT_W];
+#pragma unroll
+    for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = bias;
+
+    // slab row of tap 0:  CONV5: l (+2 halo -2 pad);  DOWN: 2*lo + 1;  UP parity 0: m + 1, parity 1: m + 2
+    const int roff = CF::MODE == MODE_CONV5 ? 0 : (CF::MODE == MODE_DOWN ? 1 : 1 + pass);
+    int abase[CF::MT_W];
+#pragma unroll
+    for (int mt = 0; mt < CF::MT_W; ++mt)
+      abase[mt] = (srow[mt] * CF::SROWS + lrow[mt] * RSTEP + roff) * CF::SSTR + hi;
+    const float4* wp = a.wpk + ((size_t)(pass * CF::WN + wn) * G) * 64 + lane;
+    mfma_taps<CF::NTAPS, CF::CINP, CF::SSTR, CF::MT_W>(acc, slab, abase, wp);
+
+    if constexpr (CF::EPI != EPI_PLAIN) gn_mish<CF::COUT, CF::LROWS, CF::MT_W>(acc, a.gamma[col], a.beta[col]);
+
+    if constexpr (CF::EPI == EPI_GN_TB) {
+      const float tb = a.tbias[col];
+#pragma unroll
+      for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] += tb;
+    }
+
+    if constexpr (CF::EPI == EPI_GN_RES && CF::RES == RES_CONV) {
+      const float rb = a.res_bias[col];
+#pragma unroll
+      for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] += rb;
+      int rbase[CF::MT_W];
+#pragma unroll
+      for (int mt = 0; mt < CF::MT_W; ++mt) rbase[mt] = (srow[mt] * CF::LIN + lrow[mt]) * CF::RSTR + hi;
+      const float4* rwp = a.res_wpk + ((size_t)wn * (CF::RCP / 8)) * 64 + lane;
+      mfma_taps<1, CF::RCP, CF::RSTR, CF::MT_W>(acc, rslab, rbase, rwp);
+    }
+
+    if constexpr (CF::EPI == EPI_GN_FINAL) {
+      // 1x1 conv COUT(32) -> 4 (final_conv.1): y tile -> LDS -> one more MFMA pass against the zero-padded W1
+      static_assert(CF::EPI != EPI_GN_FINAL || (CF::WN == 1 && CF::COUT == 32), "final conv expects COUT == 32");
+      __syncthreads();   // every wave is done reading the input slab
+      float* yt = lds + wave * (CF::RW * 33);
+#pragma unroll
+      for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          yt[row * 33 + (lane & 31)] = acc[mt][r];
+        }
+      __syncthreads();
+      const float b1 = (lane & 31) < 4 ? a.res_bias[lane & 31] : 0.f;
+      f32x16 acc2[CF::MT_W];
+      int ybase[CF::MT_W];
+#pragma unroll
+      for (int mt = 0; mt < CF::MT_W; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[mt][r] = b1;
+        ybase[mt] = (mt * 32 + (lane & 31)) * 33 + hi;
+      }
+      mfma_taps<1, 32, 33, CF::MT_W>(acc2, yt, ybase, a.res_wpk + lane);
+      if ((lane & 31) < 4) {
+#pragma unroll
+        for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int s = wm * CF::SW + row / CF::LROWS, l = row % CF::LROWS;
+            if (n0 + s < a.n) a.out[((size_t)(n0 + s) * CF::LOUT + l) * 4 + (lane & 31)] = acc2[mt][r];
+          }
+      }
+      return;
+    }
+
+    // store: rows of register r are (r&3) + 8*(r>>2) + 4*hi; a half-wave writes 32 consecutive channels (128 B)
+#pragma unroll
+    for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int s = wm * CF::SW + row / CF::LROWS, l = row % CF::LROWS;
+        if (n0 + s < a.n) {
+          const int lo = CF::MODE == MODE_UP ? 2 * l + pass : l;
+          const size_t o = ((size_t)(n0 + s) * CF::LOUT + lo) * CF::COUT + col;
+          float v = acc[mt][r];
+          if constexpr (CF::EPI == EPI_GN_RES && CF::RES == RES_IDENT) v += a.res0[o];
+          a.out[o] = v;
+        }
+      }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// time embedding table: TimeEncoder (layers.py:232-258) + every block's cond_mlp (layers.py:337-341) for all integer t
+// ----------------------------------------------------------------------------------------------------------------
+struct TimeArgs {
+  const float* w1; const float* b1;   // [128,32], [128]
+  const float* w3; const float* b3;   // [32,128], [32]
+  const float* cw[12]; const float* cb[12];   // cond_mlp.1 weight [C,32], bias [C]
+  int cout[12]; int off[12];
+  int n_rtb; int total;
+  float* table;                       // [T][total]
+};
+
+__device__ __forceinline__ float mish_exact(float y) {
+  float sp = y > 20.f ? y : log1pf(expf(y));
+  return y * tanhf(sp);
+}
+
+__global__ void time_table_kernel(TimeArgs a) {
+  __shared__ float emb[32], h1[128], m[32];
+  const int t = blockIdx.x, tid = threadIdx.x;   // 128 threads
+  if (tid < 16) {
+    const float f = expf((float)tid * -(logf(10000.f) / 15.f));
+    const float v = (float)t * f;
+    emb[tid] = sinf(v);
+    emb[tid + 16] = cosf(v);
+  }
+  __syncthreads();
+  {
+    float s = a.b1[tid];
+    for (int k = 0; k < 32; ++k) s += a.w1[tid * 32 + k] * emb[k];
+    h1[tid] = mish_exact(s);
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float s = a.b3[tid];
+    for (int k = 0; k < 128; ++k) s += a.w3[tid * 128 + k] * h1[k];
+    m[tid] = mish_exact(s);          // cond_mlp starts with Mish
+  }
+  __syncthreads();
+  for (int r = 0; r < a.n_rtb; ++r)
+    for (int c = tid; c < a.cout[r]; c += 128) {
+      float s = a.cb[r][c];
+      for (int k = 0; k < 32; ++k) s += a.cw[r][c * 32 + k] * m[k];
+      a.table[(size_t)t * a.total + a.off[r] + c] = s;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// host side: parameter spec, weight packing, forward orchestration
+// ----------------------------------------------------------------------------------------------------------------
+
+struct TensorSpec { int64_t numel; };
+
+struct Rtb { int cin, cout; bool res; int t_w0, t_b0, t_g0, t_be0, t_w1, t_b1, t_g1, t_be1, t_cw, t_cb, t_rw, t_rb; };
+
+static void add_rtb(std::vector<int64_t>& sp, std::vector<Rtb>& rtbs, int cin, int cout) {
+  Rtb r{};
+  r.cin = cin; r.cout = cout; r.res = cin != cout;
+  r.t_w0 = sp.size(); sp.push_back((int64_t)cout * cin * 5);
+  r.t_b0 = sp.size(); sp.push_back(cout);
+  r.t_g0 = sp.size(); sp.push_back(cout);
+  r.t_be0 = sp.size(); sp.push_back(cout);
+  r.t_w1 = sp.size(); sp.push_back((int64_t)cout * cout * 5);
+  r.t_b1 = sp.size(); sp.push_back(cout);
+  r.t_g1 = sp.size(); sp.push_back(cout);
+  r.t_be1 = sp.size(); sp.push_back(cout);
+  r.t_cw = sp.size(); sp.push_back((int64_t)cout * 32);
+  r.t_cb = sp.size(); sp.push_back(cout);
+  if (r.res) {
+    r.t_rw = sp.size(); sp.push_back((int64_t)cout * cin);
+    r.t_rb = sp.size(); sp.push_back(cout);
+  }
+  rtbs.push_back(r);
+}
+
+struct Spec {
+  std::vector<int64_t> numel;
+  std::vector<Rtb> rtb;           // downs.0.0, downs.0.1, downs.1.0, ..., ups.0.0, ..., mid1, mid2 (state_dict order)
+  int t_time[4];
+  int t_down[2][2], t_up[2][2];
+  int t_final[6];
+};
+
+// state_dict order of TemporalUnet(dim_mults=(1,2,4)): time_mlp, downs, ups, mid_block1, mid_block2, final_conv
+static bool build_spec(int uid, int n_levels, Spec& s) {
+  if (uid != 32 || n_levels != 3) return false;
+  const int dims[4] = {4, uid, uid * 2, uid * 4};
+  auto& sp = s.numel;
+  s.t_time[0] = sp.size(); sp.push_back(128 * 32);
+  s.t_time[1] = sp.size(); sp.push_back(128);
+  s.t_time[2] = sp.size(); sp.push_back(32 * 128);
+  s.t_time[3] = sp.size(); sp.push_back(32);
+  for (int i = 0; i < 3; ++i) {
+    add_rtb(sp, s.rtb, dims[i], dims[i + 1]);
+    add_rtb(sp, s.rtb, dims[i + 1], dims[i + 1]);
+    if (i < 2) {
+      s.t_down[i][0] = sp.size(); sp.push_back((int64_t)dims[i + 1] * dims[i + 1] * 3);
+      s.t_down[i][1] = sp.size(); sp.push_back(dims[i + 1]);
+    }
+  }
+  for (int i = 0; i < 2; ++i) {   // reversed(in_out[1:]) = (64,128), (32,64): ups.i.0 = RTB(2*dout, din)
+    const int din = dims[2 - i], dout = dims[3 - i];
+    add_rtb(sp, s.rtb, dout * 2, din);
+    add_rtb(sp, s.rtb, din, din);
+    s.t_up[i][0] = sp.size(); sp.push_back((int64_t)din * din * 4);
+    s.t_up[i][1] = sp.size(); sp.push_back(din);
+  }
+  add_rtb(sp, s.rtb, dims[3], dims[3]);
+  add_rtb(sp, s.rtb, dims[3], dims[3]);
+  s.t_final[0] = sp.size(); sp.push_back((int64_t)uid * uid * 5);
+  s.t_final[1] = sp.size(); sp.push_back(uid);
+  s.t_final[2] = sp.size(); sp.push_back(uid);
+  s.t_final[3] = sp.size(); sp.push_back(uid);
+  s.t_final[4] = sp.size(); sp.push_back((int64_t)4 * uid);
+  s.t_final[5] = sp.size(); sp.push_back(4);
+  return true;
+}
+
+// Pack W(k, n), k = tap_slot * cinp + ci, into MFMA 32x32x2 B-fragment order:
+//   out[((nt*G + g)*64 + lane)*4 + q] = W(2*(4g+q) + (lane>>5), nt*32 + (lane&31))
+// conv weight layout [cout][cin][ks] (transposed == false) or ConvTranspose1d [cin][cout][ks] (transposed == true).
+static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin, int ks, const std::vector<int>& taps,
+                   bool transposed) {
+  const int cinp = (cin + 7) / 8 * 8;
+  const int nt_n = (cout + 31) / 32;
+  const int K = (int)taps.size() * cinp;
+  const int G = K / 8;
+  const size_t base = blob.size();
+  blob.resize(base + (size_t)nt_n * G * 64 * 4, 0.f);
+  for (int nt = 0; nt < nt_n; ++nt)
+    for (int g = 0; g < G; ++g)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int q = 0; q < 4; ++q) {
+          const int k = 2 * (4 * g + q) + (lane >> 5);
+          const int n = nt * 32 + (lane & 31);
+          const int tap = taps[k / cinp], ci = k % cinp;
+          float v = 0.f;
+          if (ci < cin && n < cout)
+            v = transposed ? w[((size_t)ci * cout + n) * ks + tap] : w[((size_t)n * cin + ci) * ks + tap];
+          blob[base + (((size_t)nt * G + g) * 64 + lane) * 4 + q] = v;
+        }
+}
+
+struct ConvW { size_t wpk, bias, gamma, beta; };
+struct RtbW { ConvW a, b; size_t res_wpk, res_bias; int tb_off; };
+
+}  // namespace mmd
+
+using namespace mmd;
+
+struct mmd_unet_s {
+  int T = 0;
+  float* blob = nullptr;     // packed weights / biases / affine params
+  float* ttable = nullptr;   // [T][tb_total]
+  int tb_total = 0;
+  RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
+  ConvW down[2], up[2], fin;
+  size_t fin_w1, fin_b1;
+};
+
+namespace mmd {
+
+static size_t push(std::vector<float>& blob, const float* p, int64_t n) {
+  while (blob.size() % 4) blob.push_back(0.f);
+  size_t off = blob.size();
+  blob.insert(blob.end(), p, p + n);
+  while (blob.size() % 4) blob.push_back(0.f);
+  return off;
+}
+
+template <class CF>
+static int launch(const ConvArgs& a, hipStream_t st) {
+  const int grid = (a.n + CF::SPB - 1) / CF::SPB;
+  hipLaunchKernelGGL(conv_kernel<CF>, dim3(grid), dim3(256), 0, st, a);
+  return 0;
+}
+
+// ---- the instantiated layer shapes (unet_input_dim 32, dim_mults (1,2,4), H = 64) ------------------------------
+//                 C0   C1  COUT LIN  MODE        MT_W EPI           RES        RC0  RC1
+using D00A = Cfg<4, 0, 32, 64, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
+using D00B = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_RES, RES_CONV, 4, 0>;
+using L64A = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
+using L64B = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
+using DN0 = Cfg<32, 0, 32, 64, MODE_DOWN, 1, EPI_PLAIN, RES_NONE, 0, 0>;
+using D10A = Cfg<32, 0, 64, 32, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
+using D10B = Cfg<64, 0, 64, 32, MODE_CONV5, 2, EPI_GN_RES, RES_CONV, 32, 0>;
+using L32A = Cfg<64, 0, 64, 32, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
+using L32B = Cfg<64, 0, 64, 32, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
+using DN1 = Cfg<64, 0, 64, 32, MODE_DOWN, 1, EPI_PLAIN, RES_NONE, 0, 0>;
+using D20A = Cfg<64, 0, 128, 16, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
+using D20B = Cfg<128, 0, 128, 16, MODE_CONV5, 2, EPI_GN_RES, RES_CONV, 64, 0>;
+using L16A = Cfg<128, 0, 128, 16, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
+using L16B = Cfg<128, 0, 128, 16, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
+using U00A = Cfg<128, 128, 64, 16, MODE_CONV5, 1, EPI_GN_TB, RES_NONE, 0, 0>;
+using U00B = Cfg<64, 0, 64, 16, MODE_CONV5, 1, EPI_GN_RES, RES_CONV, 128, 128>;
+using U01A = Cfg<64, 0, 64, 16, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
+using U01B = Cfg<64, 0, 64, 16, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
+using UP0 = Cfg<64, 0, 64, 16, MODE_UP, 1, EPI_PLAIN, RES_NONE, 0, 0>;
+using U10A = Cfg<64, 64, 32, 32, MODE_CONV5, 1, EPI_GN_TB, RES_NONE, 0, 0>;
+using U10B = Cfg<32, 0, 32, 32, MODE_CONV5, 1, EPI_GN_RES, RES_CONV, 64, 64>;
+using U11A = Cfg<32, 0, 32, 32, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
+using U11B = Cfg<32, 0, 32, 32, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
+using UP1 = Cfg<32, 0, 32, 32, MODE_UP, 1, EPI_PLAIN, RES_NONE, 0, 0>;
+using FIN = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_FINAL, RES_NONE, 0, 0>;
+
+static ConvArgs args_a(const mmd_unet_s* u, const RtbW& w, const float* in0, const float* in1, float* out, int t, int n) {
+  ConvArgs a{};
+  a.in0 = in0; a.in1 = in1; a.out = out;
+  a.wpk = reinterpret_cast<const float4*>(u->blob + w.a.wpk);
+  a.bias = u->blob + w.a.bias; a.gamma = u->blob + w.a.gamma; a.beta = u->blob + w.a.beta;
+  a.tbias = u->ttable + (size_t)t * u->tb_total + w.tb_off;
+  a.n = n;
+  return a;
+}
+
+static ConvArgs args_b(const mmd_unet_s* u, const RtbW& w, const float* h, const float* res0, const float* res1,
+                       float* out, int n) {
+  ConvArgs a{};
+  a.in0 = h; a.out = out;
+  a.wpk = reinterpret_cast<const float4*>(u->blob + w.b.wpk);
+  a.bias = u->blob + w.b.bias; a.gamma = u->blob + w.b.gamma; a.beta = u->blob + w.b.beta;
+  a.res0 = res0; a.res1 = res1;
+  a.res_wpk = reinterpret_cast<const float4*>(u->blob + w.res_wpk);
+  a.res_bias = u->blob + w.res_bias;
+  a.n = n;
+  return a;
+}
+
+static ConvArgs args_plain(const mmd_unet_s* u, const ConvW& w, const float* in, float* out, int n) {
+  ConvArgs a{};
+  a.in0 = in; a.out = out;
+  a.wpk = reinterpret_cast<const float4*>(u->blob + w.wpk);
+  a.bias = u->blob + w.bias;
+  a.n = n;
+  return a;
+}
+
+constexpr size_t ACT_FLOATS = 2048;   // L * C is 2048 at every level (64x32, 32x64, 16x128)
+
+}  // namespace mmd
+
+extern "C" {
+
+int mmd_unet_num_tensors(int unet_input_dim, int n_levels) {
+  Spec s;
+  if (!build_spec(unet_input_dim, n_levels, s)) {
+    set_error("unsupported TemporalUnet configuration (unet_input_dim=%d, n_levels=%d)", unet_input_dim, n_levels);
+    return -1;
+  }
+  return (int)s.numel.size();
+}
+
+int64_t mmd_unet_tensor_numel(int unet_input_dim, int n_levels, int index) {
+  Spec s;
+  if (!build_spec(unet_input_dim, n_levels, s) || index < 0 || index >= (int)s.numel.size()) return -1;
+  return s.numel[index];
+}
+
+int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_diffusion_steps,
+                    const float* const* tensors, const int64_t* numels, int n_tensors, void* stream) {
+  Spec s;
+  MMD_REQUIRE(out != nullptr, "mmd_unet_create: out is NULL");
+  MMD_REQUIRE(build_spec(unet_input_dim, n_levels, s),
+              "unsupported TemporalUnet configuration (unet_input_dim=%d, n_levels=%d)", unet_input_dim, n_levels);
+  MMD_REQUIRE(n_tensors == (int)s.numel.size(), "expected %d parameter tensors, got %d", (int)s.numel.size(), n_tensors);
+  for (int i = 0; i < n_tensors; ++i)
+    MMD_REQUIRE(numels[i] == s.numel[i] && tensors[i] != nullptr, "parameter tensor %d has %lld elements, expected %lld",
+                i, (long long)numels[i], (long long)s.numel[i]);
+  MMD_REQUIRE(n_diffusion_steps >= 1, "n_diffusion_steps must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+
+  auto* u = new mmd_unet_s();
+  u->T = n_diffusion_steps;
+  std::vector<float> blob;
+  const std::vector<int> taps5 = {0, 1, 2, 3, 4}, taps3 = {0, 1, 2}, taps1 = {0};
+  size_t raw_time[4];
+  for (int i = 0; i < 4; ++i) raw_time[i] = push(blob, tensors[s.t_time[i]], s.numel[s.t_time[i]]);
+  size_t raw_cw[12], raw_cb[12];
+  int tb_off = 0;
+  for (int r = 0; r < 12; ++r) {
+    const Rtb& R = s.rtb[r];
+    RtbW& W = u->rtb[r];
+    while (blob.size() % 4) blob.push_back(0.f);
+    W.a.wpk = blob.size(); pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false);
+    W.a.bias = push(blob, tensors[R.t_b0], R.cout);
+    W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
+    W.a.beta = push(blob, tensors[R.t_be0], R.cout);
+    W.b.wpk = blob.size(); pack_b(blob, tensors[R.t_w1], R.cout, R.cout, 5, taps5, false);
+    W.b.bias = push(blob, tensors[R.t_b1], R.cout);
+    W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
+    W.b.beta = push(blob, tensors[R.t_be1], R.cout);
+    raw_cw[r] = push(blob, tensors[R.t_cw], (int64_t)R.cout * 32);
+    raw_cb[r] = push(blob, tensors[R.t_cb], R.cout);
+    W.res_wpk = W.res_bias = 0;
+    if (R.res) {
+      W.res_wpk = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false);
+      W.res_bias = push(blob, tensors[R.t_rb], R.cout);
+    }
+    W.tb_off = tb_off;
+    tb_off += R.cout;
+  }
+  u->tb_total = tb_off;
+  const int dims[4] = {4, unet_input_dim, unet_input_dim * 2, unet_input_dim * 4};
+  for (int i = 0; i < 2; ++i) {
+    const int c = dims[i + 1];
+    u->down[i].wpk = blob.size(); pack_b(blob, tensors[s.t_down[i][0]], c, c, 3, taps3, false);
+    u->down[i].bias = push(blob, tensors[s.t_down[i][1]], c);
+    const int cu = dims[2 - i];
+    // ConvTranspose1d(k=4, s=2, p=1): out[2m] = in[m-1] W3 + in[m] W1 ; out[2m+1] = in[m] W2 + in[m+1] W0
+    u->up[i].wpk = blob.size();
+    pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{3, 1}, true);
+    pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{2, 0}, true);
+    u->up[i].bias = push(blob, tensors[s.t_up[i][1]], cu);
+  }
+  u->fin.wpk = blob.size(); pack_b(blob, tensors[s.t_final[0]], 32, 32, 5, taps5, false);
+  u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
+  u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
+  u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
+  u->fin_w1 = blob.size(); pack_b(blob, tensors[s.t_final[4]], 4, 32, 1, taps1, false);
+  u->fin_b1 = push(blob, tensors[s.t_final[5]], 4);
+
+  if (hipMalloc(&u->blob, blob.size() * sizeof(float)) != hipSuccess ||
+      hipMalloc(&u->ttable, (size_t)u->T * u->tb_total * sizeof(float)) != hipSuccess) {
+    set_error("mmd_unet_create: hipMalloc failed");
+    mmd_unet_destroy(u);
+    return 1;
+  }
+  MMD_HIP_CHECK(hipMemcpyAsync(u->blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  MMD_HIP_CHECK(hipStreamSynchronize(st));   // blob is a local vector
+
+  TimeArgs ta{};
+  ta.w1 = u->blob + raw_time[0]; ta.b1 = u->blob + raw_time[1];
+  ta.w3 = u->blob + raw_time[2]; ta.b3 = u->blob + raw_time[3];
+  for (int r = 0; r < 12; ++r) {
+    ta.cw[r] = u->blob + raw_cw[r]; ta.cb[r] = u->blob + raw_cb[r];
+    ta.cout[r] = s.rtb[r].cout; ta.off[r] = u->rtb[r].tb_off;
+  }
+  ta.n_rtb = 12; ta.total = u->tb_total; ta.table = u->ttable;
+  hipLaunchKernelGGL(time_table_kernel, dim3(u->T), dim3(128), 0, st, ta);
+  MMD_HIP_CHECK(hipGetLastError());
+  MMD_HIP_CHECK(hipStreamSynchronize(st));
+  *out = u;
+  return 0;
+}
+
+int mmd_unet_destroy(mmd_unet_t u) {
+  if (!u) return 0;
+  if (u->blob) (void)hipFree(u->blob);
+  if (u->ttable) (void)hipFree(u->ttable);
+  delete u;
+  return 0;
+}
+
+size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) {
+  return (size_t)5 * ACT_FLOATS * sizeof(float) * (size_t)(n_traj > 0 ? n_traj : 0);
+}
+
+int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, void* stream) {
+  MMD_REQUIRE(u && x && eps && ws, "mmd_unet_forward: NULL argument");
+  MMD_REQUIRE(n >= 1, "mmd_unet_forward: n_traj must be >= 1");
+  MMD_REQUIRE(t >= 0 && t < u->T, "mmd_unet_forward: t=%d outside [0,%d)", t, u->T);
+  MMD_REQUIRE(ws_bytes >= mmd_unet_workspace_bytes(u, n), "mmd_unet_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* Hb = (float*)ws;
+  float* P0 = Hb + (size_t)n * ACT_FLOATS;
+  float* P1 = P0 + (size_t)n * ACT_FLOATS;
+  float* S1 = P1 + (size_t)n * ACT_FLOATS;
+  float* S2 = S1 + (size_t)n * ACT_FLOATS;
+  const RtbW* R = u->rtb;
+  // downs.0 @ L=64
+  launch<D00A>(args_a(u, R[0], x, nullptr, Hb, t, n), st);
+  launch<D00B>(args_b(u, R[0], Hb, x, nullptr, P0, n), st);
+  launch<L64A>(args_a(u, R[1], P0, nullptr, Hb, t, n), st);
+  launch<L64B>(args_b(u, R[1], Hb, P0, nullptr, P1, n), st);
+  launch<DN0>(args_plain(u, u->down[0], P1, P0, n), st);
+  // downs.1 @ L=32
+  launch<D10A>(args_a(u, R[2], P0, nullptr, Hb, t, n), st);
+  launch<D10B>(args_b(u, R[2], Hb, P0, nullptr, P1, n), st);
+  launch<L32A>(args_a(u, R[3], P1, nullptr, Hb, t, n), st);
+  launch<L32B>(args_b(u, R[3], Hb, P1, nullptr, S1, n), st);
+  launch<DN1>(args_plain(u, u->down[1], S1, P0, n), st);
+  // downs.2 @ L=16
+  launch<D20A>(args_a(u, R[4], P0, nullptr, Hb, t, n), st);
+  launch<D20B>(args_b(u, R[4], Hb, P0, nullptr, P1, n), st);
+  launch<L16A>(args_a(u, R[5], P1, nullptr, Hb, t, n), st);
+  launch<L16B>(args_b(u, R[5], Hb, P1, nullptr, S2, n), st);
+  // mid
+  launch<L16A>(args_a(u, R[10], S2, nullptr, Hb, t, n), st);
+  launch<L16B>(args_b(u, R[10], Hb, S2, nullptr, P0, n), st);
+  launch<L16A>(args_a(u, R[11], P0, nullptr, Hb, t, n), st);
+  launch<L16B>(args_b(u, R[11], Hb, P0, nullptr, P1, n), st);
+  // ups.0 @ L=16: cat(x, skip2)
+  launch<U00A>(args_a(u, R[6], P1, S2, Hb, t, n), st);
+  launch<U00B>(args_b(u, R[6], Hb, P1, S2, P0, n), st);
+  launch<U01A>(args_a(u, R[7], P0, nullptr, Hb, t, n), st);
+  launch<U01B>(args_b(u, R[7], Hb, P0, nullptr, P1, n), st);
+  launch<UP0>(args_plain(u, u->up[0], P1, P0, n), st);
+  // ups.1 @ L=32: cat(x, skip1)
+  launch<U10A>(args_a(u, R[8], P0, S1, Hb, t, n), st);
+  launch<U10B>(args_b(u, R[8], Hb, P0, S1, P1, n), st);
+  launch<U11A>(args_a(u, R[9], P1, nullptr, Hb, t, n), st);
+  launch<U11B>(args_b(u, R[9], Hb, P1, nullptr, P0, n), st);
+  launch<UP1>(args_plain(u, u->up[1], P0, P1, n), st);
+  // final_conv
+  ConvArgs f = args_plain(u, u->fin, P1, eps, n);
+  f.gamma = u->blob + u->fin.gamma; f.beta = u->blob + u->fin.beta;
+  f.res_wpk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
+  f.res_bias = u->blob + u->fin_b1;
+  launch<FIN>(f, st);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

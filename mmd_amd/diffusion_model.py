@@ -1,0 +1,209 @@
+"""GaussianDiffusionModel: host mirror of reference mmd/models/diffusion_models/diffusion_model_base.py:48-433
+(sampling side) + sample_functions.py.  The p_sample_loop is ONE C-ABI call (mmd_p_sample_loop) that enqueues the
+UNet kernels and the fused posterior/guide/noise kernel of every step on the current HIP stream."""
+import ctypes as C
+from copy import copy
+
+import numpy as np
+import torch
+
+from . import _lib
+from .guides import GuideManagerTrajectoriesWithVelocity
+from .schedules import SCHEDULE_KEYS, diffusion_buffers
+
+
+def ddpm_sample_fn(*args, **kwargs):
+    """Marker with the reference's name (sample_functions.py:40): the DDPM step is fused into the sampler kernels;
+    passing any other sample_fn raises."""
+    raise RuntimeError("ddpm_sample_fn is executed inside libmmd_amd.so; it is only a marker on the host side")
+
+
+def make_timesteps(batch_size, i, device):
+    return torch.full((batch_size,), i, device=device, dtype=torch.long)
+
+
+class GaussianDiffusionModel:
+    def __init__(self, model=None, variance_schedule="exponential", n_diffusion_steps=100, clip_denoised=True,
+                 predict_epsilon=False, loss_type="l2", context_model=None, **kwargs):
+        if not predict_epsilon or not clip_denoised or context_model is not None:
+            raise NotImplementedError("kernels implement predict_epsilon=True, clip_denoised=True, no context "
+                                      "(the configuration of the released MPD checkpoints)")
+        self.model = model
+        self.n_diffusion_steps = n_diffusion_steps
+        self.state_dim = model.state_dim
+        self.clip_denoised, self.predict_epsilon = clip_denoised, predict_epsilon
+        for k, v in diffusion_buffers(n_diffusion_steps, variance_schedule).items():
+            setattr(self, k, v)                                    # CPU float32 [T] buffers, reference names
+        self._tables = {k: np.ascontiguousarray(getattr(self, k).numpy()) for k in SCHEDULE_KEYS}
+        self.seed = 0
+        self._draws = 0
+
+    # ---- parameters -------------------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        self.model.load_state_dict({k[len("model."):]: v for k, v in state_dict.items() if k.startswith("model.")})
+        return self
+
+    def state_dict(self):
+        sd = {k: getattr(self, k) for k in SCHEDULE_KEYS}
+        sd.update({"model." + k: v for k, v in self.model.state_dict().items()})
+        return sd
+
+    def eval(self):
+        return self
+
+    def warmup(self, horizon=64, device="cuda"):
+        x = torch.randn((2, horizon, self.state_dim), device=device)
+        self.model(x, 1, context=None)
+
+    # ---- descriptors ------------------------------------------------------------------------------------------
+    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_std_extra, hard_mask):
+        s = _lib.SamplerDesc()
+        s.n_diffusion_steps = self.n_diffusion_steps
+        fp = C.POINTER(C.c_float)
+        for name in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+                     "posterior_mean_coef2", "posterior_log_variance_clipped"):
+            setattr(s, name, self._tables[name].ctypes.data_as(fp))
+        s.n_guide_steps = int(n_guide_steps)
+        tsg = t_start_guide
+        s.t_start_guide = int(min(tsg, 2 ** 30)) if tsg != float("inf") else 2 ** 30
+        s.noise_std_extra = float(noise_std_extra)
+        s.hard_mask = hard_mask
+        return s
+
+    @staticmethod
+    def _hard_tensor(hard_conds, n_robots, horizon, device, D):
+        """{row: [D] | [n_robots, D] | [B_total, D]} -> ([n_robots, 2, D] float32, mask).  Per-sample hard conditions
+        must be constant within a robot (they are: run_inference repeats one state, diffusion_model_base.py:327-329)."""
+        hard = torch.zeros(n_robots, 2, D, dtype=torch.float32, device=device)
+        mask = 0
+        for row, val in hard_conds.items():
+            val = torch.as_tensor(val, dtype=torch.float32, device=device)
+            if val.ndim == 1:
+                val = val[None].expand(n_robots, D)
+            elif val.shape[0] != n_robots:
+                per = val.shape[0] // n_robots
+                val = val[::per]
+            if row == 0:
+                hard[:, 0], mask = val, mask | 1
+            elif row == horizon - 1:
+                hard[:, 1], mask = val, mask | 2
+            else:
+                raise NotImplementedError("hard conditions are supported on rows 0 and H-1 (what MPD/MPDEnsemble use)")
+        return hard.contiguous(), mask
+
+    # ---- sampling ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def p_sample_loop(self, shape, hard_conds, n_diffusion_steps, context=None, return_chain=False,
+                      sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0, warm_start_path_b=None,
+                      guide=None, n_guide_steps=1, t_start_guide=float("inf"), noise_std_extra_schedule_fn=None,
+                      n_robots=1, step_noise=None, seed=None, device="cuda", **sample_kwargs):
+        """diffusion_model_base.py:162-211.  Extensions: `n_robots` (batch = n_robots * n_samples, robot-major),
+        `step_noise` [n_steps_total, B, H, D] + `warm_start_path_b` as x_T to inject every Gaussian draw (parity
+        tests), `seed` for the in-kernel Philox stream otherwise."""
+        if sample_fn is not ddpm_sample_fn:
+            raise NotImplementedError("only ddpm_sample_fn is implemented (DDIM is SURVEY §8f-4)")
+        if context is not None:
+            raise NotImplementedError("context")
+        if guide is not None and not isinstance(guide, GuideManagerTrajectoriesWithVelocity):
+            raise NotImplementedError("guide must be a mmd_amd GuideManagerTrajectoriesWithVelocity")
+        B_total, H, D = shape
+        device = torch.device(device)
+        lib = _lib.load()
+        noise_std = 1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(0))
+        hard, mask = self._hard_tensor(hard_conds, n_robots, H, device, D)
+        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std, mask)
+        n_total = n_diffusion_steps + n_diffusion_steps_without_noise
+        if warm_start_path_b is not None:
+            x = warm_start_path_b.to(device=device, dtype=torch.float32).contiguous().clone()
+            init_noise = 0
+        else:
+            x = torch.empty(shape, dtype=torch.float32, device=device)
+            init_noise = 1
+        chain = torch.empty((n_total + 1,) + tuple(shape), dtype=torch.float32, device=device) if return_chain else None
+        if step_noise is not None:
+            step_noise = step_noise.to(device=device, dtype=torch.float32).contiguous()
+            assert step_noise.shape == (n_total,) + tuple(shape)
+        gd = guide.desc() if guide is not None else None
+        ws = self.model.workspace(B_total, device, sampler=True)
+        if seed is None:
+            seed = (self.seed << 20) + self._draws
+            self._draws += 1
+        _lib.check(lib.mmd_p_sample_loop(
+            self.model.handle(self.n_diffusion_steps), C.byref(s), C.byref(gd) if gd is not None else None,
+            x.data_ptr(), hard.data_ptr(), n_robots, B_total // n_robots, n_diffusion_steps,
+            n_diffusion_steps_without_noise, init_noise, step_noise.data_ptr() if step_noise is not None else None,
+            C.c_uint64(seed), chain.data_ptr() if chain is not None else None, ws.data_ptr(), ws.numel(),
+            _lib.current_stream_ptr()))
+        if return_chain:
+            return x, chain.transpose(0, 1)                      # [B, steps+1, H, D] like torch.stack(chain, dim=1)
+        return x
+
+    @torch.no_grad()
+    def sample_step(self, x, hard_conds, i, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
+                    noise_std_extra_schedule_fn=None, n_robots=1, noise=None, seed=None):
+        """One `ddpm_sample_fn` call + the `apply_hard_conditioning` that follows it in the loop
+        (sample_functions.py:40-86, diffusion_model_base.py:199-203), in place on x; `i` is the loop index
+        (negative: t = 0).  This is what DiffusionsEnsemble interleaves across tiles (diffusion_ensemble.py:86-100)."""
+        B_total, H, D = x.shape
+        hard, mask = self._hard_tensor(hard_conds, n_robots, H, x.device, D)
+        noise_std = 1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(0))
+        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std, mask)
+        gd = guide.desc() if guide is not None else None
+        ws = self.model.workspace(B_total, x.device, sampler=True)
+        if seed is None:
+            seed = (self.seed << 20) + self._draws
+            self._draws += 1
+        _lib.check(_lib.load().mmd_ddpm_step(
+            self.model.handle(self.n_diffusion_steps), C.byref(s), C.byref(gd) if gd is not None else None,
+            _lib.require_gpu(x, "x"), hard.data_ptr(), n_robots, B_total // n_robots, int(i),
+            _lib.require_gpu(noise.contiguous(), "noise") if noise is not None else None, C.c_uint64(seed),
+            C.c_uint32(int(i) & 0xFFFFFFFF), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))
+        return x
+
+    @torch.no_grad()
+    def conditional_sample(self, hard_conds, n_diffusion_steps, horizon=None, batch_size=1, ddim=False,
+                           warm_start_path_b=None, **sample_kwargs):
+        if ddim:
+            raise NotImplementedError("DDIM sampling is out of scope (SURVEY §8f-4)")
+        shape = (batch_size, horizon or 64, self.state_dim)
+        return self.p_sample_loop(shape, hard_conds, n_diffusion_steps=n_diffusion_steps,
+                                  warm_start_path_b=warm_start_path_b, **sample_kwargs)
+
+    @torch.no_grad()
+    def run_inference(self, context=None, hard_conds=None, n_samples=1, return_chain=False, n_robots=1,
+                      **diffusion_kwargs):
+        """diffusion_model_base.py:320-351.  Returns [T+2, B, H, D] (return_chain) or [B, H, D]."""
+        samples, chain = self.conditional_sample(copy(hard_conds), n_diffusion_steps=self.n_diffusion_steps,
+                                                 context=context, batch_size=n_samples * n_robots, return_chain=True,
+                                                 n_robots=n_robots, **diffusion_kwargs)
+        chain = chain.transpose(0, 1)                            # 'b diffsteps h d -> diffsteps b h d'
+        return chain if return_chain else chain[-1]
+
+    @torch.no_grad()
+    def run_local_inference(self, seed_trajectory_b, n_noising_steps, n_denoising_steps, context=None,
+                            hard_conds=None, n_samples=1, return_chain=False, n_robots=1, q_noise=None,
+                            **diffusion_kwargs):
+        """diffusion_model_base.py:353-421: forward-noise the seed batch n_noising_steps, then denoise."""
+        if n_noising_steps is None:
+            noised = None
+        else:
+            noised = self.q_sample(seed_trajectory_b, n_noising_steps, noise=q_noise)
+        samples, chain = self.conditional_sample(copy(hard_conds), n_diffusion_steps=n_denoising_steps, context=context,
+                                                 batch_size=n_samples * n_robots, return_chain=True,
+                                                 warm_start_path_b=noised, n_robots=n_robots, **diffusion_kwargs)
+        chain = chain.transpose(0, 1)
+        return chain if return_chain else chain[-1]
+
+    def q_sample(self, x_start, t, noise=None):
+        """diffusion_model_base.py:425-433 (t: int or a constant [B] tensor)."""
+        t = int(t[0].item()) if torch.is_tensor(t) else int(t)
+        x_start = x_start.to(dtype=torch.float32).contiguous()
+        out = torch.empty_like(x_start)
+        seed = (self.seed << 20) + self._draws
+        self._draws += 1
+        _lib.check(_lib.load().mmd_q_sample(
+            out.data_ptr(), _lib.require_gpu(x_start, "x_start"),
+            _lib.require_gpu(noise.contiguous(), "noise") if noise is not None else None,
+            float(self.sqrt_alphas_cumprod[t]), float(self.sqrt_one_minus_alphas_cumprod[t]), C.c_uint64(seed),
+            0xFFFFFFFE, x_start.shape[0], _lib.current_stream_ptr()))
+        return out

@@ -1,0 +1,118 @@
+"""GuideManagerTrajectoriesWithVelocity: host mirror of reference mmd/models/diffusion_models/guides.py:152-259.
+It only holds parameters; the gradient itself is the gfx950 kernel in mmd_amd/csrc/guide.hip.
+
+One guide object can drive SEVERAL robots at once (the build's data-parallel restructuring, SURVEY.md headline fact
+3): extra costs are kept per robot, robot r's samples are rows [r*B, (r+1)*B) of the trajectory batch."""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .constraints import CostConstraint, pack_constraints
+from .environments import LIMITS, sdf_grid_texture
+
+ROBOT_RADIUS = 0.05                 # mmd/config/mmd_params.py:30
+
+
+class GuideManagerTrajectoriesWithVelocity:
+    def __init__(self, dataset, cost=None, clip_grad=True, clip_grad_rule="norm", max_grad_norm=1.0,
+                 env_id="EnvEmpty2D", obstacle_cutoff_margin=0.05, robot_radius=ROBOT_RADIUS,
+                 weight_grad_cost_collision=2e-2, weight_grad_cost_smoothness=8e-2, trajectory_duration=5.0,
+                 n_support_points=64, sigma_gp=1.0, n_robots=1, robot_env_ids: Optional[Sequence[str]] = None,
+                 device="cuda", tensor_args=None, **kwargs):
+        if not clip_grad or clip_grad_rule != "norm":
+            raise NotImplementedError("MPD uses clip_grad=True, clip_grad_rule='norm' (mpd.py:258-265)")
+        self.dataset = dataset
+        self.device = torch.device(tensor_args["device"] if tensor_args else device)
+        self.n_robots = n_robots
+        self.max_grad_norm = max_grad_norm
+        self.weight_collision = weight_grad_cost_collision
+        self.weight_smoothness = weight_grad_cost_smoothness
+        self.dt = trajectory_duration / n_support_points                      # mpd.py:140
+        self.sigma_gp = sigma_gp
+        # collision_margins + cutoff_margin in fp32 (distance_fields.py:117, robot_planar_disk.py:68)
+        self.margin = float(np.float32(np.float32(robot_radius * 1.1) + np.float32(obstacle_cutoff_margin)))
+        env_ids = list(robot_env_ids) if robot_env_ids is not None else [env_id] * n_robots
+        maps = sorted(set(env_ids))
+        tex = np.stack([sdf_grid_texture(m) for m in maps])[:, None]          # [n_maps, n_grids=1, nx, ny, 4]
+        self._grids = torch.from_numpy(np.ascontiguousarray(tex)).to(self.device)
+        self._robot_map = torch.tensor([maps.index(e) for e in env_ids], dtype=torch.int32, device=self.device)
+        self._n_maps = len(maps)
+        # extra costs, per robot (guides.py:176-178, :228-234)
+        self.extra_cost_l: List[List[CostConstraint]] = [[] for _ in range(n_robots)]
+        self.extra_costs_grad_weight_l: List[List[float]] = [[] for _ in range(n_robots)]
+        self._cons = None
+        self._cons_dirty = True
+        self._external_cons = None
+
+    # ---- extra costs (constraints) ----------------------------------------------------------------------------
+    def add_extra_costs(self, extra_costs, extra_costs_grad_weights, robot=0):
+        self.extra_cost_l[robot].extend(extra_costs)
+        self.extra_costs_grad_weight_l[robot].extend(extra_costs_grad_weights)
+        self._cons_dirty = True
+
+    def reset_extra_costs(self):
+        self.extra_cost_l = [[] for _ in range(self.n_robots)]
+        self.extra_costs_grad_weight_l = [[] for _ in range(self.n_robots)]
+        self._cons_dirty = True
+        self._external_cons = None
+
+    def set_packed_constraints(self, cons):
+        """Use device-built constraint tensors (constraints.soft_constraints_from_paths) instead of host-packed ones."""
+        self._external_cons = cons
+
+    def _constraints(self):
+        if self._external_cons is not None:
+            return self._external_cons
+        if self._cons_dirty:
+            groups = [list(zip(c, w)) for c, w in zip(self.extra_cost_l, self.extra_costs_grad_weight_l)]
+            self._cons = pack_constraints(groups, self.device)
+            self._cons_dirty = False
+        return self._cons
+
+    # ---- C-ABI descriptor -------------------------------------------------------------------------------------
+    def desc(self):
+        d = _lib.GuideDesc()
+        nz = self.dataset.normalizer
+        d.norm_min[:] = [float(v) for v in nz.mins.cpu()]
+        d.norm_max[:] = [float(v) for v in nz.maxs.cpu()]
+        d.limits_lo[:] = LIMITS[0]
+        d.limits_hi[:] = LIMITS[1]
+        d.grid_nx, d.grid_ny = self._grids.shape[2], self._grids.shape[3]
+        d.n_grids, d.n_maps = 1, self._n_maps
+        d.sdf_grids_dev = self._grids.data_ptr()
+        d.robot_map_dev = self._robot_map.data_ptr() if self._n_maps > 1 else None
+        d.ws_min[:] = [float(np.float32(LIMITS[0][k]) * np.float32(1.08)) for k in range(2)]      # tasks.py:81-83
+        d.ws_max[:] = [float(np.float32(LIMITS[1][k]) * np.float32(1.08)) for k in range(2)]
+        d.margin, d.dt, d.sigma_gp = self.margin, self.dt, self.sigma_gp
+        d.weight_collision, d.weight_smoothness = self.weight_collision, self.weight_smoothness
+        d.max_grad_norm = self.max_grad_norm
+        cons = self._constraints()
+        if cons is not None:
+            ell, gso, gw, rgo = cons
+            d.cons_ell_dev, d.grp_slot_off_dev = ell.data_ptr(), gso.data_ptr()
+            d.grp_weight_dev, d.robot_grp_off_dev = gw.data_ptr(), rgo.data_ptr()
+            self._keep = cons
+        return d
+
+    # ---- guide_gradient_steps / forward -----------------------------------------------------------------------
+    def guide_steps(self, x, hard, hard_mask, n_steps):
+        """In place: n_steps x { x += guide(x); apply_hard_conditioning } (sample_functions.py:89-107).
+        x [n_robots*B,H,D]; hard [n_robots,2,D] normalised start / goal states."""
+        d = self.desc()
+        B = x.shape[0] // self.n_robots
+        _lib.check(_lib.load().mmd_guide_steps(C.byref(d), _lib.require_gpu(x, "x"), _lib.require_gpu(hard, "hard"),
+                                               hard_mask, self.n_robots, B, n_steps, _lib.current_stream_ptr()))
+        return x
+
+    def forward(self, x_normalized):
+        """grad = guide(x) exactly as the reference returns it (guides.py:180-226): one step without hard
+        conditioning on a copy, minus the input."""
+        y = x_normalized.contiguous().clone()
+        hard = torch.zeros(self.n_robots, 2, x_normalized.shape[-1], device=y.device)
+        self.guide_steps(y, hard, 0, 1)
+        return y - x_normalized
+
+    __call__ = forward

@@ -1,0 +1,98 @@
+"""TemporalUnet: host mirror of reference mmd/models/diffusion_models/temporal_unet.py:23-174 whose forward runs as
+hand-written gfx950 kernels (mmd_amd/csrc/unet.hip) behind the C ABI (include/mmd_amd.h: mmd_unet_*)."""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .unet_spec import UNET_DIM_MULTS, unet_param_spec   # noqa: F401
+
+
+class TemporalUnet:
+    def __init__(self, n_support_points=64, state_dim=4, unet_input_dim=32, dim_mults=(1, 2, 4), time_emb_dim=32,
+                 self_attention=False, conditioning_type=None, max_timesteps=1000, **kwargs):
+        if self_attention or conditioning_type not in (None, "None"):
+            raise NotImplementedError("only the configuration MPD/MPDEnsemble instantiate is supported "
+                                      "(no self-attention, no context conditioning)")
+        if n_support_points != 64 or state_dim != 4 or time_emb_dim != 32:
+            raise NotImplementedError("kernels are instantiated for H=64, state_dim=4, time_emb_dim=32")
+        self.state_dim, self.n_support_points = state_dim, n_support_points
+        self.unet_input_dim, self.dim_mults = unet_input_dim, tuple(dim_mults)
+        self.spec = unet_param_spec(state_dim, unet_input_dim, self.dim_mults)
+        self.max_timesteps = max_timesteps
+        self._sd = None
+        self._handle = None
+        self._ws = None
+
+    # ---- parameters -------------------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's keys with or without the `model.` prefix; torch tensors or numpy arrays."""
+        sd = OrderedDict()
+        for k, shape in self.spec.items():
+            v = state_dict.get(k, state_dict.get("model." + k))
+            if v is None:
+                raise KeyError(f"missing parameter {k}")
+            v = np.ascontiguousarray(torch.as_tensor(v).detach().cpu().numpy(), dtype=np.float32)
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError(f"{k}: shape {v.shape} != {shape}")
+            sd[k] = v
+        self._sd = sd
+        self._release()
+        return self
+
+    def state_dict(self):
+        return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._sd.items())
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.load().mmd_unet_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def handle(self, n_timesteps=None):
+        """Device model (packed weights + time-embedding table for t in [0, n_timesteps))."""
+        if self._sd is None:
+            raise RuntimeError("TemporalUnet has no parameters: call load_state_dict first")
+        if n_timesteps is not None and n_timesteps > self.max_timesteps:
+            self.max_timesteps = n_timesteps
+            self._release()
+        if self._handle is None:
+            lib = _lib.load()
+            n = len(self._sd)
+            ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in self._sd.values()])
+            numels = (C.c_int64 * n)(*[v.size for v in self._sd.values()])
+            h = C.c_void_p()
+            _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), self.max_timesteps,
+                                           ptrs, numels, n, _lib.current_stream_ptr()))
+            self._handle = h
+        return self._handle
+
+    def workspace(self, n_traj, device, sampler=False):
+        lib = _lib.load()
+        nbytes = (lib.mmd_sampler_workspace_bytes if sampler else lib.mmd_unet_workspace_bytes)(self.handle(), n_traj)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != torch.device(device):
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    def forward(self, x, time, context=None):
+        """x [B,H,D] float32 on the GPU; time: int or a [B] tensor with identical entries (as make_timesteps
+        produces, diffusion_model_base.py:27-29); returns eps [B,H,D]."""
+        if context is not None:
+            raise NotImplementedError("context conditioning is not used by MPD/MPDEnsemble")
+        t = int(time[0].item()) if torch.is_tensor(time) else int(time)
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        ws = self.workspace(x.shape[0], x.device)
+        _lib.check(_lib.load().mmd_unet_forward(self.handle(), _lib.require_gpu(x, "x"), t, out.data_ptr(), x.shape[0],
+                                                ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))
+        return out
+
+    __call__ = forward

@@ -77,10 +77,15 @@ def sample_case(name):
         paths = synth.straight_line_paths(starts, goals, H)
         return dict(map="EnvConveyor2D", T=50, B=4, start=starts[2], goal=goals[2], cons=[soft_group(paths, 2)],
                     seeds=(21, 22))
+    if name == "prior_T100":
+        starts, goals = synth.start_goal_circle(6, 0.8)
+        return dict(map="EnvEmpty2D", T=100, B=8, start=starts[1], goal=goals[1], cons=[], seeds=(29, 30),
+                    use_guide=False)
     raise KeyError(name)
 
 
-SAMPLE_CASES = ("empty_T50", "highways_T100", "empty_T25_nocons", "cfg0_T50_B1", "empty32_T25", "conveyor_T50")
+SAMPLE_CASES = ("empty_T50", "highways_T100", "empty_T25_nocons", "cfg0_T50_B1", "empty32_T25", "conveyor_T50",
+                "prior_T100")
 
 
 def sample_inputs(case):
@@ -102,6 +107,8 @@ def oracle_run_inference(case, weights_seed=0, clip_mode="reference"):
     gp = guide_params(case["map"], case.get("cutoff", 0.05))
     xT, steps = sample_inputs(case)
     guide = lambda x: O.guide_grad(x, gp, case["cons"], clip_mode=clip_mode)   # noqa: E731
+    if not case.get("use_guide", True):
+        guide = None
     return O.p_sample_loop(sd, tb, xT, hard_conds_for(case["start"], case["goal"]), case["T"], steps, guide=guide,
                            n_guide_steps=20, t_start_guide=ceil(0.5 * case["T"]), noise_std_extra=0.5,
                            n_diffusion_steps_without_noise=1)

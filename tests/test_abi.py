@@ -1,0 +1,34 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mmd_amd.h declares (no compute without a GPU)."""
+import os
+import re
+
+from mmd_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mmd_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mmd_amd.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
+    assert lib.mmd_abi_version() == _lib.ABI_VERSION
+
+
+def test_unet_spec_matches_library():
+    from mmd_amd.unet_spec import unet_param_spec
+    import numpy as np
+    lib = _lib.load()
+    spec = unet_param_spec(4, 32, (1, 2, 4))
+    assert lib.mmd_unet_num_tensors(32, 3) == len(spec) == 148
+    for i, shape in enumerate(spec.values()):
+        assert lib.mmd_unet_tensor_numel(32, 3, i) == int(np.prod(shape))
+    assert lib.mmd_unet_num_tensors(64, 3) == -1 and b"unsupported" in lib.mmd_last_error()

@@ -154,11 +154,18 @@ CHAIN_ROWS = lambda T: sorted({0, 1, 2, T // 2, T // 2 + 1, T // 2 + 2, T - 1, T
 
 
 def run_ref_inference(env_id, T, B, start, goal, cons, seed_xT, seed_steps, weights_seed=0, cutoff=0.05,
-                      n_guide_steps=20, use_guide=True):
+                      n_guide_steps=20, use_guide=True, perturb=0.0, perturb_seed=0):
+    """`perturb` > 0 multiplies the reference UNet's output by (1 + perturb * N(0,1)) at every step: an fp32-rounding
+    sized disturbance (a different summation order) used to MEASURE how well-conditioned the reference's own map
+    noise -> trajectory is for this case (stored next to the golden rows as `sens`)."""
     sd = synth.synth_unet_state_dict(weights_seed)
     with quiet():
         model = make_model(sd, T)
         guide, robot, task, env = make_guide(env_id, MINS, MAXS, cutoff_margin=cutoff)
+    if perturb:
+        gen = torch.Generator().manual_seed(perturb_seed)
+        model.model.register_forward_hook(
+            lambda mod, inp, out: out * (1 + perturb * torch.empty(out.shape).normal_(generator=gen)))
     costs, ws = [], []
     for (q, tr, r, soft) in cons:
         costs.append(make_cost_constraint(robot, q, tr, r, soft))
@@ -176,47 +183,55 @@ def run_ref_inference(env_id, T, B, start, goal, cons, seed_xT, seed_steps, weig
     return chain.numpy()          # [T+2, B, H, D]
 
 
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def save_case(fname, meta, rows, *args, **kw):
+    chain = run_ref_inference(*args, **kw)
+    sens = np.zeros(len(rows))
+    for ps in (1, 2):
+        pert = run_ref_inference(*args, perturb=1e-6, perturb_seed=ps, **kw)
+        sens = np.maximum(sens, [rel_l2(pert[r], chain[r]) for r in rows])
+    np.savez_compressed(os.path.join(OUT, fname), rows=np.array(rows), chain_rows=chain[rows], sens=sens,
+                        meta=np.array(meta))
+    print("  ", fname, "final-row sensitivity to a 1e-6 relative UNet perturbation:", f"{sens[-1]:.2e}", flush=True)
+
+
 def g6():
     # (a) config 2 shape: Empty, 6 robots on a circle, robot 0, soft constraints from the 5 others, T=50
     starts, goals = synth.start_goal_circle(6, 0.8)
     paths = synth.straight_line_paths(starts, goals, H)
     q, tr, r = soft_points(paths, 0)
-    chain = run_ref_inference("EnvEmpty2D", 50, 8, starts[0], goals[0], [(q, tr, r, True)], 11, 12)
-    rows = CHAIN_ROWS(50)
-    np.savez_compressed(os.path.join(OUT, "g6_sample_empty_T50.npz"), rows=np.array(rows), chain_rows=chain[rows],
-                        meta=np.array([50, 8, 6, 0, 11, 12]))
+    save_case("g6_sample_empty_T50.npz", [50, 8, 6, 0, 11, 12], CHAIN_ROWS(50),
+              "EnvEmpty2D", 50, 8, starts[0], goals[0], [(q, tr, r, True)], 11, 12)
     # (b) config 3 shape: Highways, 10 robots small circle, robot 3, soft + one hard constraint, T=100
     starts, goals, soft, hard = highways_case()
-    chain = run_ref_inference("EnvHighways2D", 100, 8, starts[3], goals[3], [(*soft, True), (*hard, False)], 13, 14)
-    rows = CHAIN_ROWS(100)
-    np.savez_compressed(os.path.join(OUT, "g6_sample_highways_T100.npz"), rows=np.array(rows), chain_rows=chain[rows],
-                        meta=np.array([100, 8, 10, 3, 13, 14]))
+    save_case("g6_sample_highways_T100.npz", [100, 8, 10, 3, 13, 14], CHAIN_ROWS(100),
+              "EnvHighways2D", 100, 8, starts[3], goals[3], [(*soft, True), (*hard, False)], 13, 14)
     # (c) released-checkpoint step count: Empty, no constraints, T=25
-    chain = run_ref_inference("EnvEmpty2D", 25, 4, starts[0], goals[0], [], 15, 16)
-    rows = CHAIN_ROWS(25)
-    np.savez_compressed(os.path.join(OUT, "g6_sample_empty_T25_nocons.npz"), rows=np.array(rows),
-                        chain_rows=chain[rows], meta=np.array([25, 4, 10, 0, 15, 16]))
+    save_case("g6_sample_empty_T25_nocons.npz", [25, 4, 10, 0, 15, 16], CHAIN_ROWS(25),
+              "EnvEmpty2D", 25, 4, starts[0], goals[0], [], 15, 16)
     # (d) config 0: single robot, 1 sample, T=50
-    chain = run_ref_inference("EnvEmpty2D", 50, 1, np.array([-0.8, 0], np.float32), np.array([0.8, 0], np.float32),
-                              [], 17, 18)
-    np.savez_compressed(os.path.join(OUT, "g6_sample_cfg0_T50_B1.npz"), rows=np.arange(52), chain_rows=chain,
-                        meta=np.array([50, 1, 1, 0, 17, 18]))
+    save_case("g6_sample_cfg0_T50_B1.npz", [50, 1, 1, 0, 17, 18], list(range(52)),
+              "EnvEmpty2D", 50, 1, np.array([-0.8, 0], np.float32), np.array([0.8, 0], np.float32), [], 17, 18)
     # (e) north-star per-robot shape, short: Empty, 32 robots, robot 5, 31x63 soft points, T=25, B=4
     starts, goals = synth.start_goal_circle(32, 0.8)
     paths = synth.straight_line_paths(starts, goals, H)
     q, tr, r = soft_points(paths, 5)
-    chain = run_ref_inference("EnvEmpty2D", 25, 4, starts[5], goals[5], [(q, tr, r, True)], 19, 20)
-    rows = CHAIN_ROWS(25)
-    np.savez_compressed(os.path.join(OUT, "g6_sample_empty32_T25.npz"), rows=np.array(rows), chain_rows=chain[rows],
-                        meta=np.array([25, 4, 32, 5, 19, 20]))
+    save_case("g6_sample_empty32_T25.npz", [25, 4, 32, 5, 19, 20], CHAIN_ROWS(25),
+              "EnvEmpty2D", 25, 4, starts[5], goals[5], [(q, tr, r, True)], 19, 20)
     # (f) Conveyor map (config 5 shape, one robot's shard): 8 robots on the boundary, robot 2, T=50
     starts, goals = synth.start_goal_boundary(8)
     paths = synth.straight_line_paths(starts, goals, H)
     q, tr, r = soft_points(paths, 2)
-    chain = run_ref_inference("EnvConveyor2D", 50, 4, starts[2], goals[2], [(q, tr, r, True)], 21, 22)
-    rows = CHAIN_ROWS(50)
-    np.savez_compressed(os.path.join(OUT, "g6_sample_conveyor_T50.npz"), rows=np.array(rows), chain_rows=chain[rows],
-                        meta=np.array([50, 4, 8, 2, 21, 22]))
+    save_case("g6_sample_conveyor_T50.npz", [50, 4, 8, 2, 21, 22], CHAIN_ROWS(50),
+              "EnvConveyor2D", 50, 4, starts[2], goals[2], [(q, tr, r, True)], 21, 22)
+    # (g) prior only (planner_alg 'diffusion_prior'): no guide at all, T=100 -- the well-conditioned end-to-end case
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    save_case("g6_sample_prior_T100.npz", [100, 8, 6, 1, 29, 30], CHAIN_ROWS(100),
+              "EnvEmpty2D", 100, 8, starts[1], goals[1], [], 29, 30, use_guide=False)
 
 
 def g7():
@@ -236,13 +251,31 @@ def g7():
     seed = (seed + 0.02 * synth.synth_noise(23, (B, H, D))).astype(np.float32)
     qn = synth.synth_noise(24, (B, H, D))
     steps = synth.synth_noise(25, (4, B, H, D))
-    with quiet(), injected_noise([qn] + list(steps)) as q:
-        chain = model.run_local_inference(
-            torch.from_numpy(seed), 3, 3, None, hard_conds_for(starts[3], goals[3]), n_samples=B, horizon=H,
-            return_chain=True, sample_fn=ddpm_sample_fn, guide=guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
-            noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=1)
-        assert len(q) == 0
-    np.savez_compressed(os.path.join(OUT, "g7_local.npz"), chain=chain.numpy(), meta=np.array([T, B, 10, 3, 23, 24, 25]))
+
+    def run(perturb=0.0, ps=0):
+        handle = None
+        if perturb:
+            gen = torch.Generator().manual_seed(ps)
+            handle = model.model.register_forward_hook(
+                lambda mod, inp, out: out * (1 + perturb * torch.empty(out.shape).normal_(generator=gen)))
+        with quiet(), injected_noise([qn] + list(steps)) as q:
+            chain = model.run_local_inference(
+                torch.from_numpy(seed), 3, 3, None, hard_conds_for(starts[3], goals[3]), n_samples=B, horizon=H,
+                return_chain=True, sample_fn=ddpm_sample_fn, guide=guide, n_guide_steps=20,
+                t_start_guide=ceil(0.5 * T), noise_std_extra_schedule_fn=lambda x: 0.5,
+                n_diffusion_steps_without_noise=1)
+            assert len(q) == 0
+        if handle is not None:
+            handle.remove()
+        return chain.numpy()
+
+    chain = run()
+    sens = np.zeros(5)
+    for ps in (1, 2):
+        pert = run(1e-6, ps)
+        sens = np.maximum(sens, [rel_l2(pert[r], chain[r]) for r in range(5)])
+    print("   g7 sensitivity per row:", sens)
+    np.savez_compressed(os.path.join(OUT, "g7_local.npz"), chain=chain, sens=sens, meta=np.array([T, B, 10, 3, 23, 24, 25]))
 
 
 def g8():
