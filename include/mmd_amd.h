@@ -60,6 +60,15 @@ size_t mmd_unet_workspace_bytes(mmd_unet_t unet, int n_traj);
 int mmd_unet_forward(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj, void* workspace_dev,
                      size_t workspace_bytes, void* stream);
 
+/* Measurement hooks (bench.py): the forward is 29 kernel launches; layer i's short name, its algorithmic FLOPs per
+ * trajectory (2 * C_out * taps * C_in * L_out, fused 1x1 convs included), and a profiled forward that brackets every
+ * launch with HIP events on `stream` and returns the mean duration of each over `repeats` forwards in layer_ms[29]. */
+int mmd_unet_num_layers(void);
+const char* mmd_unet_layer_name(int i);
+double mmd_unet_layer_flops(int i);
+int mmd_unet_profile(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj, void* workspace_dev,
+                     size_t workspace_bytes, int repeats, float* layer_ms, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Guide  (replaces GuideManagerTrajectoriesWithVelocity.forward, mmd/models/diffusion_models/guides.py:180-226,
  * with the cost terms of deps/motion_planning_baselines/mp_baselines/planners/costs/cost_functions.py:149-193,

@@ -692,12 +692,32 @@ size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) {
   return (size_t)5 * ACT_FLOATS * sizeof(float) * (size_t)(n_traj > 0 ? n_traj : 0);
 }
 
-int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, void* stream) {
+static const char* const kLayerNames[29] = {
+    "D00A", "D00B", "L64A", "L64B", "DN0", "D10A", "D10B", "L32A", "L32B", "DN1", "D20A", "D20B", "L16A", "L16B",
+    "L16A", "L16B", "L16A", "L16B", "U00A", "U00B", "U01A", "U01B", "UP0", "U10A", "U10B", "U11A", "U11B", "UP1", "FIN"};
+
+// algorithmic FLOPs per trajectory of each launch: 2 * C_out * taps * C_in * L_out (+ the fused 1x1 convs)
+static const double kLayerFlops[29] = {
+    2.0 * 32 * 5 * 4 * 64,  2.0 * 32 * 5 * 32 * 64 + 2.0 * 32 * 4 * 64,  2.0 * 32 * 5 * 32 * 64, 2.0 * 32 * 5 * 32 * 64,
+    2.0 * 32 * 3 * 32 * 32,
+    2.0 * 64 * 5 * 32 * 32, 2.0 * 64 * 5 * 64 * 32 + 2.0 * 64 * 32 * 32, 2.0 * 64 * 5 * 64 * 32, 2.0 * 64 * 5 * 64 * 32,
+    2.0 * 64 * 3 * 64 * 16,
+    2.0 * 128 * 5 * 64 * 16, 2.0 * 128 * 5 * 128 * 16 + 2.0 * 128 * 64 * 16, 2.0 * 128 * 5 * 128 * 16, 2.0 * 128 * 5 * 128 * 16,
+    2.0 * 128 * 5 * 128 * 16, 2.0 * 128 * 5 * 128 * 16, 2.0 * 128 * 5 * 128 * 16, 2.0 * 128 * 5 * 128 * 16,
+    2.0 * 64 * 5 * 256 * 16, 2.0 * 64 * 5 * 64 * 16 + 2.0 * 64 * 256 * 16, 2.0 * 64 * 5 * 64 * 16, 2.0 * 64 * 5 * 64 * 16,
+    2.0 * 64 * 4 * 64 * 16,
+    2.0 * 32 * 5 * 128 * 32, 2.0 * 32 * 5 * 32 * 32 + 2.0 * 32 * 128 * 32, 2.0 * 32 * 5 * 32 * 32, 2.0 * 32 * 5 * 32 * 32,
+    2.0 * 32 * 4 * 32 * 32,
+    2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64};
+
+static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
+                             hipStream_t st, hipEvent_t* ev) {
   MMD_REQUIRE(u && x && eps && ws, "mmd_unet_forward: NULL argument");
   MMD_REQUIRE(n >= 1, "mmd_unet_forward: n_traj must be >= 1");
   MMD_REQUIRE(t >= 0 && t < u->T, "mmd_unet_forward: t=%d outside [0,%d)", t, u->T);
   MMD_REQUIRE(ws_bytes >= mmd_unet_workspace_bytes(u, n), "mmd_unet_forward: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
+  int li = 0;
+#define MMD_MARK() do { if (ev) (void)hipEventRecord(ev[li], st); ++li; } while (0)
   float* Hb = (float*)ws;
   float* P0 = Hb + (size_t)n * ACT_FLOATS;
   float* P1 = P0 + (size_t)n * ACT_FLOATS;
@@ -705,47 +725,108 @@ int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, voi
   float* S2 = S1 + (size_t)n * ACT_FLOATS;
   const RtbW* R = u->rtb;
   // downs.0 @ L=64
+  MMD_MARK();
   launch<D00A>(args_a(u, R[0], x, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<D00B>(args_b(u, R[0], Hb, x, nullptr, P0, n), st);
+  MMD_MARK();
   launch<L64A>(args_a(u, R[1], P0, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<L64B>(args_b(u, R[1], Hb, P0, nullptr, P1, n), st);
+  MMD_MARK();
   launch<DN0>(args_plain(u, u->down[0], P1, P0, n), st);
   // downs.1 @ L=32
+  MMD_MARK();
   launch<D10A>(args_a(u, R[2], P0, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<D10B>(args_b(u, R[2], Hb, P0, nullptr, P1, n), st);
+  MMD_MARK();
   launch<L32A>(args_a(u, R[3], P1, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<L32B>(args_b(u, R[3], Hb, P1, nullptr, S1, n), st);
+  MMD_MARK();
   launch<DN1>(args_plain(u, u->down[1], S1, P0, n), st);
   // downs.2 @ L=16
+  MMD_MARK();
   launch<D20A>(args_a(u, R[4], P0, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<D20B>(args_b(u, R[4], Hb, P0, nullptr, P1, n), st);
+  MMD_MARK();
   launch<L16A>(args_a(u, R[5], P1, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<L16B>(args_b(u, R[5], Hb, P1, nullptr, S2, n), st);
   // mid
+  MMD_MARK();
   launch<L16A>(args_a(u, R[10], S2, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<L16B>(args_b(u, R[10], Hb, S2, nullptr, P0, n), st);
+  MMD_MARK();
   launch<L16A>(args_a(u, R[11], P0, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<L16B>(args_b(u, R[11], Hb, P0, nullptr, P1, n), st);
   // ups.0 @ L=16: cat(x, skip2)
+  MMD_MARK();
   launch<U00A>(args_a(u, R[6], P1, S2, Hb, t, n), st);
+  MMD_MARK();
   launch<U00B>(args_b(u, R[6], Hb, P1, S2, P0, n), st);
+  MMD_MARK();
   launch<U01A>(args_a(u, R[7], P0, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<U01B>(args_b(u, R[7], Hb, P0, nullptr, P1, n), st);
+  MMD_MARK();
   launch<UP0>(args_plain(u, u->up[0], P1, P0, n), st);
   // ups.1 @ L=32: cat(x, skip1)
+  MMD_MARK();
   launch<U10A>(args_a(u, R[8], P0, S1, Hb, t, n), st);
+  MMD_MARK();
   launch<U10B>(args_b(u, R[8], Hb, P0, S1, P1, n), st);
+  MMD_MARK();
   launch<U11A>(args_a(u, R[9], P1, nullptr, Hb, t, n), st);
+  MMD_MARK();
   launch<U11B>(args_b(u, R[9], Hb, P1, nullptr, P0, n), st);
+  MMD_MARK();
   launch<UP1>(args_plain(u, u->up[1], P0, P1, n), st);
   // final_conv
   ConvArgs f = args_plain(u, u->fin, P1, eps, n);
   f.gamma = u->blob + u->fin.gamma; f.beta = u->blob + u->fin.beta;
   f.res_wpk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
   f.res_bias = u->blob + u->fin_b1;
+  MMD_MARK();
   launch<FIN>(f, st);
+  MMD_MARK();
+#undef MMD_MARK
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, void* stream) {
+  return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, (hipStream_t)stream, nullptr);
+}
+
+int mmd_unet_num_layers(void) { return 29; }
+const char* mmd_unet_layer_name(int i) { return i >= 0 && i < 29 ? kLayerNames[i] : ""; }
+double mmd_unet_layer_flops(int i) { return i >= 0 && i < 29 ? kLayerFlops[i] : 0.0; }
+
+int mmd_unet_profile(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, int repeats,
+                     float* layer_ms, void* stream) {
+  MMD_REQUIRE(layer_ms && repeats >= 1, "mmd_unet_profile: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t ev[30];
+  for (auto& e : ev) MMD_HIP_CHECK(hipEventCreate(&e));
+  for (int i = 0; i < 29; ++i) layer_ms[i] = 0.f;
+  int rc = 0;
+  for (int r = 0; r < repeats && rc == 0; ++r) {
+    rc = unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, st, ev);
+    if (rc) break;
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("mmd_unet_profile: sync failed"); rc = 1; break; }
+    for (int i = 0; i < 29; ++i) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      layer_ms[i] += ms / (float)repeats;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
 }
 
 }  // extern "C"
