@@ -149,6 +149,9 @@ typedef struct mmd_sampler_desc {
   int32_t t_start_guide;                    /* guide iff loop index i < t_start_guide (sample_functions.py:63) */
   float noise_std_extra;                    /* 0.5 (mpd.py:303) */
   int32_t hard_mask;                        /* as in mmd_guide_steps */
+  int32_t n_streams;                        /* mmd_p_sample_loop splits the robots into this many concurrent HIP
+                                             * streams (forked from / joined to `stream`) so one chunk's staging and
+                                             * epilogues overlap the other's MFMA phases; 0 = auto, 1 = off */
 } mmd_sampler_desc;
 
 /* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop (UNet activations + the eps buffer). */

@@ -31,7 +31,7 @@ class SamplerDesc(C.Structure):
         ("posterior_mean_coef2", C.POINTER(C.c_float)),
         ("posterior_log_variance_clipped", C.POINTER(C.c_float)),
         ("n_guide_steps", C.c_int32), ("t_start_guide", C.c_int32),
-        ("noise_std_extra", C.c_float), ("hard_mask", C.c_int32),
+        ("noise_std_extra", C.c_float), ("hard_mask", C.c_int32), ("n_streams", C.c_int32),
     ]
 
 

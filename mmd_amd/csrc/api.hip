@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/mmd_amd.h"
 #include "common.h"
@@ -24,6 +25,29 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+constexpr int kMaxChunks = 4;
+
+// side streams of the chunked sampling loop: created once per process, never destroyed
+struct Streams {
+  hipStream_t s[kMaxChunks] = {};
+  hipEvent_t fork = nullptr, join[kMaxChunks] = {};
+  bool tried = false, good = false;
+  bool ok() {
+    if (!tried) {
+      tried = true;
+      good = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+      for (int c = 0; c < kMaxChunks && good; ++c)
+        good = hipStreamCreateWithFlags(&s[c], hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&join[c], hipEventDisableTiming) == hipSuccess;
+    }
+    return good;
+  }
+};
+static Streams& streams() {
+  static thread_local Streams S;   // streams belong to the calling thread's current device
+  return S;
 }
 
 static int make_step(const mmd_sampler_desc* s, int i, bool guided, StepDev& sd) {
@@ -73,7 +97,7 @@ int mmd_ddpm_step(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_de
   if (sd.do_guide)
     if (int rc = fill_guide(guide, g)) return rc;
   if (int rc = mmd_unet_forward(unet, x_dev, i < 0 ? 0 : i, eps, n, workspace_dev, uws, stream)) return rc;
-  launch_step(g, sd, x_dev, eps, noise_dev, nullptr, hard_dev, n, samples_per_robot, st);
+  launch_step(g, sd, x_dev, eps, noise_dev, nullptr, hard_dev, 0, n, samples_per_robot, st);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -88,22 +112,66 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   MMD_REQUIRE(n_steps >= 0 && n_steps <= s->n_diffusion_steps && n_steps_without_noise >= 0, "bad step counts");
   MMD_REQUIRE(workspace_bytes >= mmd_sampler_workspace_bytes(unet, n), "mmd_p_sample_loop: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const size_t uws = mmd_unet_workspace_bytes(unet, n);
-  float* eps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace_dev) + uws);
   const size_t traj_floats = (size_t)n * H * D;
   GuideDev g{};
   if (guide)
     if (int rc = fill_guide(guide, g)) return rc;
   launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed, n, samples_per_robot, st);
+
+  // Split the robots into concurrent chunks: each chunk's kernels go to its own stream, launches interleaved layer by
+  // layer so both queues stay fed.  Robots are independent, so results are bit-identical to the unsplit run.
+  int nch = s->n_streams;
+  if (const char* e = getenv("MMD_AMD_STREAMS")) nch = atoi(e);
+  if (nch <= 0) nch = n >= 1024 ? 2 : 1;
+  if (nch > kMaxChunks) nch = kMaxChunks;
+  if (nch > n_robots) nch = n_robots;
+  Streams& S = streams();
+  if (nch > 1 && !S.ok()) nch = 1;
+  hipStream_t cs[kMaxChunks];
+  int r0[kMaxChunks + 1];
+  char* wsp[kMaxChunks];
+  size_t wsb[kMaxChunks];
+  float* epsp[kMaxChunks];
+  {
+    char* w = reinterpret_cast<char*>(workspace_dev);
+    for (int c = 0; c <= nch; ++c) r0[c] = (int)((long long)n_robots * c / nch);
+    for (int c = 0; c < nch; ++c) {
+      const int nc = (r0[c + 1] - r0[c]) * samples_per_robot;
+      wsp[c] = w;
+      wsb[c] = mmd_unet_workspace_bytes(unet, nc);
+      epsp[c] = reinterpret_cast<float*>(w + wsb[c]);
+      w += mmd_sampler_workspace_bytes(unet, nc);
+      cs[c] = nch == 1 ? st : S.s[c];
+    }
+  }
+  if (nch > 1) {
+    MMD_HIP_CHECK(hipEventRecord(S.fork, st));
+    for (int c = 0; c < nch; ++c) MMD_HIP_CHECK(hipStreamWaitEvent(cs[c], S.fork, 0));
+  }
   int k = 0;
   for (int i = n_steps - 1; i >= -n_steps_without_noise; --i, ++k) {
     StepDev sd{};
     if (int rc = make_step(s, i, guide != nullptr, sd)) return rc;
     sd.seed = seed; sd.draw = (unsigned int)k;
-    if (int rc = mmd_unet_forward(unet, x_dev, i < 0 ? 0 : i, eps, n, workspace_dev, uws, stream)) return rc;
-    launch_step(g, sd, x_dev, eps, step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr,
-                chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr, hard_dev, n, samples_per_robot, st);
+    for (int c = 0; c < nch; ++c) {
+      const int t0 = r0[c] * samples_per_robot, nc = (r0[c + 1] - r0[c]) * samples_per_robot;
+      if (int rc = mmd_unet_forward(unet, x_dev + (size_t)t0 * H * D, i < 0 ? 0 : i, epsp[c], nc, wsp[c], wsb[c], cs[c]))
+        return rc;
+    }
+    for (int c = 0; c < nch; ++c) {
+      const int t0 = r0[c] * samples_per_robot, nc = (r0[c + 1] - r0[c]) * samples_per_robot;
+      // eps of this chunk is indexed from its own buffer: pass a pointer rebased to the full-array indexing
+      launch_step(g, sd, x_dev, epsp[c] - (size_t)t0 * H * D,
+                  step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr,
+                  chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr, hard_dev, t0, nc, samples_per_robot,
+                  cs[c]);
+    }
   }
+  if (nch > 1)
+    for (int c = 0; c < nch; ++c) {
+      MMD_HIP_CHECK(hipEventRecord(S.join[c], cs[c]));
+      MMD_HIP_CHECK(hipStreamWaitEvent(st, S.join[c], 0));
+    }
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -148,11 +148,11 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
 __global__ __launch_bounds__(256) void ddpm_guide_kernel(GuideDev g, StepDev s, float4* __restrict__ x,
                                                          const float4* __restrict__ eps,
                                                          const float4* __restrict__ noise, float4* __restrict__ chain,
-                                                         const float4* __restrict__ hard, int n_traj,
+                                                         const float4* __restrict__ hard,
                                                          int samples_per_robot) {
   const int t = threadIdx.x & 63;
-  const int traj = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (traj >= n_traj) return;
+  const int traj = s.traj0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (traj >= s.traj_end) return;
   const int robot = traj / samples_per_robot;
   const size_t idx = (size_t)traj * H + t;
   float4 v = x[idx];
@@ -286,10 +286,12 @@ int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
   return 0;
 }
 
-int launch_step(const GuideDev& g, const StepDev& s, float* x, const float* eps, const float* noise, float* chain,
-                const float* hard, int n_traj, int spr, hipStream_t st) {
+int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
+                const float* hard, int traj0, int n_traj, int spr, hipStream_t st) {
+  s.traj0 = traj0;
+  s.traj_end = traj0 + n_traj;
   hipLaunchKernelGGL(ddpm_guide_kernel, dim3((n_traj + 3) / 4), dim3(256), 0, st, g, s, (float4*)x, (const float4*)eps,
-                     (const float4*)noise, (float4*)chain, (const float4*)hard, n_traj, spr);
+                     (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
   return 0;
 }
 
@@ -365,7 +367,7 @@ int mmd_guide_steps(const mmd_guide_desc* d, float* x_dev, const float* hard_dev
   if (int rc = fill_guide(d, g)) return rc;
   StepDev s{};
   s.do_guide = 1; s.n_guide_steps = n_steps; s.hard_mask = hard_mask;
-  launch_step(g, s, x_dev, nullptr, nullptr, nullptr, hard_dev, n_robots * samples_per_robot, samples_per_robot,
+  launch_step(g, s, x_dev, nullptr, nullptr, nullptr, hard_dev, 0, n_robots * samples_per_robot, samples_per_robot,
               (hipStream_t)stream);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;

@@ -31,11 +31,12 @@ struct StepDev {
   int hard_mask;
   unsigned long long seed;
   unsigned int draw;
+  int traj0, traj_end;               // this launch covers trajectories [traj0, traj_end) of the full arrays
 };
 
 int fill_guide(const mmd_guide_desc* d, GuideDev& g);
-int launch_step(const GuideDev& g, const StepDev& s, float* x, const float* eps, const float* noise, float* chain,
-                const float* hard, int n_traj, int spr, hipStream_t st);
+int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
+                const float* hard, int traj0, int n_traj, int spr, hipStream_t st);
 int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed, int n_traj,
                 int spr, hipStream_t st);
 

@@ -134,29 +134,53 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
 
 // acc[mt] += A(slab rows, taps x CP channels) * B(packed).  abase[mt] is the lane's slab offset of (row, k=lane>>5)
 // for tap 0; tap t reads STR floats further.  wp points at this lane's float4 of the first k-group.
+// B fragments are prefetched FOUR k-groups (32 MFMAs = 2048 cycles) ahead through a 4-register ring so the L2
+// latency of a weight fetch never sits in front of the MFMA that consumes it; pack_b pads every packed tensor with 4
+// zero groups so the ring may over-read unconditionally.
+template <int MT_W>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W], int aoff,
+                                           const float4 b) {
+  const float bq[4] = {b.x, b.y, b.z, b.w};
+  float a[4][MT_W];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) a[q][mt] = slab[abase[mt] + aoff + q * 2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][mt], bq[q], acc[mt], 0, 0, 0);
+}
+
 template <int NTAPS, int CP, int STR, int MT_W>
 __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W],
                                           const float4* __restrict__ wp) {
   constexpr int GPT = CP / 8;   // k-groups (of 4 k-pairs) per tap
-  float4 bnext = wp[0];
+  if constexpr (GPT % 4 != 0) {
+    // tiny K (the 4-channel input layer, padded to 8): everything in flight at once
+    float4 b[NTAPS * GPT];
 #pragma unroll
-  for (int tap = 0; tap < NTAPS; ++tap) {
-#pragma unroll 4
-    for (int cg = 0; cg < GPT; ++cg) {
-      const float4 b = bnext;
-      const int g = tap * GPT + cg;
-      if (g + 1 < NTAPS * GPT) bnext = wp[(size_t)(g + 1) * 64];
-      const float bq[4] = {b.x, b.y, b.z, b.w};
-      float a[4][MT_W];
+    for (int g = 0; g < NTAPS * GPT; ++g) b[g] = wp[(size_t)g * 64];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+    for (int g = 0; g < NTAPS * GPT; ++g) mfma_group<MT_W>(acc, slab, abase, (g / GPT) * STR + (g % GPT) * 8, b[g]);
+  } else {
+    const float4* p = wp;
+    float4 b0 = p[0], b1 = p[64], b2 = p[128], b3 = p[192];
 #pragma unroll
-        for (int mt = 0; mt < MT_W; ++mt) a[q][mt] = slab[abase[mt] + tap * STR + cg * 8 + q * 2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int mt = 0; mt < MT_W; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][mt], bq[q], acc[mt], 0, 0, 0);
+    for (int tap = 0; tap < NTAPS; ++tap) {
+#pragma unroll 1
+      for (int cg = 0; cg < GPT; cg += 4) {
+        p += 256;
+        const int aoff = tap * STR + cg * 8;
+        mfma_group<MT_W>(acc, slab, abase, aoff, b0);
+        b0 = p[0];
+        mfma_group<MT_W>(acc, slab, abase, aoff + 8, b1);
+        b1 = p[64];
+        mfma_group<MT_W>(acc, slab, abase, aoff + 16, b2);
+        b2 = p[128];
+        mfma_group<MT_W>(acc, slab, abase, aoff + 24, b3);
+        b3 = p[192];
+      }
     }
   }
 }
@@ -222,9 +246,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   const int col = wn * 32 + (lane & 31);
   const int hi = lane >> 5;
 
-  stage_slab<CF::C0, CF::C1, CF::CINP, CF::LIN, CF::SROWS, 2, CF::SSTR, CF::SPB>(slab, a.in0, a.in1, n0, a.n);
-  if constexpr (CF::RES == RES_CONV)
-    stage_slab<CF::RC0, CF::RC1, CF::RCP, CF::LIN, CF::LIN, 0, CF::RSTR, CF::SPB>(rslab, a.res0, a.res1, n0, a.n);
+#ifndef MMD_ABL
+#define MMD_ABL 0   // ablation builds only (tools/ablate.sh): 1 = no epilogue, 2 = no staging, 3 = no MFMA loop
+#endif
+  if (MMD_ABL != 2) {
+    stage_slab<CF::C0, CF::C1, CF::CINP, CF::LIN, CF::SROWS, 2, CF::SSTR, CF::SPB>(slab, a.in0, a.in1, n0, a.n);
+    if constexpr (CF::RES == RES_CONV)
+      stage_slab<CF::RC0, CF::RC1, CF::RCP, CF::LIN, CF::LIN, 0, CF::RSTR, CF::SPB>(rslab, a.res0, a.res1, n0, a.n);
+  }
   __syncthreads();
 
   // this lane's A rows: tile row i = lane&31 of m-tile mt  ->  (sample, position)
@@ -255,10 +284,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < CF::MT_W; ++mt)
       abase[mt] = (srow[mt] * CF::SROWS + lrow[mt] * RSTEP + roff) * CF::SSTR + hi;
-    const float4* wp = a.wpk + ((size_t)(pass * CF::WN + wn) * G) * 64 + lane;
-    mfma_taps<CF::NTAPS, CF::CINP, CF::SSTR, CF::MT_W>(acc, slab, abase, wp);
+    // UP: the two parity packs are separate pack_b() outputs, each padded with 4 groups
+    const float4* wp = a.wpk + ((size_t)pass * (CF::WN * G + 4) + (size_t)wn * G) * 64 + lane;
+    if (MMD_ABL != 3) mfma_taps<CF::NTAPS, CF::CINP, CF::SSTR, CF::MT_W>(acc, slab, abase, wp);
 
-    if constexpr (CF::EPI != EPI_PLAIN) gn_mish<CF::COUT, CF::LROWS, CF::MT_W>(acc, a.gamma[col], a.beta[col]);
+    if constexpr (CF::EPI != EPI_PLAIN && MMD_ABL != 1) gn_mish<CF::COUT, CF::LROWS, CF::MT_W>(acc, a.gamma[col], a.beta[col]);
 
     if constexpr (CF::EPI == EPI_GN_TB) {
       const float tb = a.tbias[col];
@@ -463,7 +493,7 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin, 
   const int K = (int)taps.size() * cinp;
   const int G = K / 8;
   const size_t base = blob.size();
-  blob.resize(base + (size_t)nt_n * G * 64 * 4, 0.f);
+  blob.resize(base + ((size_t)nt_n * G + 4) * 64 * 4, 0.f);   // + 4 zero groups: prefetch-ring over-read
   for (int nt = 0; nt < nt_n; ++nt)
     for (int g = 0; g < G; ++g)
       for (int lane = 0; lane < 64; ++lane)

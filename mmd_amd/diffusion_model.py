@@ -56,7 +56,7 @@ class GaussianDiffusionModel:
         self.model(x, 1, context=None)
 
     # ---- descriptors ------------------------------------------------------------------------------------------
-    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_std_extra, hard_mask):
+    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_std_extra, hard_mask, n_streams=0):
         s = _lib.SamplerDesc()
         s.n_diffusion_steps = self.n_diffusion_steps
         fp = C.POINTER(C.c_float)
@@ -68,6 +68,7 @@ class GaussianDiffusionModel:
         s.t_start_guide = int(min(tsg, 2 ** 30)) if tsg != float("inf") else 2 ** 30
         s.noise_std_extra = float(noise_std_extra)
         s.hard_mask = hard_mask
+        s.n_streams = int(n_streams)
         return s
 
     @staticmethod
@@ -96,7 +97,7 @@ class GaussianDiffusionModel:
     def p_sample_loop(self, shape, hard_conds, n_diffusion_steps, context=None, return_chain=False,
                       sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0, warm_start_path_b=None,
                       guide=None, n_guide_steps=1, t_start_guide=float("inf"), noise_std_extra_schedule_fn=None,
-                      n_robots=1, step_noise=None, seed=None, device="cuda", **sample_kwargs):
+                      n_robots=1, step_noise=None, seed=None, device="cuda", n_streams=0, **sample_kwargs):
         """diffusion_model_base.py:162-211.  Extensions: `n_robots` (batch = n_robots * n_samples, robot-major),
         `step_noise` [n_steps_total, B, H, D] + `warm_start_path_b` as x_T to inject every Gaussian draw (parity
         tests), `seed` for the in-kernel Philox stream otherwise."""
@@ -111,7 +112,7 @@ class GaussianDiffusionModel:
         lib = _lib.load()
         noise_std = 1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(0))
         hard, mask = self._hard_tensor(hard_conds, n_robots, H, device, D)
-        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std, mask)
+        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std, mask, n_streams)
         n_total = n_diffusion_steps + n_diffusion_steps_without_noise
         if warm_start_path_b is not None:
             x = warm_start_path_b.to(device=device, dtype=torch.float32).contiguous().clone()

@@ -211,6 +211,26 @@ def test_multi_robot_batch_equals_per_robot():
         assert torch.equal(out[r * B:(r + 1) * B], o1), r
 
 
+def test_stream_chunking_is_bit_identical():
+    """mmd_p_sample_loop split over 2 / 3 concurrent HIP streams == the single-stream run, bit for bit (Philox path,
+    so the in-kernel noise indexing is covered too)."""
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    T, B, R = 25, 8, 5
+    starts, goals = synth.start_goal_circle(R, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    model = _gc().hip_model(T)
+    hc_all = {0: torch.stack([cases.hard_conds_for(starts[r], goals[r])[0] for r in range(R)]),
+              H - 1: torch.stack([cases.hard_conds_for(starts[r], goals[r])[H - 1] for r in range(R)])}
+    guide = _gc().hip_guide("EnvHighways2D", [[cases.soft_group(paths, r)] for r in range(R)], n_robots=R)
+    kw = dict(horizon=H, return_chain=True, sample_fn=ddpm_sample_fn, n_guide_steps=20, t_start_guide=13,
+              noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=1, guide=guide, seed=77,
+              n_samples=B, n_robots=R)
+    ref = model.run_inference(None, hc_all, n_streams=1, **kw)
+    for ns in (2, 3):
+        out = model.run_inference(None, hc_all, n_streams=ns, **kw)
+        assert torch.equal(out, ref), ns
+
+
 def test_philox_noise_statistics():
     """Production path: in-kernel Philox draws (no injected noise) are N(0,1) and reproducible per seed."""
     model = _gc().hip_model(25)
