@@ -31,7 +31,7 @@ import torch         # noqa: E402
 
 H, D = 64, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
-DOMINANT_LAYER = "L16A"            # Conv1d(128->128,k5)@L16 + GroupNorm + Mish + time bias: 4 of the 29 launches
+DOMINANT_LAYER = "R_L16"           # fused ResidualTemporalBlock 128->128 @ L16 (2 x conv5 + GN + Mish): 4 of the 17 launches
 
 
 def parse():
@@ -157,7 +157,7 @@ def main():
     dom_tf = flops[dom[0]] / (dom_ms * 1e-3) / 1e12
     fwd_ms = float(sum(ms))
     fwd_tf = sum(flops) / (fwd_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": f"conv_kernel<{DOMINANT_LAYER}> Conv1d(128->128,k5,L16)+GN+Mish",
+    roofline = {"bound": "mfma", "kernel": f"rtb_kernel<{DOMINANT_LAYER}> fused ResidualTemporalBlock(128->128, L=16): 2x[Conv1d k5 + GroupNorm + Mish] + time bias + residual",
                 "achieved": dom_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": None, "launch_ms": dom_ms, "flops_per_launch": flops[dom[0]],
                 "unet_forward": {"ms": fwd_ms, "achieved": fwd_tf, "frac": fwd_tf / PEAK_FP32_MFMA_TFLOPS,

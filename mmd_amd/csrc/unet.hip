@@ -366,6 +366,140 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// Fused ResidualTemporalBlock (layers.py:346-358): out = Mish(GN(conv5(Mish(GN(conv5(x))) + tbias))) + res(x) in ONE
+// launch.  h never leaves the CU: conv A's epilogue writes it (from the MFMA accumulators) into an LDS slab that conv
+// B reads.  For identity residuals (C_in == C_out) h overwrites the x slab (x is re-read from global for the final
+// add); for 1x1-conv residuals the x slab is kept and feeds a third MFMA pass.
+// ----------------------------------------------------------------------------------------------------------------
+struct RtbArgs {
+  const float* in0; const float* in1;   // [n, L, C0], [n, L, C1]
+  float* out;                            // [n, L, COUT]
+  const float4* wa; const float* ba; const float* ga; const float* bea; const float* tbias;
+  const float4* wb; const float* bb; const float* gb; const float* beb;
+  const float4* wr; const float* br;     // residual 1x1 conv (RES_CONV)
+  int n;
+};
+
+template <int C0_, int C1_, int COUT_, int L_, int MT_W_, int RES_>
+struct RtbCfg {
+  static constexpr int C0 = C0_, C1 = C1_, COUT = COUT_, L = L_, MT_W = MT_W_, RES = RES_;
+  static constexpr int CIN = C0 + C1;
+  static constexpr int CINP = (CIN + 7) / 8 * 8;
+  static constexpr int XSTR = CINP + 1, HSTR = COUT + 1;
+  static constexpr int WN = COUT / 32, WM = 4 / WN;
+  static constexpr int RW = 32 * MT_W, SW = RW / L, SPB = WM * SW;
+  static constexpr int SROWS = L + 4;
+  static constexpr int XSLAB = SPB * SROWS * XSTR, HSLAB = SPB * SROWS * HSTR;
+  static constexpr bool SHARE = RES == RES_IDENT;          // h overwrites x
+  static constexpr int LDS_FLOATS = SHARE ? XSLAB : XSLAB + HSLAB;
+  static_assert(!SHARE || CIN == COUT, "identity residual needs C_in == C_out");
+  static_assert(COUT % 32 == 0 && RW % L == 0 && L >= 16, "tile shape");
+};
+
+template <class CF>
+__global__ __launch_bounds__(256) void rtb_kernel(RtbArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[CF::LDS_FLOATS];
+  float* xslab = lds;
+  float* hslab = CF::SHARE ? lds : lds + CF::XSLAB;
+#ifdef MMD_PRIO
+  // Co-resident workgroups start in lockstep (same code, same start time), so their MFMA phases collide and their
+  // epilogues leave the matrix pipe idle together.  Giving every other "wave" of workgroups (blocks b and b + 256 share
+  // a CU under the observed round-robin placement; only speed depends on it) a higher issue priority staggers them.
+  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(MMD_PRIO);
+#endif
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / CF::WN, wn = wave % CF::WN;
+  const int n0 = blockIdx.x * CF::SPB;
+  const int col = wn * 32 + (lane & 31);
+  const int hi = lane >> 5;
+
+  stage_slab<CF::C0, CF::C1, CF::CINP, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB>(xslab, a.in0, a.in1, n0, a.n);
+  if constexpr (!CF::SHARE) {   // zero the halo rows of the h slab
+    constexpr int TOT = CF::SPB * 4 * CF::COUT;
+    for (int idx = threadIdx.x; idx < TOT; idx += 256) {
+      const int c = idx % CF::COUT, hr = (idx / CF::COUT) % 4, s = idx / (CF::COUT * 4);
+      hslab[(s * CF::SROWS + (hr < 2 ? hr : CF::L + hr)) * CF::HSTR + c] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  int srow[CF::MT_W], lrow[CF::MT_W];
+#pragma unroll
+  for (int mt = 0; mt < CF::MT_W; ++mt) {
+    const int r = mt * 32 + (lane & 31);
+    srow[mt] = wm * CF::SW + r / CF::L;
+    lrow[mt] = r % CF::L;
+  }
+
+  f32x16 acc[CF::MT_W];
+  // ---- block 0: conv5(x) -> GN -> Mish -> + time bias --------------------------------------------------------
+  {
+    const float bias = a.ba[col];
+#pragma unroll
+    for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = bias;
+    int abase[CF::MT_W];
+#pragma unroll
+    for (int mt = 0; mt < CF::MT_W; ++mt) abase[mt] = (srow[mt] * CF::SROWS + lrow[mt]) * CF::XSTR + hi;
+    constexpr int G = 5 * CF::CINP / 8;
+    mfma_taps<5, CF::CINP, CF::XSTR, CF::MT_W>(acc, xslab, abase, a.wa + ((size_t)wn * G) * 64 + lane);
+    gn_mish<CF::COUT, CF::L, CF::MT_W>(acc, a.ga[col], a.bea[col]);
+    const float tb = a.tbias[col];
+    if constexpr (CF::SHARE) __syncthreads();   // every wave is done reading x before h overwrites it
+#pragma unroll
+    for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
+        hslab[(s * CF::SROWS + l + 2) * CF::HSTR + col] = acc[mt][r] + tb;
+      }
+    __syncthreads();
+  }
+  // ---- block 1: conv5(h) -> GN -> Mish -> + residual ----------------------------------------------------------
+  {
+    const float bias = a.bb[col];
+#pragma unroll
+    for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = bias;
+    int abase[CF::MT_W];
+#pragma unroll
+    for (int mt = 0; mt < CF::MT_W; ++mt) abase[mt] = (srow[mt] * CF::SROWS + lrow[mt]) * CF::HSTR + hi;
+    constexpr int G = 5 * CF::COUT / 8;
+    mfma_taps<5, CF::COUT, CF::HSTR, CF::MT_W>(acc, hslab, abase, a.wb + ((size_t)wn * G) * 64 + lane);
+    gn_mish<CF::COUT, CF::L, CF::MT_W>(acc, a.gb[col], a.beb[col]);
+    if constexpr (CF::RES == RES_CONV) {
+      const float rb = a.br[col];
+#pragma unroll
+      for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] += rb;
+      int rbase[CF::MT_W];
+#pragma unroll
+      for (int mt = 0; mt < CF::MT_W; ++mt) rbase[mt] = (srow[mt] * CF::SROWS + lrow[mt] + 2) * CF::XSTR + hi;
+      mfma_taps<1, CF::CINP, CF::XSTR, CF::MT_W>(acc, xslab, rbase, a.wr + ((size_t)wn * (CF::CINP / 8)) * 64 + lane);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < CF::MT_W; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
+      if (n0 + s < a.n) {
+        const size_t o = ((size_t)(n0 + s) * CF::L + l) * CF::COUT + col;
+        float v = acc[mt][r];
+        if constexpr (CF::RES == RES_IDENT) v += a.in0[o];
+        a.out[o] = v;
+      }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // time embedding table: TimeEncoder (layers.py:232-258) + every block's cond_mlp (layers.py:337-341) for all integer t
 // ----------------------------------------------------------------------------------------------------------------
 struct TimeArgs {
@@ -570,6 +704,38 @@ using U11B = Cfg<32, 0, 32, 32, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
 using UP1 = Cfg<32, 0, 32, 32, MODE_UP, 1, EPI_PLAIN, RES_NONE, 0, 0>;
 using FIN = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_FINAL, RES_NONE, 0, 0>;
 
+//                  C0   C1  COUT  L  MT_W RES
+using R_D00 = RtbCfg<4, 0, 32, 64, 2, RES_CONV>;
+using R_D01 = RtbCfg<32, 0, 32, 64, 2, RES_IDENT>;
+using R_D10 = RtbCfg<32, 0, 64, 32, 2, RES_CONV>;
+using R_D11 = RtbCfg<64, 0, 64, 32, 2, RES_IDENT>;
+using R_D20 = RtbCfg<64, 0, 128, 16, 2, RES_CONV>;
+using R_L16 = RtbCfg<128, 0, 128, 16, 2, RES_IDENT>;
+using R_U00 = RtbCfg<128, 128, 64, 16, 1, RES_CONV>;
+using R_U01 = RtbCfg<64, 0, 64, 16, 2, RES_IDENT>;
+using R_U10 = RtbCfg<64, 64, 32, 32, 1, RES_CONV>;
+using R_U11 = RtbCfg<32, 0, 32, 32, 2, RES_IDENT>;
+
+template <class CF>
+static int launch_rtb(const RtbArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(rtb_kernel<CF>, dim3((a.n + CF::SPB - 1) / CF::SPB), dim3(256), 0, st, a);
+  return 0;
+}
+
+static RtbArgs args_rtb(const mmd_unet_s* u, const RtbW& w, const float* in0, const float* in1, float* out, int t, int n) {
+  RtbArgs a{};
+  a.in0 = in0; a.in1 = in1; a.out = out;
+  a.wa = reinterpret_cast<const float4*>(u->blob + w.a.wpk);
+  a.ba = u->blob + w.a.bias; a.ga = u->blob + w.a.gamma; a.bea = u->blob + w.a.beta;
+  a.tbias = u->ttable + (size_t)t * u->tb_total + w.tb_off;
+  a.wb = reinterpret_cast<const float4*>(u->blob + w.b.wpk);
+  a.bb = u->blob + w.b.bias; a.gb = u->blob + w.b.gamma; a.beb = u->blob + w.b.beta;
+  a.wr = reinterpret_cast<const float4*>(u->blob + w.res_wpk);
+  a.br = u->blob + w.res_bias;
+  a.n = n;
+  return a;
+}
+
 static ConvArgs args_a(const mmd_unet_s* u, const RtbW& w, const float* in0, const float* in1, float* out, int t, int n) {
   ConvArgs a{};
   a.in0 = in0; a.in1 = in1; a.out = out;
@@ -719,142 +885,102 @@ int mmd_unet_destroy(mmd_unet_t u) {
 }
 
 size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) {
-  return (size_t)5 * ACT_FLOATS * sizeof(float) * (size_t)(n_traj > 0 ? n_traj : 0);
+  return (size_t)4 * ACT_FLOATS * sizeof(float) * (size_t)(n_traj > 0 ? n_traj : 0);
 }
 
-static const char* const kLayerNames[29] = {
-    "D00A", "D00B", "L64A", "L64B", "DN0", "D10A", "D10B", "L32A", "L32B", "DN1", "D20A", "D20B", "L16A", "L16B",
-    "L16A", "L16B", "L16A", "L16B", "U00A", "U00B", "U01A", "U01B", "UP0", "U10A", "U10B", "U11A", "U11B", "UP1", "FIN"};
+constexpr int kNumLayers = 17;
+static const char* const kLayerNames[kNumLayers] = {"R_D00", "R_D01", "DN0", "R_D10", "R_D11", "DN1", "R_D20", "R_L16", "R_L16",
+                                                    "R_L16", "R_U00", "R_U01", "UP0", "R_U10", "R_U11", "UP1", "FIN"};
 
-// algorithmic FLOPs per trajectory of each launch: 2 * C_out * taps * C_in * L_out (+ the fused 1x1 convs)
-static const double kLayerFlops[29] = {
-    2.0 * 32 * 5 * 4 * 64,  2.0 * 32 * 5 * 32 * 64 + 2.0 * 32 * 4 * 64,  2.0 * 32 * 5 * 32 * 64, 2.0 * 32 * 5 * 32 * 64,
-    2.0 * 32 * 3 * 32 * 32,
-    2.0 * 64 * 5 * 32 * 32, 2.0 * 64 * 5 * 64 * 32 + 2.0 * 64 * 32 * 32, 2.0 * 64 * 5 * 64 * 32, 2.0 * 64 * 5 * 64 * 32,
-    2.0 * 64 * 3 * 64 * 16,
-    2.0 * 128 * 5 * 64 * 16, 2.0 * 128 * 5 * 128 * 16 + 2.0 * 128 * 64 * 16, 2.0 * 128 * 5 * 128 * 16, 2.0 * 128 * 5 * 128 * 16,
-    2.0 * 128 * 5 * 128 * 16, 2.0 * 128 * 5 * 128 * 16, 2.0 * 128 * 5 * 128 * 16, 2.0 * 128 * 5 * 128 * 16,
-    2.0 * 64 * 5 * 256 * 16, 2.0 * 64 * 5 * 64 * 16 + 2.0 * 64 * 256 * 16, 2.0 * 64 * 5 * 64 * 16, 2.0 * 64 * 5 * 64 * 16,
-    2.0 * 64 * 4 * 64 * 16,
-    2.0 * 32 * 5 * 128 * 32, 2.0 * 32 * 5 * 32 * 32 + 2.0 * 32 * 128 * 32, 2.0 * 32 * 5 * 32 * 32, 2.0 * 32 * 5 * 32 * 32,
-    2.0 * 32 * 4 * 32 * 32,
+// algorithmic FLOPs per trajectory of each launch: sum over its convs of 2 * C_out * taps * C_in * L_out
+static constexpr double rtb_flops(double cin, double cout, double L) {
+  return 2.0 * cout * 5 * cin * L + 2.0 * cout * 5 * cout * L + (cin != cout ? 2.0 * cout * cin * L : 0.0);
+}
+static const double kLayerFlops[kNumLayers] = {
+    rtb_flops(4, 32, 64), rtb_flops(32, 32, 64), 2.0 * 32 * 3 * 32 * 32,
+    rtb_flops(32, 64, 32), rtb_flops(64, 64, 32), 2.0 * 64 * 3 * 64 * 16,
+    rtb_flops(64, 128, 16), rtb_flops(128, 128, 16), rtb_flops(128, 128, 16), rtb_flops(128, 128, 16),
+    rtb_flops(256, 64, 16), rtb_flops(64, 64, 16), 2.0 * 64 * 4 * 64 * 16,
+    rtb_flops(128, 32, 32), rtb_flops(32, 32, 32), 2.0 * 32 * 4 * 32 * 32,
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64};
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
-                             hipStream_t st, hipEvent_t* ev) {
+                             hipStream_t st, hipEvent_t* ev, int reps) {
   MMD_REQUIRE(u && x && eps && ws, "mmd_unet_forward: NULL argument");
   MMD_REQUIRE(n >= 1, "mmd_unet_forward: n_traj must be >= 1");
   MMD_REQUIRE(t >= 0 && t < u->T, "mmd_unet_forward: t=%d outside [0,%d)", t, u->T);
   MMD_REQUIRE(ws_bytes >= mmd_unet_workspace_bytes(u, n), "mmd_unet_forward: workspace too small");
   int li = 0;
-#define MMD_MARK() do { if (ev) (void)hipEventRecord(ev[li], st); ++li; } while (0)
-  float* Hb = (float*)ws;
-  float* P0 = Hb + (size_t)n * ACT_FLOATS;
+  // profiling (ev != nullptr): every launch is bracketed by events and issued `reps` times back to back (each launch
+  // is a pure function of buffers it does not write), so the event overhead is amortised over the repeats
+#define MMD_L(...)                                          \
+  do {                                                      \
+    if (ev) (void)hipEventRecord(ev[li], st);               \
+    ++li;                                                   \
+    for (int _r = 0; _r < reps; ++_r) { __VA_ARGS__; }      \
+  } while (0)
+  float* P0 = (float*)ws;
   float* P1 = P0 + (size_t)n * ACT_FLOATS;
   float* S1 = P1 + (size_t)n * ACT_FLOATS;
   float* S2 = S1 + (size_t)n * ACT_FLOATS;
   const RtbW* R = u->rtb;
   // downs.0 @ L=64
-  MMD_MARK();
-  launch<D00A>(args_a(u, R[0], x, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<D00B>(args_b(u, R[0], Hb, x, nullptr, P0, n), st);
-  MMD_MARK();
-  launch<L64A>(args_a(u, R[1], P0, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<L64B>(args_b(u, R[1], Hb, P0, nullptr, P1, n), st);
-  MMD_MARK();
-  launch<DN0>(args_plain(u, u->down[0], P1, P0, n), st);
+  MMD_L(launch_rtb<R_D00>(args_rtb(u, R[0], x, nullptr, P0, t, n), st));
+  MMD_L(launch_rtb<R_D01>(args_rtb(u, R[1], P0, nullptr, P1, t, n), st));
+  MMD_L(launch<DN0>(args_plain(u, u->down[0], P1, P0, n), st));
   // downs.1 @ L=32
-  MMD_MARK();
-  launch<D10A>(args_a(u, R[2], P0, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<D10B>(args_b(u, R[2], Hb, P0, nullptr, P1, n), st);
-  MMD_MARK();
-  launch<L32A>(args_a(u, R[3], P1, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<L32B>(args_b(u, R[3], Hb, P1, nullptr, S1, n), st);
-  MMD_MARK();
-  launch<DN1>(args_plain(u, u->down[1], S1, P0, n), st);
+  MMD_L(launch_rtb<R_D10>(args_rtb(u, R[2], P0, nullptr, P1, t, n), st));
+  MMD_L(launch_rtb<R_D11>(args_rtb(u, R[3], P1, nullptr, S1, t, n), st));
+  MMD_L(launch<DN1>(args_plain(u, u->down[1], S1, P0, n), st));
   // downs.2 @ L=16
-  MMD_MARK();
-  launch<D20A>(args_a(u, R[4], P0, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<D20B>(args_b(u, R[4], Hb, P0, nullptr, P1, n), st);
-  MMD_MARK();
-  launch<L16A>(args_a(u, R[5], P1, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<L16B>(args_b(u, R[5], Hb, P1, nullptr, S2, n), st);
+  MMD_L(launch_rtb<R_D20>(args_rtb(u, R[4], P0, nullptr, P1, t, n), st));
+  MMD_L(launch_rtb<R_L16>(args_rtb(u, R[5], P1, nullptr, S2, t, n), st));
   // mid
-  MMD_MARK();
-  launch<L16A>(args_a(u, R[10], S2, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<L16B>(args_b(u, R[10], Hb, S2, nullptr, P0, n), st);
-  MMD_MARK();
-  launch<L16A>(args_a(u, R[11], P0, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<L16B>(args_b(u, R[11], Hb, P0, nullptr, P1, n), st);
+  MMD_L(launch_rtb<R_L16>(args_rtb(u, R[10], S2, nullptr, P0, t, n), st));
+  MMD_L(launch_rtb<R_L16>(args_rtb(u, R[11], P0, nullptr, P1, t, n), st));
   // ups.0 @ L=16: cat(x, skip2)
-  MMD_MARK();
-  launch<U00A>(args_a(u, R[6], P1, S2, Hb, t, n), st);
-  MMD_MARK();
-  launch<U00B>(args_b(u, R[6], Hb, P1, S2, P0, n), st);
-  MMD_MARK();
-  launch<U01A>(args_a(u, R[7], P0, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<U01B>(args_b(u, R[7], Hb, P0, nullptr, P1, n), st);
-  MMD_MARK();
-  launch<UP0>(args_plain(u, u->up[0], P1, P0, n), st);
+  MMD_L(launch_rtb<R_U00>(args_rtb(u, R[6], P1, S2, P0, t, n), st));
+  MMD_L(launch_rtb<R_U01>(args_rtb(u, R[7], P0, nullptr, P1, t, n), st));
+  MMD_L(launch<UP0>(args_plain(u, u->up[0], P1, P0, n), st));
   // ups.1 @ L=32: cat(x, skip1)
-  MMD_MARK();
-  launch<U10A>(args_a(u, R[8], P0, S1, Hb, t, n), st);
-  MMD_MARK();
-  launch<U10B>(args_b(u, R[8], Hb, P0, S1, P1, n), st);
-  MMD_MARK();
-  launch<U11A>(args_a(u, R[9], P1, nullptr, Hb, t, n), st);
-  MMD_MARK();
-  launch<U11B>(args_b(u, R[9], Hb, P1, nullptr, P0, n), st);
-  MMD_MARK();
-  launch<UP1>(args_plain(u, u->up[1], P0, P1, n), st);
+  MMD_L(launch_rtb<R_U10>(args_rtb(u, R[8], P0, S1, P1, t, n), st));
+  MMD_L(launch_rtb<R_U11>(args_rtb(u, R[9], P1, nullptr, P0, t, n), st));
+  MMD_L(launch<UP1>(args_plain(u, u->up[1], P0, P1, n), st));
   // final_conv
   ConvArgs f = args_plain(u, u->fin, P1, eps, n);
   f.gamma = u->blob + u->fin.gamma; f.beta = u->blob + u->fin.beta;
   f.res_wpk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
   f.res_bias = u->blob + u->fin_b1;
-  MMD_MARK();
-  launch<FIN>(f, st);
-  MMD_MARK();
-#undef MMD_MARK
+  MMD_L(launch<FIN>(f, st));
+  if (ev) (void)hipEventRecord(ev[li], st);
+#undef MMD_L
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, void* stream) {
-  return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, (hipStream_t)stream, nullptr);
+  return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, (hipStream_t)stream, nullptr, 1);
 }
 
-int mmd_unet_num_layers(void) { return 29; }
-const char* mmd_unet_layer_name(int i) { return i >= 0 && i < 29 ? kLayerNames[i] : ""; }
-double mmd_unet_layer_flops(int i) { return i >= 0 && i < 29 ? kLayerFlops[i] : 0.0; }
+int mmd_unet_num_layers(void) { return kNumLayers; }
+const char* mmd_unet_layer_name(int i) { return i >= 0 && i < kNumLayers ? kLayerNames[i] : ""; }
+double mmd_unet_layer_flops(int i) { return i >= 0 && i < kNumLayers ? kLayerFlops[i] : 0.0; }
 
 int mmd_unet_profile(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, int repeats,
                      float* layer_ms, void* stream) {
   MMD_REQUIRE(layer_ms && repeats >= 1, "mmd_unet_profile: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipEvent_t ev[30];
+  hipEvent_t ev[kNumLayers + 1];
   for (auto& e : ev) MMD_HIP_CHECK(hipEventCreate(&e));
-  for (int i = 0; i < 29; ++i) layer_ms[i] = 0.f;
-  int rc = 0;
-  for (int r = 0; r < repeats && rc == 0; ++r) {
-    rc = unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, st, ev);
-    if (rc) break;
-    if (hipStreamSynchronize(st) != hipSuccess) { set_error("mmd_unet_profile: sync failed"); rc = 1; break; }
-    for (int i = 0; i < 29; ++i) {
+  for (int i = 0; i < kNumLayers; ++i) layer_ms[i] = 0.f;
+  int rc = unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, st, ev, repeats);
+  if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) { set_error("mmd_unet_profile: sync failed"); rc = 1; }
+  if (rc == 0)
+    for (int i = 0; i < kNumLayers; ++i) {
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-      layer_ms[i] += ms / (float)repeats;
+      layer_ms[i] = ms / (float)repeats;
     }
-  }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
 }

@@ -1,0 +1,418 @@
+"""MPD / MPDEnsemble: the outer drop-in boundary (what CBS / PrioritizedPlanning call).
+
+Mirrors reference mmd/planners/single_agent/{common.py:26-46, single_agent_planner_base.py:31-34, mpd.py:64-517,
+mpd_ensemble.py:65-560}: same constructor keyword names, `__call__(start_state_pos, goal_state_pos, constraints_l,
+experience) -> PlannerOutput`, same errors (ValueError on a start/goal mismatch, NotImplementedError on an unknown
+planner_alg).  Differences, all forced by what exists offline:
+  * datasets / checkpoints are not shipped, so when `<trained_models_dir>/<model_id>/args.yaml` is absent the model
+    comes from `model_state_dict` (reference key names) + `model_args`, the map from `env_id` (default: the part of
+    model_id before the first '-') and the normaliser limits from `normalizer_limits`;
+  * the guide / sampler are the HIP kernels of libmmd_amd.so; there is no CPU fallback.
+"""
+import os
+from math import ceil
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import synth
+from .constraints import CostConstraint, MultiPointConstraint   # noqa: F401
+from .diffusion_ensemble import DiffusionsEnsemble, HORIZON
+from .diffusion_model import GaussianDiffusionModel, ddpm_sample_fn
+from .guides import GuideManagerTrajectoriesWithVelocity
+from .normalization import TrajectoryDatasetFacade
+from .postprocess import (compute_path_length, compute_smoothness, compute_variance_waypoints,
+                          get_trajs_collision_and_free, smooth_trajs)
+from .temporal_unet import UNET_DIM_MULTS, TemporalUnet
+
+
+class PlannerOutput:
+    """Same fields as the reference class (mmd/planners/single_agent/common.py:26-46)."""
+
+    def __init__(self):
+        self.trajs_iters = None
+        self.trajs_final = None
+        self.trajs_final_coll = None
+        self.trajs_final_coll_idxs = None
+        self.trajs_final_free = None
+        self.trajs_final_free_idxs = None
+        self.success_free_trajs = None
+        self.fraction_free_trajs = None
+        self.collision_intensity_trajs = None
+        self.idx_best_traj = None
+        self.traj_final_free_best = None
+        self.cost_best_free_traj = None
+        self.cost_smoothness = None
+        self.cost_path_length = None
+        self.cost_all = None
+        self.variance_waypoint_trajs_final_free = None
+        self.t_total = None
+        self.constraints_l = None
+
+
+class PathBatchExperience:
+    """mmd/common/experiences.py:44: a previous batch of paths used to seed local inference."""
+
+    def __init__(self, path_b):
+        self.path_b = path_b
+
+
+class _Timer:
+    """TimerCUDA semantics (torch_timer.py:44-53): perf_counter bracketed by device synchronisation."""
+
+    def __enter__(self):
+        import time
+        torch.cuda.synchronize()
+        self._t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *a):
+        import time
+        torch.cuda.synchronize()
+        self.elapsed = time.perf_counter() - self._t0
+
+
+class _Robot:
+    """What CBS/PP read from planner.robot: radius, q_dim, get_position/get_velocity."""
+    radius = 0.05
+    q_dim = 2
+    q_min = torch.tensor([-1.0, -1.0])
+    q_max = torch.tensor([1.0, 1.0])
+
+    def get_position(self, x):
+        return x[..., :2]
+
+    def get_velocity(self, x):
+        return x[..., 2:4]
+
+
+def _load_model(model_id, trained_models_dir, model_state_dict, model_args, device):
+    """mpd.py:117-177: args.yaml + checkpoint if present on disk, else the in-memory state dict."""
+    args = dict(variance_schedule="exponential", n_diffusion_steps=25, predict_epsilon=True, unet_input_dim=32,
+                unet_dim_mults_option=0, use_ema=True)
+    model_dir = os.path.join(os.path.expanduser(trained_models_dir or ""), model_id or "")
+    yaml_path = os.path.join(model_dir, "args.yaml")
+    if model_state_dict is None and os.path.exists(yaml_path):
+        import yaml
+        with open(yaml_path) as f:
+            args.update(yaml.safe_load(f))
+        ckpt = "ema_model_current_state_dict.pth" if args.get("use_ema", True) else "model_current_state_dict.pth"
+        model_state_dict = torch.load(os.path.join(model_dir, "checkpoints", ckpt), map_location="cpu")
+    if model_args:
+        args.update(model_args)
+    if model_state_dict is None:
+        raise FileNotFoundError(f"no checkpoint under {model_dir} and no model_state_dict given")
+    unet = TemporalUnet(state_dim=4, n_support_points=HORIZON, unet_input_dim=args["unet_input_dim"],
+                        dim_mults=UNET_DIM_MULTS[args["unet_dim_mults_option"]])
+    unet.load_state_dict(model_state_dict)
+    model = GaussianDiffusionModel(model=unet, variance_schedule=args["variance_schedule"],
+                                   n_diffusion_steps=args["n_diffusion_steps"], predict_epsilon=args["predict_epsilon"])
+    return model, args
+
+
+class MPD:
+    def __init__(self, model_id: str, planner_alg: str, start_state_pos, goal_state_pos,
+                 use_guide_on_extra_objects_only: bool = False, start_guide_steps_fraction: float = 0.5,
+                 n_guide_steps: int = 20, n_diffusion_steps_without_noise: int = 1,
+                 weight_grad_cost_collision: float = 2e-2, weight_grad_cost_smoothness: float = 8e-2,
+                 weight_grad_cost_constraints: float = 2e-1, weight_grad_cost_soft_constraints: float = 2e-2,
+                 factor_num_interpolated_points_for_collision: float = 1.5, trajectory_duration: float = 5.0,
+                 device: str = "cuda", debug: bool = False, seed: int = 18, results_dir: str = "logs",
+                 trained_models_dir: str = "", n_samples: int = 64, n_local_inference_noising_steps: int = 3,
+                 n_local_inference_denoising_steps: int = 3, model_state_dict=None, model_args=None, env_id=None,
+                 normalizer_limits=None, obstacle_cutoff_margin=0.05, **kwargs):
+        self.constraints = []
+        self.weight_grad_cost_constraints = weight_grad_cost_constraints
+        self.weight_grad_cost_soft_constraints = weight_grad_cost_soft_constraints
+        if planner_alg == "mmd":
+            self.run_prior_only, self.run_prior_then_guidance = False, False
+        elif planner_alg == "diffusion_prior_then_guide":
+            self.run_prior_only, self.run_prior_then_guidance = False, True
+        elif planner_alg == "diffusion_prior":
+            self.run_prior_only, self.run_prior_then_guidance = True, False
+        else:
+            raise NotImplementedError
+        if use_guide_on_extra_objects_only:
+            raise NotImplementedError("extra objects are empty in every shipped map (SURVEY §8a A9)")
+        self.device = torch.device(device)
+        self.tensor_args = {"device": self.device, "dtype": torch.float32}
+        self.model, self.model_args = _load_model(model_id, trained_models_dir, model_state_dict, model_args, self.device)
+        self.model.seed = seed
+        self.env_id = env_id or (model_id.split("-")[0] if model_id else "EnvEmpty2D")
+        mins, maxs = normalizer_limits if normalizer_limits is not None else (synth.NORM_MINS, synth.NORM_MAXS)
+        self.dataset = TrajectoryDatasetFacade(mins, maxs)
+        self.robot = _Robot()
+        self.task = self                                   # CBS reads planner.task.get_trajs_collision_and_free
+        self.n_support_points = HORIZON
+        self.start_state_pos = torch.as_tensor(start_state_pos, dtype=torch.float32).clone()
+        self.goal_state_pos = torch.as_tensor(goal_state_pos, dtype=torch.float32).clone()
+        self.hard_conds = self.dataset.get_hard_conditions(torch.vstack((self.start_state_pos, self.goal_state_pos)),
+                                                           normalize=True)
+        self.guide = GuideManagerTrajectoriesWithVelocity(
+            self.dataset, env_id=self.env_id, obstacle_cutoff_margin=obstacle_cutoff_margin,
+            weight_grad_cost_collision=weight_grad_cost_collision,
+            weight_grad_cost_smoothness=weight_grad_cost_smoothness, trajectory_duration=trajectory_duration,
+            n_support_points=HORIZON, device=self.device)
+        self.t_start_guide = ceil(start_guide_steps_fraction * self.model.n_diffusion_steps)
+        self.n_guide_steps = n_guide_steps
+        self.n_diffusion_steps_without_noise = n_diffusion_steps_without_noise
+        self.num_samples = n_samples
+        self.n_local_inference_noising_steps = n_local_inference_noising_steps
+        self.n_local_inference_denoising_steps = n_local_inference_denoising_steps
+        self.results_dir = results_dir
+        self.context = None
+        self.recent_call_data = PlannerOutput()
+        self.sample_fn_kwargs = dict(
+            guide=None if self.run_prior_then_guidance or self.run_prior_only else self.guide,
+            n_guide_steps=self.n_guide_steps, t_start_guide=self.t_start_guide,
+            noise_std_extra_schedule_fn=lambda x: 0.5)
+
+    # ---- task facade --------------------------------------------------------------------------------------------
+    def get_trajs_collision_and_free(self, trajs, return_indices=False, num_interpolation=5):
+        out = get_trajs_collision_and_free(trajs, self.env_id, num_interpolation)
+        return out if return_indices else (out[0], out[2])
+
+    # ---- planner call -------------------------------------------------------------------------------------------
+    def _cost_constraints(self, constraints_l):
+        return [CostConstraint(self.robot, self.n_support_points, q_l=c.get_q_l(), traj_range_l=c.get_t_range_l(),
+                               radius_l=c.radius_l, is_soft=c.is_soft) for c in (constraints_l or [])]
+
+    def __call__(self, start_state_pos, goal_state_pos, constraints_l=None, experience=None, *args, **kwargs):
+        if not torch.allclose(torch.as_tensor(start_state_pos).cpu().float(), self.start_state_pos):
+            raise ValueError("The start state is different from the one stored in the planner.")
+        if not torch.allclose(torch.as_tensor(goal_state_pos).cpu().float(), self.goal_state_pos):
+            raise ValueError("The goal state is different from the one stored in the planner.")
+        cost_constraints_l = self._cost_constraints(constraints_l)
+        with _Timer() as timer:
+            if experience is None:
+                chain = self.run_constrained_inference(cost_constraints_l, **kwargs)
+            else:
+                chain = self.run_constrained_local_inference(cost_constraints_l, experience, **kwargs)
+        out = PlannerOutput()
+        out.t_total = timer.elapsed
+        trajs_iters = self.dataset.unnormalize_trajectories(chain)
+        trajs_final = trajs_iters[-1]
+        coll, coll_idxs, free, free_idxs, _ = self.get_trajs_collision_and_free(trajs_final, return_indices=True)
+        if free is not None:
+            out.cost_smoothness = compute_smoothness(free)
+            out.cost_path_length = compute_path_length(free)
+            out.cost_all = out.cost_path_length + out.cost_smoothness
+            idx_best_free = torch.argmin(out.cost_all).item()
+            out.idx_best_traj = free_idxs[idx_best_free]
+            out.idx_best_free_traj = idx_best_free
+            out.cost_best_free_traj = torch.min(out.cost_all).item()
+            out.variance_waypoint_trajs_final_free = compute_variance_waypoints(free)
+        out.trajs_iters, out.trajs_final = trajs_iters, smooth_trajs(trajs_final)
+        out.trajs_final_coll, out.trajs_final_coll_idxs = coll, coll_idxs
+        out.trajs_final_free, out.trajs_final_free_idxs = free, free_idxs
+        out.constraints_l = constraints_l
+        self.recent_call_data = out
+        return out
+
+    def _add_constraints(self, cost_constraints_l):
+        self.guide.add_extra_costs(cost_constraints_l,
+                                   [self.weight_grad_cost_soft_constraints if c.is_soft else
+                                    self.weight_grad_cost_constraints for c in cost_constraints_l])
+
+    def _post_guidance(self, chain):
+        """planner_alg 'diffusion_prior_then_guide' (mpd.py:429-453): extra guide steps after the prior sample."""
+        if not self.run_prior_then_guidance:
+            return chain
+        n_post = (self.t_start_guide + self.n_diffusion_steps_without_noise) * self.n_guide_steps
+        x = chain[-1].contiguous().clone()
+        hard = torch.stack([self.hard_conds[0], self.hard_conds[HORIZON - 1]])[None].to(x.device).contiguous()
+        extra = []
+        for _ in range(n_post):
+            self.guide.guide_steps(x, hard, 3, 1)
+            extra.append(x.clone())
+        return torch.cat((chain, torch.stack(extra)))
+
+    def run_constrained_inference(self, cost_constraints_l, **kw):
+        self._add_constraints(cost_constraints_l)
+        try:
+            chain = self.model.run_inference(
+                self.context, self.hard_conds, n_samples=self.num_samples, horizon=self.n_support_points,
+                return_chain=True, sample_fn=ddpm_sample_fn, **self.sample_fn_kwargs,
+                n_diffusion_steps_without_noise=self.n_diffusion_steps_without_noise, device=self.device, **kw)
+            chain = self._post_guidance(chain)
+        finally:
+            self.guide.reset_extra_costs()
+        return chain
+
+    def run_constrained_local_inference(self, cost_constraints_l, experience, **kw):
+        self._add_constraints(cost_constraints_l)
+        try:
+            chain = self.model.run_local_inference(
+                experience.path_b.to(self.device), self.n_local_inference_noising_steps,
+                self.n_local_inference_denoising_steps, self.context, self.hard_conds, n_samples=self.num_samples,
+                horizon=self.n_support_points, return_chain=True, sample_fn=ddpm_sample_fn, **self.sample_fn_kwargs,
+                n_diffusion_steps_without_noise=self.n_diffusion_steps_without_noise, device=self.device, **kw)
+            chain = self._post_guidance(chain)
+        finally:
+            self.guide.reset_extra_costs()
+        return chain
+
+
+class MPDEnsemble:
+    """mpd_ensemble.py:65-560: K tile models chained along the horizon (K*64 support points), one guide per tile
+    (obstacle_cutoff_margin 0.01, :139), constraints split per tile by time index and shifted to the tile frame."""
+
+    def __init__(self, model_ids: tuple, transforms: Dict[int, torch.Tensor], planner_alg: str, start_state_pos,
+                 goal_state_pos, use_guide_on_extra_objects_only: bool = False,
+                 start_guide_steps_fraction: float = 0.5, n_guide_steps: int = 20,
+                 n_diffusion_steps_without_noise: int = 1, weight_grad_cost_collision: float = 2e-2,
+                 weight_grad_cost_smoothness: float = 8e-2, weight_grad_cost_constraints: float = 2e-1,
+                 weight_grad_cost_soft_constraints: float = 2e-2,
+                 factor_num_interpolated_points_for_collision: float = 1.5, trajectory_duration: float = 5.0,
+                 device: str = "cuda", debug: bool = False, seed: int = 18, results_dir: str = "logs",
+                 trained_models_dir: str = "", n_samples: int = 64, n_local_inference_noising_steps: int = 3,
+                 n_local_inference_denoising_steps: int = 3, model_state_dicts=None, model_args=None, env_ids=None,
+                 normalizer_limits=None, **kwargs):
+        if planner_alg == "mmd":
+            self.run_prior_only, self.run_prior_then_guidance = False, False
+        elif planner_alg == "diffusion_prior_then_guide":
+            self.run_prior_only, self.run_prior_then_guidance = False, True
+        elif planner_alg == "diffusion_prior":
+            self.run_prior_only, self.run_prior_then_guidance = True, False
+        else:
+            raise NotImplementedError
+        self.weight_grad_cost_constraints = weight_grad_cost_constraints
+        self.weight_grad_cost_soft_constraints = weight_grad_cost_soft_constraints
+        self.device = torch.device(device)
+        self.tensor_args = {"device": self.device, "dtype": torch.float32}
+        mins, maxs = normalizer_limits if normalizer_limits is not None else (synth.NORM_MINS, synth.NORM_MAXS)
+        self.transforms = {k: torch.as_tensor(v, dtype=torch.float32).cpu() for k, v in transforms.items()}
+        self.models, self.guides, self.datasets, self.sample_kwargs, self.env_ids = {}, {}, [], {}, {}
+        for j, model_id in enumerate(model_ids):
+            sd = None if model_state_dicts is None else model_state_dicts[j]
+            model, _ = _load_model(model_id, trained_models_dir, sd, model_args, self.device)
+            model.seed = seed + j
+            self.models[j] = model
+            self.env_ids[j] = (env_ids[j] if env_ids is not None else model_id.split("-")[0])
+            ds = TrajectoryDatasetFacade(mins, maxs)
+            self.datasets.append(ds)
+            self.guides[j] = GuideManagerTrajectoriesWithVelocity(
+                ds, env_id=self.env_ids[j], obstacle_cutoff_margin=0.01,
+                weight_grad_cost_collision=weight_grad_cost_collision,
+                weight_grad_cost_smoothness=weight_grad_cost_smoothness, trajectory_duration=trajectory_duration,
+                n_support_points=HORIZON, device=self.device)
+            self.sample_kwargs[j] = dict(
+                guide=None if self.run_prior_then_guidance or self.run_prior_only else self.guides[j],
+                n_guide_steps=n_guide_steps,
+                t_start_guide=ceil(start_guide_steps_fraction * model.n_diffusion_steps),
+                noise_std_extra_schedule_fn=lambda x: 0.5)
+        K = len(model_ids)
+        self.robot = _Robot()
+        self.task = self
+        self.n_support_points = HORIZON
+        self.start_state_pos = torch.as_tensor(start_state_pos, dtype=torch.float32).clone()
+        self.goal_state_pos = torch.as_tensor(goal_state_pos, dtype=torch.float32).clone()
+        start_local = self.start_state_pos - self.transforms[0]          # tasks_ensemble.inverse_transform_q
+        goal_local = self.goal_state_pos - self.transforms[K - 1]
+        nz = self.datasets[0].normalizer
+        z = torch.zeros(2)
+        self.hard_conds = {0: {0: nz.normalize(torch.cat((start_local, z)))}}
+        self.hard_conds.setdefault(K - 1, {})[HORIZON - 1] = nz.normalize(torch.cat((goal_local, z)))
+        self.cross_conds = {(i, i + 1): (HORIZON - 1, 0) for i in range(K - 1)}
+        self.model = DiffusionsEnsemble(self.models, self.transforms)
+        self.n_diffusion_steps_without_noise = n_diffusion_steps_without_noise
+        self.num_samples = n_samples
+        self.n_local_inference_noising_steps = n_local_inference_noising_steps
+        self.n_local_inference_denoising_steps = n_local_inference_denoising_steps
+        self.results_dir = results_dir
+        self.recent_call_data = PlannerOutput()
+
+    def infer_task_id_from_q_idx(self, idx):
+        return int(idx) // HORIZON, int(idx) % HORIZON
+
+    def split_cost_constraints_to_tasks(self, cost_constraints_l: List[CostConstraint]):
+        """mpd_ensemble.py:431-507: one hard and one soft CostConstraint per tile, keyed by the tile of the range start."""
+        buckets: Dict[Tuple[int, bool], list] = {}
+        for c in cost_constraints_l:
+            for j in range(c.qs.shape[0]):
+                task_id, _ = self.infer_task_id_from_q_idx(c.traj_ranges[j, 0])
+                buckets.setdefault((task_id, c.is_soft), []).append((c.qs[j], c.traj_ranges[j], c.radii[j]))
+        out: Dict[int, list] = {}
+        for soft in (False, True):
+            for (task_id, is_soft), items in buckets.items():
+                if is_soft != soft:
+                    continue
+                q_l, tr_l, r_l = zip(*items)
+                out.setdefault(task_id, []).append(CostConstraint(
+                    self.robot, HORIZON, q_l=[torch.from_numpy(np.asarray(q)) for q in q_l],
+                    traj_range_l=[(float(t[0]), float(t[1])) for t in tr_l], radius_l=[float(r) for r in r_l],
+                    is_soft=soft))
+        return out
+
+    def _add_constraints(self, cost_constraints_l):
+        for task_id, cl in self.split_cost_constraints_to_tasks(cost_constraints_l).items():
+            for c in cl:
+                c.traj_ranges = c.traj_ranges - task_id * HORIZON               # mpd_ensemble.py:517
+                c.qs = c.qs - self.transforms[task_id].numpy()                  # :518
+                self.guides[task_id].add_extra_costs(
+                    [c], [self.weight_grad_cost_constraints if not c.is_soft else self.weight_grad_cost_soft_constraints])
+
+    def _reset(self):
+        for g in self.guides.values():
+            g.reset_extra_costs()
+
+    def run_constrained_inference(self, cost_constraints_l, **kw):
+        self._add_constraints(cost_constraints_l)
+        try:
+            return self.model.run_inference(None, self.hard_conds, cross_conds=self.cross_conds,
+                                            n_samples=self.num_samples, return_chain=True, sample_fn=ddpm_sample_fn,
+                                            sample_kwargs=self.sample_kwargs,
+                                            n_diffusion_steps_without_noise=self.n_diffusion_steps_without_noise,
+                                            device=self.device, **kw)
+        finally:
+            self._reset()
+
+    def run_constrained_local_inference(self, cost_constraints_l, experience, **kw):
+        self._add_constraints(cost_constraints_l)
+        try:
+            return self.model.run_local_inference(
+                experience.path_b.to(self.device), self.n_local_inference_noising_steps,
+                self.n_local_inference_denoising_steps, None, self.hard_conds, cross_conds=self.cross_conds,
+                n_samples=self.num_samples, return_chain=True, sample_fn=ddpm_sample_fn,
+                sample_kwargs=self.sample_kwargs,
+                n_diffusion_steps_without_noise=self.n_diffusion_steps_without_noise, device=self.device, **kw)
+        finally:
+            self._reset()
+
+    def __call__(self, start_state_pos, goal_state_pos, constraints_l=None, experience=None, *args, **kwargs):
+        if not torch.allclose(torch.as_tensor(start_state_pos).cpu().float(), self.start_state_pos):
+            raise ValueError("The start state is different from the one stored in the planner.")
+        if not torch.allclose(torch.as_tensor(goal_state_pos).cpu().float(), self.goal_state_pos):
+            raise ValueError("The goal state is different from the one stored in the planner.")
+        cl = [CostConstraint(self.robot, HORIZON, q_l=c.get_q_l(), traj_range_l=c.get_t_range_l(), radius_l=c.radius_l,
+                             is_soft=c.is_soft) for c in (constraints_l or [])]
+        with _Timer() as timer:
+            chains = (self.run_constrained_inference(cl, **kwargs) if experience is None
+                      else self.run_constrained_local_inference(cl, experience, **kwargs))
+        # un-normalise per tile, move to the global frame, concatenate along the horizon (tasks_ensemble.py:162-225)
+        parts = []
+        for m in sorted(chains):
+            tr = self.datasets[m].unnormalize_trajectories(chains[m]).clone()
+            tr[..., :2] += self.transforms[m].to(tr.device)
+            parts.append(tr)
+        trajs_iters = torch.cat(parts, dim=-2)
+        trajs_final = trajs_iters[-1]
+        out = PlannerOutput()
+        out.t_total = timer.elapsed
+        coll, coll_idxs, free, free_idxs, _ = get_trajs_collision_and_free(trajs_final, None, all_free=True)
+        out.trajs_iters, out.trajs_final = trajs_iters, smooth_trajs(trajs_final)
+        out.trajs_final_coll, out.trajs_final_coll_idxs = coll, coll_idxs
+        out.trajs_final_free, out.trajs_final_free_idxs = free, free_idxs
+        out.success_free_trajs = free is not None
+        out.fraction_free_trajs = 0.0 if free is None else free.shape[0] / trajs_final.shape[0]
+        if free is not None:
+            out.cost_smoothness, out.cost_path_length = compute_smoothness(free), compute_path_length(free)
+            out.cost_all = out.cost_path_length + out.cost_smoothness
+            ib = torch.argmin(out.cost_all).item()
+            out.idx_best_traj, out.traj_final_free_best = free_idxs[ib], free[ib]
+            out.cost_best_free_traj = torch.min(out.cost_all).item()
+            out.variance_waypoint_trajs_final_free = compute_variance_waypoints(free)
+        out.constraints_l = constraints_l
+        self.recent_call_data = out
+        return out

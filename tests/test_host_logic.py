@@ -1,0 +1,107 @@
+"""CPU: host-side logic of the product package (no device compute): schedule tables, SDF textures, normaliser,
+constraint time-bucketing (the host half of the C ABI), parameter spec, synthetic-input determinism."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mmd_amd import _lib, synth
+from mmd_amd.constraints import CostConstraint
+from mmd_amd.environments import sdf_grid_texture
+from mmd_amd.normalization import LimitsNormalizer, TrajectoryDatasetFacade
+from mmd_amd.schedules import SCHEDULE_KEYS, diffusion_buffers
+from cases import GOLDEN, H
+
+
+def test_schedule_tables_bit_exact_vs_reference():
+    g = np.load(os.path.join(GOLDEN, "g1_schedules.npz"))
+    for T in (25, 50, 100):
+        tb = diffusion_buffers(T)
+        for k in SCHEDULE_KEYS:
+            assert np.array_equal(tb[k].numpy(), g[f"T{T}.{k}"]), (T, k)
+
+
+@pytest.mark.parametrize("env_id", ["EnvEmpty2D", "EnvHighways2D", "EnvConveyor2D", "EnvDropRegion2D"])
+def test_sdf_texture_vs_reference(env_id):
+    g = np.load(os.path.join(GOLDEN, "g3_sdf.npz"))
+    tex = sdf_grid_texture(env_id)
+    assert tex.shape == (400, 400, 4) and tex.dtype == np.float32
+    idx = g[f"{env_id}.idx"]
+    assert np.array_equal(tex[idx[:, 0], idx[:, 1], 0], g[f"{env_id}.sdf"])
+    assert np.array_equal(tex[idx[:, 0], idx[:, 1], 1:3], g[f"{env_id}.grad"])
+    assert not tex[..., 3].any()
+
+
+def test_normalizer_roundtrip_and_clip():
+    nz = LimitsNormalizer(synth.NORM_MINS, synth.NORM_MAXS)
+    x = torch.from_numpy(synth.synth_noise(3, (5, H, 4))) * 0.3
+    assert torch.allclose(nz.unnormalize(nz.normalize(x)), x, atol=1e-6)
+    wide = torch.tensor([[1.5, -2.0, 0.0, 0.5]])
+    assert torch.equal(nz.unnormalize(wide), torch.tensor([[1.0, -1.0, 0.0, 0.75]]))      # data-dependent clip fires
+    ds = TrajectoryDatasetFacade(synth.NORM_MINS, synth.NORM_MAXS)
+    hc = ds.get_hard_conditions(torch.tensor([[0.8, 0.0], [-0.8, 0.0]]), normalize=True)
+    assert set(hc) == {0, H - 1} and torch.allclose(hc[0], torch.tensor([0.8, 0.0, 0.0, 0.0]))
+
+
+def _pack(groups):
+    lib = _lib.load()
+    G = len(groups)
+    n_pts = (C.c_int32 * G)(*[g.qs.shape[0] for g in groups])
+    arrs = [[np.ascontiguousarray(getattr(g, a), dtype=np.float32) for g in groups] for a in ("qs", "traj_ranges", "radii")]
+    ptrs = [(C.c_void_p * G)(*[a.ctypes.data for a in col]) for col in arrs]
+    slots = (C.c_int32 * G)()
+    _lib.check(lib.mmd_pack_constraints(G, n_pts, ptrs[0], ptrs[1], ptrs[2], H, None, 0, slots))
+    total = int(sum(slots))
+    ell = np.zeros((total, H, 4), np.float32)
+    _lib.check(lib.mmd_pack_constraints(G, n_pts, ptrs[0], ptrs[1], ptrs[2], H, ell.ctypes.data, total, slots))
+    return ell, list(slots)
+
+
+def test_pack_constraints_time_buckets():
+    soft = CostConstraint(None, H, q_l=[torch.tensor([0.1 * j, t / 64.0]) for j in range(3) for t in range(1, H)],
+                          traj_range_l=[(t, t + 1) for j in range(3) for t in range(1, H)],
+                          radius_l=[0.12] * (3 * 63), is_soft=True)
+    hard = CostConstraint(None, H, q_l=[torch.tensor([0.5, 0.5]), torch.tensor([-0.5, 0.25])],
+                          traj_range_l=[(20, 27), (25, 70)], radius_l=[0.12, 0.2])
+    empty_range = CostConstraint(None, H, q_l=[torch.tensor([0.0, 0.0])], traj_range_l=[(5, 5)], radius_l=[0.1])
+    ell, slots = _pack([soft, hard, empty_range])
+    assert slots == [3, 2, 0]                                   # 3 robots per step; ranges overlap on t=25,26; [5,5) empty
+    s = ell[:3]
+    assert (s[:, 0, 2] < 0).all() and (s[:, 1:, 2] == np.float32(0.12)).all()          # no point at t=0
+    assert np.allclose(sorted(s[:, 10, 0]), [0.0, 0.1, 0.2]) and np.allclose(s[:, 10, 1], 10 / 64.0)
+    h = ell[3:5]
+    active = (h[..., 2] >= 0).sum(0)
+    assert list(active[18:30]) == [0, 0, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1] and active[63] == 1   # [20,27) and [25,70) clipped to H
+    # exclusive end (cost_functions.py:305): t=27 belongs only to the second point
+    assert {tuple(np.round(r[:2], 3)) for r in h[:, 27] if r[2] >= 0} == {(-0.5, 0.25)}
+
+
+def test_pack_constraints_slot_overflow_is_an_error():
+    lib = _lib.load()
+    g = CostConstraint(None, H, q_l=[torch.zeros(2)] * 2, traj_range_l=[(1, 5), (1, 5)], radius_l=[0.1, 0.1])
+    n_pts = (C.c_int32 * 1)(2)
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (g.qs, g.traj_ranges, g.radii)]
+    ptrs = [(C.c_void_p * 1)(a.ctypes.data) for a in arrs]
+    ell = np.zeros((1, H, 4), np.float32)
+    slots = (C.c_int32 * 1)()
+    assert lib.mmd_pack_constraints(1, n_pts, ptrs[0], ptrs[1], ptrs[2], H, ell.ctypes.data, 1, slots) != 0
+    assert b"slots" in lib.mmd_last_error()
+    assert lib.mmd_pack_constraints(1, n_pts, ptrs[0], ptrs[1], ptrs[2], 32, ell.ctypes.data, 1, slots) != 0   # wrong H
+
+
+def test_synthetic_inputs_are_deterministic():
+    a, b = synth.synth_unet_state_dict(0), synth.synth_unet_state_dict(0)
+    assert list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
+    assert sum(v.size for v in a.values()) == 997124                     # 997 124 parameters
+    assert np.array_equal(synth.synth_noise(5, (2, 3)), synth.synth_noise(5, (2, 3)))
+    s, g = synth.start_goal_circle(32)
+    assert np.allclose(s, -g, atol=1e-6) and np.allclose(np.linalg.norm(s, axis=1), 0.8, atol=1e-6)
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
