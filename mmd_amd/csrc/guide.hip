@@ -59,8 +59,47 @@ __device__ __forceinline__ float clip_scale(float gx, float gy, float gz, float 
   return fminf(fmaxf(n, 0.f), max_norm) / n;
 }
 
+// wave shift by one lane through DPP (GFX9 wave_shr:1 / wave_shl:1): lane t reads lane t-1 / t+1, no LDS round trip.
+// Lanes shifted in from outside the wave read 0 (bound_ctrl) -- callers mask t == 0 / t == H-1 anyway.
+__device__ __forceinline__ float lane_prev(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_next(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+constexpr int LDS_SLOTS = 40;   // constraint slots staged per workgroup: 40 x 64 x 16 B = 40 KiB
+
+// -sum over a slot range of d/||d|| for points with ||d|| <= R  (CostConstraint, cost_functions.py:297-326), from a
+// [slot][t] table `tab` (LDS or global).  Two accumulator pairs break the dependent add chain.
+__device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t, float px, float py, float& gx,
+                                                float& gy) {
+  float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+  int s = 0;
+#pragma unroll 4
+  for (; s + 1 < n; s += 2) {
+    const float4 c0 = tab[s * H + t], c1 = tab[(s + 1) * H + t];
+    const float dx0 = px - c0.x, dy0 = py - c0.y, dx1 = px - c1.x, dy1 = py - c1.y;
+    const float d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
+    // active iff radius >= 0 and not (dist > radius)  <=>  not (dist^2 > r|r|): one transcendental (rsq) per point
+    const float m0 = (d0 > c0.z * fabsf(c0.z)) ? 0.f : rsqrtf(d0);
+    const float m1 = (d1 > c1.z * fabsf(c1.z)) ? 0.f : rsqrtf(d1);
+    ax -= dx0 * m0; ay -= dy0 * m0;
+    bx -= dx1 * m1; by -= dy1 * m1;
+  }
+  if (s < n) {
+    const float4 c0 = tab[s * H + t];
+    const float dx0 = px - c0.x, dy0 = py - c0.y;
+    const float d0 = dx0 * dx0 + dy0 * dy0;
+    const float m0 = (d0 > c0.z * fabsf(c0.z)) ? 0.f : rsqrtf(d0);
+    ax -= dx0 * m0; ay -= dy0 * m0;
+  }
+  gx += ax + bx;
+  gy += ay + by;
+}
+
 __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t, const float4* __restrict__ grid,
-                                             int grp0, int grp1) {
+                                             int grp0, int grp1, const float4* lds_cons, int lds_slot0, int lds_n) {
   // LimitsNormalizer.unnormalize (normalization.py:157-168), clip applied unconditionally
   float xu[4];
   const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
@@ -72,24 +111,16 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
   }
   const float px = xu[0], py = xu[1], vx = xu[2], vy = xu[3];
   const bool interior = t > 0 && t < H - 1;   // rows 0 and H-1 are zeroed for every term (guides.py:217-218)
-  float tx = 0.f, ty = 0.f, tz = 0.f, tw = 0.f;
 
-  // --- CostCollision over the SDF grids: d/dp max_k relu(margin - sdf_k(p))  (t >= 1; field_factor.py range [1,None])
-  {
-    int ix = (int)floorf((px - g.lo[0]) / g.dim[0] * (float)g.nx);
-    int iy = (int)floorf((py - g.lo[1]) / g.dim[1] * (float)g.ny);
-    ix = min(max(ix, 0), g.nx - 1);
-    iy = min(max(iy, 0), g.ny - 1);
-    float best = 0.f, gx = 0.f, gy = 0.f;
-    for (int k = 0; k < g.n_grids; ++k) {
-      const float4 c = grid[((size_t)k * g.nx + ix) * g.ny + iy];
-      const float v = fmaxf(g.margin - c.x, 0.f);
-      if (v > best) { best = v; gx = -c.y; gy = -c.z; }
-    }
-    const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
-    if (interior) { tx += g.w_coll * (sc * gx); ty += g.w_coll * (sc * gy); }
-  }
+  // SDF gathers are issued first and consumed last: their L2 latency hides behind the GP / constraint arithmetic
+  int ix = (int)floorf((px - g.lo[0]) / g.dim[0] * (float)g.nx);
+  int iy = (int)floorf((py - g.lo[1]) / g.dim[1] * (float)g.ny);
+  ix = min(max(ix, 0), g.nx - 1);
+  iy = min(max(iy, 0), g.ny - 1);
+  const float4 cell0 = grid[(size_t)ix * g.ny + iy];
+
   // --- CostCollision over the workspace boundaries (distance_fields.py:354-367)
+  float wsx, wsy;
   {
     const float d0 = px - g.ws_min[0], d1 = py - g.ws_min[1], d2 = g.ws_max[0] - px, d3 = g.ws_max[1] - py;
     float best = fmaxf(g.margin - d0, 0.f), gx = -1.f, gy = 0.f;
@@ -101,13 +132,13 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
     if (v > best) { best = v; gx = 0.f; gy = 1.f; }
     if (!(best > 0.f)) { gx = 0.f; gy = 0.f; }
     const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
-    if (interior) { tx += g.w_coll * (sc * gx); ty += g.w_coll * (sc * gy); }
+    wsx = g.w_coll * (sc * gx); wsy = g.w_coll * (sc * gy);
   }
   // --- CostGPTrajectory (cost_functions.py:532-542, gp_factor.py): e_t = s_{t+1} - Phi s_t, w_t = 2 Q^-1 e_t,
   //     g_t = w_{t-1} - Phi^T w_t
+  float gpx, gpy, gpz, gpw;
   {
-    const float npx = __shfl_down(px, 1), npy = __shfl_down(py, 1);
-    const float nvx = __shfl_down(vx, 1), nvy = __shfl_down(vy, 1);
+    const float npx = lane_next(px), npy = lane_next(py), nvx = lane_next(vx), nvy = lane_next(vy);
     float wpx = 0.f, wpy = 0.f, wvx = 0.f, wvy = 0.f;
     if (t < H - 1) {
       const float epx = npx - (px + g.dt * vx), epy = npy - (py + g.dt * vy);
@@ -117,30 +148,43 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
       wvx = 2.f * (g.m2 * epx + g.m3 * evx);
       wvy = 2.f * (g.m2 * epy + g.m3 * evy);
     }
-    float lpx = __shfl_up(wpx, 1), lpy = __shfl_up(wpy, 1), lvx = __shfl_up(wvx, 1), lvy = __shfl_up(wvy, 1);
-    if (t == 0) { lpx = lpy = lvx = lvy = 0.f; }
+    const float lpx = lane_prev(wpx), lpy = lane_prev(wpy), lvx = lane_prev(wvx), lvy = lane_prev(wvy);
     const float gx = lpx - wpx, gy = lpy - wpy;
     const float gz = lvx - (g.dt * wpx + wvx), gw = lvy - (g.dt * wpy + wvy);
     const float sc = clip_scale(gx, gy, gz, gw, g.max_norm);
-    if (interior) {
-      tx += g.w_smooth * (sc * gx); ty += g.w_smooth * (sc * gy);
-      tz += g.w_smooth * (sc * gz); tw += g.w_smooth * (sc * gw);
-    }
+    gpx = g.w_smooth * (sc * gx); gpy = g.w_smooth * (sc * gy);
+    gpz = g.w_smooth * (sc * gz); gpw = g.w_smooth * (sc * gw);
   }
-  // --- CostConstraint groups (cost_functions.py:297-326): -sum_{active, ||d|| <= R} d / ||d||
+  // --- CostConstraint groups: LDS-resident slots first, any overflow straight from the L2-resident table
+  float cx = 0.f, cy = 0.f;
   for (int grp = grp0; grp < grp1; ++grp) {
     const int s0 = g.grp_slot_off[grp], s1 = g.grp_slot_off[grp + 1];
     float gx = 0.f, gy = 0.f;
-    for (int s = s0; s < s1; ++s) {
-      const float4 c = g.cons[(size_t)s * H + t];
-      const float dx = px - c.x, dy = py - c.y;
-      const float dist = sqrtf(dx * dx + dy * dy);
-      if (c.z >= 0.f && !(dist > c.z)) { gx -= dx / dist; gy -= dy / dist; }
-    }
+    const int l0 = min(max(s0 - lds_slot0, 0), lds_n), l1 = min(max(s1 - lds_slot0, 0), lds_n);   // LDS part
+    if (l1 > l0) cons_accumulate(lds_cons + (size_t)l0 * H, l1 - l0, t, px, py, gx, gy);
+    const int g0 = lds_n > 0 ? max(s0, lds_slot0 + lds_n) : s0;                                    // global part
+    if (s1 > g0) cons_accumulate(g.cons + (size_t)g0 * H, s1 - g0, t, px, py, gx, gy);
     const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
     const float w = g.grp_weight[grp];
-    if (interior) { tx += w * (sc * gx); ty += w * (sc * gy); }
+    cx += w * (sc * gx); cy += w * (sc * gy);
   }
+  // --- CostCollision over the SDF grids: d/dp max_k relu(margin - sdf_k(p))  (t >= 1; field_factor.py range [1,None])
+  float ox, oy;
+  {
+    float best = fmaxf(g.margin - cell0.x, 0.f), gx = 0.f, gy = 0.f;
+    if (best > 0.f) { gx = -cell0.y; gy = -cell0.z; }
+    for (int k = 1; k < g.n_grids; ++k) {
+      const float4 c = grid[((size_t)k * g.nx + ix) * g.ny + iy];
+      const float v = fmaxf(g.margin - c.x, 0.f);
+      if (v > best) { best = v; gx = -c.y; gy = -c.z; }
+    }
+    const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
+    ox = g.w_coll * (sc * gx); oy = g.w_coll * (sc * gy);
+  }
+  // sum in the reference's cost order (objects, ws boundaries, GP, constraints), zero rows 0 / H-1, negate
+  float tx = ((ox + wsx) + gpx) + cx, ty = ((oy + wsy) + gpy) + cy;
+  float tz = gpz, tw = gpw;
+  if (!interior) { tx = ty = tz = tw = 0.f; }
   return make_float4(-tx, -ty, -tz, -tw);
 }
 
@@ -150,9 +194,28 @@ __global__ __launch_bounds__(256) void ddpm_guide_kernel(GuideDev g, StepDev s, 
                                                          const float4* __restrict__ noise, float4* __restrict__ chain,
                                                          const float4* __restrict__ hard,
                                                          int samples_per_robot) {
+  __shared__ float4 lds_cons[LDS_SLOTS * H];
   const int t = threadIdx.x & 63;
-  const int traj = s.traj0 + blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (traj >= s.traj_end) return;
+  const int traj_b = s.traj0 + blockIdx.x * 4;
+  const int traj = traj_b + (threadIdx.x >> 6);
+  const bool valid = traj < s.traj_end;
+
+  // constraint table of the workgroup's robot -> LDS (the 4 trajectories of a workgroup share a robot whenever
+  // samples_per_robot is a multiple of 4; otherwise every wave reads the L2-resident table directly)
+  int lds_slot0 = 0, lds_n = 0;
+  if (s.do_guide && g.robot_grp_off) {
+    const int rb0 = traj_b / samples_per_robot;
+    const int rb1 = min(traj_b + 3, s.traj_end - 1) / samples_per_robot;
+    if (rb0 == rb1) {
+      lds_slot0 = g.grp_slot_off[g.robot_grp_off[rb0]];
+      lds_n = min(g.grp_slot_off[g.robot_grp_off[rb0 + 1]] - lds_slot0, LDS_SLOTS);
+      const float4* src = g.cons + (size_t)lds_slot0 * H;
+      for (int i = threadIdx.x; i < lds_n * H; i += 256) lds_cons[i] = src[i];
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+
   const int robot = traj / samples_per_robot;
   const size_t idx = (size_t)traj * H + t;
   float4 v = x[idx];
@@ -181,7 +244,7 @@ __global__ __launch_bounds__(256) void ddpm_guide_kernel(GuideDev g, StepDev s, 
     int grp0 = 0, grp1 = 0;
     if (g.robot_grp_off) { grp0 = g.robot_grp_off[robot]; grp1 = g.robot_grp_off[robot + 1]; }
     for (int it = 0; it < s.n_guide_steps; ++it) {
-      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1);
+      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, lds_cons, lds_slot0, lds_n);
       v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w;
       if (is_start) v = hs;
       if (is_goal) v = hg;
