@@ -124,42 +124,60 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    lib = _lib.load()
+    import ctypes as C
+    nl = lib.mmd_unet_num_layers()
+    names = [lib.mmd_unet_layer_name(i).decode() for i in range(nl)]
+    dom = [i for i, nme in enumerate(names) if nme == DOMINANT_LAYER]
+    n_traj_local = RPG * B
+    flops = [lib.mmd_unet_layer_flops(i) * n_traj_local for i in range(nl)]
+
     for w in range(args.warmup):
         _, paths_local = sampler.plan_round(paths_local, seed=1000 + w)
+    # roofline of the dominant kernel: every one of its launches INSIDE the timed region is bracketed by a HIP event pair
+    # on the stream it is launched on (mmd_unet_profile_layer).  Every 13th of its 404 launches per step is bracketed
+    # (13 is coprime to 4, so all four call sites are sampled): ~31 event pairs per step, < 0.5 % of the timed region.
+    _lib.check(lib.mmd_unet_profile_layer(unet.handle(T), dom[0], len(dom) * (T + 1) * args.steps, 13))
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         trajs, paths_local = sampler.plan_round(paths_local, seed=k)
     barrier()
     dt = time.perf_counter() - t0
+    dom_ms_c, dom_n = C.c_double(), C.c_int()
+    _lib.check(lib.mmd_unet_profile_read(unet.handle(T), C.byref(dom_ms_c), C.byref(dom_n)))
+    _lib.check(lib.mmd_unet_profile_layer(unet.handle(T), -1, 0, 1))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(trajs).all()
-    n_traj_local = RPG * B
     value = args.steps * n_traj_local * world / dt
+    dom_ms = dom_ms_c.value
+    dom_tf = flops[dom[0]] / (dom_ms * 1e-3) / 1e12
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------------------
-    lib = _lib.load()
+    # per-layer picture of one forward (outside the timed region; each launch issued 5x back to back between events)
     x = torch.randn(n_traj_local, H, D, device=dev)
     eps = torch.empty_like(x)
     ws = unet.workspace(n_traj_local, dev)
-    nl = lib.mmd_unet_num_layers()
-    import ctypes as C
     ms = (C.c_float * nl)()
     _lib.check(lib.mmd_unet_profile(unet.handle(T), x.data_ptr(), T // 2, eps.data_ptr(), n_traj_local, ws.data_ptr(),
-                                    ws.numel(), 10, ms, _lib.current_stream_ptr()))
-    names = [lib.mmd_unet_layer_name(i).decode() for i in range(nl)]
-    flops = [lib.mmd_unet_layer_flops(i) * n_traj_local for i in range(nl)]
-    dom = [i for i, nme in enumerate(names) if nme == DOMINANT_LAYER]
-    dom_ms = float(np.mean([ms[i] for i in dom]))
-    dom_tf = flops[dom[0]] / (dom_ms * 1e-3) / 1e12
+                                    ws.numel(), 5, ms, _lib.current_stream_ptr()))
     fwd_ms = float(sum(ms))
     fwd_tf = sum(flops) / (fwd_ms * 1e-3) / 1e12
+    # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (separate runs; tools/gpu_round.sh), committed
+    # as profiles/pmc_latest.json: traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE half-count correction)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path) and n_traj_local == 2048:
+        with open(pmc_path) as f:
+            pmc = json.load(f).get(DOMINANT_LAYER)
+        if pmc:
+            traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
     roofline = {"bound": "mfma", "kernel": f"rtb_kernel<{DOMINANT_LAYER}> fused ResidualTemporalBlock(128->128, L=16): 2x[Conv1d k5 + GroupNorm + Mish] + time bias + residual",
                 "achieved": dom_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None, "launch_ms": dom_ms, "flops_per_launch": flops[dom[0]],
+                "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
+                "flops_per_launch": flops[dom[0]],
                 "unet_forward": {"ms": fwd_ms, "achieved": fwd_tf, "frac": fwd_tf / PEAK_FP32_MFMA_TFLOPS,
                                  "launches": nl, "flops": sum(flops)},
                 "per_layer_ms": {f"{i:02d}_{nme}": round(float(ms[i]), 4) for i, nme in enumerate(names)}}

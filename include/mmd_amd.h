@@ -68,6 +68,13 @@ const char* mmd_unet_layer_name(int i);
 double mmd_unet_layer_flops(int i);
 int mmd_unet_profile(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj, void* workspace_dev,
                      size_t workspace_bytes, int repeats, float* layer_ms, void* stream);
+/* In-loop profiling: bracket every launch of the kernel that runs layer `layer` (all launches of the same kernel
+ * instantiation) with a HIP event pair on its own stream, inside the normal mmd_unet_forward / mmd_p_sample_loop
+ * calls -- every `stride`-th such launch, up to max_launches (an event pair costs ~10 us of host/stream time, so the
+ * stride keeps the perturbation of the timed region below 0.5 %); layer < 0 switches it off.  After synchronising the stream, mmd_unet_profile_read returns
+ * the mean duration and the number of bracketed launches and rearms the pool. */
+int mmd_unet_profile_layer(mmd_unet_t unet, int layer, int max_launches, int stride);
+int mmd_unet_profile_read(mmd_unet_t unet, double* mean_ms, int* n_launches);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Guide  (replaces GuideManagerTrajectoriesWithVelocity.forward, mmd/models/diffusion_models/guides.py:180-226,
@@ -151,7 +158,7 @@ typedef struct mmd_sampler_desc {
   int32_t hard_mask;                        /* as in mmd_guide_steps */
   int32_t n_streams;                        /* mmd_p_sample_loop splits the robots into this many concurrent HIP
                                              * streams (forked from / joined to `stream`) so one chunk's staging and
-                                             * epilogues overlap the other's MFMA phases; 0 = auto, 1 = off */
+                                             * epilogues overlap the other's MFMA phases; 0 = auto (= 1), 1 = off */
 } mmd_sampler_desc;
 
 /* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop (UNet activations + the eps buffer). */

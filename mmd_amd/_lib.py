@@ -51,6 +51,8 @@ _SIGNATURES = {
     "mmd_unet_layer_flops": (C.c_double, [C.c_int]),
     "mmd_unet_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                    C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "mmd_unet_profile_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mmd_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mmd_pack_constraints": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "mmd_soft_constraints_from_paths": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,

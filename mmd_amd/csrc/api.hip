@@ -122,7 +122,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   // layer so both queues stay fed.  Robots are independent, so results are bit-identical to the unsplit run.
   int nch = s->n_streams;
   if (const char* e = getenv("MMD_AMD_STREAMS")) nch = atoi(e);
-  if (nch <= 0) nch = n >= 1024 ? 2 : 1;
+  if (nch <= 0) nch = 1;   // auto = off: 2 chunks measured +3 % only, and one stream keeps per-kernel accounting clean
   if (nch > kMaxChunks) nch = kMaxChunks;
   if (nch > n_robots) nch = n_robots;
   Streams& S = streams();

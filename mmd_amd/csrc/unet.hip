@@ -657,6 +657,10 @@ struct mmd_unet_s {
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
   ConvW down[2], up[2], fin;
   size_t fin_w1, fin_b1;
+  // in-loop profiling of ONE layer kind (mmd_unet_profile_layer): event pairs recorded around its launches
+  int prof_layer = -1, prof_stride = 1;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0, prof_seen = 0;
 };
 
 namespace mmd {
@@ -878,6 +882,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
 
 int mmd_unet_destroy(mmd_unet_t u) {
   if (!u) return 0;
+  for (auto& e : u->prof_ev) (void)hipEventDestroy(e);
   if (u->blob) (void)hipFree(u->blob);
   if (u->ttable) (void)hipFree(u->ttable);
   delete u;
@@ -891,6 +896,9 @@ size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) {
 constexpr int kNumLayers = 17;
 static const char* const kLayerNames[kNumLayers] = {"R_D00", "R_D01", "DN0", "R_D10", "R_D11", "DN1", "R_D20", "R_L16", "R_L16",
                                                     "R_L16", "R_U00", "R_U01", "UP0", "R_U10", "R_U11", "UP1", "FIN"};
+
+// launches that run the same kernel instantiation share a kind (index of the first such launch)
+static const int kLayerKind[kNumLayers] = {0, 1, 2, 3, 4, 5, 6, 7, 7, 7, 10, 11, 12, 13, 14, 15, 16};
 
 // algorithmic FLOPs per trajectory of each launch: sum over its convs of 2 * C_out * taps * C_in * L_out
 static constexpr double rtb_flops(double cin, double cout, double L) {
@@ -913,11 +921,15 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   int li = 0;
   // profiling (ev != nullptr): every launch is bracketed by events and issued `reps` times back to back (each launch
   // is a pure function of buffers it does not write), so the event overhead is amortised over the repeats
-#define MMD_L(...)                                          \
-  do {                                                      \
-    if (ev) (void)hipEventRecord(ev[li], st);               \
-    ++li;                                                   \
-    for (int _r = 0; _r < reps; ++_r) { __VA_ARGS__; }      \
+#define MMD_L(...)                                                                                   \
+  do {                                                                                               \
+    if (ev) (void)hipEventRecord(ev[li], st);                                                        \
+    const bool _p = !ev && u->prof_layer >= 0 && kLayerKind[li] == u->prof_layer &&                  \
+                    (u->prof_seen++ % u->prof_stride) == 0 && u->prof_used + 2 <= u->prof_ev.size(); \
+    if (_p) (void)hipEventRecord(u->prof_ev[u->prof_used], st);                                      \
+    ++li;                                                                                            \
+    for (int _r = 0; _r < reps; ++_r) { __VA_ARGS__; }                                               \
+    if (_p) { (void)hipEventRecord(u->prof_ev[u->prof_used + 1], st); u->prof_used += 2; }           \
   } while (0)
   float* P0 = (float*)ws;
   float* P1 = P0 + (size_t)n * ACT_FLOATS;
@@ -965,6 +977,35 @@ int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, voi
 int mmd_unet_num_layers(void) { return kNumLayers; }
 const char* mmd_unet_layer_name(int i) { return i >= 0 && i < kNumLayers ? kLayerNames[i] : ""; }
 double mmd_unet_layer_flops(int i) { return i >= 0 && i < kNumLayers ? kLayerFlops[i] : 0.0; }
+
+int mmd_unet_profile_layer(mmd_unet_t u, int layer, int max_launches, int stride) {
+  MMD_REQUIRE(u, "mmd_unet_profile_layer: NULL handle");
+  for (auto& e : u->prof_ev) (void)hipEventDestroy(e);
+  u->prof_ev.clear();
+  u->prof_used = u->prof_seen = 0;
+  u->prof_layer = -1;
+  u->prof_stride = stride > 0 ? stride : 1;
+  if (layer < 0) return 0;
+  MMD_REQUIRE(layer < kNumLayers && max_launches > 0, "mmd_unet_profile_layer: bad arguments");
+  u->prof_ev.resize((size_t)2 * max_launches);
+  for (auto& e : u->prof_ev) MMD_HIP_CHECK(hipEventCreate(&e));
+  u->prof_layer = kLayerKind[layer];
+  return 0;
+}
+
+int mmd_unet_profile_read(mmd_unet_t u, double* mean_ms, int* n_launches) {
+  MMD_REQUIRE(u && mean_ms && n_launches, "mmd_unet_profile_read: NULL argument");
+  double tot = 0.0;
+  int cnt = 0;
+  for (size_t i = 0; i + 1 < u->prof_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, u->prof_ev[i], u->prof_ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+  }
+  *mean_ms = cnt ? tot / cnt : 0.0;
+  *n_launches = cnt;
+  u->prof_used = 0;
+  return 0;
+}
 
 int mmd_unet_profile(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, int repeats,
                      float* layer_ms, void* stream) {
