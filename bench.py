@@ -31,7 +31,7 @@ import torch         # noqa: E402
 
 H, D = 64, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
-DOMINANT_LAYER = "R_L16"           # fused ResidualTemporalBlock 128->128 @ L16 (2 x conv5 + GN + Mish): 4 of the 17 launches
+DOMINANT_LAYER = "CH_D2"           # level-2 chain: downs.2 (2 RTBs) + mid_block1/2 @ L16, 128 ch: 55 % of all FLOPs, 1 of 6 launches
 
 
 def parse():
@@ -135,8 +135,8 @@ def main():
     for w in range(args.warmup):
         _, paths_local = sampler.plan_round(paths_local, seed=1000 + w)
     # roofline of the dominant kernel: every one of its launches INSIDE the timed region is bracketed by a HIP event pair
-    # on the stream it is launched on (mmd_unet_profile_layer).  Every 13th of its 404 launches per step is bracketed
-    # (13 is coprime to 4, so all four call sites are sampled): ~31 event pairs per step, < 0.5 % of the timed region.
+    # on the stream it is launched on (mmd_unet_profile_layer).  Every 13th of its 101 launches per step is bracketed
+    # (one launch per UNet forward): ~8 event pairs per step, < 0.5 % of the timed region.
     _lib.check(lib.mmd_unet_profile_layer(unet.handle(T), dom[0], len(dom) * (T + 1) * args.steps, 13))
     barrier()
     t0 = time.perf_counter()
@@ -174,7 +174,7 @@ def main():
             pmc = json.load(f).get(DOMINANT_LAYER)
         if pmc:
             traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
-    roofline = {"bound": "mfma", "kernel": f"rtb_kernel<{DOMINANT_LAYER}> fused ResidualTemporalBlock(128->128, L=16): 2x[Conv1d k5 + GroupNorm + Mish] + time bias + residual",
+    roofline = {"bound": "mfma", "kernel": f"chain_kernel<{DOMINANT_LAYER}> fused downs.2 + mid blocks: 4 ResidualTemporalBlocks (64->128, 3x 128->128) at L=16, each 2x[Conv1d k5 + GroupNorm + Mish] + time bias + residual",
                 "achieved": dom_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
                 "flops_per_launch": flops[dom[0]],

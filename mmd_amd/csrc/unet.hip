@@ -500,6 +500,248 @@ __global__ __launch_bounds__(256) void rtb_kernel(RtbArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// Level chain: RTB_0 (1x1-conv or identity residual; optional 2-tensor channel concat, staged K-chunk by K-chunk)
+// -> N_IDENT identity-residual RTBs -> optional Downsample1d / Upsample1d tail, for the SAME samples in ONE launch.
+// Blocks of consecutive layers depend only on each other sample-wise, so the whole chain stays inside the workgroup:
+// activations hop register tile -> LDS slab -> MFMA, never through HBM (only the skip connection and the chain output
+// are stored).  The residual of an identity RTB is the wave's own previous output tile, kept in registers.
+// ----------------------------------------------------------------------------------------------------------------
+enum { TAIL_NONE = 0, TAIL_DOWN = 1, TAIL_UP = 2 };
+constexpr int MAX_IDENT = 3;
+
+struct RtbPtrs {
+  const float4* wa; const float* ba; const float* ga; const float* bea; const float* tb;
+  const float4* wb; const float* bb; const float* gb; const float* beb;
+};
+
+struct ChainArgs {
+  const float* in0; const float* in1;   // [n, L, C0], [n, L, C1]
+  float* out;                            // TAIL_NONE [n, L, CM]; TAIL_DOWN [n, L/2, CM]; TAIL_UP [n, 2L, CM]
+  float* mid_out;                        // [n, L, CM] output of RTB number MID_AFTER (skip connection) or null
+  RtbPtrs r0;
+  const float4* wa0_c1;                  // conv A pack of the second input chunk (C1 > 0)
+  const float4* wr_c0; const float4* wr_c1; const float* br;   // residual 1x1 conv packs per chunk
+  RtbPtrs ri[MAX_IDENT];
+  const float4* wt; const float* bt;     // tail conv pack(s), bias
+  int n;
+};
+
+template <int C0_, int C1_, int CM_, int L_, int MT_W_, int RES0_, int N_IDENT_, int MID_AFTER_, int TAIL_>
+struct ChainCfg {
+  static constexpr int C0 = C0_, C1 = C1_, CM = CM_, L = L_, MT_W = MT_W_, RES0 = RES0_, N_IDENT = N_IDENT_;
+  static constexpr int MID_AFTER = MID_AFTER_, TAIL = TAIL_;
+  static constexpr int C0P = (C0 + 7) / 8 * 8, C1P = (C1 + 7) / 8 * 8;
+  static constexpr int CXP = C0P > C1P ? C0P : C1P;
+  static constexpr int XSTR = CXP + 1, HSTR = CM + 1;
+  static constexpr int WN = CM / 32, WM = 4 / WN;
+  static constexpr int RW = 32 * MT_W, SW = RW / L, SPB = WM * SW, SROWS = L + 4;
+  static constexpr bool SHARE = RES0 == RES_IDENT;         // x is staged straight into the H slab
+  static constexpr int XSLAB = SHARE ? 0 : SPB * SROWS * XSTR;
+  static constexpr int HSLAB = SPB * SROWS * HSTR;
+  static constexpr int LDS_FLOATS = XSLAB + HSLAB;
+  static_assert(CM % 32 == 0 && RW % L == 0 && L >= 16, "tile shape");
+  static_assert(!SHARE || (C0 == CM && C1 == 0), "identity residual needs C_in == C_out");
+  static_assert(TAIL != TAIL_DOWN || MT_W == 2, "the downsample tail maps a wave's 64 rows to one 32-row tile");
+  static_assert(N_IDENT <= MAX_IDENT, "too many identity RTBs");
+};
+
+template <int CM, int L, int MT_W, int SROWS, int HSTR, int SW>
+__device__ __forceinline__ void tile_to_slab(const f32x16 (&acc)[MT_W], float* hslab, int wm, int col, int hi) {
+#pragma unroll
+  for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int s = wm * SW + row / L, l = row % L;
+      hslab[(s * SROWS + l + 2) * HSTR + col] = acc[mt][r];
+    }
+}
+
+template <int MT_W>
+__device__ __forceinline__ void fill(f32x16 (&acc)[MT_W], float v) {
+#pragma unroll
+  for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = v;
+}
+
+template <class CF>
+__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[CF::LDS_FLOATS];
+  float* hslab = lds + CF::XSLAB;
+  float* xslab = CF::SHARE ? hslab : lds;
+  constexpr int XS = CF::SHARE ? CF::HSTR : CF::XSTR;      // row stride of the slab conv A reads
+  constexpr int MT_W = CF::MT_W;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / CF::WN, wn = wave % CF::WN;
+  const int n0 = blockIdx.x * CF::SPB;
+  const int col = wn * 32 + (lane & 31);
+  const int hi = lane >> 5;
+
+  if constexpr (CF::SHARE) {
+    stage_slab<CF::C0, 0, CF::CM, CF::L, CF::SROWS, 2, CF::HSTR, CF::SPB>(hslab, a.in0, nullptr, n0, a.n);
+  } else {
+    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB>(xslab, a.in0, nullptr, n0, a.n);
+    constexpr int TOT = CF::SPB * 4 * CF::CM;             // zero the halo rows of the H slab
+    for (int idx = threadIdx.x; idx < TOT; idx += 256) {
+      const int c = idx % CF::CM, hr = (idx / CF::CM) % 4, s = idx / (CF::CM * 4);
+      hslab[(s * CF::SROWS + (hr < 2 ? hr : CF::L + hr)) * CF::HSTR + c] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  int srow[MT_W], lrow[MT_W];
+#pragma unroll
+  for (int mt = 0; mt < MT_W; ++mt) {
+    const int r = mt * 32 + (lane & 31);
+    srow[mt] = wm * CF::SW + r / CF::L;
+    lrow[mt] = r % CF::L;
+  }
+  int hbase[MT_W];                                           // A-fragment base into the H slab (tap 0)
+#pragma unroll
+  for (int mt = 0; mt < MT_W; ++mt) hbase[mt] = (srow[mt] * CF::SROWS + lrow[mt]) * CF::HSTR + hi;
+
+  f32x16 acc[MT_W], res[MT_W];
+  // =================== RTB 0 ===================
+  {
+    int xbase[MT_W], rbase[MT_W];
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) {
+      xbase[mt] = (srow[mt] * CF::SROWS + lrow[mt]) * XS + hi;
+      rbase[mt] = xbase[mt] + 2 * XS;
+    }
+    fill<MT_W>(acc, a.r0.ba[col]);
+    mfma_taps<5, CF::C0P, XS, MT_W>(acc, xslab, xbase, a.r0.wa + ((size_t)wn * (5 * CF::C0P / 8)) * 64 + lane);
+    if constexpr (CF::RES0 == RES_CONV) {
+      fill<MT_W>(res, a.br[col]);
+      mfma_taps<1, CF::C0P, XS, MT_W>(res, xslab, rbase, a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane);
+    }
+    if constexpr (CF::C1 > 0) {                              // second half of the channel concat, same slab
+      __syncthreads();
+      stage_slab<CF::C1, 0, CF::C1P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB>(xslab, a.in1, nullptr, n0, a.n);
+      __syncthreads();
+      mfma_taps<5, CF::C1P, XS, MT_W>(acc, xslab, xbase, a.wa0_c1 + ((size_t)wn * (5 * CF::C1P / 8)) * 64 + lane);
+      if constexpr (CF::RES0 == RES_CONV)
+        mfma_taps<1, CF::C1P, XS, MT_W>(res, xslab, rbase, a.wr_c1 + ((size_t)wn * (CF::C1P / 8)) * 64 + lane);
+    }
+    gn_mish<CF::CM, CF::L, MT_W>(acc, a.r0.ga[col], a.r0.bea[col]);
+    {
+      const float tb = a.r0.tb[col];
+#pragma unroll
+      for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] += tb;
+    }
+    if constexpr (CF::SHARE) __syncthreads();                // every wave is done reading x before h overwrites it
+    tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
+    __syncthreads();
+    fill<MT_W>(acc, a.r0.bb[col]);
+    mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, a.r0.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
+    gn_mish<CF::CM, CF::L, MT_W>(acc, a.r0.gb[col], a.r0.beb[col]);
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (CF::RES0 == RES_CONV) {
+          acc[mt][r] += res[mt][r];
+        } else {                                             // identity residual of the chain input: from global / L2
+          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
+          if (n0 + s < a.n) acc[mt][r] += a.in0[((size_t)(n0 + s) * CF::L + l) * CF::CM + col];
+        }
+      }
+  }
+  auto store_tile = [&](float* dst) {
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
+        if (n0 + s < a.n) dst[((size_t)(n0 + s) * CF::L + l) * CF::CM + col] = acc[mt][r];
+      }
+  };
+  if (CF::MID_AFTER == 0 && a.mid_out) store_tile(a.mid_out);
+
+  // =================== identity RTBs ===================
+#pragma unroll
+  for (int k = 0; k < CF::N_IDENT; ++k) {
+    const RtbPtrs& R = a.ri[k];
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) res[mt] = acc[mt];     // this wave's tile of the RTB input = its residual
+    __syncthreads();                                         // the previous conv is done reading the H slab
+    tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
+    __syncthreads();
+    fill<MT_W>(acc, R.ba[col]);
+    mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wa + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
+    gn_mish<CF::CM, CF::L, MT_W>(acc, R.ga[col], R.bea[col]);
+    {
+      const float tb = R.tb[col];
+#pragma unroll
+      for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] += tb;
+    }
+    __syncthreads();
+    tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
+    __syncthreads();
+    fill<MT_W>(acc, R.bb[col]);
+    mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
+    gn_mish<CF::CM, CF::L, MT_W>(acc, R.gb[col], R.beb[col]);
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) acc[mt] += res[mt];
+    if (CF::MID_AFTER == k + 1 && a.mid_out) store_tile(a.mid_out);
+  }
+
+  // =================== tail ===================
+  if constexpr (CF::TAIL == TAIL_NONE) {
+    if (a.out) store_tile(a.out);
+  } else {
+    __syncthreads();
+    tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
+    __syncthreads();
+    const float bt = a.bt[col];
+    if constexpr (CF::TAIL == TAIL_DOWN) {
+      // Conv1d(k3, s2, p1): one 32-row tile per wave = its SW samples x L/2 output rows; tap 0 reads slab row 2*lo + 1
+      constexpr int LO = CF::L / 2;
+      f32x16 t[1];
+      fill<1>(t, bt);
+      const int r = lane & 31;
+      int tb_[1] = {((wm * CF::SW + r / LO) * CF::SROWS + 2 * (r % LO) + 1) * CF::HSTR + hi};
+      mfma_taps<3, CF::CM, CF::HSTR, 1>(t, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
+        const int s = wm * CF::SW + row / LO, lo = row % LO;
+        if (n0 + s < a.n) a.out[((size_t)(n0 + s) * LO + lo) * CF::CM + col] = t[0][q];
+      }
+    } else {
+      // ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes: out[2m] = in[m-1] W3 + in[m] W1, out[2m+1] = in[m] W2 + in[m+1] W0
+      constexpr int G = 2 * CF::CM / 8;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        f32x16 t[MT_W];
+        fill<MT_W>(t, bt);
+        int ub[MT_W];
+#pragma unroll
+        for (int mt = 0; mt < MT_W; ++mt) ub[mt] = hbase[mt] + (1 + pass) * CF::HSTR;
+        mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wn * G) * 64 + lane);
+#pragma unroll
+        for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
+            const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
+            if (n0 + s < a.n) a.out[((size_t)(n0 + s) * (2 * CF::L) + 2 * l + pass) * CF::CM + col] = t[mt][q];
+          }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // time embedding table: TimeEncoder (layers.py:232-258) + every block's cond_mlp (layers.py:337-341) for all integer t
 // ----------------------------------------------------------------------------------------------------------------
 struct TimeArgs {
@@ -620,8 +862,11 @@ static bool build_spec(int uid, int n_levels, Spec& s) {
 // Pack W(k, n), k = tap_slot * cinp + ci, into MFMA 32x32x2 B-fragment order:
 //   out[((nt*G + g)*64 + lane)*4 + q] = W(2*(4g+q) + (lane>>5), nt*32 + (lane&31))
 // conv weight layout [cout][cin][ks] (transposed == false) or ConvTranspose1d [cin][cout][ks] (transposed == true).
-static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin, int ks, const std::vector<int>& taps,
-                   bool transposed) {
+// c_lo..c_hi selects an input-channel sub-range (one K-chunk of a channel concat); cin is the tensor's full C_in.
+static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_full, int ks, const std::vector<int>& taps,
+                   bool transposed, int c_lo = 0, int c_hi = -1) {
+  if (c_hi < 0) c_hi = cin_full;
+  const int cin = c_hi - c_lo;
   const int cinp = (cin + 7) / 8 * 8;
   const int nt_n = (cout + 31) / 32;
   const int K = (int)taps.size() * cinp;
@@ -637,13 +882,14 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin, 
           const int tap = taps[k / cinp], ci = k % cinp;
           float v = 0.f;
           if (ci < cin && n < cout)
-            v = transposed ? w[((size_t)ci * cout + n) * ks + tap] : w[((size_t)n * cin + ci) * ks + tap];
+            v = transposed ? w[((size_t)(c_lo + ci) * cout + n) * ks + tap]
+                           : w[((size_t)n * cin_full + (c_lo + ci)) * ks + tap];
           blob[base + (((size_t)nt * G + g) * 64 + lane) * 4 + q] = v;
         }
 }
 
 struct ConvW { size_t wpk, bias, gamma, beta; };
-struct RtbW { ConvW a, b; size_t res_wpk, res_bias; int tb_off; };
+struct RtbW { ConvW a, b; size_t res_wpk, res_bias; int tb_off; size_t a_c1, res_c0, res_c1; };
 
 }  // namespace mmd
 
@@ -740,6 +986,45 @@ static RtbArgs args_rtb(const mmd_unet_s* u, const RtbW& w, const float* in0, co
   return a;
 }
 
+//                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
+using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
+using CH_D1 = ChainCfg<32, 0, 64, 32, 2, RES_CONV, 1, 1, TAIL_DOWN>;     // downs.1 (+ skip1 store)
+using CH_D2 = ChainCfg<64, 0, 128, 16, 2, RES_CONV, 3, 1, TAIL_NONE>;    // downs.2 + mid_block1/2 (+ skip2 store)
+using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.0: cat(x, skip2) RTB, RTB, Upsample1d
+using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
+
+template <class CF>
+static int launch_chain(const ChainArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(chain_kernel<CF>, dim3((a.n + CF::SPB - 1) / CF::SPB), dim3(256), 0, st, a);
+  return 0;
+}
+
+static RtbPtrs rtb_ptrs(const mmd_unet_s* u, const RtbW& w, int t) {
+  RtbPtrs p{};
+  p.wa = reinterpret_cast<const float4*>(u->blob + w.a.wpk);
+  p.ba = u->blob + w.a.bias; p.ga = u->blob + w.a.gamma; p.bea = u->blob + w.a.beta;
+  p.tb = u->ttable + (size_t)t * u->tb_total + w.tb_off;
+  p.wb = reinterpret_cast<const float4*>(u->blob + w.b.wpk);
+  p.bb = u->blob + w.b.bias; p.gb = u->blob + w.b.gamma; p.beb = u->blob + w.b.beta;
+  return p;
+}
+
+// chain over RTBs rtb[0] (first) and rtb[1..n_ident]; tail = down/up conv weights or null
+static ChainArgs args_chain(const mmd_unet_s* u, const int* rtb, int n_ident, const ConvW* tail, const float* in0,
+                            const float* in1, float* out, float* mid_out, int t, int n) {
+  ChainArgs a{};
+  a.in0 = in0; a.in1 = in1; a.out = out; a.mid_out = mid_out; a.n = n;
+  const RtbW& w0 = u->rtb[rtb[0]];
+  a.r0 = rtb_ptrs(u, w0, t);
+  a.wa0_c1 = reinterpret_cast<const float4*>(u->blob + w0.a_c1);
+  a.wr_c0 = reinterpret_cast<const float4*>(u->blob + w0.res_c0);
+  a.wr_c1 = reinterpret_cast<const float4*>(u->blob + w0.res_c1);
+  a.br = u->blob + w0.res_bias;
+  for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, u->rtb[rtb[1 + k]], t);
+  if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
+  return a;
+}
+
 static ConvArgs args_a(const mmd_unet_s* u, const RtbW& w, const float* in0, const float* in1, float* out, int t, int n) {
   ConvArgs a{};
   a.in0 = in0; a.in1 = in1; a.out = out;
@@ -833,6 +1118,17 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       W.res_wpk = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false);
       W.res_bias = push(blob, tensors[R.t_rb], R.cout);
     }
+    W.a_c1 = W.res_c0 = W.res_c1 = 0;
+    if (r == 6 || r == 8) {   // ups.0.0 / ups.1.0: input = cat(x, skip): per-chunk packs for the K-chunked staging
+      const int half = R.cin / 2;
+      // a.wpk is repacked as chunk 0 (channels [0, half)); chunk 1 follows
+      W.a.wpk = blob.size(); pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false, 0, half);
+      W.a_c1 = blob.size(); pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false, half, R.cin);
+      W.res_c0 = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false, 0, half);
+      W.res_c1 = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false, half, R.cin);
+    } else if (R.res) {
+      W.res_c0 = W.res_wpk;
+    }
     W.tb_off = tb_off;
     tb_off += R.cout;
   }
@@ -893,23 +1189,21 @@ size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) {
   return (size_t)4 * ACT_FLOATS * sizeof(float) * (size_t)(n_traj > 0 ? n_traj : 0);
 }
 
-constexpr int kNumLayers = 17;
-static const char* const kLayerNames[kNumLayers] = {"R_D00", "R_D01", "DN0", "R_D10", "R_D11", "DN1", "R_D20", "R_L16", "R_L16",
-                                                    "R_L16", "R_U00", "R_U01", "UP0", "R_U10", "R_U11", "UP1", "FIN"};
-
+constexpr int kNumLayers = 6;
+static const char* const kLayerNames[kNumLayers] = {"CH_D0", "CH_D1", "CH_D2", "CH_U0", "CH_U1", "FIN"};
 // launches that run the same kernel instantiation share a kind (index of the first such launch)
-static const int kLayerKind[kNumLayers] = {0, 1, 2, 3, 4, 5, 6, 7, 7, 7, 10, 11, 12, 13, 14, 15, 16};
+static const int kLayerKind[kNumLayers] = {0, 1, 2, 3, 4, 5};
 
 // algorithmic FLOPs per trajectory of each launch: sum over its convs of 2 * C_out * taps * C_in * L_out
 static constexpr double rtb_flops(double cin, double cout, double L) {
   return 2.0 * cout * 5 * cin * L + 2.0 * cout * 5 * cout * L + (cin != cout ? 2.0 * cout * cin * L : 0.0);
 }
 static const double kLayerFlops[kNumLayers] = {
-    rtb_flops(4, 32, 64), rtb_flops(32, 32, 64), 2.0 * 32 * 3 * 32 * 32,
-    rtb_flops(32, 64, 32), rtb_flops(64, 64, 32), 2.0 * 64 * 3 * 64 * 16,
-    rtb_flops(64, 128, 16), rtb_flops(128, 128, 16), rtb_flops(128, 128, 16), rtb_flops(128, 128, 16),
-    rtb_flops(256, 64, 16), rtb_flops(64, 64, 16), 2.0 * 64 * 4 * 64 * 16,
-    rtb_flops(128, 32, 32), rtb_flops(32, 32, 32), 2.0 * 32 * 4 * 32 * 32,
+    rtb_flops(4, 32, 64) + rtb_flops(32, 32, 64) + 2.0 * 32 * 3 * 32 * 32,
+    rtb_flops(32, 64, 32) + rtb_flops(64, 64, 32) + 2.0 * 64 * 3 * 64 * 16,
+    rtb_flops(64, 128, 16) + 3 * rtb_flops(128, 128, 16),
+    rtb_flops(256, 64, 16) + rtb_flops(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16,
+    rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32,
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64};
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
@@ -935,31 +1229,15 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   float* P1 = P0 + (size_t)n * ACT_FLOATS;
   float* S1 = P1 + (size_t)n * ACT_FLOATS;
   float* S2 = S1 + (size_t)n * ACT_FLOATS;
-  const RtbW* R = u->rtb;
-  // downs.0 @ L=64
-  MMD_L(launch_rtb<R_D00>(args_rtb(u, R[0], x, nullptr, P0, t, n), st));
-  MMD_L(launch_rtb<R_D01>(args_rtb(u, R[1], P0, nullptr, P1, t, n), st));
-  MMD_L(launch<DN0>(args_plain(u, u->down[0], P1, P0, n), st));
-  // downs.1 @ L=32
-  MMD_L(launch_rtb<R_D10>(args_rtb(u, R[2], P0, nullptr, P1, t, n), st));
-  MMD_L(launch_rtb<R_D11>(args_rtb(u, R[3], P1, nullptr, S1, t, n), st));
-  MMD_L(launch<DN1>(args_plain(u, u->down[1], S1, P0, n), st));
-  // downs.2 @ L=16
-  MMD_L(launch_rtb<R_D20>(args_rtb(u, R[4], P0, nullptr, P1, t, n), st));
-  MMD_L(launch_rtb<R_L16>(args_rtb(u, R[5], P1, nullptr, S2, t, n), st));
-  // mid
-  MMD_L(launch_rtb<R_L16>(args_rtb(u, R[10], S2, nullptr, P0, t, n), st));
-  MMD_L(launch_rtb<R_L16>(args_rtb(u, R[11], P0, nullptr, P1, t, n), st));
-  // ups.0 @ L=16: cat(x, skip2)
-  MMD_L(launch_rtb<R_U00>(args_rtb(u, R[6], P1, S2, P0, t, n), st));
-  MMD_L(launch_rtb<R_U01>(args_rtb(u, R[7], P0, nullptr, P1, t, n), st));
-  MMD_L(launch<UP0>(args_plain(u, u->up[0], P1, P0, n), st));
-  // ups.1 @ L=32: cat(x, skip1)
-  MMD_L(launch_rtb<R_U10>(args_rtb(u, R[8], P0, S1, P1, t, n), st));
-  MMD_L(launch_rtb<R_U11>(args_rtb(u, R[9], P1, nullptr, P0, t, n), st));
-  MMD_L(launch<UP1>(args_plain(u, u->up[1], P0, P1, n), st));
+  // state_dict RTB indices: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2 = 0..11
+  static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};
+  MMD_L(launch_chain<CH_D0>(args_chain(u, kD0, 1, &u->down[0], x, nullptr, P0, nullptr, t, n), st));   // -> [n,32,32]
+  MMD_L(launch_chain<CH_D1>(args_chain(u, kD1, 1, &u->down[1], P0, nullptr, P1, S1, t, n), st));        // -> [n,16,64], skip1
+  MMD_L(launch_chain<CH_D2>(args_chain(u, kD2, 3, nullptr, P1, nullptr, P0, S2, t, n), st));            // -> [n,16,128], skip2
+  MMD_L(launch_chain<CH_U0>(args_chain(u, kU0, 1, &u->up[0], P0, S2, P1, nullptr, t, n), st));          // -> [n,32,64]
+  MMD_L(launch_chain<CH_U1>(args_chain(u, kU1, 1, &u->up[1], P1, S1, P0, nullptr, t, n), st));          // -> [n,64,32]
   // final_conv
-  ConvArgs f = args_plain(u, u->fin, P1, eps, n);
+  ConvArgs f = args_plain(u, u->fin, P0, eps, n);
   f.gamma = u->blob + u->fin.gamma; f.beta = u->blob + u->fin.beta;
   f.res_wpk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
   f.res_bias = u->blob + u->fin_b1;

@@ -136,9 +136,9 @@ def test_single_step_teacher_forced_golden(name):
 def test_run_inference_golden(name):
     """End-to-end chain against the reference.  The guided sampler is CHAOTIC: the genuine reference, run twice on
     CPU with its UNet output perturbed by a relative 1e-6 (a different fp32 summation order), differs from itself by
-    `sens` (stored in the fixture by tools/make_golden.py: 1e-1..3e-1 rel. L2 on the constraint cases, 7e-7 for the
-    unguided prior).  So the bound is max(1e-3, 3 * sens): the north-star 1e-3 wherever the reference itself is that
-    reproducible, and "no worse than any other fp32 implementation" elsewhere."""
+    `sens` (max over 6 perturbation draws, stored in the fixture by tools/make_golden.py: 1e-1..3e-1 rel. L2 on the
+    constraint cases, 7e-7 for the unguided prior).  So the bound is max(1e-3, 4 * sens): the north-star 1e-3 wherever
+    the reference itself is that reproducible, and "no worse than any other fp32 implementation" elsewhere."""
     g = np.load(os.path.join(GOLDEN, f"g6_sample_{name}.npz"))
     case = cases.sample_case(name)
     xT, steps = cases.sample_inputs(case)
@@ -148,7 +148,7 @@ def test_run_inference_golden(name):
     ref = torch.from_numpy(g["chain_rows"])
     for k, r in enumerate(g["rows"]):
         err = rel_l2(chain[int(r)], ref[k])
-        assert err < max(TOL_FINAL, 3.0 * float(g["sens"][k])), (name, int(r), err, float(g["sens"][k]))
+        assert err < max(TOL_FINAL, 4.0 * float(g["sens"][k])), (name, int(r), err, float(g["sens"][k]))
     if not case.get("use_guide", True) or name in ("cfg0_T50_B1", "empty_T25_nocons"):
         assert rel_l2(chain[-1], ref[-1]) < 3e-3
 
@@ -176,7 +176,7 @@ def test_run_local_inference_golden():
     # the reference's own sensitivity to a 1e-6 UNet perturbation
     for r in range(5):
         err = rel_l2(chain[r], ref[r])
-        assert err < (2e-5 if r == 0 else max(TOL_FINAL, 3.0 * float(g["sens"][r]))), (r, err, g["sens"])
+        assert err < (2e-5 if r == 0 else max(TOL_FINAL, 4.0 * float(g["sens"][r]))), (r, err, g["sens"])
     # teacher-forced: each single step from the reference's own state
     hc = cases.hard_conds_for(starts[3], goals[3])
     for r in range(4):
