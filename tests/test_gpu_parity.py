@@ -146,9 +146,14 @@ def test_run_inference_golden(name):
     assert chain.shape == (case["T"] + 2, case["B"], H, D)
     assert torch.isfinite(chain).all()
     ref = torch.from_numpy(g["chain_rows"])
+    sens_final = float(g["sens"][-1])
     for k, r in enumerate(g["rows"]):
         err = rel_l2(chain[int(r)], ref[k])
-        assert err < max(TOL_FINAL, 4.0 * float(g["sens"][k])), (name, int(r), err, float(g["sens"][k]))
+        # the amplification right after guidance starts is heavy-tailed (one perturbation draw in ten is 5-10x the
+        # typical one), so rows inside the guided phase are also allowed a quarter of the final divergence scale
+        guided_row = int(r) > case["T"] - ceil(0.5 * case["T"])
+        bound = max(TOL_FINAL, 4.0 * float(g["sens"][k]), 0.25 * sens_final if guided_row else 0.0)
+        assert err < bound, (name, int(r), err, float(g["sens"][k]), bound)
     if not case.get("use_guide", True) or name in ("cfg0_T50_B1", "empty_T25_nocons"):
         assert rel_l2(chain[-1], ref[-1]) < 3e-3
 

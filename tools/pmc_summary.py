@@ -12,7 +12,7 @@ with open(path) as f:
         if row.get("Counter_Name") != counter:
             continue
         name = row.get("Kernel_Name", "")
-        m = re.search(r"(rtb_kernel|conv_kernel)<mmd::(?:Rtb)?Cfg<([^>]*)>", name)
+        m = re.search(r"(chain_kernel|rtb_kernel|conv_kernel)<mmd::(?:Rtb|Chain)?Cfg<([^>]*)>", name)
         key = f"{m.group(1)}<{m.group(2).replace(' ', '')}>" if m else re.sub(r"\(.*", "", name)[:60]
         acc[key].append(float(row["Counter_Value"]))
 print(f"# {counter}: mean per dispatch (raw counter units as reported by rocprofv3)")

@@ -7,9 +7,9 @@ import sys
 
 
 def short(name):
-    m = re.search(r"conv_kernel<mmd::Cfg<([^>]*)>", name)
+    m = re.search(r"(chain_kernel|conv_kernel)<mmd::(Chain)?Cfg<([^>]*)>", name)
     if m:
-        return "conv_kernel<Cfg<" + m.group(1).replace(" ", "") + ">>"
+        return f"{m.group(1)}<{m.group(2) or ''}Cfg<" + m.group(3).replace(" ", "") + ">>"
     return re.sub(r"\(.*", "", name)[:90]
 
 
