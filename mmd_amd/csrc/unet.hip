@@ -366,140 +366,6 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Fused ResidualTemporalBlock (layers.py:346-358): out = Mish(GN(conv5(Mish(GN(conv5(x))) + tbias))) + res(x) in ONE
-// launch.  h never leaves the CU: conv A's epilogue writes it (from the MFMA accumulators) into an LDS slab that conv
-// B reads.  For identity residuals (C_in == C_out) h overwrites the x slab (x is re-read from global for the final
-// add); for 1x1-conv residuals the x slab is kept and feeds a third MFMA pass.
-// ----------------------------------------------------------------------------------------------------------------
-struct RtbArgs {
-  const float* in0; const float* in1;   // [n, L, C0], [n, L, C1]
-  float* out;                            // [n, L, COUT]
-  const float4* wa; const float* ba; const float* ga; const float* bea; const float* tbias;
-  const float4* wb; const float* bb; const float* gb; const float* beb;
-  const float4* wr; const float* br;     // residual 1x1 conv (RES_CONV)
-  int n;
-};
-
-template <int C0_, int C1_, int COUT_, int L_, int MT_W_, int RES_>
-struct RtbCfg {
-  static constexpr int C0 = C0_, C1 = C1_, COUT = COUT_, L = L_, MT_W = MT_W_, RES = RES_;
-  static constexpr int CIN = C0 + C1;
-  static constexpr int CINP = (CIN + 7) / 8 * 8;
-  static constexpr int XSTR = CINP + 1, HSTR = COUT + 1;
-  static constexpr int WN = COUT / 32, WM = 4 / WN;
-  static constexpr int RW = 32 * MT_W, SW = RW / L, SPB = WM * SW;
-  static constexpr int SROWS = L + 4;
-  static constexpr int XSLAB = SPB * SROWS * XSTR, HSLAB = SPB * SROWS * HSTR;
-  static constexpr bool SHARE = RES == RES_IDENT;          // h overwrites x
-  static constexpr int LDS_FLOATS = SHARE ? XSLAB : XSLAB + HSLAB;
-  static_assert(!SHARE || CIN == COUT, "identity residual needs C_in == C_out");
-  static_assert(COUT % 32 == 0 && RW % L == 0 && L >= 16, "tile shape");
-};
-
-template <class CF>
-__global__ __launch_bounds__(256) void rtb_kernel(RtbArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[CF::LDS_FLOATS];
-  float* xslab = lds;
-  float* hslab = CF::SHARE ? lds : lds + CF::XSLAB;
-#ifdef MMD_PRIO
-  // Co-resident workgroups start in lockstep (same code, same start time), so their MFMA phases collide and their
-  // epilogues leave the matrix pipe idle together.  Giving every other "wave" of workgroups (blocks b and b + 256 share
-  // a CU under the observed round-robin placement; only speed depends on it) a higher issue priority staggers them.
-  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(MMD_PRIO);
-#endif
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave / CF::WN, wn = wave % CF::WN;
-  const int n0 = blockIdx.x * CF::SPB;
-  const int col = wn * 32 + (lane & 31);
-  const int hi = lane >> 5;
-
-  stage_slab<CF::C0, CF::C1, CF::CINP, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB>(xslab, a.in0, a.in1, n0, a.n);
-  if constexpr (!CF::SHARE) {   // zero the halo rows of the h slab
-    constexpr int TOT = CF::SPB * 4 * CF::COUT;
-    for (int idx = threadIdx.x; idx < TOT; idx += 256) {
-      const int c = idx % CF::COUT, hr = (idx / CF::COUT) % 4, s = idx / (CF::COUT * 4);
-      hslab[(s * CF::SROWS + (hr < 2 ? hr : CF::L + hr)) * CF::HSTR + c] = 0.f;
-    }
-  }
-  __syncthreads();
-
-  int srow[CF::MT_W], lrow[CF::MT_W];
-#pragma unroll
-  for (int mt = 0; mt < CF::MT_W; ++mt) {
-    const int r = mt * 32 + (lane & 31);
-    srow[mt] = wm * CF::SW + r / CF::L;
-    lrow[mt] = r % CF::L;
-  }
-
-  f32x16 acc[CF::MT_W];
-  // ---- block 0: conv5(x) -> GN -> Mish -> + time bias --------------------------------------------------------
-  {
-    const float bias = a.ba[col];
-#pragma unroll
-    for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = bias;
-    int abase[CF::MT_W];
-#pragma unroll
-    for (int mt = 0; mt < CF::MT_W; ++mt) abase[mt] = (srow[mt] * CF::SROWS + lrow[mt]) * CF::XSTR + hi;
-    constexpr int G = 5 * CF::CINP / 8;
-    mfma_taps<5, CF::CINP, CF::XSTR, CF::MT_W>(acc, xslab, abase, a.wa + ((size_t)wn * G) * 64 + lane);
-    gn_mish<CF::COUT, CF::L, CF::MT_W>(acc, a.ga[col], a.bea[col]);
-    const float tb = a.tbias[col];
-    if constexpr (CF::SHARE) __syncthreads();   // every wave is done reading x before h overwrites it
-#pragma unroll
-    for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
-        hslab[(s * CF::SROWS + l + 2) * CF::HSTR + col] = acc[mt][r] + tb;
-      }
-    __syncthreads();
-  }
-  // ---- block 1: conv5(h) -> GN -> Mish -> + residual ----------------------------------------------------------
-  {
-    const float bias = a.bb[col];
-#pragma unroll
-    for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = bias;
-    int abase[CF::MT_W];
-#pragma unroll
-    for (int mt = 0; mt < CF::MT_W; ++mt) abase[mt] = (srow[mt] * CF::SROWS + lrow[mt]) * CF::HSTR + hi;
-    constexpr int G = 5 * CF::COUT / 8;
-    mfma_taps<5, CF::COUT, CF::HSTR, CF::MT_W>(acc, hslab, abase, a.wb + ((size_t)wn * G) * 64 + lane);
-    gn_mish<CF::COUT, CF::L, CF::MT_W>(acc, a.gb[col], a.beb[col]);
-    if constexpr (CF::RES == RES_CONV) {
-      const float rb = a.br[col];
-#pragma unroll
-      for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] += rb;
-      int rbase[CF::MT_W];
-#pragma unroll
-      for (int mt = 0; mt < CF::MT_W; ++mt) rbase[mt] = (srow[mt] * CF::SROWS + lrow[mt] + 2) * CF::XSTR + hi;
-      mfma_taps<1, CF::CINP, CF::XSTR, CF::MT_W>(acc, xslab, rbase, a.wr + ((size_t)wn * (CF::CINP / 8)) * 64 + lane);
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
-      if (n0 + s < a.n) {
-        const size_t o = ((size_t)(n0 + s) * CF::L + l) * CF::COUT + col;
-        float v = acc[mt][r];
-        if constexpr (CF::RES == RES_IDENT) v += a.in0[o];
-        a.out[o] = v;
-      }
-    }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
 // Level chain: RTB_0 (1x1-conv or identity residual; optional 2-tensor channel concat, staged K-chunk by K-chunk)
 // -> N_IDENT identity-residual RTBs -> optional Downsample1d / Upsample1d tail, for the SAME samples in ONE launch.
 // Blocks of consecutive layers depend only on each other sample-wise, so the whole chain stays inside the workgroup:
@@ -928,63 +794,7 @@ static int launch(const ConvArgs& a, hipStream_t st) {
 
 // ---- the instantiated layer shapes (unet_input_dim 32, dim_mults (1,2,4), H = 64) ------------------------------
 //                 C0   C1  COUT LIN  MODE        MT_W EPI           RES        RC0  RC1
-using D00A = Cfg<4, 0, 32, 64, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
-using D00B = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_RES, RES_CONV, 4, 0>;
-using L64A = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
-using L64B = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
-using DN0 = Cfg<32, 0, 32, 64, MODE_DOWN, 1, EPI_PLAIN, RES_NONE, 0, 0>;
-using D10A = Cfg<32, 0, 64, 32, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
-using D10B = Cfg<64, 0, 64, 32, MODE_CONV5, 2, EPI_GN_RES, RES_CONV, 32, 0>;
-using L32A = Cfg<64, 0, 64, 32, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
-using L32B = Cfg<64, 0, 64, 32, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
-using DN1 = Cfg<64, 0, 64, 32, MODE_DOWN, 1, EPI_PLAIN, RES_NONE, 0, 0>;
-using D20A = Cfg<64, 0, 128, 16, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
-using D20B = Cfg<128, 0, 128, 16, MODE_CONV5, 2, EPI_GN_RES, RES_CONV, 64, 0>;
-using L16A = Cfg<128, 0, 128, 16, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
-using L16B = Cfg<128, 0, 128, 16, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
-using U00A = Cfg<128, 128, 64, 16, MODE_CONV5, 1, EPI_GN_TB, RES_NONE, 0, 0>;
-using U00B = Cfg<64, 0, 64, 16, MODE_CONV5, 1, EPI_GN_RES, RES_CONV, 128, 128>;
-using U01A = Cfg<64, 0, 64, 16, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
-using U01B = Cfg<64, 0, 64, 16, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
-using UP0 = Cfg<64, 0, 64, 16, MODE_UP, 1, EPI_PLAIN, RES_NONE, 0, 0>;
-using U10A = Cfg<64, 64, 32, 32, MODE_CONV5, 1, EPI_GN_TB, RES_NONE, 0, 0>;
-using U10B = Cfg<32, 0, 32, 32, MODE_CONV5, 1, EPI_GN_RES, RES_CONV, 64, 64>;
-using U11A = Cfg<32, 0, 32, 32, MODE_CONV5, 2, EPI_GN_TB, RES_NONE, 0, 0>;
-using U11B = Cfg<32, 0, 32, 32, MODE_CONV5, 2, EPI_GN_RES, RES_IDENT, 0, 0>;
-using UP1 = Cfg<32, 0, 32, 32, MODE_UP, 1, EPI_PLAIN, RES_NONE, 0, 0>;
 using FIN = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_FINAL, RES_NONE, 0, 0>;
-
-//                  C0   C1  COUT  L  MT_W RES
-using R_D00 = RtbCfg<4, 0, 32, 64, 2, RES_CONV>;
-using R_D01 = RtbCfg<32, 0, 32, 64, 2, RES_IDENT>;
-using R_D10 = RtbCfg<32, 0, 64, 32, 2, RES_CONV>;
-using R_D11 = RtbCfg<64, 0, 64, 32, 2, RES_IDENT>;
-using R_D20 = RtbCfg<64, 0, 128, 16, 2, RES_CONV>;
-using R_L16 = RtbCfg<128, 0, 128, 16, 2, RES_IDENT>;
-using R_U00 = RtbCfg<128, 128, 64, 16, 1, RES_CONV>;
-using R_U01 = RtbCfg<64, 0, 64, 16, 2, RES_IDENT>;
-using R_U10 = RtbCfg<64, 64, 32, 32, 1, RES_CONV>;
-using R_U11 = RtbCfg<32, 0, 32, 32, 2, RES_IDENT>;
-
-template <class CF>
-static int launch_rtb(const RtbArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(rtb_kernel<CF>, dim3((a.n + CF::SPB - 1) / CF::SPB), dim3(256), 0, st, a);
-  return 0;
-}
-
-static RtbArgs args_rtb(const mmd_unet_s* u, const RtbW& w, const float* in0, const float* in1, float* out, int t, int n) {
-  RtbArgs a{};
-  a.in0 = in0; a.in1 = in1; a.out = out;
-  a.wa = reinterpret_cast<const float4*>(u->blob + w.a.wpk);
-  a.ba = u->blob + w.a.bias; a.ga = u->blob + w.a.gamma; a.bea = u->blob + w.a.beta;
-  a.tbias = u->ttable + (size_t)t * u->tb_total + w.tb_off;
-  a.wb = reinterpret_cast<const float4*>(u->blob + w.b.wpk);
-  a.bb = u->blob + w.b.bias; a.gb = u->blob + w.b.gamma; a.beb = u->blob + w.b.beta;
-  a.wr = reinterpret_cast<const float4*>(u->blob + w.res_wpk);
-  a.br = u->blob + w.res_bias;
-  a.n = n;
-  return a;
-}
 
 //                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
 using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
@@ -1022,29 +832,6 @@ static ChainArgs args_chain(const mmd_unet_s* u, const int* rtb, int n_ident, co
   a.br = u->blob + w0.res_bias;
   for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, u->rtb[rtb[1 + k]], t);
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
-  return a;
-}
-
-static ConvArgs args_a(const mmd_unet_s* u, const RtbW& w, const float* in0, const float* in1, float* out, int t, int n) {
-  ConvArgs a{};
-  a.in0 = in0; a.in1 = in1; a.out = out;
-  a.wpk = reinterpret_cast<const float4*>(u->blob + w.a.wpk);
-  a.bias = u->blob + w.a.bias; a.gamma = u->blob + w.a.gamma; a.beta = u->blob + w.a.beta;
-  a.tbias = u->ttable + (size_t)t * u->tb_total + w.tb_off;
-  a.n = n;
-  return a;
-}
-
-static ConvArgs args_b(const mmd_unet_s* u, const RtbW& w, const float* h, const float* res0, const float* res1,
-                       float* out, int n) {
-  ConvArgs a{};
-  a.in0 = h; a.out = out;
-  a.wpk = reinterpret_cast<const float4*>(u->blob + w.b.wpk);
-  a.bias = u->blob + w.b.bias; a.gamma = u->blob + w.b.gamma; a.beta = u->blob + w.b.beta;
-  a.res0 = res0; a.res1 = res1;
-  a.res_wpk = reinterpret_cast<const float4*>(u->blob + w.res_wpk);
-  a.res_bias = u->blob + w.res_bias;
-  a.n = n;
   return a;
 }
 

@@ -33,6 +33,11 @@ def all_gather_paths(paths_local, world_size, group=None):
     if world_size == 1:
         return paths_local
     import torch.distributed as dist
+    if paths_local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device collectives: stage through the host (CPU tests / single-GPU rehearsal of the N>1 path)
+        parts = [torch.empty_like(paths_local, device="cpu") for _ in range(world_size)]
+        dist.all_gather(parts, paths_local.cpu().contiguous(), group=group)
+        return torch.cat(parts, dim=0).to(paths_local.device)
     out = torch.empty((world_size * paths_local.shape[0],) + tuple(paths_local.shape[1:]), dtype=paths_local.dtype,
                       device=paths_local.device)
     dist.all_gather_into_tensor(out, paths_local.contiguous(), group=group)

@@ -1,0 +1,110 @@
+"""-m gpu: BASELINE.json's full sizes (32 robots x 64 samples, H=64, T=100) through size-independent properties,
+plus a spot check of the (well-conditioned) prior against the oracle on a random subset of the 2048 trajectories."""
+from math import ceil
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmd_amd import synth                # noqa: E402
+from oracle import mmd_oracle as O       # noqa: E402
+import cases                             # noqa: E402
+from cases import H, D, rel_l2           # noqa: E402
+
+R, B, T = 32, 64, 100
+
+
+@pytest.fixture(scope="module")
+def headline():
+    import gpu_common
+    from mmd_amd.multi_robot import MultiRobotSampler
+    model = gpu_common.hip_model(T)
+    starts, goals = synth.start_goal_circle(R, 0.8)
+    s = MultiRobotSampler(model, starts, goals, env_id="EnvEmpty2D", n_samples=B)
+    paths = torch.from_numpy(synth.straight_line_paths(starts, goals, H)).cuda()
+    return model, s, starts, goals, paths
+
+
+def test_headline_round_properties(headline):
+    model, s, starts, goals, paths = headline
+    s.set_other_paths(paths)
+    a = s.sample(seed=11)
+    assert a.shape == (R * B, H, D) and torch.isfinite(a).all()
+    # determinism per seed, sensitivity to the seed
+    assert torch.equal(a, s.sample(seed=11)) and not torch.equal(a, s.sample(seed=12))
+    # hard conditioning: rows 0 / H-1 are exactly the normalised start / goal of the robot that owns the sample
+    hs = s.hard_conds[0].repeat_interleave(B, 0)
+    hg = s.hard_conds[H - 1].repeat_interleave(B, 0)
+    assert torch.equal(a[:, 0], hs) and torch.equal(a[:, -1], hg)
+    # the sampler stays in the normalised box up to the guide's step size
+    assert float(a.abs().max()) < 1.5
+    # best-path pick + the all-pairs constraint table round trip
+    bp = s.best_paths(a)
+    assert bp.shape == (R, H, 2) and torch.allclose(bp[:, 0].cpu(), torch.from_numpy(starts), atol=1e-5)
+
+
+def test_headline_batched_equals_sharded(headline):
+    """The property the multi-GPU sharding relies on, at full size: sampling robots [8,16) alone (as rank 1 of 4 would)
+    gives bit-identical trajectories to the same robots inside the 32-robot batch (Philox noise is keyed by the global
+    trajectory index only when the shard offsets are equal, so inject the noise)."""
+    model, s, starts, goals, paths = headline
+    from mmd_amd.multi_robot import MultiRobotSampler
+    Ts = 25                                   # short schedule keeps the injected-noise tensor small
+    import gpu_common
+    m25 = gpu_common.hip_model(Ts)
+    full = MultiRobotSampler(m25, starts, goals, env_id="EnvEmpty2D", n_samples=B)
+    part = MultiRobotSampler(m25, starts, goals, env_id="EnvEmpty2D", n_samples=B, rank=1, world_size=4)
+    full.set_other_paths(paths)
+    part.set_other_paths(paths)
+    xT = torch.from_numpy(synth.synth_noise(80, (R * B, H, D))).cuda()
+    steps = torch.from_numpy(synth.synth_noise(81, (Ts + 1, R * B, H, D))).cuda()
+    a = full.sample(x_init=xT, step_noise=steps)
+    sl = slice(part.robot0 * B, (part.robot0 + part.n_local) * B)
+    b = part.sample(x_init=xT[sl].contiguous(), step_noise=steps[:, sl].contiguous())
+    assert torch.equal(a[sl], b)
+
+
+def test_headline_prior_spot_check_vs_oracle(headline):
+    """planner_alg 'diffusion_prior' at full size: the unguided chain is well conditioned (sens 7e-7), so 6 of the 2048
+    trajectories are compared with the oracle end to end at the north-star tolerance."""
+    model, s, starts, goals, paths = headline
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    xT = torch.from_numpy(synth.synth_noise(82, (R * B, H, D)))
+    steps = torch.from_numpy(synth.synth_noise(83, (T + 1, R * B, H, D)))
+    out = model.run_inference(None, s.hard_conds, n_samples=B, n_robots=R, horizon=H, return_chain=False,
+                              sample_fn=ddpm_sample_fn, guide=None, noise_std_extra_schedule_fn=lambda t: 0.5,
+                              n_diffusion_steps_without_noise=1, warm_start_path_b=xT.cuda(), step_noise=steps.cuda()).cpu()
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    tb = O.schedule_tables(T)
+    rng = np.random.Generator(np.random.PCG64(7))
+    for idx in rng.choice(R * B, size=6, replace=False):
+        r = int(idx) // B
+        hc = cases.hard_conds_for(starts[r], goals[r])
+        ref = O.p_sample_loop(sd, tb, xT[idx:idx + 1], hc, T, steps[:, idx:idx + 1], guide=None, noise_std_extra=0.5,
+                              n_diffusion_steps_without_noise=1)[-1]
+        assert rel_l2(out[idx:idx + 1], ref) < 1e-3, (int(idx), rel_l2(out[idx:idx + 1], ref))
+
+
+def test_guide_zero_weights_is_identity(headline):
+    """Idempotence-type property: with every gradient weight at 0 the guide leaves x untouched (only hard conditioning)."""
+    import gpu_common
+    from mmd_amd.guides import GuideManagerTrajectoriesWithVelocity
+    g = GuideManagerTrajectoriesWithVelocity(gpu_common.dataset(), env_id="EnvHighways2D", n_robots=4,
+                                             weight_grad_cost_collision=0.0, weight_grad_cost_smoothness=0.0)
+    x = (torch.from_numpy(synth.synth_noise(84, (4 * B, H, D))) * 0.7).cuda()
+    y = x.clone()
+    g.guide_steps(y, torch.zeros(4, 2, D, device="cuda"), 0, 20)
+    assert torch.equal(x, y)
+
+
+def test_large_batch_and_ragged_tail():
+    """8192 trajectories (4 waves of workgroups) and a batch that is not a multiple of the 4-sample workgroup tile."""
+    import gpu_common
+    model = gpu_common.hip_model(T)
+    x = torch.from_numpy(synth.synth_noise(85, (8192 + 3, H, D))).cuda()
+    big = model.model(x, 17)
+    assert torch.isfinite(big).all()
+    small = model.model(x[4096:4096 + 7].contiguous(), 17)
+    assert torch.equal(big[4096:4096 + 7], small)          # per-sample results do not depend on the batch they sit in
