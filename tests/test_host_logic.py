@@ -105,3 +105,20 @@ def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_postprocess_vs_reference_g9():
+    """SURVEY §8f-2 pinned: collision / free split, smoothness, path length and SavGol smoothing against the reference's
+    PlanningTask.get_trajs_collision_and_free / metrics / smooth_trajs on a Highways batch (tests/golden/g9_post.npz)."""
+    from mmd_amd.postprocess import (compute_path_length, compute_smoothness, get_trajs_collision_and_free,
+                                     smooth_trajs)
+    g = np.load(os.path.join(GOLDEN, "g9_post.npz"))
+    trajs = torch.from_numpy(g["trajs"])
+    coll, coll_idxs, free, free_idxs, wp = get_trajs_collision_and_free(trajs, "EnvHighways2D")
+    assert free_idxs.reshape(-1).tolist() == g["free_idxs"].tolist()
+    assert sorted(coll_idxs.reshape(-1).tolist()) == sorted(g["coll_idxs"].tolist())
+    assert np.array_equal(wp.numpy(), g["waypoint_collisions"])
+    assert free.shape[0] == len(g["free_idxs"]) and coll.shape[0] == len(g["coll_idxs"])
+    assert np.allclose(compute_smoothness(trajs).numpy(), g["smoothness"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(compute_path_length(trajs).numpy(), g["path_length"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(smooth_trajs(trajs).numpy(), g["smoothed"], rtol=1e-6, atol=1e-7)

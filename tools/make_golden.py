@@ -14,6 +14,7 @@ Fixtures:
   g6_sample_*.npz      run_inference chains with injected noise
   g7_local.npz         run_local_inference (3 noising / 3 denoising steps)
   g8_ensemble.npz      2-tile DiffusionsEnsemble.run_inference
+  g9_post.npz          post-sampling selection: collision/free split, smoothness, path length, SavGol smoothing
 """
 import os
 import sys
@@ -318,11 +319,37 @@ def g8():
                         meta=np.array([T, B, 26, 27, 28]))
 
 
+def g9():
+    """Post-sampling selection: PlanningTask.get_trajs_collision_and_free (tasks.py:236-311),
+    compute_smoothness / compute_path_length (trajectory/metrics.py:7-39), smooth_trajs (trajectory_utils.py:31-40) on
+    a Highways batch: the reference's own final samples of case (b) + straight lines that cross obstacles / leave the map."""
+    from torch_robotics.trajectory.metrics import compute_path_length, compute_smoothness
+    from mmd.common.trajectory_utils import smooth_trajs
+    g = np.load(os.path.join(OUT, "g6_sample_highways_T100.npz"))
+    final_n = torch.from_numpy(g["chain_rows"][-1])
+    with quiet():
+        guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS)
+    trajs = guide.dataset.unnormalize_trajectories(final_n)
+    a = torch.linspace(0, 1, H)[None, :, None]
+    ends = torch.tensor([[[-0.9, -0.9], [0.9, 0.9]], [[-0.6, 0.45], [0.6, 0.45]], [[-0.45, -0.9], [-0.45, 0.9]],
+                         [[-0.99, 0.45], [1.05, 0.45]], [[0.0, 0.0], [0.45, 0.45]], [[-0.45, 0.45], [0.45, -0.45]]])
+    lines = ends[:, 0:1, :] * (1 - a) + ends[:, 1:2, :] * a
+    vel = torch.zeros_like(lines)
+    vel[:, :-1] = (lines[:, 1:] - lines[:, :-1]) / (5.0 / 64)
+    trajs = torch.cat((trajs, torch.cat((lines, vel), -1)))
+    coll, coll_idxs, free, free_idxs, wp = task.get_trajs_collision_and_free(trajs, return_indices=True)
+    out = {"trajs": trajs.numpy(), "free_idxs": free_idxs.numpy().reshape(-1), "coll_idxs": coll_idxs.numpy().reshape(-1),
+           "waypoint_collisions": wp.numpy(), "smoothness": compute_smoothness(trajs, robot).numpy(),
+           "path_length": compute_path_length(trajs, robot).numpy(), "smoothed": smooth_trajs(trajs).numpy()}
+    print("   g9: free", out["free_idxs"], "coll", out["coll_idxs"])
+    np.savez_compressed(os.path.join(OUT, "g9_post.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9}[name]()
     print("done")
