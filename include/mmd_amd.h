@@ -190,6 +190,24 @@ int mmd_q_sample(float* x_dev, const float* x_start_dev, const float* noise_dev,
 int mmd_cross_condition(float* x1_dev, float* x2_dev, int ind1, int ind2, const float* rel, const float* boundary,
                         int n_traj, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-agent layer next to the sampler
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* RobotPlanarDisk.check_rr_collisions (deps/torch_robotics/torch_robotics/robots/robot_planar_disk.py:173-203) as
+ * CBS.get_conflicts calls it (mmd/planners/multi_agent/cbs.py:185-190, equal start times, densification 1):
+ * mask_dev [H][N][N] uint8 = (||p_i(t) - p_j(t)|| < margin) && i != j; midpoints_dev [H][N][N][2] = (p_i + p_j)/2 or
+ * NaN where there is no collision (may be NULL).  paths_dev [N,H,2] un-normalised positions; margin = 2.1 * radius. */
+int mmd_rr_collisions(const float* paths_dev, int n_robots, int horizon, float margin, uint8_t* mask_dev,
+                      float* midpoints_dev, void* stream);
+
+/* The 'least_collisions' scan of CBS.expand (cbs.py:446-458) without the per-sample get_conflicts loop:
+ * counts_dev[r*B + b] = #{(t, j != robot0 + r) : ||x_{r,b}(t) - p_j(t)|| < margin} for the local robots' sample
+ * batches trajs_dev [n_local*B, H, 4] (un-normalised; only x, y are read) against ALL robots' best paths
+ * paths_dev [n_all, H, 2].  (The reference's conflict count for sample b is a constant plus twice this number.) */
+int mmd_count_collisions(const float* trajs_dev, const float* paths_dev, int robot0, int n_local,
+                         int samples_per_robot, int n_all, int horizon, float margin, int32_t* counts_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,9 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "mmd_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint32,
                                C.c_int, C.c_void_p]),
+    "mmd_rr_collisions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmd_count_collisions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                       C.c_void_p, C.c_void_p]),
     "mmd_cross_condition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.c_int, C.c_void_p]),
 }

@@ -87,19 +87,28 @@ class MultiRobotSampler:
             n_diffusion_steps_without_noise=self.n_extra, warm_start_path_b=x_init, step_noise=step_noise, seed=seed,
             device=self.device)
 
-    def best_paths(self, trajs_normalized):
-        """Stand-in selection for the exchange step: sample 0 of every local robot, un-normalised positions
-        [n_local,H,2] (the reference picks argmin(path length + smoothness) among collision-free samples,
-        mpd.py:368-382 -- post-processing)."""
-        t = trajs_normalized.view(self.n_local, self.n_samples, H, D)[:, 0]
+    def unnormalize(self, trajs_normalized):
         nz = self.dataset.normalizer
-        mins, maxs = nz.mins.to(t.device), nz.maxs.to(t.device)
-        pos = (torch.clip(t[..., :2], -1, 1) + 1) / 2.0 * (maxs[:2] - mins[:2]) + mins[:2]
-        return pos.contiguous()
+        mins, maxs = nz.mins.to(trajs_normalized.device), nz.maxs.to(trajs_normalized.device)
+        return (torch.clip(trajs_normalized, -1, 1) + 1) / 2.0 * (maxs - mins) + mins
+
+    def best_paths(self, trajs_normalized, paths_all=None):
+        """Selection for the exchange step: per local robot the sample with the fewest robot-robot collisions against the
+        other robots' current best paths (CBS 'least_collisions', cbs.py:446-458; device scan), or sample 0 when no
+        paths are known yet.  Returns un-normalised positions [n_local,H,2].  (The reference first drops samples that
+        collide with the map, mpd.py:357-382 -- post-processing, not part of this exchange.)"""
+        t = self.unnormalize(trajs_normalized)
+        tv = t.view(self.n_local, self.n_samples, H, D)
+        if paths_all is None or self.n_robots < 2:
+            idx = torch.zeros(self.n_local, dtype=torch.long, device=t.device)
+        else:
+            from .multi_agent import least_collision_samples
+            idx = least_collision_samples(t, paths_all, self.robot0, self.n_local)
+        return tv[torch.arange(self.n_local, device=t.device), idx][..., :2].contiguous()
 
     def plan_round(self, paths_local, seed=None):
         """all-gather -> constraint table -> guided sampling -> new local best paths."""
         paths_all = all_gather_paths(paths_local, self.world_size, self.group)
         self.set_other_paths(paths_all)
         trajs = self.sample(seed=seed)
-        return trajs, self.best_paths(trajs)
+        return trajs, self.best_paths(trajs, paths_all)

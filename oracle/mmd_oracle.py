@@ -544,3 +544,29 @@ def soft_constraints_from_paths(paths, agent_id, radius, weight, start_times=Non
                 tr.append((t, t + 1))
     return ConstraintGroup(q=torch.stack(q), t_range=torch.tensor(tr, dtype=torch.float32),
                            radius=torch.full((len(q),), radius), weight=weight)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# §8f-1  multi-agent layer next to the sampler
+# --------------------------------------------------------------------------------------------------------------
+
+
+def check_rr_collisions(robot_q, radius=0.05):
+    """RobotPlanarDisk.check_rr_collisions (deps/torch_robotics/torch_robotics/robots/robot_planar_disk.py:173-203).
+    robot_q [..., n_robots, 2] -> (collisions [..., n, n] bool, midpoints [..., n, n, 2] with NaN where no collision)."""
+    margin = 2.1 * radius
+    p1, p2 = robot_q.unsqueeze(-2), robot_q.unsqueeze(-3)
+    coll = torch.norm(p1 - p2, dim=-1) < margin
+    coll = coll & ~torch.eye(coll.shape[-1], dtype=coll.dtype)
+    mid = (p1 + p2) / 2
+    mid = mid * coll.unsqueeze(-1)
+    mid[~coll.unsqueeze(-1).expand_as(mid)] = float("nan")
+    return coll, mid
+
+
+def count_collisions_with_others(samples_pos, paths, self_idx, radius=0.05):
+    """#{(t, j != self): ||x_b(t) - p_j(t)|| < 2.1 r} per sample b -- what CBS's 'least_collisions' scan (cbs.py:446-458)
+    ranks by: get_conflicts(state with sample b) has nonzero(collisions) = const + 2 * this count."""
+    others = torch.cat((paths[:self_idx], paths[self_idx + 1:]))                    # [N-1,H,2]
+    d = torch.norm(samples_pos[:, None] - others[None], dim=-1)                     # [B,N-1,H]
+    return (d < 2.1 * radius).sum(dim=(1, 2))

@@ -148,3 +148,28 @@ def test_mpd_ensemble_call_contract():
     assert out.fraction_free_trajs == 1.0
     with pytest.raises(ValueError):
         p(goal, goal)
+
+
+def test_multi_agent_layer_vs_reference_g10():
+    """SURVEY §8f-1 on device: robot-robot collisions (bit-exact mask, midpoints) and the least_collisions scan against
+    the reference robot's check_rr_collisions / the conflict totals CBS would count (tests/golden/g10_multi_agent.npz)."""
+    from mmd_amd.multi_agent import check_rr_collisions, count_collisions, least_collision_samples
+    from oracle import mmd_oracle as O
+    g = np.load(os.path.join(GOLDEN, "g10_multi_agent.npz"))
+    paths = torch.from_numpy(g["paths"]).cuda()
+    coll, mid = check_rr_collisions(paths)
+    assert np.array_equal(coll.cpu().numpy(), g["collisions"])
+    assert np.array_equal(np.isnan(mid.cpu().numpy()), np.isnan(g["midpoints"]))
+    assert np.array_equal(np.nan_to_num(mid.cpu().numpy()), np.nan_to_num(g["midpoints"]))
+    samples = torch.from_numpy(g["samples"]).cuda()
+    cnt = count_collisions(samples, paths, 0, 1)[0].cpu()
+    base = int(O.check_rr_collisions(paths[1:].cpu().permute(1, 0, 2))[0].sum())
+    assert (base + 2 * cnt).tolist() == g["conflict_totals"].tolist()
+    assert int(least_collision_samples(samples, paths, 0, 1)[0]) == int(np.argmin(g["conflict_totals"]))
+    # several local robots at once == one at a time, and == the oracle
+    rng_paths = paths + 0.02 * torch.from_numpy(synth.synth_noise(90, tuple(paths.shape))).cuda()
+    batch = torch.from_numpy(synth.synth_noise(91, (3 * 8, H, D))).cuda() * 0.5
+    c3 = count_collisions(batch, rng_paths, 2, 3).cpu()
+    for r in range(3):
+        ref = O.count_collisions_with_others(batch[r * 8:(r + 1) * 8, :, :2].cpu(), rng_paths.cpu(), 2 + r)
+        assert c3[r].tolist() == ref.tolist()

@@ -141,3 +141,17 @@ def test_g8_ensemble():
             mid = {m: x[m].clone() for m in (0, 1)}
     assert rel_l2(mid[0], g["chain0_mid"]) < 1e-4 and rel_l2(mid[1], g["chain1_mid"]) < 1e-4
     assert rel_l2(x[0], g["final0"]) < 1e-4 and rel_l2(x[1], g["final1"]) < 1e-4
+
+
+def test_g10_multi_agent_layer():
+    g = np.load(os.path.join(GOLDEN, "g10_multi_agent.npz"))
+    paths = torch.from_numpy(g["paths"])
+    coll, mid = O.check_rr_collisions(paths.permute(1, 0, 2))
+    assert np.array_equal(coll.numpy(), g["collisions"])
+    assert np.array_equal(np.isnan(mid.numpy()), np.isnan(g["midpoints"]))
+    assert np.allclose(np.nan_to_num(mid.numpy()), np.nan_to_num(g["midpoints"]), atol=0)
+    samples = torch.from_numpy(g["samples"])
+    cnt = O.count_collisions_with_others(samples[..., :2], paths, 0)
+    base = int(O.check_rr_collisions(paths[1:].permute(1, 0, 2))[0].sum())
+    assert (base + 2 * cnt).tolist() == g["conflict_totals"].tolist()
+    assert int(cnt.max()) > 0

@@ -14,6 +14,7 @@ Fixtures:
   g6_sample_*.npz      run_inference chains with injected noise
   g7_local.npz         run_local_inference (3 noising / 3 denoising steps)
   g8_ensemble.npz      2-tile DiffusionsEnsemble.run_inference
+  g10_multi_agent.npz  robot-robot collisions of a best-path set + per-sample conflict totals (least_collisions scan)
   g9_post.npz          post-sampling selection: collision/free split, smoothness, path length, SavGol smoothing
 """
 import os
@@ -345,11 +346,38 @@ def g9():
     np.savez_compressed(os.path.join(OUT, "g9_post.npz"), **out)
 
 
+def g10():
+    """Multi-agent layer: the reference robot's check_rr_collisions on a 6-robot best-path set, and the
+    conflict count CBS.get_conflicts would see for every sample of robot 0's batch (cbs.py:166-246, :446-458)."""
+    with quiet():
+        env, robot, task = make_task("EnvEmpty2D")
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    paths = torch.from_numpy(synth.straight_line_paths(starts, goals, H))
+    paths = paths + 0.03 * torch.from_numpy(synth.synth_noise(31, tuple(paths.shape)))     # break the symmetry
+    coll, mid = robot.check_rr_collisions(paths.permute(1, 0, 2))                           # (H, n, n)
+    g = np.load(os.path.join(OUT, "g6_sample_empty_T50.npz"))
+    guide, _, _, _ = make_guide("EnvEmpty2D", MINS, MAXS)
+    samples = guide.dataset.unnormalize_trajectories(torch.from_numpy(g["chain_rows"][-1]))   # robot 0's batch [8,H,4]
+    # the guided samples avoid everybody; make half of the batch noisy straight lines so that the counts differ
+    line = torch.from_numpy(synth.straight_line_paths(starts, goals, H))[0]
+    for b in range(4, 8):
+        samples[b, :, :2] = line + 0.01 * (b - 3) * torch.from_numpy(synth.synth_noise(32 + b, (H, 2)))
+    totals = []
+    for b in range(samples.shape[0]):
+        ps = paths.clone()
+        ps[0] = samples[b, :, :2]
+        c, _ = robot.check_rr_collisions(ps.permute(1, 0, 2))
+        totals.append(int(torch.nonzero(c.int()).shape[0]))
+    print("   g10: collisions in the base set", int(coll.sum()), "per-sample conflict totals", totals)
+    np.savez_compressed(os.path.join(OUT, "g10_multi_agent.npz"), paths=paths.numpy(), collisions=coll.numpy(),
+                        midpoints=mid.numpy(), samples=samples.numpy(), conflict_totals=np.array(totals))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}[name]()
     print("done")
