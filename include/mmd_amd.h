@@ -114,6 +114,7 @@ typedef struct mmd_guide_desc {
   const int32_t* grp_slot_off_dev;
   const float* grp_weight_dev;
   const int32_t* robot_grp_off_dev;
+  int32_t max_slots_per_robot;       /* max over robots of their total slot count (sizes the LDS staging; 0 = unknown) */
 } mmd_guide_desc;
 
 /* Host helper: time-bucket one robot's constraint groups.  For group g (n_pts[g] points): q [n,2], t_range [n,2]

@@ -18,7 +18,7 @@ class GuideDesc(C.Structure):
         ("margin", C.c_float), ("dt", C.c_float), ("sigma_gp", C.c_float),
         ("weight_collision", C.c_float), ("weight_smoothness", C.c_float), ("max_grad_norm", C.c_float),
         ("cons_ell_dev", C.c_void_p), ("grp_slot_off_dev", C.c_void_p), ("grp_weight_dev", C.c_void_p),
-        ("robot_grp_off_dev", C.c_void_p),
+        ("robot_grp_off_dev", C.c_void_p), ("max_slots_per_robot", C.c_int32),
     ]
 
 

@@ -68,7 +68,11 @@ __device__ __forceinline__ float lane_next(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-constexpr int LDS_SLOTS = 40;   // constraint slots staged per workgroup: 40 x 64 x 16 B = 40 KiB
+// Constraint slots staged per workgroup (1 KiB each).  A workgroup is WPB waves = WPB trajectories of one robot sharing
+// the table: 4 waves x 40 slots for small batches, 16 waves x up to 144 slots (dynamic LDS) when samples_per_robot is a
+// multiple of 16 -- so a 128..256-robot instance (weak scaling over 4-8 GPUs) still reads most of its table from LDS.
+constexpr int LDS_SLOTS_SMALL = 40;
+constexpr int LDS_SLOTS_MAX = 144;
 
 // -sum over a slot range of d/||d|| for points with ||d|| <= R  (CostConstraint, cost_functions.py:297-326), from a
 // [slot][t] table `tab` (LDS or global).  Two accumulator pairs break the dependent add chain.
@@ -189,14 +193,15 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
 }
 
 // One ddpm_sample_fn (sample_functions.py:40-86) + the apply_hard_conditioning after it, for one trajectory per wave.
-__global__ __launch_bounds__(256) void ddpm_guide_kernel(GuideDev g, StepDev s, float4* __restrict__ x,
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDev s, int lds_slots, float4* __restrict__ x,
                                                          const float4* __restrict__ eps,
                                                          const float4* __restrict__ noise, float4* __restrict__ chain,
                                                          const float4* __restrict__ hard,
                                                          int samples_per_robot) {
-  __shared__ float4 lds_cons[LDS_SLOTS * H];
+  extern __shared__ __attribute__((aligned(16))) float4 lds_cons[];
   const int t = threadIdx.x & 63;
-  const int traj_b = s.traj0 + blockIdx.x * 4;
+  const int traj_b = s.traj0 + blockIdx.x * WPB;
   const int traj = traj_b + (threadIdx.x >> 6);
   const bool valid = traj < s.traj_end;
 
@@ -205,12 +210,12 @@ __global__ __launch_bounds__(256) void ddpm_guide_kernel(GuideDev g, StepDev s, 
   int lds_slot0 = 0, lds_n = 0;
   if (s.do_guide && g.robot_grp_off) {
     const int rb0 = traj_b / samples_per_robot;
-    const int rb1 = min(traj_b + 3, s.traj_end - 1) / samples_per_robot;
+    const int rb1 = min(traj_b + WPB - 1, s.traj_end - 1) / samples_per_robot;
     if (rb0 == rb1) {
       lds_slot0 = g.grp_slot_off[g.robot_grp_off[rb0]];
-      lds_n = min(g.grp_slot_off[g.robot_grp_off[rb0 + 1]] - lds_slot0, LDS_SLOTS);
+      lds_n = min(g.grp_slot_off[g.robot_grp_off[rb0 + 1]] - lds_slot0, lds_slots);
       const float4* src = g.cons + (size_t)lds_slot0 * H;
-      for (int i = threadIdx.x; i < lds_n * H; i += 256) lds_cons[i] = src[i];
+      for (int i = threadIdx.x; i < lds_n * H; i += WPB * 64) lds_cons[i] = src[i];
     }
   }
   __syncthreads();
@@ -343,6 +348,7 @@ int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
   g.m1 = (float)(12.0 / (dt * dt * dt) * qc);
   g.m2 = (float)(-6.0 / (dt * dt) * qc);
   g.m3 = (float)(4.0 / dt * qc);
+  g.max_slots = d->max_slots_per_robot > 0 ? d->max_slots_per_robot : LDS_SLOTS_SMALL;
   g.cons = reinterpret_cast<const float4*>(d->cons_ell_dev);
   g.grp_slot_off = d->grp_slot_off_dev; g.grp_weight = d->grp_weight_dev; g.robot_grp_off = d->robot_grp_off_dev;
   if (!g.cons || !g.grp_slot_off || !g.grp_weight) g.robot_grp_off = nullptr;
@@ -353,8 +359,24 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
                 const float* hard, int traj0, int n_traj, int spr, hipStream_t st) {
   s.traj0 = traj0;
   s.traj_end = traj0 + n_traj;
-  hipLaunchKernelGGL(ddpm_guide_kernel, dim3((n_traj + 3) / 4), dim3(256), 0, st, g, s, (float4*)x, (const float4*)eps,
-                     (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
+  const bool guided = s.do_guide && g.robot_grp_off;
+  if (guided && g.max_slots > LDS_SLOTS_SMALL && spr % 16 == 0 && traj0 % 16 == 0) {
+    // 16 trajectories of one robot per workgroup; LDS sized to the largest table any robot can have (g.max_slots)
+    int slots = guided ? (g.max_slots < LDS_SLOTS_MAX ? g.max_slots : LDS_SLOTS_MAX) : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpm_guide_kernel<16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SLOTS_MAX * H * 16);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(ddpm_guide_kernel<16>, dim3((n_traj + 15) / 16), dim3(1024), (size_t)slots * H * 16, st, g, s,
+                       slots, (float4*)x, (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard,
+                       spr);
+  } else {
+    const int slots = guided ? LDS_SLOTS_SMALL : 0;
+    hipLaunchKernelGGL(ddpm_guide_kernel<4>, dim3((n_traj + 3) / 4), dim3(256), (size_t)slots * H * 16, st, g, s, slots,
+                       (float4*)x, (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
+  }
   return 0;
 }
 

@@ -20,6 +20,7 @@ struct GuideDev {
   const int* grp_slot_off;
   const float* grp_weight;
   const int* robot_grp_off;
+  int max_slots;                     // largest number of constraint slots any robot owns (LDS sizing)
 };
 
 struct StepDev {

@@ -46,6 +46,7 @@ class GuideManagerTrajectoriesWithVelocity:
         self._cons = None
         self._cons_dirty = True
         self._external_cons = None
+        self._max_slots = 0
 
     # ---- extra costs (constraints) ----------------------------------------------------------------------------
     def add_extra_costs(self, extra_costs, extra_costs_grad_weights, robot=0):
@@ -62,6 +63,7 @@ class GuideManagerTrajectoriesWithVelocity:
     def set_packed_constraints(self, cons):
         """Use device-built constraint tensors (constraints.soft_constraints_from_paths) instead of host-packed ones."""
         self._external_cons = cons
+        self._max_slots = 0
 
     def _constraints(self):
         if self._external_cons is not None:
@@ -70,6 +72,9 @@ class GuideManagerTrajectoriesWithVelocity:
             groups = [list(zip(c, w)) for c, w in zip(self.extra_cost_l, self.extra_costs_grad_weight_l)]
             self._cons = pack_constraints(groups, self.device)
             self._cons_dirty = False
+            if self._cons is not None:
+                gso, rgo = self._cons[1].cpu(), self._cons[3].cpu()
+                self._max_slots = int(max(int(gso[rgo[r + 1]]) - int(gso[rgo[r]]) for r in range(self.n_robots)))
         return self._cons
 
     # ---- C-ABI descriptor -------------------------------------------------------------------------------------
@@ -94,6 +99,8 @@ class GuideManagerTrajectoriesWithVelocity:
             ell, gso, gw, rgo = cons
             d.cons_ell_dev, d.grp_slot_off_dev = ell.data_ptr(), gso.data_ptr()
             d.grp_weight_dev, d.robot_grp_off_dev = gw.data_ptr(), rgo.data_ptr()
+            # upper bound of the slots any one robot owns (exact when robots own equal shares, as the all-pairs table)
+            d.max_slots_per_robot = int(self._max_slots) if self._max_slots else -(-ell.shape[0] // max(self.n_robots, 1))
             self._keep = cons
         return d
 

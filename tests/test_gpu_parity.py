@@ -247,3 +247,26 @@ def test_philox_noise_statistics():
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3
     assert abs(float((a ** 4).mean()) - 3.0) < 0.05
+
+
+@pytest.mark.parametrize("n_robots,B", [(48, 4), (48, 16), (160, 16)])
+def test_guide_large_constraint_tables(n_robots, B):
+    """More constraint slots than the LDS staging holds (4-wave workgroups: 40; 16-wave workgroups: 144): the overflow
+    is read from the L2-resident table.  47 / 159 other robots + a hard group, both workgroup shapes, vs the oracle."""
+    starts, goals = synth.start_goal_circle(n_robots, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    soft = cases.soft_group(paths, 1)
+    hard = cases.hard_group([[0.3, 0.1], [-0.2, 0.4]], [[10, 30], [25, 40]])
+    assert soft.q.shape[0] == (n_robots - 1) * 63
+    guide = _gc().hip_guide("EnvHighways2D", [[soft, hard]])
+    gp = cases.guide_params("EnvHighways2D")
+    x = torch.from_numpy(synth.synth_noise(95, (B, H, D))) * 0.5
+    ref = O.guide_grad(x, gp, [soft, hard], clip_mode="always")
+    out = guide(x.cuda()).cpu()
+    assert float((out - ref).abs().max()) < 3e-6
+    y = x.clone().cuda()
+    guide.guide_steps(y, torch.zeros(1, 2, D, device="cuda"), 0, 5)
+    r = x.clone()
+    for _ in range(5):
+        r = r + O.guide_grad(r, gp, [soft, hard], clip_mode="always")
+    assert rel_l2(y.cpu(), r) < 1e-4
