@@ -138,20 +138,33 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
 // latency of a weight fetch never sits in front of the MFMA that consumes it; pack_b pads every packed tensor with 4
 // zero groups so the ring may over-read unconditionally.
 template <int MT_W>
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W], int aoff,
-                                           const float4 b) {
-  const float bq[4] = {b.x, b.y, b.z, b.w};
-  float a[4][MT_W];
+__device__ __forceinline__ void load_a(float (&a)[4][MT_W], const float* slab, const int (&abase)[MT_W], int aoff) {
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt) a[q][mt] = slab[abase[mt] + aoff + q * 2];
+}
+
+template <int MT_W>
+__device__ __forceinline__ void mfma_a(f32x16 (&acc)[MT_W], const float (&a)[4][MT_W], const float4 b) {
+  const float bq[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][mt], bq[q], acc[mt], 0, 0, 0);
 }
 
+template <int MT_W>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W], int aoff,
+                                           const float4 b) {
+  float a[4][MT_W];
+  load_a<MT_W>(a, slab, abase, aoff);
+  mfma_a<MT_W>(acc, a, b);
+}
+
+// A fragments are double-buffered in registers (the LDS reads of k-group g+1 are issued before the 4*MT_W MFMAs of
+// group g), B fragments ride a 4-deep register ring fed straight from L2: a lone wave keeps the matrix pipe busy, so a
+// co-resident wave's epilogue overlaps instead of stalling it.
 template <int NTAPS, int CP, int STR, int MT_W>
 __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W],
                                           const float4* __restrict__ wp) {
@@ -166,19 +179,27 @@ __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab
   } else {
     const float4* p = wp;
     float4 b0 = p[0], b1 = p[64], b2 = p[128], b3 = p[192];
+    float a0[4][MT_W], a1[4][MT_W];
+    load_a<MT_W>(a0, slab, abase, 0);
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap) {
 #pragma unroll 1
       for (int cg = 0; cg < GPT; cg += 4) {
         p += 256;
         const int aoff = tap * STR + cg * 8;
-        mfma_group<MT_W>(acc, slab, abase, aoff, b0);
+        // offset of the group after this chunk: next chunk of the same tap, or the first group of the next tap
+        const int anext = cg + 4 < GPT ? aoff + 32 : (tap + 1) * STR;
+        load_a<MT_W>(a1, slab, abase, aoff + 8);
+        mfma_a<MT_W>(acc, a0, b0);
         b0 = p[0];
-        mfma_group<MT_W>(acc, slab, abase, aoff + 8, b1);
+        load_a<MT_W>(a0, slab, abase, aoff + 16);
+        mfma_a<MT_W>(acc, a1, b1);
         b1 = p[64];
-        mfma_group<MT_W>(acc, slab, abase, aoff + 16, b2);
+        load_a<MT_W>(a1, slab, abase, aoff + 24);
+        mfma_a<MT_W>(acc, a0, b2);
         b2 = p[128];
-        mfma_group<MT_W>(acc, slab, abase, aoff + 24, b3);
+        load_a<MT_W>(a0, slab, abase, anext);      // (after the last group this reads a valid slab row and is unused)
+        mfma_a<MT_W>(acc, a1, b3);
         b3 = p[192];
       }
     }
@@ -431,6 +452,9 @@ __device__ __forceinline__ void fill(f32x16 (&acc)[MT_W], float v) {
     for (int r = 0; r < 16; ++r) acc[mt][r] = v;
 }
 
+#ifndef MMD_ABL
+#define MMD_ABL 0   // ablation builds only: 1 = no GroupNorm/Mish, 3 = no MFMA loops
+#endif
 template <class CF>
 __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[CF::LDS_FLOATS];
@@ -446,6 +470,14 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   const int col = wn * 32 + (lane & 31);
   const int hi = lane >> 5;
 
+#ifdef MMD_STAGGER
+  // experiment: offset the second "wave" of workgroups (b >= 256 shares a CU with b - 256) by MMD_STAGGER x ~0.5 us so
+  // that co-resident workgroups do not run their MFMA phases / epilogues in lockstep
+  if ((blockIdx.x >> MMD_STAGGER_BIT) & 1) {
+    if (MMD_STAGGER > 0) { for (int i = 0; i < MMD_STAGGER; ++i) __builtin_amdgcn_s_sleep(16); }
+    else __builtin_amdgcn_s_setprio(2);
+  }
+#endif
   if constexpr (CF::SHARE) {
     stage_slab<CF::C0, 0, CF::CM, CF::L, CF::SROWS, 2, CF::HSTR, CF::SPB>(hslab, a.in0, nullptr, n0, a.n);
   } else {
@@ -479,20 +511,20 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
       rbase[mt] = xbase[mt] + 2 * XS;
     }
     fill<MT_W>(acc, a.r0.ba[col]);
-    mfma_taps<5, CF::C0P, XS, MT_W>(acc, xslab, xbase, a.r0.wa + ((size_t)wn * (5 * CF::C0P / 8)) * 64 + lane);
+    if (MMD_ABL != 3) mfma_taps<5, CF::C0P, XS, MT_W>(acc, xslab, xbase, a.r0.wa + ((size_t)wn * (5 * CF::C0P / 8)) * 64 + lane);
     if constexpr (CF::RES0 == RES_CONV) {
       fill<MT_W>(res, a.br[col]);
-      mfma_taps<1, CF::C0P, XS, MT_W>(res, xslab, rbase, a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane);
+      if (MMD_ABL != 3) mfma_taps<1, CF::C0P, XS, MT_W>(res, xslab, rbase, a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane);
     }
     if constexpr (CF::C1 > 0) {                              // second half of the channel concat, same slab
       __syncthreads();
       stage_slab<CF::C1, 0, CF::C1P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB>(xslab, a.in1, nullptr, n0, a.n);
       __syncthreads();
-      mfma_taps<5, CF::C1P, XS, MT_W>(acc, xslab, xbase, a.wa0_c1 + ((size_t)wn * (5 * CF::C1P / 8)) * 64 + lane);
+      if (MMD_ABL != 3) mfma_taps<5, CF::C1P, XS, MT_W>(acc, xslab, xbase, a.wa0_c1 + ((size_t)wn * (5 * CF::C1P / 8)) * 64 + lane);
       if constexpr (CF::RES0 == RES_CONV)
-        mfma_taps<1, CF::C1P, XS, MT_W>(res, xslab, rbase, a.wr_c1 + ((size_t)wn * (CF::C1P / 8)) * 64 + lane);
+        if (MMD_ABL != 3) mfma_taps<1, CF::C1P, XS, MT_W>(res, xslab, rbase, a.wr_c1 + ((size_t)wn * (CF::C1P / 8)) * 64 + lane);
     }
-    gn_mish<CF::CM, CF::L, MT_W>(acc, a.r0.ga[col], a.r0.bea[col]);
+    if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, a.r0.ga[col], a.r0.bea[col]);
     {
       const float tb = a.r0.tb[col];
 #pragma unroll
@@ -504,8 +536,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
     __syncthreads();
     fill<MT_W>(acc, a.r0.bb[col]);
-    mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, a.r0.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
-    gn_mish<CF::CM, CF::L, MT_W>(acc, a.r0.gb[col], a.r0.beb[col]);
+    if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, a.r0.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
+    if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, a.r0.gb[col], a.r0.beb[col]);
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt)
 #pragma unroll
@@ -541,8 +573,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
     __syncthreads();
     fill<MT_W>(acc, R.ba[col]);
-    mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wa + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
-    gn_mish<CF::CM, CF::L, MT_W>(acc, R.ga[col], R.bea[col]);
+    if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wa + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
+    if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, R.ga[col], R.bea[col]);
     {
       const float tb = R.tb[col];
 #pragma unroll
@@ -554,8 +586,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
     __syncthreads();
     fill<MT_W>(acc, R.bb[col]);
-    mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
-    gn_mish<CF::CM, CF::L, MT_W>(acc, R.gb[col], R.beb[col]);
+    if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
+    if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, R.gb[col], R.beb[col]);
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt) acc[mt] += res[mt];
     if (CF::MID_AFTER == k + 1 && a.mid_out) store_tile(a.mid_out);
@@ -576,7 +608,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
       fill<1>(t, bt);
       const int r = lane & 31;
       int tb_[1] = {((wm * CF::SW + r / LO) * CF::SROWS + 2 * (r % LO) + 1) * CF::HSTR + hi};
-      mfma_taps<3, CF::CM, CF::HSTR, 1>(t, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
+      if (MMD_ABL != 3) mfma_taps<3, CF::CM, CF::HSTR, 1>(t, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
@@ -593,7 +625,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
         int ub[MT_W];
 #pragma unroll
         for (int mt = 0; mt < MT_W; ++mt) ub[mt] = hbase[mt] + (1 + pass) * CF::HSTR;
-        mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wn * G) * 64 + lane);
+        if (MMD_ABL != 3) mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wn * G) * 64 + lane);
 #pragma unroll
         for (int mt = 0; mt < MT_W; ++mt)
 #pragma unroll
