@@ -67,7 +67,7 @@ def compute_variance_waypoints(trajs):
     total = 0.0
     for via in pos.permute(1, 0, 2):
         d = torch.cdist(via, via, p=2)
-        total = total + torch.var(torch.triu(d, diagonal=1).view(-1))
+        total = total + (torch.var(torch.triu(d, diagonal=1).view(-1)) if d.numel() > 1 else 0.0)
     return total
 
 
