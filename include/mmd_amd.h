@@ -89,7 +89,8 @@ typedef struct mmd_guide_desc {
   float norm_min[MMD_STATE_DIM];
   float norm_max[MMD_STATE_DIM];
   /* SDF grids of the fixed objects: GridMapSDF (grid_map_sdf.py:9-114).  Cell (ix,iy) holds float4
-   * (sdf, d sdf/dx, d sdf/dy, 0); layout [n_maps][n_grids][nx][ny][4]; index = floor((p-lo)/(hi-lo)*n) clamped. */
+   * (sdf, d sdf/dx, d sdf/dy, 0); layout [n_maps][n_grids][nx][ny][4]; index = floor((p-lo)/(hi-lo)*n) clamped.
+   * n_grids == 0 declares an obstacle-free map (EnvEmpty2D: sdf == 1, primitives.py:109-110): no gather is issued. */
   float limits_lo[2];
   float limits_hi[2];
   int32_t grid_nx, grid_ny, n_grids, n_maps;

@@ -121,7 +121,8 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
   int iy = (int)floorf((py - g.lo[1]) / g.dim[1] * (float)g.ny);
   ix = min(max(ix, 0), g.nx - 1);
   iy = min(max(iy, 0), g.ny - 1);
-  const float4 cell0 = grid[(size_t)ix * g.ny + iy];
+  // n_grids == 0: the map has no fixed objects (sdf == 1 everywhere, primitives.py:109-110) -> the term is identically 0
+  const float4 cell0 = g.n_grids > 0 ? grid[(size_t)ix * g.ny + iy] : make_float4(1e30f, 0.f, 0.f, 0.f);
 
   // --- CostCollision over the workspace boundaries (distance_fields.py:354-367)
   float wsx, wsy;
@@ -331,7 +332,7 @@ __global__ void soft_cons_kernel(const float2* __restrict__ paths, int n_all, in
 }
 
 int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
-  MMD_REQUIRE(d->sdf_grids_dev && d->n_grids >= 1 && d->grid_nx >= 1 && d->grid_ny >= 1, "guide: SDF grid missing");
+  MMD_REQUIRE(d->n_grids == 0 || (d->sdf_grids_dev && d->grid_nx >= 1 && d->grid_ny >= 1), "guide: SDF grid missing");
   for (int k = 0; k < 4; ++k) { g.nmin[k] = d->norm_min[k]; g.nscale[k] = d->norm_max[k] - d->norm_min[k]; }
   for (int k = 0; k < 2; ++k) {
     g.lo[k] = d->limits_lo[k];

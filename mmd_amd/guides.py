@@ -40,6 +40,8 @@ class GuideManagerTrajectoriesWithVelocity:
         self._grids = torch.from_numpy(np.ascontiguousarray(tex)).to(self.device)
         self._robot_map = torch.tensor([maps.index(e) for e in env_ids], dtype=torch.int32, device=self.device)
         self._n_maps = len(maps)
+        from .environments import MAP_BOXES
+        self._obstacle_free = all(len(MAP_BOXES[m.replace("ExtraObjects", "")][0]) == 0 for m in maps)
         # extra costs, per robot (guides.py:176-178, :228-234)
         self.extra_cost_l: List[List[CostConstraint]] = [[] for _ in range(n_robots)]
         self.extra_costs_grad_weight_l: List[List[float]] = [[] for _ in range(n_robots)]
@@ -86,7 +88,7 @@ class GuideManagerTrajectoriesWithVelocity:
         d.limits_lo[:] = LIMITS[0]
         d.limits_hi[:] = LIMITS[1]
         d.grid_nx, d.grid_ny = self._grids.shape[2], self._grids.shape[3]
-        d.n_grids, d.n_maps = 1, self._n_maps
+        d.n_grids, d.n_maps = (0 if self._obstacle_free else 1), self._n_maps
         d.sdf_grids_dev = self._grids.data_ptr()
         d.robot_map_dev = self._robot_map.data_ptr() if self._n_maps > 1 else None
         d.ws_min[:] = [float(np.float32(LIMITS[0][k]) * np.float32(1.08)) for k in range(2)]      # tasks.py:81-83
