@@ -87,6 +87,19 @@ class _Robot:
         return x[..., 2:4]
 
 
+def normalizer_limits_from_dataset(dataset_dir):
+    """LimitsNormalizer limits exactly as TrajectoryDataset derives them (mmd/datasets/trajectories.py:84-112,
+    normalization.py:91-94): min / max over every support point of every `trajs-free.pt` found under dataset_dir."""
+    trajs = []
+    for cur, _, files in os.walk(os.path.expanduser(dataset_dir), topdown=True):
+        if "trajs-free.pt" in files:
+            trajs.append(torch.load(os.path.join(cur, "trajs-free.pt"), map_location="cpu"))
+    if not trajs:
+        raise FileNotFoundError(f"no trajs-free.pt under {dataset_dir}")
+    flat = torch.cat(trajs).float().reshape(-1, trajs[0].shape[-1])
+    return flat.min(dim=0).values.numpy(), flat.max(dim=0).values.numpy()
+
+
 def _load_model(model_id, trained_models_dir, model_state_dict, model_args, device):
     """mpd.py:117-177: args.yaml + checkpoint if present on disk, else the in-memory state dict."""
     args = dict(variance_schedule="exponential", n_diffusion_steps=25, predict_epsilon=True, unet_input_dim=32,
@@ -140,6 +153,8 @@ class MPD:
         self.model, self.model_args = _load_model(model_id, trained_models_dir, model_state_dict, model_args, self.device)
         self.model.seed = seed
         self.env_id = env_id or (model_id.split("-")[0] if model_id else "EnvEmpty2D")
+        if normalizer_limits is None and kwargs.get("dataset_dir"):
+            normalizer_limits = normalizer_limits_from_dataset(kwargs["dataset_dir"])
         mins, maxs = normalizer_limits if normalizer_limits is not None else (synth.NORM_MINS, synth.NORM_MAXS)
         self.dataset = TrajectoryDatasetFacade(mins, maxs)
         self.robot = _Robot()

@@ -173,3 +173,40 @@ def test_multi_agent_layer_vs_reference_g10():
     for r in range(3):
         ref = O.count_collisions_with_others(batch[r * 8:(r + 1) * 8, :, :2].cpu(), rng_paths.cpu(), 2 + r)
         assert c3[r].tolist() == ref.tolist()
+
+
+def test_mpd_loads_checkpoint_and_dataset_from_disk(tmp_path):
+    """the released on-disk formats -- <trained_models_dir>/<model_id>/{args.yaml,
+    checkpoints/ema_model_current_state_dict.pth} (state-dict keys with the `model.` prefix + the 12 schedule buffers,
+    mpd.py:120,167-171) and the dataset's trajs-free.pt for the normaliser limits (trajectories.py:84-112)."""
+    import yaml
+    from mmd_amd.planners import MPD, normalizer_limits_from_dataset
+    from mmd_amd.schedules import diffusion_buffers
+    model_id = "EnvEmpty2D-RobotPlanarDisk"
+    mdir = tmp_path / "models" / model_id
+    (mdir / "checkpoints").mkdir(parents=True)
+    yaml.safe_dump(dict(variance_schedule="exponential", n_diffusion_steps=25, predict_epsilon=True, unet_input_dim=32,
+                        unet_dim_mults_option=0, use_ema=True, dataset_subdir=model_id, include_velocity=True),
+                   open(mdir / "args.yaml", "w"))
+    sd = {"model." + k: torch.from_numpy(v) for k, v in synth.synth_unet_state_dict(0).items()}
+    sd.update(diffusion_buffers(25))
+    torch.save(sd, mdir / "checkpoints" / "ema_model_current_state_dict.pth")
+    ddir = tmp_path / "data" / model_id / "0"
+    ddir.mkdir(parents=True)
+    trajs = torch.from_numpy(synth.synth_noise(110, (20, H, D))) * torch.tensor([0.9, 0.9, 1.2, 1.2])
+    torch.save(trajs, ddir / "trajs-free.pt")
+    mins, maxs = normalizer_limits_from_dataset(tmp_path / "data" / model_id)
+    assert np.allclose(mins, trajs.reshape(-1, D).min(0).values.numpy()) and mins.shape == (D,)
+    start, goal = torch.tensor([-0.5, 0.1]), torch.tensor([0.5, -0.1])
+    p = MPD(model_id=model_id, planner_alg="mmd", start_state_pos=start, goal_state_pos=goal, n_samples=8,
+            trained_models_dir=str(tmp_path / "models"), dataset_dir=str(tmp_path / "data" / model_id), device="cuda")
+    assert p.model.n_diffusion_steps == 25 and p.env_id == "EnvEmpty2D"
+    assert torch.allclose(p.dataset.normalizer.mins, torch.from_numpy(mins))
+    out = p(start, goal)
+    assert out.trajs_iters.shape == (27, 8, H, D) and torch.isfinite(out.trajs_iters).all()
+    assert torch.allclose(out.trajs_iters[-1][:, 0, :2].cpu(), start.expand(8, 2), atol=1e-5)
+    # same weights given in memory -> same samples for the same seed
+    p2 = MPD(model_id=model_id, planner_alg="mmd", start_state_pos=start, goal_state_pos=goal, n_samples=8,
+             model_state_dict=synth.synth_unet_state_dict(0), model_args=dict(n_diffusion_steps=25),
+             normalizer_limits=(mins, maxs), device="cuda")
+    assert torch.equal(p2(start, goal, seed=9).trajs_iters, p(start, goal, seed=9).trajs_iters)
