@@ -83,7 +83,7 @@ __device__ __forceinline__ float mish(float y) {
 
 // Stage SPB samples' [LIN, C] rows (channels-last, optionally a concat of two tensors) into an LDS slab
 // [SPB][ROWS][STR] at row offset ROFF; samples >= n are zero filled.
-template <int C0, int C1, int CP, int LIN, int ROWS, int ROFF, int STR, int SPB>
+template <int C0, int C1, int CP, int LIN, int ROWS, int ROFF, int STR, int SPB, int SS = ROWS * STR>
 __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict__ in0, const float* __restrict__ in1,
                                            int n0, int n) {
   constexpr int C = C0 + C1;
@@ -103,7 +103,7 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
         else
           v = *reinterpret_cast<const float4*>(in1 + ((size_t)(n0 + s) * LIN + l) * C1 + (c - C0));
       }
-      float* d = slab + (s * ROWS + l + ROFF) * STR + c;
+      float* d = slab + s * SS + (l + ROFF) * STR + c;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
@@ -115,7 +115,7 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
       int c = C + idx % PADC;
       int l = (idx / PADC) % LIN;
       int s = idx / (PADC * LIN);
-      slab[(s * ROWS + l + ROFF) * STR + c] = 0.f;
+      slab[s * SS + (l + ROFF) * STR + c] = 0.f;
     }
   }
   // zero halo rows
@@ -127,7 +127,7 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
       int hr = (idx / CP) % HR;
       int s = idx / (CP * HR);
       int row = hr < ROFF ? hr : LIN + hr;
-      slab[(s * ROWS + row) * STR + c] = 0.f;
+      slab[s * SS + row * STR + c] = 0.f;
     }
   }
 }
@@ -423,8 +423,14 @@ struct ChainCfg {
   static constexpr int WN = CM / 32, WM = 4 / WN;
   static constexpr int RW = 32 * MT_W, SW = RW / L, SPB = WM * SW, SROWS = L + 4;
   static constexpr bool SHARE = RES0 == RES_IDENT;         // x is staged straight into the H slab
-  static constexpr int XSLAB = SHARE ? 0 : SPB * SROWS * XSTR;
-  static constexpr int HSLAB = SPB * SROWS * HSTR;
+  // Sample stride.  With L = 16 a 32-row A tile spans two samples (rows s*stride + l*STR, STR odd): pad the stride to
+  // 16 (mod 32) floats so the second sample's rows fall on the other 16 banks (without the pad rows 0-3 of sample 1
+  // alias rows 12-15 of sample 0: a 2-way conflict on every A-fragment read, SQ_LDS_BANK_CONFLICT = 46 % of LDS cycles).
+  static constexpr int spad(int n) { return L == 16 ? (16 - n % 32 + 32) % 32 : 0; }
+  static constexpr int XSS = SROWS * XSTR + spad(SROWS * XSTR);
+  static constexpr int HSS = SROWS * HSTR + spad(SROWS * HSTR);
+  static constexpr int XSLAB = SHARE ? 0 : SPB * XSS;
+  static constexpr int HSLAB = SPB * HSS;
   static constexpr int LDS_FLOATS = XSLAB + HSLAB;
   static_assert(CM % 32 == 0 && RW % L == 0 && L >= 16, "tile shape");
   static_assert(!SHARE || (C0 == CM && C1 == 0), "identity residual needs C_in == C_out");
@@ -432,7 +438,7 @@ struct ChainCfg {
   static_assert(N_IDENT <= MAX_IDENT, "too many identity RTBs");
 };
 
-template <int CM, int L, int MT_W, int SROWS, int HSTR, int SW>
+template <int CM, int L, int MT_W, int HSS, int HSTR, int SW>
 __device__ __forceinline__ void tile_to_slab(const f32x16 (&acc)[MT_W], float* hslab, int wm, int col, int hi) {
 #pragma unroll
   for (int mt = 0; mt < MT_W; ++mt)
@@ -440,7 +446,7 @@ __device__ __forceinline__ void tile_to_slab(const f32x16 (&acc)[MT_W], float* h
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const int s = wm * SW + row / L, l = row % L;
-      hslab[(s * SROWS + l + 2) * HSTR + col] = acc[mt][r];
+      hslab[s * HSS + (l + 2) * HSTR + col] = acc[mt][r];
     }
 }
 
@@ -461,6 +467,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   float* hslab = lds + CF::XSLAB;
   float* xslab = CF::SHARE ? hslab : lds;
   constexpr int XS = CF::SHARE ? CF::HSTR : CF::XSTR;      // row stride of the slab conv A reads
+  constexpr int XSSv = CF::SHARE ? CF::HSS : CF::XSS;      // its sample stride
   constexpr int MT_W = CF::MT_W;
 
   const int lane = threadIdx.x & 63;
@@ -479,13 +486,13 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   }
 #endif
   if constexpr (CF::SHARE) {
-    stage_slab<CF::C0, 0, CF::CM, CF::L, CF::SROWS, 2, CF::HSTR, CF::SPB>(hslab, a.in0, nullptr, n0, a.n);
+    stage_slab<CF::C0, 0, CF::CM, CF::L, CF::SROWS, 2, CF::HSTR, CF::SPB, CF::HSS>(hslab, a.in0, nullptr, n0, a.n);
   } else {
-    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB>(xslab, a.in0, nullptr, n0, a.n);
+    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
     constexpr int TOT = CF::SPB * 4 * CF::CM;             // zero the halo rows of the H slab
     for (int idx = threadIdx.x; idx < TOT; idx += 256) {
       const int c = idx % CF::CM, hr = (idx / CF::CM) % 4, s = idx / (CF::CM * 4);
-      hslab[(s * CF::SROWS + (hr < 2 ? hr : CF::L + hr)) * CF::HSTR + c] = 0.f;
+      hslab[s * CF::HSS + (hr < 2 ? hr : CF::L + hr) * CF::HSTR + c] = 0.f;
     }
   }
   __syncthreads();
@@ -499,7 +506,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   }
   int hbase[MT_W];                                           // A-fragment base into the H slab (tap 0)
 #pragma unroll
-  for (int mt = 0; mt < MT_W; ++mt) hbase[mt] = (srow[mt] * CF::SROWS + lrow[mt]) * CF::HSTR + hi;
+  for (int mt = 0; mt < MT_W; ++mt) hbase[mt] = srow[mt] * CF::HSS + lrow[mt] * CF::HSTR + hi;
 
   f32x16 acc[MT_W], res[MT_W];
   // =================== RTB 0 ===================
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     int xbase[MT_W], rbase[MT_W];
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt) {
-      xbase[mt] = (srow[mt] * CF::SROWS + lrow[mt]) * XS + hi;
+      xbase[mt] = srow[mt] * XSSv + lrow[mt] * XS + hi;
       rbase[mt] = xbase[mt] + 2 * XS;
     }
     fill<MT_W>(acc, a.r0.ba[col]);
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     }
     if constexpr (CF::C1 > 0) {                              // second half of the channel concat, same slab
       __syncthreads();
-      stage_slab<CF::C1, 0, CF::C1P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB>(xslab, a.in1, nullptr, n0, a.n);
+      stage_slab<CF::C1, 0, CF::C1P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in1, nullptr, n0, a.n);
       __syncthreads();
       if (MMD_ABL != 3) mfma_taps<5, CF::C1P, XS, MT_W>(acc, xslab, xbase, a.wa0_c1 + ((size_t)wn * (5 * CF::C1P / 8)) * 64 + lane);
       if constexpr (CF::RES0 == RES_CONV)
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
         for (int r = 0; r < 16; ++r) acc[mt][r] += tb;
     }
     if constexpr (CF::SHARE) __syncthreads();                // every wave is done reading x before h overwrites it
-    tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
+    tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
     __syncthreads();
     fill<MT_W>(acc, a.r0.bb[col]);
     if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, a.r0.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt) res[mt] = acc[mt];     // this wave's tile of the RTB input = its residual
     __syncthreads();                                         // the previous conv is done reading the H slab
-    tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
+    tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
     __syncthreads();
     fill<MT_W>(acc, R.ba[col]);
     if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wa + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
         for (int r = 0; r < 16; ++r) acc[mt][r] += tb;
     }
     __syncthreads();
-    tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
+    tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
     __syncthreads();
     fill<MT_W>(acc, R.bb[col]);
     if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     if (a.out) store_tile(a.out);
   } else {
     __syncthreads();
-    tile_to_slab<CF::CM, CF::L, MT_W, CF::SROWS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
+    tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
     __syncthreads();
     const float bt = a.bt[col];
     if constexpr (CF::TAIL == TAIL_DOWN) {
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
       f32x16 t[1];
       fill<1>(t, bt);
       const int r = lane & 31;
-      int tb_[1] = {((wm * CF::SW + r / LO) * CF::SROWS + 2 * (r % LO) + 1) * CF::HSTR + hi};
+      int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
       if (MMD_ABL != 3) mfma_taps<3, CF::CM, CF::HSTR, 1>(t, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
