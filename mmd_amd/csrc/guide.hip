@@ -69,8 +69,8 @@ __device__ __forceinline__ float lane_next(float v) {
 }
 
 // Constraint slots staged per workgroup (1 KiB each).  A workgroup is WPB waves = WPB trajectories of one robot sharing
-// the table: 4 waves x 40 slots for small batches, 16 waves x up to 144 slots (dynamic LDS) when samples_per_robot is a
-// multiple of 16 -- so a 128..256-robot instance (weak scaling over 4-8 GPUs) still reads most of its table from LDS.
+// the table: 4 waves x 40 slots normally, 8 waves x up to 144 slots (dynamic LDS) for bigger tables when samples_per_robot
+// is a multiple of 8 -- so a 128..256-robot instance (weak scaling over 4-8 GPUs) still reads most of its table from LDS.
 constexpr int LDS_SLOTS_SMALL = 40;
 constexpr int LDS_SLOTS_MAX = 144;
 
@@ -86,8 +86,8 @@ __device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t,
     const float dx0 = px - c0.x, dy0 = py - c0.y, dx1 = px - c1.x, dy1 = py - c1.y;
     const float d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
     // active iff radius >= 0 and not (dist > radius)  <=>  not (dist^2 > r|r|): one transcendental (rsq) per point
-    const float m0 = (d0 > c0.z * fabsf(c0.z)) ? 0.f : rsqrtf(d0);
-    const float m1 = (d1 > c1.z * fabsf(c1.z)) ? 0.f : rsqrtf(d1);
+    const float m0 = (d0 > c0.z * fabsf(c0.z)) ? 0.f : __builtin_amdgcn_rsqf(d0);
+    const float m1 = (d1 > c1.z * fabsf(c1.z)) ? 0.f : __builtin_amdgcn_rsqf(d1);
     ax -= dx0 * m0; ay -= dy0 * m0;
     bx -= dx1 * m1; by -= dy1 * m1;
   }
@@ -95,7 +95,7 @@ __device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t,
     const float4 c0 = tab[s * H + t];
     const float dx0 = px - c0.x, dy0 = py - c0.y;
     const float d0 = dx0 * dx0 + dy0 * dy0;
-    const float m0 = (d0 > c0.z * fabsf(c0.z)) ? 0.f : rsqrtf(d0);
+    const float m0 = (d0 > c0.z * fabsf(c0.z)) ? 0.f : __builtin_amdgcn_rsqf(d0);
     ax -= dx0 * m0; ay -= dy0 * m0;
   }
   gx += ax + bx;
@@ -361,16 +361,16 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
   s.traj0 = traj0;
   s.traj_end = traj0 + n_traj;
   const bool guided = s.do_guide && g.robot_grp_off;
-  if (guided && g.max_slots > LDS_SLOTS_SMALL && spr % 16 == 0 && traj0 % 16 == 0) {
-    // 16 trajectories of one robot per workgroup; LDS sized to the largest table any robot can have (g.max_slots)
+  if (guided && g.max_slots > LDS_SLOTS_SMALL && spr % 8 == 0 && traj0 % 8 == 0) {
+    // 8 trajectories of one robot per workgroup (2048 trajectories = 256 workgroups = one per CU); LDS sized to the largest table any robot can have (g.max_slots)
     int slots = guided ? (g.max_slots < LDS_SLOTS_MAX ? g.max_slots : LDS_SLOTS_MAX) : 0;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpm_guide_kernel<16>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpm_guide_kernel<8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SLOTS_MAX * H * 16);
       attr_set = true;
     }
-    hipLaunchKernelGGL(ddpm_guide_kernel<16>, dim3((n_traj + 15) / 16), dim3(1024), (size_t)slots * H * 16, st, g, s,
+    hipLaunchKernelGGL(ddpm_guide_kernel<8>, dim3((n_traj + 7) / 8), dim3(512), (size_t)slots * H * 16, st, g, s,
                        slots, (float4*)x, (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard,
                        spr);
   } else {

@@ -249,7 +249,7 @@ def test_philox_noise_statistics():
     assert abs(float((a ** 4).mean()) - 3.0) < 0.05
 
 
-@pytest.mark.parametrize("n_robots,B", [(48, 4), (48, 16), (160, 16)])
+@pytest.mark.parametrize("n_robots,B", [(48, 4), (48, 8), (160, 16)])
 def test_guide_large_constraint_tables(n_robots, B):
     """More constraint slots than the LDS staging holds (4-wave workgroups: 40; 16-wave workgroups: 144): the overflow
     is read from the L2-resident table.  47 / 159 other robots + a hard group, both workgroup shapes, vs the oracle."""
