@@ -71,7 +71,21 @@ def compute_variance_waypoints(trajs):
     return total
 
 
+_SAVGOL = {}
+
+
+def savgol_matrix(n, window_size=10, poly_order=2):
+    """The Savitzky-Golay filter (scipy mode='interp') is linear in the signal: column j of the [n,n] operator is the
+    filter applied to the j-th unit vector.  Built once on the host, applied on the device."""
+    key = (n, window_size, poly_order)
+    if key not in _SAVGOL:
+        from scipy.signal import savgol_filter
+        _SAVGOL[key] = torch.from_numpy(savgol_filter(np.eye(n), window_size, poly_order, axis=0)).float()
+    return _SAVGOL[key]
+
+
 def smooth_trajs(trajs, window_size=10, poly_order=2):
-    """mmd/common/trajectory_utils.py:31-40 (GPU -> CPU scipy -> GPU, as the reference)."""
-    from scipy.signal import savgol_filter
-    return torch.tensor(savgol_filter(trajs.cpu().numpy(), window_size, poly_order, axis=1)).to(trajs.device)
+    """mmd/common/trajectory_utils.py:31-40 without its GPU -> CPU scipy -> GPU round trip: out = S @ trajs along the
+    horizon with the precomputed SavGol operator S (same result up to fp32 rounding, pinned by golden g9)."""
+    S = savgol_matrix(trajs.shape[1], window_size, poly_order).to(trajs.device)
+    return torch.einsum("ij,bjd->bid", S, trajs.float())
