@@ -31,7 +31,7 @@ import torch         # noqa: E402
 
 H, D = 64, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
-DOMINANT_LAYER = "CH_D2"           # level-2 chain: downs.2 (2 RTBs) + mid_block1/2 @ L16, 128 ch: 55 % of all FLOPs, 1 of 6 launches
+DOMINANT_LAYER = "UNET"            # unet_kernel: the whole TemporalUnet forward in one launch (all 25 convs + GN/Mish)
 
 
 def parse():
@@ -182,7 +182,7 @@ def main():
             pmc = json.load(f).get(DOMINANT_LAYER)
         if pmc:
             traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
-    roofline = {"bound": "mfma", "kernel": f"chain_kernel<{DOMINANT_LAYER}> fused downs.2 + mid blocks: 4 ResidualTemporalBlocks (64->128, 3x 128->128) at L=16, each 2x[Conv1d k5 + GroupNorm + Mish] + time bias + residual",
+    roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; fp32 MFMA implicit-im2col GEMMs, GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
                 "achieved": dom_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
                 "flops_per_launch": flops[dom[0]],

@@ -402,9 +402,7 @@ struct RtbPtrs {
 };
 
 struct ChainArgs {
-  const float* in0; const float* in1;   // [n, L, C0], [n, L, C1]
-  float* out;                            // TAIL_NONE [n, L, CM]; TAIL_DOWN [n, L/2, CM]; TAIL_UP [n, 2L, CM]
-  float* mid_out;                        // [n, L, CM] output of RTB number MID_AFTER (skip connection) or null
+  const float* in0;                      // [n, L, C0] network input (first chain only)
   RtbPtrs r0;
   const float4* wa0_c1;                  // conv A pack of the second input chunk (C1 > 0)
   const float4* wr_c0; const float4* wr_c1; const float* br;   // residual 1x1 conv packs per chunk
@@ -461,40 +459,53 @@ __device__ __forceinline__ void fill(f32x16 (&acc)[MT_W], float v) {
 #ifndef MMD_ABL
 #define MMD_ABL 0   // ablation builds only: 1 = no GroupNorm/Mish, 3 = no MFMA loops
 #endif
-template <class CF>
-__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[CF::LDS_FLOATS];
+// A register tile written into a slab laid out for another stage: rows (sample, position) and columns keep their meaning,
+// only the strides change.  SRC gives the producing stage's tiling (which wave owns which samples / channel slice).
+template <int L_SRC, int MT_W, int SW_SRC, int WN_SRC, int ROW_MUL, int DSS, int DSTR>
+__device__ __forceinline__ void tile_to_stage(const f32x16 (&t)[MT_W], float* dst, int wave, int lane, int row_add) {
+  const int wm = wave / WN_SRC, col = (wave % WN_SRC) * 32 + (lane & 31), hi = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT_W; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int s = wm * SW_SRC + row / L_SRC, l = row % L_SRC;
+      dst[s * DSS + (ROW_MUL * l + row_add + 2) * DSTR + col] = t[mt][r];
+    }
+}
+
+template <int CP, int L, int SROWS, int STR, int SS, int SPB>
+__device__ __forceinline__ void zero_halo(float* slab) {
+  constexpr int TOT = SPB * 4 * CP;
+  for (int idx = threadIdx.x; idx < TOT; idx += 256) {
+    const int c = idx % CP, hr = (idx / CP) % 4, s = idx / (CP * 4);
+    slab[s * SS + (hr < 2 ? hr : L + hr) * STR + c] = 0.f;
+  }
+}
+
+// One level chain for the workgroup's 4 samples.  FIRST: chunk 0 of the input is staged from global memory (the network
+// input); otherwise the previous stage has already written it (and zeroed its halo rows) into the x slab.  The second
+// chunk of a channel concat is the register tile `skip` kept from the down path (tiling SKIP_*).  Results stay in
+// registers: `acc` = output of the RTB chain, `mid` = copy after RTB number MID_AFTER (the skip connection), `tout` = tail
+// conv result (TAIL_DOWN: tout[0][0]; TAIL_UP: tout[parity][mt]).
+template <class CF, bool FIRST, int SKIP_L, int SKIP_MT, int SKIP_SW, int SKIP_WN>
+__device__ __forceinline__ void chain_body(const ChainArgs& a, float* lds, int n0, int lane, int wave,
+                                           const f32x16* skip, f32x16 (&acc)[CF::MT_W], f32x16 (&mid)[CF::MT_W],
+                                           f32x16 (&tout)[2][CF::MT_W]) {
   float* hslab = lds + CF::XSLAB;
   float* xslab = CF::SHARE ? hslab : lds;
   constexpr int XS = CF::SHARE ? CF::HSTR : CF::XSTR;      // row stride of the slab conv A reads
   constexpr int XSSv = CF::SHARE ? CF::HSS : CF::XSS;      // its sample stride
   constexpr int MT_W = CF::MT_W;
 
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / CF::WN, wn = wave % CF::WN;
-  const int n0 = blockIdx.x * CF::SPB;
   const int col = wn * 32 + (lane & 31);
   const int hi = lane >> 5;
 
-#ifdef MMD_STAGGER
-  // experiment: offset the second "wave" of workgroups (b >= 256 shares a CU with b - 256) by MMD_STAGGER x ~0.5 us so
-  // that co-resident workgroups do not run their MFMA phases / epilogues in lockstep
-  if ((blockIdx.x >> MMD_STAGGER_BIT) & 1) {
-    if (MMD_STAGGER > 0) { for (int i = 0; i < MMD_STAGGER; ++i) __builtin_amdgcn_s_sleep(16); }
-    else __builtin_amdgcn_s_setprio(2);
-  }
-#endif
-  if constexpr (CF::SHARE) {
-    stage_slab<CF::C0, 0, CF::CM, CF::L, CF::SROWS, 2, CF::HSTR, CF::SPB, CF::HSS>(hslab, a.in0, nullptr, n0, a.n);
-  } else {
+  static_assert(!CF::SHARE, "level chains start with a channel-changing RTB");
+  if constexpr (FIRST)
     stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
-    constexpr int TOT = CF::SPB * 4 * CF::CM;             // zero the halo rows of the H slab
-    for (int idx = threadIdx.x; idx < TOT; idx += 256) {
-      const int c = idx % CF::CM, hr = (idx / CF::CM) % 4, s = idx / (CF::CM * 4);
-      hslab[s * CF::HSS + (hr < 2 ? hr : CF::L + hr) * CF::HSTR + c] = 0.f;
-    }
-  }
+  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
 
   int srow[MT_W], lrow[MT_W];
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
 #pragma unroll
   for (int mt = 0; mt < MT_W; ++mt) hbase[mt] = srow[mt] * CF::HSS + lrow[mt] * CF::HSTR + hi;
 
-  f32x16 acc[MT_W], res[MT_W];
+  f32x16 res[MT_W];
   // =================== RTB 0 ===================
   {
     int xbase[MT_W], rbase[MT_W];
@@ -524,8 +535,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
       if (MMD_ABL != 3) mfma_taps<1, CF::C0P, XS, MT_W>(res, xslab, rbase, a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane);
     }
     if constexpr (CF::C1 > 0) {                              // second half of the channel concat, same slab
-      __syncthreads();
-      stage_slab<CF::C1, 0, CF::C1P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in1, nullptr, n0, a.n);
+      __syncthreads();                                       // chunk 0 has been consumed by every wave
+      tile_to_stage<SKIP_L, SKIP_MT, SKIP_SW, SKIP_WN, 1, CF::XSS, CF::XSTR>(
+          *reinterpret_cast<const f32x16(*)[SKIP_MT]>(skip), xslab, wave, lane, 0);
       __syncthreads();
       if (MMD_ABL != 3) mfma_taps<5, CF::C1P, XS, MT_W>(acc, xslab, xbase, a.wa0_c1 + ((size_t)wn * (5 * CF::C1P / 8)) * 64 + lane);
       if constexpr (CF::RES0 == RES_CONV)
@@ -549,26 +561,13 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     for (int mt = 0; mt < MT_W; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if constexpr (CF::RES0 == RES_CONV) {
-          acc[mt][r] += res[mt][r];
-        } else {                                             // identity residual of the chain input: from global / L2
-          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
-          if (n0 + s < a.n) acc[mt][r] += a.in0[((size_t)(n0 + s) * CF::L + l) * CF::CM + col];
-        }
+        acc[mt][r] += res[mt][r];
       }
   }
-  auto store_tile = [&](float* dst) {
+  if constexpr (CF::MID_AFTER == 0) {
 #pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
-        if (n0 + s < a.n) dst[((size_t)(n0 + s) * CF::L + l) * CF::CM + col] = acc[mt][r];
-      }
-  };
-  if (CF::MID_AFTER == 0 && a.mid_out) store_tile(a.mid_out);
+    for (int mt = 0; mt < MT_W; ++mt) mid[mt] = acc[mt];
+  }
 
   // =================== identity RTBs ===================
 #pragma unroll
@@ -597,13 +596,14 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, R.gb[col], R.beb[col]);
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt) acc[mt] += res[mt];
-    if (CF::MID_AFTER == k + 1 && a.mid_out) store_tile(a.mid_out);
+    if (CF::MID_AFTER == k + 1) {
+#pragma unroll
+      for (int mt = 0; mt < MT_W; ++mt) mid[mt] = acc[mt];
+    }
   }
 
   // =================== tail ===================
-  if constexpr (CF::TAIL == TAIL_NONE) {
-    if (a.out) store_tile(a.out);
-  } else {
+  if constexpr (CF::TAIL != TAIL_NONE) {
     __syncthreads();
     tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
     __syncthreads();
@@ -611,37 +611,137 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     if constexpr (CF::TAIL == TAIL_DOWN) {
       // Conv1d(k3, s2, p1): one 32-row tile per wave = its SW samples x L/2 output rows; tap 0 reads slab row 2*lo + 1
       constexpr int LO = CF::L / 2;
-      f32x16 t[1];
+      f32x16 (&t)[1] = *reinterpret_cast<f32x16(*)[1]>(&tout[0][0]);
       fill<1>(t, bt);
       const int r = lane & 31;
       int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
       if (MMD_ABL != 3) mfma_taps<3, CF::CM, CF::HSTR, 1>(t, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
-        const int s = wm * CF::SW + row / LO, lo = row % LO;
-        if (n0 + s < a.n) a.out[((size_t)(n0 + s) * LO + lo) * CF::CM + col] = t[0][q];
-      }
     } else {
       // ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes: out[2m] = in[m-1] W3 + in[m] W1, out[2m+1] = in[m] W2 + in[m+1] W0
       constexpr int G = 2 * CF::CM / 8;
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
-        f32x16 t[MT_W];
+        f32x16 (&t)[MT_W] = tout[pass];
         fill<MT_W>(t, bt);
         int ub[MT_W];
 #pragma unroll
         for (int mt = 0; mt < MT_W; ++mt) ub[mt] = hbase[mt] + (1 + pass) * CF::HSTR;
         if (MMD_ABL != 3) mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wn * G) * 64 + lane);
-#pragma unroll
-        for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
-            const int s = wm * CF::SW + row / CF::L, l = row % CF::L;
-            if (n0 + s < a.n) a.out[((size_t)(n0 + s) * (2 * CF::L) + 2 * l + pass) * CF::CM + col] = t[mt][q];
-          }
       }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The whole TemporalUnet forward for 4 samples in ONE workgroup / ONE launch: the five level chains and the final conv
+// hand their activations to each other through LDS (tail tile -> next stage's x slab), the two skip connections wait in
+// registers (32 VGPRs each) for the up path.  HBM traffic per trajectory and forward: 1 KiB in, 1 KiB out.
+// ----------------------------------------------------------------------------------------------------------------
+//                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
+using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
+using CH_D1 = ChainCfg<32, 0, 64, 32, 2, RES_CONV, 1, 1, TAIL_DOWN>;     // downs.1 (skip1 = output of its 2nd RTB)
+using CH_D2 = ChainCfg<64, 0, 128, 16, 2, RES_CONV, 3, 1, TAIL_NONE>;    // downs.2 + mid_block1/2 (skip2 after downs.2)
+using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.0: cat(x, skip2) RTB, RTB, Upsample1d
+using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
+constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
+
+struct UnetArgs {
+  ChainArgs c[5];
+  ConvArgs fin;    // final Conv1dBlock(32->32) + 1x1 conv (32->4): wpk/bias/gamma/beta + res_wpk/res_bias = 1x1, out = eps
+  int n;
+};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int UNET_LDS_FLOATS =
+    cmax(cmax(cmax(CH_D0::LDS_FLOATS, CH_D1::LDS_FLOATS), cmax(CH_D2::LDS_FLOATS, CH_U0::LDS_FLOATS)),
+         cmax(CH_U1::LDS_FLOATS, 4 * FIN_SS));
+static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SPB == 4 && CH_U1::SPB == 4,
+              "every stage must own the same 4 samples");
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel(UnetArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * 4;
+
+  f32x16 skip1[2], skip2[2];
+  // ---- downs.0 @ L=64 -> [4][32][32]
+  {
+    f32x16 acc[2], mid[2], t[2][2];
+    chain_body<CH_D0, true, 16, 1, 1, 1>(a.c[0], lds, n0, lane, wave, nullptr, acc, mid, t);
+    __syncthreads();                                                       // the tail conv is done reading the H slab
+    tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(
+        *reinterpret_cast<f32x16(*)[1]>(&t[0][0]), lds, wave, lane, 0);
+    zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
+  }
+  // ---- downs.1 @ L=32 -> [4][16][64], skip1
+  {
+    f32x16 acc[2], t[2][2];
+    chain_body<CH_D1, false, 16, 1, 1, 1>(a.c[1], lds, n0, lane, wave, nullptr, acc, skip1, t);
+    __syncthreads();
+    tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(
+        *reinterpret_cast<f32x16(*)[1]>(&t[0][0]), lds, wave, lane, 0);
+    zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
+  }
+  // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2
+  {
+    f32x16 acc[2], t[2][2];
+    chain_body<CH_D2, false, 16, 1, 1, 1>(a.c[2], lds, n0, lane, wave, nullptr, acc, skip2, t);
+    __syncthreads();
+    tile_to_stage<16, 2, CH_D2::SW, CH_D2::WN, 1, CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane, 0);
+    zero_halo<CH_U0::C0P, CH_U0::L, CH_U0::SROWS, CH_U0::XSTR, CH_U0::XSS, 4>(lds);
+  }
+  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
+  {
+    f32x16 acc[1], mid[1], t[2][1];
+    chain_body<CH_U0, false, CH_D2::L, 2, CH_D2::SW, CH_D2::WN>(a.c[3], lds, n0, lane, wave, skip2, acc, mid, t);
+    __syncthreads();
+    tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
+    tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
+    zero_halo<CH_U1::C0P, CH_U1::L, CH_U1::SROWS, CH_U1::XSTR, CH_U1::XSS, 4>(lds);
+  }
+  // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
+  {
+    f32x16 acc[1], mid[1], t[2][1];
+    chain_body<CH_U1, false, CH_D1::L, 2, CH_D1::SW, CH_D1::WN>(a.c[4], lds, n0, lane, wave, skip1, acc, mid, t);
+    __syncthreads();
+    tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
+    tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
+    zero_halo<32, 64, FIN_SROWS, FIN_STR, FIN_SS, 4>(lds);
+    __syncthreads();
+  }
+  // ---- final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]
+  {
+    const ConvArgs& f = a.fin;
+    const int col = lane & 31, hi = lane >> 5;
+    f32x16 acc[2];
+    int abase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) abase[mt] = wave * FIN_SS + (mt * 32 + (lane & 31)) * FIN_STR + hi;
+    fill<2>(acc, f.bias[col]);
+    if (MMD_ABL != 3) mfma_taps<5, 32, FIN_STR, 2>(acc, lds, abase, f.wpk + lane);
+    if (MMD_ABL != 1) gn_mish<32, 64, 2>(acc, f.gamma[col], f.beta[col]);
+    __syncthreads();                                                       // every wave is done reading the slab
+    float* yt = lds + wave * (64 * 33);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yt[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + col] = acc[mt][r];
+    __syncthreads();
+    f32x16 acc2[2];
+    int ybase[2];
+    fill<2>(acc2, col < 4 ? f.res_bias[col] : 0.f);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) ybase[mt] = (mt * 32 + (lane & 31)) * 33 + hi;
+    if (MMD_ABL != 3) mfma_taps<1, 32, 33, 2>(acc2, yt, ybase, f.res_wpk + lane);
+    if (col < 4 && n0 + wave < a.n) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          f.out[((size_t)(n0 + wave) * 64 + row) * 4 + col] = acc2[mt][r];
+        }
     }
   }
 }
@@ -824,30 +924,6 @@ static size_t push(std::vector<float>& blob, const float* p, int64_t n) {
   return off;
 }
 
-template <class CF>
-static int launch(const ConvArgs& a, hipStream_t st) {
-  const int grid = (a.n + CF::SPB - 1) / CF::SPB;
-  hipLaunchKernelGGL(conv_kernel<CF>, dim3(grid), dim3(256), 0, st, a);
-  return 0;
-}
-
-// ---- the instantiated layer shapes (unet_input_dim 32, dim_mults (1,2,4), H = 64) ------------------------------
-//                 C0   C1  COUT LIN  MODE        MT_W EPI           RES        RC0  RC1
-using FIN = Cfg<32, 0, 32, 64, MODE_CONV5, 2, EPI_GN_FINAL, RES_NONE, 0, 0>;
-
-//                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
-using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
-using CH_D1 = ChainCfg<32, 0, 64, 32, 2, RES_CONV, 1, 1, TAIL_DOWN>;     // downs.1 (+ skip1 store)
-using CH_D2 = ChainCfg<64, 0, 128, 16, 2, RES_CONV, 3, 1, TAIL_NONE>;    // downs.2 + mid_block1/2 (+ skip2 store)
-using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.0: cat(x, skip2) RTB, RTB, Upsample1d
-using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
-
-template <class CF>
-static int launch_chain(const ChainArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(chain_kernel<CF>, dim3((a.n + CF::SPB - 1) / CF::SPB), dim3(256), 0, st, a);
-  return 0;
-}
-
 static RtbPtrs rtb_ptrs(const mmd_unet_s* u, const RtbW& w, int t) {
   RtbPtrs p{};
   p.wa = reinterpret_cast<const float4*>(u->blob + w.a.wpk);
@@ -859,10 +935,10 @@ static RtbPtrs rtb_ptrs(const mmd_unet_s* u, const RtbW& w, int t) {
 }
 
 // chain over RTBs rtb[0] (first) and rtb[1..n_ident]; tail = down/up conv weights or null
-static ChainArgs args_chain(const mmd_unet_s* u, const int* rtb, int n_ident, const ConvW* tail, const float* in0,
-                            const float* in1, float* out, float* mid_out, int t, int n) {
+static ChainArgs args_chain(const mmd_unet_s* u, const int* rtb, int n_ident, const ConvW* tail, const float* in0, int t,
+                            int n) {
   ChainArgs a{};
-  a.in0 = in0; a.in1 = in1; a.out = out; a.mid_out = mid_out; a.n = n;
+  a.in0 = in0; a.n = n;
   const RtbW& w0 = u->rtb[rtb[0]];
   a.r0 = rtb_ptrs(u, w0, t);
   a.wa0_c1 = reinterpret_cast<const float4*>(u->blob + w0.a_c1);
@@ -873,17 +949,6 @@ static ChainArgs args_chain(const mmd_unet_s* u, const int* rtb, int n_ident, co
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
   return a;
 }
-
-static ConvArgs args_plain(const mmd_unet_s* u, const ConvW& w, const float* in, float* out, int n) {
-  ConvArgs a{};
-  a.in0 = in; a.out = out;
-  a.wpk = reinterpret_cast<const float4*>(u->blob + w.wpk);
-  a.bias = u->blob + w.bias;
-  a.n = n;
-  return a;
-}
-
-constexpr size_t ACT_FLOATS = 2048;   // L * C is 2048 at every level (64x32, 32x64, 16x128)
 
 }  // namespace mmd
 
@@ -1011,25 +1076,24 @@ int mmd_unet_destroy(mmd_unet_t u) {
   return 0;
 }
 
-size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) {
-  return (size_t)4 * ACT_FLOATS * sizeof(float) * (size_t)(n_traj > 0 ? n_traj : 0);
-}
+// The forward keeps every intermediate in LDS / registers; the workspace argument is kept in the ABI (callers pass the
+// buffer they sized with this function) but only a token size is asked for.
+size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) { return n_traj > 0 ? 256 : 0; }
 
-constexpr int kNumLayers = 6;
-static const char* const kLayerNames[kNumLayers] = {"CH_D0", "CH_D1", "CH_D2", "CH_U0", "CH_U1", "FIN"};
-// launches that run the same kernel instantiation share a kind (index of the first such launch)
-static const int kLayerKind[kNumLayers] = {0, 1, 2, 3, 4, 5};
+constexpr int kNumLayers = 1;
+static const char* const kLayerNames[kNumLayers] = {"UNET"};
+static const int kLayerKind[kNumLayers] = {0};
 
-// algorithmic FLOPs per trajectory of each launch: sum over its convs of 2 * C_out * taps * C_in * L_out
+// algorithmic FLOPs per trajectory of one forward: sum over its convs of 2 * C_out * taps * C_in * L_out
 static constexpr double rtb_flops(double cin, double cout, double L) {
   return 2.0 * cout * 5 * cin * L + 2.0 * cout * 5 * cout * L + (cin != cout ? 2.0 * cout * cin * L : 0.0);
 }
 static const double kLayerFlops[kNumLayers] = {
-    rtb_flops(4, 32, 64) + rtb_flops(32, 32, 64) + 2.0 * 32 * 3 * 32 * 32,
-    rtb_flops(32, 64, 32) + rtb_flops(64, 64, 32) + 2.0 * 64 * 3 * 64 * 16,
-    rtb_flops(64, 128, 16) + 3 * rtb_flops(128, 128, 16),
-    rtb_flops(256, 64, 16) + rtb_flops(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16,
-    rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32,
+    rtb_flops(4, 32, 64) + rtb_flops(32, 32, 64) + 2.0 * 32 * 3 * 32 * 32 +
+    rtb_flops(32, 64, 32) + rtb_flops(64, 64, 32) + 2.0 * 64 * 3 * 64 * 16 +
+    rtb_flops(64, 128, 16) + 3 * rtb_flops(128, 128, 16) +
+    rtb_flops(256, 64, 16) + rtb_flops(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16 +
+    rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64};
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
@@ -1051,23 +1115,21 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
     for (int _r = 0; _r < reps; ++_r) { __VA_ARGS__; }                                               \
     if (_p) { (void)hipEventRecord(u->prof_ev[u->prof_used + 1], st); u->prof_used += 2; }           \
   } while (0)
-  float* P0 = (float*)ws;
-  float* P1 = P0 + (size_t)n * ACT_FLOATS;
-  float* S1 = P1 + (size_t)n * ACT_FLOATS;
-  float* S2 = S1 + (size_t)n * ACT_FLOATS;
   // state_dict RTB indices: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2 = 0..11
   static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};
-  MMD_L(launch_chain<CH_D0>(args_chain(u, kD0, 1, &u->down[0], x, nullptr, P0, nullptr, t, n), st));   // -> [n,32,32]
-  MMD_L(launch_chain<CH_D1>(args_chain(u, kD1, 1, &u->down[1], P0, nullptr, P1, S1, t, n), st));        // -> [n,16,64], skip1
-  MMD_L(launch_chain<CH_D2>(args_chain(u, kD2, 3, nullptr, P1, nullptr, P0, S2, t, n), st));            // -> [n,16,128], skip2
-  MMD_L(launch_chain<CH_U0>(args_chain(u, kU0, 1, &u->up[0], P0, S2, P1, nullptr, t, n), st));          // -> [n,32,64]
-  MMD_L(launch_chain<CH_U1>(args_chain(u, kU1, 1, &u->up[1], P1, S1, P0, nullptr, t, n), st));          // -> [n,64,32]
-  // final_conv
-  ConvArgs f = args_plain(u, u->fin, P0, eps, n);
-  f.gamma = u->blob + u->fin.gamma; f.beta = u->blob + u->fin.beta;
-  f.res_wpk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
-  f.res_bias = u->blob + u->fin_b1;
-  MMD_L(launch<FIN>(f, st));
+  UnetArgs a{};
+  a.n = n;
+  a.c[0] = args_chain(u, kD0, 1, &u->down[0], x, t, n);
+  a.c[1] = args_chain(u, kD1, 1, &u->down[1], nullptr, t, n);
+  a.c[2] = args_chain(u, kD2, 3, nullptr, nullptr, t, n);
+  a.c[3] = args_chain(u, kU0, 1, &u->up[0], nullptr, t, n);
+  a.c[4] = args_chain(u, kU1, 1, &u->up[1], nullptr, t, n);
+  a.fin.out = eps; a.fin.n = n;
+  a.fin.wpk = reinterpret_cast<const float4*>(u->blob + u->fin.wpk);
+  a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
+  a.fin.res_wpk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
+  a.fin.res_bias = u->blob + u->fin_b1;
+  MMD_L(hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a));
   if (ev) (void)hipEventRecord(ev[li], st);
 #undef MMD_L
   MMD_HIP_CHECK(hipGetLastError());
