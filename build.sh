@@ -1,8 +1,10 @@
 #!/bin/bash
 # Build libmmd_amd.so for gfx950 (cross-compiles without a GPU).  Usage: ./build.sh [extra hipcc flags]
+# -fno-slp-vectorize: the SLP vectorizer pairs fp32 ops into v_pk_* and pays for it with v_mov shuffles in the MFMA loops
+# (10 extra VALU ops per Winograd k-step); packed fp32 is not faster here.
 set -e
 cd "$(dirname "$0")"
 mkdir -p mmd_amd/lib
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -fno-slp-vectorize \
   mmd_amd/csrc/unet.hip mmd_amd/csrc/guide.hip mmd_amd/csrc/api.hip mmd_amd/csrc/multi_agent.hip -o mmd_amd/lib/libmmd_amd.so "$@"
 echo "built mmd_amd/lib/libmmd_amd.so"

@@ -52,7 +52,8 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
                     const float* const* tensors, const int64_t* numels, int n_tensors, void* stream);
 int mmd_unet_destroy(mmd_unet_t unet);
 
-/* Scratch (activations) needed by mmd_unet_forward for n_traj trajectories; allocate it with the host framework. */
+/* Scratch needed by mmd_unet_forward for n_traj trajectories; allocate it with the host framework.  (The forward keeps
+ * every activation on chip, so this is a token size; the argument stays in the ABI.) */
 size_t mmd_unet_workspace_bytes(mmd_unet_t unet, int n_traj);
 
 /* eps = model(x, t, context=None)  (temporal_unet.py:121; called from p_mean_variance,
@@ -60,12 +61,15 @@ size_t mmd_unet_workspace_bytes(mmd_unet_t unet, int n_traj);
 int mmd_unet_forward(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj, void* workspace_dev,
                      size_t workspace_bytes, void* stream);
 
-/* Measurement hooks (bench.py): the forward is 29 kernel launches; layer i's short name, its algorithmic FLOPs per
- * trajectory (2 * C_out * taps * C_in * L_out, fused 1x1 convs included), and a profiled forward that brackets every
- * launch with HIP events on `stream` and returns the mean duration of each over `repeats` forwards in layer_ms[29]. */
+/* Measurement hooks (bench.py): the forward is mmd_unet_num_layers() kernel launches (one: "UNET"); launch i's short
+ * name, its algorithmic FLOPs per trajectory (direct-convolution count: 2 * C_out * taps * C_in * L_out over its
+ * convs), the MFMA FLOPs it actually issues per trajectory (Winograd convs issue 0.6x, channel padding included), and
+ * a profiled forward that brackets every launch with HIP events on `stream` and returns the mean duration of each
+ * over `repeats` forwards in layer_ms[mmd_unet_num_layers()]. */
 int mmd_unet_num_layers(void);
 const char* mmd_unet_layer_name(int i);
 double mmd_unet_layer_flops(int i);
+double mmd_unet_layer_mfma_flops(int i);
 int mmd_unet_profile(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj, void* workspace_dev,
                      size_t workspace_bytes, int repeats, float* layer_ms, void* stream);
 /* In-loop profiling: bracket every launch of the kernel that runs layer `layer` (all launches of the same kernel

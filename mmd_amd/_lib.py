@@ -49,6 +49,7 @@ _SIGNATURES = {
     "mmd_unet_num_layers": (C.c_int, []),
     "mmd_unet_layer_name": (C.c_char_p, [C.c_int]),
     "mmd_unet_layer_flops": (C.c_double, [C.c_int]),
+    "mmd_unet_layer_mfma_flops": (C.c_double, [C.c_int]),
     "mmd_unet_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                    C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "mmd_unet_profile_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),

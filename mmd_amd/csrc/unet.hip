@@ -1,19 +1,22 @@
-// TemporalUnet forward for gfx950 (MI355X): every Conv1d / ConvTranspose1d of the reference network
-// (mmd/models/diffusion_models/temporal_unet.py:121-174, mmd/models/layers/layers.py:261-358) is an implicit-im2col
-// GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32), with GroupNorm + Mish + time-bias / residual fused
-// into the epilogue.
+// TemporalUnet forward for gfx950 (MI355X), the whole network in ONE launch (unet_kernel).  Every Conv1d /
+// ConvTranspose1d of the reference network (mmd/models/diffusion_models/temporal_unet.py:121-174,
+// mmd/models/layers/layers.py:261-358) is a GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and
+// accumulation), with GroupNorm + Mish + time-bias / residual fused into the epilogue:
+//   * down path, mid blocks and the final block: the stride-1 k=5 convs run as Winograd F(2,5) (6 instead of 10
+//     multiplies per 2 outputs; fp32, ~1e-6 relative difference to the direct sum);
+//   * up path, strided / transposed / 1x1 convs: direct implicit-im2col GEMMs (taps = row-shifted views of an LDS slab).
 //
-// Layout.  Activations are channels-last [n_traj, L, C] fp32 in HBM, so the trajectory tensor [n, 64, 4] needs no
-// transpose on either side.  A workgroup (4 waves) owns SPB whole samples: it stages their [L+4, C_in] slabs (zero
-// halo) into LDS once, then every wave runs its K loop (taps x channels) with no further barrier -- the five taps
-// are row-shifted views of the same slab, so the input is read from HBM once, not five times.  A wave owns whole
-// samples x a 32-channel slice (RW = 32*MT_W rows x 32 cols): the GroupNorm groups (C_out/8 channels) and samples
-// never straddle waves, so the statistics are pure in-register + cross-lane reductions.  Weights are pre-packed
-// on the host in MFMA B-fragment order so a lane fetches 4 consecutive k-steps with one 16-byte load straight from
-// L2 (no LDS staging: a B element is used by at most two m-tiles).
+// Layout.  The trajectory tensor is channels-last [n_traj, 64, 4] fp32 in HBM on both sides (no transposes).  A
+// workgroup (4 waves) owns 4 whole samples for the entire forward: activations live in LDS slabs [sample][L+4][C+1]
+// (zero halo, odd row stride: conflict-free A-fragment reads) and in register tiles; the two skip connections wait in
+// registers for the up path; nothing but the input, the output and the weights touches HBM/L2.  A wave owns whole
+// samples x a 32-channel slice, so GroupNorm groups (C/8 channels) and samples never straddle waves: the statistics
+// are in-register + cross-lane reductions.  Weights are pre-packed on the host in MFMA B-fragment order and fetched
+// straight from L2 through a register ring (no LDS staging: a B element is used once per workgroup).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -24,61 +27,25 @@ namespace mmd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { MODE_CONV5 = 0, MODE_DOWN = 1, MODE_UP = 2 };
-enum { EPI_PLAIN = 0, EPI_GN_TB = 1, EPI_GN_RES = 2, EPI_GN_FINAL = 3 };
 enum { RES_NONE = 0, RES_IDENT = 1, RES_CONV = 2 };
 
-struct ConvArgs {
-  const float* in0;      // [n, LIN, C0]
-  const float* in1;      // [n, LIN, C1] (second half of a channel concat) or null
-  float* out;            // [n, LOUT, COUT]   (EPI_GN_FINAL: [n, 64, 4])
-  const float4* wpk;     // packed B fragments (UP: parity 0 then parity 1)
-  const float* bias;     // [COUT]
-  const float* gamma;    // [COUT] GroupNorm weight
-  const float* beta;     // [COUT] GroupNorm bias
-  const float* tbias;    // [COUT] time-embedding projection for the current t (EPI_GN_TB)
-  const float* res0;     // residual source (RES_IDENT: [n, L, COUT]; RES_CONV: [n, L, RC0])
-  const float* res1;     // second half of the residual concat or null
-  const float4* res_wpk; // packed 1x1 residual conv (RES_CONV) / final 1x1 conv (EPI_GN_FINAL)
-  const float* res_bias; // [COUT] / [4]
-  int n;                 // number of trajectories
-};
-
-template <int C0_, int C1_, int COUT_, int LIN_, int MODE_, int MT_W_, int EPI_, int RES_, int RC0_, int RC1_>
-struct Cfg {
-  static constexpr int C0 = C0_, C1 = C1_, COUT = COUT_, LIN = LIN_, MODE = MODE_, MT_W = MT_W_, EPI = EPI_;
-  static constexpr int RES = RES_, RC0 = RC0_, RC1 = RC1_;
-  static constexpr int CIN = C0 + C1;
-  static constexpr int CINP = (CIN + 7) / 8 * 8;         // K per tap, multiple of 8 (4 k-pairs per 16-byte B load)
-  static constexpr int SSTR = CINP + 1;                  // odd row stride: A-fragment reads are bank-conflict free
-  static constexpr int WN = COUT / 32;                   // waves along channels
-  static constexpr int WM = 4 / WN;                      // waves along samples
-  static constexpr int LROWS = MODE == MODE_DOWN ? LIN / 2 : LIN;   // GEMM rows per sample
-  static constexpr int LOUT = MODE == MODE_DOWN ? LIN / 2 : (MODE == MODE_UP ? LIN * 2 : LIN);
-  static constexpr int RW = 32 * MT_W;                   // GEMM rows per wave
-  static constexpr int SW = RW / LROWS;                  // samples per wave
-  static constexpr int SPB = WM * SW;                    // samples per workgroup
-  static constexpr int SROWS = LIN + 4;                  // slab rows per sample (2-row zero halo each side)
-  static constexpr int SLAB = SPB * SROWS * SSTR;        // floats
-  static constexpr int NTAPS = MODE == MODE_CONV5 ? 5 : (MODE == MODE_DOWN ? 3 : 2);
-  static constexpr int RC = RC0 + RC1;
-  static constexpr int RCP = (RC + 7) / 8 * 8;
-  static constexpr int RSTR = RCP + 1;
-  static constexpr int RSLAB = RES == RES_CONV ? SPB * LIN * RSTR : 0;
-  static constexpr int YSLAB = EPI == EPI_GN_FINAL ? 4 * RW * 33 : 0;
-  static constexpr int LDS_FLOATS = (SLAB + RSLAB) > YSLAB ? (SLAB + RSLAB) : YSLAB;
-  static constexpr int CPG = COUT / 8;                   // channels per GroupNorm group (8 groups for 32/64/128)
-  static_assert(COUT % 32 == 0 && (WN == 1 || WN == 2 || WN == 4), "COUT must be 32, 64 or 128");
-  static_assert(RW % LROWS == 0 && SW >= 1, "a wave must own whole samples");
-  static_assert(LROWS >= 16, "sample index must be a function of (mt, reg>>3)");
+// final Conv1dBlock(32->32, k5) + Conv1d(32->4, k1) of the network
+struct FinalArgs {
+  float* out;             // eps [n, 64, 4]
+  const float4* wpk;      // Winograd pack of the k5 conv
+  const float* bias;      // [32]
+  const float* gamma;     // [32] GroupNorm weight
+  const float* beta;      // [32] GroupNorm bias
+  const float4* w1_pk;    // packed 1x1 conv (B fragments, N padded to 32)
+  const float* w1_bias;   // [4]
 };
 
 // Mish(y) = y * tanh(softplus(y)) = y * n / (n + 2), n = e^y (e^y + 2)   (torch.nn.Mish; softplus threshold 20)
 __device__ __forceinline__ float mish(float y) {
-  if (y > 20.f) return y;
-  float e = __expf(y);
-  float n = e * (e + 2.f);
-  return y * __fdividef(n, n + 2.f);
+  const float e = __expf(fminf(y, 20.f));
+  const float n = e * (e + 2.f);
+  const float m = y * __fdividef(n, n + 2.f);
+  return y > 20.f ? y : m;       // branch-free: a select, not 32 divergent branches per tile
 }
 
 // Stage SPB samples' [LIN, C] rows (channels-last, optionally a concat of two tensors) into an LDS slab
@@ -137,6 +104,29 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
 // B fragments are prefetched FOUR k-groups (32 MFMAs = 2048 cycles) ahead through a 4-register ring so the L2
 // latency of a weight fetch never sits in front of the MFMA that consumes it; pack_b pads every packed tensor with 4
 // zero groups so the ring may over-read unconditionally.
+// A compiler-level memory barrier right after a ring refill: the weight loads are read-only, so LLVM is otherwise free to
+// sink them down to their first use (one k-group later: the L2 latency then sits in front of the MFMA again).
+// The machine scheduler gets a full barrier at the same point, or it hoists the VALU consumers of an LDS read up to the
+// read (and with them the s_waitcnt), which exposes the LDS latency once per k-step.
+#define MMD_PIN_LOADS()                 \
+  do {                                  \
+    asm volatile("" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);  \
+  } while (0)
+
+// Phase tracing (side builds with -DMMD_TRACE only; tools/dbg/trace_phases.py): lane 0 of every wave stamps the 100 MHz
+// wall clock at tagged points into a [block][wave][256] table set with mmd_debug_set_trace().
+#ifdef MMD_TRACE
+__device__ unsigned long long* g_trace = nullptr;
+#define TR(tag)                                                                                                       \
+  do {                                                                                                                \
+    if (g_trace && (threadIdx.x & 63) == 0)                                                                           \
+      g_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 256 + (tag)] = wall_clock64();                          \
+  } while (0)
+#else
+#define TR(tag) do { } while (0)
+#endif
+
 template <int MT_W>
 __device__ __forceinline__ void load_a(float (&a)[4][MT_W], const float* slab, const int (&abase)[MT_W], int aoff) {
 #pragma unroll
@@ -192,15 +182,19 @@ __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab
         load_a<MT_W>(a1, slab, abase, aoff + 8);
         mfma_a<MT_W>(acc, a0, b0);
         b0 = p[0];
+        MMD_PIN_LOADS();
         load_a<MT_W>(a0, slab, abase, aoff + 16);
         mfma_a<MT_W>(acc, a1, b1);
         b1 = p[64];
+        MMD_PIN_LOADS();
         load_a<MT_W>(a1, slab, abase, aoff + 24);
         mfma_a<MT_W>(acc, a0, b2);
         b2 = p[128];
+        MMD_PIN_LOADS();
         load_a<MT_W>(a0, slab, abase, anext);      // (after the last group this reads a valid slab row and is unused)
         mfma_a<MT_W>(acc, a1, b3);
         b3 = p[192];
+        MMD_PIN_LOADS();
       }
     }
   }
@@ -254,144 +248,6 @@ __device__ __forceinline__ void gn_mish(f32x16 (&acc)[MT_W], float gamma, float 
     }
 }
 
-template <class CF>
-__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[CF::LDS_FLOATS];
-  float* slab = lds;
-  float* rslab = lds + CF::SLAB;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave / CF::WN, wn = wave % CF::WN;
-  const int n0 = blockIdx.x * CF::SPB;
-  const int col = wn * 32 + (lane & 31);
-  const int hi = lane >> 5;
-
-#ifndef MMD_ABL
-#define MMD_ABL 0   // ablation builds only (tools/ablate.sh): 1 = no epilogue, 2 = no staging, 3 = no MFMA loop
-#endif
-  if (MMD_ABL != 2) {
-    stage_slab<CF::C0, CF::C1, CF::CINP, CF::LIN, CF::SROWS, 2, CF::SSTR, CF::SPB>(slab, a.in0, a.in1, n0, a.n);
-    if constexpr (CF::RES == RES_CONV)
-      stage_slab<CF::RC0, CF::RC1, CF::RCP, CF::LIN, CF::LIN, 0, CF::RSTR, CF::SPB>(rslab, a.res0, a.res1, n0, a.n);
-  }
-  __syncthreads();
-
-  // this lane's A rows: tile row i = lane&31 of m-tile mt  ->  (sample, position)
-  constexpr int RSTEP = CF::MODE == MODE_DOWN ? 2 : 1;
-  int srow[CF::MT_W];      // wave-local sample of the lane's A row
-  int lrow[CF::MT_W];      // position within the sample
-#pragma unroll
-  for (int mt = 0; mt < CF::MT_W; ++mt) {
-    const int r = mt * 32 + (lane & 31);
-    srow[mt] = wm * CF::SW + r / CF::LROWS;
-    lrow[mt] = r % CF::LROWS;
-  }
-  constexpr int G = CF::NTAPS * CF::CINP / 8;   // 16-byte B groups per n-tile
-  const float bias = a.bias[col];
-
-  constexpr int NPASS = CF::MODE == MODE_UP ? 2 : 1;
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    f32x16 acc[CF::MT_W];
-#pragma unroll
-    for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = bias;
-
-    // slab row of tap 0:  CONV5: l (+2 halo -2 pad);  DOWN: 2*lo + 1;  UP parity 0: m + 1, parity 1: m + 2
-    const int roff = CF::MODE == MODE_CONV5 ? 0 : (CF::MODE == MODE_DOWN ? 1 : 1 + pass);
-    int abase[CF::MT_W];
-#pragma unroll
-    for (int mt = 0; mt < CF::MT_W; ++mt)
-      abase[mt] = (srow[mt] * CF::SROWS + lrow[mt] * RSTEP + roff) * CF::SSTR + hi;
-    // UP: the two parity packs are separate pack_b() outputs, each padded with 4 groups
-    const float4* wp = a.wpk + ((size_t)pass * (CF::WN * G + 4) + (size_t)wn * G) * 64 + lane;
-    if (MMD_ABL != 3) mfma_taps<CF::NTAPS, CF::CINP, CF::SSTR, CF::MT_W>(acc, slab, abase, wp);
-
-    if constexpr (CF::EPI != EPI_PLAIN && MMD_ABL != 1) gn_mish<CF::COUT, CF::LROWS, CF::MT_W>(acc, a.gamma[col], a.beta[col]);
-
-    if constexpr (CF::EPI == EPI_GN_TB) {
-      const float tb = a.tbias[col];
-#pragma unroll
-      for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] += tb;
-    }
-
-    if constexpr (CF::EPI == EPI_GN_RES && CF::RES == RES_CONV) {
-      const float rb = a.res_bias[col];
-#pragma unroll
-      for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] += rb;
-      int rbase[CF::MT_W];
-#pragma unroll
-      for (int mt = 0; mt < CF::MT_W; ++mt) rbase[mt] = (srow[mt] * CF::LIN + lrow[mt]) * CF::RSTR + hi;
-      const float4* rwp = a.res_wpk + ((size_t)wn * (CF::RCP / 8)) * 64 + lane;
-      mfma_taps<1, CF::RCP, CF::RSTR, CF::MT_W>(acc, rslab, rbase, rwp);
-    }
-
-    if constexpr (CF::EPI == EPI_GN_FINAL) {
-      // 1x1 conv COUT(32) -> 4 (final_conv.1): y tile -> LDS -> one more MFMA pass against the zero-padded W1
-      static_assert(CF::EPI != EPI_GN_FINAL || (CF::WN == 1 && CF::COUT == 32), "final conv expects COUT == 32");
-      __syncthreads();   // every wave is done reading the input slab
-      float* yt = lds + wave * (CF::RW * 33);
-#pragma unroll
-      for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          yt[row * 33 + (lane & 31)] = acc[mt][r];
-        }
-      __syncthreads();
-      const float b1 = (lane & 31) < 4 ? a.res_bias[lane & 31] : 0.f;
-      f32x16 acc2[CF::MT_W];
-      int ybase[CF::MT_W];
-#pragma unroll
-      for (int mt = 0; mt < CF::MT_W; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[mt][r] = b1;
-        ybase[mt] = (mt * 32 + (lane & 31)) * 33 + hi;
-      }
-      mfma_taps<1, 32, 33, CF::MT_W>(acc2, yt, ybase, a.res_wpk + lane);
-      if ((lane & 31) < 4) {
-#pragma unroll
-        for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int s = wm * CF::SW + row / CF::LROWS, l = row % CF::LROWS;
-            if (n0 + s < a.n) a.out[((size_t)(n0 + s) * CF::LOUT + l) * 4 + (lane & 31)] = acc2[mt][r];
-          }
-      }
-      return;
-    }
-
-    // store: rows of register r are (r&3) + 8*(r>>2) + 4*hi; a half-wave writes 32 consecutive channels (128 B)
-#pragma unroll
-    for (int mt = 0; mt < CF::MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const int s = wm * CF::SW + row / CF::LROWS, l = row % CF::LROWS;
-        if (n0 + s < a.n) {
-          const int lo = CF::MODE == MODE_UP ? 2 * l + pass : l;
-          const size_t o = ((size_t)(n0 + s) * CF::LOUT + lo) * CF::COUT + col;
-          float v = acc[mt][r];
-          if constexpr (CF::EPI == EPI_GN_RES && CF::RES == RES_IDENT) v += a.res0[o];
-          a.out[o] = v;
-        }
-      }
-  }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// Level chain: RTB_0 (1x1-conv or identity residual; optional 2-tensor channel concat, staged K-chunk by K-chunk)
-// -> N_IDENT identity-residual RTBs -> optional Downsample1d / Upsample1d tail, for the SAME samples in ONE launch.
-// Blocks of consecutive layers depend only on each other sample-wise, so the whole chain stays inside the workgroup:
-// activations hop register tile -> LDS slab -> MFMA, never through HBM (only the skip connection and the chain output
-// are stored).  The residual of an identity RTB is the wave's own previous output tile, kept in registers.
 // ----------------------------------------------------------------------------------------------------------------
 enum { TAIL_NONE = 0, TAIL_DOWN = 1, TAIL_UP = 2 };
 constexpr int MAX_IDENT = 3;
@@ -483,14 +339,253 @@ __device__ __forceinline__ void zero_halo(float* slab) {
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Winograd F(2,5) for the stride-1 k=5 convolutions (points 0, +-1, +-2, inf): two outputs from six products instead
+// of ten, i.e. 0.6x the MFMA work.  A GEMM row is an output PAIR (sample, tile): rows l = 2*tile, 2*tile + 1.  The
+// input transform V = B^T d (six slab rows 2*tile .. 2*tile + 5 -> six positions) is done on the fly on the A fragment
+// (6 ds_read_b32 + 12 VALU ops per 6 MFMAs, hidden under the matrix pipe); the weights are transformed on the host
+// (U = G g, fp64 -> fp32) and packed [n-tile][k-step][lane][6 positions]; the output transform Y = A^T M is element-wise
+// on the six accumulators.  fp32 throughout: the result differs from the direct sum by ~1e-6 relative (tools/dbg/
+// winograd_accuracy.py: 1.6e-6 vs 0.8e-6 against an fp64-accumulated forward).
+// ----------------------------------------------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(8)));
+struct B6 { f32x4u lo; f32x2u hi; };
+
+__device__ __forceinline__ B6 load_b6(const float* __restrict__ p) {
+  B6 b;
+  b.lo = *reinterpret_cast<const f32x4u*>(p);
+  b.hi = *reinterpret_cast<const f32x2u*>(p + 4);
+  return b;
+}
+
+template <int STR>
+__device__ __forceinline__ void load_d(float (&d)[6], const float* s) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) d[j] = s[j * STR];
+}
+
+__device__ __forceinline__ void wino_step(f32x16 (&m)[6], const float (&d)[6], const B6& b) {
+  const float a = fmaf(-4.f, d[2], d[4]), bb = fmaf(-4.f, d[1], d[3]);
+  const float c = d[4] - d[2], e = d[3] - d[1];
+  const float v0 = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+  const float v1 = a + bb, v2 = a - bb;
+  const float v3 = fmaf(2.f, e, c), v4 = fmaf(-2.f, e, c);
+  const float v5 = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+  m[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, b.lo[0], m[0], 0, 0, 0);
+  m[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, b.lo[1], m[1], 0, 0, 0);
+  m[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, b.lo[2], m[2], 0, 0, 0);
+  m[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3, b.lo[3], m[3], 0, 0, 0);
+  m[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4, b.hi[0], m[4], 0, 0, 0);
+  m[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(v5, b.hi[1], m[5], 0, 0, 0);
+}
+
+constexpr int WINO_KSTRIDE = 64 * 6;   // floats per k-step of a packed n-tile
+
+// m[p] += V_p(slab) * U_p for the CP input channels of one slab.  abase = lane's offset of (sample, row 2*tile, k = lane>>5);
+// wp = this lane's six floats of k-step 0 of the wave's n-tile.  d is double-buffered, U rides a 4-k-step register ring.
+#ifndef MMD_WINO_RING
+#define MMD_WINO_RING 4
+#endif
+template <int CP, int STR>
+__device__ __forceinline__ void wino_taps(f32x16 (&m)[6], const float* slab, int abase, const float* __restrict__ wp) {
+  constexpr int KS = CP / 2;
+  constexpr int RD = KS % MMD_WINO_RING == 0 ? MMD_WINO_RING : 4;   // ring depth in k-steps
+  static_assert(KS % RD == 0 && RD % 2 == 0, "k-steps are unrolled by the ring depth");
+  const float* p = wp;
+  const float* s = slab + abase;
+  B6 b[RD];
+#pragma unroll
+  for (int j = 0; j < RD; ++j) b[j] = load_b6(p + j * WINO_KSTRIDE);
+  float d[2][6];
+  load_d<STR>(d[0], s);
+#pragma unroll 1
+  for (int ks = 0; ks < KS; ks += RD) {
+    p += RD * WINO_KSTRIDE;
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+      load_d<STR>(d[(j + 1) & 1], s + 2 * (j + 1));   // (past the last k-step this reads the next slab row and is unused)
+      MMD_PIN_LOADS();
+      wino_step(m, d[j & 1], b[j]);
+      b[j] = load_b6(p + j * WINO_KSTRIDE);
+      MMD_PIN_LOADS();
+    }
+    s += 2 * RD;
+  }
+}
+
+// Y = A^T M + bias: pr[0] = rows 2*tile, pr[1] = rows 2*tile + 1
+__device__ __forceinline__ void wino_out(f32x16 (&pr)[2], const f32x16 (&m)[6], float bias) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float s12 = m[1][r] + m[2][r], d12 = m[1][r] - m[2][r];
+    const float s34 = m[3][r] + m[4][r], d34 = m[3][r] - m[4][r];
+    pr[0][r] = (m[0][r] + s12) + (s34 + bias);
+    pr[1][r] = (d12 + m[5][r]) + fmaf(2.f, d34, bias);
+  }
+}
+
+__device__ __forceinline__ void zero6(f32x16 (&m)[6]) {
+#pragma unroll
+  for (int p = 0; p < 6; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[p][r] = 0.f;
+}
+
+// GroupNorm + Mish on a pair tile: register r of both halves belongs to sample (8 * (r >> 2)) / (L / 2) of the wave
+template <int CM, int L>
+__device__ __forceinline__ void gn_mish_pair(f32x16 (&pr)[2], float gamma, float beta) {
+  constexpr int CPG = CM / 8;
+  constexpr int SW = 64 / L;                     // samples per wave
+  constexpr float inv_n = 1.f / (float)(L * CPG);
+  float mean[SW], rstd[SW];
+#pragma unroll
+  for (int s = 0; s < SW; ++s) {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((8 * (r >> 2)) / (L / 2) == s) sum += pr[0][r] + pr[1][r];
+    mean[s] = group_allreduce<CPG>(sum) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((8 * (r >> 2)) / (L / 2) == s) {
+        const float d0 = pr[0][r] - mean[s], d1 = pr[1][r] - mean[s];
+        sq += d0 * d0 + d1 * d1;
+      }
+    rstd[s] = rsqrtf(group_allreduce<CPG>(sq) * inv_n + 1e-5f);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int s = (8 * (r >> 2)) / (L / 2);
+      pr[h][r] = mish((pr[h][r] - mean[s]) * rstd[s] * gamma + beta);
+    }
+}
+
+// pair tile -> slab rows 2*tile + h (+2 halo) of a stage laid out [sample][row][DSTR]
+template <int L, int WN_SRC, int DSS, int DSTR>
+__device__ __forceinline__ void pair_to_stage(const f32x16 (&pr)[2], float* dst, int wave, int lane) {
+  tile_to_stage<L / 2, 1, 64 / L, WN_SRC, 2, DSS, DSTR>(*reinterpret_cast<const f32x16(*)[1]>(&pr[0]), dst, wave, lane, 0);
+  tile_to_stage<L / 2, 1, 64 / L, WN_SRC, 2, DSS, DSTR>(*reinterpret_cast<const f32x16(*)[1]>(&pr[1]), dst, wave, lane, 1);
+}
+
+// A level chain of the down path with every k=5 conv in Winograd form.  Same slabs and sample ownership as chain_body
+// (wave wm = wave / WN owns 64 / L samples, wn its 32-channel slice); activations live in registers as pair tiles.
+template <class CF, bool FIRST>
+__device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int n0, int lane, int wave,
+                                             f32x16 (&acc)[2], f32x16 (&mid)[2], f32x16 (&tout)[1], int trb) {
+  static_assert(!CF::SHARE && CF::C1 == 0 && CF::MT_W == 2 && CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP, "down-path chain");
+  float* hslab = lds + CF::XSLAB;
+  float* xslab = lds;
+  const int wm = wave / CF::WN, wn = wave % CF::WN;
+  const int col = wn * 32 + (lane & 31);
+  const int hi = lane >> 5;
+  constexpr int TPS = CF::L / 2;                             // pair rows (tiles) per sample
+
+  if constexpr (FIRST)
+    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
+  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
+  __syncthreads();
+
+  const int g = wm * 32 + (lane & 31);                       // this lane's A row: pair (sample, tile)
+  const int srow = g / TPS, tile = g % TPS;
+  const int xbase = srow * CF::XSS + 2 * tile * CF::XSTR + hi;
+  const int hbase = srow * CF::HSS + 2 * tile * CF::HSTR + hi;
+  f32x16 m[6], res[2];
+
+  auto conv_h = [&](const float4* w, float bias) {           // conv over the H slab (CM -> CM)
+    zero6(m);
+    if (MMD_ABL != 3)
+      wino_taps<CF::CM, CF::HSTR>(m, hslab, hbase, reinterpret_cast<const float*>(w) + (size_t)wn * (CF::CM / 2) * WINO_KSTRIDE + lane * 6);
+    wino_out(acc, m, bias);
+  };
+  auto add_tb = [&](float tb) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][r] += tb;
+  };
+
+  // =================== RTB 0 (C0 -> CM, 1x1 residual conv) ===================
+  TR(trb + 0);
+  zero6(m);
+  if (MMD_ABL != 3)
+    wino_taps<CF::C0P, CF::XSTR>(m, xslab, xbase, reinterpret_cast<const float*>(a.r0.wa) + (size_t)wn * (CF::C0P / 2) * WINO_KSTRIDE + lane * 6);
+  wino_out(acc, m, a.r0.ba[col]);
+  TR(trb + 1);
+  {
+    int rbase[2] = {xbase + 2 * CF::XSTR, xbase + 3 * CF::XSTR};
+    fill<2>(res, a.br[col]);
+    if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 2>(res, xslab, rbase, a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane);
+  }
+  TR(trb + 2);
+  if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.ga[col], a.r0.bea[col]);
+  add_tb(a.r0.tb[col]);
+  pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+  TR(trb + 3);
+  __syncthreads();
+  TR(trb + 4);
+  conv_h(a.r0.wb, a.r0.bb[col]);
+  TR(trb + 5);
+  if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.gb[col], a.r0.beb[col]);
+  acc[0] += res[0];
+  acc[1] += res[1];
+  TR(trb + 6);
+  if constexpr (CF::MID_AFTER == 0) { mid[0] = acc[0]; mid[1] = acc[1]; }
+
+  // =================== identity RTBs ===================
+#pragma unroll
+  for (int k = 0; k < CF::N_IDENT; ++k) {
+    const RtbPtrs& R = a.ri[k];
+    res[0] = acc[0];
+    res[1] = acc[1];
+    __syncthreads();                                         // the previous conv is done reading the H slab
+    TR(trb + 8 + k * 8 + 0);
+    pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    __syncthreads();
+    TR(trb + 8 + k * 8 + 1);
+    conv_h(R.wa, R.ba[col]);
+    TR(trb + 8 + k * 8 + 2);
+    if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.ga[col], R.bea[col]);
+    add_tb(R.tb[col]);
+    TR(trb + 8 + k * 8 + 3);
+    __syncthreads();
+    TR(trb + 8 + k * 8 + 4);
+    pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    __syncthreads();
+    TR(trb + 8 + k * 8 + 5);
+    conv_h(R.wb, R.bb[col]);
+    TR(trb + 8 + k * 8 + 6);
+    if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.gb[col], R.beb[col]);
+    acc[0] += res[0];
+    acc[1] += res[1];
+    TR(trb + 8 + k * 8 + 7);
+    if (CF::MID_AFTER == k + 1) { mid[0] = acc[0]; mid[1] = acc[1]; }
+  }
+
+  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct ===================
+  if constexpr (CF::TAIL == TAIL_DOWN) {
+    __syncthreads();
+    pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    __syncthreads();
+    constexpr int LO = CF::L / 2;
+    fill<1>(tout, a.bt[col]);
+    const int r = lane & 31;
+    int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
+    if (MMD_ABL != 3) mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
+  }
+}
+
 // One level chain for the workgroup's 4 samples.  FIRST: chunk 0 of the input is staged from global memory (the network
 // input); otherwise the previous stage has already written it (and zeroed its halo rows) into the x slab.  The second
-// chunk of a channel concat is the register tile `skip` kept from the down path (tiling SKIP_*).  Results stay in
+// chunk of a channel concat is the pair tile `skip` kept from the down path (level length SKIP_L, SKIP_WN channel waves).  Results stay in
 // registers: `acc` = output of the RTB chain, `mid` = copy after RTB number MID_AFTER (the skip connection), `tout` = tail
 // conv result (TAIL_DOWN: tout[0][0]; TAIL_UP: tout[parity][mt]).
-template <class CF, bool FIRST, int SKIP_L, int SKIP_MT, int SKIP_SW, int SKIP_WN>
+template <class CF, bool FIRST, int SKIP_L, int SKIP_WN>
 __device__ __forceinline__ void chain_body(const ChainArgs& a, float* lds, int n0, int lane, int wave,
-                                           const f32x16* skip, f32x16 (&acc)[CF::MT_W], f32x16 (&mid)[CF::MT_W],
+                                           const f32x16 (&skip)[2], f32x16 (&acc)[CF::MT_W], f32x16 (&mid)[CF::MT_W],
                                            f32x16 (&tout)[2][CF::MT_W]) {
   float* hslab = lds + CF::XSLAB;
   float* xslab = CF::SHARE ? hslab : lds;
@@ -536,8 +631,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, float* lds, int n
     }
     if constexpr (CF::C1 > 0) {                              // second half of the channel concat, same slab
       __syncthreads();                                       // chunk 0 has been consumed by every wave
-      tile_to_stage<SKIP_L, SKIP_MT, SKIP_SW, SKIP_WN, 1, CF::XSS, CF::XSTR>(
-          *reinterpret_cast<const f32x16(*)[SKIP_MT]>(skip), xslab, wave, lane, 0);
+      pair_to_stage<SKIP_L, SKIP_WN, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
       __syncthreads();
       if (MMD_ABL != 3) mfma_taps<5, CF::C1P, XS, MT_W>(acc, xslab, xbase, a.wa0_c1 + ((size_t)wn * (5 * CF::C1P / 8)) * 64 + lane);
       if constexpr (CF::RES0 == RES_CONV)
@@ -647,14 +741,14 @@ constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
 
 struct UnetArgs {
   ChainArgs c[5];
-  ConvArgs fin;    // final Conv1dBlock(32->32) + 1x1 conv (32->4): wpk/bias/gamma/beta + res_wpk/res_bias = 1x1, out = eps
+  FinalArgs fin;
   int n;
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int UNET_LDS_FLOATS =
     cmax(cmax(cmax(CH_D0::LDS_FLOATS, CH_D1::LDS_FLOATS), cmax(CH_D2::LDS_FLOATS, CH_U0::LDS_FLOATS)),
-         cmax(CH_U1::LDS_FLOATS, 4 * FIN_SS));
+         cmax(CH_U1::LDS_FLOATS, 4 * FIN_SS)) + 8;   // + slack: the A double buffer reads one k-step past the last row
 static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SPB == 4 && CH_U1::SPB == 4,
               "every stage must own the same 4 samples");
 
@@ -667,73 +761,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x16 skip1[2], skip2[2];
   // ---- downs.0 @ L=64 -> [4][32][32]
   {
-    f32x16 acc[2], mid[2], t[2][2];
-    chain_body<CH_D0, true, 16, 1, 1, 1>(a.c[0], lds, n0, lane, wave, nullptr, acc, mid, t);
+    f32x16 acc[2], mid[2], t[1];
+    chain_body_w<CH_D0, true>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
     __syncthreads();                                                       // the tail conv is done reading the H slab
-    tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(
-        *reinterpret_cast<f32x16(*)[1]>(&t[0][0]), lds, wave, lane, 0);
+    tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
   }
   // ---- downs.1 @ L=32 -> [4][16][64], skip1
   {
-    f32x16 acc[2], t[2][2];
-    chain_body<CH_D1, false, 16, 1, 1, 1>(a.c[1], lds, n0, lane, wave, nullptr, acc, skip1, t);
+    f32x16 acc[2], t[1];
+    chain_body_w<CH_D1, false>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
     __syncthreads();
-    tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(
-        *reinterpret_cast<f32x16(*)[1]>(&t[0][0]), lds, wave, lane, 0);
+    tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
   }
   // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2
   {
-    f32x16 acc[2], t[2][2];
-    chain_body<CH_D2, false, 16, 1, 1, 1>(a.c[2], lds, n0, lane, wave, nullptr, acc, skip2, t);
+    f32x16 acc[2], t[1];
+    chain_body_w<CH_D2, false>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
     __syncthreads();
-    tile_to_stage<16, 2, CH_D2::SW, CH_D2::WN, 1, CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane, 0);
+    pair_to_stage<CH_D2::L, CH_D2::WN, CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane);
     zero_halo<CH_U0::C0P, CH_U0::L, CH_U0::SROWS, CH_U0::XSTR, CH_U0::XSS, 4>(lds);
   }
+  TR(130);
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
   {
     f32x16 acc[1], mid[1], t[2][1];
-    chain_body<CH_U0, false, CH_D2::L, 2, CH_D2::SW, CH_D2::WN>(a.c[3], lds, n0, lane, wave, skip2, acc, mid, t);
+    chain_body<CH_U0, false, CH_D2::L, CH_D2::WN>(a.c[3], lds, n0, lane, wave, skip2, acc, mid, t);
     __syncthreads();
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
     zero_halo<CH_U1::C0P, CH_U1::L, CH_U1::SROWS, CH_U1::XSTR, CH_U1::XSS, 4>(lds);
   }
+  TR(131);
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
   {
     f32x16 acc[1], mid[1], t[2][1];
-    chain_body<CH_U1, false, CH_D1::L, 2, CH_D1::SW, CH_D1::WN>(a.c[4], lds, n0, lane, wave, skip1, acc, mid, t);
+    chain_body<CH_U1, false, CH_D1::L, CH_D1::WN>(a.c[4], lds, n0, lane, wave, skip1, acc, mid, t);
     __syncthreads();
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
     zero_halo<32, 64, FIN_SROWS, FIN_STR, FIN_SS, 4>(lds);
     __syncthreads();
   }
+  TR(132);
   // ---- final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]
   {
-    const ConvArgs& f = a.fin;
+    const FinalArgs& f = a.fin;
     const int col = lane & 31, hi = lane >> 5;
     f32x16 acc[2];
-    int abase[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) abase[mt] = wave * FIN_SS + (mt * 32 + (lane & 31)) * FIN_STR + hi;
-    fill<2>(acc, f.bias[col]);
-    if (MMD_ABL != 3) mfma_taps<5, 32, FIN_STR, 2>(acc, lds, abase, f.wpk + lane);
-    if (MMD_ABL != 1) gn_mish<32, 64, 2>(acc, f.gamma[col], f.beta[col]);
+    {
+      f32x16 m[6];
+      zero6(m);
+      if (MMD_ABL != 3) wino_taps<32, FIN_STR>(m, lds, wave * FIN_SS + 2 * (lane & 31) * FIN_STR + hi, reinterpret_cast<const float*>(f.wpk) + lane * 6);
+      wino_out(acc, m, f.bias[col]);
+    }
+    if (MMD_ABL != 1) gn_mish_pair<32, 64>(acc, f.gamma[col], f.beta[col]);
     __syncthreads();                                                       // every wave is done reading the slab
     float* yt = lds + wave * (64 * 33);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) yt[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + col] = acc[mt][r];
+      for (int r = 0; r < 16; ++r) yt[(2 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + h) * 33 + col] = acc[h][r];
     __syncthreads();
     f32x16 acc2[2];
     int ybase[2];
-    fill<2>(acc2, col < 4 ? f.res_bias[col] : 0.f);
+    fill<2>(acc2, col < 4 ? f.w1_bias[col] : 0.f);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) ybase[mt] = (mt * 32 + (lane & 31)) * 33 + hi;
-    if (MMD_ABL != 3) mfma_taps<1, 32, 33, 2>(acc2, yt, ybase, f.res_wpk + lane);
+    if (MMD_ABL != 3) mfma_taps<1, 32, 33, 2>(acc2, yt, ybase, f.w1_pk + lane);
     if (col < 4 && n0 + wave < a.n) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -744,6 +840,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
   }
+  TR(133);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -893,6 +990,37 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_f
         }
 }
 
+// Winograd F(2,5) weight transform U = G g (points 0, +-1, +-2, inf) in fp64, packed for wino_taps:
+//   out[((nt*KS + ks)*64 + lane)*6 + p] = U_p(c = 2*ks + (lane>>5), n = nt*32 + (lane&31)),  KS = cinp / 2
+// followed by 8 zero k-steps (register-ring over-read).  conv weight layout [cout][cin][5].
+static void pack_w(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo = 0, int c_hi = -1) {
+  static const double G[6][5] = {{1.0 / 4, 0, 0, 0, 0},
+                                 {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
+                                 {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3},
+                                 {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3},
+                                 {0, 0, 0, 0, 1}};
+  if (c_hi < 0) c_hi = cin_full;
+  const int cin = c_hi - c_lo;
+  const int cinp = (cin + 7) / 8 * 8;
+  const int nt_n = (cout + 31) / 32, KS = cinp / 2;
+  const size_t base = blob.size();
+  blob.resize(base + ((size_t)nt_n * KS + 8) * 64 * 6, 0.f);
+  for (int nt = 0; nt < nt_n; ++nt)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int ci = 2 * ks + (lane >> 5), n = nt * 32 + (lane & 31);
+        if (ci >= cin || n >= cout) continue;
+        const float* g = w + ((size_t)n * cin_full + (c_lo + ci)) * 5;
+        for (int p = 0; p < 6; ++p) {
+          double u = 0.0;
+          for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
+          blob[base + (((size_t)nt * KS + ks) * 64 + lane) * 6 + p] = (float)u;
+        }
+      }
+  while (blob.size() % 4) blob.push_back(0.f);
+}
+
 struct ConvW { size_t wpk, bias, gamma, beta; };
 struct RtbW { ConvW a, b; size_t res_wpk, res_bias; int tb_off; size_t a_c1, res_c0, res_c1; };
 
@@ -994,11 +1122,14 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     while (blob.size() % 4) blob.push_back(0.f);
-    W.a.wpk = blob.size(); pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false);
+    const bool wino = r < 6 || r >= 10;   // down path + mid blocks: Winograd packs; up path: direct
+    W.a.wpk = blob.size();
+    if (wino) pack_w(blob, tensors[R.t_w0], R.cout, R.cin); else pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false);
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
-    W.b.wpk = blob.size(); pack_b(blob, tensors[R.t_w1], R.cout, R.cout, 5, taps5, false);
+    W.b.wpk = blob.size();
+    if (wino) pack_w(blob, tensors[R.t_w1], R.cout, R.cout); else pack_b(blob, tensors[R.t_w1], R.cout, R.cout, 5, taps5, false);
     W.b.bias = push(blob, tensors[R.t_b1], R.cout);
     W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
     W.b.beta = push(blob, tensors[R.t_be1], R.cout);
@@ -1036,7 +1167,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{2, 0}, true);
     u->up[i].bias = push(blob, tensors[s.t_up[i][1]], cu);
   }
-  u->fin.wpk = blob.size(); pack_b(blob, tensors[s.t_final[0]], 32, 32, 5, taps5, false);
+  u->fin.wpk = blob.size(); pack_w(blob, tensors[s.t_final[0]], 32, 32);
   u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
   u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
   u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
@@ -1096,6 +1227,19 @@ static const double kLayerFlops[kNumLayers] = {
     rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64};
 
+// MFMA FLOPs actually issued per trajectory (Winograd convs: 6 products per output pair; channel / N padding included)
+static constexpr double wino_flops(double cinp, double cout, double L) { return (cinp / 2) * 6 * (cout / 32) * (L / 16) * 4096.0 / 4; }
+static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
+  return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
+}
+static const double kLayerMfmaFlops[kNumLayers] = {
+    wino_flops(8, 32, 64) + direct_flops(1, 8, 32, 64) + 3 * wino_flops(32, 32, 64) + direct_flops(3, 32, 32, 32) +
+    wino_flops(32, 64, 32) + direct_flops(1, 32, 64, 32) + 3 * wino_flops(64, 64, 32) + direct_flops(3, 64, 64, 16) +
+    wino_flops(64, 128, 16) + direct_flops(1, 64, 128, 16) + 7 * wino_flops(128, 128, 16) +
+    direct_flops(5, 256, 64, 16) + direct_flops(1, 256, 64, 16) + 3 * direct_flops(5, 64, 64, 16) + 2 * direct_flops(2, 64, 64, 16) +
+    direct_flops(5, 128, 32, 32) + direct_flops(1, 128, 32, 32) + 3 * direct_flops(5, 32, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
+    wino_flops(32, 32, 64) + direct_flops(1, 32, 32, 64)};
+
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
                              hipStream_t st, hipEvent_t* ev, int reps) {
   MMD_REQUIRE(u && x && eps && ws, "mmd_unet_forward: NULL argument");
@@ -1124,11 +1268,11 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.c[2] = args_chain(u, kD2, 3, nullptr, nullptr, t, n);
   a.c[3] = args_chain(u, kU0, 1, &u->up[0], nullptr, t, n);
   a.c[4] = args_chain(u, kU1, 1, &u->up[1], nullptr, t, n);
-  a.fin.out = eps; a.fin.n = n;
+  a.fin.out = eps;
   a.fin.wpk = reinterpret_cast<const float4*>(u->blob + u->fin.wpk);
   a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
-  a.fin.res_wpk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
-  a.fin.res_bias = u->blob + u->fin_b1;
+  a.fin.w1_pk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
+  a.fin.w1_bias = u->blob + u->fin_b1;
   MMD_L(hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a));
   if (ev) (void)hipEventRecord(ev[li], st);
 #undef MMD_L
@@ -1140,9 +1284,16 @@ int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, voi
   return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, (hipStream_t)stream, nullptr, 1);
 }
 
+#ifdef MMD_TRACE
+int mmd_debug_set_trace(void* dev_ptr) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dev_ptr, sizeof(dev_ptr)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int mmd_unet_num_layers(void) { return kNumLayers; }
 const char* mmd_unet_layer_name(int i) { return i >= 0 && i < kNumLayers ? kLayerNames[i] : ""; }
 double mmd_unet_layer_flops(int i) { return i >= 0 && i < kNumLayers ? kLayerFlops[i] : 0.0; }
+double mmd_unet_layer_mfma_flops(int i) { return i >= 0 && i < kNumLayers ? kLayerMfmaFlops[i] : 0.0; }
 
 int mmd_unet_profile_layer(mmd_unet_t u, int layer, int max_launches, int stride) {
   MMD_REQUIRE(u, "mmd_unet_profile_layer: NULL handle");

@@ -1,0 +1,49 @@
+"""Phase timeline of unet_kernel from a -DMMD_TRACE side build (MMD_AMD_LIB=<that .so>): per tag, the time since the
+previous tag of the same wave (100 MHz wall clock -> ns), averaged over blocks/waves.  Usage: trace_phases.py [n_traj]"""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+from mmd_amd import _lib, synth
+_lib.LIB_PATH = os.environ["MMD_AMD_LIB"]
+from mmd_amd.temporal_unet import TemporalUnet
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+lib = _lib.load()
+unet = TemporalUnet()
+unet.load_state_dict(synth.synth_unet_state_dict(0))
+x = torch.randn(n, 64, 4, device="cuda")
+nb = (n + 3) // 4
+trace = torch.zeros(nb * 4 * 256, dtype=torch.int64, device="cuda")
+for _ in range(3):
+    unet(x, 50)
+torch.cuda.synchronize()
+lib.mmd_debug_set_trace.argtypes = [C.c_void_p]
+assert lib.mmd_debug_set_trace(trace.data_ptr()) == 0
+unet(x, 50)
+torch.cuda.synchronize()
+lib.mmd_debug_set_trace(None)
+t = trace.cpu().numpy().reshape(nb, 4, 256).astype(np.float64) * 10.0   # ns
+tags = [i for i in range(256) if (t[:, :, i] > 0).all()]
+t0 = t[:, :, tags[0]].min()
+print(f"n={n} blocks={nb}; tags {len(tags)}; kernel span {(t[:, :, tags[-1]].max() - t0) / 1e3:.1f} us")
+names = {}
+for base, nm in ((0, "D0"), (40, "D1"), (80, "D2")):
+    for j, w in enumerate(("rtb0 start", "convA done", "res conv done", "gn+write", "barrier", "convB done", "gn+res")):
+        names[base + j] = f"{nm} {w}"
+    for k in range(3):
+        for j, w in enumerate(("barrier(prev)", "write+barrier", "convA done", "gn", "barrier", "write+barrier", "convB done", "gn+res")):
+            names[base + 8 + k * 8 + j] = f"{nm} id{k} {w}"
+names.update({130: "-> U0 start", 131: "-> U1 start", 132: "-> FIN start", 133: "end"})
+prev = None
+print(f"{'tag':>4s} {'phase':28s} {'mean dt us':>10s} {'min':>8s} {'max':>8s}   cumulative(mean) us")
+for tg in tags:
+    cur = t[:, :, tg]
+    if prev is not None:
+        d = (cur - prev) / 1e3
+        print(f"{tg:4d} {names.get(tg, ''):28s} {d.mean():10.2f} {d.min():8.2f} {d.max():8.2f}   {(cur.mean() - t0) / 1e3:8.1f}")
+    prev = cur
+# start skew between blocks
+print("block start spread us:", (t[:, :, tags[0]].max() - t0) / 1e3)
