@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MMD_AMD_ABI_VERSION 1
+#define MMD_AMD_ABI_VERSION 2
 #define MMD_STATE_DIM 4
 #define MMD_HORIZON 64
 
@@ -111,7 +111,7 @@ typedef struct mmd_guide_desc {
   float max_grad_norm;               /* 1.0 (guides.py:154) */
   /* Constraints: one group per CostConstraint (= per MultiPointConstraint, mmd/common/constraints.py:46-85),
    * stored time-bucketed (ELL): slot j of a group holds, for every time step t, at most one active point
-   * float4 (qx, qy, radius, 0) with radius < 0 meaning "no point".  cons_ell_dev is [n_slots][H][4];
+   * float4 (qx, qy, radius, radius * |radius|) with radius < 0 meaning "no point".  cons_ell_dev is [n_slots][H][4];
    * group g owns slots [grp_slot_off[g], grp_slot_off[g+1]); robot r owns groups
    * [robot_grp_off[r], robot_grp_off[r+1]).  Build it with mmd_pack_constraints or
    * mmd_soft_constraints_from_paths.  NULL pointers = no constraints. */
@@ -120,6 +120,9 @@ typedef struct mmd_guide_desc {
   const float* grp_weight_dev;
   const int32_t* robot_grp_off_dev;
   int32_t max_slots_per_robot;       /* max over robots of their total slot count (sizes the LDS staging; 0 = unknown) */
+  float cons_uniform_radius;         /* > 0: every active point of the table has exactly this radius (tables made by
+                                      * mmd_soft_constraints_from_paths): the kernel then keeps only (qx, qy) on chip,
+                                      * twice the slots per workgroup.  0 = radii vary, general path. */
 } mmd_guide_desc;
 
 /* Host helper: time-bucket one robot's constraint groups.  For group g (n_pts[g] points): q [n,2], t_range [n,2]

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmd_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GuideDesc(C.Structure):
@@ -18,7 +18,7 @@ class GuideDesc(C.Structure):
         ("margin", C.c_float), ("dt", C.c_float), ("sigma_gp", C.c_float),
         ("weight_collision", C.c_float), ("weight_smoothness", C.c_float), ("max_grad_norm", C.c_float),
         ("cons_ell_dev", C.c_void_p), ("grp_slot_off_dev", C.c_void_p), ("grp_weight_dev", C.c_void_p),
-        ("robot_grp_off_dev", C.c_void_p), ("max_slots_per_robot", C.c_int32),
+        ("robot_grp_off_dev", C.c_void_p), ("max_slots_per_robot", C.c_int32), ("cons_uniform_radius", C.c_float),
     ]
 
 

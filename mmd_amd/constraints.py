@@ -102,4 +102,4 @@ def soft_constraints_from_paths(paths: torch.Tensor, robot0: int, n_local: int, 
     _lib.check(lib.mmd_soft_constraints_from_paths(_lib.require_gpu(paths, "paths"), n_all, robot0, n_local, H,
                                                    float(radius), float(weight), ell.data_ptr(), gso.data_ptr(),
                                                    gw.data_ptr(), rgo.data_ptr(), _lib.current_stream_ptr()))
-    return ell, gso, gw, rgo
+    return ell, gso, gw, rgo, float(radius)

@@ -75,19 +75,22 @@ constexpr int LDS_SLOTS_SMALL = 40;
 constexpr int LDS_SLOTS_MAX = 144;
 
 // -sum over a slot range of d/||d|| for points with ||d|| <= R  (CostConstraint, cost_functions.py:297-326), from a
-// [slot][t] table `tab` (LDS or global).  Two accumulator pairs break the dependent add chain.
+// [slot][t] table `tab` (LDS or global) of (qx, qy, R, R|R|).  A point is active iff R >= 0 and not (dist > R)
+// <=> not (dist^2 > R|R|): one transcendental (rsq) per point, no branch (a wave-uniform skip of inactive slot pairs was
+// measured slower: most pairs have an active lane somewhere along the horizon).  Two accumulator pairs break the
+// dependent add chain.
+template <int UNROLL>
 __device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t, float px, float py, float& gx,
                                                 float& gy) {
   float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
   int s = 0;
-#pragma unroll 4
+#pragma unroll UNROLL
   for (; s + 1 < n; s += 2) {
     const float4 c0 = tab[s * H + t], c1 = tab[(s + 1) * H + t];
     const float dx0 = px - c0.x, dy0 = py - c0.y, dx1 = px - c1.x, dy1 = py - c1.y;
     const float d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
-    // active iff radius >= 0 and not (dist > radius)  <=>  not (dist^2 > r|r|): one transcendental (rsq) per point
-    const float m0 = (d0 > c0.z * fabsf(c0.z)) ? 0.f : __builtin_amdgcn_rsqf(d0);
-    const float m1 = (d1 > c1.z * fabsf(c1.z)) ? 0.f : __builtin_amdgcn_rsqf(d1);
+    const float m0 = (d0 > c0.w) ? 0.f : __builtin_amdgcn_rsqf(d0);
+    const float m1 = (d1 > c1.w) ? 0.f : __builtin_amdgcn_rsqf(d1);
     ax -= dx0 * m0; ay -= dy0 * m0;
     bx -= dx1 * m1; by -= dy1 * m1;
   }
@@ -95,13 +98,42 @@ __device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t,
     const float4 c0 = tab[s * H + t];
     const float dx0 = px - c0.x, dy0 = py - c0.y;
     const float d0 = dx0 * dx0 + dy0 * dy0;
-    const float m0 = (d0 > c0.z * fabsf(c0.z)) ? 0.f : __builtin_amdgcn_rsqf(d0);
+    const float m0 = (d0 > c0.w) ? 0.f : __builtin_amdgcn_rsqf(d0);
     ax -= dx0 * m0; ay -= dy0 * m0;
   }
   gx += ax + bx;
   gy += ay + by;
 }
 
+// the same sum over a compact on-chip table of (qx, qy) with one radius for every active point; "no point" is stored
+// as (1e30, 1e30): dist^2 = inf > R^2 and dx * 0 = -0, i.e. exactly the 0 the general path adds
+template <int UNROLL>
+__device__ __forceinline__ void cons_accumulate_xy(const float2* tab, int n, int t, float px, float py, float r2,
+                                                   float& gx, float& gy) {
+  float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+  int s = 0;
+#pragma unroll UNROLL
+  for (; s + 1 < n; s += 2) {
+    const float2 c0 = tab[s * H + t], c1 = tab[(s + 1) * H + t];
+    const float dx0 = px - c0.x, dy0 = py - c0.y, dx1 = px - c1.x, dy1 = py - c1.y;
+    const float d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
+    const float m0 = (d0 > r2) ? 0.f : __builtin_amdgcn_rsqf(d0);
+    const float m1 = (d1 > r2) ? 0.f : __builtin_amdgcn_rsqf(d1);
+    ax -= dx0 * m0; ay -= dy0 * m0;
+    bx -= dx1 * m1; by -= dy1 * m1;
+  }
+  if (s < n) {
+    const float2 c0 = tab[s * H + t];
+    const float dx0 = px - c0.x, dy0 = py - c0.y;
+    const float d0 = dx0 * dx0 + dy0 * dy0;
+    const float m0 = (d0 > r2) ? 0.f : __builtin_amdgcn_rsqf(d0);
+    ax -= dx0 * m0; ay -= dy0 * m0;
+  }
+  gx += ax + bx;
+  gy += ay + by;
+}
+
+template <bool COMPACT>
 __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t, const float4* __restrict__ grid,
                                              int grp0, int grp1, const float4* lds_cons, int lds_slot0, int lds_n) {
   // LimitsNormalizer.unnormalize (normalization.py:157-168), clip applied unconditionally
@@ -166,9 +198,15 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
     const int s0 = g.grp_slot_off[grp], s1 = g.grp_slot_off[grp + 1];
     float gx = 0.f, gy = 0.f;
     const int l0 = min(max(s0 - lds_slot0, 0), lds_n), l1 = min(max(s1 - lds_slot0, 0), lds_n);   // LDS part
-    if (l1 > l0) cons_accumulate(lds_cons + (size_t)l0 * H, l1 - l0, t, px, py, gx, gy);
+    if (l1 > l0) {
+      if constexpr (COMPACT)
+        cons_accumulate_xy<4>(reinterpret_cast<const float2*>(lds_cons) + (size_t)l0 * H, l1 - l0, t, px, py, g.uniform_r2,
+                              gx, gy);
+      else
+        cons_accumulate<4>(lds_cons + (size_t)l0 * H, l1 - l0, t, px, py, gx, gy);
+    }
     const int g0 = lds_n > 0 ? max(s0, lds_slot0 + lds_n) : s0;                                    // global part
-    if (s1 > g0) cons_accumulate(g.cons + (size_t)g0 * H, s1 - g0, t, px, py, gx, gy);
+    if (s1 > g0) cons_accumulate<4>(g.cons + (size_t)g0 * H, s1 - g0, t, px, py, gx, gy);
     const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
     const float w = g.grp_weight[grp];
     cx += w * (sc * gx); cy += w * (sc * gy);
@@ -194,7 +232,7 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
 }
 
 // One ddpm_sample_fn (sample_functions.py:40-86) + the apply_hard_conditioning after it, for one trajectory per wave.
-template <int WPB>
+template <int WPB, bool COMPACT>
 __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDev s, int lds_slots, float4* __restrict__ x,
                                                          const float4* __restrict__ eps,
                                                          const float4* __restrict__ noise, float4* __restrict__ chain,
@@ -216,7 +254,15 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
       lds_slot0 = g.grp_slot_off[g.robot_grp_off[rb0]];
       lds_n = min(g.grp_slot_off[g.robot_grp_off[rb0 + 1]] - lds_slot0, lds_slots);
       const float4* src = g.cons + (size_t)lds_slot0 * H;
-      for (int i = threadIdx.x; i < lds_n * H; i += WPB * 64) lds_cons[i] = src[i];
+      if constexpr (COMPACT) {
+        float2* dst = reinterpret_cast<float2*>(lds_cons);
+        for (int i = threadIdx.x; i < lds_n * H; i += WPB * 64) {
+          const float4 c = src[i];
+          dst[i] = c.z < 0.f ? make_float2(1e30f, 1e30f) : make_float2(c.x, c.y);
+        }
+      } else {
+        for (int i = threadIdx.x; i < lds_n * H; i += WPB * 64) lds_cons[i] = src[i];
+      }
     }
   }
   __syncthreads();
@@ -250,7 +296,7 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
     int grp0 = 0, grp1 = 0;
     if (g.robot_grp_off) { grp0 = g.robot_grp_off[robot]; grp1 = g.robot_grp_off[robot + 1]; }
     for (int it = 0; it < s.n_guide_steps; ++it) {
-      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, lds_cons, lds_slot0, lds_n);
+      const float4 gr = guide_grad<COMPACT>(g, v, t, grid, grp0, grp1, lds_cons, lds_slot0, lds_n);
       v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w;
       if (is_start) v = hs;
       if (is_goal) v = hg;
@@ -321,7 +367,8 @@ __global__ void soft_cons_kernel(const float2* __restrict__ paths, int n_all, in
     const int i = idx / ((size_t)H * slots);
     const int other = j + (j >= robot0 + i ? 1 : 0);
     const float2 p = paths[(size_t)other * H + t];
-    ell[idx] = make_float4(p.x, p.y, t >= 1 ? radius : -1.f, 0.f);   // constraints cover t in [1, H-1]
+    const float r = t >= 1 ? radius : -1.f;                               // constraints cover t in [1, H-1]
+    ell[idx] = make_float4(p.x, p.y, r, r * fabsf(r));
   }
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid <= n_local) {
@@ -350,6 +397,7 @@ int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
   g.m2 = (float)(-6.0 / (dt * dt) * qc);
   g.m3 = (float)(4.0 / dt * qc);
   g.max_slots = d->max_slots_per_robot > 0 ? d->max_slots_per_robot : LDS_SLOTS_SMALL;
+  g.uniform_r2 = d->cons_uniform_radius > 0.f ? d->cons_uniform_radius * fabsf(d->cons_uniform_radius) : 0.f;
   g.cons = reinterpret_cast<const float4*>(d->cons_ell_dev);
   g.grp_slot_off = d->grp_slot_off_dev; g.grp_weight = d->grp_weight_dev; g.robot_grp_off = d->robot_grp_off_dev;
   if (!g.cons || !g.grp_slot_off || !g.grp_weight) g.robot_grp_off = nullptr;
@@ -361,22 +409,32 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
   s.traj0 = traj0;
   s.traj_end = traj0 + n_traj;
   const bool guided = s.do_guide && g.robot_grp_off;
-  if (guided && g.max_slots > LDS_SLOTS_SMALL && spr % 8 == 0 && traj0 % 8 == 0) {
-    // 8 trajectories of one robot per workgroup (2048 trajectories = 256 workgroups = one per CU); LDS sized to the largest table any robot can have (g.max_slots)
-    int slots = guided ? (g.max_slots < LDS_SLOTS_MAX ? g.max_slots : LDS_SLOTS_MAX) : 0;
+  // LDS staging of the workgroup's robot's table: 16 B per (slot, t), or 8 B when every active point has the same radius
+  const bool compact = guided && g.uniform_r2 > 0.f;
+  const int bytes_per_slot = H * (compact ? 8 : 16);
+  const int small = LDS_SLOTS_SMALL * (compact ? 2 : 1), big = LDS_SLOTS_MAX * (compact ? 2 : 1);
+  auto launch = [&](auto kern, int wpb, int slots) {
+    hipLaunchKernelGGL(kern, dim3((n_traj + wpb - 1) / wpb), dim3(wpb * 64), (size_t)slots * bytes_per_slot, st, g, s, slots,
+                       (float4*)x, (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
+  };
+  if (guided && g.max_slots > small && spr % 8 == 0 && traj0 % 8 == 0) {
+    // 8 trajectories of one robot per workgroup (2048 trajectories = 256 workgroups = one per CU); LDS sized to the
+    // largest table any robot can have (g.max_slots), the rest of a larger table is read from L2
+    const int slots = g.max_slots < big ? g.max_slots : big;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpm_guide_kernel<8>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpm_guide_kernel<8, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SLOTS_MAX * H * 16);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpm_guide_kernel<8, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SLOTS_MAX * H * 16);
       attr_set = true;
     }
-    hipLaunchKernelGGL(ddpm_guide_kernel<8>, dim3((n_traj + 7) / 8), dim3(512), (size_t)slots * H * 16, st, g, s,
-                       slots, (float4*)x, (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard,
-                       spr);
+    if (compact) launch(ddpm_guide_kernel<8, true>, 8, slots);
+    else launch(ddpm_guide_kernel<8, false>, 8, slots);
   } else {
-    const int slots = guided ? LDS_SLOTS_SMALL : 0;
-    hipLaunchKernelGGL(ddpm_guide_kernel<4>, dim3((n_traj + 3) / 4), dim3(256), (size_t)slots * H * 16, st, g, s, slots,
-                       (float4*)x, (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
+    const int slots = guided ? small : 0;
+    if (compact) launch(ddpm_guide_kernel<4, true>, 4, slots);
+    else launch(ddpm_guide_kernel<4, false>, 4, slots);
   }
   return 0;
 }
@@ -414,7 +472,7 @@ int mmd_pack_constraints(int n_groups, const int32_t* n_pts, const float* const*
     for (int s = 0; s < slots; ++s)
       for (int t = 0; t < H; ++t) {
         float* e = ell_out + ((size_t)(used + s) * H + t) * 4;
-        e[0] = 0.f; e[1] = 0.f; e[2] = -1.f; e[3] = 0.f;
+        e[0] = 0.f; e[1] = 0.f; e[2] = -1.f; e[3] = -1.f;
       }
     std::fill(fill.begin(), fill.end(), 0);
     for (int c = 0; c < n_pts[g]; ++c) {
@@ -422,6 +480,7 @@ int mmd_pack_constraints(int n_groups, const int32_t* n_pts, const float* const*
       for (int t = t0 < 0 ? 0 : t0; t < t1 && t < H; ++t) {
         float* e = ell_out + ((size_t)(used + fill[t]) * H + t) * 4;
         e[0] = q[g][2 * c]; e[1] = q[g][2 * c + 1]; e[2] = radius[g][c];
+        e[3] = radius[g][c] * fabsf(radius[g][c]);
         ++fill[t];
       }
     }

@@ -21,6 +21,7 @@ struct GuideDev {
   const float* grp_weight;
   const int* robot_grp_off;
   int max_slots;                     // largest number of constraint slots any robot owns (LDS sizing)
+  float uniform_r2;                  // > 0: every active point has radius^2 = this (compact float2 staging); else 0
 };
 
 struct StepDev {

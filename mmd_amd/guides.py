@@ -98,7 +98,9 @@ class GuideManagerTrajectoriesWithVelocity:
         d.max_grad_norm = self.max_grad_norm
         cons = self._constraints()
         if cons is not None:
-            ell, gso, gw, rgo = cons
+            ell, gso, gw, rgo = cons[:4]
+            # 5th element (soft_constraints_from_paths): the one radius every active point of the table has
+            d.cons_uniform_radius = float(cons[4]) if len(cons) > 4 else 0.0
             d.cons_ell_dev, d.grp_slot_off_dev = ell.data_ptr(), gso.data_ptr()
             d.grp_weight_dev, d.robot_grp_off_dev = gw.data_ptr(), rgo.data_ptr()
             # upper bound of the slots any one robot owns (exact when robots own equal shares, as the all-pairs table)

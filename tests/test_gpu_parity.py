@@ -87,17 +87,43 @@ def test_soft_constraints_from_paths_kernel():
     from mmd_amd.constraints import soft_constraints_from_paths
     starts, goals = synth.start_goal_circle(6, 0.8)
     paths = synth.straight_line_paths(starts, goals, H)
-    ell, gso, gw, rgo = soft_constraints_from_paths(torch.from_numpy(paths).cuda(), 2, 3)
+    ell, gso, gw, rgo, radius = soft_constraints_from_paths(torch.from_numpy(paths).cuda(), 2, 3)
     assert ell.shape == (3 * 5, H, 4) and gso.tolist() == [0, 5, 10, 15] and rgo.tolist() == [0, 1, 2, 3]
     x = (torch.from_numpy(synth.synth_noise(51, (3 * 4, H, D))) * 0.5).cuda()
     g_dev = _gc().hip_guide("EnvEmpty2D", [[], [], []], n_robots=3)
-    g_dev.set_packed_constraints((ell, gso, gw, rgo))
+    g_dev.set_packed_constraints((ell, gso, gw, rgo))                 # general staging: (qx, qy, R, R|R|) on chip
+    g_cmp = _gc().hip_guide("EnvEmpty2D", [[], [], []], n_robots=3)
+    g_cmp.set_packed_constraints((ell, gso, gw, rgo, radius))         # uniform radius: only (qx, qy) on chip
     g_host = _gc().hip_guide("EnvEmpty2D", [[cases.soft_group(paths, r)] for r in (2, 3, 4)], n_robots=3)
     assert torch.equal(g_dev(x), g_host(x))
+    assert torch.equal(g_cmp(x), g_host(x))
     gp = cases.guide_params("EnvEmpty2D")
     for k, r in enumerate((2, 3, 4)):
         ref = O.guide_grad(x[k * 4:(k + 1) * 4].cpu(), gp, [cases.soft_group(paths, r)], clip_mode="always")
         assert float((g_dev(x)[k * 4:(k + 1) * 4].cpu() - ref).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("n_all", [100, 300])
+def test_large_constraint_tables(n_all):
+    """99 / 299 slots per robot: the 8-wave workgroups stage the table in LDS (all of it when only (qx, qy) is kept, the
+    first 288 / 144 slots otherwise) and read the rest from L2; both stagings agree with each other and with the oracle."""
+    from mmd_amd.constraints import soft_constraints_from_paths
+    starts, goals = synth.start_goal_circle(n_all, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    cons = soft_constraints_from_paths(torch.from_numpy(paths).cuda(), 7, 2)
+    x = (torch.from_numpy(synth.synth_noise(52, (2 * 8, H, D))) * 0.5).cuda()
+    g_gen = _gc().hip_guide("EnvEmpty2D", [[], []], n_robots=2)
+    g_gen.set_packed_constraints(cons[:4])
+    g_cmp = _gc().hip_guide("EnvEmpty2D", [[], []], n_robots=2)
+    g_cmp.set_packed_constraints(cons)
+    out = g_cmp(x)
+    if n_all - 1 <= 144:
+        assert torch.equal(out, g_gen(x))          # both fully on chip: the same sums in the same order
+    else:
+        assert float((out - g_gen(x)).abs().max()) < 1e-6   # LDS / L2 split at 288 vs 144 slots: another sum order
+    gp = cases.guide_params("EnvEmpty2D")
+    ref = O.guide_grad(x[:8].cpu(), gp, [cases.soft_group(paths, 7)], clip_mode="always")
+    assert float((out[:8].cpu() - ref).abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("name", cases.SAMPLE_CASES)

@@ -8,6 +8,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(8)));
 struct B6 { f32x4u lo; f32x2u hi; };
+typedef int i4_ __attribute__((ext_vector_type(4)));
+typedef int i2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ B6 buf_b6(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  B6 b;
+  i4_ x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  i2_ y = __builtin_amdgcn_raw_buffer_load_b64(r, voff + 16, soff, 0);
+  b.lo = __builtin_bit_cast(f32x4u, x); b.hi = __builtin_bit_cast(f32x2u, y);
+  return b;
+}
 #define PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 constexpr int STR = 129, KSTRIDE = 64 * 6, KS = 64;
 
@@ -43,6 +52,7 @@ __global__ __launch_bounds__(256) void wino(const float* __restrict__ w, float* 
   // LDS == 2: lane stride STR (odd) instead of 2 * STR: bank-conflict free
   const float* s0 = slab + srow * 20 * STR + (LDS == 2 ? 1 : 2) * tile * STR + (lane >> 5);
   const float* wp0 = w + ((size_t)wave * KS * KSTRIDE) + lane * 6;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(w + (size_t)wave * KS * KSTRIDE), 0, (KS + 16) * KSTRIDE * 4, 0x00020000);
   f32x16 m[6];
   float dummy = 0.f;
   for (int p = 0; p < 6; ++p) for (int r = 0; r < 16; ++r) m[p][r] = 0.f;
@@ -66,6 +76,7 @@ __global__ __launch_bounds__(256) void wino(const float* __restrict__ w, float* 
         step<VALU>(m, d[j & 1], b[j]);
         if (GLD == 3) bx[j] = load_b6(p + j * KSTRIDE);
         if (GLD == 1) b[j] = load_b6(p + j * KSTRIDE);
+        if (GLD == 4) b[j] = buf_b6(rsrc, lane * 24, (int)((p - wp0) + j * KSTRIDE) * 4);
         if (GLD == 2) {   // dense: three 16-byte loads per TWO k-steps (same bytes, lanes contiguous)
           const float4* q = reinterpret_cast<const float4*>(w + (size_t)(threadIdx.x >> 6) * KS * KSTRIDE) + ((ks + j) / 2 * 3) * 64 + lane;
           if ((j & 1) == 0) { float4 x = q[0], y = q[64]; b[j].lo = {x.x, x.y, x.z, x.w}; b[j].hi = {y.x, y.y}; b[j + 1].lo[0] = y.z; b[j + 1].lo[1] = y.w; }
@@ -344,6 +355,7 @@ int main(int argc, char** argv) {
   run_pipe<1, true>("hand-interleaved", wps, w, out);
   run_pipe<2, true>("hand-interleaved, conflict-free", wps, w, out);
   run<1, 1, true>("full", wps, w, out);
+  run<1, 4, true>("buffer loads (SGPR offset)", wps, w, out);
   run<2, 1, true>("conflict-free LDS", wps, w, out);
   run<1, 2, true>("dense weight loads", wps, w, out);
   run<2, 2, true>("conflict-free + dense", wps, w, out);
