@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mmd_amd.h"
@@ -155,9 +156,15 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[MT_W], const float* sla
 // A fragments are double-buffered in registers (the LDS reads of k-group g+1 are issued before the 4*MT_W MFMAs of
 // group g), B fragments ride a 4-deep register ring fed straight from L2: a lone wave keeps the matrix pipe busy, so a
 // co-resident wave's epilogue overlaps instead of stalling it.
+// first four k-groups of a direct-conv pack, requested ahead of time (see wino_ring_load)
+__device__ __forceinline__ void mfma_ring_load(float4 (&b)[4], const float4* __restrict__ wp) {
+  b[0] = wp[0]; b[1] = wp[64]; b[2] = wp[128]; b[3] = wp[192];
+  MMD_PIN_LOADS();
+}
+
 template <int NTAPS, int CP, int STR, int MT_W>
 __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W],
-                                          const float4* __restrict__ wp) {
+                                          const float4* __restrict__ wp, const float4 (*pre)[4] = nullptr) {
   constexpr int GPT = CP / 8;   // k-groups (of 4 k-pairs) per tap
   if constexpr (GPT % 4 != 0) {
     // tiny K (the 4-channel input layer, padded to 8): everything in flight at once
@@ -168,7 +175,9 @@ __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab
     for (int g = 0; g < NTAPS * GPT; ++g) mfma_group<MT_W>(acc, slab, abase, (g / GPT) * STR + (g % GPT) * 8, b[g]);
   } else {
     const float4* p = wp;
-    float4 b0 = p[0], b1 = p[64], b2 = p[128], b3 = p[192];
+    float4 b0, b1, b2, b3;
+    if (pre) { b0 = (*pre)[0]; b1 = (*pre)[1]; b2 = (*pre)[2]; b3 = (*pre)[3]; }
+    else { b0 = p[0]; b1 = p[64]; b2 = p[128]; b3 = p[192]; }
     float a0[4][MT_W], a1[4][MT_W];
     load_a<MT_W>(a0, slab, abase, 0);
 #pragma unroll
@@ -292,18 +301,6 @@ struct ChainCfg {
   static_assert(N_IDENT <= MAX_IDENT, "too many identity RTBs");
 };
 
-template <int CM, int L, int MT_W, int HSS, int HSTR, int SW>
-__device__ __forceinline__ void tile_to_slab(const f32x16 (&acc)[MT_W], float* hslab, int wm, int col, int hi) {
-#pragma unroll
-  for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int s = wm * SW + row / L, l = row % L;
-      hslab[s * HSS + (l + 2) * HSTR + col] = acc[mt][r];
-    }
-}
-
 template <int MT_W>
 __device__ __forceinline__ void fill(f32x16 (&acc)[MT_W], float v) {
 #pragma unroll
@@ -384,19 +381,27 @@ constexpr int WINO_KSTRIDE = 64 * 6;   // floats per k-step of a packed n-tile
 
 // m[p] += V_p(slab) * U_p for the CP input channels of one slab.  abase = lane's offset of (sample, row 2*tile, k = lane>>5);
 // wp = this lane's six floats of k-step 0 of the wave's n-tile.  d is double-buffered, U rides a 4-k-step register ring.
-#ifndef MMD_WINO_RING
-#define MMD_WINO_RING 4
-#endif
+constexpr int WINO_RD = 4;   // depth of the weight ring in k-steps
+
+// first WINO_RD k-steps of a packed conv into the ring.  Issued BEFORE the previous conv's epilogue so that the L2
+// latency of a conv's first weights is not exposed once per conv.
+__device__ __forceinline__ void wino_ring_load(B6 (&b)[WINO_RD], const float* __restrict__ wp) {
+#pragma unroll
+  for (int j = 0; j < WINO_RD; ++j) b[j] = load_b6(wp + j * WINO_KSTRIDE);
+  MMD_PIN_LOADS();
+}
+
+// m[p] += V_p(slab) * U_p for the CP input channels of one slab.  abase = lane's offset of (sample, row 2*tile, k = lane>>5);
+// wp = this lane's six floats of k-step 0 of the wave's n-tile; b = the ring, pre-loaded with k-steps 0..3 (wino_ring_load).
+// d is double-buffered, U rides the register ring.
 template <int CP, int STR>
-__device__ __forceinline__ void wino_taps(f32x16 (&m)[6], const float* slab, int abase, const float* __restrict__ wp) {
+__device__ __forceinline__ void wino_taps(f32x16 (&m)[6], const float* slab, int abase, const float* __restrict__ wp,
+                                          B6 (&b)[WINO_RD]) {
   constexpr int KS = CP / 2;
-  constexpr int RD = KS % MMD_WINO_RING == 0 ? MMD_WINO_RING : 4;   // ring depth in k-steps
+  constexpr int RD = WINO_RD;
   static_assert(KS % RD == 0 && RD % 2 == 0, "k-steps are unrolled by the ring depth");
   const float* p = wp;
   const float* s = slab + abase;
-  B6 b[RD];
-#pragma unroll
-  for (int j = 0; j < RD; ++j) b[j] = load_b6(p + j * WINO_KSTRIDE);
   float d[2][6];
   load_d<STR>(d[0], s);
 #pragma unroll 1
@@ -484,6 +489,10 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
   const int hi = lane >> 5;
   constexpr int TPS = CF::L / 2;                             // pair rows (tiles) per sample
 
+  B6 ring[WINO_RD];
+  const float* w0 = reinterpret_cast<const float*>(a.r0.wa) + (size_t)wn * (CF::C0P / 2) * WINO_KSTRIDE + lane * 6;
+  const float4* wres = a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane;
+
   if constexpr (FIRST)
     stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
@@ -495,10 +504,15 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
   const int hbase = srow * CF::HSS + 2 * tile * CF::HSTR + hi;
   f32x16 m[6], res[2];
 
-  auto conv_h = [&](const float4* w, float bias) {           // conv over the H slab (CM -> CM)
+  auto wlane = [&](const float4* w) {                        // this lane's first k-step of a CM -> CM pack
+    return reinterpret_cast<const float*>(w) + (size_t)wn * (CF::CM / 2) * WINO_KSTRIDE + lane * 6;
+  };
+  // conv over the H slab (CM -> CM); `next` = weights of the conv after this one (or null): their first k-steps are
+  // requested before this conv's epilogue
+  auto conv_h = [&](const float4* w, float bias, const float4* next) {
     zero6(m);
-    if (MMD_ABL != 3)
-      wino_taps<CF::CM, CF::HSTR>(m, hslab, hbase, reinterpret_cast<const float*>(w) + (size_t)wn * (CF::CM / 2) * WINO_KSTRIDE + lane * 6);
+    if (MMD_ABL != 3) wino_taps<CF::CM, CF::HSTR>(m, hslab, hbase, wlane(w), ring);
+    if (next) wino_ring_load(ring, wlane(next));
     wino_out(acc, m, bias);
   };
   auto add_tb = [&](float tb) {
@@ -511,14 +525,15 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
   // =================== RTB 0 (C0 -> CM, 1x1 residual conv) ===================
   TR(trb + 0);
   zero6(m);
-  if (MMD_ABL != 3)
-    wino_taps<CF::C0P, CF::XSTR>(m, xslab, xbase, reinterpret_cast<const float*>(a.r0.wa) + (size_t)wn * (CF::C0P / 2) * WINO_KSTRIDE + lane * 6);
+  wino_ring_load(ring, w0);
+  if (MMD_ABL != 3) wino_taps<CF::C0P, CF::XSTR>(m, xslab, xbase, w0, ring);
+  wino_ring_load(ring, wlane(a.r0.wb));
   wino_out(acc, m, a.r0.ba[col]);
   TR(trb + 1);
   {
     int rbase[2] = {xbase + 2 * CF::XSTR, xbase + 3 * CF::XSTR};
     fill<2>(res, a.br[col]);
-    if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 2>(res, xslab, rbase, a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane);
+    if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 2>(res, xslab, rbase, wres);
   }
   TR(trb + 2);
   if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.ga[col], a.r0.bea[col]);
@@ -527,7 +542,7 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
   TR(trb + 3);
   __syncthreads();
   TR(trb + 4);
-  conv_h(a.r0.wb, a.r0.bb[col]);
+  conv_h(a.r0.wb, a.r0.bb[col], CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
   TR(trb + 5);
   if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.gb[col], a.r0.beb[col]);
   acc[0] += res[0];
@@ -546,7 +561,7 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
     pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
     __syncthreads();
     TR(trb + 8 + k * 8 + 1);
-    conv_h(R.wa, R.ba[col]);
+    conv_h(R.wa, R.ba[col], R.wb);
     TR(trb + 8 + k * 8 + 2);
     if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.ga[col], R.bea[col]);
     add_tb(R.tb[col]);
@@ -556,7 +571,7 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
     pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
     __syncthreads();
     TR(trb + 8 + k * 8 + 5);
-    conv_h(R.wb, R.bb[col]);
+    conv_h(R.wb, R.bb[col], k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
     TR(trb + 8 + k * 8 + 6);
     if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.gb[col], R.beb[col]);
     acc[0] += res[0];
@@ -578,150 +593,190 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
   }
 }
 
-// One level chain for the workgroup's 4 samples.  FIRST: chunk 0 of the input is staged from global memory (the network
-// input); otherwise the previous stage has already written it (and zeroed its halo rows) into the x slab.  The second
-// chunk of a channel concat is the pair tile `skip` kept from the down path (level length SKIP_L, SKIP_WN channel waves).  Results stay in
-// registers: `acc` = output of the RTB chain, `mid` = copy after RTB number MID_AFTER (the skip connection), `tout` = tail
-// conv result (TAIL_DOWN: tout[0][0]; TAIL_UP: tout[parity][mt]).
-template <class CF, bool FIRST, int SKIP_L, int SKIP_WN>
-__device__ __forceinline__ void chain_body(const ChainArgs& a, float* lds, int n0, int lane, int wave,
-                                           const f32x16 (&skip)[2], f32x16 (&acc)[CF::MT_W], f32x16 (&mid)[CF::MT_W],
-                                           f32x16 (&tout)[2][CF::MT_W]) {
+// ----------------------------------------------------------------------------------------------------------------
+// Up-path stage in Winograd form.  C_out is 64 / 32 here, so the four samples give only two (M, N) tiles per position:
+// the four waves are two PAIRS, and the waves of a pair split the input channels (K) of every conv between them.  Each
+// computes all six positions over its K half, applies the output transform to its partial sums, hands the output-row
+// parity it does not own (kh = 0 keeps rows 2t, kh = 1 rows 2t + 1) to its partner through LDS together with its
+// partial GroupNorm sums, and runs GroupNorm + Mish on its own 16 values per lane: 0.6x the MFMAs of the direct form
+// and half the epilogue VALU work per wave, for two extra barriers per conv.  The exchange buffer lives in the x slab
+// (free once conv A of the first RTB has consumed it).
+// ----------------------------------------------------------------------------------------------------------------
+template <int CM, int L>
+__device__ __forceinline__ void exchange_gn_mish(const f32x16 (&P)[2], f32x16& own, float* exch, int wave, int lane,
+                                                 float gamma, float beta) {
+  constexpr int CPG = CM / 8, TPS = L / 2, SW = 32 / TPS;     // channels per group, pair rows per sample, samples per tile
+  constexpr float inv_n = 1.f / (float)(L * CPG);
+  const int kh = wave & 1, partner = wave ^ 1;
+  float* ybuf = exch;                                          // [4 waves][16][64]
+  float* st1 = exch + 4 * 1024;                                // [4 waves][SW][32] partial sums
+  float* st2 = st1 + 4 * SW * 32;                              // [4 waves][SW][32] partial centred squares
+  float sl[SW];
+#pragma unroll
+  for (int s = 0; s < SW; ++s) {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((8 * (r >> 2)) / TPS == s) sum += P[0][r] + P[1][r];
+    sl[s] = group_allreduce<CPG>(sum);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ybuf[(wave * 16 + r) * 64 + lane] = kh ? P[0][r] : P[1][r];
+  if (lane < 32) {
+#pragma unroll
+    for (int s = 0; s < SW; ++s) st1[(wave * SW + s) * 32 + lane] = sl[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) own[r] = (kh ? P[1][r] : P[0][r]) + ybuf[(partner * 16 + r) * 64 + lane];
+  float mean[SW], rstd[SW], sq[SW];
+#pragma unroll
+  for (int s = 0; s < SW; ++s) {
+    mean[s] = (sl[s] + st1[(partner * SW + s) * 32 + (lane & 31)]) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((8 * (r >> 2)) / TPS == s) {
+        const float d = own[r] - mean[s];
+        q += d * d;
+      }
+    sq[s] = group_allreduce<CPG>(q);
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int s = 0; s < SW; ++s) st2[(wave * SW + s) * 32 + lane] = sq[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < SW; ++s) rstd[s] = rsqrtf((sq[s] + st2[(partner * SW + s) * 32 + (lane & 31)]) * inv_n + 1e-5f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int s = (8 * (r >> 2)) / TPS;
+    own[r] = MMD_ABL == 1 ? own[r] : mish((own[r] - mean[s]) * rstd[s] * gamma + beta);
+  }
+}
+
+template <class CF, int SKIP_L, int SKIP_WN>
+__device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, int n0, int lane, int wave,
+                                              const f32x16 (&skip)[2], f32x16 (&tout)[2][CF::MT_W], int trb) {
+  static_assert(!CF::SHARE && CF::C1 == CF::C0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "up-path stage");
   float* hslab = lds + CF::XSLAB;
-  float* xslab = CF::SHARE ? hslab : lds;
-  constexpr int XS = CF::SHARE ? CF::HSTR : CF::XSTR;      // row stride of the slab conv A reads
-  constexpr int XSSv = CF::SHARE ? CF::HSS : CF::XSS;      // its sample stride
-  constexpr int MT_W = CF::MT_W;
+  float* xslab = lds;
+  float* exch = lds;                                          // exchange buffers overlay the x slab
+  constexpr int TPS = CF::L / 2, WNU = CF::CM / 32;
+  static_assert(CF::XSLAB >= 4 * 1024 + 2 * 4 * (32 / TPS) * 32, "exchange buffers must fit into the x slab");
+  const int kh = wave & 1, pw = wave >> 1;
+  const int wn = pw % WNU, wmu = pw / WNU;
+  const int col = wn * 32 + (lane & 31), hi = lane >> 5;
+  const int g = wmu * 32 + (lane & 31);
+  const int srow = g / TPS, tile = g % TPS;
 
-  const int wm = wave / CF::WN, wn = wave % CF::WN;
-  const int col = wn * 32 + (lane & 31);
-  const int hi = lane >> 5;
+  f32x16 m[6], P[2], own, res;
+  // one conv's K half of this wave over a slab with CP channels
+  B6 ring[WINO_RD];
+  auto wlane = [&](auto cp_tag, const float4* w) {            // this lane's first k-step of its K half of a CP-channel pack
+    constexpr int CP = decltype(cp_tag)::value;
+    return reinterpret_cast<const float*>(w) + ((size_t)(wn * (CP / 2) + kh * (CP / 4)) * 64 + lane) * 6;
+  };
+  // `ring` must hold the first k-steps of w (wino_ring_load); afterwards it is re-armed with those of `next`
+  auto conv = [&](auto cp_tag, const float* slab, int ss, const float4* w, auto next_tag, const float4* next) {
+    constexpr int CP = decltype(cp_tag)::value;
+    const int abase = srow * ss + 2 * tile * (CP + 1) + hi + kh * (CP / 2);
+    if (MMD_ABL != 3) wino_taps<CP / 2, CP + 1>(m, slab, abase, wlane(cp_tag, w), ring);
+    if (next) wino_ring_load(ring, wlane(next_tag, next));
+  };
+  using TC0 = std::integral_constant<int, CF::C0P>;
+  using TC1 = std::integral_constant<int, CF::C1P>;
+  using TCM = std::integral_constant<int, CF::CM>;
+  auto own_to_h = [&]() {                                     // rows 2t + kh of the H slab
+    tile_to_stage<TPS, 1, 32 / TPS, 1, 2, CF::HSS, CF::HSTR>(*reinterpret_cast<const f32x16(*)[1]>(&own), hslab + wn * 32,
+                                                             wmu, lane, kh);
+  };
+  const int rbase1 = srow * CF::XSS + (2 * tile + 2 + kh) * CF::XSTR + hi;   // 1x1 residual conv: this wave's own rows
 
-  static_assert(!CF::SHARE, "level chains start with a channel-changing RTB");
-  if constexpr (FIRST)
-    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
+  // =================== RTB 0: cat(x, skip) -> CM, 1x1-conv residual ===================
+  const float4* wres0 = a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane;
+  const float4* wres1 = a.wr_c1 + ((size_t)wn * (CF::C1P / 8)) * 64 + lane;
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
-
-  int srow[MT_W], lrow[MT_W];
-#pragma unroll
-  for (int mt = 0; mt < MT_W; ++mt) {
-    const int r = mt * 32 + (lane & 31);
-    srow[mt] = wm * CF::SW + r / CF::L;
-    lrow[mt] = r % CF::L;
-  }
-  int hbase[MT_W];                                           // A-fragment base into the H slab (tap 0)
-#pragma unroll
-  for (int mt = 0; mt < MT_W; ++mt) hbase[mt] = srow[mt] * CF::HSS + lrow[mt] * CF::HSTR + hi;
-
-  f32x16 res[MT_W];
-  // =================== RTB 0 ===================
+  TR(trb + 0);
+  zero6(m);
+  wino_ring_load(ring, wlane(TC0{}, a.r0.wa));
   {
-    int xbase[MT_W], rbase[MT_W];
+    f32x16 rr[1];
+    fill<1>(rr, a.br[col]);
+    int rb[1] = {rbase1};
+    conv(TC0{}, xslab, CF::XSS, a.r0.wa, TC1{}, a.wa0_c1);
+    if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 1>(rr, xslab, rb, wres0);
+    __syncthreads();                                          // chunk 0 has been consumed by every wave
+    pair_to_stage<SKIP_L, SKIP_WN, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
+    __syncthreads();
+    conv(TC1{}, xslab, CF::XSS, a.wa0_c1, TCM{}, a.r0.wb);
+    if (MMD_ABL != 3) mfma_taps<1, CF::C1P, CF::XSTR, 1>(rr, xslab, rb, wres1);
+    res = rr[0];
+  }
+  wino_out(P, m, kh == 0 ? a.r0.ba[col] : 0.f);
+  TR(trb + 1);
+  __syncthreads();                                            // every wave is done reading the x slab: it becomes the exchange buffer
+  exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, a.r0.ga[col], a.r0.bea[col]);
+  own += a.r0.tb[col];
+  own_to_h();
+  __syncthreads();
+  TR(trb + 2);
+  zero6(m);
+  conv(TCM{}, hslab, CF::HSS, a.r0.wb, TCM{}, a.ri[0].wa);
+  wino_out(P, m, kh == 0 ? a.r0.bb[col] : 0.f);
+  TR(trb + 3);
+  exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, a.r0.gb[col], a.r0.beb[col]);   // (its first barrier also frees the H slab)
+  own += res;
+  TR(trb + 4);
+
+  // =================== identity RTB ===================
+  {
+    const RtbPtrs& R = a.ri[0];
+    res = own;
+    own_to_h();
+    __syncthreads();
+    zero6(m);
+    conv(TCM{}, hslab, CF::HSS, R.wa, TCM{}, R.wb);
+    wino_out(P, m, kh == 0 ? R.ba[col] : 0.f);
+    TR(trb + 5);
+    exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, R.ga[col], R.bea[col]);
+    own += R.tb[col];
+    own_to_h();
+    __syncthreads();
+    zero6(m);
+    conv(TCM{}, hslab, CF::HSS, R.wb, TCM{}, static_cast<const float4*>(nullptr));
+    wino_out(P, m, kh == 0 ? R.bb[col] : 0.f);
+    TR(trb + 6);
+    exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, R.gb[col], R.beb[col]);
+    own += res;
+  }
+
+  // =================== tail: Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, direct ===================
+  own_to_h();
+  __syncthreads();
+  TR(trb + 7);
+  {
+    constexpr int MT_W = CF::MT_W;
+    const int wm = wave / CF::WN, wnt = wave % CF::WN, colt = wnt * 32 + (lane & 31);
+    int hbase[MT_W];
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt) {
-      xbase[mt] = srow[mt] * XSSv + lrow[mt] * XS + hi;
-      rbase[mt] = xbase[mt] + 2 * XS;
+      const int r = mt * 32 + (lane & 31);
+      hbase[mt] = (wm * CF::SW + r / CF::L) * CF::HSS + (r % CF::L) * CF::HSTR + hi;
     }
-    fill<MT_W>(acc, a.r0.ba[col]);
-    if (MMD_ABL != 3) mfma_taps<5, CF::C0P, XS, MT_W>(acc, xslab, xbase, a.r0.wa + ((size_t)wn * (5 * CF::C0P / 8)) * 64 + lane);
-    if constexpr (CF::RES0 == RES_CONV) {
-      fill<MT_W>(res, a.br[col]);
-      if (MMD_ABL != 3) mfma_taps<1, CF::C0P, XS, MT_W>(res, xslab, rbase, a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane);
-    }
-    if constexpr (CF::C1 > 0) {                              // second half of the channel concat, same slab
-      __syncthreads();                                       // chunk 0 has been consumed by every wave
-      pair_to_stage<SKIP_L, SKIP_WN, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
-      __syncthreads();
-      if (MMD_ABL != 3) mfma_taps<5, CF::C1P, XS, MT_W>(acc, xslab, xbase, a.wa0_c1 + ((size_t)wn * (5 * CF::C1P / 8)) * 64 + lane);
-      if constexpr (CF::RES0 == RES_CONV)
-        if (MMD_ABL != 3) mfma_taps<1, CF::C1P, XS, MT_W>(res, xslab, rbase, a.wr_c1 + ((size_t)wn * (CF::C1P / 8)) * 64 + lane);
-    }
-    if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, a.r0.ga[col], a.r0.bea[col]);
-    {
-      const float tb = a.r0.tb[col];
+    const float bt = a.bt[colt];
+    constexpr int G = 2 * CF::CM / 8;
 #pragma unroll
-      for (int mt = 0; mt < MT_W; ++mt)
+    for (int pass = 0; pass < 2; ++pass) {
+      f32x16 (&t)[MT_W] = tout[pass];
+      fill<MT_W>(t, bt);
+      int ub[MT_W];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] += tb;
-    }
-    if constexpr (CF::SHARE) __syncthreads();                // every wave is done reading x before h overwrites it
-    tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
-    __syncthreads();
-    fill<MT_W>(acc, a.r0.bb[col]);
-    if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, a.r0.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
-    if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, a.r0.gb[col], a.r0.beb[col]);
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[mt][r] += res[mt][r];
-      }
-  }
-  if constexpr (CF::MID_AFTER == 0) {
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt) mid[mt] = acc[mt];
-  }
-
-  // =================== identity RTBs ===================
-#pragma unroll
-  for (int k = 0; k < CF::N_IDENT; ++k) {
-    const RtbPtrs& R = a.ri[k];
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt) res[mt] = acc[mt];     // this wave's tile of the RTB input = its residual
-    __syncthreads();                                         // the previous conv is done reading the H slab
-    tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
-    __syncthreads();
-    fill<MT_W>(acc, R.ba[col]);
-    if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wa + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
-    if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, R.ga[col], R.bea[col]);
-    {
-      const float tb = R.tb[col];
-#pragma unroll
-      for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] += tb;
-    }
-    __syncthreads();
-    tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
-    __syncthreads();
-    fill<MT_W>(acc, R.bb[col]);
-    if (MMD_ABL != 3) mfma_taps<5, CF::CM, CF::HSTR, MT_W>(acc, hslab, hbase, R.wb + ((size_t)wn * (5 * CF::CM / 8)) * 64 + lane);
-    if (MMD_ABL != 1) gn_mish<CF::CM, CF::L, MT_W>(acc, R.gb[col], R.beb[col]);
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt) acc[mt] += res[mt];
-    if (CF::MID_AFTER == k + 1) {
-#pragma unroll
-      for (int mt = 0; mt < MT_W; ++mt) mid[mt] = acc[mt];
-    }
-  }
-
-  // =================== tail ===================
-  if constexpr (CF::TAIL != TAIL_NONE) {
-    __syncthreads();
-    tile_to_slab<CF::CM, CF::L, MT_W, CF::HSS, CF::HSTR, CF::SW>(acc, hslab, wm, col, hi);
-    __syncthreads();
-    const float bt = a.bt[col];
-    if constexpr (CF::TAIL == TAIL_DOWN) {
-      // Conv1d(k3, s2, p1): one 32-row tile per wave = its SW samples x L/2 output rows; tap 0 reads slab row 2*lo + 1
-      constexpr int LO = CF::L / 2;
-      f32x16 (&t)[1] = *reinterpret_cast<f32x16(*)[1]>(&tout[0][0]);
-      fill<1>(t, bt);
-      const int r = lane & 31;
-      int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
-      if (MMD_ABL != 3) mfma_taps<3, CF::CM, CF::HSTR, 1>(t, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
-    } else {
-      // ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes: out[2m] = in[m-1] W3 + in[m] W1, out[2m+1] = in[m] W2 + in[m+1] W0
-      constexpr int G = 2 * CF::CM / 8;
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        f32x16 (&t)[MT_W] = tout[pass];
-        fill<MT_W>(t, bt);
-        int ub[MT_W];
-#pragma unroll
-        for (int mt = 0; mt < MT_W; ++mt) ub[mt] = hbase[mt] + (1 + pass) * CF::HSTR;
-        if (MMD_ABL != 3) mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wn * G) * 64 + lane);
-      }
+      for (int mt = 0; mt < MT_W; ++mt) ub[mt] = hbase[mt] + (1 + pass) * CF::HSTR;
+      if (MMD_ABL != 3)
+        mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wnt * G) * 64 + lane);
     }
   }
 }
@@ -786,8 +841,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   TR(130);
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
   {
-    f32x16 acc[1], mid[1], t[2][1];
-    chain_body<CH_U0, false, CH_D2::L, CH_D2::WN>(a.c[3], lds, n0, lane, wave, skip2, acc, mid, t);
+    f32x16 t[2][1];
+    chain_body_wu<CH_U0, CH_D2::L, CH_D2::WN>(a.c[3], lds, n0, lane, wave, skip2, t, 136);
     __syncthreads();
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
@@ -796,8 +851,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   TR(131);
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
   {
-    f32x16 acc[1], mid[1], t[2][1];
-    chain_body<CH_U1, false, CH_D1::L, CH_D1::WN>(a.c[4], lds, n0, lane, wave, skip1, acc, mid, t);
+    f32x16 t[2][1];
+    chain_body_wu<CH_U1, CH_D1::L, CH_D1::WN>(a.c[4], lds, n0, lane, wave, skip1, t, 146);
     __syncthreads();
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
@@ -813,7 +868,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       f32x16 m[6];
       zero6(m);
-      if (MMD_ABL != 3) wino_taps<32, FIN_STR>(m, lds, wave * FIN_SS + 2 * (lane & 31) * FIN_STR + hi, reinterpret_cast<const float*>(f.wpk) + lane * 6);
+      B6 ring[WINO_RD];
+      const float* w0 = reinterpret_cast<const float*>(f.wpk) + lane * 6;
+      wino_ring_load(ring, w0);
+      if (MMD_ABL != 3) wino_taps<32, FIN_STR>(m, lds, wave * FIN_SS + 2 * (lane & 31) * FIN_STR + hi, w0, ring);
       wino_out(acc, m, f.bias[col]);
     }
     if (MMD_ABL != 1) gn_mish_pair<32, 64>(acc, f.gamma[col], f.beta[col]);
@@ -1122,7 +1180,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     while (blob.size() % 4) blob.push_back(0.f);
-    const bool wino = r < 6 || r >= 10;   // down path + mid blocks: Winograd packs; up path: direct
+    const bool wino = true;               // every stride-1 k=5 conv runs in Winograd form
     W.a.wpk = blob.size();
     if (wino) pack_w(blob, tensors[R.t_w0], R.cout, R.cin); else pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false);
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
@@ -1144,8 +1202,8 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     if (r == 6 || r == 8) {   // ups.0.0 / ups.1.0: input = cat(x, skip): per-chunk packs for the K-chunked staging
       const int half = R.cin / 2;
       // a.wpk is repacked as chunk 0 (channels [0, half)); chunk 1 follows
-      W.a.wpk = blob.size(); pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false, 0, half);
-      W.a_c1 = blob.size(); pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false, half, R.cin);
+      W.a.wpk = blob.size(); pack_w(blob, tensors[R.t_w0], R.cout, R.cin, 0, half);
+      W.a_c1 = blob.size(); pack_w(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin);
       W.res_c0 = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false, 0, half);
       W.res_c1 = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false, half, R.cin);
     } else if (R.res) {

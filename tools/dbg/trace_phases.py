@@ -36,6 +36,9 @@ for base, nm in ((0, "D0"), (40, "D1"), (80, "D2")):
     for k in range(3):
         for j, w in enumerate(("barrier(prev)", "write+barrier", "convA done", "gn", "barrier", "write+barrier", "convB done", "gn+res")):
             names[base + 8 + k * 8 + j] = f"{nm} id{k} {w}"
+for base, nm in ((136, "U0"), (146, "U1")):
+    for j, w in enumerate(("start", "rtb0 convA+res done", "gn+write+barrier", "rtb0 convB done", "gn+res", "id convA done", "id convB done", "gn+write -> tail")):
+        names[base + j] = f"{nm} {w}"
 names.update({130: "-> U0 start", 131: "-> U1 start", 132: "-> FIN start", 133: "end"})
 prev = None
 print(f"{'tag':>4s} {'phase':28s} {'mean dt us':>10s} {'min':>8s} {'max':>8s}   cumulative(mean) us")
