@@ -210,10 +210,18 @@ __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab
 }
 
 // sum over the CPG lanes of a GroupNorm group and over both half-waves (rows r and r+4 live in lanes l and l+32)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {   // v + v[DPP-permuted lane] in one VALU op
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int CPG>
 __device__ __forceinline__ float group_allreduce(float v) {
-#pragma unroll
-  for (int m = 1; m < CPG; m <<= 1) v += __shfl_xor(v, m);
+  // butterfly inside a 16-lane DPP row: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+  static_assert(CPG == 4 || CPG == 8 || CPG == 16, "GroupNorm group = 4, 8 or 16 adjacent lanes");
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  if constexpr (CPG >= 8) v = dpp_add<0x141>(v);
+  if constexpr (CPG >= 16) v = dpp_add<0x140>(v);
   v += __shfl_xor(v, 32);
   return v;
 }
@@ -1294,8 +1302,8 @@ static const double kLayerMfmaFlops[kNumLayers] = {
     wino_flops(8, 32, 64) + direct_flops(1, 8, 32, 64) + 3 * wino_flops(32, 32, 64) + direct_flops(3, 32, 32, 32) +
     wino_flops(32, 64, 32) + direct_flops(1, 32, 64, 32) + 3 * wino_flops(64, 64, 32) + direct_flops(3, 64, 64, 16) +
     wino_flops(64, 128, 16) + direct_flops(1, 64, 128, 16) + 7 * wino_flops(128, 128, 16) +
-    direct_flops(5, 256, 64, 16) + direct_flops(1, 256, 64, 16) + 3 * direct_flops(5, 64, 64, 16) + 2 * direct_flops(2, 64, 64, 16) +
-    direct_flops(5, 128, 32, 32) + direct_flops(1, 128, 32, 32) + 3 * direct_flops(5, 32, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
+    wino_flops(256, 64, 16) + direct_flops(1, 256, 64, 16) + 3 * wino_flops(64, 64, 16) + 2 * direct_flops(2, 64, 64, 16) +
+    wino_flops(128, 32, 32) + direct_flops(1, 128, 32, 32) + 3 * wino_flops(32, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
     wino_flops(32, 32, 64) + direct_flops(1, 32, 32, 64)};
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
