@@ -49,6 +49,27 @@ __device__ __forceinline__ float mish(float y) {
   return y > 20.f ? y : m;       // branch-free: a select, not 32 divergent branches per tile
 }
 
+// GroupNorm affine + Mish of one activation in 10 VALU ops (every VALU op costs the SIMD ~5 cycles of MFMA issue):
+// y = x * sa + sb with sa = rstd * gamma, sb = beta - mean * sa folded per (sample, channel); the exponent argument
+// y * log2(e) comes from a second fma (sa2 = sa * log2 e, sb2 = sb * log2 e) instead of a multiply.  Clamping the
+// exponent at 20 makes n / (n + 2) round to 1 for y > 20 (n ~ 2.4e17), i.e. mish(y) = y up to one ulp, the softplus
+// threshold branch of torch.nn.Mish without a select.
+struct GnCoef { float sa, sb, sa2, sb2; };
+__device__ __forceinline__ GnCoef gn_coef(float mean, float rstd, float gamma, float beta) {
+  GnCoef c;
+  c.sa = rstd * gamma;
+  c.sb = fmaf(-mean, c.sa, beta);
+  c.sa2 = c.sa * 1.44269504088896341f;
+  c.sb2 = c.sb * 1.44269504088896341f;
+  return c;
+}
+__device__ __forceinline__ float gn_mish1(float x, const GnCoef& c) {
+  const float y = fmaf(x, c.sa, c.sb);
+  const float e = __builtin_amdgcn_exp2f(fminf(fmaf(x, c.sa2, c.sb2), 28.8539008177792681f));
+  const float n = e * (e + 2.f);
+  return y * (n * __builtin_amdgcn_rcpf(n + 2.f));
+}
+
 // Stage SPB samples' [LIN, C] rows (channels-last, optionally a concat of two tensors) into an LDS slab
 // [SPB][ROWS][STR] at row offset ROFF; samples >= n are zero filled.
 template <int C0, int C1, int CP, int LIN, int ROWS, int ROFF, int STR, int SPB, int SS = ROWS * STR>
@@ -324,14 +345,17 @@ __device__ __forceinline__ void fill(f32x16 (&acc)[MT_W], float v) {
 // only the strides change.  SRC gives the producing stage's tiling (which wave owns which samples / channel slice).
 template <int L_SRC, int MT_W, int SW_SRC, int WN_SRC, int ROW_MUL, int DSS, int DSTR>
 __device__ __forceinline__ void tile_to_stage(const f32x16 (&t)[MT_W], float* dst, int wave, int lane, int row_add) {
+  static_assert(L_SRC % 8 == 0, "rows r and r + 4 (the two half-waves) must belong to the same sample");
   const int wm = wave / WN_SRC, col = (wave % WN_SRC) * 32 + (lane & 31), hi = lane >> 5;
+  // one runtime base (sample block of the wave, column, half-wave, row parity), compile-time offsets per register:
+  // every store is a ds_write_b32 with an immediate offset, no per-element address arithmetic
+  float* base = dst + wm * SW_SRC * DSS + (ROW_MUL * 4 * hi + row_add + 2) * DSTR + col;
 #pragma unroll
   for (int mt = 0; mt < MT_W; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int s = wm * SW_SRC + row / L_SRC, l = row % L_SRC;
-      dst[s * DSS + (ROW_MUL * l + row_add + 2) * DSTR + col] = t[mt][r];
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2);          // + 4 * hi, which never crosses a sample
+      base[(row / L_SRC) * DSS + ROW_MUL * (row % L_SRC) * DSTR] = t[mt][r];
     }
 }
 
@@ -370,7 +394,13 @@ __device__ __forceinline__ void load_d(float (&d)[6], const float* s) {
   for (int j = 0; j < 6; ++j) d[j] = s[j * STR];
 }
 
+template <bool ZERO = false>
 __device__ __forceinline__ void wino_step(f32x16 (&m)[6], const float (&d)[6], const B6& b) {
+  if constexpr (ZERO) {   // first k-step of a conv: srcC = inline constant 0 instead of 96 v_mov to clear the accumulators
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 6; ++p) m[p] = z;
+  }
   const float a = fmaf(-4.f, d[2], d[4]), bb = fmaf(-4.f, d[1], d[3]);
   const float c = d[4] - d[2], e = d[3] - d[1];
   const float v0 = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
@@ -402,7 +432,8 @@ __device__ __forceinline__ void wino_ring_load(B6 (&b)[WINO_RD], const float* __
 // m[p] += V_p(slab) * U_p for the CP input channels of one slab.  abase = lane's offset of (sample, row 2*tile, k = lane>>5);
 // wp = this lane's six floats of k-step 0 of the wave's n-tile; b = the ring, pre-loaded with k-steps 0..3 (wino_ring_load).
 // d is double-buffered, U rides the register ring.
-template <int CP, int STR>
+// FRESH: the accumulators start at zero (first k-step issues its MFMAs with srcC = 0)
+template <int CP, int STR, bool FRESH>
 __device__ __forceinline__ void wino_taps(f32x16 (&m)[6], const float* slab, int abase, const float* __restrict__ wp,
                                           B6 (&b)[WINO_RD]) {
   constexpr int KS = CP / 2;
@@ -412,30 +443,49 @@ __device__ __forceinline__ void wino_taps(f32x16 (&m)[6], const float* slab, int
   const float* s = slab + abase;
   float d[2][6];
   load_d<STR>(d[0], s);
-#pragma unroll 1
-  for (int ks = 0; ks < KS; ks += RD) {
+  auto iter = [&](auto first) {
     p += RD * WINO_KSTRIDE;
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
       load_d<STR>(d[(j + 1) & 1], s + 2 * (j + 1));   // (past the last k-step this reads the next slab row and is unused)
       MMD_PIN_LOADS();
-      wino_step(m, d[j & 1], b[j]);
+      if (decltype(first)::value && j == 0) wino_step<true>(m, d[0], b[0]);
+      else wino_step<false>(m, d[j & 1], b[j]);
       b[j] = load_b6(p + j * WINO_KSTRIDE);
       MMD_PIN_LOADS();
     }
     s += 2 * RD;
+  };
+  if constexpr (FRESH) {
+    iter(std::true_type{});
+#pragma unroll 1
+    for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
+  } else {
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += RD) iter(std::false_type{});
   }
 }
 
 // Y = A^T M + bias: pr[0] = rows 2*tile, pr[1] = rows 2*tile + 1
-__device__ __forceinline__ void wino_out(f32x16 (&pr)[2], const f32x16 (&m)[6], float bias) {
+// (the conv bias is not added here: GroupNorm folds it into its statistics and affine, gn_mish_pair / exchange_gn_mish)
+__device__ __forceinline__ void wino_out(f32x16 (&pr)[2], const f32x16 (&m)[6]) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float s12 = m[1][r] + m[2][r], d12 = m[1][r] - m[2][r];
     const float s34 = m[3][r] + m[4][r], d34 = m[3][r] - m[4][r];
-    pr[0][r] = (m[0][r] + s12) + (s34 + bias);
-    pr[1][r] = (d12 + m[5][r]) + fmaf(2.f, d34, bias);
+    pr[0][r] = (m[0][r] + s12) + s34;
+    pr[1][r] = (d12 + m[5][r]) + 2.f * d34;
   }
+}
+
+// sum over the CPG adjacent lanes (channels) of a GroupNorm group, same value in all of them
+template <int CPG>
+__device__ __forceinline__ float group_colsum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  if constexpr (CPG >= 8) v = dpp_add<0x141>(v);
+  if constexpr (CPG >= 16) v = dpp_add<0x140>(v);
+  return v;
 }
 
 __device__ __forceinline__ void zero6(f32x16 (&m)[6]) {
@@ -445,36 +495,37 @@ __device__ __forceinline__ void zero6(f32x16 (&m)[6]) {
     for (int r = 0; r < 16; ++r) m[p][r] = 0.f;
 }
 
-// GroupNorm + Mish on a pair tile: register r of both halves belongs to sample (8 * (r >> 2)) / (L / 2) of the wave
+// GroupNorm + Mish on a pair tile x + bias: register r of both halves belongs to sample (8 * (r >> 2)) / (L / 2) of the
+// wave.  The per-channel conv bias is never added to the tile: mean = (sum x + L * sum_group bias) / N, the centred
+// values are x - (mean - bias), and the affine absorbs the rest.
 template <int CM, int L>
-__device__ __forceinline__ void gn_mish_pair(f32x16 (&pr)[2], float gamma, float beta) {
+__device__ __forceinline__ void gn_mish_pair(f32x16 (&pr)[2], float bias, float gamma, float beta) {
   constexpr int CPG = CM / 8;
   constexpr int SW = 64 / L;                     // samples per wave
   constexpr float inv_n = 1.f / (float)(L * CPG);
-  float mean[SW], rstd[SW];
+  const float bsum = group_colsum<CPG>(bias) * (float)L;
+  GnCoef cf[SW];
 #pragma unroll
   for (int s = 0; s < SW; ++s) {
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if ((8 * (r >> 2)) / (L / 2) == s) sum += pr[0][r] + pr[1][r];
-    mean[s] = group_allreduce<CPG>(sum) * inv_n;
+    const float dm = (group_allreduce<CPG>(sum) + bsum) * inv_n - bias;     // mean - bias of this lane's channel
     float sq = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if ((8 * (r >> 2)) / (L / 2) == s) {
-        const float d0 = pr[0][r] - mean[s], d1 = pr[1][r] - mean[s];
-        sq += d0 * d0 + d1 * d1;
+        const float d0 = pr[0][r] - dm, d1 = pr[1][r] - dm;
+        sq = fmaf(d0, d0, sq);
+        sq = fmaf(d1, d1, sq);
       }
-    rstd[s] = rsqrtf(group_allreduce<CPG>(sq) * inv_n + 1e-5f);
+    cf[s] = gn_coef(dm, rsqrtf(group_allreduce<CPG>(sq) * inv_n + 1e-5f), gamma, beta);
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int s = (8 * (r >> 2)) / (L / 2);
-      pr[h][r] = mish((pr[h][r] - mean[s]) * rstd[s] * gamma + beta);
-    }
+    for (int r = 0; r < 16; ++r) pr[h][r] = gn_mish1(pr[h][r], cf[(8 * (r >> 2)) / (L / 2)]);
 }
 
 // pair tile -> slab rows 2*tile + h (+2 halo) of a stage laid out [sample][row][DSTR]
@@ -517,11 +568,11 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
   };
   // conv over the H slab (CM -> CM); `next` = weights of the conv after this one (or null): their first k-steps are
   // requested before this conv's epilogue
-  auto conv_h = [&](const float4* w, float bias, const float4* next) {
-    zero6(m);
-    if (MMD_ABL != 3) wino_taps<CF::CM, CF::HSTR>(m, hslab, hbase, wlane(w), ring);
+  auto conv_h = [&](const float4* w, const float4* next) {
+    if (MMD_ABL != 3) wino_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w), ring);
+    else zero6(m);
     if (next) wino_ring_load(ring, wlane(next));
-    wino_out(acc, m, bias);
+    wino_out(acc, m);
   };
   auto add_tb = [&](float tb) {
 #pragma unroll
@@ -532,11 +583,11 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
 
   // =================== RTB 0 (C0 -> CM, 1x1 residual conv) ===================
   TR(trb + 0);
-  zero6(m);
   wino_ring_load(ring, w0);
-  if (MMD_ABL != 3) wino_taps<CF::C0P, CF::XSTR>(m, xslab, xbase, w0, ring);
+  if (MMD_ABL != 3) wino_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, w0, ring);
+  else zero6(m);
   wino_ring_load(ring, wlane(a.r0.wb));
-  wino_out(acc, m, a.r0.ba[col]);
+  wino_out(acc, m);
   TR(trb + 1);
   {
     int rbase[2] = {xbase + 2 * CF::XSTR, xbase + 3 * CF::XSTR};
@@ -544,15 +595,15 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
     if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 2>(res, xslab, rbase, wres);
   }
   TR(trb + 2);
-  if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.ga[col], a.r0.bea[col]);
+  if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col]);
   add_tb(a.r0.tb[col]);
   pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
   TR(trb + 3);
   __syncthreads();
   TR(trb + 4);
-  conv_h(a.r0.wb, a.r0.bb[col], CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
+  conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
   TR(trb + 5);
-  if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.gb[col], a.r0.beb[col]);
+  if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col]);
   acc[0] += res[0];
   acc[1] += res[1];
   TR(trb + 6);
@@ -569,9 +620,9 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
     pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
     __syncthreads();
     TR(trb + 8 + k * 8 + 1);
-    conv_h(R.wa, R.ba[col], R.wb);
+    conv_h(R.wa, R.wb);
     TR(trb + 8 + k * 8 + 2);
-    if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.ga[col], R.bea[col]);
+    if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col]);
     add_tb(R.tb[col]);
     TR(trb + 8 + k * 8 + 3);
     __syncthreads();
@@ -579,9 +630,9 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
     pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
     __syncthreads();
     TR(trb + 8 + k * 8 + 5);
-    conv_h(R.wb, R.bb[col], k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
+    conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
     TR(trb + 8 + k * 8 + 6);
-    if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.gb[col], R.beb[col]);
+    if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col]);
     acc[0] += res[0];
     acc[1] += res[1];
     TR(trb + 8 + k * 8 + 7);
@@ -612,13 +663,14 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
 // ----------------------------------------------------------------------------------------------------------------
 template <int CM, int L>
 __device__ __forceinline__ void exchange_gn_mish(const f32x16 (&P)[2], f32x16& own, float* exch, int wave, int lane,
-                                                 float gamma, float beta) {
+                                                 float bias, float gamma, float beta) {
   constexpr int CPG = CM / 8, TPS = L / 2, SW = 32 / TPS;     // channels per group, pair rows per sample, samples per tile
   constexpr float inv_n = 1.f / (float)(L * CPG);
   const int kh = wave & 1, partner = wave ^ 1;
   float* ybuf = exch;                                          // [4 waves][16][64]
   float* st1 = exch + 4 * 1024;                                // [4 waves][SW][32] partial sums
   float* st2 = st1 + 4 * SW * 32;                              // [4 waves][SW][32] partial centred squares
+  const float bsum = group_colsum<CPG>(bias) * (float)L;
   float sl[SW];
 #pragma unroll
   for (int s = 0; s < SW; ++s) {
@@ -628,25 +680,37 @@ __device__ __forceinline__ void exchange_gn_mish(const f32x16 (&P)[2], f32x16& o
       if ((8 * (r >> 2)) / TPS == s) sum += P[0][r] + P[1][r];
     sl[s] = group_allreduce<CPG>(sum);
   }
+  float* outbox = ybuf + wave * 1024 + lane;
+  const float* inbox = ybuf + partner * 1024 + lane;
+  if (kh) {                                                    // wave-uniform: rows 2t + 1 stay, rows 2t go to the partner
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ybuf[(wave * 16 + r) * 64 + lane] = kh ? P[0][r] : P[1][r];
+    for (int r = 0; r < 16; ++r) outbox[r * 64] = P[0][r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) outbox[r * 64] = P[1][r];
+  }
   if (lane < 32) {
 #pragma unroll
     for (int s = 0; s < SW; ++s) st1[(wave * SW + s) * 32 + lane] = sl[s];
   }
   __syncthreads();
+  if (kh) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) own[r] = (kh ? P[1][r] : P[0][r]) + ybuf[(partner * 16 + r) * 64 + lane];
-  float mean[SW], rstd[SW], sq[SW];
+    for (int r = 0; r < 16; ++r) own[r] = P[1][r] + inbox[r * 64];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) own[r] = P[0][r] + inbox[r * 64];
+  }
+  float dm[SW], sq[SW];
 #pragma unroll
   for (int s = 0; s < SW; ++s) {
-    mean[s] = (sl[s] + st1[(partner * SW + s) * 32 + (lane & 31)]) * inv_n;
+    dm[s] = (sl[s] + st1[(partner * SW + s) * 32 + (lane & 31)] + bsum) * inv_n - bias;
     float q = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if ((8 * (r >> 2)) / TPS == s) {
-        const float d = own[r] - mean[s];
-        q += d * d;
+        const float d = own[r] - dm[s];
+        q = fmaf(d, d, q);
       }
     sq[s] = group_allreduce<CPG>(q);
   }
@@ -655,13 +719,12 @@ __device__ __forceinline__ void exchange_gn_mish(const f32x16 (&P)[2], f32x16& o
     for (int s = 0; s < SW; ++s) st2[(wave * SW + s) * 32 + lane] = sq[s];
   }
   __syncthreads();
+  GnCoef cf[SW];
 #pragma unroll
-  for (int s = 0; s < SW; ++s) rstd[s] = rsqrtf((sq[s] + st2[(partner * SW + s) * 32 + (lane & 31)]) * inv_n + 1e-5f);
+  for (int s = 0; s < SW; ++s)
+    cf[s] = gn_coef(dm[s], rsqrtf((sq[s] + st2[(partner * SW + s) * 32 + (lane & 31)]) * inv_n + 1e-5f), gamma, beta);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int s = (8 * (r >> 2)) / TPS;
-    own[r] = MMD_ABL == 1 ? own[r] : mish((own[r] - mean[s]) * rstd[s] * gamma + beta);
-  }
+  for (int r = 0; r < 16; ++r) own[r] = MMD_ABL == 1 ? own[r] : gn_mish1(own[r], cf[(8 * (r >> 2)) / TPS]);
 }
 
 template <class CF, int SKIP_L, int SKIP_WN>
@@ -687,10 +750,11 @@ __device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, in
     return reinterpret_cast<const float*>(w) + ((size_t)(wn * (CP / 2) + kh * (CP / 4)) * 64 + lane) * 6;
   };
   // `ring` must hold the first k-steps of w (wino_ring_load); afterwards it is re-armed with those of `next`
-  auto conv = [&](auto cp_tag, const float* slab, int ss, const float4* w, auto next_tag, const float4* next) {
+  auto conv = [&](auto cp_tag, auto fresh, const float* slab, int ss, const float4* w, auto next_tag, const float4* next) {
     constexpr int CP = decltype(cp_tag)::value;
     const int abase = srow * ss + 2 * tile * (CP + 1) + hi + kh * (CP / 2);
-    if (MMD_ABL != 3) wino_taps<CP / 2, CP + 1>(m, slab, abase, wlane(cp_tag, w), ring);
+    if (MMD_ABL != 3) wino_taps<CP / 2, CP + 1, decltype(fresh)::value>(m, slab, abase, wlane(cp_tag, w), ring);
+    else if (decltype(fresh)::value) zero6(m);
     if (next) wino_ring_load(ring, wlane(next_tag, next));
   };
   using TC0 = std::integral_constant<int, CF::C0P>;
@@ -708,34 +772,32 @@ __device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, in
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
   TR(trb + 0);
-  zero6(m);
   wino_ring_load(ring, wlane(TC0{}, a.r0.wa));
   {
     f32x16 rr[1];
     fill<1>(rr, a.br[col]);
     int rb[1] = {rbase1};
-    conv(TC0{}, xslab, CF::XSS, a.r0.wa, TC1{}, a.wa0_c1);
+    conv(TC0{}, std::true_type{}, xslab, CF::XSS, a.r0.wa, TC1{}, a.wa0_c1);
     if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 1>(rr, xslab, rb, wres0);
     __syncthreads();                                          // chunk 0 has been consumed by every wave
     pair_to_stage<SKIP_L, SKIP_WN, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
     __syncthreads();
-    conv(TC1{}, xslab, CF::XSS, a.wa0_c1, TCM{}, a.r0.wb);
+    conv(TC1{}, std::false_type{}, xslab, CF::XSS, a.wa0_c1, TCM{}, a.r0.wb);
     if (MMD_ABL != 3) mfma_taps<1, CF::C1P, CF::XSTR, 1>(rr, xslab, rb, wres1);
     res = rr[0];
   }
-  wino_out(P, m, kh == 0 ? a.r0.ba[col] : 0.f);
+  wino_out(P, m);
   TR(trb + 1);
   __syncthreads();                                            // every wave is done reading the x slab: it becomes the exchange buffer
-  exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, a.r0.ga[col], a.r0.bea[col]);
+  exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col]);
   own += a.r0.tb[col];
   own_to_h();
   __syncthreads();
   TR(trb + 2);
-  zero6(m);
-  conv(TCM{}, hslab, CF::HSS, a.r0.wb, TCM{}, a.ri[0].wa);
-  wino_out(P, m, kh == 0 ? a.r0.bb[col] : 0.f);
+  conv(TCM{}, std::true_type{}, hslab, CF::HSS, a.r0.wb, TCM{}, a.ri[0].wa);
+  wino_out(P, m);
   TR(trb + 3);
-  exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, a.r0.gb[col], a.r0.beb[col]);   // (its first barrier also frees the H slab)
+  exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col]);   // (its first barrier also frees the H slab)
   own += res;
   TR(trb + 4);
 
@@ -745,19 +807,17 @@ __device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, in
     res = own;
     own_to_h();
     __syncthreads();
-    zero6(m);
-    conv(TCM{}, hslab, CF::HSS, R.wa, TCM{}, R.wb);
-    wino_out(P, m, kh == 0 ? R.ba[col] : 0.f);
+    conv(TCM{}, std::true_type{}, hslab, CF::HSS, R.wa, TCM{}, R.wb);
+    wino_out(P, m);
     TR(trb + 5);
-    exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, R.ga[col], R.bea[col]);
+    exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, R.ba[col], R.ga[col], R.bea[col]);
     own += R.tb[col];
     own_to_h();
     __syncthreads();
-    zero6(m);
-    conv(TCM{}, hslab, CF::HSS, R.wb, TCM{}, static_cast<const float4*>(nullptr));
-    wino_out(P, m, kh == 0 ? R.bb[col] : 0.f);
+    conv(TCM{}, std::true_type{}, hslab, CF::HSS, R.wb, TCM{}, static_cast<const float4*>(nullptr));
+    wino_out(P, m);
     TR(trb + 6);
-    exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, R.gb[col], R.beb[col]);
+    exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, R.bb[col], R.gb[col], R.beb[col]);
     own += res;
   }
 
@@ -875,14 +935,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x16 acc[2];
     {
       f32x16 m[6];
-      zero6(m);
       B6 ring[WINO_RD];
       const float* w0 = reinterpret_cast<const float*>(f.wpk) + lane * 6;
       wino_ring_load(ring, w0);
-      if (MMD_ABL != 3) wino_taps<32, FIN_STR>(m, lds, wave * FIN_SS + 2 * (lane & 31) * FIN_STR + hi, w0, ring);
-      wino_out(acc, m, f.bias[col]);
+      if (MMD_ABL != 3) wino_taps<32, FIN_STR, true>(m, lds, wave * FIN_SS + 2 * (lane & 31) * FIN_STR + hi, w0, ring);
+      else zero6(m);
+      wino_out(acc, m);
     }
-    if (MMD_ABL != 1) gn_mish_pair<32, 64>(acc, f.gamma[col], f.beta[col]);
+    if (MMD_ABL != 1) gn_mish_pair<32, 64>(acc, f.bias[col], f.gamma[col], f.beta[col]);
     __syncthreads();                                                       // every wave is done reading the slab
     float* yt = lds + wave * (64 * 33);
 #pragma unroll

@@ -30,7 +30,7 @@ def _gc():
     return gpu_common
 
 
-@pytest.mark.parametrize("n", [4, 13, 64])
+@pytest.mark.parametrize("n", [1, 4, 13, 64])
 def test_unet_forward_vs_oracle(n):
     model = _gc().hip_model(100)
     sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
@@ -40,6 +40,18 @@ def test_unet_forward_vs_oracle(n):
         out = model.model(x.cuda(), t).cpu()
         assert torch.isfinite(out).all()
         assert rel_l2(out, ref) < 2e-5, (n, t, rel_l2(out, ref))
+
+
+@pytest.mark.parametrize("scale", [1e-3, 8.0])
+def test_unet_forward_input_range(scale):
+    """The k=5 convs run as Winograd F(2,5) in fp32: tiny and large inputs (x_T draws reach |x| ~ 4, the clamp keeps the
+    rest in [-1, 1]) stay at fp32-grade agreement with the direct-convolution oracle."""
+    model = _gc().hip_model(100)
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    x = torch.from_numpy(synth.synth_noise(77, (8, H, D))) * scale
+    ref = O.unet_forward(sd, x, torch.full((8,), 63, dtype=torch.long))
+    out = model.model(x.cuda(), 63).cpu()
+    assert torch.isfinite(out).all() and rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
 
 
 def test_unet_forward_golden():
