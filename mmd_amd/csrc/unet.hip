@@ -653,6 +653,263 @@ __device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// Winograd F(4,5) for the L = 16 level (downs.2 + mid blocks: 55 % of the network's FLOPs): four outputs from eight
+// products instead of twenty (points 0, +-1, +-2, +-1/2, inf).  The four samples give 4 x 4 = 16 output quads, one
+// v_mfma_f32_16x16x4_f32 M tile: a GEMM row is (sample, quad t) = rows 4t .. 4t+3 of a sample.  C/D layout of that
+// instruction: lane = 16 * sample + column, register = quad, so a lane holds ALL 16 positions of one (sample, channel)
+// in 4 outputs x 4 registers, and a GroupNorm group (16 channels at C = 128) is exactly one 16-lane DPP row: the
+// statistics need no LDS and no cross-half shuffles.  A wave owns 32 channels = two 16-column n-tiles x 8 positions =
+// 16 accumulators of 4 registers.  Input transform: 8 ds_read_b32 + 26 VALU per 16 MFMAs (K step = 4 channels), weights
+// packed [wave][k-step][lane][8 positions][2 n-tiles] (fp64-transformed, 64 B per lane and k-step).  fp32 throughout;
+// 1.9e-6 relative against an fp64-accumulated forward (tools/dbg/winograd_accuracy.py).
+// ----------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int W4_KSTRIDE = 64 * 16;    // floats per k-step of one wave's pack
+constexpr int W4_RD = 4;               // weight ring depth in k-steps
+struct B16 { float4 q[4]; };           // q[j] = positions 2j, 2j+1 x n-tiles 0, 1
+
+__device__ __forceinline__ B16 load_b16(const float* __restrict__ p) {
+  B16 b;
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b.q[j] = p4[j];
+  return b;
+}
+__device__ __forceinline__ void w4_ring_load(B16 (&b)[W4_RD], const float* __restrict__ wp) {
+#pragma unroll
+  for (int j = 0; j < W4_RD; ++j) b[j] = load_b16(wp + j * W4_KSTRIDE);
+  MMD_PIN_LOADS();
+}
+template <int STR>
+__device__ __forceinline__ void load_d8(float (&d)[8], const float* s) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = s[j * STR];
+}
+
+// V = B^T d (8 slab rows -> 8 positions), then 16 MFMAs: m[p * 2 + nt] += V_p x U_p[nt]
+template <bool ZERO>
+__device__ __forceinline__ void w4_step(f32x4 (&m)[16], const float (&d)[8], const B16& b) {
+  if constexpr (ZERO) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = z;
+  }
+  float v[8];
+  v[0] = fmaf(5.25f, d[2] - d[4], d[6] - d[0]);
+  v[7] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
+  const float e1 = fmaf(-4.25f, d[4], d[2]) + d[6], o1 = fmaf(-4.25f, d[3], d[1]) + d[5];
+  v[1] = e1 + o1; v[2] = e1 - o1;
+  const float e2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), o2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
+  v[3] = e2 + o2; v[4] = e2 - o2;
+  const float e3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), o3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
+  v[5] = e3 + o3; v[6] = e3 - o3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    m[4 * j + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j], b.q[j].x, m[4 * j + 0], 0, 0, 0);
+    m[4 * j + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j], b.q[j].y, m[4 * j + 1], 0, 0, 0);
+    m[4 * j + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j + 1], b.q[j].z, m[4 * j + 2], 0, 0, 0);
+    m[4 * j + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j + 1], b.q[j].w, m[4 * j + 3], 0, 0, 0);
+  }
+}
+
+// m += conv over CP channels of a slab; abase = lane's offset of (sample, slab row 4 * quad, channel lane >> 4);
+// b = ring pre-loaded with k-steps 0..3 of wp
+template <int CP, int STR, bool FRESH>
+__device__ __forceinline__ void w4_taps(f32x4 (&m)[16], const float* slab, int abase, const float* __restrict__ wp,
+                                        B16 (&b)[W4_RD]) {
+  constexpr int KS = CP / 4, RD = W4_RD;
+  static_assert(KS % RD == 0, "k-steps are unrolled by the ring depth");
+  const float* p = wp;
+  const float* s = slab + abase;
+  float d[2][8];
+  load_d8<STR>(d[0], s);
+  auto iter = [&](auto first) {
+    p += RD * W4_KSTRIDE;
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+      load_d8<STR>(d[(j + 1) & 1], s + 4 * (j + 1));   // (past the last k-step this reads the next slab row and is unused)
+      MMD_PIN_LOADS();
+      if (decltype(first)::value && j == 0) w4_step<true>(m, d[0], b[0]);
+      else w4_step<false>(m, d[j & 1], b[j]);
+      b[j] = load_b16(p + j * W4_KSTRIDE);
+      MMD_PIN_LOADS();
+    }
+    s += 4 * RD;
+  };
+  if constexpr (FRESH) {
+    iter(std::true_type{});
+#pragma unroll 1
+    for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
+  } else {
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += RD) iter(std::false_type{});
+  }
+}
+
+// Y = A^T M: q[o * 2 + nt] = outputs 4t + o of n-tile nt (register = quad t)
+__device__ __forceinline__ void w4_out(f32x4 (&q)[8], const f32x4 (&m)[16]) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const f32x4 s1 = m[2 + nt] + m[4 + nt], t1 = m[2 + nt] - m[4 + nt];
+    const f32x4 s2 = m[6 + nt] + m[8 + nt], t2 = m[6 + nt] - m[8 + nt];
+    const f32x4 s3 = m[10 + nt] + m[12 + nt], t3 = m[10 + nt] - m[12 + nt];
+    q[0 + nt] = (m[0 + nt] + s1) + (s2 + s3);
+    q[2 + nt] = t1 + 2.f * t2 + 0.5f * t3;
+    q[4 + nt] = s1 + 4.f * s2 + 0.25f * s3;
+    q[6 + nt] = (t1 + m[14 + nt]) + (8.f * t2 + 0.125f * t3);
+  }
+}
+
+// GroupNorm (16 channels = one DPP row) + Mish on a quad tile x + bias; b/g/be = bias, gamma, beta of the lane's channel
+// in n-tile 0 / 1
+__device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[2], const float (&gamma)[2],
+                                             const float (&beta)[2]) {
+  constexpr float inv_n = 1.f / 256.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    float sum = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += q[o * 2 + nt][r];
+    const float dm = (group_colsum<16>(sum) + group_colsum<16>(bias[nt]) * 16.f) * inv_n - bias[nt];
+    float sq = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = q[o * 2 + nt][r] - dm;
+        sq = fmaf(d, d, sq);
+      }
+    const GnCoef cf = gn_coef(dm, rsqrtf(group_colsum<16>(sq) * inv_n + 1e-5f), gamma[nt], beta[nt]);
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[o * 2 + nt][r] = gn_mish1(q[o * 2 + nt][r], cf);
+  }
+}
+
+// quad tile -> slab rows 4t + o (+2 halo) of a stage laid out [sample][row][DSTR]
+template <int DSS, int DSTR>
+__device__ __forceinline__ void quad_to_stage(const f32x4 (&q)[8], float* dst, int wave, int lane) {
+  float* base = dst + (lane >> 4) * DSS + 2 * DSTR + wave * 32 + (lane & 15);
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR + nt * 16] = q[o * 2 + nt][r];
+}
+
+// downs.2 + mid_block1/2 at L = 16, C = 128 in F(4,5) form.  Same slabs as the other stages; activations in registers as quad tiles.
+template <class CF>
+__device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[8],
+                                              f32x4 (&mid)[8], int trb) {
+  static_assert(CF::L == 16 && CF::CM == 128 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_NONE, "L = 16 level");
+  float* hslab = lds + CF::XSLAB;
+  float* xslab = lds;
+  const int as = (lane & 15) >> 2, at = lane & 3, ak = lane >> 4;       // A fragment: row = (sample, quad), k
+  const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
+  const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
+  const int col0 = wave * 32 + (lane & 15), col1 = col0 + 16;           // C/D fragment: this lane's channels
+  B16 ring[W4_RD];
+  auto wlane = [&](const float4* w, int cp) {
+    return reinterpret_cast<const float*>(w) + (size_t)wave * (cp / 4) * W4_KSTRIDE + lane * 16;
+  };
+  w4_ring_load(ring, wlane(a.r0.wa, CF::C0P));
+  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
+  __syncthreads();
+  TR(trb + 0);
+
+  f32x4 m[16], res[8];
+  auto conv_h = [&](const float4* w, const float4* next) {
+    if (MMD_ABL != 3) w4_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w, CF::CM), ring);
+    if (next) w4_ring_load(ring, wlane(next, CF::CM));
+    w4_out(acc, m);
+  };
+  auto gn = [&](const float* b, const float* g, const float* be) {
+    const float bb[2] = {b[col0], b[col1]}, gg[2] = {g[col0], g[col1]}, ee[2] = {be[col0], be[col1]};
+    if (MMD_ABL != 1) gn_mish_quad(acc, bb, gg, ee);
+  };
+  auto add_cols = [&](const float* v) {
+    const float v0 = v[col0], v1 = v[col1];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { acc[o * 2] += v0; acc[o * 2 + 1] += v1; }
+  };
+
+  // =================== RTB 0 (64 -> 128, 1x1 residual conv) ===================
+  if (MMD_ABL != 3) w4_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, wlane(a.r0.wa, CF::C0P), ring);
+  w4_ring_load(ring, wlane(a.r0.wb, CF::CM));
+  w4_out(acc, m);
+  {
+    // res[o * 2 + nt] = x (rows 4t + o) * Wr: 16 k-steps of 4 channels, pack [wave][k-step][lane][2 n-tiles]
+    const float2* wr = reinterpret_cast<const float2*>(a.wr_c0) + (size_t)wave * (CF::C0P / 4) * 64 + lane;
+    const float br0 = a.br[col0], br1 = a.br[col1];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      res[o * 2] = f32x4{br0, br0, br0, br0};
+      res[o * 2 + 1] = f32x4{br1, br1, br1, br1};
+    }
+    const float* xr = xslab + xbase + 2 * CF::XSTR;
+#pragma unroll 2
+    for (int ks = 0; ks < CF::C0P / 4; ++ks) {
+      const float2 b = wr[ks * 64];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const float av = xr[o * CF::XSTR + 4 * ks];
+        res[o * 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.x, res[o * 2], 0, 0, 0);
+        res[o * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.y, res[o * 2 + 1], 0, 0, 0);
+      }
+    }
+  }
+  TR(trb + 2);
+  gn(a.r0.ba, a.r0.ga, a.r0.bea);
+  add_cols(a.r0.tb);
+  quad_to_stage<CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+  __syncthreads();
+  TR(trb + 4);
+  conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
+  TR(trb + 5);
+  gn(a.r0.bb, a.r0.gb, a.r0.beb);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] += res[i];
+  if constexpr (CF::MID_AFTER == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mid[i] = acc[i];
+  }
+
+  // =================== identity RTBs ===================
+#pragma unroll
+  for (int k = 0; k < CF::N_IDENT; ++k) {
+    const RtbPtrs& R = a.ri[k];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) res[i] = acc[i];
+    __syncthreads();                                         // the previous conv is done reading the H slab
+    TR(trb + 8 + k * 8 + 0);
+    quad_to_stage<CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    __syncthreads();
+    TR(trb + 8 + k * 8 + 1);
+    conv_h(R.wa, R.wb);
+    TR(trb + 8 + k * 8 + 2);
+    gn(R.ba, R.ga, R.bea);
+    add_cols(R.tb);
+    __syncthreads();
+    quad_to_stage<CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    __syncthreads();
+    TR(trb + 8 + k * 8 + 5);
+    conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
+    TR(trb + 8 + k * 8 + 6);
+    gn(R.bb, R.gb, R.beb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += res[i];
+    if (CF::MID_AFTER == k + 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mid[i] = acc[i];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Up-path stage in Winograd form.  C_out is 64 / 32 here, so the four samples give only two (M, N) tiles per position:
 // the four waves are two PAIRS, and the waves of a pair split the input channels (K) of every conv between them.  Each
 // computes all six positions over its K half, applies the output transform to its partial sums, hands the output-row
@@ -727,9 +984,9 @@ __device__ __forceinline__ void exchange_gn_mish(const f32x16 (&P)[2], f32x16& o
   for (int r = 0; r < 16; ++r) own[r] = MMD_ABL == 1 ? own[r] : gn_mish1(own[r], cf[(8 * (r >> 2)) / TPS]);
 }
 
-template <class CF, int SKIP_L, int SKIP_WN>
+template <class CF, int SKIP_L, int SKIP_WN, bool SKIP_QUAD, class SKIP_T>
 __device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, int n0, int lane, int wave,
-                                              const f32x16 (&skip)[2], f32x16 (&tout)[2][CF::MT_W], int trb) {
+                                              const SKIP_T& skip, f32x16 (&tout)[2][CF::MT_W], int trb) {
   static_assert(!CF::SHARE && CF::C1 == CF::C0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "up-path stage");
   float* hslab = lds + CF::XSLAB;
   float* xslab = lds;
@@ -780,7 +1037,8 @@ __device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, in
     conv(TC0{}, std::true_type{}, xslab, CF::XSS, a.r0.wa, TC1{}, a.wa0_c1);
     if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 1>(rr, xslab, rb, wres0);
     __syncthreads();                                          // chunk 0 has been consumed by every wave
-    pair_to_stage<SKIP_L, SKIP_WN, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
+    if constexpr (SKIP_QUAD) quad_to_stage<CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
+    else pair_to_stage<SKIP_L, SKIP_WN, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
     __syncthreads();
     conv(TC1{}, std::false_type{}, xslab, CF::XSS, a.wa0_c1, TCM{}, a.r0.wb);
     if (MMD_ABL != 3) mfma_taps<1, CF::C1P, CF::XSTR, 1>(rr, xslab, rb, wres1);
@@ -881,7 +1139,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * 4;
 
-  f32x16 skip1[2], skip2[2];
+  f32x16 skip1[2];
+  f32x4 skip2[8];
   // ---- downs.0 @ L=64 -> [4][32][32]
   {
     f32x16 acc[2], mid[2], t[1];
@@ -900,17 +1159,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2
   {
-    f32x16 acc[2], t[1];
-    chain_body_w<CH_D2, false>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
+    f32x4 acc[8];
+    chain_body_w4<CH_D2>(a.c[2], lds, n0, lane, wave, acc, skip2, 80);
     __syncthreads();
-    pair_to_stage<CH_D2::L, CH_D2::WN, CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane);
+    quad_to_stage<CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane);
     zero_halo<CH_U0::C0P, CH_U0::L, CH_U0::SROWS, CH_U0::XSTR, CH_U0::XSS, 4>(lds);
   }
   TR(130);
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
   {
     f32x16 t[2][1];
-    chain_body_wu<CH_U0, CH_D2::L, CH_D2::WN>(a.c[3], lds, n0, lane, wave, skip2, t, 136);
+    chain_body_wu<CH_U0, CH_D2::L, CH_D2::WN, true>(a.c[3], lds, n0, lane, wave, skip2, t, 136);
     __syncthreads();
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
@@ -920,7 +1179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
   {
     f32x16 t[2][1];
-    chain_body_wu<CH_U1, CH_D1::L, CH_D1::WN>(a.c[4], lds, n0, lane, wave, skip1, t, 146);
+    chain_body_wu<CH_U1, CH_D1::L, CH_D1::WN, false>(a.c[4], lds, n0, lane, wave, skip1, t, 146);
     __syncthreads();
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
@@ -1147,6 +1406,50 @@ static void pack_w(std::vector<float>& blob, const float* w, int cout, int cin_f
   while (blob.size() % 4) blob.push_back(0.f);
 }
 
+// Winograd F(4,5) weight transform (points 0, +-1, +-2, +-1/2, inf) in fp64, packed for w4_taps:
+//   out[((wv*KS + ks)*64 + lane)*16 + p*2 + nt] = U_p(c = 4*ks + (lane>>4), n = wv*32 + nt*16 + (lane&15)),  KS = cin/4
+// followed by 8 zero k-steps (register-ring over-read).  conv weight layout [cout][cin][5].
+static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin) {
+  static const double G[8][5] = {{-1, 0, 0, 0, 0},
+                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                 {0, 0, 0, 0, 1}};
+  const int nw = cout / 32, KS = cin / 4;
+  const size_t base = blob.size();
+  blob.resize(base + ((size_t)nw * KS + 8) * 64 * 16, 0.f);
+  for (int wv = 0; wv < nw; ++wv)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int nt = 0; nt < 2; ++nt) {
+          const int ci = 4 * ks + (lane >> 4), n = wv * 32 + nt * 16 + (lane & 15);
+          const float* g = w + ((size_t)n * cin + ci) * 5;
+          for (int p = 0; p < 8; ++p) {
+            double u = 0.0;
+            for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
+            blob[base + (((size_t)wv * KS + ks) * 64 + lane) * 16 + p * 2 + nt] = (float)u;
+          }
+        }
+}
+
+// 1x1 conv for the 16x16x4 MFMA: out[((wv*KS + ks)*64 + lane)*2 + nt] = W(c = 4*ks + (lane>>4), n = wv*32 + nt*16 + (lane&15))
+static void pack_b4_1x1(std::vector<float>& blob, const float* w, int cout, int cin) {
+  const int nw = cout / 32, KS = cin / 4;
+  const size_t base = blob.size();
+  blob.resize(base + (size_t)nw * KS * 64 * 2, 0.f);
+  for (int wv = 0; wv < nw; ++wv)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int nt = 0; nt < 2; ++nt) {
+          const int ci = 4 * ks + (lane >> 4), n = wv * 32 + nt * 16 + (lane & 15);
+          blob[base + (((size_t)wv * KS + ks) * 64 + lane) * 2 + nt] = w[(size_t)n * cin + ci];
+        }
+  while (blob.size() % 4) blob.push_back(0.f);
+}
+
 struct ConvW { size_t wpk, bias, gamma, beta; };
 struct RtbW { ConvW a, b; size_t res_wpk, res_bias; int tb_off; size_t a_c1, res_c0, res_c1; };
 
@@ -1248,14 +1551,14 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     while (blob.size() % 4) blob.push_back(0.f);
-    const bool wino = true;               // every stride-1 k=5 conv runs in Winograd form
+    const bool w4 = r == 4 || r == 5 || r >= 10;   // L = 16 level (downs.2, mid blocks): F(4,5) packs; the rest: F(2,5)
     W.a.wpk = blob.size();
-    if (wino) pack_w(blob, tensors[R.t_w0], R.cout, R.cin); else pack_b(blob, tensors[R.t_w0], R.cout, R.cin, 5, taps5, false);
+    if (w4) pack_w4(blob, tensors[R.t_w0], R.cout, R.cin); else pack_w(blob, tensors[R.t_w0], R.cout, R.cin);
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
     W.b.wpk = blob.size();
-    if (wino) pack_w(blob, tensors[R.t_w1], R.cout, R.cout); else pack_b(blob, tensors[R.t_w1], R.cout, R.cout, 5, taps5, false);
+    if (w4) pack_w4(blob, tensors[R.t_w1], R.cout, R.cout); else pack_w(blob, tensors[R.t_w1], R.cout, R.cout);
     W.b.bias = push(blob, tensors[R.t_b1], R.cout);
     W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
     W.b.beta = push(blob, tensors[R.t_be1], R.cout);
@@ -1263,7 +1566,8 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     raw_cb[r] = push(blob, tensors[R.t_cb], R.cout);
     W.res_wpk = W.res_bias = 0;
     if (R.res) {
-      W.res_wpk = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false);
+      W.res_wpk = blob.size();
+      if (w4) pack_b4_1x1(blob, tensors[R.t_rw], R.cout, R.cin); else pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false);
       W.res_bias = push(blob, tensors[R.t_rb], R.cout);
     }
     W.a_c1 = W.res_c0 = W.res_c1 = 0;
@@ -1355,13 +1659,14 @@ static const double kLayerFlops[kNumLayers] = {
 
 // MFMA FLOPs actually issued per trajectory (Winograd convs: 6 products per output pair; channel / N padding included)
 static constexpr double wino_flops(double cinp, double cout, double L) { return (cinp / 2) * 6 * (cout / 32) * (L / 16) * 4096.0 / 4; }
+static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // F(4,5), L = 16
 static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
 }
 static const double kLayerMfmaFlops[kNumLayers] = {
     wino_flops(8, 32, 64) + direct_flops(1, 8, 32, 64) + 3 * wino_flops(32, 32, 64) + direct_flops(3, 32, 32, 32) +
     wino_flops(32, 64, 32) + direct_flops(1, 32, 64, 32) + 3 * wino_flops(64, 64, 32) + direct_flops(3, 64, 64, 16) +
-    wino_flops(64, 128, 16) + direct_flops(1, 64, 128, 16) + 7 * wino_flops(128, 128, 16) +
+    wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) + 7 * wino4_flops(128, 128) +
     wino_flops(256, 64, 16) + direct_flops(1, 256, 64, 16) + 3 * wino_flops(64, 64, 16) + 2 * direct_flops(2, 64, 64, 16) +
     wino_flops(128, 32, 32) + direct_flops(1, 128, 32, 32) + 3 * wino_flops(32, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
     wino_flops(32, 32, 64) + direct_flops(1, 32, 32, 64)};
