@@ -760,11 +760,20 @@ __device__ __forceinline__ void w4_out(f32x4 (&q)[8], const f32x4 (&m)[16]) {
   }
 }
 
-// GroupNorm (16 channels = one DPP row) + Mish on a quad tile x + bias; b/g/be = bias, gamma, beta of the lane's channel
-// in n-tile 0 / 1
+// GroupNorm + Mish on a quad tile x + bias; b/g/be = bias, gamma, beta of the lane's channel in n-tile 0 / 1.  A group is
+// CPG adjacent lanes (channels) of a 16-lane DPP row x all L positions: the lane's own 16, and for L = 32 the 16 of the
+// lane 16 further (QB = 2 row blocks per sample).
+template <int CPG, int QB>
+__device__ __forceinline__ float quad_groupsum(float v) {
+  v = group_colsum<CPG>(v);
+  if constexpr (QB == 2) v += __shfl_xor(v, 16);
+  return v;
+}
+template <int CM, int L>
 __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[2], const float (&gamma)[2],
                                              const float (&beta)[2]) {
-  constexpr float inv_n = 1.f / 256.f;
+  constexpr int CPG = CM / 8, QB = L / 16;
+  constexpr float inv_n = 1.f / (float)(L * CPG);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     float sum = 0.f;
@@ -772,7 +781,7 @@ __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[
     for (int o = 0; o < 4; ++o)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sum += q[o * 2 + nt][r];
-    const float dm = (group_colsum<16>(sum) + group_colsum<16>(bias[nt]) * 16.f) * inv_n - bias[nt];
+    const float dm = (quad_groupsum<CPG, QB>(sum) + group_colsum<CPG>(bias[nt]) * (float)L) * inv_n - bias[nt];
     float sq = 0.f;
 #pragma unroll
     for (int o = 0; o < 4; ++o)
@@ -781,7 +790,7 @@ __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[
         const float d = q[o * 2 + nt][r] - dm;
         sq = fmaf(d, d, sq);
       }
-    const GnCoef cf = gn_coef(dm, rsqrtf(group_colsum<16>(sq) * inv_n + 1e-5f), gamma[nt], beta[nt]);
+    const GnCoef cf = gn_coef(dm, rsqrtf(quad_groupsum<CPG, QB>(sq) * inv_n + 1e-5f), gamma[nt], beta[nt]);
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -789,10 +798,14 @@ __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[
   }
 }
 
-// quad tile -> slab rows 4t + o (+2 halo) of a stage laid out [sample][row][DSTR]
-template <int DSS, int DSTR>
+// quad tile of a level of length L with CM channels -> slab rows 4t + o (+2 halo) of a stage laid out [sample][row][DSTR].
+// Producer tiling: wave = (M tile, 32-channel slice); lane >> 4 = (sample within the M tile, 16-row block)
+template <int L, int CM, int DSS, int DSTR>
 __device__ __forceinline__ void quad_to_stage(const f32x4 (&q)[8], float* dst, int wave, int lane) {
-  float* base = dst + (lane >> 4) * DSS + 2 * DSTR + wave * 32 + (lane & 15);
+  constexpr int QB = L / 16, SPT = 4 / QB, WN = CM / 32;        // row blocks per sample, samples per M tile, channel waves
+  const int mt = wave / WN, wn = wave % WN;
+  const int smp = mt * SPT + (lane >> 4) / QB, qb = (lane >> 4) % QB;
+  float* base = dst + smp * DSS + (16 * qb + 2) * DSTR + wn * 32 + (lane & 15);
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -801,20 +814,27 @@ __device__ __forceinline__ void quad_to_stage(const f32x4 (&q)[8], float* dst, i
       for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR + nt * 16] = q[o * 2 + nt][r];
 }
 
-// downs.2 + mid_block1/2 at L = 16, C = 128 in F(4,5) form.  Same slabs as the other stages; activations in registers as quad tiles.
+// A down-path stage (L = 32 / C = 64: downs.1; L = 16 / C = 128: downs.2 + mid blocks) in F(4,5) form.  Same slabs as
+// the other stages; activations in registers as quad tiles.  The 4 * L / 4 output quads are L / 16 M tiles of 16 rows; a
+// wave owns one M tile x 32 channels (two n-tiles).
 template <class CF>
 __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[8],
-                                              f32x4 (&mid)[8], int trb) {
-  static_assert(CF::L == 16 && CF::CM == 128 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_NONE, "L = 16 level");
+                                              f32x4 (&mid)[8], f32x16 (&tout)[1], int trb) {
+  static_assert((CF::L == 16 || CF::L == 32) && CF::CM * CF::L == 2048 && CF::C1 == 0 && CF::RES0 == RES_CONV &&
+                    CF::TAIL != TAIL_UP, "down-path stage with 4 waves = (L / 16 M tiles) x (CM / 32 channel slices)");
   float* hslab = lds + CF::XSLAB;
   float* xslab = lds;
-  const int as = (lane & 15) >> 2, at = lane & 3, ak = lane >> 4;       // A fragment: row = (sample, quad), k
+  constexpr int QPS = CF::L / 4, WNQ = CF::CM / 32;                     // quads per sample, channel slices
+  const int mt = wave / WNQ, wnq = wave % WNQ;
+  // A fragment: row i = lane & 15 of M tile mt = (sample, quad), k = lane >> 4
+  const int ai = mt * 16 + (lane & 15);
+  const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
   const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
   const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
-  const int col0 = wave * 32 + (lane & 15), col1 = col0 + 16;           // C/D fragment: this lane's channels
+  const int col0 = wnq * 32 + (lane & 15), col1 = col0 + 16;            // C/D fragment: this lane's channels
   B16 ring[W4_RD];
   auto wlane = [&](const float4* w, int cp) {
-    return reinterpret_cast<const float*>(w) + (size_t)wave * (cp / 4) * W4_KSTRIDE + lane * 16;
+    return reinterpret_cast<const float*>(w) + (size_t)wnq * (cp / 4) * W4_KSTRIDE + lane * 16;
   };
   w4_ring_load(ring, wlane(a.r0.wa, CF::C0P));
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
@@ -829,7 +849,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   };
   auto gn = [&](const float* b, const float* g, const float* be) {
     const float bb[2] = {b[col0], b[col1]}, gg[2] = {g[col0], g[col1]}, ee[2] = {be[col0], be[col1]};
-    if (MMD_ABL != 1) gn_mish_quad(acc, bb, gg, ee);
+    if (MMD_ABL != 1) gn_mish_quad<CF::CM, CF::L>(acc, bb, gg, ee);
   };
   auto add_cols = [&](const float* v) {
     const float v0 = v[col0], v1 = v[col1];
@@ -843,7 +863,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   w4_out(acc, m);
   {
     // res[o * 2 + nt] = x (rows 4t + o) * Wr: 16 k-steps of 4 channels, pack [wave][k-step][lane][2 n-tiles]
-    const float2* wr = reinterpret_cast<const float2*>(a.wr_c0) + (size_t)wave * (CF::C0P / 4) * 64 + lane;
+    const float2* wr = reinterpret_cast<const float2*>(a.wr_c0) + (size_t)wnq * (CF::C0P / 4) * 64 + lane;
     const float br0 = a.br[col0], br1 = a.br[col1];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -865,7 +885,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   TR(trb + 2);
   gn(a.r0.ba, a.r0.ga, a.r0.bea);
   add_cols(a.r0.tb);
-  quad_to_stage<CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+  quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
   __syncthreads();
   TR(trb + 4);
   conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
@@ -886,7 +906,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     for (int i = 0; i < 8; ++i) res[i] = acc[i];
     __syncthreads();                                         // the previous conv is done reading the H slab
     TR(trb + 8 + k * 8 + 0);
-    quad_to_stage<CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
     __syncthreads();
     TR(trb + 8 + k * 8 + 1);
     conv_h(R.wa, R.wb);
@@ -894,7 +914,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     gn(R.ba, R.ga, R.bea);
     add_cols(R.tb);
     __syncthreads();
-    quad_to_stage<CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
     __syncthreads();
     TR(trb + 8 + k * 8 + 5);
     conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
@@ -906,6 +926,19 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
 #pragma unroll
       for (int i = 0; i < 8; ++i) mid[i] = acc[i];
     }
+  }
+
+  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct (32x32x2 tiles as in chain_body_w) ===================
+  if constexpr (CF::TAIL == TAIL_DOWN) {
+    __syncthreads();
+    quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    __syncthreads();
+    constexpr int LO = CF::L / 2;
+    const int wm = wave / CF::WN, wn = wave % CF::WN, hi = lane >> 5;
+    fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
+    const int r = lane & 31;
+    int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
+    if (MMD_ABL != 3) mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
   }
 }
 
@@ -1037,7 +1070,7 @@ __device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, in
     conv(TC0{}, std::true_type{}, xslab, CF::XSS, a.r0.wa, TC1{}, a.wa0_c1);
     if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 1>(rr, xslab, rb, wres0);
     __syncthreads();                                          // chunk 0 has been consumed by every wave
-    if constexpr (SKIP_QUAD) quad_to_stage<CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
+    if constexpr (SKIP_QUAD) quad_to_stage<SKIP_L, SKIP_WN * 32, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
     else pair_to_stage<SKIP_L, SKIP_WN, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
     __syncthreads();
     conv(TC1{}, std::false_type{}, xslab, CF::XSS, a.wa0_c1, TCM{}, a.r0.wb);
@@ -1139,8 +1172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * 4;
 
-  f32x16 skip1[2];
-  f32x4 skip2[8];
+  f32x4 skip1[8], skip2[8];
   // ---- downs.0 @ L=64 -> [4][32][32]
   {
     f32x16 acc[2], mid[2], t[1];
@@ -1151,8 +1183,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // ---- downs.1 @ L=32 -> [4][16][64], skip1
   {
-    f32x16 acc[2], t[1];
-    chain_body_w<CH_D1, false>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
+    f32x4 acc[8];
+    f32x16 t[1];
+    chain_body_w4<CH_D1>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
     __syncthreads();
     tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
@@ -1160,9 +1193,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2
   {
     f32x4 acc[8];
-    chain_body_w4<CH_D2>(a.c[2], lds, n0, lane, wave, acc, skip2, 80);
+    f32x16 t[1];
+    chain_body_w4<CH_D2>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
     __syncthreads();
-    quad_to_stage<CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane);
+    quad_to_stage<CH_D2::L, CH_D2::CM, CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane);
     zero_halo<CH_U0::C0P, CH_U0::L, CH_U0::SROWS, CH_U0::XSTR, CH_U0::XSS, 4>(lds);
   }
   TR(130);
@@ -1179,7 +1213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
   {
     f32x16 t[2][1];
-    chain_body_wu<CH_U1, CH_D1::L, CH_D1::WN, false>(a.c[4], lds, n0, lane, wave, skip1, t, 146);
+    chain_body_wu<CH_U1, CH_D1::L, CH_D1::WN, true>(a.c[4], lds, n0, lane, wave, skip1, t, 146);
     __syncthreads();
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
@@ -1551,7 +1585,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     while (blob.size() % 4) blob.push_back(0.f);
-    const bool w4 = r == 4 || r == 5 || r >= 10;   // L = 16 level (downs.2, mid blocks): F(4,5) packs; the rest: F(2,5)
+    const bool w4 = (r >= 2 && r <= 5) || r >= 10;   // downs.1, downs.2, mid blocks: F(4,5) packs; the rest: F(2,5)
     W.a.wpk = blob.size();
     if (w4) pack_w4(blob, tensors[R.t_w0], R.cout, R.cin); else pack_w(blob, tensors[R.t_w0], R.cout, R.cin);
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
@@ -1665,7 +1699,7 @@ static constexpr double direct_flops(double taps, double cinp, double coutp, dou
 }
 static const double kLayerMfmaFlops[kNumLayers] = {
     wino_flops(8, 32, 64) + direct_flops(1, 8, 32, 64) + 3 * wino_flops(32, 32, 64) + direct_flops(3, 32, 32, 32) +
-    wino_flops(32, 64, 32) + direct_flops(1, 32, 64, 32) + 3 * wino_flops(64, 64, 32) + direct_flops(3, 64, 64, 16) +
+    2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) + direct_flops(3, 64, 64, 16) +
     wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) + 7 * wino4_flops(128, 128) +
     wino_flops(256, 64, 16) + direct_flops(1, 256, 64, 16) + 3 * wino_flops(64, 64, 16) + 2 * direct_flops(2, 64, 64, 16) +
     wino_flops(128, 32, 32) + direct_flops(1, 128, 32, 32) + 3 * wino_flops(32, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
