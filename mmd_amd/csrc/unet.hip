@@ -686,6 +686,16 @@ __device__ __forceinline__ void load_d8(float (&d)[8], const float* s) {
   for (int j = 0; j < 8; ++j) d[j] = s[j * STR];
 }
 
+__device__ __forceinline__ void w4_transform(float (&v)[8], const float (&d)[8]) {
+  v[0] = fmaf(5.25f, d[2] - d[4], d[6] - d[0]);
+  v[7] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
+  const float e1 = fmaf(-4.25f, d[4], d[2]) + d[6], o1 = fmaf(-4.25f, d[3], d[1]) + d[5];
+  v[1] = e1 + o1; v[2] = e1 - o1;
+  const float e2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), o2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
+  v[3] = e2 + o2; v[4] = e2 - o2;
+  const float e3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), o3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
+  v[5] = e3 + o3; v[6] = e3 - o3;
+}
 // V = B^T d (8 slab rows -> 8 positions), then 16 MFMAs: m[p * 2 + nt] += V_p x U_p[nt]
 template <bool ZERO>
 __device__ __forceinline__ void w4_step(f32x4 (&m)[16], const float (&d)[8], const B16& b) {
@@ -695,14 +705,7 @@ __device__ __forceinline__ void w4_step(f32x4 (&m)[16], const float (&d)[8], con
     for (int i = 0; i < 16; ++i) m[i] = z;
   }
   float v[8];
-  v[0] = fmaf(5.25f, d[2] - d[4], d[6] - d[0]);
-  v[7] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
-  const float e1 = fmaf(-4.25f, d[4], d[2]) + d[6], o1 = fmaf(-4.25f, d[3], d[1]) + d[5];
-  v[1] = e1 + o1; v[2] = e1 - o1;
-  const float e2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), o2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
-  v[3] = e2 + o2; v[4] = e2 - o2;
-  const float e3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), o3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
-  v[5] = e3 + o3; v[6] = e3 - o3;
+  w4_transform(v, d);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     m[4 * j + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j], b.q[j].x, m[4 * j + 0], 0, 0, 0);
@@ -943,187 +946,230 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Up-path stage in Winograd form.  C_out is 64 / 32 here, so the four samples give only two (M, N) tiles per position:
-// the four waves are two PAIRS, and the waves of a pair split the input channels (K) of every conv between them.  Each
-// computes all six positions over its K half, applies the output transform to its partial sums, hands the output-row
-// parity it does not own (kh = 0 keeps rows 2t, kh = 1 rows 2t + 1) to its partner through LDS together with its
-// partial GroupNorm sums, and runs GroupNorm + Mish on its own 16 values per lane: 0.6x the MFMAs of the direct form
-// and half the epilogue VALU work per wave, for two extra barriers per conv.  The exchange buffer lives in the x slab
-// (free once conv A of the first RTB has consumed it).
+// Up-path stage (ups.0: L = 16 / C = 64, ups.1: L = 32 / C = 32) in F(4,5) form.  C_out is small here: the L / 16 M tiles
+// x C / 16 n-tiles are exactly four (M, N) units, one per wave (8 accumulators), so every wave runs the whole K of its
+// unit and nothing is exchanged between waves.  The input is the channel concat cat(x, skip): chunk 0 arrives in the x
+// slab from the previous stage, chunk 1 is the quad tile kept from the down path and is staged into the same slab.
 // ----------------------------------------------------------------------------------------------------------------
+constexpr int W4N1_KSTRIDE = 64 * 8;
+struct B8 { float4 q[2]; };            // positions 0..3, 4..7 of the wave's n-tile
+__device__ __forceinline__ B8 load_b8(const float* __restrict__ p) {
+  B8 b;
+  b.q[0] = reinterpret_cast<const float4*>(p)[0];
+  b.q[1] = reinterpret_cast<const float4*>(p)[1];
+  return b;
+}
+__device__ __forceinline__ void w4n1_ring_load(B8 (&b)[W4_RD], const float* __restrict__ wp) {
+#pragma unroll
+  for (int j = 0; j < W4_RD; ++j) b[j] = load_b8(wp + j * W4N1_KSTRIDE);
+  MMD_PIN_LOADS();
+}
+template <bool ZERO>
+__device__ __forceinline__ void w4n1_step(f32x4 (&m)[8], const float (&d)[8], const B8& b) {
+  if constexpr (ZERO) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = z;
+  }
+  float v[8];
+  w4_transform(v, d);
+  const float bb[8] = {b.q[0].x, b.q[0].y, b.q[0].z, b.q[0].w, b.q[1].x, b.q[1].y, b.q[1].z, b.q[1].w};
+#pragma unroll
+  for (int p = 0; p < 8; ++p) m[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], bb[p], m[p], 0, 0, 0);
+}
+template <int CP, int STR, bool FRESH>
+__device__ __forceinline__ void w4n1_taps(f32x4 (&m)[8], const float* slab, int abase, const float* __restrict__ wp,
+                                          B8 (&b)[W4_RD]) {
+  constexpr int KS = CP / 4, RD = W4_RD;
+  static_assert(KS % RD == 0, "k-steps are unrolled by the ring depth");
+  const float* p = wp;
+  const float* s = slab + abase;
+  float d[2][8];
+  load_d8<STR>(d[0], s);
+  auto iter = [&](auto first) {
+    p += RD * W4N1_KSTRIDE;
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+      load_d8<STR>(d[(j + 1) & 1], s + 4 * (j + 1));
+      MMD_PIN_LOADS();
+      if (decltype(first)::value && j == 0) w4n1_step<true>(m, d[0], b[0]);
+      else w4n1_step<false>(m, d[j & 1], b[j]);
+      b[j] = load_b8(p + j * W4N1_KSTRIDE);
+      MMD_PIN_LOADS();
+    }
+    s += 4 * RD;
+  };
+  if constexpr (FRESH) {
+    iter(std::true_type{});
+#pragma unroll 1
+    for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
+  } else {
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += RD) iter(std::false_type{});
+  }
+}
+__device__ __forceinline__ void w4n1_out(f32x4 (&q)[4], const f32x4 (&m)[8]) {
+  const f32x4 s1 = m[1] + m[2], t1 = m[1] - m[2];
+  const f32x4 s2 = m[3] + m[4], t2 = m[3] - m[4];
+  const f32x4 s3 = m[5] + m[6], t3 = m[5] - m[6];
+  q[0] = (m[0] + s1) + (s2 + s3);
+  q[1] = t1 + 2.f * t2 + 0.5f * t3;
+  q[2] = s1 + 4.f * s2 + 0.25f * s3;
+  q[3] = (t1 + m[7]) + (8.f * t2 + 0.125f * t3);
+}
 template <int CM, int L>
-__device__ __forceinline__ void exchange_gn_mish(const f32x16 (&P)[2], f32x16& own, float* exch, int wave, int lane,
-                                                 float bias, float gamma, float beta) {
-  constexpr int CPG = CM / 8, TPS = L / 2, SW = 32 / TPS;     // channels per group, pair rows per sample, samples per tile
+__device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float gamma, float beta) {
+  constexpr int CPG = CM / 8, QB = L / 16;
   constexpr float inv_n = 1.f / (float)(L * CPG);
-  const int kh = wave & 1, partner = wave ^ 1;
-  float* ybuf = exch;                                          // [4 waves][16][64]
-  float* st1 = exch + 4 * 1024;                                // [4 waves][SW][32] partial sums
-  float* st2 = st1 + 4 * SW * 32;                              // [4 waves][SW][32] partial centred squares
-  const float bsum = group_colsum<CPG>(bias) * (float)L;
-  float sl[SW];
+  float sum = 0.f;
 #pragma unroll
-  for (int s = 0; s < SW; ++s) {
-    float sum = 0.f;
+  for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if ((8 * (r >> 2)) / TPS == s) sum += P[0][r] + P[1][r];
-    sl[s] = group_allreduce<CPG>(sum);
-  }
-  float* outbox = ybuf + wave * 1024 + lane;
-  const float* inbox = ybuf + partner * 1024 + lane;
-  if (kh) {                                                    // wave-uniform: rows 2t + 1 stay, rows 2t go to the partner
+    for (int r = 0; r < 4; ++r) sum += q[o][r];
+  const float dm = (quad_groupsum<CPG, QB>(sum) + group_colsum<CPG>(bias) * (float)L) * inv_n - bias;
+  float sq = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) outbox[r * 64] = P[0][r];
-  } else {
+  for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) outbox[r * 64] = P[1][r];
-  }
-  if (lane < 32) {
+    for (int r = 0; r < 4; ++r) {
+      const float d = q[o][r] - dm;
+      sq = fmaf(d, d, sq);
+    }
+  const GnCoef cf = gn_coef(dm, rsqrtf(quad_groupsum<CPG, QB>(sq) * inv_n + 1e-5f), gamma, beta);
 #pragma unroll
-    for (int s = 0; s < SW; ++s) st1[(wave * SW + s) * 32 + lane] = sl[s];
-  }
-  __syncthreads();
-  if (kh) {
+  for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) own[r] = P[1][r] + inbox[r * 64];
-  } else {
+    for (int r = 0; r < 4; ++r) q[o][r] = gn_mish1(q[o][r], cf);
+}
+// one-n-tile quad tile -> slab; producer tiling: wave = (M tile, 16-channel n-tile)
+template <int L, int CM, int DSS, int DSTR>
+__device__ __forceinline__ void quad1_to_stage(const f32x4 (&q)[4], float* dst, int wave, int lane) {
+  constexpr int QB = L / 16, SPT = 4 / QB, NTQ = CM / 16;
+  const int mt = wave / NTQ, nq = wave % NTQ;
+  const int smp = mt * SPT + (lane >> 4) / QB, qb = (lane >> 4) % QB;
+  float* base = dst + smp * DSS + (16 * qb + 2) * DSTR + nq * 16 + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) own[r] = P[0][r] + inbox[r * 64];
-  }
-  float dm[SW], sq[SW];
+  for (int o = 0; o < 4; ++o)
 #pragma unroll
-  for (int s = 0; s < SW; ++s) {
-    dm[s] = (sl[s] + st1[(partner * SW + s) * 32 + (lane & 31)] + bsum) * inv_n - bias;
-    float q = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if ((8 * (r >> 2)) / TPS == s) {
-        const float d = own[r] - dm[s];
-        q = fmaf(d, d, q);
-      }
-    sq[s] = group_allreduce<CPG>(q);
-  }
-  if (lane < 32) {
-#pragma unroll
-    for (int s = 0; s < SW; ++s) st2[(wave * SW + s) * 32 + lane] = sq[s];
-  }
-  __syncthreads();
-  GnCoef cf[SW];
-#pragma unroll
-  for (int s = 0; s < SW; ++s)
-    cf[s] = gn_coef(dm[s], rsqrtf((sq[s] + st2[(partner * SW + s) * 32 + (lane & 31)]) * inv_n + 1e-5f), gamma, beta);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) own[r] = MMD_ABL == 1 ? own[r] : gn_mish1(own[r], cf[(8 * (r >> 2)) / TPS]);
+    for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR] = q[o][r];
 }
 
-template <class CF, int SKIP_L, int SKIP_WN, bool SKIP_QUAD, class SKIP_T>
-__device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, int n0, int lane, int wave,
-                                              const SKIP_T& skip, f32x16 (&tout)[2][CF::MT_W], int trb) {
-  static_assert(!CF::SHARE && CF::C1 == CF::C0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "up-path stage");
+template <class CF, int SKIP_L, int SKIP_CM>
+__device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int n0, int lane, int wave,
+                                               const f32x4 (&skip)[8], f32x16 (&tout)[2][CF::MT_W], int trb) {
+  static_assert((CF::L == 16 || CF::L == 32) && CF::CM * CF::L == 1024 && CF::C1 == CF::C0 && CF::RES0 == RES_CONV &&
+                    CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "up-path stage with 4 waves = (L / 16 M tiles) x (CM / 16 n-tiles)");
   float* hslab = lds + CF::XSLAB;
   float* xslab = lds;
-  float* exch = lds;                                          // exchange buffers overlay the x slab
-  constexpr int TPS = CF::L / 2, WNU = CF::CM / 32;
-  static_assert(CF::XSLAB >= 4 * 1024 + 2 * 4 * (32 / TPS) * 32, "exchange buffers must fit into the x slab");
-  const int kh = wave & 1, pw = wave >> 1;
-  const int wn = pw % WNU, wmu = pw / WNU;
-  const int col = wn * 32 + (lane & 31), hi = lane >> 5;
-  const int g = wmu * 32 + (lane & 31);
-  const int srow = g / TPS, tile = g % TPS;
-
-  f32x16 m[6], P[2], own, res;
-  // one conv's K half of this wave over a slab with CP channels
-  B6 ring[WINO_RD];
-  auto wlane = [&](auto cp_tag, const float4* w) {            // this lane's first k-step of its K half of a CP-channel pack
-    constexpr int CP = decltype(cp_tag)::value;
-    return reinterpret_cast<const float*>(w) + ((size_t)(wn * (CP / 2) + kh * (CP / 4)) * 64 + lane) * 6;
+  constexpr int QPS = CF::L / 4, NTQ = CF::CM / 16;
+  const int mt = wave / NTQ, nq = wave % NTQ;
+  const int ai = mt * 16 + (lane & 15);
+  const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
+  const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
+  const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
+  const int col = nq * 16 + (lane & 15);
+  B8 ring[W4_RD];
+  auto wlane = [&](const float4* w, int cp) {
+    return reinterpret_cast<const float*>(w) + (size_t)nq * (cp / 4) * W4N1_KSTRIDE + lane * 8;
   };
-  // `ring` must hold the first k-steps of w (wino_ring_load); afterwards it is re-armed with those of `next`
-  auto conv = [&](auto cp_tag, auto fresh, const float* slab, int ss, const float4* w, auto next_tag, const float4* next) {
-    constexpr int CP = decltype(cp_tag)::value;
-    const int abase = srow * ss + 2 * tile * (CP + 1) + hi + kh * (CP / 2);
-    if (MMD_ABL != 3) wino_taps<CP / 2, CP + 1, decltype(fresh)::value>(m, slab, abase, wlane(cp_tag, w), ring);
-    else if (decltype(fresh)::value) zero6(m);
-    if (next) wino_ring_load(ring, wlane(next_tag, next));
-  };
-  using TC0 = std::integral_constant<int, CF::C0P>;
-  using TC1 = std::integral_constant<int, CF::C1P>;
-  using TCM = std::integral_constant<int, CF::CM>;
-  auto own_to_h = [&]() {                                     // rows 2t + kh of the H slab
-    tile_to_stage<TPS, 1, 32 / TPS, 1, 2, CF::HSS, CF::HSTR>(*reinterpret_cast<const f32x16(*)[1]>(&own), hslab + wn * 32,
-                                                             wmu, lane, kh);
-  };
-  const int rbase1 = srow * CF::XSS + (2 * tile + 2 + kh) * CF::XSTR + hi;   // 1x1 residual conv: this wave's own rows
-
-  // =================== RTB 0: cat(x, skip) -> CM, 1x1-conv residual ===================
-  const float4* wres0 = a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane;
-  const float4* wres1 = a.wr_c1 + ((size_t)wn * (CF::C1P / 8)) * 64 + lane;
+  w4n1_ring_load(ring, wlane(a.r0.wa, CF::C0P));
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
   TR(trb + 0);
-  wino_ring_load(ring, wlane(TC0{}, a.r0.wa));
+
+  f32x4 m[8], acc[4], res[4];
+  auto conv_h = [&](const float4* w, const float4* next) {
+    if (MMD_ABL != 3) w4n1_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w, CF::CM), ring);
+    if (next) w4n1_ring_load(ring, wlane(next, CF::CM));
+    w4n1_out(acc, m);
+  };
+  auto to_h = [&]() { quad1_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane); };
+  // res += x (rows 4t + o) * Wr over one chunk: pack [n-tile][k-step][lane]
+  auto res_chunk = [&](auto cp_tag, const float4* w) {
+    constexpr int CP = decltype(cp_tag)::value;
+    const float* wr = reinterpret_cast<const float*>(w) + (size_t)nq * (CP / 4) * 64 + lane;
+    const float* xr = xslab + xbase + 2 * CF::XSTR;
+#pragma unroll 4
+    for (int ks = 0; ks < CP / 4; ++ks) {
+      const float b = wr[ks * 64];
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        res[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[o * CF::XSTR + 4 * ks], b, res[o], 0, 0, 0);
+    }
+  };
+
+  // =================== RTB 0: cat(x, skip) -> CM, 1x1-conv residual ===================
+  if (MMD_ABL != 3) w4n1_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, wlane(a.r0.wa, CF::C0P), ring);
+  w4n1_ring_load(ring, wlane(a.wa0_c1, CF::C1P));
   {
-    f32x16 rr[1];
-    fill<1>(rr, a.br[col]);
-    int rb[1] = {rbase1};
-    conv(TC0{}, std::true_type{}, xslab, CF::XSS, a.r0.wa, TC1{}, a.wa0_c1);
-    if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 1>(rr, xslab, rb, wres0);
-    __syncthreads();                                          // chunk 0 has been consumed by every wave
-    if constexpr (SKIP_QUAD) quad_to_stage<SKIP_L, SKIP_WN * 32, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
-    else pair_to_stage<SKIP_L, SKIP_WN, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
-    __syncthreads();
-    conv(TC1{}, std::false_type{}, xslab, CF::XSS, a.wa0_c1, TCM{}, a.r0.wb);
-    if (MMD_ABL != 3) mfma_taps<1, CF::C1P, CF::XSTR, 1>(rr, xslab, rb, wres1);
-    res = rr[0];
+    const float br = a.br[col];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
   }
-  wino_out(P, m);
+  if (MMD_ABL != 3) res_chunk(std::integral_constant<int, CF::C0P>{}, a.wr_c0);
+  __syncthreads();                                            // chunk 0 has been consumed by every wave
+  quad_to_stage<SKIP_L, SKIP_CM, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
+  __syncthreads();
+  if (MMD_ABL != 3) w4n1_taps<CF::C1P, CF::XSTR, false>(m, xslab, xbase, wlane(a.wa0_c1, CF::C1P), ring);
+  w4n1_ring_load(ring, wlane(a.r0.wb, CF::CM));
+  if (MMD_ABL != 3) res_chunk(std::integral_constant<int, CF::C1P>{}, a.wr_c1);
+  w4n1_out(acc, m);
   TR(trb + 1);
-  __syncthreads();                                            // every wave is done reading the x slab: it becomes the exchange buffer
-  exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col]);
-  own += a.r0.tb[col];
-  own_to_h();
+  if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col]);
+  {
+    const float tb = a.r0.tb[col];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] += tb;
+  }
+  to_h();
   __syncthreads();
   TR(trb + 2);
-  conv(TCM{}, std::true_type{}, hslab, CF::HSS, a.r0.wb, TCM{}, a.ri[0].wa);
-  wino_out(P, m);
+  conv_h(a.r0.wb, a.ri[0].wa);
   TR(trb + 3);
-  exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col]);   // (its first barrier also frees the H slab)
-  own += res;
+  if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col]);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o] += res[o];
   TR(trb + 4);
 
   // =================== identity RTB ===================
   {
     const RtbPtrs& R = a.ri[0];
-    res = own;
-    own_to_h();
+#pragma unroll
+    for (int o = 0; o < 4; ++o) res[o] = acc[o];
+    __syncthreads();                                         // the previous conv is done reading the H slab
+    to_h();
     __syncthreads();
-    conv(TCM{}, std::true_type{}, hslab, CF::HSS, R.wa, TCM{}, R.wb);
-    wino_out(P, m);
+    conv_h(R.wa, R.wb);
     TR(trb + 5);
-    exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, R.ba[col], R.ga[col], R.bea[col]);
-    own += R.tb[col];
-    own_to_h();
+    if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col]);
+    {
+      const float tb = R.tb[col];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] += tb;
+    }
     __syncthreads();
-    conv(TCM{}, std::true_type{}, hslab, CF::HSS, R.wb, TCM{}, static_cast<const float4*>(nullptr));
-    wino_out(P, m);
+    to_h();
+    __syncthreads();
+    conv_h(R.wb, nullptr);
     TR(trb + 6);
-    exchange_gn_mish<CF::CM, CF::L>(P, own, exch, wave, lane, R.bb[col], R.gb[col], R.beb[col]);
-    own += res;
+    if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col]);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] += res[o];
   }
 
   // =================== tail: Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, direct ===================
-  own_to_h();
+  __syncthreads();
+  to_h();
   __syncthreads();
   TR(trb + 7);
   {
     constexpr int MT_W = CF::MT_W;
-    const int wm = wave / CF::WN, wnt = wave % CF::WN, colt = wnt * 32 + (lane & 31);
-    int hbase[MT_W];
+    const int wm = wave / CF::WN, wnt = wave % CF::WN, colt = wnt * 32 + (lane & 31), hi = lane >> 5;
+    int hb[MT_W];
 #pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt) {
-      const int r = mt * 32 + (lane & 31);
-      hbase[mt] = (wm * CF::SW + r / CF::L) * CF::HSS + (r % CF::L) * CF::HSTR + hi;
+    for (int t = 0; t < MT_W; ++t) {
+      const int r = t * 32 + (lane & 31);
+      hb[t] = (wm * CF::SW + r / CF::L) * CF::HSS + (r % CF::L) * CF::HSTR + hi;
     }
     const float bt = a.bt[colt];
     constexpr int G = 2 * CF::CM / 8;
@@ -1133,9 +1179,8 @@ __device__ __forceinline__ void chain_body_wu(const ChainArgs& a, float* lds, in
       fill<MT_W>(t, bt);
       int ub[MT_W];
 #pragma unroll
-      for (int mt = 0; mt < MT_W; ++mt) ub[mt] = hbase[mt] + (1 + pass) * CF::HSTR;
-      if (MMD_ABL != 3)
-        mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wnt * G) * 64 + lane);
+      for (int i = 0; i < MT_W; ++i) ub[i] = hb[i] + (1 + pass) * CF::HSTR;
+      if (MMD_ABL != 3) mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wnt * G) * 64 + lane);
     }
   }
 }
@@ -1203,7 +1248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
   {
     f32x16 t[2][1];
-    chain_body_wu<CH_U0, CH_D2::L, CH_D2::WN, true>(a.c[3], lds, n0, lane, wave, skip2, t, 136);
+    chain_body_w4u<CH_U0, CH_D2::L, CH_D2::CM>(a.c[3], lds, n0, lane, wave, skip2, t, 136);
     __syncthreads();
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
@@ -1213,7 +1258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
   {
     f32x16 t[2][1];
-    chain_body_wu<CH_U1, CH_D1::L, CH_D1::WN, true>(a.c[4], lds, n0, lane, wave, skip1, t, 146);
+    chain_body_w4u<CH_U1, CH_D1::L, CH_D1::CM>(a.c[4], lds, n0, lane, wave, skip1, t, 146);
     __syncthreads();
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
@@ -1469,6 +1514,45 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin)
         }
 }
 
+// F(4,5) pack for one n-tile per wave (up path): out[((nq*KS + ks)*64 + lane)*8 + p] = U_p(c = c_lo + 4*ks + (lane>>4),
+// n = nq*16 + (lane&15)), KS = (c_hi - c_lo) / 4, followed by 8 zero k-steps
+static void pack_w4n1(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi) {
+  static const double G[8][5] = {{-1, 0, 0, 0, 0},
+                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                 {0, 0, 0, 0, 1}};
+  const int nq_n = cout / 16, KS = (c_hi - c_lo) / 4;
+  const size_t base = blob.size();
+  blob.resize(base + ((size_t)nq_n * KS + 8) * 64 * 8, 0.f);
+  for (int nq = 0; nq < nq_n; ++nq)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int ci = c_lo + 4 * ks + (lane >> 4), n = nq * 16 + (lane & 15);
+        const float* g = w + ((size_t)n * cin_full + ci) * 5;
+        for (int p = 0; p < 8; ++p) {
+          double u = 0.0;
+          for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
+          blob[base + (((size_t)nq * KS + ks) * 64 + lane) * 8 + p] = (float)u;
+        }
+      }
+}
+// 1x1 conv, one n-tile per wave: out[(nq*KS + ks)*64 + lane] = W(c = c_lo + 4*ks + (lane>>4), n = nq*16 + (lane&15))
+static void pack_b4n1_1x1(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi) {
+  const int nq_n = cout / 16, KS = (c_hi - c_lo) / 4;
+  const size_t base = blob.size();
+  blob.resize(base + (size_t)nq_n * KS * 64, 0.f);
+  for (int nq = 0; nq < nq_n; ++nq)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        blob[base + ((size_t)nq * KS + ks) * 64 + lane] =
+            w[(size_t)(nq * 16 + (lane & 15)) * cin_full + c_lo + 4 * ks + (lane >> 4)];
+  while (blob.size() % 4) blob.push_back(0.f);
+}
+
 // 1x1 conv for the 16x16x4 MFMA: out[((wv*KS + ks)*64 + lane)*2 + nt] = W(c = 4*ks + (lane>>4), n = wv*32 + nt*16 + (lane&15))
 static void pack_b4_1x1(std::vector<float>& blob, const float* w, int cout, int cin) {
   const int nw = cout / 32, KS = cin / 4;
@@ -1585,14 +1669,19 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     while (blob.size() % 4) blob.push_back(0.f);
-    const bool w4 = (r >= 2 && r <= 5) || r >= 10;   // downs.1, downs.2, mid blocks: F(4,5) packs; the rest: F(2,5)
+    const bool w4 = (r >= 2 && r <= 5) || r >= 10;   // downs.1, downs.2, mid blocks: F(4,5), two n-tiles per wave
+    const bool w4u = r >= 6 && r <= 9;               // ups.0, ups.1: F(4,5), one n-tile per wave; downs.0: F(2,5)
     W.a.wpk = blob.size();
-    if (w4) pack_w4(blob, tensors[R.t_w0], R.cout, R.cin); else pack_w(blob, tensors[R.t_w0], R.cout, R.cin);
+    if (w4) pack_w4(blob, tensors[R.t_w0], R.cout, R.cin);
+    else if (w4u) pack_w4n1(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin);
+    else pack_w(blob, tensors[R.t_w0], R.cout, R.cin);
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
     W.b.wpk = blob.size();
-    if (w4) pack_w4(blob, tensors[R.t_w1], R.cout, R.cout); else pack_w(blob, tensors[R.t_w1], R.cout, R.cout);
+    if (w4) pack_w4(blob, tensors[R.t_w1], R.cout, R.cout);
+    else if (w4u) pack_w4n1(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout);
+    else pack_w(blob, tensors[R.t_w1], R.cout, R.cout);
     W.b.bias = push(blob, tensors[R.t_b1], R.cout);
     W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
     W.b.beta = push(blob, tensors[R.t_be1], R.cout);
@@ -1608,10 +1697,10 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     if (r == 6 || r == 8) {   // ups.0.0 / ups.1.0: input = cat(x, skip): per-chunk packs for the K-chunked staging
       const int half = R.cin / 2;
       // a.wpk is repacked as chunk 0 (channels [0, half)); chunk 1 follows
-      W.a.wpk = blob.size(); pack_w(blob, tensors[R.t_w0], R.cout, R.cin, 0, half);
-      W.a_c1 = blob.size(); pack_w(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin);
-      W.res_c0 = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false, 0, half);
-      W.res_c1 = blob.size(); pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false, half, R.cin);
+      W.a.wpk = blob.size(); pack_w4n1(blob, tensors[R.t_w0], R.cout, R.cin, 0, half);
+      W.a_c1 = blob.size(); pack_w4n1(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin);
+      W.res_c0 = blob.size(); pack_b4n1_1x1(blob, tensors[R.t_rw], R.cout, R.cin, 0, half);
+      W.res_c1 = blob.size(); pack_b4n1_1x1(blob, tensors[R.t_rw], R.cout, R.cin, half, R.cin);
     } else if (R.res) {
       W.res_c0 = W.res_wpk;
     }
@@ -1701,8 +1790,8 @@ static const double kLayerMfmaFlops[kNumLayers] = {
     wino_flops(8, 32, 64) + direct_flops(1, 8, 32, 64) + 3 * wino_flops(32, 32, 64) + direct_flops(3, 32, 32, 32) +
     2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) + direct_flops(3, 64, 64, 16) +
     wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) + 7 * wino4_flops(128, 128) +
-    wino_flops(256, 64, 16) + direct_flops(1, 256, 64, 16) + 3 * wino_flops(64, 64, 16) + 2 * direct_flops(2, 64, 64, 16) +
-    wino_flops(128, 32, 32) + direct_flops(1, 128, 32, 32) + 3 * wino_flops(32, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
+    wino4_flops(256, 64) + direct_flops(1, 256, 64, 16) + 3 * wino4_flops(64, 64) + 2 * direct_flops(2, 64, 64, 16) +
+    2 * (wino4_flops(128, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 128, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
     wino_flops(32, 32, 64) + direct_flops(1, 32, 32, 64)};
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
