@@ -1,18 +1,20 @@
 // TemporalUnet forward for gfx950 (MI355X), the whole network in ONE launch (unet_kernel).  Every Conv1d /
 // ConvTranspose1d of the reference network (mmd/models/diffusion_models/temporal_unet.py:121-174,
-// mmd/models/layers/layers.py:261-358) is a GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and
-// accumulation), with GroupNorm + Mish + time-bias / residual fused into the epilogue:
-//   * down path, mid blocks and the final block: the stride-1 k=5 convs run as Winograd F(2,5) (6 instead of 10
-//     multiplies per 2 outputs; fp32, ~1e-6 relative difference to the direct sum);
-//   * up path, strided / transposed / 1x1 convs: direct implicit-im2col GEMMs (taps = row-shifted views of an LDS slab).
+// mmd/models/layers/layers.py:261-358) is a GEMM on the fp32 MFMA (exact fp32 products and accumulation), with
+// GroupNorm + Mish + time-bias / residual fused into the epilogue:
+//   * all 25 stride-1 k=5 convs run as Winograd F(4,5) on v_mfma_f32_16x16x4_f32 (8 instead of 20 multiplies per 4
+//     outputs; fp32, ~2e-6 relative difference to the direct sum);
+//   * strided / transposed / 1x1 convs: direct GEMMs (taps = row-shifted views of an LDS slab; v_mfma_f32_32x32x2_f32
+//     for the down / up-sampling convs and the final 1x1, 16x16x4 for the 1x1 residual convs).
 //
 // Layout.  The trajectory tensor is channels-last [n_traj, 64, 4] fp32 in HBM on both sides (no transposes).  A
 // workgroup (4 waves) owns 4 whole samples for the entire forward: activations live in LDS slabs [sample][L+4][C+1]
-// (zero halo, odd row stride: conflict-free A-fragment reads) and in register tiles; the two skip connections wait in
-// registers for the up path; nothing but the input, the output and the weights touches HBM/L2.  A wave owns whole
-// samples x a 32-channel slice, so GroupNorm groups (C/8 channels) and samples never straddle waves: the statistics
-// are in-register + cross-lane reductions.  Weights are pre-packed on the host in MFMA B-fragment order and fetched
-// straight from L2 through a register ring (no LDS staging: a B element is used once per workgroup).
+// (zero halo, odd row stride) and in register tiles; the two skip connections wait in registers for the up path;
+// nothing but the input, the output and the weights touches HBM/L2.  In the 16x16x4 C/D layout a lane holds 16
+// consecutive positions of one (sample, channel), so a GroupNorm group (C/8 adjacent channels x all L positions) is a
+// few lanes of one DPP row (x 2 / 4 row blocks at L = 32 / 64): the statistics are in-register + cross-lane reductions.
+// Weights are pre-packed on the host in MFMA B-fragment order (Winograd-transformed in fp64) and fetched straight from
+// L2 through a register ring (no LDS staging: a B element is used once per workgroup).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -41,14 +43,7 @@ struct FinalArgs {
   const float* w1_bias;   // [4]
 };
 
-// Mish(y) = y * tanh(softplus(y)) = y * n / (n + 2), n = e^y (e^y + 2)   (torch.nn.Mish; softplus threshold 20)
-__device__ __forceinline__ float mish(float y) {
-  const float e = __expf(fminf(y, 20.f));
-  const float n = e * (e + 2.f);
-  const float m = y * __fdividef(n, n + 2.f);
-  return y > 20.f ? y : m;       // branch-free: a select, not 32 divergent branches per tile
-}
-
+// Mish(y) = y * tanh(softplus(y)) = y * n / (n + 2), n = e^y (e^y + 2)   (torch.nn.Mish; softplus threshold 20).
 // GroupNorm affine + Mish of one activation in 10 VALU ops (every VALU op costs the SIMD ~5 cycles of MFMA issue):
 // y = x * sa + sb with sa = rstd * gamma, sb = beta - mean * sa folded per (sample, channel); the exponent argument
 // y * log2(e) comes from a second fma (sa2 = sa * log2 e, sb2 = sb * log2 e) instead of a multiply.  Clamping the
@@ -177,15 +172,9 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[MT_W], const float* sla
 // A fragments are double-buffered in registers (the LDS reads of k-group g+1 are issued before the 4*MT_W MFMAs of
 // group g), B fragments ride a 4-deep register ring fed straight from L2: a lone wave keeps the matrix pipe busy, so a
 // co-resident wave's epilogue overlaps instead of stalling it.
-// first four k-groups of a direct-conv pack, requested ahead of time (see wino_ring_load)
-__device__ __forceinline__ void mfma_ring_load(float4 (&b)[4], const float4* __restrict__ wp) {
-  b[0] = wp[0]; b[1] = wp[64]; b[2] = wp[128]; b[3] = wp[192];
-  MMD_PIN_LOADS();
-}
-
 template <int NTAPS, int CP, int STR, int MT_W>
 __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W],
-                                          const float4* __restrict__ wp, const float4 (*pre)[4] = nullptr) {
+                                          const float4* __restrict__ wp) {
   constexpr int GPT = CP / 8;   // k-groups (of 4 k-pairs) per tap
   if constexpr (GPT % 4 != 0) {
     // tiny K (the 4-channel input layer, padded to 8): everything in flight at once
@@ -196,9 +185,7 @@ __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab
     for (int g = 0; g < NTAPS * GPT; ++g) mfma_group<MT_W>(acc, slab, abase, (g / GPT) * STR + (g % GPT) * 8, b[g]);
   } else {
     const float4* p = wp;
-    float4 b0, b1, b2, b3;
-    if (pre) { b0 = (*pre)[0]; b1 = (*pre)[1]; b2 = (*pre)[2]; b3 = (*pre)[3]; }
-    else { b0 = p[0]; b1 = p[64]; b2 = p[128]; b3 = p[192]; }
+    float4 b0 = p[0], b1 = p[64], b2 = p[128], b3 = p[192];
     float a0[4][MT_W], a1[4][MT_W];
     load_a<MT_W>(a0, slab, abase, 0);
 #pragma unroll
@@ -247,45 +234,6 @@ __device__ __forceinline__ float group_allreduce(float v) {
   return v;
 }
 
-// GroupNorm (biased variance, eps 1e-5, two-pass in registers) + affine + Mish on a wave tile.
-template <int COUT, int LROWS, int MT_W>
-__device__ __forceinline__ void gn_mish(f32x16 (&acc)[MT_W], float gamma, float beta) {
-  constexpr int CPG = COUT / 8;
-  constexpr int RW = 32 * MT_W;
-  constexpr int SW = RW / LROWS;                 // samples per wave
-  constexpr float inv_n = 1.f / (float)(LROWS * CPG);
-  float mean[SW], rstd[SW];
-  // element (mt, reg) belongs to sample (mt*32 + 8*(reg>>2)) / LROWS
-#pragma unroll
-  for (int s = 0; s < SW; ++s) {
-    float sum = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((mt * 32 + 8 * (r >> 2)) / LROWS == s) sum += acc[mt][r];
-    mean[s] = group_allreduce<CPG>(sum) * inv_n;
-    float sq = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((mt * 32 + 8 * (r >> 2)) / LROWS == s) {
-          float d = acc[mt][r] - mean[s];
-          sq += d * d;
-        }
-    rstd[s] = rsqrtf(group_allreduce<CPG>(sq) * inv_n + 1e-5f);
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int s = (mt * 32 + 8 * (r >> 2)) / LROWS;
-      float y = (acc[mt][r] - mean[s]) * rstd[s] * gamma + beta;
-      acc[mt][r] = mish(y);
-    }
-}
-
 // ----------------------------------------------------------------------------------------------------------------
 enum { TAIL_NONE = 0, TAIL_DOWN = 1, TAIL_UP = 2 };
 constexpr int MAX_IDENT = 3;
@@ -309,7 +257,7 @@ template <int C0_, int C1_, int CM_, int L_, int MT_W_, int RES0_, int N_IDENT_,
 struct ChainCfg {
   static constexpr int C0 = C0_, C1 = C1_, CM = CM_, L = L_, MT_W = MT_W_, RES0 = RES0_, N_IDENT = N_IDENT_;
   static constexpr int MID_AFTER = MID_AFTER_, TAIL = TAIL_;
-  static constexpr int C0P = (C0 + 7) / 8 * 8, C1P = (C1 + 7) / 8 * 8;
+  static constexpr int C0P = C0 < 16 ? 16 : (C0 + 7) / 8 * 8, C1P = (C1 + 7) / 8 * 8;   // (4-channel input: 4 k-steps of 4)
   static constexpr int CXP = C0P > C1P ? C0P : C1P;
   static constexpr int XSTR = CXP + 1, HSTR = CM + 1;
   static constexpr int WN = CM / 32, WM = 4 / WN;
@@ -368,116 +316,6 @@ __device__ __forceinline__ void zero_halo(float* slab) {
   }
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// Winograd F(2,5) for the stride-1 k=5 convolutions (points 0, +-1, +-2, inf): two outputs from six products instead
-// of ten, i.e. 0.6x the MFMA work.  A GEMM row is an output PAIR (sample, tile): rows l = 2*tile, 2*tile + 1.  The
-// input transform V = B^T d (six slab rows 2*tile .. 2*tile + 5 -> six positions) is done on the fly on the A fragment
-// (6 ds_read_b32 + 12 VALU ops per 6 MFMAs, hidden under the matrix pipe); the weights are transformed on the host
-// (U = G g, fp64 -> fp32) and packed [n-tile][k-step][lane][6 positions]; the output transform Y = A^T M is element-wise
-// on the six accumulators.  fp32 throughout: the result differs from the direct sum by ~1e-6 relative (tools/dbg/
-// winograd_accuracy.py: 1.6e-6 vs 0.8e-6 against an fp64-accumulated forward).
-// ----------------------------------------------------------------------------------------------------------------
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(8)));
-struct B6 { f32x4u lo; f32x2u hi; };
-
-__device__ __forceinline__ B6 load_b6(const float* __restrict__ p) {
-  B6 b;
-  b.lo = *reinterpret_cast<const f32x4u*>(p);
-  b.hi = *reinterpret_cast<const f32x2u*>(p + 4);
-  return b;
-}
-
-template <int STR>
-__device__ __forceinline__ void load_d(float (&d)[6], const float* s) {
-#pragma unroll
-  for (int j = 0; j < 6; ++j) d[j] = s[j * STR];
-}
-
-template <bool ZERO = false>
-__device__ __forceinline__ void wino_step(f32x16 (&m)[6], const float (&d)[6], const B6& b) {
-  if constexpr (ZERO) {   // first k-step of a conv: srcC = inline constant 0 instead of 96 v_mov to clear the accumulators
-    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int p = 0; p < 6; ++p) m[p] = z;
-  }
-  const float a = fmaf(-4.f, d[2], d[4]), bb = fmaf(-4.f, d[1], d[3]);
-  const float c = d[4] - d[2], e = d[3] - d[1];
-  const float v0 = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
-  const float v1 = a + bb, v2 = a - bb;
-  const float v3 = fmaf(2.f, e, c), v4 = fmaf(-2.f, e, c);
-  const float v5 = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
-  m[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, b.lo[0], m[0], 0, 0, 0);
-  m[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, b.lo[1], m[1], 0, 0, 0);
-  m[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, b.lo[2], m[2], 0, 0, 0);
-  m[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3, b.lo[3], m[3], 0, 0, 0);
-  m[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4, b.hi[0], m[4], 0, 0, 0);
-  m[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(v5, b.hi[1], m[5], 0, 0, 0);
-}
-
-constexpr int WINO_KSTRIDE = 64 * 6;   // floats per k-step of a packed n-tile
-
-// m[p] += V_p(slab) * U_p for the CP input channels of one slab.  abase = lane's offset of (sample, row 2*tile, k = lane>>5);
-// wp = this lane's six floats of k-step 0 of the wave's n-tile.  d is double-buffered, U rides a 4-k-step register ring.
-constexpr int WINO_RD = 4;   // depth of the weight ring in k-steps
-
-// first WINO_RD k-steps of a packed conv into the ring.  Issued BEFORE the previous conv's epilogue so that the L2
-// latency of a conv's first weights is not exposed once per conv.
-__device__ __forceinline__ void wino_ring_load(B6 (&b)[WINO_RD], const float* __restrict__ wp) {
-#pragma unroll
-  for (int j = 0; j < WINO_RD; ++j) b[j] = load_b6(wp + j * WINO_KSTRIDE);
-  MMD_PIN_LOADS();
-}
-
-// m[p] += V_p(slab) * U_p for the CP input channels of one slab.  abase = lane's offset of (sample, row 2*tile, k = lane>>5);
-// wp = this lane's six floats of k-step 0 of the wave's n-tile; b = the ring, pre-loaded with k-steps 0..3 (wino_ring_load).
-// d is double-buffered, U rides the register ring.
-// FRESH: the accumulators start at zero (first k-step issues its MFMAs with srcC = 0)
-template <int CP, int STR, bool FRESH>
-__device__ __forceinline__ void wino_taps(f32x16 (&m)[6], const float* slab, int abase, const float* __restrict__ wp,
-                                          B6 (&b)[WINO_RD]) {
-  constexpr int KS = CP / 2;
-  constexpr int RD = WINO_RD;
-  static_assert(KS % RD == 0 && RD % 2 == 0, "k-steps are unrolled by the ring depth");
-  const float* p = wp;
-  const float* s = slab + abase;
-  float d[2][6];
-  load_d<STR>(d[0], s);
-  auto iter = [&](auto first) {
-    p += RD * WINO_KSTRIDE;
-#pragma unroll
-    for (int j = 0; j < RD; ++j) {
-      load_d<STR>(d[(j + 1) & 1], s + 2 * (j + 1));   // (past the last k-step this reads the next slab row and is unused)
-      MMD_PIN_LOADS();
-      if (decltype(first)::value && j == 0) wino_step<true>(m, d[0], b[0]);
-      else wino_step<false>(m, d[j & 1], b[j]);
-      b[j] = load_b6(p + j * WINO_KSTRIDE);
-      MMD_PIN_LOADS();
-    }
-    s += 2 * RD;
-  };
-  if constexpr (FRESH) {
-    iter(std::true_type{});
-#pragma unroll 1
-    for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
-  } else {
-#pragma unroll 1
-    for (int ks = 0; ks < KS; ks += RD) iter(std::false_type{});
-  }
-}
-
-// Y = A^T M + bias: pr[0] = rows 2*tile, pr[1] = rows 2*tile + 1
-// (the conv bias is not added here: GroupNorm folds it into its statistics and affine, gn_mish_pair / exchange_gn_mish)
-__device__ __forceinline__ void wino_out(f32x16 (&pr)[2], const f32x16 (&m)[6]) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float s12 = m[1][r] + m[2][r], d12 = m[1][r] - m[2][r];
-    const float s34 = m[3][r] + m[4][r], d34 = m[3][r] - m[4][r];
-    pr[0][r] = (m[0][r] + s12) + s34;
-    pr[1][r] = (d12 + m[5][r]) + 2.f * d34;
-  }
-}
-
 // sum over the CPG adjacent lanes (channels) of a GroupNorm group, same value in all of them
 template <int CPG>
 __device__ __forceinline__ float group_colsum(float v) {
@@ -493,163 +331,6 @@ __device__ __forceinline__ void zero6(f32x16 (&m)[6]) {
   for (int p = 0; p < 6; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) m[p][r] = 0.f;
-}
-
-// GroupNorm + Mish on a pair tile x + bias: register r of both halves belongs to sample (8 * (r >> 2)) / (L / 2) of the
-// wave.  The per-channel conv bias is never added to the tile: mean = (sum x + L * sum_group bias) / N, the centred
-// values are x - (mean - bias), and the affine absorbs the rest.
-template <int CM, int L>
-__device__ __forceinline__ void gn_mish_pair(f32x16 (&pr)[2], float bias, float gamma, float beta) {
-  constexpr int CPG = CM / 8;
-  constexpr int SW = 64 / L;                     // samples per wave
-  constexpr float inv_n = 1.f / (float)(L * CPG);
-  const float bsum = group_colsum<CPG>(bias) * (float)L;
-  GnCoef cf[SW];
-#pragma unroll
-  for (int s = 0; s < SW; ++s) {
-    float sum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if ((8 * (r >> 2)) / (L / 2) == s) sum += pr[0][r] + pr[1][r];
-    const float dm = (group_allreduce<CPG>(sum) + bsum) * inv_n - bias;     // mean - bias of this lane's channel
-    float sq = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if ((8 * (r >> 2)) / (L / 2) == s) {
-        const float d0 = pr[0][r] - dm, d1 = pr[1][r] - dm;
-        sq = fmaf(d0, d0, sq);
-        sq = fmaf(d1, d1, sq);
-      }
-    cf[s] = gn_coef(dm, rsqrtf(group_allreduce<CPG>(sq) * inv_n + 1e-5f), gamma, beta);
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pr[h][r] = gn_mish1(pr[h][r], cf[(8 * (r >> 2)) / (L / 2)]);
-}
-
-// pair tile -> slab rows 2*tile + h (+2 halo) of a stage laid out [sample][row][DSTR]
-template <int L, int WN_SRC, int DSS, int DSTR>
-__device__ __forceinline__ void pair_to_stage(const f32x16 (&pr)[2], float* dst, int wave, int lane) {
-  tile_to_stage<L / 2, 1, 64 / L, WN_SRC, 2, DSS, DSTR>(*reinterpret_cast<const f32x16(*)[1]>(&pr[0]), dst, wave, lane, 0);
-  tile_to_stage<L / 2, 1, 64 / L, WN_SRC, 2, DSS, DSTR>(*reinterpret_cast<const f32x16(*)[1]>(&pr[1]), dst, wave, lane, 1);
-}
-
-// A level chain of the down path with every k=5 conv in Winograd form.  Same slabs and sample ownership as chain_body
-// (wave wm = wave / WN owns 64 / L samples, wn its 32-channel slice); activations live in registers as pair tiles.
-template <class CF, bool FIRST>
-__device__ __forceinline__ void chain_body_w(const ChainArgs& a, float* lds, int n0, int lane, int wave,
-                                             f32x16 (&acc)[2], f32x16 (&mid)[2], f32x16 (&tout)[1], int trb) {
-  static_assert(!CF::SHARE && CF::C1 == 0 && CF::MT_W == 2 && CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP, "down-path chain");
-  float* hslab = lds + CF::XSLAB;
-  float* xslab = lds;
-  const int wm = wave / CF::WN, wn = wave % CF::WN;
-  const int col = wn * 32 + (lane & 31);
-  const int hi = lane >> 5;
-  constexpr int TPS = CF::L / 2;                             // pair rows (tiles) per sample
-
-  B6 ring[WINO_RD];
-  const float* w0 = reinterpret_cast<const float*>(a.r0.wa) + (size_t)wn * (CF::C0P / 2) * WINO_KSTRIDE + lane * 6;
-  const float4* wres = a.wr_c0 + ((size_t)wn * (CF::C0P / 8)) * 64 + lane;
-
-  if constexpr (FIRST)
-    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
-  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
-  __syncthreads();
-
-  const int g = wm * 32 + (lane & 31);                       // this lane's A row: pair (sample, tile)
-  const int srow = g / TPS, tile = g % TPS;
-  const int xbase = srow * CF::XSS + 2 * tile * CF::XSTR + hi;
-  const int hbase = srow * CF::HSS + 2 * tile * CF::HSTR + hi;
-  f32x16 m[6], res[2];
-
-  auto wlane = [&](const float4* w) {                        // this lane's first k-step of a CM -> CM pack
-    return reinterpret_cast<const float*>(w) + (size_t)wn * (CF::CM / 2) * WINO_KSTRIDE + lane * 6;
-  };
-  // conv over the H slab (CM -> CM); `next` = weights of the conv after this one (or null): their first k-steps are
-  // requested before this conv's epilogue
-  auto conv_h = [&](const float4* w, const float4* next) {
-    if (MMD_ABL != 3) wino_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w), ring);
-    else zero6(m);
-    if (next) wino_ring_load(ring, wlane(next));
-    wino_out(acc, m);
-  };
-  auto add_tb = [&](float tb) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[h][r] += tb;
-  };
-
-  // =================== RTB 0 (C0 -> CM, 1x1 residual conv) ===================
-  TR(trb + 0);
-  wino_ring_load(ring, w0);
-  if (MMD_ABL != 3) wino_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, w0, ring);
-  else zero6(m);
-  wino_ring_load(ring, wlane(a.r0.wb));
-  wino_out(acc, m);
-  TR(trb + 1);
-  {
-    int rbase[2] = {xbase + 2 * CF::XSTR, xbase + 3 * CF::XSTR};
-    fill<2>(res, a.br[col]);
-    if (MMD_ABL != 3) mfma_taps<1, CF::C0P, CF::XSTR, 2>(res, xslab, rbase, wres);
-  }
-  TR(trb + 2);
-  if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col]);
-  add_tb(a.r0.tb[col]);
-  pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
-  TR(trb + 3);
-  __syncthreads();
-  TR(trb + 4);
-  conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
-  TR(trb + 5);
-  if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col]);
-  acc[0] += res[0];
-  acc[1] += res[1];
-  TR(trb + 6);
-  if constexpr (CF::MID_AFTER == 0) { mid[0] = acc[0]; mid[1] = acc[1]; }
-
-  // =================== identity RTBs ===================
-#pragma unroll
-  for (int k = 0; k < CF::N_IDENT; ++k) {
-    const RtbPtrs& R = a.ri[k];
-    res[0] = acc[0];
-    res[1] = acc[1];
-    __syncthreads();                                         // the previous conv is done reading the H slab
-    TR(trb + 8 + k * 8 + 0);
-    pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
-    __syncthreads();
-    TR(trb + 8 + k * 8 + 1);
-    conv_h(R.wa, R.wb);
-    TR(trb + 8 + k * 8 + 2);
-    if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col]);
-    add_tb(R.tb[col]);
-    TR(trb + 8 + k * 8 + 3);
-    __syncthreads();
-    TR(trb + 8 + k * 8 + 4);
-    pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
-    __syncthreads();
-    TR(trb + 8 + k * 8 + 5);
-    conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
-    TR(trb + 8 + k * 8 + 6);
-    if (MMD_ABL != 1) gn_mish_pair<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col]);
-    acc[0] += res[0];
-    acc[1] += res[1];
-    TR(trb + 8 + k * 8 + 7);
-    if (CF::MID_AFTER == k + 1) { mid[0] = acc[0]; mid[1] = acc[1]; }
-  }
-
-  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct ===================
-  if constexpr (CF::TAIL == TAIL_DOWN) {
-    __syncthreads();
-    pair_to_stage<CF::L, CF::WN, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
-    __syncthreads();
-    constexpr int LO = CF::L / 2;
-    fill<1>(tout, a.bt[col]);
-    const int r = lane & 31;
-    int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
-    if (MMD_ABL != 3) mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
-  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -765,11 +446,12 @@ __device__ __forceinline__ void w4_out(f32x4 (&q)[8], const f32x4 (&m)[16]) {
 
 // GroupNorm + Mish on a quad tile x + bias; b/g/be = bias, gamma, beta of the lane's channel in n-tile 0 / 1.  A group is
 // CPG adjacent lanes (channels) of a 16-lane DPP row x all L positions: the lane's own 16, and for L = 32 the 16 of the
-// lane 16 further (QB = 2 row blocks per sample).
+// lanes 16 / 32 / 48 further (QB = 2 / 4 row blocks per sample at L = 32 / 64).
 template <int CPG, int QB>
 __device__ __forceinline__ float quad_groupsum(float v) {
   v = group_colsum<CPG>(v);
-  if constexpr (QB == 2) v += __shfl_xor(v, 16);
+  if constexpr (QB >= 2) v += __shfl_xor(v, 16);
+  if constexpr (QB == 4) v += __shfl_xor(v, 32);
   return v;
 }
 template <int CM, int L>
@@ -820,11 +502,12 @@ __device__ __forceinline__ void quad_to_stage(const f32x4 (&q)[8], float* dst, i
 // A down-path stage (L = 32 / C = 64: downs.1; L = 16 / C = 128: downs.2 + mid blocks) in F(4,5) form.  Same slabs as
 // the other stages; activations in registers as quad tiles.  The 4 * L / 4 output quads are L / 16 M tiles of 16 rows; a
 // wave owns one M tile x 32 channels (two n-tiles).
-template <class CF>
+template <class CF, bool FIRST>
 __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[8],
                                               f32x4 (&mid)[8], f32x16 (&tout)[1], int trb) {
-  static_assert((CF::L == 16 || CF::L == 32) && CF::CM * CF::L == 2048 && CF::C1 == 0 && CF::RES0 == RES_CONV &&
-                    CF::TAIL != TAIL_UP, "down-path stage with 4 waves = (L / 16 M tiles) x (CM / 32 channel slices)");
+  static_assert((CF::L == 16 || CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 &&
+                    CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP,
+                "down-path stage with 4 waves = (L / 16 M tiles) x (CM / 32 channel slices)");
   float* hslab = lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, WNQ = CF::CM / 32;                     // quads per sample, channel slices
@@ -840,6 +523,8 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     return reinterpret_cast<const float*>(w) + (size_t)wnq * (cp / 4) * W4_KSTRIDE + lane * 16;
   };
   w4_ring_load(ring, wlane(a.r0.wa, CF::C0P));
+  if constexpr (FIRST)     // the network input, channels-last [n, 64, 4] in HBM (channels 4..15 of the slab are zero)
+    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
   TR(trb + 0);
@@ -1220,8 +905,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 skip1[8], skip2[8];
   // ---- downs.0 @ L=64 -> [4][32][32]
   {
-    f32x16 acc[2], mid[2], t[1];
-    chain_body_w<CH_D0, true>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
+    f32x4 acc[8], mid[8];
+    f32x16 t[1];
+    chain_body_w4<CH_D0, true>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
     __syncthreads();                                                       // the tail conv is done reading the H slab
     tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
@@ -1230,7 +916,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     f32x4 acc[8];
     f32x16 t[1];
-    chain_body_w4<CH_D1>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
+    chain_body_w4<CH_D1, false>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
     __syncthreads();
     tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
@@ -1239,7 +925,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     f32x4 acc[8];
     f32x16 t[1];
-    chain_body_w4<CH_D2>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
+    chain_body_w4<CH_D2, false>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
     __syncthreads();
     quad_to_stage<CH_D2::L, CH_D2::CM, CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane);
     zero_halo<CH_U0::C0P, CH_U0::L, CH_U0::SROWS, CH_U0::XSTR, CH_U0::XSS, 4>(lds);
@@ -1270,23 +956,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     const FinalArgs& f = a.fin;
     const int col = lane & 31, hi = lane >> 5;
-    f32x16 acc[2];
+    f32x4 q[8];
     {
-      f32x16 m[6];
-      B6 ring[WINO_RD];
-      const float* w0 = reinterpret_cast<const float*>(f.wpk) + lane * 6;
-      wino_ring_load(ring, w0);
-      if (MMD_ABL != 3) wino_taps<32, FIN_STR, true>(m, lds, wave * FIN_SS + 2 * (lane & 31) * FIN_STR + hi, w0, ring);
-      else zero6(m);
-      wino_out(acc, m);
+      // wave = sample: one 16-quad M tile x both n-tiles of the 32 channels
+      f32x4 m[16];
+      B16 ring[W4_RD];
+      const float* w0 = reinterpret_cast<const float*>(f.wpk) + lane * 16;
+      w4_ring_load(ring, w0);
+      if (MMD_ABL != 3) w4_taps<32, FIN_STR, true>(m, lds, wave * FIN_SS + 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
+      w4_out(q, m);
     }
-    if (MMD_ABL != 1) gn_mish_pair<32, 64>(acc, f.bias[col], f.gamma[col], f.beta[col]);
+    {
+      const int c0 = lane & 15, c1 = c0 + 16;
+      const float bb[2] = {f.bias[c0], f.bias[c1]}, gg[2] = {f.gamma[c0], f.gamma[c1]}, ee[2] = {f.beta[c0], f.beta[c1]};
+      if (MMD_ABL != 1) gn_mish_quad<32, 64>(q, bb, gg, ee);
+    }
     __syncthreads();                                                       // every wave is done reading the slab
     float* yt = lds + wave * (64 * 33);
+    {
+      float* base = yt + 16 * (lane >> 4) * 33 + (lane & 15);             // rows 16 * block + 4 * quad + o
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int o = 0; o < 4; ++o)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) yt[(2 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + h) * 33 + col] = acc[h][r];
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) base[(4 * r + o) * 33 + nt * 16] = q[o * 2 + nt][r];
+    }
     __syncthreads();
     f32x16 acc2[2];
     int ybase[2];
@@ -1454,41 +1149,11 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_f
         }
 }
 
-// Winograd F(2,5) weight transform U = G g (points 0, +-1, +-2, inf) in fp64, packed for wino_taps:
-//   out[((nt*KS + ks)*64 + lane)*6 + p] = U_p(c = 2*ks + (lane>>5), n = nt*32 + (lane&31)),  KS = cinp / 2
-// followed by 8 zero k-steps (register-ring over-read).  conv weight layout [cout][cin][5].
-static void pack_w(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo = 0, int c_hi = -1) {
-  static const double G[6][5] = {{1.0 / 4, 0, 0, 0, 0},
-                                 {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
-                                 {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                 {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3},
-                                 {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3},
-                                 {0, 0, 0, 0, 1}};
-  if (c_hi < 0) c_hi = cin_full;
-  const int cin = c_hi - c_lo;
-  const int cinp = (cin + 7) / 8 * 8;
-  const int nt_n = (cout + 31) / 32, KS = cinp / 2;
-  const size_t base = blob.size();
-  blob.resize(base + ((size_t)nt_n * KS + 8) * 64 * 6, 0.f);
-  for (int nt = 0; nt < nt_n; ++nt)
-    for (int ks = 0; ks < KS; ++ks)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int ci = 2 * ks + (lane >> 5), n = nt * 32 + (lane & 31);
-        if (ci >= cin || n >= cout) continue;
-        const float* g = w + ((size_t)n * cin_full + (c_lo + ci)) * 5;
-        for (int p = 0; p < 6; ++p) {
-          double u = 0.0;
-          for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
-          blob[base + (((size_t)nt * KS + ks) * 64 + lane) * 6 + p] = (float)u;
-        }
-      }
-  while (blob.size() % 4) blob.push_back(0.f);
-}
-
 // Winograd F(4,5) weight transform (points 0, +-1, +-2, +-1/2, inf) in fp64, packed for w4_taps:
 //   out[((wv*KS + ks)*64 + lane)*16 + p*2 + nt] = U_p(c = 4*ks + (lane>>4), n = wv*32 + nt*16 + (lane&15)),  KS = cin/4
 // followed by 8 zero k-steps (register-ring over-read).  conv weight layout [cout][cin][5].
-static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin) {
+static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin, int cinp = 0) {
+  if (cinp == 0) cinp = cin;
   static const double G[8][5] = {{-1, 0, 0, 0, 0},
                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -1497,7 +1162,7 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin)
                                  {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
                                  {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
                                  {0, 0, 0, 0, 1}};
-  const int nw = cout / 32, KS = cin / 4;
+  const int nw = cout / 32, KS = cinp / 4;
   const size_t base = blob.size();
   blob.resize(base + ((size_t)nw * KS + 8) * 64 * 16, 0.f);
   for (int wv = 0; wv < nw; ++wv)
@@ -1505,6 +1170,7 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin)
       for (int lane = 0; lane < 64; ++lane)
         for (int nt = 0; nt < 2; ++nt) {
           const int ci = 4 * ks + (lane >> 4), n = wv * 32 + nt * 16 + (lane & 15);
+          if (ci >= cin) continue;                     // channel padding (the 4-channel network input -> 16)
           const float* g = w + ((size_t)n * cin + ci) * 5;
           for (int p = 0; p < 8; ++p) {
             double u = 0.0;
@@ -1554,8 +1220,9 @@ static void pack_b4n1_1x1(std::vector<float>& blob, const float* w, int cout, in
 }
 
 // 1x1 conv for the 16x16x4 MFMA: out[((wv*KS + ks)*64 + lane)*2 + nt] = W(c = 4*ks + (lane>>4), n = wv*32 + nt*16 + (lane&15))
-static void pack_b4_1x1(std::vector<float>& blob, const float* w, int cout, int cin) {
-  const int nw = cout / 32, KS = cin / 4;
+static void pack_b4_1x1(std::vector<float>& blob, const float* w, int cout, int cin, int cinp = 0) {
+  if (cinp == 0) cinp = cin;
+  const int nw = cout / 32, KS = cinp / 4;
   const size_t base = blob.size();
   blob.resize(base + (size_t)nw * KS * 64 * 2, 0.f);
   for (int wv = 0; wv < nw; ++wv)
@@ -1563,7 +1230,7 @@ static void pack_b4_1x1(std::vector<float>& blob, const float* w, int cout, int 
       for (int lane = 0; lane < 64; ++lane)
         for (int nt = 0; nt < 2; ++nt) {
           const int ci = 4 * ks + (lane >> 4), n = wv * 32 + nt * 16 + (lane & 15);
-          blob[base + (((size_t)wv * KS + ks) * 64 + lane) * 2 + nt] = w[(size_t)n * cin + ci];
+          if (ci < cin) blob[base + (((size_t)wv * KS + ks) * 64 + lane) * 2 + nt] = w[(size_t)n * cin + ci];
         }
   while (blob.size() % 4) blob.push_back(0.f);
 }
@@ -1669,19 +1336,17 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     while (blob.size() % 4) blob.push_back(0.f);
-    const bool w4 = (r >= 2 && r <= 5) || r >= 10;   // downs.1, downs.2, mid blocks: F(4,5), two n-tiles per wave
-    const bool w4u = r >= 6 && r <= 9;               // ups.0, ups.1: F(4,5), one n-tile per wave; downs.0: F(2,5)
+    const bool w4u = r >= 6 && r <= 9;               // ups.0, ups.1: F(4,5) with one n-tile per wave; the rest: two
+    const int cinp = R.cin < 16 ? 16 : R.cin;        // the 4-channel network input is padded to one ring of 4 k-steps
     W.a.wpk = blob.size();
-    if (w4) pack_w4(blob, tensors[R.t_w0], R.cout, R.cin);
-    else if (w4u) pack_w4n1(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin);
-    else pack_w(blob, tensors[R.t_w0], R.cout, R.cin);
+    if (w4u) pack_w4n1(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin);
+    else pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, cinp);
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
     W.b.wpk = blob.size();
-    if (w4) pack_w4(blob, tensors[R.t_w1], R.cout, R.cout);
-    else if (w4u) pack_w4n1(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout);
-    else pack_w(blob, tensors[R.t_w1], R.cout, R.cout);
+    if (w4u) pack_w4n1(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout);
+    else pack_w4(blob, tensors[R.t_w1], R.cout, R.cout);
     W.b.bias = push(blob, tensors[R.t_b1], R.cout);
     W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
     W.b.beta = push(blob, tensors[R.t_be1], R.cout);
@@ -1690,7 +1355,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.res_wpk = W.res_bias = 0;
     if (R.res) {
       W.res_wpk = blob.size();
-      if (w4) pack_b4_1x1(blob, tensors[R.t_rw], R.cout, R.cin); else pack_b(blob, tensors[R.t_rw], R.cout, R.cin, 1, taps1, false);
+      if (!w4u) pack_b4_1x1(blob, tensors[R.t_rw], R.cout, R.cin, cinp);   // (ups.*.0: per-chunk packs below)
       W.res_bias = push(blob, tensors[R.t_rb], R.cout);
     }
     W.a_c1 = W.res_c0 = W.res_c1 = 0;
@@ -1720,7 +1385,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{2, 0}, true);
     u->up[i].bias = push(blob, tensors[s.t_up[i][1]], cu);
   }
-  u->fin.wpk = blob.size(); pack_w(blob, tensors[s.t_final[0]], 32, 32);
+  u->fin.wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32);
   u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
   u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
   u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
@@ -1781,18 +1446,17 @@ static const double kLayerFlops[kNumLayers] = {
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64};
 
 // MFMA FLOPs actually issued per trajectory (Winograd convs: 6 products per output pair; channel / N padding included)
-static constexpr double wino_flops(double cinp, double cout, double L) { return (cinp / 2) * 6 * (cout / 32) * (L / 16) * 4096.0 / 4; }
 static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // F(4,5), L = 16
 static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
 }
 static const double kLayerMfmaFlops[kNumLayers] = {
-    wino_flops(8, 32, 64) + direct_flops(1, 8, 32, 64) + 3 * wino_flops(32, 32, 64) + direct_flops(3, 32, 32, 32) +
+    4 * (wino4_flops(16, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 16, 32, 64) + direct_flops(3, 32, 32, 32) +
     2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) + direct_flops(3, 64, 64, 16) +
     wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) + 7 * wino4_flops(128, 128) +
     wino4_flops(256, 64) + direct_flops(1, 256, 64, 16) + 3 * wino4_flops(64, 64) + 2 * direct_flops(2, 64, 64, 16) +
     2 * (wino4_flops(128, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 128, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
-    wino_flops(32, 32, 64) + direct_flops(1, 32, 32, 64)};
+    4 * wino4_flops(32, 32) + direct_flops(1, 32, 32, 64)};
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
                              hipStream_t st, hipEvent_t* ev, int reps) {
