@@ -3,7 +3,9 @@ the constraint table from all 32W paths + one guided sampling call for the 32 lo
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from mmd_amd import synth
+from mmd_amd import synth, _lib
+if os.environ.get("MMD_AMD_LIB"):
+    _lib.LIB_PATH = os.environ["MMD_AMD_LIB"]
 from mmd_amd.diffusion_model import GaussianDiffusionModel
 from mmd_amd.multi_robot import MultiRobotSampler
 from mmd_amd.temporal_unet import TemporalUnet
