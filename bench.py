@@ -174,12 +174,14 @@ def main():
             pmc = json.load(f).get(DOMINANT_LAYER)
         if pmc:
             traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
-    roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; fp32 MFMA implicit-im2col GEMMs, GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
+    roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; fp32 MFMA GEMMs, the 25 k=5 convs as Winograd F(4,5); GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
                 "achieved": dom_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
                 "flops_per_launch": flops[dom[0]],
-                # `achieved` counts ALGORITHMIC FLOPs (direct-convolution definition).  The down path runs
-                # its k=5 convs as Winograd F(2,5), so the matrix pipe issues fewer: this is its own utilisation.
+                # `achieved` counts ALGORITHMIC FLOPs (direct-convolution definition).  The k=5 convs run as
+                # Winograd F(4,5) in fp32, so the matrix pipe issues 0.45x of them and `frac` can exceed 1: `mfma_issued` is
+                # the pipe's own utilisation (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 = flops_per_launch below).
+                "note": "achieved = algorithmic (direct-conv) FLOPs / time; Winograd F(4,5) issues 0.45x of them, see mfma_issued",
                 "mfma_issued": {"flops_per_launch": mfma_flops[dom[0]],
                                 "achieved": mfma_flops[dom[0]] / (dom_ms * 1e-3) / 1e12,
                                 "frac": mfma_flops[dom[0]] / (dom_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
