@@ -346,7 +346,7 @@ __device__ __forceinline__ void zero6(f32x16 (&m)[6]) {
 // ----------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int W4_KSTRIDE = 64 * 16;    // floats per k-step of one wave's pack
-constexpr int W4_RD = 4;               // weight ring depth in k-steps
+constexpr int W4_RD = 2;               // weight ring depth in k-steps (4 costs 32 more VGPRs = spills: +4 % time)
 struct B16 { float4 q[4]; };           // q[j] = positions 2j, 2j+1 x n-tiles 0, 1
 
 __device__ __forceinline__ B16 load_b16(const float* __restrict__ p) {
