@@ -1,4 +1,4 @@
-"""Accuracy of Winograd F(2,5) (points 0, +-1, +-2, inf  /  0, +-1, +-1/2, inf) fp32 k5 convs in the TemporalUnet, against
+"""Accuracy of Winograd F(2,5) / F(4,5) fp32 k5 convs in the TemporalUnet (the kernel uses F(4,5)), against
 fp64 truth, next to the direct fp32 conv.  CPU emulation: every stride-1 k5 conv of the oracle UNet is replaced."""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -45,25 +45,26 @@ def cook_toom(points, m, r):
     return f(AT), f(G), f(BT)
 
 
-def check(points):
-    AT, G, BT = cook_toom(points, 2, 5)
+def check(points, m=2):
+    AT, G, BT = cook_toom(points, m, 5)
     rng = np.random.default_rng(0)
-    d, g = rng.standard_normal(6), rng.standard_normal(5)
+    d, g = rng.standard_normal(m + 4), rng.standard_normal(5)
     y = AT @ ((G @ g) * (BT @ d))
-    ref = np.array([np.dot(d[i:i + 5], g) for i in range(2)])
+    ref = np.array([np.dot(d[i:i + 5], g) for i in range(m)])
     assert np.allclose(y, ref, atol=1e-12), (y, ref)
     return AT, G, BT
 
 
 def make_conv(orig, AT, G, BT, dtype):
     AT_t, G_t, BT_t = (torch.tensor(M, dtype=dtype) for M in (AT, G, BT))
+    m = AT.shape[0]                                             # outputs per tile
     def conv(x, w, b=None, stride=1, padding=0, **kw):
         if w.shape[-1] != 5 or stride != 1:
             return orig(x, w, b, stride=stride, padding=padding, **kw)
         n, cin, L = x.shape
         U = torch.einsum('pk,oik->poi', torch.tensor(G, dtype=torch.float64), w.double()).to(dtype)   # host-side, fp64
         xp = F.pad(x, (2, 2))
-        d = xp.unfold(2, 6, 2)                                  # [n, cin, L/2, 6]
+        d = xp.unfold(2, m + 4, m)                              # [n, cin, L/m, m+4]
         V = torch.einsum('pj,nitj->pnit', BT_t, d)              # [6, n, cin, tiles]
         M = torch.einsum('poi,pnit->pnot', U, V)
         Y = torch.einsum('mp,pnot->notm', AT_t, M).reshape(n, w.shape[0], L)
@@ -83,11 +84,12 @@ for t in (0, 37, 99):
     F.conv1d = c1
     direct = O.unet_forward(sd, x, tt)
     print(f"t={t}: direct fp32 vs fp64 {rel_l2(direct.double(), truth):.2e}")
-    for name, pts in (("0,+-1,+-2", [0, 1, -1, 2, -2]), ("0,+-1,+-1/2", [0, 1, -1, Fr(1, 2), Fr(-1, 2)])):
-        AT, G, BT = check(pts)
+    for name, m, pts in (("F(2,5) 0,+-1,+-2", 2, [0, 1, -1, 2, -2]), ("F(2,5) 0,+-1,+-1/2", 2, [0, 1, -1, Fr(1, 2), Fr(-1, 2)]),
+                         ("F(4,5) 0,+-1,+-2,+-1/2 (the kernel's)", 4, [0, 1, -1, 2, -2, Fr(1, 2), Fr(-1, 2)])):
+        AT, G, BT = check(pts, m)
         F.conv1d = make_conv(c1, AT, G, BT, torch.float32)
         try:
             out = O.unet_forward(sd, x, tt)
         finally:
             F.conv1d = c1
-        print(f"   winograd F(2,5) [{name}] fp32 vs fp64 {rel_l2(out.double(), truth):.2e}   vs direct fp32 {rel_l2(out, direct):.2e}")
+        print(f"   winograd {name} fp32 vs fp64 {rel_l2(out.double(), truth):.2e}   vs direct fp32 {rel_l2(out, direct):.2e}")
