@@ -161,14 +161,6 @@ __device__ __forceinline__ void mfma_a(f32x16 (&acc)[MT_W], const float (&a)[4][
     for (int mt = 0; mt < MT_W; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][mt], bq[q], acc[mt], 0, 0, 0);
 }
 
-template <int MT_W>
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W], int aoff,
-                                           const float4 b) {
-  float a[4][MT_W];
-  load_a<MT_W>(a, slab, abase, aoff);
-  mfma_a<MT_W>(acc, a, b);
-}
-
 // A fragments are double-buffered in registers (the LDS reads of k-group g+1 are issued before the 4*MT_W MFMAs of
 // group g), B fragments ride a 4-deep register ring fed straight from L2: a lone wave keeps the matrix pipe busy, so a
 // co-resident wave's epilogue overlaps instead of stalling it.
@@ -176,14 +168,8 @@ template <int NTAPS, int CP, int STR, int MT_W>
 __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W],
                                           const float4* __restrict__ wp) {
   constexpr int GPT = CP / 8;   // k-groups (of 4 k-pairs) per tap
-  if constexpr (GPT % 4 != 0) {
-    // tiny K (the 4-channel input layer, padded to 8): everything in flight at once
-    float4 b[NTAPS * GPT];
-#pragma unroll
-    for (int g = 0; g < NTAPS * GPT; ++g) b[g] = wp[(size_t)g * 64];
-#pragma unroll
-    for (int g = 0; g < NTAPS * GPT; ++g) mfma_group<MT_W>(acc, slab, abase, (g / GPT) * STR + (g % GPT) * 8, b[g]);
-  } else {
+  static_assert(GPT % 4 == 0, "k-groups are unrolled by the ring depth");
+  {
     const float4* p = wp;
     float4 b0 = p[0], b1 = p[64], b2 = p[128], b3 = p[192];
     float a0[4][MT_W], a1[4][MT_W];
@@ -217,23 +203,10 @@ __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab
   }
 }
 
-// sum over the CPG lanes of a GroupNorm group and over both half-waves (rows r and r+4 live in lanes l and l+32)
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {   // v + v[DPP-permuted lane] in one VALU op
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-template <int CPG>
-__device__ __forceinline__ float group_allreduce(float v) {
-  // butterfly inside a 16-lane DPP row: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
-  static_assert(CPG == 4 || CPG == 8 || CPG == 16, "GroupNorm group = 4, 8 or 16 adjacent lanes");
-  v = dpp_add<0xB1>(v);
-  v = dpp_add<0x4E>(v);
-  if constexpr (CPG >= 8) v = dpp_add<0x141>(v);
-  if constexpr (CPG >= 16) v = dpp_add<0x140>(v);
-  v += __shfl_xor(v, 32);
-  return v;
-}
-
 // ----------------------------------------------------------------------------------------------------------------
 enum { TAIL_NONE = 0, TAIL_DOWN = 1, TAIL_UP = 2 };
 constexpr int MAX_IDENT = 3;
@@ -263,9 +236,8 @@ struct ChainCfg {
   static constexpr int WN = CM / 32, WM = 4 / WN;
   static constexpr int RW = 32 * MT_W, SW = RW / L, SPB = WM * SW, SROWS = L + 4;
   static constexpr bool SHARE = RES0 == RES_IDENT;         // x is staged straight into the H slab
-  // Sample stride.  With L = 16 a 32-row A tile spans two samples (rows s*stride + l*STR, STR odd): pad the stride to
-  // 16 (mod 32) floats so the second sample's rows fall on the other 16 banks (without the pad rows 0-3 of sample 1
-  // alias rows 12-15 of sample 0: a 2-way conflict on every A-fragment read, SQ_LDS_BANK_CONFLICT = 46 % of LDS cycles).
+  // Sample stride.  With L = 16 an A tile spans all four samples (rows s*stride + l*STR, STR odd): pad the stride to
+  // 16 (mod 32) floats so that odd samples fall on the other 16 banks.
   static constexpr int spad(int n) { return L == 16 ? (16 - n % 32 + 32) % 32 : 0; }
   static constexpr int XSS = SROWS * XSTR + spad(SROWS * XSTR);
   static constexpr int HSS = SROWS * HSTR + spad(SROWS * HSTR);
@@ -287,7 +259,7 @@ __device__ __forceinline__ void fill(f32x16 (&acc)[MT_W], float v) {
 }
 
 #ifndef MMD_ABL
-#define MMD_ABL 0   // ablation builds only: 1 = no GroupNorm/Mish, 3 = no MFMA loops
+#define MMD_ABL 0   // ablation builds only (tools/ablate.sh): 1 = no GroupNorm/Mish
 #endif
 // A register tile written into a slab laid out for another stage: rows (sample, position) and columns keep their meaning,
 // only the strides change.  SRC gives the producing stage's tiling (which wave owns which samples / channel slice).
@@ -326,21 +298,14 @@ __device__ __forceinline__ float group_colsum(float v) {
   return v;
 }
 
-__device__ __forceinline__ void zero6(f32x16 (&m)[6]) {
-#pragma unroll
-  for (int p = 0; p < 6; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m[p][r] = 0.f;
-}
-
 // ----------------------------------------------------------------------------------------------------------------
-// Winograd F(4,5) for the L = 16 level (downs.2 + mid blocks: 55 % of the network's FLOPs): four outputs from eight
-// products instead of twenty (points 0, +-1, +-2, +-1/2, inf).  The four samples give 4 x 4 = 16 output quads, one
-// v_mfma_f32_16x16x4_f32 M tile: a GEMM row is (sample, quad t) = rows 4t .. 4t+3 of a sample.  C/D layout of that
-// instruction: lane = 16 * sample + column, register = quad, so a lane holds ALL 16 positions of one (sample, channel)
-// in 4 outputs x 4 registers, and a GroupNorm group (16 channels at C = 128) is exactly one 16-lane DPP row: the
-// statistics need no LDS and no cross-half shuffles.  A wave owns 32 channels = two 16-column n-tiles x 8 positions =
-// 16 accumulators of 4 registers.  Input transform: 8 ds_read_b32 + 26 VALU per 16 MFMAs (K step = 4 channels), weights
+// Winograd F(4,5) for every stride-1 k=5 conv: four outputs from eight products instead of twenty (points 0, +-1, +-2,
+// +-1/2, inf).  A GEMM row is (sample, quad t) = rows 4t .. 4t+3 of a sample; the 4 samples x L / 4 quads are L / 16 M
+// tiles of v_mfma_f32_16x16x4_f32.  C/D layout of that instruction: lane = 16 * (row / 4) + column, register = row % 4
+// = quad, so a lane holds 16 consecutive positions of one (sample, channel) in 4 outputs x 4 registers (at L = 16: all
+// of them, and a GroupNorm group of 16 channels is exactly one 16-lane DPP row; at L = 32 / 64 two / four row blocks
+// per sample).  Down path / mid / final block: a wave owns one M tile x 32 channels = two 16-column n-tiles x 8
+// positions = 16 accumulators of 4 registers.  Input transform: 8 ds_read_b32 + 26 VALU per 16 MFMAs (K step = 4 channels), weights
 // packed [wave][k-step][lane][8 positions][2 n-tiles] (fp64-transformed, 64 B per lane and k-step).  fp32 throughout;
 // 1.9e-6 relative against an fp64-accumulated forward (tools/dbg/winograd_accuracy.py).
 // ----------------------------------------------------------------------------------------------------------------
@@ -531,7 +496,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
 
   f32x4 m[16], res[8];
   auto conv_h = [&](const float4* w, const float4* next) {
-    if (MMD_ABL != 3) w4_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w, CF::CM), ring);
+    w4_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w, CF::CM), ring);
     if (next) w4_ring_load(ring, wlane(next, CF::CM));
     w4_out(acc, m);
   };
@@ -546,7 +511,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   };
 
   // =================== RTB 0 (64 -> 128, 1x1 residual conv) ===================
-  if (MMD_ABL != 3) w4_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, wlane(a.r0.wa, CF::C0P), ring);
+  w4_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, wlane(a.r0.wa, CF::C0P), ring);
   w4_ring_load(ring, wlane(a.r0.wb, CF::CM));
   w4_out(acc, m);
   {
@@ -616,7 +581,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     }
   }
 
-  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct (32x32x2 tiles as in chain_body_w) ===================
+  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32 ===================
   if constexpr (CF::TAIL == TAIL_DOWN) {
     __syncthreads();
     quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
@@ -626,7 +591,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
     const int r = lane & 31;
     int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
-    if (MMD_ABL != 3) mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
+    mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
   }
 }
 
@@ -764,7 +729,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 
   f32x4 m[8], acc[4], res[4];
   auto conv_h = [&](const float4* w, const float4* next) {
-    if (MMD_ABL != 3) w4n1_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w, CF::CM), ring);
+    w4n1_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w, CF::CM), ring);
     if (next) w4n1_ring_load(ring, wlane(next, CF::CM));
     w4n1_out(acc, m);
   };
@@ -784,20 +749,20 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   };
 
   // =================== RTB 0: cat(x, skip) -> CM, 1x1-conv residual ===================
-  if (MMD_ABL != 3) w4n1_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, wlane(a.r0.wa, CF::C0P), ring);
+  w4n1_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, wlane(a.r0.wa, CF::C0P), ring);
   w4n1_ring_load(ring, wlane(a.wa0_c1, CF::C1P));
   {
     const float br = a.br[col];
 #pragma unroll
     for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
   }
-  if (MMD_ABL != 3) res_chunk(std::integral_constant<int, CF::C0P>{}, a.wr_c0);
+  res_chunk(std::integral_constant<int, CF::C0P>{}, a.wr_c0);
   __syncthreads();                                            // chunk 0 has been consumed by every wave
   quad_to_stage<SKIP_L, SKIP_CM, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
   __syncthreads();
-  if (MMD_ABL != 3) w4n1_taps<CF::C1P, CF::XSTR, false>(m, xslab, xbase, wlane(a.wa0_c1, CF::C1P), ring);
+  w4n1_taps<CF::C1P, CF::XSTR, false>(m, xslab, xbase, wlane(a.wa0_c1, CF::C1P), ring);
   w4n1_ring_load(ring, wlane(a.r0.wb, CF::CM));
-  if (MMD_ABL != 3) res_chunk(std::integral_constant<int, CF::C1P>{}, a.wr_c1);
+  res_chunk(std::integral_constant<int, CF::C1P>{}, a.wr_c1);
   w4n1_out(acc, m);
   TR(trb + 1);
   if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col]);
@@ -865,7 +830,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
       int ub[MT_W];
 #pragma unroll
       for (int i = 0; i < MT_W; ++i) ub[i] = hb[i] + (1 + pass) * CF::HSTR;
-      if (MMD_ABL != 3) mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wnt * G) * 64 + lane);
+      mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wnt * G) * 64 + lane);
     }
   }
 }
@@ -963,7 +928,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       B16 ring[W4_RD];
       const float* w0 = reinterpret_cast<const float*>(f.wpk) + lane * 16;
       w4_ring_load(ring, w0);
-      if (MMD_ABL != 3) w4_taps<32, FIN_STR, true>(m, lds, wave * FIN_SS + 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
+      w4_taps<32, FIN_STR, true>(m, lds, wave * FIN_SS + 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
       w4_out(q, m);
     }
     {
@@ -988,7 +953,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fill<2>(acc2, col < 4 ? f.w1_bias[col] : 0.f);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) ybase[mt] = (mt * 32 + (lane & 31)) * 33 + hi;
-    if (MMD_ABL != 3) mfma_taps<1, 32, 33, 2>(acc2, yt, ybase, f.w1_pk + lane);
+    mfma_taps<1, 32, 33, 2>(acc2, yt, ybase, f.w1_pk + lane);
     if (col < 4 && n0 + wave < a.n) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
