@@ -220,7 +220,7 @@ struct ChainArgs {
   const float* in0;                      // [n, L, C0] network input (first chain only)
   RtbPtrs r0;
   const float4* wa0_c1;                  // conv A pack of the second input chunk (C1 > 0)
-  const float4* wr_c0; const float4* wr_c1; const float* br;   // residual 1x1 conv packs per chunk
+  const float* br;                       // bias of the 1x1 residual conv (its weights ride in the conv A packs)
   RtbPtrs ri[MAX_IDENT];
   const float4* wt; const float* bt;     // tail conv pack(s), bias
   int n;
@@ -310,21 +310,30 @@ __device__ __forceinline__ float group_colsum(float v) {
 // 1.9e-6 relative against an fp64-accumulated forward (tools/dbg/winograd_accuracy.py).
 // ----------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int W4_KSTRIDE = 64 * 16;    // floats per k-step of one wave's pack
 constexpr int W4_RD = 2;               // weight ring depth in k-steps (4 costs 32 more VGPRs = spills: +4 % time)
-struct B16 { float4 q[4]; };           // q[j] = positions 2j, 2j+1 x n-tiles 0, 1
-
-__device__ __forceinline__ B16 load_b16(const float* __restrict__ p) {
-  B16 b;
+// Weights of one k-step for one lane: NQ float4 = 8 positions x NT n-tiles (index p * NT + nt), plus, for a conv with a
+// fused 1x1 residual conv, one more float4 whose .x / .y are the residual weights of n-tile 0 / 1.
+template <int NQ> struct BQ { float4 q[NQ]; };
+template <int NQ>
+__device__ __forceinline__ BQ<NQ> load_bq(const float* __restrict__ p) {
+  BQ<NQ> b;
   const float4* p4 = reinterpret_cast<const float4*>(p);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) b.q[j] = p4[j];
+  for (int j = 0; j < NQ; ++j) b.q[j] = p4[j];
   return b;
 }
-__device__ __forceinline__ void w4_ring_load(B16 (&b)[W4_RD], const float* __restrict__ wp) {
+template <int NQ>
+__device__ __forceinline__ void w4_ring_load(BQ<NQ> (&b)[W4_RD], const float* __restrict__ wp) {
 #pragma unroll
-  for (int j = 0; j < W4_RD; ++j) b[j] = load_b16(wp + j * W4_KSTRIDE);
+  for (int j = 0; j < W4_RD; ++j) b[j] = load_bq<NQ>(wp + j * 64 * 4 * NQ);
   MMD_PIN_LOADS();
+}
+template <int I>
+__device__ __forceinline__ float f4at(const float4& v) {
+  if constexpr (I == 0) return v.x;
+  else if constexpr (I == 1) return v.y;
+  else if constexpr (I == 2) return v.z;
+  else return v.w;
 }
 template <int STR>
 __device__ __forceinline__ void load_d8(float (&d)[8], const float* s) {
@@ -342,45 +351,63 @@ __device__ __forceinline__ void w4_transform(float (&v)[8], const float (&d)[8])
   const float e3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), o3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
   v[5] = e3 + o3; v[6] = e3 - o3;
 }
-// V = B^T d (8 slab rows -> 8 positions), then 16 MFMAs: m[p * 2 + nt] += V_p x U_p[nt]
-template <bool ZERO>
-__device__ __forceinline__ void w4_step(f32x4 (&m)[16], const float (&d)[8], const B16& b) {
-  if constexpr (ZERO) {
+// V = B^T d (8 slab rows -> 8 positions), then 8 * NT MFMAs: m[p * NT + nt] += V_p x U_p[nt].  RES: the stage's 1x1
+// residual conv rides along -- its A operands are the untransformed rows 4t + 2 .. 4t + 5 = d[2..5] already in
+// registers, its weights the last float4 of the fragment: res[o * NT + nt] += d[2 + o] x Wr[nt], no extra LDS read,
+// no separate loop, no exposed weight latency.
+template <int NT, bool RES, bool ZERO, int P = 0>
+__device__ __forceinline__ void w4_mfma_pos(f32x4 (&m)[8 * NT], const float (&v)[8], const BQ<2 * NT + (RES ? 1 : 0)>& b) {
+  if constexpr (P < 8) {
+    if constexpr (NT == 2) {
+      m[P * 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[P], f4at<(P * 2) % 4>(b.q[(P * 2) / 4]), m[P * 2], 0, 0, 0);
+      m[P * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[P], f4at<(P * 2 + 1) % 4>(b.q[(P * 2 + 1) / 4]), m[P * 2 + 1], 0, 0, 0);
+    } else {
+      m[P] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[P], f4at<P % 4>(b.q[P / 4]), m[P], 0, 0, 0);
+    }
+    w4_mfma_pos<NT, RES, ZERO, P + 1>(m, v, b);
+  }
+}
+template <int NT, bool RES, bool ZERO>
+__device__ __forceinline__ void w4_step(f32x4 (&m)[8 * NT], f32x4 (&res)[4 * NT], const float (&d)[8],
+                                        const BQ<2 * NT + (RES ? 1 : 0)>& b) {
+  if constexpr (ZERO) {   // first k-step of a conv: srcC = inline constant 0 instead of clearing the accumulators
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) m[i] = z;
+    for (int i = 0; i < 8 * NT; ++i) m[i] = z;
   }
   float v[8];
   w4_transform(v, d);
+  w4_mfma_pos<NT, RES, ZERO>(m, v, b);
+  if constexpr (RES) {
+    const float4 wr = b.q[2 * NT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    m[4 * j + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j], b.q[j].x, m[4 * j + 0], 0, 0, 0);
-    m[4 * j + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j], b.q[j].y, m[4 * j + 1], 0, 0, 0);
-    m[4 * j + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j + 1], b.q[j].z, m[4 * j + 2], 0, 0, 0);
-    m[4 * j + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * j + 1], b.q[j].w, m[4 * j + 3], 0, 0, 0);
+    for (int o = 0; o < 4; ++o) {
+      res[o * NT] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[2 + o], wr.x, res[o * NT], 0, 0, 0);
+      if constexpr (NT == 2) res[o * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[2 + o], wr.y, res[o * 2 + 1], 0, 0, 0);
+    }
   }
 }
 
 // m += conv over CP channels of a slab; abase = lane's offset of (sample, slab row 4 * quad, channel lane >> 4);
-// b = ring pre-loaded with k-steps 0..3 of wp
-template <int CP, int STR, bool FRESH>
-__device__ __forceinline__ void w4_taps(f32x4 (&m)[16], const float* slab, int abase, const float* __restrict__ wp,
-                                        B16 (&b)[W4_RD]) {
-  constexpr int KS = CP / 4, RD = W4_RD;
+// b = ring pre-loaded with the first W4_RD k-steps of wp.  FRESH: the accumulators start at zero.
+template <int CP, int STR, int NT, bool RES, bool FRESH>
+__device__ __forceinline__ void w4_taps(f32x4 (&m)[8 * NT], f32x4 (&res)[4 * NT], const float* slab, int abase,
+                                        const float* __restrict__ wp, BQ<2 * NT + (RES ? 1 : 0)> (&b)[W4_RD]) {
+  constexpr int KS = CP / 4, RD = W4_RD, NQ = 2 * NT + (RES ? 1 : 0), KSTRIDE = 64 * 4 * NQ;
   static_assert(KS % RD == 0, "k-steps are unrolled by the ring depth");
   const float* p = wp;
   const float* s = slab + abase;
   float d[2][8];
   load_d8<STR>(d[0], s);
   auto iter = [&](auto first) {
-    p += RD * W4_KSTRIDE;
+    p += RD * KSTRIDE;
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
       load_d8<STR>(d[(j + 1) & 1], s + 4 * (j + 1));   // (past the last k-step this reads the next slab row and is unused)
       MMD_PIN_LOADS();
-      if (decltype(first)::value && j == 0) w4_step<true>(m, d[0], b[0]);
-      else w4_step<false>(m, d[j & 1], b[j]);
-      b[j] = load_b16(p + j * W4_KSTRIDE);
+      if (decltype(first)::value && j == 0) w4_step<NT, RES, true>(m, res, d[0], b[0]);
+      else w4_step<NT, RES, false>(m, res, d[j & 1], b[j]);
+      b[j] = load_bq<NQ>(p + j * KSTRIDE);
       MMD_PIN_LOADS();
     }
     s += 4 * RD;
@@ -483,11 +510,14 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
   const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
   const int col0 = wnq * 32 + (lane & 15), col1 = col0 + 16;            // C/D fragment: this lane's channels
-  B16 ring[W4_RD];
+  // conv A of the first RTB carries the 1x1 residual conv (5 float4 per lane and k-step), all other convs 4
+  BQ<5> ring5[W4_RD];
+  BQ<4> ring[W4_RD];
   auto wlane = [&](const float4* w, int cp) {
-    return reinterpret_cast<const float*>(w) + (size_t)wnq * (cp / 4) * W4_KSTRIDE + lane * 16;
+    return reinterpret_cast<const float*>(w) + ((size_t)wnq * (cp / 4) * 64 + lane) * 16;
   };
-  w4_ring_load(ring, wlane(a.r0.wa, CF::C0P));
+  const float* w0 = reinterpret_cast<const float*>(a.r0.wa) + ((size_t)wnq * (CF::C0P / 4) * 64 + lane) * 20;
+  w4_ring_load<5>(ring5, w0);
   if constexpr (FIRST)     // the network input, channels-last [n, 64, 4] in HBM (channels 4..15 of the slab are zero)
     stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
@@ -496,8 +526,8 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
 
   f32x4 m[16], res[8];
   auto conv_h = [&](const float4* w, const float4* next) {
-    w4_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w, CF::CM), ring);
-    if (next) w4_ring_load(ring, wlane(next, CF::CM));
+    w4_taps<CF::CM, CF::HSTR, 2, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
+    if (next) w4_ring_load<4>(ring, wlane(next, CF::CM));
     w4_out(acc, m);
   };
   auto gn = [&](const float* b, const float* g, const float* be) {
@@ -510,31 +540,18 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     for (int o = 0; o < 4; ++o) { acc[o * 2] += v0; acc[o * 2 + 1] += v1; }
   };
 
-  // =================== RTB 0 (64 -> 128, 1x1 residual conv) ===================
-  w4_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, wlane(a.r0.wa, CF::C0P), ring);
-  w4_ring_load(ring, wlane(a.r0.wb, CF::CM));
-  w4_out(acc, m);
+  // =================== RTB 0 (C0 -> CM) with its 1x1 residual conv fused into conv A ===================
   {
-    // res[o * 2 + nt] = x (rows 4t + o) * Wr: 16 k-steps of 4 channels, pack [wave][k-step][lane][2 n-tiles]
-    const float2* wr = reinterpret_cast<const float2*>(a.wr_c0) + (size_t)wnq * (CF::C0P / 4) * 64 + lane;
     const float br0 = a.br[col0], br1 = a.br[col1];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       res[o * 2] = f32x4{br0, br0, br0, br0};
       res[o * 2 + 1] = f32x4{br1, br1, br1, br1};
     }
-    const float* xr = xslab + xbase + 2 * CF::XSTR;
-#pragma unroll 2
-    for (int ks = 0; ks < CF::C0P / 4; ++ks) {
-      const float2 b = wr[ks * 64];
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const float av = xr[o * CF::XSTR + 4 * ks];
-        res[o * 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.x, res[o * 2], 0, 0, 0);
-        res[o * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.y, res[o * 2 + 1], 0, 0, 0);
-      }
-    }
   }
+  w4_taps<CF::C0P, CF::XSTR, 2, true, true>(m, res, xslab, xbase, w0, ring5);
+  w4_ring_load<4>(ring, wlane(a.r0.wb, CF::CM));
+  w4_out(acc, m);
   TR(trb + 2);
   gn(a.r0.ba, a.r0.ga, a.r0.bea);
   add_cols(a.r0.tb);
@@ -601,63 +618,6 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
 // unit and nothing is exchanged between waves.  The input is the channel concat cat(x, skip): chunk 0 arrives in the x
 // slab from the previous stage, chunk 1 is the quad tile kept from the down path and is staged into the same slab.
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int W4N1_KSTRIDE = 64 * 8;
-struct B8 { float4 q[2]; };            // positions 0..3, 4..7 of the wave's n-tile
-__device__ __forceinline__ B8 load_b8(const float* __restrict__ p) {
-  B8 b;
-  b.q[0] = reinterpret_cast<const float4*>(p)[0];
-  b.q[1] = reinterpret_cast<const float4*>(p)[1];
-  return b;
-}
-__device__ __forceinline__ void w4n1_ring_load(B8 (&b)[W4_RD], const float* __restrict__ wp) {
-#pragma unroll
-  for (int j = 0; j < W4_RD; ++j) b[j] = load_b8(wp + j * W4N1_KSTRIDE);
-  MMD_PIN_LOADS();
-}
-template <bool ZERO>
-__device__ __forceinline__ void w4n1_step(f32x4 (&m)[8], const float (&d)[8], const B8& b) {
-  if constexpr (ZERO) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = z;
-  }
-  float v[8];
-  w4_transform(v, d);
-  const float bb[8] = {b.q[0].x, b.q[0].y, b.q[0].z, b.q[0].w, b.q[1].x, b.q[1].y, b.q[1].z, b.q[1].w};
-#pragma unroll
-  for (int p = 0; p < 8; ++p) m[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], bb[p], m[p], 0, 0, 0);
-}
-template <int CP, int STR, bool FRESH>
-__device__ __forceinline__ void w4n1_taps(f32x4 (&m)[8], const float* slab, int abase, const float* __restrict__ wp,
-                                          B8 (&b)[W4_RD]) {
-  constexpr int KS = CP / 4, RD = W4_RD;
-  static_assert(KS % RD == 0, "k-steps are unrolled by the ring depth");
-  const float* p = wp;
-  const float* s = slab + abase;
-  float d[2][8];
-  load_d8<STR>(d[0], s);
-  auto iter = [&](auto first) {
-    p += RD * W4N1_KSTRIDE;
-#pragma unroll
-    for (int j = 0; j < RD; ++j) {
-      load_d8<STR>(d[(j + 1) & 1], s + 4 * (j + 1));
-      MMD_PIN_LOADS();
-      if (decltype(first)::value && j == 0) w4n1_step<true>(m, d[0], b[0]);
-      else w4n1_step<false>(m, d[j & 1], b[j]);
-      b[j] = load_b8(p + j * W4N1_KSTRIDE);
-      MMD_PIN_LOADS();
-    }
-    s += 4 * RD;
-  };
-  if constexpr (FRESH) {
-    iter(std::true_type{});
-#pragma unroll 1
-    for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
-  } else {
-#pragma unroll 1
-    for (int ks = 0; ks < KS; ks += RD) iter(std::false_type{});
-  }
-}
 __device__ __forceinline__ void w4n1_out(f32x4 (&q)[4], const f32x4 (&m)[8]) {
   const f32x4 s1 = m[1] + m[2], t1 = m[1] - m[2];
   const f32x4 s2 = m[3] + m[4], t2 = m[3] - m[4];
@@ -718,51 +678,41 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
   const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
   const int col = nq * 16 + (lane & 15);
-  B8 ring[W4_RD];
+  // both chunks of conv A carry the 1x1 residual conv (3 float4 per lane and k-step), all other convs 2
+  BQ<3> ring3[W4_RD];
+  BQ<2> ring[W4_RD];
   auto wlane = [&](const float4* w, int cp) {
-    return reinterpret_cast<const float*>(w) + (size_t)nq * (cp / 4) * W4N1_KSTRIDE + lane * 8;
+    return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 8;
   };
-  w4n1_ring_load(ring, wlane(a.r0.wa, CF::C0P));
+  auto wlane3 = [&](const float4* w, int cp) {
+    return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
+  };
+  w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
   TR(trb + 0);
 
   f32x4 m[8], acc[4], res[4];
   auto conv_h = [&](const float4* w, const float4* next) {
-    w4n1_taps<CF::CM, CF::HSTR, true>(m, hslab, hbase, wlane(w, CF::CM), ring);
-    if (next) w4n1_ring_load(ring, wlane(next, CF::CM));
+    w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
+    if (next) w4_ring_load<2>(ring, wlane(next, CF::CM));
     w4n1_out(acc, m);
   };
   auto to_h = [&]() { quad1_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane); };
-  // res += x (rows 4t + o) * Wr over one chunk: pack [n-tile][k-step][lane]
-  auto res_chunk = [&](auto cp_tag, const float4* w) {
-    constexpr int CP = decltype(cp_tag)::value;
-    const float* wr = reinterpret_cast<const float*>(w) + (size_t)nq * (CP / 4) * 64 + lane;
-    const float* xr = xslab + xbase + 2 * CF::XSTR;
-#pragma unroll 4
-    for (int ks = 0; ks < CP / 4; ++ks) {
-      const float b = wr[ks * 64];
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-        res[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[o * CF::XSTR + 4 * ks], b, res[o], 0, 0, 0);
-    }
-  };
 
-  // =================== RTB 0: cat(x, skip) -> CM, 1x1-conv residual ===================
-  w4n1_taps<CF::C0P, CF::XSTR, true>(m, xslab, xbase, wlane(a.r0.wa, CF::C0P), ring);
-  w4n1_ring_load(ring, wlane(a.wa0_c1, CF::C1P));
+  // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
   {
     const float br = a.br[col];
 #pragma unroll
     for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
   }
-  res_chunk(std::integral_constant<int, CF::C0P>{}, a.wr_c0);
+  w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res, xslab, xbase, wlane3(a.r0.wa, CF::C0P), ring3);
+  w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
   __syncthreads();                                            // chunk 0 has been consumed by every wave
   quad_to_stage<SKIP_L, SKIP_CM, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
   __syncthreads();
-  w4n1_taps<CF::C1P, CF::XSTR, false>(m, xslab, xbase, wlane(a.wa0_c1, CF::C1P), ring);
-  w4n1_ring_load(ring, wlane(a.r0.wb, CF::CM));
-  res_chunk(std::integral_constant<int, CF::C1P>{}, a.wr_c1);
+  w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
+  w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
   w4n1_out(acc, m);
   TR(trb + 1);
   if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col]);
@@ -925,10 +875,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       // wave = sample: one 16-quad M tile x both n-tiles of the 32 channels
       f32x4 m[16];
-      B16 ring[W4_RD];
+      f32x4 nores[8];
+      BQ<4> ring[W4_RD];
       const float* w0 = reinterpret_cast<const float*>(f.wpk) + lane * 16;
-      w4_ring_load(ring, w0);
-      w4_taps<32, FIN_STR, true>(m, lds, wave * FIN_SS + 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
+      w4_ring_load<4>(ring, w0);
+      w4_taps<32, FIN_STR, 2, false, true>(m, nores, lds, wave * FIN_SS + 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
       w4_out(q, m);
     }
     {
@@ -1114,11 +1065,13 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_f
         }
 }
 
-// Winograd F(4,5) weight transform (points 0, +-1, +-2, +-1/2, inf) in fp64, packed for w4_taps:
-//   out[((wv*KS + ks)*64 + lane)*16 + p*2 + nt] = U_p(c = 4*ks + (lane>>4), n = wv*32 + nt*16 + (lane&15)),  KS = cin/4
-// followed by 8 zero k-steps (register-ring over-read).  conv weight layout [cout][cin][5].
-static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin, int cinp = 0) {
-  if (cinp == 0) cinp = cin;
+// Winograd F(4,5) weight transform U = G g (points 0, +-1, +-2, +-1/2, inf) in fp64, packed for w4_taps.  A wave slice
+// is NT 16-column n-tiles; per slice, k-step (4 channels) and lane: NF = 8 * NT floats U_p(c, n) at index p * NT + nt,
+// c = c_lo + 4 * ks + (lane >> 4), n = slice * 16 * NT + nt * 16 + (lane & 15); with a fused 1x1 residual conv (wres, layout
+// [cout][cin_full]) four more floats: Wr(c, n) for nt = 0, 1, then zeros.  Channels >= c_hi (padding up to cinp) are
+// zero; 8 zero k-steps follow the pack (register-ring over-read).  conv weight layout [cout][cin_full][5].
+static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi, int cinp, int NT,
+                    const float* wres) {
   static const double G[8][5] = {{-1, 0, 0, 0, 0},
                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -1127,81 +1080,28 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin,
                                  {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
                                  {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
                                  {0, 0, 0, 0, 1}};
-  const int nw = cout / 32, KS = cinp / 4;
+  const int NF = 8 * NT + (wres ? 4 : 0), nsl = cout / (16 * NT), KS = cinp / 4;
   const size_t base = blob.size();
-  blob.resize(base + ((size_t)nw * KS + 8) * 64 * 16, 0.f);
-  for (int wv = 0; wv < nw; ++wv)
+  blob.resize(base + ((size_t)nsl * KS + 8) * 64 * NF, 0.f);
+  for (int sl = 0; sl < nsl; ++sl)
     for (int ks = 0; ks < KS; ++ks)
       for (int lane = 0; lane < 64; ++lane)
-        for (int nt = 0; nt < 2; ++nt) {
-          const int ci = 4 * ks + (lane >> 4), n = wv * 32 + nt * 16 + (lane & 15);
-          if (ci >= cin) continue;                     // channel padding (the 4-channel network input -> 16)
-          const float* g = w + ((size_t)n * cin + ci) * 5;
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ci = c_lo + 4 * ks + (lane >> 4), n = sl * 16 * NT + nt * 16 + (lane & 15);
+          if (ci >= c_hi) continue;
+          float* out = &blob[base + (((size_t)sl * KS + ks) * 64 + lane) * NF];
+          const float* g = w + ((size_t)n * cin_full + ci) * 5;
           for (int p = 0; p < 8; ++p) {
             double u = 0.0;
             for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
-            blob[base + (((size_t)wv * KS + ks) * 64 + lane) * 16 + p * 2 + nt] = (float)u;
+            out[p * NT + nt] = (float)u;
           }
+          if (wres) out[8 * NT + nt] = wres[(size_t)n * cin_full + ci];
         }
-}
-
-// F(4,5) pack for one n-tile per wave (up path): out[((nq*KS + ks)*64 + lane)*8 + p] = U_p(c = c_lo + 4*ks + (lane>>4),
-// n = nq*16 + (lane&15)), KS = (c_hi - c_lo) / 4, followed by 8 zero k-steps
-static void pack_w4n1(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi) {
-  static const double G[8][5] = {{-1, 0, 0, 0, 0},
-                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
-                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
-                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
-                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
-                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
-                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
-                                 {0, 0, 0, 0, 1}};
-  const int nq_n = cout / 16, KS = (c_hi - c_lo) / 4;
-  const size_t base = blob.size();
-  blob.resize(base + ((size_t)nq_n * KS + 8) * 64 * 8, 0.f);
-  for (int nq = 0; nq < nq_n; ++nq)
-    for (int ks = 0; ks < KS; ++ks)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int ci = c_lo + 4 * ks + (lane >> 4), n = nq * 16 + (lane & 15);
-        const float* g = w + ((size_t)n * cin_full + ci) * 5;
-        for (int p = 0; p < 8; ++p) {
-          double u = 0.0;
-          for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
-          blob[base + (((size_t)nq * KS + ks) * 64 + lane) * 8 + p] = (float)u;
-        }
-      }
-}
-// 1x1 conv, one n-tile per wave: out[(nq*KS + ks)*64 + lane] = W(c = c_lo + 4*ks + (lane>>4), n = nq*16 + (lane&15))
-static void pack_b4n1_1x1(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi) {
-  const int nq_n = cout / 16, KS = (c_hi - c_lo) / 4;
-  const size_t base = blob.size();
-  blob.resize(base + (size_t)nq_n * KS * 64, 0.f);
-  for (int nq = 0; nq < nq_n; ++nq)
-    for (int ks = 0; ks < KS; ++ks)
-      for (int lane = 0; lane < 64; ++lane)
-        blob[base + ((size_t)nq * KS + ks) * 64 + lane] =
-            w[(size_t)(nq * 16 + (lane & 15)) * cin_full + c_lo + 4 * ks + (lane >> 4)];
-  while (blob.size() % 4) blob.push_back(0.f);
-}
-
-// 1x1 conv for the 16x16x4 MFMA: out[((wv*KS + ks)*64 + lane)*2 + nt] = W(c = 4*ks + (lane>>4), n = wv*32 + nt*16 + (lane&15))
-static void pack_b4_1x1(std::vector<float>& blob, const float* w, int cout, int cin, int cinp = 0) {
-  if (cinp == 0) cinp = cin;
-  const int nw = cout / 32, KS = cinp / 4;
-  const size_t base = blob.size();
-  blob.resize(base + (size_t)nw * KS * 64 * 2, 0.f);
-  for (int wv = 0; wv < nw; ++wv)
-    for (int ks = 0; ks < KS; ++ks)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int nt = 0; nt < 2; ++nt) {
-          const int ci = 4 * ks + (lane >> 4), n = wv * 32 + nt * 16 + (lane & 15);
-          if (ci < cin) blob[base + (((size_t)wv * KS + ks) * 64 + lane) * 2 + nt] = w[(size_t)n * cin + ci];
-        }
-  while (blob.size() % 4) blob.push_back(0.f);
 }
 
 struct ConvW { size_t wpk, bias, gamma, beta; };
-struct RtbW { ConvW a, b; size_t res_wpk, res_bias; int tb_off; size_t a_c1, res_c0, res_c1; };
+struct RtbW { ConvW a, b; size_t res_bias; int tb_off; size_t a_c1; };
 
 }  // namespace mmd
 
@@ -1249,8 +1149,6 @@ static ChainArgs args_chain(const mmd_unet_s* u, const int* rtb, int n_ident, co
   const RtbW& w0 = u->rtb[rtb[0]];
   a.r0 = rtb_ptrs(u, w0, t);
   a.wa0_c1 = reinterpret_cast<const float4*>(u->blob + w0.a_c1);
-  a.wr_c0 = reinterpret_cast<const float4*>(u->blob + w0.res_c0);
-  a.wr_c1 = reinterpret_cast<const float4*>(u->blob + w0.res_c1);
   a.br = u->blob + w0.res_bias;
   for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, u->rtb[rtb[1 + k]], t);
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
@@ -1301,39 +1199,30 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     while (blob.size() % 4) blob.push_back(0.f);
-    const bool w4u = r >= 6 && r <= 9;               // ups.0, ups.1: F(4,5) with one n-tile per wave; the rest: two
-    const int cinp = R.cin < 16 ? 16 : R.cin;        // the 4-channel network input is padded to one ring of 4 k-steps
+    const int NT = (r >= 6 && r <= 9) ? 1 : 2;       // ups.0, ups.1: one n-tile per wave; the rest: two
+    const int cinp = R.cin < 16 ? 16 : R.cin;        // the 4-channel network input is padded to 4 k-steps
+    const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
+    W.a_c1 = 0;
     W.a.wpk = blob.size();
-    if (w4u) pack_w4n1(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin);
-    else pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, cinp);
+    if (r == 6 || r == 8) {   // ups.*.0: input = cat(x, skip), staged chunk by chunk: one pack per chunk
+      const int half = R.cin / 2;
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres);
+      W.a_c1 = blob.size();
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
+    } else {
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres);
+    }
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
     W.b.wpk = blob.size();
-    if (w4u) pack_w4n1(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout);
-    else pack_w4(blob, tensors[R.t_w1], R.cout, R.cout);
+    pack_w4(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, R.cout, NT, nullptr);
     W.b.bias = push(blob, tensors[R.t_b1], R.cout);
     W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
     W.b.beta = push(blob, tensors[R.t_be1], R.cout);
     raw_cw[r] = push(blob, tensors[R.t_cw], (int64_t)R.cout * 32);
     raw_cb[r] = push(blob, tensors[R.t_cb], R.cout);
-    W.res_wpk = W.res_bias = 0;
-    if (R.res) {
-      W.res_wpk = blob.size();
-      if (!w4u) pack_b4_1x1(blob, tensors[R.t_rw], R.cout, R.cin, cinp);   // (ups.*.0: per-chunk packs below)
-      W.res_bias = push(blob, tensors[R.t_rb], R.cout);
-    }
-    W.a_c1 = W.res_c0 = W.res_c1 = 0;
-    if (r == 6 || r == 8) {   // ups.0.0 / ups.1.0: input = cat(x, skip): per-chunk packs for the K-chunked staging
-      const int half = R.cin / 2;
-      // a.wpk is repacked as chunk 0 (channels [0, half)); chunk 1 follows
-      W.a.wpk = blob.size(); pack_w4n1(blob, tensors[R.t_w0], R.cout, R.cin, 0, half);
-      W.a_c1 = blob.size(); pack_w4n1(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin);
-      W.res_c0 = blob.size(); pack_b4n1_1x1(blob, tensors[R.t_rw], R.cout, R.cin, 0, half);
-      W.res_c1 = blob.size(); pack_b4n1_1x1(blob, tensors[R.t_rw], R.cout, R.cin, half, R.cin);
-    } else if (R.res) {
-      W.res_c0 = W.res_wpk;
-    }
+    W.res_bias = R.res ? push(blob, tensors[R.t_rb], R.cout) : 0;
     W.tb_off = tb_off;
     tb_off += R.cout;
   }
@@ -1350,7 +1239,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{2, 0}, true);
     u->up[i].bias = push(blob, tensors[s.t_up[i][1]], cu);
   }
-  u->fin.wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32);
+  u->fin.wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 2, nullptr);
   u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
   u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
   u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
