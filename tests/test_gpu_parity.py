@@ -54,6 +54,17 @@ def test_unet_forward_input_range(scale):
     assert torch.isfinite(out).all() and rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
 
 
+def test_unet_forward_batch_independence():
+    """A trajectory's eps does not depend on which workgroup / wave slot it lands in: 2051 trajectories (513 workgroups,
+    the last one ragged) against the same rows evaluated in small batches -- bit-identical."""
+    model = _gc().hip_model(100)
+    x = torch.from_numpy(synth.synth_noise(91, (2051, H, D))).cuda()
+    big = model.model(x, 17)
+    for rows in ([0, 1, 2, 3], [5, 1030, 2046], [2047, 2048, 2049, 2050], [2050]):
+        small = model.model(x[rows].contiguous(), 17)
+        assert torch.equal(big[rows], small), rows
+
+
 def test_unet_forward_golden():
     g = np.load(os.path.join(GOLDEN, "g2_unet.npz"))
     model = _gc().hip_model(100)
