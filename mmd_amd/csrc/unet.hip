@@ -44,25 +44,29 @@ struct FinalArgs {
 };
 
 // Mish(y) = y * tanh(softplus(y)) = y * n / (n + 2), n = e^y (e^y + 2)   (torch.nn.Mish; softplus threshold 20).
-// GroupNorm affine + Mish of one activation in 10 VALU ops (every VALU op costs the SIMD ~5 cycles of MFMA issue):
-// y = x * sa + sb with sa = rstd * gamma, sb = beta - mean * sa folded per (sample, channel); the exponent argument
-// y * log2(e) comes from a second fma (sa2 = sa * log2 e, sb2 = sb * log2 e) instead of a multiply.  Clamping the
-// exponent at 20 makes n / (n + 2) round to 1 for y > 20 (n ~ 2.4e17), i.e. mish(y) = y up to one ulp, the softplus
-// threshold branch of torch.nn.Mish without a select.
-struct GnCoef { float sa, sb, sa2, sb2; };
+// GroupNorm affine + Mish + the add that follows it (time bias after conv A, residual after conv B) in 9 VALU ops per
+// activation (every VALU op costs the SIMD ~5 cycles of MFMA issue).  Everything is carried in units of log2(e):
+// yl = y * log2 e = x * sa + sb with sa = rstd * gamma * log2 e, sb = (beta - mean * rstd * gamma) * log2 e folded per
+// (sample, channel); e^y = exp2(yl); the 1 / log2 e is folded into the denominator: q = n / ((n + 2) log2 e), so
+// y * n / (n + 2) = yl * q, and the trailing add rides in the last fma.  Clamping the exponent at 20 makes n / (n + 2)
+// round to 1 for y > 20 (n ~ 2.4e17), i.e. mish(y) = y up to an ulp or two: the softplus threshold branch of
+// torch.nn.Mish without a select.
+struct GnCoef { float sa, sb; };
 __device__ __forceinline__ GnCoef gn_coef(float mean, float rstd, float gamma, float beta) {
+  constexpr float LOG2E = 1.44269504088896341f;
   GnCoef c;
-  c.sa = rstd * gamma;
-  c.sb = fmaf(-mean, c.sa, beta);
-  c.sa2 = c.sa * 1.44269504088896341f;
-  c.sb2 = c.sb * 1.44269504088896341f;
+  const float s = rstd * gamma;
+  c.sa = s * LOG2E;
+  c.sb = fmaf(-mean, s, beta) * LOG2E;
   return c;
 }
-__device__ __forceinline__ float gn_mish1(float x, const GnCoef& c) {
-  const float y = fmaf(x, c.sa, c.sb);
-  const float e = __builtin_amdgcn_exp2f(fminf(fmaf(x, c.sa2, c.sb2), 28.8539008177792681f));
+__device__ __forceinline__ float gn_mish1(float x, const GnCoef& c, float addend) {
+  constexpr float LOG2E = 1.44269504088896341f;
+  const float yl = fmaf(x, c.sa, c.sb);
+  const float e = __builtin_amdgcn_exp2f(fminf(yl, 20.f * LOG2E));
   const float n = e * (e + 2.f);
-  return y * (n * __builtin_amdgcn_rcpf(n + 2.f));
+  const float q = n * __builtin_amdgcn_rcpf(fmaf(n, LOG2E, 2.f * LOG2E));
+  return fmaf(yl, q, addend);
 }
 
 // Stage SPB samples' [LIN, C] rows (channels-last, optionally a concat of two tensors) into an LDS slab
@@ -446,9 +450,10 @@ __device__ __forceinline__ float quad_groupsum(float v) {
   if constexpr (QB == 4) v += __shfl_xor(v, 32);
   return v;
 }
-template <int CM, int L>
+// add(i, r) = what is added to element r of q[i] after the Mish (time bias / residual / 0)
+template <int CM, int L, class ADD>
 __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[2], const float (&gamma)[2],
-                                             const float (&beta)[2]) {
+                                             const float (&beta)[2], ADD add) {
   constexpr int CPG = CM / 8, QB = L / 16;
   constexpr float inv_n = 1.f / (float)(L * CPG);
 #pragma unroll
@@ -471,7 +476,7 @@ __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) q[o * 2 + nt][r] = gn_mish1(q[o * 2 + nt][r], cf);
+      for (int r = 0; r < 4; ++r) q[o * 2 + nt][r] = gn_mish1(q[o * 2 + nt][r], cf, add(o * 2 + nt, r));
   }
 }
 
@@ -530,14 +535,16 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     if (next) w4_ring_load<4>(ring, wlane(next, CF::CM));
     w4_out(acc, m);
   };
-  auto gn = [&](const float* b, const float* g, const float* be) {
+  // GroupNorm + Mish of acc, then + the time bias tb (conv A) or + the residual tile (conv B, tb == nullptr)
+  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
     const float bb[2] = {b[col0], b[col1]}, gg[2] = {g[col0], g[col1]}, ee[2] = {be[col0], be[col1]};
-    if (MMD_ABL != 1) gn_mish_quad<CF::CM, CF::L>(acc, bb, gg, ee);
-  };
-  auto add_cols = [&](const float* v) {
-    const float v0 = v[col0], v1 = v[col1];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) { acc[o * 2] += v0; acc[o * 2 + 1] += v1; }
+    if (MMD_ABL == 1) return;
+    if (tb) {
+      const float t0 = tb[col0], t1 = tb[col1];
+      gn_mish_quad<CF::CM, CF::L>(acc, bb, gg, ee, [&](int i, int) { return (i & 1) ? t1 : t0; });
+    } else {
+      gn_mish_quad<CF::CM, CF::L>(acc, bb, gg, ee, [&](int i, int r) { return res[i][r]; });
+    }
   };
 
   // =================== RTB 0 (C0 -> CM) with its 1x1 residual conv fused into conv A ===================
@@ -553,16 +560,13 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   w4_ring_load<4>(ring, wlane(a.r0.wb, CF::CM));
   w4_out(acc, m);
   TR(trb + 2);
-  gn(a.r0.ba, a.r0.ga, a.r0.bea);
-  add_cols(a.r0.tb);
+  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
   quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
   __syncthreads();
   TR(trb + 4);
   conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
   TR(trb + 5);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] += res[i];
+  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
   if constexpr (CF::MID_AFTER == 0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) mid[i] = acc[i];
@@ -581,17 +585,14 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     TR(trb + 8 + k * 8 + 1);
     conv_h(R.wa, R.wb);
     TR(trb + 8 + k * 8 + 2);
-    gn(R.ba, R.ga, R.bea);
-    add_cols(R.tb);
+    gn(R.ba, R.ga, R.bea, R.tb);
     __syncthreads();
     quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
     __syncthreads();
     TR(trb + 8 + k * 8 + 5);
     conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
     TR(trb + 8 + k * 8 + 6);
-    gn(R.bb, R.gb, R.beb);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += res[i];
+    gn(R.bb, R.gb, R.beb, nullptr);
     if (CF::MID_AFTER == k + 1) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) mid[i] = acc[i];
@@ -627,8 +628,8 @@ __device__ __forceinline__ void w4n1_out(f32x4 (&q)[4], const f32x4 (&m)[8]) {
   q[2] = s1 + 4.f * s2 + 0.25f * s3;
   q[3] = (t1 + m[7]) + (8.f * t2 + 0.125f * t3);
 }
-template <int CM, int L>
-__device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float gamma, float beta) {
+template <int CM, int L, class ADD>
+__device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float gamma, float beta, ADD add) {
   constexpr int CPG = CM / 8, QB = L / 16;
   constexpr float inv_n = 1.f / (float)(L * CPG);
   float sum = 0.f;
@@ -649,7 +650,7 @@ __device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float g
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) q[o][r] = gn_mish1(q[o][r], cf);
+    for (int r = 0; r < 4; ++r) q[o][r] = gn_mish1(q[o][r], cf, add(o, r));
 }
 // one-n-tile quad tile -> slab; producer tiling: wave = (M tile, 16-channel n-tile)
 template <int L, int CM, int DSS, int DSTR>
@@ -715,20 +716,17 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
   w4n1_out(acc, m);
   TR(trb + 1);
-  if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col]);
   {
     const float tb = a.r0.tb[col];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) acc[o] += tb;
+    if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
   }
   to_h();
   __syncthreads();
   TR(trb + 2);
   conv_h(a.r0.wb, a.ri[0].wa);
   TR(trb + 3);
-  if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col]);
-#pragma unroll
-  for (int o = 0; o < 4; ++o) acc[o] += res[o];
+  if (MMD_ABL != 1)
+    gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col], [&](int o, int r) { return res[o][r]; });
   TR(trb + 4);
 
   // =================== identity RTB ===================
@@ -741,20 +739,17 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     __syncthreads();
     conv_h(R.wa, R.wb);
     TR(trb + 5);
-    if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col]);
     {
       const float tb = R.tb[col];
-#pragma unroll
-      for (int o = 0; o < 4; ++o) acc[o] += tb;
+      if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col], [&](int, int) { return tb; });
     }
     __syncthreads();
     to_h();
     __syncthreads();
     conv_h(R.wb, nullptr);
     TR(trb + 6);
-    if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col]);
-#pragma unroll
-    for (int o = 0; o < 4; ++o) acc[o] += res[o];
+    if (MMD_ABL != 1)
+      gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col], [&](int o, int r) { return res[o][r]; });
   }
 
   // =================== tail: Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, direct ===================
@@ -885,7 +880,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       const int c0 = lane & 15, c1 = c0 + 16;
       const float bb[2] = {f.bias[c0], f.bias[c1]}, gg[2] = {f.gamma[c0], f.gamma[c1]}, ee[2] = {f.beta[c0], f.beta[c1]};
-      if (MMD_ABL != 1) gn_mish_quad<32, 64>(q, bb, gg, ee);
+      if (MMD_ABL != 1) gn_mish_quad<32, 64>(q, bb, gg, ee, [](int, int) { return 0.f; });
     }
     __syncthreads();                                                       // every wave is done reading the slab
     float* yt = lds + wave * (64 * 33);
