@@ -190,6 +190,19 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
                       int n_steps_without_noise, int init_noise, const float* step_noise_dev, uint64_t seed,
                       float* chain_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* GaussianDiffusionModel.ddim_sample (diffusion_model_base.py:213-290) with eta = 0: x_T (drawn with Philox when
+ * init_noise != 0, else the contents of x_dev) -> conditioned -> one step per consecutive pair (times[k], times[k+1]) of
+ * the host array `times` ([n_times], strictly decreasing, as the reference builds it: reversed int(linspace(0, T-1,
+ * T/5 + 1)) followed by -1): eps = model(x, times[k]); x_start = predict_start_from_noise (not clamped);
+ * x = x_start sqrt(acp[t_next]) + sqrt(1 - acp[t_next]) eps; s->n_guide_steps guide steps iff a guide is given and
+ * t_next < s->t_start_guide (the reference effectively runs ONE: it does not forward n_guide_steps to
+ * guide_gradient_steps); hard conditioning; on the pair that ends in -1, x = x_start.  alphas_cumprod is the host [T]
+ * buffer of that name.  chain_dev: [n_times][n_traj, H, 4] or NULL. */
+int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alphas_cumprod, const int32_t* times,
+                    int n_times, const mmd_guide_desc* guide, float* x_dev, const float* hard_dev, int n_robots,
+                    int samples_per_robot, int init_noise, uint64_t seed, float* chain_dev, void* workspace_dev,
+                    size_t workspace_bytes, void* stream);
+
 /* q_sample (diffusion_model_base.py:425-433): x = a * x_start + b * noise (noise injected or Philox). */
 int mmd_q_sample(float* x_dev, const float* x_start_dev, const float* noise_dev, float sqrt_alphas_cumprod_t,
                  float sqrt_one_minus_alphas_cumprod_t, uint64_t seed, uint32_t draw_index, int n_traj, void* stream);

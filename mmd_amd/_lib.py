@@ -67,6 +67,9 @@ _SIGNATURES = {
     "mmd_p_sample_loop": (C.c_int, [C.c_void_p, C.POINTER(SamplerDesc), C.POINTER(GuideDesc), C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mmd_ddim_sample": (C.c_int, [C.c_void_p, C.POINTER(SamplerDesc), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(GuideDesc),
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
     "mmd_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint32,
                                C.c_int, C.c_void_p]),
     "mmd_rr_collisions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

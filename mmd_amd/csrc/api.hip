@@ -176,4 +176,44 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   return 0;
 }
 
+int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alphas_cumprod, const int32_t* times,
+                    int n_times, const mmd_guide_desc* guide, float* x_dev, const float* hard_dev, int n_robots,
+                    int samples_per_robot, int init_noise, uint64_t seed, float* chain_dev, void* workspace_dev,
+                    size_t workspace_bytes, void* stream) {
+  MMD_REQUIRE(unet && s && alphas_cumprod && times && x_dev && hard_dev && workspace_dev, "mmd_ddim_sample: NULL argument");
+  const int n = n_robots * samples_per_robot;
+  MMD_REQUIRE(n >= 1 && n_times >= 2, "mmd_ddim_sample: empty batch or fewer than two times");
+  MMD_REQUIRE(workspace_bytes >= mmd_sampler_workspace_bytes(unet, n), "mmd_ddim_sample: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t traj_floats = (size_t)n * H * D;
+  const size_t uws = mmd_unet_workspace_bytes(unet, n);
+  float* eps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace_dev) + uws);
+  GuideDev g{};
+  if (guide)
+    if (int rc = fill_guide(guide, g)) return rc;
+  launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed, n, samples_per_robot, st);
+  for (int k = 0; k + 1 < n_times; ++k) {
+    const int t = times[k], tn = times[k + 1];
+    MMD_REQUIRE(t >= 0 && t < s->n_diffusion_steps && tn < t, "mmd_ddim_sample: times must decrease inside the schedule");
+    StepDev sd{};
+    sd.ddim = 1;
+    sd.a_t = s->sqrt_recip_alphas_cumprod[t];
+    sd.b_t = s->sqrt_recipm1_alphas_cumprod[t];
+    sd.c1 = tn < 0 ? 1.f : sqrtf(alphas_cumprod[tn]);               // x = x_start on the last pair (time_next = -1)
+    sd.c2 = tn < 0 ? 0.f : sqrtf(1.f - alphas_cumprod[tn]);         // sigma = eta * ... = 0
+    sd.do_model = 1;
+    sd.do_guide = guide && tn >= 0 && tn < s->t_start_guide ? 1 : 0;  // torch.all(t_next < t_start_guide); none after the break
+    sd.do_noise = 0;
+    sd.n_guide_steps = s->n_guide_steps;
+    sd.hard_mask = s->hard_mask;
+    sd.seed = seed; sd.draw = (unsigned int)k;
+    if (int rc = mmd_unet_forward(unet, x_dev, t, eps, n, workspace_dev, uws, stream)) return rc;
+    launch_step(g, sd, x_dev, eps, nullptr, chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr, hard_dev, 0, n,
+                samples_per_robot, st);
+    if (tn < 0) break;
+  }
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

@@ -275,15 +275,24 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
   if (s.do_model) {
     // p_mean_variance (diffusion_model_base.py:148-160): x0 = a x - b eps; clamp; mean = c1 x0 + c2 x
     const float4 e = eps[idx];
-    float4 x0;
-    x0.x = fminf(fmaxf(s.a_t * v.x - s.b_t * e.x, -1.f), 1.f);
-    x0.y = fminf(fmaxf(s.a_t * v.y - s.b_t * e.y, -1.f), 1.f);
-    x0.z = fminf(fmaxf(s.a_t * v.z - s.b_t * e.z, -1.f), 1.f);
-    x0.w = fminf(fmaxf(s.a_t * v.w - s.b_t * e.w, -1.f), 1.f);
-    v.x = s.c1 * x0.x + s.c2 * v.x;
-    v.y = s.c1 * x0.y + s.c2 * v.y;
-    v.z = s.c1 * x0.z + s.c2 * v.z;
-    v.w = s.c1 * x0.w + s.c2 * v.w;
+    if (s.ddim) {
+      // ddim_sample, eta = 0 (diffusion_model_base.py:245-262): x_start = a x - b eps (not clamped);
+      // x = x_start sqrt(alpha_next) + sqrt(1 - alpha_next) eps   (c1 = 1, c2 = 0 on the last pair: x = x_start)
+      v.x = s.c1 * (s.a_t * v.x - s.b_t * e.x) + s.c2 * e.x;
+      v.y = s.c1 * (s.a_t * v.y - s.b_t * e.y) + s.c2 * e.y;
+      v.z = s.c1 * (s.a_t * v.z - s.b_t * e.z) + s.c2 * e.z;
+      v.w = s.c1 * (s.a_t * v.w - s.b_t * e.w) + s.c2 * e.w;
+    } else {
+      float4 x0;
+      x0.x = fminf(fmaxf(s.a_t * v.x - s.b_t * e.x, -1.f), 1.f);
+      x0.y = fminf(fmaxf(s.a_t * v.y - s.b_t * e.y, -1.f), 1.f);
+      x0.z = fminf(fmaxf(s.a_t * v.z - s.b_t * e.z, -1.f), 1.f);
+      x0.w = fminf(fmaxf(s.a_t * v.w - s.b_t * e.w, -1.f), 1.f);
+      v.x = s.c1 * x0.x + s.c2 * v.x;
+      v.y = s.c1 * x0.y + s.c2 * v.y;
+      v.z = s.c1 * x0.z + s.c2 * v.z;
+      v.w = s.c1 * x0.w + s.c2 * v.w;
+    }
   }
 
   const float4 hs = hard[robot * 2 + 0], hg = hard[robot * 2 + 1];

@@ -29,6 +29,7 @@ struct StepDev {
   float sigma;                       // exp(0.5 * posterior_log_variance_clipped[t])
   float noise_std_extra;
   int do_model, do_guide, do_noise;  // do_model = 0: guide-only launch (mmd_guide_steps)
+  int ddim;                          // 1: DDIM update x <- c1 * (a x - b eps) + c2 * eps, x0 not clamped (mmd_ddim_sample)
   int n_guide_steps;
   int hard_mask;
   unsigned long long seed;

@@ -102,7 +102,7 @@ class GaussianDiffusionModel:
         `step_noise` [n_steps_total, B, H, D] + `warm_start_path_b` as x_T to inject every Gaussian draw (parity
         tests), `seed` for the in-kernel Philox stream otherwise."""
         if sample_fn is not ddpm_sample_fn:
-            raise NotImplementedError("only ddpm_sample_fn is implemented (DDIM is SURVEY §8f-4)")
+            raise NotImplementedError("only ddpm_sample_fn is implemented (DDIM: conditional_sample(ddim=True) / ddim_sample)")
         if context is not None:
             raise NotImplementedError("context")
         if guide is not None and not isinstance(guide, GuideManagerTrajectoriesWithVelocity):
@@ -139,6 +139,52 @@ class GaussianDiffusionModel:
             return x, chain.transpose(0, 1)                      # [B, steps+1, H, D] like torch.stack(chain, dim=1)
         return x
 
+    @staticmethod
+    def ddim_times(n_diffusion_steps):
+        """[T-1, ..., 0, -1]: diffusion_model_base.py:225-235 (sampling_timesteps = T // 5), computed as the reference does."""
+        times = torch.linspace(0, n_diffusion_steps - 1, steps=n_diffusion_steps // 5 + 1)
+        times = torch.cat((torch.tensor([-1.0]), times))
+        return list(reversed(times.int().tolist()))
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, hard_conds, n_diffusion_steps, context=None, return_chain=False,
+                    t_start_guide=float("inf"), guide=None, n_guide_steps=1, n_robots=1, x_init=None, seed=None,
+                    device="cuda", **sample_kwargs):
+        """diffusion_model_base.py:213-290 (eta = 0).  As in the reference, `n_guide_steps` is accepted and NOT forwarded
+        to guide_gradient_steps: one guide step per sampling step.  Extensions: `n_robots`, `x_init` (injected x_T),
+        `seed` for the Philox draw of x_T otherwise."""
+        if context is not None:
+            raise NotImplementedError("context")
+        if guide is not None and not isinstance(guide, GuideManagerTrajectoriesWithVelocity):
+            raise NotImplementedError("guide must be a mmd_amd GuideManagerTrajectoriesWithVelocity")
+        B_total, H, D = shape
+        device = torch.device(device)
+        lib = _lib.load()
+        hard, mask = self._hard_tensor(hard_conds, n_robots, H, device, D)
+        s = self._sampler_desc(1, t_start_guide, 1.0, mask)
+        times = np.asarray(self.ddim_times(n_diffusion_steps), dtype=np.int32)
+        acp = np.ascontiguousarray(self._tables["alphas_cumprod"], dtype=np.float32)
+        if x_init is not None:
+            x = x_init.to(device=device, dtype=torch.float32).contiguous().clone()
+            init_noise = 0
+        else:
+            x = torch.empty(shape, dtype=torch.float32, device=device)
+            init_noise = 1
+        chain = torch.empty((len(times),) + tuple(shape), dtype=torch.float32, device=device) if return_chain else None
+        gd = guide.desc() if guide is not None else None
+        ws = self.model.workspace(B_total, device, sampler=True)
+        if seed is None:
+            seed = (self.seed << 20) + self._draws
+            self._draws += 1
+        _lib.check(lib.mmd_ddim_sample(
+            self.model.handle(self.n_diffusion_steps), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
+            C.byref(gd) if gd is not None else None, x.data_ptr(), hard.data_ptr(), n_robots, B_total // n_robots,
+            init_noise, C.c_uint64(seed), chain.data_ptr() if chain is not None else None, ws.data_ptr(), ws.numel(),
+            _lib.current_stream_ptr()))
+        if return_chain:
+            return x, chain.transpose(0, 1)
+        return x
+
     @torch.no_grad()
     def sample_step(self, x, hard_conds, i, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
                     noise_std_extra_schedule_fn=None, n_robots=1, noise=None, seed=None):
@@ -164,9 +210,11 @@ class GaussianDiffusionModel:
     @torch.no_grad()
     def conditional_sample(self, hard_conds, n_diffusion_steps, horizon=None, batch_size=1, ddim=False,
                            warm_start_path_b=None, **sample_kwargs):
-        if ddim:
-            raise NotImplementedError("DDIM sampling is out of scope (SURVEY §8f-4)")
         shape = (batch_size, horizon or 64, self.state_dim)
+        if ddim:
+            if warm_start_path_b is not None:
+                raise ValueError("warm_start_path_b is not supported for ddim sampling.")     # diffusion_model_base.py:303
+            return self.ddim_sample(shape, hard_conds, n_diffusion_steps=n_diffusion_steps, **sample_kwargs)
         return self.p_sample_loop(shape, hard_conds, n_diffusion_steps=n_diffusion_steps,
                                   warm_start_path_b=warm_start_path_b, **sample_kwargs)
 

@@ -506,6 +506,42 @@ def p_sample_loop(sd, tb, x_init, hard_conds, n_diffusion_steps, step_noise, *, 
     return torch.stack(chain, dim=0)
 
 
+def ddim_times(n_diffusion_steps):
+    """Time pairs of ddim_sample (diffusion_model_base.py:225-235): sampling_timesteps = T // 5, eta = 0."""
+    S = n_diffusion_steps // 5
+    times = torch.linspace(0, n_diffusion_steps - 1, steps=S + 1)
+    times = torch.cat((torch.tensor([-1.0]), times))
+    return list(reversed(times.int().tolist()))
+
+
+def ddim_sample(sd, tb, x_init, hard_conds, n_diffusion_steps, *, guide=None, t_start_guide=float("inf"), n_levels=3):
+    """GaussianDiffusionModel.ddim_sample (diffusion_model_base.py:213-290), predict_epsilon=True, eta = 0 (sigma = 0: the
+    per-step randn_like draw is multiplied by 0).  x_init [B,H,D] is the injected x_T.  Quirk kept: the guide runs ONE
+    gradient step per sampling step -- ddim_sample binds `n_guide_steps` itself and forwards only **sample_kwargs, so
+    guide_gradient_steps (sample_functions.py:89) runs with its default n_guide_steps=1.  x_start is NOT clamped here.
+    Returns chain [n_pairs+1, B,H,D]."""
+    times = ddim_times(n_diffusion_steps)
+    x = apply_hard_conditioning(x_init.clone(), hard_conds)
+    chain = [x]
+    B = x.shape[0]
+    for time, time_next in zip(times[:-1], times[1:]):
+        eps = unet_forward(sd, x, torch.full((B,), time, dtype=torch.long), n_levels)
+        x_start = tb["sqrt_recip_alphas_cumprod"][time] * x - tb["sqrt_recipm1_alphas_cumprod"][time] * eps
+        if time_next < 0:
+            x = apply_hard_conditioning(x_start, hard_conds)
+            chain.append(x)
+            break
+        alpha_next = tb["alphas_cumprod"][time_next]
+        c = (1 - alpha_next).sqrt()
+        x = x_start * alpha_next.sqrt() + c * eps
+        if guide is not None and time_next < t_start_guide:
+            x = x + guide(x)
+            x = apply_hard_conditioning(x, hard_conds)
+        x = apply_hard_conditioning(x, hard_conds)
+        chain.append(x)
+    return torch.stack(chain, dim=0)
+
+
 def q_sample(tb, x_start, t, noise):
     """diffusion_model_base.py:425-433."""
     return tb["sqrt_alphas_cumprod"][t] * x_start + tb["sqrt_one_minus_alphas_cumprod"][t] * noise

@@ -84,6 +84,30 @@ def sample_case(name):
     raise KeyError(name)
 
 
+def ddim_case(name):
+    """DDIM golden cases (g11): name -> dict like sample_case plus the x_T seed."""
+    if name == "empty_T50":
+        starts, goals = synth.start_goal_circle(6, 0.8)
+        return dict(map="EnvEmpty2D", T=50, B=8, start=starts[0], goal=goals[0], cons=[], seed=31, use_guide=False)
+    if name == "highways_T100":
+        starts, goals, soft, hard = highways_case()
+        return dict(map="EnvHighways2D", T=100, B=8, start=starts[3], goal=goals[3], cons=[soft, hard], seed=32)
+    raise KeyError(name)
+
+
+DDIM_CASES = ("empty_T50", "highways_T100")
+
+
+def oracle_ddim(case, weights_seed=0, clip_mode="reference"):
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(weights_seed))
+    tb = O.schedule_tables(case["T"])
+    gp = guide_params(case["map"])
+    xT = torch.from_numpy(synth.synth_noise(case["seed"], (case["B"], H, D)))
+    guide = (lambda x: O.guide_grad(x, gp, case["cons"], clip_mode=clip_mode)) if case.get("use_guide", True) else None
+    return O.ddim_sample(sd, tb, xT, hard_conds_for(case["start"], case["goal"]), case["T"], guide=guide,
+                         t_start_guide=ceil(0.5 * case["T"]))
+
+
 SAMPLE_CASES = ("empty_T50", "highways_T100", "empty_T25_nocons", "cfg0_T50_B1", "empty32_T25", "conveyor_T50",
                 "prior_T100")
 

@@ -207,6 +207,29 @@ def test_run_inference_golden(name):
         assert rel_l2(chain[-1], ref[-1]) < 3e-3
 
 
+@pytest.mark.parametrize("name", cases.DDIM_CASES)
+def test_ddim_sample_golden(name):
+    """conditional_sample(ddim=True) (diffusion_model_base.py:213-290) against every chain row of the reference (g11).
+    The DDIM chain is deterministic and takes ONE guide step per sampling step: well conditioned (sens 4e-7)."""
+    g = np.load(os.path.join(GOLDEN, f"g11_ddim_{name}.npz"))
+    case = cases.ddim_case(name)
+    T, B = case["T"], case["B"]
+    model = _gc().hip_model(T)
+    guide = _gc().hip_guide(case["map"], [case["cons"]], n_robots=1) if case.get("use_guide", True) else None
+    hc = cases.hard_conds_for(case["start"], case["goal"])
+    xT = torch.from_numpy(synth.synth_noise(case["seed"], (B, H, D)))
+    x, chain = model.ddim_sample((B, H, D), hc, n_diffusion_steps=T, return_chain=True, guide=guide,
+                                 t_start_guide=ceil(0.5 * T), n_guide_steps=20, x_init=xT)
+    ref = torch.from_numpy(g["chain"])
+    chain = chain.transpose(0, 1).cpu()
+    assert chain.shape == ref.shape
+    for r in range(ref.shape[0]):
+        assert rel_l2(chain[r], ref[r]) < 1e-4, (name, r, rel_l2(chain[r], ref[r]))
+    assert torch.equal(x.cpu(), chain[-1])
+    with pytest.raises(ValueError):
+        model.conditional_sample(hc, T, batch_size=B, ddim=True, warm_start_path_b=xT)
+
+
 def test_run_local_inference_golden():
     g = np.load(os.path.join(GOLDEN, "g7_local.npz"))
     T, B = 50, 8

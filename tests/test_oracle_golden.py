@@ -90,6 +90,18 @@ def test_g6_run_inference(name):
     assert rel_l2(chain[-1], ref[-1]) < 1e-4
 
 
+@pytest.mark.parametrize("name", cases.DDIM_CASES)
+def test_g11_ddim_sample(name):
+    """GaussianDiffusionModel.ddim_sample (diffusion_model_base.py:213-290): every chain row of the reference."""
+    g = np.load(os.path.join(GOLDEN, f"g11_ddim_{name}.npz"))
+    case = cases.ddim_case(name)
+    chain = cases.oracle_ddim(case)
+    ref = torch.from_numpy(g["chain"])
+    assert chain.shape == ref.shape and chain.shape[0] == case["T"] // 5 + 2
+    for r in range(chain.shape[0]):
+        assert rel_l2(chain[r], ref[r]) < 1e-5, (name, r, rel_l2(chain[r], ref[r]))
+
+
 def test_g7_run_local_inference():
     g = np.load(os.path.join(GOLDEN, "g7_local.npz"))
     T, B = 50, 8

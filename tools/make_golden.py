@@ -373,11 +373,57 @@ def g10():
                         midpoints=mid.numpy(), samples=samples.numpy(), conflict_totals=np.array(totals))
 
 
+def run_ref_ddim(env_id, T, B, start, goal, cons, seed_xT, use_guide=True, perturb=0.0, perturb_seed=0):
+    """GaussianDiffusionModel.ddim_sample (diffusion_model_base.py:213-290) of the genuine reference with x_T injected;
+    the per-step randn_like draws are multiplied by sigma = 0 (eta = 0) and are fed zeros."""
+    sd = synth.synth_unet_state_dict(0)
+    with quiet():
+        model = make_model(sd, T)
+        guide, robot, task, env = make_guide(env_id, MINS, MAXS)
+    if perturb:
+        gen = torch.Generator().manual_seed(perturb_seed)
+        model.model.register_forward_hook(
+            lambda mod, inp, out: out * (1 + perturb * torch.empty(out.shape).normal_(generator=gen)))
+    costs, ws = [], []
+    for (q, tr, r, soft) in cons:
+        costs.append(make_cost_constraint(robot, q, tr, r, soft))
+        ws.append(2e-2 if soft else 2e-1)
+    guide.add_extra_costs(costs, ws)
+    xT = synth.synth_noise(seed_xT, (B, H, D))
+    n_pairs = T // 5 + 1
+    with quiet(), injected_noise([xT] + [np.zeros((B, H, D), np.float32)] * n_pairs) as q:
+        x, chain = model.ddim_sample((B, H, D), hard_conds_for(start, goal), n_diffusion_steps=T, return_chain=True,
+                                     guide=guide if use_guide else None, t_start_guide=ceil(0.5 * T), n_guide_steps=20)
+    guide.reset_extra_costs()
+    return chain.transpose(0, 1).numpy()      # [n_pairs + 1, B, H, D]
+
+
+def g11():
+    """DDIM sampler: unguided on the Empty map (T=50: 10 sampling steps) and guided with constraints on
+    Highways (T=100: 20 sampling steps); full chains + the reference's own sensitivity to a 1e-6 UNet perturbation."""
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    chain = run_ref_ddim("EnvEmpty2D", 50, 8, starts[0], goals[0], [], 31, use_guide=False)
+    pert = run_ref_ddim("EnvEmpty2D", 50, 8, starts[0], goals[0], [], 31, use_guide=False, perturb=1e-6, perturb_seed=1)
+    np.savez_compressed(os.path.join(OUT, "g11_ddim_empty_T50.npz"), chain=chain, sens=rel_l2(pert[-1], chain[-1]),
+                        meta=np.array([50, 8, 6, 0, 31]))
+    print("   g11 empty: sens", rel_l2(pert[-1], chain[-1]))
+    starts, goals, soft, hard = highways_case()
+    cons_h = [(*soft, True), (*hard, False)]
+    chain = run_ref_ddim("EnvHighways2D", 100, 8, starts[3], goals[3], cons_h, 32)
+    sens = 0.0
+    for ps in range(1, 4):
+        pert = run_ref_ddim("EnvHighways2D", 100, 8, starts[3], goals[3], cons_h, 32, perturb=1e-6, perturb_seed=ps)
+        sens = max(sens, rel_l2(pert[-1], chain[-1]))
+    np.savez_compressed(os.path.join(OUT, "g11_ddim_highways_T100.npz"), chain=chain, sens=sens,
+                        meta=np.array([100, 8, 10, 3, 32]))
+    print("   g11 highways: sens", sens)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}[name]()
     print("done")
