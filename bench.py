@@ -9,9 +9,12 @@ A "step" is ONE planning round of the hot path: (all-gather of the robots' best 
 table -> one guided DDPM sampling call (T=100 denoise steps + 1 no-noise step, 20 guide iterations on the 51 guided
 steps) for every local robot's B=64 samples -> best-path selection for the next round.  N=1 is BASELINE.json's headline
 workload: 32 robots on the Empty map (circle r=0.8) = 2048 trajectories, each robot soft-constrained by the other 31
-(31 x 63 = 1953 points).  N>1 is weak scaling: 32 robots PER GPU of one 32N-robot instance (the pairwise term grows
-with N), one RCCL all-gather of [32,64,2] fp32 per rank per round.  UNet weights are synthetic random-init (numpy
-PCG64), Gaussian noise is drawn in-kernel (Philox), inputs are resident in HBM before the timed region.
+(31 x 63 = 1953 points).  N>1, `--scaling strong` (default): the SAME 32-robot instance, the metric's own workload,
+sharded 32/N robots per GPU (512 trajectories per GPU at N=4, 256 at N=8).  `--scaling weak`: 32 robots PER GPU of one
+32N-robot instance (the pairwise term grows with N).  Either way ONE RCCL all-gather of [robots/GPU,64,2] fp32 per rank
+per round.  UNet weights are synthetic random-init (numpy PCG64), Gaussian noise is drawn in-kernel (Philox keyed by the
+global trajectory index, so every rank's rows equal the unsharded run's), inputs are resident in HBM before the timed
+region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,7 +34,8 @@ import torch         # noqa: E402
 
 H, D = 64, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
-DOMINANT_LAYER = "UNET"            # unet_kernel: the whole TemporalUnet forward in one launch (all 25 convs + GN/Mish)
+DOMINANT_KERNEL = "UNET"           # unet_kernel: the whole TemporalUnet forward in one launch (all 25 convs + GN/Mish)
+HEADLINE_ROBOTS = 32               # BASELINE.json: 32-robot Empty map
 
 
 def parse():
@@ -39,7 +43,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--robots-per-gpu", type=int, default=32)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N>1: strong = the metric's 32-robot instance sharded 32/N robots per GPU; weak = 32 robots per "
+                         "GPU of a 32N-robot instance")
+    ap.add_argument("--robots-per-gpu", type=int, default=0, help="override (0 = 32/N for strong, 32 for weak)")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -47,14 +54,25 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(T, B, n_robots, budget_s):
     """The oracle's reference-SHAPED path (dense (n,B,H,2) CostConstraint broadcast + one autograd pass per cost term,
     torch-CPU UNet) for ONE robot of the headline instance, timed on this host's cores on a bounded sample and
     extrapolated to the full 101-step call.  Robots are planned sequentially by the reference, so trajectories/s of
-    one robot's call is the whole-round rate."""
+    one robot's call is the whole-round rate.  The thread count is swept (8 / 32 / all logical CPUs -- an oversubscribed
+    pool is slower for these small tensors) and the best setting is reported."""
     import cases_for_bench as cb
     from oracle import mmd_oracle as O
-    cores = torch.get_num_threads()
     sd, tb, gp, grp, hc = cb.oracle_headline_robot(T, n_robots)
     x = torch.from_numpy(cb.synth.synth_noise(91, (B, H, D))) * 0.5
     x = O.apply_hard_conditioning(x, hc)
@@ -69,22 +87,27 @@ def cpu_baseline(T, B, n_robots, budget_s):
                                noise_std_extra=0.5)
         return time.perf_counter() - t0
 
-    timed(T - 1, None)                                              # warm-up (thread pool, allocator)
-    t_u = min(timed(T - 1 - k, None) for k in range(3))
-    t_g, n_g, spent = [], 0, 0.0
-    while n_g < 3 and (n_g == 0 or spent + (spent / n_g) < budget_s):
-        dt = timed(tsg - 1 - n_g, guide)
-        t_g.append(dt)
-        spent += dt
-        n_g += 1
-    n_guided = tsg + 1                                              # i = tsg-1 ... -1
-    n_unguided = T - tsg
-    est = n_guided * float(np.mean(t_g)) + n_unguided * t_u
-    return {"value": B / est, "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "sample": f"1 of {n_robots} robots (B={B}, {grp.q.shape[0]} soft-constraint points), {n_g} guided + 3 unguided "
-                      f"DDPM steps timed ({np.mean(t_g):.2f} s / {t_u * 1e3:.0f} ms each) and extrapolated to the "
-                      f"{n_guided}+{n_unguided}-step call; robots are sequential in the reference",
-            "est_seconds_per_robot_call": est}
+    n_cpus = os.cpu_count() or 1
+    sweep = sorted({min(8, n_cpus), min(32, n_cpus), max(n_cpus // 2, 1), n_cpus})
+    n_guided, n_unguided = tsg + 1, T - tsg                          # i = tsg-1 ... -1 guided; the rest unguided
+    results, t_start = [], time.perf_counter()
+    for nt in sweep:
+        if results and time.perf_counter() - t_start > budget_s:
+            break
+        torch.set_num_threads(nt)
+        timed(T - 1, None)                                           # warm-up (thread pool, allocator)
+        t_u = min(timed(T - 1 - k, None) for k in range(2))
+        t_g = [timed(tsg - 1 - k, guide) for k in range(2)]
+        est = n_guided * float(np.mean(t_g)) + n_unguided * t_u
+        results.append({"threads": nt, "guided_step_s": float(np.mean(t_g)), "unguided_step_s": t_u,
+                        "est_seconds_per_robot_call": est, "trajectories_per_s": B / est})
+    best = max(results, key=lambda r: r["trajectories_per_s"])
+    return {"value": best["trajectories_per_s"], "unit": "trajectories/s", "cores": best["threads"], "kind": "port",
+            "cpu_model": cpu_model_name(), "logical_cpus": n_cpus,
+            "sample": f"1 of {n_robots} robots (B={B}, {grp.q.shape[0]} soft-constraint points): per thread count 2 guided "
+                      f"+ 2 unguided DDPM steps timed and extrapolated to the {n_guided}+{n_unguided}-step call (robots "
+                      f"are sequential in the reference); best of the thread sweep reported",
+            "est_seconds_per_robot_call": best["est_seconds_per_robot_call"], "thread_sweep": results}
 
 
 def main():
@@ -115,7 +138,15 @@ def main():
     from mmd_amd.multi_robot import MultiRobotSampler
     from mmd_amd.temporal_unet import TemporalUnet
 
-    T, B, RPG = args.diffusion_steps, args.samples, args.robots_per_gpu
+    T, B = args.diffusion_steps, args.samples
+    if args.robots_per_gpu:
+        RPG = args.robots_per_gpu
+    elif args.scaling == "strong":
+        if HEADLINE_ROBOTS % world:
+            raise SystemExit(f"--scaling strong needs {HEADLINE_ROBOTS} % gpus == 0")
+        RPG = HEADLINE_ROBOTS // world
+    else:
+        RPG = HEADLINE_ROBOTS
     n_robots = RPG * world
     unet = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=32, dim_mults=(1, 2, 4))
     unet.load_state_dict(synth.synth_unet_state_dict(0))
@@ -134,28 +165,28 @@ def main():
 
     lib = _lib.load()
     import ctypes as C
-    nl = lib.mmd_unet_num_layers()
-    names = [lib.mmd_unet_layer_name(i).decode() for i in range(nl)]
-    dom = [i for i, nme in enumerate(names) if nme == DOMINANT_LAYER]
     n_traj_local = RPG * B
-    flops = [lib.mmd_unet_layer_flops(i) * n_traj_local for i in range(nl)]
-    mfma_flops = [lib.mmd_unet_layer_mfma_flops(i) * n_traj_local for i in range(nl)]
+    flops = lib.mmd_unet_flops_per_trajectory() * n_traj_local              # algorithmic (direct-conv) FLOPs per launch
+    mfma_flops = lib.mmd_unet_mfma_flops_per_trajectory() * n_traj_local    # FLOPs the matrix pipe actually issues
 
     for w in range(args.warmup):
         _, paths_local = sampler.plan_round(paths_local, seed=1000 + w)
-    # roofline of the dominant kernel: every one of its launches INSIDE the timed region is bracketed by a HIP event pair
-    # on the stream it is launched on (mmd_unet_profile_layer).  Every 13th of its 101 launches per step is bracketed
-    # (one launch per UNet forward): ~8 event pairs per step, < 0.5 % of the timed region.
-    _lib.check(lib.mmd_unet_profile_layer(unet.handle(T), dom[0], len(dom) * (T + 1) * args.steps, 13))
+    # roofline of the dominant kernel: its launches INSIDE the timed region are bracketed by HIP event pairs on the stream
+    # it is launched on (mmd_amd_debug.h profiler attached to the sampler).  Every 13th of the 101 launches per step is
+    # bracketed: ~8 event pairs per step, < 0.5 % of the timed region.
+    prof = C.c_void_p()
+    _lib.check(lib.mmd_profiler_create(C.byref(prof), (T + 1) * args.steps, 13))
+    model.profiler = prof
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         trajs, paths_local = sampler.plan_round(paths_local, seed=k)
     barrier()
     dt = time.perf_counter() - t0
+    model.profiler = None
     dom_ms_c, dom_n = C.c_double(), C.c_int()
-    _lib.check(lib.mmd_unet_profile_read(unet.handle(T), C.byref(dom_ms_c), C.byref(dom_n)))
-    _lib.check(lib.mmd_unet_profile_layer(unet.handle(T), -1, 0, 1))
+    _lib.check(lib.mmd_profiler_read(prof, C.byref(dom_ms_c), C.byref(dom_n)))
+    _lib.check(lib.mmd_profiler_destroy(prof))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -163,7 +194,8 @@ def main():
     assert torch.isfinite(trajs).all()
     value = args.steps * n_traj_local * world / dt
     dom_ms = dom_ms_c.value
-    dom_tf = flops[dom[0]] / (dom_ms * 1e-3) / 1e12
+    issued_tf = mfma_flops / (dom_ms * 1e-3) / 1e12
+    alg_tf = flops / (dom_ms * 1e-3) / 1e12
 
     # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (separate runs; tools/gpu_round.sh), committed
     # as profiles/pmc_latest.json: traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE half-count correction)
@@ -171,34 +203,36 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path) and n_traj_local == 2048:
         with open(pmc_path) as f:
-            pmc = json.load(f).get(DOMINANT_LAYER)
+            pmc = json.load(f).get(DOMINANT_KERNEL)
         if pmc:
             traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
+    # `achieved` / `frac` are the matrix pipe's own utilisation: MFMA FLOPs actually ISSUED per launch (= PMC
+    # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) / launch time / fp32-MFMA peak.  The k=5 convs run as Winograd F(4,5) in fp32,
+    # which issues 0.45x the multiplies of the direct form: the ALGORITHMIC (direct-convolution) rate is
+    # reported separately and may exceed the peak -- it is not a utilisation.
     roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; fp32 MFMA GEMMs, the 25 k=5 convs as Winograd F(4,5); GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
-                "achieved": dom_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / PEAK_FP32_MFMA_TFLOPS,
+                "achieved": issued_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued_tf / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
-                "flops_per_launch": flops[dom[0]],
-                # `achieved` counts ALGORITHMIC FLOPs (direct-convolution definition).  The k=5 convs run as
-                # Winograd F(4,5) in fp32, so the matrix pipe issues 0.45x of them and `frac` can exceed 1: `mfma_issued` is
-                # the pipe's own utilisation (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 = flops_per_launch below).
-                "note": "achieved = algorithmic (direct-conv) FLOPs / time; Winograd F(4,5) issues 0.45x of them, see mfma_issued",
-                "mfma_issued": {"flops_per_launch": mfma_flops[dom[0]],
-                                "achieved": mfma_flops[dom[0]] / (dom_ms * 1e-3) / 1e12,
-                                "frac": mfma_flops[dom[0]] / (dom_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
-                "launches_per_forward": nl}
+                "flops_per_launch": mfma_flops,
+                "note": "achieved = MFMA FLOPs issued per launch / launch time (matrix-pipe utilisation); see `algorithmic` for the direct-convolution count",
+                "algorithmic": {"flops_per_launch": flops, "achieved": alg_tf, "ratio_to_peak": alg_tf / PEAK_FP32_MFMA_TFLOPS,
+                                "note": "direct-conv FLOPs (2*C_out*taps*C_in*L_out) / time; Winograd F(4,5) issues 0.45x of them, so this can exceed the MFMA peak"},
+                "launches_per_forward": 1}
 
     out = {
         "metric": "guided trajectories/sec (H=64, 100 denoise steps), 32-robot Empty map",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n_robots}-robot EnvEmpty2D circle r=0.8, {RPG} robots/GPU x B={B} samples, H=64, "
+        "config": {"workload": f"{args.scaling}-scaling over {world} GPU(s): "
+                               f"{n_robots}-robot EnvEmpty2D circle r=0.8, {RPG} robots/GPU x B={B} samples, H=64, "
                                f"T={T}+1 DDPM steps, 20 guide iterations on {ceil(0.5 * T) + 1} guided steps, "
                                f"{n_robots - 1} x 63 soft-constraint points per robot",
                    "n_robots": n_robots, "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": H,
                    "diffusion_steps": T, "trajectories_per_step": n_traj_local * world,
                    "parallelism": f"robots sharded x{world}; 1 all-gather of [{RPG},64,2] fp32 per round" if world > 1
-                   else "single GPU", "noise": "in-kernel Philox4x32-10", "weights": "random-init (numpy PCG64 seed 0)"},
+                   else "single GPU", "noise": "in-kernel Philox4x32-10 keyed by global trajectory index", "weights": "random-init (numpy PCG64 seed 0)"},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -7,7 +7,8 @@
  * (paths relative to the reference checkout).  All pointers suffixed _dev are device (HIP) pointers to contiguous
  * fp32 / int32 data; everything else is host memory.  `stream` is a hipStream_t passed as void* (NULL = default
  * stream).  Every function returns 0 on success and a non-zero code on failure; mmd_last_error() gives the text.
- * No global state besides the last-error string; entry points are re-entrant per (handle, stream).
+ * No global state besides the last-error string (thread-local) and lazily created per-(thread, device) side streams;
+ * handles are immutable after creation, so entry points are re-entrant per (handle, stream).
  *
  * Trajectory tensors are [n_traj, H, D] fp32 with D = 4 (x, y, vx, vy) and H = 64 support points, in the
  * NORMALISED space of the diffusion model; n_traj = n_robots * samples_per_robot, robot-major.
@@ -22,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMD_AMD_ABI_VERSION 2
+#define MMD_AMD_ABI_VERSION 3
 #define MMD_STATE_DIM 4
 #define MMD_HORIZON 64
 
@@ -60,25 +61,6 @@ size_t mmd_unet_workspace_bytes(mmd_unet_t unet, int n_traj);
  * diffusion_model_base.py:152).  t is one integer for the whole batch. */
 int mmd_unet_forward(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj, void* workspace_dev,
                      size_t workspace_bytes, void* stream);
-
-/* Measurement hooks (bench.py): the forward is mmd_unet_num_layers() kernel launches (one: "UNET"); launch i's short
- * name, its algorithmic FLOPs per trajectory (direct-convolution count: 2 * C_out * taps * C_in * L_out over its
- * convs), the MFMA FLOPs it actually issues per trajectory (Winograd convs issue 0.6x, channel padding included), and
- * a profiled forward that brackets every launch with HIP events on `stream` and returns the mean duration of each
- * over `repeats` forwards in layer_ms[mmd_unet_num_layers()]. */
-int mmd_unet_num_layers(void);
-const char* mmd_unet_layer_name(int i);
-double mmd_unet_layer_flops(int i);
-double mmd_unet_layer_mfma_flops(int i);
-int mmd_unet_profile(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj, void* workspace_dev,
-                     size_t workspace_bytes, int repeats, float* layer_ms, void* stream);
-/* In-loop profiling: bracket every launch of the kernel that runs layer `layer` (all launches of the same kernel
- * instantiation) with a HIP event pair on its own stream, inside the normal mmd_unet_forward / mmd_p_sample_loop
- * calls -- every `stride`-th such launch, up to max_launches (an event pair costs ~10 us of host/stream time, so the
- * stride keeps the perturbation of the timed region below 0.5 %); layer < 0 switches it off.  After synchronising the stream, mmd_unet_profile_read returns
- * the mean duration and the number of bracketed launches and rearms the pool. */
-int mmd_unet_profile_layer(mmd_unet_t unet, int layer, int max_launches, int stride);
-int mmd_unet_profile_read(mmd_unet_t unet, double* mean_ms, int* n_launches);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Guide  (replaces GuideManagerTrajectoriesWithVelocity.forward, mmd/models/diffusion_models/guides.py:180-226,
@@ -144,9 +126,11 @@ int mmd_soft_constraints_from_paths(const float* paths_dev, int n_all, int robot
 
 /* n_steps x { x += guide(x); apply_hard_conditioning }  (guide_gradient_steps,
  * mmd/models/diffusion_models/sample_functions.py:89-107).  hard_dev [n_robots][2][4]: normalised start / goal
- * state of each robot; hard_mask bit0 = row 0 is conditioned, bit1 = row H-1 is conditioned. */
+ * state of each robot; hard_mask bit0 = row 0 is conditioned, bit1 = row H-1 is conditioned.  chain_dev, if not NULL,
+ * receives the state after EVERY iteration, [n_steps][n_traj, H, 4] (the post-diffusion guide steps of planner_alg
+ * 'diffusion_prior_then_guide', mmd/planners/single_agent/mpd.py:429-453, in one launch). */
 int mmd_guide_steps(const mmd_guide_desc* g, float* x_dev, const float* hard_dev, int hard_mask, int n_robots,
-                    int samples_per_robot, int n_steps, void* stream);
+                    int samples_per_robot, int n_steps, float* chain_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * DDPM sampling  (replaces ddpm_sample_fn, sample_functions.py:40-86, and GaussianDiffusionModel.p_sample_loop /
@@ -168,9 +152,19 @@ typedef struct mmd_sampler_desc {
   int32_t n_streams;                        /* mmd_p_sample_loop splits the robots into this many concurrent HIP
                                              * streams (forked from / joined to `stream`) so one chunk's staging and
                                              * epilogues overlap the other's MFMA phases; 0 = auto (= 1), 1 = off */
+  int64_t traj_index_base;                  /* GLOBAL index of this call's trajectory 0 (= first global robot * samples per
+                                             * robot).  The in-kernel Philox4x32-10 draws are keyed by (seed, draw, global
+                                             * trajectory * H + t), so a rank that samples robots [r0, r1) of an N-robot
+                                             * instance draws exactly the noise those rows get in the unsharded call
+                                             * (per-robot outputs bitwise identical for G = 1, 2, 4, 8) */
+  const float* noise_std_extra_by_t;        /* optional [T] host table: noise_std_extra_schedule_fn(t) evaluated for every
+                                             * t (sample_functions.py:83-86 calls it per step); NULL = the constant above */
+  void* profiler;                           /* optional mmd_profiler_t (include/mmd_amd_debug.h) that brackets UNet launches
+                                             * with HIP events; NULL in production */
 } mmd_sampler_desc;
 
-/* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop (UNet activations + the eps buffer). */
+/* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop: [UNet token (256 B)][eps: n_traj * H * 4 floats].  The chunked
+ * (n_streams > 1) loop uses slices of the same eps block, so this size is exact for every n_streams. */
 size_t mmd_sampler_workspace_bytes(mmd_unet_t unet, int n_traj);
 
 /* One ddpm_sample_fn call + the apply_hard_conditioning that follows it in p_sample_loop
@@ -203,14 +197,44 @@ int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alp
                     int samples_per_robot, int init_noise, uint64_t seed, float* chain_dev, void* workspace_dev,
                     size_t workspace_bytes, void* stream);
 
-/* q_sample (diffusion_model_base.py:425-433): x = a * x_start + b * noise (noise injected or Philox). */
+/* q_sample (diffusion_model_base.py:425-433): x = a * x_start + b * noise (noise injected or Philox keyed by
+ * traj_index_base like the sampler).  n_traj counts blocks of H = 64 support points: a [B, K*64, 4] ensemble seed
+ * (diffusion_ensemble.py:279-281) is n_traj = B * K. */
 int mmd_q_sample(float* x_dev, const float* x_start_dev, const float* noise_dev, float sqrt_alphas_cumprod_t,
-                 float sqrt_one_minus_alphas_cumprod_t, uint64_t seed, uint32_t draw_index, int n_traj, void* stream);
+                 float sqrt_one_minus_alphas_cumprod_t, uint64_t seed, uint32_t draw_index, int64_t traj_index_base,
+                 int n_traj, void* stream);
 
 /* apply_cross_conditioning for one (m1, m2) tile pair (sample_functions.py:17-31): row ind1 of x1 := min(row ind2
  * of x2 + rel, boundary); then row ind2 of x2 := max(row ind1 of x1 - rel, -boundary); rel / boundary are [4] host. */
 int mmd_cross_condition(float* x1_dev, float* x2_dev, int ind1, int ind2, const float* rel, const float* boundary,
                         int n_traj, void* stream);
+
+/* DiffusionsEnsemble.p_sample_loop (mmd/models/diffusion_models/diffusion_ensemble.py:55-106): K tile models chained
+ * along the horizon.  Per outer step the tiles step IN ORDER (UNet + fused DDPM/guide kernel of tile m on its own
+ * x_dev), each followed by apply_cross_conditioning over all (m1, m2) pairs (sample_functions.py:17-31) -- the whole
+ * loop is enqueued by this ONE call (no per-step host round trip).  Every tile has its own model handle, sampler
+ * (schedule, guide-step counts, hard mask, Philox seed via `seed`), guide, state, chain and injected-noise buffers; all
+ * tiles share n_robots / samples_per_robot and the workspace (sized by mmd_sampler_workspace_bytes of the largest). */
+typedef struct mmd_ensemble_tile {
+  mmd_unet_t unet;
+  const mmd_sampler_desc* sampler;
+  const mmd_guide_desc* guide;       /* or NULL */
+  float* x_dev;                      /* [n_traj, H, 4]: x_T / warm start on entry (init_noise != 0: drawn), result on exit */
+  const float* hard_dev;             /* [n_robots][2][4] */
+  const float* step_noise_dev;       /* [n_steps + n_steps_without_noise][n_traj, H, 4] injected draws, or NULL */
+  float* chain_dev;                  /* [n_steps + n_steps_without_noise + 1][n_traj, H, 4], or NULL */
+  uint64_t seed;
+} mmd_ensemble_tile;
+
+typedef struct mmd_cross_cond {
+  int32_t m1, m2, ind1, ind2;        /* row ind1 of tile m1 is stitched to row ind2 of tile m2 */
+  float rel[4];                      /* transforms[m2] - transforms[m1], zero padded to the state dim */
+  float boundary[4];                 /* rel / ||rel|| with zeros replaced by 1e6 */
+} mmd_cross_cond;
+
+int mmd_p_sample_loop_ensemble(const mmd_ensemble_tile* tiles, int n_tiles, const mmd_cross_cond* cross, int n_cross,
+                               int n_robots, int samples_per_robot, int n_steps, int n_steps_without_noise,
+                               int init_noise, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Multi-agent layer next to the sampler
@@ -218,8 +242,9 @@ int mmd_cross_condition(float* x1_dev, float* x2_dev, int ind1, int ind2, const 
 
 /* RobotPlanarDisk.check_rr_collisions (deps/torch_robotics/torch_robotics/robots/robot_planar_disk.py:173-203) as
  * CBS.get_conflicts calls it (mmd/planners/multi_agent/cbs.py:185-190, equal start times, densification 1):
- * mask_dev [H][N][N] uint8 = (||p_i(t) - p_j(t)|| < margin) && i != j; midpoints_dev [H][N][N][2] = (p_i + p_j)/2 or
- * NaN where there is no collision (may be NULL).  paths_dev [N,H,2] un-normalised positions; margin = 2.1 * radius. */
+ * mask_dev [T][N][N] uint8 = (||p_i(t) - p_j(t)|| < margin) && i != j; midpoints_dev [T][N][N][2] = (p_i + p_j)/2 or
+ * NaN where there is no collision (may be NULL).  paths_dev [N,T,2] un-normalised positions, T = `horizon` >= 1 (T = 1:
+ * the start / goal validity check of mmd/common/multi_agent_utils.py:74-79); margin = 2.1 * radius. */
 int mmd_rr_collisions(const float* paths_dev, int n_robots, int horizon, float margin, uint8_t* mask_dev,
                       float* midpoints_dev, void* stream);
 
@@ -229,6 +254,48 @@ int mmd_rr_collisions(const float* paths_dev, int n_robots, int horizon, float m
  * paths_dev [n_all, H, 2].  (The reference's conflict count for sample b is a constant plus twice this number.) */
 int mmd_count_collisions(const float* trajs_dev, const float* paths_dev, int robot0, int n_local,
                          int samples_per_robot, int n_all, int horizon, float margin, int32_t* counts_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Post-sampling selection: the step right after the sampler in MPD.__call__
+ * (mmd/planners/single_agent/mpd.py:344-405)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* PlanningTask.get_trajs_collision_and_free (deps/torch_robotics/torch_robotics/tasks/tasks.py:236-311) +
+ * compute_path_length / compute_smoothness (trajectory/metrics.py:7-39) + smooth_trajs
+ * (mmd/common/trajectory_utils.py:31-40) for a batch of UN-normalised trajectories trajs_dev [n_traj, horizon, 4]
+ * (horizon = 64, or K * 64 for MPDEnsemble's K tiles chained along the horizon; H below = horizon):
+ *   - every segment is linearly interpolated at `num_interpolation` points x_t * alpha_j + x_{t+1} * (1 - alpha_j)
+ *     (alpha [num_interpolation] host = torch.linspace(0, 1, n + 2)[1:n+1], trajectory/utils.py:73-86) and each point
+ *     is tested against the fixed-object SDF grids and workspace boundaries of `env` (only its map / boundary fields
+ *     are read: limits_*, grid_*, n_grids, sdf_grids_dev, robot_map_dev, ws_*) with `margin` (= robot radius,
+ *     tasks.py:251-253): waypoint_collisions_dev [n_traj][(H-1) * num_interpolation] (may be NULL);
+ *   - free_dev[n] = 1 iff no interpolated point collides and every support point lies inside [q_min, q_max]
+ *     (tasks.py:262-281); all_free != 0 skips both tests (PlanningTaskEnsemble, tasks_ensemble.py:271-277);
+ *   - path_length_dev / smoothness_dev [n_traj]: sum_t ||p_{t+1} - p_t||, sum_t ||v_{t+1} - v_t||;
+ *   - smoothed_dev [n_traj, H, 4] (may be NULL) = S @ trajectory with the Savitzky-Golay operator savgol_dev [H][H]
+ *     (row-major, device; NULL = copy) whose row r is zero outside columns [r - savgol_band, r + savgol_band]. */
+int mmd_postprocess_trajs(const mmd_guide_desc* env, const float* trajs_dev, int n_robots, int samples_per_robot,
+                          int horizon, int num_interpolation, const float* alpha, float margin, const float* q_min,
+                          const float* q_max, int all_free, const float* savgol_dev, int savgol_band,
+                          uint8_t* waypoint_collisions_dev,
+                          uint8_t* free_dev, float* path_length_dev, float* smoothness_dev, float* smoothed_dev,
+                          void* stream);
+
+/* Per robot, the index (within its samples_per_robot samples) of the best FREE sample: with counts_dev == NULL the
+ * argmin of cost_a (+ cost_b if not NULL) (torch.argmin(cost_all), mpd.py:366-370); with counts_dev the first free
+ * sample with the fewest robot-robot collisions (CBS 'least_collisions', cbs.py:446-458).  n_free_dev[r] = number of
+ * free samples; when it is 0 the pick is made over all samples instead. */
+int mmd_select_best(const uint8_t* free_dev, const float* cost_a_dev, const float* cost_b_dev, const int32_t* counts_dev,
+                    int n_robots, int samples_per_robot, int32_t* idx_best_dev, int32_t* n_free_dev, void* stream);
+
+/* PlanningTask.compute_collision (tasks.py:141-143, :204-232; occupancy of the fixed objects + workspace boundaries)
+ * for n_points positions (x, y at points_dev[i * point_stride + {0, 1}]) on map `map_index` of `env`. */
+int mmd_points_collision(const mmd_guide_desc* env, const float* points_dev, int n_points, int point_stride, int map_index,
+                         float margin, uint8_t* out_dev, void* stream);
+
+/* compute_variance_waypoints (trajectory/metrics.py:17-27): var_per_waypoint_dev[t] = unbiased variance of all
+ * n_traj^2 entries of triu(cdist(p_t, p_t), 1); the metric is their sum over t. */
+int mmd_variance_waypoints(const float* trajs_dev, int n_traj, int horizon, float* var_per_waypoint_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,41 @@
+/*
+ * mmd_amd_debug.h -- measurement hooks of libmmd_amd.so (bench.py / tools only; NOT part of the drop-in boundary of
+ * include/mmd_amd.h).  The product handles (mmd_unet_t) are immutable: all profiling state lives in a caller-owned
+ * mmd_profiler_t that is handed to the sampler through mmd_sampler_desc.profiler.
+ */
+#ifndef MMD_AMD_DEBUG_H
+#define MMD_AMD_DEBUG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mmd_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Event-pair pool: every `stride`-th UNet launch issued with this profiler attached is bracketed by a HIP event pair
+ * recorded on the stream the kernel is launched on, up to max_launches pairs (an event pair costs ~10 us of host/stream
+ * time, so a stride keeps the perturbation of a timed region below 0.5 %).  One profiler must not be shared by
+ * concurrent calls. */
+typedef struct mmd_profiler_s* mmd_profiler_t;
+int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride);
+int mmd_profiler_destroy(mmd_profiler_t p);
+/* After synchronising the stream(s): mean duration [ms] and number of bracketed launches; rearms the pool. */
+int mmd_profiler_read(mmd_profiler_t p, double* mean_ms, int* n_launches);
+
+/* One TemporalUnet forward = one launch of unet_kernel.  Algorithmic FLOPs per trajectory (direct-convolution count:
+ * 2 * C_out * taps * C_in * L_out over its convs) and the MFMA FLOPs the kernel actually issues per
+ * trajectory (the 25 k=5 convs run as Winograd F(4,5): 8 products per 4 outputs; channel / N padding included). */
+double mmd_unet_flops_per_trajectory(void);
+double mmd_unet_mfma_flops_per_trajectory(void);
+
+/* mmd_unet_forward with the profiler attached (what mmd_p_sample_loop does internally when desc.profiler is set). */
+int mmd_unet_forward_profiled(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj,
+                              void* workspace_dev, size_t workspace_bytes, mmd_profiler_t profiler, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMD_AMD_DEBUG_H */

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmd_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GuideDesc(C.Structure):
@@ -32,7 +32,21 @@ class SamplerDesc(C.Structure):
         ("posterior_log_variance_clipped", C.POINTER(C.c_float)),
         ("n_guide_steps", C.c_int32), ("t_start_guide", C.c_int32),
         ("noise_std_extra", C.c_float), ("hard_mask", C.c_int32), ("n_streams", C.c_int32),
+        ("traj_index_base", C.c_int64), ("noise_std_extra_by_t", C.POINTER(C.c_float)), ("profiler", C.c_void_p),
     ]
+
+
+class EnsembleTile(C.Structure):
+    _fields_ = [
+        ("unet", C.c_void_p), ("sampler", C.POINTER(SamplerDesc)), ("guide", C.POINTER(GuideDesc)),
+        ("x_dev", C.c_void_p), ("hard_dev", C.c_void_p), ("step_noise_dev", C.c_void_p), ("chain_dev", C.c_void_p),
+        ("seed", C.c_uint64),
+    ]
+
+
+class CrossCond(C.Structure):
+    _fields_ = [("m1", C.c_int32), ("m2", C.c_int32), ("ind1", C.c_int32), ("ind2", C.c_int32),
+                ("rel", C.c_float * 4), ("boundary", C.c_float * 4)]
 
 
 _SIGNATURES = {
@@ -46,20 +60,12 @@ _SIGNATURES = {
     "mmd_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "mmd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),
-    "mmd_unet_num_layers": (C.c_int, []),
-    "mmd_unet_layer_name": (C.c_char_p, [C.c_int]),
-    "mmd_unet_layer_flops": (C.c_double, [C.c_int]),
-    "mmd_unet_layer_mfma_flops": (C.c_double, [C.c_int]),
-    "mmd_unet_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
-                                   C.c_int, C.POINTER(C.c_float), C.c_void_p]),
-    "mmd_unet_profile_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
-    "mmd_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mmd_pack_constraints": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "mmd_soft_constraints_from_paths": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmd_guide_steps": (C.c_int, [C.POINTER(GuideDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                  C.c_void_p]),
+                                  C.c_void_p, C.c_void_p]),
     "mmd_sampler_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "mmd_ddpm_step": (C.c_int, [C.c_void_p, C.POINTER(SamplerDesc), C.POINTER(GuideDesc), C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_size_t,
@@ -70,16 +76,39 @@ _SIGNATURES = {
     "mmd_ddim_sample": (C.c_int, [C.c_void_p, C.POINTER(SamplerDesc), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(GuideDesc),
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
+    "mmd_p_sample_loop_ensemble": (C.c_int, [C.POINTER(EnsembleTile), C.c_int, C.POINTER(CrossCond), C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mmd_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint32,
-                               C.c_int, C.c_void_p]),
+                               C.c_int64, C.c_int, C.c_void_p]),
     "mmd_rr_collisions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmd_count_collisions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                        C.c_void_p, C.c_void_p]),
+    "mmd_postprocess_trajs": (C.c_int, [C.POINTER(GuideDesc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "mmd_select_best": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "mmd_points_collision": (C.c_int, [C.POINTER(GuideDesc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                       C.c_void_p]),
+    "mmd_variance_waypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mmd_cross_condition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.c_int, C.c_void_p]),
 }
 
+# include/mmd_amd_debug.h: measurement hooks (bench.py / tools), not part of the drop-in boundary
+_DEBUG_SIGNATURES = {
+    "mmd_profiler_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "mmd_profiler_destroy": (C.c_int, [C.c_void_p]),
+    "mmd_profiler_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "mmd_unet_flops_per_trajectory": (C.c_double, []),
+    "mmd_unet_mfma_flops_per_trajectory": (C.c_double, []),
+    "mmd_unet_forward_profiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_void_p]),
+}
+
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+DEBUG_SYMBOLS = tuple(_DEBUG_SIGNATURES)
 _lib = None
 
 
@@ -91,7 +120,7 @@ def load():
             raise ImportError(f"{LIB_PATH} not found: the HIP extension is required (run ./build.sh or "
                               f"`python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
         lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGNATURES.items():
+        for name, (res, args) in list(_SIGNATURES.items()) + list(_DEBUG_SIGNATURES.items()):
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
         if lib.mmd_abi_version() != ABI_VERSION:

@@ -1,7 +1,7 @@
 // Sampling-loop orchestration and ABI bookkeeping of libmmd_amd.so.
 //
-// p_sample_loop (diffusion_model_base.py:162-211) = per outer step: 29 UNet kernels (unet.hip) + ONE fused kernel
-// doing posterior mean, the n_guide_steps guide iterations, noise and hard conditioning (guide.hip).  Everything is
+// p_sample_loop (diffusion_model_base.py:162-211) = per outer step: ONE UNet launch (unet.hip) + ONE fused kernel doing
+// posterior mean, the n_guide_steps guide iterations, noise and hard conditioning (guide.hip).  Everything is
 // enqueued on the caller's stream with no host synchronisation: the reference's per-step `.item()`-style syncs
 // (sample_functions.py:53,63; normalization.py:161) do not exist here because the branches depend only on the
 // loop index, which the host knows.
@@ -11,8 +11,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 
 #include "../../include/mmd_amd.h"
+#include "../../include/mmd_amd_debug.h"
 #include "common.h"
 #include "guide_dev.h"
 
@@ -29,7 +31,7 @@ void set_error(const char* fmt, ...) {
 
 constexpr int kMaxChunks = 4;
 
-// side streams of the chunked sampling loop: created once per process, never destroyed
+// side streams of the chunked sampling loop: created once per (thread, device), never destroyed
 struct Streams {
   hipStream_t s[kMaxChunks] = {};
   hipEvent_t fork = nullptr, join[kMaxChunks] = {};
@@ -46,8 +48,10 @@ struct Streams {
   }
 };
 static Streams& streams() {
-  static thread_local Streams S;   // streams belong to the calling thread's current device
-  return S;
+  static thread_local std::map<int, Streams> S;   // keyed by the device that is current at the call
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return S[dev];
 }
 
 static int make_step(const mmd_sampler_desc* s, int i, bool guided, StepDev& sd) {
@@ -58,13 +62,19 @@ static int make_step(const mmd_sampler_desc* s, int i, bool guided, StepDev& sd)
   sd.c1 = s->posterior_mean_coef1[t];
   sd.c2 = s->posterior_mean_coef2[t];
   sd.sigma = expf(0.5f * s->posterior_log_variance_clipped[t]);   // model_std, sample_functions.py:60
-  sd.noise_std_extra = s->noise_std_extra;
+  // noise_std_extra_schedule_fn(t_single), evaluated per step (sample_functions.py:83-86)
+  sd.noise_std_extra = s->noise_std_extra_by_t ? s->noise_std_extra_by_t[t] : s->noise_std_extra;
   sd.do_model = 1;
   sd.do_guide = guided && i < s->t_start_guide ? 1 : 0;           // sample_functions.py:63
   sd.do_noise = t == 0 ? 0 : 1;                                   // noise[t == 0] = 0, sample_functions.py:76
   sd.n_guide_steps = s->n_guide_steps;
   sd.hard_mask = s->hard_mask;
+  sd.traj_base = (long long)s->traj_index_base;
   return 0;
+}
+
+static inline float* eps_of(void* workspace_dev, mmd_unet_t unet, int n) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(workspace_dev) + mmd_unet_workspace_bytes(unet, n));
 }
 
 }  // namespace mmd
@@ -76,6 +86,7 @@ extern "C" {
 int mmd_abi_version(void) { return MMD_AMD_ABI_VERSION; }
 const char* mmd_last_error(void) { return g_err; }
 
+// [UNet token][eps of all n trajectories]; stream chunks use slices of the one eps block
 size_t mmd_sampler_workspace_bytes(mmd_unet_t unet, int n_traj) {
   return mmd_unet_workspace_bytes(unet, n_traj) + (size_t)(n_traj > 0 ? n_traj : 0) * H * D * sizeof(float);
 }
@@ -89,14 +100,16 @@ int mmd_ddpm_step(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_de
   MMD_REQUIRE(workspace_bytes >= mmd_sampler_workspace_bytes(unet, n), "mmd_ddpm_step: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const size_t uws = mmd_unet_workspace_bytes(unet, n);
-  float* eps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace_dev) + uws);
+  float* eps = eps_of(workspace_dev, unet, n);
   StepDev sd{};
   if (int rc = make_step(s, i, guide != nullptr, sd)) return rc;
   sd.seed = seed; sd.draw = draw_index;
   GuideDev g{};
   if (sd.do_guide)
     if (int rc = fill_guide(guide, g)) return rc;
-  if (int rc = mmd_unet_forward(unet, x_dev, i < 0 ? 0 : i, eps, n, workspace_dev, uws, stream)) return rc;
+  if (int rc = mmd_unet_forward_profiled(unet, x_dev, i < 0 ? 0 : i, eps, n, workspace_dev, uws,
+                                         (mmd_profiler_t)s->profiler, stream))
+    return rc;
   launch_step(g, sd, x_dev, eps, noise_dev, nullptr, hard_dev, 0, n, samples_per_robot, st);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
@@ -116,62 +129,118 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   GuideDev g{};
   if (guide)
     if (int rc = fill_guide(guide, g)) return rc;
-  launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed, n, samples_per_robot, st);
+  launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed,
+              (long long)s->traj_index_base, n, samples_per_robot, st);
 
   // Split the robots into concurrent chunks: each chunk's kernels go to its own stream, launches interleaved layer by
-  // layer so both queues stay fed.  Robots are independent, so results are bit-identical to the unsplit run.
+  // layer so both queues stay fed.  Robots are independent and the noise is keyed by the global trajectory index, so
+  // results are bit-identical to the unsplit run.
   int nch = s->n_streams;
   if (const char* e = getenv("MMD_AMD_STREAMS")) nch = atoi(e);
   if (nch <= 0) nch = 1;   // auto = off: 2 chunks measured +3 % only, and one stream keeps per-kernel accounting clean
   if (nch > kMaxChunks) nch = kMaxChunks;
   if (nch > n_robots) nch = n_robots;
-  Streams& S = streams();
-  if (nch > 1 && !S.ok()) nch = 1;
+  Streams* S = nullptr;
+  if (nch > 1) {
+    S = &streams();
+    if (!S->ok()) nch = 1;
+  }
   hipStream_t cs[kMaxChunks];
   int r0[kMaxChunks + 1];
-  char* wsp[kMaxChunks];
-  size_t wsb[kMaxChunks];
-  float* epsp[kMaxChunks];
-  {
-    char* w = reinterpret_cast<char*>(workspace_dev);
-    for (int c = 0; c <= nch; ++c) r0[c] = (int)((long long)n_robots * c / nch);
-    for (int c = 0; c < nch; ++c) {
-      const int nc = (r0[c + 1] - r0[c]) * samples_per_robot;
-      wsp[c] = w;
-      wsb[c] = mmd_unet_workspace_bytes(unet, nc);
-      epsp[c] = reinterpret_cast<float*>(w + wsb[c]);
-      w += mmd_sampler_workspace_bytes(unet, nc);
-      cs[c] = nch == 1 ? st : S.s[c];
-    }
-  }
+  for (int c = 0; c <= nch; ++c) r0[c] = (int)((long long)n_robots * c / nch);
+  for (int c = 0; c < nch; ++c) cs[c] = nch == 1 ? st : S->s[c];
+  const size_t uws = mmd_unet_workspace_bytes(unet, n);
+  float* eps = eps_of(workspace_dev, unet, n);           // chunk c uses rows [r0[c] * spr, r0[c+1] * spr) of it
   if (nch > 1) {
-    MMD_HIP_CHECK(hipEventRecord(S.fork, st));
-    for (int c = 0; c < nch; ++c) MMD_HIP_CHECK(hipStreamWaitEvent(cs[c], S.fork, 0));
+    MMD_HIP_CHECK(hipEventRecord(S->fork, st));
+    for (int c = 0; c < nch; ++c) MMD_HIP_CHECK(hipStreamWaitEvent(cs[c], S->fork, 0));
   }
-  int k = 0;
-  for (int i = n_steps - 1; i >= -n_steps_without_noise; --i, ++k) {
+  int rc = 0, k = 0;
+  for (int i = n_steps - 1; i >= -n_steps_without_noise && rc == 0; --i, ++k) {
     StepDev sd{};
-    if (int rc = make_step(s, i, guide != nullptr, sd)) return rc;
+    if ((rc = make_step(s, i, guide != nullptr, sd))) break;
     sd.seed = seed; sd.draw = (unsigned int)k;
-    for (int c = 0; c < nch; ++c) {
+    for (int c = 0; c < nch && rc == 0; ++c) {
       const int t0 = r0[c] * samples_per_robot, nc = (r0[c + 1] - r0[c]) * samples_per_robot;
-      if (int rc = mmd_unet_forward(unet, x_dev + (size_t)t0 * H * D, i < 0 ? 0 : i, epsp[c], nc, wsp[c], wsb[c], cs[c]))
-        return rc;
+      rc = mmd_unet_forward_profiled(unet, x_dev + (size_t)t0 * H * D, i < 0 ? 0 : i, eps + (size_t)t0 * H * D, nc,
+                                     workspace_dev, uws, (mmd_profiler_t)s->profiler, cs[c]);
     }
-    for (int c = 0; c < nch; ++c) {
+    for (int c = 0; c < nch && rc == 0; ++c) {
       const int t0 = r0[c] * samples_per_robot, nc = (r0[c + 1] - r0[c]) * samples_per_robot;
-      // eps of this chunk is indexed from its own buffer: pass a pointer rebased to the full-array indexing
-      launch_step(g, sd, x_dev, epsp[c] - (size_t)t0 * H * D,
-                  step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr,
+      launch_step(g, sd, x_dev, eps, step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr,
                   chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr, hard_dev, t0, nc, samples_per_robot,
                   cs[c]);
     }
   }
+  // join on every exit path: an error above must not leave the caller's stream detached from the side streams
   if (nch > 1)
     for (int c = 0; c < nch; ++c) {
-      MMD_HIP_CHECK(hipEventRecord(S.join[c], cs[c]));
-      MMD_HIP_CHECK(hipStreamWaitEvent(st, S.join[c], 0));
+      if (hipEventRecord(S->join[c], cs[c]) != hipSuccess || hipStreamWaitEvent(st, S->join[c], 0) != hipSuccess) {
+        if (rc == 0) { set_error("mmd_p_sample_loop: joining side stream %d failed", c); rc = 1; }
+      }
     }
+  if (rc) return rc;
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int mmd_p_sample_loop_ensemble(const mmd_ensemble_tile* tiles, int n_tiles, const mmd_cross_cond* cross, int n_cross,
+                               int n_robots, int samples_per_robot, int n_steps, int n_steps_without_noise,
+                               int init_noise, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  MMD_REQUIRE(tiles && n_tiles >= 1 && (n_cross == 0 || cross) && workspace_dev, "mmd_p_sample_loop_ensemble: NULL argument");
+  const int n = n_robots * samples_per_robot;
+  MMD_REQUIRE(n >= 1 && n_steps >= 0 && n_steps_without_noise >= 0, "mmd_p_sample_loop_ensemble: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t traj_floats = (size_t)n * H * D;
+  GuideDev g[8];
+  MMD_REQUIRE(n_tiles <= 8, "mmd_p_sample_loop_ensemble: at most 8 tiles");
+  for (int m = 0; m < n_tiles; ++m) {
+    const mmd_ensemble_tile& T = tiles[m];
+    MMD_REQUIRE(T.unet && T.sampler && T.x_dev && T.hard_dev, "tile %d: NULL member", m);
+    MMD_REQUIRE(n_steps <= T.sampler->n_diffusion_steps, "tile %d: more steps than its schedule has", m);
+    MMD_REQUIRE(workspace_bytes >= mmd_sampler_workspace_bytes(T.unet, n), "mmd_p_sample_loop_ensemble: workspace too small");
+    g[m] = GuideDev{};
+    if (T.guide)
+      if (int rc = fill_guide(T.guide, g[m])) return rc;
+  }
+  for (int c = 0; c < n_cross; ++c)
+    MMD_REQUIRE(cross[c].m1 >= 0 && cross[c].m1 < n_tiles && cross[c].m2 >= 0 && cross[c].m2 < n_tiles &&
+                    cross[c].ind1 >= 0 && cross[c].ind1 < H && cross[c].ind2 >= 0 && cross[c].ind2 < H,
+                "cross condition %d out of range", c);
+  // apply_cross_conditioning (sample_functions.py:17-31) over all pairs; row `crow` of the chains is kept in step
+  auto cross_all = [&](int crow) {
+    for (int c = 0; c < n_cross; ++c) {
+      const mmd_cross_cond& C = cross[c];
+      float* ch1 = tiles[C.m1].chain_dev ? tiles[C.m1].chain_dev + (size_t)crow * traj_floats : nullptr;
+      float* ch2 = tiles[C.m2].chain_dev ? tiles[C.m2].chain_dev + (size_t)crow * traj_floats : nullptr;
+      launch_cross(tiles[C.m1].x_dev, tiles[C.m2].x_dev, ch1, ch2, C.ind1, C.ind2, C.rel, C.boundary, n, st);
+    }
+  };
+  // x_T per tile (diffusion_ensemble.py:66-81): draw / keep, hard conditioning, then cross conditioning; chain[0]
+  for (int m = 0; m < n_tiles; ++m)
+    launch_init(tiles[m].x_dev, tiles[m].chain_dev, tiles[m].hard_dev, tiles[m].sampler->hard_mask, init_noise,
+                (unsigned long long)tiles[m].seed, (long long)tiles[m].sampler->traj_index_base, n, samples_per_robot, st);
+  cross_all(0);
+  int k = 0;
+  for (int i = n_steps - 1; i >= -n_steps_without_noise; --i, ++k) {
+    // tiles step IN ORDER inside an outer step and every tile's step is followed by the cross conditioning of all pairs
+    // (diffusion_ensemble.py:86-100): tile m+1's UNet input already carries the boundary row stitched after tile m's
+    // step, so the tiles of one outer step cannot be merged into one batched launch without changing the result
+    for (int m = 0; m < n_tiles; ++m) {
+      const mmd_ensemble_tile& T = tiles[m];
+      StepDev sd{};
+      if (int rc = make_step(T.sampler, i, T.guide != nullptr, sd)) return rc;
+      sd.seed = T.seed; sd.draw = (unsigned int)k;
+      float* eps = eps_of(workspace_dev, T.unet, n);
+      if (int rc = mmd_unet_forward_profiled(T.unet, T.x_dev, i < 0 ? 0 : i, eps, n, workspace_dev,
+                                             mmd_unet_workspace_bytes(T.unet, n), (mmd_profiler_t)T.sampler->profiler, st))
+        return rc;
+      launch_step(g[m], sd, T.x_dev, eps, T.step_noise_dev ? T.step_noise_dev + (size_t)k * traj_floats : nullptr,
+                  T.chain_dev ? T.chain_dev + (size_t)(k + 1) * traj_floats : nullptr, T.hard_dev, 0, n,
+                  samples_per_robot, st);
+      cross_all(k + 1);
+    }
+  }
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -187,11 +256,12 @@ int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alp
   hipStream_t st = (hipStream_t)stream;
   const size_t traj_floats = (size_t)n * H * D;
   const size_t uws = mmd_unet_workspace_bytes(unet, n);
-  float* eps = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace_dev) + uws);
+  float* eps = eps_of(workspace_dev, unet, n);
   GuideDev g{};
   if (guide)
     if (int rc = fill_guide(guide, g)) return rc;
-  launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed, n, samples_per_robot, st);
+  launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed,
+              (long long)s->traj_index_base, n, samples_per_robot, st);
   for (int k = 0; k + 1 < n_times; ++k) {
     const int t = times[k], tn = times[k + 1];
     MMD_REQUIRE(t >= 0 && t < s->n_diffusion_steps && tn < t, "mmd_ddim_sample: times must decrease inside the schedule");
@@ -207,7 +277,9 @@ int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alp
     sd.n_guide_steps = s->n_guide_steps;
     sd.hard_mask = s->hard_mask;
     sd.seed = seed; sd.draw = (unsigned int)k;
-    if (int rc = mmd_unet_forward(unet, x_dev, t, eps, n, workspace_dev, uws, stream)) return rc;
+    sd.traj_base = (long long)s->traj_index_base;
+    if (int rc = mmd_unet_forward_profiled(unet, x_dev, t, eps, n, workspace_dev, uws, (mmd_profiler_t)s->profiler, stream))
+      return rc;
     launch_step(g, sd, x_dev, eps, nullptr, chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr, hard_dev, 0, n,
                 samples_per_robot, st);
     if (tn < 0) break;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -39,8 +40,10 @@ __device__ __forceinline__ void philox4x32(unsigned int (&c)[4], unsigned int k0
   }
 }
 
-__device__ __forceinline__ float4 normal4(unsigned long long seed, unsigned int draw, unsigned int point) {
-  unsigned int c[4] = {point, draw, 0u, 0u};
+// counter = (GLOBAL point index lo, draw, GLOBAL point index hi, 0), key = seed: a (robot, sample, t) point draws the same
+// noise whichever rank / stream chunk / batch position it is sampled in
+__device__ __forceinline__ float4 normal4(unsigned long long seed, unsigned int draw, unsigned long long point) {
+  unsigned int c[4] = {(unsigned int)point, draw, (unsigned int)(point >> 32), 0u};
   philox4x32(c, (unsigned int)seed, (unsigned int)(seed >> 32));
   const float s = 2.3283064365386963e-10f;   // 2^-32
   const float u0 = ((float)c[0] + 0.5f) * s, u1 = ((float)c[1] + 0.5f) * s;
@@ -79,6 +82,11 @@ constexpr int LDS_SLOTS_MAX = 144;
 // <=> not (dist^2 > R|R|): one transcendental (rsq) per point, no branch (a wave-uniform skip of inactive slot pairs was
 // measured slower: most pairs have an active lane somewhere along the horizon).  Two accumulator pairs break the
 // dependent add chain.
+// 1 / sqrt(d2) for the unit direction d / ||d||.  A point that coincides exactly with a constraint centre has d = 0: the
+// reference's torch.norm backward gives a zero gradient there (subgradient 0), so the reciprocal is taken of
+// max(d2, tiny) and d * m = 0 instead of 0 * inf = NaN.
+__device__ __forceinline__ float rsq_pos(float d2) { return __builtin_amdgcn_rsqf(fmaxf(d2, 1e-30f)); }
+
 template <int UNROLL>
 __device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t, float px, float py, float& gx,
                                                 float& gy) {
@@ -89,8 +97,8 @@ __device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t,
     const float4 c0 = tab[s * H + t], c1 = tab[(s + 1) * H + t];
     const float dx0 = px - c0.x, dy0 = py - c0.y, dx1 = px - c1.x, dy1 = py - c1.y;
     const float d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
-    const float m0 = (d0 > c0.w) ? 0.f : __builtin_amdgcn_rsqf(d0);
-    const float m1 = (d1 > c1.w) ? 0.f : __builtin_amdgcn_rsqf(d1);
+    const float m0 = (d0 > c0.w) ? 0.f : rsq_pos(d0);
+    const float m1 = (d1 > c1.w) ? 0.f : rsq_pos(d1);
     ax -= dx0 * m0; ay -= dy0 * m0;
     bx -= dx1 * m1; by -= dy1 * m1;
   }
@@ -98,7 +106,7 @@ __device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t,
     const float4 c0 = tab[s * H + t];
     const float dx0 = px - c0.x, dy0 = py - c0.y;
     const float d0 = dx0 * dx0 + dy0 * dy0;
-    const float m0 = (d0 > c0.w) ? 0.f : __builtin_amdgcn_rsqf(d0);
+    const float m0 = (d0 > c0.w) ? 0.f : rsq_pos(d0);
     ax -= dx0 * m0; ay -= dy0 * m0;
   }
   gx += ax + bx;
@@ -117,8 +125,8 @@ __device__ __forceinline__ void cons_accumulate_xy(const float2* tab, int n, int
     const float2 c0 = tab[s * H + t], c1 = tab[(s + 1) * H + t];
     const float dx0 = px - c0.x, dy0 = py - c0.y, dx1 = px - c1.x, dy1 = py - c1.y;
     const float d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
-    const float m0 = (d0 > r2) ? 0.f : __builtin_amdgcn_rsqf(d0);
-    const float m1 = (d1 > r2) ? 0.f : __builtin_amdgcn_rsqf(d1);
+    const float m0 = (d0 > r2) ? 0.f : rsq_pos(d0);
+    const float m1 = (d1 > r2) ? 0.f : rsq_pos(d1);
     ax -= dx0 * m0; ay -= dy0 * m0;
     bx -= dx1 * m1; by -= dy1 * m1;
   }
@@ -126,7 +134,7 @@ __device__ __forceinline__ void cons_accumulate_xy(const float2* tab, int n, int
     const float2 c0 = tab[s * H + t];
     const float dx0 = px - c0.x, dy0 = py - c0.y;
     const float d0 = dx0 * dx0 + dy0 * dy0;
-    const float m0 = (d0 > r2) ? 0.f : __builtin_amdgcn_rsqf(d0);
+    const float m0 = (d0 > r2) ? 0.f : rsq_pos(d0);
     ax -= dx0 * m0; ay -= dy0 * m0;
   }
   gx += ax + bx;
@@ -309,11 +317,12 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
       v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w;
       if (is_start) v = hs;
       if (is_goal) v = hg;
+      if (s.guide_chain) s.guide_chain[(size_t)it * s.guide_chain_stride + idx] = v;
     }
   }
 
   if (s.do_noise) {
-    float4 z = noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned int)idx);
+    float4 z = noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx);
     // x + model_std * noise * noise_std  (sample_functions.py:86)
     v.x += s.sigma * z.x * s.noise_std_extra;
     v.y += s.sigma * z.y * s.noise_std_extra;
@@ -328,12 +337,13 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
 
 // x <- conditioned init: optional Philox draw of x_T, apply_hard_conditioning, optional chain[0] write
 __global__ void init_kernel(float4* __restrict__ x, float4* __restrict__ chain, const float4* __restrict__ hard,
-                            int hard_mask, int draw_noise, unsigned long long seed, int n_traj, int samples_per_robot) {
+                            int hard_mask, int draw_noise, unsigned long long seed, long long traj_base, int n_traj,
+                            int samples_per_robot) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n_traj * H) return;
   const int t = idx % H;
   const int robot = (idx / H) / samples_per_robot;
-  float4 v = draw_noise ? normal4(seed, 0xFFFFFFFFu, (unsigned int)idx) : x[idx];
+  float4 v = draw_noise ? normal4(seed, 0xFFFFFFFFu, (unsigned long long)traj_base * H + idx) : x[idx];
   if ((hard_mask & 1) && t == 0) v = hard[robot * 2];
   if ((hard_mask & 2) && t == H - 1) v = hard[robot * 2 + 1];
   x[idx] = v;
@@ -341,16 +351,19 @@ __global__ void init_kernel(float4* __restrict__ x, float4* __restrict__ chain, 
 }
 
 __global__ void q_sample_kernel(float4* __restrict__ x, const float4* __restrict__ x0, const float4* __restrict__ noise,
-                                float a, float b, unsigned long long seed, unsigned int draw, size_t n_pts) {
+                                float a, float b, unsigned long long seed, unsigned int draw, long long traj_base,
+                                size_t n_pts) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_pts) return;
-  const float4 z = noise ? noise[idx] : normal4(seed, draw, (unsigned int)idx);
+  const float4 z = noise ? noise[idx] : normal4(seed, draw, (unsigned long long)traj_base * H + idx);
   const float4 s = x0[idx];
   x[idx] = make_float4(a * s.x + b * z.x, a * s.y + b * z.y, a * s.z + b * z.z, a * s.w + b * z.w);
 }
 
-__global__ void cross_condition_kernel(float4* __restrict__ x1, float4* __restrict__ x2, int ind1, int ind2,
-                                       float4 rel, float4 bnd, int n_traj) {
+// apply_cross_conditioning for one (m1, m2) pair (sample_functions.py:28-29); c1 / c2: the chain rows of the current
+// outer step (or NULL), kept equal to x1 / x2
+__global__ void cross_condition_kernel(float4* __restrict__ x1, float4* __restrict__ x2, float4* __restrict__ c1,
+                                       float4* __restrict__ c2, int ind1, int ind2, float4 rel, float4 bnd, int n_traj) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_traj) return;
   const float4 v2 = x2[(size_t)b * H + ind2];
@@ -362,6 +375,8 @@ __global__ void cross_condition_kernel(float4* __restrict__ x1, float4* __restri
   w.x = fmaxf(v1.x - rel.x, -bnd.x); w.y = fmaxf(v1.y - rel.y, -bnd.y);
   w.z = fmaxf(v1.z - rel.z, -bnd.z); w.w = fmaxf(v1.w - rel.w, -bnd.w);
   x2[(size_t)b * H + ind2] = w;
+  if (c1) c1[(size_t)b * H + ind1] = v1;
+  if (c2) c2[(size_t)b * H + ind2] = w;
 }
 
 // all-pairs soft constraints from best paths (cbs.py:468-508): slot j of local robot i = other robot j (+1 past i)
@@ -430,13 +445,18 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
     // 8 trajectories of one robot per workgroup (2048 trajectories = 256 workgroups = one per CU); LDS sized to the
     // largest table any robot can have (g.max_slots), the rest of a larger table is read from L2
     const int slots = g.max_slots < big ? g.max_slots : big;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the 144 KiB dynamic-LDS opt-in is a per-device function attribute: set it once for every device this process
+    // launches on (two threads racing on the same device both set the same value, which is harmless)
+    static std::atomic<unsigned long long> attr_devices{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpm_guide_kernel<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SLOTS_MAX * H * 16);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ddpm_guide_kernel<8, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SLOTS_MAX * H * 16);
-      attr_set = true;
+      attr_devices.fetch_or(bit, std::memory_order_release);
     }
     if (compact) launch(ddpm_guide_kernel<8, true>, 8, slots);
     else launch(ddpm_guide_kernel<8, false>, 8, slots);
@@ -448,11 +468,18 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
   return 0;
 }
 
-int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed, int n_traj,
-                int spr, hipStream_t st) {
+void launch_cross(float* x1, float* x2, float* c1, float* c2, int ind1, int ind2, const float* rel, const float* bnd,
+                  int n_traj, hipStream_t st) {
+  hipLaunchKernelGGL(cross_condition_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, st, (float4*)x1, (float4*)x2,
+                     (float4*)c1, (float4*)c2, ind1, ind2, make_float4(rel[0], rel[1], rel[2], rel[3]),
+                     make_float4(bnd[0], bnd[1], bnd[2], bnd[3]), n_traj);
+}
+
+int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed,
+                long long traj_base, int n_traj, int spr, hipStream_t st) {
   const size_t n = (size_t)n_traj * H;
   hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float4*)x, (float4*)chain,
-                     (const float4*)hard, hard_mask, draw, seed, n_traj, spr);
+                     (const float4*)hard, hard_mask, draw, seed, traj_base, n_traj, spr);
   return 0;
 }
 
@@ -515,12 +542,14 @@ int mmd_soft_constraints_from_paths(const float* paths_dev, int n_all, int robot
 }
 
 int mmd_guide_steps(const mmd_guide_desc* d, float* x_dev, const float* hard_dev, int hard_mask, int n_robots,
-                    int samples_per_robot, int n_steps, void* stream) {
+                    int samples_per_robot, int n_steps, float* chain_dev, void* stream) {
   MMD_REQUIRE(d && x_dev && hard_dev, "mmd_guide_steps: NULL argument");
   GuideDev g{};
   if (int rc = fill_guide(d, g)) return rc;
   StepDev s{};
   s.do_guide = 1; s.n_guide_steps = n_steps; s.hard_mask = hard_mask;
+  s.guide_chain = reinterpret_cast<float4*>(chain_dev);
+  s.guide_chain_stride = (long long)n_robots * samples_per_robot * H;
   launch_step(g, s, x_dev, nullptr, nullptr, nullptr, hard_dev, 0, n_robots * samples_per_robot, samples_per_robot,
               (hipStream_t)stream);
   MMD_HIP_CHECK(hipGetLastError());
@@ -528,21 +557,21 @@ int mmd_guide_steps(const mmd_guide_desc* d, float* x_dev, const float* hard_dev
 }
 
 int mmd_q_sample(float* x_dev, const float* x_start_dev, const float* noise_dev, float a, float b, uint64_t seed,
-                 uint32_t draw_index, int n_traj, void* stream) {
+                 uint32_t draw_index, int64_t traj_index_base, int n_traj, void* stream) {
+  MMD_REQUIRE(x_dev && x_start_dev && n_traj >= 1, "mmd_q_sample: bad arguments");
   const size_t n = (size_t)n_traj * H;
   hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (float4*)x_dev, (const float4*)x_start_dev, (const float4*)noise_dev, a, b,
-                     (unsigned long long)seed, draw_index, n);
+                     (unsigned long long)seed, draw_index, (long long)traj_index_base, n);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int mmd_cross_condition(float* x1_dev, float* x2_dev, int ind1, int ind2, const float* rel, const float* boundary,
                         int n_traj, void* stream) {
+  MMD_REQUIRE(x1_dev && x2_dev && rel && boundary, "mmd_cross_condition: NULL argument");
   MMD_REQUIRE(ind1 >= 0 && ind1 < H && ind2 >= 0 && ind2 < H, "row index out of range");
-  hipLaunchKernelGGL(cross_condition_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     (float4*)x1_dev, (float4*)x2_dev, ind1, ind2, make_float4(rel[0], rel[1], rel[2], rel[3]),
-                     make_float4(boundary[0], boundary[1], boundary[2], boundary[3]), n_traj);
+  launch_cross(x1_dev, x2_dev, nullptr, nullptr, ind1, ind2, rel, boundary, n_traj, (hipStream_t)stream);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }

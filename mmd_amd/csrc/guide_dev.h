@@ -35,12 +35,18 @@ struct StepDev {
   unsigned long long seed;
   unsigned int draw;
   int traj0, traj_end;               // this launch covers trajectories [traj0, traj_end) of the full arrays
+  float4* guide_chain;               // optional [n_guide_steps][n_traj_total][H]: state after every guide iteration
+  long long guide_chain_stride;      // float4 elements between consecutive iterations
+  long long traj_base;               // global index of trajectory 0 of the arrays (mmd_sampler_desc.traj_index_base)
 };
 
 int fill_guide(const mmd_guide_desc* d, GuideDev& g);
 int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
                 const float* hard, int traj0, int n_traj, int spr, hipStream_t st);
-int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed, int n_traj,
-                int spr, hipStream_t st);
+int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed,
+                long long traj_base, int n_traj, int spr, hipStream_t st);
+
+void launch_cross(float* x1, float* x2, float* c1, float* c2, int ind1, int ind2, const float* rel, const float* bnd,
+                  int n_traj, hipStream_t st);
 
 }  // namespace mmd

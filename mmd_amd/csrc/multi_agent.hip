@@ -12,12 +12,12 @@
 
 namespace mmd {
 
-__global__ void rr_collisions_kernel(const float2* __restrict__ paths, int n, float margin,
+__global__ void rr_collisions_kernel(const float2* __restrict__ paths, int n, int T, float margin,
                                      unsigned char* __restrict__ mask, float2* __restrict__ mid) {
-  const size_t tot = (size_t)H * n * n;
+  const size_t tot = (size_t)T * n * n;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
     const int j = idx % n, i = (idx / n) % n, t = idx / ((size_t)n * n);
-    const float2 a = paths[(size_t)i * H + t], b = paths[(size_t)j * H + t];
+    const float2 a = paths[(size_t)i * T + t], b = paths[(size_t)j * T + t];
     const float dx = a.x - b.x, dy = a.y - b.y;
     const bool c = sqrtf(dx * dx + dy * dy) < margin && i != j;
     mask[idx] = c ? 1 : 0;
@@ -58,13 +58,12 @@ extern "C" {
 
 int mmd_rr_collisions(const float* paths_dev, int n_robots, int horizon, float margin, uint8_t* mask_dev,
                       float* midpoints_dev, void* stream) {
-  MMD_REQUIRE(paths_dev && mask_dev && n_robots >= 1, "mmd_rr_collisions: bad arguments");
-  MMD_REQUIRE(horizon == H, "horizon must be %d", H);
-  const size_t tot = (size_t)H * n_robots * n_robots;
+  MMD_REQUIRE(paths_dev && mask_dev && n_robots >= 1 && horizon >= 1, "mmd_rr_collisions: bad arguments");
+  const size_t tot = (size_t)horizon * n_robots * n_robots;
   int grid = (int)((tot + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(rr_collisions_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float2*)paths_dev,
-                     n_robots, margin, mask_dev, (float2*)midpoints_dev);
+                     n_robots, horizon, margin, mask_dev, (float2*)midpoints_dev);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/mmd_amd.h"
+#include "../../include/mmd_amd_debug.h"
 #include "common.h"
 
 namespace mmd {
@@ -1110,10 +1111,13 @@ struct mmd_unet_s {
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
   ConvW down[2], up[2], fin;
   size_t fin_w1, fin_b1;
-  // in-loop profiling of ONE layer kind (mmd_unet_profile_layer): event pairs recorded around its launches
-  int prof_layer = -1, prof_stride = 1;
-  std::vector<hipEvent_t> prof_ev;
-  size_t prof_used = 0, prof_seen = 0;
+};
+
+// caller-owned event-pair pool (include/mmd_amd_debug.h); the unet handle itself is immutable after creation
+struct mmd_profiler_s {
+  int stride = 1;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0, seen = 0;
 };
 
 namespace mmd {
@@ -1267,7 +1271,6 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
 
 int mmd_unet_destroy(mmd_unet_t u) {
   if (!u) return 0;
-  for (auto& e : u->prof_ev) (void)hipEventDestroy(e);
   if (u->blob) (void)hipFree(u->blob);
   if (u->ttable) (void)hipFree(u->ttable);
   delete u;
@@ -1278,54 +1281,37 @@ int mmd_unet_destroy(mmd_unet_t u) {
 // buffer they sized with this function) but only a token size is asked for.
 size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) { return n_traj > 0 ? 256 : 0; }
 
-constexpr int kNumLayers = 1;
-static const char* const kLayerNames[kNumLayers] = {"UNET"};
-static const int kLayerKind[kNumLayers] = {0};
-
 // algorithmic FLOPs per trajectory of one forward: sum over its convs of 2 * C_out * taps * C_in * L_out
 static constexpr double rtb_flops(double cin, double cout, double L) {
   return 2.0 * cout * 5 * cin * L + 2.0 * cout * 5 * cout * L + (cin != cout ? 2.0 * cout * cin * L : 0.0);
 }
-static const double kLayerFlops[kNumLayers] = {
+static const double kUnetFlops =
     rtb_flops(4, 32, 64) + rtb_flops(32, 32, 64) + 2.0 * 32 * 3 * 32 * 32 +
     rtb_flops(32, 64, 32) + rtb_flops(64, 64, 32) + 2.0 * 64 * 3 * 64 * 16 +
     rtb_flops(64, 128, 16) + 3 * rtb_flops(128, 128, 16) +
     rtb_flops(256, 64, 16) + rtb_flops(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16 +
     rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +
-    2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64};
+    2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64;
 
-// MFMA FLOPs actually issued per trajectory (Winograd convs: 6 products per output pair; channel / N padding included)
-static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // F(4,5), L = 16
+// MFMA FLOPs actually issued per trajectory (Winograd convs: 8 products per 4 outputs; channel / N padding included)
+static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // per sample
 static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
 }
-static const double kLayerMfmaFlops[kNumLayers] = {
+static const double kUnetMfmaFlops =
     4 * (wino4_flops(16, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 16, 32, 64) + direct_flops(3, 32, 32, 32) +
     2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) + direct_flops(3, 64, 64, 16) +
     wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) + 7 * wino4_flops(128, 128) +
     wino4_flops(256, 64) + direct_flops(1, 256, 64, 16) + 3 * wino4_flops(64, 64) + 2 * direct_flops(2, 64, 64, 16) +
     2 * (wino4_flops(128, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 128, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
-    4 * wino4_flops(32, 32) + direct_flops(1, 32, 32, 64)};
+    4 * wino4_flops(32, 32) + direct_flops(1, 32, 32, 64);
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
-                             hipStream_t st, hipEvent_t* ev, int reps) {
+                             hipStream_t st, mmd_profiler_t prof) {
   MMD_REQUIRE(u && x && eps && ws, "mmd_unet_forward: NULL argument");
   MMD_REQUIRE(n >= 1, "mmd_unet_forward: n_traj must be >= 1");
   MMD_REQUIRE(t >= 0 && t < u->T, "mmd_unet_forward: t=%d outside [0,%d)", t, u->T);
   MMD_REQUIRE(ws_bytes >= mmd_unet_workspace_bytes(u, n), "mmd_unet_forward: workspace too small");
-  int li = 0;
-  // profiling (ev != nullptr): every launch is bracketed by events and issued `reps` times back to back (each launch
-  // is a pure function of buffers it does not write), so the event overhead is amortised over the repeats
-#define MMD_L(...)                                                                                   \
-  do {                                                                                               \
-    if (ev) (void)hipEventRecord(ev[li], st);                                                        \
-    const bool _p = !ev && u->prof_layer >= 0 && kLayerKind[li] == u->prof_layer &&                  \
-                    (u->prof_seen++ % u->prof_stride) == 0 && u->prof_used + 2 <= u->prof_ev.size(); \
-    if (_p) (void)hipEventRecord(u->prof_ev[u->prof_used], st);                                      \
-    ++li;                                                                                            \
-    for (int _r = 0; _r < reps; ++_r) { __VA_ARGS__; }                                               \
-    if (_p) { (void)hipEventRecord(u->prof_ev[u->prof_used + 1], st); u->prof_used += 2; }           \
-  } while (0)
   // state_dict RTB indices: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2 = 0..11
   static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};
   UnetArgs a{};
@@ -1340,15 +1326,21 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
   a.fin.w1_pk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
   a.fin.w1_bias = u->blob + u->fin_b1;
-  MMD_L(hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a));
-  if (ev) (void)hipEventRecord(ev[li], st);
-#undef MMD_L
+  const bool bracket = prof && (prof->seen++ % prof->stride) == 0 && prof->used + 2 <= prof->ev.size();
+  if (bracket) (void)hipEventRecord(prof->ev[prof->used], st);
+  hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+  if (bracket) { (void)hipEventRecord(prof->ev[prof->used + 1], st); prof->used += 2; }
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, void* stream) {
-  return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, (hipStream_t)stream, nullptr, 1);
+  return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, (hipStream_t)stream, nullptr);
+}
+
+int mmd_unet_forward_profiled(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
+                              mmd_profiler_t prof, void* stream) {
+  return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, (hipStream_t)stream, prof);
 }
 
 #ifdef MMD_TRACE
@@ -1357,57 +1349,45 @@ int mmd_debug_set_trace(void* dev_ptr) {
 }
 #endif
 
-int mmd_unet_num_layers(void) { return kNumLayers; }
-const char* mmd_unet_layer_name(int i) { return i >= 0 && i < kNumLayers ? kLayerNames[i] : ""; }
-double mmd_unet_layer_flops(int i) { return i >= 0 && i < kNumLayers ? kLayerFlops[i] : 0.0; }
-double mmd_unet_layer_mfma_flops(int i) { return i >= 0 && i < kNumLayers ? kLayerMfmaFlops[i] : 0.0; }
+double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
+double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }
 
-int mmd_unet_profile_layer(mmd_unet_t u, int layer, int max_launches, int stride) {
-  MMD_REQUIRE(u, "mmd_unet_profile_layer: NULL handle");
-  for (auto& e : u->prof_ev) (void)hipEventDestroy(e);
-  u->prof_ev.clear();
-  u->prof_used = u->prof_seen = 0;
-  u->prof_layer = -1;
-  u->prof_stride = stride > 0 ? stride : 1;
-  if (layer < 0) return 0;
-  MMD_REQUIRE(layer < kNumLayers && max_launches > 0, "mmd_unet_profile_layer: bad arguments");
-  u->prof_ev.resize((size_t)2 * max_launches);
-  for (auto& e : u->prof_ev) MMD_HIP_CHECK(hipEventCreate(&e));
-  u->prof_layer = kLayerKind[layer];
+int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride) {
+  MMD_REQUIRE(out && max_launches > 0, "mmd_profiler_create: bad arguments");
+  auto* p = new mmd_profiler_s();
+  p->stride = stride > 0 ? stride : 1;
+  p->ev.resize((size_t)2 * max_launches);
+  for (auto& e : p->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      set_error("mmd_profiler_create: hipEventCreate failed");
+      e = nullptr;
+      mmd_profiler_destroy(p);
+      return 1;
+    }
+  *out = p;
   return 0;
 }
 
-int mmd_unet_profile_read(mmd_unet_t u, double* mean_ms, int* n_launches) {
-  MMD_REQUIRE(u && mean_ms && n_launches, "mmd_unet_profile_read: NULL argument");
+int mmd_profiler_destroy(mmd_profiler_t p) {
+  if (!p) return 0;
+  for (auto& e : p->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete p;
+  return 0;
+}
+
+int mmd_profiler_read(mmd_profiler_t p, double* mean_ms, int* n_launches) {
+  MMD_REQUIRE(p && mean_ms && n_launches, "mmd_profiler_read: NULL argument");
   double tot = 0.0;
   int cnt = 0;
-  for (size_t i = 0; i + 1 < u->prof_used; i += 2) {
+  for (size_t i = 0; i + 1 < p->used; i += 2) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, u->prof_ev[i], u->prof_ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+    if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
   }
   *mean_ms = cnt ? tot / cnt : 0.0;
   *n_launches = cnt;
-  u->prof_used = 0;
+  p->used = 0;
   return 0;
-}
-
-int mmd_unet_profile(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, int repeats,
-                     float* layer_ms, void* stream) {
-  MMD_REQUIRE(layer_ms && repeats >= 1, "mmd_unet_profile: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  hipEvent_t ev[kNumLayers + 1];
-  for (auto& e : ev) MMD_HIP_CHECK(hipEventCreate(&e));
-  for (int i = 0; i < kNumLayers; ++i) layer_ms[i] = 0.f;
-  int rc = unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, st, ev, repeats);
-  if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) { set_error("mmd_unet_profile: sync failed"); rc = 1; }
-  if (rc == 0)
-    for (int i = 0; i < kNumLayers; ++i) {
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-      layer_ms[i] = ms / (float)repeats;
-    }
-  for (auto& e : ev) (void)hipEventDestroy(e);
-  return rc;
 }
 
 }  // extern "C"

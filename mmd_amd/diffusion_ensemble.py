@@ -1,6 +1,7 @@
 """DiffusionsEnsemble: host mirror of reference mmd/models/diffusion_models/diffusion_ensemble.py:37-313 (composition
-of tile models along the horizon).  Per outer step every tile runs one fused DDPM step (mmd_ddpm_step) and the tile
-boundaries are stitched by the cross-conditioning kernel (mmd_cross_condition, sample_functions.py:17-31)."""
+of tile models along the horizon).  The whole sampling loop is ONE C-ABI call (mmd_p_sample_loop_ensemble): per outer
+step every tile runs its UNet + fused DDPM/guide kernel in order, each followed by the cross-conditioning kernel that
+stitches the tile boundaries (sample_functions.py:17-31); chains are written on the device."""
 import ctypes as C
 from copy import deepcopy
 from typing import Dict, Tuple
@@ -8,26 +9,30 @@ from typing import Dict, Tuple
 import torch
 
 from . import _lib
-from .diffusion_model import GaussianDiffusionModel, ddpm_sample_fn
+from .diffusion_model import GaussianDiffusionModel, ddpm_sample_fn, next_stream_seed
 
 HORIZON = 64     # mmd/config/mmd_params.py:34
+
+
+def _rel_boundary(transforms, m1, m2, D):
+    """relative transform padded to D and its clamp boundary (sample_functions.py:19-27)."""
+    rel = (torch.as_tensor(transforms[m2]) - torch.as_tensor(transforms[m1])).float().cpu()
+    if D > rel.shape[0]:
+        rel = torch.cat([rel, torch.zeros(D - rel.shape[0])])
+    boundary = rel / torch.norm(rel, keepdim=True)
+    boundary[boundary == 0] = 1e6
+    return [float(v) for v in rel], [float(v) for v in boundary]
 
 
 def apply_cross_conditioning(x: Dict[int, torch.Tensor], conditions, transforms):
     """sample_functions.py:17-31 on device tensors (in place)."""
     lib = _lib.load()
     for (m1, m2), (ind1, ind2) in conditions.items():
-        rel = (torch.as_tensor(transforms[m2]) - torch.as_tensor(transforms[m1])).float().cpu()
-        D = x[m1].shape[2]
-        if D > rel.shape[0]:
-            rel = torch.cat([rel, torch.zeros(D - rel.shape[0])])
-        boundary = rel / torch.norm(rel, keepdim=True)
-        boundary[boundary == 0] = 1e6
-        relc = (C.c_float * 4)(*[float(v) for v in rel])
-        bndc = (C.c_float * 4)(*[float(v) for v in boundary])
+        rel, boundary = _rel_boundary(transforms, m1, m2, x[m1].shape[2])
         _lib.check(lib.mmd_cross_condition(_lib.require_gpu(x[m1], "x[m1]"), _lib.require_gpu(x[m2], "x[m2]"),
-                                           int(ind1) % x[m1].shape[1], int(ind2) % x[m2].shape[1], relc, bndc,
-                                           x[m1].shape[0], _lib.current_stream_ptr()))
+                                           int(ind1) % x[m1].shape[1], int(ind2) % x[m2].shape[1],
+                                           (C.c_float * 4)(*rel), (C.c_float * 4)(*boundary), x[m1].shape[0],
+                                           _lib.current_stream_ptr()))
     return x
 
 
@@ -43,43 +48,68 @@ class DiffusionsEnsemble:
     @torch.no_grad()
     def p_sample_loop(self, shape, hard_conds, cross_conds, n_diffusion_steps=None, contexts=None, return_chain=False,
                       sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0, warm_start_path_b=None,
-                      x_init=None, step_noise=None, device="cuda", **sample_kwargs):
+                      x_init=None, step_noise=None, device="cuda", seed=None, **sample_kwargs):
         """diffusion_ensemble.py:55-106.  `x_init` {m: [B,H,D]} / `step_noise` [n_steps, n_models, B,H,D] inject the
-        Gaussian draws (parity tests); otherwise Philox."""
+        Gaussian draws (parity tests); otherwise Philox (`seed` + tile index, or the global stream counter)."""
         if sample_fn is not ddpm_sample_fn:
             raise NotImplementedError("only ddpm_sample_fn")
+        if contexts is not None:
+            raise NotImplementedError("contexts")
+        lib = _lib.load()
         keys = list(self.models.keys())
-        x = {}
+        K = len(keys)
+        pos = {m: j for j, m in enumerate(keys)}
+        device = torch.device(device)
+        B, H, D = shape
+        n_total = n_diffusion_steps + n_diffusion_steps_without_noise
+        kw = sample_kwargs["sample_kwargs"]
+        x, chains, keep = {}, {}, []
+        init_noise = 0
         for m in keys:
             if warm_start_path_b is not None:
-                x[m] = warm_start_path_b[:, m * HORIZON:(m + 1) * HORIZON, :].clone().to(device).contiguous()
+                x[m] = warm_start_path_b[:, m * HORIZON:(m + 1) * HORIZON, :].to(device=device, dtype=torch.float32).contiguous().clone()
                 x[m][:, :, :2] -= torch.as_tensor(self.transforms[m]).to(x[m].device)
             elif x_init is not None:
                 x[m] = x_init[m].to(device=device, dtype=torch.float32).contiguous().clone()
             else:
-                x[m] = self.models[m].p_sample_loop(shape, {}, 0, device=device)        # Philox N(0,1)
-            for row, val in hard_conds.get(m, {}).items():
-                x[m][:, row, :] = torch.as_tensor(val, device=x[m].device)
+                x[m] = torch.empty(shape, dtype=torch.float32, device=device)
+                init_noise = 1
             hard_conds.setdefault(m, {})
-        x = apply_cross_conditioning(x, cross_conds, self.transforms)
-        chains = {m: [x[m].clone()] for m in keys} if return_chain else None
-        kw = sample_kwargs["sample_kwargs"]
-        k = 0
-        for i in reversed(range(-n_diffusion_steps_without_noise, n_diffusion_steps)):
-            for j, m in enumerate(keys):
-                skw = kw[m]
-                self.models[m].sample_step(
-                    x[m], hard_conds[m], i, guide=skw.get("guide"), n_guide_steps=skw.get("n_guide_steps", 1),
-                    t_start_guide=skw.get("t_start_guide", float("inf")),
-                    noise_std_extra_schedule_fn=skw.get("noise_std_extra_schedule_fn"),
-                    noise=step_noise[k, j] if step_noise is not None else None)
-                x = apply_cross_conditioning(x, cross_conds, self.transforms)
-            if return_chain:
-                for m in keys:
-                    chains[m].append(x[m].clone())
-            k += 1
+        tiles = (_lib.EnsembleTile * K)()
+        ws_bytes = 0
+        for j, m in enumerate(keys):
+            model, skw = self.models[m], kw[m]
+            guide = skw.get("guide")
+            hard, mask = model._hard_tensor(hard_conds[m], 1, H, device, D)
+            sd = model._sampler_desc(skw.get("n_guide_steps", 1), skw.get("t_start_guide", float("inf")),
+                                     skw.get("noise_std_extra_schedule_fn"), mask)
+            gd = guide.desc() if guide is not None else None
+            noise_m = None
+            if step_noise is not None:
+                noise_m = step_noise[:, j].to(device=device, dtype=torch.float32).contiguous()
+                assert noise_m.shape == (n_total,) + tuple(shape)
+            chains[m] = torch.empty((n_total + 1,) + tuple(shape), dtype=torch.float32, device=device) if return_chain else None
+            keep.append((hard, sd, gd, noise_m))
+            t = tiles[j]
+            t.unet = model.model.handle(model.n_diffusion_steps)
+            t.sampler = C.pointer(sd)
+            t.guide = C.pointer(gd) if gd is not None else None
+            t.x_dev, t.hard_dev = x[m].data_ptr(), hard.data_ptr()
+            t.step_noise_dev = noise_m.data_ptr() if noise_m is not None else None
+            t.chain_dev = chains[m].data_ptr() if chains[m] is not None else None
+            t.seed = (int(seed) + j) if seed is not None else next_stream_seed(model.seed)
+            ws_bytes = max(ws_bytes, lib.mmd_sampler_workspace_bytes(t.unet, B))
+        cc = (_lib.CrossCond * max(len(cross_conds), 1))()
+        for c, ((m1, m2), (ind1, ind2)) in enumerate(cross_conds.items()):
+            rel, boundary = _rel_boundary(self.transforms, m1, m2, D)
+            cc[c].m1, cc[c].m2, cc[c].ind1, cc[c].ind2 = pos[m1], pos[m2], int(ind1) % H, int(ind2) % H
+            cc[c].rel[:], cc[c].boundary[:] = rel, boundary
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        _lib.check(lib.mmd_p_sample_loop_ensemble(tiles, K, cc, len(cross_conds), 1, B, n_diffusion_steps,
+                                                  n_diffusion_steps_without_noise, init_noise, ws.data_ptr(), ws.numel(),
+                                                  _lib.current_stream_ptr()))
         if return_chain:
-            return x, {m: torch.stack(v, dim=1) for m, v in chains.items()}
+            return x, {m: chains[m].transpose(0, 1) for m in keys}            # [B, steps+1, H, D] like torch.stack(dim=1)
         return x
 
     @torch.no_grad()

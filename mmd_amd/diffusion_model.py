@@ -18,6 +18,19 @@ def ddpm_sample_fn(*args, **kwargs):
     raise RuntimeError("ddpm_sample_fn is executed inside libmmd_amd.so; it is only a marker on the host side")
 
 
+# Every sampling call that draws its own noise consumes one Philox stream id from this process-wide counter, the way
+# every reference call advances torch's global RNG: planners built with the same `seed` (the reference seeds once,
+# fix_random_seed, then draws from one global stream) never repeat each other's noise.
+_GLOBAL_DRAWS = 0
+
+
+def next_stream_seed(base_seed):
+    global _GLOBAL_DRAWS
+    seed = (int(base_seed) << 24) + _GLOBAL_DRAWS
+    _GLOBAL_DRAWS += 1
+    return seed & 0xFFFFFFFFFFFFFFFF
+
+
 def make_timesteps(batch_size, i, device):
     return torch.full((batch_size,), i, device=device, dtype=torch.long)
 
@@ -30,13 +43,16 @@ class GaussianDiffusionModel:
                                       "(the configuration of the released MPD checkpoints)")
         self.model = model
         self.n_diffusion_steps = n_diffusion_steps
+        if hasattr(model, "max_timesteps"):
+            model.max_timesteps = n_diffusion_steps              # the time-embedding table is sized to the schedule
         self.state_dim = model.state_dim
         self.clip_denoised, self.predict_epsilon = clip_denoised, predict_epsilon
         for k, v in diffusion_buffers(n_diffusion_steps, variance_schedule).items():
             setattr(self, k, v)                                    # CPU float32 [T] buffers, reference names
         self._tables = {k: np.ascontiguousarray(getattr(self, k).numpy()) for k in SCHEDULE_KEYS}
         self.seed = 0
-        self._draws = 0
+        self.profiler = None                                       # optional mmd_profiler_t (bench.py), see mmd_amd_debug.h
+        self._noise_tables = {}
 
     # ---- parameters -------------------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -56,7 +72,18 @@ class GaussianDiffusionModel:
         self.model(x, 1, context=None)
 
     # ---- descriptors ------------------------------------------------------------------------------------------
-    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_std_extra, hard_mask, n_streams=0):
+    def _noise_std_table(self, fn):
+        """noise_std_extra_schedule_fn evaluated for every t of the schedule (the reference calls it with t_single on
+        every step, sample_functions.py:83-86); None -> 1.0."""
+        key = id(fn)
+        if key not in self._noise_tables:
+            vals = [1.0 if fn is None else float(fn(t)) for t in range(self.n_diffusion_steps)]
+            self._noise_tables[key] = (fn, np.ascontiguousarray(vals, dtype=np.float32))   # holds fn: its id stays unique
+            while len(self._noise_tables) > 32:     # descriptors built earlier in the same call keep pointing at live tables
+                self._noise_tables.pop(next(iter(self._noise_tables)))
+        return self._noise_tables[key][1]
+
+    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_fn, hard_mask, n_streams=0, traj_index_base=0):
         s = _lib.SamplerDesc()
         s.n_diffusion_steps = self.n_diffusion_steps
         fp = C.POINTER(C.c_float)
@@ -66,9 +93,13 @@ class GaussianDiffusionModel:
         s.n_guide_steps = int(n_guide_steps)
         tsg = t_start_guide
         s.t_start_guide = int(min(tsg, 2 ** 30)) if tsg != float("inf") else 2 ** 30
-        s.noise_std_extra = float(noise_std_extra)
+        table = self._noise_std_table(noise_fn)
+        s.noise_std_extra = float(table[0])
+        s.noise_std_extra_by_t = table.ctypes.data_as(fp)
         s.hard_mask = hard_mask
         s.n_streams = int(n_streams)
+        s.traj_index_base = int(traj_index_base)
+        s.profiler = self.profiler
         return s
 
     @staticmethod
@@ -97,10 +128,13 @@ class GaussianDiffusionModel:
     def p_sample_loop(self, shape, hard_conds, n_diffusion_steps, context=None, return_chain=False,
                       sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0, warm_start_path_b=None,
                       guide=None, n_guide_steps=1, t_start_guide=float("inf"), noise_std_extra_schedule_fn=None,
-                      n_robots=1, step_noise=None, seed=None, device="cuda", n_streams=0, **sample_kwargs):
+                      n_robots=1, step_noise=None, seed=None, device="cuda", n_streams=0, traj_index_base=0,
+                      **sample_kwargs):
         """diffusion_model_base.py:162-211.  Extensions: `n_robots` (batch = n_robots * n_samples, robot-major),
         `step_noise` [n_steps_total, B, H, D] + `warm_start_path_b` as x_T to inject every Gaussian draw (parity
-        tests), `seed` for the in-kernel Philox stream otherwise."""
+        tests), `seed` for the in-kernel Philox stream otherwise, `traj_index_base` = global index of this call's first
+        trajectory (a rank sampling robots [r0, r1) of a bigger instance passes r0 * n_samples and draws exactly the noise
+        those rows get in the unsharded call)."""
         if sample_fn is not ddpm_sample_fn:
             raise NotImplementedError("only ddpm_sample_fn is implemented (DDIM: conditional_sample(ddim=True) / ddim_sample)")
         if context is not None:
@@ -110,9 +144,8 @@ class GaussianDiffusionModel:
         B_total, H, D = shape
         device = torch.device(device)
         lib = _lib.load()
-        noise_std = 1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(0))
         hard, mask = self._hard_tensor(hard_conds, n_robots, H, device, D)
-        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std, mask, n_streams)
+        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std_extra_schedule_fn, mask, n_streams, traj_index_base)
         n_total = n_diffusion_steps + n_diffusion_steps_without_noise
         if warm_start_path_b is not None:
             x = warm_start_path_b.to(device=device, dtype=torch.float32).contiguous().clone()
@@ -127,8 +160,7 @@ class GaussianDiffusionModel:
         gd = guide.desc() if guide is not None else None
         ws = self.model.workspace(B_total, device, sampler=True)
         if seed is None:
-            seed = (self.seed << 20) + self._draws
-            self._draws += 1
+            seed = next_stream_seed(self.seed)
         _lib.check(lib.mmd_p_sample_loop(
             self.model.handle(self.n_diffusion_steps), C.byref(s), C.byref(gd) if gd is not None else None,
             x.data_ptr(), hard.data_ptr(), n_robots, B_total // n_robots, n_diffusion_steps,
@@ -149,7 +181,7 @@ class GaussianDiffusionModel:
     @torch.no_grad()
     def ddim_sample(self, shape, hard_conds, n_diffusion_steps, context=None, return_chain=False,
                     t_start_guide=float("inf"), guide=None, n_guide_steps=1, n_robots=1, x_init=None, seed=None,
-                    device="cuda", **sample_kwargs):
+                    device="cuda", traj_index_base=0, **sample_kwargs):
         """diffusion_model_base.py:213-290 (eta = 0).  As in the reference, `n_guide_steps` is accepted and NOT forwarded
         to guide_gradient_steps: one guide step per sampling step.  Extensions: `n_robots`, `x_init` (injected x_T),
         `seed` for the Philox draw of x_T otherwise."""
@@ -161,7 +193,7 @@ class GaussianDiffusionModel:
         device = torch.device(device)
         lib = _lib.load()
         hard, mask = self._hard_tensor(hard_conds, n_robots, H, device, D)
-        s = self._sampler_desc(1, t_start_guide, 1.0, mask)
+        s = self._sampler_desc(1, t_start_guide, None, mask, traj_index_base=traj_index_base)
         times = np.asarray(self.ddim_times(n_diffusion_steps), dtype=np.int32)
         acp = np.ascontiguousarray(self._tables["alphas_cumprod"], dtype=np.float32)
         if x_init is not None:
@@ -174,8 +206,7 @@ class GaussianDiffusionModel:
         gd = guide.desc() if guide is not None else None
         ws = self.model.workspace(B_total, device, sampler=True)
         if seed is None:
-            seed = (self.seed << 20) + self._draws
-            self._draws += 1
+            seed = next_stream_seed(self.seed)
         _lib.check(lib.mmd_ddim_sample(
             self.model.handle(self.n_diffusion_steps), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
             C.byref(gd) if gd is not None else None, x.data_ptr(), hard.data_ptr(), n_robots, B_total // n_robots,
@@ -187,19 +218,18 @@ class GaussianDiffusionModel:
 
     @torch.no_grad()
     def sample_step(self, x, hard_conds, i, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
-                    noise_std_extra_schedule_fn=None, n_robots=1, noise=None, seed=None):
+                    noise_std_extra_schedule_fn=None, n_robots=1, noise=None, seed=None, traj_index_base=0):
         """One `ddpm_sample_fn` call + the `apply_hard_conditioning` that follows it in the loop
         (sample_functions.py:40-86, diffusion_model_base.py:199-203), in place on x; `i` is the loop index
         (negative: t = 0).  This is what DiffusionsEnsemble interleaves across tiles (diffusion_ensemble.py:86-100)."""
         B_total, H, D = x.shape
         hard, mask = self._hard_tensor(hard_conds, n_robots, H, x.device, D)
-        noise_std = 1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(0))
-        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std, mask)
+        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std_extra_schedule_fn, mask,
+                               traj_index_base=traj_index_base)
         gd = guide.desc() if guide is not None else None
         ws = self.model.workspace(B_total, x.device, sampler=True)
         if seed is None:
-            seed = (self.seed << 20) + self._draws
-            self._draws += 1
+            seed = next_stream_seed(self.seed)
         _lib.check(_lib.load().mmd_ddpm_step(
             self.model.handle(self.n_diffusion_steps), C.byref(s), C.byref(gd) if gd is not None else None,
             _lib.require_gpu(x, "x"), hard.data_ptr(), n_robots, B_total // n_robots, int(i),
@@ -243,16 +273,19 @@ class GaussianDiffusionModel:
         chain = chain.transpose(0, 1)
         return chain if return_chain else chain[-1]
 
-    def q_sample(self, x_start, t, noise=None):
-        """diffusion_model_base.py:425-433 (t: int or a constant [B] tensor)."""
+    def q_sample(self, x_start, t, noise=None, traj_index_base=0):
+        """diffusion_model_base.py:425-433 (t: int or a constant [B] tensor).  x_start is [B, K*64, 4]: K = 1 for a
+        single model, K tiles chained along the horizon for the ensemble's seed (diffusion_ensemble.py:279-281) -- every
+        one of the B*K*64 points is noised."""
         t = int(t[0].item()) if torch.is_tensor(t) else int(t)
         x_start = x_start.to(dtype=torch.float32).contiguous()
+        if x_start.ndim != 3 or x_start.shape[1] % 64 or x_start.shape[2] != self.state_dim:
+            raise ValueError(f"q_sample: expected [B, K*64, {self.state_dim}], got {tuple(x_start.shape)}")
         out = torch.empty_like(x_start)
-        seed = (self.seed << 20) + self._draws
-        self._draws += 1
         _lib.check(_lib.load().mmd_q_sample(
             out.data_ptr(), _lib.require_gpu(x_start, "x_start"),
             _lib.require_gpu(noise.contiguous(), "noise") if noise is not None else None,
-            float(self.sqrt_alphas_cumprod[t]), float(self.sqrt_one_minus_alphas_cumprod[t]), C.c_uint64(seed),
-            0xFFFFFFFE, x_start.shape[0], _lib.current_stream_ptr()))
+            float(self.sqrt_alphas_cumprod[t]), float(self.sqrt_one_minus_alphas_cumprod[t]),
+            C.c_uint64(next_stream_seed(self.seed)), 0xFFFFFFFE, C.c_int64(int(traj_index_base)),
+            x_start.numel() // (64 * self.state_dim), _lib.current_stream_ptr()))
         return out

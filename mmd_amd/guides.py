@@ -15,6 +15,25 @@ from .environments import LIMITS, sdf_grid_texture
 
 ROBOT_RADIUS = 0.05                 # mmd/config/mmd_params.py:30
 
+# Device-side sharing (SURVEY §8f-3): one resident SDF texture per (map set, device) for every guide / task facade of the
+# process (the reference precomputes the grid once per planner object, grid_map_sdf.py:34-63, N+1 times per instance).
+_TEXTURES = {}
+N_TEXTURE_UPLOADS = 0
+
+
+def device_sdf_textures(maps, device):
+    """[n_maps, n_grids=1, nx, ny, 4] float32 on `device`, uploaded once per process."""
+    global N_TEXTURE_UPLOADS
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (tuple(maps), str(device))
+    if key not in _TEXTURES:
+        tex = np.stack([sdf_grid_texture(m) for m in maps])[:, None]
+        _TEXTURES[key] = torch.from_numpy(np.ascontiguousarray(tex)).to(device)
+        N_TEXTURE_UPLOADS += 1
+    return _TEXTURES[key]
+
 
 class GuideManagerTrajectoriesWithVelocity:
     def __init__(self, dataset, cost=None, clip_grad=True, clip_grad_rule="norm", max_grad_norm=1.0,
@@ -36,8 +55,7 @@ class GuideManagerTrajectoriesWithVelocity:
         self.margin = float(np.float32(np.float32(robot_radius * 1.1) + np.float32(obstacle_cutoff_margin)))
         env_ids = list(robot_env_ids) if robot_env_ids is not None else [env_id] * n_robots
         maps = sorted(set(env_ids))
-        tex = np.stack([sdf_grid_texture(m) for m in maps])[:, None]          # [n_maps, n_grids=1, nx, ny, 4]
-        self._grids = torch.from_numpy(np.ascontiguousarray(tex)).to(self.device)
+        self._grids = device_sdf_textures(maps, self.device)                  # [n_maps, n_grids=1, nx, ny, 4], shared
         self._robot_map = torch.tensor([maps.index(e) for e in env_ids], dtype=torch.int32, device=self.device)
         self._n_maps = len(maps)
         from .environments import MAP_BOXES
@@ -109,13 +127,18 @@ class GuideManagerTrajectoriesWithVelocity:
         return d
 
     # ---- guide_gradient_steps / forward -----------------------------------------------------------------------
-    def guide_steps(self, x, hard, hard_mask, n_steps):
+    def guide_steps(self, x, hard, hard_mask, n_steps, chain=None):
         """In place: n_steps x { x += guide(x); apply_hard_conditioning } (sample_functions.py:89-107).
-        x [n_robots*B,H,D]; hard [n_robots,2,D] normalised start / goal states."""
+        x [n_robots*B,H,D]; hard [n_robots,2,D] normalised start / goal states; chain (optional) [n_steps, n_robots*B, H, D]
+        receives the state after every iteration."""
         d = self.desc()
         B = x.shape[0] // self.n_robots
+        if chain is not None:
+            assert chain.shape == (n_steps,) + tuple(x.shape)
         _lib.check(_lib.load().mmd_guide_steps(C.byref(d), _lib.require_gpu(x, "x"), _lib.require_gpu(hard, "hard"),
-                                               hard_mask, self.n_robots, B, n_steps, _lib.current_stream_ptr()))
+                                               hard_mask, self.n_robots, B, n_steps,
+                                               _lib.require_gpu(chain, "chain") if chain is not None else None,
+                                               _lib.current_stream_ptr()))
         return x
 
     def forward(self, x_normalized):

@@ -11,11 +11,11 @@ RR_MARGIN = 2.1 * ROBOT_RADIUS           # robot_planar_disk.py:186
 
 
 def check_rr_collisions(paths, margin=RR_MARGIN, with_midpoints=True):
-    """paths [N,H,2] un-normalised positions on the GPU -> (collisions [H,N,N] bool, midpoints [H,N,N,2] | None)."""
-    n = paths.shape[0]
-    mask = torch.empty((H, n, n), dtype=torch.uint8, device=paths.device)
-    mid = torch.empty((H, n, n, 2), dtype=torch.float32, device=paths.device) if with_midpoints else None
-    _lib.check(_lib.load().mmd_rr_collisions(_lib.require_gpu(paths.contiguous(), "paths"), n, H, float(margin),
+    """paths [N,T,2] un-normalised positions on the GPU -> (collisions [T,N,N] bool, midpoints [T,N,N,2] | None)."""
+    n, T = paths.shape[0], paths.shape[1]
+    mask = torch.empty((T, n, n), dtype=torch.uint8, device=paths.device)
+    mid = torch.empty((T, n, n, 2), dtype=torch.float32, device=paths.device) if with_midpoints else None
+    _lib.check(_lib.load().mmd_rr_collisions(_lib.require_gpu(paths.contiguous(), "paths"), n, T, float(margin),
                                              mask.data_ptr(), mid.data_ptr() if mid is not None else None,
                                              _lib.current_stream_ptr()))
     return mask.bool(), mid

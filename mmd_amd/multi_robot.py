@@ -79,13 +79,15 @@ class MultiRobotSampler:
                 paths_all.contiguous(), self.robot0, self.n_local, self.radius, self.w_soft))
 
     def sample(self, seed=None, x_init=None, step_noise=None, return_chain=False):
-        """One guided sampling round for the local robots: [n_local*B, H, D] normalised trajectories."""
+        """One guided sampling round for the local robots: [n_local*B, H, D] normalised trajectories.  The in-kernel
+        Philox noise is keyed by (seed, global trajectory index): every rank passes the SAME seed and gets exactly the
+        rows the unsharded run would produce."""
         return self.model.run_inference(
             None, self.hard_conds, n_samples=self.n_samples, n_robots=self.n_local, horizon=H,
             return_chain=return_chain, sample_fn=ddpm_sample_fn, guide=self.guide, n_guide_steps=self.n_guide_steps,
             t_start_guide=self.t_start_guide, noise_std_extra_schedule_fn=lambda t: 0.5,
             n_diffusion_steps_without_noise=self.n_extra, warm_start_path_b=x_init, step_noise=step_noise, seed=seed,
-            device=self.device)
+            traj_index_base=self.robot0 * self.n_samples, device=self.device)
 
     def unnormalize(self, trajs_normalized):
         nz = self.dataset.normalizer
@@ -93,18 +95,24 @@ class MultiRobotSampler:
         return (torch.clip(trajs_normalized, -1, 1) + 1) / 2.0 * (maxs - mins) + mins
 
     def best_paths(self, trajs_normalized, paths_all=None):
-        """Selection for the exchange step: per local robot the sample with the fewest robot-robot collisions against the
-        other robots' current best paths (CBS 'least_collisions', cbs.py:446-458; device scan), or sample 0 when no
-        paths are known yet.  Returns un-normalised positions [n_local,H,2].  (The reference first drops samples that
-        collide with the map, mpd.py:357-382 -- post-processing, not part of this exchange.)"""
-        t = self.unnormalize(trajs_normalized)
-        tv = t.view(self.n_local, self.n_samples, H, D)
+        """Selection for the exchange step, on the device: samples that collide with the map or leave the joint limits
+        are dropped first (PlanningTask.get_trajs_collision_and_free, tasks.py:236-311, as MPD.__call__ does at
+        mpd.py:357-382); among the free ones the pick is the first sample with the fewest robot-robot collisions against
+        the other robots' current best paths (CBS 'least_collisions', cbs.py:446-458), or the cheapest one (path length +
+        smoothness, mpd.py:366-370) when no paths are known yet.  A robot without any free sample falls back to the same
+        criterion over all its samples (`self.last_n_free` tells).  Returns un-normalised positions [n_local,H,2]."""
+        from . import postprocess as post
+        t = self.unnormalize(trajs_normalized).contiguous()
+        r = post.postprocess_batch(self.guide, t, n_robots=self.n_local, smooth=False)
         if paths_all is None or self.n_robots < 2:
-            idx = torch.zeros(self.n_local, dtype=torch.long, device=t.device)
+            idx, n_free = post.select_best(r.free_mask, self.n_local, cost_a=r.path_length, cost_b=r.smoothness)
         else:
-            from .multi_agent import least_collision_samples
-            idx = least_collision_samples(t, paths_all, self.robot0, self.n_local)
-        return tv[torch.arange(self.n_local, device=t.device), idx][..., :2].contiguous()
+            from .multi_agent import count_collisions
+            counts = count_collisions(t, paths_all, self.robot0, self.n_local)
+            idx, n_free = post.select_best(r.free_mask, self.n_local, counts=counts.view(-1))
+        self.last_n_free = n_free
+        tv = t.view(self.n_local, self.n_samples, H, D)
+        return tv[torch.arange(self.n_local, device=t.device), idx.long()][..., :2].contiguous()
 
     def plan_round(self, paths_local, seed=None):
         """all-gather -> constraint table -> guided sampling -> new local best paths."""

@@ -22,8 +22,7 @@ from .diffusion_ensemble import DiffusionsEnsemble, HORIZON
 from .diffusion_model import GaussianDiffusionModel, ddpm_sample_fn
 from .guides import GuideManagerTrajectoriesWithVelocity
 from .normalization import TrajectoryDatasetFacade
-from .postprocess import (compute_path_length, compute_smoothness, compute_variance_waypoints,
-                          get_trajs_collision_and_free, smooth_trajs)
+from . import postprocess as post
 from .temporal_unet import UNET_DIM_MULTS, TemporalUnet
 
 
@@ -73,18 +72,98 @@ class _Timer:
         self.elapsed = time.perf_counter() - self._t0
 
 
-class _Robot:
-    """What CBS/PP read from planner.robot: radius, q_dim, get_position/get_velocity."""
-    radius = 0.05
+class RobotPlanarDiskFacade:
+    """What CBS / PrioritizedPlanning read from `planner.robot` (cbs.py:144,178,192,486; prioritized_planning.py:73,224,
+    260,276; mmd/common/multi_agent_utils.py:44,74,79): the disk robot's constants, position / velocity slicing and
+    `check_rr_collisions` (deps/torch_robotics/torch_robotics/robots/robot_planar_disk.py:173-203) -- the latter on the
+    device through mmd_rr_collisions."""
+    name = "RobotPlanarDisk"
+    radius = 0.05                                    # mmd_params.py:30
     q_dim = 2
-    q_min = torch.tensor([-1.0, -1.0])
-    q_max = torch.tensor([1.0, 1.0])
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        self.tensor_args = {"device": self.device, "dtype": torch.float32}
+        self.q_min = torch.tensor([-1.0, -1.0], device=self.device)      # robot_planar_disk.py:31-33
+        self.q_max = torch.tensor([1.0, 1.0], device=self.device)
 
     def get_position(self, x):
         return x[..., :2]
 
     def get_velocity(self, x):
         return x[..., 2:4]
+
+    def check_rr_collisions(self, robot_q):
+        """robot_q (..., n_robots, q_dim) -> (collisions (..., n, n) bool, collision_points (..., n, n, 2) with NaN where
+        the pair does not collide)."""
+        from .multi_agent import check_rr_collisions
+        robot_q = torch.as_tensor(robot_q)
+        assert robot_q.dim() >= 2
+        lead, n = tuple(robot_q.shape[:-2]), robot_q.shape[-2]
+        q = robot_q.to(device=self.device, dtype=torch.float32).reshape(-1, n, robot_q.shape[-1])[..., :2]
+        coll, mid = check_rr_collisions(q.permute(1, 0, 2).contiguous(), margin=2.1 * self.radius)   # [T,n,n], [T,n,n,2]
+        return (coll.view(lead + (n, n)).to(robot_q.device), mid.view(lead + (n, n, 2)).to(robot_q.device))
+
+
+class PlanningTaskFacade:
+    """What CBS / PP and the planner itself read from `planner.task`: `compute_collision`
+    (deps/torch_robotics/torch_robotics/tasks/tasks.py:141-143, called from multi_agent_utils.py:47,84,89) and
+    `get_trajs_collision_and_free` (tasks.py:236-311), both on the device against the guide's resident SDF texture."""
+
+    def __init__(self, guide, robot, all_free=False):
+        self.guide, self.robot, self.all_free = guide, robot, all_free
+        self.tensor_args = robot.tensor_args
+
+    def compute_collision(self, x, margin=None, **kwargs):
+        """x [D] | [B, D] | [B, H, D] -> bool [1, 1] | [B, 1] | [B, H] (tasks.py:145-165 + the "(b h) -> b h" of
+        distance_fields.py:47-48)."""
+        x = torch.as_tensor(x)
+        q = self.robot.get_position(x).to(device=self.guide.device, dtype=torch.float32)
+        if q.ndim > 3:
+            raise NotImplementedError
+        if self.all_free:
+            out = torch.zeros(q.shape[:-1], dtype=torch.bool, device=q.device)
+        else:
+            out = post.compute_collision(q, self.guide, margin=margin)
+        if q.ndim == 1:
+            out = out.view(1, 1)
+        elif q.ndim == 2:
+            out = out.view(-1, 1)
+        return out.to(x.device)
+
+    def get_trajs_collision_and_free(self, trajs, return_indices=False, num_interpolation=5):
+        out = post.get_trajs_collision_and_free(trajs, self.guide, num_interpolation, all_free=self.all_free)
+        return out if return_indices else (out[0], out[2])
+
+    def compute_fraction_free_trajs(self, trajs, **kwargs):
+        free_idxs = self.get_trajs_collision_and_free(trajs, return_indices=True)[3]
+        return free_idxs.shape[0] / trajs.shape[0]
+
+
+def _fill_output(out, guide, trajs_iters, all_free=False):
+    """mpd.py:344-405 / mpd_ensemble.py:385-429 on the device: ONE fused launch (collision / free split, path length,
+    smoothness, SavGol) + the per-batch argmin + the waypoint variance of the free set."""
+    trajs_final = trajs_iters[-1].contiguous()
+    r = post.postprocess_batch(guide, trajs_final, all_free=all_free, smooth=True)
+    coll, coll_idxs, free, free_idxs = post.split_free(trajs_final, r.free_mask)
+    out.trajs_iters, out.trajs_final = trajs_iters, r.smoothed
+    out.trajs_final_coll, out.trajs_final_coll_idxs = coll, coll_idxs
+    out.trajs_final_free, out.trajs_final_free_idxs = free, free_idxs
+    out.success_free_trajs = free is not None
+    out.fraction_free_trajs = 0.0 if free is None else free.shape[0] / trajs_final.shape[0]
+    if free is not None:
+        fm = r.free_mask.bool()
+        out.cost_smoothness, out.cost_path_length = r.smoothness[fm], r.path_length[fm]
+        out.cost_all = out.cost_path_length + out.cost_smoothness
+        idx, _ = post.select_best(r.free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness)
+        ib = int(idx.item())                                   # index in the batch of the cheapest free sample
+        idx_best_free = int((free_idxs.view(-1) == ib).nonzero()[0])
+        out.idx_best_traj = free_idxs[idx_best_free]
+        out.idx_best_free_traj = idx_best_free
+        out.traj_final_free_best = free[idx_best_free]
+        out.cost_best_free_traj = float(out.cost_all[idx_best_free])
+        out.variance_waypoint_trajs_final_free = post.compute_variance_waypoints(free)
+    return out
 
 
 def normalizer_limits_from_dataset(dataset_dir):
@@ -157,8 +236,7 @@ class MPD:
             normalizer_limits = normalizer_limits_from_dataset(kwargs["dataset_dir"])
         mins, maxs = normalizer_limits if normalizer_limits is not None else (synth.NORM_MINS, synth.NORM_MAXS)
         self.dataset = TrajectoryDatasetFacade(mins, maxs)
-        self.robot = _Robot()
-        self.task = self                                   # CBS reads planner.task.get_trajs_collision_and_free
+        self.robot = RobotPlanarDiskFacade(self.device)
         self.n_support_points = HORIZON
         self.start_state_pos = torch.as_tensor(start_state_pos, dtype=torch.float32).clone()
         self.goal_state_pos = torch.as_tensor(goal_state_pos, dtype=torch.float32).clone()
@@ -169,6 +247,7 @@ class MPD:
             weight_grad_cost_collision=weight_grad_cost_collision,
             weight_grad_cost_smoothness=weight_grad_cost_smoothness, trajectory_duration=trajectory_duration,
             n_support_points=HORIZON, device=self.device)
+        self.task = PlanningTaskFacade(self.guide, self.robot)     # CBS reads planner.task (cbs.py:149)
         self.t_start_guide = ceil(start_guide_steps_fraction * self.model.n_diffusion_steps)
         self.n_guide_steps = n_guide_steps
         self.n_diffusion_steps_without_noise = n_diffusion_steps_without_noise
@@ -182,11 +261,6 @@ class MPD:
             guide=None if self.run_prior_then_guidance or self.run_prior_only else self.guide,
             n_guide_steps=self.n_guide_steps, t_start_guide=self.t_start_guide,
             noise_std_extra_schedule_fn=lambda x: 0.5)
-
-    # ---- task facade --------------------------------------------------------------------------------------------
-    def get_trajs_collision_and_free(self, trajs, return_indices=False, num_interpolation=5):
-        out = get_trajs_collision_and_free(trajs, self.env_id, num_interpolation)
-        return out if return_indices else (out[0], out[2])
 
     # ---- planner call -------------------------------------------------------------------------------------------
     def _cost_constraints(self, constraints_l):
@@ -206,21 +280,7 @@ class MPD:
                 chain = self.run_constrained_local_inference(cost_constraints_l, experience, **kwargs)
         out = PlannerOutput()
         out.t_total = timer.elapsed
-        trajs_iters = self.dataset.unnormalize_trajectories(chain)
-        trajs_final = trajs_iters[-1]
-        coll, coll_idxs, free, free_idxs, _ = self.get_trajs_collision_and_free(trajs_final, return_indices=True)
-        if free is not None:
-            out.cost_smoothness = compute_smoothness(free)
-            out.cost_path_length = compute_path_length(free)
-            out.cost_all = out.cost_path_length + out.cost_smoothness
-            idx_best_free = torch.argmin(out.cost_all).item()
-            out.idx_best_traj = free_idxs[idx_best_free]
-            out.idx_best_free_traj = idx_best_free
-            out.cost_best_free_traj = torch.min(out.cost_all).item()
-            out.variance_waypoint_trajs_final_free = compute_variance_waypoints(free)
-        out.trajs_iters, out.trajs_final = trajs_iters, smooth_trajs(trajs_final)
-        out.trajs_final_coll, out.trajs_final_coll_idxs = coll, coll_idxs
-        out.trajs_final_free, out.trajs_final_free_idxs = free, free_idxs
+        _fill_output(out, self.guide, self.dataset.unnormalize_trajectories(chain))
         out.constraints_l = constraints_l
         self.recent_call_data = out
         return out
@@ -237,11 +297,9 @@ class MPD:
         n_post = (self.t_start_guide + self.n_diffusion_steps_without_noise) * self.n_guide_steps
         x = chain[-1].contiguous().clone()
         hard = torch.stack([self.hard_conds[0], self.hard_conds[HORIZON - 1]])[None].to(x.device).contiguous()
-        extra = []
-        for _ in range(n_post):
-            self.guide.guide_steps(x, hard, 3, 1)
-            extra.append(x.clone())
-        return torch.cat((chain, torch.stack(extra)))
+        extra = torch.empty((n_post,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+        self.guide.guide_steps(x, hard, 3, n_post, chain=extra)        # ONE launch; every iteration lands in `extra`
+        return torch.cat((chain, extra))
 
     def run_constrained_inference(self, cost_constraints_l, **kw):
         self._add_constraints(cost_constraints_l)
@@ -318,8 +376,8 @@ class MPDEnsemble:
                 t_start_guide=ceil(start_guide_steps_fraction * model.n_diffusion_steps),
                 noise_std_extra_schedule_fn=lambda x: 0.5)
         K = len(model_ids)
-        self.robot = _Robot()
-        self.task = self
+        self.robot = RobotPlanarDiskFacade(self.device)
+        self.task = PlanningTaskFacade(self.guides[0], self.robot, all_free=True)   # PlanningTaskEnsemble: tasks_ensemble.py:271-277
         self.n_support_points = HORIZON
         self.start_state_pos = torch.as_tensor(start_state_pos, dtype=torch.float32).clone()
         self.goal_state_pos = torch.as_tensor(goal_state_pos, dtype=torch.float32).clone()
@@ -411,23 +469,11 @@ class MPDEnsemble:
             tr = self.datasets[m].unnormalize_trajectories(chains[m]).clone()
             tr[..., :2] += self.transforms[m].to(tr.device)
             parts.append(tr)
-        trajs_iters = torch.cat(parts, dim=-2)
-        trajs_final = trajs_iters[-1]
+        trajs_iters = torch.cat(parts, dim=-2)                     # [T+2, B, K*64, D]
         out = PlannerOutput()
         out.t_total = timer.elapsed
-        coll, coll_idxs, free, free_idxs, _ = get_trajs_collision_and_free(trajs_final, None, all_free=True)
-        out.trajs_iters, out.trajs_final = trajs_iters, smooth_trajs(trajs_final)
-        out.trajs_final_coll, out.trajs_final_coll_idxs = coll, coll_idxs
-        out.trajs_final_free, out.trajs_final_free_idxs = free, free_idxs
-        out.success_free_trajs = free is not None
-        out.fraction_free_trajs = 0.0 if free is None else free.shape[0] / trajs_final.shape[0]
-        if free is not None:
-            out.cost_smoothness, out.cost_path_length = compute_smoothness(free), compute_path_length(free)
-            out.cost_all = out.cost_path_length + out.cost_smoothness
-            ib = torch.argmin(out.cost_all).item()
-            out.idx_best_traj, out.traj_final_free_best = free_idxs[ib], free[ib]
-            out.cost_best_free_traj = torch.min(out.cost_all).item()
-            out.variance_waypoint_trajs_final_free = compute_variance_waypoints(free)
+        # every sample is free (PlanningTaskEnsemble, tasks_ensemble.py:271-277); costs / SavGol over the K*64 points
+        _fill_output(out, self.guides[0], trajs_iters, all_free=True)
         out.constraints_l = constraints_l
         self.recent_call_data = out
         return out

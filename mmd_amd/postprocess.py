@@ -1,91 +1,137 @@
 """Post-sampling selection (the step right after the hot path): collision / free split, path length +
-smoothness costs, SavGol smoothing.  torch ops on the device tensors (+ scipy for the SavGol filter, as the reference
-does in mmd/common/trajectory_utils.py:31-51).  Restated from deps/torch_robotics/torch_robotics/tasks/tasks.py:236-311,
-trajectory/metrics.py:7-39, trajectory/utils.py:73-86."""
+smoothness costs, SavGol smoothing, waypoint variance and the per-robot pick -- gfx950 kernels of
+mmd_amd/csrc/postprocess.hip behind the C ABI (mmd_postprocess_trajs, mmd_select_best, mmd_points_collision,
+mmd_variance_waypoints).  Mirrors deps/torch_robotics/torch_robotics/tasks/tasks.py:141-311, trajectory/metrics.py:7-39,
+trajectory/utils.py:73-86 and mmd/common/trajectory_utils.py:31-51.  The SDF texture is the guide's resident one; there
+is no CPU path."""
+import ctypes as C
+
 import numpy as np
 import torch
 
-from .environments import LIMITS, sdf_grid_texture
+from . import _lib
 
-ROBOT_RADIUS = 0.05
+ROBOT_RADIUS = 0.05                 # mmd/config/mmd_params.py:30
+H = 64
+Q_MIN, Q_MAX = (-1.0, -1.0), (1.0, 1.0)     # RobotPlanarDisk q_limits (robot_planar_disk.py:31-33)
 
-
-def interpolate_traj_via_points(trajs, num_interpolation=10):
-    H, D = trajs.shape[-2:]
-    if num_interpolation <= 0:
-        return trajs
-    alpha = torch.linspace(0, 1, num_interpolation + 2).type_as(trajs)[1:num_interpolation + 1]
-    alpha = alpha.view((1,) * len(trajs.shape[:-1]) + (-1, 1))
-    out = trajs[..., 0:H - 1, None, :] * alpha + trajs[..., 1:H, None, :] * (1 - alpha)
-    return out.view(trajs.shape[:-2] + (-1, D))
-
-
-def compute_collision(pos, env_id, margin=ROBOT_RADIUS):
-    """occupancy-type check of PlanningTask._compute_collision_or_cost (tasks.py:141-234): a point collides iff the
-    fixed-object SDF (nearest grid cell) or any workspace-boundary distance is below `margin`."""
-    tex = torch.from_numpy(sdf_grid_texture(env_id)).to(pos.device)
-    lo = torch.tensor(LIMITS[0], device=pos.device)
-    hi = torch.tensor(LIMITS[1], device=pos.device)
-    n = torch.tensor(tex.shape[:2], device=pos.device)
-    idx = ((pos - lo) / (hi - lo).abs() * n).floor().long()
-    idx = torch.minimum(torch.maximum(idx, torch.zeros_like(idx)), n - 1)
-    sdf = tex[idx[..., 0], idx[..., 1], 0]
-    ws = torch.cat((pos - lo * 1.08, hi * 1.08 - pos), dim=-1)
-    return (sdf < margin) | (ws < margin).any(dim=-1)
-
-
-def get_trajs_collision_and_free(trajs, env_id, num_interpolation=5, all_free=False):
-    """tasks.py:236-311 for [B,H,D] batches.  Returns (coll, coll_idxs, free, free_idxs, waypoint_collisions)."""
-    B = trajs.shape[0]
-    if all_free:                                             # PlanningTaskEnsemble, tasks_ensemble.py:271-277
-        coll_pts = torch.zeros(B, 1, dtype=torch.bool, device=trajs.device)
-    else:
-        coll_pts = compute_collision(interpolate_traj_via_points(trajs, num_interpolation)[..., :2], env_id)
-    in_coll = coll_pts.any(dim=-1)
-    pos = trajs[..., :2]
-    inside = ((pos >= torch.tensor(LIMITS[0], device=pos.device)) & (pos <= torch.tensor(LIMITS[1], device=pos.device)))
-    free_mask = ~in_coll & inside.all(dim=-1).all(dim=-1)
-    if all_free:
-        free_mask = torch.ones_like(in_coll)
-    free_idxs = torch.argwhere(free_mask)
-    coll_idxs = torch.argwhere(~free_mask)
-    free = trajs[free_mask] if free_mask.any() else None
-    coll = trajs[~free_mask] if (~free_mask).any() else None
-    return coll, coll_idxs, free, free_idxs, coll_pts
-
-
-def compute_path_length(trajs):
-    return torch.linalg.norm(torch.diff(trajs[..., :2], dim=-2), dim=-1).sum(-1)
-
-
-def compute_smoothness(trajs):
-    return torch.linalg.norm(torch.diff(trajs[..., 2:4], dim=-2), dim=-1).sum(-1)
-
-
-def compute_variance_waypoints(trajs):
-    pos = trajs[..., :2]
-    total = 0.0
-    for via in pos.permute(1, 0, 2):
-        d = torch.cdist(via, via, p=2)
-        total = total + (torch.var(torch.triu(d, diagonal=1).view(-1)) if d.numel() > 1 else 0.0)
-    return total
-
-
-_SAVGOL = {}
+_SAVGOL_HOST, _SAVGOL_DEV = {}, {}
 
 
 def savgol_matrix(n, window_size=10, poly_order=2):
     """The Savitzky-Golay filter (scipy mode='interp') is linear in the signal: column j of the [n,n] operator is the
     filter applied to the j-th unit vector.  Built once on the host, applied on the device."""
     key = (n, window_size, poly_order)
-    if key not in _SAVGOL:
+    if key not in _SAVGOL_HOST:
         from scipy.signal import savgol_filter
-        _SAVGOL[key] = torch.from_numpy(savgol_filter(np.eye(n), window_size, poly_order, axis=0)).float()
-    return _SAVGOL[key]
+        _SAVGOL_HOST[key] = torch.from_numpy(savgol_filter(np.eye(n), window_size, poly_order, axis=0)).float().contiguous()
+    return _SAVGOL_HOST[key]
 
 
-def smooth_trajs(trajs, window_size=10, poly_order=2):
-    """mmd/common/trajectory_utils.py:31-40 without its GPU -> CPU scipy -> GPU round trip: out = S @ trajs along the
-    horizon with the precomputed SavGol operator S (same result up to fp32 rounding, pinned by golden g9)."""
-    S = savgol_matrix(trajs.shape[1], window_size, poly_order).to(trajs.device)
-    return torch.einsum("ij,bjd->bid", S, trajs.float())
+def _savgol_dev(n, device, window_size=10, poly_order=2):
+    key = (n, str(device), window_size, poly_order)
+    if key not in _SAVGOL_DEV:
+        _SAVGOL_DEV[key] = savgol_matrix(n, window_size, poly_order).to(device)
+    return _SAVGOL_DEV[key]
+
+
+def interpolation_alphas(num_interpolation):
+    """torch.linspace(0, 1, n + 2)[1:n+1] (trajectory/utils.py:79), fp32."""
+    return np.ascontiguousarray(torch.linspace(0, 1, num_interpolation + 2)[1:num_interpolation + 1].numpy(),
+                                dtype=np.float32)
+
+
+class PostprocessResult:
+    """Per-trajectory outputs of ONE mmd_postprocess_trajs launch (all device tensors)."""
+    __slots__ = ("free_mask", "path_length", "smoothness", "smoothed", "waypoint_collisions")
+
+
+def postprocess_batch(guide, trajs, n_robots=1, num_interpolation=5, margin=ROBOT_RADIUS, all_free=False, smooth=True,
+                      want_waypoints=False, window_size=10, poly_order=2):
+    """trajs [n_robots*B, K*64, 4] un-normalised on the GPU (K = 1; K tiles for MPDEnsemble); `guide` supplies the resident
+    map (its C-ABI descriptor)."""
+    trajs = trajs.contiguous()
+    n, h, d = trajs.shape
+    if h % H or d != 4 or n % n_robots:
+        raise ValueError(f"postprocess_batch: expected [n_robots*B, K*{H}, 4], got {tuple(trajs.shape)}")
+    dev = trajs.device
+    desc = guide.desc() if hasattr(guide, "desc") else guide
+    r = PostprocessResult()
+    r.free_mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    r.path_length = torch.empty(n, dtype=torch.float32, device=dev)
+    r.smoothness = torch.empty(n, dtype=torch.float32, device=dev)
+    r.smoothed = torch.empty_like(trajs) if smooth else None
+    r.waypoint_collisions = (torch.empty((n, (h - 1) * num_interpolation), dtype=torch.uint8, device=dev)
+                             if want_waypoints else None)
+    alpha = interpolation_alphas(num_interpolation)
+    sav = _savgol_dev(h, dev, window_size, poly_order) if smooth else None
+    fp = C.POINTER(C.c_float)
+    _lib.check(_lib.load().mmd_postprocess_trajs(
+        C.byref(desc), _lib.require_gpu(trajs, "trajs"), n_robots, n // n_robots, h, num_interpolation,
+        alpha.ctypes.data_as(fp), float(margin), (C.c_float * 2)(*Q_MIN), (C.c_float * 2)(*Q_MAX), int(bool(all_free)),
+        sav.data_ptr() if sav is not None else None, window_size,      # rows of the operator are zero beyond +-window
+        r.waypoint_collisions.data_ptr() if r.waypoint_collisions is not None else None, r.free_mask.data_ptr(),
+        r.path_length.data_ptr(), r.smoothness.data_ptr(), r.smoothed.data_ptr() if smooth else None,
+        _lib.current_stream_ptr()))
+    return r
+
+
+def select_best(free_mask, n_robots, cost_a=None, cost_b=None, counts=None):
+    """Per robot: (index of the best free sample, number of free samples), int32 device tensors (mmd_select_best)."""
+    n = free_mask.shape[0]
+    dev = free_mask.device
+    idx = torch.empty(n_robots, dtype=torch.int32, device=dev)
+    n_free = torch.empty(n_robots, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().mmd_select_best(
+        free_mask.data_ptr(), cost_a.data_ptr() if cost_a is not None else None,
+        cost_b.data_ptr() if cost_b is not None else None,
+        counts.contiguous().data_ptr() if counts is not None else None, n_robots, n // n_robots, idx.data_ptr(),
+        n_free.data_ptr(), _lib.current_stream_ptr()))
+    return idx, n_free
+
+
+def split_free(trajs, free_mask):
+    """(coll, coll_idxs, free, free_idxs) with the reference's shapes (tasks.py:258-307): idxs are [n, 1]."""
+    fm = free_mask.bool()
+    free_idxs = torch.argwhere(fm)
+    coll_idxs = torch.argwhere(~fm)
+    free = trajs[fm] if free_idxs.numel() else None
+    coll = trajs[~fm] if coll_idxs.numel() else None
+    return coll, coll_idxs, free, free_idxs
+
+
+def get_trajs_collision_and_free(trajs, guide, num_interpolation=5, all_free=False):
+    """tasks.py:236-311 for [B,H,D] batches.  Returns (coll, coll_idxs, free, free_idxs, waypoint_collisions)."""
+    r = postprocess_batch(guide, trajs, num_interpolation=num_interpolation, all_free=all_free, smooth=False,
+                          want_waypoints=True)
+    coll, coll_idxs, free, free_idxs = split_free(trajs, r.free_mask)
+    return coll, coll_idxs, free, free_idxs, r.waypoint_collisions.bool()
+
+
+def compute_collision(points, guide, margin=None, map_index=0):
+    """PlanningTask.compute_collision (tasks.py:141-143): points [..., >=2] on the GPU -> bool [...]; default margin =
+    collision_margins + cutoff_margin (distance_fields.py:320)."""
+    pts = points.to(dtype=torch.float32).contiguous()
+    flat = pts.reshape(-1, pts.shape[-1])
+    out = torch.empty(flat.shape[0], dtype=torch.uint8, device=pts.device)
+    desc = guide.desc() if hasattr(guide, "desc") else guide
+    _lib.check(_lib.load().mmd_points_collision(C.byref(desc), _lib.require_gpu(flat, "points"), flat.shape[0],
+                                                flat.shape[1], map_index,
+                                                float(guide.margin if margin is None else margin), out.data_ptr(),
+                                                _lib.current_stream_ptr()))
+    return out.bool().view(pts.shape[:-1])
+
+
+def compute_variance_waypoints(trajs):
+    """trajectory/metrics.py:17-27 for a [B,L,4] batch on the GPU."""
+    trajs = trajs.contiguous()
+    var_t = torch.empty(trajs.shape[1], dtype=torch.float32, device=trajs.device)
+    _lib.check(_lib.load().mmd_variance_waypoints(_lib.require_gpu(trajs, "trajs"), trajs.shape[0], trajs.shape[1],
+                                                  var_t.data_ptr(), _lib.current_stream_ptr()))
+    return var_t.sum()
+
+
+def smooth_trajs(trajs, guide, window_size=10, poly_order=2):
+    """mmd/common/trajectory_utils.py:31-40 without its GPU -> CPU scipy -> GPU round trip."""
+    return postprocess_batch(guide, trajs, num_interpolation=0, all_free=True, smooth=True, window_size=window_size,
+                             poly_order=poly_order).smoothed

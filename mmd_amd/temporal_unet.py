@@ -1,6 +1,8 @@
 """TemporalUnet: host mirror of reference mmd/models/diffusion_models/temporal_unet.py:23-174 whose forward runs as
 hand-written gfx950 kernels (mmd_amd/csrc/unet.hip) behind the C ABI (include/mmd_amd.h: mmd_unet_*)."""
 import ctypes as C
+import hashlib
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -8,6 +10,28 @@ import torch
 
 from . import _lib
 from .unet_spec import UNET_DIM_MULTS, unet_param_spec   # noqa: F401
+
+# Device-side sharing: the reference builds N+1 planner objects, each reloading the same checkpoint
+# (scripts/inference/inference_multi_agent.py:186-237).  Here every TemporalUnet with the same parameters (content hash),
+# the same number of diffusion steps and the same device shares ONE device model: one packed weight blob + one
+# time-embedding table.  The cache holds weak references: the device model is freed when its last user goes away.
+_DEVICE_MODELS = weakref.WeakValueDictionary()
+N_DEVICE_MODELS_CREATED = 0          # number of mmd_unet_create calls made by this process (tests / constructor reports)
+
+
+class _DeviceModel:
+    """Owner of one mmd_unet_t."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                _lib.load().mmd_unet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class TemporalUnet:
@@ -23,7 +47,8 @@ class TemporalUnet:
         self.spec = unet_param_spec(state_dim, unet_input_dim, self.dim_mults)
         self.max_timesteps = max_timesteps
         self._sd = None
-        self._handle = None
+        self._sd_hash = None
+        self._models = {}               # n_timesteps -> _DeviceModel (shared through _DEVICE_MODELS)
         self._ws = None
 
     # ---- parameters -------------------------------------------------------------------------------------------
@@ -39,40 +64,39 @@ class TemporalUnet:
                 raise ValueError(f"{k}: shape {v.shape} != {shape}")
             sd[k] = v
         self._sd = sd
-        self._release()
+        h = hashlib.blake2b(digest_size=16)
+        for v in sd.values():
+            h.update(v.tobytes())
+        self._sd_hash = h.hexdigest()
+        self._models = {}
         return self
 
     def state_dict(self):
         return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._sd.items())
 
-    def _release(self):
-        if self._handle is not None:
-            _lib.load().mmd_unet_destroy(self._handle)
-            self._handle = None
-
-    def __del__(self):
-        try:
-            self._release()
-        except Exception:
-            pass
-
     def handle(self, n_timesteps=None):
-        """Device model (packed weights + time-embedding table for t in [0, n_timesteps))."""
+        """Device model (packed weights + time-embedding table for t in [0, n_timesteps)), shared by every TemporalUnet
+        of this process that holds the same parameters on the same device."""
+        global N_DEVICE_MODELS_CREATED
         if self._sd is None:
             raise RuntimeError("TemporalUnet has no parameters: call load_state_dict first")
-        if n_timesteps is not None and n_timesteps > self.max_timesteps:
-            self.max_timesteps = n_timesteps
-            self._release()
-        if self._handle is None:
-            lib = _lib.load()
-            n = len(self._sd)
-            ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in self._sd.values()])
-            numels = (C.c_int64 * n)(*[v.size for v in self._sd.values()])
-            h = C.c_void_p()
-            _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), self.max_timesteps,
-                                           ptrs, numels, n, _lib.current_stream_ptr()))
-            self._handle = h
-        return self._handle
+        T = int(n_timesteps) if n_timesteps is not None else (max(self._models) if self._models else self.max_timesteps)
+        if T not in self._models:
+            key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, torch.cuda.current_device())
+            dm = _DEVICE_MODELS.get(key)
+            if dm is None:
+                lib = _lib.load()
+                n = len(self._sd)
+                ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in self._sd.values()])
+                numels = (C.c_int64 * n)(*[v.size for v in self._sd.values()])
+                h = C.c_void_p()
+                _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), T, ptrs, numels, n,
+                                               _lib.current_stream_ptr()))
+                N_DEVICE_MODELS_CREATED += 1
+                dm = _DeviceModel(h)
+                _DEVICE_MODELS[key] = dm
+            self._models[T] = dm
+        return self._models[T].handle
 
     def workspace(self, n_traj, device, sampler=False):
         lib = _lib.load()

@@ -367,7 +367,9 @@ def grad_constraint(xu, grp: ConstraintGroup):
         d = p[None] - q[:, None, None, :]                                           # [n,B,H,2]
         dist = torch.linalg.norm(d, dim=-1)                                         # [n,B,H]
         act = active_t[:, None, :] & ~(dist > r[:, None, None])
-        contrib = torch.where(act[..., None], d / dist[..., None], torch.zeros_like(d))
+        # a point exactly on a constraint centre: torch.norm's backward yields the zero sub-gradient there
+        unit = torch.where(dist[..., None] > 0, d / dist[..., None].clamp_min(1e-38), torch.zeros_like(d))
+        contrib = torch.where(act[..., None], unit, torch.zeros_like(d))
         g[..., :2] -= contrib.sum(0)
     return g
 
@@ -606,3 +608,79 @@ def count_collisions_with_others(samples_pos, paths, self_idx, radius=0.05):
     others = torch.cat((paths[:self_idx], paths[self_idx + 1:]))                    # [N-1,H,2]
     d = torch.norm(samples_pos[:, None] - others[None], dim=-1)                     # [B,N-1,H]
     return (d < 2.1 * radius).sum(dim=(1, 2))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 8f-2  post-sampling selection (the step right after the hot path), pinned by golden g9 / g12
+# --------------------------------------------------------------------------------------------------------------
+
+
+def interpolate_traj_via_points(trajs, num_interpolation=10):
+    """deps/torch_robotics/torch_robotics/trajectory/utils.py:73-86."""
+    H, D = trajs.shape[-2:]
+    if num_interpolation <= 0:
+        return trajs
+    alpha = torch.linspace(0, 1, num_interpolation + 2).type_as(trajs)[1:num_interpolation + 1]
+    alpha = alpha.view((1,) * len(trajs.shape[:-1]) + (-1, 1))
+    out = trajs[..., 0:H - 1, None, :] * alpha + trajs[..., 1:H, None, :] * (1 - alpha)
+    return out.view(trajs.shape[:-2] + (-1, D))
+
+
+def compute_collision(pos, gp: GuideParams, margin=None):
+    """occupancy branch of PlanningTask._compute_collision_or_cost (tasks.py:141-143, :204-232): a point collides iff a
+    fixed-object SDF (nearest grid cell, distance_fields.py:318-326, :342-351) or a workspace-boundary distance
+    (:361-367) is below `margin` (default: collision_margins + cutoff_margin, :320)."""
+    margin = gp.margin if margin is None else margin
+    coll = torch.zeros(pos.shape[:-1], dtype=torch.bool)
+    for k in range(len(gp.sdf_grids)):
+        coll = coll | (sdf_lookup(pos, gp, k)[0] < margin)
+    ws = torch.cat((pos - gp.ws_min, gp.ws_max - pos), dim=-1)
+    return coll | (ws < margin).any(dim=-1)
+
+
+def get_trajs_collision_and_free(trajs, gp: GuideParams, num_interpolation=5, all_free=False, q_min=(-1.0, -1.0),
+                                 q_max=(1.0, 1.0)):
+    """tasks.py:236-311 for [B,H,D] batches (margin = robot radius, :251-253).  Returns (coll, coll_idxs, free, free_idxs,
+    waypoint_collisions); all_free: PlanningTaskEnsemble (tasks_ensemble.py:271-277)."""
+    B = trajs.shape[0]
+    if all_free:
+        coll_pts = torch.zeros(B, 1, dtype=torch.bool)
+    else:
+        coll_pts = compute_collision(interpolate_traj_via_points(trajs, num_interpolation)[..., :2], gp, gp.robot_radius)
+    in_coll = coll_pts.any(dim=-1)
+    pos = trajs[..., :2]
+    inside = (pos >= torch.tensor(q_min)) & (pos <= torch.tensor(q_max))
+    free_mask = ~in_coll & inside.all(dim=-1).all(dim=-1)
+    if all_free:
+        free_mask = torch.ones_like(in_coll)
+    free_idxs = torch.argwhere(free_mask)
+    coll_idxs = torch.argwhere(~free_mask)
+    free = trajs[free_mask] if free_mask.any() else None
+    coll = trajs[~free_mask] if (~free_mask).any() else None
+    return coll, coll_idxs, free, free_idxs, coll_pts
+
+
+def compute_path_length(trajs):
+    """trajectory/metrics.py:7-15."""
+    return torch.linalg.norm(torch.diff(trajs[..., :2], dim=-2), dim=-1).sum(-1)
+
+
+def compute_smoothness(trajs):
+    """trajectory/metrics.py:30-39."""
+    return torch.linalg.norm(torch.diff(trajs[..., 2:4], dim=-2), dim=-1).sum(-1)
+
+
+def compute_variance_waypoints(trajs):
+    """trajectory/metrics.py:17-27."""
+    pos = trajs[..., :2]
+    total = 0.0
+    for via in pos.permute(1, 0, 2):
+        d = torch.cdist(via, via, p=2)
+        total = total + torch.var(torch.triu(d, diagonal=1).view(-1))
+    return total
+
+
+def smooth_trajs(trajs, window_size=10, poly_order=2):
+    """mmd/common/trajectory_utils.py:31-40 (scipy savgol_filter along the horizon, mode='interp')."""
+    from scipy.signal import savgol_filter
+    return torch.from_numpy(savgol_filter(trajs.numpy(), window_size, poly_order, axis=1))

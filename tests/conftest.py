@@ -22,3 +22,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import parity_log
+    path = parity_log.flush()
+    if path:
+        print(f"\nparity records written to {path}")

@@ -7,8 +7,8 @@ from mmd_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "mmd_amd.h")).read()
+def _declared_symbols(header="mmd_amd.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(mmd_[a-z0-9_]+)\s*\(", txt)))
 
@@ -21,6 +21,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mmd_amd.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
     assert lib.mmd_abi_version() == _lib.ABI_VERSION
+    debug = _declared_symbols("mmd_amd_debug.h")
+    for name in debug:
+        assert hasattr(lib, name), f"{name} declared in include/mmd_amd_debug.h but not exported"
+    assert sorted(_lib.DEBUG_SYMBOLS) == debug
+    assert not set(debug) & set(declared), "measurement hooks must stay out of the product header"
 
 
 def test_unet_spec_matches_library():

@@ -66,6 +66,45 @@ def test_headline_batched_equals_sharded(headline):
     assert torch.equal(a[sl], b)
 
 
+@pytest.mark.parametrize("world,rank", [(2, 1), (4, 1), (4, 3), (8, 0), (8, 5)])
+def test_headline_sharded_equals_unsharded_with_inkernel_noise(headline, world, rank):
+    """per-robot outputs bitwise identical for G = 1, 2, 4, 8 -- in the PRODUCTION noise path.  The in-kernel
+    Philox draws are keyed by (seed, draw, GLOBAL trajectory index), so rank `rank` of `world`, sampling only its robots
+    with the same seed, reproduces exactly the rows those robots have in the one-GPU 32-robot run (x_T and every step's
+    noise), and different robots never share noise."""
+    model, s, starts, goals, paths = headline
+    from mmd_amd.multi_robot import MultiRobotSampler
+    import gpu_common
+    m25 = gpu_common.hip_model(25)
+    full = MultiRobotSampler(m25, starts, goals, env_id="EnvEmpty2D", n_samples=B)
+    part = MultiRobotSampler(m25, starts, goals, env_id="EnvEmpty2D", n_samples=B, rank=rank, world_size=world)
+    full.set_other_paths(paths)
+    part.set_other_paths(paths)
+    a = full.sample(seed=2024)
+    b = part.sample(seed=2024)
+    sl = slice(part.robot0 * B, (part.robot0 + part.n_local) * B)
+    assert torch.equal(a[sl], b), (world, rank)
+    # robots do not share noise: the first two robots' batches differ already in their initial draws
+    x0 = m25.p_sample_loop((2 * B, H, D), {}, 0, seed=2024)
+    assert not torch.equal(x0[:B], x0[B:])
+    # and the shard's x_T is the matching slice of the global x_T
+    xg = m25.p_sample_loop((R * B, H, D), {}, 0, seed=2024)
+    xs = m25.p_sample_loop((part.n_local * B, H, D), {}, 0, seed=2024, traj_index_base=part.robot0 * B)
+    assert torch.equal(xg[sl], xs)
+
+
+def test_planners_with_the_same_seed_draw_independent_noise():
+    """N planners built with the default seed must not sample identical trajectories (the reference seeds once
+    and every call advances one global RNG)."""
+    from mmd_amd.planners import MPD
+    kw = dict(model_id="EnvEmpty2D-RobotPlanarDisk", planner_alg="diffusion_prior", n_samples=4, device="cuda",
+              model_state_dict=synth.synth_unet_state_dict(0), model_args=dict(n_diffusion_steps=25), seed=18)
+    s, g = torch.tensor([-0.5, 0.0]), torch.tensor([0.5, 0.0])
+    p1, p2 = MPD(start_state_pos=s, goal_state_pos=g, **kw), MPD(start_state_pos=s, goal_state_pos=g, **kw)
+    o1, o2, o1b = p1(s, g).trajs_iters[-1], p2(s, g).trajs_iters[-1], p1(s, g).trajs_iters[-1]
+    assert not torch.equal(o1, o2) and not torch.equal(o1, o1b)
+
+
 def test_headline_prior_spot_check_vs_oracle(headline):
     """planner_alg 'diffusion_prior' at full size: the unguided chain is well conditioned (sens 7e-7), so 6 of the 2048
     trajectories are compared with the oracle end to end at the north-star tolerance."""

@@ -13,9 +13,13 @@ pytestmark = pytest.mark.gpu
 from mmd_amd import synth            # noqa: E402
 from oracle import mmd_oracle as O   # noqa: E402
 import cases                         # noqa: E402
+import parity_log                    # noqa: E402
 from cases import GOLDEN, H, D, rel_l2   # noqa: E402
 
-TOL_FINAL = 1e-3
+TOL_FINAL = 1e-3          # BASELINE.json north_star: within 1e-3 relative L2 of the reference sampler
+TOL_STEP_GUIDED = 1e-3    # one teacher-forced guided DDPM step (20 norm-clipped guide iterations); measured <= 3e-4
+TOL_STEP_PLAIN = 2e-5     # one teacher-forced unguided step
+SENS_FACTOR = 1.5         # end-to-end rows of a chaotic (guided) chain: err < max(TOL_FINAL, SENS_FACTOR * sens)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -87,6 +91,162 @@ def test_guide_single_eval_golden():
     guide = _gc().hip_guide("EnvEmpty2D", [[grp]])
     x3 = (torch.from_numpy(synth.synth_noise(9, (4, H, D))) * 0.5).cuda()
     assert float((guide(x3).cpu() - torch.from_numpy(g["empty32_B4"])).abs().max()) < 2e-6
+
+
+def _raw_guide_grad(guide, x, patch):
+    """guide(x) through the C ABI with a patched descriptor (isolates one cost term)."""
+    import ctypes as C
+    from mmd_amd import _lib
+    d = guide.desc()
+    patch(d)
+    y = x.contiguous().clone()
+    hard = torch.zeros(1, 2, D, device="cuda")
+    _lib.check(_lib.load().mmd_guide_steps(C.byref(d), y.data_ptr(), hard.data_ptr(), 0, 1, x.shape[0], 1, None,
+                                           _lib.current_stream_ptr()))
+    return (y - x).cpu()
+
+
+def test_guide_per_term_golden_g4():
+    """Every cost term of the guide on its own against the reference's clipped per-term gradients (g4): fixed-object SDF,
+    workspace boundaries, GP prior, soft and hard constraint groups -- each isolated by zeroing the other weights /
+    moving the workspace walls out of reach, so an error in one term cannot hide behind another's clip or weight."""
+    g = np.load(os.path.join(GOLDEN, "g4_guide_terms.npz"))
+    _, _, soft, hard = cases.highways_case()
+    x = (torch.from_numpy(synth.synth_noise(int(g["x_seed"]), (8, H, D))) * float(g["x_scale"])).cuda()
+    gc = _gc()
+    far = 1e6
+
+    def only_obj(d):
+        d.weight_collision, d.weight_smoothness = 1.0, 0.0
+        d.ws_min[:], d.ws_max[:] = [-far, -far], [far, far]
+
+    def only_ws(d):
+        d.weight_collision, d.weight_smoothness, d.n_grids = 1.0, 0.0, 0
+
+    def only_gp(d):
+        d.weight_collision, d.weight_smoothness = 0.0, 1.0
+
+    def no_base(d):
+        d.weight_collision, d.weight_smoothness = 0.0, 0.0
+
+    plain = gc.hip_guide("EnvHighways2D", [[]])
+    checks = [("obj", plain, only_obj), ("ws", plain, only_ws), ("gp", plain, only_gp)]
+    soft1 = type(soft)(q=soft.q, t_range=soft.t_range, radius=soft.radius, weight=1.0)
+    hard0 = type(hard)(q=hard.q, t_range=hard.t_range, radius=hard.radius, weight=0.0)
+    hard1 = type(hard)(q=hard.q, t_range=hard.t_range, radius=hard.radius, weight=1.0)
+    checks.append(("cons_soft", gc.hip_guide("EnvHighways2D", [[soft1, hard0]]), no_base))
+    checks.append(("cons_hard", gc.hip_guide("EnvHighways2D", [[hard1]]), no_base))
+    for name, guide, patch in checks:
+        got = -_raw_guide_grad(guide, x, patch)
+        err = float((got - torch.from_numpy(g[f"term_{name}"])).abs().max())
+        parity_log.record("guide_per_term_g4", name, None, err, bound=2e-6, note="max abs")
+        assert err < 2e-6, (name, err)
+        assert float(torch.from_numpy(g[f"term_{name}"]).abs().max()) > 1e-3, name      # the term is exercised
+
+
+def test_guide_point_on_constraint_centre_is_finite():
+    """A support point that coincides exactly with a constraint centre: torch.norm's backward gives a zero gradient there;
+    the kernel must not produce 0 * inf = NaN."""
+    x = torch.zeros(4, H, D)
+    x[..., 0] = torch.linspace(-0.5, 0.5, H)[None]
+    gp = cases.guide_params("EnvEmpty2D")
+    xu = O.unnormalize(x, gp.norm_mins, gp.norm_maxs, clip_mode="always")
+    centre = [float(xu[0, 20, 0]), float(xu[0, 20, 1])]               # exactly where support point 20 sits
+    grp = cases.hard_group([[0.0, 0.0], centre], [[30, 34], [20, 21]])
+    guide = _gc().hip_guide("EnvEmpty2D", [[grp]])
+    out = guide(x.cuda()).cpu()
+    assert torch.isfinite(out).all()
+    ref = O.guide_grad(x, gp, [grp], clip_mode="always")
+    ref_autograd = O.guide_grad_dense_autograd(x, gp, [grp])          # torch.norm backward: zero sub-gradient at d = 0
+    assert torch.isfinite(ref_autograd).all() and float((ref - ref_autograd).abs().max()) < 2e-6
+    assert float((out - ref).abs().max()) < 2e-6
+
+
+def test_guide_steps_chain_output():
+    """mmd_guide_steps with a chain buffer (the post-diffusion guide steps of 'diffusion_prior_then_guide' in ONE launch)
+    == n single-step launches."""
+    starts, goals, soft, hard = cases.highways_case()
+    hc = cases.hard_conds_for(starts[3], goals[3])
+    guide = _gc().hip_guide("EnvHighways2D", [[soft, hard]])
+    x = O.apply_hard_conditioning(torch.from_numpy(synth.synth_noise(53, (8, H, D))) * 0.5, hc).cuda()
+    hardt = torch.stack([hc[0], hc[H - 1]])[None].cuda().contiguous()
+    y = x.clone()
+    chain = torch.empty((7, 8, H, D), device="cuda")
+    guide.guide_steps(y, hardt, 3, 7, chain=chain)
+    z = x.clone()
+    for k in range(7):
+        guide.guide_steps(z, hardt, 3, 1)
+        assert torch.equal(chain[k], z), k
+    assert torch.equal(y, z)
+
+
+def test_q_sample_ensemble_seed_covers_every_tile():
+    """DiffusionsEnsemble.run_local_inference noises a [B, K*64, 4] seed with models[0].q_sample
+    (diffusion_ensemble.py:279-281): every point of every tile must be noised (the C ABI counts blocks of 64 points)."""
+    model = _gc().hip_model(25)
+    B, K = 4, 2
+    x0 = torch.from_numpy(synth.synth_noise(54, (B, K * H, D))) * 0.4
+    noise = torch.from_numpy(synth.synth_noise(55, (B, K * H, D)))
+    out = model.q_sample(x0.cuda(), 3, noise=noise.cuda()).cpu()
+    ref = O.q_sample(O.schedule_tables(25), x0, 3, noise)
+    assert out.shape == ref.shape and rel_l2(out, ref) < 1e-6
+    # Philox path: every tile gets noise, reproducible per global index
+    a = model.q_sample(x0.cuda(), 3).cpu()
+    assert torch.isfinite(a).all() and float((a[:, H:] - x0[:, H:]).abs().mean()) > 1e-3
+    with pytest.raises(ValueError):
+        model.q_sample(x0[:, :100].cuda(), 3)
+
+
+def test_noise_std_extra_schedule_is_evaluated_per_step():
+    """noise_std_extra_schedule_fn(t) is called with t on every step (sample_functions.py:83-86): a non-constant schedule
+    must reach the kernel per step, checked against the oracle on the unguided prior."""
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    T, B = 25, 4
+    model = _gc().hip_model(T)
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    hc = cases.hard_conds_for(starts[0], goals[0])
+    xT = torch.from_numpy(synth.synth_noise(56, (B, H, D)))
+    steps = torch.from_numpy(synth.synth_noise(57, (T + 1, B, H, D)))
+    fn = lambda t: 0.25 + 0.03 * float(t)          # noqa: E731
+    out = model.run_inference(None, hc, n_samples=B, horizon=H, return_chain=False, sample_fn=ddpm_sample_fn, guide=None,
+                              noise_std_extra_schedule_fn=fn, n_diffusion_steps_without_noise=1,
+                              warm_start_path_b=xT.cuda(), step_noise=steps.cuda()).cpu()
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    tb = O.schedule_tables(T)
+    x = O.apply_hard_conditioning(xT.clone(), hc)
+    for k, i in enumerate(reversed(range(-1, T))):
+        x = O.ddpm_sample_step(sd, tb, x, hc, i, guide=None, noise=steps[k], noise_std_extra=fn(max(i, 0)))
+        x = O.apply_hard_conditioning(x, hc)
+    assert rel_l2(out, x) < 1e-4, rel_l2(out, x)
+
+
+def test_workspace_is_exact_for_every_stream_count():
+    """the chunked loop must stay inside mmd_sampler_workspace_bytes.  The workspace is allocated with
+    exactly that many bytes inside a guarded buffer; the guard words survive n_streams = 1, 2, 3."""
+    import ctypes as C
+    from mmd_amd import _lib
+    from mmd_amd.diffusion_model import ddpm_sample_fn   # noqa: F401
+    lib = _lib.load()
+    T, B, R = 25, 8, 5
+    model = _gc().hip_model(T)
+    n = R * B
+    handle = model.model.handle(T)
+    nbytes = lib.mmd_sampler_workspace_bytes(handle, n)
+    assert nbytes == lib.mmd_unet_workspace_bytes(handle, n) + n * H * D * 4
+    guard = 4096
+    buf = torch.full((nbytes + 2 * guard,), 0xA5, dtype=torch.uint8, device="cuda")
+    ws_ptr = buf.data_ptr() + guard
+    starts, goals = synth.start_goal_circle(R, 0.8)
+    hard = torch.stack([torch.stack([cases.hard_conds_for(starts[r], goals[r])[0],
+                                     cases.hard_conds_for(starts[r], goals[r])[H - 1]]) for r in range(R)]).cuda().contiguous()
+    for ns in (1, 2, 3):
+        s = model._sampler_desc(20, 13, lambda t: 0.5, 3, ns)
+        x = torch.empty((n, H, D), device="cuda")
+        _lib.check(lib.mmd_p_sample_loop(handle, C.byref(s), None, x.data_ptr(), hard.data_ptr(), R, B, T, 1, 1, None,
+                                         C.c_uint64(5), None, C.c_void_p(ws_ptr), nbytes, _lib.current_stream_ptr()))
+        torch.cuda.synchronize()
+        assert bool((buf[:guard] == 0xA5).all()) and bool((buf[guard + nbytes:] == 0xA5).all()), ns
+        assert torch.isfinite(x).all()
 
 
 def test_guide_20_steps_vs_oracle():
@@ -175,8 +335,10 @@ def test_single_step_teacher_forced_golden(name):
         err = rel_l2(x.cpu(), ref[k + 1])
         guided = guide is not None and i < ceil(0.5 * T)
         # unguided steps are smooth: 2e-5.  A guided step is 20 bang-bang (norm-clipped) gradient iterations whose
-        # direction flips on rounding-size differences: 2e-3 (measured: 1e-6 ... 3e-4).
-        assert err < (2e-3 if guided else 2e-5), (name, r, i, err)
+        # direction flips on rounding-size differences: the north-star 1e-3 (measured: 1e-6 ... 3e-4).
+        bound = TOL_STEP_GUIDED if guided else TOL_STEP_PLAIN
+        parity_log.record("single_step_teacher_forced", name, r, err, bound=bound, note="guided" if guided else "unguided")
+        assert err < bound, (name, r, i, err)
         n_pairs += 1
     assert n_pairs >= 5
 
@@ -185,9 +347,11 @@ def test_single_step_teacher_forced_golden(name):
 def test_run_inference_golden(name):
     """End-to-end chain against the reference.  The guided sampler is CHAOTIC: the genuine reference, run twice on
     CPU with its UNet output perturbed by a relative 1e-6 (a different fp32 summation order), differs from itself by
-    `sens` (max over 6 perturbation draws, stored in the fixture by tools/make_golden.py: 1e-1..3e-1 rel. L2 on the
-    constraint cases, 7e-7 for the unguided prior).  So the bound is max(1e-3, 4 * sens): the north-star 1e-3 wherever
-    the reference itself is that reproducible, and "no worse than any other fp32 implementation" elsewhere."""
+    `sens` (max over MMD_SENS_DRAWS = 24 perturbation draws per row, stored in the fixture by tools/make_golden.py:
+    1e-1..3e-1 rel. L2 on the constraint cases, 7e-7 for the unguided prior).  So the bound per row is
+    max(1e-3, 1.5 * sens): the north-star 1e-3 wherever the reference itself is that reproducible, and "no further from
+    the reference than the reference is from itself" elsewhere.  The sharp per-step statement is
+    test_single_step_teacher_forced_golden; every measured error lands in r02_parity.json."""
     g = np.load(os.path.join(GOLDEN, f"g6_sample_{name}.npz"))
     case = cases.sample_case(name)
     xT, steps = cases.sample_inputs(case)
@@ -195,16 +359,16 @@ def test_run_inference_golden(name):
     assert chain.shape == (case["T"] + 2, case["B"], H, D)
     assert torch.isfinite(chain).all()
     ref = torch.from_numpy(g["chain_rows"])
-    sens_final = float(g["sens"][-1])
+    failures = []
     for k, r in enumerate(g["rows"]):
         err = rel_l2(chain[int(r)], ref[k])
-        # the amplification right after guidance starts is heavy-tailed (one perturbation draw in ten is 5-10x the
-        # typical one), so rows inside the guided phase are also allowed a quarter of the final divergence scale
-        guided_row = int(r) > case["T"] - ceil(0.5 * case["T"])
-        bound = max(TOL_FINAL, 4.0 * float(g["sens"][k]), 0.25 * sens_final if guided_row else 0.0)
-        assert err < bound, (name, int(r), err, float(g["sens"][k]), bound)
-    if not case.get("use_guide", True) or name in ("cfg0_T50_B1", "empty_T25_nocons"):
-        assert rel_l2(chain[-1], ref[-1]) < 3e-3
+        bound = max(TOL_FINAL, SENS_FACTOR * float(g["sens"][k]))
+        parity_log.record("run_inference_golden", name, r, err, sens=float(g["sens"][k]), bound=bound)
+        if not err < bound:
+            failures.append((name, int(r), err, float(g["sens"][k]), bound))
+    assert not failures, failures
+    if not case.get("use_guide", True):
+        assert rel_l2(chain[-1], ref[-1]) < TOL_FINAL
 
 
 @pytest.mark.parametrize("name", cases.DDIM_CASES)
@@ -224,6 +388,7 @@ def test_ddim_sample_golden(name):
     chain = chain.transpose(0, 1).cpu()
     assert chain.shape == ref.shape
     for r in range(ref.shape[0]):
+        parity_log.record("ddim_sample_golden", name, r, rel_l2(chain[r], ref[r]), sens=float(g["sens"]), bound=1e-4)
         assert rel_l2(chain[r], ref[r]) < 1e-4, (name, r, rel_l2(chain[r], ref[r]))
     assert torch.equal(x.cpu(), chain[-1])
     with pytest.raises(ValueError):
@@ -253,14 +418,18 @@ def test_run_local_inference_golden():
     # the reference's own sensitivity to a 1e-6 UNet perturbation
     for r in range(5):
         err = rel_l2(chain[r], ref[r])
-        assert err < (2e-5 if r == 0 else max(TOL_FINAL, 4.0 * float(g["sens"][r]))), (r, err, g["sens"])
+        bound = 2e-5 if r == 0 else max(TOL_FINAL, SENS_FACTOR * float(g["sens"][r]))
+        parity_log.record("run_local_inference_golden", "highways_T50", r, err, sens=float(g["sens"][r]), bound=bound)
+        assert err < bound, (r, err, g["sens"])
     # teacher-forced: each single step from the reference's own state
     hc = cases.hard_conds_for(starts[3], goals[3])
     for r in range(4):
         x = ref[r].clone().cuda()
         model.sample_step(x, hc, 2 - r, guide=guide, n_guide_steps=20, t_start_guide=25,
                           noise_std_extra_schedule_fn=lambda t: 0.5, noise=steps[r])
-        assert rel_l2(x.cpu(), ref[r + 1]) < 2e-3, (r, rel_l2(x.cpu(), ref[r + 1]))
+        parity_log.record("run_local_inference_teacher_forced", "highways_T50", r, rel_l2(x.cpu(), ref[r + 1]),
+                          bound=TOL_STEP_GUIDED)
+        assert rel_l2(x.cpu(), ref[r + 1]) < TOL_STEP_GUIDED, (r, rel_l2(x.cpu(), ref[r + 1]))
 
 
 def test_multi_robot_batch_equals_per_robot():

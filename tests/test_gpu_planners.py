@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from mmd_amd import synth                # noqa: E402
 import cases                             # noqa: E402
+import parity_log                        # noqa: E402
 from cases import GOLDEN, H, D, rel_l2   # noqa: E402
 
 
@@ -52,10 +53,81 @@ def test_ensemble_two_tiles_golden():
     # the stitched boundary: end of tile 0 == start of tile 1 shifted by the tile offset (where not clamped)
     rel = torch.tensor([2.0, 0, 0, 0], device="cuda")
     assert torch.allclose(x[0][:, H - 1] - rel, x[1][:, 0], atol=1e-5)
-    # row T//2+1 is the state after the FIRST guided step of both tiles: tight; finals: chaotic regime
-    assert rel_l2(chains[0][:, T // 2 + 1].cpu(), g["chain0_mid"]) < 2e-3
-    assert rel_l2(chains[1][:, T // 2 + 1].cpu(), g["chain1_mid"]) < 2e-3
-    assert rel_l2(x[0].cpu(), g["final0"]) < 0.3 and rel_l2(x[1].cpu(), g["final1"]) < 0.3
+    # EVERY chain row of both tiles against the reference; bound per row max(1e-3, 1.5 * sens) with the reference's own
+    # sensitivity to a relative 1e-6 UNet perturbation (stored in g8 by tools/make_golden.py, like g6)
+    failures = []
+    for m in (0, 1):
+        ref, sens = g[f"chain{m}"], g[f"sens{m}"]
+        got = chains[m].transpose(0, 1).cpu()
+        assert got.shape == ref.shape
+        for r in range(ref.shape[0]):
+            err = rel_l2(got[r], ref[r])
+            bound = max(1e-3, 1.5 * float(sens[r]))
+            parity_log.record("ensemble_two_tiles_golden", f"tile{m}", r, err, sens=float(sens[r]), bound=bound)
+            if not err < bound:
+                failures.append((m, r, err, float(sens[r])))
+        assert torch.equal(got[-1], x[m].cpu())
+    assert not failures, failures
+    # teacher-forced per outer step: restart both tiles from the reference's rows k, run the product loop for ONE outer step
+    # (tile 0 step, stitch, tile 1 step, stitch) and compare with the reference's rows k + 1
+    worst = 0.0
+    for k in range(T + 1):
+        xk = {m: torch.from_numpy(g[f"chain{m}"][k]) for m in (0, 1)}
+        i = T - 1 - k
+        # drive the two tiles through sample_step + apply_cross_conditioning exactly as the C loop orders them
+        from mmd_amd.diffusion_ensemble import apply_cross_conditioning
+        xs = {m: xk[m].clone().cuda() for m in (0, 1)}
+        for j, m in enumerate((0, 1)):
+            models[m].sample_step(xs[m], hard[m] if m in hard else {}, i, noise=steps[k, j], **skw[m])
+            xs = apply_cross_conditioning(xs, {(0, 1): (H - 1, 0)}, transforms)
+        for m in (0, 1):
+            err = rel_l2(xs[m].cpu(), g[f"chain{m}"][k + 1])
+            worst = max(worst, err)
+            guided = i < ceil(0.5 * T)
+            parity_log.record("ensemble_teacher_forced", f"tile{m}", k, err, bound=1e-3 if guided else 2e-5)
+            assert err < (1e-3 if guided else 2e-5), (m, k, i, err)
+
+
+def test_ensemble_local_inference_warm_start():
+    """MPDEnsemble with an experience (XCBS re-plan): DiffusionsEnsemble.run_local_inference forward-noises the whole
+    [B, K*64, 4] seed with models[0].q_sample and splits it per tile (diffusion_ensemble.py:279-300).  Row 0 of every
+    tile's chain is checked against the oracle's q_sample + tile split + hard / cross conditioning (the
+    second tile used to start from uninitialised memory)."""
+    import gpu_common
+    from mmd_amd.diffusion_ensemble import DiffusionsEnsemble
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    from oracle import mmd_oracle as O
+    T, B, K = 25, 4, 2
+    models = {0: gpu_common.hip_model(T), 1: gpu_common.hip_model(T)}
+    transforms = {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])}
+    ens = DiffusionsEnsemble(models, transforms)
+    s = cases.hard_conds_for([-0.7, 0.3], [0, 0])[0]
+    gl = cases.hard_conds_for([0.6, -0.4], [0, 0])[0]
+    hard = {0: {0: s}, 1: {H - 1: gl}}
+    a = torch.linspace(0, 1, K * H)[None, :, None]
+    seed = torch.cat((torch.tensor([-0.7, 0.3]) * (1 - a) + torch.tensor([2.6, -0.4]) * a, torch.zeros(1, K * H, 2)), -1)
+    seed = (seed.repeat(B, 1, 1) + 0.01 * torch.from_numpy(synth.synth_noise(58, (B, K * H, D)))).float()
+    skw = {m: dict(guide=None, n_guide_steps=20, t_start_guide=13, noise_std_extra_schedule_fn=lambda x: 0.5) for m in (0, 1)}
+    # injected q_sample noise: patch through the model's q_sample
+    qn = torch.from_numpy(synth.synth_noise(59, (B, K * H, D)))
+    noised = models[0].q_sample(seed.cuda(), 3, noise=qn.cuda())
+    ref_noised = O.q_sample(O.schedule_tables(T), seed, 3, qn)
+    assert rel_l2(noised.cpu(), ref_noised) < 1e-6
+    chains = ens.run_local_inference(seed.cuda(), None, 3, None, hard, cross_conds={(0, 1): (H - 1, 0)}, n_samples=B,
+                                     return_chain=True, sample_fn=ddpm_sample_fn, sample_kwargs=skw,
+                                     n_diffusion_steps_without_noise=1)
+    assert chains[0].shape == (5, B, H, D) and all(torch.isfinite(c).all() for c in chains.values())
+    chains = ens.run_local_inference(seed.cuda(), 3, 3, None, hard, cross_conds={(0, 1): (H - 1, 0)}, n_samples=B,
+                                     return_chain=True, sample_fn=ddpm_sample_fn, sample_kwargs=skw,
+                                     n_diffusion_steps_without_noise=1)
+    assert chains[0].shape == (5, B, H, D) and all(torch.isfinite(c).all() for c in chains.values())
+    # the warm start of both tiles is the noised seed (in-kernel noise here: compare its statistics with the seed)
+    for m in (0, 1):
+        x0 = chains[m][0].cpu()
+        tile = seed[:, m * H:(m + 1) * H].clone()
+        tile[..., :2] -= transforms[m]
+        dev = (x0[:, 1:-1] - float(models[0].sqrt_alphas_cumprod[3]) * tile[:, 1:-1]).std()
+        assert abs(float(dev) - float(models[0].sqrt_one_minus_alphas_cumprod[3])) < 0.02, (m, float(dev))
 
 
 def test_mpd_call_contract():
@@ -210,3 +282,192 @@ def test_mpd_loads_checkpoint_and_dataset_from_disk(tmp_path):
              model_state_dict=synth.synth_unet_state_dict(0), model_args=dict(n_diffusion_steps=25),
              normalizer_limits=(mins, maxs), device="cuda")
     assert torch.equal(p2(start, goal, seed=9).trajs_iters, p(start, goal, seed=9).trajs_iters)
+
+
+def test_postprocess_vs_reference_g9():
+    """SURVEY §8f-2 on the device: mmd_postprocess_trajs (collision / free split bit-exact incl. every interpolated
+    waypoint, path length + smoothness, SavGol) and mmd_variance_waypoints against the reference's
+    PlanningTask.get_trajs_collision_and_free / metrics / smooth_trajs on a Highways batch (g9, g12)."""
+    import gpu_common
+    from mmd_amd import postprocess as post
+    g = np.load(os.path.join(GOLDEN, "g9_post.npz"))
+    g12 = np.load(os.path.join(GOLDEN, "g12_boundary.npz"))
+    guide = gpu_common.hip_guide("EnvHighways2D", [[]])
+    trajs = torch.from_numpy(g["trajs"]).cuda()
+    coll, coll_idxs, free, free_idxs, wp = post.get_trajs_collision_and_free(trajs, guide)
+    assert free_idxs.reshape(-1).tolist() == g["free_idxs"].tolist() and free_idxs.ndim == 2
+    assert sorted(coll_idxs.reshape(-1).tolist()) == sorted(g["coll_idxs"].tolist())
+    assert np.array_equal(wp.cpu().numpy(), g["waypoint_collisions"])
+    assert free.shape[0] == len(g["free_idxs"]) and coll.shape[0] == len(g["coll_idxs"])
+    r = post.postprocess_batch(guide, trajs, smooth=True)
+    for name, got, ref, tol in (("smoothness", r.smoothness, g["smoothness"], 1e-6),
+                                ("path_length", r.path_length, g["path_length"], 1e-6),
+                                ("savgol", r.smoothed, g["smoothed"], 1e-6)):
+        err = float(np.max(np.abs(got.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1.0)))
+        parity_log.record("postprocess_g9", name, None, err, bound=tol, note="max rel (abs below 1)")
+        assert err < tol, (name, err)
+    var = float(post.compute_variance_waypoints(trajs))
+    parity_log.record("postprocess_g9", "variance_waypoints", None, abs(var - float(g12["variance_waypoints"])) / float(g12["variance_waypoints"]), bound=1e-5)
+    assert abs(var - float(g12["variance_waypoints"])) < 1e-5 * float(g12["variance_waypoints"])
+    # per-batch pick: argmin of path length + smoothness over the free samples == torch.argmin on the reference's costs
+    idx, n_free = post.select_best(r.free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness)
+    cost = (g["path_length"] + g["smoothness"])[g["free_idxs"]]
+    assert int(n_free) == len(g["free_idxs"]) and int(idx) == int(g["free_idxs"][int(np.argmin(cost))])
+    # several robots in one launch == one robot at a time; least-collisions pick = first free sample with the fewest
+    rep = torch.cat([trajs, trajs.flip(0)])
+    r2 = post.postprocess_batch(guide, rep, n_robots=2, smooth=False)
+    assert torch.equal(r2.free_mask[:trajs.shape[0]], r.free_mask) and torch.equal(r2.free_mask[trajs.shape[0]:], r.free_mask.flip(0))
+    counts = torch.arange(rep.shape[0], dtype=torch.int32, device="cuda") % 5
+    idx2, nf2 = post.select_best(r2.free_mask, 2, counts=counts)
+    for rb in range(2):
+        fm = r2.free_mask.view(2, -1)[rb].bool().cpu().numpy()
+        c = counts.view(2, -1)[rb].cpu().numpy()
+        cand = np.where(fm)[0]
+        assert int(idx2[rb]) == int(cand[np.argmin(c[cand])]) and int(nf2[rb]) == int(fm.sum())
+
+
+def test_outer_boundary_contract_cbs_pp_g12():
+    """What the reference's CBS / PrioritizedPlanning constructors and loops call on `planner.robot` / `planner.task`
+    (cbs.py:142-156,178-192,316-336,427-458; prioritized_planning.py:141-180,260-276;
+    mmd/common/multi_agent_utils.py:30-95), executed against MPD and MPDEnsemble with the reference's own outputs (g12)."""
+    from mmd_amd.planners import MPD, MPDEnsemble
+    g = np.load(os.path.join(GOLDEN, "g12_boundary.npz"))
+    starts, goals = synth.start_goal_circle(10, 0.45)
+    planners = [MPD(start_state_pos=torch.from_numpy(starts[i]), goal_state_pos=torch.from_numpy(goals[i]),
+                    **_mpd_kwargs(n_samples=8)) for i in range(3)]
+    p0 = planners[0]
+    robot, task = p0.robot, p0.task                      # cbs.py:144,149
+    assert p0.tensor_args["device"].type == "cuda" and isinstance(p0.results_dir, str)      # cbs.py:152-153
+    dev = p0.tensor_args["device"]
+    # --- is_multi_agent_start_goal_states_valid (multi_agent_utils.py:47-95): [N,2] stacks
+    for key in ("starts", "close"):
+        q = torch.from_numpy(g[key]).to(dev)
+        coll, pts = robot.check_rr_collisions(q)
+        assert coll.dtype == torch.bool and coll.shape == (q.shape[0], q.shape[0]) and pts.shape == (q.shape[0], q.shape[0], 2)
+        assert np.array_equal(coll.cpu().numpy(), g[f"rr_{key}"])
+    _, pts = robot.check_rr_collisions(torch.from_numpy(g["close"]).to(dev))
+    assert np.array_equal(np.isnan(pts.cpu().numpy()), np.isnan(g["mid_close"]))
+    assert np.array_equal(np.nan_to_num(pts.cpu().numpy()), np.nan_to_num(g["mid_close"]))
+    wc = task.compute_collision(torch.from_numpy(g["points"]).to(dev))
+    assert wc.dtype == torch.bool and tuple(wc.shape) == tuple(g["coll_points"].shape)
+    assert np.array_equal(wc.cpu().numpy(), g["coll_points"])
+    assert tuple(task.compute_collision(torch.from_numpy(g["points"][5]).to(dev)).shape) == tuple(g["coll_one"].shape)
+    # CPU tensors are accepted too and come back on the CPU
+    assert not task.compute_collision(torch.from_numpy(g["points"])).is_cuda
+    # --- get_conflicts (cbs.py:178-192): (H, n_robots, q_dim) -> (H, n, n), (H, n, n, 2)
+    paths = torch.from_numpy(g["paths"]).to(dev)
+    coll, pts = robot.check_rr_collisions(paths)
+    assert np.array_equal(coll.cpu().numpy(), g["rr_paths"])
+    assert np.array_equal(np.nan_to_num(pts.cpu().numpy()), np.nan_to_num(g["mid_paths"]))
+    assert torch.nonzero(coll.int()).shape[1] == 3
+    # trajectories: [B,H,4] -> [B,H]
+    g9 = np.load(os.path.join(GOLDEN, "g9_post.npz"))
+    ct = task.compute_collision(torch.from_numpy(g9["trajs"]).to(dev))
+    assert np.array_equal(ct.cpu().numpy(), g["coll_trajs"])
+    # positions / velocities (cbs.py:178,486)
+    x = torch.from_numpy(g9["trajs"]).to(dev)
+    assert torch.equal(robot.get_position(x), x[..., :2]) and torch.equal(robot.get_velocity(x), x[..., 2:4])
+    assert robot.radius == 0.05 and robot.q_dim == 2
+    # --- the planner call surface of the CBS / PP root loops (cbs.py:316-336, prioritized_planning.py:141-180)
+    path_bl, ix_best = [], []
+    for i, p in enumerate(planners):
+        out = p(torch.from_numpy(starts[i]), torch.from_numpy(goals[i]), constraints_l=[])
+        assert out.trajs_final_free_idxs.ndim == 2 and out.trajs_final_free_idxs.shape[0] > 0
+        ix_best.append(out.idx_best_traj)
+        path_bl.append(out.trajs_final)
+        for ix_traj in out.trajs_final_free_idxs:                     # cbs.py:448 iterates the free indices
+            assert out.trajs_final[ix_traj].shape == (1, H, D)
+    best = [path_bl[i][ix].squeeze(0) for i, ix in enumerate(ix_best)]                      # cbs.py:171-172
+    pos_b = torch.stack([robot.get_position(b) for b in best]).permute(1, 0, 2)             # cbs.py:189-191
+    coll, pts = robot.check_rr_collisions(pos_b)
+    assert coll.shape == (H, 3, 3) and pts.shape == (H, 3, 3, 2)
+    # --- MPDEnsemble exposes the same surface
+    kw = _mpd_kwargs(n_samples=4)
+    for k in ("model_id", "model_state_dict"):
+        kw.pop(k)
+    pe = MPDEnsemble(model_ids=("EnvEmptyNoWait2D-RobotPlanarDisk",) * 2,
+                     transforms={0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])},
+                     start_state_pos=torch.tensor([-0.7, 0.3]), goal_state_pos=torch.tensor([2.6, -0.4]),
+                     model_state_dicts=[synth.synth_unet_state_dict(0)] * 2, **kw)
+    c, _ = pe.robot.check_rr_collisions(torch.tensor([[-0.7, 0.3], [-0.62, 0.3]], device=dev))
+    assert c.tolist() == [[False, True], [True, False]]
+    assert not pe.task.compute_collision(torch.tensor([[-0.7, 0.3], [2.6, -0.4]], device=dev)).any()
+
+
+def test_device_side_sharing_of_models_and_maps():
+    """N+1 planner objects (the reference builds one per agent + a reference one,
+    inference_multi_agent.py:186-237) hold ONE packed weight blob + ONE time table (sized to the schedule) and ONE SDF
+    texture per map on the device."""
+    import time
+    from mmd_amd import guides, temporal_unet
+    from mmd_amd.planners import MPD
+    sd = synth.synth_unet_state_dict(3)                               # weights no other test uses
+    starts, goals = synth.start_goal_circle(8, 0.8)
+    created0, tex0 = temporal_unet.N_DEVICE_MODELS_CREATED, guides.N_TEXTURE_UPLOADS
+    t0 = time.perf_counter()
+    planners = [MPD(start_state_pos=torch.from_numpy(starts[i]), goal_state_pos=torch.from_numpy(goals[i]),
+                    **_mpd_kwargs(model_id="EnvDropRegion2D-RobotPlanarDisk", model_state_dict=sd, n_samples=4))
+                for i in range(8)]
+    outs = [p(torch.from_numpy(starts[i]), torch.from_numpy(goals[i])) for i, p in enumerate(planners)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(torch.isfinite(o.trajs_iters).all() for o in outs)
+    assert temporal_unet.N_DEVICE_MODELS_CREATED - created0 == 1, "8 planners must share one mmd_unet_create"
+    assert guides.N_TEXTURE_UPLOADS - tex0 <= 1, "8 planners must share one SDF texture upload"
+    handles = {p.model.model.handle(25).value for p in planners}
+    assert len(handles) == 1
+    assert len({p.guide._grids.data_ptr() for p in planners}) == 1
+    print(f"8 MPD constructors + first calls: {dt * 1e3:.0f} ms")
+    parity_log.record("device_side_sharing", "8_planners_construct_and_call_ms", None, dt * 1e3)
+    del planners, outs
+
+
+def test_torch_ops_match_the_ctypes_path():
+    """torch.ops.mmd_amd.{unet_forward, guide_steps, p_sample_loop, ddim_sample} (torch.library custom ops over the same
+    C ABI) are bit-identical to the ctypes host mirror, run on the current stream, and capture into a HIP graph."""
+    import gpu_common
+    from mmd_amd import ops
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    T, B, R = 25, 8, 2
+    model = gpu_common.hip_model(T)
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    guide = gpu_common.hip_guide("EnvHighways2D", [[cases.soft_group(paths, r)] for r in range(R)], n_robots=R)
+    hc = {0: torch.stack([cases.hard_conds_for(starts[r], goals[r])[0] for r in range(R)]),
+          H - 1: torch.stack([cases.hard_conds_for(starts[r], goals[r])[H - 1] for r in range(R)])}
+    hard = torch.stack([hc[0], hc[H - 1]], dim=1).cuda().contiguous()
+    tm, tu, tg = ops.register(model), ops.register(model.model), ops.register(guide)
+    x = torch.from_numpy(synth.synth_noise(120, (R * B, H, D))).cuda()
+    assert torch.equal(torch.ops.mmd_amd.unet_forward(x, 7, T, tu), model.model(x, 7))
+    y1, y2 = x.clone(), x.clone()
+    torch.ops.mmd_amd.guide_steps(y1, hard, 3, 5, tg)
+    guide.guide_steps(y2, hard, 3, 5)
+    assert torch.equal(y1, y2)
+    ref = model.run_inference(None, hc, n_samples=B, n_robots=R, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn,
+                              guide=guide, n_guide_steps=20, t_start_guide=13, noise_std_extra_schedule_fn=lambda t: 0.5,
+                              n_diffusion_steps_without_noise=1, seed=77)
+    xo = torch.empty((R * B, H, D), device="cuda")
+    chain = torch.ops.mmd_amd.p_sample_loop(xo, hard, 3, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
+    assert torch.equal(chain, ref) and torch.equal(xo, ref[-1])
+    refd, chd = model.ddim_sample((R * B, H, D), hc, n_diffusion_steps=T, return_chain=True, guide=guide,
+                                  t_start_guide=13, n_robots=R, seed=78)
+    xd = torch.empty((R * B, H, D), device="cuda")
+    chain_d = torch.ops.mmd_amd.ddim_sample(xd, hard, 3, tm, tg, R, T, True, 78, 13, 0, True)
+    assert torch.equal(chain_d, chd.transpose(0, 1)) and torch.equal(xd, refd)
+    # a side stream: the op runs on torch's current stream
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        xs = torch.empty((R * B, H, D), device="cuda")
+        cs = torch.ops.mmd_amd.p_sample_loop(xs, hard, 3, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(cs, ref)
+    # stream capture: the whole 26-step guided loop as one hipGraph, replayed
+    xg = torch.empty((R * B, H, D), device="cuda")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cg = torch.ops.mmd_amd.p_sample_loop(xg, hard, 3, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cg, ref) and torch.equal(xg, ref[-1])

@@ -107,18 +107,34 @@ def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
         _lib.load()
 
 
-def test_postprocess_vs_reference_g9():
-    """SURVEY §8f-2 pinned: collision / free split, smoothness, path length and SavGol smoothing against the reference's
-    PlanningTask.get_trajs_collision_and_free / metrics / smooth_trajs on a Highways batch (tests/golden/g9_post.npz)."""
-    from mmd_amd.postprocess import (compute_path_length, compute_smoothness, get_trajs_collision_and_free,
-                                     smooth_trajs)
-    g = np.load(os.path.join(GOLDEN, "g9_post.npz"))
-    trajs = torch.from_numpy(g["trajs"])
-    coll, coll_idxs, free, free_idxs, wp = get_trajs_collision_and_free(trajs, "EnvHighways2D")
-    assert free_idxs.reshape(-1).tolist() == g["free_idxs"].tolist()
-    assert sorted(coll_idxs.reshape(-1).tolist()) == sorted(g["coll_idxs"].tolist())
-    assert np.array_equal(wp.numpy(), g["waypoint_collisions"])
-    assert free.shape[0] == len(g["free_idxs"]) and coll.shape[0] == len(g["coll_idxs"])
-    assert np.allclose(compute_smoothness(trajs).numpy(), g["smoothness"], rtol=1e-6, atol=1e-6)
-    assert np.allclose(compute_path_length(trajs).numpy(), g["path_length"], rtol=1e-6, atol=1e-6)
-    assert np.allclose(smooth_trajs(trajs).numpy(), g["smoothed"], rtol=1e-6, atol=1e-7)
+def test_torch_library_ops_are_registered_with_fake_impls():
+    """torch.ops.mmd_amd.* exist with the documented schemas and meta (fake) implementations (no GPU needed)."""
+    import mmd_amd.ops  # noqa: F401
+    for name in ("unet_forward", "guide_steps", "p_sample_loop", "ddim_sample"):
+        assert hasattr(torch.ops.mmd_amd, name)
+    schema = str(torch.ops.mmd_amd.p_sample_loop.default._schema)
+    assert "Tensor(a0!) x" in schema and "Tensor? step_noise" in schema and "-> Tensor" in schema
+    x, h = torch.empty(8, H, 4, device="meta"), torch.empty(1, 2, 4, device="meta")
+    assert torch.ops.mmd_amd.p_sample_loop(x, h, 3, 0, 0, 1, 25, 1, False, None, 0, 20, 13, 0.5, 0, True).shape == (27, 8, H, 4)
+    assert torch.ops.mmd_amd.ddim_sample(x, h, 3, 0, 0, 1, 100, False, 0, 50, 0, True).shape == (22, 8, H, 4)
+    assert torch.ops.mmd_amd.unet_forward(x, 3, 25, 0).shape == x.shape
+    with pytest.raises(RuntimeError):                       # CPU tensors: no kernel is registered for them
+        torch.ops.mmd_amd.unet_forward(torch.zeros(1, H, 4), 0, 25, 0)
+
+
+def test_philox_stream_ids_are_process_wide():
+    """Sampling calls that draw their own noise take consecutive stream ids from ONE process-wide counter (the way every
+    reference call advances torch's global RNG): two planners with the same base seed never reuse a stream."""
+    from mmd_amd.diffusion_model import next_stream_seed
+    a, b, c = next_stream_seed(18), next_stream_seed(18), next_stream_seed(19)
+    assert b == a + 1 and c != a and c != b and (a >> 24) == 18 and (c >> 24) == 19
+
+
+def test_bench_sharding_modes():
+    """bench.py --scaling strong shards the metric's own 32-robot instance; weak keeps 32 robots per GPU; the Philox key
+    base of a rank is its first global trajectory."""
+    from mmd_amd.multi_robot import shard_range
+    for world in (1, 2, 4, 8):
+        r0, n_local = shard_range(32, world - 1, world)
+        assert n_local == 32 // world and r0 + n_local == 32
+        assert r0 * 64 == (32 - n_local) * 64                # traj_index_base of the last rank

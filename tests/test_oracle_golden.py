@@ -167,3 +167,19 @@ def test_g10_multi_agent_layer():
     base = int(O.check_rr_collisions(paths[1:].permute(1, 0, 2))[0].sum())
     assert (base + 2 * cnt).tolist() == g["conflict_totals"].tolist()
     assert int(cnt.max()) > 0
+
+
+def test_postprocess_oracle_vs_reference_g9():
+    """SURVEY §8f-2 pinned: the oracle's collision / free split, smoothness, path length and SavGol smoothing against the
+    reference's PlanningTask.get_trajs_collision_and_free / metrics / smooth_trajs on a Highways batch (g9_post.npz)."""
+    g = np.load(os.path.join(GOLDEN, "g9_post.npz"))
+    trajs = torch.from_numpy(g["trajs"])
+    gp = cases.guide_params("EnvHighways2D")
+    coll, coll_idxs, free, free_idxs, wp = O.get_trajs_collision_and_free(trajs, gp)
+    assert free_idxs.reshape(-1).tolist() == g["free_idxs"].tolist()
+    assert sorted(coll_idxs.reshape(-1).tolist()) == sorted(g["coll_idxs"].tolist())
+    assert np.array_equal(wp.numpy(), g["waypoint_collisions"])
+    assert free.shape[0] == len(g["free_idxs"]) and coll.shape[0] == len(g["coll_idxs"])
+    assert np.allclose(O.compute_smoothness(trajs).numpy(), g["smoothness"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(O.compute_path_length(trajs).numpy(), g["path_length"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(O.smooth_trajs(trajs).numpy(), g["smoothed"], rtol=1e-6, atol=1e-7)

@@ -8,7 +8,7 @@ rocprofv3 -L 2>/dev/null | grep -i -E "MFMA|GRBM_GUI_ACTIVE|SQ_BUSY_CYCLES|SQ_WA
 for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $set | tr ' ' '_')
   rm -rf $OUT/pmcx
-  rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/pmcx -o pmc -- python tools/prof_layers.py 2048 > /dev/null 2> $OUT/pmcx.err
+  rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/pmcx -o pmc -- python tools/unet_forward_loop.py 2048 > /dev/null 2> $OUT/pmcx.err
   f=$(find $OUT/pmcx -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then for c in $set; do python tools/pmc_summary.py "$f" $c | head -8; done | tee $OUT/pmc_$tag.txt; else tail -3 $OUT/pmcx.err; fi
 done

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --step
 python tools/rocpd_summary.py $OUT/prof/bench_results.db > $OUT/kernel_stats.md && head -30 $OUT/kernel_stats.md
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace -f csv -d $OUT/pmc_$c -o pmc -- python tools/prof_layers.py 2048 > /dev/null 2> $OUT/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace -f csv -d $OUT/pmc_$c -o pmc -- python tools/unet_forward_loop.py 2048 > /dev/null 2> $OUT/pmc_$c.err
   f=$(find $OUT/pmc_$c -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py "$f" $c | tee $OUT/pmc_$c.txt
 done

@@ -16,6 +16,7 @@ Fixtures:
   g8_ensemble.npz      2-tile DiffusionsEnsemble.run_inference
   g10_multi_agent.npz  robot-robot collisions of a best-path set + per-sample conflict totals (least_collisions scan)
   g9_post.npz          post-sampling selection: collision/free split, smoothness, path length, SavGol smoothing
+  g12_boundary.npz     outer-boundary contract: check_rr_collisions / compute_collision on the shapes CBS / PP pass
 """
 import os
 import sys
@@ -36,6 +37,9 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 MINS, MAXS = synth.NORM_MINS, synth.NORM_MAXS
 H, D = 64, 4
 RADIUS_SOFT = 0.05 * 2.4        # mmd_params.py:52
+# number of independent 1e-6 perturbation draws whose max is stored as `sens` (the amplification of the chaotic guided
+# loop is heavy-tailed: the more draws, the better the estimate of how far two fp32 implementations can drift apart)
+N_SENS_DRAWS = int(os.environ.get("MMD_SENS_DRAWS", "24"))
 
 
 def normalize(x):
@@ -193,11 +197,13 @@ def rel_l2(a, b):
 def save_case(fname, meta, rows, *args, **kw):
     chain = run_ref_inference(*args, **kw)
     sens = np.zeros(len(rows))
-    for ps in range(1, 7):          # the amplification is itself random: take the max over 6 perturbation draws
+    draws = []
+    for ps in range(1, N_SENS_DRAWS + 1):   # the amplification is itself random: max over N_SENS_DRAWS perturbation draws
         pert = run_ref_inference(*args, perturb=1e-6, perturb_seed=ps, **kw)
-        sens = np.maximum(sens, [rel_l2(pert[r], chain[r]) for r in rows])
+        draws.append([rel_l2(pert[r], chain[r]) for r in rows])
+        sens = np.maximum(sens, draws[-1])
     np.savez_compressed(os.path.join(OUT, fname), rows=np.array(rows), chain_rows=chain[rows], sens=sens,
-                        meta=np.array(meta))
+                        sens_draws=np.array(draws), meta=np.array(meta))
     print("  ", fname, "final-row sensitivity to a 1e-6 relative UNet perturbation:", f"{sens[-1]:.2e}", flush=True)
 
 
@@ -273,7 +279,7 @@ def g7():
 
     chain = run()
     sens = np.zeros(5)
-    for ps in range(1, 7):
+    for ps in range(1, N_SENS_DRAWS + 1):
         pert = run(1e-6, ps)
         sens = np.maximum(sens, [rel_l2(pert[r], chain[r]) for r in range(5)])
     print("   g7 sensitivity per row:", sens)
@@ -282,7 +288,9 @@ def g7():
 
 def g8():
     """2-tile DiffusionsEnsemble.p_sample_loop (diffusion_ensemble.py:55-106): tiles at x-offsets 0 and 2, the end of
-    tile 0 cross-conditioned onto the start of tile 1 (sample_functions.py:17-31)."""
+    tile 0 cross-conditioned onto the start of tile 1 (sample_functions.py:17-31).  Stores every chain row of both tiles
+    and, like g6, the reference's own sensitivity `sens` (per row, max over 6 draws) to a relative 1e-6 perturbation of
+    the UNet output."""
     from mmd.models.diffusion_models.diffusion_ensemble import DiffusionsEnsemble
     T, B = 25, 4
     sd = synth.synth_unet_state_dict(0)
@@ -298,7 +306,6 @@ def g8():
     goal = np.array([0.6, -0.4], np.float32)          # in tile 1's local frame
     s = hard_conds_for(start, start)[0]
     g = hard_conds_for(goal, goal)[0]
-    hard_conds = {0: {0: s.repeat(B, 1)}, 1: {H - 1: g.repeat(B, 1)}}
     cross_conds = {(0, 1): (H - 1, 0)}
     # one soft constraint point per tile so that the guides differ
     cons = {0: (np.array([[0.2, 0.1]], np.float32), np.array([[30, 36]]), np.array([RADIUS_SOFT], np.float32)),
@@ -310,14 +317,34 @@ def g8():
     draws = list(x0) + [steps[k, m] for k in range(T + 1) for m in (0, 1)]
     sample_kwargs = {m: dict(guide=guides[m], n_guide_steps=20, t_start_guide=ceil(0.5 * T),
                              noise_std_extra_schedule_fn=lambda x: 0.5) for m in (0, 1)}
-    with quiet(), injected_noise(draws) as q:
-        x, chains = ens.p_sample_loop((B, H, D), hard_conds, cross_conds, n_diffusion_steps=T, return_chain=True,
-                                      sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=1,
-                                      sample_kwargs=sample_kwargs)
-        assert len(q) == 0
-    np.savez_compressed(os.path.join(OUT, "g8_ensemble.npz"), final0=x[0].numpy(), final1=x[1].numpy(),
-                        chain0_mid=chains[0][:, T // 2 + 1].numpy(), chain1_mid=chains[1][:, T // 2 + 1].numpy(),
-                        meta=np.array([T, B, 26, 27, 28]))
+
+    def run(perturb=0.0, ps=0):
+        handles = []
+        if perturb:
+            gen = torch.Generator().manual_seed(ps)
+            for m in (0, 1):
+                handles.append(models[m].model.register_forward_hook(
+                    lambda mod, inp, out: out * (1 + perturb * torch.empty(out.shape).normal_(generator=gen))))
+        hard_conds = {0: {0: s.repeat(B, 1)}, 1: {H - 1: g.repeat(B, 1)}}
+        with quiet(), injected_noise(draws) as q:
+            x, chains = ens.p_sample_loop((B, H, D), hard_conds, cross_conds, n_diffusion_steps=T, return_chain=True,
+                                          sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=1,
+                                          sample_kwargs=sample_kwargs)
+            assert len(q) == 0
+        for h in handles:
+            h.remove()
+        return {m: chains[m].transpose(0, 1).numpy().copy() for m in (0, 1)}     # [T+2, B, H, D]
+
+    chains = run()
+    sens = {m: np.zeros(T + 2) for m in (0, 1)}
+    for ps in range(1, N_SENS_DRAWS + 1):
+        pert = run(1e-6, ps)
+        for m in (0, 1):
+            sens[m] = np.maximum(sens[m], [rel_l2(pert[m][r], chains[m][r]) for r in range(T + 2)])
+    print("   g8 final-row sensitivity:", sens[0][-1], sens[1][-1])
+    np.savez_compressed(os.path.join(OUT, "g8_ensemble.npz"), final0=chains[0][-1], final1=chains[1][-1],
+                        chain0_mid=chains[0][T // 2 + 1], chain1_mid=chains[1][T // 2 + 1], chain0=chains[0],
+                        chain1=chains[1], sens0=sens[0], sens1=sens[1], meta=np.array([T, B, 26, 27, 28]))
 
 
 def g9():
@@ -419,11 +446,45 @@ def g11():
     print("   g11 highways: sens", sens)
 
 
+def g12():
+    """Outer-boundary contract (what CBS / PP call on planner.robot / planner.task): RobotPlanarDisk.check_rr_collisions
+    (robot_planar_disk.py:173-203) on [N,2] and [H,N,2] inputs and PlanningTask.compute_collision (tasks.py:141-234) on
+    [D], [N,2] and [B,H,4] inputs of the Highways task (default margin = collision margin + cutoff), plus the
+    compute_variance_waypoints metric of the g9 batch."""
+    from torch_robotics.trajectory.metrics import compute_variance_waypoints
+    with quiet():
+        env, robot, task = make_task("EnvHighways2D")
+    rng = np.random.Generator(np.random.PCG64(41))
+    pts = torch.from_numpy(rng.uniform(-1.12, 1.12, size=(96, 2)).astype(np.float32))
+    starts, goals = synth.start_goal_circle(10, 0.45)
+    starts_t = torch.from_numpy(starts)
+    close = starts_t.clone()
+    close[1] = close[0] + torch.tensor([0.08, 0.0])                   # two robots closer than 2.1 r
+    g9 = np.load(os.path.join(OUT, "g9_post.npz"))
+    trajs = torch.from_numpy(g9["trajs"])
+    paths = trajs[:6, :, :2].permute(1, 0, 2).contiguous()             # [H, 6, 2]
+    paths[:, 1] = paths[:, 0] + 0.07                                  # robots 0 and 1 collide at every step
+    c_pts = task.compute_collision(pts)
+    c_one = task.compute_collision(pts[5])
+    c_traj = task.compute_collision(trajs)
+    rr_starts, mid_starts = robot.check_rr_collisions(starts_t)
+    rr_close, mid_close = robot.check_rr_collisions(close)
+    rr_paths, mid_paths = robot.check_rr_collisions(paths)
+    out = {"points": pts.numpy(), "coll_points": c_pts.numpy(), "coll_one": c_one.numpy(), "coll_trajs": c_traj.numpy(),
+           "starts": starts, "close": close.numpy(), "paths": paths.numpy(),
+           "rr_starts": rr_starts.numpy(), "rr_close": rr_close.numpy(), "mid_close": mid_close.numpy(),
+           "rr_paths": rr_paths.numpy(), "mid_paths": mid_paths.numpy(),
+           "variance_waypoints": np.float64(compute_variance_waypoints(trajs, robot))}
+    print("   g12: colliding points", int(c_pts.sum()), "of", pts.shape[0], "shapes", tuple(c_pts.shape), tuple(c_one.shape),
+          tuple(c_traj.shape), "rr pairs", int(rr_close.sum()), int(rr_paths.sum()))
+    np.savez_compressed(os.path.join(OUT, "g12_boundary.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}[name]()
     print("done")

@@ -1,0 +1,30 @@
+"""N back-to-back TemporalUnet forwards of n trajectories (the body of the PMC / A-B passes).  MMD_AMD_LIB selects the
+.so.  Usage: python tools/unet_forward_loop.py [n_traj ...]   -> per n: mean unet_kernel time by HIP events."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mmd_amd import _lib, synth
+if os.environ.get("MMD_AMD_LIB"):
+    _lib.LIB_PATH = os.environ["MMD_AMD_LIB"]
+from mmd_amd.temporal_unet import TemporalUnet
+
+lib = _lib.load()
+unet = TemporalUnet()
+unet.load_state_dict(synth.synth_unet_state_dict(0))
+reps = int(os.environ.get("REPS", "30"))
+for n in [int(a) for a in sys.argv[1:]] or [2048]:
+    x = torch.randn(n, 64, 4, device="cuda")
+    for _ in range(3):
+        unet(x, 50)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        unet(x, 50)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    fl, mf = lib.mmd_unet_flops_per_trajectory() * n, lib.mmd_unet_mfma_flops_per_trajectory() * n
+    print(f"n={n:5d}: unet forward {us:8.1f} us  algorithmic {fl / us / 1e6:6.1f} TF  issued {mf / us / 1e6:6.1f} TF "
+          f"({mf / us / 1e6 / 157.3:.3f} of fp32 MFMA peak)  [{os.environ.get('MMD_AMD_LIB', 'default lib')}]", flush=True)
