@@ -497,6 +497,116 @@ __device__ __forceinline__ void quad_to_stage(const f32x4 (&q)[8], float* dst, i
       for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR + nt * 16] = q[o * 2 + nt][r];
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// V-form slabs (the L = 16 stages: downs.2 + mid blocks, ups.0).  At L = 16 the four waves of a workgroup share ONE M tile
+// (16 rows = 4 samples x 4 quads) and differ only in their channel slice, so with the input transform V = B^T d inside
+// the K loop every wave repeated the same 26 VALU ops per k-step.  But at L = 16 a lane of the C/D fragment holds ALL 16
+// positions of one (sample, channel): the producing epilogue computes the transform of its four quads in registers
+// (zero padding included, no neighbour exchange) ONCE and stores the conv input already transformed,
+//     V[channel][row = 4 * sample + quad][8 positions],  channel stride VCS = 16 * 8 + 4 floats.
+// The K loop then needs no VALU at all: the A operands of a k-step (4 channels x 16 rows x 8 positions) are two
+// ds_read_b128 per lane (instead of 8 ds_read_b32 + 26 VALU), bank-conflict free for reads (lane = (row i, channel k):
+// dword address 132 k + 8 i, the b128 lane groups of MI355X_MICROARCH.md section LDS hit 16 distinct 4-bank sets) and
+// for the epilogue's ds_write_b128 (8 consecutive channels of one row: banks 4 c .. 4 c + 3).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int VROW = 8;                    // floats per (channel, row)
+constexpr int VCS = 16 * VROW + 4;         // channel stride in floats
+constexpr int VSLAB_FLOATS = 128 * VCS;    // the largest V slab: 128 channels (67.6 KB)
+
+// x(o, r) = position 4 r + o of the lane's (sample, channel); vb = slab + channel * VCS + 4 * sample * VROW
+template <class GET>
+__device__ __forceinline__ void vform_store(float* vb, GET x) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float d[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pos = 4 * r - 2 + j;                                   // the conv's zero padding outside [0, 16)
+      d[j] = (pos < 0 || pos > 15) ? 0.f : x(pos & 3, pos >> 2);
+    }
+    w4_transform(v, d);
+    *reinterpret_cast<float4*>(vb + r * VROW) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(vb + r * VROW + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+// two-n-tile quad tile (wave = 32-channel slice `slice`) -> V slab
+__device__ __forceinline__ void quad2_to_vform(const f32x4 (&q)[8], float* vslab, int slice, int lane) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+    vform_store(vslab + (slice * 32 + nt * 16 + (lane & 15)) * VCS + (lane >> 4) * 4 * VROW,
+                [&](int o, int r) { return q[o * 2 + nt][r]; });
+}
+// one-n-tile quad tile (wave = 16-channel n-tile `ntile`) -> V slab
+__device__ __forceinline__ void quad1_to_vform(const f32x4 (&q)[4], float* vslab, int ntile, int lane) {
+  vform_store(vslab + (ntile * 16 + (lane & 15)) * VCS + (lane >> 4) * 4 * VROW, [&](int o, int r) { return q[o][r]; });
+}
+
+// One k-step on a V slab: 8 * NT MFMAs m[p * NT + nt] += V_p x U_p[nt].  RESW (NT = 1): the stage's 1x1 residual conv
+// rides along IN THE WINOGRAD DOMAIN -- a 1x1 conv is a k = 5 conv with only the centre tap, whose transformed kernel
+// G g = w * (0, -2/9, -2/9, 2/45, 2/45, 8/45, 8/45, 0) is zero at positions 0 and 7: six more MFMAs on the operands already
+// in registers, weights (w * -2/9, w * 2/45, w * 8/45) in the last float4 of the fragment.
+template <int NT, bool RESW, bool ZERO>
+__device__ __forceinline__ void w4v_step(f32x4 (&m)[8 * NT], f32x4 (&rm)[6 * NT], const float4 (&a)[2],
+                                         const BQ<2 * NT + (RESW ? 1 : 0)>& b) {
+  static_assert(!RESW || NT == 1, "the Winograd-domain residual rides with one n-tile per wave");
+  if constexpr (ZERO) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8 * NT; ++i) m[i] = z;
+    if constexpr (RESW) {
+#pragma unroll
+      for (int i = 0; i < 6 * NT; ++i) rm[i] = z;
+    }
+  }
+  const float v[8] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w};
+  w4_mfma_pos<NT, RESW, ZERO>(m, v, b);
+  if constexpr (RESW) {
+    const float4 wr = b.q[2 * NT];
+    rm[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], wr.x, rm[0], 0, 0, 0);
+    rm[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], wr.x, rm[1], 0, 0, 0);
+    rm[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[3], wr.y, rm[2], 0, 0, 0);
+    rm[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4], wr.y, rm[3], 0, 0, 0);
+    rm[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[5], wr.z, rm[4], 0, 0, 0);
+    rm[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[6], wr.z, rm[5], 0, 0, 0);
+  }
+}
+
+// m += conv over CP channels of a V slab; abase = the lane's float offset of (channel lane >> 4, row lane & 15);
+// b = ring pre-loaded with the first W4_RD k-steps of wp.  A operands are double-buffered (the two ds_read_b128 of k-step
+// j + 1 are issued before the MFMAs of k-step j); past the last k-step they read the slab's slack and are unused.
+template <int CP, int NT, bool RESW, bool FRESH>
+__device__ __forceinline__ void w4v_taps(f32x4 (&m)[8 * NT], f32x4 (&rm)[6 * NT], const float* vslab, int abase,
+                                         const float* __restrict__ wp, BQ<2 * NT + (RESW ? 1 : 0)> (&b)[W4_RD]) {
+  constexpr int KS = CP / 4, RD = W4_RD, NQ = 2 * NT + (RESW ? 1 : 0), KSTRIDE = 64 * 4 * NQ;
+  static_assert(KS % RD == 0, "k-steps are unrolled by the ring depth");
+  const float* p = wp;
+  const float4* s = reinterpret_cast<const float4*>(vslab + abase);   // one k-step = 4 channels = VCS float4 further
+  float4 a[2][2];
+  a[0][0] = s[0]; a[0][1] = s[1];
+  auto iter = [&](auto first) {
+    p += RD * KSTRIDE;
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+      a[(j + 1) & 1][0] = s[(j + 1) * VCS];
+      a[(j + 1) & 1][1] = s[(j + 1) * VCS + 1];
+      MMD_PIN_LOADS();
+      if (decltype(first)::value && j == 0) w4v_step<NT, RESW, true>(m, rm, a[0], b[0]);
+      else w4v_step<NT, RESW, false>(m, rm, a[j & 1], b[j]);
+      b[j] = load_bq<NQ>(p + j * KSTRIDE);
+      MMD_PIN_LOADS();
+    }
+    s += RD * VCS;
+  };
+  if constexpr (FRESH) {
+    iter(std::true_type{});
+#pragma unroll 1
+    for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
+  } else {
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += RD) iter(std::false_type{});
+  }
+}
+
 // A down-path stage (L = 32 / C = 64: downs.1; L = 16 / C = 128: downs.2 + mid blocks) in F(4,5) form.  Same slabs as
 // the other stages; activations in registers as quad tiles.  The 4 * L / 4 output quads are L / 16 M tiles of 16 rows; a
 // wave owns one M tile x 32 channels (two n-tiles).
@@ -506,10 +616,13 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   static_assert((CF::L == 16 || CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 &&
                     CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP,
                 "down-path stage with 4 waves = (L / 16 M tiles) x (CM / 32 channel slices)");
-  float* hslab = lds + CF::XSLAB;
+  // L = 16 (downs.2 + mid blocks): every conv after the first reads a V-form H slab that ALIASES the stage's d-form x slab
+  constexpr bool VH = CF::L == 16;
+  float* hslab = VH ? lds : lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, WNQ = CF::CM / 32;                     // quads per sample, channel slices
   const int mt = wave / WNQ, wnq = wave % WNQ;
+  const int vbase = (lane >> 4) * VCS + (lane & 15) * VROW;             // V slab: (channel lane >> 4, row lane & 15)
   // A fragment: row i = lane & 15 of M tile mt = (sample, quad), k = lane >> 4
   const int ai = mt * 16 + (lane & 15);
   const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
@@ -526,15 +639,25 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   w4_ring_load<5>(ring5, w0);
   if constexpr (FIRST)     // the network input, channels-last [n, 64, 4] in HBM (channels 4..15 of the slab are zero)
     stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
-  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
+  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
   TR(trb + 0);
 
   f32x4 m[16], res[8];
   auto conv_h = [&](const float4* w, const float4* next) {
-    w4_taps<CF::CM, CF::HSTR, 2, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
+    if constexpr (VH) {
+      f32x4 nores[12];
+      w4v_taps<CF::CM, 2, false, true>(m, nores, hslab, vbase, wlane(w, CF::CM), ring);
+    } else {
+      w4_taps<CF::CM, CF::HSTR, 2, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
+    }
     if (next) w4_ring_load<4>(ring, wlane(next, CF::CM));
     w4_out(acc, m);
+  };
+  // acc -> the H slab the next conv reads (V form at L = 16, row form otherwise)
+  auto to_h = [&]() {
+    if constexpr (VH) quad2_to_vform(acc, hslab, wnq, lane);
+    else quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
   };
   // GroupNorm + Mish of acc, then + the time bias tb (conv A) or + the residual tile (conv B, tb == nullptr)
   auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
@@ -562,7 +685,8 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   w4_out(acc, m);
   TR(trb + 2);
   gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
-  quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+  if constexpr (VH) __syncthreads();                         // conv A is done reading the x slab the V-form H slab aliases
+  to_h();
   __syncthreads();
   TR(trb + 4);
   conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
@@ -581,14 +705,14 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     for (int i = 0; i < 8; ++i) res[i] = acc[i];
     __syncthreads();                                         // the previous conv is done reading the H slab
     TR(trb + 8 + k * 8 + 0);
-    quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    to_h();
     __syncthreads();
     TR(trb + 8 + k * 8 + 1);
     conv_h(R.wa, R.wb);
     TR(trb + 8 + k * 8 + 2);
     gn(R.ba, R.ga, R.bea, R.tb);
     __syncthreads();
-    quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    to_h();
     __syncthreads();
     TR(trb + 8 + k * 8 + 5);
     conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
@@ -602,6 +726,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
 
   // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32 ===================
   if constexpr (CF::TAIL == TAIL_DOWN) {
+    static_assert(!VH, "the strided tail conv reads a row-form H slab");
     __syncthreads();
     quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
     __syncthreads();
@@ -666,12 +791,27 @@ __device__ __forceinline__ void quad1_to_stage(const f32x4 (&q)[4], float* dst, 
     for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR] = q[o][r];
 }
 
+// residual 1x1 conv accumulated in the Winograd domain (positions 1..6) -> its four outputs, + bias
+__device__ __forceinline__ void w4n1_res_out(f32x4 (&q)[4], const f32x4 (&rm)[6], float bias) {
+  const f32x4 s1 = rm[0] + rm[1], t1 = rm[0] - rm[1];
+  const f32x4 s2 = rm[2] + rm[3], t2 = rm[2] - rm[3];
+  const f32x4 s3 = rm[4] + rm[5], t3 = rm[4] - rm[5];
+  q[0] = (s1 + bias) + (s2 + s3);
+  q[1] = (t1 + bias) + (2.f * t2 + 0.5f * t3);
+  q[2] = (s1 + bias) + (4.f * s2 + 0.25f * s3);
+  q[3] = (t1 + bias) + (8.f * t2 + 0.125f * t3);
+}
+
 template <class CF, int SKIP_L, int SKIP_CM>
 __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int n0, int lane, int wave,
                                                const f32x4 (&skip)[8], f32x16 (&tout)[2][CF::MT_W], int trb) {
   static_assert((CF::L == 16 || CF::L == 32) && CF::CM * CF::L == 1024 && CF::C1 == CF::C0 && CF::RES0 == RES_CONV &&
                     CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "up-path stage with 4 waves = (L / 16 M tiles) x (CM / 16 n-tiles)");
-  float* hslab = lds + CF::XSLAB;
+  // L = 16 (ups.0): conv inputs are V-form slabs at the start of the LDS (the two chunks of cat(x, skip) one after the
+  // other, then H), all aliasing each other and the row-form H slab of the tail conv; barriers separate the phases
+  constexpr bool VH = CF::L == 16;
+  static_assert(!VH || (CF::C0P == 128 && SKIP_L == 16 && SKIP_CM == 128), "V-form ups.0: 128-channel chunks from the L = 16 down stage");
+  float* hslab = VH ? lds : lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, NTQ = CF::CM / 16;
   const int mt = wave / NTQ, nq = wave % NTQ;
@@ -679,6 +819,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
   const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
   const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
+  const int vbase = (lane >> 4) * VCS + (lane & 15) * VROW;
   const int col = nq * 16 + (lane & 15);
   // both chunks of conv A carry the 1x1 residual conv (3 float4 per lane and k-step), all other convs 2
   BQ<3> ring3[W4_RD];
@@ -690,30 +831,49 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
   };
   w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
-  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
+  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
   TR(trb + 0);
 
   f32x4 m[8], acc[4], res[4];
   auto conv_h = [&](const float4* w, const float4* next) {
-    w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
+    if constexpr (VH) {
+      f32x4 nores[6];
+      w4v_taps<CF::CM, 1, false, true>(m, nores, hslab, vbase, wlane(w, CF::CM), ring);
+    } else {
+      w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
+    }
     if (next) w4_ring_load<2>(ring, wlane(next, CF::CM));
     w4n1_out(acc, m);
   };
-  auto to_h = [&]() { quad1_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane); };
+  auto to_h = [&]() {
+    if constexpr (VH) quad1_to_vform(acc, hslab, nq, lane);
+    else quad1_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+  };
 
   // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
-  {
-    const float br = a.br[col];
+  if constexpr (VH) {
+    f32x4 rm[6];
+    w4v_taps<CF::C0P, 1, true, true>(m, rm, xslab, vbase, wlane3(a.r0.wa, CF::C0P), ring3);
+    w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
+    __syncthreads();                                          // chunk 0 has been consumed by every wave
+    quad2_to_vform(skip, xslab, wave % (SKIP_CM / 32), lane);
+    __syncthreads();
+    w4v_taps<CF::C1P, 1, true, false>(m, rm, xslab, vbase, wlane3(a.wa0_c1, CF::C1P), ring3);
+    w4n1_res_out(res, rm, a.br[col]);
+  } else {
+    {
+      const float br = a.br[col];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
+      for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
+    }
+    w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res, xslab, xbase, wlane3(a.r0.wa, CF::C0P), ring3);
+    w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
+    __syncthreads();                                            // chunk 0 has been consumed by every wave
+    quad_to_stage<SKIP_L, SKIP_CM, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
+    __syncthreads();
+    w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
   }
-  w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res, xslab, xbase, wlane3(a.r0.wa, CF::C0P), ring3);
-  w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
-  __syncthreads();                                            // chunk 0 has been consumed by every wave
-  quad_to_stage<SKIP_L, SKIP_CM, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
-  __syncthreads();
-  w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
   w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
   w4n1_out(acc, m);
   TR(trb + 1);
@@ -721,6 +881,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     const float tb = a.r0.tb[col];
     if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
   }
+  if constexpr (VH) __syncthreads();                         // chunk 1 is consumed: the H slab aliases it
   to_h();
   __syncthreads();
   TR(trb + 2);
@@ -754,8 +915,10 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   }
 
   // =================== tail: Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, direct ===================
+  // (reads a row-form H slab; at L = 16 it aliases the V-form slabs, which are dead after the barrier)
   __syncthreads();
-  to_h();
+  if constexpr (VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
+  quad1_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
   __syncthreads();
   TR(trb + 7);
   {
@@ -801,9 +964,10 @@ struct UnetArgs {
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// The L = 16 stages (downs.2 + mid, ups.0) work on V-form slabs of up to 128 channels that alias their row-form slabs.
 constexpr int UNET_LDS_FLOATS =
-    cmax(cmax(cmax(CH_D0::LDS_FLOATS, CH_D1::LDS_FLOATS), cmax(CH_D2::LDS_FLOATS, CH_U0::LDS_FLOATS)),
-         cmax(CH_U1::LDS_FLOATS, 4 * FIN_SS)) + 8;   // + slack: the A double buffer reads one k-step past the last row
+    cmax(cmax(cmax(CH_D0::LDS_FLOATS, CH_D1::LDS_FLOATS), cmax(CH_D2::XSLAB, CH_U0::HSLAB)),
+         cmax(cmax(CH_U1::LDS_FLOATS, 4 * FIN_SS), VSLAB_FLOATS + 4 * VCS)) + 8;   // + slack: the A double buffers read one k-step past the end
 static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SPB == 4 && CH_U1::SPB == 4,
               "every stage must own the same 4 samples");
 
@@ -838,8 +1002,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x16 t[1];
     chain_body_w4<CH_D2, false>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
     __syncthreads();
-    quad_to_stage<CH_D2::L, CH_D2::CM, CH_U0::XSS, CH_U0::XSTR>(acc, lds, wave, lane);
-    zero_halo<CH_U0::C0P, CH_U0::L, CH_U0::SROWS, CH_U0::XSTR, CH_U0::XSS, 4>(lds);
+    quad2_to_vform(acc, lds, wave % (CH_D2::CM / 32), lane);              // chunk 0 of ups.0's conv A input, V form
   }
   TR(130);
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
@@ -1066,8 +1229,10 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_f
 // c = c_lo + 4 * ks + (lane >> 4), n = slice * 16 * NT + nt * 16 + (lane & 15); with a fused 1x1 residual conv (wres, layout
 // [cout][cin_full]) four more floats: Wr(c, n) for nt = 0, 1, then zeros.  Channels >= c_hi (padding up to cinp) are
 // zero; 8 zero k-steps follow the pack (register-ring over-read).  conv weight layout [cout][cin_full][5].
+// wres_wino: the residual weights are stored Winograd-transformed, (Wr * -2/9, Wr * 2/45, Wr * 8/45, 0) = G g for the
+// centre-tap-only kernel at positions (1,2), (3,4), (5,6) (V-form stages, NT = 1).
 static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi, int cinp, int NT,
-                    const float* wres) {
+                    const float* wres, bool wres_wino = false) {
   static const double G[8][5] = {{-1, 0, 0, 0, 0},
                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -1092,7 +1257,13 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_
             for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
             out[p * NT + nt] = (float)u;
           }
-          if (wres) out[8 * NT + nt] = wres[(size_t)n * cin_full + ci];
+          if (wres && !wres_wino) out[8 * NT + nt] = wres[(size_t)n * cin_full + ci];
+          if (wres && wres_wino) {
+            const double wr = (double)wres[(size_t)n * cin_full + ci];
+            out[8 * NT + 0] = (float)(wr * G[1][2]);
+            out[8 * NT + 1] = (float)(wr * G[3][2]);
+            out[8 * NT + 2] = (float)(wr * G[5][2]);
+          }
         }
 }
 
@@ -1205,9 +1376,10 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.a.wpk = blob.size();
     if (r == 6 || r == 8) {   // ups.*.0: input = cat(x, skip), staged chunk by chunk: one pack per chunk
       const int half = R.cin / 2;
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres);
+      const bool wino_res = r == 6;   // ups.0 (L = 16) reads V-form slabs: its residual conv runs in the Winograd domain
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres, wino_res);
       W.a_c1 = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres, wino_res);
     } else {
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres);
     }
@@ -1302,7 +1474,7 @@ static const double kUnetMfmaFlops =
     4 * (wino4_flops(16, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 16, 32, 64) + direct_flops(3, 32, 32, 32) +
     2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) + direct_flops(3, 64, 64, 16) +
     wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) + 7 * wino4_flops(128, 128) +
-    wino4_flops(256, 64) + direct_flops(1, 256, 64, 16) + 3 * wino4_flops(64, 64) + 2 * direct_flops(2, 64, 64, 16) +
+    wino4_flops(256, 64) * 14.0 / 8.0 + 3 * wino4_flops(64, 64) + 2 * direct_flops(2, 64, 64, 16) +   // ups.0 conv A: 8 + 6 (residual, Winograd domain) MFMAs per k-step
     2 * (wino4_flops(128, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 128, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
     4 * wino4_flops(32, 32) + direct_flops(1, 32, 32, 64);
 
