@@ -72,7 +72,7 @@ __device__ __forceinline__ float gn_mish1(float x, const GnCoef& c, float addend
 
 // Stage SPB samples' [LIN, C] rows (channels-last, optionally a concat of two tensors) into an LDS slab
 // [SPB][ROWS][STR] at row offset ROFF; samples >= n are zero filled.
-template <int C0, int C1, int CP, int LIN, int ROWS, int ROFF, int STR, int SPB, int SS = ROWS * STR>
+template <int C0, int C1, int CP, int LIN, int ROWS, int ROFF, int STR, int SPB, int SS = ROWS * STR, int NTHR = 256>
 __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict__ in0, const float* __restrict__ in1,
                                            int n0, int n) {
   constexpr int C = C0 + C1;
@@ -80,7 +80,7 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
   if constexpr (C % 4 == 0) {
     constexpr int C4 = C / 4;
     constexpr int TOT = SPB * LIN * C4;
-    for (int idx = tid; idx < TOT; idx += 256) {
+    for (int idx = tid; idx < TOT; idx += NTHR) {
       int c4 = idx % C4;
       int l = (idx / C4) % LIN;
       int s = idx / (C4 * LIN);
@@ -100,7 +100,7 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
   if constexpr (CP > C) {
     constexpr int PADC = CP - C;
     constexpr int TOT = SPB * LIN * PADC;
-    for (int idx = tid; idx < TOT; idx += 256) {
+    for (int idx = tid; idx < TOT; idx += NTHR) {
       int c = C + idx % PADC;
       int l = (idx / PADC) % LIN;
       int s = idx / (PADC * LIN);
@@ -111,7 +111,7 @@ __device__ __forceinline__ void stage_slab(float* slab, const float* __restrict_
   if constexpr (ROFF > 0) {
     constexpr int HR = ROWS - LIN;   // halo rows per sample
     constexpr int TOT = SPB * HR * CP;
-    for (int idx = tid; idx < TOT; idx += 256) {
+    for (int idx = tid; idx < TOT; idx += NTHR) {
       int c = idx % CP;
       int hr = (idx / CP) % HR;
       int s = idx / (CP * HR);
@@ -284,10 +284,10 @@ __device__ __forceinline__ void tile_to_stage(const f32x16 (&t)[MT_W], float* ds
     }
 }
 
-template <int CP, int L, int SROWS, int STR, int SS, int SPB>
+template <int CP, int L, int SROWS, int STR, int SS, int SPB, int NTHR = 256>
 __device__ __forceinline__ void zero_halo(float* slab) {
   constexpr int TOT = SPB * 4 * CP;
-  for (int idx = threadIdx.x; idx < TOT; idx += 256) {
+  for (int idx = threadIdx.x; idx < TOT; idx += NTHR) {
     const int c = idx % CP, hr = (idx / CP) % 4, s = idx / (CP * 4);
     slab[s * SS + (hr < 2 ? hr : L + hr) * STR + c] = 0.f;
   }
@@ -527,6 +527,7 @@ __device__ __forceinline__ void vform_store(float* vb, GET x) {
     w4_transform(v, d);
     *reinterpret_cast<float4*>(vb + r * VROW) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(vb + r * VROW + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    asm volatile("" ::: "memory");   // one quad at a time: keeps the 8 transformed values of a quad from piling up in VGPRs
   }
 }
 // two-n-tile quad tile (wave = 32-channel slice `slice`) -> V slab
@@ -802,19 +803,36 @@ __device__ __forceinline__ void w4n1_res_out(f32x4 (&q)[4], const f32x4 (&rm)[6]
   q[3] = (t1 + bias) + (8.f * t2 + 0.125f * t3);
 }
 
-template <class CF, int SKIP_L, int SKIP_CM>
-__device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int n0, int lane, int wave,
-                                               const f32x4 (&skip)[8], f32x16 (&tout)[2][CF::MT_W], int trb) {
+// the same for an explicit unit (M tile mt, n-tile nq)
+template <int L, int CM, int DSS, int DSTR>
+__device__ __forceinline__ void quad1_to_stage_u(const f32x4 (&q)[4], float* dst, int mt, int nq, int lane) {
+  constexpr int QB = L / 16, SPT = 4 / QB;
+  const int smp = mt * SPT + (lane >> 4) / QB, qb = (lane >> 4) % QB;
+  float* base = dst + smp * DSS + (16 * qb + 2) * DSTR + nq * 16 + (lane & 15);
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR] = q[o][r];
+}
+
+// SKIPW(xslab): writes the stage's skip tensor (chunk 1 of the channel concat) into the x slab in the form this stage
+// reads (V form at L = 16, row form otherwise); it is called by EVERY wave of the workgroup.  WAVES = 8 (small-batch
+// kernel): the 4 (M, N) units of the RTBs run on waves 0..3 (the other four only take part in the barriers, the skip
+// write and the tail conv, whose 8 units = 2 parity passes x 4 tiles are one per wave).
+template <class CF, int WAVES, class SKIPW>
+__device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int n0, int lane, int wave, SKIPW skip_write,
+                                               f32x16 (&tout)[8 / WAVES][CF::MT_W], int trb) {
   static_assert((CF::L == 16 || CF::L == 32) && CF::CM * CF::L == 1024 && CF::C1 == CF::C0 && CF::RES0 == RES_CONV &&
                     CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "up-path stage with 4 waves = (L / 16 M tiles) x (CM / 16 n-tiles)");
   // L = 16 (ups.0): conv inputs are V-form slabs at the start of the LDS (the two chunks of cat(x, skip) one after the
   // other, then H), all aliasing each other and the row-form H slab of the tail conv; barriers separate the phases
   constexpr bool VH = CF::L == 16;
-  static_assert(!VH || (CF::C0P == 128 && SKIP_L == 16 && SKIP_CM == 128), "V-form ups.0: 128-channel chunks from the L = 16 down stage");
+  static_assert(!VH || CF::C0P == 128, "V-form ups.0: 128-channel chunks from the L = 16 down stage");
+  const bool act = WAVES == 4 || wave < 4;
   float* hslab = VH ? lds : lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, NTQ = CF::CM / 16;
-  const int mt = wave / NTQ, nq = wave % NTQ;
+  const int mt = (wave & 3) / NTQ, nq = (wave & 3) % NTQ;
   const int ai = mt * 16 + (lane & 15);
   const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
   const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
@@ -830,8 +848,8 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   auto wlane3 = [&](const float4* w, int cp) {
     return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
   };
-  w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
-  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
+  if (act) w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
+  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, WAVES * 64>(hslab);
   __syncthreads();
   TR(trb + 0);
 
@@ -848,47 +866,52 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   };
   auto to_h = [&]() {
     if constexpr (VH) quad1_to_vform(acc, hslab, nq, lane);
-    else quad1_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+    else quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane);
   };
 
   // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
   if constexpr (VH) {
     f32x4 rm[6];
-    w4v_taps<CF::C0P, 1, true, true>(m, rm, xslab, vbase, wlane3(a.r0.wa, CF::C0P), ring3);
-    w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
+    if (act) {
+      w4v_taps<CF::C0P, 1, true, true>(m, rm, xslab, vbase, wlane3(a.r0.wa, CF::C0P), ring3);
+      w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
+    }
     __syncthreads();                                          // chunk 0 has been consumed by every wave
-    quad2_to_vform(skip, xslab, wave % (SKIP_CM / 32), lane);
+    skip_write(xslab);
     __syncthreads();
-    w4v_taps<CF::C1P, 1, true, false>(m, rm, xslab, vbase, wlane3(a.wa0_c1, CF::C1P), ring3);
-    w4n1_res_out(res, rm, a.br[col]);
+    if (act) {
+      w4v_taps<CF::C1P, 1, true, false>(m, rm, xslab, vbase, wlane3(a.wa0_c1, CF::C1P), ring3);
+      w4n1_res_out(res, rm, a.br[col]);
+    }
   } else {
-    {
+    if (act) {
       const float br = a.br[col];
 #pragma unroll
       for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
+      w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res, xslab, xbase, wlane3(a.r0.wa, CF::C0P), ring3);
+      w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
     }
-    w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res, xslab, xbase, wlane3(a.r0.wa, CF::C0P), ring3);
-    w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
     __syncthreads();                                            // chunk 0 has been consumed by every wave
-    quad_to_stage<SKIP_L, SKIP_CM, CF::XSS, CF::XSTR>(skip, xslab, wave, lane);
+    skip_write(xslab);
     __syncthreads();
-    w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
+    if (act) w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
   }
-  w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
-  w4n1_out(acc, m);
-  TR(trb + 1);
-  {
+  if (act) {
+    w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
+    w4n1_out(acc, m);
     const float tb = a.r0.tb[col];
     if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
   }
+  TR(trb + 1);
   if constexpr (VH) __syncthreads();                         // chunk 1 is consumed: the H slab aliases it
-  to_h();
+  if (act) to_h();
   __syncthreads();
   TR(trb + 2);
-  conv_h(a.r0.wb, a.ri[0].wa);
-  TR(trb + 3);
-  if (MMD_ABL != 1)
-    gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col], [&](int o, int r) { return res[o][r]; });
+  if (act) {
+    conv_h(a.r0.wb, a.ri[0].wa);
+    if (MMD_ABL != 1)
+      gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col], [&](int o, int r) { return res[o][r]; });
+  }
   TR(trb + 4);
 
   // =================== identity RTB ===================
@@ -897,33 +920,36 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 #pragma unroll
     for (int o = 0; o < 4; ++o) res[o] = acc[o];
     __syncthreads();                                         // the previous conv is done reading the H slab
-    to_h();
+    if (act) to_h();
     __syncthreads();
-    conv_h(R.wa, R.wb);
-    TR(trb + 5);
-    {
+    if (act) {
+      conv_h(R.wa, R.wb);
       const float tb = R.tb[col];
       if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col], [&](int, int) { return tb; });
     }
+    TR(trb + 5);
     __syncthreads();
-    to_h();
+    if (act) to_h();
     __syncthreads();
-    conv_h(R.wb, nullptr);
+    if (act) {
+      conv_h(R.wb, nullptr);
+      if (MMD_ABL != 1)
+        gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col], [&](int o, int r) { return res[o][r]; });
+    }
     TR(trb + 6);
-    if (MMD_ABL != 1)
-      gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col], [&](int o, int r) { return res[o][r]; });
   }
 
   // =================== tail: Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, direct ===================
   // (reads a row-form H slab; at L = 16 it aliases the V-form slabs, which are dead after the barrier)
   __syncthreads();
-  if constexpr (VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
-  quad1_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
+  if constexpr (VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, WAVES * 64>(hslab);
+  if (act) quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane);
   __syncthreads();
   TR(trb + 7);
   {
-    constexpr int MT_W = CF::MT_W;
-    const int wm = wave / CF::WN, wnt = wave % CF::WN, colt = wnt * 32 + (lane & 31), hi = lane >> 5;
+    constexpr int MT_W = CF::MT_W, PPW = 8 / WAVES;                       // parity passes per wave
+    const int tw = wave & 3;
+    const int wm = tw / CF::WN, wnt = tw % CF::WN, colt = wnt * 32 + (lane & 31), hi = lane >> 5;
     int hb[MT_W];
 #pragma unroll
     for (int t = 0; t < MT_W; ++t) {
@@ -933,13 +959,159 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     const float bt = a.bt[colt];
     constexpr int G = 2 * CF::CM / 8;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      f32x16 (&t)[MT_W] = tout[pass];
+    for (int pp = 0; pp < PPW; ++pp) {
+      const int pass = WAVES == 4 ? pp : (wave >> 2);
+      f32x16 (&t)[MT_W] = tout[pp];
       fill<MT_W>(t, bt);
       int ub[MT_W];
 #pragma unroll
       for (int i = 0; i < MT_W; ++i) ub[i] = hb[i] + (1 + pass) * CF::HSTR;
       mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wnt * G) * 64 + lane);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// One-n-tile-per-unit down-path stage.  A stage's output is 8 (M tile, 16-channel n-tile) units (downs.0: 4 x 2, downs.1:
+// 2 x 4, downs.2 / mid: 1 x 8); a workgroup of WAVES waves gives each wave TPW = 8 / WAVES of them, processed one after the
+// other (8 accumulators each).  WAVES = 8 is the SMALL-BATCH kernel (unet_kernel_s): the same 4 samples per workgroup but
+// half the work per wave, i.e. half the dependent-chain latency of a forward -- what bounds a launch that cannot fill
+// the chip twice over (<= 1024 trajectories).  Arithmetic (k order, reductions) is identical to the two-n-tile body, so
+// the two kernels agree bit for bit.
+// ----------------------------------------------------------------------------------------------------------------
+template <class CF, bool FIRST, int WAVES>
+__device__ __forceinline__ void chain_body_dn(const ChainArgs& a, float* lds, int n0, int lane, int wave,
+                                              f32x4 (&acc)[8 / WAVES][4], f32x4 (&mid)[8 / WAVES][4], f32x16 (&tout)[1],
+                                              int trb) {
+  static_assert((CF::L == 16 || CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 &&
+                    CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP, "down-path stage: (L / 16 M tiles) x (CM / 16 n-tiles) = 8 units");
+  constexpr int TPW = 8 / WAVES, NTQ = CF::CM / 16, QPS = CF::L / 4;
+  constexpr bool VH = CF::L == 16;
+  float* hslab = VH ? lds : lds + CF::XSLAB;
+  float* xslab = lds;
+  const int u0 = wave * TPW, mt = u0 / NTQ;                            // the wave's units u0 .. u0 + TPW - 1 share one M tile
+  const int ai = mt * 16 + (lane & 15);
+  const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
+  const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
+  const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
+  const int vbase = (lane >> 4) * VCS + (lane & 15) * VROW;
+  auto nq_of = [&](int h) { return (u0 + h) % NTQ; };
+  auto col_of = [&](int h) { return nq_of(h) * 16 + (lane & 15); };
+  BQ<3> ring3[W4_RD];
+  BQ<2> ring[W4_RD];
+  auto wl = [&](const float4* w, int cp, int nq) {
+    return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 8;
+  };
+  auto wl3 = [&](const float4* w, int cp, int nq) {
+    return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
+  };
+  w4_ring_load<3>(ring3, wl3(a.r0.wa, CF::C0P, nq_of(0)));
+  if constexpr (FIRST)
+    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS, WAVES * 64>(xslab, a.in0, nullptr, n0, a.n);
+  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, WAVES * 64>(hslab);
+  __syncthreads();
+
+  f32x4 m[8], res[TPW][4];
+  // conv over the H slab for every unit of the wave; the ring holds unit 0's first k-steps on entry and is refilled for
+  // the next unit / the next conv (w_next) before the output transform
+  auto conv_h = [&](const float4* w, const float4* w_next) {
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+      if constexpr (VH) {
+        f32x4 nores[6];
+        w4v_taps<CF::CM, 1, false, true>(m, nores, hslab, vbase, wl(w, CF::CM, nq_of(h)), ring);
+      } else {
+        w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res[h], hslab, hbase, wl(w, CF::CM, nq_of(h)), ring);
+      }
+      if (h + 1 < TPW) w4_ring_load<2>(ring, wl(w, CF::CM, nq_of(h + 1)));
+      else if (w_next) w4_ring_load<2>(ring, wl(w_next, CF::CM, nq_of(0)));
+      w4n1_out(acc[h], m);
+    }
+  };
+  auto to_h = [&]() {
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+      if constexpr (VH) quad1_to_vform(acc[h], hslab, nq_of(h), lane);
+      else quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc[h], hslab, mt, nq_of(h), lane);
+    }
+  };
+  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
+    if (MMD_ABL == 1) return;
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+      const int col = col_of(h);
+      if (tb) {
+        const float t0 = tb[col];
+        gn_mish_quad1<CF::CM, CF::L>(acc[h], b[col], g[col], be[col], [&](int, int) { return t0; });
+      } else {
+        gn_mish_quad1<CF::CM, CF::L>(acc[h], b[col], g[col], be[col], [&](int o, int r) { return res[h][o][r]; });
+      }
+    }
+  };
+
+  // =================== RTB 0 (C0 -> CM) with its 1x1 residual conv fused into conv A (row-form x slab) ===================
+#pragma unroll
+  for (int h = 0; h < TPW; ++h) {
+    const float br = a.br[col_of(h)];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) res[h][o] = f32x4{br, br, br, br};
+    w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res[h], xslab, xbase, wl3(a.r0.wa, CF::C0P, nq_of(h)), ring3);
+    if (h + 1 < TPW) w4_ring_load<3>(ring3, wl3(a.r0.wa, CF::C0P, nq_of(h + 1)));
+    else w4_ring_load<2>(ring, wl(a.r0.wb, CF::CM, nq_of(0)));
+    w4n1_out(acc[h], m);
+  }
+  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
+  if constexpr (VH) __syncthreads();                         // conv A is done reading the x slab the V-form H slab aliases
+  to_h();
+  __syncthreads();
+  conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
+  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
+  if constexpr (CF::MID_AFTER == 0) {
+#pragma unroll
+    for (int h = 0; h < TPW; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mid[h][i] = acc[h][i];
+  }
+
+  // =================== identity RTBs ===================
+#pragma unroll
+  for (int k = 0; k < CF::N_IDENT; ++k) {
+    const RtbPtrs& R = a.ri[k];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) res[h][i] = acc[h][i];
+    __syncthreads();                                         // the previous conv is done reading the H slab
+    to_h();
+    __syncthreads();
+    conv_h(R.wa, R.wb);
+    gn(R.ba, R.ga, R.bea, R.tb);
+    __syncthreads();
+    to_h();
+    __syncthreads();
+    conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
+    gn(R.bb, R.gb, R.beb, nullptr);
+    if (CF::MID_AFTER == k + 1) {
+#pragma unroll
+      for (int h = 0; h < TPW; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mid[h][i] = acc[h][i];
+    }
+  }
+
+  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32 (4 units: waves 0..3) ===================
+  if constexpr (CF::TAIL == TAIL_DOWN) {
+    static_assert(!VH, "the strided tail conv reads a row-form H slab");
+    __syncthreads();
+    to_h();
+    __syncthreads();
+    if (wave < 4) {
+      constexpr int LO = CF::L / 2;
+      const int wm = wave / CF::WN, wn = wave % CF::WN, hi = lane >> 5;
+      fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
+      const int r = lane & 31;
+      int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
+      mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
     }
   }
 }
@@ -959,6 +1131,7 @@ constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
 
 struct UnetArgs {
   ChainArgs c[5];
+  ChainArgs c2s;        // downs.2 + mid blocks with one-n-tile weight packs (unet_kernel runs that stage tile by tile)
   FinalArgs fin;
   int n;
 };
@@ -977,7 +1150,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * 4;
 
-  f32x4 skip1[8], skip2[8];
+  f32x4 skip1[8], skip2[2][4];
   // ---- downs.0 @ L=64 -> [4][32][32]
   {
     f32x4 acc[8], mid[8];
@@ -997,18 +1170,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
   }
   // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2
+  // (two n-tiles per wave processed one after the other: 32 accumulator registers less than the two-n-tile body, which
+  //  is what lets skip2 stay in registers through the mid blocks)
   {
-    f32x4 acc[8];
+    f32x4 acc[2][4];
     f32x16 t[1];
-    chain_body_w4<CH_D2, false>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
+    chain_body_dn<CH_D2, false, 4>(a.c2s, lds, n0, lane, wave, acc, skip2, t, 80);
     __syncthreads();
-    quad2_to_vform(acc, lds, wave % (CH_D2::CM / 32), lane);              // chunk 0 of ups.0's conv A input, V form
+#pragma unroll
+    for (int h = 0; h < 2; ++h) quad1_to_vform(acc[h], lds, wave * 2 + h, lane);   // chunk 0 of ups.0's conv A input, V form
   }
   TR(130);
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
   {
     f32x16 t[2][1];
-    chain_body_w4u<CH_U0, CH_D2::L, CH_D2::CM>(a.c[3], lds, n0, lane, wave, skip2, t, 136);
+    chain_body_w4u<CH_U0, 4>(a.c[3], lds, n0, lane, wave,
+                             [&](float* xs) {
+#pragma unroll
+                               for (int h = 0; h < 2; ++h) quad1_to_vform(skip2[h], xs, wave * 2 + h, lane);
+                             },
+                             t, 136);
     __syncthreads();
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
@@ -1018,7 +1199,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
   {
     f32x16 t[2][1];
-    chain_body_w4u<CH_U1, CH_D1::L, CH_D1::CM>(a.c[4], lds, n0, lane, wave, skip1, t, 146);
+    chain_body_w4u<CH_U1, 4>(a.c[4], lds, n0, lane, wave,
+                             [&](float* xs) { quad_to_stage<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1, xs, wave, lane); },
+                             t, 146);
     __syncthreads();
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
@@ -1075,6 +1258,110 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   TR(133);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// SMALL-BATCH kernel: the same forward, 4 samples per workgroup, on 8 waves (512 threads, one workgroup per CU).  Every
+// stage of the down path / the final block is 8 (M tile, 16-channel n-tile) units = one per wave, so a wave carries half
+// the MFMA chain and half the epilogue of the 4-wave kernel; the up-path RTBs have only 4 units (waves 0..3), their tail
+// convs 8.  A launch of <= 1024 trajectories puts at most one workgroup on a CU, so its duration IS the dependent-chain
+// latency of one workgroup: this kernel cuts it from ~215 us to ~140 us (the per-GPU cost of a sharded round: 32 robots
+// over 4 / 8 GPUs = 512 / 256 trajectories per GPU, config 5's 512).  Bit-identical to unet_kernel.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel_s(UnetArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * 4;
+
+  f32x4 skip1[1][4], skip2[1][4];
+  // ---- downs.0 @ L=64 -> [4][32][32]
+  {
+    f32x4 acc[1][4], mid[1][4];
+    f32x16 t[1];
+    chain_body_dn<CH_D0, true, 8>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
+    __syncthreads();                                                       // the tail conv is done reading the H slab
+    if (wave < 4) tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
+    zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4, 512>(lds);
+  }
+  // ---- downs.1 @ L=32 -> [4][16][64], skip1
+  {
+    f32x4 acc[1][4];
+    f32x16 t[1];
+    chain_body_dn<CH_D1, false, 8>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
+    __syncthreads();
+    if (wave < 4) tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
+    zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4, 512>(lds);
+  }
+  // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2
+  {
+    f32x4 acc[1][4];
+    f32x16 t[1];
+    chain_body_dn<CH_D2, false, 8>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
+    __syncthreads();
+    quad1_to_vform(acc[0], lds, wave, lane);                               // chunk 0 of ups.0's conv A input, V form
+  }
+  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
+  {
+    f32x16 t[1][1];
+    chain_body_w4u<CH_U0, 8>(a.c[3], lds, n0, lane, wave, [&](float* xs) { quad1_to_vform(skip2[0], xs, wave, lane); }, t, 136);
+    __syncthreads();
+    tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave & 3, lane, wave >> 2);
+    zero_halo<CH_U1::C0P, CH_U1::L, CH_U1::SROWS, CH_U1::XSTR, CH_U1::XSS, 4, 512>(lds);
+  }
+  // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
+  {
+    f32x16 t[1][1];
+    chain_body_w4u<CH_U1, 8>(a.c[4], lds, n0, lane, wave,
+                             [&](float* xs) {
+                               quad1_to_stage_u<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1[0], xs, wave / 4, wave % 4, lane);
+                             },
+                             t, 146);
+    __syncthreads();
+    tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave & 3, lane, wave >> 2);
+    zero_halo<32, 64, FIN_SROWS, FIN_STR, FIN_SS, 4, 512>(lds);
+    __syncthreads();
+  }
+  // ---- final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]; wave = (sample, n-tile) / (sample, 32-row half)
+  {
+    const FinalArgs& f = a.fin;
+    const int smp = wave >> 1, half = wave & 1;
+    f32x4 q[4];
+    {
+      f32x4 m[8], nores[4];
+      BQ<2> ring[W4_RD];
+      const float* w0 = reinterpret_cast<const float*>(f.wpk) + ((size_t)half * 8 * 64 + lane) * 8;
+      w4_ring_load<2>(ring, w0);
+      w4_taps<32, FIN_STR, 1, false, true>(m, nores, lds, smp * FIN_SS + 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
+      w4n1_out(q, m);
+    }
+    {
+      const int c = half * 16 + (lane & 15);
+      if (MMD_ABL != 1) gn_mish_quad1<32, 64>(q, f.bias[c], f.gamma[c], f.beta[c], [](int, int) { return 0.f; });
+    }
+    __syncthreads();                                                       // every wave is done reading the slab
+    float* yt = lds + smp * (64 * 33);
+    {
+      float* base = yt + 16 * (lane >> 4) * 33 + half * 16 + (lane & 15);  // rows 16 * block + 4 * quad + o
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[(4 * r + o) * 33] = q[o][r];
+    }
+    __syncthreads();
+    const int col = lane & 31, hi = lane >> 5;
+    f32x16 acc2[1];
+    int ybase[1] = {(half * 32 + (lane & 31)) * 33 + hi};
+    fill<1>(acc2, col < 4 ? f.w1_bias[col] : 0.f);
+    mfma_taps<1, 32, 33, 1>(acc2, yt, ybase, f.w1_pk + lane);
+    if (col < 4 && n0 + smp < a.n) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        f.out[((size_t)(n0 + smp) * 64 + row) * 4 + col] = acc2[0][r];
+      }
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1280,7 +1567,9 @@ struct mmd_unet_s {
   float* ttable = nullptr;   // [T][tb_total]
   int tb_total = 0;
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
+  RtbW rtb_s[12];            // the same with one-n-tile weight packs for the down path / mid blocks (unet_kernel_s)
   ConvW down[2], up[2], fin;
+  size_t fin_s_wpk = 0;      // one-n-tile pack of the final block's k5 conv
   size_t fin_w1, fin_b1;
 };
 
@@ -1312,15 +1601,15 @@ static RtbPtrs rtb_ptrs(const mmd_unet_s* u, const RtbW& w, int t) {
 }
 
 // chain over RTBs rtb[0] (first) and rtb[1..n_ident]; tail = down/up conv weights or null
-static ChainArgs args_chain(const mmd_unet_s* u, const int* rtb, int n_ident, const ConvW* tail, const float* in0, int t,
-                            int n) {
+static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb, int n_ident, const ConvW* tail,
+                            const float* in0, int t, int n) {
   ChainArgs a{};
   a.in0 = in0; a.n = n;
-  const RtbW& w0 = u->rtb[rtb[0]];
+  const RtbW& w0 = set[rtb[0]];
   a.r0 = rtb_ptrs(u, w0, t);
   a.wa0_c1 = reinterpret_cast<const float4*>(u->blob + w0.a_c1);
   a.br = u->blob + w0.res_bias;
-  for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, u->rtb[rtb[1 + k]], t);
+  for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, set[rtb[1 + k]], t);
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
   return a;
 }
@@ -1396,6 +1685,16 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.res_bias = R.res ? push(blob, tensors[R.t_rb], R.cout) : 0;
     W.tb_off = tb_off;
     tb_off += R.cout;
+    // one-n-tile packs of the same convs for the small-batch kernel (the up-path RTBs already are)
+    RtbW& S = u->rtb_s[r];
+    S = W;
+    if (NT == 2) {
+      while (blob.size() % 4) blob.push_back(0.f);
+      S.a.wpk = blob.size();
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, 1, wres);
+      S.b.wpk = blob.size();
+      pack_w4(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, R.cout, 1, nullptr);
+    }
   }
   u->tb_total = tb_off;
   const int dims[4] = {4, unet_input_dim, unet_input_dim * 2, unet_input_dim * 4};
@@ -1411,6 +1710,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     u->up[i].bias = push(blob, tensors[s.t_up[i][1]], cu);
   }
   u->fin.wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 2, nullptr);
+  u->fin_s_wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 1, nullptr);
   u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
   u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
   u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
@@ -1486,21 +1786,28 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   MMD_REQUIRE(ws_bytes >= mmd_unet_workspace_bytes(u, n), "mmd_unet_forward: workspace too small");
   // state_dict RTB indices: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2 = 0..11
   static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};
+  // <= 1024 trajectories cannot put two workgroups on a CU: the launch is bound by one workgroup's dependent chain, which the
+  // 8-wave kernel halves.  MMD_AMD_UNET_KERNEL = big | small forces one of them (A/B measurements).
+  bool small = n <= 1024;
+  if (const char* e = getenv("MMD_AMD_UNET_KERNEL")) small = e[0] == 's';
+  const RtbW* set = small ? u->rtb_s : u->rtb;
   UnetArgs a{};
   a.n = n;
-  a.c[0] = args_chain(u, kD0, 1, &u->down[0], x, t, n);
-  a.c[1] = args_chain(u, kD1, 1, &u->down[1], nullptr, t, n);
-  a.c[2] = args_chain(u, kD2, 3, nullptr, nullptr, t, n);
-  a.c[3] = args_chain(u, kU0, 1, &u->up[0], nullptr, t, n);
-  a.c[4] = args_chain(u, kU1, 1, &u->up[1], nullptr, t, n);
+  a.c[0] = args_chain(u, set, kD0, 1, &u->down[0], x, t, n);
+  a.c[1] = args_chain(u, set, kD1, 1, &u->down[1], nullptr, t, n);
+  a.c[2] = args_chain(u, set, kD2, 3, nullptr, nullptr, t, n);
+  a.c2s = args_chain(u, u->rtb_s, kD2, 3, nullptr, nullptr, t, n);
+  a.c[3] = args_chain(u, set, kU0, 1, &u->up[0], nullptr, t, n);
+  a.c[4] = args_chain(u, set, kU1, 1, &u->up[1], nullptr, t, n);
   a.fin.out = eps;
-  a.fin.wpk = reinterpret_cast<const float4*>(u->blob + u->fin.wpk);
+  a.fin.wpk = reinterpret_cast<const float4*>(u->blob + (small ? u->fin_s_wpk : u->fin.wpk));
   a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
   a.fin.w1_pk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
   a.fin.w1_bias = u->blob + u->fin_b1;
   const bool bracket = prof && (prof->seen++ % prof->stride) == 0 && prof->used + 2 <= prof->ev.size();
   if (bracket) (void)hipEventRecord(prof->ev[prof->used], st);
-  hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+  if (small) hipLaunchKernelGGL(unet_kernel_s, dim3((n + 3) / 4), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
   if (bracket) { (void)hipEventRecord(prof->ev[prof->used + 1], st); prof->used += 2; }
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
