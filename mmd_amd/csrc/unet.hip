@@ -235,7 +235,7 @@ template <int C0_, int C1_, int CM_, int L_, int MT_W_, int RES0_, int N_IDENT_,
 struct ChainCfg {
   static constexpr int C0 = C0_, C1 = C1_, CM = CM_, L = L_, MT_W = MT_W_, RES0 = RES0_, N_IDENT = N_IDENT_;
   static constexpr int MID_AFTER = MID_AFTER_, TAIL = TAIL_;
-  static constexpr int C0P = C0 < 16 ? 16 : (C0 + 7) / 8 * 8, C1P = (C1 + 7) / 8 * 8;   // (4-channel input: 4 k-steps of 4)
+  static constexpr int C0P = (C0 + 7) / 8 * 8, C1P = (C1 + 7) / 8 * 8;   // (4-channel input: 2 k-steps of 4 = the weight ring's depth)
   static constexpr int CXP = C0P > C1P ? C0P : C1P;
   static constexpr int XSTR = CXP + 1, HSTR = CM + 1;
   static constexpr int WN = CM / 32, WM = 4 / WN;
@@ -1659,7 +1659,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     RtbW& W = u->rtb[r];
     while (blob.size() % 4) blob.push_back(0.f);
     const int NT = (r >= 6 && r <= 9) ? 1 : 2;       // ups.0, ups.1: one n-tile per wave; the rest: two
-    const int cinp = R.cin < 16 ? 16 : R.cin;        // the 4-channel network input is padded to 4 k-steps
+    const int cinp = (R.cin + 7) / 8 * 8;            // the 4-channel network input is padded to 2 k-steps (the ring depth)
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
     W.a_c1 = 0;
     W.a.wpk = blob.size();
@@ -1771,7 +1771,7 @@ static constexpr double direct_flops(double taps, double cinp, double coutp, dou
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
 }
 static const double kUnetMfmaFlops =
-    4 * (wino4_flops(16, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 16, 32, 64) + direct_flops(3, 32, 32, 32) +
+    4 * (wino4_flops(8, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 8, 32, 64) + direct_flops(3, 32, 32, 32) +
     2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) + direct_flops(3, 64, 64, 16) +
     wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) + 7 * wino4_flops(128, 128) +
     wino4_flops(256, 64) * 14.0 / 8.0 + 3 * wino4_flops(64, 64) + 2 * direct_flops(2, 64, 64, 16) +   // ups.0 conv A: 8 + 6 (residual, Winograd domain) MFMAs per k-step

@@ -117,7 +117,8 @@ def compute_collision(points, guide, margin=None, map_index=0):
     desc = guide.desc() if hasattr(guide, "desc") else guide
     _lib.check(_lib.load().mmd_points_collision(C.byref(desc), _lib.require_gpu(flat, "points"), flat.shape[0],
                                                 flat.shape[1], map_index,
-                                                float(guide.margin if margin is None else margin), out.data_ptr(),
+                                                float(getattr(guide, "margin", desc.margin) if margin is None else margin),
+                                                out.data_ptr(),
                                                 _lib.current_stream_ptr()))
     return out.bool().view(pts.shape[:-1])
 

@@ -144,6 +144,35 @@ def test_guide_per_term_golden_g4():
         assert float(torch.from_numpy(g[f"term_{name}"]).abs().max()) > 1e-3, name      # the term is exercised
 
 
+def test_guide_and_postprocess_with_two_sdf_grids():
+    """n_grids > 1 (a map's fixed-object grid + an extra ObjectField grid, mpd.py:215-233 / env_base.py:76-89): the guide
+    takes max_k relu(margin - sdf_k) with the arg-max grid's gradient, the occupancy check ORs the grids -- both kernels'
+    k >= 1 loops against the oracle with the Highways and the Conveyor grids stacked as two objects of one map."""
+    import ctypes as C
+    from mmd_amd import _lib, postprocess as post
+    from mmd_amd.environments import sdf_grid_texture
+    tex = torch.from_numpy(np.stack([sdf_grid_texture("EnvHighways2D"), sdf_grid_texture("EnvConveyor2D")])[None]).cuda().contiguous()
+    guide = _gc().hip_guide("EnvHighways2D", [[]])
+    gp = cases.guide_params("EnvHighways2D")
+    gp.sdf_grids = [cases.sdf_grid("EnvHighways2D"), cases.sdf_grid("EnvConveyor2D")]
+    x = (torch.from_numpy(synth.synth_noise(60, (8, H, D))) * 0.6)
+
+    def two_grids(d):
+        d.n_grids, d.n_maps, d.sdf_grids_dev = 2, 1, tex.data_ptr()
+
+    got = _raw_guide_grad(guide, x.cuda(), two_grids)
+    ref = O.guide_grad(x, gp, [], clip_mode="always")
+    assert float((got - ref).abs().max()) < 2e-6
+    one = _raw_guide_grad(guide, x.cuda(), lambda d: None)
+    assert float((got - one).abs().max()) > 1e-3                         # the second grid matters on this batch
+    # occupancy over both grids
+    d = guide.desc()
+    two_grids(d)
+    pts = torch.from_numpy(np.random.Generator(np.random.PCG64(61)).uniform(-1, 1, size=(4096, 2)).astype(np.float32))
+    occ = post.compute_collision(pts.cuda(), d, margin=0.05).cpu()
+    assert torch.equal(occ, O.compute_collision(pts, gp, 0.05)) and occ.any() and not occ.all()
+
+
 def test_guide_point_on_constraint_centre_is_finite():
     """A support point that coincides exactly with a constraint centre: torch.norm's backward gives a zero gradient there;
     the kernel must not produce 0 * inf = NaN."""
