@@ -611,6 +611,20 @@ __device__ __forceinline__ void w4v_taps(f32x4 (&m)[8 * NT], f32x4 (&rm)[6 * NT]
 // A down-path stage (L = 32 / C = 64: downs.1; L = 16 / C = 128: downs.2 + mid blocks) in F(4,5) form.  Same slabs as
 // the other stages; activations in registers as quad tiles.  The 4 * L / 4 output quads are L / 16 M tiles of 16 rows; a
 // wave owns one M tile x 32 channels (two n-tiles).
+// Synchronisation between a slab write and the conv that reads it.  WAVE_PRIVATE: the stage's tiling gives every wave whole
+// samples with all their channels (L = 64: one M tile = one sample per wave), so a wave only ever reads what it wrote --
+// LDS operations of one wave execute in order, and only the compiler has to be kept from reordering them; no workgroup
+// barrier, i.e. no waiting for the slowest of the four SIMDs (each barrier costs its skew).
+template <bool WAVE_PRIVATE>
+__device__ __forceinline__ void slab_sync() {
+  if constexpr (WAVE_PRIVATE) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
 template <class CF, bool FIRST>
 __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[8],
                                               f32x4 (&mid)[8], f32x16 (&tout)[1], int trb) {
@@ -619,6 +633,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
                 "down-path stage with 4 waves = (L / 16 M tiles) x (CM / 32 channel slices)");
   // L = 16 (downs.2 + mid blocks): every conv after the first reads a V-form H slab that ALIASES the stage's d-form x slab
   constexpr bool VH = CF::L == 16;
+  constexpr bool PRIV = CF::L == 64;                                    // 4 M tiles x 1 channel slice: wave = sample
   float* hslab = VH ? lds : lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, WNQ = CF::CM / 32;                     // quads per sample, channel slices
@@ -688,7 +703,7 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
   if constexpr (VH) __syncthreads();                         // conv A is done reading the x slab the V-form H slab aliases
   to_h();
-  __syncthreads();
+  slab_sync<PRIV>();
   TR(trb + 4);
   conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
   TR(trb + 5);
@@ -704,17 +719,17 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
     const RtbPtrs& R = a.ri[k];
 #pragma unroll
     for (int i = 0; i < 8; ++i) res[i] = acc[i];
-    __syncthreads();                                         // the previous conv is done reading the H slab
+    slab_sync<PRIV>();                                       // the previous conv is done reading the H slab
     TR(trb + 8 + k * 8 + 0);
     to_h();
-    __syncthreads();
+    slab_sync<PRIV>();
     TR(trb + 8 + k * 8 + 1);
     conv_h(R.wa, R.wb);
     TR(trb + 8 + k * 8 + 2);
     gn(R.ba, R.ga, R.bea, R.tb);
-    __syncthreads();
+    slab_sync<PRIV>();
     to_h();
-    __syncthreads();
+    slab_sync<PRIV>();
     TR(trb + 8 + k * 8 + 5);
     conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
     TR(trb + 8 + k * 8 + 6);
@@ -728,9 +743,10 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32 ===================
   if constexpr (CF::TAIL == TAIL_DOWN) {
     static_assert(!VH, "the strided tail conv reads a row-form H slab");
-    __syncthreads();
+    static_assert(!PRIV || (CF::WN == 1 && CF::SW == 1), "wave-private stage: the tail tile of a wave is its own sample");
+    slab_sync<PRIV>();
     quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
-    __syncthreads();
+    slab_sync<PRIV>();
     constexpr int LO = CF::L / 2;
     const int wm = wave / CF::WN, wn = wave % CF::WN, hi = lane >> 5;
     fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
@@ -1229,8 +1245,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float bb[2] = {f.bias[c0], f.bias[c1]}, gg[2] = {f.gamma[c0], f.gamma[c1]}, ee[2] = {f.beta[c0], f.beta[c1]};
       if (MMD_ABL != 1) gn_mish_quad<32, 64>(q, bb, gg, ee, [](int, int) { return 0.f; });
     }
-    __syncthreads();                                                       // every wave is done reading the slab
-    float* yt = lds + wave * (64 * 33);
+    // wave = sample: the y tile goes over the wave's OWN slab region (stride FIN_SS), so no other wave is affected
+    slab_sync<true>();
+    float* yt = lds + wave * FIN_SS;
     {
       float* base = yt + 16 * (lane >> 4) * 33 + (lane & 15);             // rows 16 * block + 4 * quad + o
 #pragma unroll
@@ -1240,7 +1257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int r = 0; r < 4; ++r) base[(4 * r + o) * 33 + nt * 16] = q[o * 2 + nt][r];
     }
-    __syncthreads();
+    slab_sync<true>();
     f32x16 acc2[2];
     int ybase[2];
     fill<2>(acc2, col < 4 ? f.w1_bias[col] : 0.f);
@@ -1268,7 +1285,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // latency of one workgroup: this kernel cuts it from ~215 us to ~140 us (the per-GPU cost of a sharded round: 32 robots
 // over 4 / 8 GPUs = 512 / 256 trajectories per GPU, config 5's 512).  Bit-identical to unet_kernel.
 // ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel_s(UnetArgs a) {
+#ifndef MMD_S_WAVES
+#define MMD_S_WAVES 2
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MMD_S_WAVES, MMD_S_WAVES))) void unet_kernel_s(UnetArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -50,3 +50,14 @@ for tg in tags:
     prev = cur
 # start skew between blocks
 print("block start spread us:", (t[:, :, tags[0]].max() - t0) / 1e3)
+# ---- where does the tail come from?  end time of every workgroup (last tag) against its placement guesses
+end = (t[:, :, tags[-1]].max(axis=1) - t0) / 1e3
+start = (t[:, :, tags[0]].min(axis=1) - t0) / 1e3
+q = np.quantile(end, [0, 0.1, 0.5, 0.9, 1.0])
+print(f"workgroup end time us: min {q[0]:.1f} p10 {q[1]:.1f} median {q[2]:.1f} p90 {q[3]:.1f} max {q[4]:.1f}; duration mean {np.mean(end - start):.1f}")
+b = np.arange(nb)
+for name, key in (("blockIdx % 8 (XCD)", b % 8), ("blockIdx // (nb/2) (dispatch half)", b // max(nb // 2, 1)), ("(blockIdx // 8) % 2", (b // 8) % 2)):
+    print(f"  mean end by {name}: " + " ".join(f"{end[key == k].mean():.1f}" for k in np.unique(key)))
+if nb >= 512:
+    pair = np.abs(end[:nb // 2] - end[nb // 2:])
+    print(f"  |end(b) - end(b + nb/2)| mean {pair.mean():.1f} us; corr(end(b), end(b+nb/2)) = {np.corrcoef(end[:nb // 2], end[nb // 2:])[0, 1]:.2f}")
