@@ -40,7 +40,7 @@ class GuideManagerTrajectoriesWithVelocity:
                  env_id="EnvEmpty2D", obstacle_cutoff_margin=0.05, robot_radius=ROBOT_RADIUS,
                  weight_grad_cost_collision=2e-2, weight_grad_cost_smoothness=8e-2, trajectory_duration=5.0,
                  n_support_points=64, sigma_gp=1.0, n_robots=1, robot_env_ids: Optional[Sequence[str]] = None,
-                 device="cuda", tensor_args=None, **kwargs):
+                 extra_objects_only=False, device="cuda", tensor_args=None, **kwargs):
         if not clip_grad or clip_grad_rule != "norm":
             raise NotImplementedError("MPD uses clip_grad=True, clip_grad_rule='norm' (mpd.py:258-265)")
         self.dataset = dataset
@@ -60,6 +60,10 @@ class GuideManagerTrajectoriesWithVelocity:
         self._n_maps = len(maps)
         from .environments import MAP_BOXES
         self._obstacle_free = all(len(MAP_BOXES[m.replace("ExtraObjects", "")][0]) == 0 for m in maps)
+        # use_guide_on_extra_objects_only (mpd.py:216-219): the only collision field is task.get_collision_fields_extra_objects()
+        # = the env's extra ObjectField, which is EMPTY in every shipped map (env_*_extra_objects.py: MultiSphereField([]),
+        # sdf == 1) -- no fixed-object grid and no workspace walls in the guide; GP prior and constraints stay
+        self.extra_objects_only = bool(extra_objects_only)
         # extra costs, per robot (guides.py:176-178, :228-234)
         self.extra_cost_l: List[List[CostConstraint]] = [[] for _ in range(n_robots)]
         self.extra_costs_grad_weight_l: List[List[float]] = [[] for _ in range(n_robots)]
@@ -106,11 +110,13 @@ class GuideManagerTrajectoriesWithVelocity:
         d.limits_lo[:] = LIMITS[0]
         d.limits_hi[:] = LIMITS[1]
         d.grid_nx, d.grid_ny = self._grids.shape[2], self._grids.shape[3]
-        d.n_grids, d.n_maps = (0 if self._obstacle_free else 1), self._n_maps
+        d.n_grids, d.n_maps = (0 if self._obstacle_free or self.extra_objects_only else 1), self._n_maps
         d.sdf_grids_dev = self._grids.data_ptr()
         d.robot_map_dev = self._robot_map.data_ptr() if self._n_maps > 1 else None
         d.ws_min[:] = [float(np.float32(LIMITS[0][k]) * np.float32(1.08)) for k in range(2)]      # tasks.py:81-83
         d.ws_max[:] = [float(np.float32(LIMITS[1][k]) * np.float32(1.08)) for k in range(2)]
+        if self.extra_objects_only:
+            d.ws_min[:], d.ws_max[:] = [-1e6, -1e6], [1e6, 1e6]      # out of reach: the workspace term is identically 0
         d.margin, d.dt, d.sigma_gp = self.margin, self.dt, self.sigma_gp
         d.weight_collision, d.weight_smoothness = self.weight_collision, self.weight_smoothness
         d.max_grad_norm = self.max_grad_norm

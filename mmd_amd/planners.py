@@ -225,8 +225,6 @@ class MPD:
             self.run_prior_only, self.run_prior_then_guidance = True, False
         else:
             raise NotImplementedError
-        if use_guide_on_extra_objects_only:
-            raise NotImplementedError("extra objects are empty in every shipped map (SURVEY §8a A9)")
         self.device = torch.device(device)
         self.tensor_args = {"device": self.device, "dtype": torch.float32}
         self.model, self.model_args = _load_model(model_id, trained_models_dir, model_state_dict, model_args, self.device)
@@ -246,8 +244,12 @@ class MPD:
             self.dataset, env_id=self.env_id, obstacle_cutoff_margin=obstacle_cutoff_margin,
             weight_grad_cost_collision=weight_grad_cost_collision,
             weight_grad_cost_smoothness=weight_grad_cost_smoothness, trajectory_duration=trajectory_duration,
-            n_support_points=HORIZON, device=self.device)
-        self.task = PlanningTaskFacade(self.guide, self.robot)     # CBS reads planner.task (cbs.py:149)
+            n_support_points=HORIZON, extra_objects_only=use_guide_on_extra_objects_only, device=self.device)
+        # the task's own collision checks (post-processing, compute_collision) always see the full map (tasks.py:141-311)
+        self._task_guide = self.guide if not use_guide_on_extra_objects_only else GuideManagerTrajectoriesWithVelocity(
+            self.dataset, env_id=self.env_id, obstacle_cutoff_margin=obstacle_cutoff_margin, n_support_points=HORIZON,
+            device=self.device)
+        self.task = PlanningTaskFacade(self._task_guide, self.robot)     # CBS reads planner.task (cbs.py:149)
         self.t_start_guide = ceil(start_guide_steps_fraction * self.model.n_diffusion_steps)
         self.n_guide_steps = n_guide_steps
         self.n_diffusion_steps_without_noise = n_diffusion_steps_without_noise
@@ -280,7 +282,7 @@ class MPD:
                 chain = self.run_constrained_local_inference(cost_constraints_l, experience, **kwargs)
         out = PlannerOutput()
         out.t_total = timer.elapsed
-        _fill_output(out, self.guide, self.dataset.unnormalize_trajectories(chain))
+        _fill_output(out, self._task_guide, self.dataset.unnormalize_trajectories(chain))
         out.constraints_l = constraints_l
         self.recent_call_data = out
         return out

@@ -169,6 +169,31 @@ def test_mpd_call_contract():
     assert out3.trajs_iters.shape[0] == 27 + (13 + 1) * 20
 
 
+def test_mpd_guide_on_extra_objects_only():
+    """use_guide_on_extra_objects_only (mpd.py:216-219): the guide's only collision field is the env's extra ObjectField,
+    empty in every shipped map, so the guide is GP prior + constraints (no fixed-object grid, no workspace walls); the
+    planner's own collision checks still see the full map."""
+    import gpu_common
+    from mmd_amd.planners import MPD
+    from oracle import mmd_oracle as O
+    starts, goals = synth.start_goal_circle(10, 0.45)
+    p = MPD(start_state_pos=torch.from_numpy(starts[3]), goal_state_pos=torch.from_numpy(goals[3]),
+            **_mpd_kwargs(use_guide_on_extra_objects_only=True, n_samples=8))
+    x = torch.from_numpy(synth.synth_noise(130, (8, H, D))) * 0.9
+    gp = cases.guide_params("EnvHighways2D")
+    gp.sdf_grids = []
+    gp.ws_min, gp.ws_max = torch.tensor([-1e6, -1e6]), torch.tensor([1e6, 1e6])
+    ref = O.guide_grad(x, gp, [], clip_mode="always")
+    assert float((p.guide(x.cuda()).cpu() - ref).abs().max()) < 2e-6
+    full = gpu_common.hip_guide("EnvHighways2D", [[]])
+    assert float((p.guide(x.cuda()) - full(x.cuda())).abs().max()) > 1e-3          # the map terms really are off
+    out = p(torch.from_numpy(starts[3]), torch.from_numpy(goals[3]))
+    assert torch.isfinite(out.trajs_iters).all()
+    pts = torch.tensor([[0.0, 0.0], [0.45, 0.45], [0.9, -0.2]])
+    expect = O.compute_collision(pts, cases.guide_params("EnvHighways2D"))
+    assert p.task.compute_collision(pts.cuda()).view(-1).cpu().tolist() == expect.tolist() and expect.any()
+
+
 def test_mpd_guidance_reduces_constraint_violations():
     """Domain property at full B=64: with the inter-robot term on, samples keep further from the other robots' paths
     than the unguided prior does."""
