@@ -1,0 +1,122 @@
+// Do the two waves of a SIMD overlap an fp32 MFMA stream with a VALU stream?  One 512-thread workgroup per CU: waves 0..3
+// land on SIMDs 0..3 and waves 4..7 on the same SIMDs again.  Role A (waves 0..3) / role B (waves 4..7) in {idle, MFMA
+// (v_mfma_f32_16x16x4_f32, 16 independent accumulators), VALU (independent v_fma_f32 chains), TRANS (v_exp_f32)}; each
+// active wave runs a fixed amount of work and reports its own cycles (s_memtime).  Usage: mfma_valu_overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+enum { IDLE = 0, MFMA = 1, VALU = 2, TRANS = 3, PK = 4, RCP = 5, LDSR = 6 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void run_mfma(int iters, float* out) {
+  f32x4 m[16];
+  for (int i = 0; i < 16; ++i) m[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, m[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += m[i][0] + m[i][1] + m[i][2] + m[i][3];
+  out[threadIdx.x] = s;
+}
+__device__ __forceinline__ void run_valu(int iters, float* out) {
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 1e-3f + i;
+  const float c = 1.0001f, d = 1e-4f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(v[i], c, d);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[threadIdx.x] = s;
+}
+__device__ __forceinline__ void run_trans(int iters, float* out) {
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 1e-3f + i * 0.01f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __builtin_amdgcn_exp2f(v[i]) * 0.25f;
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[threadIdx.x] = s;
+}
+
+__device__ __forceinline__ void run_pk(int iters, float* out) {   // 16 v_pk_fma_f32 = 32 fp32 FMAs per iteration
+  f32x2 v[16];
+  for (int i = 0; i < 16; ++i) v[i] = f32x2{threadIdx.x * 1e-3f + i, threadIdx.x * 2e-3f - i};
+  const f32x2 c = {1.0001f, 0.9999f}, d = {1e-4f, -1e-4f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __builtin_elementwise_fma(v[i], c, d);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += v[i][0] + v[i][1];
+  out[threadIdx.x] = s;
+}
+__device__ __forceinline__ void run_rcp(int iters, float* out) {
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = 1.0f + threadIdx.x * 1e-3f + i * 0.01f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __builtin_amdgcn_rcpf(v[i]);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[threadIdx.x] = s;
+}
+__device__ __forceinline__ void run_ldsr(int iters, float* out) {   // 16 ds_read_b128 per iteration
+  __shared__ float4 buf[8][64 * 17];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int i = 0; i < 17; ++i) buf[w][l * 17 + i] = make_float4(l, i, 0.f, 1.f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 t = buf[w][l * 17 + ((i + it) & 15)];
+      acc.x += t.x; acc.y += t.y;
+    }
+  }
+  out[threadIdx.x] = acc.x + acc.y;
+}
+
+__global__ __launch_bounds__(512) void k(int roleA, int roleB, int iters, float* out, long long* cyc) {
+  const int wave = threadIdx.x >> 6;
+  const int role = wave < 4 ? roleA : roleB;
+  __syncthreads();
+  const long long t0 = __builtin_readcyclecounter();
+  if (role == MFMA) run_mfma(iters, out + blockIdx.x * 512);
+  else if (role == VALU) run_valu(iters, out + blockIdx.x * 512);
+  else if (role == TRANS) run_trans(iters, out + blockIdx.x * 512);
+  else if (role == PK) run_pk(iters, out + blockIdx.x * 512);
+  else if (role == RCP) run_rcp(iters, out + blockIdx.x * 512);
+  else if (role == LDSR) run_ldsr(iters, out + blockIdx.x * 512);
+  const long long t1 = __builtin_readcyclecounter();
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+int main() {
+  const int nb = 256, iters = 2000;
+  float* out; long long* cyc;
+  hipMalloc(&out, nb * 512 * sizeof(float));
+  hipMalloc(&cyc, nb * 8 * sizeof(long long));
+  const char* names[] = {"idle", "MFMA", "VALU", "TRANS", "PK", "RCP", "LDSR"};
+  std::vector<long long> h(nb * 8);
+  for (int a = 0; a < 7; ++a)
+    for (int b = 0; b < 7; ++b) {
+      if (a == IDLE && b == IDLE) continue;
+      if (a != IDLE && a != MFMA && b != IDLE && b != MFMA && a != b) continue;   // alone, paired with MFMA, or with itself
+      hipLaunchKernelGGL(k, dim3(nb), dim3(512), 0, 0, a, b, iters, out, cyc);
+      hipLaunchKernelGGL(k, dim3(nb), dim3(512), 0, 0, a, b, iters, out, cyc);
+      hipDeviceSynchronize();
+      hipMemcpy(h.data(), cyc, nb * 8 * sizeof(long long), hipMemcpyDeviceToHost);
+      double ca = 0, cb = 0;
+      for (int i = 0; i < nb; ++i) for (int w = 0; w < 8; ++w) (w < 4 ? ca : cb) += h[i * 8 + w];
+      ca /= nb * 4; cb /= nb * 4;
+      printf("A=%-5s B=%-5s : A %8.1f cycles per 16-op iteration, B %8.1f\n", names[a], names[b], a ? ca / iters : 0.0, b ? cb / iters : 0.0);
+    }
+  return 0;
+}
