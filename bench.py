@@ -41,8 +41,8 @@ HEADLINE_ROBOTS = 32               # BASELINE.json: 32-robot Empty map
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N>1: strong = the metric's 32-robot instance sharded 32/N robots per GPU; weak = 32 robots per "
                          "GPU of a 32N-robot instance")
