@@ -835,7 +835,7 @@ __device__ __forceinline__ void quad1_to_stage_u(const f32x4 (&q)[4], float* dst
 // reads (V form at L = 16, row form otherwise); it is called by EVERY wave of the workgroup.  WAVES = 8 (small-batch
 // kernel): the 4 (M, N) units of the RTBs run on waves 0..3 (the other four only take part in the barriers, the skip
 // write and the tail conv, whose 8 units = 2 parity passes x 4 tiles are one per wave).
-template <class CF, int WAVES, class SKIPW>
+template <class CF, int WAVES, class SKIPW, int SMP = 4>
 __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int n0, int lane, int wave, SKIPW skip_write,
                                                f32x16 (&tout)[8 / WAVES][CF::MT_W], int trb) {
   static_assert((CF::L == 16 || CF::L == 32) && CF::CM * CF::L == 1024 && CF::C1 == CF::C0 && CF::RES0 == RES_CONV &&
@@ -844,7 +844,8 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   // other, then H), all aliasing each other and the row-form H slab of the tail conv; barriers separate the phases
   constexpr bool VH = CF::L == 16;
   static_assert(!VH || CF::C0P == 128, "V-form ups.0: 128-channel chunks from the L = 16 down stage");
-  const bool act = WAVES == 4 || wave < 4;
+  // SMP = 1: the workgroup owns one sample = M tile 0 only (ups.1: waves 0, 1)
+  const bool act = (WAVES == 4 || wave < 4) && (SMP == 4 || (wave & 3) / (CF::CM / 16) == 0);
   float* hslab = VH ? lds : lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, NTQ = CF::CM / 16;
@@ -976,6 +977,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     constexpr int G = 2 * CF::CM / 8;
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
+      if (SMP == 1 && wm != 0) break;                                    // one sample: its rows are in the first M tile
       const int pass = WAVES == 4 ? pp : (wave >> 2);
       f32x16 (&t)[MT_W] = tout[pp];
       fill<MT_W>(t, bt);
@@ -995,17 +997,29 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 // the chip twice over (<= 1024 trajectories).  Arithmetic (k order, reductions) is identical to the two-n-tile body, so
 // the two kernels agree bit for bit.
 // ----------------------------------------------------------------------------------------------------------------
-template <class CF, bool FIRST, int WAVES>
+// SMP = 1 (unet_kernel_1): the workgroup owns ONE sample, i.e. only M tile 0 (whose other rows belong to samples that are
+// zero-filled and ignored): units = the CM / 16 n-tiles, spread over the waves; waves without a unit only take part in
+// the barriers.
+template <int WAVES, int SMP, int NTQ> struct DnTiling {
+  static constexpr int UNITS = SMP == 4 ? 8 : NTQ;
+  static constexpr int TPW = UNITS >= WAVES ? UNITS / WAVES : 1;
+  static constexpr int NACT = UNITS / TPW;          // waves that own units
+};
+template <class CF, bool FIRST, int WAVES, int SMP = 4>
 __device__ __forceinline__ void chain_body_dn(const ChainArgs& a, float* lds, int n0, int lane, int wave,
-                                              f32x4 (&acc)[8 / WAVES][4], f32x4 (&mid)[8 / WAVES][4], f32x16 (&tout)[1],
+                                              f32x4 (&acc)[DnTiling<WAVES, SMP, CF::CM / 16>::TPW][4],
+                                              f32x4 (&mid)[DnTiling<WAVES, SMP, CF::CM / 16>::TPW][4], f32x16 (&tout)[1],
                                               int trb) {
   static_assert((CF::L == 16 || CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 &&
                     CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP, "down-path stage: (L / 16 M tiles) x (CM / 16 n-tiles) = 8 units");
-  constexpr int TPW = 8 / WAVES, NTQ = CF::CM / 16, QPS = CF::L / 4;
+  constexpr int NTQ = CF::CM / 16, QPS = CF::L / 4;
+  using TL = DnTiling<WAVES, SMP, NTQ>;
+  constexpr int TPW = TL::TPW;
   constexpr bool VH = CF::L == 16;
   float* hslab = VH ? lds : lds + CF::XSLAB;
   float* xslab = lds;
-  const int u0 = wave * TPW, mt = u0 / NTQ;                            // the wave's units u0 .. u0 + TPW - 1 share one M tile
+  const bool act = wave < TL::NACT;
+  const int u0 = act ? wave * TPW : 0, mt = u0 / NTQ;                   // the wave's units u0 .. u0 + TPW - 1 share one M tile
   const int ai = mt * 16 + (lane & 15);
   const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
   const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
@@ -1021,9 +1035,10 @@ __device__ __forceinline__ void chain_body_dn(const ChainArgs& a, float* lds, in
   auto wl3 = [&](const float4* w, int cp, int nq) {
     return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
   };
-  w4_ring_load<3>(ring3, wl3(a.r0.wa, CF::C0P, nq_of(0)));
+  if (act) w4_ring_load<3>(ring3, wl3(a.r0.wa, CF::C0P, nq_of(0)));
   if constexpr (FIRST)
-    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS, WAVES * 64>(xslab, a.in0, nullptr, n0, a.n);
+    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS, WAVES * 64>(
+        xslab, a.in0, nullptr, n0, SMP == 4 ? a.n : (n0 + 1 < a.n ? n0 + 1 : a.n));
   if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, WAVES * 64>(hslab);
   __syncthreads();
 
@@ -1068,6 +1083,7 @@ __device__ __forceinline__ void chain_body_dn(const ChainArgs& a, float* lds, in
   // =================== RTB 0 (C0 -> CM) with its 1x1 residual conv fused into conv A (row-form x slab) ===================
 #pragma unroll
   for (int h = 0; h < TPW; ++h) {
+    if (!act) break;
     const float br = a.br[col_of(h)];
 #pragma unroll
     for (int o = 0; o < 4; ++o) res[h][o] = f32x4{br, br, br, br};
@@ -1076,12 +1092,14 @@ __device__ __forceinline__ void chain_body_dn(const ChainArgs& a, float* lds, in
     else w4_ring_load<2>(ring, wl(a.r0.wb, CF::CM, nq_of(0)));
     w4n1_out(acc[h], m);
   }
-  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
+  if (act) gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
   if constexpr (VH) __syncthreads();                         // conv A is done reading the x slab the V-form H slab aliases
-  to_h();
+  if (act) to_h();
   __syncthreads();
-  conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
+  if (act) {
+    conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
+    gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
+  }
   if constexpr (CF::MID_AFTER == 0) {
 #pragma unroll
     for (int h = 0; h < TPW; ++h)
@@ -1098,15 +1116,19 @@ __device__ __forceinline__ void chain_body_dn(const ChainArgs& a, float* lds, in
 #pragma unroll
       for (int i = 0; i < 4; ++i) res[h][i] = acc[h][i];
     __syncthreads();                                         // the previous conv is done reading the H slab
-    to_h();
+    if (act) to_h();
     __syncthreads();
-    conv_h(R.wa, R.wb);
-    gn(R.ba, R.ga, R.bea, R.tb);
+    if (act) {
+      conv_h(R.wa, R.wb);
+      gn(R.ba, R.ga, R.bea, R.tb);
+    }
     __syncthreads();
-    to_h();
+    if (act) to_h();
     __syncthreads();
-    conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
-    gn(R.bb, R.gb, R.beb, nullptr);
+    if (act) {
+      conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
+      gn(R.bb, R.gb, R.beb, nullptr);
+    }
     if (CF::MID_AFTER == k + 1) {
 #pragma unroll
       for (int h = 0; h < TPW; ++h)
@@ -1119,9 +1141,10 @@ __device__ __forceinline__ void chain_body_dn(const ChainArgs& a, float* lds, in
   if constexpr (CF::TAIL == TAIL_DOWN) {
     static_assert(!VH, "the strided tail conv reads a row-form H slab");
     __syncthreads();
-    to_h();
+    if (act) to_h();
     __syncthreads();
-    if (wave < 4) {
+    // 4 tail units (32 output rows x 32 channels each); one sample: only those whose rows are the sample's
+    if (wave < (SMP == 4 ? 4 : (CF::L == 64 ? 1 : CF::WN))) {
       constexpr int LO = CF::L / 2;
       const int wm = wave / CF::WN, wn = wave % CF::WN, hi = lane >> 5;
       fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
@@ -1145,9 +1168,15 @@ using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.
 using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
 constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
 
+struct OneArgs {           // role packs of the L = 16 stages (unet_kernel_1); same biases / affine / time tables as ChainArgs
+  const float* d2_a;       // downs.2 conv A: [4 roles][64 + 4][64 lanes][8]  (main float4, wr)
+  const float* d2_h[7];    // downs.2 conv B, mid1 A/B, mid2 A/B ... in execution order: [4 roles][128 + 4][64][4]
+};
+
 struct UnetArgs {
   ChainArgs c[5];
   ChainArgs c2s;        // downs.2 + mid blocks with one-n-tile weight packs (unet_kernel runs that stage tile by tile)
+  OneArgs one;          // role packs of the one-sample kernel's L = 16 stages
   FinalArgs fin;
   int n;
 };
@@ -1385,6 +1414,332 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MMD_S_WAVES
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// One-sample machinery for the L = 16 stages: v_mfma_f32_4x4x1_16B_f32.  At L = 16 a sample is 4 quads = the 4 rows of that
+// shape's blocks; its 16 blocks are 16 groups of 4 output channels (64 channels per instruction), K = 1 (one input
+// channel).  One instruction is 512 FLOP in 9.5 cycles (tools/ubench/mfma_4x4.hip) -- 84 % of the 16x16x4 rate with no row
+// wasted, where the 16x16x4 tile would carry 12 rows of other samples -- and a chain of them over the input channels is
+// the same k-ascending fmaf chain the 16x16x4 runs, so the results stay bit-identical.
+//   A operand: lane l holds row (quad) l & 3, replicated over the blocks: V1[channel][quad][8 positions], read with ONE
+//              ds_read_b128 per channel because the positions are stored in the order (0, 1, 2, 7 | 3, 4, 5, 6) of the two
+//              position sets the wave pairs split;
+//   B operand: lane l holds output channel n0 + l: per role and channel one float4 of the Winograd weights of its positions;
+//   C/D:       lane l = channel n0 + l, register = quad: the lane holds all 16 positions of its channel again, so the
+//              output transform, GroupNorm + Mish and the V transform of the epilogue are the code of the other kernels.
+// Waves: (N half h = wave & 1) x (position set s = wave >> 1) at 128 output channels (downs.2 / mid), four position
+// groups at 64 (ups.0).  After the K loop the set-1 waves hand their accumulators to the set-0 wave of their half through
+// LDS; it transforms them in the original association (the sets {0,1,2,7} | {3,4,5,6} never split a sum of w4n1_out).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int V1S = 4 * VROW + 4;          // channel stride of the one-sample V slab (36 floats: conflict-free b128 writes)
+constexpr int XQS = 16;                    // [channel][quad][4 positions of the quad]: the residual conv's untransformed rows
+
+template <class GET>
+__device__ __forceinline__ void vform_store1(float* vb, GET x) {      // vb = slab + channel * V1S; x(o, r) = position 4 r + o
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float d[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pos = 4 * r - 2 + j;
+      d[j] = (pos < 0 || pos > 15) ? 0.f : x(pos & 3, pos >> 2);
+    }
+    w4_transform(v, d);
+    *reinterpret_cast<float4*>(vb + r * VROW) = make_float4(v[0], v[1], v[2], v[7]);
+    *reinterpret_cast<float4*>(vb + r * VROW + 4) = make_float4(v[3], v[4], v[5], v[6]);
+  }
+}
+
+// acc[i] += A_c[i] x B_c[i] over C channels, i < NM accumulators (vector index = quad); optional RESD direct residual:
+// r[j] += Xq_c[o0 + j] x wr_c (the 1x1 conv's rows 4 t + o).  ap = the lane's float4 of channel 0 (role / quad offset
+// applied), stride V1S; xq likewise with stride XQS; wp = the lane's floats of channel 0 in the role's pack, PK floats
+// per (channel, lane), [main float4][wr, 0, 0, 0 if RESD].  Ring of 4 channels of weights, A double-buffered; both
+// over-read 4 channels past the end (slabs and packs carry the slack).
+template <int C, int NM, bool RESD>
+__device__ __forceinline__ void x4_taps(f32x4 (&m)[8], f32x4 (&r)[2], const float* ap, const float* xq, int o0,
+                                        const float* __restrict__ wp) {
+  constexpr int PK = RESD ? 8 : 4, CST = 64 * PK;
+  static_assert(C % 4 == 0 && NM >= 2 && NM <= 4, "channels are unrolled by 4");
+  float4 b[4], a[2][4];
+  float wr[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 xa[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    b[j] = *reinterpret_cast<const float4*>(wp + j * CST);
+    if constexpr (RESD) wr[j] = wp[j * CST + 4];
+    a[0][j] = *reinterpret_cast<const float4*>(ap + j * V1S);
+    if constexpr (RESD) xa[0][j] = *reinterpret_cast<const float4*>(xq + j * XQS);
+  }
+  MMD_PIN_LOADS();
+  auto body = [&](int cur) {
+    wp += 4 * CST; ap += 4 * V1S; xq += 4 * XQS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[cur ^ 1][j] = *reinterpret_cast<const float4*>(ap + j * V1S);
+      if constexpr (RESD) xa[cur ^ 1][j] = *reinterpret_cast<const float4*>(xq + j * XQS);
+    }
+    MMD_PIN_LOADS();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float av[4] = {a[cur][j].x, a[cur][j].y, a[cur][j].z, a[cur][j].w};
+      const float bv[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+#pragma unroll
+      for (int i = 0; i < NM; ++i) m[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], bv[i], m[i], 0, 0, 0);
+      if constexpr (RESD) {
+        const float xv[4] = {xa[cur][j].x, xa[cur][j].y, xa[cur][j].z, xa[cur][j].w};
+        r[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(o0 ? xv[2] : xv[0], wr[j], r[0], 0, 0, 0);
+        r[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(o0 ? xv[3] : xv[1], wr[j], r[1], 0, 0, 0);
+      }
+      b[j] = *reinterpret_cast<const float4*>(wp + j * CST);
+      if constexpr (RESD) wr[j] = wp[j * CST + 4];
+    }
+    MMD_PIN_LOADS();
+  };
+#pragma unroll 1
+  for (int c = 0; c < C; c += 8) {
+    body(0);
+    body(1);
+  }
+}
+
+// scratch hand-over of NV f32x4 per lane (elements OFF .. OFF + NV - 1 of an array): [slot][lane][4 * NV] floats
+template <int NV, int OFF, int N>
+__device__ __forceinline__ void x4_put(float* scr, int slot, int lane, const f32x4 (&v)[N]) {
+  float4* p = reinterpret_cast<float4*>(scr + ((size_t)slot * 64 + lane) * (4 * NV));
+#pragma unroll
+  for (int i = 0; i < NV; ++i) p[i] = make_float4(v[OFF + i][0], v[OFF + i][1], v[OFF + i][2], v[OFF + i][3]);
+}
+template <int NV, int OFF, int N>
+__device__ __forceinline__ void x4_get(const float* scr, int slot, int lane, f32x4 (&v)[N]) {
+  const float4* p = reinterpret_cast<const float4*>(scr + ((size_t)slot * 64 + lane) * (4 * NV));
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 t = p[i];
+    v[OFF + i] = f32x4{t.x, t.y, t.z, t.w};
+  }
+}
+
+
+// downs.2 + mid blocks for ONE sample.  LDS: [x row-form slab of the 4-sample layout (written by downs.1's tail)]
+// [V1 slab: conv A's transformed input, then H][Xq][hand-over scratch].
+constexpr int ONE_V = CH_D2::XSLAB, ONE_XQ = ONE_V + (128 + 4) * V1S, ONE_SCR = ONE_XQ + (64 + 4) * XQS;
+static_assert(ONE_SCR + 2 * 64 * 24 <= UNET_LDS_FLOATS, "one-sample LDS map of downs.2");
+__device__ __forceinline__ void d2_one(const ChainArgs& a, const OneArgs& w1, float* lds, int lane, int wave,
+                                       f32x4 (&acc)[4], f32x4 (&mid)[4]) {
+  using CF = CH_D2;
+  const int h = wave & 1, s = wave >> 1, n = 64 * h + lane;          // N half, position set, the lane's channel
+  float* vs = lds + ONE_V;
+  float* xqs = lds + ONE_XQ;
+  float* scr = lds + ONE_SCR;
+  __syncthreads();                                            // downs.1's tail tile and the halo zeros are in the x slab
+  // ---- x (row form, sample 0) -> V1 (positions permuted) + Xq: one (channel, quad) per thread
+  {
+    const int c = threadIdx.x >> 2, t = threadIdx.x & 3;
+    float d[8], v[8];
+    load_d8<CF::XSTR>(d, lds + 4 * t * CF::XSTR + c);
+    w4_transform(v, d);
+    *reinterpret_cast<float4*>(vs + c * V1S + t * VROW) = make_float4(v[0], v[1], v[2], v[7]);
+    *reinterpret_cast<float4*>(vs + c * V1S + t * VROW + 4) = make_float4(v[3], v[4], v[5], v[6]);
+    *reinterpret_cast<float4*>(xqs + c * XQS + t * 4) = make_float4(d[2], d[3], d[4], d[5]);
+  }
+  __syncthreads();
+  f32x4 m[8], res[4], r2[2];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const int aoff = (lane & 3) * VROW + s * 4;
+  // one conv: K loop on all four waves, set-1 accumulators handed to set 0, output transform in wave (h, 0)
+  auto finish = [&](bool with_res) {
+    if (s == 1) {
+      x4_put<4, 0>(scr, h, lane, m);
+      if (with_res) x4_put<2, 0>(scr + 2 * 64 * 16, h, lane, r2);
+    }
+    __syncthreads();
+    if (s == 0) {
+      // m[0..3] holds positions (0, 1, 2, 7); fetch (3, 4, 5, 6) into m[3..6] and restore the natural order
+      m[7] = m[3];
+      x4_get<4, 3>(scr, h, lane, m);
+      if (with_res) {
+        res[0] = r2[0]; res[1] = r2[1];
+        x4_get<2, 2>(scr + 2 * 64 * 16, h, lane, res);
+      }
+      w4n1_out(acc, m);
+    }
+  };
+  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
+    if (MMD_ABL == 1) return;
+    if (tb) {
+      const float t0 = tb[n];
+      gn_mish_quad1<CF::CM, CF::L>(acc, b[n], g[n], be[n], [&](int, int) { return t0; });
+    } else {
+      gn_mish_quad1<CF::CM, CF::L>(acc, b[n], g[n], be[n], [&](int o, int r) { return res[o][r]; });
+    }
+  };
+  auto to_h = [&]() { vform_store1(vs + n * V1S, [&](int o, int r) { return acc[o][r]; }); };
+  auto conv_h = [&](const float* pack) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = z;
+    x4_taps<CF::CM, 4, false>(m, r2, vs + aoff, xqs, 0,
+                              pack + ((size_t)wave * (CF::CM + 4) * 64 + lane) * 4);
+    finish(false);
+  };
+  // =================== RTB 0: conv A (64 -> 128) with the direct 1x1 residual conv (rows 4 t + o) ===================
+  {
+    const float br = a.br[n];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = z;
+    r2[0] = f32x4{br, br, br, br};
+    r2[1] = r2[0];
+    x4_taps<CF::C0P, 4, true>(m, r2, vs + aoff, xqs + (lane & 3) * 4, 2 * s,
+                              w1.d2_a + ((size_t)wave * (CF::C0P + 4) * 64 + lane) * 8);
+    finish(true);
+  }
+  if (s == 0) {
+    gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
+    to_h();                                                   // (the hand-over barrier separated it from every K loop)
+  }
+  __syncthreads();
+  conv_h(w1.d2_h[0]);
+  if (s == 0) gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
+  // =================== identity RTBs (downs.2's second block, mid_block1, mid_block2) ===================
+#pragma unroll
+  for (int k = 0; k < CF::N_IDENT; ++k) {
+    const RtbPtrs& R = a.ri[k];
+    if (s == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) res[i] = acc[i];
+      to_h();
+    }
+    __syncthreads();
+    conv_h(w1.d2_h[1 + 2 * k]);
+    if (s == 0) {
+      gn(R.ba, R.ga, R.bea, R.tb);
+      to_h();
+    }
+    __syncthreads();
+    conv_h(w1.d2_h[2 + 2 * k]);
+    if (s == 0) gn(R.bb, R.gb, R.beb, nullptr);
+    if (CF::MID_AFTER == k + 1 && s == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mid[i] = acc[i];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// ONE-SAMPLE kernel (unet_kernel_1, <= 512 trajectories): one trajectory per workgroup (4 waves), so a launch of 256 / 512
+// trajectories -- a rank's share of the 32-robot instance on 8 / 4 GPUs, config 5's shard -- spreads over all 256 CUs
+// instead of leaving 3 / 4 or half of them idle.  The workgroup computes only the M tile that holds its sample (the
+// other rows of that tile belong to zero-filled / ignored samples); bit-identical to the other two kernels.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel_1(UnetArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x;
+
+  f32x4 skip1[1][4], skip2[4];
+  TR(200);
+  // ---- downs.0 @ L=64: 2 units (waves 0, 1)
+  {
+    f32x4 acc[1][4], mid[1][4];
+    f32x16 t[1];
+    chain_body_dn<CH_D0, true, 4, 1>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
+    __syncthreads();
+    if (wave < 1) tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
+    zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
+  }
+  TR(201);
+  // ---- downs.1 @ L=32: 4 units, skip1
+  {
+    f32x4 acc[1][4];
+    f32x16 t[1];
+    chain_body_dn<CH_D1, false, 4, 1>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
+    __syncthreads();
+    if (wave < CH_D1::WN) tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
+    zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
+  }
+  TR(202);
+  // ---- downs.2 + mid blocks @ L=16 on the 4x4x1 MFMA: waves (N half) x (position set); acc / skip2 live in the set-0 waves
+  f32x4 acc2[4];
+  {
+    d2_one(a.c[2], a.one, lds, lane, wave, acc2, skip2);
+    __syncthreads();
+    // chunk 0 of ups.0's conv A input in the 4-sample V layout the (still 16x16x4) ups.0 body reads: sample 0 = rows 0..3
+    if ((wave >> 1) == 0) vform_store(lds + (64 * (wave & 1) + lane) * VCS, [&](int o, int r) { return acc2[o][r]; });
+  }
+  TR(203);
+  // ---- ups.0 @ L=16: 4 units
+  {
+    f32x16 t[2][1];
+    auto sw = [&](float* xs) {
+      if ((wave >> 1) == 0) vform_store(xs + (64 * (wave & 1) + lane) * VCS, [&](int o, int r) { return skip2[o][r]; });
+    };
+    chain_body_w4u<CH_U0, 4, decltype(sw), 1>(a.c[3], lds, n0, lane, wave, sw, t, 136);
+    __syncthreads();
+    if (wave / CH_U0::WN == 0) {
+      tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
+      tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
+    }
+    zero_halo<CH_U1::C0P, CH_U1::L, CH_U1::SROWS, CH_U1::XSTR, CH_U1::XSS, 4>(lds);
+  }
+  TR(204);
+  // ---- ups.1 @ L=32: 2 units (waves 0, 1)
+  {
+    f32x16 t[2][1];
+    auto sw = [&](float* xs) { quad1_to_stage_u<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1[0], xs, 0, wave, lane); };
+    chain_body_w4u<CH_U1, 4, decltype(sw), 1>(a.c[4], lds, n0, lane, wave, sw, t, 146);
+    __syncthreads();
+    if (wave / CH_U1::WN == 0) {
+      tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
+      tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
+    }
+    zero_halo<32, 64, FIN_SROWS, FIN_STR, FIN_SS, 4>(lds);
+    __syncthreads();
+  }
+  TR(205);
+  // ---- final_conv: waves 0, 1 = the two 16-channel n-tiles / 32-row halves of the sample
+  {
+    const FinalArgs& f = a.fin;
+    const int half = wave & 1;
+    const bool act = wave < 2;
+    f32x4 q[4];
+    if (act) {
+      f32x4 m[8], nores[4];
+      BQ<2> ring[W4_RD];
+      const float* w0 = reinterpret_cast<const float*>(f.wpk) + ((size_t)half * 8 * 64 + lane) * 8;
+      w4_ring_load<2>(ring, w0);
+      w4_taps<32, FIN_STR, 1, false, true>(m, nores, lds, 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
+      w4n1_out(q, m);
+      const int c = half * 16 + (lane & 15);
+      if (MMD_ABL != 1) gn_mish_quad1<32, 64>(q, f.bias[c], f.gamma[c], f.beta[c], [](int, int) { return 0.f; });
+    }
+    __syncthreads();                                                       // both waves are done reading the slab
+    float* yt = lds;
+    if (act) {
+      float* base = yt + 16 * (lane >> 4) * 33 + half * 16 + (lane & 15);  // rows 16 * block + 4 * quad + o
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[(4 * r + o) * 33] = q[o][r];
+    }
+    __syncthreads();
+    if (act) {
+      const int col = lane & 31, hi = lane >> 5;
+      f32x16 acc2[1];
+      int ybase[1] = {(half * 32 + (lane & 31)) * 33 + hi};
+      fill<1>(acc2, col < 4 ? f.w1_bias[col] : 0.f);
+      mfma_taps<1, 32, 33, 1>(acc2, yt, ybase, f.w1_pk + lane);
+      if (col < 4 && n0 < a.n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          f.out[((size_t)n0 * 64 + row) * 4 + col] = acc2[0][r];
+        }
+      }
+    }
+  }
+  TR(206);
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------
 // time embedding table: TimeEncoder (layers.py:232-258) + every block's cond_mlp (layers.py:337-341) for all integer t
 // ----------------------------------------------------------------------------------------------------------------
 struct TimeArgs {
@@ -1574,6 +1929,43 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_
         }
 }
 
+// Role pack of the one-sample kernel (4x4x1 MFMA): [channel c_lo .. c_hi + 4 zero channels][lane][PK] floats for the 64
+// output channels n0 + lane.  cols[i] (i < 4) and col4 (PK = 8: float 4) select what a float holds: 0..7 = Winograd
+// position p of U = G g; 8 / 9 / 10 = the 1x1 residual weight x G[1][2] / G[3][2] / G[5][2] (Winograd-domain residual);
+// 11 = the residual weight itself (direct residual); -1 = 0.
+static void pack_x4_role(std::vector<float>& blob, const float* w, int cin_full, int c_lo, int c_hi, int n0,
+                         const int (&cols)[4], int col4, const float* wres, int PK) {
+  static const double G[8][5] = {{-1, 0, 0, 0, 0},
+                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                 {0, 0, 0, 0, 1}};
+  const int nc = c_hi - c_lo;
+  const size_t base = blob.size();
+  blob.resize(base + (size_t)(nc + 4) * 64 * PK, 0.f);
+  auto value = [&](int code, int n, int ci) -> float {
+    if (code < 0) return 0.f;
+    if (code < 8) {
+      const float* g = w + ((size_t)n * cin_full + ci) * 5;
+      double u = 0.0;
+      for (int k = 0; k < 5; ++k) u += G[code][k] * (double)g[k];
+      return (float)u;
+    }
+    const double wr = (double)wres[(size_t)n * cin_full + ci];
+    if (code == 11) return (float)wr;
+    return (float)(wr * G[1 + 2 * (code - 8)][2]);
+  };
+  for (int c = 0; c < nc; ++c)
+    for (int lane = 0; lane < 64; ++lane) {
+      float* out = &blob[base + ((size_t)c * 64 + lane) * PK];
+      for (int i = 0; i < 4; ++i) out[i] = value(cols[i], n0 + lane, c_lo + c);
+      if (PK == 8) out[4] = value(col4, n0 + lane, c_lo + c);
+    }
+}
+
 struct ConvW { size_t wpk, bias, gamma, beta; };
 struct RtbW { ConvW a, b; size_t res_bias; int tb_off; size_t a_c1; };
 
@@ -1590,6 +1982,7 @@ struct mmd_unet_s {
   RtbW rtb_s[12];            // the same with one-n-tile weight packs for the down path / mid blocks (unet_kernel_s)
   ConvW down[2], up[2], fin;
   size_t fin_s_wpk = 0;      // one-n-tile pack of the final block's k5 conv
+  size_t one_d2a = 0, one_d2h[7] = {};   // role packs of unet_kernel_1 (downs.2 + mid blocks)
   size_t fin_w1, fin_b1;
 };
 
@@ -1731,6 +2124,26 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   }
   u->fin.wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 2, nullptr);
   u->fin_s_wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 1, nullptr);
+  {
+    // one-sample kernel, downs.2 + mid blocks (128 output channels): role = (N half h) + 2 * (position set), sets
+    // (0, 1, 2, 7) | (3, 4, 5, 6)
+    static const int kSet[2][4] = {{0, 1, 2, 7}, {3, 4, 5, 6}};
+    static const int kD2[] = {4, 5, 10, 11};
+    const Rtb& R0 = s.rtb[kD2[0]];
+    while (blob.size() % 4) blob.push_back(0.f);
+    u->one_d2a = blob.size();
+    for (int role = 0; role < 4; ++role)
+      pack_x4_role(blob, tensors[R0.t_w0], R0.cin, 0, R0.cin, 64 * (role & 1), kSet[role >> 1], 11, tensors[R0.t_rw], 8);
+    int k = 0;
+    for (int j = 0; j < 4; ++j) {
+      const Rtb& R = s.rtb[kD2[j]];
+      for (int ab = (j == 0 ? 1 : 0); ab < 2; ++ab) {
+        u->one_d2h[k++] = blob.size();
+        for (int role = 0; role < 4; ++role)
+          pack_x4_role(blob, tensors[ab ? R.t_w1 : R.t_w0], R.cout, 0, R.cout, 64 * (role & 1), kSet[role >> 1], -1, nullptr, 4);
+      }
+    }
+  }
   u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
   u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
   u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
@@ -1808,8 +2221,8 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};
   // <= 1024 trajectories cannot put two workgroups on a CU: the launch is bound by one workgroup's dependent chain, which the
   // 8-wave kernel halves.  MMD_AMD_UNET_KERNEL = big | small forces one of them (A/B measurements).
-  bool small = n <= 1024;
-  if (const char* e = getenv("MMD_AMD_UNET_KERNEL")) small = e[0] == 's';
+  bool small = n <= 1024, one = false;   // `one` (unet_kernel_1) is opt-in until it wins: MMD_AMD_UNET_KERNEL=one
+  if (const char* e = getenv("MMD_AMD_UNET_KERNEL")) { small = e[0] == 's' || e[0] == 'o'; one = e[0] == 'o'; }
   const RtbW* set = small ? u->rtb_s : u->rtb;
   UnetArgs a{};
   a.n = n;
@@ -1819,6 +2232,8 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.c2s = args_chain(u, u->rtb_s, kD2, 3, nullptr, nullptr, t, n);
   a.c[3] = args_chain(u, set, kU0, 1, &u->up[0], nullptr, t, n);
   a.c[4] = args_chain(u, set, kU1, 1, &u->up[1], nullptr, t, n);
+  a.one.d2_a = u->blob + u->one_d2a;
+  for (int k = 0; k < 7; ++k) a.one.d2_h[k] = u->blob + u->one_d2h[k];
   a.fin.out = eps;
   a.fin.wpk = reinterpret_cast<const float4*>(u->blob + (small ? u->fin_s_wpk : u->fin.wpk));
   a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
@@ -1826,7 +2241,8 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.fin.w1_bias = u->blob + u->fin_b1;
   const bool bracket = prof && (prof->seen++ % prof->stride) == 0 && prof->used + 2 <= prof->ev.size();
   if (bracket) (void)hipEventRecord(prof->ev[prof->used], st);
-  if (small) hipLaunchKernelGGL(unet_kernel_s, dim3((n + 3) / 4), dim3(512), 0, st, a);
+  if (one) hipLaunchKernelGGL(unet_kernel_1, dim3(n), dim3(256), 0, st, a);
+  else if (small) hipLaunchKernelGGL(unet_kernel_s, dim3((n + 3) / 4), dim3(512), 0, st, a);
   else hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
   if (bracket) { (void)hipEventRecord(prof->ev[prof->used + 1], st); prof->used += 2; }
   MMD_HIP_CHECK(hipGetLastError());

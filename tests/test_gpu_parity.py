@@ -70,23 +70,26 @@ def test_unet_forward_batch_independence():
 
 
 def test_unet_kernels_agree_bitwise(monkeypatch):
-    """unet_kernel (4 waves, two workgroups per CU) and unet_kernel_s (8 waves, <= 1024 trajectories) run the same
-    arithmetic in the same order: forced through MMD_AMD_UNET_KERNEL they agree bit for bit at small, ragged and large n,
-    and both meet the oracle bound."""
+    """unet_kernel (4 waves x 4 samples, two workgroups per CU), unet_kernel_s (8 waves, <= 1024 trajectories) and
+    unet_kernel_1 (one sample per workgroup) run the same arithmetic in the same order: forced through
+    MMD_AMD_UNET_KERNEL they agree bit for bit at small, ragged and large n, and meet the oracle bound."""
     model = _gc().hip_model(100)
     sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
     for n in (3, 64, 1026):
         x = torch.from_numpy(synth.synth_noise(300 + n, (n, H, D))).cuda()
-        monkeypatch.setenv("MMD_AMD_UNET_KERNEL", "big")
-        big = model.model(x, 41)
-        monkeypatch.setenv("MMD_AMD_UNET_KERNEL", "small")
-        small = model.model(x, 41)
+        outs = {}
+        for k in ("big", "small", "one"):
+            monkeypatch.setenv("MMD_AMD_UNET_KERNEL", k)
+            outs[k] = model.model(x, 41)
         monkeypatch.delenv("MMD_AMD_UNET_KERNEL")
-        assert torch.equal(big, small), n
-        assert torch.equal(model.model(x, 41), small if n <= 1024 else big)
+        assert torch.isfinite(outs["one"]).all()
+        assert torch.equal(outs["big"], outs["small"]), n
+        assert torch.equal(outs["big"], outs["one"]), n
+        auto = model.model(x, 41)
+        assert torch.equal(auto, outs["big"])
         if n <= 64:
             ref = O.unet_forward(sd, x.cpu(), torch.full((n,), 41, dtype=torch.long))
-            assert rel_l2(small.cpu(), ref) < 2e-5
+            assert rel_l2(auto.cpu(), ref) < 2e-5
 
 
 def test_unet_forward_golden():

@@ -83,9 +83,53 @@ __device__ __forceinline__ void run_ldsr(int iters, float* out) {   // 16 ds_rea
   out[threadIdx.x] = acc.x + acc.y;
 }
 
-__global__ __launch_bounds__(512) void k(int roleA, int roleB, int iters, float* out, long long* cyc) {
+// MIX: one wave interleaves NV independent v_fma_f32 after every MFMA (does VALU issue in the MFMA's shadow?)
+template <int NV>
+__device__ __forceinline__ void run_mix(int iters, float* out) {
+  f32x4 m[16];
+  float v[16];
+  for (int i = 0; i < 16; ++i) { m[i] = f32x4{0.f, 0.f, 0.f, 0.f}; v[i] = threadIdx.x * 1e-3f + i; }
+  float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
+  const float c = 1.0001f, d = 1e-4f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      m[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, m[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[(i * NV + j) & 15] = __builtin_fmaf(v[(i * NV + j) & 15], c, d);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += m[i][0] + m[i][1] + m[i][2] + m[i][3] + v[i];
+  out[threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(512) void kmix(int nv, int iters, float* out, long long* cyc) {
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  const long long t0 = __builtin_readcyclecounter();
+  if (wave < 4) {
+    if (nv == 2) run_mix<2>(iters, out + blockIdx.x * 512);
+    else if (nv == 4) run_mix<4>(iters, out + blockIdx.x * 512);
+    else if (nv == 6) run_mix<6>(iters, out + blockIdx.x * 512);
+    else if (nv == 8) run_mix<8>(iters, out + blockIdx.x * 512);
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+// itersB: role B's own iteration count (so that B's work can be sized to finish inside A's run); prioB: s_setprio of role B
+__global__ __launch_bounds__(512) void k(int roleA, int roleB, int iters, float* out, long long* cyc, int itersB = 0,
+                                         int prioB = 0) {
   const int wave = threadIdx.x >> 6;
   const int role = wave < 4 ? roleA : roleB;
+  if (wave >= 4) {
+    if (itersB) iters = itersB;
+    if (prioB == 1) __builtin_amdgcn_s_setprio(1);
+    if (prioB == 3) __builtin_amdgcn_s_setprio(3);
+  }
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
   if (role == MFMA) run_mfma(iters, out + blockIdx.x * 512);
@@ -118,5 +162,31 @@ int main() {
       ca /= nb * 4; cb /= nb * 4;
       printf("A=%-5s B=%-5s : A %8.1f cycles per 16-op iteration, B %8.1f\n", names[a], names[b], a ? ca / iters : 0.0, b ? cb / iters : 0.0);
     }
+  // priority / starvation probes: B does 8x the iterations (so B alone = 8 * 60 = 483 cycles per A iteration, about A's
+  // 512) and we report both waves' TOTAL cycles: "time-shared" => A ~ 512 + 483, "B hidden in A's shadow" => both ~ 512
+  for (int prio = 0; prio <= 3; prio += (prio ? 2 : 1)) {
+    for (int role = VALU; role <= LDSR; ++role) {
+      const int mult = role == VALU ? 8 : role == TRANS ? 2 : role == PK ? 4 : role == RCP ? 3 : 1;
+      hipLaunchKernelGGL(k, dim3(nb), dim3(512), 0, 0, MFMA, role, iters, out, cyc, iters * mult, prio);
+      hipLaunchKernelGGL(k, dim3(nb), dim3(512), 0, 0, MFMA, role, iters, out, cyc, iters * mult, prio);
+      hipDeviceSynchronize();
+      hipMemcpy(h.data(), cyc, nb * 8 * sizeof(long long), hipMemcpyDeviceToHost);
+      double ca = 0, cb = 0;
+      for (int i = 0; i < nb; ++i) for (int w = 0; w < 8; ++w) (w < 4 ? ca : cb) += h[i * 8 + w];
+      ca /= nb * 4; cb /= nb * 4;
+      printf("prio(B)=%d A=MFMA x%d, B=%-5s x%d : A total %9.0f  B total %9.0f  (per A iteration: A %.1f, B %.1f)\n", prio, iters,
+             names[role], iters * mult, ca, cb, ca / iters, cb / iters);
+    }
+  }
+  for (int nv = 2; nv <= 8; nv += 2) {
+    hipLaunchKernelGGL(kmix, dim3(nb), dim3(512), 0, 0, nv, iters, out, cyc);
+    hipLaunchKernelGGL(kmix, dim3(nb), dim3(512), 0, 0, nv, iters, out, cyc);
+    hipDeviceSynchronize();
+    hipMemcpy(h.data(), cyc, nb * 8 * sizeof(long long), hipMemcpyDeviceToHost);
+    double ca = 0;
+    for (int i = 0; i < nb; ++i) for (int w = 0; w < 4; ++w) ca += h[i * 8 + w];
+    printf("same wave: 16 x (MFMA + %d v_fma_f32): %.1f cycles per iteration (MFMA alone 512, VALU alone %.0f)\n", nv,
+           ca / (nb * 4) / iters, 3.77 * 16 * nv);
+  }
   return 0;
 }
