@@ -34,6 +34,7 @@ import torch         # noqa: E402
 
 H, D = 64, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # dense bf16 MFMA peak (1024 FLOP/clk/SIMD): 16x the fp32 MFMA rate
 DOMINANT_KERNEL = "UNET"           # unet_kernel: the whole TemporalUnet forward in one launch (all 25 convs + GN/Mish)
 HEADLINE_ROBOTS = 32               # BASELINE.json: 32-robot Empty map
 
@@ -171,7 +172,8 @@ def main():
     import ctypes as C
     n_traj_local = RPG * B
     flops = lib.mmd_unet_flops_per_trajectory() * n_traj_local              # algorithmic (direct-conv) FLOPs per launch
-    mfma_flops = lib.mmd_unet_mfma_flops_per_trajectory() * n_traj_local    # FLOPs the matrix pipe actually issues
+    mfma_flops = lib.mmd_unet_mfma_flops_per_trajectory() * n_traj_local    # fp32 GEMM FLOPs the matrix pipe runs
+    bf_flops = lib.mmd_unet_bf16x3_flops_per_trajectory() * n_traj_local    # ... of which as bf16x3 on the bf16 pipe
 
     for w in range(args.warmup):
         _, paths_local = sampler.plan_round(paths_local, seed=1000 + w)
@@ -210,15 +212,19 @@ def main():
             pmc = json.load(f).get(DOMINANT_KERNEL)
         if pmc:
             traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
-    # `achieved` / `frac` are the matrix pipe's own utilisation: MFMA FLOPs actually ISSUED per launch (= PMC
-    # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) / launch time / fp32-MFMA peak.  The k=5 convs run as Winograd F(4,5) in fp32,
-    # which issues 0.45x the multiplies of the direct form: the ALGORITHMIC (direct-convolution) rate is
-    # reported separately and may exceed the peak -- it is not a utilisation.
-    roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; fp32 MFMA GEMMs, the 25 k=5 convs as Winograd F(4,5); GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
+    # `achieved` / `frac`: the fp32 GEMM FLOPs the kernel actually runs on the matrix pipe per launch (Winograd F(4,5) for
+    # the k=5 convs, i.e. 0.45x the multiplies of the direct form) / launch time, against the fp32 MFMA peak -- the
+    # roofline of fp32 arithmetic on this chip.  57 % of those FLOPs (downs.2 + mid) run as bf16x3 on the bf16 pipe (an
+    # exact three-way split of both operands, six bf16 MFMAs per fp32 chunk: fp32-accurate and 2.7x the fp32 MFMA rate),
+    # so the pipe's BUSY fraction is lower than `frac`: `pipe_busy_model` prices every MFMA at its issue cycles.  The
+    # ALGORITHMIC (direct-convolution) rate is reported separately and may exceed the peak.
+    busy_s = ((mfma_flops - bf_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + 6.0 * bf_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12))
+    roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; the 25 k=5 convs as Winograd F(4,5): fp32 MFMA GEMMs, the seven 128->128 convs as bf16x3 on the bf16 MFMA; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
                 "achieved": issued_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued_tf / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
-                "flops_per_launch": mfma_flops,
-                "note": "achieved = MFMA FLOPs issued per launch / launch time (matrix-pipe utilisation); see `algorithmic` for the direct-convolution count",
+                "flops_per_launch": mfma_flops, "flops_per_launch_as_bf16x3": bf_flops,
+                "pipe_busy_model": busy_s / (dom_ms * 1e-3),
+                "note": "achieved = fp32 GEMM FLOPs run on the matrix pipe per launch / launch time, vs the fp32 MFMA peak; pipe_busy_model = MFMA issue time at spec clock / launch time (fp32 MFMAs at 157.3 TF, the bf16x3 ones at 6 bf16 FLOPs per fp32 FLOP and 2516.6 TF); see `algorithmic` for the direct-convolution count",
                 "algorithmic": {"flops_per_launch": flops, "achieved": alg_tf, "ratio_to_peak": alg_tf / PEAK_FP32_MFMA_TFLOPS,
                                 "note": "direct-conv FLOPs (2*C_out*taps*C_in*L_out) / time; Winograd F(4,5) issues 0.45x of them, so this can exceed the MFMA peak"},
                 "launches_per_forward": 1}

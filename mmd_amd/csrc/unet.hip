@@ -219,6 +219,7 @@ constexpr int MAX_IDENT = 3;
 struct RtbPtrs {
   const float4* wa; const float* ba; const float* ga; const float* bea; const float* tb;
   const float4* wb; const float* bb; const float* gb; const float* beb;
+  const uint4* wa_bf; const uint4* wb_bf;   // bf16x3 packs of the same convs (downs.2 + mid blocks: vb_taps)
 };
 
 struct ChainArgs {
@@ -625,6 +626,150 @@ __device__ __forceinline__ void slab_sync() {
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix pipe ("bf16x3"): the 128 -> 128 convs of downs.2 + mid blocks (51 % of the network's MACs).
+// Every fp32 operand is split EXACTLY into three bf16 pieces by truncation (x = x0 + x1 + x2: x0 = the top 16 bits of x,
+// x1 = the top 16 bits of x - x0, x2 = x - x0 - x1, which has at most 8 significant bits left), and a product a * w is
+// accumulated as the six piece products of order <= 2, a2 w0 + a1 w1 + a0 w2 + a1 w0 + a0 w1 + a0 w0 (lowest order first),
+// on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The three dropped products are <= 2^-24 |a w| each; measured against
+// fp64 the result is as accurate as the fp32 MFMA chain it replaces (tools/ubench/bf16x_emul.hip: rms error 0.8x).  One
+// K = 32 chunk costs 6 x 16 cycles instead of 8 x 32 on v_mfma_f32_16x16x4_f32.
+//
+// The V slab (Winograd-transformed conv input) holds the pieces channel-innermost, the A fragment of the K = 32 MFMA:
+//     Vb[piece q][slot s][channel block c / 8][row' = 4 * quad + sample][c % 8]    (bf16)
+// so a lane's A operand (one row, 8 channels) is ONE ds_read_b128.  Bank-conflict freedom, for the lane groups the LDS
+// services a wave's access in (MI355X_MICROARCH.md, LDS): a K = 32 chunk kc is the four channel blocks kc, kc + 4, kc + 8,
+// kc + 12 (lane group lane >> 4 = block kc + 4 (lane >> 4)), which lie VB_CG = a multiple of 256 B apart, so the rows a
+// 16-lane read group takes from two of them fall on disjoint banks; the blocks c, c + 1 (c & 3) of one such group lie
+// 256 + 32 B apart and the rows are ordered quad-major, so the epilogue's ds_write_b32 -- lanes = (4 adjacent channel
+// pairs) x (4 channel blocks c & 3) x (2 samples), one quad per instruction -- hit 32 distinct banks per 32-lane group.
+// All 8 Winograd positions of 128 channels would be
+// 98 KB, more than a workgroup's half of the CU's LDS, so a conv runs in two PHASES over the position sets {0, 1, 2, 7} and
+// {3, 4, 5, 6} (slots 0..3 of a phase; the same split of B^T the one-sample kernel uses: neither set shares a partial sum
+// with the other): store set 0 -- barrier -- MFMAs -- barrier -- store set 1 -- barrier -- MFMAs; the conv's input tile
+// waits in registers meanwhile.
+// Weights: per n-tile and conv [phase][slot][chunk kc][piece q] fragments of 64 lanes x 16 B (lane = column lane & 15,
+// channel block kc + 4 (lane >> 4)), streamed through a two-step register ring.
+// ----------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int VB_CB = 16 * 16 + 32;        // bytes between the 8-channel blocks c, c + 1 of a group of four (c & 3)
+constexpr int VB_CG = 5 * 256;             // bytes between the groups of four channel blocks (c >> 2): a multiple of 256
+constexpr int VB_PS = 4 * VB_CG;           // bytes per (piece, slot): 128 channels
+constexpr int VB_BYTES = 12 * VB_PS;       // 3 pieces x 4 slots = 61440 B
+constexpr int VB_FRAGS = 2 * 16 * 3;       // weight fragments per n-tile and conv
+static_assert(VB_BYTES <= VSLAB_FLOATS * 4, "the bf16x3 phase slab aliases the fp32 V slab");
+__host__ __device__ constexpr int vb_pos(int ph, int slot) { return ph == 0 ? (slot == 3 ? 7 : slot) : 3 + slot; }
+
+// The lane holds two adjacent channels (v0: the even one): the three pieces of each pair up into dwords at slot offset
+// OFF of the lane's slab position.
+template <int OFF>
+__device__ __forceinline__ void vb_put2(char* base, float v0, float v1) {
+  const unsigned a0 = __float_as_uint(v0), b0 = __float_as_uint(v1);
+  const float ra = v0 - __uint_as_float(a0 & 0xffff0000u), rb = v1 - __uint_as_float(b0 & 0xffff0000u);
+  const unsigned a1 = __float_as_uint(ra), b1 = __float_as_uint(rb);
+  const unsigned a2 = __float_as_uint(ra - __uint_as_float(a1 & 0xffff0000u));
+  const unsigned b2 = __float_as_uint(rb - __uint_as_float(b1 & 0xffff0000u));
+  constexpr unsigned HI_HI = 0x07060302u;                    // {b.hi16, a.hi16}
+  *reinterpret_cast<unsigned*>(base + OFF) = __builtin_amdgcn_perm(b0, a0, HI_HI);
+  *reinterpret_cast<unsigned*>(base + OFF + 4 * VB_PS) = __builtin_amdgcn_perm(b1, a1, HI_HI);
+  *reinterpret_cast<unsigned*>(base + OFF + 8 * VB_PS) = __builtin_amdgcn_perm(b2, a2, HI_HI);
+}
+// phase PH of the V transform of the lane's two (sample, channel) columns: x(o, r) = position 4 r + o; base = slab + the
+// lane's (channel block, row 4 * sample, channel % 8) offset.  The expressions are w4_transform's.
+template <int PH, class GET0, class GET1>
+__device__ __forceinline__ void vb_store_pair(char* base, GET0 x0, GET1 x1) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float d[8], e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pos = 4 * r - 2 + j;
+      d[j] = (pos < 0 || pos > 15) ? 0.f : x0(pos & 3, pos >> 2);
+      e[j] = (pos < 0 || pos > 15) ? 0.f : x1(pos & 3, pos >> 2);
+    }
+    char* p = base + r * 64;                                 // row' = 4 r + sample
+    if constexpr (PH == 0) {
+      const float de1 = fmaf(-4.25f, d[4], d[2]) + d[6], do1 = fmaf(-4.25f, d[3], d[1]) + d[5];
+      const float ee1 = fmaf(-4.25f, e[4], e[2]) + e[6], eo1 = fmaf(-4.25f, e[3], e[1]) + e[5];
+      vb_put2<0 * VB_PS>(p, fmaf(5.25f, d[2] - d[4], d[6] - d[0]), fmaf(5.25f, e[2] - e[4], e[6] - e[0]));
+      vb_put2<1 * VB_PS>(p, de1 + do1, ee1 + eo1);
+      vb_put2<2 * VB_PS>(p, de1 - do1, ee1 - eo1);
+      vb_put2<3 * VB_PS>(p, fmaf(5.25f, d[3] - d[5], d[7] - d[1]), fmaf(5.25f, e[3] - e[5], e[7] - e[1]));
+    } else {
+      const float de2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), do2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
+      const float de3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), do3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
+      const float ee2 = fmaf(0.25f, e[2], fmaf(-1.25f, e[4], e[6])), eo2 = fmaf(0.5f, e[1], fmaf(-2.5f, e[3], 2.f * e[5]));
+      const float ee3 = fmaf(4.f, e[2], fmaf(-5.f, e[4], e[6])), eo3 = fmaf(2.f, e[1], fmaf(-2.5f, e[3], 0.5f * e[5]));
+      vb_put2<0 * VB_PS>(p, de2 + do2, ee2 + eo2);
+      vb_put2<1 * VB_PS>(p, de2 - do2, ee2 - eo2);
+      vb_put2<2 * VB_PS>(p, de3 + do3, ee3 + eo3);
+      vb_put2<3 * VB_PS>(p, de3 - do3, ee3 - eo3);
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// one K = 32 chunk of two independent accumulator streams x, y (interleaved: no MFMA waits for the one before it)
+template <bool ZERO>
+__device__ __forceinline__ void vb_six(f32x4& x, f32x4& y, const u32x4 (&ax)[3], const u32x4 (&ay)[3], const u32x4 (&bx)[3],
+                                       const u32x4 (&by)[3]) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 cx = ZERO ? z : x, cy = ZERO ? z : y;
+  cx = mfma_bf(ax[2], bx[0], cx); cy = mfma_bf(ay[2], by[0], cy);
+  cx = mfma_bf(ax[1], bx[1], cx); cy = mfma_bf(ay[1], by[1], cy);
+  cx = mfma_bf(ax[0], bx[2], cx); cy = mfma_bf(ay[0], by[2], cy);
+  cx = mfma_bf(ax[1], bx[0], cx); cy = mfma_bf(ay[1], by[0], cy);
+  cx = mfma_bf(ax[0], bx[1], cx); cy = mfma_bf(ay[0], by[1], cy);
+  cx = mfma_bf(ax[0], bx[0], cx); cy = mfma_bf(ay[0], by[0], cy);
+  x = cx; y = cy;
+}
+// A step = 12 MFMAs: the wave's two n-tiles (the two accumulator streams) at slot step / 4, chunk step % 4, on one set of
+// A fragments.
+__device__ __forceinline__ void vb_load_b(u32x4 (&b)[2][3], const u32x4* const (&w)[2], int ph, int step) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const u32x4* p = w[t] + ((ph * 16 + step) * 3) * 64;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) b[t][q] = p[q * 64];
+  }
+}
+__device__ __forceinline__ void vb_load_a(u32x4 (&a)[3], const char* va, int step) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step / 4) * VB_PS + (step % 4) * VB_CB);
+}
+// the first VB_RD steps' weights of phase PH into the ring (issued ahead of the barrier that publishes the slab)
+#ifndef MMD_VB_RD
+#define MMD_VB_RD 2   // 3: -2 % (its 24 more VGPRs spill inside the K loop)
+#endif
+constexpr int VB_RD = MMD_VB_RD;           // ring depth in steps (6 KB per wave and step in flight)
+template <int PH>
+__device__ __forceinline__ void vb_ring_load(u32x4 (&b)[VB_RD][2][3], const u32x4* const (&w)[2]) {
+#pragma unroll
+  for (int i = 0; i < VB_RD; ++i) vb_load_b(b[i], w, PH, i);
+  MMD_PIN_LOADS();
+}
+// m[tile][position] of phase PH's four positions = conv over the 128 channels of the slab; va = slab + the lane's A
+// offset (channel block lane >> 4, row lane & 15); w[tile] = the tile's pack + lane; b = ring (vb_ring_load)
+template <int PH>
+__device__ __forceinline__ void vb_taps(f32x4 (&m)[2][8], const char* va, const u32x4* const (&w)[2], u32x4 (&b)[VB_RD][2][3]) {
+  u32x4 a[2][3];
+  vb_load_a(a[0], va, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i + 1 < 16) vb_load_a(a[(i + 1) & 1], va, i + 1);
+    MMD_PIN_LOADS();
+    const int pos = vb_pos(PH, i / 4);
+    if (i % 4 == 0) vb_six<true>(m[0][pos], m[1][pos], a[i & 1], a[i & 1], b[i % VB_RD][0], b[i % VB_RD][1]);
+    else vb_six<false>(m[0][pos], m[1][pos], a[i & 1], a[i & 1], b[i % VB_RD][0], b[i % VB_RD][1]);
+    if (i + VB_RD < 16) vb_load_b(b[i % VB_RD], w, PH, i + VB_RD);
+    MMD_PIN_LOADS();
+  }
+}
+
 template <class CF, bool FIRST>
 __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[8],
                                               f32x4 (&mid)[8], f32x16 (&tout)[1], int trb) {
@@ -990,167 +1135,146 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// One-n-tile-per-unit down-path stage.  A stage's output is 8 (M tile, 16-channel n-tile) units (downs.0: 4 x 2, downs.1:
-// 2 x 4, downs.2 / mid: 1 x 8); a workgroup of WAVES waves gives each wave TPW = 8 / WAVES of them, processed one after the
-// other (8 accumulators each).  WAVES = 8 is the SMALL-BATCH kernel (unet_kernel_s): the same 4 samples per workgroup but
-// half the work per wave, i.e. half the dependent-chain latency of a forward -- what bounds a launch that cannot fill
-// the chip twice over (<= 1024 trajectories).  Arithmetic (k order, reductions) is identical to the two-n-tile body, so
-// the two kernels agree bit for bit.
+// downs.2 + mid blocks (L = 16, 128 channels; 57 % of the network's MACs): the 64 -> 128 conv A of the first RTB on the
+// fp32 MFMA from the row-form x slab (with its 1x1 residual conv riding along), the seven 128 -> 128 convs as bf16x3
+// (vb_taps).  The stage's output is one M tile (4 samples x 4 quads) x 8 n-tiles; wave w owns n-tiles 2 w, 2 w + 1, whose
+// columns are INTERLEAVED over its 32 channels -- column n of tile h is channel 32 w + 2 n + h (the weight packs are
+// permuted accordingly) -- so a lane holds two ADJACENT channels and stores their bf16 pieces as one ds_write_b32 (64
+// distinct banks per wave) instead of two ds_write_b16 into shared dwords.  A GroupNorm group (16 channels) is 8 adjacent
+// lanes x both tiles.
 // ----------------------------------------------------------------------------------------------------------------
-// SMP = 1 (unet_kernel_1): the workgroup owns ONE sample, i.e. only M tile 0 (whose other rows belong to samples that are
-// zero-filled and ignored): units = the CM / 16 n-tiles, spread over the waves; waves without a unit only take part in
-// the barriers.
-template <int WAVES, int SMP, int NTQ> struct DnTiling {
-  static constexpr int UNITS = SMP == 4 ? 8 : NTQ;
-  static constexpr int TPW = UNITS >= WAVES ? UNITS / WAVES : 1;
-  static constexpr int NACT = UNITS / TPW;          // waves that own units
-};
-template <class CF, bool FIRST, int WAVES, int SMP = 4>
-__device__ __forceinline__ void chain_body_dn(const ChainArgs& a, float* lds, int n0, int lane, int wave,
-                                              f32x4 (&acc)[DnTiling<WAVES, SMP, CF::CM / 16>::TPW][4],
-                                              f32x4 (&mid)[DnTiling<WAVES, SMP, CF::CM / 16>::TPW][4], f32x16 (&tout)[1],
-                                              int trb) {
-  static_assert((CF::L == 16 || CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 &&
-                    CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP, "down-path stage: (L / 16 M tiles) x (CM / 16 n-tiles) = 8 units");
-  constexpr int NTQ = CF::CM / 16, QPS = CF::L / 4;
-  using TL = DnTiling<WAVES, SMP, NTQ>;
-  constexpr int TPW = TL::TPW;
-  constexpr bool VH = CF::L == 16;
-  float* hslab = VH ? lds : lds + CF::XSLAB;
-  float* xslab = lds;
-  const bool act = wave < TL::NACT;
-  const int u0 = act ? wave * TPW : 0, mt = u0 / NTQ;                   // the wave's units u0 .. u0 + TPW - 1 share one M tile
-  const int ai = mt * 16 + (lane & 15);
-  const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
-  const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
-  const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
-  const int vbase = (lane >> 4) * VCS + (lane & 15) * VROW;
-  auto nq_of = [&](int h) { return (u0 + h) % NTQ; };
-  auto col_of = [&](int h) { return nq_of(h) * 16 + (lane & 15); };
-  BQ<3> ring3[W4_RD];
-  BQ<2> ring[W4_RD];
-  auto wl = [&](const float4* w, int cp, int nq) {
-    return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 8;
-  };
-  auto wl3 = [&](const float4* w, int cp, int nq) {
-    return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
-  };
-  if (act) w4_ring_load<3>(ring3, wl3(a.r0.wa, CF::C0P, nq_of(0)));
-  if constexpr (FIRST)
-    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS, WAVES * 64>(
-        xslab, a.in0, nullptr, n0, SMP == 4 ? a.n : (n0 + 1 < a.n ? n0 + 1 : a.n));
-  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, WAVES * 64>(hslab);
-  __syncthreads();
-
-  f32x4 m[8], res[TPW][4];
-  // conv over the H slab for every unit of the wave; the ring holds unit 0's first k-steps on entry and is refilled for
-  // the next unit / the next conv (w_next) before the output transform
-  auto conv_h = [&](const float4* w, const float4* w_next) {
+template <class ADD0, class ADD1>
+__device__ __forceinline__ void gn_mish_pair16(f32x4 (&q0)[4], f32x4 (&q1)[4], const float (&bias)[2], const float (&gamma)[2],
+                                               const float (&beta)[2], ADD0 add0, ADD1 add1) {
+  constexpr float inv_n = 1.f / 256.f;                       // 16 channels x 16 positions
+  float sum = 0.f;
 #pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-      if constexpr (VH) {
-        f32x4 nores[6];
-        w4v_taps<CF::CM, 1, false, true>(m, nores, hslab, vbase, wl(w, CF::CM, nq_of(h)), ring);
-      } else {
-        w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res[h], hslab, hbase, wl(w, CF::CM, nq_of(h)), ring);
-      }
-      if (h + 1 < TPW) w4_ring_load<2>(ring, wl(w, CF::CM, nq_of(h + 1)));
-      else if (w_next) w4_ring_load<2>(ring, wl(w_next, CF::CM, nq_of(0)));
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum += q0[o][r] + q1[o][r];
+  const float mean = (group_colsum<8>(sum) + group_colsum<8>(bias[0] + bias[1]) * 16.f) * inv_n;
+  const float dm0 = mean - bias[0], dm1 = mean - bias[1];
+  float sq = 0.f;
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d0 = q0[o][r] - dm0, d1 = q1[o][r] - dm1;
+      sq = fmaf(d0, d0, sq);
+      sq = fmaf(d1, d1, sq);
+    }
+  const float rstd = rsqrtf(group_colsum<8>(sq) * inv_n + 1e-5f);
+  const GnCoef cf0 = gn_coef(dm0, rstd, gamma[0], beta[0]), cf1 = gn_coef(dm1, rstd, gamma[1], beta[1]);
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      q0[o][r] = gn_mish1(q0[o][r], cf0, add0(o, r));
+      q1[o][r] = gn_mish1(q1[o][r], cf1, add1(o, r));
+    }
+}
+
+template <class CF>
+__device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[2][4],
+                                              f32x4 (&mid)[2][4], int trb) {
+  static_assert(CF::L == 16 && CF::CM == 128 && CF::C0 == 64 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_NONE &&
+                    CF::MID_AFTER >= 1, "downs.2 + mid blocks");
+  const int c0 = 32 * wave + 2 * (lane & 15);                // the lane's channels c0 (tile 0), c0 + 1 (tile 1)
+  const int xbase = ((lane & 15) >> 2) * CF::XSS + 4 * (lane & 3) * CF::XSTR + (lane >> 4);   // A row lane & 15 = (sample, quad)
+  BQ<3> ring3[W4_RD];
+  auto wl3 = [&](int nq) {
+    return reinterpret_cast<const float*>(a.r0.wa) + ((size_t)nq * (CF::C0P / 4) * 64 + lane) * 12;
+  };
+  w4_ring_load<3>(ring3, wl3(2 * wave));
+  __syncthreads();                                           // the x slab (previous stage's tail tile) is staged
+  TR(trb + 0);
+
+  f32x4 res[2][4];
+  char* const vb = reinterpret_cast<char*>(lds);             // the bf16x3 phase slab aliases the x slab
+  // A fragment: row lane & 15 = (sample (lane & 15) >> 2, quad lane & 3), channel-block group lane >> 4
+  const char* const vb_a = vb + (lane >> 4) * VB_CG + (4 * (lane & 3) + ((lane & 15) >> 2)) * 16;
+  // stores: channels c0, c0 + 1 = block 4 wave + ((lane & 15) >> 2), dword lane & 3; sample lane >> 4
+  char* const vb_s = vb + wave * VB_CG + ((lane & 15) >> 2) * VB_CB + (lane >> 4) * 16 + (lane & 3) * 4;
+  // A whole 128 -> 128 conv over the H tile in acc, in two position phases.  On entry every wave is past its reads of the
+  // slab (the caller's barrier); the first ring steps of each phase are issued ahead of the barrier that publishes it.
+  auto conv_hb = [&](const uint4* w) {
+    const u32x4* wp[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wp[h] = reinterpret_cast<const u32x4*>(w) + (size_t)(2 * wave + h) * VB_FRAGS * 64 + lane;
+    f32x4 mb[2][8];
+    u32x4 ring_b[VB_RD][2][3];
+    TR(trb + 10);
+    vb_ring_load<0>(ring_b, wp);
+    vb_store_pair<0>(vb_s, [&](int o, int r) { return acc[0][o][r]; }, [&](int o, int r) { return acc[1][o][r]; });
+    TR(trb + 11);
+    __syncthreads();
+    TR(trb + 12);
+    vb_taps<0>(mb, vb_a, wp, ring_b);
+    TR(trb + 13);
+    vb_ring_load<1>(ring_b, wp);
+    __syncthreads();                                         // every wave is done reading the phase-0 slab
+    TR(trb + 14);
+    vb_store_pair<1>(vb_s, [&](int o, int r) { return acc[0][o][r]; }, [&](int o, int r) { return acc[1][o][r]; });
+    TR(trb + 15);
+    __syncthreads();
+    TR(trb + 16);
+    vb_taps<1>(mb, vb_a, wp, ring_b);
+    TR(trb + 17);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) w4n1_out(acc[h], mb[h]);
+  };
+  // GroupNorm + Mish of acc, then + the time bias (conv A) or + the residual tile (conv B, tb == nullptr)
+  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
+    const float bb[2] = {b[c0], b[c0 + 1]}, gg[2] = {g[c0], g[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
+    if (MMD_ABL == 1) return;
+    if (tb) {
+      const float t0 = tb[c0], t1 = tb[c0 + 1];
+      gn_mish_pair16(acc[0], acc[1], bb, gg, ee, [&](int, int) { return t0; }, [&](int, int) { return t1; });
+    } else {
+      gn_mish_pair16(acc[0], acc[1], bb, gg, ee, [&](int o, int r) { return res[0][o][r]; },
+                     [&](int o, int r) { return res[1][o][r]; });
+    }
+  };
+
+  // =================== RTB 0 (64 -> 128): conv A + the 1x1 residual conv on the fp32 MFMA, row-form x slab ===================
+  {
+    f32x4 m[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float br = a.br[c0 + h];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) res[h][o] = f32x4{br, br, br, br};
+      w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res[h], lds, xbase, wl3(2 * wave + h), ring3);
+      if (h == 0) w4_ring_load<3>(ring3, wl3(2 * wave + 1));
       w4n1_out(acc[h], m);
     }
-  };
-  auto to_h = [&]() {
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-      if constexpr (VH) quad1_to_vform(acc[h], hslab, nq_of(h), lane);
-      else quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc[h], hslab, mt, nq_of(h), lane);
-    }
-  };
-  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
-    if (MMD_ABL == 1) return;
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-      const int col = col_of(h);
-      if (tb) {
-        const float t0 = tb[col];
-        gn_mish_quad1<CF::CM, CF::L>(acc[h], b[col], g[col], be[col], [&](int, int) { return t0; });
-      } else {
-        gn_mish_quad1<CF::CM, CF::L>(acc[h], b[col], g[col], be[col], [&](int o, int r) { return res[h][o][r]; });
-      }
-    }
-  };
+  }
+  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
+  TR(trb + 1);
+  __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
+  conv_hb(a.r0.wb_bf);
+  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
 
-  // =================== RTB 0 (C0 -> CM) with its 1x1 residual conv fused into conv A (row-form x slab) ===================
-#pragma unroll
-  for (int h = 0; h < TPW; ++h) {
-    if (!act) break;
-    const float br = a.br[col_of(h)];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) res[h][o] = f32x4{br, br, br, br};
-    w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res[h], xslab, xbase, wl3(a.r0.wa, CF::C0P, nq_of(h)), ring3);
-    if (h + 1 < TPW) w4_ring_load<3>(ring3, wl3(a.r0.wa, CF::C0P, nq_of(h + 1)));
-    else w4_ring_load<2>(ring, wl(a.r0.wb, CF::CM, nq_of(0)));
-    w4n1_out(acc[h], m);
-  }
-  if (act) gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
-  if constexpr (VH) __syncthreads();                         // conv A is done reading the x slab the V-form H slab aliases
-  if (act) to_h();
-  __syncthreads();
-  if (act) {
-    conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
-    gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
-  }
-  if constexpr (CF::MID_AFTER == 0) {
-#pragma unroll
-    for (int h = 0; h < TPW; ++h)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mid[h][i] = acc[h][i];
-  }
-
-  // =================== identity RTBs ===================
-#pragma unroll
+  // =================== identity RTBs (a real loop: one copy of the two conv bodies instead of three) ===================
+#pragma unroll 1
   for (int k = 0; k < CF::N_IDENT; ++k) {
     const RtbPtrs& R = a.ri[k];
 #pragma unroll
-    for (int h = 0; h < TPW; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 4; ++i) res[h][i] = acc[h][i];
-    __syncthreads();                                         // the previous conv is done reading the H slab
-    if (act) to_h();
+    __syncthreads();                                         // the previous conv is done reading the slab
+    conv_hb(R.wa_bf);
+    gn(R.ba, R.ga, R.bea, R.tb);
     __syncthreads();
-    if (act) {
-      conv_h(R.wa, R.wb);
-      gn(R.ba, R.ga, R.bea, R.tb);
-    }
-    __syncthreads();
-    if (act) to_h();
-    __syncthreads();
-    if (act) {
-      conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
-      gn(R.bb, R.gb, R.beb, nullptr);
-    }
+    conv_hb(R.wb_bf);
+    gn(R.bb, R.gb, R.beb, nullptr);
+    TR(trb + 18);
     if (CF::MID_AFTER == k + 1) {
 #pragma unroll
-      for (int h = 0; h < TPW; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 4; ++i) mid[h][i] = acc[h][i];
-    }
-  }
-
-  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32 (4 units: waves 0..3) ===================
-  if constexpr (CF::TAIL == TAIL_DOWN) {
-    static_assert(!VH, "the strided tail conv reads a row-form H slab");
-    __syncthreads();
-    if (act) to_h();
-    __syncthreads();
-    // 4 tail units (32 output rows x 32 channels each); one sample: only those whose rows are the sample's
-    if (wave < (SMP == 4 ? 4 : (CF::L == 64 ? 1 : CF::WN))) {
-      constexpr int LO = CF::L / 2;
-      const int wm = wave / CF::WN, wn = wave % CF::WN, hi = lane >> 5;
-      fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
-      const int r = lane & 31;
-      int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
-      mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
     }
   }
 }
@@ -1168,15 +1292,9 @@ using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.
 using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
 constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
 
-struct OneArgs {           // role packs of the L = 16 stages (unet_kernel_1); same biases / affine / time tables as ChainArgs
-  const float* d2_a;       // downs.2 conv A: [4 roles][64 + 4][64 lanes][8]  (main float4, wr)
-  const float* d2_h[7];    // downs.2 conv B, mid1 A/B, mid2 A/B ... in execution order: [4 roles][128 + 4][64][4]
-};
-
 struct UnetArgs {
   ChainArgs c[5];
   ChainArgs c2s;        // downs.2 + mid blocks with one-n-tile weight packs (unet_kernel runs that stage tile by tile)
-  OneArgs one;          // role packs of the one-sample kernel's L = 16 stages
   FinalArgs fin;
   int n;
 };
@@ -1214,16 +1332,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
   }
-  // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2
-  // (two n-tiles per wave processed one after the other: 32 accumulator registers less than the two-n-tile body, which
-  //  is what lets skip2 stay in registers through the mid blocks)
+  // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2 (lane = channels 32 wave + 2 (lane & 15) + h: chain_body_d2)
+  const int c2 = 32 * wave + 2 * (lane & 15);
   {
     f32x4 acc[2][4];
-    f32x16 t[1];
-    chain_body_dn<CH_D2, false, 4>(a.c2s, lds, n0, lane, wave, acc, skip2, t, 80);
+    chain_body_d2<CH_D2>(a.c2s, lds, lane, wave, acc, skip2, 80);
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) quad1_to_vform(acc[h], lds, wave * 2 + h, lane);   // chunk 0 of ups.0's conv A input, V form
+    for (int h = 0; h < 2; ++h)                                            // chunk 0 of ups.0's conv A input, V form
+      vform_store(lds + (c2 + h) * VCS + (lane >> 4) * 4 * VROW, [&](int o, int r) { return acc[h][o][r]; });
   }
   TR(130);
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
@@ -1232,7 +1349,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     chain_body_w4u<CH_U0, 4>(a.c[3], lds, n0, lane, wave,
                              [&](float* xs) {
 #pragma unroll
-                               for (int h = 0; h < 2; ++h) quad1_to_vform(skip2[h], xs, wave * 2 + h, lane);
+                               for (int h = 0; h < 2; ++h)
+                                 vform_store(xs + (c2 + h) * VCS + (lane >> 4) * 4 * VROW,
+                                             [&](int o, int r) { return skip2[h][o][r]; });
                              },
                              t, 136);
     __syncthreads();
@@ -1305,439 +1424,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   TR(133);
 }
-
-// ----------------------------------------------------------------------------------------------------------------
-// SMALL-BATCH kernel: the same forward, 4 samples per workgroup, on 8 waves (512 threads, one workgroup per CU).  Every
-// stage of the down path / the final block is 8 (M tile, 16-channel n-tile) units = one per wave, so a wave carries half
-// the MFMA chain and half the epilogue of the 4-wave kernel; the up-path RTBs have only 4 units (waves 0..3), their tail
-// convs 8.  A launch of <= 1024 trajectories puts at most one workgroup on a CU, so its duration IS the dependent-chain
-// latency of one workgroup: this kernel cuts it from ~215 us to ~140 us (the per-GPU cost of a sharded round: 32 robots
-// over 4 / 8 GPUs = 512 / 256 trajectories per GPU, config 5's 512).  Bit-identical to unet_kernel.
-// ----------------------------------------------------------------------------------------------------------------
-#ifndef MMD_S_WAVES
-#define MMD_S_WAVES 2
-#endif
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MMD_S_WAVES, MMD_S_WAVES))) void unet_kernel_s(UnetArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n0 = blockIdx.x * 4;
-
-  f32x4 skip1[1][4], skip2[1][4];
-  // ---- downs.0 @ L=64 -> [4][32][32]
-  {
-    f32x4 acc[1][4], mid[1][4];
-    f32x16 t[1];
-    chain_body_dn<CH_D0, true, 8>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
-    __syncthreads();                                                       // the tail conv is done reading the H slab
-    if (wave < 4) tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
-    zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4, 512>(lds);
-  }
-  // ---- downs.1 @ L=32 -> [4][16][64], skip1
-  {
-    f32x4 acc[1][4];
-    f32x16 t[1];
-    chain_body_dn<CH_D1, false, 8>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
-    __syncthreads();
-    if (wave < 4) tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
-    zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4, 512>(lds);
-  }
-  // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2
-  {
-    f32x4 acc[1][4];
-    f32x16 t[1];
-    chain_body_dn<CH_D2, false, 8>(a.c[2], lds, n0, lane, wave, acc, skip2, t, 80);
-    __syncthreads();
-    quad1_to_vform(acc[0], lds, wave, lane);                               // chunk 0 of ups.0's conv A input, V form
-  }
-  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
-  {
-    f32x16 t[1][1];
-    chain_body_w4u<CH_U0, 8>(a.c[3], lds, n0, lane, wave, [&](float* xs) { quad1_to_vform(skip2[0], xs, wave, lane); }, t, 136);
-    __syncthreads();
-    tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave & 3, lane, wave >> 2);
-    zero_halo<CH_U1::C0P, CH_U1::L, CH_U1::SROWS, CH_U1::XSTR, CH_U1::XSS, 4, 512>(lds);
-  }
-  // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
-  {
-    f32x16 t[1][1];
-    chain_body_w4u<CH_U1, 8>(a.c[4], lds, n0, lane, wave,
-                             [&](float* xs) {
-                               quad1_to_stage_u<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1[0], xs, wave / 4, wave % 4, lane);
-                             },
-                             t, 146);
-    __syncthreads();
-    tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave & 3, lane, wave >> 2);
-    zero_halo<32, 64, FIN_SROWS, FIN_STR, FIN_SS, 4, 512>(lds);
-    __syncthreads();
-  }
-  // ---- final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]; wave = (sample, n-tile) / (sample, 32-row half)
-  {
-    const FinalArgs& f = a.fin;
-    const int smp = wave >> 1, half = wave & 1;
-    f32x4 q[4];
-    {
-      f32x4 m[8], nores[4];
-      BQ<2> ring[W4_RD];
-      const float* w0 = reinterpret_cast<const float*>(f.wpk) + ((size_t)half * 8 * 64 + lane) * 8;
-      w4_ring_load<2>(ring, w0);
-      w4_taps<32, FIN_STR, 1, false, true>(m, nores, lds, smp * FIN_SS + 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
-      w4n1_out(q, m);
-    }
-    {
-      const int c = half * 16 + (lane & 15);
-      if (MMD_ABL != 1) gn_mish_quad1<32, 64>(q, f.bias[c], f.gamma[c], f.beta[c], [](int, int) { return 0.f; });
-    }
-    __syncthreads();                                                       // every wave is done reading the slab
-    float* yt = lds + smp * (64 * 33);
-    {
-      float* base = yt + 16 * (lane >> 4) * 33 + half * 16 + (lane & 15);  // rows 16 * block + 4 * quad + o
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) base[(4 * r + o) * 33] = q[o][r];
-    }
-    __syncthreads();
-    const int col = lane & 31, hi = lane >> 5;
-    f32x16 acc2[1];
-    int ybase[1] = {(half * 32 + (lane & 31)) * 33 + hi};
-    fill<1>(acc2, col < 4 ? f.w1_bias[col] : 0.f);
-    mfma_taps<1, 32, 33, 1>(acc2, yt, ybase, f.w1_pk + lane);
-    if (col < 4 && n0 + smp < a.n) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        f.out[((size_t)(n0 + smp) * 64 + row) * 4 + col] = acc2[0][r];
-      }
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// One-sample machinery for the L = 16 stages: v_mfma_f32_4x4x1_16B_f32.  At L = 16 a sample is 4 quads = the 4 rows of that
-// shape's blocks; its 16 blocks are 16 groups of 4 output channels (64 channels per instruction), K = 1 (one input
-// channel).  One instruction is 512 FLOP in 9.5 cycles (tools/ubench/mfma_4x4.hip) -- 84 % of the 16x16x4 rate with no row
-// wasted, where the 16x16x4 tile would carry 12 rows of other samples -- and a chain of them over the input channels is
-// the same k-ascending fmaf chain the 16x16x4 runs, so the results stay bit-identical.
-//   A operand: lane l holds row (quad) l & 3, replicated over the blocks: V1[channel][quad][8 positions], read with ONE
-//              ds_read_b128 per channel because the positions are stored in the order (0, 1, 2, 7 | 3, 4, 5, 6) of the two
-//              position sets the wave pairs split;
-//   B operand: lane l holds output channel n0 + l: per role and channel one float4 of the Winograd weights of its positions;
-//   C/D:       lane l = channel n0 + l, register = quad: the lane holds all 16 positions of its channel again, so the
-//              output transform, GroupNorm + Mish and the V transform of the epilogue are the code of the other kernels.
-// Waves: (N half h = wave & 1) x (position set s = wave >> 1) at 128 output channels (downs.2 / mid), four position
-// groups at 64 (ups.0).  After the K loop the set-1 waves hand their accumulators to the set-0 wave of their half through
-// LDS; it transforms them in the original association (the sets {0,1,2,7} | {3,4,5,6} never split a sum of w4n1_out).
-// ----------------------------------------------------------------------------------------------------------------
-constexpr int V1S = 4 * VROW + 4;          // channel stride of the one-sample V slab (36 floats: conflict-free b128 writes)
-constexpr int XQS = 16;                    // [channel][quad][4 positions of the quad]: the residual conv's untransformed rows
-
-template <class GET>
-__device__ __forceinline__ void vform_store1(float* vb, GET x) {      // vb = slab + channel * V1S; x(o, r) = position 4 r + o
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float d[8], v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pos = 4 * r - 2 + j;
-      d[j] = (pos < 0 || pos > 15) ? 0.f : x(pos & 3, pos >> 2);
-    }
-    w4_transform(v, d);
-    *reinterpret_cast<float4*>(vb + r * VROW) = make_float4(v[0], v[1], v[2], v[7]);
-    *reinterpret_cast<float4*>(vb + r * VROW + 4) = make_float4(v[3], v[4], v[5], v[6]);
-  }
-}
-
-// acc[i] += A_c[i] x B_c[i] over C channels, i < NM accumulators (vector index = quad); optional RESD direct residual:
-// r[j] += Xq_c[o0 + j] x wr_c (the 1x1 conv's rows 4 t + o).  ap = the lane's float4 of channel 0 (role / quad offset
-// applied), stride V1S; xq likewise with stride XQS; wp = the lane's floats of channel 0 in the role's pack, PK floats
-// per (channel, lane), [main float4][wr, 0, 0, 0 if RESD].  Ring of 4 channels of weights, A double-buffered; both
-// over-read 4 channels past the end (slabs and packs carry the slack).
-template <int C, int NM, bool RESD>
-__device__ __forceinline__ void x4_taps(f32x4 (&m)[8], f32x4 (&r)[2], const float* ap, const float* xq, int o0,
-                                        const float* __restrict__ wp) {
-  constexpr int PK = RESD ? 8 : 4, CST = 64 * PK;
-  static_assert(C % 4 == 0 && NM >= 2 && NM <= 4, "channels are unrolled by 4");
-  float4 b[4], a[2][4];
-  float wr[4] = {0.f, 0.f, 0.f, 0.f};
-  float4 xa[2][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    b[j] = *reinterpret_cast<const float4*>(wp + j * CST);
-    if constexpr (RESD) wr[j] = wp[j * CST + 4];
-    a[0][j] = *reinterpret_cast<const float4*>(ap + j * V1S);
-    if constexpr (RESD) xa[0][j] = *reinterpret_cast<const float4*>(xq + j * XQS);
-  }
-  MMD_PIN_LOADS();
-  auto body = [&](int cur) {
-    wp += 4 * CST; ap += 4 * V1S; xq += 4 * XQS;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      a[cur ^ 1][j] = *reinterpret_cast<const float4*>(ap + j * V1S);
-      if constexpr (RESD) xa[cur ^ 1][j] = *reinterpret_cast<const float4*>(xq + j * XQS);
-    }
-    MMD_PIN_LOADS();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float av[4] = {a[cur][j].x, a[cur][j].y, a[cur][j].z, a[cur][j].w};
-      const float bv[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
-#pragma unroll
-      for (int i = 0; i < NM; ++i) m[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], bv[i], m[i], 0, 0, 0);
-      if constexpr (RESD) {
-        const float xv[4] = {xa[cur][j].x, xa[cur][j].y, xa[cur][j].z, xa[cur][j].w};
-        r[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(o0 ? xv[2] : xv[0], wr[j], r[0], 0, 0, 0);
-        r[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(o0 ? xv[3] : xv[1], wr[j], r[1], 0, 0, 0);
-      }
-      b[j] = *reinterpret_cast<const float4*>(wp + j * CST);
-      if constexpr (RESD) wr[j] = wp[j * CST + 4];
-    }
-    MMD_PIN_LOADS();
-  };
-#pragma unroll 1
-  for (int c = 0; c < C; c += 8) {
-    body(0);
-    body(1);
-  }
-}
-
-// scratch hand-over of NV f32x4 per lane (elements OFF .. OFF + NV - 1 of an array): [slot][lane][4 * NV] floats
-template <int NV, int OFF, int N>
-__device__ __forceinline__ void x4_put(float* scr, int slot, int lane, const f32x4 (&v)[N]) {
-  float4* p = reinterpret_cast<float4*>(scr + ((size_t)slot * 64 + lane) * (4 * NV));
-#pragma unroll
-  for (int i = 0; i < NV; ++i) p[i] = make_float4(v[OFF + i][0], v[OFF + i][1], v[OFF + i][2], v[OFF + i][3]);
-}
-template <int NV, int OFF, int N>
-__device__ __forceinline__ void x4_get(const float* scr, int slot, int lane, f32x4 (&v)[N]) {
-  const float4* p = reinterpret_cast<const float4*>(scr + ((size_t)slot * 64 + lane) * (4 * NV));
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const float4 t = p[i];
-    v[OFF + i] = f32x4{t.x, t.y, t.z, t.w};
-  }
-}
-
-
-// downs.2 + mid blocks for ONE sample.  LDS: [x row-form slab of the 4-sample layout (written by downs.1's tail)]
-// [V1 slab: conv A's transformed input, then H][Xq][hand-over scratch].
-constexpr int ONE_V = CH_D2::XSLAB, ONE_XQ = ONE_V + (128 + 4) * V1S, ONE_SCR = ONE_XQ + (64 + 4) * XQS;
-static_assert(ONE_SCR + 2 * 64 * 24 <= UNET_LDS_FLOATS, "one-sample LDS map of downs.2");
-__device__ __forceinline__ void d2_one(const ChainArgs& a, const OneArgs& w1, float* lds, int lane, int wave,
-                                       f32x4 (&acc)[4], f32x4 (&mid)[4]) {
-  using CF = CH_D2;
-  const int h = wave & 1, s = wave >> 1, n = 64 * h + lane;          // N half, position set, the lane's channel
-  float* vs = lds + ONE_V;
-  float* xqs = lds + ONE_XQ;
-  float* scr = lds + ONE_SCR;
-  __syncthreads();                                            // downs.1's tail tile and the halo zeros are in the x slab
-  // ---- x (row form, sample 0) -> V1 (positions permuted) + Xq: one (channel, quad) per thread
-  {
-    const int c = threadIdx.x >> 2, t = threadIdx.x & 3;
-    float d[8], v[8];
-    load_d8<CF::XSTR>(d, lds + 4 * t * CF::XSTR + c);
-    w4_transform(v, d);
-    *reinterpret_cast<float4*>(vs + c * V1S + t * VROW) = make_float4(v[0], v[1], v[2], v[7]);
-    *reinterpret_cast<float4*>(vs + c * V1S + t * VROW + 4) = make_float4(v[3], v[4], v[5], v[6]);
-    *reinterpret_cast<float4*>(xqs + c * XQS + t * 4) = make_float4(d[2], d[3], d[4], d[5]);
-  }
-  __syncthreads();
-  f32x4 m[8], res[4], r2[2];
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  const int aoff = (lane & 3) * VROW + s * 4;
-  // one conv: K loop on all four waves, set-1 accumulators handed to set 0, output transform in wave (h, 0)
-  auto finish = [&](bool with_res) {
-    if (s == 1) {
-      x4_put<4, 0>(scr, h, lane, m);
-      if (with_res) x4_put<2, 0>(scr + 2 * 64 * 16, h, lane, r2);
-    }
-    __syncthreads();
-    if (s == 0) {
-      // m[0..3] holds positions (0, 1, 2, 7); fetch (3, 4, 5, 6) into m[3..6] and restore the natural order
-      m[7] = m[3];
-      x4_get<4, 3>(scr, h, lane, m);
-      if (with_res) {
-        res[0] = r2[0]; res[1] = r2[1];
-        x4_get<2, 2>(scr + 2 * 64 * 16, h, lane, res);
-      }
-      w4n1_out(acc, m);
-    }
-  };
-  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
-    if (MMD_ABL == 1) return;
-    if (tb) {
-      const float t0 = tb[n];
-      gn_mish_quad1<CF::CM, CF::L>(acc, b[n], g[n], be[n], [&](int, int) { return t0; });
-    } else {
-      gn_mish_quad1<CF::CM, CF::L>(acc, b[n], g[n], be[n], [&](int o, int r) { return res[o][r]; });
-    }
-  };
-  auto to_h = [&]() { vform_store1(vs + n * V1S, [&](int o, int r) { return acc[o][r]; }); };
-  auto conv_h = [&](const float* pack) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = z;
-    x4_taps<CF::CM, 4, false>(m, r2, vs + aoff, xqs, 0,
-                              pack + ((size_t)wave * (CF::CM + 4) * 64 + lane) * 4);
-    finish(false);
-  };
-  // =================== RTB 0: conv A (64 -> 128) with the direct 1x1 residual conv (rows 4 t + o) ===================
-  {
-    const float br = a.br[n];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = z;
-    r2[0] = f32x4{br, br, br, br};
-    r2[1] = r2[0];
-    x4_taps<CF::C0P, 4, true>(m, r2, vs + aoff, xqs + (lane & 3) * 4, 2 * s,
-                              w1.d2_a + ((size_t)wave * (CF::C0P + 4) * 64 + lane) * 8);
-    finish(true);
-  }
-  if (s == 0) {
-    gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
-    to_h();                                                   // (the hand-over barrier separated it from every K loop)
-  }
-  __syncthreads();
-  conv_h(w1.d2_h[0]);
-  if (s == 0) gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
-  // =================== identity RTBs (downs.2's second block, mid_block1, mid_block2) ===================
-#pragma unroll
-  for (int k = 0; k < CF::N_IDENT; ++k) {
-    const RtbPtrs& R = a.ri[k];
-    if (s == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) res[i] = acc[i];
-      to_h();
-    }
-    __syncthreads();
-    conv_h(w1.d2_h[1 + 2 * k]);
-    if (s == 0) {
-      gn(R.ba, R.ga, R.bea, R.tb);
-      to_h();
-    }
-    __syncthreads();
-    conv_h(w1.d2_h[2 + 2 * k]);
-    if (s == 0) gn(R.bb, R.gb, R.beb, nullptr);
-    if (CF::MID_AFTER == k + 1 && s == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mid[i] = acc[i];
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// ONE-SAMPLE kernel (unet_kernel_1, <= 512 trajectories): one trajectory per workgroup (4 waves), so a launch of 256 / 512
-// trajectories -- a rank's share of the 32-robot instance on 8 / 4 GPUs, config 5's shard -- spreads over all 256 CUs
-// instead of leaving 3 / 4 or half of them idle.  The workgroup computes only the M tile that holds its sample (the
-// other rows of that tile belong to zero-filled / ignored samples); bit-identical to the other two kernels.
-// ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel_1(UnetArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n0 = blockIdx.x;
-
-  f32x4 skip1[1][4], skip2[4];
-  TR(200);
-  // ---- downs.0 @ L=64: 2 units (waves 0, 1)
-  {
-    f32x4 acc[1][4], mid[1][4];
-    f32x16 t[1];
-    chain_body_dn<CH_D0, true, 4, 1>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
-    __syncthreads();
-    if (wave < 1) tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
-    zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
-  }
-  TR(201);
-  // ---- downs.1 @ L=32: 4 units, skip1
-  {
-    f32x4 acc[1][4];
-    f32x16 t[1];
-    chain_body_dn<CH_D1, false, 4, 1>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
-    __syncthreads();
-    if (wave < CH_D1::WN) tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
-    zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
-  }
-  TR(202);
-  // ---- downs.2 + mid blocks @ L=16 on the 4x4x1 MFMA: waves (N half) x (position set); acc / skip2 live in the set-0 waves
-  f32x4 acc2[4];
-  {
-    d2_one(a.c[2], a.one, lds, lane, wave, acc2, skip2);
-    __syncthreads();
-    // chunk 0 of ups.0's conv A input in the 4-sample V layout the (still 16x16x4) ups.0 body reads: sample 0 = rows 0..3
-    if ((wave >> 1) == 0) vform_store(lds + (64 * (wave & 1) + lane) * VCS, [&](int o, int r) { return acc2[o][r]; });
-  }
-  TR(203);
-  // ---- ups.0 @ L=16: 4 units
-  {
-    f32x16 t[2][1];
-    auto sw = [&](float* xs) {
-      if ((wave >> 1) == 0) vform_store(xs + (64 * (wave & 1) + lane) * VCS, [&](int o, int r) { return skip2[o][r]; });
-    };
-    chain_body_w4u<CH_U0, 4, decltype(sw), 1>(a.c[3], lds, n0, lane, wave, sw, t, 136);
-    __syncthreads();
-    if (wave / CH_U0::WN == 0) {
-      tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
-      tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
-    }
-    zero_halo<CH_U1::C0P, CH_U1::L, CH_U1::SROWS, CH_U1::XSTR, CH_U1::XSS, 4>(lds);
-  }
-  TR(204);
-  // ---- ups.1 @ L=32: 2 units (waves 0, 1)
-  {
-    f32x16 t[2][1];
-    auto sw = [&](float* xs) { quad1_to_stage_u<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1[0], xs, 0, wave, lane); };
-    chain_body_w4u<CH_U1, 4, decltype(sw), 1>(a.c[4], lds, n0, lane, wave, sw, t, 146);
-    __syncthreads();
-    if (wave / CH_U1::WN == 0) {
-      tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
-      tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
-    }
-    zero_halo<32, 64, FIN_SROWS, FIN_STR, FIN_SS, 4>(lds);
-    __syncthreads();
-  }
-  TR(205);
-  // ---- final_conv: waves 0, 1 = the two 16-channel n-tiles / 32-row halves of the sample
-  {
-    const FinalArgs& f = a.fin;
-    const int half = wave & 1;
-    const bool act = wave < 2;
-    f32x4 q[4];
-    if (act) {
-      f32x4 m[8], nores[4];
-      BQ<2> ring[W4_RD];
-      const float* w0 = reinterpret_cast<const float*>(f.wpk) + ((size_t)half * 8 * 64 + lane) * 8;
-      w4_ring_load<2>(ring, w0);
-      w4_taps<32, FIN_STR, 1, false, true>(m, nores, lds, 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
-      w4n1_out(q, m);
-      const int c = half * 16 + (lane & 15);
-      if (MMD_ABL != 1) gn_mish_quad1<32, 64>(q, f.bias[c], f.gamma[c], f.beta[c], [](int, int) { return 0.f; });
-    }
-    __syncthreads();                                                       // both waves are done reading the slab
-    float* yt = lds;
-    if (act) {
-      float* base = yt + 16 * (lane >> 4) * 33 + half * 16 + (lane & 15);  // rows 16 * block + 4 * quad + o
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) base[(4 * r + o) * 33] = q[o][r];
-    }
-    __syncthreads();
-    if (act) {
-      const int col = lane & 31, hi = lane >> 5;
-      f32x16 acc2[1];
-      int ybase[1] = {(half * 32 + (lane & 31)) * 33 + hi};
-      fill<1>(acc2, col < 4 ? f.w1_bias[col] : 0.f);
-      mfma_taps<1, 32, 33, 1>(acc2, yt, ybase, f.w1_pk + lane);
-      if (col < 4 && n0 < a.n) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          f.out[((size_t)n0 * 64 + row) * 4 + col] = acc2[0][r];
-        }
-      }
-    }
-  }
-  TR(206);
-}
-
 
 // ----------------------------------------------------------------------------------------------------------------
 // time embedding table: TimeEncoder (layers.py:232-258) + every block's cond_mlp (layers.py:337-341) for all integer t
@@ -1894,7 +1580,7 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_f
 // wres_wino: the residual weights are stored Winograd-transformed, (Wr * -2/9, Wr * 2/45, Wr * 8/45, 0) = G g for the
 // centre-tap-only kernel at positions (1,2), (3,4), (5,6) (V-form stages, NT = 1).
 static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi, int cinp, int NT,
-                    const float* wres, bool wres_wino = false) {
+                    const float* wres, bool wres_wino = false, bool pair_cols = false) {
   static const double G[8][5] = {{-1, 0, 0, 0, 0},
                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -1910,7 +1596,9 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_
     for (int ks = 0; ks < KS; ++ks)
       for (int lane = 0; lane < 64; ++lane)
         for (int nt = 0; nt < NT; ++nt) {
-          const int ci = c_lo + 4 * ks + (lane >> 4), n = sl * 16 * NT + nt * 16 + (lane & 15);
+          // pair_cols (NT = 1): slices 2 w, 2 w + 1 interleave over the 32 channels of wave w (chain_body_d2)
+          const int ci = c_lo + 4 * ks + (lane >> 4);
+          const int n = pair_cols ? (sl / 2) * 32 + 2 * (lane & 15) + (sl & 1) : sl * 16 * NT + nt * 16 + (lane & 15);
           if (ci >= c_hi) continue;
           float* out = &blob[base + (((size_t)sl * KS + ks) * 64 + lane) * NF];
           const float* g = w + ((size_t)n * cin_full + ci) * 5;
@@ -1929,12 +1617,10 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_
         }
 }
 
-// Role pack of the one-sample kernel (4x4x1 MFMA): [channel c_lo .. c_hi + 4 zero channels][lane][PK] floats for the 64
-// output channels n0 + lane.  cols[i] (i < 4) and col4 (PK = 8: float 4) select what a float holds: 0..7 = Winograd
-// position p of U = G g; 8 / 9 / 10 = the 1x1 residual weight x G[1][2] / G[3][2] / G[5][2] (Winograd-domain residual);
-// 11 = the residual weight itself (direct residual); -1 = 0.
-static void pack_x4_role(std::vector<float>& blob, const float* w, int cin_full, int c_lo, int c_hi, int n0,
-                         const int (&cols)[4], int col4, const float* wres, int PK) {
+// bf16x3 pack of a 128 -> 128 k5 conv for vb_taps: per n-tile [phase][slot][chunk kc][piece q][lane] x 16 B, lane = (column
+// lane & 15 of the tile, channels 8 (4 (lane >> 4) + kc) + j, j = 0..7 at bf16 index j); U = G g as in pack_w4, split by
+// truncation into three bf16 pieces (exact).  Returns the pack's offset in the blob (in floats; 16-byte aligned).
+static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int cin) {
   static const double G[8][5] = {{-1, 0, 0, 0, 0},
                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -1943,30 +1629,40 @@ static void pack_x4_role(std::vector<float>& blob, const float* w, int cin_full,
                                  {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
                                  {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
                                  {0, 0, 0, 0, 1}};
-  const int nc = c_hi - c_lo;
+  while (blob.size() % 4) blob.push_back(0.f);
   const size_t base = blob.size();
-  blob.resize(base + (size_t)(nc + 4) * 64 * PK, 0.f);
-  auto value = [&](int code, int n, int ci) -> float {
-    if (code < 0) return 0.f;
-    if (code < 8) {
-      const float* g = w + ((size_t)n * cin_full + ci) * 5;
-      double u = 0.0;
-      for (int k = 0; k < 5; ++k) u += G[code][k] * (double)g[k];
-      return (float)u;
-    }
-    const double wr = (double)wres[(size_t)n * cin_full + ci];
-    if (code == 11) return (float)wr;
-    return (float)(wr * G[1 + 2 * (code - 8)][2]);
-  };
-  for (int c = 0; c < nc; ++c)
-    for (int lane = 0; lane < 64; ++lane) {
-      float* out = &blob[base + ((size_t)c * 64 + lane) * PK];
-      for (int i = 0; i < 4; ++i) out[i] = value(cols[i], n0 + lane, c_lo + c);
-      if (PK == 8) out[4] = value(col4, n0 + lane, c_lo + c);
-    }
+  const int tiles = cout / 16, KC = cin / 32;
+  const size_t frags = (size_t)tiles * 2 * 4 * KC * 3;
+  blob.resize(base + (frags + 8) * 64 * 4, 0.f);             // + slack for the ring's over-read past the last tile
+  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
+  for (int t = 0; t < tiles; ++t)
+    for (int ph = 0; ph < 2; ++ph)
+      for (int sl = 0; sl < 4; ++sl)
+        for (int kc = 0; kc < KC; ++kc)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int n = (t / 2) * 32 + 2 * (lane & 15) + (t & 1);   // interleaved tile pair of a wave (chain_body_d2)
+              const int ci = 8 * (4 * (lane >> 4) + kc) + j, pos = vb_pos(ph, sl);   // chunk kc = channel blocks kc + 4 g
+              const float* g = w + ((size_t)n * cin + ci) * 5;
+              double ud = 0.0;
+              for (int k = 0; k < 5; ++k) ud += G[pos][k] * (double)g[k];
+              const float u = (float)ud;
+              uint32_t b0, b1, b2;
+              memcpy(&b0, &u, 4);
+              uint32_t h0 = b0 & 0xffff0000u; float f0; memcpy(&f0, &h0, 4);
+              const float r1 = u - f0; memcpy(&b1, &r1, 4);
+              uint32_t h1 = b1 & 0xffff0000u; float f1; memcpy(&f1, &h1, 4);
+              const float r2 = r1 - f1; memcpy(&b2, &r2, 4);
+              const uint32_t piece[3] = {b0 >> 16, b1 >> 16, b2 >> 16};
+              for (int q = 0; q < 3; ++q) {
+                const size_t frag = ((((size_t)t * 2 + ph) * 4 + sl) * KC + kc) * 3 + q;
+                out[(frag * 64 + lane) * 8 + j] = (uint16_t)piece[q];
+              }
+            }
+  return base;
 }
 
-struct ConvW { size_t wpk, bias, gamma, beta; };
+struct ConvW { size_t wpk, bias, gamma, beta, wbf; };
 struct RtbW { ConvW a, b; size_t res_bias; int tb_off; size_t a_c1; };
 
 }  // namespace mmd
@@ -1979,10 +1675,8 @@ struct mmd_unet_s {
   float* ttable = nullptr;   // [T][tb_total]
   int tb_total = 0;
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
-  RtbW rtb_s[12];            // the same with one-n-tile weight packs for the down path / mid blocks (unet_kernel_s)
+  RtbW rtb_s[12];            // the same; downs.2's conv A with a one-n-tile, column-paired pack (chain_body_d2)
   ConvW down[2], up[2], fin;
-  size_t fin_s_wpk = 0;      // one-n-tile pack of the final block's k5 conv
-  size_t one_d2a = 0, one_d2h[7] = {};   // role packs of unet_kernel_1 (downs.2 + mid blocks)
   size_t fin_w1, fin_b1;
 };
 
@@ -2010,6 +1704,8 @@ static RtbPtrs rtb_ptrs(const mmd_unet_s* u, const RtbW& w, int t) {
   p.tb = u->ttable + (size_t)t * u->tb_total + w.tb_off;
   p.wb = reinterpret_cast<const float4*>(u->blob + w.b.wpk);
   p.bb = u->blob + w.b.bias; p.gb = u->blob + w.b.gamma; p.beb = u->blob + w.b.beta;
+  p.wa_bf = w.a.wbf ? reinterpret_cast<const uint4*>(u->blob + w.a.wbf) : nullptr;
+  p.wb_bf = w.b.wbf ? reinterpret_cast<const uint4*>(u->blob + w.b.wbf) : nullptr;
   return p;
 }
 
@@ -2098,15 +1794,18 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.res_bias = R.res ? push(blob, tensors[R.t_rb], R.cout) : 0;
     W.tb_off = tb_off;
     tb_off += R.cout;
-    // one-n-tile packs of the same convs for the small-batch kernel (the up-path RTBs already are)
+    W.a.wbf = W.b.wbf = 0;
+    if (r == 4 || r == 5 || r == 10 || r == 11) {          // downs.2 + mid blocks: bf16x3 packs of the 128 -> 128 convs
+      if (R.cin == R.cout) W.a.wbf = pack_vb(blob, tensors[R.t_w0], R.cout, R.cin);
+      W.b.wbf = pack_vb(blob, tensors[R.t_w1], R.cout, R.cout);
+    }
+    // downs.2's first conv (64 -> 128, fp32, with the residual conv): one-n-tile pack with chain_body_d2's column pairing
     RtbW& S = u->rtb_s[r];
     S = W;
-    if (NT == 2) {
+    if (r == 4) {
       while (blob.size() % 4) blob.push_back(0.f);
       S.a.wpk = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, 1, wres);
-      S.b.wpk = blob.size();
-      pack_w4(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, R.cout, 1, nullptr);
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, 1, wres, false, true);
     }
   }
   u->tb_total = tb_off;
@@ -2123,27 +1822,6 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     u->up[i].bias = push(blob, tensors[s.t_up[i][1]], cu);
   }
   u->fin.wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 2, nullptr);
-  u->fin_s_wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 1, nullptr);
-  {
-    // one-sample kernel, downs.2 + mid blocks (128 output channels): role = (N half h) + 2 * (position set), sets
-    // (0, 1, 2, 7) | (3, 4, 5, 6)
-    static const int kSet[2][4] = {{0, 1, 2, 7}, {3, 4, 5, 6}};
-    static const int kD2[] = {4, 5, 10, 11};
-    const Rtb& R0 = s.rtb[kD2[0]];
-    while (blob.size() % 4) blob.push_back(0.f);
-    u->one_d2a = blob.size();
-    for (int role = 0; role < 4; ++role)
-      pack_x4_role(blob, tensors[R0.t_w0], R0.cin, 0, R0.cin, 64 * (role & 1), kSet[role >> 1], 11, tensors[R0.t_rw], 8);
-    int k = 0;
-    for (int j = 0; j < 4; ++j) {
-      const Rtb& R = s.rtb[kD2[j]];
-      for (int ab = (j == 0 ? 1 : 0); ab < 2; ++ab) {
-        u->one_d2h[k++] = blob.size();
-        for (int role = 0; role < 4; ++role)
-          pack_x4_role(blob, tensors[ab ? R.t_w1 : R.t_w0], R.cout, 0, R.cout, 64 * (role & 1), kSet[role >> 1], -1, nullptr, 4);
-      }
-    }
-  }
   u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
   u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
   u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
@@ -2198,7 +1876,8 @@ static const double kUnetFlops =
     rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64;
 
-// MFMA FLOPs actually issued per trajectory (Winograd convs: 8 products per 4 outputs; channel / N padding included)
+// fp32 GEMM FLOPs the matrix pipe executes per trajectory (Winograd convs: 8 products per 4 outputs; channel / N padding
+// included).  The seven 128 -> 128 convs of downs.2 + mid run them as bf16x3 (6 bf16 MFMA FLOPs per fp32 FLOP).
 static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // per sample
 static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
@@ -2219,11 +1898,7 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   MMD_REQUIRE(ws_bytes >= mmd_unet_workspace_bytes(u, n), "mmd_unet_forward: workspace too small");
   // state_dict RTB indices: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2 = 0..11
   static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};
-  // <= 1024 trajectories cannot put two workgroups on a CU: the launch is bound by one workgroup's dependent chain, which the
-  // 8-wave kernel halves.  MMD_AMD_UNET_KERNEL = big | small forces one of them (A/B measurements).
-  bool small = n <= 1024, one = false;   // `one` (unet_kernel_1) is opt-in until it wins: MMD_AMD_UNET_KERNEL=one
-  if (const char* e = getenv("MMD_AMD_UNET_KERNEL")) { small = e[0] == 's' || e[0] == 'o'; one = e[0] == 'o'; }
-  const RtbW* set = small ? u->rtb_s : u->rtb;
+  const RtbW* set = u->rtb;
   UnetArgs a{};
   a.n = n;
   a.c[0] = args_chain(u, set, kD0, 1, &u->down[0], x, t, n);
@@ -2232,18 +1907,14 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.c2s = args_chain(u, u->rtb_s, kD2, 3, nullptr, nullptr, t, n);
   a.c[3] = args_chain(u, set, kU0, 1, &u->up[0], nullptr, t, n);
   a.c[4] = args_chain(u, set, kU1, 1, &u->up[1], nullptr, t, n);
-  a.one.d2_a = u->blob + u->one_d2a;
-  for (int k = 0; k < 7; ++k) a.one.d2_h[k] = u->blob + u->one_d2h[k];
   a.fin.out = eps;
-  a.fin.wpk = reinterpret_cast<const float4*>(u->blob + (small ? u->fin_s_wpk : u->fin.wpk));
+  a.fin.wpk = reinterpret_cast<const float4*>(u->blob + u->fin.wpk);
   a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
   a.fin.w1_pk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
   a.fin.w1_bias = u->blob + u->fin_b1;
   const bool bracket = prof && (prof->seen++ % prof->stride) == 0 && prof->used + 2 <= prof->ev.size();
   if (bracket) (void)hipEventRecord(prof->ev[prof->used], st);
-  if (one) hipLaunchKernelGGL(unet_kernel_1, dim3(n), dim3(256), 0, st, a);
-  else if (small) hipLaunchKernelGGL(unet_kernel_s, dim3((n + 3) / 4), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
   if (bracket) { (void)hipEventRecord(prof->ev[prof->used + 1], st); prof->used += 2; }
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
@@ -2266,6 +1937,7 @@ int mmd_debug_set_trace(void* dev_ptr) {
 
 double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
 double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }
+double mmd_unet_bf16x3_flops_per_trajectory(void) { return 7 * wino4_flops(128, 128); }
 
 int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride) {
   MMD_REQUIRE(out && max_launches > 0, "mmd_profiler_create: bad arguments");
