@@ -200,6 +200,13 @@ def main():
     assert torch.isfinite(trajs).all()
     value = args.steps * n_traj_local * world / dt
     dom_ms = dom_ms_c.value
+    # mmd_p_sample_loop splits the robots into `chunks` concurrent launch chains (HIP streams, default 2): at any time
+    # `chunks` unet_kernel launches of n_traj_local / chunks trajectories each share the GPU.  launch_ms is the mean
+    # duration of ONE such launch (what rocprofv3 --stats reports for unet_kernel); the rate the GPU sustains is that of
+    # all `chunks` launches in flight.
+    chunks = int(os.environ.get("MMD_AMD_STREAMS", "0") or 0) or 2
+    chunks = max(1, min(chunks, 4, RPG))
+    launch_flops, launch_mfma, launch_bf = flops / chunks, mfma_flops / chunks, bf_flops / chunks
     issued_tf = mfma_flops / (dom_ms * 1e-3) / 1e12
     alg_tf = flops / (dom_ms * 1e-3) / 1e12
 
@@ -207,7 +214,7 @@ def main():
     # as profiles/pmc_latest.json: traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE half-count correction)
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path) and n_traj_local == 2048:
+    if os.path.exists(pmc_path) and n_traj_local // chunks == 1024:
         with open(pmc_path) as f:
             pmc = json.load(f).get(DOMINANT_KERNEL)
         if pmc:
@@ -222,12 +229,19 @@ def main():
     roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; the 25 k=5 convs as Winograd F(4,5): fp32 MFMA GEMMs, the seven 128->128 convs as bf16x3 on the bf16 MFMA; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
                 "achieved": issued_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued_tf / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
-                "flops_per_launch": mfma_flops, "flops_per_launch_as_bf16x3": bf_flops,
+                "concurrent_launches": chunks, "trajectories_per_launch": n_traj_local // chunks,
+                "flops_per_launch": launch_mfma, "flops_per_launch_as_bf16x3": launch_bf,
+                "achieved_single_launch": launch_mfma / (dom_ms * 1e-3) / 1e12,
                 "pipe_busy_model": busy_s / (dom_ms * 1e-3),
-                "note": "achieved = fp32 GEMM FLOPs run on the matrix pipe per launch / launch time, vs the fp32 MFMA peak; pipe_busy_model = MFMA issue time at spec clock / launch time (fp32 MFMAs at 157.3 TF, the bf16x3 ones at 6 bf16 FLOPs per fp32 FLOP and 2516.6 TF); see `algorithmic` for the direct-convolution count",
-                "algorithmic": {"flops_per_launch": flops, "achieved": alg_tf, "ratio_to_peak": alg_tf / PEAK_FP32_MFMA_TFLOPS,
-                                "note": "direct-conv FLOPs (2*C_out*taps*C_in*L_out) / time; Winograd F(4,5) issues 0.45x of them, so this can exceed the MFMA peak"},
-                "launches_per_forward": 1}
+                "note": "flops = fp32 GEMM FLOPs run on the matrix pipe (Winograd-domain; 57 % of them as bf16x3: 6 bf16 MFMA FLOPs per fp32 FLOP). "
+                        "`concurrent_launches` launches of `trajectories_per_launch` trajectories share the GPU at any time (the sampler's stream chunks); "
+                        "launch_ms = mean duration of one of them (HIP events on its stream; = rocprofv3's average for unet_kernel). "
+                        "achieved = concurrent_launches x flops_per_launch / launch_ms = the rate the GPU sustains, vs the fp32 MFMA peak; "
+                        "achieved_single_launch = flops_per_launch / launch_ms is one launch's share of it. "
+                        "pipe_busy_model = MFMA issue time at spec clock (fp32 MFMAs at 157.3 TF, bf16 ones at 2516.6 TF) / launch time",
+                "algorithmic": {"flops_per_launch": launch_flops, "achieved": alg_tf, "ratio_to_peak": alg_tf / PEAK_FP32_MFMA_TFLOPS,
+                                "note": "direct-conv FLOPs (2*C_out*taps*C_in*L_out), all concurrent launches / launch time; Winograd F(4,5) issues 0.45x of them, so this can exceed the MFMA peak"},
+                "launches_per_forward": chunks}
 
     out = {
         "metric": "guided trajectories/sec (H=64, 100 denoise steps), 32-robot Empty map",

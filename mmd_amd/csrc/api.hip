@@ -31,6 +31,7 @@ void set_error(const char* fmt, ...) {
 
 constexpr int kMaxChunks = 4;
 
+
 // side streams of the chunked sampling loop: created once per (thread, device), never destroyed
 struct Streams {
   hipStream_t s[kMaxChunks] = {};
@@ -137,7 +138,10 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   // results are bit-identical to the unsplit run.
   int nch = s->n_streams;
   if (const char* e = getenv("MMD_AMD_STREAMS")) nch = atoi(e);
-  if (nch <= 0) nch = 1;   // auto = off: 2 chunks measured +3 % only, and one stream keeps per-kernel accounting clean
+  // auto = 2 chunks: +7 % on the 32-robot round since downs.2 + mid run weight-stream-bound (bf16x3) -- one chunk's
+  // bandwidth-bound stages and step kernels meet the other's compute-bound ones on a CU, and a chunk's forward no longer
+  // ends with CUs idling until its slowest workgroup is done
+  if (nch <= 0) nch = 2;
   if (nch > kMaxChunks) nch = kMaxChunks;
   if (nch > n_robots) nch = n_robots;
   Streams* S = nullptr;

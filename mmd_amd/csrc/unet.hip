@@ -1,9 +1,11 @@
 // TemporalUnet forward for gfx950 (MI355X), the whole network in ONE launch (unet_kernel).  Every Conv1d /
 // ConvTranspose1d of the reference network (mmd/models/diffusion_models/temporal_unet.py:121-174,
-// mmd/models/layers/layers.py:261-358) is a GEMM on the fp32 MFMA (exact fp32 products and accumulation), with
-// GroupNorm + Mish + time-bias / residual fused into the epilogue:
-//   * all 25 stride-1 k=5 convs run as Winograd F(4,5) on v_mfma_f32_16x16x4_f32 (8 instead of 20 multiplies per 4
-//     outputs; fp32, ~2e-6 relative difference to the direct sum);
+// mmd/models/layers/layers.py:261-358) is an fp32 GEMM on the matrix pipe, with GroupNorm + Mish + time-bias / residual
+// fused into the epilogue:
+//   * all 25 stride-1 k=5 convs run as Winograd F(4,5) (8 instead of 20 multiplies per 4 outputs; ~2e-6 relative
+//     difference to the direct sum): 18 of them on v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation), the
+//     seven 128 -> 128 convs of downs.2 + mid blocks (51 % of the MACs) as an exact three-way bf16 split of both
+//     operands on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- as accurate as the fp32 MFMA, 2.7x its rate;
 //   * strided / transposed / 1x1 convs: direct GEMMs (taps = row-shifted views of an LDS slab; v_mfma_f32_32x32x2_f32
 //     for the down / up-sampling convs and the final 1x1, 16x16x4 for the 1x1 residual convs).
 //
@@ -643,11 +645,13 @@ __device__ __forceinline__ void slab_sync() {
 // 16-lane read group takes from two of them fall on disjoint banks; the blocks c, c + 1 (c & 3) of one such group lie
 // 256 + 32 B apart and the rows are ordered quad-major, so the epilogue's ds_write_b32 -- lanes = (4 adjacent channel
 // pairs) x (4 channel blocks c & 3) x (2 samples), one quad per instruction -- hit 32 distinct banks per 32-lane group.
-// All 8 Winograd positions of 128 channels would be
-// 98 KB, more than a workgroup's half of the CU's LDS, so a conv runs in two PHASES over the position sets {0, 1, 2, 7} and
-// {3, 4, 5, 6} (slots 0..3 of a phase; the same split of B^T the one-sample kernel uses: neither set shares a partial sum
-// with the other): store set 0 -- barrier -- MFMAs -- barrier -- store set 1 -- barrier -- MFMAs; the conv's input tile
-// waits in registers meanwhile.
+// All 8 Winograd positions of 128 channels would be 120 KB, more than a workgroup's half of the CU's LDS, so a conv runs
+// in two PHASES over the position sets {0, 1, 2, 7} and {3, 4, 5, 6} (slots 0..3 of a phase; neither set shares a partial
+// sum of B^T or A^T with the other): store set 0 -- barrier -- MFMAs -- barrier -- store set 1 -- barrier -- MFMAs; the
+// conv's input tile waits in registers meanwhile.
+// What bounds these convs is the weight stream, not the matrix pipe: a workgroup has only 16 rows (4 samples x 4 quads)
+// to use a weight fragment on, so the four waves of a CU's SIMDs at the full bf16 rate would pull 112 B/clk through the
+// 64 B/clk/CU vector-memory path; the phases run at ~45 B/clk.
 // Weights: per n-tile and conv [phase][slot][chunk kc][piece q] fragments of 64 lanes x 16 B (lane = column lane & 15,
 // channel block kc + 4 (lane >> 4)), streamed through a two-step register ring.
 // ----------------------------------------------------------------------------------------------------------------
@@ -977,24 +981,20 @@ __device__ __forceinline__ void quad1_to_stage_u(const f32x4 (&q)[4], float* dst
 }
 
 // SKIPW(xslab): writes the stage's skip tensor (chunk 1 of the channel concat) into the x slab in the form this stage
-// reads (V form at L = 16, row form otherwise); it is called by EVERY wave of the workgroup.  WAVES = 8 (small-batch
-// kernel): the 4 (M, N) units of the RTBs run on waves 0..3 (the other four only take part in the barriers, the skip
-// write and the tail conv, whose 8 units = 2 parity passes x 4 tiles are one per wave).
-template <class CF, int WAVES, class SKIPW, int SMP = 4>
-__device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int n0, int lane, int wave, SKIPW skip_write,
-                                               f32x16 (&tout)[8 / WAVES][CF::MT_W], int trb) {
+// reads (V form at L = 16, row form otherwise); it is called by every wave of the workgroup.
+template <class CF, class SKIPW>
+__device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int lane, int wave, SKIPW skip_write,
+                                               f32x16 (&tout)[2][CF::MT_W], int trb) {
   static_assert((CF::L == 16 || CF::L == 32) && CF::CM * CF::L == 1024 && CF::C1 == CF::C0 && CF::RES0 == RES_CONV &&
                     CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "up-path stage with 4 waves = (L / 16 M tiles) x (CM / 16 n-tiles)");
   // L = 16 (ups.0): conv inputs are V-form slabs at the start of the LDS (the two chunks of cat(x, skip) one after the
   // other, then H), all aliasing each other and the row-form H slab of the tail conv; barriers separate the phases
   constexpr bool VH = CF::L == 16;
   static_assert(!VH || CF::C0P == 128, "V-form ups.0: 128-channel chunks from the L = 16 down stage");
-  // SMP = 1: the workgroup owns one sample = M tile 0 only (ups.1: waves 0, 1)
-  const bool act = (WAVES == 4 || wave < 4) && (SMP == 4 || (wave & 3) / (CF::CM / 16) == 0);
   float* hslab = VH ? lds : lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, NTQ = CF::CM / 16;
-  const int mt = (wave & 3) / NTQ, nq = (wave & 3) % NTQ;
+  const int mt = wave / NTQ, nq = wave % NTQ;
   const int ai = mt * 16 + (lane & 15);
   const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
   const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
@@ -1010,8 +1010,8 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   auto wlane3 = [&](const float4* w, int cp) {
     return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
   };
-  if (act) w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
-  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, WAVES * 64>(hslab);
+  w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
+  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, 256>(hslab);
   __syncthreads();
   TR(trb + 0);
 
@@ -1034,19 +1034,19 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
   if constexpr (VH) {
     f32x4 rm[6];
-    if (act) {
+    {
       w4v_taps<CF::C0P, 1, true, true>(m, rm, xslab, vbase, wlane3(a.r0.wa, CF::C0P), ring3);
       w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
     }
     __syncthreads();                                          // chunk 0 has been consumed by every wave
     skip_write(xslab);
     __syncthreads();
-    if (act) {
+    {
       w4v_taps<CF::C1P, 1, true, false>(m, rm, xslab, vbase, wlane3(a.wa0_c1, CF::C1P), ring3);
       w4n1_res_out(res, rm, a.br[col]);
     }
   } else {
-    if (act) {
+    {
       const float br = a.br[col];
 #pragma unroll
       for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
@@ -1056,9 +1056,9 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     __syncthreads();                                            // chunk 0 has been consumed by every wave
     skip_write(xslab);
     __syncthreads();
-    if (act) w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
+    w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
   }
-  if (act) {
+  {
     w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
     w4n1_out(acc, m);
     const float tb = a.r0.tb[col];
@@ -1066,10 +1066,10 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   }
   TR(trb + 1);
   if constexpr (VH) __syncthreads();                         // chunk 1 is consumed: the H slab aliases it
-  if (act) to_h();
+  to_h();
   __syncthreads();
   TR(trb + 2);
-  if (act) {
+  {
     conv_h(a.r0.wb, a.ri[0].wa);
     if (MMD_ABL != 1)
       gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col], [&](int o, int r) { return res[o][r]; });
@@ -1082,18 +1082,18 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 #pragma unroll
     for (int o = 0; o < 4; ++o) res[o] = acc[o];
     __syncthreads();                                         // the previous conv is done reading the H slab
-    if (act) to_h();
+    to_h();
     __syncthreads();
-    if (act) {
+    {
       conv_h(R.wa, R.wb);
       const float tb = R.tb[col];
       if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col], [&](int, int) { return tb; });
     }
     TR(trb + 5);
     __syncthreads();
-    if (act) to_h();
+    to_h();
     __syncthreads();
-    if (act) {
+    {
       conv_h(R.wb, nullptr);
       if (MMD_ABL != 1)
         gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col], [&](int o, int r) { return res[o][r]; });
@@ -1104,14 +1104,13 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   // =================== tail: Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, direct ===================
   // (reads a row-form H slab; at L = 16 it aliases the V-form slabs, which are dead after the barrier)
   __syncthreads();
-  if constexpr (VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, WAVES * 64>(hslab);
-  if (act) quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane);
+  if constexpr (VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, 256>(hslab);
+  quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane);
   __syncthreads();
   TR(trb + 7);
   {
-    constexpr int MT_W = CF::MT_W, PPW = 8 / WAVES;                       // parity passes per wave
-    const int tw = wave & 3;
-    const int wm = tw / CF::WN, wnt = tw % CF::WN, colt = wnt * 32 + (lane & 31), hi = lane >> 5;
+    constexpr int MT_W = CF::MT_W;
+    const int wm = wave / CF::WN, wnt = wave % CF::WN, colt = wnt * 32 + (lane & 31), hi = lane >> 5;
     int hb[MT_W];
 #pragma unroll
     for (int t = 0; t < MT_W; ++t) {
@@ -1121,10 +1120,8 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     const float bt = a.bt[colt];
     constexpr int G = 2 * CF::CM / 8;
 #pragma unroll
-    for (int pp = 0; pp < PPW; ++pp) {
-      if (SMP == 1 && wm != 0) break;                                    // one sample: its rows are in the first M tile
-      const int pass = WAVES == 4 ? pp : (wave >> 2);
-      f32x16 (&t)[MT_W] = tout[pp];
+    for (int pass = 0; pass < 2; ++pass) {                                // the two output parities
+      f32x16 (&t)[MT_W] = tout[pass];
       fill<MT_W>(t, bt);
       int ub[MT_W];
 #pragma unroll
@@ -1346,7 +1343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
   {
     f32x16 t[2][1];
-    chain_body_w4u<CH_U0, 4>(a.c[3], lds, n0, lane, wave,
+    chain_body_w4u<CH_U0>(a.c[3], lds, lane, wave,
                              [&](float* xs) {
 #pragma unroll
                                for (int h = 0; h < 2; ++h)
@@ -1363,7 +1360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
   {
     f32x16 t[2][1];
-    chain_body_w4u<CH_U1, 4>(a.c[4], lds, n0, lane, wave,
+    chain_body_w4u<CH_U1>(a.c[4], lds, lane, wave,
                              [&](float* xs) { quad_to_stage<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1, xs, wave, lane); },
                              t, 146);
     __syncthreads();
