@@ -228,6 +228,7 @@ struct ChainArgs {
   const float* in0;                      // [n, L, C0] network input (first chain only)
   RtbPtrs r0;
   const float4* wa0_c1;                  // conv A pack of the second input chunk (C1 > 0)
+  const uint4* wa0_c1_bf;                // ... its bf16x3 form (ups.0: vbu_taps)
   const float* br;                       // bias of the 1x1 residual conv (its weights ride in the conv A packs)
   RtbPtrs ri[MAX_IDENT];
   const float4* wt; const float* bt;     // tail conv pack(s), bias
@@ -774,6 +775,65 @@ __device__ __forceinline__ void vb_taps(f32x4 (&m)[2][8], const char* va, const 
   }
 }
 
+// ups.0's conv A (256 -> 64 over the two 128-channel chunks of cat(x, skip2), with the stage's 1x1 residual conv in the
+// Winograd domain) in the same bf16x3 form.  One n-tile per wave; the two accumulator streams of a step are the two
+// slots of a slot pair (pair, pair + 1), and the residual conv -- G g of a centre-tap-only kernel is w * (-2/9, -2/9, 2/45,
+// 2/45, 8/45, 8/45) at positions 1..6, zero at 0 and 7 -- rides on the A fragments already loaded: one more stream in
+// phase 0 (position 1 resp. 2 of the pair), two in phase 1.  Weights per n-tile and chunk: [phase][pair][chunk kc][9
+// fragments: slot 0 pieces, slot 1 pieces, residual pieces].
+constexpr int VBU_FRAGS = 2 * 2 * 4 * 9;
+__device__ __forceinline__ void vbu_load_b(u32x4 (&b)[9], const u32x4* w, int ph, int step) {
+  const u32x4* p = w + ((ph * 8 + step) * 9) * 64;
+#pragma unroll
+  for (int f = 0; f < 9; ++f) b[f] = p[f * 64];
+}
+__device__ __forceinline__ void vbu_load_a(u32x4 (&a)[2][3], const char* va, int step) {
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      a[st][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + 2 * (step / 4) + st) * VB_PS + (step % 4) * VB_CB);
+}
+template <int PH>
+__device__ __forceinline__ void vbu_ring_load(u32x4 (&b)[VB_RD][9], const u32x4* w) {
+#pragma unroll
+  for (int i = 0; i < VB_RD; ++i) vbu_load_b(b[i], w, PH, i);
+  MMD_PIN_LOADS();
+}
+// phase PH of one chunk: m[position] (+)= conv, rm[position - 1] (+)= residual conv; FRESH: first chunk (start from zero)
+template <int PH, bool FRESH>
+__device__ __forceinline__ void vbu_taps(f32x4 (&m)[8], f32x4 (&rm)[6], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][9]) {
+  constexpr int PI[6] = {2, 1, 0, 1, 0, 0}, PJ[6] = {0, 1, 2, 0, 1, 0};   // piece products, lowest order first
+  u32x4 a[2][2][3];
+  vbu_load_a(a[0], va, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i + 1 < 8) vbu_load_a(a[(i + 1) & 1], va, i + 1);
+    MMD_PIN_LOADS();
+    const int pair = i / 4, px = vb_pos(PH, 2 * pair), py = vb_pos(PH, 2 * pair + 1);
+    // residual streams: phase 0: the pair's one position in 1..6 (pair 0: position 1 = slot 1, pair 1: position 2 = slot 0)
+    const int r0 = PH == 0 ? pair : px - 1, r1 = py - 1, sa0 = PH == 0 ? 1 - pair : 0;
+    const bool zero = FRESH && i % 4 == 0;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cx = zero ? z : m[px], cy = zero ? z : m[py], c0 = zero ? z : rm[r0], c1 = zero ? z : rm[PH == 0 ? r0 : r1];
+    const u32x4(&ax)[3] = a[i & 1][0];
+    const u32x4(&ay)[3] = a[i & 1][1];
+    const u32x4(&ar)[3] = a[i & 1][sa0];
+    const u32x4(&bb)[9] = b[i % VB_RD];
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      cx = mfma_bf(ax[PI[pr]], bb[PJ[pr]], cx);
+      cy = mfma_bf(ay[PI[pr]], bb[3 + PJ[pr]], cy);
+      c0 = mfma_bf(ar[PI[pr]], bb[6 + PJ[pr]], c0);
+      if constexpr (PH == 1) c1 = mfma_bf(ay[PI[pr]], bb[6 + PJ[pr]], c1);
+    }
+    m[px] = cx; m[py] = cy; rm[r0] = c0;
+    if constexpr (PH == 1) rm[r1] = c1;
+    if (i + VB_RD < 8) vbu_load_b(b[i % VB_RD], w, PH, i + VB_RD);
+    MMD_PIN_LOADS();
+  }
+}
+
 template <class CF, bool FIRST>
 __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[8],
                                               f32x4 (&mid)[8], f32x16 (&tout)[1], int trb) {
@@ -1010,9 +1070,11 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   auto wlane3 = [&](const float4* w, int cp) {
     return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
   };
-  w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
-  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, 256>(hslab);
-  __syncthreads();
+  if constexpr (!VH) {
+    w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
+    zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, 256>(hslab);
+  }
+  __syncthreads();                                           // the previous stage is done with the LDS
   TR(trb + 0);
 
   f32x4 m[8], acc[4], res[4];
@@ -1033,18 +1095,34 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 
   // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
   if constexpr (VH) {
+    // bf16x3 (vbu_taps): skip_write(chunk, phase) stores that phase of chunk 0 (x) / 1 (skip) into the phase slab
     f32x4 rm[6];
-    {
-      w4v_taps<CF::C0P, 1, true, true>(m, rm, xslab, vbase, wlane3(a.r0.wa, CF::C0P), ring3);
-      w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
-    }
-    __syncthreads();                                          // chunk 0 has been consumed by every wave
-    skip_write(xslab);
+    const u32x4* wp0 = reinterpret_cast<const u32x4*>(a.r0.wa_bf) + (size_t)nq * VBU_FRAGS * 64 + lane;
+    const u32x4* wp1 = reinterpret_cast<const u32x4*>(a.wa0_c1_bf) + (size_t)nq * VBU_FRAGS * 64 + lane;
+    const char* const vb_a = reinterpret_cast<const char*>(lds) + (lane >> 4) * VB_CG + (4 * (lane & 3) + ((lane & 15) >> 2)) * 16;
+    u32x4 ring_u[VB_RD][9];
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    vbu_ring_load<0>(ring_u, wp0);
+    skip_write(C0{}, C0{});
     __syncthreads();
-    {
-      w4v_taps<CF::C1P, 1, true, false>(m, rm, xslab, vbase, wlane3(a.wa0_c1, CF::C1P), ring3);
-      w4n1_res_out(res, rm, a.br[col]);
-    }
+    vbu_taps<0, true>(m, rm, vb_a, wp0, ring_u);
+    vbu_ring_load<1>(ring_u, wp0);
+    __syncthreads();                                         // every wave is done reading the slab
+    skip_write(C0{}, C1{});
+    __syncthreads();
+    vbu_taps<1, true>(m, rm, vb_a, wp0, ring_u);
+    vbu_ring_load<0>(ring_u, wp1);
+    __syncthreads();
+    skip_write(C1{}, C0{});
+    __syncthreads();
+    vbu_taps<0, false>(m, rm, vb_a, wp1, ring_u);
+    vbu_ring_load<1>(ring_u, wp1);
+    __syncthreads();
+    skip_write(C1{}, C1{});
+    __syncthreads();
+    vbu_taps<1, false>(m, rm, vb_a, wp1, ring_u);
+    w4n1_res_out(res, rm, a.br[col]);
   } else {
     {
       const float br = a.br[col];
@@ -1330,27 +1408,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
   }
   // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2 (lane = channels 32 wave + 2 (lane & 15) + h: chain_body_d2)
-  const int c2 = 32 * wave + 2 * (lane & 15);
-  {
-    f32x4 acc[2][4];
-    chain_body_d2<CH_D2>(a.c2s, lds, lane, wave, acc, skip2, 80);
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)                                            // chunk 0 of ups.0's conv A input, V form
-      vform_store(lds + (c2 + h) * VCS + (lane >> 4) * 4 * VROW, [&](int o, int r) { return acc[h][o][r]; });
-  }
+  f32x4 mid_out[2][4];
+  chain_body_d2<CH_D2>(a.c2s, lds, lane, wave, mid_out, skip2, 80);
   TR(130);
-  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]
+  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]; conv A reads both chunks as bf16x3 phase slabs stored from the tiles
   {
     f32x16 t[2][1];
+    char* const vb_s = reinterpret_cast<char*>(lds) + wave * VB_CG + ((lane & 15) >> 2) * VB_CB + (lane >> 4) * 16 + (lane & 3) * 4;
     chain_body_w4u<CH_U0>(a.c[3], lds, lane, wave,
-                             [&](float* xs) {
-#pragma unroll
-                               for (int h = 0; h < 2; ++h)
-                                 vform_store(xs + (c2 + h) * VCS + (lane >> 4) * 4 * VROW,
-                                             [&](int o, int r) { return skip2[h][o][r]; });
-                             },
-                             t, 136);
+                          [&](auto chunk, auto ph) {
+                            if constexpr (decltype(chunk)::value == 0)
+                              vb_store_pair<decltype(ph)::value>(vb_s, [&](int o, int r) { return mid_out[0][o][r]; },
+                                                                 [&](int o, int r) { return mid_out[1][o][r]; });
+                            else
+                              vb_store_pair<decltype(ph)::value>(vb_s, [&](int o, int r) { return skip2[0][o][r]; },
+                                                                 [&](int o, int r) { return skip2[1][o][r]; });
+                          },
+                          t, 136);
     __syncthreads();
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
     tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
@@ -1659,8 +1733,60 @@ static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int ci
   return base;
 }
 
+// bf16x3 pack of one 128-channel chunk [c_lo, c_lo + 128) of ups.0's conv A (k5, cout 64, with the 1x1 residual conv wres
+// in the Winograd domain) for vbu_taps: per n-tile [phase][slot pair][chunk kc][9 fragments][lane] x 16 B; fragments 0..2 /
+// 3..5 = the pieces of the pair's two slots, 6..8 = the pieces of wres * G[p][2] for the pair's residual position(s)
+// (-2/9 in phase 0, 2/45 and 8/45 for the pairs of phase 1).  Columns are plain (n = 16 tile + (lane & 15)).
+static size_t pack_vbu(std::vector<float>& blob, const float* w, const float* wres, int cout, int cin_full, int c_lo) {
+  static const double G[8][5] = {{-1, 0, 0, 0, 0},
+                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                 {0, 0, 0, 0, 1}};
+  while (blob.size() % 4) blob.push_back(0.f);
+  const size_t base = blob.size();
+  const int tiles = cout / 16;
+  const size_t frags = (size_t)tiles * 2 * 2 * 4 * 9;
+  blob.resize(base + (frags + 16) * 64 * 4, 0.f);            // + slack for the ring's over-read past the last tile
+  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
+  for (int t = 0; t < tiles; ++t)
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pair = 0; pair < 2; ++pair)
+        for (int kc = 0; kc < 4; ++kc)
+          for (int grp = 0; grp < 3; ++grp)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int n = 16 * t + (lane & 15), ci = c_lo + 8 * (4 * (lane >> 4) + kc) + j;
+                double ud;
+                if (grp < 2) {
+                  const int pos = vb_pos(ph, 2 * pair + grp);
+                  const float* g = w + ((size_t)n * cin_full + ci) * 5;
+                  ud = 0.0;
+                  for (int k = 0; k < 5; ++k) ud += G[pos][k] * (double)g[k];
+                } else {
+                  ud = (double)wres[(size_t)n * cin_full + ci] * G[ph == 0 ? 1 : (pair == 0 ? 3 : 5)][2];
+                }
+                const float u = (float)ud;
+                uint32_t b0, b1, b2;
+                memcpy(&b0, &u, 4);
+                uint32_t h0 = b0 & 0xffff0000u; float f0; memcpy(&f0, &h0, 4);
+                const float r1 = u - f0; memcpy(&b1, &r1, 4);
+                uint32_t h1 = b1 & 0xffff0000u; float f1; memcpy(&f1, &h1, 4);
+                const float r2 = r1 - f1; memcpy(&b2, &r2, 4);
+                const uint32_t piece[3] = {b0 >> 16, b1 >> 16, b2 >> 16};
+                for (int q = 0; q < 3; ++q) {
+                  const size_t frag = (((((size_t)t * 2 + ph) * 2 + pair) * 4 + kc) * 9) + grp * 3 + q;
+                  out[(frag * 64 + lane) * 8 + j] = (uint16_t)piece[q];
+                }
+              }
+  return base;
+}
+
 struct ConvW { size_t wpk, bias, gamma, beta, wbf; };
-struct RtbW { ConvW a, b; size_t res_bias; int tb_off; size_t a_c1; };
+struct RtbW { ConvW a, b; size_t res_bias; int tb_off; size_t a_c1, a_c1_bf; };
 
 }  // namespace mmd
 
@@ -1714,6 +1840,7 @@ static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb
   const RtbW& w0 = set[rtb[0]];
   a.r0 = rtb_ptrs(u, w0, t);
   a.wa0_c1 = reinterpret_cast<const float4*>(u->blob + w0.a_c1);
+  a.wa0_c1_bf = w0.a_c1_bf ? reinterpret_cast<const uint4*>(u->blob + w0.a_c1_bf) : nullptr;
   a.br = u->blob + w0.res_bias;
   for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, set[rtb[1 + k]], t);
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
@@ -1769,12 +1896,12 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
     W.a_c1 = 0;
     W.a.wpk = blob.size();
-    if (r == 6 || r == 8) {   // ups.*.0: input = cat(x, skip), staged chunk by chunk: one pack per chunk
+    if (r == 6) {             // ups.0 conv A runs as bf16x3 (pack_vbu below)
+    } else if (r == 8) {      // ups.1: input = cat(x, skip), staged chunk by chunk: one pack per chunk
       const int half = R.cin / 2;
-      const bool wino_res = r == 6;   // ups.0 (L = 16) reads V-form slabs: its residual conv runs in the Winograd domain
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres, wino_res);
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres);
       W.a_c1 = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres, wino_res);
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
     } else {
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres);
     }
@@ -1791,7 +1918,11 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.res_bias = R.res ? push(blob, tensors[R.t_rb], R.cout) : 0;
     W.tb_off = tb_off;
     tb_off += R.cout;
-    W.a.wbf = W.b.wbf = 0;
+    W.a.wbf = W.b.wbf = W.a_c1_bf = 0;
+    if (r == 6) {                                          // ups.0 conv A: bf16x3 packs of its two input chunks
+      W.a.wbf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, 0);
+      W.a_c1_bf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, R.cin / 2);
+    }
     if (r == 4 || r == 5 || r == 10 || r == 11) {          // downs.2 + mid blocks: bf16x3 packs of the 128 -> 128 convs
       if (R.cin == R.cout) W.a.wbf = pack_vb(blob, tensors[R.t_w0], R.cout, R.cin);
       W.b.wbf = pack_vb(blob, tensors[R.t_w1], R.cout, R.cout);
