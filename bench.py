@@ -204,7 +204,7 @@ def main():
     # `chunks` unet_kernel launches of n_traj_local / chunks trajectories each share the GPU.  launch_ms is the mean
     # duration of ONE such launch (what rocprofv3 --stats reports for unet_kernel); the rate the GPU sustains is that of
     # all `chunks` launches in flight.
-    chunks = int(os.environ.get("MMD_AMD_STREAMS", "0") or 0) or 2
+    chunks = int(os.environ.get("MMD_AMD_STREAMS", "0") or 0) or (2 if n_traj_local >= 2048 else 1)
     chunks = max(1, min(chunks, 4, RPG))
     launch_flops, launch_mfma, launch_bf = flops / chunks, mfma_flops / chunks, bf_flops / chunks
     issued_tf = mfma_flops / (dom_ms * 1e-3) / 1e12
@@ -221,19 +221,19 @@ def main():
             traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
     # `achieved` / `frac`: the fp32 GEMM FLOPs the kernel actually runs on the matrix pipe per launch (Winograd F(4,5) for
     # the k=5 convs, i.e. 0.45x the multiplies of the direct form) / launch time, against the fp32 MFMA peak -- the
-    # roofline of fp32 arithmetic on this chip.  57 % of those FLOPs (downs.2 + mid) run as bf16x3 on the bf16 pipe (an
+    # roofline of fp32 arithmetic on this chip.  55 % of those FLOPs (downs.2 + mid, ups.0 conv A) run as bf16x3 on the bf16 pipe (an
     # exact three-way split of both operands, six bf16 MFMAs per fp32 chunk: fp32-accurate and 2.7x the fp32 MFMA rate),
     # so the pipe's BUSY fraction is lower than `frac`: `pipe_busy_model` prices every MFMA at its issue cycles.  The
     # ALGORITHMIC (direct-convolution) rate is reported separately and may exceed the peak.
     busy_s = ((mfma_flops - bf_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + 6.0 * bf_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12))
-    roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; the 25 k=5 convs as Winograd F(4,5): fp32 MFMA GEMMs, the seven 128->128 convs as bf16x3 on the bf16 MFMA; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
+    roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; the 25 k=5 convs as Winograd F(4,5): fp32 MFMA GEMMs, the seven 128->128 convs and ups.0 conv A as bf16x3 on the bf16 MFMA; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
                 "achieved": issued_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued_tf / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
                 "concurrent_launches": chunks, "trajectories_per_launch": n_traj_local // chunks,
                 "flops_per_launch": launch_mfma, "flops_per_launch_as_bf16x3": launch_bf,
                 "achieved_single_launch": launch_mfma / (dom_ms * 1e-3) / 1e12,
                 "pipe_busy_model": busy_s / (dom_ms * 1e-3),
-                "note": "flops = fp32 GEMM FLOPs run on the matrix pipe (Winograd-domain; 57 % of them as bf16x3: 6 bf16 MFMA FLOPs per fp32 FLOP). "
+                "note": f"flops = fp32 GEMM FLOPs run on the matrix pipe (Winograd-domain; {100 * bf_flops / mfma_flops:.0f} % of them as bf16x3: 6 bf16 MFMA FLOPs per fp32 FLOP). "
                         "`concurrent_launches` launches of `trajectories_per_launch` trajectories share the GPU at any time (the sampler's stream chunks); "
                         "launch_ms = mean duration of one of them (HIP events on its stream; = rocprofv3's average for unet_kernel). "
                         "achieved = concurrent_launches x flops_per_launch / launch_ms = the rate the GPU sustains, vs the fp32 MFMA peak; "

@@ -138,10 +138,12 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   // results are bit-identical to the unsplit run.
   int nch = s->n_streams;
   if (const char* e = getenv("MMD_AMD_STREAMS")) nch = atoi(e);
-  // auto = 2 chunks: +7 % on the 32-robot round since downs.2 + mid run weight-stream-bound (bf16x3) -- one chunk's
-  // bandwidth-bound stages and step kernels meet the other's compute-bound ones on a CU, and a chunk's forward no longer
-  // ends with CUs idling until its slowest workgroup is done
-  if (nch <= 0) nch = 2;
+  // auto: 2 chunks once a chunk alone fills the chip (>= 1024 trajectories = one workgroup per CU): +7 % on the 32-robot
+  // round since downs.2 + mid run weight-stream-bound (bf16x3) -- one chunk's bandwidth-bound stages and step kernels
+  // meet the other's compute-bound ones on a CU, and a chunk's forward no longer ends with CUs idling until its slowest
+  // workgroup is done.  Smaller batches stay whole: two half-empty launches would share CUs that one leaves free (a
+  // 1024-trajectory round: 31.1 ms in two chunks, 23 ms in one).
+  if (nch <= 0) nch = n >= 2048 ? 2 : 1;
   if (nch > kMaxChunks) nch = kMaxChunks;
   if (nch > n_robots) nch = n_robots;
   Streams* S = nullptr;

@@ -534,55 +534,30 @@ __device__ __forceinline__ void vform_store(float* vb, GET x) {
     asm volatile("" ::: "memory");   // one quad at a time: keeps the 8 transformed values of a quad from piling up in VGPRs
   }
 }
-// two-n-tile quad tile (wave = 32-channel slice `slice`) -> V slab
-__device__ __forceinline__ void quad2_to_vform(const f32x4 (&q)[8], float* vslab, int slice, int lane) {
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-    vform_store(vslab + (slice * 32 + nt * 16 + (lane & 15)) * VCS + (lane >> 4) * 4 * VROW,
-                [&](int o, int r) { return q[o * 2 + nt][r]; });
-}
 // one-n-tile quad tile (wave = 16-channel n-tile `ntile`) -> V slab
 __device__ __forceinline__ void quad1_to_vform(const f32x4 (&q)[4], float* vslab, int ntile, int lane) {
   vform_store(vslab + (ntile * 16 + (lane & 15)) * VCS + (lane >> 4) * 4 * VROW, [&](int o, int r) { return q[o][r]; });
 }
 
-// One k-step on a V slab: 8 * NT MFMAs m[p * NT + nt] += V_p x U_p[nt].  RESW (NT = 1): the stage's 1x1 residual conv
-// rides along IN THE WINOGRAD DOMAIN -- a 1x1 conv is a k = 5 conv with only the centre tap, whose transformed kernel
-// G g = w * (0, -2/9, -2/9, 2/45, 2/45, 8/45, 8/45, 0) is zero at positions 0 and 7: six more MFMAs on the operands already
-// in registers, weights (w * -2/9, w * 2/45, w * 8/45) in the last float4 of the fragment.
-template <int NT, bool RESW, bool ZERO>
-__device__ __forceinline__ void w4v_step(f32x4 (&m)[8 * NT], f32x4 (&rm)[6 * NT], const float4 (&a)[2],
-                                         const BQ<2 * NT + (RESW ? 1 : 0)>& b) {
-  static_assert(!RESW || NT == 1, "the Winograd-domain residual rides with one n-tile per wave");
+// One k-step on an fp32 V slab: 8 * NT MFMAs m[p * NT + nt] += V_p x U_p[nt] (ups.0's 64 -> 64 convs).
+template <int NT, bool ZERO>
+__device__ __forceinline__ void w4v_step(f32x4 (&m)[8 * NT], const float4 (&a)[2], const BQ<2 * NT>& b) {
   if constexpr (ZERO) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8 * NT; ++i) m[i] = z;
-    if constexpr (RESW) {
-#pragma unroll
-      for (int i = 0; i < 6 * NT; ++i) rm[i] = z;
-    }
   }
   const float v[8] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w};
-  w4_mfma_pos<NT, RESW, ZERO>(m, v, b);
-  if constexpr (RESW) {
-    const float4 wr = b.q[2 * NT];
-    rm[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], wr.x, rm[0], 0, 0, 0);
-    rm[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], wr.x, rm[1], 0, 0, 0);
-    rm[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[3], wr.y, rm[2], 0, 0, 0);
-    rm[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4], wr.y, rm[3], 0, 0, 0);
-    rm[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[5], wr.z, rm[4], 0, 0, 0);
-    rm[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[6], wr.z, rm[5], 0, 0, 0);
-  }
+  w4_mfma_pos<NT, false, ZERO>(m, v, b);
 }
 
-// m += conv over CP channels of a V slab; abase = the lane's float offset of (channel lane >> 4, row lane & 15);
+// m = conv over CP channels of a V slab; abase = the lane's float offset of (channel lane >> 4, row lane & 15);
 // b = ring pre-loaded with the first W4_RD k-steps of wp.  A operands are double-buffered (the two ds_read_b128 of k-step
 // j + 1 are issued before the MFMAs of k-step j); past the last k-step they read the slab's slack and are unused.
-template <int CP, int NT, bool RESW, bool FRESH>
-__device__ __forceinline__ void w4v_taps(f32x4 (&m)[8 * NT], f32x4 (&rm)[6 * NT], const float* vslab, int abase,
-                                         const float* __restrict__ wp, BQ<2 * NT + (RESW ? 1 : 0)> (&b)[W4_RD]) {
-  constexpr int KS = CP / 4, RD = W4_RD, NQ = 2 * NT + (RESW ? 1 : 0), KSTRIDE = 64 * 4 * NQ;
+template <int CP, int NT>
+__device__ __forceinline__ void w4v_taps(f32x4 (&m)[8 * NT], const float* vslab, int abase, const float* __restrict__ wp,
+                                         BQ<2 * NT> (&b)[W4_RD]) {
+  constexpr int KS = CP / 4, RD = W4_RD, NQ = 2 * NT, KSTRIDE = 64 * 4 * NQ;
   static_assert(KS % RD == 0, "k-steps are unrolled by the ring depth");
   const float* p = wp;
   const float4* s = reinterpret_cast<const float4*>(vslab + abase);   // one k-step = 4 channels = VCS float4 further
@@ -595,24 +570,19 @@ __device__ __forceinline__ void w4v_taps(f32x4 (&m)[8 * NT], f32x4 (&rm)[6 * NT]
       a[(j + 1) & 1][0] = s[(j + 1) * VCS];
       a[(j + 1) & 1][1] = s[(j + 1) * VCS + 1];
       MMD_PIN_LOADS();
-      if (decltype(first)::value && j == 0) w4v_step<NT, RESW, true>(m, rm, a[0], b[0]);
-      else w4v_step<NT, RESW, false>(m, rm, a[j & 1], b[j]);
+      if (decltype(first)::value && j == 0) w4v_step<NT, true>(m, a[0], b[0]);
+      else w4v_step<NT, false>(m, a[j & 1], b[j]);
       b[j] = load_bq<NQ>(p + j * KSTRIDE);
       MMD_PIN_LOADS();
     }
     s += RD * VCS;
   };
-  if constexpr (FRESH) {
-    iter(std::true_type{});
+  iter(std::true_type{});
 #pragma unroll 1
-    for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
-  } else {
-#pragma unroll 1
-    for (int ks = 0; ks < KS; ks += RD) iter(std::false_type{});
-  }
+  for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
 }
 
-// A down-path stage (L = 32 / C = 64: downs.1; L = 16 / C = 128: downs.2 + mid blocks) in F(4,5) form.  Same slabs as
+// A down-path stage (L = 64 / C = 32: downs.0; L = 32 / C = 64: downs.1) in F(4,5) form.  Same slabs as
 // the other stages; activations in registers as quad tiles.  The 4 * L / 4 output quads are L / 16 M tiles of 16 rows; a
 // wave owns one M tile x 32 channels (two n-tiles).
 // Synchronisation between a slab write and the conv that reads it.  WAVE_PRIVATE: the stage's tiling gives every wave whole
@@ -837,17 +807,14 @@ __device__ __forceinline__ void vbu_taps(f32x4 (&m)[8], f32x4 (&rm)[6], const ch
 template <class CF, bool FIRST>
 __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[8],
                                               f32x4 (&mid)[8], f32x16 (&tout)[1], int trb) {
-  static_assert((CF::L == 16 || CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 &&
+  static_assert((CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 &&
                     CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP,
                 "down-path stage with 4 waves = (L / 16 M tiles) x (CM / 32 channel slices)");
-  // L = 16 (downs.2 + mid blocks): every conv after the first reads a V-form H slab that ALIASES the stage's d-form x slab
-  constexpr bool VH = CF::L == 16;
   constexpr bool PRIV = CF::L == 64;                                    // 4 M tiles x 1 channel slice: wave = sample
-  float* hslab = VH ? lds : lds + CF::XSLAB;
+  float* hslab = lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, WNQ = CF::CM / 32;                     // quads per sample, channel slices
   const int mt = wave / WNQ, wnq = wave % WNQ;
-  const int vbase = (lane >> 4) * VCS + (lane & 15) * VROW;             // V slab: (channel lane >> 4, row lane & 15)
   // A fragment: row i = lane & 15 of M tile mt = (sample, quad), k = lane >> 4
   const int ai = mt * 16 + (lane & 15);
   const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
@@ -864,26 +831,18 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   w4_ring_load<5>(ring5, w0);
   if constexpr (FIRST)     // the network input, channels-last [n, 64, 4] in HBM (channels 4..15 of the slab are zero)
     stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
-  if constexpr (!VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
+  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
   __syncthreads();
   TR(trb + 0);
 
   f32x4 m[16], res[8];
   auto conv_h = [&](const float4* w, const float4* next) {
-    if constexpr (VH) {
-      f32x4 nores[12];
-      w4v_taps<CF::CM, 2, false, true>(m, nores, hslab, vbase, wlane(w, CF::CM), ring);
-    } else {
-      w4_taps<CF::CM, CF::HSTR, 2, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
-    }
+    w4_taps<CF::CM, CF::HSTR, 2, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
     if (next) w4_ring_load<4>(ring, wlane(next, CF::CM));
     w4_out(acc, m);
   };
-  // acc -> the H slab the next conv reads (V form at L = 16, row form otherwise)
-  auto to_h = [&]() {
-    if constexpr (VH) quad2_to_vform(acc, hslab, wnq, lane);
-    else quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
-  };
+  // acc -> the row-form H slab the next conv reads
+  auto to_h = [&]() { quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane); };
   // GroupNorm + Mish of acc, then + the time bias tb (conv A) or + the residual tile (conv B, tb == nullptr)
   auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
     const float bb[2] = {b[col0], b[col1]}, gg[2] = {g[col0], g[col1]}, ee[2] = {be[col0], be[col1]};
@@ -910,7 +869,6 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
   w4_out(acc, m);
   TR(trb + 2);
   gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
-  if constexpr (VH) __syncthreads();                         // conv A is done reading the x slab the V-form H slab aliases
   to_h();
   slab_sync<PRIV>();
   TR(trb + 4);
@@ -951,7 +909,6 @@ __device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, in
 
   // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32 ===================
   if constexpr (CF::TAIL == TAIL_DOWN) {
-    static_assert(!VH, "the strided tail conv reads a row-form H slab");
     static_assert(!PRIV || (CF::WN == 1 && CF::SW == 1), "wave-private stage: the tail tile of a wave is its own sample");
     slab_sync<PRIV>();
     quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
@@ -1080,8 +1037,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   f32x4 m[8], acc[4], res[4];
   auto conv_h = [&](const float4* w, const float4* next) {
     if constexpr (VH) {
-      f32x4 nores[6];
-      w4v_taps<CF::CM, 1, false, true>(m, nores, hslab, vbase, wlane(w, CF::CM), ring);
+      w4v_taps<CF::CM, 1>(m, hslab, vbase, wlane(w, CF::CM), ring);
     } else {
       w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
     }
@@ -2005,7 +1961,8 @@ static const double kUnetFlops =
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64;
 
 // fp32 GEMM FLOPs the matrix pipe executes per trajectory (Winograd convs: 8 products per 4 outputs; channel / N padding
-// included).  The seven 128 -> 128 convs of downs.2 + mid run them as bf16x3 (6 bf16 MFMA FLOPs per fp32 FLOP).
+// included).  The seven 128 -> 128 convs of downs.2 + mid and ups.0's conv A run them as bf16x3 (6 bf16 MFMA FLOPs per
+// fp32 FLOP).
 static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // per sample
 static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
@@ -2065,7 +2022,7 @@ int mmd_debug_set_trace(void* dev_ptr) {
 
 double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
 double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }
-double mmd_unet_bf16x3_flops_per_trajectory(void) { return 7 * wino4_flops(128, 128); }
+double mmd_unet_bf16x3_flops_per_trajectory(void) { return 7 * wino4_flops(128, 128) + wino4_flops(256, 64) * 14.0 / 8.0; }
 
 int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride) {
   MMD_REQUIRE(out && max_launches > 0, "mmd_profiler_create: bad arguments");

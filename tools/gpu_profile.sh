@@ -18,11 +18,11 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   rm -rf $OUT/pmcx
-  REPS=8 timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/pmcx -o pmc -- python tools/unet_forward_loop.py 2048 > /dev/null 2> $OUT/pmcx.err
+  REPS=8 timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/pmcx -o pmc -- python tools/unet_forward_loop.py ${PMC_N:-1024} > /dev/null 2> $OUT/pmcx.err
   f=$(find $OUT/pmcx -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then for c in $set; do python tools/pmc_summary.py "$f" $c | grep -E "unet_kernel|^#"; done >> $OUT/${TAG}_pmc_unet_kernel.txt
   else echo "FAILED: $set: $(tail -2 $OUT/pmcx.err | tr '\n' ' ')" >> $OUT/${TAG}_pmc_unet_kernel.txt; fi
 done
 rm -rf $OUT/pmcx $OUT/prof/bench_results.db
 cat $OUT/${TAG}_pmc_unet_kernel.txt
-timeout 300 python tools/unet_forward_loop.py 256 512 1024 2048 2>&1 | grep "n=" | tee $OUT/${TAG}_unet_sizes.txt
+timeout 300 python tools/unet_forward_loop.py 256 512 1024 2048 4096 2>&1 | grep "n=" | tee $OUT/${TAG}_unet_sizes.txt
