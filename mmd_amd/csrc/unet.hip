@@ -639,16 +639,15 @@ __host__ __device__ constexpr int vb_pos(int ph, int slot) { return ph == 0 ? (s
 // The lane holds two adjacent channels (v0: the even one): the three pieces of each pair up into dwords at slot offset
 // OFF of the lane's slab position.
 template <int OFF>
-__device__ __forceinline__ void vb_put2(char* base, float v0, float v1) {
+__device__ __forceinline__ void vb_put2(char* base, float v0, float v1, unsigned sel = 0x07060302u) {   // {v1.hi16, v0.hi16}
   const unsigned a0 = __float_as_uint(v0), b0 = __float_as_uint(v1);
   const float ra = v0 - __uint_as_float(a0 & 0xffff0000u), rb = v1 - __uint_as_float(b0 & 0xffff0000u);
   const unsigned a1 = __float_as_uint(ra), b1 = __float_as_uint(rb);
   const unsigned a2 = __float_as_uint(ra - __uint_as_float(a1 & 0xffff0000u));
   const unsigned b2 = __float_as_uint(rb - __uint_as_float(b1 & 0xffff0000u));
-  constexpr unsigned HI_HI = 0x07060302u;                    // {b.hi16, a.hi16}
-  *reinterpret_cast<unsigned*>(base + OFF) = __builtin_amdgcn_perm(b0, a0, HI_HI);
-  *reinterpret_cast<unsigned*>(base + OFF + 4 * VB_PS) = __builtin_amdgcn_perm(b1, a1, HI_HI);
-  *reinterpret_cast<unsigned*>(base + OFF + 8 * VB_PS) = __builtin_amdgcn_perm(b2, a2, HI_HI);
+  *reinterpret_cast<unsigned*>(base + OFF) = __builtin_amdgcn_perm(b0, a0, sel);
+  *reinterpret_cast<unsigned*>(base + OFF + 4 * VB_PS) = __builtin_amdgcn_perm(b1, a1, sel);
+  *reinterpret_cast<unsigned*>(base + OFF + 8 * VB_PS) = __builtin_amdgcn_perm(b2, a2, sel);
 }
 // phase PH of the V transform of the lane's two (sample, channel) columns: x(o, r) = position 4 r + o; base = slab + the
 // lane's (channel block, row 4 * sample, channel % 8) offset.  The expressions are w4_transform's.
@@ -1166,6 +1165,220 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// downs.1 (L = 32, 64 channels) with its three 64 -> 64 convs as bf16x3.  The stage's output is 2 M tiles (M tile = 2
+// samples x 8 quads) x 4 n-tiles; a wave owns ONE n-tile and BOTH M tiles -- the two accumulator streams of a step, so
+// a weight fragment is used twice (a (1 M tile x 2 n-tiles) wave would stream 2 x the weights and gain nothing over the
+// fp32 MFMA: these convs are weight-stream bound too).  A lane of the C/D fragment then holds one channel x 16 consecutive
+// positions (half a sample) in each M tile; for the dword stores of the slab the lanes of a pair (n, n ^ 1) swap one tile
+// by DPP, so that the even lane holds channels (c, c + 1) of M tile 0 and the odd lane those of M tile 1, and the two
+// positions either side of a half-sample come from lane ^ 16 (the sample's other half).  Slab: rows = 16 mt + i (the
+// MFMA row order), 32 rows x 16 B per 8-channel block; blocks c, c + 1 of an n-tile 512 + 32 B apart, block pairs a
+// multiple of 256 B: the b128 reads are conflict-free, the b32 stores 2-way (free) -- K chunk kc = blocks kc, kc + 2, kc +
+// 4, kc + 6.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int VD_X = 512 + 32;
+constexpr int VD_G = 5 * 256;
+constexpr int VBD_FRAGS = 2 * 4 * 2 * 3;   // weight fragments per n-tile and conv: [phase][slot][chunk][piece]
+static_assert(4 * VD_G == VB_PS, "downs.1 and downs.2 share the phase-slab size");
+
+__device__ __forceinline__ void vbd_load_b(u32x4 (&b)[3], const u32x4* w, int ph, int step) {
+  const u32x4* p = w + ((ph * 8 + step) * 3) * 64;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) b[q] = p[q * 64];
+}
+__device__ __forceinline__ void vbd_load_a(u32x4 (&a)[2][3], const char* va, int step) {   // step = 2 * slot + chunk
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      a[mt][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step / 2) * VB_PS + (step % 2) * VD_X + mt * 256);
+}
+template <int PH>
+__device__ __forceinline__ void vbd_ring_load(u32x4 (&b)[VB_RD][3], const u32x4* w) {
+#pragma unroll
+  for (int i = 0; i < VB_RD; ++i) vbd_load_b(b[i], w, PH, i);
+  MMD_PIN_LOADS();
+}
+// m[M tile][position] of phase PH's four positions = conv over the slab's 64 channels
+template <int PH>
+__device__ __forceinline__ void vbd_taps(f32x4 (&m)[2][8], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][3]) {
+  u32x4 a[2][2][3];
+  vbd_load_a(a[0], va, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i + 1 < 8) vbd_load_a(a[(i + 1) & 1], va, i + 1);
+    MMD_PIN_LOADS();
+    const int pos = vb_pos(PH, i / 2);
+    if (i % 2 == 0) vb_six<true>(m[0][pos], m[1][pos], a[i & 1][0], a[i & 1][1], b[i % VB_RD], b[i % VB_RD]);
+    else vb_six<false>(m[0][pos], m[1][pos], a[i & 1][0], a[i & 1][1], b[i % VB_RD], b[i % VB_RD]);
+    if (i + VB_RD < 8) vbd_load_b(b[i % VB_RD], w, PH, i + VB_RD);
+    MMD_PIN_LOADS();
+  }
+}
+// The lane's two tiles P (own channel), Q (pair partner's channel) of its M tile, with the two positions before / after
+// its 16: phase PH of their V transforms -> the slab (sel orders the pair: even lane P = low channel, odd lane Q).
+template <int PH>
+__device__ __forceinline__ void vbd_store(char* base, const f32x4 (&P)[4], const float (&pp)[2], const float (&pn)[2],
+                                          const f32x4 (&Q)[4], const float (&qp)[2], const float (&qn)[2], unsigned sel) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float d[8], e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pos = 4 * r - 2 + j;
+      d[j] = pos < 0 ? pp[pos + 2] : (pos > 15 ? pn[pos - 16] : P[pos & 3][pos >> 2]);
+      e[j] = pos < 0 ? qp[pos + 2] : (pos > 15 ? qn[pos - 16] : Q[pos & 3][pos >> 2]);
+    }
+    char* p = base + r * 16;
+    if constexpr (PH == 0) {
+      const float de1 = fmaf(-4.25f, d[4], d[2]) + d[6], do1 = fmaf(-4.25f, d[3], d[1]) + d[5];
+      const float ee1 = fmaf(-4.25f, e[4], e[2]) + e[6], eo1 = fmaf(-4.25f, e[3], e[1]) + e[5];
+      vb_put2<0 * VB_PS>(p, fmaf(5.25f, d[2] - d[4], d[6] - d[0]), fmaf(5.25f, e[2] - e[4], e[6] - e[0]), sel);
+      vb_put2<1 * VB_PS>(p, de1 + do1, ee1 + eo1, sel);
+      vb_put2<2 * VB_PS>(p, de1 - do1, ee1 - eo1, sel);
+      vb_put2<3 * VB_PS>(p, fmaf(5.25f, d[3] - d[5], d[7] - d[1]), fmaf(5.25f, e[3] - e[5], e[7] - e[1]), sel);
+    } else {
+      const float de2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), do2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
+      const float de3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), do3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
+      const float ee2 = fmaf(0.25f, e[2], fmaf(-1.25f, e[4], e[6])), eo2 = fmaf(0.5f, e[1], fmaf(-2.5f, e[3], 2.f * e[5]));
+      const float ee3 = fmaf(4.f, e[2], fmaf(-5.f, e[4], e[6])), eo3 = fmaf(2.f, e[1], fmaf(-2.5f, e[3], 0.5f * e[5]));
+      vb_put2<0 * VB_PS>(p, de2 + do2, ee2 + eo2, sel);
+      vb_put2<1 * VB_PS>(p, de2 - do2, ee2 - eo2, sel);
+      vb_put2<2 * VB_PS>(p, de3 + do3, ee3 + eo3, sel);
+      vb_put2<3 * VB_PS>(p, de3 - do3, ee3 - eo3, sel);
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
+template <class CF>
+__device__ __forceinline__ void chain_body_d1(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[2][4],
+                                              f32x4 (&mid)[2][4], f32x16 (&tout)[1], int trb) {
+  static_assert(CF::L == 32 && CF::CM == 64 && CF::C0 == 32 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
+                    CF::MID_AFTER == 1 && CF::TAIL == TAIL_DOWN, "downs.1");
+  constexpr int QPS = CF::L / 4;                             // 8 quads per sample
+  float* hslab = lds + CF::XSLAB;                            // row-form H slab of the tail conv
+  const int nq = wave, col = 16 * nq + (lane & 15);          // the wave's n-tile, the lane's channel
+  // A row lane & 15 of M tile mt = (sample, quad) of the row-form x slab (conv A of the first RTB)
+  int xbase[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int ai = mt * 16 + (lane & 15);
+    xbase[mt] = (ai / QPS) * CF::XSS + 4 * (ai % QPS) * CF::XSTR + (lane >> 4);
+  }
+  BQ<3> ring3[W4_RD];
+  const float* w3 = reinterpret_cast<const float*>(a.r0.wa) + ((size_t)nq * (CF::C0P / 4) * 64 + lane) * 12;
+  w4_ring_load<3>(ring3, w3);
+  __syncthreads();                                           // the x slab (downs.0's tail tile) is staged
+  TR(trb + 0);
+
+  f32x4 res[2][4];
+  char* const vb = reinterpret_cast<char*>(lds);             // the bf16x3 phase slab aliases the x and H slabs
+  const char* const vb_a = vb + (lane >> 4) * VD_G + (lane & 15) * 16;
+  const int odd = lane & 1, gl = (lane >> 4) & 1;            // pair position; first / second half of the sample
+  char* const vb_s = vb + nq * VD_G + ((lane & 15) >> 3) * VD_X + (16 * odd + 4 * (lane >> 4)) * 16 + ((lane & 7) >> 1) * 4;
+  const unsigned sel = odd ? 0x03020706u : 0x07060302u;
+  auto conv_hb = [&](const uint4* w) {
+    const u32x4* wp = reinterpret_cast<const u32x4*>(w) + (size_t)nq * VBD_FRAGS * 64 + lane;
+    u32x4 ring_b[VB_RD][3];
+    vbd_ring_load<0>(ring_b, wp);
+    // pair exchange: P = the lane's own channel in ITS M tile (even lane: 0, odd: 1), Q = the partner's channel there
+    f32x4 P[4], Q[4];
+    float pp[2], pn[2], qp[2], qn[2];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float send = odd ? acc[0][o][r] : acc[1][o][r];
+        Q[o][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));
+        P[o][r] = odd ? acc[1][o][r] : acc[0][o][r];
+      }
+    }
+    {
+      // the sample's other half (lane ^ 16) supplies the two positions after (first half) / before (second half) the lane's
+      const float pa = __shfl_xor(gl ? P[0][0] : P[2][3], 16), pb = __shfl_xor(gl ? P[1][0] : P[3][3], 16);
+      const float qa = __shfl_xor(gl ? Q[0][0] : Q[2][3], 16), qb = __shfl_xor(gl ? Q[1][0] : Q[3][3], 16);
+      pp[0] = gl ? pa : 0.f; pp[1] = gl ? pb : 0.f; pn[0] = gl ? 0.f : pa; pn[1] = gl ? 0.f : pb;
+      qp[0] = gl ? qa : 0.f; qp[1] = gl ? qb : 0.f; qn[0] = gl ? 0.f : qa; qn[1] = gl ? 0.f : qb;
+    }
+    f32x4 mb[2][8];
+    vbd_store<0>(vb_s, P, pp, pn, Q, qp, qn, sel);
+    __syncthreads();
+    vbd_taps<0>(mb, vb_a, wp, ring_b);
+    vbd_ring_load<1>(ring_b, wp);
+    __syncthreads();                                         // every wave is done reading the phase-0 slab
+    vbd_store<1>(vb_s, P, pp, pn, Q, qp, qn, sel);
+    __syncthreads();
+    vbd_taps<1>(mb, vb_a, wp, ring_b);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) w4n1_out(acc[mt], mb[mt]);
+  };
+  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
+    if (MMD_ABL == 1) return;
+    const float bb = b[col], gg = g[col], ee = be[col];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (tb) {
+        const float t0 = tb[col];
+        gn_mish_quad1<CF::CM, CF::L>(acc[mt], bb, gg, ee, [&](int, int) { return t0; });
+      } else {
+        gn_mish_quad1<CF::CM, CF::L>(acc[mt], bb, gg, ee, [&](int o, int r) { return res[mt][o][r]; });
+      }
+    }
+  };
+
+  // =================== RTB 0 (32 -> 64): conv A + the 1x1 residual conv on the fp32 MFMA, row-form x slab ===================
+  {
+    f32x4 m[8];
+    const float br = a.br[col];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) res[mt][o] = f32x4{br, br, br, br};
+      w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res[mt], lds, xbase[mt], w3, ring3);
+      if (mt == 0) w4_ring_load<3>(ring3, w3);
+      w4n1_out(acc[mt], m);
+    }
+  }
+  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
+  __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
+  conv_hb(a.r0.wb_bf);
+  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
+  // =================== identity RTB ===================
+  {
+    const RtbPtrs& R = a.ri[0];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) res[mt][i] = acc[mt][i];
+    __syncthreads();                                         // the previous conv is done reading the slab
+    conv_hb(R.wa_bf);
+    gn(R.ba, R.ga, R.bea, R.tb);
+    __syncthreads();
+    conv_hb(R.wb_bf);
+    gn(R.bb, R.gb, R.beb, nullptr);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mid[mt][i] = acc[mt][i];
+  }
+  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32, row-form H slab ===================
+  __syncthreads();                                           // the last conv is done reading the phase slab
+  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc[mt], hslab, mt, nq, lane);
+  __syncthreads();
+  {
+    constexpr int LO = CF::L / 2;
+    const int wm = wave / CF::WN, wn = wave % CF::WN, hi = lane >> 5;
+    fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
+    const int r = lane & 31;
+    int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
+    mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // downs.2 + mid blocks (L = 16, 128 channels; 57 % of the network's MACs): the 64 -> 128 conv A of the first RTB on the
 // fp32 MFMA from the row-form x slab (with its 1x1 residual conv riding along), the seven 128 -> 128 convs as bf16x3
 // (vb_taps).  The stage's output is one M tile (4 samples x 4 quads) x 8 n-tiles; wave w owns n-tiles 2 w, 2 w + 1, whose
@@ -1325,7 +1538,6 @@ constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
 
 struct UnetArgs {
   ChainArgs c[5];
-  ChainArgs c2s;        // downs.2 + mid blocks with one-n-tile weight packs (unet_kernel runs that stage tile by tile)
   FinalArgs fin;
   int n;
 };
@@ -1344,7 +1556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * 4;
 
-  f32x4 skip1[8], skip2[2][4];
+  f32x4 skip1[2][4], skip2[2][4];
   // ---- downs.0 @ L=64 -> [4][32][32]
   {
     f32x4 acc[8], mid[8];
@@ -1354,18 +1566,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
   }
-  // ---- downs.1 @ L=32 -> [4][16][64], skip1
+  // ---- downs.1 @ L=32 -> [4][16][64], skip1 (lane = channel 16 wave + (lane & 15) in both M tiles: chain_body_d1)
   {
-    f32x4 acc[8];
+    f32x4 acc[2][4];
     f32x16 t[1];
-    chain_body_w4<CH_D1, false>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
+    chain_body_d1<CH_D1>(a.c[1], lds, lane, wave, acc, skip1, t, 40);
     __syncthreads();
     tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
   }
   // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2 (lane = channels 32 wave + 2 (lane & 15) + h: chain_body_d2)
   f32x4 mid_out[2][4];
-  chain_body_d2<CH_D2>(a.c2s, lds, lane, wave, mid_out, skip2, 80);
+  chain_body_d2<CH_D2>(a.c[2], lds, lane, wave, mid_out, skip2, 80);
   TR(130);
   // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]; conv A reads both chunks as bf16x3 phase slabs stored from the tiles
   {
@@ -1391,7 +1603,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     f32x16 t[2][1];
     chain_body_w4u<CH_U1>(a.c[4], lds, lane, wave,
-                             [&](float* xs) { quad_to_stage<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1, xs, wave, lane); },
+                             [&](float* xs) {
+#pragma unroll
+                               for (int mt = 0; mt < 2; ++mt)
+                                 quad1_to_stage_u<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1[mt], xs, mt, wave, lane);
+                             },
                              t, 146);
     __syncthreads();
     tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
@@ -1689,6 +1905,49 @@ static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int ci
   return base;
 }
 
+// bf16x3 pack of a 64 -> 64 k5 conv of downs.1 for vbd_taps: per n-tile [phase][slot][chunk kc][piece q][lane] x 16 B; lane =
+// (column n = 16 tile + (lane & 15), channels 8 (kc + 2 (lane >> 4)) + j, j = 0..7 at bf16 index j).
+static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin) {
+  static const double G[8][5] = {{-1, 0, 0, 0, 0},
+                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                 {0, 0, 0, 0, 1}};
+  while (blob.size() % 4) blob.push_back(0.f);
+  const size_t base = blob.size();
+  const int tiles = cout / 16, KC = cin / 32;
+  const size_t frags = (size_t)tiles * 2 * 4 * KC * 3;
+  blob.resize(base + (frags + 8) * 64 * 4, 0.f);             // + slack for the ring's over-read past the last tile
+  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
+  for (int t = 0; t < tiles; ++t)
+    for (int ph = 0; ph < 2; ++ph)
+      for (int sl = 0; sl < 4; ++sl)
+        for (int kc = 0; kc < KC; ++kc)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int n = 16 * t + (lane & 15), ci = 8 * (kc + KC * (lane >> 4)) + j, pos = vb_pos(ph, sl);
+              const float* g = w + ((size_t)n * cin + ci) * 5;
+              double ud = 0.0;
+              for (int k = 0; k < 5; ++k) ud += G[pos][k] * (double)g[k];
+              const float u = (float)ud;
+              uint32_t b0, b1, b2;
+              memcpy(&b0, &u, 4);
+              uint32_t h0 = b0 & 0xffff0000u; float f0; memcpy(&f0, &h0, 4);
+              const float r1 = u - f0; memcpy(&b1, &r1, 4);
+              uint32_t h1 = b1 & 0xffff0000u; float f1; memcpy(&f1, &h1, 4);
+              const float r2 = r1 - f1; memcpy(&b2, &r2, 4);
+              const uint32_t piece[3] = {b0 >> 16, b1 >> 16, b2 >> 16};
+              for (int q = 0; q < 3; ++q) {
+                const size_t frag = ((((size_t)t * 2 + ph) * 4 + sl) * KC + kc) * 3 + q;
+                out[(frag * 64 + lane) * 8 + j] = (uint16_t)piece[q];
+              }
+            }
+  return base;
+}
+
 // bf16x3 pack of one 128-channel chunk [c_lo, c_lo + 128) of ups.0's conv A (k5, cout 64, with the 1x1 residual conv wres
 // in the Winograd domain) for vbu_taps: per n-tile [phase][slot pair][chunk kc][9 fragments][lane] x 16 B; fragments 0..2 /
 // 3..5 = the pieces of the pair's two slots, 6..8 = the pieces of wres * G[p][2] for the pair's residual position(s)
@@ -1754,7 +2013,6 @@ struct mmd_unet_s {
   float* ttable = nullptr;   // [T][tb_total]
   int tb_total = 0;
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
-  RtbW rtb_s[12];            // the same; downs.2's conv A with a one-n-tile, column-paired pack (chain_body_d2)
   ConvW down[2], up[2], fin;
   size_t fin_w1, fin_b1;
 };
@@ -1844,28 +2102,43 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   size_t raw_cw[12], raw_cb[12];
   int tb_off = 0;
   for (int r = 0; r < 12; ++r) {
+    // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2.  Every conv gets the one pack its stage body
+    // reads: fp32 Winograd packs (pack_w4) for downs.0, the up path and the first convs of downs.1 / downs.2 (one n-tile
+    // per slice there, with the 1x1 residual conv riding along), bf16x3 packs for downs.1's 64 -> 64 convs (pack_vbd),
+    // downs.2 + mid's 128 -> 128 convs (pack_vb, paired columns) and ups.0's conv A (pack_vbu).
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
+    W = RtbW{};
     while (blob.size() % 4) blob.push_back(0.f);
-    const int NT = (r >= 6 && r <= 9) ? 1 : 2;       // ups.0, ups.1: one n-tile per wave; the rest: two
+    const bool d1 = r == 2 || r == 3, d2 = r == 4 || r == 5 || r == 10 || r == 11;
+    const int NT = (r >= 6 && r <= 9) || d1 || d2 ? 1 : 2;   // n-tiles per weight slice
     const int cinp = (R.cin + 7) / 8 * 8;            // the 4-channel network input is padded to 2 k-steps (the ring depth)
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
-    W.a_c1 = 0;
-    W.a.wpk = blob.size();
-    if (r == 6) {             // ups.0 conv A runs as bf16x3 (pack_vbu below)
-    } else if (r == 8) {      // ups.1: input = cat(x, skip), staged chunk by chunk: one pack per chunk
+    if (r == 6) {             // ups.0 conv A: the two chunks of cat(x, skip2)
+      W.a.wbf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, 0);
+      W.a_c1_bf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, R.cin / 2);
+    } else if (r == 8) {      // ups.1: input = cat(x, skip1), staged chunk by chunk: one pack per chunk
       const int half = R.cin / 2;
+      W.a.wpk = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres);
       W.a_c1 = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
+    } else if ((d1 || d2) && R.cin == R.cout) {
+      W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin);
     } else {
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres);
+      W.a.wpk = blob.size();
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres, false, /*pair_cols=*/d2);
     }
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
-    W.b.wpk = blob.size();
-    pack_w4(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, R.cout, NT, nullptr);
+    if (d1 || d2) {
+      W.b.wbf = d1 ? pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout) : pack_vb(blob, tensors[R.t_w1], R.cout, R.cout);
+    } else {
+      while (blob.size() % 4) blob.push_back(0.f);
+      W.b.wpk = blob.size();
+      pack_w4(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, R.cout, NT, nullptr);
+    }
     W.b.bias = push(blob, tensors[R.t_b1], R.cout);
     W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
     W.b.beta = push(blob, tensors[R.t_be1], R.cout);
@@ -1874,23 +2147,6 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.res_bias = R.res ? push(blob, tensors[R.t_rb], R.cout) : 0;
     W.tb_off = tb_off;
     tb_off += R.cout;
-    W.a.wbf = W.b.wbf = W.a_c1_bf = 0;
-    if (r == 6) {                                          // ups.0 conv A: bf16x3 packs of its two input chunks
-      W.a.wbf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, 0);
-      W.a_c1_bf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, R.cin / 2);
-    }
-    if (r == 4 || r == 5 || r == 10 || r == 11) {          // downs.2 + mid blocks: bf16x3 packs of the 128 -> 128 convs
-      if (R.cin == R.cout) W.a.wbf = pack_vb(blob, tensors[R.t_w0], R.cout, R.cin);
-      W.b.wbf = pack_vb(blob, tensors[R.t_w1], R.cout, R.cout);
-    }
-    // downs.2's first conv (64 -> 128, fp32, with the residual conv): one-n-tile pack with chain_body_d2's column pairing
-    RtbW& S = u->rtb_s[r];
-    S = W;
-    if (r == 4) {
-      while (blob.size() % 4) blob.push_back(0.f);
-      S.a.wpk = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, 1, wres, false, true);
-    }
   }
   u->tb_total = tb_off;
   const int dims[4] = {4, unet_input_dim, unet_input_dim * 2, unet_input_dim * 4};
@@ -1989,7 +2245,6 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.c[0] = args_chain(u, set, kD0, 1, &u->down[0], x, t, n);
   a.c[1] = args_chain(u, set, kD1, 1, &u->down[1], nullptr, t, n);
   a.c[2] = args_chain(u, set, kD2, 3, nullptr, nullptr, t, n);
-  a.c2s = args_chain(u, u->rtb_s, kD2, 3, nullptr, nullptr, t, n);
   a.c[3] = args_chain(u, set, kU0, 1, &u->up[0], nullptr, t, n);
   a.c[4] = args_chain(u, set, kU1, 1, &u->up[1], nullptr, t, n);
   a.fin.out = eps;

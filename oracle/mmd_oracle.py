@@ -139,8 +139,9 @@ def _rtb(sd, prefix, x, c):
 
 def unet_forward(sd: Dict[str, torch.Tensor], x, t, n_levels=3):
     """TemporalUnet.forward with conditioning_type=None, self_attention=False
-    (mmd/models/diffusion_models/temporal_unet.py:121-174).  x [B,H,D] fp32, t [B] (any numeric) -> [B,H,D]."""
-    c = time_embedding(sd, t.to(torch.float32))
+    (mmd/models/diffusion_models/temporal_unet.py:121-174).  x [B,H,D] fp32, t [B] (any numeric) -> [B,H,D].  With a
+    float64 state dict and x it is the fp64 yardstick of the accuracy tests."""
+    c = time_embedding(sd, t.to(x.dtype))
     x = x.transpose(1, 2)                                            # 'b h c -> b c h'
     skips = []
     for ind in range(n_levels):

@@ -85,6 +85,24 @@ def test_unet_forward_is_batch_independent():
     assert rel_l2(full[:64].cpu(), ref) < 2e-5
 
 
+def test_unet_forward_accuracy_against_fp64():
+    """The kernel computes fp32 arithmetic (part of it as an exact bf16x3 split on the bf16 matrix pipe): against the
+    oracle run in float64 its error is of the size of the fp32 reference's own rounding error -- Winograd F(4,5) costs a
+    small factor (1.9e-6 vs 0.8e-6), the bf16x3 convs nothing."""
+    model = _gc().hip_model(100)
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    sd64 = {k: v.double() for k, v in sd.items()}
+    t = torch.full((16,), 41, dtype=torch.long)
+    for scale in (1.0, 1e-3, 8.0):
+        x = torch.from_numpy(synth.synth_noise(300, (16, H, D))) * scale
+        ref64 = O.unet_forward(sd64, x.double(), t)
+        err_ref32 = float((O.unet_forward(sd, x, t).double() - ref64).norm() / ref64.norm())
+        err_hip = float((model.model(x.cuda(), 41).cpu().double() - ref64).norm() / ref64.norm())
+        parity_log.record("unet_forward_vs_fp64", f"scale={scale:g}", None, err_hip, sens=err_ref32, bound=max(4e-6, 4 * err_ref32),
+                          note="sens = the fp32 reference forward against the same float64 forward")
+        assert err_hip < max(4e-6, 4 * err_ref32), (scale, err_hip, err_ref32)
+
+
 def test_unet_forward_golden():
     g = np.load(os.path.join(GOLDEN, "g2_unet.npz"))
     model = _gc().hip_model(100)
