@@ -487,19 +487,6 @@ __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[
 
 // quad tile of a level of length L with CM channels -> slab rows 4t + o (+2 halo) of a stage laid out [sample][row][DSTR].
 // Producer tiling: wave = (M tile, 32-channel slice); lane >> 4 = (sample within the M tile, 16-row block)
-template <int L, int CM, int DSS, int DSTR>
-__device__ __forceinline__ void quad_to_stage(const f32x4 (&q)[8], float* dst, int wave, int lane) {
-  constexpr int QB = L / 16, SPT = 4 / QB, WN = CM / 32;        // row blocks per sample, samples per M tile, channel waves
-  const int mt = wave / WN, wn = wave % WN;
-  const int smp = mt * SPT + (lane >> 4) / QB, qb = (lane >> 4) % QB;
-  float* base = dst + smp * DSS + (16 * qb + 2) * DSTR + wn * 32 + (lane & 15);
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR + nt * 16] = q[o * 2 + nt][r];
-}
 
 // ----------------------------------------------------------------------------------------------------------------
 // V-form slabs (the L = 16 stages: downs.2 + mid blocks, ups.0).  At L = 16 the four waves of a workgroup share ONE M tile
@@ -582,13 +569,9 @@ __device__ __forceinline__ void w4v_taps(f32x4 (&m)[8 * NT], const float* vslab,
   for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
 }
 
-// A down-path stage (L = 64 / C = 32: downs.0; L = 32 / C = 64: downs.1) in F(4,5) form.  Same slabs as
-// the other stages; activations in registers as quad tiles.  The 4 * L / 4 output quads are L / 16 M tiles of 16 rows; a
-// wave owns one M tile x 32 channels (two n-tiles).
-// Synchronisation between a slab write and the conv that reads it.  WAVE_PRIVATE: the stage's tiling gives every wave whole
-// samples with all their channels (L = 64: one M tile = one sample per wave), so a wave only ever reads what it wrote --
-// LDS operations of one wave execute in order, and only the compiler has to be kept from reordering them; no workgroup
-// barrier, i.e. no waiting for the slowest of the four SIMDs (each barrier costs its skew).
+// Synchronisation between a slab write and the conv that reads it.  WAVE_PRIVATE (the final block: one M tile = one sample
+// per wave): a wave only ever reads what it wrote -- LDS operations of one wave execute in order, and only the compiler
+// has to be kept from reordering them; no workgroup barrier, i.e. no waiting for the slowest of the four SIMDs.
 template <bool WAVE_PRIVATE>
 __device__ __forceinline__ void slab_sync() {
   if constexpr (WAVE_PRIVATE) {
@@ -800,124 +783,6 @@ __device__ __forceinline__ void vbu_taps(f32x4 (&m)[8], f32x4 (&rm)[6], const ch
     if constexpr (PH == 1) rm[r1] = c1;
     if (i + VB_RD < 8) vbu_load_b(b[i % VB_RD], w, PH, i + VB_RD);
     MMD_PIN_LOADS();
-  }
-}
-
-template <class CF, bool FIRST>
-__device__ __forceinline__ void chain_body_w4(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[8],
-                                              f32x4 (&mid)[8], f32x16 (&tout)[1], int trb) {
-  static_assert((CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 &&
-                    CF::RES0 == RES_CONV && CF::TAIL != TAIL_UP,
-                "down-path stage with 4 waves = (L / 16 M tiles) x (CM / 32 channel slices)");
-  constexpr bool PRIV = CF::L == 64;                                    // 4 M tiles x 1 channel slice: wave = sample
-  float* hslab = lds + CF::XSLAB;
-  float* xslab = lds;
-  constexpr int QPS = CF::L / 4, WNQ = CF::CM / 32;                     // quads per sample, channel slices
-  const int mt = wave / WNQ, wnq = wave % WNQ;
-  // A fragment: row i = lane & 15 of M tile mt = (sample, quad), k = lane >> 4
-  const int ai = mt * 16 + (lane & 15);
-  const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
-  const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
-  const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
-  const int col0 = wnq * 32 + (lane & 15), col1 = col0 + 16;            // C/D fragment: this lane's channels
-  // conv A of the first RTB carries the 1x1 residual conv (5 float4 per lane and k-step), all other convs 4
-  BQ<5> ring5[W4_RD];
-  BQ<4> ring[W4_RD];
-  auto wlane = [&](const float4* w, int cp) {
-    return reinterpret_cast<const float*>(w) + ((size_t)wnq * (cp / 4) * 64 + lane) * 16;
-  };
-  const float* w0 = reinterpret_cast<const float*>(a.r0.wa) + ((size_t)wnq * (CF::C0P / 4) * 64 + lane) * 20;
-  w4_ring_load<5>(ring5, w0);
-  if constexpr (FIRST)     // the network input, channels-last [n, 64, 4] in HBM (channels 4..15 of the slab are zero)
-    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(xslab, a.in0, nullptr, n0, a.n);
-  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
-  __syncthreads();
-  TR(trb + 0);
-
-  f32x4 m[16], res[8];
-  auto conv_h = [&](const float4* w, const float4* next) {
-    w4_taps<CF::CM, CF::HSTR, 2, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
-    if (next) w4_ring_load<4>(ring, wlane(next, CF::CM));
-    w4_out(acc, m);
-  };
-  // acc -> the row-form H slab the next conv reads
-  auto to_h = [&]() { quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane); };
-  // GroupNorm + Mish of acc, then + the time bias tb (conv A) or + the residual tile (conv B, tb == nullptr)
-  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
-    const float bb[2] = {b[col0], b[col1]}, gg[2] = {g[col0], g[col1]}, ee[2] = {be[col0], be[col1]};
-    if (MMD_ABL == 1) return;
-    if (tb) {
-      const float t0 = tb[col0], t1 = tb[col1];
-      gn_mish_quad<CF::CM, CF::L>(acc, bb, gg, ee, [&](int i, int) { return (i & 1) ? t1 : t0; });
-    } else {
-      gn_mish_quad<CF::CM, CF::L>(acc, bb, gg, ee, [&](int i, int r) { return res[i][r]; });
-    }
-  };
-
-  // =================== RTB 0 (C0 -> CM) with its 1x1 residual conv fused into conv A ===================
-  {
-    const float br0 = a.br[col0], br1 = a.br[col1];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      res[o * 2] = f32x4{br0, br0, br0, br0};
-      res[o * 2 + 1] = f32x4{br1, br1, br1, br1};
-    }
-  }
-  w4_taps<CF::C0P, CF::XSTR, 2, true, true>(m, res, xslab, xbase, w0, ring5);
-  w4_ring_load<4>(ring, wlane(a.r0.wb, CF::CM));
-  w4_out(acc, m);
-  TR(trb + 2);
-  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
-  to_h();
-  slab_sync<PRIV>();
-  TR(trb + 4);
-  conv_h(a.r0.wb, CF::N_IDENT > 0 ? a.ri[0].wa : nullptr);
-  TR(trb + 5);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
-  if constexpr (CF::MID_AFTER == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) mid[i] = acc[i];
-  }
-
-  // =================== identity RTBs ===================
-#pragma unroll
-  for (int k = 0; k < CF::N_IDENT; ++k) {
-    const RtbPtrs& R = a.ri[k];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) res[i] = acc[i];
-    slab_sync<PRIV>();                                       // the previous conv is done reading the H slab
-    TR(trb + 8 + k * 8 + 0);
-    to_h();
-    slab_sync<PRIV>();
-    TR(trb + 8 + k * 8 + 1);
-    conv_h(R.wa, R.wb);
-    TR(trb + 8 + k * 8 + 2);
-    gn(R.ba, R.ga, R.bea, R.tb);
-    slab_sync<PRIV>();
-    to_h();
-    slab_sync<PRIV>();
-    TR(trb + 8 + k * 8 + 5);
-    conv_h(R.wb, k + 1 < CF::N_IDENT ? a.ri[k + 1 < CF::N_IDENT ? k + 1 : k].wa : nullptr);
-    TR(trb + 8 + k * 8 + 6);
-    gn(R.bb, R.gb, R.beb, nullptr);
-    if (CF::MID_AFTER == k + 1) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) mid[i] = acc[i];
-    }
-  }
-
-  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32 ===================
-  if constexpr (CF::TAIL == TAIL_DOWN) {
-    static_assert(!PRIV || (CF::WN == 1 && CF::SW == 1), "wave-private stage: the tail tile of a wave is its own sample");
-    slab_sync<PRIV>();
-    quad_to_stage<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, wave, lane);
-    slab_sync<PRIV>();
-    constexpr int LO = CF::L / 2;
-    const int wm = wave / CF::WN, wn = wave % CF::WN, hi = lane >> 5;
-    fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
-    const int r = lane & 31;
-    int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
-    mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
   }
 }
 
@@ -1165,61 +1030,86 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// downs.1 (L = 32, 64 channels) with its three 64 -> 64 convs as bf16x3.  The stage's output is 2 M tiles (M tile = 2
-// samples x 8 quads) x 4 n-tiles; a wave owns ONE n-tile and BOTH M tiles -- the two accumulator streams of a step, so
-// a weight fragment is used twice (a (1 M tile x 2 n-tiles) wave would stream 2 x the weights and gain nothing over the
-// fp32 MFMA: these convs are weight-stream bound too).  A lane of the C/D fragment then holds one channel x 16 consecutive
-// positions (half a sample) in each M tile; for the dword stores of the slab the lanes of a pair (n, n ^ 1) swap one tile
-// by DPP, so that the even lane holds channels (c, c + 1) of M tile 0 and the odd lane those of M tile 1, and the two
-// positions either side of a half-sample come from lane ^ 16 (the sample's other half).  Slab: rows = 16 mt + i (the
-// MFMA row order), 32 rows x 16 B per 8-channel block; blocks c, c + 1 of an n-tile 512 + 32 B apart, block pairs a
-// multiple of 256 B: the b128 reads are conflict-free, the b32 stores 2-way (free) -- K chunk kc = blocks kc, kc + 2, kc +
-// 4, kc + 6.
+// downs.0 (L = 64, 32 channels) and downs.1 (L = 32, 64 channels) with their three C -> C convs as bf16x3.  The stage's
+// output is L / 16 M tiles x C / 16 n-tiles = 8 units; a wave owns ONE n-tile and TWO M tiles -- the two accumulator
+// streams of a step, so a weight fragment is used twice (a (1 M tile x 2 n-tiles) wave would stream 2 x the weights and
+// gain nothing over the fp32 MFMA: these convs are weight-stream bound too).  A lane of the C/D fragment then holds one
+// channel x 16 consecutive positions (a half / a quarter of a sample) in each M tile; for the dword stores of the slab the
+// lanes of a pair (n, n ^ 1) swap one tile by DPP, so that the even lane holds channels (c, c + 1) of the first M tile
+// and the odd lane those of the second, and the two positions either side of the lane's 16 come from lane -+ 16 (the
+// neighbouring part of the sample).  Slab: rows = 16 mt + i (the MFMA row order), L rows x 16 B per 8-channel block;
+// the blocks c, c + 1 of an n-tile lie L * 16 + 32 B apart, block pairs a multiple of 256 B, and the two channel-block
+// groups (lane >> 4) that a 16-lane b128 read group spans are blocks of different pairs at the same position in the pair:
+// reads conflict-free, b32 stores 2-way (free).  K chunk kc (downs.1 has two) = blocks kc, kc + 2, kc + 4, kc + 6; downs.0's one
+// chunk takes its four blocks in the order 0, 2, 1, 3.
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int VD_X = 512 + 32;
-constexpr int VD_G = 5 * 256;
-constexpr int VBD_FRAGS = 2 * 4 * 2 * 3;   // weight fragments per n-tile and conv: [phase][slot][chunk][piece]
-static_assert(4 * VD_G == VB_PS, "downs.1 and downs.2 share the phase-slab size");
+template <int L, int CM> struct DbGeo {
+  static constexpr int KC = CM / 32, NTQ = CM / 16, QB = L / 16;        // K chunks, n-tiles, lane groups per sample
+  static constexpr int X = L * 16 + 32;                                 // bytes between the blocks of a pair
+  static constexpr int G = (2 * X + 255) / 256 * 256;                   // bytes between block pairs
+  static constexpr int PS = 2 * KC * G;                                 // bytes per (piece, slot)
+  static constexpr int STEPS = 4 * KC;                                  // (slot, chunk) steps per phase
+  static constexpr int FRAGS = 2 * STEPS * 3;                           // weight fragments per n-tile and conv
+  static_assert(12 * PS <= VSLAB_FLOATS * 4, "the phase slab must fit the V slab's space");
+  // channel block of (chunk kc, lane group j): pair index and position in the pair
+  __host__ __device__ static constexpr int pair_of(int kc, int j) { return KC == 2 ? j : (j & 1); }
+  __host__ __device__ static constexpr int half_of(int kc, int j) { return KC == 2 ? kc : (j >> 1); }
+};
 
+template <class GEO>
 __device__ __forceinline__ void vbd_load_b(u32x4 (&b)[3], const u32x4* w, int ph, int step) {
-  const u32x4* p = w + ((ph * 8 + step) * 3) * 64;
+  const u32x4* p = w + ((ph * GEO::STEPS + step) * 3) * 64;
 #pragma unroll
   for (int q = 0; q < 3; ++q) b[q] = p[q * 64];
 }
-__device__ __forceinline__ void vbd_load_a(u32x4 (&a)[2][3], const char* va, int step) {   // step = 2 * slot + chunk
+// va = slab + the lane's (pair, [position in the pair for one-chunk stages], first M tile's row lane & 15) offset
+template <class GEO>
+__device__ __forceinline__ void vbd_load_a(u32x4 (&a)[2][3], const char* va, int step) {   // step = KC * slot + chunk
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      a[mt][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step / 2) * VB_PS + (step % 2) * VD_X + mt * 256);
+      a[mt][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step / GEO::KC) * GEO::PS +
+                                                 (GEO::KC == 2 ? (step % GEO::KC) * GEO::X : 0) + mt * 256);
 }
-template <int PH>
+template <class GEO, int PH>
 __device__ __forceinline__ void vbd_ring_load(u32x4 (&b)[VB_RD][3], const u32x4* w) {
 #pragma unroll
-  for (int i = 0; i < VB_RD; ++i) vbd_load_b(b[i], w, PH, i);
+  for (int i = 0; i < VB_RD; ++i) vbd_load_b<GEO>(b[i], w, PH, i);
   MMD_PIN_LOADS();
 }
-// m[M tile][position] of phase PH's four positions = conv over the slab's 64 channels
-template <int PH>
+// m[M tile][position] of phase PH's four positions = conv over the slab's channels
+template <class GEO, int PH>
 __device__ __forceinline__ void vbd_taps(f32x4 (&m)[2][8], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][3]) {
   u32x4 a[2][2][3];
-  vbd_load_a(a[0], va, 0);
+  vbd_load_a<GEO>(a[0], va, 0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (i + 1 < 8) vbd_load_a(a[(i + 1) & 1], va, i + 1);
+  for (int i = 0; i < GEO::STEPS; ++i) {
+    if (i + 1 < GEO::STEPS) vbd_load_a<GEO>(a[(i + 1) & 1], va, i + 1);
     MMD_PIN_LOADS();
-    const int pos = vb_pos(PH, i / 2);
-    if (i % 2 == 0) vb_six<true>(m[0][pos], m[1][pos], a[i & 1][0], a[i & 1][1], b[i % VB_RD], b[i % VB_RD]);
+    const int pos = vb_pos(PH, i / GEO::KC);
+    if (i % GEO::KC == 0) vb_six<true>(m[0][pos], m[1][pos], a[i & 1][0], a[i & 1][1], b[i % VB_RD], b[i % VB_RD]);
     else vb_six<false>(m[0][pos], m[1][pos], a[i & 1][0], a[i & 1][1], b[i % VB_RD], b[i % VB_RD]);
-    if (i + VB_RD < 8) vbd_load_b(b[i % VB_RD], w, PH, i + VB_RD);
+    if (i + VB_RD < GEO::STEPS) vbd_load_b<GEO>(b[i % VB_RD], w, PH, i + VB_RD);
     MMD_PIN_LOADS();
   }
 }
 // The lane's two tiles P (own channel), Q (pair partner's channel) of its M tile, with the two positions before / after
 // its 16: phase PH of their V transforms -> the slab (sel orders the pair: even lane P = low channel, odd lane Q).
-template <int PH>
+template <class GEO, int PH>
 __device__ __forceinline__ void vbd_store(char* base, const f32x4 (&P)[4], const float (&pp)[2], const float (&pn)[2],
                                           const f32x4 (&Q)[4], const float (&qp)[2], const float (&qn)[2], unsigned sel) {
+  constexpr int PS = GEO::PS;
+  auto put2 = [&](char* p, int slot, float v0, float v1) {   // the three pieces of the pair at slot `slot`
+    const unsigned a0 = __float_as_uint(v0), b0 = __float_as_uint(v1);
+    const float ra = v0 - __uint_as_float(a0 & 0xffff0000u), rb = v1 - __uint_as_float(b0 & 0xffff0000u);
+    const unsigned a1 = __float_as_uint(ra), b1 = __float_as_uint(rb);
+    const unsigned a2 = __float_as_uint(ra - __uint_as_float(a1 & 0xffff0000u));
+    const unsigned b2 = __float_as_uint(rb - __uint_as_float(b1 & 0xffff0000u));
+    *reinterpret_cast<unsigned*>(p + slot * PS) = __builtin_amdgcn_perm(b0, a0, sel);
+    *reinterpret_cast<unsigned*>(p + (4 + slot) * PS) = __builtin_amdgcn_perm(b1, a1, sel);
+    *reinterpret_cast<unsigned*>(p + (8 + slot) * PS) = __builtin_amdgcn_perm(b2, a2, sel);
+  };
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float d[8], e[8];
@@ -1233,56 +1123,62 @@ __device__ __forceinline__ void vbd_store(char* base, const f32x4 (&P)[4], const
     if constexpr (PH == 0) {
       const float de1 = fmaf(-4.25f, d[4], d[2]) + d[6], do1 = fmaf(-4.25f, d[3], d[1]) + d[5];
       const float ee1 = fmaf(-4.25f, e[4], e[2]) + e[6], eo1 = fmaf(-4.25f, e[3], e[1]) + e[5];
-      vb_put2<0 * VB_PS>(p, fmaf(5.25f, d[2] - d[4], d[6] - d[0]), fmaf(5.25f, e[2] - e[4], e[6] - e[0]), sel);
-      vb_put2<1 * VB_PS>(p, de1 + do1, ee1 + eo1, sel);
-      vb_put2<2 * VB_PS>(p, de1 - do1, ee1 - eo1, sel);
-      vb_put2<3 * VB_PS>(p, fmaf(5.25f, d[3] - d[5], d[7] - d[1]), fmaf(5.25f, e[3] - e[5], e[7] - e[1]), sel);
+      put2(p, 0, fmaf(5.25f, d[2] - d[4], d[6] - d[0]), fmaf(5.25f, e[2] - e[4], e[6] - e[0]));
+      put2(p, 1, de1 + do1, ee1 + eo1);
+      put2(p, 2, de1 - do1, ee1 - eo1);
+      put2(p, 3, fmaf(5.25f, d[3] - d[5], d[7] - d[1]), fmaf(5.25f, e[3] - e[5], e[7] - e[1]));
     } else {
       const float de2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), do2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
       const float de3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), do3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
       const float ee2 = fmaf(0.25f, e[2], fmaf(-1.25f, e[4], e[6])), eo2 = fmaf(0.5f, e[1], fmaf(-2.5f, e[3], 2.f * e[5]));
       const float ee3 = fmaf(4.f, e[2], fmaf(-5.f, e[4], e[6])), eo3 = fmaf(2.f, e[1], fmaf(-2.5f, e[3], 0.5f * e[5]));
-      vb_put2<0 * VB_PS>(p, de2 + do2, ee2 + eo2, sel);
-      vb_put2<1 * VB_PS>(p, de2 - do2, ee2 - eo2, sel);
-      vb_put2<2 * VB_PS>(p, de3 + do3, ee3 + eo3, sel);
-      vb_put2<3 * VB_PS>(p, de3 - do3, ee3 - eo3, sel);
+      put2(p, 0, de2 + do2, ee2 + eo2);
+      put2(p, 1, de2 - do2, ee2 - eo2);
+      put2(p, 2, de3 + do3, ee3 + eo3);
+      put2(p, 3, de3 - do3, ee3 - eo3);
     }
     asm volatile("" ::: "memory");
   }
 }
 
-template <class CF>
-__device__ __forceinline__ void chain_body_d1(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[2][4],
+template <class CF, bool FIRST>
+__device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[2][4],
                                               f32x4 (&mid)[2][4], f32x16 (&tout)[1], int trb) {
-  static_assert(CF::L == 32 && CF::CM == 64 && CF::C0 == 32 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
-                    CF::MID_AFTER == 1 && CF::TAIL == TAIL_DOWN, "downs.1");
-  constexpr int QPS = CF::L / 4;                             // 8 quads per sample
+  static_assert((CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 && CF::RES0 == RES_CONV &&
+                    CF::N_IDENT == 1 && CF::TAIL == TAIL_DOWN, "downs.0 / downs.1");
+  using GEO = DbGeo<CF::L, CF::CM>;
+  constexpr int QPS = CF::L / 4, QB = GEO::QB;               // quads / lane groups per sample
   float* hslab = lds + CF::XSLAB;                            // row-form H slab of the tail conv
-  const int nq = wave, col = 16 * nq + (lane & 15);          // the wave's n-tile, the lane's channel
-  // A row lane & 15 of M tile mt = (sample, quad) of the row-form x slab (conv A of the first RTB)
+  const int nq = wave % GEO::NTQ, mt0 = 2 * (wave / GEO::NTQ);          // the wave's n-tile and first M tile
+  const int col = 16 * nq + (lane & 15);                     // the lane's channel
+  // A row lane & 15 of M tile mt0 + mt = (sample, quad) of the row-form x slab (conv A of the first RTB)
   int xbase[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    const int ai = mt * 16 + (lane & 15);
+    const int ai = (mt0 + mt) * 16 + (lane & 15);
     xbase[mt] = (ai / QPS) * CF::XSS + 4 * (ai % QPS) * CF::XSTR + (lane >> 4);
   }
   BQ<3> ring3[W4_RD];
   const float* w3 = reinterpret_cast<const float*>(a.r0.wa) + ((size_t)nq * (CF::C0P / 4) * 64 + lane) * 12;
   w4_ring_load<3>(ring3, w3);
-  __syncthreads();                                           // the x slab (downs.0's tail tile) is staged
+  if constexpr (FIRST)     // the network input, channels-last [n, 64, 4] in HBM (channels 4..7 of the slab are zero)
+    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(lds, a.in0, nullptr, n0, a.n);
+  __syncthreads();                                           // the x slab is staged
   TR(trb + 0);
 
   f32x4 res[2][4];
   char* const vb = reinterpret_cast<char*>(lds);             // the bf16x3 phase slab aliases the x and H slabs
-  const char* const vb_a = vb + (lane >> 4) * VD_G + (lane & 15) * 16;
-  const int odd = lane & 1, gl = (lane >> 4) & 1;            // pair position; first / second half of the sample
-  char* const vb_s = vb + nq * VD_G + ((lane & 15) >> 3) * VD_X + (16 * odd + 4 * (lane >> 4)) * 16 + ((lane & 7) >> 1) * 4;
+  const int jg = lane >> 4;
+  const char* const vb_a = vb + GEO::pair_of(0, jg) * GEO::G + (GEO::KC == 1 ? GEO::half_of(0, jg) * GEO::X : 0) +
+                           (16 * mt0 + (lane & 15)) * 16;
+  const int odd = lane & 1, gs = jg % QB;                    // pair position; the lane group's place in its sample
+  char* const vb_s = vb + nq * GEO::G + ((lane & 15) >> 3) * GEO::X + (16 * (mt0 + odd) + 4 * jg) * 16 + ((lane & 7) >> 1) * 4;
   const unsigned sel = odd ? 0x03020706u : 0x07060302u;
   auto conv_hb = [&](const uint4* w) {
-    const u32x4* wp = reinterpret_cast<const u32x4*>(w) + (size_t)nq * VBD_FRAGS * 64 + lane;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(w) + (size_t)nq * GEO::FRAGS * 64 + lane;
     u32x4 ring_b[VB_RD][3];
-    vbd_ring_load<0>(ring_b, wp);
-    // pair exchange: P = the lane's own channel in ITS M tile (even lane: 0, odd: 1), Q = the partner's channel there
+    vbd_ring_load<GEO, 0>(ring_b, wp);
+    // pair exchange: P = the lane's own channel in ITS M tile (even lane: the first, odd: the second), Q = the partner's
     f32x4 P[4], Q[4];
     float pp[2], pn[2], qp[2], qn[2];
 #pragma unroll
@@ -1295,21 +1191,23 @@ __device__ __forceinline__ void chain_body_d1(const ChainArgs& a, float* lds, in
       }
     }
     {
-      // the sample's other half (lane ^ 16) supplies the two positions after (first half) / before (second half) the lane's
-      const float pa = __shfl_xor(gl ? P[0][0] : P[2][3], 16), pb = __shfl_xor(gl ? P[1][0] : P[3][3], 16);
-      const float qa = __shfl_xor(gl ? Q[0][0] : Q[2][3], 16), qb = __shfl_xor(gl ? Q[1][0] : Q[3][3], 16);
-      pp[0] = gl ? pa : 0.f; pp[1] = gl ? pb : 0.f; pn[0] = gl ? 0.f : pa; pn[1] = gl ? 0.f : pb;
-      qp[0] = gl ? qa : 0.f; qp[1] = gl ? qb : 0.f; qn[0] = gl ? 0.f : qa; qn[1] = gl ? 0.f : qb;
+      // the two positions before the lane's 16 are the last two of lane - 16, the two after the first two of lane + 16;
+      // outside the sample: the conv's zero padding
+      const bool hp = gs > 0, hn = gs < QB - 1;
+      const float p0 = __shfl_up(P[2][3], 16), p1 = __shfl_up(P[3][3], 16), p2 = __shfl_down(P[0][0], 16), p3 = __shfl_down(P[1][0], 16);
+      const float q0 = __shfl_up(Q[2][3], 16), q1 = __shfl_up(Q[3][3], 16), q2 = __shfl_down(Q[0][0], 16), q3 = __shfl_down(Q[1][0], 16);
+      pp[0] = hp ? p0 : 0.f; pp[1] = hp ? p1 : 0.f; pn[0] = hn ? p2 : 0.f; pn[1] = hn ? p3 : 0.f;
+      qp[0] = hp ? q0 : 0.f; qp[1] = hp ? q1 : 0.f; qn[0] = hn ? q2 : 0.f; qn[1] = hn ? q3 : 0.f;
     }
     f32x4 mb[2][8];
-    vbd_store<0>(vb_s, P, pp, pn, Q, qp, qn, sel);
+    vbd_store<GEO, 0>(vb_s, P, pp, pn, Q, qp, qn, sel);
     __syncthreads();
-    vbd_taps<0>(mb, vb_a, wp, ring_b);
-    vbd_ring_load<1>(ring_b, wp);
+    vbd_taps<GEO, 0>(mb, vb_a, wp, ring_b);
+    vbd_ring_load<GEO, 1>(ring_b, wp);
     __syncthreads();                                         // every wave is done reading the phase-0 slab
-    vbd_store<1>(vb_s, P, pp, pn, Q, qp, qn, sel);
+    vbd_store<GEO, 1>(vb_s, P, pp, pn, Q, qp, qn, sel);
     __syncthreads();
-    vbd_taps<1>(mb, vb_a, wp, ring_b);
+    vbd_taps<GEO, 1>(mb, vb_a, wp, ring_b);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) w4n1_out(acc[mt], mb[mt]);
   };
@@ -1327,7 +1225,7 @@ __device__ __forceinline__ void chain_body_d1(const ChainArgs& a, float* lds, in
     }
   };
 
-  // =================== RTB 0 (32 -> 64): conv A + the 1x1 residual conv on the fp32 MFMA, row-form x slab ===================
+  // =================== RTB 0 (C0 -> CM): conv A + the 1x1 residual conv on the fp32 MFMA, row-form x slab ===================
   {
     f32x4 m[8];
     const float br = a.br[col];
@@ -1357,16 +1255,18 @@ __device__ __forceinline__ void chain_body_d1(const ChainArgs& a, float* lds, in
     __syncthreads();
     conv_hb(R.wb_bf);
     gn(R.bb, R.gb, R.beb, nullptr);
+    if constexpr (CF::MID_AFTER == 1) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mid[mt][i] = acc[mt][i];
+        for (int i = 0; i < 4; ++i) mid[mt][i] = acc[mt][i];
+    }
   }
   // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32, row-form H slab ===================
   __syncthreads();                                           // the last conv is done reading the phase slab
   zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc[mt], hslab, mt, nq, lane);
+  for (int mt = 0; mt < 2; ++mt) quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc[mt], hslab, mt0 + mt, nq, lane);
   __syncthreads();
   {
     constexpr int LO = CF::L / 2;
@@ -1557,20 +1457,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int n0 = blockIdx.x * 4;
 
   f32x4 skip1[2][4], skip2[2][4];
-  // ---- downs.0 @ L=64 -> [4][32][32]
+  // ---- downs.0 @ L=64 -> [4][32][32]  (chain_body_db: lane = channel 16 nq + (lane & 15) in the wave's two M tiles)
   {
-    f32x4 acc[8], mid[8];
+    f32x4 acc[2][4], mid[2][4];
     f32x16 t[1];
-    chain_body_w4<CH_D0, true>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
+    chain_body_db<CH_D0, true>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
     __syncthreads();                                                       // the tail conv is done reading the H slab
     tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
   }
-  // ---- downs.1 @ L=32 -> [4][16][64], skip1 (lane = channel 16 wave + (lane & 15) in both M tiles: chain_body_d1)
+  // ---- downs.1 @ L=32 -> [4][16][64], skip1 (lane = channel 16 wave + (lane & 15) in both M tiles)
   {
     f32x4 acc[2][4];
     f32x16 t[1];
-    chain_body_d1<CH_D1>(a.c[1], lds, lane, wave, acc, skip1, t, 40);
+    chain_body_db<CH_D1, false>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
     __syncthreads();
     tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
@@ -1905,8 +1805,8 @@ static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int ci
   return base;
 }
 
-// bf16x3 pack of a 64 -> 64 k5 conv of downs.1 for vbd_taps: per n-tile [phase][slot][chunk kc][piece q][lane] x 16 B; lane =
-// (column n = 16 tile + (lane & 15), channels 8 (kc + 2 (lane >> 4)) + j, j = 0..7 at bf16 index j).
+// bf16x3 pack of a C -> C k5 conv of downs.0 / downs.1 for vbd_taps: per n-tile [phase][slot][chunk kc][piece q][lane] x 16 B;
+// lane = (column n = 16 tile + (lane & 15), the 8 channels of the block DbGeo assigns to (kc, lane >> 4), j at bf16 index j).
 static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin) {
   static const double G[8][5] = {{-1, 0, 0, 0, 0},
                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
@@ -1928,7 +1828,9 @@ static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int c
         for (int kc = 0; kc < KC; ++kc)
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
-              const int n = 16 * t + (lane & 15), ci = 8 * (kc + KC * (lane >> 4)) + j, pos = vb_pos(ph, sl);
+              // channel block of (chunk kc, lane group g): 2 * pair + half (DbGeo::pair_of / half_of)
+              const int jg = lane >> 4, blk = KC == 2 ? 2 * jg + kc : 2 * (jg & 1) + (jg >> 1);
+              const int n = 16 * t + (lane & 15), ci = 8 * blk + j, pos = vb_pos(ph, sl);
               const float* g = w + ((size_t)n * cin + ci) * 5;
               double ud = 0.0;
               for (int k = 0; k < 5; ++k) ud += G[pos][k] * (double)g[k];
@@ -2103,14 +2005,14 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   int tb_off = 0;
   for (int r = 0; r < 12; ++r) {
     // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2.  Every conv gets the one pack its stage body
-    // reads: fp32 Winograd packs (pack_w4) for downs.0, the up path and the first convs of downs.1 / downs.2 (one n-tile
-    // per slice there, with the 1x1 residual conv riding along), bf16x3 packs for downs.1's 64 -> 64 convs (pack_vbd),
+    // reads: fp32 Winograd packs (pack_w4) for the up path and the first convs of the down stages (one n-tile per slice
+    // there, with the 1x1 residual conv riding along), bf16x3 packs for downs.0's / downs.1's C -> C convs (pack_vbd),
     // downs.2 + mid's 128 -> 128 convs (pack_vb, paired columns) and ups.0's conv A (pack_vbu).
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     W = RtbW{};
     while (blob.size() % 4) blob.push_back(0.f);
-    const bool d1 = r == 2 || r == 3, d2 = r == 4 || r == 5 || r == 10 || r == 11;
+    const bool d1 = r <= 3, d2 = r == 4 || r == 5 || r == 10 || r == 11;   // d1: downs.0 / downs.1 (chain_body_db)
     const int NT = (r >= 6 && r <= 9) || d1 || d2 ? 1 : 2;   // n-tiles per weight slice
     const int cinp = (R.cin + 7) / 8 * 8;            // the 4-channel network input is padded to 2 k-steps (the ring depth)
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
@@ -2217,8 +2119,8 @@ static const double kUnetFlops =
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64;
 
 // fp32 GEMM FLOPs the matrix pipe executes per trajectory (Winograd convs: 8 products per 4 outputs; channel / N padding
-// included).  The seven 128 -> 128 convs of downs.2 + mid and ups.0's conv A run them as bf16x3 (6 bf16 MFMA FLOPs per
-// fp32 FLOP).
+// included).  The C -> C convs of the three down stages + mid and ups.0's conv A run them as bf16x3 (6 bf16 MFMA FLOPs
+// per fp32 FLOP).
 static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // per sample
 static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
@@ -2277,7 +2179,9 @@ int mmd_debug_set_trace(void* dev_ptr) {
 
 double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
 double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }
-double mmd_unet_bf16x3_flops_per_trajectory(void) { return 7 * wino4_flops(128, 128) + wino4_flops(256, 64) * 14.0 / 8.0; }
+double mmd_unet_bf16x3_flops_per_trajectory(void) {
+  return 4 * 3 * wino4_flops(32, 32) + 2 * 3 * wino4_flops(64, 64) + 7 * wino4_flops(128, 128) + wino4_flops(256, 64) * 14.0 / 8.0;
+}
 
 int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride) {
   MMD_REQUIRE(out && max_launches > 0, "mmd_profiler_create: bad arguments");
