@@ -489,7 +489,8 @@ __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[
 // Producer tiling: wave = (M tile, 32-channel slice); lane >> 4 = (sample within the M tile, 16-row block)
 
 // ----------------------------------------------------------------------------------------------------------------
-// V-form slabs (the L = 16 stages: downs.2 + mid blocks, ups.0).  At L = 16 the four waves of a workgroup share ONE M tile
+// fp32 V-form slabs (today: the 64 -> 64 convs of ups.0; the wider L = 16 convs use the bf16x3 form of the same idea
+// below).  At L = 16 the four waves of a workgroup share ONE M tile
 // (16 rows = 4 samples x 4 quads) and differ only in their channel slice, so with the input transform V = B^T d inside
 // the K loop every wave repeated the same 26 VALU ops per k-step.  But at L = 16 a lane of the C/D fragment holds ALL 16
 // positions of one (sample, channel): the producing epilogue computes the transform of its four quads in registers
@@ -1720,10 +1721,8 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_f
 // c = c_lo + 4 * ks + (lane >> 4), n = slice * 16 * NT + nt * 16 + (lane & 15); with a fused 1x1 residual conv (wres, layout
 // [cout][cin_full]) four more floats: Wr(c, n) for nt = 0, 1, then zeros.  Channels >= c_hi (padding up to cinp) are
 // zero; 8 zero k-steps follow the pack (register-ring over-read).  conv weight layout [cout][cin_full][5].
-// wres_wino: the residual weights are stored Winograd-transformed, (Wr * -2/9, Wr * 2/45, Wr * 8/45, 0) = G g for the
-// centre-tap-only kernel at positions (1,2), (3,4), (5,6) (V-form stages, NT = 1).
 static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi, int cinp, int NT,
-                    const float* wres, bool wres_wino = false, bool pair_cols = false) {
+                    const float* wres, bool pair_cols = false) {
   static const double G[8][5] = {{-1, 0, 0, 0, 0},
                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -1750,13 +1749,7 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_
             for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
             out[p * NT + nt] = (float)u;
           }
-          if (wres && !wres_wino) out[8 * NT + nt] = wres[(size_t)n * cin_full + ci];
-          if (wres && wres_wino) {
-            const double wr = (double)wres[(size_t)n * cin_full + ci];
-            out[8 * NT + 0] = (float)(wr * G[1][2]);
-            out[8 * NT + 1] = (float)(wr * G[3][2]);
-            out[8 * NT + 2] = (float)(wr * G[5][2]);
-          }
+          if (wres) out[8 * NT + nt] = wres[(size_t)n * cin_full + ci];
         }
 }
 
@@ -2029,7 +2022,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin);
     } else {
       W.a.wpk = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres, false, /*pair_cols=*/d2);
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres, /*pair_cols=*/d2);
     }
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
