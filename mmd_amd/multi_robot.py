@@ -30,9 +30,9 @@ def shard_range(n_robots, rank, world_size):
 
 def all_gather_paths(paths_local, world_size, group=None):
     """[n_local,H,2] -> [n_local*world_size,H,2], rank-major (== robot order).  One collective per planning round."""
-    if world_size == 1:
-        return paths_local
     import torch.distributed as dist
+    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
+        return paths_local
     if paths_local.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no device collectives: stage through the host (CPU tests / single-GPU rehearsal of the N>1 path)
         parts = [torch.empty_like(paths_local, device="cpu") for _ in range(world_size)]
