@@ -200,6 +200,19 @@ def main():
     assert torch.isfinite(trajs).all()
     value = args.steps * n_traj_local * world / dt
     dom_ms = dom_ms_c.value
+    # outside the timed region: the same kernel as ONE launch of all local trajectories, back to back on one stream -- the
+    # per-launch figure that does not depend on how the sampler chunks its batch (kernel quality from round to round)
+    xs = torch.randn(n_traj_local, H, 4, device=dev)
+    for _ in range(3):
+        unet(xs, 50)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        unet(xs, 50)
+    e1.record()
+    torch.cuda.synchronize()
+    solo_ms = e0.elapsed_time(e1) / 20
     # mmd_p_sample_loop splits the robots into `chunks` concurrent launch chains (HIP streams, default 2): at any time
     # `chunks` unet_kernel launches of n_traj_local / chunks trajectories each share the GPU.  launch_ms is the mean
     # duration of ONE such launch (what rocprofv3 --stats reports for unet_kernel); the rate the GPU sustains is that of
@@ -233,6 +246,10 @@ def main():
                 "flops_per_launch": launch_mfma, "flops_per_launch_as_bf16x3": launch_bf,
                 "achieved_single_launch": launch_mfma / (dom_ms * 1e-3) / 1e12,
                 "pipe_busy_model": busy_s / (dom_ms * 1e-3),
+                "whole_batch_single_launch": {"trajectories": n_traj_local, "launch_ms": solo_ms,
+                                              "achieved": mfma_flops / (solo_ms * 1e-3) / 1e12,
+                                              "frac": mfma_flops / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                              "note": "the same kernel as one launch of all local trajectories, 20 back to back on one stream, outside the timed region"},
                 "note": f"flops = fp32 GEMM FLOPs run on the matrix pipe (Winograd-domain; {100 * bf_flops / mfma_flops:.0f} % of them as bf16x3: 6 bf16 MFMA FLOPs per fp32 FLOP). "
                         "`concurrent_launches` launches of `trajectories_per_launch` trajectories share the GPU at any time (the sampler's stream chunks); "
                         "launch_ms = mean duration of one of them (HIP events on its stream; = rocprofv3's average for unet_kernel). "
