@@ -173,7 +173,7 @@ def main():
     n_traj_local = RPG * B
     flops = lib.mmd_unet_flops_per_trajectory() * n_traj_local              # algorithmic (direct-conv) FLOPs per launch
     mfma_flops = lib.mmd_unet_mfma_flops_per_trajectory() * n_traj_local    # fp32 GEMM FLOPs the matrix pipe runs
-    bf_flops = lib.mmd_unet_bf16x3_flops_per_trajectory() * n_traj_local    # ... of which as bf16x3 on the bf16 pipe
+    bf_flops = lib.mmd_unet_f16x2_flops_per_trajectory() * n_traj_local    # ... of which as bf16x3 on the bf16 pipe
 
     for w in range(args.warmup):
         _, paths_local = sampler.plan_round(paths_local, seed=1000 + w)

@@ -103,7 +103,7 @@ _DEBUG_SIGNATURES = {
     "mmd_profiler_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mmd_unet_flops_per_trajectory": (C.c_double, []),
     "mmd_unet_mfma_flops_per_trajectory": (C.c_double, []),
-    "mmd_unet_bf16x3_flops_per_trajectory": (C.c_double, []),
+    "mmd_unet_f16x2_flops_per_trajectory": (C.c_double, []),
     "mmd_unet_forward_profiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_void_p]),
 }

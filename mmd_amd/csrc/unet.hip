@@ -221,15 +221,17 @@ constexpr int MAX_IDENT = 3;
 struct RtbPtrs {
   const float4* wa; const float* ba; const float* ga; const float* bea; const float* tb;
   const float4* wb; const float* bb; const float* gb; const float* beb;
-  const uint4* wa_bf; const uint4* wb_bf;   // bf16x3 packs of the same convs (downs.2 + mid blocks: vb_taps)
+  const uint4* wa_bf; const uint4* wb_bf;   // f16x2 packs of the same convs (C -> C convs of the down stages + mid, ups.0 conv A)
+  const float* isa; const float* isb;       // [C_out] inverse per-channel weight scales of the f16x2 packs
 };
 
 struct ChainArgs {
   const float* in0;                      // [n, L, C0] network input (first chain only)
   RtbPtrs r0;
   const float4* wa0_c1;                  // conv A pack of the second input chunk (C1 > 0)
-  const uint4* wa0_c1_bf;                // ... its bf16x3 form (ups.0: vbu_taps)
+  const uint4* wa0_c1_bf;                // ... its f16x2 form (ups.0: vbu_taps)
   const float* br;                       // bias of the 1x1 residual conv (its weights ride in the conv A packs)
+  const float* isr;                      // [C_out] inverse scale of the residual weights in the f16x2 packs (ups.0)
   RtbPtrs ri[MAX_IDENT];
   const float4* wt; const float* bt;     // tail conv pack(s), bias
   int n;
@@ -584,54 +586,66 @@ __device__ __forceinline__ void slab_sync() {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// fp32 GEMM on the bf16 matrix pipe ("bf16x3"): the 128 -> 128 convs of downs.2 + mid blocks (51 % of the network's MACs).
-// Every fp32 operand is split EXACTLY into three bf16 pieces by truncation (x = x0 + x1 + x2: x0 = the top 16 bits of x,
-// x1 = the top 16 bits of x - x0, x2 = x - x0 - x1, which has at most 8 significant bits left), and a product a * w is
-// accumulated as the six piece products of order <= 2, a2 w0 + a1 w1 + a0 w2 + a1 w0 + a0 w1 + a0 w0 (lowest order first),
-// on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The three dropped products are <= 2^-24 |a w| each; measured against
-// fp64 the result is as accurate as the fp32 MFMA chain it replaces (tools/ubench/bf16x_emul.hip: rms error 0.8x).  One
-// K = 32 chunk costs 6 x 16 cycles instead of 8 x 32 on v_mfma_f32_16x16x4_f32.
+// fp32 GEMM on the fp16 matrix pipe ("f16x2"): the C -> C convs of the three down stages + mid blocks and ups.0's conv A
+// (70 % of the network's matrix work).  Every fp32 operand is split into TWO fp16 pieces by rounding to nearest,
+// x0 = RN16(x), x1 = RN16(x - x0) (x - x0 is exact in fp32; |x - x0 - x1| <= 2^-24 |x|, half an fp32 ulp, as long as x1 stays
+// above fp16's denormal step 2^-24), and a product a * w is accumulated as a1 w0 + a0 w1 + a0 w0 (low order first) on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation; the dropped a1 w1 is <= 2^-24 |a w|.  Measured against fp64 the result is
+// more accurate than the fp32 MFMA chain it replaces and than the three-piece bf16 split of round 2
+// (tools/ubench/f16x2_emul.hip: rms error 1.5e-7 / 2.9e-7 / 4.0e-7 of rms(D) at K = 128 / 640 / 1280 against 2.1e-7 / 4.4e-7 /
+// 6.4e-7 for the fp32 chain and 1.7e-7 / 3.9e-7 / 5.5e-7 for bf16x3) at HALF the matrix-pipe time of bf16x3 (3 instead of 6
+// MFMAs per K = 32 chunk, 1/5 of the fp32 MFMA's) and 4 instead of 6 bytes per weight.  fp16 has five exponent bits:
+// gfx950's MFMA honours fp16 denormal inputs (probed in the same ubench), so a low piece below 2^-14 keeps an ABSOLUTE
+// precision of 2^-25; the weights of every output channel are scaled on the host by a power of two that puts the channel's
+// largest |U| into [2^14, 2^15) (exact; undone for free inside the GroupNorm epilogue, `isc`), and conv inputs (GroupNorm +
+// Mish outputs, V = B^T d of them) sit around 1, where the low pieces are normal or within 2^-25 of it (error 1.5e-7 down to
+// rms 0.2; 7.7e-7 at rms 0.02, same ubench).  |V| must stay below 65504.
+// Three MFMAs on ONE accumulator issue back to back without a bubble, while an MFMA that depends on the one two
+// before it waits (ubench: 8 accumulators x 3 in a row 17.2 cycles per MFMA, two alternating accumulators 30): a step
+// runs its accumulator streams one after the other, and consecutive steps go to different accumulators (chunk-major).
 //
 // The V slab (Winograd-transformed conv input) holds the pieces channel-innermost, the A fragment of the K = 32 MFMA:
-//     Vb[piece q][slot s][channel block c / 8][row' = 4 * quad + sample][c % 8]    (bf16)
+//     Vb[piece q][slot s][channel block c / 8][row' = 4 * quad + sample][c % 8]    (fp16)
 // so a lane's A operand (one row, 8 channels) is ONE ds_read_b128.  Bank-conflict freedom, for the lane groups the LDS
 // services a wave's access in (MI355X_MICROARCH.md, LDS): a K = 32 chunk kc is the four channel blocks kc, kc + 4, kc + 8,
 // kc + 12 (lane group lane >> 4 = block kc + 4 (lane >> 4)), which lie VB_CG = a multiple of 256 B apart, so the rows a
 // 16-lane read group takes from two of them fall on disjoint banks; the blocks c, c + 1 (c & 3) of one such group lie
 // 256 + 32 B apart and the rows are ordered quad-major, so the epilogue's ds_write_b32 -- lanes = (4 adjacent channel
 // pairs) x (4 channel blocks c & 3) x (2 samples), one quad per instruction -- hit 32 distinct banks per 32-lane group.
-// All 8 Winograd positions of 128 channels would be 120 KB, more than a workgroup's half of the CU's LDS, so a conv runs
-// in two PHASES over the position sets {0, 1, 2, 7} and {3, 4, 5, 6} (slots 0..3 of a phase; neither set shares a partial
-// sum of B^T or A^T with the other): store set 0 -- barrier -- MFMAs -- barrier -- store set 1 -- barrier -- MFMAs; the
-// conv's input tile waits in registers meanwhile.
+// A conv runs in two PHASES over the position sets {0, 1, 2, 7} and {3, 4, 5, 6} (slots 0..3 of a phase; neither set shares
+// a partial sum of B^T or A^T with the other): store set 0 -- barrier -- MFMAs -- barrier -- store set 1 -- barrier -- MFMAs; the
+// conv's input tile waits in registers meanwhile (all eight positions at once would need 128 accumulator registers).
 // What bounds these convs is the weight stream, not the matrix pipe: a workgroup has only 16 rows (4 samples x 4 quads)
-// to use a weight fragment on, so the four waves of a CU's SIMDs at the full bf16 rate would pull 112 B/clk through the
-// 64 B/clk/CU vector-memory path; the phases run at ~45 B/clk.
-// Weights: per n-tile and conv [phase][slot][chunk kc][piece q] fragments of 64 lanes x 16 B (lane = column lane & 15,
-// channel block kc + 4 (lane >> 4)), streamed through a two-step register ring.
+// to use a weight fragment on.
+// Weights: per n-tile and conv [phase][step = 4 chunk + slot][piece q] fragments of 64 lanes x 16 B (lane = column lane & 15,
+// channel block kc + 4 (lane >> 4)), streamed through a register ring.
 // ----------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int VB_CB = 16 * 16 + 32;        // bytes between the 8-channel blocks c, c + 1 of a group of four (c & 3)
 constexpr int VB_CG = 5 * 256;             // bytes between the groups of four channel blocks (c >> 2): a multiple of 256
 constexpr int VB_PS = 4 * VB_CG;           // bytes per (piece, slot): 128 channels
-constexpr int VB_BYTES = 12 * VB_PS;       // 3 pieces x 4 slots = 61440 B
-constexpr int VB_FRAGS = 2 * 16 * 3;       // weight fragments per n-tile and conv
-static_assert(VB_BYTES <= VSLAB_FLOATS * 4, "the bf16x3 phase slab aliases the fp32 V slab");
+constexpr int VB_BYTES = 8 * VB_PS;        // 2 pieces x 4 slots = 40960 B
+constexpr int VB_FRAGS = 2 * 16 * 2;       // weight fragments per n-tile and conv
+static_assert(VB_BYTES <= VSLAB_FLOATS * 4, "the f16x2 phase slab aliases the fp32 V slab");
 __host__ __device__ constexpr int vb_pos(int ph, int slot) { return ph == 0 ? (slot == 3 ? 7 : slot) : 3 + slot; }
 
-// The lane holds two adjacent channels (v0: the even one): the three pieces of each pair up into dwords at slot offset
-// OFF of the lane's slab position.
+// the two pieces of a pair of values (v0: the even channel) as dwords {v1 piece, v0 piece}: hi = RN16(v), lo = RN16(v - hi)
+struct F16Pair { unsigned hi, lo; };
+__device__ __forceinline__ F16Pair f16_split2(float v0, float v1) {
+  const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);                  // v_cvt_pk_f16_f32 (round to nearest even)
+  const f16x2 l = __builtin_convertvector(f32x2{v0 - (float)h.x, v1 - (float)h.y}, f16x2);
+  return F16Pair{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
+}
+// The lane holds two adjacent channels (v0: the even one): their pieces pair up into dwords at slot offset OFF of the
+// lane's slab position.
 template <int OFF>
-__device__ __forceinline__ void vb_put2(char* base, float v0, float v1, unsigned sel = 0x07060302u) {   // {v1.hi16, v0.hi16}
-  const unsigned a0 = __float_as_uint(v0), b0 = __float_as_uint(v1);
-  const float ra = v0 - __uint_as_float(a0 & 0xffff0000u), rb = v1 - __uint_as_float(b0 & 0xffff0000u);
-  const unsigned a1 = __float_as_uint(ra), b1 = __float_as_uint(rb);
-  const unsigned a2 = __float_as_uint(ra - __uint_as_float(a1 & 0xffff0000u));
-  const unsigned b2 = __float_as_uint(rb - __uint_as_float(b1 & 0xffff0000u));
-  *reinterpret_cast<unsigned*>(base + OFF) = __builtin_amdgcn_perm(b0, a0, sel);
-  *reinterpret_cast<unsigned*>(base + OFF + 4 * VB_PS) = __builtin_amdgcn_perm(b1, a1, sel);
-  *reinterpret_cast<unsigned*>(base + OFF + 8 * VB_PS) = __builtin_amdgcn_perm(b2, a2, sel);
+__device__ __forceinline__ void vb_put2(char* base, float v0, float v1) {
+  const F16Pair p = f16_split2(v0, v1);
+  *reinterpret_cast<unsigned*>(base + OFF) = p.hi;
+  *reinterpret_cast<unsigned*>(base + OFF + 4 * VB_PS) = p.lo;
 }
 // phase PH of the V transform of the lane's two (sample, channel) columns: x(o, r) = position 4 r + o; base = slab + the
 // lane's (channel block, row 4 * sample, channel % 8) offset.  The expressions are w4_transform's.
@@ -668,44 +682,40 @@ __device__ __forceinline__ void vb_store_pair(char* base, GET0 x0, GET1 x1) {
   }
 }
 
-__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// one K = 32 chunk of two independent accumulator streams x, y (interleaved: no MFMA waits for the one before it)
+// one K = 32 chunk of one accumulator stream: a1 b0 + a0 b1 + a0 b0, back to back on the same accumulator
 template <bool ZERO>
-__device__ __forceinline__ void vb_six(f32x4& x, f32x4& y, const u32x4 (&ax)[3], const u32x4 (&ay)[3], const u32x4 (&bx)[3],
-                                       const u32x4 (&by)[3]) {
+__device__ __forceinline__ void vb_three(f32x4& x, const u32x4 (&a)[2], const u32x4 (&b)[2]) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  f32x4 cx = ZERO ? z : x, cy = ZERO ? z : y;
-  cx = mfma_bf(ax[2], bx[0], cx); cy = mfma_bf(ay[2], by[0], cy);
-  cx = mfma_bf(ax[1], bx[1], cx); cy = mfma_bf(ay[1], by[1], cy);
-  cx = mfma_bf(ax[0], bx[2], cx); cy = mfma_bf(ay[0], by[2], cy);
-  cx = mfma_bf(ax[1], bx[0], cx); cy = mfma_bf(ay[1], by[0], cy);
-  cx = mfma_bf(ax[0], bx[1], cx); cy = mfma_bf(ay[0], by[1], cy);
-  cx = mfma_bf(ax[0], bx[0], cx); cy = mfma_bf(ay[0], by[0], cy);
-  x = cx; y = cy;
+  f32x4 c = ZERO ? z : x;
+  c = mfma_h(a[1], b[0], c);
+  c = mfma_h(a[0], b[1], c);
+  c = mfma_h(a[0], b[0], c);
+  x = c;
 }
-// A step = 12 MFMAs: the wave's two n-tiles (the two accumulator streams) at slot step / 4, chunk step % 4, on one set of
-// A fragments.
-__device__ __forceinline__ void vb_load_b(u32x4 (&b)[2][3], const u32x4* const (&w)[2], int ph, int step) {
+// A step = 6 MFMAs: the wave's two n-tiles (two accumulator streams, one after the other) at chunk step / 4, slot step % 4,
+// on one set of A fragments.
+__device__ __forceinline__ void vb_load_b(u32x4 (&b)[2][2], const u32x4* const (&w)[2], int ph, int step) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const u32x4* p = w[t] + ((ph * 16 + step) * 3) * 64;
+    const u32x4* p = w[t] + ((ph * 16 + step) * 2) * 64;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) b[t][q] = p[q * 64];
+    for (int q = 0; q < 2; ++q) b[t][q] = p[q * 64];
   }
 }
-__device__ __forceinline__ void vb_load_a(u32x4 (&a)[3], const char* va, int step) {
+__device__ __forceinline__ void vb_load_a(u32x4 (&a)[2], const char* va, int step) {
 #pragma unroll
-  for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step / 4) * VB_PS + (step % 4) * VB_CB);
+  for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step % 4) * VB_PS + (step / 4) * VB_CB);
 }
 // the first VB_RD steps' weights of phase PH into the ring (issued ahead of the barrier that publishes the slab)
 #ifndef MMD_VB_RD
-#define MMD_VB_RD 2   // 3: -2 % (its 24 more VGPRs spill inside the K loop)
+#define MMD_VB_RD 2
 #endif
-constexpr int VB_RD = MMD_VB_RD;           // ring depth in steps (6 KB per wave and step in flight)
+constexpr int VB_RD = MMD_VB_RD;           // ring depth in steps (4 KB per wave and step in flight)
 template <int PH>
-__device__ __forceinline__ void vb_ring_load(u32x4 (&b)[VB_RD][2][3], const u32x4* const (&w)[2]) {
+__device__ __forceinline__ void vb_ring_load(u32x4 (&b)[VB_RD][2][2], const u32x4* const (&w)[2]) {
 #pragma unroll
   for (int i = 0; i < VB_RD; ++i) vb_load_b(b[i], w, PH, i);
   MMD_PIN_LOADS();
@@ -713,75 +723,76 @@ __device__ __forceinline__ void vb_ring_load(u32x4 (&b)[VB_RD][2][3], const u32x
 // m[tile][position] of phase PH's four positions = conv over the 128 channels of the slab; va = slab + the lane's A
 // offset (channel block lane >> 4, row lane & 15); w[tile] = the tile's pack + lane; b = ring (vb_ring_load)
 template <int PH>
-__device__ __forceinline__ void vb_taps(f32x4 (&m)[2][8], const char* va, const u32x4* const (&w)[2], u32x4 (&b)[VB_RD][2][3]) {
-  u32x4 a[2][3];
+__device__ __forceinline__ void vb_taps(f32x4 (&m)[2][8], const char* va, const u32x4* const (&w)[2], u32x4 (&b)[VB_RD][2][2]) {
+  u32x4 a[2][2];
   vb_load_a(a[0], va, 0);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     if (i + 1 < 16) vb_load_a(a[(i + 1) & 1], va, i + 1);
     MMD_PIN_LOADS();
-    const int pos = vb_pos(PH, i / 4);
-    if (i % 4 == 0) vb_six<true>(m[0][pos], m[1][pos], a[i & 1], a[i & 1], b[i % VB_RD][0], b[i % VB_RD][1]);
-    else vb_six<false>(m[0][pos], m[1][pos], a[i & 1], a[i & 1], b[i % VB_RD][0], b[i % VB_RD][1]);
+    const int pos = vb_pos(PH, i % 4);
+    if (i / 4 == 0) {
+      vb_three<true>(m[0][pos], a[i & 1], b[i % VB_RD][0]);
+      vb_three<true>(m[1][pos], a[i & 1], b[i % VB_RD][1]);
+    } else {
+      vb_three<false>(m[0][pos], a[i & 1], b[i % VB_RD][0]);
+      vb_three<false>(m[1][pos], a[i & 1], b[i % VB_RD][1]);
+    }
     if (i + VB_RD < 16) vb_load_b(b[i % VB_RD], w, PH, i + VB_RD);
     MMD_PIN_LOADS();
   }
 }
 
 // ups.0's conv A (256 -> 64 over the two 128-channel chunks of cat(x, skip2), with the stage's 1x1 residual conv in the
-// Winograd domain) in the same bf16x3 form.  One n-tile per wave; the two accumulator streams of a step are the two
-// slots of a slot pair (pair, pair + 1), and the residual conv -- G g of a centre-tap-only kernel is w * (-2/9, -2/9, 2/45,
-// 2/45, 8/45, 8/45) at positions 1..6, zero at 0 and 7 -- rides on the A fragments already loaded: one more stream in
-// phase 0 (position 1 resp. 2 of the pair), two in phase 1.  Weights per n-tile and chunk: [phase][pair][chunk kc][9
-// fragments: slot 0 pieces, slot 1 pieces, residual pieces].
-constexpr int VBU_FRAGS = 2 * 2 * 4 * 9;
-__device__ __forceinline__ void vbu_load_b(u32x4 (&b)[9], const u32x4* w, int ph, int step) {
-  const u32x4* p = w + ((ph * 8 + step) * 9) * 64;
+// Winograd domain) in the same f16x2 form.  One n-tile per wave; the accumulator streams of a step are the two slots of a
+// slot pair (pair, pair + 1), and the residual conv -- G g of a centre-tap-only kernel is w * (-2/9, -2/9, 2/45, 2/45, 8/45,
+// 8/45) at positions 1..6, zero at 0 and 7 -- rides on the A fragments already loaded: one more stream in phase 0 (position
+// 1 resp. 2 of the pair), two in phase 1.  Weights per n-tile and chunk: [phase][step = 2 chunk kc + pair][6 fragments:
+// slot 0 pieces, slot 1 pieces, residual pieces]; the residual weights carry their own per-channel scale.
+constexpr int VBU_FRAGS = 2 * 2 * 4 * 6;
+__device__ __forceinline__ void vbu_load_b(u32x4 (&b)[6], const u32x4* w, int ph, int step) {
+  const u32x4* p = w + ((ph * 8 + step) * 6) * 64;
 #pragma unroll
-  for (int f = 0; f < 9; ++f) b[f] = p[f * 64];
+  for (int f = 0; f < 6; ++f) b[f] = p[f * 64];
 }
-__device__ __forceinline__ void vbu_load_a(u32x4 (&a)[2][3], const char* va, int step) {
+__device__ __forceinline__ void vbu_load_a(u32x4 (&a)[2][2], const char* va, int step) {   // step = 2 kc + pair
 #pragma unroll
   for (int st = 0; st < 2; ++st)
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-      a[st][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + 2 * (step / 4) + st) * VB_PS + (step % 4) * VB_CB);
+    for (int q = 0; q < 2; ++q)
+      a[st][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + 2 * (step % 2) + st) * VB_PS + (step / 2) * VB_CB);
 }
 template <int PH>
-__device__ __forceinline__ void vbu_ring_load(u32x4 (&b)[VB_RD][9], const u32x4* w) {
+__device__ __forceinline__ void vbu_ring_load(u32x4 (&b)[VB_RD][6], const u32x4* w) {
 #pragma unroll
   for (int i = 0; i < VB_RD; ++i) vbu_load_b(b[i], w, PH, i);
   MMD_PIN_LOADS();
 }
 // phase PH of one chunk: m[position] (+)= conv, rm[position - 1] (+)= residual conv; FRESH: first chunk (start from zero)
 template <int PH, bool FRESH>
-__device__ __forceinline__ void vbu_taps(f32x4 (&m)[8], f32x4 (&rm)[6], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][9]) {
-  constexpr int PI[6] = {2, 1, 0, 1, 0, 0}, PJ[6] = {0, 1, 2, 0, 1, 0};   // piece products, lowest order first
-  u32x4 a[2][2][3];
+__device__ __forceinline__ void vbu_taps(f32x4 (&m)[8], f32x4 (&rm)[6], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][6]) {
+  u32x4 a[2][2][2];
   vbu_load_a(a[0], va, 0);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (i + 1 < 8) vbu_load_a(a[(i + 1) & 1], va, i + 1);
     MMD_PIN_LOADS();
-    const int pair = i / 4, px = vb_pos(PH, 2 * pair), py = vb_pos(PH, 2 * pair + 1);
+    const int pair = i % 2, px = vb_pos(PH, 2 * pair), py = vb_pos(PH, 2 * pair + 1);
     // residual streams: phase 0: the pair's one position in 1..6 (pair 0: position 1 = slot 1, pair 1: position 2 = slot 0)
     const int r0 = PH == 0 ? pair : px - 1, r1 = py - 1, sa0 = PH == 0 ? 1 - pair : 0;
-    const bool zero = FRESH && i % 4 == 0;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cx = zero ? z : m[px], cy = zero ? z : m[py], c0 = zero ? z : rm[r0], c1 = zero ? z : rm[PH == 0 ? r0 : r1];
-    const u32x4(&ax)[3] = a[i & 1][0];
-    const u32x4(&ay)[3] = a[i & 1][1];
-    const u32x4(&ar)[3] = a[i & 1][sa0];
-    const u32x4(&bb)[9] = b[i % VB_RD];
-#pragma unroll
-    for (int pr = 0; pr < 6; ++pr) {
-      cx = mfma_bf(ax[PI[pr]], bb[PJ[pr]], cx);
-      cy = mfma_bf(ay[PI[pr]], bb[3 + PJ[pr]], cy);
-      c0 = mfma_bf(ar[PI[pr]], bb[6 + PJ[pr]], c0);
-      if constexpr (PH == 1) c1 = mfma_bf(ay[PI[pr]], bb[6 + PJ[pr]], c1);
+    const u32x4(&bb)[6] = b[i % VB_RD];
+    const u32x4 b0[2] = {bb[0], bb[1]}, b1[2] = {bb[2], bb[3]}, br[2] = {bb[4], bb[5]};
+    if (FRESH && i / 2 == 0) {
+      vb_three<true>(m[px], a[i & 1][0], b0);
+      vb_three<true>(m[py], a[i & 1][1], b1);
+      vb_three<true>(rm[r0], a[i & 1][sa0], br);
+      if constexpr (PH == 1) vb_three<true>(rm[r1], a[i & 1][1], br);
+    } else {
+      vb_three<false>(m[px], a[i & 1][0], b0);
+      vb_three<false>(m[py], a[i & 1][1], b1);
+      vb_three<false>(rm[r0], a[i & 1][sa0], br);
+      if constexpr (PH == 1) vb_three<false>(rm[r1], a[i & 1][1], br);
     }
-    m[px] = cx; m[py] = cy; rm[r0] = c0;
-    if constexpr (PH == 1) rm[r1] = c1;
     if (i + VB_RD < 8) vbu_load_b(b[i % VB_RD], w, PH, i + VB_RD);
     MMD_PIN_LOADS();
   }
@@ -802,8 +813,10 @@ __device__ __forceinline__ void w4n1_out(f32x4 (&q)[4], const f32x4 (&m)[8]) {
   q[2] = s1 + 4.f * s2 + 0.25f * s3;
   q[3] = (t1 + m[7]) + (8.f * t2 + 0.125f * t3);
 }
-template <int CM, int L, class ADD>
-__device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float gamma, float beta, ADD add) {
+// isc (SCALED): the conv ran as f16x2 on weights scaled per output channel -- q is the true output times 1 / isc; the
+// factor is folded into the statistics and the affine coefficient (two more VALU ops per tile, none per element).
+template <int CM, int L, bool SCALED = false, class ADD>
+__device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float gamma, float beta, ADD add, float isc = 1.f) {
   constexpr int CPG = CM / 8, QB = L / 16;
   constexpr float inv_n = 1.f / (float)(L * CPG);
   float sum = 0.f;
@@ -811,16 +824,18 @@ __device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float g
   for (int o = 0; o < 4; ++o)
 #pragma unroll
     for (int r = 0; r < 4; ++r) sum += q[o][r];
+  if constexpr (SCALED) sum *= isc;
   const float dm = (quad_groupsum<CPG, QB>(sum) + group_colsum<CPG>(bias) * (float)L) * inv_n - bias;
   float sq = 0.f;
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float d = q[o][r] - dm;
+      const float d = SCALED ? fmaf(q[o][r], isc, -dm) : q[o][r] - dm;
       sq = fmaf(d, d, sq);
     }
-  const GnCoef cf = gn_coef(dm, rsqrtf(quad_groupsum<CPG, QB>(sq) * inv_n + 1e-5f), gamma, beta);
+  GnCoef cf = gn_coef(dm, rsqrtf(quad_groupsum<CPG, QB>(sq) * inv_n + 1e-5f), gamma, beta);
+  if constexpr (SCALED) cf.sa *= isc;
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -839,15 +854,16 @@ __device__ __forceinline__ void quad1_to_stage(const f32x4 (&q)[4], float* dst, 
     for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR] = q[o][r];
 }
 
-// residual 1x1 conv accumulated in the Winograd domain (positions 1..6) -> its four outputs, + bias
-__device__ __forceinline__ void w4n1_res_out(f32x4 (&q)[4], const f32x4 (&rm)[6], float bias) {
+// residual 1x1 conv accumulated in the Winograd domain (positions 1..6) -> its four outputs * isc (the inverse of the
+// f16x2 weight scale of the lane's channel) + bias
+__device__ __forceinline__ void w4n1_res_out(f32x4 (&q)[4], const f32x4 (&rm)[6], float bias, float isc) {
   const f32x4 s1 = rm[0] + rm[1], t1 = rm[0] - rm[1];
   const f32x4 s2 = rm[2] + rm[3], t2 = rm[2] - rm[3];
   const f32x4 s3 = rm[4] + rm[5], t3 = rm[4] - rm[5];
-  q[0] = (s1 + bias) + (s2 + s3);
-  q[1] = (t1 + bias) + (2.f * t2 + 0.5f * t3);
-  q[2] = (s1 + bias) + (4.f * s2 + 0.25f * s3);
-  q[3] = (t1 + bias) + (8.f * t2 + 0.125f * t3);
+  q[0] = (s1 + (s2 + s3)) * isc + bias;
+  q[1] = (t1 + (2.f * t2 + 0.5f * t3)) * isc + bias;
+  q[2] = (s1 + (4.f * s2 + 0.25f * s3)) * isc + bias;
+  q[3] = (t1 + (8.f * t2 + 0.125f * t3)) * isc + bias;
 }
 
 // the same for an explicit unit (M tile mt, n-tile nq)
@@ -916,12 +932,12 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
 
   // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
   if constexpr (VH) {
-    // bf16x3 (vbu_taps): skip_write(chunk, phase) stores that phase of chunk 0 (x) / 1 (skip) into the phase slab
+    // f16x2 (vbu_taps): skip_write(chunk, phase) stores that phase of chunk 0 (x) / 1 (skip) into the phase slab
     f32x4 rm[6];
     const u32x4* wp0 = reinterpret_cast<const u32x4*>(a.r0.wa_bf) + (size_t)nq * VBU_FRAGS * 64 + lane;
     const u32x4* wp1 = reinterpret_cast<const u32x4*>(a.wa0_c1_bf) + (size_t)nq * VBU_FRAGS * 64 + lane;
     const char* const vb_a = reinterpret_cast<const char*>(lds) + (lane >> 4) * VB_CG + (4 * (lane & 3) + ((lane & 15) >> 2)) * 16;
-    u32x4 ring_u[VB_RD][9];
+    u32x4 ring_u[VB_RD][6];
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     vbu_ring_load<0>(ring_u, wp0);
@@ -943,7 +959,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     skip_write(C1{}, C1{});
     __syncthreads();
     vbu_taps<1, false>(m, rm, vb_a, wp1, ring_u);
-    w4n1_res_out(res, rm, a.br[col]);
+    w4n1_res_out(res, rm, a.br[col], a.isr[col]);
   } else {
     {
       const float br = a.br[col];
@@ -961,7 +977,12 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
     w4n1_out(acc, m);
     const float tb = a.r0.tb[col];
-    if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
+    if constexpr (VH) {
+      if (MMD_ABL != 1)
+        gn_mish_quad1<CF::CM, CF::L, true>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; }, a.r0.isa[col]);
+    } else {
+      if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
+    }
   }
   TR(trb + 1);
   if constexpr (VH) __syncthreads();                         // chunk 1 is consumed: the H slab aliases it
@@ -1049,48 +1070,54 @@ template <int L, int CM> struct DbGeo {
   static constexpr int X = L * 16 + 32;                                 // bytes between the blocks of a pair
   static constexpr int G = (2 * X + 255) / 256 * 256;                   // bytes between block pairs
   static constexpr int PS = 2 * KC * G;                                 // bytes per (piece, slot)
-  static constexpr int STEPS = 4 * KC;                                  // (slot, chunk) steps per phase
-  static constexpr int FRAGS = 2 * STEPS * 3;                           // weight fragments per n-tile and conv
-  static_assert(12 * PS <= VSLAB_FLOATS * 4, "the phase slab must fit the V slab's space");
+  static constexpr int STEPS = 4 * KC;                                  // (chunk, slot) steps per phase: step = 4 chunk + slot
+  static constexpr int FRAGS = 2 * STEPS * 2;                           // weight fragments per n-tile and conv
+  static_assert(8 * PS <= VSLAB_FLOATS * 4, "the phase slab must fit the V slab's space");
   // channel block of (chunk kc, lane group j): pair index and position in the pair
   __host__ __device__ static constexpr int pair_of(int kc, int j) { return KC == 2 ? j : (j & 1); }
   __host__ __device__ static constexpr int half_of(int kc, int j) { return KC == 2 ? kc : (j >> 1); }
 };
 
 template <class GEO>
-__device__ __forceinline__ void vbd_load_b(u32x4 (&b)[3], const u32x4* w, int ph, int step) {
-  const u32x4* p = w + ((ph * GEO::STEPS + step) * 3) * 64;
+__device__ __forceinline__ void vbd_load_b(u32x4 (&b)[2], const u32x4* w, int ph, int step) {
+  const u32x4* p = w + ((ph * GEO::STEPS + step) * 2) * 64;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) b[q] = p[q * 64];
+  for (int q = 0; q < 2; ++q) b[q] = p[q * 64];
 }
 // va = slab + the lane's (pair, [position in the pair for one-chunk stages], first M tile's row lane & 15) offset
 template <class GEO>
-__device__ __forceinline__ void vbd_load_a(u32x4 (&a)[2][3], const char* va, int step) {   // step = KC * slot + chunk
+__device__ __forceinline__ void vbd_load_a(u32x4 (&a)[2][2], const char* va, int step) {   // step = 4 chunk + slot
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-      a[mt][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step / GEO::KC) * GEO::PS +
-                                                 (GEO::KC == 2 ? (step % GEO::KC) * GEO::X : 0) + mt * 256);
+    for (int q = 0; q < 2; ++q)
+      a[mt][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step % 4) * GEO::PS +
+                                                 (GEO::KC == 2 ? (step / 4) * GEO::X : 0) + mt * 256);
 }
 template <class GEO, int PH>
-__device__ __forceinline__ void vbd_ring_load(u32x4 (&b)[VB_RD][3], const u32x4* w) {
+__device__ __forceinline__ void vbd_ring_load(u32x4 (&b)[VB_RD][2], const u32x4* w) {
 #pragma unroll
   for (int i = 0; i < VB_RD; ++i) vbd_load_b<GEO>(b[i], w, PH, i);
   MMD_PIN_LOADS();
 }
-// m[M tile][position] of phase PH's four positions = conv over the slab's channels
+// m[M tile][position] of phase PH's four positions = conv over the slab's channels (the two M tiles of a step share the
+// weight fragment: two accumulator streams, one after the other)
 template <class GEO, int PH>
-__device__ __forceinline__ void vbd_taps(f32x4 (&m)[2][8], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][3]) {
-  u32x4 a[2][2][3];
+__device__ __forceinline__ void vbd_taps(f32x4 (&m)[2][8], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][2]) {
+  u32x4 a[2][2][2];
   vbd_load_a<GEO>(a[0], va, 0);
 #pragma unroll
   for (int i = 0; i < GEO::STEPS; ++i) {
     if (i + 1 < GEO::STEPS) vbd_load_a<GEO>(a[(i + 1) & 1], va, i + 1);
     MMD_PIN_LOADS();
-    const int pos = vb_pos(PH, i / GEO::KC);
-    if (i % GEO::KC == 0) vb_six<true>(m[0][pos], m[1][pos], a[i & 1][0], a[i & 1][1], b[i % VB_RD], b[i % VB_RD]);
-    else vb_six<false>(m[0][pos], m[1][pos], a[i & 1][0], a[i & 1][1], b[i % VB_RD], b[i % VB_RD]);
+    const int pos = vb_pos(PH, i % 4);
+    if (i / 4 == 0) {
+      vb_three<true>(m[0][pos], a[i & 1][0], b[i % VB_RD]);
+      vb_three<true>(m[1][pos], a[i & 1][1], b[i % VB_RD]);
+    } else {
+      vb_three<false>(m[0][pos], a[i & 1][0], b[i % VB_RD]);
+      vb_three<false>(m[1][pos], a[i & 1][1], b[i % VB_RD]);
+    }
     if (i + VB_RD < GEO::STEPS) vbd_load_b<GEO>(b[i % VB_RD], w, PH, i + VB_RD);
     MMD_PIN_LOADS();
   }
@@ -1101,15 +1128,10 @@ template <class GEO, int PH>
 __device__ __forceinline__ void vbd_store(char* base, const f32x4 (&P)[4], const float (&pp)[2], const float (&pn)[2],
                                           const f32x4 (&Q)[4], const float (&qp)[2], const float (&qn)[2], unsigned sel) {
   constexpr int PS = GEO::PS;
-  auto put2 = [&](char* p, int slot, float v0, float v1) {   // the three pieces of the pair at slot `slot`
-    const unsigned a0 = __float_as_uint(v0), b0 = __float_as_uint(v1);
-    const float ra = v0 - __uint_as_float(a0 & 0xffff0000u), rb = v1 - __uint_as_float(b0 & 0xffff0000u);
-    const unsigned a1 = __float_as_uint(ra), b1 = __float_as_uint(rb);
-    const unsigned a2 = __float_as_uint(ra - __uint_as_float(a1 & 0xffff0000u));
-    const unsigned b2 = __float_as_uint(rb - __uint_as_float(b1 & 0xffff0000u));
-    *reinterpret_cast<unsigned*>(p + slot * PS) = __builtin_amdgcn_perm(b0, a0, sel);
-    *reinterpret_cast<unsigned*>(p + (4 + slot) * PS) = __builtin_amdgcn_perm(b1, a1, sel);
-    *reinterpret_cast<unsigned*>(p + (8 + slot) * PS) = __builtin_amdgcn_perm(b2, a2, sel);
+  auto put2 = [&](char* p, int slot, float v0, float v1) {   // the two pieces of the pair at slot `slot`
+    const F16Pair f = f16_split2(v0, v1);
+    *reinterpret_cast<unsigned*>(p + slot * PS) = __builtin_amdgcn_perm(f.hi, f.hi, sel);
+    *reinterpret_cast<unsigned*>(p + (4 + slot) * PS) = __builtin_amdgcn_perm(f.lo, f.lo, sel);
   };
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1174,10 +1196,10 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
                            (16 * mt0 + (lane & 15)) * 16;
   const int odd = lane & 1, gs = jg % QB;                    // pair position; the lane group's place in its sample
   char* const vb_s = vb + nq * GEO::G + ((lane & 15) >> 3) * GEO::X + (16 * (mt0 + odd) + 4 * jg) * 16 + ((lane & 7) >> 1) * 4;
-  const unsigned sel = odd ? 0x03020706u : 0x07060302u;
+  const unsigned sel = odd ? 0x01000302u : 0x03020100u;     // odd lanes hold (Q, P) = (high, low): swap the halves
   auto conv_hb = [&](const uint4* w) {
     const u32x4* wp = reinterpret_cast<const u32x4*>(w) + (size_t)nq * GEO::FRAGS * 64 + lane;
-    u32x4 ring_b[VB_RD][3];
+    u32x4 ring_b[VB_RD][2];
     vbd_ring_load<GEO, 0>(ring_b, wp);
     // pair exchange: P = the lane's own channel in ITS M tile (even lane: the first, odd: the second), Q = the partner's
     f32x4 P[4], Q[4];
@@ -1212,16 +1234,19 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) w4n1_out(acc[mt], mb[mt]);
   };
-  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
+  // GroupNorm + Mish of acc, then + the time bias (conv A) or + the residual tile (conv B, tb == nullptr); isc: the conv's
+  // inverse f16x2 weight scales (SCALED), unused for the fp32 conv A of the first RTB
+  auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc) {
+    constexpr bool SCALED = decltype(scaled)::value;
     if (MMD_ABL == 1) return;
-    const float bb = b[col], gg = g[col], ee = be[col];
+    const float bb = b[col], gg = g[col], ee = be[col], is = SCALED ? isc[col] : 1.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       if (tb) {
         const float t0 = tb[col];
-        gn_mish_quad1<CF::CM, CF::L>(acc[mt], bb, gg, ee, [&](int, int) { return t0; });
+        gn_mish_quad1<CF::CM, CF::L, SCALED>(acc[mt], bb, gg, ee, [&](int, int) { return t0; }, is);
       } else {
-        gn_mish_quad1<CF::CM, CF::L>(acc[mt], bb, gg, ee, [&](int o, int r) { return res[mt][o][r]; });
+        gn_mish_quad1<CF::CM, CF::L, SCALED>(acc[mt], bb, gg, ee, [&](int o, int r) { return res[mt][o][r]; }, is);
       }
     }
   };
@@ -1239,10 +1264,10 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
       w4n1_out(acc[mt], m);
     }
   }
-  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
+  gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr);
   __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
   conv_hb(a.r0.wb_bf);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
+  gn(std::true_type{}, a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
   // =================== identity RTB ===================
   {
     const RtbPtrs& R = a.ri[0];
@@ -1252,10 +1277,10 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
       for (int i = 0; i < 4; ++i) res[mt][i] = acc[mt][i];
     __syncthreads();                                         // the previous conv is done reading the slab
     conv_hb(R.wa_bf);
-    gn(R.ba, R.ga, R.bea, R.tb);
+    gn(std::true_type{}, R.ba, R.ga, R.bea, R.tb, R.isa);
     __syncthreads();
     conv_hb(R.wb_bf);
-    gn(R.bb, R.gb, R.beb, nullptr);
+    gn(std::true_type{}, R.bb, R.gb, R.beb, nullptr, R.isb);
     if constexpr (CF::MID_AFTER == 1) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -1288,15 +1313,19 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
 // distinct banks per wave) instead of two ds_write_b16 into shared dwords.  A GroupNorm group (16 channels) is 8 adjacent
 // lanes x both tiles.
 // ----------------------------------------------------------------------------------------------------------------
-template <class ADD0, class ADD1>
+template <bool SCALED, class ADD0, class ADD1>
 __device__ __forceinline__ void gn_mish_pair16(f32x4 (&q0)[4], f32x4 (&q1)[4], const float (&bias)[2], const float (&gamma)[2],
-                                               const float (&beta)[2], ADD0 add0, ADD1 add1) {
+                                               const float (&beta)[2], const float (&isc)[2], ADD0 add0, ADD1 add1) {
   constexpr float inv_n = 1.f / 256.f;                       // 16 channels x 16 positions
-  float sum = 0.f;
+  float sum0 = 0.f, sum1 = 0.f;
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sum += q0[o][r] + q1[o][r];
+    for (int r = 0; r < 4; ++r) {
+      sum0 += q0[o][r];
+      sum1 += q1[o][r];
+    }
+  const float sum = SCALED ? fmaf(sum0, isc[0], sum1 * isc[1]) : sum0 + sum1;
   const float mean = (group_colsum<8>(sum) + group_colsum<8>(bias[0] + bias[1]) * 16.f) * inv_n;
   const float dm0 = mean - bias[0], dm1 = mean - bias[1];
   float sq = 0.f;
@@ -1304,12 +1333,14 @@ __device__ __forceinline__ void gn_mish_pair16(f32x4 (&q0)[4], f32x4 (&q1)[4], c
   for (int o = 0; o < 4; ++o)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float d0 = q0[o][r] - dm0, d1 = q1[o][r] - dm1;
+      const float d0 = SCALED ? fmaf(q0[o][r], isc[0], -dm0) : q0[o][r] - dm0;
+      const float d1 = SCALED ? fmaf(q1[o][r], isc[1], -dm1) : q1[o][r] - dm1;
       sq = fmaf(d0, d0, sq);
       sq = fmaf(d1, d1, sq);
     }
   const float rstd = rsqrtf(group_colsum<8>(sq) * inv_n + 1e-5f);
-  const GnCoef cf0 = gn_coef(dm0, rstd, gamma[0], beta[0]), cf1 = gn_coef(dm1, rstd, gamma[1], beta[1]);
+  GnCoef cf0 = gn_coef(dm0, rstd, gamma[0], beta[0]), cf1 = gn_coef(dm1, rstd, gamma[1], beta[1]);
+  if constexpr (SCALED) { cf0.sa *= isc[0]; cf1.sa *= isc[1]; }
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -1347,7 +1378,7 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
 #pragma unroll
     for (int h = 0; h < 2; ++h) wp[h] = reinterpret_cast<const u32x4*>(w) + (size_t)(2 * wave + h) * VB_FRAGS * 64 + lane;
     f32x4 mb[2][8];
-    u32x4 ring_b[VB_RD][2][3];
+    u32x4 ring_b[VB_RD][2][2];
     TR(trb + 10);
     vb_ring_load<0>(ring_b, wp);
     vb_store_pair<0>(vb_s, [&](int o, int r) { return acc[0][o][r]; }, [&](int o, int r) { return acc[1][o][r]; });
@@ -1369,15 +1400,18 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
     for (int h = 0; h < 2; ++h) w4n1_out(acc[h], mb[h]);
   };
   // GroupNorm + Mish of acc, then + the time bias (conv A) or + the residual tile (conv B, tb == nullptr)
-  auto gn = [&](const float* b, const float* g, const float* be, const float* tb) {
+  // (isc: the conv's inverse f16x2 weight scales; unused (SCALED = false) for the fp32 conv A of the first RTB)
+  auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc) {
+    constexpr bool SCALED = decltype(scaled)::value;
     const float bb[2] = {b[c0], b[c0 + 1]}, gg[2] = {g[c0], g[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
+    const float is[2] = {SCALED ? isc[c0] : 1.f, SCALED ? isc[c0 + 1] : 1.f};
     if (MMD_ABL == 1) return;
     if (tb) {
       const float t0 = tb[c0], t1 = tb[c0 + 1];
-      gn_mish_pair16(acc[0], acc[1], bb, gg, ee, [&](int, int) { return t0; }, [&](int, int) { return t1; });
+      gn_mish_pair16<SCALED>(acc[0], acc[1], bb, gg, ee, is, [&](int, int) { return t0; }, [&](int, int) { return t1; });
     } else {
-      gn_mish_pair16(acc[0], acc[1], bb, gg, ee, [&](int o, int r) { return res[0][o][r]; },
-                     [&](int o, int r) { return res[1][o][r]; });
+      gn_mish_pair16<SCALED>(acc[0], acc[1], bb, gg, ee, is, [&](int o, int r) { return res[0][o][r]; },
+                             [&](int o, int r) { return res[1][o][r]; });
     }
   };
 
@@ -1394,11 +1428,11 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
       w4n1_out(acc[h], m);
     }
   }
-  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb);
+  gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr);
   TR(trb + 1);
   __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
   conv_hb(a.r0.wb_bf);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr);
+  gn(std::true_type{}, a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
 
   // =================== identity RTBs (a real loop: one copy of the two conv bodies instead of three) ===================
 #pragma unroll 1
@@ -1410,10 +1444,10 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
       for (int i = 0; i < 4; ++i) res[h][i] = acc[h][i];
     __syncthreads();                                         // the previous conv is done reading the slab
     conv_hb(R.wa_bf);
-    gn(R.ba, R.ga, R.bea, R.tb);
+    gn(std::true_type{}, R.ba, R.ga, R.bea, R.tb, R.isa);
     __syncthreads();
     conv_hb(R.wb_bf);
-    gn(R.bb, R.gb, R.beb, nullptr);
+    gn(std::true_type{}, R.bb, R.gb, R.beb, nullptr, R.isb);
     TR(trb + 18);
     if (CF::MID_AFTER == k + 1) {
 #pragma unroll
@@ -1753,150 +1787,152 @@ static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_
         }
 }
 
-// bf16x3 pack of a 128 -> 128 k5 conv for vb_taps: per n-tile [phase][slot][chunk kc][piece q][lane] x 16 B, lane = (column
-// lane & 15 of the tile, channels 8 (4 (lane >> 4) + kc) + j, j = 0..7 at bf16 index j); U = G g as in pack_w4, split by
-// truncation into three bf16 pieces (exact).  Returns the pack's offset in the blob (in floats; 16-byte aligned).
-static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int cin) {
-  static const double G[8][5] = {{-1, 0, 0, 0, 0},
-                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
-                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
-                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
-                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
-                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
-                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
-                                 {0, 0, 0, 0, 1}};
+// ---- f16x2 packs: U = G g in fp64 -> float, scaled per output channel by a power of two, split into two fp16 pieces ----
+static const double kG45[8][5] = {{-1, 0, 0, 0, 0},
+                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                  {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                  {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                  {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                  {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                  {0, 0, 0, 0, 1}};
+static inline float wino_u(const float* w, int cin_full, int n, int ci, int pos) {   // conv weight layout [cout][cin_full][5]
+  const float* g = w + ((size_t)n * cin_full + ci) * 5;
+  double u = 0.0;
+  for (int k = 0; k < 5; ++k) u += kG45[pos][k] * (double)g[k];
+  return (float)u;
+}
+// power of two that puts m into [2^14, 2^15) (fp16's largest binade but one); 1 for m = 0 or non-finite
+static inline float f16_scale_for(float m) {
+  if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+  int ex;
+  (void)frexpf(m, &ex);                    // m = f * 2^ex, f in [0.5, 1)
+  return ldexpf(1.f, 15 - ex);
+}
+// per-output-channel scales of a k5 conv over all 8 Winograd positions and ALL its input channels (the chunks of a channel
+// concat accumulate into the same tile, so they share the scale)
+static std::vector<float> f16_col_scales(const float* w, int cout, int cin_full) {
+  std::vector<float> sc(cout);
+  for (int n = 0; n < cout; ++n) {
+    float m = 0.f;
+    for (int ci = 0; ci < cin_full; ++ci)
+      for (int pos = 0; pos < 8; ++pos) m = fmaxf(m, fabsf(wino_u(w, cin_full, n, ci, pos)));
+    sc[n] = f16_scale_for(m);
+  }
+  return sc;
+}
+// u * scale -> hi = RN16, lo = RN16(u * scale - hi) (the device-side split of f16_split2)
+static inline void f16_split_host(float u, float scale, uint16_t (&piece)[2]) {
+  const float us = u * scale;              // exact (power of two), |us| < 2^15
+  const _Float16 h = (_Float16)us;
+  const _Float16 l = (_Float16)(us - (float)h);
+  memcpy(&piece[0], &h, 2);
+  memcpy(&piece[1], &l, 2);
+}
+static size_t push_inverse(std::vector<float>& blob, const std::vector<float>& sc) {
   while (blob.size() % 4) blob.push_back(0.f);
+  const size_t off = blob.size();
+  for (float v : sc) blob.push_back(1.f / v);
+  while (blob.size() % 4) blob.push_back(0.f);
+  return off;
+}
+
+// f16x2 pack of a 128 -> 128 k5 conv for vb_taps: per n-tile [phase][step = 4 chunk kc + slot][piece q][lane] x 16 B, lane =
+// (column lane & 15 of the tile, channels 8 (4 (lane >> 4) + kc) + j, j = 0..7 at fp16 index j).  Returns the pack's offset
+// in the blob (in floats; 16-byte aligned); isc_off = offset of the [cout] inverse channel scales.
+static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off) {
+  const std::vector<float> sc = f16_col_scales(w, cout, cin);
+  isc_off = push_inverse(blob, sc);
   const size_t base = blob.size();
   const int tiles = cout / 16, KC = cin / 32;
-  const size_t frags = (size_t)tiles * 2 * 4 * KC * 3;
+  const size_t frags = (size_t)tiles * 2 * 4 * KC * 2;
   blob.resize(base + (frags + 8) * 64 * 4, 0.f);             // + slack for the ring's over-read past the last tile
   uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
   for (int t = 0; t < tiles; ++t)
     for (int ph = 0; ph < 2; ++ph)
-      for (int sl = 0; sl < 4; ++sl)
-        for (int kc = 0; kc < KC; ++kc)
+      for (int kc = 0; kc < KC; ++kc)
+        for (int sl = 0; sl < 4; ++sl)
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
               const int n = (t / 2) * 32 + 2 * (lane & 15) + (t & 1);   // interleaved tile pair of a wave (chain_body_d2)
-              const int ci = 8 * (4 * (lane >> 4) + kc) + j, pos = vb_pos(ph, sl);   // chunk kc = channel blocks kc + 4 g
-              const float* g = w + ((size_t)n * cin + ci) * 5;
-              double ud = 0.0;
-              for (int k = 0; k < 5; ++k) ud += G[pos][k] * (double)g[k];
-              const float u = (float)ud;
-              uint32_t b0, b1, b2;
-              memcpy(&b0, &u, 4);
-              uint32_t h0 = b0 & 0xffff0000u; float f0; memcpy(&f0, &h0, 4);
-              const float r1 = u - f0; memcpy(&b1, &r1, 4);
-              uint32_t h1 = b1 & 0xffff0000u; float f1; memcpy(&f1, &h1, 4);
-              const float r2 = r1 - f1; memcpy(&b2, &r2, 4);
-              const uint32_t piece[3] = {b0 >> 16, b1 >> 16, b2 >> 16};
-              for (int q = 0; q < 3; ++q) {
-                const size_t frag = ((((size_t)t * 2 + ph) * 4 + sl) * KC + kc) * 3 + q;
-                out[(frag * 64 + lane) * 8 + j] = (uint16_t)piece[q];
+              const int ci = 8 * (4 * (lane >> 4) + kc) + j;            // chunk kc = channel blocks kc + 4 g
+              uint16_t piece[2];
+              f16_split_host(wino_u(w, cin, n, ci, vb_pos(ph, sl)), sc[n], piece);
+              for (int q = 0; q < 2; ++q) {
+                const size_t frag = ((((size_t)t * 2 + ph) * KC + kc) * 4 + sl) * 2 + q;
+                out[(frag * 64 + lane) * 8 + j] = piece[q];
               }
             }
   return base;
 }
 
-// bf16x3 pack of a C -> C k5 conv of downs.0 / downs.1 for vbd_taps: per n-tile [phase][slot][chunk kc][piece q][lane] x 16 B;
-// lane = (column n = 16 tile + (lane & 15), the 8 channels of the block DbGeo assigns to (kc, lane >> 4), j at bf16 index j).
-static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin) {
-  static const double G[8][5] = {{-1, 0, 0, 0, 0},
-                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
-                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
-                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
-                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
-                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
-                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
-                                 {0, 0, 0, 0, 1}};
-  while (blob.size() % 4) blob.push_back(0.f);
+// f16x2 pack of a C -> C k5 conv of downs.0 / downs.1 for vbd_taps: per n-tile [phase][step = 4 chunk kc + slot][piece q][lane]
+// x 16 B; lane = (column n = 16 tile + (lane & 15), the 8 channels of the block DbGeo assigns to (kc, lane >> 4), j at fp16
+// index j).
+static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off) {
+  const std::vector<float> sc = f16_col_scales(w, cout, cin);
+  isc_off = push_inverse(blob, sc);
   const size_t base = blob.size();
   const int tiles = cout / 16, KC = cin / 32;
-  const size_t frags = (size_t)tiles * 2 * 4 * KC * 3;
+  const size_t frags = (size_t)tiles * 2 * 4 * KC * 2;
   blob.resize(base + (frags + 8) * 64 * 4, 0.f);             // + slack for the ring's over-read past the last tile
   uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
   for (int t = 0; t < tiles; ++t)
     for (int ph = 0; ph < 2; ++ph)
-      for (int sl = 0; sl < 4; ++sl)
-        for (int kc = 0; kc < KC; ++kc)
+      for (int kc = 0; kc < KC; ++kc)
+        for (int sl = 0; sl < 4; ++sl)
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
               // channel block of (chunk kc, lane group g): 2 * pair + half (DbGeo::pair_of / half_of)
               const int jg = lane >> 4, blk = KC == 2 ? 2 * jg + kc : 2 * (jg & 1) + (jg >> 1);
-              const int n = 16 * t + (lane & 15), ci = 8 * blk + j, pos = vb_pos(ph, sl);
-              const float* g = w + ((size_t)n * cin + ci) * 5;
-              double ud = 0.0;
-              for (int k = 0; k < 5; ++k) ud += G[pos][k] * (double)g[k];
-              const float u = (float)ud;
-              uint32_t b0, b1, b2;
-              memcpy(&b0, &u, 4);
-              uint32_t h0 = b0 & 0xffff0000u; float f0; memcpy(&f0, &h0, 4);
-              const float r1 = u - f0; memcpy(&b1, &r1, 4);
-              uint32_t h1 = b1 & 0xffff0000u; float f1; memcpy(&f1, &h1, 4);
-              const float r2 = r1 - f1; memcpy(&b2, &r2, 4);
-              const uint32_t piece[3] = {b0 >> 16, b1 >> 16, b2 >> 16};
-              for (int q = 0; q < 3; ++q) {
-                const size_t frag = ((((size_t)t * 2 + ph) * 4 + sl) * KC + kc) * 3 + q;
-                out[(frag * 64 + lane) * 8 + j] = (uint16_t)piece[q];
+              const int n = 16 * t + (lane & 15), ci = 8 * blk + j;
+              uint16_t piece[2];
+              f16_split_host(wino_u(w, cin, n, ci, vb_pos(ph, sl)), sc[n], piece);
+              for (int q = 0; q < 2; ++q) {
+                const size_t frag = ((((size_t)t * 2 + ph) * KC + kc) * 4 + sl) * 2 + q;
+                out[(frag * 64 + lane) * 8 + j] = piece[q];
               }
             }
   return base;
 }
 
-// bf16x3 pack of one 128-channel chunk [c_lo, c_lo + 128) of ups.0's conv A (k5, cout 64, with the 1x1 residual conv wres
-// in the Winograd domain) for vbu_taps: per n-tile [phase][slot pair][chunk kc][9 fragments][lane] x 16 B; fragments 0..2 /
-// 3..5 = the pieces of the pair's two slots, 6..8 = the pieces of wres * G[p][2] for the pair's residual position(s)
-// (-2/9 in phase 0, 2/45 and 8/45 for the pairs of phase 1).  Columns are plain (n = 16 tile + (lane & 15)).
-static size_t pack_vbu(std::vector<float>& blob, const float* w, const float* wres, int cout, int cin_full, int c_lo) {
-  static const double G[8][5] = {{-1, 0, 0, 0, 0},
-                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
-                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
-                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
-                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
-                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
-                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
-                                 {0, 0, 0, 0, 1}};
+// f16x2 pack of one 128-channel chunk [c_lo, c_lo + 128) of ups.0's conv A (k5, cout 64, with the 1x1 residual conv wres
+// in the Winograd domain) for vbu_taps: per n-tile [phase][step = 2 chunk kc + slot pair][6 fragments][lane] x 16 B; fragments
+// 0..1 / 2..3 = the pieces of the pair's two slots, 4..5 = the pieces of wres * G[p][2] for the pair's residual position(s)
+// (-2/9 in phase 0, 2/45 and 8/45 for the pairs of phase 1).  Columns are plain (n = 16 tile + (lane & 15)).  sc / scr = the
+// channel scales of the conv / of the residual weights (shared by both chunks).
+static size_t pack_vbu(std::vector<float>& blob, const float* w, const float* wres, int cout, int cin_full, int c_lo,
+                       const std::vector<float>& sc, const std::vector<float>& scr) {
   while (blob.size() % 4) blob.push_back(0.f);
   const size_t base = blob.size();
   const int tiles = cout / 16;
-  const size_t frags = (size_t)tiles * 2 * 2 * 4 * 9;
+  const size_t frags = (size_t)tiles * 2 * 2 * 4 * 6;
   blob.resize(base + (frags + 16) * 64 * 4, 0.f);            // + slack for the ring's over-read past the last tile
   uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
   for (int t = 0; t < tiles; ++t)
     for (int ph = 0; ph < 2; ++ph)
-      for (int pair = 0; pair < 2; ++pair)
-        for (int kc = 0; kc < 4; ++kc)
+      for (int kc = 0; kc < 4; ++kc)
+        for (int pair = 0; pair < 2; ++pair)
           for (int grp = 0; grp < 3; ++grp)
             for (int lane = 0; lane < 64; ++lane)
               for (int j = 0; j < 8; ++j) {
                 const int n = 16 * t + (lane & 15), ci = c_lo + 8 * (4 * (lane >> 4) + kc) + j;
-                double ud;
-                if (grp < 2) {
-                  const int pos = vb_pos(ph, 2 * pair + grp);
-                  const float* g = w + ((size_t)n * cin_full + ci) * 5;
-                  ud = 0.0;
-                  for (int k = 0; k < 5; ++k) ud += G[pos][k] * (double)g[k];
-                } else {
-                  ud = (double)wres[(size_t)n * cin_full + ci] * G[ph == 0 ? 1 : (pair == 0 ? 3 : 5)][2];
-                }
-                const float u = (float)ud;
-                uint32_t b0, b1, b2;
-                memcpy(&b0, &u, 4);
-                uint32_t h0 = b0 & 0xffff0000u; float f0; memcpy(&f0, &h0, 4);
-                const float r1 = u - f0; memcpy(&b1, &r1, 4);
-                uint32_t h1 = b1 & 0xffff0000u; float f1; memcpy(&f1, &h1, 4);
-                const float r2 = r1 - f1; memcpy(&b2, &r2, 4);
-                const uint32_t piece[3] = {b0 >> 16, b1 >> 16, b2 >> 16};
-                for (int q = 0; q < 3; ++q) {
-                  const size_t frag = (((((size_t)t * 2 + ph) * 2 + pair) * 4 + kc) * 9) + grp * 3 + q;
-                  out[(frag * 64 + lane) * 8 + j] = (uint16_t)piece[q];
+                uint16_t piece[2];
+                if (grp < 2)
+                  f16_split_host(wino_u(w, cin_full, n, ci, vb_pos(ph, 2 * pair + grp)), sc[n], piece);
+                else
+                  f16_split_host((float)((double)wres[(size_t)n * cin_full + ci] * kG45[ph == 0 ? 1 : (pair == 0 ? 3 : 5)][2]),
+                                 scr[n], piece);
+                for (int q = 0; q < 2; ++q) {
+                  const size_t frag = (((((size_t)t * 2 + ph) * 4 + kc) * 2 + pair) * 6) + grp * 2 + q;
+                  out[(frag * 64 + lane) * 8 + j] = piece[q];
                 }
               }
   return base;
 }
 
-struct ConvW { size_t wpk, bias, gamma, beta, wbf; };
-struct RtbW { ConvW a, b; size_t res_bias; int tb_off; size_t a_c1, a_c1_bf; };
+struct ConvW { size_t wpk, bias, gamma, beta, wbf, isc; };   // wbf / isc: f16x2 pack and its inverse channel scales
+struct RtbW { ConvW a, b; size_t res_bias, res_isc; int tb_off; size_t a_c1, a_c1_bf; };
 
 }  // namespace mmd
 
@@ -1938,6 +1974,8 @@ static RtbPtrs rtb_ptrs(const mmd_unet_s* u, const RtbW& w, int t) {
   p.bb = u->blob + w.b.bias; p.gb = u->blob + w.b.gamma; p.beb = u->blob + w.b.beta;
   p.wa_bf = w.a.wbf ? reinterpret_cast<const uint4*>(u->blob + w.a.wbf) : nullptr;
   p.wb_bf = w.b.wbf ? reinterpret_cast<const uint4*>(u->blob + w.b.wbf) : nullptr;
+  p.isa = w.a.wbf ? u->blob + w.a.isc : nullptr;
+  p.isb = w.b.wbf ? u->blob + w.b.isc : nullptr;
   return p;
 }
 
@@ -1951,6 +1989,7 @@ static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb
   a.wa0_c1 = reinterpret_cast<const float4*>(u->blob + w0.a_c1);
   a.wa0_c1_bf = w0.a_c1_bf ? reinterpret_cast<const uint4*>(u->blob + w0.a_c1_bf) : nullptr;
   a.br = u->blob + w0.res_bias;
+  a.isr = w0.res_isc ? u->blob + w0.res_isc : nullptr;
   for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, set[rtb[1 + k]], t);
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
   return a;
@@ -2010,8 +2049,17 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const int cinp = (R.cin + 7) / 8 * 8;            // the 4-channel network input is padded to 2 k-steps (the ring depth)
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
     if (r == 6) {             // ups.0 conv A: the two chunks of cat(x, skip2)
-      W.a.wbf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, 0);
-      W.a_c1_bf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, R.cin / 2);
+      const std::vector<float> sc = f16_col_scales(tensors[R.t_w0], R.cout, R.cin);
+      std::vector<float> scr(R.cout);
+      for (int n = 0; n < R.cout; ++n) {
+        float m = 0.f;
+        for (int ci = 0; ci < R.cin; ++ci) m = fmaxf(m, fabsf((float)((double)wres[(size_t)n * R.cin + ci] * (2.0 / 9))));
+        scr[n] = f16_scale_for(m);
+      }
+      W.a.isc = push_inverse(blob, sc);
+      W.res_isc = push_inverse(blob, scr);
+      W.a.wbf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, 0, sc, scr);
+      W.a_c1_bf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, R.cin / 2, sc, scr);
     } else if (r == 8) {      // ups.1: input = cat(x, skip1), staged chunk by chunk: one pack per chunk
       const int half = R.cin / 2;
       W.a.wpk = blob.size();
@@ -2019,7 +2067,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       W.a_c1 = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
     } else if ((d1 || d2) && R.cin == R.cout) {
-      W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin);
+      W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc);
     } else {
       W.a.wpk = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres, /*pair_cols=*/d2);
@@ -2028,7 +2076,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
     if (d1 || d2) {
-      W.b.wbf = d1 ? pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout) : pack_vb(blob, tensors[R.t_w1], R.cout, R.cout);
+      W.b.wbf = d1 ? pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc) : pack_vb(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc);
     } else {
       while (blob.size() % 4) blob.push_back(0.f);
       W.b.wpk = blob.size();
@@ -2172,7 +2220,7 @@ int mmd_debug_set_trace(void* dev_ptr) {
 
 double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
 double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }
-double mmd_unet_bf16x3_flops_per_trajectory(void) {
+double mmd_unet_f16x2_flops_per_trajectory(void) {
   return 4 * 3 * wino4_flops(32, 32) + 2 * 3 * wino4_flops(64, 64) + 7 * wino4_flops(128, 128) + wino4_flops(256, 64) * 14.0 / 8.0;
 }
 
