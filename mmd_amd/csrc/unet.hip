@@ -63,14 +63,50 @@ __device__ __forceinline__ GnCoef gn_coef(float mean, float rstd, float gamma, f
   c.sb = fmaf(-mean, s, beta) * LOG2E;
   return c;
 }
-__device__ __forceinline__ float gn_mish1(float x, const GnCoef& c, float addend) {
+// ActScale: the activations this epilogue produces are carried times a power of two `s` (the static f16x2 input scale of the
+// conv that consumes them, chosen on the host from the GroupNorm affine / time-bias bounds): mish(y) * s = yl * (n / ((n + 2)
+// log2 e / s)) -- the scale rides in the denominator's two constants, which become registers (l2e = log2 e / s, l2e2 = 2 l2e);
+// the addend arrives already scaled.  ACT = false: the literal constants (s = 1).
+struct ActScale { float l2e, l2e2; };
+__device__ __forceinline__ ActScale act_scale(float s) {
+  constexpr float LOG2E = 1.44269504088896341f;
+  const float inv = __builtin_amdgcn_rcpf(s);            // exact: s is a power of two
+  return ActScale{LOG2E * inv, 2.f * LOG2E * inv};
+}
+template <bool ACT = false>
+__device__ __forceinline__ float gn_mish1(float x, const GnCoef& c, float addend, const ActScale& as = ActScale{}) {
   constexpr float LOG2E = 1.44269504088896341f;
   const float yl = fmaf(x, c.sa, c.sb);
   const float e = __builtin_amdgcn_exp2f(fminf(yl, 20.f * LOG2E));
   const float n = e * (e + 2.f);
-  const float q = n * __builtin_amdgcn_rcpf(fmaf(n, LOG2E, 2.f * LOG2E));
+  const float q = n * __builtin_amdgcn_rcpf(ACT ? fmaf(n, as.l2e, as.l2e2) : fmaf(n, LOG2E, 2.f * LOG2E));
   return fmaf(yl, q, addend);
 }
+
+// Dynamic f16x2 input scale of a conv whose input is NOT bounded by a GroupNorm (the input of a ResidualTemporalBlock: the
+// residual stream, which follows the magnitude of the network input): per sample, from the exact maximum M of the conv's
+// input tile, s = 2^(10 - floor(log2 M)), so that every Winograd-transformed value |V| <= 15 M s < 30720 fits fp16 whatever
+// the input's magnitude, and the values that matter (within 2^-13 of the maximum) keep both pieces normal.  inv = 1 / s.
+struct DynScale { float s, inv; };
+__device__ __forceinline__ DynScale dyn_scale(float M) {
+  unsigned eb = (__float_as_uint(M) >> 23) & 0xffu;        // M >= 0: biased exponent (inf / NaN: 255 -> NaN out, as in fp32)
+  eb = eb < 64u ? 64u : eb;                                  // M < 2^-63 (all zero): s = 2^73
+  return DynScale{__uint_as_float((264u - eb) << 23), __uint_as_float((eb - 10u) << 23)};
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)));
+}
+__device__ __forceinline__ float row_max16(float v) {      // max over the 16 lanes of a DPP row, in all of them (v >= 0)
+  v = dpp_max<0xB1>(v);
+  v = dpp_max<0x4E>(v);
+  v = dpp_max<0x141>(v);
+  v = dpp_max<0x140>(v);
+  return v;
+}
+constexpr int MX_SLOTS = 8;                                  // partial maxima per sample (waves x lane groups sharing a sample)
+constexpr int MX_REGION = 4 * MX_SLOTS;                      // region 0: the conv being prepared; 1 / 2: downs.2's skip2 / the
+constexpr int MX_FLOATS = 3 * MX_REGION;                     // mid blocks' output, kept for ups.0's conv A
 
 // Stage SPB samples' [LIN, C] rows (channels-last, optionally a concat of two tensors) into an LDS slab
 // [SPB][ROWS][STR] at row offset ROFF; samples >= n are zero filled.
@@ -222,7 +258,8 @@ struct RtbPtrs {
   const float4* wa; const float* ba; const float* ga; const float* bea; const float* tb;
   const float4* wb; const float* bb; const float* gb; const float* beb;
   const uint4* wa_bf; const uint4* wb_bf;   // f16x2 packs of the same convs (C -> C convs of the down stages + mid, ups.0 conv A)
-  const float* isa; const float* isb;       // [C_out] inverse per-channel weight scales of the f16x2 packs
+  const float* isa; const float* isb;       // [C_out] inverse per-channel weight scales of the f16x2 packs (isb: / act_a)
+  float act_a;                              // static power-of-two scale of conv A's output activations = conv B's f16x2 input
 };
 
 struct ChainArgs {
@@ -506,6 +543,21 @@ __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[
 constexpr int VROW = 8;                    // floats per (channel, row)
 constexpr int VCS = 16 * VROW + 4;         // channel stride in floats
 constexpr int VSLAB_FLOATS = 128 * VCS;    // the largest V slab: 128 channels (67.6 KB)
+
+//                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
+using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
+using CH_D1 = ChainCfg<32, 0, 64, 32, 2, RES_CONV, 1, 1, TAIL_DOWN>;     // downs.1 (skip1 = output of its 2nd RTB)
+using CH_D2 = ChainCfg<64, 0, 128, 16, 2, RES_CONV, 3, 1, TAIL_NONE>;    // downs.2 + mid_block1/2 (skip2 after downs.2)
+using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.0: cat(x, skip2) RTB, RTB, Upsample1d
+using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
+constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// The L = 16 stages (downs.2 + mid, ups.0) work on V-form slabs of up to 128 channels that alias their row-form slabs.
+constexpr int MX_OFF =
+    cmax(cmax(cmax(CH_D0::LDS_FLOATS, CH_D1::LDS_FLOATS), cmax(CH_D2::XSLAB, CH_U0::HSLAB)),
+         cmax(cmax(CH_U1::LDS_FLOATS, 4 * FIN_SS), VSLAB_FLOATS + 4 * VCS)) + 8;   // + slack: the A double buffers read one k-step past the end
+constexpr int UNET_LDS_FLOATS = MX_OFF + MX_FLOATS;          // + the per-sample maxima of the dynamic input scales
 
 // x(o, r) = position 4 r + o of the lane's (sample, channel); vb = slab + channel * VCS + 4 * sample * VROW
 template <class GET>
@@ -815,8 +867,9 @@ __device__ __forceinline__ void w4n1_out(f32x4 (&q)[4], const f32x4 (&m)[8]) {
 }
 // isc (SCALED): the conv ran as f16x2 on weights scaled per output channel -- q is the true output times 1 / isc; the
 // factor is folded into the statistics and the affine coefficient (two more VALU ops per tile, none per element).
-template <int CM, int L, bool SCALED = false, class ADD>
-__device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float gamma, float beta, ADD add, float isc = 1.f) {
+template <int CM, int L, bool SCALED = false, bool ACT = false, class ADD>
+__device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float gamma, float beta, ADD add, float isc = 1.f,
+                                              const ActScale& as = ActScale{}) {
   constexpr int CPG = CM / 8, QB = L / 16;
   constexpr float inv_n = 1.f / (float)(L * CPG);
   float sum = 0.f;
@@ -839,7 +892,7 @@ __device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float g
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) q[o][r] = gn_mish1(q[o][r], cf, add(o, r));
+    for (int r = 0; r < 4; ++r) q[o][r] = gn_mish1<ACT>(q[o][r], cf, add(o, r), as);
 }
 // one-n-tile quad tile -> slab; producer tiling: wave = (M tile, 16-channel n-tile)
 template <int L, int CM, int DSS, int DSTR>
@@ -931,6 +984,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   };
 
   // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
+  float isc_a = 1.f;
   if constexpr (VH) {
     // f16x2 (vbu_taps): skip_write(chunk, phase) stores that phase of chunk 0 (x) / 1 (skip) into the phase slab
     f32x4 rm[6];
@@ -941,7 +995,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     vbu_ring_load<0>(ring_u, wp0);
-    skip_write(C0{}, C0{});
+    const float inv_dyn = skip_write(C0{}, C0{});            // (also applies the dynamic input scale to both chunks' tiles)
     __syncthreads();
     vbu_taps<0, true>(m, rm, vb_a, wp0, ring_u);
     vbu_ring_load<1>(ring_u, wp0);
@@ -959,7 +1013,8 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     skip_write(C1{}, C1{});
     __syncthreads();
     vbu_taps<1, false>(m, rm, vb_a, wp1, ring_u);
-    w4n1_res_out(res, rm, a.br[col], a.isr[col]);
+    w4n1_res_out(res, rm, a.br[col], a.isr[col] * inv_dyn);
+    isc_a = a.r0.isa[col] * inv_dyn;
   } else {
     {
       const float br = a.br[col];
@@ -979,7 +1034,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     const float tb = a.r0.tb[col];
     if constexpr (VH) {
       if (MMD_ABL != 1)
-        gn_mish_quad1<CF::CM, CF::L, true>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; }, a.r0.isa[col]);
+        gn_mish_quad1<CF::CM, CF::L, true>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; }, isc_a);
     } else {
       if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
     }
@@ -1234,22 +1289,51 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) w4n1_out(acc[mt], mb[mt]);
   };
-  // GroupNorm + Mish of acc, then + the time bias (conv A) or + the residual tile (conv B, tb == nullptr); isc: the conv's
-  // inverse f16x2 weight scales (SCALED), unused for the fp32 conv A of the first RTB
-  auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc) {
+  // GroupNorm + Mish of acc (chain_body_d2's gn, for one channel x two M tiles): conv A (tb != nullptr) + the time bias,
+  // output carried times act_s; conv B + the residual tile.  inv_dyn[mt]: inverse dynamic input scale of tile mt's sample.
+  auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc,
+                const float (&inv_dyn)[2], float act_s) {
     constexpr bool SCALED = decltype(scaled)::value;
     if (MMD_ABL == 1) return;
     const float bb = b[col], gg = g[col], ee = be[col], is = SCALED ? isc[col] : 1.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       if (tb) {
-        const float t0 = tb[col];
-        gn_mish_quad1<CF::CM, CF::L, SCALED>(acc[mt], bb, gg, ee, [&](int, int) { return t0; }, is);
+        const float t0 = tb[col] * act_s;
+        gn_mish_quad1<CF::CM, CF::L, SCALED, true>(acc[mt], bb, gg, ee, [&](int, int) { return t0; }, is * inv_dyn[mt], act_scale(act_s));
       } else {
-        gn_mish_quad1<CF::CM, CF::L, SCALED>(acc[mt], bb, gg, ee, [&](int o, int r) { return res[mt][o][r]; }, is);
+        gn_mish_quad1<CF::CM, CF::L, SCALED, false>(acc[mt], bb, gg, ee, [&](int o, int r) { return res[mt][o][r]; }, is * inv_dyn[mt]);
       }
     }
   };
+  // Dynamic input scale of an identity RTB's conv A: tile mt of the lane belongs to sample smp(mt); the sample's 2048 values
+  // are spread over MX_SLOTS = NTQ x QB (wave, lane group) pairs.
+  float* const mx = lds + MX_OFF;
+  static_assert(GEO::NTQ * QB == MX_SLOTS, "partial maxima per sample");
+  auto smp = [&](int mt) { return (mt0 + mt) * (64 / CF::L) + jg / QB; };
+  auto dyn_out = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float m = 0.f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(acc[mt][o][r]));
+      m = row_max16(m);
+      if ((lane & 15) == 0) mx[smp(mt) * MX_SLOTS + nq * QB + gs] = m;
+    }
+  };
+  auto dyn_in = [&](float (&inv)[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float4 p = *reinterpret_cast<const float4*>(mx + smp(mt) * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + smp(mt) * MX_SLOTS + 4);
+      const DynScale ds = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w))));
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[mt][o] *= ds.s;
+      inv[mt] = ds.inv;
+    }
+  };
+  const float one2[2] = {1.f, 1.f};
 
   // =================== RTB 0 (C0 -> CM): conv A + the 1x1 residual conv on the fp32 MFMA, row-form x slab ===================
   {
@@ -1264,10 +1348,12 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
       w4n1_out(acc[mt], m);
     }
   }
-  gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr);
+  gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr, one2, a.r0.act_a);
+  TR(trb + 1);
   __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
   conv_hb(a.r0.wb_bf);
-  gn(std::true_type{}, a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+  gn(std::true_type{}, a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one2, 1.f);
+  TR(trb + 2);
   // =================== identity RTB ===================
   {
     const RtbPtrs& R = a.ri[0];
@@ -1275,12 +1361,17 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) res[mt][i] = acc[mt][i];
+    dyn_out();
     __syncthreads();                                         // the previous conv is done reading the slab
+    float inv_dyn[2];
+    dyn_in(inv_dyn);
     conv_hb(R.wa_bf);
-    gn(std::true_type{}, R.ba, R.ga, R.bea, R.tb, R.isa);
+    gn(std::true_type{}, R.ba, R.ga, R.bea, R.tb, R.isa, inv_dyn, R.act_a);
+    TR(trb + 3);
     __syncthreads();
     conv_hb(R.wb_bf);
-    gn(std::true_type{}, R.bb, R.gb, R.beb, nullptr, R.isb);
+    gn(std::true_type{}, R.bb, R.gb, R.beb, nullptr, R.isb, one2, 1.f);
+    TR(trb + 4);
     if constexpr (CF::MID_AFTER == 1) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -1302,6 +1393,7 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
     int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
     mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
   }
+  TR(trb + 5);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1313,9 +1405,9 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
 // distinct banks per wave) instead of two ds_write_b16 into shared dwords.  A GroupNorm group (16 channels) is 8 adjacent
 // lanes x both tiles.
 // ----------------------------------------------------------------------------------------------------------------
-template <bool SCALED, class ADD0, class ADD1>
+template <bool SCALED, bool ACT, class ADD0, class ADD1>
 __device__ __forceinline__ void gn_mish_pair16(f32x4 (&q0)[4], f32x4 (&q1)[4], const float (&bias)[2], const float (&gamma)[2],
-                                               const float (&beta)[2], const float (&isc)[2], ADD0 add0, ADD1 add1) {
+                                               const float (&beta)[2], const float (&isc)[2], const ActScale& as, ADD0 add0, ADD1 add1) {
   constexpr float inv_n = 1.f / 256.f;                       // 16 channels x 16 positions
   float sum0 = 0.f, sum1 = 0.f;
 #pragma unroll
@@ -1345,8 +1437,8 @@ __device__ __forceinline__ void gn_mish_pair16(f32x4 (&q0)[4], f32x4 (&q1)[4], c
   for (int o = 0; o < 4; ++o)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      q0[o][r] = gn_mish1(q0[o][r], cf0, add0(o, r));
-      q1[o][r] = gn_mish1(q1[o][r], cf1, add1(o, r));
+      q0[o][r] = gn_mish1<ACT>(q0[o][r], cf0, add0(o, r), as);
+      q1[o][r] = gn_mish1<ACT>(q1[o][r], cf1, add1(o, r), as);
     }
 }
 
@@ -1366,7 +1458,8 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
   TR(trb + 0);
 
   f32x4 res[2][4];
-  char* const vb = reinterpret_cast<char*>(lds);             // the bf16x3 phase slab aliases the x slab
+  float* const mx = lds + MX_OFF;                            // per-sample partial maxima (dynamic f16x2 input scales)
+  char* const vb = reinterpret_cast<char*>(lds);             // the f16x2 phase slab aliases the x slab
   // A fragment: row lane & 15 = (sample (lane & 15) >> 2, quad lane & 3), channel-block group lane >> 4
   const char* const vb_a = vb + (lane >> 4) * VB_CG + (4 * (lane & 3) + ((lane & 15) >> 2)) * 16;
   // stores: channels c0, c0 + 1 = block 4 wave + ((lane & 15) >> 2), dword lane & 3; sample lane >> 4
@@ -1399,20 +1492,46 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
 #pragma unroll
     for (int h = 0; h < 2; ++h) w4n1_out(acc[h], mb[h]);
   };
-  // GroupNorm + Mish of acc, then + the time bias (conv A) or + the residual tile (conv B, tb == nullptr)
-  // (isc: the conv's inverse f16x2 weight scales; unused (SCALED = false) for the fp32 conv A of the first RTB)
-  auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc) {
+  // GroupNorm + Mish of acc.  Conv A (tb != nullptr): + the time bias, output carried times act_s, the static f16x2 input
+  // scale of conv B (ACT); conv B: + the residual tile.  SCALED: the conv ran as f16x2 -- isc = its inverse weight scales
+  // (conv B's include 1 / act_s), inv_dyn = the inverse of the dynamic input scale (conv A of an identity RTB), per sample.
+  auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc, float inv_dyn,
+                float act_s) {
     constexpr bool SCALED = decltype(scaled)::value;
     const float bb[2] = {b[c0], b[c0 + 1]}, gg[2] = {g[c0], g[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
-    const float is[2] = {SCALED ? isc[c0] : 1.f, SCALED ? isc[c0 + 1] : 1.f};
+    const float is[2] = {SCALED ? isc[c0] * inv_dyn : 1.f, SCALED ? isc[c0 + 1] * inv_dyn : 1.f};
     if (MMD_ABL == 1) return;
     if (tb) {
-      const float t0 = tb[c0], t1 = tb[c0 + 1];
-      gn_mish_pair16<SCALED>(acc[0], acc[1], bb, gg, ee, is, [&](int, int) { return t0; }, [&](int, int) { return t1; });
+      const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
+      gn_mish_pair16<SCALED, true>(acc[0], acc[1], bb, gg, ee, is, act_scale(act_s), [&](int, int) { return t0; },
+                                   [&](int, int) { return t1; });
     } else {
-      gn_mish_pair16<SCALED>(acc[0], acc[1], bb, gg, ee, is, [&](int o, int r) { return res[0][o][r]; },
-                             [&](int o, int r) { return res[1][o][r]; });
+      gn_mish_pair16<SCALED, false>(acc[0], acc[1], bb, gg, ee, is, ActScale{}, [&](int o, int r) { return res[0][o][r]; },
+                                    [&](int o, int r) { return res[1][o][r]; });
     }
+  };
+  // The lane's two tiles belong to sample lane >> 4: partial |x| maximum of the wave's 32 channels -> mx[sample][wave]
+  // (before a barrier); after it dyn_in() combines the four waves' and scales acc in place (the conv's f16x2 input).
+  auto dyn_out = [&](int region2) {                          // region2 > 0: also kept there for ups.0
+    float m = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(fabsf(acc[0][o][r]), fabsf(acc[1][o][r])));
+    m = row_max16(m);
+    if ((lane & 15) == 0) {
+      mx[(lane >> 4) * MX_SLOTS + wave] = m;
+      if (region2) mx[region2 * MX_REGION + (lane >> 4) * MX_SLOTS + wave] = m;
+    }
+  };
+  auto dyn_in = [&]() {
+    const float4 p = *reinterpret_cast<const float4*>(mx + (lane >> 4) * MX_SLOTS);
+    const DynScale ds = dyn_scale(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)));
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[h][o] *= ds.s;
+    return ds.inv;
   };
 
   // =================== RTB 0 (64 -> 128): conv A + the 1x1 residual conv on the fp32 MFMA, row-form x slab ===================
@@ -1428,11 +1547,11 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
       w4n1_out(acc[h], m);
     }
   }
-  gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr);
+  gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr, 1.f, a.r0.act_a);
   TR(trb + 1);
   __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
   conv_hb(a.r0.wb_bf);
-  gn(std::true_type{}, a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+  gn(std::true_type{}, a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, 1.f, 1.f);
 
   // =================== identity RTBs (a real loop: one copy of the two conv bodies instead of three) ===================
 #pragma unroll 1
@@ -1442,12 +1561,14 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 4; ++i) res[h][i] = acc[h][i];
+    dyn_out(k == CF::MID_AFTER ? 1 : 0);                    // (the input of the RTB after MID_AFTER is the skip tensor)
     __syncthreads();                                         // the previous conv is done reading the slab
+    const float inv_dyn = dyn_in();
     conv_hb(R.wa_bf);
-    gn(std::true_type{}, R.ba, R.ga, R.bea, R.tb, R.isa);
+    gn(std::true_type{}, R.ba, R.ga, R.bea, R.tb, R.isa, inv_dyn, R.act_a);
     __syncthreads();
     conv_hb(R.wb_bf);
-    gn(std::true_type{}, R.bb, R.gb, R.beb, nullptr, R.isb);
+    gn(std::true_type{}, R.bb, R.gb, R.beb, nullptr, R.isb, 1.f, 1.f);
     TR(trb + 18);
     if (CF::MID_AFTER == k + 1) {
 #pragma unroll
@@ -1456,6 +1577,7 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
         for (int i = 0; i < 4; ++i) mid[h][i] = acc[h][i];
     }
   }
+  dyn_out(2);                                                // the stage's output: ups.0's conv A takes its maximum from region 2
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1463,25 +1585,12 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
 // hand their activations to each other through LDS (tail tile -> next stage's x slab), the two skip connections wait in
 // registers (32 VGPRs each) for the up path.  HBM traffic per trajectory and forward: 1 KiB in, 1 KiB out.
 // ----------------------------------------------------------------------------------------------------------------
-//                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
-using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
-using CH_D1 = ChainCfg<32, 0, 64, 32, 2, RES_CONV, 1, 1, TAIL_DOWN>;     // downs.1 (skip1 = output of its 2nd RTB)
-using CH_D2 = ChainCfg<64, 0, 128, 16, 2, RES_CONV, 3, 1, TAIL_NONE>;    // downs.2 + mid_block1/2 (skip2 after downs.2)
-using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.0: cat(x, skip2) RTB, RTB, Upsample1d
-using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
-constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
-
 struct UnetArgs {
   ChainArgs c[5];
   FinalArgs fin;
   int n;
 };
 
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
-// The L = 16 stages (downs.2 + mid, ups.0) work on V-form slabs of up to 128 channels that alias their row-form slabs.
-constexpr int UNET_LDS_FLOATS =
-    cmax(cmax(cmax(CH_D0::LDS_FLOATS, CH_D1::LDS_FLOATS), cmax(CH_D2::XSLAB, CH_U0::HSLAB)),
-         cmax(cmax(CH_U1::LDS_FLOATS, 4 * FIN_SS), VSLAB_FLOATS + 4 * VCS)) + 8;   // + slack: the A double buffers read one k-step past the end
 static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SPB == 4 && CH_U1::SPB == 4,
               "every stage must own the same 4 samples");
 
@@ -1518,14 +1627,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     f32x16 t[2][1];
     char* const vb_s = reinterpret_cast<char*>(lds) + wave * VB_CG + ((lane & 15) >> 2) * VB_CB + (lane >> 4) * 16 + (lane & 3) * 4;
+    // conv A's input cat(mid output, skip2) is residual-stream data: dynamic per-sample f16x2 scale from its maximum (the
+    // partial maxima were left in regions 1 / 2 of mx by chain_body_d2; combined behind the stage's first barrier)
+    const float* const mx = lds + MX_OFF;
     chain_body_w4u<CH_U0>(a.c[3], lds, lane, wave,
                           [&](auto chunk, auto ph) {
+                            float inv = 1.f;
+                            if constexpr (decltype(chunk)::value == 0 && decltype(ph)::value == 0) {
+                              const float4 p = *reinterpret_cast<const float4*>(mx + MX_REGION + (lane >> 4) * MX_SLOTS);
+                              const float4 q = *reinterpret_cast<const float4*>(mx + 2 * MX_REGION + (lane >> 4) * MX_SLOTS);
+                              const DynScale ds = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w))));
+#pragma unroll
+                              for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int o = 0; o < 4; ++o) {
+                                  mid_out[h][o] *= ds.s;
+                                  skip2[h][o] *= ds.s;
+                                }
+                              inv = ds.inv;
+                            }
                             if constexpr (decltype(chunk)::value == 0)
                               vb_store_pair<decltype(ph)::value>(vb_s, [&](int o, int r) { return mid_out[0][o][r]; },
                                                                  [&](int o, int r) { return mid_out[1][o][r]; });
                             else
                               vb_store_pair<decltype(ph)::value>(vb_s, [&](int o, int r) { return skip2[0][o][r]; },
                                                                  [&](int o, int r) { return skip2[1][o][r]; });
+                            return inv;
                           },
                           t, 136);
     __syncthreads();
@@ -1829,10 +1956,10 @@ static inline void f16_split_host(float u, float scale, uint16_t (&piece)[2]) {
   memcpy(&piece[0], &h, 2);
   memcpy(&piece[1], &l, 2);
 }
-static size_t push_inverse(std::vector<float>& blob, const std::vector<float>& sc) {
+static size_t push_inverse(std::vector<float>& blob, const std::vector<float>& sc, float in_scale = 1.f) {
   while (blob.size() % 4) blob.push_back(0.f);
   const size_t off = blob.size();
-  for (float v : sc) blob.push_back(1.f / v);
+  for (float v : sc) blob.push_back(1.f / (v * in_scale));   // powers of two: exact
   while (blob.size() % 4) blob.push_back(0.f);
   return off;
 }
@@ -1840,9 +1967,9 @@ static size_t push_inverse(std::vector<float>& blob, const std::vector<float>& s
 // f16x2 pack of a 128 -> 128 k5 conv for vb_taps: per n-tile [phase][step = 4 chunk kc + slot][piece q][lane] x 16 B, lane =
 // (column lane & 15 of the tile, channels 8 (4 (lane >> 4) + kc) + j, j = 0..7 at fp16 index j).  Returns the pack's offset
 // in the blob (in floats; 16-byte aligned); isc_off = offset of the [cout] inverse channel scales.
-static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off) {
+static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off, float in_scale) {
   const std::vector<float> sc = f16_col_scales(w, cout, cin);
-  isc_off = push_inverse(blob, sc);
+  isc_off = push_inverse(blob, sc, in_scale);                // in_scale: the static scale the conv's input arrives with
   const size_t base = blob.size();
   const int tiles = cout / 16, KC = cin / 32;
   const size_t frags = (size_t)tiles * 2 * 4 * KC * 2;
@@ -1869,9 +1996,9 @@ static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int ci
 // f16x2 pack of a C -> C k5 conv of downs.0 / downs.1 for vbd_taps: per n-tile [phase][step = 4 chunk kc + slot][piece q][lane]
 // x 16 B; lane = (column n = 16 tile + (lane & 15), the 8 channels of the block DbGeo assigns to (kc, lane >> 4), j at fp16
 // index j).
-static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off) {
+static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off, float in_scale) {
   const std::vector<float> sc = f16_col_scales(w, cout, cin);
-  isc_off = push_inverse(blob, sc);
+  isc_off = push_inverse(blob, sc, in_scale);
   const size_t base = blob.size();
   const int tiles = cout / 16, KC = cin / 32;
   const size_t frags = (size_t)tiles * 2 * 4 * KC * 2;
@@ -1931,8 +2058,47 @@ static size_t pack_vbu(std::vector<float>& blob, const float* w, const float* wr
   return base;
 }
 
+// max over t of |time bias| per (RTB, channel): a host replica (double) of time_table_kernel, used only for the bound
+// behind the static activation scales below (layers.py:232-258, 337-341)
+static std::vector<std::vector<float>> time_bias_absmax(const float* const* tensors, const Spec& s, int T) {
+  auto mish = [](double y) { return y * std::tanh(y > 20.0 ? y : std::log1p(std::exp(y))); };
+  const float *w1 = tensors[s.t_time[0]], *b1 = tensors[s.t_time[1]], *w3 = tensors[s.t_time[2]], *b3 = tensors[s.t_time[3]];
+  std::vector<std::vector<float>> mxv(s.rtb.size());
+  for (size_t r = 0; r < s.rtb.size(); ++r) mxv[r].assign(s.rtb[r].cout, 0.f);
+  for (int t = 0; t < T; ++t) {
+    double emb[32], h1[128], m[32];
+    for (int i = 0; i < 16; ++i) {
+      const double f = std::exp((double)i * -(std::log(10000.0) / 15.0)), v = (double)t * f;
+      emb[i] = std::sin(v); emb[i + 16] = std::cos(v);
+    }
+    for (int j = 0; j < 128; ++j) { double a = b1[j]; for (int k = 0; k < 32; ++k) a += (double)w1[j * 32 + k] * emb[k]; h1[j] = mish(a); }
+    for (int j = 0; j < 32; ++j) { double a = b3[j]; for (int k = 0; k < 128; ++k) a += (double)w3[j * 128 + k] * h1[k]; m[j] = mish(a); }
+    for (size_t r = 0; r < s.rtb.size(); ++r) {
+      const float *cw = tensors[s.rtb[r].t_cw], *cb = tensors[s.rtb[r].t_cb];
+      for (int c = 0; c < s.rtb[r].cout; ++c) {
+        double a = cb[c];
+        for (int k = 0; k < 32; ++k) a += (double)cw[c * 32 + k] * m[k];
+        mxv[r][c] = fmaxf(mxv[r][c], (float)std::fabs(a));
+      }
+    }
+  }
+  return mxv;
+}
+// Static f16x2 input scale of a conv B: its input Mish(GroupNorm(.)) + time bias is bounded whatever the data --
+// |x_hat| <= sqrt(N - 1) < 16 for a group of N = 256 values, Mish(y) in [-0.31, max(y, 0)] -- by B = max_c (max(0.31, 16
+// |gamma_c| + |beta_c|) + max_t |tb_c(t)|); the power of two s = 2^(10 - floor(log2 B)) keeps every Winograd-transformed
+// value |V| <= 15 B s < 30720 inside fp16 and the typical ones (|x_hat| ~ 1) far above its denormals.
+static float static_act_scale(const float* gamma, const float* beta, const std::vector<float>& tbmax, int c) {
+  float B = 0.f;
+  for (int i = 0; i < c; ++i) B = fmaxf(B, fmaxf(0.31f, 16.f * fabsf(gamma[i]) + fabsf(beta[i])) + tbmax[i] * 1.001f);
+  if (!std::isfinite(B)) return 1.f;
+  int ex;
+  (void)frexpf(B, &ex);                      // B = f * 2^ex, f in [0.5, 1): floor(log2 B) = ex - 1
+  return ldexpf(1.f, 10 - (ex - 1));
+}
+
 struct ConvW { size_t wpk, bias, gamma, beta, wbf, isc; };   // wbf / isc: f16x2 pack and its inverse channel scales
-struct RtbW { ConvW a, b; size_t res_bias, res_isc; int tb_off; size_t a_c1, a_c1_bf; };
+struct RtbW { ConvW a, b; size_t res_bias, res_isc; int tb_off; size_t a_c1, a_c1_bf; float act_a; };
 
 }  // namespace mmd
 
@@ -1976,6 +2142,7 @@ static RtbPtrs rtb_ptrs(const mmd_unet_s* u, const RtbW& w, int t) {
   p.wb_bf = w.b.wbf ? reinterpret_cast<const uint4*>(u->blob + w.b.wbf) : nullptr;
   p.isa = w.a.wbf ? u->blob + w.a.isc : nullptr;
   p.isb = w.b.wbf ? u->blob + w.b.isc : nullptr;
+  p.act_a = w.act_a;
   return p;
 }
 
@@ -2035,6 +2202,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   for (int i = 0; i < 4; ++i) raw_time[i] = push(blob, tensors[s.t_time[i]], s.numel[s.t_time[i]]);
   size_t raw_cw[12], raw_cb[12];
   int tb_off = 0;
+  const std::vector<std::vector<float>> tbmax = time_bias_absmax(tensors, s, n_diffusion_steps);
   for (int r = 0; r < 12; ++r) {
     // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2.  Every conv gets the one pack its stage body
     // reads: fp32 Winograd packs (pack_w4) for the up path and the first convs of the down stages (one n-tile per slice
@@ -2043,6 +2211,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     W = RtbW{};
+    W.act_a = 1.f;
     while (blob.size() % 4) blob.push_back(0.f);
     const bool d1 = r <= 3, d2 = r == 4 || r == 5 || r == 10 || r == 11;   // d1: downs.0 / downs.1 (chain_body_db)
     const int NT = (r >= 6 && r <= 9) || d1 || d2 ? 1 : 2;   // n-tiles per weight slice
@@ -2067,7 +2236,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       W.a_c1 = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
     } else if ((d1 || d2) && R.cin == R.cout) {
-      W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc);
+      W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);   // dynamic input scale
     } else {
       W.a.wpk = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres, /*pair_cols=*/d2);
@@ -2076,7 +2245,8 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
     if (d1 || d2) {
-      W.b.wbf = d1 ? pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc) : pack_vb(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc);
+      W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
+      W.b.wbf = d1 ? pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc, W.act_a) : pack_vb(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc, W.act_a);
     } else {
       while (blob.size() % 4) blob.push_back(0.f);
       W.b.wpk = blob.size();

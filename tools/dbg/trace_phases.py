@@ -30,18 +30,15 @@ tags = [i for i in range(256) if (t[:, :, i] > 0).all()]
 t0 = t[:, :, tags[0]].min()
 print(f"n={n} blocks={nb}; tags {len(tags)}; kernel span {(t[:, :, tags[-1]].max() - t0) / 1e3:.1f} us")
 names = {}
-for base, nm in ((0, "D0"), (40, "D1"), (80, "D2")):
-    for j, w in enumerate(("rtb0 start", "convA done", "res conv done", "gn+write", "barrier", "convB done", "gn+res")):
+for base, nm in ((0, "D0"), (40, "D1")):
+    for j, w in enumerate(("start (x slab staged)", "convA + res + gn (fp32)", "convB + gn (f16x2)", "id convA + gn", "id convB + gn", "tail conv done")):
         names[base + j] = f"{nm} {w}"
-    for k in range(3):
-        for j, w in enumerate(("barrier(prev)", "write+barrier", "convA done", "gn", "barrier", "write+barrier", "convB done", "gn+res")):
-            names[base + 8 + k * 8 + j] = f"{nm} id{k} {w}"
 for base, nm in ((136, "U0"), (146, "U1")):
     for j, w in enumerate(("start", "rtb0 convA+res done", "gn+write+barrier", "rtb0 convB done", "gn+res", "id convA done", "id convB done", "gn+write -> tail")):
         names[base + j] = f"{nm} {w}"
 names.update({130: "-> U0 start", 131: "-> U1 start", 132: "-> FIN start", 133: "end"})
-# bf16x3 body of downs.2 + mid (tags are overwritten by every conv: the values are the LAST conv's, mid_block2 conv B)
-names.update({80: "D2 start", 81: "D2 rtb0 convA+gn (fp32)", 90: "last conv: start", 91: "  store set 0", 92: "  barrier",
+# f16x2 body of downs.2 + mid (tags 90..98 are overwritten by every conv: the values are the LAST conv's, mid_block2 conv B)
+names.update({80: "D2 start", 81: "D2 rtb0 convA+gn (fp32)", 90: "last conv: start", 91: "  ring + store set 0", 92: "  barrier",
               93: "  MFMAs set 0", 94: "  ring + barrier", 95: "  store set 1", 96: "  barrier", 97: "  MFMAs set 1",
               98: "  out transform + GN + Mish"})
 prev = None
