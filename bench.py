@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- guided trajectories/sec of the MI355X sampler on BASELINE.json's headline config.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 re-launches itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -9,18 +9,20 @@ A "step" is ONE planning round of the hot path: (all-gather of the robots' best 
 table -> one guided DDPM sampling call (T=100 denoise steps + 1 no-noise step, 20 guide iterations on the 51 guided
 steps) for every local robot's B=64 samples -> best-path selection for the next round.  N=1 is BASELINE.json's headline
 workload: 32 robots on the Empty map (circle r=0.8) = 2048 trajectories, each robot soft-constrained by the other 31
-(31 x 63 = 1953 points).  N>1, `--scaling strong` (default): the SAME 32-robot instance, the metric's own workload,
-sharded 32/N robots per GPU (512 trajectories per GPU at N=4, 256 at N=8).  `--scaling weak`: 32 robots PER GPU of one
-32N-robot instance (the pairwise term grows with N).  Either way ONE RCCL all-gather of [robots/GPU,64,2] fp32 per rank
-per round.  UNet weights are synthetic random-init (numpy PCG64), Gaussian noise is drawn in-kernel (Philox keyed by the
-global trajectory index, so every rank's rows equal the unsharded run's), inputs are resident in HBM before the timed
-region.
+(31 x 63 = 1953 points).  N>1, `--scaling strong` (default, the headline): the SAME 32-robot instance, the metric's own
+workload, sharded 32/N robots per GPU (512 trajectories per GPU at N=4, 256 at N=8); the weak-scaling variant (32 robots
+PER GPU of one 32N-robot instance; the pairwise term grows with N) is timed right after it and reported in the same line as
+`weak_scaling` (`--scaling weak` makes it the headline instead).  Either way ONE RCCL all-gather of [robots/GPU,64,2] fp32
+per rank per round.  UNet weights are synthetic random-init (numpy PCG64), Gaussian noise is drawn in-kernel (Philox keyed
+by the global trajectory index, so every rank's rows equal the unsharded run's), inputs are resident in HBM before the
+timed region.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 from math import ceil
@@ -34,9 +36,11 @@ import torch         # noqa: E402
 
 H, D = 64, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
-PEAK_BF16_MFMA_TFLOPS = 2516.6     # dense bf16 MFMA peak (1024 FLOP/clk/SIMD): 16x the fp32 MFMA rate
+PEAK_F16_MFMA_TFLOPS = 2516.6      # dense fp16 / bf16 MFMA peak (1024 FLOP/clk/SIMD): 16x the fp32 MFMA rate
+PEAK_HBM_GBPS = 8000.0             # HBM3E spec (6.3 TB/s achievable, same guide)
 DOMINANT_KERNEL = "UNET"           # unet_kernel: the whole TemporalUnet forward in one launch (all 25 convs + GN/Mish)
 HEADLINE_ROBOTS = 32               # BASELINE.json: 32-robot Empty map
+PROF_UNET, PROF_STEP_GUIDED, PROF_STEP_PLAIN = 0, 1, 2     # include/mmd_amd_debug.h
 
 
 def parse():
@@ -45,12 +49,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
-                    help="N>1: strong = the metric's 32-robot instance sharded 32/N robots per GPU; weak = 32 robots per "
-                         "GPU of a 32N-robot instance")
+                    help="N>1 headline: strong = the metric's 32-robot instance sharded 32/N robots per GPU; weak = 32 robots "
+                         "per GPU of a 32N-robot instance (the other one is timed too and reported alongside)")
     ap.add_argument("--robots-per-gpu", type=int, default=0, help="override (0 = 32/N for strong, 32 for weak)")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-scaling", action="store_true", help="N>1: time only the headline scaling mode")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     return ap.parse_args()
 
@@ -71,7 +76,8 @@ def cpu_baseline(T, B, n_robots, budget_s):
     torch-CPU UNet) for ONE robot of the headline instance, timed on this host's cores on a bounded sample and
     extrapolated to the full 101-step call.  Robots are planned sequentially by the reference, so trajectories/s of
     one robot's call is the whole-round rate.  The thread count is swept upwards from 8 (an oversubscribed pool is slower
-    for these small tensors) and the best setting is reported."""
+    for these small tensors); the rest of the budget then goes into more steps at the best thread count (spread over the
+    guided and the unguided half of the schedule), and that longer sample is what is reported."""
     import cases_for_bench as cb
     from oracle import mmd_oracle as O
     sd, tb, gp, grp, hc = cb.oracle_headline_robot(T, n_robots)
@@ -95,7 +101,7 @@ def cpu_baseline(T, B, n_robots, budget_s):
     n_guided, n_unguided = tsg + 1, T - tsg                          # i = tsg-1 ... -1 guided; the rest unguided
     results, t_start = [], time.perf_counter()
     for nt in sweep:
-        if results and time.perf_counter() - t_start > budget_s:
+        if results and time.perf_counter() - t_start > 0.6 * budget_s:
             break
         torch.set_num_threads(nt)
         timed(T - 1, None)                                           # warm-up (thread pool, allocator)
@@ -107,37 +113,57 @@ def cpu_baseline(T, B, n_robots, budget_s):
         if B / est < 0.7 * max(r["trajectories_per_s"] for r in results):
             break
     best = max(results, key=lambda r: r["trajectories_per_s"])
-    return {"value": best["trajectories_per_s"], "unit": "trajectories/s", "cores": best["threads"], "kind": "port",
+    # the longer sample at the best thread count: guided / unguided steps spread over their halves of the schedule
+    torch.set_num_threads(best["threads"])
+    tg, tu = [], []
+    gi = list(np.linspace(tsg - 1, 0, 8).astype(int))
+    ui = list(np.linspace(T - 1, tsg, 8).astype(int))
+    k = 0
+    while time.perf_counter() - t_start < budget_s and k < 8:
+        tg.append(timed(int(gi[k]), guide))
+        tu.append(timed(int(ui[k]), None))
+        k += 1
+    if tg:
+        est = n_guided * float(np.mean(tg)) + n_unguided * float(np.mean(tu))
+    else:
+        est = best["est_seconds_per_robot_call"]
+    return {"value": B / est, "unit": "trajectories/s", "cores": best["threads"], "kind": "port",
             "cpu_model": cpu_model_name(), "logical_cpus": n_cpus,
-            "sample": f"1 of {n_robots} robots (B={B}, {grp.q.shape[0]} soft-constraint points): per thread count 2 guided "
-                      f"+ 2 unguided DDPM steps timed and extrapolated to the {n_guided}+{n_unguided}-step call (robots "
-                      f"are sequential in the reference); best of the thread sweep reported",
-            "est_seconds_per_robot_call": best["est_seconds_per_robot_call"], "thread_sweep": results}
+            "sample": f"1 of {n_robots} robots (B={B}, {grp.q.shape[0]} soft-constraint points): {len(tg)} guided + {len(tu)} "
+                      f"unguided DDPM steps at {best['threads']} threads (the best of a thread sweep that timed 2 + 2 steps per "
+                      f"count), {sum(tg) + sum(tu):.1f} s of CPU work, extrapolated to the {n_guided}+{n_unguided}-step call "
+                      f"(robots are sequential in the reference)",
+            "est_seconds_per_robot_call": est, "thread_sweep": results}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback for the product path)"
-    # MMD_BENCH_REHEARSAL=1: rehearse the N>1 path on ONE GPU (all ranks on cuda:0, gloo) -- not a measurement
-    rehearsal = os.environ.get("MMD_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-exec under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvp(sys.executable, cmd)
+
+
+def union_length(intervals):
+    tot, cur_s, cur_e = 0.0, None, None
+    for a, b in sorted(intervals):
+        if cur_e is None or a > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = a, b
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            cur_e = max(cur_e, b)
+    if cur_e is not None:
+        tot += cur_e - cur_s
+    return tot
 
+
+def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
+    """Time args.steps planning rounds of one scaling mode; returns (value, ms_per_step, config, roofline objects or None)."""
+    import ctypes as C
     from mmd_amd import _lib, synth
     from mmd_amd.diffusion_model import GaussianDiffusionModel
     from mmd_amd.multi_robot import MultiRobotSampler
@@ -146,7 +172,7 @@ def main():
     T, B = args.diffusion_steps, args.samples
     if args.robots_per_gpu:
         RPG = args.robots_per_gpu
-    elif args.scaling == "strong":
+    elif scaling == "strong":
         if HEADLINE_ROBOTS % world:
             raise SystemExit(f"--scaling strong needs {HEADLINE_ROBOTS} % gpus == 0")
         RPG = HEADLINE_ROBOTS // world
@@ -169,20 +195,21 @@ def main():
         torch.cuda.synchronize()
 
     lib = _lib.load()
-    import ctypes as C
     n_traj_local = RPG * B
-    flops = lib.mmd_unet_flops_per_trajectory() * n_traj_local              # algorithmic (direct-conv) FLOPs per launch
-    mfma_flops = lib.mmd_unet_mfma_flops_per_trajectory() * n_traj_local    # fp32 GEMM FLOPs the matrix pipe runs
-    bf_flops = lib.mmd_unet_f16x2_flops_per_trajectory() * n_traj_local    # ... of which as bf16x3 on the bf16 pipe
-
+    # the sampler splits the robots into `chunks` concurrent launch chains (HIP streams) from 2048 trajectories on
+    chunks = max(1, min(2 if n_traj_local >= 2048 else 1, RPG))
     for w in range(args.warmup):
         _, paths_local = sampler.plan_round(paths_local, seed=1000 + w)
-    # roofline of the dominant kernel: its launches INSIDE the timed region are bracketed by HIP event pairs on the stream
-    # it is launched on (mmd_amd_debug.h profiler attached to the sampler).  Every 13th of the 101 launches per step is
-    # bracketed: ~8 event pairs per step, < 0.5 % of the timed region.
+    # Roofline measurements INSIDE the timed region: every UNet launch and step-kernel launch of two consecutive DDPM steps
+    # out of every twelve (all stream chunks) is bracketed by a HIP event pair on the stream it is launched on
+    # (mmd_amd_debug.h profiler attached to the sampler): ~130 event pairs per 101-step round, < 1 % of it.
     prof = C.c_void_p()
-    _lib.check(lib.mmd_profiler_create(C.byref(prof), (T + 1) * args.steps, 13))
-    model.profiler = prof
+    window, stride = 2 * chunks, 6
+    per_call = (T + 1) * chunks
+    max_pairs = 2 * (per_call // (window * stride) + 1) * window * max(args.steps, 1)
+    if with_roofline:
+        _lib.check(lib.mmd_profiler_create_windowed(C.byref(prof), max_pairs, stride, window, per_call))
+        model.profiler = prof
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -190,18 +217,46 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     model.profiler = None
-    dom_ms_c, dom_n = C.c_double(), C.c_int()
-    _lib.check(lib.mmd_profiler_read(prof, C.byref(dom_ms_c), C.byref(dom_n)))
-    _lib.check(lib.mmd_profiler_destroy(prof))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(trajs).all()
     value = args.steps * n_traj_local * world / dt
-    dom_ms = dom_ms_c.value
-    # outside the timed region: the same kernel as ONE launch of all local trajectories, back to back on one stream -- the
-    # per-launch figure that does not depend on how the sampler chunks its batch (kernel quality from round to round)
+    config = {"workload": f"{scaling}-scaling over {world} GPU(s): "
+                          f"{n_robots}-robot EnvEmpty2D circle r=0.8, {RPG} robots/GPU x B={B} samples, H=64, "
+                          f"T={T}+1 DDPM steps, 20 guide iterations on {ceil(0.5 * T) + 1} guided steps, "
+                          f"{n_robots - 1} x 63 soft-constraint points per robot",
+              "n_robots": n_robots, "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": H,
+              "diffusion_steps": T, "trajectories_per_step": n_traj_local * world,
+              "parallelism": f"robots sharded x{world}; 1 all-gather of [{RPG},64,2] fp32 per round" if world > 1
+              else "single GPU", "noise": "in-kernel Philox4x32-10 keyed by global trajectory index",
+              "weights": "random-init (numpy PCG64 seed 0)"}
+    if not with_roofline:
+        return value, dt / args.steps * 1e3, config, None, None
+
+    def intervals(kind):
+        a = (C.c_double * max_pairs)()
+        b = (C.c_double * max_pairs)()
+        n = C.c_int()
+        _lib.check(lib.mmd_profiler_intervals(prof, kind, a, b, max_pairs, C.byref(n)))
+        return [(a[i] * 1e-3, b[i] * 1e-3) for i in range(n.value)]       # seconds
+
+    iv_unet, iv_g, iv_p = intervals(PROF_UNET), intervals(PROF_STEP_GUIDED), intervals(PROF_STEP_PLAIN)
+    _lib.check(lib.mmd_profiler_destroy(prof))
+    n_launch = n_traj_local // chunks                                            # trajectories per launch
+    flops = lib.mmd_unet_flops_per_trajectory() * n_launch                      # algorithmic (direct-conv) FLOPs per launch
+    mfma_flops = lib.mmd_unet_mfma_flops_per_trajectory() * n_launch            # fp32 GEMM FLOPs the matrix pipe runs
+    h_flops = lib.mmd_unet_f16x2_flops_per_trajectory() * n_launch              # ... of which as f16x2 on the fp16 pipe
+    # matrix-pipe issue time of ONE launch at spec clock: fp32 MFMAs at the fp32 MFMA peak, the f16x2 part as 3 fp16 MFMA
+    # FLOPs per fp32 FLOP at the fp16 MFMA peak (16x)
+    busy_s = (mfma_flops - h_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + 3.0 * h_flops / (PEAK_F16_MFMA_TFLOPS * 1e12)
+    dur = [b - a for a, b in iv_unet]
+    launch_s = float(np.mean(dur))
+    union_s = union_length(iv_unet)                      # wall time during which at least one bracketed UNet launch runs
+    concurrency = sum(dur) / union_s
+    pipe_busy = busy_s * len(dur) / union_s
+    # outside the timed region: the same kernel as ONE launch of all local trajectories, back to back on one stream
     xs = torch.randn(n_traj_local, H, 4, device=dev)
     for _ in range(3):
         unet(xs, 50)
@@ -212,73 +267,106 @@ def main():
         unet(xs, 50)
     e1.record()
     torch.cuda.synchronize()
-    solo_ms = e0.elapsed_time(e1) / 20
-    # mmd_p_sample_loop splits the robots into `chunks` concurrent launch chains (HIP streams, default 2): at any time
-    # `chunks` unet_kernel launches of n_traj_local / chunks trajectories each share the GPU.  launch_ms is the mean
-    # duration of ONE such launch (what rocprofv3 --stats reports for unet_kernel); the rate the GPU sustains is that of
-    # all `chunks` launches in flight.
-    chunks = int(os.environ.get("MMD_AMD_STREAMS", "0") or 0) or (2 if n_traj_local >= 2048 else 1)
-    chunks = max(1, min(chunks, 4, RPG))
-    launch_flops, launch_mfma, launch_bf = flops / chunks, mfma_flops / chunks, bf_flops / chunks
-    issued_tf = mfma_flops / (dom_ms * 1e-3) / 1e12
-    alg_tf = flops / (dom_ms * 1e-3) / 1e12
-
-    # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (separate runs; tools/gpu_round.sh), committed
-    # as profiles/pmc_latest.json: traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE half-count correction)
-    traffic = None
+    solo_s = e0.elapsed_time(e1) / 20 * 1e-3
+    # HBM-side traffic per launch: rocprofv3 PMC passes (separate runs, kernel-trace only: tools/gpu_profile.sh), committed as
+    # profiles/pmc_latest.json; traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE half-count correction)
+    traffic, traffic_src, pmc_all = None, None, {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path) and n_traj_local // chunks == 1024:
+    if os.path.exists(pmc_path):
         with open(pmc_path) as f:
-            pmc = json.load(f).get(DOMINANT_KERNEL)
-        if pmc:
+            pmc_all = json.load(f)
+        pmc = pmc_all.get(DOMINANT_KERNEL)
+        if pmc and pmc.get("trajectories_per_launch", 1024) == n_launch:
             traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
-    # `achieved` / `frac`: the fp32 GEMM FLOPs the kernel actually runs on the matrix pipe per launch (Winograd F(4,5) for
-    # the k=5 convs, i.e. 0.45x the multiplies of the direct form) / launch time, against the fp32 MFMA peak -- the
-    # roofline of fp32 arithmetic on this chip.  55 % of those FLOPs (downs.2 + mid, ups.0 conv A) run as bf16x3 on the bf16 pipe (an
-    # exact three-way split of both operands, six bf16 MFMAs per fp32 chunk: fp32-accurate and 2.7x the fp32 MFMA rate),
-    # so the pipe's BUSY fraction is lower than `frac`: `pipe_busy_model` prices every MFMA at its issue cycles.  The
-    # ALGORITHMIC (direct-convolution) rate is reported separately and may exceed the peak.
-    busy_s = ((mfma_flops - bf_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + 6.0 * bf_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12))
-    roofline = {"bound": "mfma", "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; the 25 k=5 convs as Winograd F(4,5): fp32 MFMA GEMMs, the seven 128->128 convs and ups.0 conv A as bf16x3 on the bf16 MFMA; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
-                "achieved": issued_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued_tf / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": traffic, "launch_ms": dom_ms, "launches_timed": dom_n.value,
-                "concurrent_launches": chunks, "trajectories_per_launch": n_traj_local // chunks,
-                "flops_per_launch": launch_mfma, "flops_per_launch_as_bf16x3": launch_bf,
-                "achieved_single_launch": launch_mfma / (dom_ms * 1e-3) / 1e12,
-                "pipe_busy_model": busy_s / (dom_ms * 1e-3),
-                "whole_batch_single_launch": {"trajectories": n_traj_local, "launch_ms": solo_ms,
-                                              "achieved": mfma_flops / (solo_ms * 1e-3) / 1e12,
-                                              "frac": mfma_flops / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                              "note": "the same kernel as one launch of all local trajectories, 20 back to back on one stream, outside the timed region"},
-                "note": f"flops = fp32 GEMM FLOPs run on the matrix pipe (Winograd-domain; {100 * bf_flops / mfma_flops:.0f} % of them as bf16x3: 6 bf16 MFMA FLOPs per fp32 FLOP). "
-                        "`concurrent_launches` launches of `trajectories_per_launch` trajectories share the GPU at any time (the sampler's stream chunks); "
-                        "launch_ms = mean duration of one of them (HIP events on its stream; = rocprofv3's average for unet_kernel). "
-                        "achieved = concurrent_launches x flops_per_launch / launch_ms = the rate the GPU sustains, vs the fp32 MFMA peak; "
-                        "achieved_single_launch = flops_per_launch / launch_ms is one launch's share of it. "
-                        "pipe_busy_model = MFMA issue time at spec clock (fp32 MFMAs at 157.3 TF, bf16 ones at 2516.6 TF) / launch time",
-                "algorithmic": {"flops_per_launch": launch_flops, "achieved": alg_tf, "ratio_to_peak": alg_tf / PEAK_FP32_MFMA_TFLOPS,
-                                "note": "direct-conv FLOPs (2*C_out*taps*C_in*L_out), all concurrent launches / launch time; Winograd F(4,5) issues 0.45x of them, so this can exceed the MFMA peak"},
-                "launches_per_forward": chunks}
+            traffic_src = f"profiles/pmc_latest.json ({pmc_all.get('source', 'rocprofv3 PMC passes')}); not measured by this run"
+    eq_tf = mfma_flops * len(dur) / union_s / 1e12
+    roofline = {
+        "bound": "mfma",
+        "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; the 25 k=5 convs as Winograd F(4,5) GEMMs: 70 % of the matrix work as an fp16 two-piece split of fp32 (f16x2) on v_mfma_f32_16x16x32_f16, the rest on the fp32 MFMA; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
+        "achieved": pipe_busy * PEAK_FP32_MFMA_TFLOPS, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": pipe_busy,
+        "frac_definition": "matrix-pipe busy fraction: MFMA issue time of the bracketed launches at spec clock (fp32 MFMAs at "
+                           "157.3 TFLOP/s, fp16 MFMAs at 2516.6) / wall time during which at least one of them runs (union of "
+                           "their HIP-event intervals, all stream chunks); `achieved` = frac x peak, i.e. the issued MFMA work "
+                           "in fp32-MFMA-equivalent TFLOP/s (an fp16 MFMA FLOP counts 1/16)",
+        "traffic": traffic, "traffic_source": traffic_src,
+        "hbm_gbps": None if traffic is None else traffic * len(dur) / union_s / 1e9,
+        "launch_ms": launch_s * 1e3, "launches_timed": len(dur), "trajectories_per_launch": n_launch,
+        "stream_chunks": chunks, "measured_concurrency": concurrency, "union_ms_per_launch": union_s / len(dur) * 1e3,
+        "pipe_busy_single_launch_alone": busy_s * chunks / solo_s,
+        "whole_batch_single_launch": {"trajectories": n_traj_local, "launch_ms": solo_s * 1e3,
+                                      "note": "the same kernel as one launch of all local trajectories, 20 back to back on one stream, outside the timed region"},
+        "mfma_issue_ms_per_launch": busy_s * 1e3,
+        "flops_per_launch": {"algorithmic_direct_conv": flops, "fp32_gemm_issued": mfma_flops, "of_which_f16x2": h_flops},
+        "not_utilisation": {
+            "fp32_equivalent_gemm_rate_tflops": eq_tf, "ratio_to_fp32_mfma_peak": eq_tf / PEAK_FP32_MFMA_TFLOPS,
+            "algorithmic_rate_tflops": flops * len(dur) / union_s / 1e12,
+            "note": "fp32 GEMM FLOPs the kernel performs (Winograd domain; an f16x2 chunk counted as the fp32 math it does) and "
+                    "direct-convolution FLOPs (SURVEY 8d) per second of UNet wall time: both exceed what the fp32 pipe could "
+                    "issue because Winograd F(4,5) needs 0.45x the multiplies and the f16x2 part runs on the 16x faster pipe"},
+    }
+    pmc_busy = pmc_all.get(DOMINANT_KERNEL, {}).get("mfma_busy_frac")
+    if pmc_busy is not None:
+        roofline["mfma_busy_pmc"] = {"value": pmc_busy, "source": "profiles/pmc_latest.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs), rocprofv3 PMC pass (serialises kernels: one launch at a time)"}
+    # second kernel: the fused DDPM-step + guide kernel, HBM roofline on its algorithmic bytes
+    step_bytes = 3.0 * 1024.0 * n_launch                     # x read + eps read + x write per trajectory and step
+    guide = {"kernel": "ddpm_guide_kernel: posterior mean + 20 guide iterations (SDF gather, workspace walls, GP prior, 31 x 63 soft-constraint points) + noise + hard conditioning, one wave per trajectory",
+             "bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_launch": step_bytes,
+             "note": "algorithmic bytes = 3 KiB per trajectory and step; the kernel is bound by the latency of its 20 dependent guide iterations (VALU issue), not by HBM"}
+    for name, iv in (("guided", iv_g), ("unguided", iv_p)):
+        if iv:
+            d = float(np.mean([b - a for a, b in iv]))
+            guide[name] = {"launch_ms": d * 1e3, "launches_timed": len(iv), "achieved": step_bytes / d / 1e9,
+                           "frac": step_bytes / d / 1e9 / PEAK_HBM_GBPS}
+    gp = pmc_all.get("GUIDE")
+    if gp:
+        guide["pmc"] = gp
+    return value, dt / args.steps * 1e3, config, roofline, guide
 
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)                                   # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback for the product path)"
+    # MMD_BENCH_REHEARSAL=1: rehearse the N>1 path on ONE GPU (all ranks on cuda:0, gloo) -- not a measurement
+    rehearsal = os.environ.get("MMD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    value, ms, config, roofline, guide = run_mode(args, args.scaling, rank, world, dev, rehearsal, with_roofline=True)
     out = {
         "metric": "guided trajectories/sec (H=64, 100 denoise steps), 32-robot Empty map",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.scaling}-scaling over {world} GPU(s): "
-                               f"{n_robots}-robot EnvEmpty2D circle r=0.8, {RPG} robots/GPU x B={B} samples, H=64, "
-                               f"T={T}+1 DDPM steps, 20 guide iterations on {ceil(0.5 * T) + 1} guided steps, "
-                               f"{n_robots - 1} x 63 soft-constraint points per robot",
-                   "n_robots": n_robots, "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": H,
-                   "diffusion_steps": T, "trajectories_per_step": n_traj_local * world,
-                   "parallelism": f"robots sharded x{world}; 1 all-gather of [{RPG},64,2] fp32 per round" if world > 1
-                   else "single GPU", "noise": "in-kernel Philox4x32-10 keyed by global trajectory index", "weights": "random-init (numpy PCG64 seed 0)"},
+        "config": config,
         "roofline": roofline,
+        "roofline_step_kernel": guide,
     }
+    if rehearsal:
+        out["rehearsal"] = "all ranks on ONE GPU over gloo (MMD_BENCH_REHEARSAL=1): exercises the N>1 code path, NOT a measurement"
+    if world > 1 and not args.no_second_scaling and not args.robots_per_gpu:
+        other = "weak" if args.scaling == "strong" else "strong"
+        v2, ms2, cfg2, _, _ = run_mode(args, other, rank, world, dev, rehearsal, with_roofline=False)
+        out[f"{other}_scaling"] = {"value": v2, "unit": "trajectories/s", "ms_per_step": ms2, "scaling": other, "config": cfg2}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        out["cpu_baseline"] = cpu_baseline(T, B, n_robots, args.cpu_budget_s)
+        out["cpu_baseline"] = cpu_baseline(args.diffusion_steps, args.samples, config["n_robots"], args.cpu_budget_s)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -22,7 +22,17 @@ extern "C" {
 typedef struct mmd_profiler_s* mmd_profiler_t;
 int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride);
 int mmd_profiler_destroy(mmd_profiler_t p);
-/* After synchronising the stream(s): mean duration [ms] and number of bracketed launches; rearms the pool. */
+/* Windowed form: launches are counted modulo `period` (0 = never wrap; e.g. the launches of one sampling call) and launch i
+ * of a period is bracketed iff (i / window) % stride == 0 -- `window` consecutive launches (e.g. every stream chunk of two
+ * consecutive steps) out of every window * stride, so that the overlap of concurrent launches can be read off the intervals. */
+int mmd_profiler_create_windowed(mmd_profiler_t* out, int max_launches, int stride, int window, int period);
+/* Kinds of bracketed launches: the UNet forward, and the fused DDPM-step + guide kernel of a guided / an unguided step (the
+ * step kernels of the same steps as the UNet launches are bracketed). */
+enum { MMD_PROF_UNET = 0, MMD_PROF_STEP_GUIDED = 1, MMD_PROF_STEP_PLAIN = 2 };
+/* After synchronising the stream(s), BEFORE mmd_profiler_read: [start, end] of every bracketed launch of `kind` in ms since
+ * the first bracket (one clock across streams), up to `cap` intervals. */
+int mmd_profiler_intervals(mmd_profiler_t p, int kind, double* start_ms, double* end_ms, int cap, int* n_out);
+/* After synchronising the stream(s): mean duration [ms] and number of bracketed UNet launches; rearms the pool. */
 int mmd_profiler_read(mmd_profiler_t p, double* mean_ms, int* n_launches);
 
 /* One TemporalUnet forward = one launch of unet_kernel.  Algorithmic FLOPs per trajectory (direct-convolution count:

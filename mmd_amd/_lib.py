@@ -99,6 +99,9 @@ _SIGNATURES = {
 # include/mmd_amd_debug.h: measurement hooks (bench.py / tools), not part of the drop-in boundary
 _DEBUG_SIGNATURES = {
     "mmd_profiler_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "mmd_profiler_create_windowed": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mmd_profiler_intervals": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                                         C.POINTER(C.c_int)]),
     "mmd_profiler_destroy": (C.c_int, [C.c_void_p]),
     "mmd_profiler_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mmd_unet_flops_per_trajectory": (C.c_double, []),

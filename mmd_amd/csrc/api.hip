@@ -30,6 +30,12 @@ void set_error(const char* fmt, ...) {
 }
 
 constexpr int kMaxChunks = 4;
+// MMD_AMD_STREAMS=<n>: A/B override of mmd_sampler_desc.n_streams for tools/gpu_streams.sh, sampled ONCE at load time -- the
+// sampling entry points themselves never touch the environment
+static const int kEnvStreams = [] {
+  const char* e = getenv("MMD_AMD_STREAMS");
+  return e ? atoi(e) : 0;
+}();
 
 
 // side streams of the chunked sampling loop: created once per (thread, device), never destroyed
@@ -136,8 +142,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   // Split the robots into concurrent chunks: each chunk's kernels go to its own stream, launches interleaved layer by
   // layer so both queues stay fed.  Robots are independent and the noise is keyed by the global trajectory index, so
   // results are bit-identical to the unsplit run.
-  int nch = s->n_streams;
-  if (const char* e = getenv("MMD_AMD_STREAMS")) nch = atoi(e);
+  int nch = kEnvStreams > 0 ? kEnvStreams : s->n_streams;   // (measurement override, read once when the library is loaded)
   // auto: 2 chunks once a chunk alone fills the chip (>= 1024 trajectories = one workgroup per CU): +7 % on the 32-robot
   // round since downs.2 + mid run weight-stream-bound (bf16x3) -- one chunk's bandwidth-bound stages and step kernels
   // meet the other's compute-bound ones on a CU, and a chunk's forward no longer ends with CUs idling until its slowest
@@ -173,9 +178,11 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
     }
     for (int c = 0; c < nch && rc == 0; ++c) {
       const int t0 = r0[c] * samples_per_robot, nc = (r0[c + 1] - r0[c]) * samples_per_robot;
+      const bool br = prof_begin((mmd_profiler_t)s->profiler, 1, sd.do_guide ? MMD_PROF_STEP_GUIDED : MMD_PROF_STEP_PLAIN, cs[c]);
       launch_step(g, sd, x_dev, eps, step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr,
                   chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr, hard_dev, t0, nc, samples_per_robot,
                   cs[c]);
+      if (br) prof_end((mmd_profiler_t)s->profiler, cs[c]);
     }
   }
   // join on every exit path: an error above must not leave the caller's stream detached from the side streams

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <string>
 
+struct mmd_profiler_s;
+
 namespace mmd {
 
 void set_error(const char* fmt, ...);
@@ -26,6 +28,10 @@ void set_error(const char* fmt, ...);
       return 2;                     \
     }                               \
   } while (0)
+
+// measurement brackets of include/mmd_amd_debug.h (unet.hip): true = an event was recorded and prof_end must follow
+bool prof_begin(::mmd_profiler_s* prof, int counter, int kind, hipStream_t st);
+void prof_end(::mmd_profiler_s* prof, hipStream_t st);
 
 constexpr int H = 64;   // support points per trajectory
 constexpr int D = 4;    // state dim (x, y, vx, vy)

@@ -306,9 +306,6 @@ __device__ __forceinline__ void fill(f32x16 (&acc)[MT_W], float v) {
     for (int r = 0; r < 16; ++r) acc[mt][r] = v;
 }
 
-#ifndef MMD_ABL
-#define MMD_ABL 0   // ablation builds only (tools/ablate.sh): 1 = no GroupNorm/Mish
-#endif
 // A register tile written into a slab laid out for another stage: rows (sample, position) and columns keep their meaning,
 // only the strides change.  SRC gives the producing stage's tiling (which wave owns which samples / channel slice).
 template <int L_SRC, int MT_W, int SW_SRC, int WN_SRC, int ROW_MUL, int DSS, int DSTR>
@@ -1033,10 +1030,9 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     w4n1_out(acc, m);
     const float tb = a.r0.tb[col];
     if constexpr (VH) {
-      if (MMD_ABL != 1)
-        gn_mish_quad1<CF::CM, CF::L, true>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; }, isc_a);
+      gn_mish_quad1<CF::CM, CF::L, true>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; }, isc_a);
     } else {
-      if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
+      gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
     }
   }
   TR(trb + 1);
@@ -1046,8 +1042,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   TR(trb + 2);
   {
     conv_h(a.r0.wb, a.ri[0].wa);
-    if (MMD_ABL != 1)
-      gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col], [&](int o, int r) { return res[o][r]; });
+    gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col], [&](int o, int r) { return res[o][r]; });
   }
   TR(trb + 4);
 
@@ -1062,7 +1057,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     {
       conv_h(R.wa, R.wb);
       const float tb = R.tb[col];
-      if (MMD_ABL != 1) gn_mish_quad1<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col], [&](int, int) { return tb; });
+      gn_mish_quad1<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col], [&](int, int) { return tb; });
     }
     TR(trb + 5);
     __syncthreads();
@@ -1070,8 +1065,7 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
     __syncthreads();
     {
       conv_h(R.wb, nullptr);
-      if (MMD_ABL != 1)
-        gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col], [&](int o, int r) { return res[o][r]; });
+      gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col], [&](int o, int r) { return res[o][r]; });
     }
     TR(trb + 6);
   }
@@ -1294,7 +1288,6 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
   auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc,
                 const float (&inv_dyn)[2], float act_s) {
     constexpr bool SCALED = decltype(scaled)::value;
-    if (MMD_ABL == 1) return;
     const float bb = b[col], gg = g[col], ee = be[col], is = SCALED ? isc[col] : 1.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -1500,7 +1493,6 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
     constexpr bool SCALED = decltype(scaled)::value;
     const float bb[2] = {b[c0], b[c0 + 1]}, gg[2] = {g[c0], g[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
     const float is[2] = {SCALED ? isc[c0] * inv_dyn : 1.f, SCALED ? isc[c0 + 1] * inv_dyn : 1.f};
-    if (MMD_ABL == 1) return;
     if (tb) {
       const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
       gn_mish_pair16<SCALED, true>(acc[0], acc[1], bb, gg, ee, is, act_scale(act_s), [&](int, int) { return t0; },
@@ -1696,7 +1688,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       const int c0 = lane & 15, c1 = c0 + 16;
       const float bb[2] = {f.bias[c0], f.bias[c1]}, gg[2] = {f.gamma[c0], f.gamma[c1]}, ee[2] = {f.beta[c0], f.beta[c1]};
-      if (MMD_ABL != 1) gn_mish_quad<32, 64>(q, bb, gg, ee, [](int, int) { return 0.f; });
+      gn_mish_quad<32, 64>(q, bb, gg, ee, [](int, int) { return 0.f; });
     }
     // wave = sample: the y tile goes over the wave's OWN slab region (stride FIN_SS), so no other wave is affected
     slab_sync<true>();
@@ -2116,10 +2108,32 @@ struct mmd_unet_s {
 
 // caller-owned event-pair pool (include/mmd_amd_debug.h); the unet handle itself is immutable after creation
 struct mmd_profiler_s {
-  int stride = 1;
-  std::vector<hipEvent_t> ev;
-  size_t used = 0, seen = 0;
+  int stride = 1, window = 1, period = 0;   // launch i of a period is bracketed iff (i / window) % stride == 0
+  std::vector<hipEvent_t> ev;               // event pairs, in bracketing order
+  std::vector<int> kind;                    // per pair: MMD_PROF_UNET / MMD_PROF_STEP_GUIDED / MMD_PROF_STEP_PLAIN
+  hipEvent_t base = nullptr;                // recorded with the first bracket: origin of the interval clock
+  size_t used = 0;                          // events handed out
+  size_t seen[2] = {0, 0};                  // launches counted: UNet, step kernel (the same steps of both are bracketed)
 };
+
+namespace mmd {
+// counter 0: UNet launches, 1: step-kernel launches.  Both are issued once per (step, stream chunk) in the same order, so
+// the same steps of both are bracketed.
+bool prof_begin(mmd_profiler_t prof, int counter, int kind, hipStream_t st) {
+  if (!prof) return false;
+  const size_t i = prof->period > 0 ? prof->seen[counter] % (size_t)prof->period : prof->seen[counter];
+  ++prof->seen[counter];
+  if (((i / (size_t)prof->window) % (size_t)prof->stride) != 0 || prof->used + 2 > prof->ev.size()) return false;
+  if (prof->used == 0) (void)hipEventRecord(prof->base, st);
+  (void)hipEventRecord(prof->ev[prof->used], st);
+  prof->kind[prof->used / 2] = kind;
+  return true;
+}
+void prof_end(mmd_profiler_t prof, hipStream_t st) {
+  (void)hipEventRecord(prof->ev[prof->used + 1], st);
+  prof->used += 2;
+}
+}  // namespace mmd
 
 namespace mmd {
 
@@ -2365,10 +2379,9 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
   a.fin.w1_pk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
   a.fin.w1_bias = u->blob + u->fin_b1;
-  const bool bracket = prof && (prof->seen++ % prof->stride) == 0 && prof->used + 2 <= prof->ev.size();
-  if (bracket) (void)hipEventRecord(prof->ev[prof->used], st);
+  const bool bracket = prof_begin(prof, 0, MMD_PROF_UNET, st);
   hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
-  if (bracket) { (void)hipEventRecord(prof->ev[prof->used + 1], st); prof->used += 2; }
+  if (bracket) prof_end(prof, st);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -2395,10 +2408,22 @@ double mmd_unet_f16x2_flops_per_trajectory(void) {
 }
 
 int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride) {
+  return mmd_profiler_create_windowed(out, max_launches, stride, 1, 0);
+}
+
+int mmd_profiler_create_windowed(mmd_profiler_t* out, int max_launches, int stride, int window, int period) {
   MMD_REQUIRE(out && max_launches > 0, "mmd_profiler_create: bad arguments");
   auto* p = new mmd_profiler_s();
   p->stride = stride > 0 ? stride : 1;
+  p->window = window > 0 ? window : 1;
+  p->period = period > 0 ? period : 0;
+  if (hipEventCreate(&p->base) != hipSuccess) {
+    set_error("mmd_profiler_create: hipEventCreate failed");
+    delete p;
+    return 1;
+  }
   p->ev.resize((size_t)2 * max_launches);
+  p->kind.assign((size_t)max_launches, 0);
   for (auto& e : p->ev)
     if (hipEventCreate(&e) != hipSuccess) {
       set_error("mmd_profiler_create: hipEventCreate failed");
@@ -2414,7 +2439,24 @@ int mmd_profiler_destroy(mmd_profiler_t p) {
   if (!p) return 0;
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
+  if (p->base) (void)hipEventDestroy(p->base);
   delete p;
+  return 0;
+}
+
+int mmd_profiler_intervals(mmd_profiler_t p, int kind, double* start_ms, double* end_ms, int cap, int* n_out) {
+  MMD_REQUIRE(p && start_ms && end_ms && n_out, "mmd_profiler_intervals: NULL argument");
+  int cnt = 0;
+  for (size_t i = 0; i + 1 < p->used && cnt < cap; i += 2) {
+    if (p->kind[i / 2] != kind) continue;
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, p->base, p->ev[i]) == hipSuccess && hipEventElapsedTime(&b, p->base, p->ev[i + 1]) == hipSuccess) {
+      start_ms[cnt] = a;
+      end_ms[cnt] = b;
+      ++cnt;
+    }
+  }
+  *n_out = cnt;
   return 0;
 }
 
@@ -2424,11 +2466,12 @@ int mmd_profiler_read(mmd_profiler_t p, double* mean_ms, int* n_launches) {
   int cnt = 0;
   for (size_t i = 0; i + 1 < p->used; i += 2) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+    if (p->kind[i / 2] == MMD_PROF_UNET && hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
   }
   *mean_ms = cnt ? tot / cnt : 0.0;
   *n_launches = cnt;
   p->used = 0;
+  p->seen[0] = p->seen[1] = 0;
   return 0;
 }
 

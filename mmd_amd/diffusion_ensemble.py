@@ -91,7 +91,7 @@ class DiffusionsEnsemble:
             chains[m] = torch.empty((n_total + 1,) + tuple(shape), dtype=torch.float32, device=device) if return_chain else None
             keep.append((hard, sd, gd, noise_m))
             t = tiles[j]
-            t.unet = model.model.handle(model.n_diffusion_steps)
+            t.unet = model.model.handle(model.n_diffusion_steps, device)
             t.sampler = C.pointer(sd)
             t.guide = C.pointer(gd) if gd is not None else None
             t.x_dev, t.hard_dev = x[m].data_ptr(), hard.data_ptr()

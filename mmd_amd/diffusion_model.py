@@ -162,7 +162,7 @@ class GaussianDiffusionModel:
         if seed is None:
             seed = next_stream_seed(self.seed)
         _lib.check(lib.mmd_p_sample_loop(
-            self.model.handle(self.n_diffusion_steps), C.byref(s), C.byref(gd) if gd is not None else None,
+            self.model.handle(self.n_diffusion_steps, device), C.byref(s), C.byref(gd) if gd is not None else None,
             x.data_ptr(), hard.data_ptr(), n_robots, B_total // n_robots, n_diffusion_steps,
             n_diffusion_steps_without_noise, init_noise, step_noise.data_ptr() if step_noise is not None else None,
             C.c_uint64(seed), chain.data_ptr() if chain is not None else None, ws.data_ptr(), ws.numel(),
@@ -208,7 +208,7 @@ class GaussianDiffusionModel:
         if seed is None:
             seed = next_stream_seed(self.seed)
         _lib.check(lib.mmd_ddim_sample(
-            self.model.handle(self.n_diffusion_steps), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
+            self.model.handle(self.n_diffusion_steps, device), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
             C.byref(gd) if gd is not None else None, x.data_ptr(), hard.data_ptr(), n_robots, B_total // n_robots,
             init_noise, C.c_uint64(seed), chain.data_ptr() if chain is not None else None, ws.data_ptr(), ws.numel(),
             _lib.current_stream_ptr()))
@@ -231,7 +231,7 @@ class GaussianDiffusionModel:
         if seed is None:
             seed = next_stream_seed(self.seed)
         _lib.check(_lib.load().mmd_ddpm_step(
-            self.model.handle(self.n_diffusion_steps), C.byref(s), C.byref(gd) if gd is not None else None,
+            self.model.handle(self.n_diffusion_steps, x.device), C.byref(s), C.byref(gd) if gd is not None else None,
             _lib.require_gpu(x, "x"), hard.data_ptr(), n_robots, B_total // n_robots, int(i),
             _lib.require_gpu(noise.contiguous(), "noise") if noise is not None else None, C.c_uint64(seed),
             C.c_uint32(int(i) & 0xFFFFFFFF), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))

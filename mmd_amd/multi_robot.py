@@ -28,11 +28,18 @@ def shard_range(n_robots, rank, world_size):
     return rank * n_local, n_local
 
 
-def all_gather_paths(paths_local, world_size, group=None):
-    """[n_local,H,2] -> [n_local*world_size,H,2], rank-major (== robot order).  One collective per planning round."""
+def all_gather_paths(paths_local, world_size, group=None, force_collective=False):
+    """[n_local,H,2] -> [n_local*world_size,H,2], rank-major (== robot order).  One collective per planning round.
+    `force_collective` runs the collective even in a one-rank group (the hardware test of the RCCL branch)."""
     import torch.distributed as dist
-    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
+    if world_size == 1 and not force_collective:
+        # a single-rank sampler never issues a collective, whether or not a (larger) process group exists around it
         return paths_local
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("all_gather_paths: world_size > 1 needs an initialised torch.distributed process group")
+    if dist.get_world_size(group) != world_size:
+        raise ValueError(f"all_gather_paths: world_size={world_size} but the process group has "
+                         f"{dist.get_world_size(group)} ranks")
     if paths_local.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no device collectives: stage through the host (CPU tests / single-GPU rehearsal of the N>1 path)
         parts = [torch.empty_like(paths_local, device="cpu") for _ in range(world_size)]
@@ -48,7 +55,8 @@ class MultiRobotSampler:
     def __init__(self, model, starts, goals, env_id="EnvEmpty2D", n_samples=64, rank=0, world_size=1,
                  norm_mins=synth.NORM_MINS, norm_maxs=synth.NORM_MAXS, n_guide_steps=20,
                  start_guide_steps_fraction=0.5, n_diffusion_steps_without_noise=1,
-                 weight_grad_cost_soft_constraints=2e-2, radius=VERTEX_CONSTRAINT_RADIUS, device="cuda", group=None):
+                 weight_grad_cost_soft_constraints=2e-2, radius=VERTEX_CONSTRAINT_RADIUS, device="cuda", group=None,
+                 n_streams=0):
         self.model = model
         self.n_robots = starts.shape[0]
         self.rank, self.world_size, self.group = rank, world_size, group
@@ -69,6 +77,7 @@ class MultiRobotSampler:
         self.t_start_guide = ceil(start_guide_steps_fraction * model.n_diffusion_steps)
         self.n_extra = n_diffusion_steps_without_noise
         self.w_soft, self.radius = weight_grad_cost_soft_constraints, radius
+        self.n_streams = n_streams      # mmd_sampler_desc.n_streams (0 = the library's choice: 2 chunks from 2048 trajectories)
 
     def set_other_paths(self, paths_all):
         """paths_all [N,H,2] un-normalised best paths of ALL robots (this device) or None (no inter-robot term)."""
@@ -87,7 +96,7 @@ class MultiRobotSampler:
             return_chain=return_chain, sample_fn=ddpm_sample_fn, guide=self.guide, n_guide_steps=self.n_guide_steps,
             t_start_guide=self.t_start_guide, noise_std_extra_schedule_fn=lambda t: 0.5,
             n_diffusion_steps_without_noise=self.n_extra, warm_start_path_b=x_init, step_noise=step_noise, seed=seed,
-            traj_index_base=self.robot0 * self.n_samples, device=self.device)
+            traj_index_base=self.robot0 * self.n_samples, device=self.device, n_streams=self.n_streams)
 
     def unnormalize(self, trajs_normalized):
         nz = self.dataset.normalizer

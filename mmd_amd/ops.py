@@ -9,6 +9,7 @@ resident SDF texture and constraint tables).  Ops receive them as integer tokens
 holds weak references, so a token dies with its object.
 """
 import ctypes as C
+import itertools
 import weakref
 
 import torch
@@ -16,12 +17,20 @@ import torch
 from . import _lib
 
 _REGISTRY = weakref.WeakValueDictionary()
+_NEXT_TOKEN = itertools.count(1)
 
 
 def register(obj) -> int:
-    """Token for a GaussianDiffusionModel / TemporalUnet / GuideManagerTrajectoriesWithVelocity to pass to the ops."""
-    _REGISTRY[id(obj)] = obj
-    return id(obj)
+    """Token for a GaussianDiffusionModel / TemporalUnet / GuideManagerTrajectoriesWithVelocity to pass to the ops.
+    Tokens come from a process-wide counter and are stored on the object (registering twice returns the same token), so
+    a token is never reused: after its object is gone the ops raise "expired token" instead of resolving to whatever
+    CPython later allocated at the same address."""
+    tok = getattr(obj, "_mmd_amd_op_token", None)
+    if tok is None:
+        tok = next(_NEXT_TOKEN)
+        obj._mmd_amd_op_token = tok
+    _REGISTRY[tok] = obj
+    return tok
 
 
 def _get(token, what):
@@ -45,7 +54,7 @@ def unet_forward(x: torch.Tensor, t: int, n_timesteps: int, unet: int) -> torch.
     model = _get(unet, "unet")
     out = torch.empty_like(x)
     ws = model.workspace(x.shape[0], x.device)
-    _lib.check(_lib.load().mmd_unet_forward(model.handle(n_timesteps), x.data_ptr(), int(t), out.data_ptr(), x.shape[0],
+    _lib.check(_lib.load().mmd_unet_forward(model.handle(n_timesteps, x.device), x.data_ptr(), int(t), out.data_ptr(), x.shape[0],
                                             ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))
     return out
 
@@ -90,7 +99,7 @@ def p_sample_loop(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: in
         raise RuntimeError("mmd_amd::p_sample_loop: step_noise must be [n_steps_total, n_traj, 64, 4]")
     ws = m.model.workspace(x.shape[0], x.device, sampler=True)
     _lib.check(_lib.load().mmd_p_sample_loop(
-        m.model.handle(m.n_diffusion_steps), C.byref(s), C.byref(gd) if gd is not None else None, x.data_ptr(),
+        m.model.handle(m.n_diffusion_steps, x.device), C.byref(s), C.byref(gd) if gd is not None else None, x.data_ptr(),
         _lib.require_gpu(hard, "hard"), int(n_robots), x.shape[0] // int(n_robots), int(n_steps), int(n_steps_without_noise),
         int(bool(init_noise)), _lib.require_gpu(step_noise, "step_noise") if step_noise is not None else None,
         C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), chain.data_ptr() if return_chain else None, ws.data_ptr(), ws.numel(),
@@ -123,7 +132,7 @@ def ddim_sample(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: int,
              else torch.empty(0, dtype=torch.float32, device=x.device))
     ws = m.model.workspace(x.shape[0], x.device, sampler=True)
     _lib.check(_lib.load().mmd_ddim_sample(
-        m.model.handle(m.n_diffusion_steps), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
+        m.model.handle(m.n_diffusion_steps, x.device), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
         C.byref(gd) if gd is not None else None, x.data_ptr(), _lib.require_gpu(hard, "hard"), int(n_robots),
         x.shape[0] // int(n_robots), int(bool(init_noise)), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
         chain.data_ptr() if return_chain else None, ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))

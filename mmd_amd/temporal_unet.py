@@ -48,8 +48,8 @@ class TemporalUnet:
         self.max_timesteps = max_timesteps
         self._sd = None
         self._sd_hash = None
-        self._models = {}               # n_timesteps -> _DeviceModel (shared through _DEVICE_MODELS)
-        self._ws = None
+        self._models = {}               # (n_timesteps, device index) -> _DeviceModel (shared through _DEVICE_MODELS)
+        self._ws = {}                   # (device index, stream) -> scratch buffer
 
     # ---- parameters -------------------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -74,15 +74,28 @@ class TemporalUnet:
     def state_dict(self):
         return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._sd.items())
 
-    def handle(self, n_timesteps=None):
+    @staticmethod
+    def _device_index(device):
+        if device is None:
+            return torch.cuda.current_device()
+        d = torch.device(device)
+        return torch.cuda.current_device() if d.index is None else d.index
+
+    def handle(self, n_timesteps=None, device=None):
         """Device model (packed weights + time-embedding table for t in [0, n_timesteps)), shared by every TemporalUnet
-        of this process that holds the same parameters on the same device."""
+        of this process that holds the same parameters on the same device.  `device`: where the caller's tensors live
+        (default: the current device); one TemporalUnet may serve several devices, each gets its own handle."""
         global N_DEVICE_MODELS_CREATED
         if self._sd is None:
             raise RuntimeError("TemporalUnet has no parameters: call load_state_dict first")
-        T = int(n_timesteps) if n_timesteps is not None else (max(self._models) if self._models else self.max_timesteps)
-        if T not in self._models:
-            key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, torch.cuda.current_device())
+        dev = self._device_index(device)
+        if n_timesteps is not None:
+            T = int(n_timesteps)
+        else:
+            have = [t for (t, d) in self._models if d == dev]
+            T = max(have) if have else self.max_timesteps
+        if (T, dev) not in self._models:
+            key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, dev)
             dm = _DEVICE_MODELS.get(key)
             if dm is None:
                 lib = _lib.load()
@@ -90,20 +103,27 @@ class TemporalUnet:
                 ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in self._sd.values()])
                 numels = (C.c_int64 * n)(*[v.size for v in self._sd.values()])
                 h = C.c_void_p()
-                _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), T, ptrs, numels, n,
-                                               _lib.current_stream_ptr()))
+                with torch.cuda.device(dev):
+                    _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), T, ptrs, numels, n,
+                                                   _lib.current_stream_ptr()))
                 N_DEVICE_MODELS_CREATED += 1
                 dm = _DeviceModel(h)
                 _DEVICE_MODELS[key] = dm
-            self._models[T] = dm
-        return self._models[T].handle
+            self._models[(T, dev)] = dm
+        return self._models[(T, dev)].handle
 
     def workspace(self, n_traj, device, sampler=False):
+        """Scratch for one call: one buffer per (device, stream), so calls issued on different streams never share the
+        eps block (grown on demand, reused by later calls on the same stream)."""
         lib = _lib.load()
-        nbytes = (lib.mmd_sampler_workspace_bytes if sampler else lib.mmd_unet_workspace_bytes)(self.handle(), n_traj)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != torch.device(device):
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self._ws
+        dev = self._device_index(device)
+        nbytes = (lib.mmd_sampler_workspace_bytes if sampler else lib.mmd_unet_workspace_bytes)(self.handle(device=dev), n_traj)
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", dev))
+            self._ws[key] = ws
+        return ws
 
     # ---- forward ----------------------------------------------------------------------------------------------
     def forward(self, x, time, context=None):
@@ -115,7 +135,7 @@ class TemporalUnet:
         x = x.contiguous()
         out = torch.empty_like(x)
         ws = self.workspace(x.shape[0], x.device)
-        _lib.check(_lib.load().mmd_unet_forward(self.handle(), _lib.require_gpu(x, "x"), t, out.data_ptr(), x.shape[0],
+        _lib.check(_lib.load().mmd_unet_forward(self.handle(device=x.device), _lib.require_gpu(x, "x"), t, out.data_ptr(), x.shape[0],
                                                 ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))
         return out
 

@@ -48,7 +48,7 @@ def test_unet_forward_vs_oracle(n):
 
 @pytest.mark.parametrize("scale", [1e-3, 8.0])
 def test_unet_forward_input_range(scale):
-    """The k=5 convs run as Winograd F(2,5) in fp32: tiny and large inputs (x_T draws reach |x| ~ 4, the clamp keeps the
+    """The k=5 convs run as Winograd F(4,5) in fp32: tiny and large inputs (x_T draws reach |x| ~ 4, the clamp keeps the
     rest in [-1, 1]) stay at fp32-grade agreement with the direct-convolution oracle."""
     model = _gc().hip_model(100)
     sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
@@ -425,7 +425,7 @@ def test_run_inference_golden(name):
     1e-1..3e-1 rel. L2 on the constraint cases, 7e-7 for the unguided prior).  So the bound per row is
     max(1e-3, 1.5 * sens): the north-star 1e-3 wherever the reference itself is that reproducible, and "no further from
     the reference than the reference is from itself" elsewhere.  The sharp per-step statement is
-    test_single_step_teacher_forced_golden; every measured error lands in r02_parity.json."""
+    test_single_step_teacher_forced_golden; every measured error lands in r03_parity.json."""
     g = np.load(os.path.join(GOLDEN, f"g6_sample_{name}.npz"))
     case = cases.sample_case(name)
     xT, steps = cases.sample_inputs(case)

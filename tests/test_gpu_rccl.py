@@ -23,7 +23,7 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 assert dist.get_backend() == "nccl"
 starts, goals = synth.start_goal_circle(32, 0.8)
 paths = torch.from_numpy(synth.straight_line_paths(starts, goals, 64)).cuda()
-out = all_gather_paths(paths, 1)
+out = all_gather_paths(paths, 1, force_collective=True)
 torch.cuda.synchronize()
 assert out.data_ptr() != paths.data_ptr(), "the collective must have run (a fresh output tensor)"
 assert torch.equal(out, paths)

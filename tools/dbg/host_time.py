@@ -13,7 +13,7 @@ s = MultiRobotSampler(model, starts, goals, n_samples=B)
 paths = torch.from_numpy(synth.straight_line_paths(starts, goals, 64)).cuda()
 s.set_other_paths(paths)
 for ns in (1, 2, 1, 2):
-    os.environ["MMD_AMD_STREAMS"] = str(ns)
+    s.n_streams = ns
     s.sample(seed=1); torch.cuda.synchronize()
     t0 = time.perf_counter(); s.sample(seed=2); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"streams {ns}: host enqueue {1e3*(t1-t0):.1f} ms, total {1e3*(t2-t0):.1f} ms")

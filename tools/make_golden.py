@@ -289,7 +289,7 @@ def g7():
 def g8():
     """2-tile DiffusionsEnsemble.p_sample_loop (diffusion_ensemble.py:55-106): tiles at x-offsets 0 and 2, the end of
     tile 0 cross-conditioned onto the start of tile 1 (sample_functions.py:17-31).  Stores every chain row of both tiles
-    and, like g6, the reference's own sensitivity `sens` (per row, max over 6 draws) to a relative 1e-6 perturbation of
+    and, like g6, the reference's own sensitivity `sens` (per row, max over 24 draws; `sens_draws` keeps all of them) to a relative 1e-6 perturbation of
     the UNet output."""
     from mmd.models.diffusion_models.diffusion_ensemble import DiffusionsEnsemble
     T, B = 25, 4
