@@ -268,7 +268,8 @@ struct ChainArgs {
   const float4* wa0_c1;                  // conv A pack of the second input chunk (C1 > 0)
   const uint4* wa0_c1_bf;                // ... its f16x2 form (ups.0: vbu_taps)
   const float* br;                       // bias of the 1x1 residual conv (its weights ride in the conv A packs)
-  const float* isr;                      // [C_out] inverse scale of the residual weights in the f16x2 packs (ups.0)
+  const float* isr;                      // [C_out] inverse scale of the residual weights in the f16x2 packs
+  const uint4* wres_bf;                  // f16x2 pack of the 1x1 residual conv where it runs as its own GEMM (downs.2)
   RtbPtrs ri[MAX_IDENT];
   const float4* wt; const float* bt;     // tail conv pack(s), bias
   int n;
@@ -280,7 +281,9 @@ struct ChainCfg {
   static constexpr int MID_AFTER = MID_AFTER_, TAIL = TAIL_;
   static constexpr int C0P = (C0 + 7) / 8 * 8, C1P = (C1 + 7) / 8 * 8;   // (4-channel input: 2 k-steps of 4 = the weight ring's depth)
   static constexpr int CXP = C0P > C1P ? C0P : C1P;
-  static constexpr int XSTR = CXP + 1, HSTR = CM + 1;
+  // (downs.2 + mid, the stage without a tail: its row-form x slab is only read by rowform_to_vslab, two channels per
+  // ds_read_b64 -- an even row stride keeps them 8-byte aligned)
+  static constexpr int XSTR = TAIL == TAIL_NONE ? CXP + 2 : CXP + 1, HSTR = CM + 1;
   static constexpr int WN = CM / 32, WM = 4 / WN;
   static constexpr int RW = 32 * MT_W, SW = RW / L, SPB = WM * SW, SROWS = L + 4;
   static constexpr bool SHARE = RES0 == RES_IDENT;         // x is staged straight into the H slab
@@ -744,40 +747,50 @@ __device__ __forceinline__ void vb_three(f32x4& x, const u32x4 (&a)[2], const u3
   c = mfma_h(a[0], b[0], c);
   x = c;
 }
+// Geometry of a phase slab of C channels at L = 16 (16 rows): C / 8 channel blocks; K chunk kc (of KC = C / 32), lane group j
+// = block kc + KC j at byte j * G + kc * X of a (piece, slot) region of PS bytes -- the blocks of one chunk lie G = a
+// multiple of 256 B apart (conflict-free b128 reads), those of one lane group X = 256 + 32 B.
+template <int C> struct VbGeo {
+  static constexpr int KC = C / 32, X = VB_CB, G = (KC * VB_CB + 255) / 256 * 256, PS = 4 * G, STEPS = 4 * KC;
+  static constexpr int BYTES = 8 * PS, FRAGS = 2 * STEPS * 2;
+};
+static_assert(VbGeo<128>::G == VB_CG && VbGeo<128>::PS == VB_PS && VbGeo<128>::FRAGS == VB_FRAGS, "128-channel geometry");
 // A step = 6 MFMAs: the wave's two n-tiles (two accumulator streams, one after the other) at chunk step / 4, slot step % 4,
 // on one set of A fragments.
+template <class GEO>
 __device__ __forceinline__ void vb_load_b(u32x4 (&b)[2][2], const u32x4* const (&w)[2], int ph, int step) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const u32x4* p = w[t] + ((ph * 16 + step) * 2) * 64;
+    const u32x4* p = w[t] + ((ph * GEO::STEPS + step) * 2) * 64;
 #pragma unroll
     for (int q = 0; q < 2; ++q) b[t][q] = p[q * 64];
   }
 }
+template <class GEO>
 __device__ __forceinline__ void vb_load_a(u32x4 (&a)[2], const char* va, int step) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step % 4) * VB_PS + (step / 4) * VB_CB);
+  for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step % 4) * GEO::PS + (step / 4) * GEO::X);
 }
 // the first VB_RD steps' weights of phase PH into the ring (issued ahead of the barrier that publishes the slab)
 #ifndef MMD_VB_RD
 #define MMD_VB_RD 2
 #endif
 constexpr int VB_RD = MMD_VB_RD;           // ring depth in steps (4 KB per wave and step in flight)
-template <int PH>
+template <class GEO, int PH>
 __device__ __forceinline__ void vb_ring_load(u32x4 (&b)[VB_RD][2][2], const u32x4* const (&w)[2]) {
 #pragma unroll
-  for (int i = 0; i < VB_RD; ++i) vb_load_b(b[i], w, PH, i);
+  for (int i = 0; i < VB_RD; ++i) vb_load_b<GEO>(b[i], w, PH, i);
   MMD_PIN_LOADS();
 }
-// m[tile][position] of phase PH's four positions = conv over the 128 channels of the slab; va = slab + the lane's A
-// offset (channel block lane >> 4, row lane & 15); w[tile] = the tile's pack + lane; b = ring (vb_ring_load)
-template <int PH>
+// m[tile][position] of phase PH's four positions = conv over the channels of the slab; va = slab + the lane's A offset
+// (lane group lane >> 4, row lane & 15); w[tile] = the tile's pack + lane; b = ring (vb_ring_load)
+template <class GEO, int PH>
 __device__ __forceinline__ void vb_taps(f32x4 (&m)[2][8], const char* va, const u32x4* const (&w)[2], u32x4 (&b)[VB_RD][2][2]) {
   u32x4 a[2][2];
-  vb_load_a(a[0], va, 0);
+  vb_load_a<GEO>(a[0], va, 0);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    if (i + 1 < 16) vb_load_a(a[(i + 1) & 1], va, i + 1);
+  for (int i = 0; i < GEO::STEPS; ++i) {
+    if (i + 1 < GEO::STEPS) vb_load_a<GEO>(a[(i + 1) & 1], va, i + 1);
     MMD_PIN_LOADS();
     const int pos = vb_pos(PH, i % 4);
     if (i / 4 == 0) {
@@ -787,8 +800,105 @@ __device__ __forceinline__ void vb_taps(f32x4 (&m)[2][8], const char* va, const 
       vb_three<false>(m[0][pos], a[i & 1], b[i % VB_RD][0]);
       vb_three<false>(m[1][pos], a[i & 1], b[i % VB_RD][1]);
     }
-    if (i + VB_RD < 16) vb_load_b(b[i % VB_RD], w, PH, i + VB_RD);
+    if (i + VB_RD < GEO::STEPS) vb_load_b<GEO>(b[i % VB_RD], w, PH, i + VB_RD);
     MMD_PIN_LOADS();
+  }
+}
+
+// ---- a stage's FIRST conv (conv A of its first RTB) as f16x2: the input arrives as a row-form fp32 slab [sample][L + 4][STR]
+// (2-row zero halo) from the previous stage's strided conv; all 256 threads turn it into the conv's phase slab -- V = B^T d
+// of phase PH's four positions, scaled by the sample's dynamic input scale, two pieces -- and (with phase 0) into the RAW slab
+// of the stage's 1x1 residual conv: the untransformed positions themselves, laid out as four M tiles o = position % 4 with
+// rows (sample, quad), so that the residual GEMM's C/D fragment is the res tile (res[o][quad] of (sample, channel)).  One
+// item = (sample, quad, channel pair): 8 ds_read_b64, ~40 VALU, 8 (+ 8) ds_write_b32 -- once per workgroup, where the
+// in-loop transform of the fp32 form cost every wave 26 VALU + 8 ds_read_b32 per k-step and n-tile.
+template <int PH>
+__device__ __forceinline__ void w4_phase(float (&v)[4], const float (&d)[8]) {   // slots 0..3 of phase PH (w4_transform's rows)
+  if constexpr (PH == 0) {
+    const float e1 = fmaf(-4.25f, d[4], d[2]) + d[6], o1 = fmaf(-4.25f, d[3], d[1]) + d[5];
+    v[0] = fmaf(5.25f, d[2] - d[4], d[6] - d[0]);
+    v[1] = e1 + o1;
+    v[2] = e1 - o1;
+    v[3] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
+  } else {
+    const float e2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), o2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
+    const float e3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), o3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
+    v[0] = e2 + o2;
+    v[1] = e2 - o2;
+    v[2] = e3 + o3;
+    v[3] = e3 - o3;
+  }
+}
+template <int C> struct VrGeo {               // raw slab of the residual GEMM: 4 M tiles x 16 rows x 16 B per channel block
+  static constexpr int KC = C / 32, X = 64 * 16 + 32, G = (KC * X + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
+};
+template <int PH, int C, int XSS, int XSTR>
+__device__ __forceinline__ void rowform_to_vslab(const float* xslab, char* vphase, char* vraw, const float* mx) {
+  using GEO = VbGeo<C>;
+  using GR = VrGeo<C>;
+  constexpr int CP2 = C / 2, ITEMS = 16 * CP2;      // (sample, quad) x channel pairs
+  static_assert(ITEMS % 256 == 0, "items per thread");
+#pragma unroll
+  for (int it = 0; it < ITEMS / 256; ++it) {
+    const int idx = it * 256 + threadIdx.x;
+    const int cp = idx % CP2, row = idx / CP2, smp = row >> 2, quad = row & 3;      // row = 4 * sample + quad = A row
+    const float4 p = *reinterpret_cast<const float4*>(mx + smp * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + smp * MX_SLOTS + 4);
+    const float sc = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)))).s;
+    const float* src = xslab + smp * XSS + 4 * quad * XSTR + 2 * cp;                 // slab row 4 quad = position 4 quad - 2
+    float d[8], e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 t = *reinterpret_cast<const float2*>(src + j * XSTR);
+      d[j] = t.x * sc;
+      e[j] = t.y * sc;
+    }
+    const int blk = cp >> 2, jg = blk / GEO::KC, kc = blk % GEO::KC;
+    char* dst = vphase + jg * GEO::G + kc * GEO::X + row * 16 + (cp & 3) * 4;
+    float v[4], w[4];
+    w4_phase<PH>(v, d);
+    w4_phase<PH>(w, e);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const F16Pair f = f16_split2(v[sl], w[sl]);
+      *reinterpret_cast<unsigned*>(dst + sl * GEO::PS) = f.hi;
+      *reinterpret_cast<unsigned*>(dst + (4 + sl) * GEO::PS) = f.lo;
+    }
+    if constexpr (PH == 0) {
+      char* dr = vraw + jg * GR::G + kc * GR::X + row * 16 + (cp & 3) * 4;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {                 // position 4 quad + o = slab row 4 quad + 2 + o -> M tile o
+        const F16Pair f = f16_split2(d[2 + o], e[2 + o]);
+        *reinterpret_cast<unsigned*>(dr + o * 256) = f.hi;
+        *reinterpret_cast<unsigned*>(dr + GR::PS + o * 256) = f.lo;
+      }
+    }
+  }
+}
+// res[tile][o] (C/D fragment of M tile o) = 1x1 conv over the raw slab's C channels; vr = raw slab + the lane's A offset
+// (lane group lane >> 4, row lane & 15); w[tile] = the tile's residual pack [chunk kc][piece] + lane
+template <int C>
+__device__ __forceinline__ void vr_taps(f32x4 (&res)[2][4], const char* vr, const u32x4* const (&w)[2]) {
+  using GR = VrGeo<C>;
+#pragma unroll
+  for (int kc = 0; kc < GR::KC; ++kc) {
+    u32x4 b[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) b[t][q] = w[t][(kc * 2 + q) * 64];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      u32x4 a[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const u32x4*>(vr + q * GR::PS + kc * GR::X + o * 256);
+      if (kc == 0) {
+        vb_three<true>(res[0][o], a, b[0]);
+        vb_three<true>(res[1][o], a, b[1]);
+      } else {
+        vb_three<false>(res[0][o], a, b[0]);
+        vb_three<false>(res[1][o], a, b[1]);
+      }
+    }
   }
 }
 
@@ -1213,7 +1323,7 @@ __device__ __forceinline__ void vbd_store(char* base, const f32x4 (&P)[4], const
   }
 }
 
-template <class CF, bool FIRST>
+template <class CF, bool FIRST, bool TAIL_MAX>
 __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[2][4],
                                               f32x4 (&mid)[2][4], f32x16 (&tout)[1], int trb) {
   static_assert((CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 && CF::RES0 == RES_CONV &&
@@ -1385,6 +1495,24 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
     const int r = lane & 31;
     int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
     mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
+    if constexpr (TAIL_MAX) {
+      // the next stage's first conv runs as f16x2 on this tile: per-sample |x| maxima for its dynamic input scale.  Registers
+      // 0..7 / 8..15 of the 32 x 32 C/D fragment are the wave's first / second sample; a sample is shared by the WN waves of
+      // its channel slices x 4 lane groups = MX_SLOTS partial maxima.
+      static_assert(CF::WN * 4 == MX_SLOTS && CF::SW == 2, "tail tile: two samples per wave");
+      float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        m0 = fmaxf(m0, fabsf(tout[0][r8]));
+        m1 = fmaxf(m1, fabsf(tout[0][8 + r8]));
+      }
+      m0 = row_max16(m0);
+      m1 = row_max16(m1);
+      if ((lane & 15) == 0) {
+        mx[(wm * 2) * MX_SLOTS + wn * 4 + (lane >> 4)] = m0;
+        mx[(wm * 2 + 1) * MX_SLOTS + wn * 4 + (lane >> 4)] = m1;
+      }
+    }
   }
   TR(trb + 5);
 }
@@ -1441,13 +1569,24 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
   static_assert(CF::L == 16 && CF::CM == 128 && CF::C0 == 64 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_NONE &&
                     CF::MID_AFTER >= 1, "downs.2 + mid blocks");
   const int c0 = 32 * wave + 2 * (lane & 15);                // the lane's channels c0 (tile 0), c0 + 1 (tile 1)
-  const int xbase = ((lane & 15) >> 2) * CF::XSS + 4 * (lane & 3) * CF::XSTR + (lane >> 4);   // A row lane & 15 = (sample, quad)
-  BQ<3> ring3[W4_RD];
-  auto wl3 = [&](int nq) {
-    return reinterpret_cast<const float*>(a.r0.wa) + ((size_t)nq * (CF::C0P / 4) * 64 + lane) * 12;
-  };
-  w4_ring_load<3>(ring3, wl3(2 * wave));
-  __syncthreads();                                           // the x slab (previous stage's tail tile) is staged
+  // conv A of the first RTB (64 -> 128) + the 1x1 residual conv, both f16x2: the row-form x slab (previous stage's tail
+  // tile) stays at the start of the LDS through both phases, its phase slab and the residual's raw slab follow it
+  using GA = VbGeo<CF::C0P>;
+  using GR = VrGeo<CF::C0P>;
+  constexpr int VA_OFF = (CF::SPB * CF::XSS * 4 + 255) / 256 * 256, VR_OFF = VA_OFF + GA::BYTES;
+  static_assert(VR_OFF + GR::BYTES <= MX_OFF * 4, "x slab + phase slab + raw slab must fit below the maxima");
+  char* const va_slab = reinterpret_cast<char*>(lds) + VA_OFF;
+  char* const vr_slab = reinterpret_cast<char*>(lds) + VR_OFF;
+  const u32x4* wpa[2];
+  const u32x4* wpr[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    wpa[h] = reinterpret_cast<const u32x4*>(a.r0.wa_bf) + (size_t)(2 * wave + h) * GA::FRAGS * 64 + lane;
+    wpr[h] = reinterpret_cast<const u32x4*>(a.wres_bf) + (size_t)(2 * wave + h) * (2 * GR::KC) * 64 + lane;
+  }
+  u32x4 ring_a[VB_RD][2][2];
+  vb_ring_load<GA, 0>(ring_a, wpa);
+  __syncthreads();                                           // the x slab (previous stage's tail tile) and its maxima are staged
   TR(trb + 0);
 
   f32x4 res[2][4];
@@ -1466,21 +1605,21 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
     f32x4 mb[2][8];
     u32x4 ring_b[VB_RD][2][2];
     TR(trb + 10);
-    vb_ring_load<0>(ring_b, wp);
+    vb_ring_load<VbGeo<128>, 0>(ring_b, wp);
     vb_store_pair<0>(vb_s, [&](int o, int r) { return acc[0][o][r]; }, [&](int o, int r) { return acc[1][o][r]; });
     TR(trb + 11);
     __syncthreads();
     TR(trb + 12);
-    vb_taps<0>(mb, vb_a, wp, ring_b);
+    vb_taps<VbGeo<128>, 0>(mb, vb_a, wp, ring_b);
     TR(trb + 13);
-    vb_ring_load<1>(ring_b, wp);
+    vb_ring_load<VbGeo<128>, 1>(ring_b, wp);
     __syncthreads();                                         // every wave is done reading the phase-0 slab
     TR(trb + 14);
     vb_store_pair<1>(vb_s, [&](int o, int r) { return acc[0][o][r]; }, [&](int o, int r) { return acc[1][o][r]; });
     TR(trb + 15);
     __syncthreads();
     TR(trb + 16);
-    vb_taps<1>(mb, vb_a, wp, ring_b);
+    vb_taps<VbGeo<128>, 1>(mb, vb_a, wp, ring_b);
     TR(trb + 17);
 #pragma unroll
     for (int h = 0; h < 2; ++h) w4n1_out(acc[h], mb[h]);
@@ -1526,20 +1665,33 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
     return ds.inv;
   };
 
-  // =================== RTB 0 (64 -> 128): conv A + the 1x1 residual conv on the fp32 MFMA, row-form x slab ===================
+  // =================== RTB 0 (64 -> 128): conv A + the 1x1 residual conv as f16x2 from the row-form x slab ===================
+  float inv_in;
   {
-    f32x4 m[8];
+    // the stage input is residual-stream data: dynamic per-sample scale from the maxima the previous stage's tail left in mx
+    const float4 p = *reinterpret_cast<const float4*>(mx + (lane >> 4) * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + (lane >> 4) * MX_SLOTS + 4);
+    inv_in = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)))).inv;
+    const char* const va = va_slab + (lane >> 4) * GA::G + (lane & 15) * 16;
+    const char* const vr = vr_slab + (lane >> 4) * GR::G + (lane & 15) * 16;
+    f32x4 mb[2][8];
+    rowform_to_vslab<0, CF::C0P, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
+    __syncthreads();
+    vb_taps<GA, 0>(mb, va, wpa, ring_a);
+    vb_ring_load<GA, 1>(ring_a, wpa);
+    vr_taps<CF::C0P>(res, vr, wpr);
+    __syncthreads();                                         // every wave is done reading the phase-0 slab
+    rowform_to_vslab<1, CF::C0P, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
+    __syncthreads();
+    vb_taps<GA, 1>(mb, va, wpa, ring_a);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const float br = a.br[c0 + h];
+      w4n1_out(acc[h], mb[h]);
+      const float br = a.br[c0 + h], isr = a.isr[c0 + h] * inv_in;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) res[h][o] = f32x4{br, br, br, br};
-      w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res[h], lds, xbase, wl3(2 * wave + h), ring3);
-      if (h == 0) w4_ring_load<3>(ring3, wl3(2 * wave + 1));
-      w4n1_out(acc[h], m);
+      for (int o = 0; o < 4; ++o) res[h][o] = res[h][o] * isr + br;
     }
   }
-  gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr, 1.f, a.r0.act_a);
+  gn(std::true_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
   TR(trb + 1);
   __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
   conv_hb(a.r0.wb_bf);
@@ -1597,7 +1749,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     f32x4 acc[2][4], mid[2][4];
     f32x16 t[1];
-    chain_body_db<CH_D0, true>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
+    chain_body_db<CH_D0, true, false>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
     __syncthreads();                                                       // the tail conv is done reading the H slab
     tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
@@ -1606,7 +1758,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     f32x4 acc[2][4];
     f32x16 t[1];
-    chain_body_db<CH_D1, false>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
+    chain_body_db<CH_D1, false, true>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
     __syncthreads();
     tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
@@ -1974,7 +2126,7 @@ static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int ci
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
               const int n = (t / 2) * 32 + 2 * (lane & 15) + (t & 1);   // interleaved tile pair of a wave (chain_body_d2)
-              const int ci = 8 * (4 * (lane >> 4) + kc) + j;            // chunk kc = channel blocks kc + 4 g
+              const int ci = 8 * (KC * (lane >> 4) + kc) + j;           // chunk kc, lane group g = channel block kc + KC g (VbGeo)
               uint16_t piece[2];
               f16_split_host(wino_u(w, cin, n, ci, vb_pos(ph, sl)), sc[n], piece);
               for (int q = 0; q < 2; ++q) {
@@ -1982,6 +2134,34 @@ static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int ci
                 out[(frag * 64 + lane) * 8 + j] = piece[q];
               }
             }
+  return base;
+}
+
+// f16x2 pack of a stage's 1x1 residual conv [cout][cin] for vr_taps: per n-tile [chunk kc][piece q][lane] x 16 B, columns and
+// channels as in pack_vb; isc_off = offset of the [cout] inverse channel scales.
+static size_t pack_vr(std::vector<float>& blob, const float* wres, int cout, int cin, size_t& isc_off) {
+  std::vector<float> sc(cout);
+  for (int n = 0; n < cout; ++n) {
+    float m = 0.f;
+    for (int ci = 0; ci < cin; ++ci) m = fmaxf(m, fabsf(wres[(size_t)n * cin + ci]));
+    sc[n] = f16_scale_for(m);
+  }
+  isc_off = push_inverse(blob, sc);
+  const size_t base = blob.size();
+  const int tiles = cout / 16, KC = cin / 32;
+  const size_t frags = (size_t)tiles * KC * 2;
+  blob.resize(base + (frags + 8) * 64 * 4, 0.f);
+  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
+  for (int t = 0; t < tiles; ++t)
+    for (int kc = 0; kc < KC; ++kc)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int n = (t / 2) * 32 + 2 * (lane & 15) + (t & 1);
+          const int ci = 8 * (KC * (lane >> 4) + kc) + j;
+          uint16_t piece[2];
+          f16_split_host(wres[(size_t)n * cin + ci], sc[n], piece);
+          for (int q = 0; q < 2; ++q) out[((((size_t)t * KC + kc) * 2 + q) * 64 + lane) * 8 + j] = piece[q];
+        }
   return base;
 }
 
@@ -2090,7 +2270,7 @@ static float static_act_scale(const float* gamma, const float* beta, const std::
 }
 
 struct ConvW { size_t wpk, bias, gamma, beta, wbf, isc; };   // wbf / isc: f16x2 pack and its inverse channel scales
-struct RtbW { ConvW a, b; size_t res_bias, res_isc; int tb_off; size_t a_c1, a_c1_bf; float act_a; };
+struct RtbW { ConvW a, b; size_t res_bias, res_isc, res_bf; int tb_off; size_t a_c1, a_c1_bf; float act_a; };
 
 }  // namespace mmd
 
@@ -2171,6 +2351,7 @@ static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb
   a.wa0_c1_bf = w0.a_c1_bf ? reinterpret_cast<const uint4*>(u->blob + w0.a_c1_bf) : nullptr;
   a.br = u->blob + w0.res_bias;
   a.isr = w0.res_isc ? u->blob + w0.res_isc : nullptr;
+  a.wres_bf = w0.res_bf ? reinterpret_cast<const uint4*>(u->blob + w0.res_bf) : nullptr;
   for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, set[rtb[1 + k]], t);
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
   return a;
@@ -2249,6 +2430,9 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres);
       W.a_c1 = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
+    } else if (r == 4) {      // downs.2's first RTB: conv A (64 -> 128) and the 1x1 residual conv as f16x2 (rowform_to_vslab)
+      W.a.wbf = pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);
+      W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc);
     } else if ((d1 || d2) && R.cin == R.cout) {
       W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);   // dynamic input scale
     } else {
@@ -2404,7 +2588,8 @@ int mmd_debug_set_trace(void* dev_ptr) {
 double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
 double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }
 double mmd_unet_f16x2_flops_per_trajectory(void) {
-  return 4 * 3 * wino4_flops(32, 32) + 2 * 3 * wino4_flops(64, 64) + 7 * wino4_flops(128, 128) + wino4_flops(256, 64) * 14.0 / 8.0;
+  return 4 * 3 * wino4_flops(32, 32) + 2 * 3 * wino4_flops(64, 64) + 7 * wino4_flops(128, 128) + wino4_flops(256, 64) * 14.0 / 8.0 +
+         wino4_flops(64, 128) + direct_flops(1, 64, 128, 16);   // downs.2's conv A and its 1x1 residual GEMM
 }
 
 int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride) {
