@@ -281,9 +281,9 @@ struct ChainCfg {
   static constexpr int MID_AFTER = MID_AFTER_, TAIL = TAIL_;
   static constexpr int C0P = (C0 + 7) / 8 * 8, C1P = (C1 + 7) / 8 * 8;   // (4-channel input: 2 k-steps of 4 = the weight ring's depth)
   static constexpr int CXP = C0P > C1P ? C0P : C1P;
-  // (downs.2 + mid, the stage without a tail: its row-form x slab is only read by rowform_to_vslab, two channels per
-  // ds_read_b64 -- an even row stride keeps them 8-byte aligned)
-  static constexpr int XSTR = TAIL == TAIL_NONE ? CXP + 2 : CXP + 1, HSTR = CM + 1;
+  // (downs.1 / downs.2: their row-form x slab is only read by rowform_to_vslab, two channels per ds_read_b64 -- an even row
+  // stride keeps them 8-byte aligned)
+  static constexpr int XSTR = (C0 % 32 == 0 && C1 == 0) ? CXP + 2 : CXP + 1, HSTR = CM + 1;
   static constexpr int WN = CM / 32, WM = 4 / WN;
   static constexpr int RW = 32 * MT_W, SW = RW / L, SPB = WM * SW, SROWS = L + 4;
   static constexpr bool SHARE = RES0 == RES_IDENT;         // x is staged straight into the H slab
@@ -750,10 +750,11 @@ __device__ __forceinline__ void vb_three(f32x4& x, const u32x4 (&a)[2], const u3
 // Geometry of a phase slab of C channels at L = 16 (16 rows): C / 8 channel blocks; K chunk kc (of KC = C / 32), lane group j
 // = block kc + KC j at byte j * G + kc * X of a (piece, slot) region of PS bytes -- the blocks of one chunk lie G = a
 // multiple of 256 B apart (conflict-free b128 reads), those of one lane group X = 256 + 32 B.
-template <int C> struct VbGeo {
-  static constexpr int KC = C / 32, X = VB_CB, G = (KC * VB_CB + 255) / 256 * 256, PS = 4 * G, STEPS = 4 * KC;
+template <int C, int L> struct VbGeoL {        // L rows (4 samples x L / 4 quads) per channel block
+  static constexpr int KC = C / 32, X = L * 16 + 32, G = (KC * X + 255) / 256 * 256, PS = 4 * G, STEPS = 4 * KC;
   static constexpr int BYTES = 8 * PS, FRAGS = 2 * STEPS * 2;
 };
+template <int C> using VbGeo = VbGeoL<C, 16>;
 static_assert(VbGeo<128>::G == VB_CG && VbGeo<128>::PS == VB_PS && VbGeo<128>::FRAGS == VB_FRAGS, "128-channel geometry");
 // A step = 6 MFMAs: the wave's two n-tiles (two accumulator streams, one after the other) at chunk step / 4, slot step % 4,
 // on one set of A fragments.
@@ -829,19 +830,20 @@ __device__ __forceinline__ void w4_phase(float (&v)[4], const float (&d)[8]) {  
     v[3] = e3 - o3;
   }
 }
-template <int C> struct VrGeo {               // raw slab of the residual GEMM: 4 M tiles x 16 rows x 16 B per channel block
-  static constexpr int KC = C / 32, X = 64 * 16 + 32, G = (KC * X + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
+template <int C, int L> struct VrGeoL {        // raw slab of the residual GEMM: 4 position classes o x L rows x 16 B per channel block
+  static constexpr int KC = C / 32, X = 4 * L * 16 + 32, G = (KC * X + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
 };
-template <int PH, int C, int XSS, int XSTR>
+template <int C> using VrGeo = VrGeoL<C, 16>;
+template <int PH, int C, int L, int XSS, int XSTR>
 __device__ __forceinline__ void rowform_to_vslab(const float* xslab, char* vphase, char* vraw, const float* mx) {
-  using GEO = VbGeo<C>;
-  using GR = VrGeo<C>;
-  constexpr int CP2 = C / 2, ITEMS = 16 * CP2;      // (sample, quad) x channel pairs
-  static_assert(ITEMS % 256 == 0, "items per thread");
+  using GEO = VbGeoL<C, L>;
+  using GR = VrGeoL<C, L>;
+  constexpr int CP2 = C / 2, QPS = L / 4, ITEMS = L * CP2;      // (sample, quad) x channel pairs
+  static_assert(ITEMS % 256 == 0 && XSTR % 2 == 0, "items per thread; 8-byte aligned channel pairs");
 #pragma unroll
   for (int it = 0; it < ITEMS / 256; ++it) {
     const int idx = it * 256 + threadIdx.x;
-    const int cp = idx % CP2, row = idx / CP2, smp = row >> 2, quad = row & 3;      // row = 4 * sample + quad = A row
+    const int cp = idx % CP2, row = idx / CP2, smp = row / QPS, quad = row % QPS;   // row = QPS * sample + quad = GEMM row
     const float4 p = *reinterpret_cast<const float4*>(mx + smp * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + smp * MX_SLOTS + 4);
     const float sc = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)))).s;
     const float* src = xslab + smp * XSS + 4 * quad * XSTR + 2 * cp;                 // slab row 4 quad = position 4 quad - 2
@@ -866,12 +868,33 @@ __device__ __forceinline__ void rowform_to_vslab(const float* xslab, char* vphas
     if constexpr (PH == 0) {
       char* dr = vraw + jg * GR::G + kc * GR::X + row * 16 + (cp & 3) * 4;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {                 // position 4 quad + o = slab row 4 quad + 2 + o -> M tile o
+      for (int o = 0; o < 4; ++o) {                 // position 4 quad + o = slab row 4 quad + 2 + o -> position class o
         const F16Pair f = f16_split2(d[2 + o], e[2 + o]);
-        *reinterpret_cast<unsigned*>(dr + o * 256) = f.hi;
-        *reinterpret_cast<unsigned*>(dr + GR::PS + o * 256) = f.lo;
+        *reinterpret_cast<unsigned*>(dr + o * L * 16) = f.hi;
+        *reinterpret_cast<unsigned*>(dr + GR::PS + o * L * 16) = f.lo;
       }
     }
+  }
+}
+// the same GEMM for one n-tile x the two M tiles of an L = 32 stage (downs.1): res[M tile][o]
+template <int C, int L>
+__device__ __forceinline__ void vr_taps_m2(f32x4 (&res)[2][4], const char* vr, const u32x4* w) {
+  using GR = VrGeoL<C, L>;
+#pragma unroll
+  for (int kc = 0; kc < GR::KC; ++kc) {
+    u32x4 b[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) b[q] = w[(kc * 2 + q) * 64];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        u32x4 a[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const u32x4*>(vr + q * GR::PS + kc * GR::X + o * L * 16 + mt * 256);
+        if (kc == 0) vb_three<true>(res[mt][o], a, b);
+        else vb_three<false>(res[mt][o], a, b);
+      }
   }
 }
 // res[tile][o] (C/D fragment of M tile o) = 1x1 conv over the raw slab's C channels; vr = raw slab + the lane's A offset
@@ -1333,7 +1356,7 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
   float* hslab = lds + CF::XSLAB;                            // row-form H slab of the tail conv
   const int nq = wave % GEO::NTQ, mt0 = 2 * (wave / GEO::NTQ);          // the wave's n-tile and first M tile
   const int col = 16 * nq + (lane & 15);                     // the lane's channel
-  // A row lane & 15 of M tile mt0 + mt = (sample, quad) of the row-form x slab (conv A of the first RTB)
+  // A row lane & 15 of M tile mt0 + mt = (sample, quad) of the row-form x slab (fp32 conv A of downs.0's first RTB)
   int xbase[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -1342,9 +1365,21 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
   }
   BQ<3> ring3[W4_RD];
   const float* w3 = reinterpret_cast<const float*>(a.r0.wa) + ((size_t)nq * (CF::C0P / 4) * 64 + lane) * 12;
-  w4_ring_load<3>(ring3, w3);
-  if constexpr (FIRST)     // the network input, channels-last [n, 64, 4] in HBM (channels 4..7 of the slab are zero)
+  // downs.1: conv A of the first RTB (32 -> 64) + the 1x1 residual conv as f16x2 from the row-form x slab (chain_body_d2)
+  using GA = VbGeoL<FIRST ? 32 : CF::C0P, CF::L>;
+  using GR = VrGeoL<FIRST ? 32 : CF::C0P, CF::L>;
+  constexpr int VA_OFF = (CF::SPB * CF::XSS * 4 + 255) / 256 * 256, VR_OFF = VA_OFF + GA::BYTES;
+  static_assert(FIRST || VR_OFF + GR::BYTES <= MX_OFF * 4, "x slab + phase slab + raw slab must fit below the maxima");
+  const u32x4* const wpa = reinterpret_cast<const u32x4*>(a.r0.wa_bf) + (size_t)nq * GA::FRAGS * 64 + lane;
+  const u32x4* const wpr = reinterpret_cast<const u32x4*>(a.wres_bf) + (size_t)nq * (2 * GR::KC) * 64 + lane;
+  u32x4 ring_a[VB_RD][2];
+  if constexpr (FIRST) {
+    w4_ring_load<3>(ring3, w3);
+    // the network input, channels-last [n, 64, 4] in HBM (channels 4..7 of the slab are zero)
     stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(lds, a.in0, nullptr, n0, a.n);
+  } else {
+    vbd_ring_load<GA, 0>(ring_a, wpa);
+  }
   __syncthreads();                                           // the x slab is staged
   TR(trb + 0);
 
@@ -1438,8 +1473,10 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
   };
   const float one2[2] = {1.f, 1.f};
 
-  // =================== RTB 0 (C0 -> CM): conv A + the 1x1 residual conv on the fp32 MFMA, row-form x slab ===================
-  {
+  // =================== RTB 0 (C0 -> CM): conv A + the 1x1 residual conv ===================
+  float inv_in[2] = {1.f, 1.f};
+  if constexpr (FIRST) {
+    // downs.0: on the fp32 MFMA from the row-form x slab (4 input channels; the raw network input has no bounded range)
     f32x4 m[8];
     const float br = a.br[col];
 #pragma unroll
@@ -1450,8 +1487,37 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
       if (mt == 0) w4_ring_load<3>(ring3, w3);
       w4n1_out(acc[mt], m);
     }
+    gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr, inv_in, a.r0.act_a);
+  } else {
+    // downs.1: f16x2 (the stage input is residual-stream data: dynamic per-sample scale from the maxima downs.0's tail left)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float4 p = *reinterpret_cast<const float4*>(mx + smp(mt) * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + smp(mt) * MX_SLOTS + 4);
+      inv_in[mt] = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)))).inv;
+    }
+    char* const va_slab = reinterpret_cast<char*>(lds) + VA_OFF;
+    char* const vr_slab = reinterpret_cast<char*>(lds) + VR_OFF;
+    const char* const va = va_slab + jg * GA::G + (16 * mt0 + (lane & 15)) * 16;
+    const char* const vr = vr_slab + jg * GR::G + (16 * mt0 + (lane & 15)) * 16;
+    f32x4 mb[2][8];
+    rowform_to_vslab<0, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
+    __syncthreads();
+    vbd_taps<GA, 0>(mb, va, wpa, ring_a);
+    vbd_ring_load<GA, 1>(ring_a, wpa);
+    vr_taps_m2<CF::C0P, CF::L>(res, vr, wpr);
+    __syncthreads();                                         // every wave is done reading the phase-0 slab
+    rowform_to_vslab<1, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
+    __syncthreads();
+    vbd_taps<GA, 1>(mb, va, wpa, ring_a);
+    const float br = a.br[col], isr = a.isr[col];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      w4n1_out(acc[mt], mb[mt]);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) res[mt][o] = res[mt][o] * (isr * inv_in[mt]) + br;
+    }
+    gn(std::true_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
   }
-  gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr, one2, a.r0.act_a);
   TR(trb + 1);
   __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
   conv_hb(a.r0.wb_bf);
@@ -1496,21 +1562,28 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
     int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
     mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
     if constexpr (TAIL_MAX) {
-      // the next stage's first conv runs as f16x2 on this tile: per-sample |x| maxima for its dynamic input scale.  Registers
-      // 0..7 / 8..15 of the 32 x 32 C/D fragment are the wave's first / second sample; a sample is shared by the WN waves of
-      // its channel slices x 4 lane groups = MX_SLOTS partial maxima.
-      static_assert(CF::WN * 4 == MX_SLOTS && CF::SW == 2, "tail tile: two samples per wave");
+      // the next stage's first conv runs as f16x2 on this tile: per-sample |x| maxima for its dynamic input scale.  The 32
+      // rows of the 32 x 32 C/D fragment are SW samples (registers 0..7 / 8..15 when there are two); a sample is shared by
+      // the WN waves of its channel slices x 4 lane groups (every one of the MX_SLOTS slots is written).
+      static_assert(CF::SW == 1 || CF::SW == 2, "tail tile: one or two samples per wave");
       float m0 = 0.f, m1 = 0.f;
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         m0 = fmaxf(m0, fabsf(tout[0][r8]));
         m1 = fmaxf(m1, fabsf(tout[0][8 + r8]));
       }
+      if constexpr (CF::SW == 1) m0 = m1 = fmaxf(m0, m1);
       m0 = row_max16(m0);
       m1 = row_max16(m1);
       if ((lane & 15) == 0) {
-        mx[(wm * 2) * MX_SLOTS + wn * 4 + (lane >> 4)] = m0;
-        mx[(wm * 2 + 1) * MX_SLOTS + wn * 4 + (lane >> 4)] = m1;
+        if constexpr (CF::SW == 2) {
+          static_assert(CF::SW == 1 || CF::WN * 4 == MX_SLOTS, "partial maxima per sample");
+          mx[(wm * 2) * MX_SLOTS + wn * 4 + (lane >> 4)] = m0;
+          mx[(wm * 2 + 1) * MX_SLOTS + wn * 4 + (lane >> 4)] = m1;
+        } else {                                             // one channel slice (WN = 1): its four maxima fill both halves
+          mx[wm * MX_SLOTS + (lane >> 4)] = m0;
+          mx[wm * MX_SLOTS + 4 + (lane >> 4)] = m0;
+        }
       }
     }
   }
@@ -1674,13 +1747,13 @@ __device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, in
     const char* const va = va_slab + (lane >> 4) * GA::G + (lane & 15) * 16;
     const char* const vr = vr_slab + (lane >> 4) * GR::G + (lane & 15) * 16;
     f32x4 mb[2][8];
-    rowform_to_vslab<0, CF::C0P, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
+    rowform_to_vslab<0, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
     __syncthreads();
     vb_taps<GA, 0>(mb, va, wpa, ring_a);
     vb_ring_load<GA, 1>(ring_a, wpa);
     vr_taps<CF::C0P>(res, vr, wpr);
     __syncthreads();                                         // every wave is done reading the phase-0 slab
-    rowform_to_vslab<1, CF::C0P, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
+    rowform_to_vslab<1, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
     __syncthreads();
     vb_taps<GA, 1>(mb, va, wpa, ring_a);
 #pragma unroll
@@ -1749,7 +1822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     f32x4 acc[2][4], mid[2][4];
     f32x16 t[1];
-    chain_body_db<CH_D0, true, false>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
+    chain_body_db<CH_D0, true, true>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
     __syncthreads();                                                       // the tail conv is done reading the H slab
     tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
@@ -2139,7 +2212,7 @@ static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int ci
 
 // f16x2 pack of a stage's 1x1 residual conv [cout][cin] for vr_taps: per n-tile [chunk kc][piece q][lane] x 16 B, columns and
 // channels as in pack_vb; isc_off = offset of the [cout] inverse channel scales.
-static size_t pack_vr(std::vector<float>& blob, const float* wres, int cout, int cin, size_t& isc_off) {
+static size_t pack_vr(std::vector<float>& blob, const float* wres, int cout, int cin, size_t& isc_off, bool pair_cols) {
   std::vector<float> sc(cout);
   for (int n = 0; n < cout; ++n) {
     float m = 0.f;
@@ -2156,7 +2229,7 @@ static size_t pack_vr(std::vector<float>& blob, const float* wres, int cout, int
     for (int kc = 0; kc < KC; ++kc)
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
-          const int n = (t / 2) * 32 + 2 * (lane & 15) + (t & 1);
+          const int n = pair_cols ? (t / 2) * 32 + 2 * (lane & 15) + (t & 1) : 16 * t + (lane & 15);
           const int ci = 8 * (KC * (lane >> 4) + kc) + j;
           uint16_t piece[2];
           f16_split_host(wres[(size_t)n * cin + ci], sc[n], piece);
@@ -2168,7 +2241,8 @@ static size_t pack_vr(std::vector<float>& blob, const float* wres, int cout, int
 // f16x2 pack of a C -> C k5 conv of downs.0 / downs.1 for vbd_taps: per n-tile [phase][step = 4 chunk kc + slot][piece q][lane]
 // x 16 B; lane = (column n = 16 tile + (lane & 15), the 8 channels of the block DbGeo assigns to (kc, lane >> 4), j at fp16
 // index j).
-static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off, float in_scale) {
+static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off, float in_scale,
+                       bool plain_blocks = false) {
   const std::vector<float> sc = f16_col_scales(w, cout, cin);
   isc_off = push_inverse(blob, sc, in_scale);
   const size_t base = blob.size();
@@ -2183,7 +2257,8 @@ static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int c
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
               // channel block of (chunk kc, lane group g): 2 * pair + half (DbGeo::pair_of / half_of)
-              const int jg = lane >> 4, blk = KC == 2 ? 2 * jg + kc : 2 * (jg & 1) + (jg >> 1);
+              // (plain_blocks: the VbGeoL order of a stage's first conv, block kc + KC g)
+              const int jg = lane >> 4, blk = plain_blocks ? kc + KC * jg : (KC == 2 ? 2 * jg + kc : 2 * (jg & 1) + (jg >> 1));
               const int n = 16 * t + (lane & 15), ci = 8 * blk + j;
               uint16_t piece[2];
               f16_split_host(wino_u(w, cin, n, ci, vb_pos(ph, sl)), sc[n], piece);
@@ -2432,7 +2507,10 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
     } else if (r == 4) {      // downs.2's first RTB: conv A (64 -> 128) and the 1x1 residual conv as f16x2 (rowform_to_vslab)
       W.a.wbf = pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);
-      W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc);
+      W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc, /*pair_cols=*/true);
+    } else if (r == 2) {      // downs.1's first RTB: the same for 32 -> 64 (chain_body_db; plain columns)
+      W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f, /*plain_blocks=*/true);
+      W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc, /*pair_cols=*/false);
     } else if ((d1 || d2) && R.cin == R.cout) {
       W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);   // dynamic input scale
     } else {
@@ -2589,7 +2667,8 @@ double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
 double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }
 double mmd_unet_f16x2_flops_per_trajectory(void) {
   return 4 * 3 * wino4_flops(32, 32) + 2 * 3 * wino4_flops(64, 64) + 7 * wino4_flops(128, 128) + wino4_flops(256, 64) * 14.0 / 8.0 +
-         wino4_flops(64, 128) + direct_flops(1, 64, 128, 16);   // downs.2's conv A and its 1x1 residual GEMM
+         wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) +   // downs.2's / downs.1's conv A and their 1x1 residual GEMMs
+         2 * wino4_flops(32, 64) + direct_flops(1, 32, 64, 32);
 }
 
 int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride) {

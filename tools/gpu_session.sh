@@ -1,6 +1,3 @@
 export TMPDIR=/tmp
-OUT=gpurun_out; mkdir -p $OUT
-timeout 300 python bench.py --steps 5 --warmup 1 2>$OUT/bench.err | tee $OUT/r03b_bench.json | cut -c1-600; tail -3 $OUT/bench.err
-bash tools/gpu_rehearsal.sh r03b
-tools/gpu_pmc.sh r03b_bench "unet_kernel|ddpm_guide" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null
-grep -A1 -E "VALU|WAVE_CYCLES|WAIT|ACTIVE|FETCH|WRITE|LDS" $OUT/r03b_bench_pmc.txt | grep -E "#|ddpm" | head -60
+for n in 1024 2048; do MMD_AMD_LIB=$PWD/build_tmp/libmmd_amd_trace.so timeout 120 python tools/dbg/trace_phases.py $n > gpurun_out/r03e_trace_$n.txt 2>&1; done
+REPS=8 tools/gpu_pmc.sh r03e_unet2048 unet_kernel -- python tools/unet_forward_loop.py 2048 > /dev/null
