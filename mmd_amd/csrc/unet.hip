@@ -269,7 +269,10 @@ struct ChainArgs {
   const uint4* wa0_c1_bf;                // ... its f16x2 form (ups.0: vbu_taps)
   const float* br;                       // bias of the 1x1 residual conv (its weights ride in the conv A packs)
   const float* isr;                      // [C_out] inverse scale of the residual weights in the f16x2 packs
-  const uint4* wres_bf;                  // f16x2 pack of the 1x1 residual conv where it runs as its own GEMM (downs.2)
+  const uint4* wres_bf;                  // f16x2 pack of the 1x1 residual conv (downs.1 / downs.2 / ups.0 chunk 0)
+  const uint4* wres_c1_bf;               // ... of the second input chunk (ups.0)
+  const uint4* wt_bf0; const uint4* wt_bf1;   // f16x2 packs of the two parity passes of the transposed tail conv (ups.0)
+  const float* ist0; const float* ist1;       // ... their inverse channel scales
   RtbPtrs ri[MAX_IDENT];
   const float4* wt; const float* bt;     // tail conv pack(s), bias
   int n;
@@ -1591,6 +1594,511 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// The L = 16 stages (downs.2 + mid blocks, ups.0) as DIRECT f16x2 convolutions on a row-form slab.  Their convs are bound
+// by the weight stream (a workgroup re-uses a weight fragment on 16 GEMM rows in the Winograd form; the vector-memory path
+// of a CU delivers 64 B/clk), not by the matrix pipe, which at the fp16 rate idles 80 % of a Winograd conv.  The direct
+// form trades 2.5 x the MFMAs (5 taps instead of 8 Winograd positions per 4 outputs) for
+//   * 5 / 8 of the weight bytes, every fragment re-used on 64 GEMM rows (a wave's unit is 1-2 n-tiles x the FOUR M tiles
+//     = samples of the workgroup),
+//   * no position phases: ONE slab store and one barrier pair per conv instead of two stores and four barriers, no input /
+//     output transforms (~250 VALU per conv and lane), 8 accumulator streams (32-64 registers),
+//   * direct-convolution accuracy (0.8e-6 instead of 1.9e-6 of the forward against fp64).
+// GEMM: M tile s = sample s, row i = position; the taps of a k = 5 conv are row-shifted views of the slab
+//     Rd[piece][lane group j][chunk kc][row = 20 s + 2 + position][8 channels]   (fp16, 2-row zero halo per sample)
+// (channel block kc + KC j, KC = C / 32: the four blocks of a K = 32 chunk lie G = a multiple of 256 B apart, so a b128 A
+// read is conflict free; the blocks of one lane group BX = 1280 + 32 B, so the epilogue's dword stores -- lanes = 4
+// channel pairs x 4 blocks x 4 position groups -- are 2-way at worst, which is free).  C/D layout: a lane holds positions
+// 4 g .. 4 g + 3 (g = lane >> 4) of ALL four samples for its 1-2 channels; a GroupNorm group (8 lanes x 16 positions) is
+// reduced by three DPP steps and two cross-row shuffles.  Weights: per n-tile [tap][chunk kc][piece][lane] x 16 B.
+// ----------------------------------------------------------------------------------------------------------------
+template <int C> struct RdGeo {
+  static constexpr int KC = C / 32, RPS = 20, BX = 4 * RPS * 16 + 32, G = (KC * BX + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
+  static constexpr int FRAGS5 = 5 * KC * 2;                  // weight fragments per n-tile of a k = 5 conv
+};
+template <class GEO>
+__device__ __forceinline__ void rd_zero_halo(char* slab) {
+  constexpr int TOT = 2 * 4 * GEO::KC * 4 * 4;               // pieces x lane groups x chunks x samples x halo rows, 16 B each
+  for (int idx = threadIdx.x; idx < TOT; idx += 256) {
+    const int hr = idx & 3, sm = (idx >> 2) & 3, blk = (idx >> 4) % (4 * GEO::KC), q = idx / (64 * GEO::KC);
+    *reinterpret_cast<uint4*>(slab + q * GEO::PS + (blk / GEO::KC) * GEO::G + (blk % GEO::KC) * GEO::BX +
+                              (sm * GEO::RPS + (hr < 2 ? hr : 16 + hr)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+template <class GEO, int NT>
+__device__ __forceinline__ void rd_load_b(u32x4 (&b)[NT][2], const u32x4* const (&w)[NT], int step) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) b[t][q] = w[t][(step * 2 + q) * 64];
+}
+// A fragments of one sample PAIR (M tiles 2 hp, 2 hp + 1) at slab-row offset rowoff, chunk kc
+template <class GEO>
+__device__ __forceinline__ void rd_load_a(u32x4 (&a)[2][2], const char* va, int rowoff, int kc, int hp) {
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      a[sm][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + ((2 * hp + sm) * GEO::RPS + rowoff) * 16);
+}
+constexpr int RD_RD = 2;                    // weight ring depth in steps
+template <class GEO, int NT>
+__device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD_RD][NT][2], const u32x4* const (&w)[NT]) {
+#pragma unroll
+  for (int i = 0; i < RD_RD; ++i) rd_load_b<GEO, NT>(b[i], w, i);
+  MMD_PIN_LOADS();
+}
+// acc[sample][tile] (+)= conv over TAPS taps (slab rows TAP0 .. TAP0 + TAPS - 1 relative to the output position) x the C
+// channels of the slab; va = slab + the lane's A offset (lane group lane >> 4, row lane & 15); w[tile] = the tile's pack +
+// lane; b = ring pre-loaded with the first RD_RD steps.  RES: the stage's 1x1 residual conv rides on the centre tap's A
+// fragments (res[sample][tile] (+)=, weights wr[tile] = [chunk kc][piece] + lane).  FRESH: start from zero.
+template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES>
+__device__ __forceinline__ void rd_taps(f32x4 (&acc)[4][NT], f32x4 (&res)[4][NT], const char* va, const u32x4* const (&w)[NT],
+                                        const u32x4* const (&wr)[NT], u32x4 (&b)[RD_RD][NT][2]) {
+  constexpr int KC = GEO::KC, STEPS = TAPS * KC;
+  static_assert(KC % RD_RD == 0, "the ring index must be static inside a tap");
+  // A fragments are double-buffered by sample pair (half a step = 2 M tiles x NT n-tiles x 3 MFMAs): 32 registers
+  u32x4 a[2][2][2];
+  rd_load_a<GEO>(a[0], va, TAP0, 0, 0);
+  auto one_tap = [&](auto zero, int tap) {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      u32x4 br[NT][2];
+      const bool with_res = RES && TAP0 + tap == 2;
+      if constexpr (RES) {
+        if (with_res) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) br[t][q] = wr[t][(kc * 2 + q) * 64];
+        }
+      }
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        // the next half step's A fragments (the other sample pair; then the next chunk, or chunk 0 of the next tap; past the
+        // last step: a valid, unused read)
+        if (hp == 0) rd_load_a<GEO>(a[1], va, TAP0 + tap, kc, 1);
+        else rd_load_a<GEO>(a[0], va, kc + 1 < KC ? TAP0 + tap : TAP0 + tap + 1, kc + 1 < KC ? kc + 1 : 0, 0);
+        MMD_PIN_LOADS();
+        const u32x4(&ac)[2][2] = a[hp];
+        const u32x4(&bc)[NT][2] = b[kc % RD_RD];
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (decltype(zero)::value && kc == 0) vb_three<true>(acc[2 * hp + sm][t], ac[sm], bc[t]);
+            else vb_three<false>(acc[2 * hp + sm][t], ac[sm], bc[t]);
+          }
+        if constexpr (RES) {
+          if (with_res) {
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], br[t]);
+                else vb_three<false>(res[2 * hp + sm][t], ac[sm], br[t]);
+              }
+          }
+        }
+      }
+      const int nxt = tap * KC + kc + RD_RD;
+      if (nxt < STEPS) rd_load_b<GEO, NT>(b[kc % RD_RD], w, nxt);
+      MMD_PIN_LOADS();
+    }
+  };
+  if constexpr (FRESH) {
+    one_tap(std::true_type{}, 0);
+#pragma unroll 1
+    for (int tap = 1; tap < TAPS; ++tap) one_tap(std::false_type{}, tap);
+  } else {
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) one_tap(std::false_type{}, tap);
+  }
+}
+// GroupNorm + Mish of the direct-layout tile acc[sample][tile] (raw f16x2 conv output: true value = acc * isc[tile] *
+// inv[sample]) + add(sample, tile, r); NG = values per group (16 channels x 16 positions for two interleaved n-tiles at C =
+// 128, 8 x 16 for one n-tile at C = 64); the lane's NT channels all belong to one group, which is 8 lanes x the wave's four
+// 16-lane rows (position groups).
+template <int NT, int NG, bool ACT, class ADD>
+__device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[4][NT], const float (&bias)[NT], const float (&gamma)[NT],
+                                           const float (&beta)[NT], const float (&isc)[NT], const float (&inv)[4],
+                                           const ActScale& as, ADD add) {
+  constexpr float inv_n = 1.f / (float)NG;
+  float bsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bsum += bias[t];
+  const float bmean = group_colsum<8>(bsum) * 16.f * inv_n;
+  float k[4][NT], sum[4], dm[4][NT], sq[4];
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) {
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      k[sm][t] = isc[t] * inv[sm];
+      v = fmaf((acc[sm][t][0] + acc[sm][t][1]) + (acc[sm][t][2] + acc[sm][t][3]), k[sm][t], v);
+    }
+    sum[sm] = group_colsum<8>(v);
+  }
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) sum[sm] += __shfl_xor(sum[sm], 16);
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) sum[sm] += __shfl_xor(sum[sm], 32);
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) {
+    const float mean = fmaf(sum[sm], inv_n, bmean);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      dm[sm][t] = mean - bias[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = fmaf(acc[sm][t][r], k[sm][t], -dm[sm][t]);
+        v = fmaf(d, d, v);
+      }
+    }
+    sq[sm] = group_colsum<8>(v);
+  }
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) sq[sm] += __shfl_xor(sq[sm], 16);
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) sq[sm] += __shfl_xor(sq[sm], 32);
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) {
+    const float rstd = rsqrtf(fmaf(sq[sm], inv_n, 1e-5f));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      GnCoef cf = gn_coef(dm[sm][t], rstd, gamma[t], beta[t]);
+      cf.sa *= k[sm][t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[sm][t][r] = gn_mish1<ACT>(acc[sm][t][r], cf, add(sm, t, r), as);
+    }
+  }
+}
+// per-sample |x| maxima of a direct-layout tile -> mx region 0 (and region2 if > 0): row_max16, one cross-row step,
+// lanes 0 / 32 write the wave's two partials: slots 2 wave + {0, 1} of MX_SLOTS = 8
+template <int NT>
+__device__ __forceinline__ void rd_dyn_out(const f32x4 (&acc)[4][NT], float* mx, int wave, int lane, int region2) {
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) {
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(acc[sm][t][r]));
+    m = row_max16(m);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    if ((lane & 31) == 0) {
+      mx[sm * MX_SLOTS + 2 * wave + (lane >> 5)] = m;
+      if (region2) mx[region2 * MX_REGION + sm * MX_SLOTS + 2 * wave + (lane >> 5)] = m;
+    }
+  }
+}
+__device__ __forceinline__ float mx_read(const float* mx, int sm) {
+  const float4 p = *reinterpret_cast<const float4*>(mx + sm * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + sm * MX_SLOTS + 4);
+  return fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+}
+// two-interleaved-n-tile tile (lane: channels c0, c0 + 1 = block 4 wave + (n >> 2), dword n & 3; positions 4 g + r) -> slab
+template <class GEO>
+__device__ __forceinline__ void rd_store2(char* vs, const f32x4 (&acc)[4][2]) {   // vs = slab + lane's (block, row 2 + 4 g, dword)
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const F16Pair f = f16_split2(acc[sm][0][r], acc[sm][1][r]);
+      *reinterpret_cast<unsigned*>(vs + (sm * GEO::RPS + r) * 16) = f.hi;
+      *reinterpret_cast<unsigned*>(vs + GEO::PS + (sm * GEO::RPS + r) * 16) = f.lo;
+    }
+}
+// one-n-tile tile (lane: channel c, positions 4 g + r of all four samples): the lanes of a pair (n, n ^ 1) swap two samples,
+// the even lane stores samples 0 / 1 of channels (c, c + 1), the odd lane samples 2 / 3 of (c - 1, c).
+// vs = slab + the lane's (block of c, row 2 + 4 g, dword (c & 7) >> 1) offset
+template <class GEO>
+__device__ __forceinline__ void rd_store1(char* vs, const f32x4 (&acc)[4][1], int lane) {
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float send = odd ? acc[h][0][r] : acc[2 + h][0][r];
+      const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));
+      const float own = odd ? acc[2 + h][0][r] : acc[h][0][r];
+      const F16Pair f = f16_split2(odd ? recv : own, odd ? own : recv);        // (low channel, high channel)
+      char* p = vs + ((odd ? 2 + h : h) * GEO::RPS + r) * 16;
+      *reinterpret_cast<unsigned*>(p) = f.hi;
+      *reinterpret_cast<unsigned*>(p + GEO::PS) = f.lo;
+    }
+}
+// row-form fp32 slab [sample][20][XSTR] (2-row halo) of C channels -> the Rd slab, times the sample's dynamic scale
+template <int C, int XSS, int XSTR>
+__device__ __forceinline__ void rowform_to_rd(const float* xslab, char* slab, const float* mx) {
+  using GEO = RdGeo<C>;
+  constexpr int CP2 = C / 2, ITEMS = 64 * CP2;               // (sample, position) x channel pairs
+  static_assert(ITEMS % 256 == 0 && XSTR % 2 == 0, "items per thread; 8-byte aligned channel pairs");
+#pragma unroll
+  for (int it = 0; it < ITEMS / 256; ++it) {
+    const int idx = it * 256 + threadIdx.x;
+    const int cp = idx % CP2, sp = idx / CP2, sm = sp >> 4, pos = sp & 15;
+    const float sc = dyn_scale(mx_read(mx, sm)).s;
+    const float2 t = *reinterpret_cast<const float2*>(xslab + sm * XSS + (2 + pos) * XSTR + 2 * cp);
+    const F16Pair f = f16_split2(t.x * sc, t.y * sc);
+    const int blk = cp >> 2;
+    char* dst = slab + (blk / GEO::KC) * GEO::G + (blk % GEO::KC) * GEO::BX + (sm * GEO::RPS + 2 + pos) * 16 + (cp & 3) * 4;
+    *reinterpret_cast<unsigned*>(dst) = f.hi;
+    *reinterpret_cast<unsigned*>(dst + GEO::PS) = f.lo;
+  }
+}
+
+// downs.2 + mid blocks in the direct form.  Wave w owns the n-tiles 2 w, 2 w + 1 with INTERLEAVED columns (column n of tile h =
+// channel 32 w + 2 n + h: adjacent channels per lane, dword slab stores) x all four samples; acc[sample][h][r] = position
+// 4 (lane >> 4) + r.  acc: the stage's output; mid: the skip tensor (after RTB MID_AFTER).
+template <class CF>
+__device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[4][2],
+                                               f32x4 (&mid)[4][2], int trb) {
+  static_assert(CF::L == 16 && CF::CM == 128 && CF::C0 == 64 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_NONE &&
+                    CF::MID_AFTER >= 1, "downs.2 + mid blocks");
+  using G128 = RdGeo<128>;
+  using G64 = RdGeo<64>;
+  const int n = lane & 15, g = lane >> 4;
+  const int c0 = 32 * wave + 2 * n;                          // the lane's channels c0 (tile 0), c0 + 1 (tile 1)
+  // LDS: the row-form fp32 x slab (previous stage's tail tile) at the start, the Rd slab behind it (conv A's 64-channel
+  // input uses its first bytes in the 64-channel geometry)
+  constexpr int S_OFF = (CF::SPB * CF::XSS * 4 + 255) / 256 * 256;
+  static_assert(S_OFF + G128::BYTES <= MX_OFF * 4, "x slab + Rd slab must fit below the maxima");
+  char* const slab = reinterpret_cast<char*>(lds) + S_OFF;
+  float* const mx = lds + MX_OFF;
+  const char* const va128 = slab + g * G128::G + n * 16;     // A fragment: row lane & 15 = position, lane group lane >> 4
+  const char* const va64 = slab + g * G64::G + n * 16;
+  char* const vs = slab + wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4;
+  auto wptr = [&](const uint4* w, int frags, int h) { return reinterpret_cast<const u32x4*>(w) + (size_t)(2 * wave + h) * frags * 64 + lane; };
+  u32x4 ring[RD_RD][2][2];
+  const u32x4* wpa[2] = {wptr(a.r0.wa_bf, G64::FRAGS5, 0), wptr(a.r0.wa_bf, G64::FRAGS5, 1)};
+  const u32x4* wpr[2] = {wptr(a.wres_bf, 2 * G64::KC, 0), wptr(a.wres_bf, 2 * G64::KC, 1)};
+  rd_ring_load<G64, 2>(ring, wpa);
+  __syncthreads();                                           // the x slab (previous stage's tail tile) and its maxima are staged
+  TR(trb + 0);
+
+  f32x4 res[4][2];
+  const float one4[4] = {1.f, 1.f, 1.f, 1.f};
+  // GroupNorm + Mish of acc.  Conv A (tb != nullptr): + the time bias, output carried times act_s (conv B's static f16x2
+  // input scale); conv B: + the residual tile.  isc: the conv's inverse weight scales, inv: inverse dynamic input scales
+  auto gn = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc, const float (&inv)[4],
+                float act_s) {
+    const float bb[2] = {b[c0], b[c0 + 1]}, gg[2] = {gm[c0], gm[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
+    const float is[2] = {isc[c0], isc[c0 + 1]};
+    if (tb) {
+      const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
+      rd_gn_mish<2, 256, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
+    } else {
+      rd_gn_mish<2, 256, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int sm, int t, int r) { return res[sm][t][r]; });
+    }
+  };
+  // one 128 -> 128 conv over the tile in acc (already scaled for f16x2); on entry every wave is past its reads of the slab
+  auto conv = [&](const uint4* w) {
+    const u32x4* wp[2] = {wptr(w, G128::FRAGS5, 0), wptr(w, G128::FRAGS5, 1)};
+    TR(trb + 10);
+    rd_ring_load<G128, 2>(ring, wp);
+    rd_store2<G128>(vs, acc);
+    TR(trb + 11);
+    __syncthreads();
+    TR(trb + 12);
+    rd_taps<G128, 2, 0, 5, true, false>(acc, res, va128, wp, wp, ring);
+    TR(trb + 13);
+  };
+
+  // =================== RTB 0 (64 -> 128): conv A + the 1x1 residual conv from the row-form x slab ===================
+  float inv_in[4];
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) inv_in[sm] = dyn_scale(mx_read(mx, sm)).inv;
+  rd_zero_halo<G64>(slab);
+  rowform_to_rd<CF::C0P, CF::XSS, CF::XSTR>(lds, slab, mx);
+  __syncthreads();
+  rd_taps<G64, 2, 0, 5, true, true>(acc, res, va64, wpa, wpr, ring);
+  {
+    const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[sm][t] = res[sm][t] * (isr[t] * inv_in[sm]) + br[t];
+  }
+  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+  TR(trb + 1);
+  __syncthreads();                                           // conv A is done reading the 64-channel slab
+  rd_zero_halo<G128>(slab);
+  conv(a.r0.wb_bf);
+  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one4, 1.f);
+
+  // =================== identity RTBs ===================
+#pragma unroll 1
+  for (int k = 0; k < CF::N_IDENT; ++k) {
+    const RtbPtrs& R = a.ri[k];
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[sm][t] = acc[sm][t];
+    rd_dyn_out<2>(acc, mx, wave, lane, k == CF::MID_AFTER ? 1 : 0);   // (the input of the RTB after MID_AFTER is the skip tensor)
+    __syncthreads();                                         // the previous conv is done reading the slab
+    float inv[4];
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm) {
+      const DynScale ds = dyn_scale(mx_read(mx, sm));
+      inv[sm] = ds.inv;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[sm][t] *= ds.s;
+    }
+    conv(R.wa_bf);
+    gn(R.ba, R.ga, R.bea, R.tb, R.isa, inv, R.act_a);
+    __syncthreads();
+    conv(R.wb_bf);
+    gn(R.bb, R.gb, R.beb, nullptr, R.isb, one4, 1.f);
+    TR(trb + 18);
+    if (CF::MID_AFTER == k + 1) {
+#pragma unroll
+      for (int sm = 0; sm < 4; ++sm)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) mid[sm][t] = acc[sm][t];
+    }
+  }
+  rd_dyn_out<2>(acc, mx, wave, lane, 2);                     // the stage's output: ups.0's conv A takes its maximum from region 2
+}
+
+// ups.0 in the direct form: cat(mid output, skip2) -> RTB (256 -> 64, with its 1x1 residual conv) -> RTB (64 -> 64) ->
+// Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, all f16x2 on Rd slabs.  Wave w owns the n-tile of
+// channels 16 w + (lane & 15) x all four samples.  x0 / x1: the two 128-channel chunks of the input (downs.2's tiles, in
+// ITS layout: store2(tile) writes one into the 128-channel slab); CFN: the next stage (its row-form fp32 x slab geometry).
+template <class CF, class CFN, class STORE2>
+__device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&x0)[4][2],
+                                               f32x4 (&x1)[4][2], STORE2 store2, char* slab128, int trb) {
+  static_assert(CF::L == 16 && CF::CM == 64 && CF::C0 == 128 && CF::C1 == 128 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_UP &&
+                    CF::N_IDENT == 1, "ups.0");
+  using G128 = RdGeo<128>;
+  using G64 = RdGeo<64>;
+  const int n = lane & 15, g = lane >> 4, col = 16 * wave + n;
+  char* const slab64 = reinterpret_cast<char*>(lds);
+  static_assert(G64::BYTES <= MX_OFF * 4, "64-channel Rd slab");
+  float* const mx = lds + MX_OFF;
+  const char* const va128 = slab128 + g * G128::G + n * 16;
+  const char* const va64 = slab64 + g * G64::G + n * 16;
+  char* const vs64 = slab64 + wave * G64::G + (n >> 3) * G64::BX + (2 + 4 * g) * 16 + ((n & 7) >> 1) * 4;
+  auto wptr = [&](const uint4* w, int frags) { return reinterpret_cast<const u32x4*>(w) + (size_t)wave * frags * 64 + lane; };
+  u32x4 ring[RD_RD][1][2];
+  const u32x4* wp0[1] = {wptr(a.r0.wa_bf, G128::FRAGS5)};
+  const u32x4* wp1[1] = {wptr(a.wa0_c1_bf, G128::FRAGS5)};
+  const u32x4* wr0[1] = {wptr(a.wres_bf, 2 * G128::KC)};
+  const u32x4* wr1[1] = {wptr(a.wres_c1_bf, 2 * G128::KC)};
+  rd_ring_load<G128, 1>(ring, wp0);
+  __syncthreads();                                           // the previous stage is done with the slab; its maxima are in mx
+  TR(trb + 0);
+
+  f32x4 acc[4][1], res[4][1];
+  const float one4[4] = {1.f, 1.f, 1.f, 1.f};
+  auto gn = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc, const float (&inv)[4],
+                float act_s) {
+    const float bb[1] = {b[col]}, gg[1] = {gm[col]}, ee[1] = {be[col]}, is[1] = {isc[col]};
+    if (tb) {
+      const float t0 = tb[col] * act_s;
+      rd_gn_mish<1, 128, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int, int) { return t0; });
+    } else {
+      rd_gn_mish<1, 128, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int sm, int, int r) { return res[sm][0][r]; });
+    }
+  };
+  // dynamic input scale of a conv on the tile in acc: (maxima -> mx, barrier, then) scale in place; the inverse scales
+  auto dyn_scale_acc = [&](float (&inv)[4]) {
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm) {
+      const DynScale ds = dyn_scale(mx_read(mx, sm));
+      inv[sm] = ds.inv;
+      acc[sm][0] *= ds.s;
+    }
+  };
+  // one 64 -> 64 conv over the tile in acc (already scaled); on entry every wave is past its reads of the slab
+  auto conv64 = [&](const uint4* w) {
+    const u32x4* wp[1] = {wptr(w, G64::FRAGS5)};
+    rd_ring_load<G64, 1>(ring, wp);
+    rd_store1<G64>(vs64, acc, lane);
+    __syncthreads();
+    rd_taps<G64, 1, 0, 5, true, false>(acc, res, va64, wp, wp, ring);
+  };
+
+  // =================== RTB 0: cat(x0, x1) -> 64 channels; the 1x1 residual conv rides on the centre tap ===================
+  float inv_in[4];
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) {
+    // residual-stream input: dynamic scale from the maxima downs.2 left in regions 1 (skip2) and 2 (mid output) of mx
+    const DynScale ds = dyn_scale(fmaxf(mx_read(mx + MX_REGION, sm), mx_read(mx + 2 * MX_REGION, sm)));
+    inv_in[sm] = ds.inv;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      x0[sm][t] *= ds.s;
+      x1[sm][t] *= ds.s;
+    }
+  }
+  store2(x0);
+  __syncthreads();
+  rd_taps<G128, 1, 0, 5, true, true>(acc, res, va128, wp0, wr0, ring);
+  rd_ring_load<G128, 1>(ring, wp1);
+  __syncthreads();                                           // every wave is done reading chunk 0
+  store2(x1);
+  __syncthreads();
+  rd_taps<G128, 1, 0, 5, false, true>(acc, res, va128, wp1, wr1, ring);
+  {
+    const float br = a.br[col], isr = a.isr[col];
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm) res[sm][0] = res[sm][0] * (isr * inv_in[sm]) + br;
+  }
+  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+  TR(trb + 1);
+  __syncthreads();                                           // chunk 1 is consumed
+  rd_zero_halo<G64>(slab64);
+  conv64(a.r0.wb_bf);
+  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one4, 1.f);
+  TR(trb + 4);
+  // =================== identity RTB ===================
+  {
+    const RtbPtrs& R = a.ri[0];
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm) res[sm][0] = acc[sm][0];
+    rd_dyn_out<1>(acc, mx, wave, lane, 0);
+    __syncthreads();                                         // the previous conv is done reading the slab
+    float inv[4];
+    dyn_scale_acc(inv);
+    conv64(R.wa_bf);
+    gn(R.ba, R.ga, R.bea, R.tb, R.isa, inv, R.act_a);
+    TR(trb + 5);
+    __syncthreads();
+    conv64(R.wb_bf);
+    gn(R.bb, R.gb, R.beb, nullptr, R.isb, one4, 1.f);
+    TR(trb + 6);
+  }
+  // =================== tail: out[2 m] = in[m - 1] W3 + in[m] W1, out[2 m + 1] = in[m] W2 + in[m + 1] W0 ===================
+  {
+    rd_dyn_out<1>(acc, mx, wave, lane, 0);
+    __syncthreads();
+    float inv[4];
+    dyn_scale_acc(inv);
+    const u32x4* wt0[1] = {wptr(a.wt_bf0, 2 * G64::KC * 2)};
+    const u32x4* wt1[1] = {wptr(a.wt_bf1, 2 * G64::KC * 2)};
+    rd_ring_load<G64, 1>(ring, wt0);
+    rd_store1<G64>(vs64, acc, lane);
+    __syncthreads();
+    TR(trb + 7);
+    f32x4 e[4][1], o[4][1];
+    rd_taps<G64, 1, 1, 2, true, false>(e, res, va64, wt0, wt0, ring);
+    rd_ring_load<G64, 1>(ring, wt1);
+    rd_taps<G64, 1, 2, 2, true, false>(o, res, va64, wt1, wt1, ring);
+    const float bt = a.bt[col], is0 = a.ist0[col], is1 = a.ist1[col];
+    __syncthreads();                                         // the tail is done reading the slab the next stage's x slab aliases
+    // -> the next stage's row-form x slab [sample][2 + position][CFN::XSTR], positions 2 m + parity, m = 4 g + r
+    float* xb = lds + (2 + 8 * g) * CFN::XSTR + col;
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xb[sm * CFN::XSS + (2 * r) * CFN::XSTR] = fmaf(e[sm][0][r], is0 * inv[sm], bt);
+        xb[sm * CFN::XSS + (2 * r + 1) * CFN::XSTR] = fmaf(o[sm][0][r], is1 * inv[sm], bt);
+      }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // downs.2 + mid blocks (L = 16, 128 channels; 57 % of the network's MACs): the 64 -> 128 conv A of the first RTB on the
 // fp32 MFMA from the row-form x slab (with its 1x1 residual conv riding along), the seven 128 -> 128 convs as bf16x3
 // (vb_taps).  The stage's output is one M tile (4 samples x 4 quads) x 8 n-tiles; wave w owns n-tiles 2 w, 2 w + 1, whose
@@ -1817,7 +2325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * 4;
 
-  f32x4 skip1[2][4], skip2[2][4];
+  f32x4 skip1[2][4], skip2[4][2];
   // ---- downs.0 @ L=64 -> [4][32][32]  (chain_body_db: lane = channel 16 nq + (lane & 15) in the wave's two M tiles)
   {
     f32x4 acc[2][4], mid[2][4];
@@ -1836,45 +2344,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
   }
-  // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2 (lane = channels 32 wave + 2 (lane & 15) + h: chain_body_d2)
-  f32x4 mid_out[2][4];
-  chain_body_d2<CH_D2>(a.c[2], lds, lane, wave, mid_out, skip2, 80);
+  // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2: direct f16x2 convs (chain_body_d2d; lane = channels 32 wave + 2
+  //      (lane & 15) + h, positions 4 (lane >> 4) + r of all four samples)
+  f32x4 mid_out[4][2];
+  chain_body_d2d<CH_D2>(a.c[2], lds, lane, wave, mid_out, skip2, 80);
   TR(130);
-  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64]; conv A reads both chunks as bf16x3 phase slabs stored from the tiles
+  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64] (chain_body_u0d; the chunks are stored from downs.2's tiles)
   {
-    f32x16 t[2][1];
-    char* const vb_s = reinterpret_cast<char*>(lds) + wave * VB_CG + ((lane & 15) >> 2) * VB_CB + (lane >> 4) * 16 + (lane & 3) * 4;
-    // conv A's input cat(mid output, skip2) is residual-stream data: dynamic per-sample f16x2 scale from its maximum (the
-    // partial maxima were left in regions 1 / 2 of mx by chain_body_d2; combined behind the stage's first barrier)
-    const float* const mx = lds + MX_OFF;
-    chain_body_w4u<CH_U0>(a.c[3], lds, lane, wave,
-                          [&](auto chunk, auto ph) {
-                            float inv = 1.f;
-                            if constexpr (decltype(chunk)::value == 0 && decltype(ph)::value == 0) {
-                              const float4 p = *reinterpret_cast<const float4*>(mx + MX_REGION + (lane >> 4) * MX_SLOTS);
-                              const float4 q = *reinterpret_cast<const float4*>(mx + 2 * MX_REGION + (lane >> 4) * MX_SLOTS);
-                              const DynScale ds = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w))));
-#pragma unroll
-                              for (int h = 0; h < 2; ++h)
-#pragma unroll
-                                for (int o = 0; o < 4; ++o) {
-                                  mid_out[h][o] *= ds.s;
-                                  skip2[h][o] *= ds.s;
-                                }
-                              inv = ds.inv;
-                            }
-                            if constexpr (decltype(chunk)::value == 0)
-                              vb_store_pair<decltype(ph)::value>(vb_s, [&](int o, int r) { return mid_out[0][o][r]; },
-                                                                 [&](int o, int r) { return mid_out[1][o][r]; });
-                            else
-                              vb_store_pair<decltype(ph)::value>(vb_s, [&](int o, int r) { return skip2[0][o][r]; },
-                                                                 [&](int o, int r) { return skip2[1][o][r]; });
-                            return inv;
-                          },
-                          t, 136);
-    __syncthreads();
-    tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[0], lds, wave, lane, 0);
-    tile_to_stage<16, 1, CH_U0::SW, CH_U0::WN, 2, CH_U1::XSS, CH_U1::XSTR>(t[1], lds, wave, lane, 1);
+    using G128 = RdGeo<128>;
+    constexpr int S_OFF = (CH_D2::SPB * CH_D2::XSS * 4 + 255) / 256 * 256;
+    char* const slab128 = reinterpret_cast<char*>(lds) + S_OFF;
+    char* const vs = slab128 + wave * G128::G + ((lane & 15) >> 2) * G128::BX + (2 + 4 * (lane >> 4)) * 16 + (lane & 3) * 4;
+    chain_body_u0d<CH_U0, CH_U1>(a.c[3], lds, lane, wave, mid_out, skip2,
+                                 [&](const f32x4 (&t)[4][2]) { rd_store2<G128>(vs, t); }, slab128, 136);
     zero_halo<CH_U1::C0P, CH_U1::L, CH_U1::SROWS, CH_U1::XSTR, CH_U1::XSS, 4>(lds);
   }
   TR(131);
@@ -2305,6 +2787,50 @@ static size_t pack_vbu(std::vector<float>& blob, const float* w, const float* wr
   return base;
 }
 
+// ---- direct f16x2 packs (rd_taps): per n-tile [tap][chunk kc][piece q][lane] x 16 B; lane = (column n, the 8 channels of
+// block kc + KC (lane >> 4) of the chunk [c_lo, c_lo + cin_chunk)); kidx[tap] = the kernel index of slab-row tap `tap`; conv
+// weight layout [cout][cin_full][ks], or ConvTranspose1d [cin_full][cout][ks] (transposed); pair_cols: the interleaved
+// n-tile pairs of chain_body_d2d.  sc = the per-output-channel scales (rd_col_scales over ALL chunks and taps).
+static inline float rd_w(const float* w, int cout, int cin_full, int ks, bool transposed, int n, int ci, int k) {
+  return transposed ? w[((size_t)ci * cout + n) * ks + k] : w[((size_t)n * cin_full + ci) * ks + k];
+}
+static std::vector<float> rd_col_scales(const float* w, int cout, int cin_full, int ks, const std::vector<int>& kidx, bool transposed) {
+  std::vector<float> sc(cout);
+  for (int n = 0; n < cout; ++n) {
+    float m = 0.f;
+    for (int ci = 0; ci < cin_full; ++ci)
+      for (int k : kidx) m = fmaxf(m, fabsf(rd_w(w, cout, cin_full, ks, transposed, n, ci, k)));
+    sc[n] = f16_scale_for(m);
+  }
+  return sc;
+}
+static size_t pack_rd(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int cin_chunk, int ks,
+                      const std::vector<int>& kidx, bool transposed, bool pair_cols, const std::vector<float>& sc) {
+  while (blob.size() % 4) blob.push_back(0.f);
+  const size_t base = blob.size();
+  const int tiles = cout / 16, KC = cin_chunk / 32, T = (int)kidx.size();
+  const size_t frags = (size_t)tiles * T * KC * 2;
+  blob.resize(base + (frags + 8) * 64 * 4, 0.f);             // + slack for the ring's over-read past the last tile
+  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
+  for (int t = 0; t < tiles; ++t)
+    for (int tap = 0; tap < T; ++tap)
+      for (int kc = 0; kc < KC; ++kc)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int n = pair_cols ? (t / 2) * 32 + 2 * (lane & 15) + (t & 1) : 16 * t + (lane & 15);
+            const int ci = c_lo + 8 * (KC * (lane >> 4) + kc) + j;
+            uint16_t piece[2];
+            f16_split_host(rd_w(w, cout, cin_full, ks, transposed, n, ci, kidx[tap]), sc[n], piece);
+            for (int q = 0; q < 2; ++q) out[(((((size_t)t * T + tap) * KC + kc) * 2 + q) * 64 + lane) * 8 + j] = piece[q];
+          }
+  return base;
+}
+// ... of a 1x1 residual conv [cout][cin_full] chunk for the centre tap's extra streams: per n-tile [chunk kc][piece][lane]
+static size_t pack_rd_res(std::vector<float>& blob, const float* wres, int cout, int cin_full, int c_lo, int cin_chunk,
+                          bool pair_cols, const std::vector<float>& sc) {
+  return pack_rd(blob, wres, cout, cin_full, c_lo, cin_chunk, 1, std::vector<int>{0}, false, pair_cols, sc);
+}
+
 // max over t of |time bias| per (RTB, channel): a host replica (double) of time_table_kernel, used only for the bound
 // behind the static activation scales below (layers.py:232-258, 337-341)
 static std::vector<std::vector<float>> time_bias_absmax(const float* const* tensors, const Spec& s, int T) {
@@ -2345,7 +2871,7 @@ static float static_act_scale(const float* gamma, const float* beta, const std::
 }
 
 struct ConvW { size_t wpk, bias, gamma, beta, wbf, isc; };   // wbf / isc: f16x2 pack and its inverse channel scales
-struct RtbW { ConvW a, b; size_t res_bias, res_isc, res_bf; int tb_off; size_t a_c1, a_c1_bf; float act_a; };
+struct RtbW { ConvW a, b; size_t res_bias, res_isc, res_bf, res_c1_bf; int tb_off; size_t a_c1, a_c1_bf; float act_a; };
 
 }  // namespace mmd
 
@@ -2358,6 +2884,7 @@ struct mmd_unet_s {
   int tb_total = 0;
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
   ConvW down[2], up[2], fin;
+  size_t up_bf[2] = {0, 0}, up_is[2] = {0, 0};   // ups.0's tail: f16x2 parity packs and their inverse scales
   size_t fin_w1, fin_b1;
 };
 
@@ -2427,8 +2954,15 @@ static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb
   a.br = u->blob + w0.res_bias;
   a.isr = w0.res_isc ? u->blob + w0.res_isc : nullptr;
   a.wres_bf = w0.res_bf ? reinterpret_cast<const uint4*>(u->blob + w0.res_bf) : nullptr;
+  a.wres_c1_bf = w0.res_c1_bf ? reinterpret_cast<const uint4*>(u->blob + w0.res_c1_bf) : nullptr;
   for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, set[rtb[1 + k]], t);
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
+  if (tail == &u->up[0]) {
+    a.wt_bf0 = reinterpret_cast<const uint4*>(u->blob + u->up_bf[0]);
+    a.wt_bf1 = reinterpret_cast<const uint4*>(u->blob + u->up_bf[1]);
+    a.ist0 = u->blob + u->up_is[0];
+    a.ist1 = u->blob + u->up_is[1];
+  }
   return a;
 }
 
@@ -2487,42 +3021,51 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const int NT = (r >= 6 && r <= 9) || d1 || d2 ? 1 : 2;   // n-tiles per weight slice
     const int cinp = (R.cin + 7) / 8 * 8;            // the 4-channel network input is padded to 2 k-steps (the ring depth)
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
-    if (r == 6) {             // ups.0 conv A: the two chunks of cat(x, skip2)
-      const std::vector<float> sc = f16_col_scales(tensors[R.t_w0], R.cout, R.cin);
-      std::vector<float> scr(R.cout);
-      for (int n = 0; n < R.cout; ++n) {
-        float m = 0.f;
-        for (int ci = 0; ci < R.cin; ++ci) m = fmaxf(m, fabsf((float)((double)wres[(size_t)n * R.cin + ci] * (2.0 / 9))));
-        scr[n] = f16_scale_for(m);
-      }
+    const std::vector<int> k5 = {0, 1, 2, 3, 4};
+    const bool u0 = r == 6 || r == 7;                  // ups.0 (chain_body_u0d)
+    if (r == 6 || r == 4) {   // ups.0 / downs.2 conv A of the first RTB: direct f16x2 (rd_taps), the 1x1 residual conv on the
+                              // centre tap; ups.0's input is the two 128-channel chunks of cat(x, skip2)
+      const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
+      const std::vector<float> scr = rd_col_scales(wres, R.cout, R.cin, 1, std::vector<int>{0}, false);
+      const int chunk = r == 6 ? R.cin / 2 : R.cin;
       W.a.isc = push_inverse(blob, sc);
       W.res_isc = push_inverse(blob, scr);
-      W.a.wbf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, 0, sc, scr);
-      W.a_c1_bf = pack_vbu(blob, tensors[R.t_w0], wres, R.cout, R.cin, R.cin / 2, sc, scr);
+      W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, chunk, 5, k5, false, /*pair_cols=*/d2, sc);
+      W.res_bf = pack_rd_res(blob, wres, R.cout, R.cin, 0, chunk, d2, scr);
+      if (r == 6) {
+        W.a_c1_bf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, chunk, chunk, 5, k5, false, false, sc);
+        W.res_c1_bf = pack_rd_res(blob, wres, R.cout, R.cin, chunk, chunk, false, scr);
+      }
     } else if (r == 8) {      // ups.1: input = cat(x, skip1), staged chunk by chunk: one pack per chunk
       const int half = R.cin / 2;
       W.a.wpk = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres);
       W.a_c1 = blob.size();
       pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
-    } else if (r == 4) {      // downs.2's first RTB: conv A (64 -> 128) and the 1x1 residual conv as f16x2 (rowform_to_vslab)
-      W.a.wbf = pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);
-      W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc, /*pair_cols=*/true);
-    } else if (r == 2) {      // downs.1's first RTB: the same for 32 -> 64 (chain_body_db; plain columns)
+    } else if (r == 2) {      // downs.1's first RTB: conv A (32 -> 64) and the 1x1 residual conv as f16x2 (rowform_to_vslab)
       W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f, /*plain_blocks=*/true);
       W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc, /*pair_cols=*/false);
-    } else if ((d1 || d2) && R.cin == R.cout) {
-      W.a.wbf = d1 ? pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f) : pack_vb(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);   // dynamic input scale
+    } else if ((d2 || u0) && R.cin == R.cout) {   // conv A of an identity RTB of the L = 16 stages: direct, dynamic input scale
+      const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
+      W.a.isc = push_inverse(blob, sc);
+      W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, 5, k5, false, d2, sc);
+    } else if (d1 && R.cin == R.cout) {
+      W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);   // dynamic input scale
     } else {
       W.a.wpk = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres, /*pair_cols=*/d2);
+      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres);
     }
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
-    if (d1 || d2) {
+    if (d2 || u0) {           // conv B: direct f16x2, its input scaled by the static act_a
       W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
-      W.b.wbf = d1 ? pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc, W.act_a) : pack_vb(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc, W.act_a);
+      const std::vector<float> sc = rd_col_scales(tensors[R.t_w1], R.cout, R.cout, 5, k5, false);
+      W.b.isc = push_inverse(blob, sc, W.act_a);
+      W.b.wbf = pack_rd(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, 5, k5, false, d2, sc);
+    } else if (d1) {
+      W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
+      W.b.wbf = pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc, W.act_a);
     } else {
       while (blob.size() % 4) blob.push_back(0.f);
       W.b.wpk = blob.size();
@@ -2549,6 +3092,15 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{3, 1}, true);
     pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{2, 0}, true);
     u->up[i].bias = push(blob, tensors[s.t_up[i][1]], cu);
+    if (i == 0) {             // ups.0's tail as two direct f16x2 parity passes (chain_body_u0d)
+      const std::vector<int> ke = {3, 1}, ko = {2, 0};
+      const std::vector<float> sce = rd_col_scales(tensors[s.t_up[i][0]], cu, cu, 4, ke, true);
+      const std::vector<float> sco = rd_col_scales(tensors[s.t_up[i][0]], cu, cu, 4, ko, true);
+      u->up_is[0] = push_inverse(blob, sce);
+      u->up_is[1] = push_inverse(blob, sco);
+      u->up_bf[0] = pack_rd(blob, tensors[s.t_up[i][0]], cu, cu, 0, cu, 4, ke, true, false, sce);
+      u->up_bf[1] = pack_rd(blob, tensors[s.t_up[i][0]], cu, cu, 0, cu, 4, ko, true, false, sco);
+    }
   }
   u->fin.wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 2, nullptr);
   u->fin.bias = push(blob, tensors[s.t_final[1]], 32);

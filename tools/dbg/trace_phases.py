@@ -37,10 +37,9 @@ for base, nm in ((136, "U0"), (146, "U1")):
     for j, w in enumerate(("start", "rtb0 convA+res done", "gn+write+barrier", "rtb0 convB done", "gn+res", "id convA done", "id convB done", "gn+write -> tail")):
         names[base + j] = f"{nm} {w}"
 names.update({130: "-> U0 start", 131: "-> U1 start", 132: "-> FIN start", 133: "end"})
-# f16x2 body of downs.2 + mid (tags 90..98 are overwritten by every conv: the values are the LAST conv's, mid_block2 conv B)
-names.update({80: "D2 start", 81: "D2 rtb0 convA+gn (fp32)", 90: "last conv: start", 91: "  ring + store set 0", 92: "  barrier",
-              93: "  MFMAs set 0", 94: "  ring + barrier", 95: "  store set 1", 96: "  barrier", 97: "  MFMAs set 1",
-              98: "  out transform + GN + Mish"})
+# direct f16x2 body of downs.2 + mid (tags 90..93 are overwritten by every conv: the values are the LAST conv's, mid_block2 conv B)
+names.update({80: "D2 start", 81: "D2 rtb0 convA+res+gn", 90: "last conv: start (prev gn done)", 91: "  ring + slab store", 92: "  barrier",
+              93: "  MFMAs (5 taps x 4 chunks)", 98: "  GN + Mish (+ dyn max)"})
 prev = None
 print(f"{'tag':>4s} {'phase':28s} {'mean dt us':>10s} {'min':>8s} {'max':>8s}   cumulative(mean) us")
 for tg in tags:
