@@ -1651,67 +1651,91 @@ __device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD_RD][NT][2], const u32
 // channels of the slab; va = slab + the lane's A offset (lane group lane >> 4, row lane & 15); w[tile] = the tile's pack +
 // lane; b = ring pre-loaded with the first RD_RD steps.  RES: the stage's 1x1 residual conv rides on the centre tap's A
 // fragments (res[sample][tile] (+)=, weights wr[tile] = [chunk kc][piece] + lane).  FRESH: start from zero.
-template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES>
-__device__ __forceinline__ void rd_taps(f32x4 (&acc)[4][NT], f32x4 (&res)[4][NT], const char* va, const u32x4* const (&w)[NT],
+template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES, int MT = 4>
+__device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][NT], const char* va, const u32x4* const (&w)[NT],
                                         const u32x4* const (&wr)[NT], u32x4 (&b)[RD_RD][NT][2]) {
-  constexpr int KC = GEO::KC, STEPS = TAPS * KC;
-  static_assert(KC % RD_RD == 0, "the ring index must be static inside a tap");
-  // A fragments are double-buffered by sample pair (half a step = 2 M tiles x NT n-tiles x 3 MFMAs): 32 registers
+  constexpr int KC = GEO::KC, STEPS = TAPS * KC, HP = MT / 2;
+  static_assert(KC % RD_RD == 0 || KC == 1, "the ring index must be static inside a tap");
+  static_assert(MT % 2 == 0, "M tiles are processed in pairs");
+  // A fragments are double-buffered by M-tile pair (half a step = 2 M tiles x NT n-tiles x 3 MFMAs): 32 registers
   u32x4 a[2][2][2];
   rd_load_a<GEO>(a[0], va, TAP0, 0, 0);
-  auto one_tap = [&](auto zero, int tap) {
+  // one step = (tap, chunk kc); ri = its static ring slot
+  auto step = [&](auto zero, int tap, int kc, int ri, auto last_kc) {
+    u32x4 br[NT][2];
+    const bool with_res = RES && TAP0 + tap == 2;
+    if constexpr (RES) {
+      if (with_res) {
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      u32x4 br[NT][2];
-      const bool with_res = RES && TAP0 + tap == 2;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) br[t][q] = wr[t][(kc * 2 + q) * 64];
+      }
+    }
+#pragma unroll
+    for (int hp = 0; hp < HP; ++hp) {
+      // the next half step's A fragments (the next M-tile pair; then the next chunk, or chunk 0 of the next tap; past the
+      // last step: a valid, unused read)
+      // (buffer parity = the half step's index: static, because a rolled tap has an even number of half steps)
+      const int cur = (kc * HP + hp + (KC == 1 ? tap * HP : 0)) & 1;
+      if (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, TAP0 + tap, kc, hp + 1);
+      else rd_load_a<GEO>(a[cur ^ 1], va, decltype(last_kc)::value ? TAP0 + tap + 1 : TAP0 + tap, decltype(last_kc)::value ? 0 : kc + 1, 0);
+      MMD_PIN_LOADS();
+      const u32x4(&ac)[2][2] = a[cur];
+      const u32x4(&bc)[NT][2] = b[ri];
+#pragma unroll
+      for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (decltype(zero)::value) vb_three<true>(acc[2 * hp + sm][t], ac[sm], bc[t]);
+          else vb_three<false>(acc[2 * hp + sm][t], ac[sm], bc[t]);
+        }
       if constexpr (RES) {
         if (with_res) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
+          for (int sm = 0; sm < 2; ++sm)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) br[t][q] = wr[t][(kc * 2 + q) * 64];
+            for (int t = 0; t < NT; ++t) {
+              if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], br[t]);
+              else vb_three<false>(res[2 * hp + sm][t], ac[sm], br[t]);
+            }
         }
       }
-#pragma unroll
-      for (int hp = 0; hp < 2; ++hp) {
-        // the next half step's A fragments (the other sample pair; then the next chunk, or chunk 0 of the next tap; past the
-        // last step: a valid, unused read)
-        if (hp == 0) rd_load_a<GEO>(a[1], va, TAP0 + tap, kc, 1);
-        else rd_load_a<GEO>(a[0], va, kc + 1 < KC ? TAP0 + tap : TAP0 + tap + 1, kc + 1 < KC ? kc + 1 : 0, 0);
-        MMD_PIN_LOADS();
-        const u32x4(&ac)[2][2] = a[hp];
-        const u32x4(&bc)[NT][2] = b[kc % RD_RD];
-#pragma unroll
-        for (int sm = 0; sm < 2; ++sm)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (decltype(zero)::value && kc == 0) vb_three<true>(acc[2 * hp + sm][t], ac[sm], bc[t]);
-            else vb_three<false>(acc[2 * hp + sm][t], ac[sm], bc[t]);
-          }
-        if constexpr (RES) {
-          if (with_res) {
-#pragma unroll
-            for (int sm = 0; sm < 2; ++sm)
-#pragma unroll
-              for (int t = 0; t < NT; ++t) {
-                if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], br[t]);
-                else vb_three<false>(res[2 * hp + sm][t], ac[sm], br[t]);
-              }
-          }
-        }
-      }
-      const int nxt = tap * KC + kc + RD_RD;
-      if (nxt < STEPS) rd_load_b<GEO, NT>(b[kc % RD_RD], w, nxt);
-      MMD_PIN_LOADS();
     }
+    const int nxt = tap * KC + kc + RD_RD;
+    if (nxt < STEPS) rd_load_b<GEO, NT>(b[ri], w, nxt);
+    MMD_PIN_LOADS();
   };
-  if constexpr (FRESH) {
-    one_tap(std::true_type{}, 0);
-#pragma unroll 1
-    for (int tap = 1; tap < TAPS; ++tap) one_tap(std::false_type{}, tap);
+  static_assert(KC == 1 || (KC * HP) % 2 == 0, "A buffer parity must be static across the rolled tap loop");
+  if constexpr (KC == 1) {
+    // one chunk per tap: the ring slot alternates with the tap, so taps are unrolled in pairs (TAPS is small)
+    static_assert(RD_RD == 2, "ring of two steps");
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      if (FRESH && tap == 0) step(std::true_type{}, tap, 0, tap & 1, std::true_type{});
+      else step(std::false_type{}, tap, 0, tap & 1, std::true_type{});
+    }
   } else {
+    auto one_tap = [&](auto zero, int tap) {
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        if (decltype(zero)::value && kc == 0) {
+          if (kc + 1 < KC) step(std::true_type{}, tap, kc, kc % RD_RD, std::false_type{});
+          else step(std::true_type{}, tap, kc, kc % RD_RD, std::true_type{});
+        } else {
+          if (kc + 1 < KC) step(std::false_type{}, tap, kc, kc % RD_RD, std::false_type{});
+          else step(std::false_type{}, tap, kc, kc % RD_RD, std::true_type{});
+        }
+      }
+    };
+    if constexpr (FRESH) {
+      one_tap(std::true_type{}, 0);
 #pragma unroll 1
-    for (int tap = 0; tap < TAPS; ++tap) one_tap(std::false_type{}, tap);
+      for (int tap = 1; tap < TAPS; ++tap) one_tap(std::false_type{}, tap);
+    } else {
+#pragma unroll 1
+      for (int tap = 0; tap < TAPS; ++tap) one_tap(std::false_type{}, tap);
+    }
   }
 }
 // GroupNorm + Mish of the direct-layout tile acc[sample][tile] (raw f16x2 conv output: true value = acc * isc[tile] *
@@ -1845,6 +1869,263 @@ __device__ __forceinline__ void rowform_to_rd(const float* xslab, char* slab, co
     *reinterpret_cast<unsigned*>(dst) = f.hi;
     *reinterpret_cast<unsigned*>(dst + GEO::PS) = f.lo;
   }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// WAVE-PRIVATE direct stages (downs.0; one sample per wave): at L = 64 a sample is four M tiles of its own, and with 32
+// channels a wave holds a whole sample (4 M tiles x 2 interleaved n-tiles = 8 accumulators) -- so every conv of the stage
+// reads only what the same wave wrote: no workgroup barrier anywhere inside the stage (LDS operations of one wave execute in
+// order), GroupNorm statistics and the dynamic input scales are wave reductions, and the weights (20 KB per conv) are
+// streamed by each wave.  Slab of one sample: Rw[piece][lane group j][chunk kc][row = 2 + position][8 channels].
+// ----------------------------------------------------------------------------------------------------------------
+template <int C, int L> struct RwGeo {
+  static constexpr int KC = C / 32, RPS = 16, ROWS = L + 4, BX = ROWS * 16 + 32, G = (KC * BX + 255) / 256 * 256, PS = 4 * G;
+  static constexpr int BYTES = 2 * PS, FRAGS5 = 5 * KC * 2, FRAGS3 = 3 * KC * 2;
+};
+__device__ __forceinline__ float wave_sum_rows(float v) {   // v + the same lane of the other three 16-lane rows
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+// GroupNorm + Mish of ONE sample's tile acc[M tile][tile] (positions 16 mt + 4 g + r; true value = acc * isc[tile] * inv);
+// GL = lanes per group (the lane's NT channels belong to one group), NG = values per group
+template <int MT, int NT, int GL, int NG, bool ACT, class ADD>
+__device__ __forceinline__ void rw_gn_mish(f32x4 (&acc)[MT][NT], const float (&bias)[NT], const float (&gamma)[NT],
+                                           const float (&beta)[NT], const float (&isc)[NT], float inv, const ActScale& as, ADD add) {
+  constexpr float inv_n = 1.f / (float)NG;
+  auto gsum = [](float v) {
+    v = dpp_add<0xB1>(v);
+    if constexpr (GL >= 4) v = dpp_add<0x4E>(v);
+    if constexpr (GL >= 8) v = dpp_add<0x141>(v);
+    return wave_sum_rows(v);
+  };
+  float k[NT], bsum = 0.f, v = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    k[t] = isc[t] * inv;
+    bsum += bias[t];
+    float st = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) st += (acc[mt][t][0] + acc[mt][t][1]) + (acc[mt][t][2] + acc[mt][t][3]);
+    v = fmaf(st, k[t], v);
+  }
+  // mean over the group of (x + bias): every channel's bias counts at the sample's 16 MT positions, 4 per lane row
+  const float mean = (gsum(v) + gsum(bsum) * (float)(4 * MT)) * inv_n;
+  float dm[NT], q = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    dm[t] = mean - bias[t];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = fmaf(acc[mt][t][r], k[t], -dm[t]);
+        q = fmaf(d, d, q);
+      }
+  }
+  const float rstd = rsqrtf(fmaf(gsum(q), inv_n, 1e-5f));
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    GnCoef cf = gn_coef(dm[t], rstd, gamma[t], beta[t]);
+    cf.sa *= k[t];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][t][r] = gn_mish1<ACT>(acc[mt][t][r], cf, add(mt, t, r), as);
+  }
+}
+template <int MT, int NT>
+__device__ __forceinline__ float rw_absmax(const f32x4 (&acc)[MT][NT]) {   // the sample's |x| maximum, in every lane
+  float m = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(acc[mt][t][r]));
+  m = row_max16(m);
+  m = fmaxf(m, __shfl_xor(m, 16));
+  return fmaxf(m, __shfl_xor(m, 32));
+}
+// two-interleaved-n-tile tile of one sample (lane: channels 2 n, 2 n + 1 (+ 32 per further pair); positions 16 mt + 4 g + r)
+// -> the wave's slab; vs = slab + the lane's (block n >> 2, row 2 + 4 g, dword n & 3) offset
+template <class GEO, int MT>
+__device__ __forceinline__ void rw_store2(char* vs, const f32x4 (&acc)[MT][2]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const F16Pair f = f16_split2(acc[mt][0][r], acc[mt][1][r]);
+      *reinterpret_cast<unsigned*>(vs + (mt * 16 + r) * 16) = f.hi;
+      *reinterpret_cast<unsigned*>(vs + GEO::PS + (mt * 16 + r) * 16) = f.lo;
+    }
+}
+__device__ __forceinline__ void wave_lds_fence() {           // a wave's own LDS writes before its own later reads
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// downs.0 (4 -> 32 -> 32 channels at L = 64, Downsample1d): wave = sample.  The first conv's K is 5 taps x 4 channels = 20
+// of the 32 slots of ONE MFMA chunk (im2col: lane group j holds taps 2 j, 2 j + 1 -- two consecutive 8-byte rows of the
+// [row][4 channel] input slab), its 1x1 residual conv a second chunk with only the centre tap's slots non-zero.  The raw
+// network input has no bounded range: dynamic scale from the sample's own maximum.  The stride-2 tail is evaluated at every
+// position (3 taps, 72 MFMAs) and the even ones are kept -- stride-2 A reads would be 2-way bank conflicted.
+// xn: the next stage's row-form fp32 x slab (written behind a workgroup barrier: it aliases the waves' slabs); mxn: the
+// per-sample maxima of the tile for the next stage's dynamic scale.
+template <class CF, class CFN>
+__device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb) {
+  static_assert(CF::L == 64 && CF::CM == 32 && CF::C0 == 4 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
+                    CF::TAIL == TAIL_DOWN, "downs.0");
+  using GW = RwGeo<32, 64>;
+  constexpr int XIN = 72 * 8;                                // bytes per piece of the [row][4 channel] input slab (rows -2 .. 69)
+  constexpr int W_BYTES = GW::BYTES + 2 * XIN + 128;
+  static_assert(4 * W_BYTES <= MX_OFF * 4, "four private slabs");
+  char* const slab = reinterpret_cast<char*>(lds) + wave * W_BYTES;
+  char* const xin = slab + GW::BYTES;
+  const int n = lane & 15, g = lane >> 4, c0 = 2 * n;
+  const char* const va = slab + g * GW::G + n * 16;          // A fragment: row lane & 15, lane group lane >> 4 (KC = 1: block j)
+  char* const vs = slab + (n >> 2) * GW::G + (2 + 4 * g) * 16 + (n & 3) * 4;
+  auto wptr = [&](const uint4* w, int frags, int t) { return reinterpret_cast<const u32x4*>(w) + (size_t)t * frags * 64 + lane; };
+  TR(trb + 0);
+  // ---- stage the sample: lane = position; [row = 2 + position][4 channels] x two pieces, zero rows around it
+  float inv_in;
+  {
+    const bool valid = n0 + wave < a.n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *reinterpret_cast<const float4*>(a.in0 + ((size_t)(n0 + wave) * 64 + lane) * 4);
+    float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = row_max16(m);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const DynScale ds = dyn_scale(m);
+    inv_in = ds.inv;
+    const F16Pair p0 = f16_split2(v.x * ds.s, v.y * ds.s), p1 = f16_split2(v.z * ds.s, v.w * ds.s);
+    *reinterpret_cast<uint2*>(xin + (2 + lane) * 8) = make_uint2(p0.hi, p1.hi);
+    *reinterpret_cast<uint2*>(xin + XIN + (2 + lane) * 8) = make_uint2(p0.lo, p1.lo);
+    if (lane < 16) {                                         // rows 0, 1, 66 .. 71 of both pieces
+      const int row = (lane & 7) < 2 ? (lane & 7) : 64 + (lane & 7);
+      *reinterpret_cast<uint2*>(xin + (lane >> 3) * XIN + row * 8) = make_uint2(0u, 0u);
+    }
+    // zero halo rows of the conv slab (rows 0, 1, 66, 67 of the 4 blocks x 2 pieces)
+    if (lane < 32) *reinterpret_cast<uint4*>(slab + (lane >> 4) * GW::PS + ((lane >> 2) & 3) * GW::G + ((lane & 3) < 2 ? (lane & 3) : 64 + (lane & 3)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  wave_lds_fence();
+  f32x4 acc[4][2], res[4][2];
+  // ---- RTB 0 conv A (im2col chunk) + the 1x1 residual conv
+  {
+    u32x4 b[2][2], br[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        b[t][q] = wptr(a.r0.wa_bf, 2, t)[q * 64];
+        br[t][q] = wptr(a.wres_bf, 2, t)[q * 64];
+      }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      u32x4 af[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint2* p = reinterpret_cast<const uint2*>(xin + q * XIN + (mt * 16 + n + 2 * g) * 8);
+        const uint2 lo = p[0], hi = p[1];
+        af[q] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        vb_three<true>(acc[mt][t], af, b[t]);
+        vb_three<true>(res[mt][t], af, br[t]);
+      }
+    }
+  }
+  const float one = 1.f;
+  auto gn = [&](const float* bs, const float* gm, const float* be, const float* tb, const float* isc, float inv, float act_s) {
+    const float bb[2] = {bs[c0], bs[c0 + 1]}, gg[2] = {gm[c0], gm[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
+    const float is[2] = {isc[c0], isc[c0 + 1]};
+    if (tb) {
+      const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
+      rw_gn_mish<4, 2, 2, 256, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
+    } else {
+      rw_gn_mish<4, 2, 2, 256, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
+    }
+  };
+  u32x4 ring[RD_RD][2][2];
+  auto conv = [&](const uint4* w) {                          // one 32 -> 32 conv over the tile in acc (already scaled)
+    const u32x4* wp[2] = {wptr(w, GW::FRAGS5, 0), wptr(w, GW::FRAGS5, 1)};
+    rd_ring_load<GW, 2>(ring, wp);
+    rw_store2<GW, 4>(vs, acc);
+    wave_lds_fence();
+    rd_taps<GW, 2, 0, 5, true, false, 4>(acc, res, va, wp, wp, ring);
+    wave_lds_fence();                                        // (the next store must not overtake these reads)
+  };
+  {
+    const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[mt][t] = res[mt][t] * (isr[t] * inv_in) + br[t];
+  }
+  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+  TR(trb + 1);
+  conv(a.r0.wb_bf);
+  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one, 1.f);
+  TR(trb + 2);
+  // ---- identity RTB
+  {
+    const RtbPtrs& R = a.ri[0];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[mt][t] = acc[mt][t];
+    const DynScale ds = dyn_scale(rw_absmax<4, 2>(acc));
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
+    conv(R.wa_bf);
+    gn(R.ba, R.ga, R.bea, R.tb, R.isa, ds.inv, R.act_a);
+    TR(trb + 3);
+    conv(R.wb_bf);
+    gn(R.bb, R.gb, R.beb, nullptr, R.isb, one, 1.f);
+    TR(trb + 4);
+  }
+  // ---- tail: Downsample1d = Conv1d(k3, s2, p1): y[p] = sum_t x[p + t - 1] W_t at the even p
+  {
+    const DynScale ds = dyn_scale(rw_absmax<4, 2>(acc));
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
+    const u32x4* wt[2] = {wptr(a.wt_bf0, GW::FRAGS3, 0), wptr(a.wt_bf0, GW::FRAGS3, 1)};
+    rd_ring_load<GW, 2>(ring, wt);
+    rw_store2<GW, 4>(vs, acc);
+    wave_lds_fence();
+    f32x4 y[4][2];
+    rd_taps<GW, 2, 1, 3, true, false, 4>(y, res, va, wt, wt, ring);
+    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv};
+    float mo = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          y[mt][t][r] = fmaf(y[mt][t][r], ist[t], bt[t]);
+          mo = fmaxf(mo, fabsf(y[mt][t][r]));
+        }
+    mo = row_max16(mo);
+    mo = fmaxf(mo, __shfl_xor(mo, 16));
+    mo = fmaxf(mo, __shfl_xor(mo, 32));
+    __syncthreads();                                         // every wave is done with its slab: the next stage's x slab aliases them
+    if (lane < MX_SLOTS) (lds + MX_OFF)[wave * MX_SLOTS + lane] = mo;
+    // -> the next stage's row-form x slab [sample][2 + m][CFN::XSTR], m = p / 2 = 8 mt + 2 g + r / 2, channels 2 n, 2 n + 1
+    float* xb = lds + wave * CFN::XSS + (2 + 2 * g) * CFN::XSTR + c0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<float2*>(xb + (8 * mt + h) * CFN::XSTR) = make_float2(y[mt][0][2 * h], y[mt][1][2 * h]);
+  }
+  TR(trb + 5);
 }
 
 // downs.2 + mid blocks in the direct form.  Wave w owns the n-tiles 2 w, 2 w + 1 with INTERLEAVED columns (column n of tile h =
@@ -2326,15 +2607,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int n0 = blockIdx.x * 4;
 
   f32x4 skip1[2][4], skip2[4][2];
-  // ---- downs.0 @ L=64 -> [4][32][32]  (chain_body_db: lane = channel 16 nq + (lane & 15) in the wave's two M tiles)
-  {
-    f32x4 acc[2][4], mid[2][4];
-    f32x16 t[1];
-    chain_body_db<CH_D0, true, true>(a.c[0], lds, n0, lane, wave, acc, mid, t, 0);
-    __syncthreads();                                                       // the tail conv is done reading the H slab
-    tile_to_stage<32, 1, CH_D0::SW, CH_D0::WN, 1, CH_D1::XSS, CH_D1::XSTR>(t, lds, wave, lane, 0);
-    zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
-  }
+  // ---- downs.0 @ L=64 -> [4][32][32]: wave = sample, direct f16x2 convs on the wave's own slab (chain_body_d0w)
+  chain_body_d0w<CH_D0, CH_D1>(a.c[0], lds, n0, lane, wave, 0);
+  zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
   // ---- downs.1 @ L=32 -> [4][16][64], skip1 (lane = channel 16 wave + (lane & 15) in both M tiles)
   {
     f32x4 acc[2][4];
@@ -2825,6 +3100,27 @@ static size_t pack_rd(std::vector<float>& blob, const float* w, int cout, int ci
           }
   return base;
 }
+// downs.0's first conv (4 -> 32, k5) as ONE K = 32 chunk per n-tile: slot jj of lane (column n, lane group j) = tap 2 j + (jj >> 2),
+// channel jj & 3 (taps >= 5: zero); is_res: the 1x1 residual conv [cout][4] on the centre tap's slots.  Interleaved column pairs.
+static size_t pack_im2col4(std::vector<float>& blob, const float* w, int cout, bool is_res, const std::vector<float>& sc) {
+  while (blob.size() % 4) blob.push_back(0.f);
+  const size_t base = blob.size();
+  const int tiles = cout / 16;
+  blob.resize(base + ((size_t)tiles * 2 + 8) * 64 * 4, 0.f);
+  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
+  for (int t = 0; t < tiles; ++t)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int jj = 0; jj < 8; ++jj) {
+        const int n = (t / 2) * 32 + 2 * (lane & 15) + (t & 1), tap = 2 * (lane >> 4) + (jj >> 2), c = jj & 3;
+        float v = 0.f;
+        if (is_res) v = tap == 2 ? w[(size_t)n * 4 + c] : 0.f;
+        else if (tap < 5) v = w[((size_t)n * 4 + c) * 5 + tap];
+        uint16_t piece[2];
+        f16_split_host(v, sc[n], piece);
+        for (int q = 0; q < 2; ++q) out[(((size_t)t * 2 + q) * 64 + lane) * 8 + jj] = piece[q];
+      }
+  return base;
+}
 // ... of a 1x1 residual conv [cout][cin_full] chunk for the centre tap's extra streams: per n-tile [chunk kc][piece][lane]
 static size_t pack_rd_res(std::vector<float>& blob, const float* wres, int cout, int cin_full, int c_lo, int cin_chunk,
                           bool pair_cols, const std::vector<float>& sc) {
@@ -2885,6 +3181,7 @@ struct mmd_unet_s {
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
   ConvW down[2], up[2], fin;
   size_t up_bf[2] = {0, 0}, up_is[2] = {0, 0};   // ups.0's tail: f16x2 parity packs and their inverse scales
+  size_t down_bf = 0, down_is = 0;               // downs.0's tail: f16x2 pack and its inverse scales
   size_t fin_w1, fin_b1;
 };
 
@@ -2957,6 +3254,10 @@ static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb
   a.wres_c1_bf = w0.res_c1_bf ? reinterpret_cast<const uint4*>(u->blob + w0.res_c1_bf) : nullptr;
   for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, set[rtb[1 + k]], t);
   if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
+  if (tail == &u->down[0]) {
+    a.wt_bf0 = reinterpret_cast<const uint4*>(u->blob + u->down_bf);
+    a.ist0 = u->blob + u->down_is;
+  }
   if (tail == &u->up[0]) {
     a.wt_bf0 = reinterpret_cast<const uint4*>(u->blob + u->up_bf[0]);
     a.wt_bf1 = reinterpret_cast<const uint4*>(u->blob + u->up_bf[1]);
@@ -3023,7 +3324,15 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
     const std::vector<int> k5 = {0, 1, 2, 3, 4};
     const bool u0 = r == 6 || r == 7;                  // ups.0 (chain_body_u0d)
-    if (r == 6 || r == 4) {   // ups.0 / downs.2 conv A of the first RTB: direct f16x2 (rd_taps), the 1x1 residual conv on the
+    const bool d0 = r == 0 || r == 1;                  // downs.0 (chain_body_d0w): interleaved column pairs like downs.2
+    if (r == 0) {             // downs.0's first conv (4 -> 32): one im2col chunk + the 1x1 residual conv's chunk
+      const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
+      const std::vector<float> scr = rd_col_scales(wres, R.cout, R.cin, 1, std::vector<int>{0}, false);
+      W.a.isc = push_inverse(blob, sc);
+      W.res_isc = push_inverse(blob, scr);
+      W.a.wbf = pack_im2col4(blob, tensors[R.t_w0], R.cout, false, sc);
+      W.res_bf = pack_im2col4(blob, wres, R.cout, true, scr);
+    } else if (r == 6 || r == 4) {   // ups.0 / downs.2 conv A of the first RTB: direct f16x2 (rd_taps), the 1x1 residual conv on the
                               // centre tap; ups.0's input is the two 128-channel chunks of cat(x, skip2)
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
       const std::vector<float> scr = rd_col_scales(wres, R.cout, R.cin, 1, std::vector<int>{0}, false);
@@ -3045,10 +3354,10 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     } else if (r == 2) {      // downs.1's first RTB: conv A (32 -> 64) and the 1x1 residual conv as f16x2 (rowform_to_vslab)
       W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f, /*plain_blocks=*/true);
       W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc, /*pair_cols=*/false);
-    } else if ((d2 || u0) && R.cin == R.cout) {   // conv A of an identity RTB of the L = 16 stages: direct, dynamic input scale
+    } else if ((d2 || u0 || d0) && R.cin == R.cout) {   // conv A of an identity RTB of the direct stages: dynamic input scale
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
       W.a.isc = push_inverse(blob, sc);
-      W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, 5, k5, false, d2, sc);
+      W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, 5, k5, false, d2 || d0, sc);
     } else if (d1 && R.cin == R.cout) {
       W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);   // dynamic input scale
     } else {
@@ -3058,11 +3367,11 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
-    if (d2 || u0) {           // conv B: direct f16x2, its input scaled by the static act_a
+    if (d2 || u0 || d0) {     // conv B: direct f16x2, its input scaled by the static act_a
       W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w1], R.cout, R.cout, 5, k5, false);
       W.b.isc = push_inverse(blob, sc, W.act_a);
-      W.b.wbf = pack_rd(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, 5, k5, false, d2, sc);
+      W.b.wbf = pack_rd(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, 5, k5, false, d2 || d0, sc);
     } else if (d1) {
       W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
       W.b.wbf = pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc, W.act_a);
@@ -3086,6 +3395,12 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     const int c = dims[i + 1];
     u->down[i].wpk = blob.size(); pack_b(blob, tensors[s.t_down[i][0]], c, c, 3, taps3, false);
     u->down[i].bias = push(blob, tensors[s.t_down[i][1]], c);
+    if (i == 0) {             // downs.0's tail as a direct f16x2 conv (chain_body_d0w): taps 0..2, interleaved column pairs
+      const std::vector<int> k3 = {0, 1, 2};
+      const std::vector<float> sct = rd_col_scales(tensors[s.t_down[i][0]], c, c, 3, k3, false);
+      u->down_is = push_inverse(blob, sct);
+      u->down_bf = pack_rd(blob, tensors[s.t_down[i][0]], c, c, 0, c, 3, k3, false, true, sct);
+    }
     const int cu = dims[2 - i];
     // ConvTranspose1d(k=4, s=2, p=1): out[2m] = in[m-1] W3 + in[m] W1 ; out[2m+1] = in[m] W2 + in[m+1] W0
     u->up[i].wpk = blob.size();
