@@ -1641,21 +1641,21 @@ __device__ __forceinline__ void rd_load_a(u32x4 (&a)[2][2], const char* va, int 
       a[sm][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + ((2 * hp + sm) * GEO::RPS + rowoff) * 16);
 }
 constexpr int RD_RD = 2;                    // weight ring depth in steps
-template <class GEO, int NT>
-__device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD_RD][NT][2], const u32x4* const (&w)[NT]) {
+template <class GEO, int NT, int RD = RD_RD>
+__device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD][NT][2], const u32x4* const (&w)[NT]) {
 #pragma unroll
-  for (int i = 0; i < RD_RD; ++i) rd_load_b<GEO, NT>(b[i], w, i);
+  for (int i = 0; i < RD; ++i) rd_load_b<GEO, NT>(b[i], w, i);
   MMD_PIN_LOADS();
 }
 // acc[sample][tile] (+)= conv over TAPS taps (slab rows TAP0 .. TAP0 + TAPS - 1 relative to the output position) x the C
 // channels of the slab; va = slab + the lane's A offset (lane group lane >> 4, row lane & 15); w[tile] = the tile's pack +
 // lane; b = ring pre-loaded with the first RD_RD steps.  RES: the stage's 1x1 residual conv rides on the centre tap's A
 // fragments (res[sample][tile] (+)=, weights wr[tile] = [chunk kc][piece] + lane).  FRESH: start from zero.
-template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES, int MT = 4>
+template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES, int MT = 4, int RD = RD_RD>
 __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][NT], const char* va, const u32x4* const (&w)[NT],
-                                        const u32x4* const (&wr)[NT], u32x4 (&b)[RD_RD][NT][2]) {
+                                        const u32x4* const (&wr)[NT], u32x4 (&b)[RD][NT][2]) {
   constexpr int KC = GEO::KC, STEPS = TAPS * KC, HP = MT / 2;
-  static_assert(KC % RD_RD == 0 || KC == 1, "the ring index must be static inside a tap");
+  static_assert(KC % RD == 0 || KC == 1, "the ring index must be static inside a tap");
   static_assert(MT % 2 == 0, "M tiles are processed in pairs");
   // A fragments are double-buffered by M-tile pair (half a step = 2 M tiles x NT n-tiles x 3 MFMAs): 32 registers
   u32x4 a[2][2][2];
@@ -1702,18 +1702,18 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
         }
       }
     }
-    const int nxt = tap * KC + kc + RD_RD;
+    const int nxt = tap * KC + kc + RD;
     if (nxt < STEPS) rd_load_b<GEO, NT>(b[ri], w, nxt);
     MMD_PIN_LOADS();
   };
   static_assert(KC == 1 || (KC * HP) % 2 == 0, "A buffer parity must be static across the rolled tap loop");
   if constexpr (KC == 1) {
-    // one chunk per tap: the ring slot alternates with the tap, so taps are unrolled in pairs (TAPS is small)
-    static_assert(RD_RD == 2, "ring of two steps");
+    // one chunk per tap: the taps are unrolled (TAPS is small), ring slot tap % RD (RD = TAPS: the whole conv's weights are
+    // in flight before the first MFMA -- a wave-private conv is too short to hide a weight fetch behind two steps)
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-      if (FRESH && tap == 0) step(std::true_type{}, tap, 0, tap & 1, std::true_type{});
-      else step(std::false_type{}, tap, 0, tap & 1, std::true_type{});
+      if (FRESH && tap == 0) step(std::true_type{}, tap, 0, tap % RD, std::true_type{});
+      else step(std::false_type{}, tap, 0, tap % RD, std::true_type{});
     }
   } else {
     auto one_tap = [&](auto zero, int tap) {
@@ -2048,13 +2048,18 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
       rw_gn_mish<4, 2, 2, 256, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
     }
   };
-  u32x4 ring[RD_RD][2][2];
+  // The whole weight set of a conv (5 taps x 2 n-tiles x 2 pieces = 20 KB per wave) is requested BEFORE the epilogue that
+  // produces the conv's input (preload), so the L2 latency hides behind GroupNorm + Mish instead of in front of the MFMAs.
+  u32x4 ring[5][2][2];
+  auto preload = [&](const uint4* w) {
+    const u32x4* wp[2] = {wptr(w, GW::FRAGS5, 0), wptr(w, GW::FRAGS5, 1)};
+    rd_ring_load<GW, 2, 5>(ring, wp);
+  };
   auto conv = [&](const uint4* w) {                          // one 32 -> 32 conv over the tile in acc (already scaled)
     const u32x4* wp[2] = {wptr(w, GW::FRAGS5, 0), wptr(w, GW::FRAGS5, 1)};
-    rd_ring_load<GW, 2>(ring, wp);
     rw_store2<GW, 4>(vs, acc);
     wave_lds_fence();
-    rd_taps<GW, 2, 0, 5, true, false, 4>(acc, res, va, wp, wp, ring);
+    rd_taps<GW, 2, 0, 5, true, false, 4, 5>(acc, res, va, wp, wp, ring);
     wave_lds_fence();                                        // (the next store must not overtake these reads)
   };
   {
@@ -2064,9 +2069,11 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
 #pragma unroll
       for (int t = 0; t < 2; ++t) res[mt][t] = res[mt][t] * (isr[t] * inv_in) + br[t];
   }
+  preload(a.r0.wb_bf);
   gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
   TR(trb + 1);
   conv(a.r0.wb_bf);
+  preload(a.ri[0].wa_bf);
   gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one, 1.f);
   TR(trb + 2);
   // ---- identity RTB
@@ -2082,6 +2089,7 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
     conv(R.wa_bf);
+    preload(R.wb_bf);
     gn(R.ba, R.ga, R.bea, R.tb, R.isa, ds.inv, R.act_a);
     TR(trb + 3);
     conv(R.wb_bf);
@@ -2096,11 +2104,12 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
     const u32x4* wt[2] = {wptr(a.wt_bf0, GW::FRAGS3, 0), wptr(a.wt_bf0, GW::FRAGS3, 1)};
-    rd_ring_load<GW, 2>(ring, wt);
+    u32x4 ring3[3][2][2];
+    rd_ring_load<GW, 2, 3>(ring3, wt);
     rw_store2<GW, 4>(vs, acc);
     wave_lds_fence();
     f32x4 y[4][2];
-    rd_taps<GW, 2, 1, 3, true, false, 4>(y, res, va, wt, wt, ring);
+    rd_taps<GW, 2, 1, 3, true, false, 4, 3>(y, res, va, wt, wt, ring3);
     const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv};
     float mo = 0.f;
 #pragma unroll
