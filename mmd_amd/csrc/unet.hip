@@ -108,57 +108,6 @@ constexpr int MX_SLOTS = 8;                                  // partial maxima p
 constexpr int MX_REGION = 4 * MX_SLOTS;                      // region 0: the conv being prepared; 1 / 2: downs.2's skip2 / the
 constexpr int MX_FLOATS = 3 * MX_REGION;                     // mid blocks' output, kept for ups.0's conv A
 
-// Stage SPB samples' [LIN, C] rows (channels-last, optionally a concat of two tensors) into an LDS slab
-// [SPB][ROWS][STR] at row offset ROFF; samples >= n are zero filled.
-template <int C0, int C1, int CP, int LIN, int ROWS, int ROFF, int STR, int SPB, int SS = ROWS * STR, int NTHR = 256>
-__device__ __forceinline__ void stage_slab(float* slab, const float* __restrict__ in0, const float* __restrict__ in1,
-                                           int n0, int n) {
-  constexpr int C = C0 + C1;
-  const int tid = threadIdx.x;
-  if constexpr (C % 4 == 0) {
-    constexpr int C4 = C / 4;
-    constexpr int TOT = SPB * LIN * C4;
-    for (int idx = tid; idx < TOT; idx += NTHR) {
-      int c4 = idx % C4;
-      int l = (idx / C4) % LIN;
-      int s = idx / (C4 * LIN);
-      int c = c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + s < n) {
-        if (c < C0)
-          v = *reinterpret_cast<const float4*>(in0 + ((size_t)(n0 + s) * LIN + l) * C0 + c);
-        else
-          v = *reinterpret_cast<const float4*>(in1 + ((size_t)(n0 + s) * LIN + l) * C1 + (c - C0));
-      }
-      float* d = slab + s * SS + (l + ROFF) * STR + c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-  }
-  // zero the channel padding (C..CP) -- only the 4-channel input layer has any
-  if constexpr (CP > C) {
-    constexpr int PADC = CP - C;
-    constexpr int TOT = SPB * LIN * PADC;
-    for (int idx = tid; idx < TOT; idx += NTHR) {
-      int c = C + idx % PADC;
-      int l = (idx / PADC) % LIN;
-      int s = idx / (PADC * LIN);
-      slab[s * SS + (l + ROFF) * STR + c] = 0.f;
-    }
-  }
-  // zero halo rows
-  if constexpr (ROFF > 0) {
-    constexpr int HR = ROWS - LIN;   // halo rows per sample
-    constexpr int TOT = SPB * HR * CP;
-    for (int idx = tid; idx < TOT; idx += NTHR) {
-      int c = idx % CP;
-      int hr = (idx / CP) % HR;
-      int s = idx / (CP * HR);
-      int row = hr < ROFF ? hr : LIN + hr;
-      slab[s * SS + row * STR + c] = 0.f;
-    }
-  }
-}
-
 // acc[mt] += A(slab rows, taps x CP channels) * B(packed).  abase[mt] is the lane's slab offset of (row, k=lane>>5)
 // for tap 0; tap t reads STR floats further.  wp points at this lane's float4 of the first k-group.
 // B fragments are prefetched FOUR k-groups (32 MFMAs = 2048 cycles) ahead through a 4-register ring so the L2
@@ -543,9 +492,6 @@ __device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[
 // dword address 132 k + 8 i, the b128 lane groups of MI355X_MICROARCH.md section LDS hit 16 distinct 4-bank sets) and
 // for the epilogue's ds_write_b128 (8 consecutive channels of one row: banks 4 c .. 4 c + 3).
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int VROW = 8;                    // floats per (channel, row)
-constexpr int VCS = 16 * VROW + 4;         // channel stride in floats
-constexpr int VSLAB_FLOATS = 128 * VCS;    // the largest V slab: 128 channels (67.6 KB)
 
 //                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
 using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
@@ -557,75 +503,12 @@ constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // The L = 16 stages (downs.2 + mid, ups.0) work on V-form slabs of up to 128 channels that alias their row-form slabs.
-constexpr int MX_OFF =
-    cmax(cmax(cmax(CH_D0::LDS_FLOATS, CH_D1::LDS_FLOATS), cmax(CH_D2::XSLAB, CH_U0::HSLAB)),
-         cmax(cmax(CH_U1::LDS_FLOATS, 4 * FIN_SS), VSLAB_FLOATS + 4 * VCS)) + 8;   // + slack: the A double buffers read one k-step past the end
+// LDS of a workgroup: the largest stage is downs.2 / ups.0 -- the row-form fp32 x slab of downs.2's input + the 128-channel Rd
+// slab (2 x 21504 B) behind it; downs.1 (x slab + phase slab + raw slab of its first conv: 62720 B), ups.1 (56448 B), the
+// four private slabs of downs.0 (46080 B) and the final block fit below it (static_asserts in the stage bodies).
+constexpr int MX_OFF = ((CH_D2::SPB * CH_D2::XSS * 4 + 255) / 256 * 256 + 43008) / 4 + 8;
+static_assert(MX_OFF >= CH_D1::LDS_FLOATS && MX_OFF >= CH_U1::LDS_FLOATS && MX_OFF >= 4 * FIN_SS, "stage slabs");
 constexpr int UNET_LDS_FLOATS = MX_OFF + MX_FLOATS;          // + the per-sample maxima of the dynamic input scales
-
-// x(o, r) = position 4 r + o of the lane's (sample, channel); vb = slab + channel * VCS + 4 * sample * VROW
-template <class GET>
-__device__ __forceinline__ void vform_store(float* vb, GET x) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float d[8], v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pos = 4 * r - 2 + j;                                   // the conv's zero padding outside [0, 16)
-      d[j] = (pos < 0 || pos > 15) ? 0.f : x(pos & 3, pos >> 2);
-    }
-    w4_transform(v, d);
-    *reinterpret_cast<float4*>(vb + r * VROW) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(vb + r * VROW + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    asm volatile("" ::: "memory");   // one quad at a time: keeps the 8 transformed values of a quad from piling up in VGPRs
-  }
-}
-// one-n-tile quad tile (wave = 16-channel n-tile `ntile`) -> V slab
-__device__ __forceinline__ void quad1_to_vform(const f32x4 (&q)[4], float* vslab, int ntile, int lane) {
-  vform_store(vslab + (ntile * 16 + (lane & 15)) * VCS + (lane >> 4) * 4 * VROW, [&](int o, int r) { return q[o][r]; });
-}
-
-// One k-step on an fp32 V slab: 8 * NT MFMAs m[p * NT + nt] += V_p x U_p[nt] (ups.0's 64 -> 64 convs).
-template <int NT, bool ZERO>
-__device__ __forceinline__ void w4v_step(f32x4 (&m)[8 * NT], const float4 (&a)[2], const BQ<2 * NT>& b) {
-  if constexpr (ZERO) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8 * NT; ++i) m[i] = z;
-  }
-  const float v[8] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w};
-  w4_mfma_pos<NT, false, ZERO>(m, v, b);
-}
-
-// m = conv over CP channels of a V slab; abase = the lane's float offset of (channel lane >> 4, row lane & 15);
-// b = ring pre-loaded with the first W4_RD k-steps of wp.  A operands are double-buffered (the two ds_read_b128 of k-step
-// j + 1 are issued before the MFMAs of k-step j); past the last k-step they read the slab's slack and are unused.
-template <int CP, int NT>
-__device__ __forceinline__ void w4v_taps(f32x4 (&m)[8 * NT], const float* vslab, int abase, const float* __restrict__ wp,
-                                         BQ<2 * NT> (&b)[W4_RD]) {
-  constexpr int KS = CP / 4, RD = W4_RD, NQ = 2 * NT, KSTRIDE = 64 * 4 * NQ;
-  static_assert(KS % RD == 0, "k-steps are unrolled by the ring depth");
-  const float* p = wp;
-  const float4* s = reinterpret_cast<const float4*>(vslab + abase);   // one k-step = 4 channels = VCS float4 further
-  float4 a[2][2];
-  a[0][0] = s[0]; a[0][1] = s[1];
-  auto iter = [&](auto first) {
-    p += RD * KSTRIDE;
-#pragma unroll
-    for (int j = 0; j < RD; ++j) {
-      a[(j + 1) & 1][0] = s[(j + 1) * VCS];
-      a[(j + 1) & 1][1] = s[(j + 1) * VCS + 1];
-      MMD_PIN_LOADS();
-      if (decltype(first)::value && j == 0) w4v_step<NT, true>(m, a[0], b[0]);
-      else w4v_step<NT, false>(m, a[j & 1], b[j]);
-      b[j] = load_bq<NQ>(p + j * KSTRIDE);
-      MMD_PIN_LOADS();
-    }
-    s += RD * VCS;
-  };
-  iter(std::true_type{});
-#pragma unroll 1
-  for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
-}
 
 // Synchronisation between a slab write and the conv that reads it.  WAVE_PRIVATE (the final block: one M tile = one sample
 // per wave): a wave only ever reads what it wrote -- LDS operations of one wave execute in order, and only the compiler
@@ -679,12 +562,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int VB_CB = 16 * 16 + 32;        // bytes between the 8-channel blocks c, c + 1 of a group of four (c & 3)
-constexpr int VB_CG = 5 * 256;             // bytes between the groups of four channel blocks (c >> 2): a multiple of 256
-constexpr int VB_PS = 4 * VB_CG;           // bytes per (piece, slot): 128 channels
-constexpr int VB_BYTES = 8 * VB_PS;        // 2 pieces x 4 slots = 40960 B
-constexpr int VB_FRAGS = 2 * 16 * 2;       // weight fragments per n-tile and conv
-static_assert(VB_BYTES <= VSLAB_FLOATS * 4, "the f16x2 phase slab aliases the fp32 V slab");
 __host__ __device__ constexpr int vb_pos(int ph, int slot) { return ph == 0 ? (slot == 3 ? 7 : slot) : 3 + slot; }
 
 // the two pieces of a pair of values (v0: the even channel) as dwords {v1 piece, v0 piece}: hi = RN16(v), lo = RN16(v - hi)
@@ -694,49 +571,6 @@ __device__ __forceinline__ F16Pair f16_split2(float v0, float v1) {
   const f16x2 l = __builtin_convertvector(f32x2{v0 - (float)h.x, v1 - (float)h.y}, f16x2);
   return F16Pair{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
 }
-// The lane holds two adjacent channels (v0: the even one): their pieces pair up into dwords at slot offset OFF of the
-// lane's slab position.
-template <int OFF>
-__device__ __forceinline__ void vb_put2(char* base, float v0, float v1) {
-  const F16Pair p = f16_split2(v0, v1);
-  *reinterpret_cast<unsigned*>(base + OFF) = p.hi;
-  *reinterpret_cast<unsigned*>(base + OFF + 4 * VB_PS) = p.lo;
-}
-// phase PH of the V transform of the lane's two (sample, channel) columns: x(o, r) = position 4 r + o; base = slab + the
-// lane's (channel block, row 4 * sample, channel % 8) offset.  The expressions are w4_transform's.
-template <int PH, class GET0, class GET1>
-__device__ __forceinline__ void vb_store_pair(char* base, GET0 x0, GET1 x1) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float d[8], e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pos = 4 * r - 2 + j;
-      d[j] = (pos < 0 || pos > 15) ? 0.f : x0(pos & 3, pos >> 2);
-      e[j] = (pos < 0 || pos > 15) ? 0.f : x1(pos & 3, pos >> 2);
-    }
-    char* p = base + r * 64;                                 // row' = 4 r + sample
-    if constexpr (PH == 0) {
-      const float de1 = fmaf(-4.25f, d[4], d[2]) + d[6], do1 = fmaf(-4.25f, d[3], d[1]) + d[5];
-      const float ee1 = fmaf(-4.25f, e[4], e[2]) + e[6], eo1 = fmaf(-4.25f, e[3], e[1]) + e[5];
-      vb_put2<0 * VB_PS>(p, fmaf(5.25f, d[2] - d[4], d[6] - d[0]), fmaf(5.25f, e[2] - e[4], e[6] - e[0]));
-      vb_put2<1 * VB_PS>(p, de1 + do1, ee1 + eo1);
-      vb_put2<2 * VB_PS>(p, de1 - do1, ee1 - eo1);
-      vb_put2<3 * VB_PS>(p, fmaf(5.25f, d[3] - d[5], d[7] - d[1]), fmaf(5.25f, e[3] - e[5], e[7] - e[1]));
-    } else {
-      const float de2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), do2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
-      const float de3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), do3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
-      const float ee2 = fmaf(0.25f, e[2], fmaf(-1.25f, e[4], e[6])), eo2 = fmaf(0.5f, e[1], fmaf(-2.5f, e[3], 2.f * e[5]));
-      const float ee3 = fmaf(4.f, e[2], fmaf(-5.f, e[4], e[6])), eo3 = fmaf(2.f, e[1], fmaf(-2.5f, e[3], 0.5f * e[5]));
-      vb_put2<0 * VB_PS>(p, de2 + do2, ee2 + eo2);
-      vb_put2<1 * VB_PS>(p, de2 - do2, ee2 - eo2);
-      vb_put2<2 * VB_PS>(p, de3 + do3, ee3 + eo3);
-      vb_put2<3 * VB_PS>(p, de3 - do3, ee3 - eo3);
-    }
-    asm volatile("" ::: "memory");
-  }
-}
-
 __device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -757,57 +591,10 @@ template <int C, int L> struct VbGeoL {        // L rows (4 samples x L / 4 quad
   static constexpr int KC = C / 32, X = L * 16 + 32, G = (KC * X + 255) / 256 * 256, PS = 4 * G, STEPS = 4 * KC;
   static constexpr int BYTES = 8 * PS, FRAGS = 2 * STEPS * 2;
 };
-template <int C> using VbGeo = VbGeoL<C, 16>;
-static_assert(VbGeo<128>::G == VB_CG && VbGeo<128>::PS == VB_PS && VbGeo<128>::FRAGS == VB_FRAGS, "128-channel geometry");
-// A step = 6 MFMAs: the wave's two n-tiles (two accumulator streams, one after the other) at chunk step / 4, slot step % 4,
-// on one set of A fragments.
-template <class GEO>
-__device__ __forceinline__ void vb_load_b(u32x4 (&b)[2][2], const u32x4* const (&w)[2], int ph, int step) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const u32x4* p = w[t] + ((ph * GEO::STEPS + step) * 2) * 64;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) b[t][q] = p[q * 64];
-  }
-}
-template <class GEO>
-__device__ __forceinline__ void vb_load_a(u32x4 (&a)[2], const char* va, int step) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step % 4) * GEO::PS + (step / 4) * GEO::X);
-}
-// the first VB_RD steps' weights of phase PH into the ring (issued ahead of the barrier that publishes the slab)
 #ifndef MMD_VB_RD
 #define MMD_VB_RD 2
 #endif
-constexpr int VB_RD = MMD_VB_RD;           // ring depth in steps (4 KB per wave and step in flight)
-template <class GEO, int PH>
-__device__ __forceinline__ void vb_ring_load(u32x4 (&b)[VB_RD][2][2], const u32x4* const (&w)[2]) {
-#pragma unroll
-  for (int i = 0; i < VB_RD; ++i) vb_load_b<GEO>(b[i], w, PH, i);
-  MMD_PIN_LOADS();
-}
-// m[tile][position] of phase PH's four positions = conv over the channels of the slab; va = slab + the lane's A offset
-// (lane group lane >> 4, row lane & 15); w[tile] = the tile's pack + lane; b = ring (vb_ring_load)
-template <class GEO, int PH>
-__device__ __forceinline__ void vb_taps(f32x4 (&m)[2][8], const char* va, const u32x4* const (&w)[2], u32x4 (&b)[VB_RD][2][2]) {
-  u32x4 a[2][2];
-  vb_load_a<GEO>(a[0], va, 0);
-#pragma unroll
-  for (int i = 0; i < GEO::STEPS; ++i) {
-    if (i + 1 < GEO::STEPS) vb_load_a<GEO>(a[(i + 1) & 1], va, i + 1);
-    MMD_PIN_LOADS();
-    const int pos = vb_pos(PH, i % 4);
-    if (i / 4 == 0) {
-      vb_three<true>(m[0][pos], a[i & 1], b[i % VB_RD][0]);
-      vb_three<true>(m[1][pos], a[i & 1], b[i % VB_RD][1]);
-    } else {
-      vb_three<false>(m[0][pos], a[i & 1], b[i % VB_RD][0]);
-      vb_three<false>(m[1][pos], a[i & 1], b[i % VB_RD][1]);
-    }
-    if (i + VB_RD < GEO::STEPS) vb_load_b<GEO>(b[i % VB_RD], w, PH, i + VB_RD);
-    MMD_PIN_LOADS();
-  }
-}
+constexpr int VB_RD = MMD_VB_RD;           // weight ring depth in steps of the Winograd-form f16x2 convs (downs.1)
 
 // ---- a stage's FIRST conv (conv A of its first RTB) as f16x2: the input arrives as a row-form fp32 slab [sample][L + 4][STR]
 // (2-row zero halo) from the previous stage's strided conv; all 256 threads turn it into the conv's phase slab -- V = B^T d
@@ -836,7 +623,6 @@ __device__ __forceinline__ void w4_phase(float (&v)[4], const float (&d)[8]) {  
 template <int C, int L> struct VrGeoL {        // raw slab of the residual GEMM: 4 position classes o x L rows x 16 B per channel block
   static constexpr int KC = C / 32, X = 4 * L * 16 + 32, G = (KC * X + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
 };
-template <int C> using VrGeo = VrGeoL<C, 16>;
 template <int PH, int C, int L, int XSS, int XSTR>
 __device__ __forceinline__ void rowform_to_vslab(const float* xslab, char* vphase, char* vraw, const float* mx) {
   using GEO = VbGeoL<C, L>;
@@ -900,89 +686,6 @@ __device__ __forceinline__ void vr_taps_m2(f32x4 (&res)[2][4], const char* vr, c
       }
   }
 }
-// res[tile][o] (C/D fragment of M tile o) = 1x1 conv over the raw slab's C channels; vr = raw slab + the lane's A offset
-// (lane group lane >> 4, row lane & 15); w[tile] = the tile's residual pack [chunk kc][piece] + lane
-template <int C>
-__device__ __forceinline__ void vr_taps(f32x4 (&res)[2][4], const char* vr, const u32x4* const (&w)[2]) {
-  using GR = VrGeo<C>;
-#pragma unroll
-  for (int kc = 0; kc < GR::KC; ++kc) {
-    u32x4 b[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) b[t][q] = w[t][(kc * 2 + q) * 64];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      u32x4 a[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const u32x4*>(vr + q * GR::PS + kc * GR::X + o * 256);
-      if (kc == 0) {
-        vb_three<true>(res[0][o], a, b[0]);
-        vb_three<true>(res[1][o], a, b[1]);
-      } else {
-        vb_three<false>(res[0][o], a, b[0]);
-        vb_three<false>(res[1][o], a, b[1]);
-      }
-    }
-  }
-}
-
-// ups.0's conv A (256 -> 64 over the two 128-channel chunks of cat(x, skip2), with the stage's 1x1 residual conv in the
-// Winograd domain) in the same f16x2 form.  One n-tile per wave; the accumulator streams of a step are the two slots of a
-// slot pair (pair, pair + 1), and the residual conv -- G g of a centre-tap-only kernel is w * (-2/9, -2/9, 2/45, 2/45, 8/45,
-// 8/45) at positions 1..6, zero at 0 and 7 -- rides on the A fragments already loaded: one more stream in phase 0 (position
-// 1 resp. 2 of the pair), two in phase 1.  Weights per n-tile and chunk: [phase][step = 2 chunk kc + pair][6 fragments:
-// slot 0 pieces, slot 1 pieces, residual pieces]; the residual weights carry their own per-channel scale.
-constexpr int VBU_FRAGS = 2 * 2 * 4 * 6;
-__device__ __forceinline__ void vbu_load_b(u32x4 (&b)[6], const u32x4* w, int ph, int step) {
-  const u32x4* p = w + ((ph * 8 + step) * 6) * 64;
-#pragma unroll
-  for (int f = 0; f < 6; ++f) b[f] = p[f * 64];
-}
-__device__ __forceinline__ void vbu_load_a(u32x4 (&a)[2][2], const char* va, int step) {   // step = 2 kc + pair
-#pragma unroll
-  for (int st = 0; st < 2; ++st)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      a[st][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + 2 * (step % 2) + st) * VB_PS + (step / 2) * VB_CB);
-}
-template <int PH>
-__device__ __forceinline__ void vbu_ring_load(u32x4 (&b)[VB_RD][6], const u32x4* w) {
-#pragma unroll
-  for (int i = 0; i < VB_RD; ++i) vbu_load_b(b[i], w, PH, i);
-  MMD_PIN_LOADS();
-}
-// phase PH of one chunk: m[position] (+)= conv, rm[position - 1] (+)= residual conv; FRESH: first chunk (start from zero)
-template <int PH, bool FRESH>
-__device__ __forceinline__ void vbu_taps(f32x4 (&m)[8], f32x4 (&rm)[6], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][6]) {
-  u32x4 a[2][2][2];
-  vbu_load_a(a[0], va, 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (i + 1 < 8) vbu_load_a(a[(i + 1) & 1], va, i + 1);
-    MMD_PIN_LOADS();
-    const int pair = i % 2, px = vb_pos(PH, 2 * pair), py = vb_pos(PH, 2 * pair + 1);
-    // residual streams: phase 0: the pair's one position in 1..6 (pair 0: position 1 = slot 1, pair 1: position 2 = slot 0)
-    const int r0 = PH == 0 ? pair : px - 1, r1 = py - 1, sa0 = PH == 0 ? 1 - pair : 0;
-    const u32x4(&bb)[6] = b[i % VB_RD];
-    const u32x4 b0[2] = {bb[0], bb[1]}, b1[2] = {bb[2], bb[3]}, br[2] = {bb[4], bb[5]};
-    if (FRESH && i / 2 == 0) {
-      vb_three<true>(m[px], a[i & 1][0], b0);
-      vb_three<true>(m[py], a[i & 1][1], b1);
-      vb_three<true>(rm[r0], a[i & 1][sa0], br);
-      if constexpr (PH == 1) vb_three<true>(rm[r1], a[i & 1][1], br);
-    } else {
-      vb_three<false>(m[px], a[i & 1][0], b0);
-      vb_three<false>(m[py], a[i & 1][1], b1);
-      vb_three<false>(rm[r0], a[i & 1][sa0], br);
-      if constexpr (PH == 1) vb_three<false>(rm[r1], a[i & 1][1], br);
-    }
-    if (i + VB_RD < 8) vbu_load_b(b[i % VB_RD], w, PH, i + VB_RD);
-    MMD_PIN_LOADS();
-  }
-}
-
 // ----------------------------------------------------------------------------------------------------------------
 // Up-path stage (ups.0: L = 16 / C = 64, ups.1: L = 32 / C = 32) in F(4,5) form.  C_out is small here: the L / 16 M tiles
 // x C / 16 n-tiles are exactly four (M, N) units, one per wave (8 accumulators), so every wave runs the whole K of its
@@ -1040,18 +743,6 @@ __device__ __forceinline__ void quad1_to_stage(const f32x4 (&q)[4], float* dst, 
     for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR] = q[o][r];
 }
 
-// residual 1x1 conv accumulated in the Winograd domain (positions 1..6) -> its four outputs * isc (the inverse of the
-// f16x2 weight scale of the lane's channel) + bias
-__device__ __forceinline__ void w4n1_res_out(f32x4 (&q)[4], const f32x4 (&rm)[6], float bias, float isc) {
-  const f32x4 s1 = rm[0] + rm[1], t1 = rm[0] - rm[1];
-  const f32x4 s2 = rm[2] + rm[3], t2 = rm[2] - rm[3];
-  const f32x4 s3 = rm[4] + rm[5], t3 = rm[4] - rm[5];
-  q[0] = (s1 + (s2 + s3)) * isc + bias;
-  q[1] = (t1 + (2.f * t2 + 0.5f * t3)) * isc + bias;
-  q[2] = (s1 + (4.f * s2 + 0.25f * s3)) * isc + bias;
-  q[3] = (t1 + (8.f * t2 + 0.125f * t3)) * isc + bias;
-}
-
 // the same for an explicit unit (M tile mt, n-tile nq)
 template <int L, int CM, int DSS, int DSTR>
 __device__ __forceinline__ void quad1_to_stage_u(const f32x4 (&q)[4], float* dst, int mt, int nq, int lane) {
@@ -1069,13 +760,9 @@ __device__ __forceinline__ void quad1_to_stage_u(const f32x4 (&q)[4], float* dst
 template <class CF, class SKIPW>
 __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int lane, int wave, SKIPW skip_write,
                                                f32x16 (&tout)[2][CF::MT_W], int trb) {
-  static_assert((CF::L == 16 || CF::L == 32) && CF::CM * CF::L == 1024 && CF::C1 == CF::C0 && CF::RES0 == RES_CONV &&
-                    CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "up-path stage with 4 waves = (L / 16 M tiles) x (CM / 16 n-tiles)");
-  // L = 16 (ups.0): conv inputs are V-form slabs at the start of the LDS (the two chunks of cat(x, skip) one after the
-  // other, then H), all aliasing each other and the row-form H slab of the tail conv; barriers separate the phases
-  constexpr bool VH = CF::L == 16;
-  static_assert(!VH || CF::C0P == 128, "V-form ups.0: 128-channel chunks from the L = 16 down stage");
-  float* hslab = VH ? lds : lds + CF::XSLAB;
+  static_assert(CF::L == 32 && CF::CM * CF::L == 1024 && CF::C1 == CF::C0 && CF::RES0 == RES_CONV &&
+                    CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "ups.1: 4 waves = (L / 16 M tiles) x (CM / 16 n-tiles)");
+  float* hslab = lds + CF::XSLAB;
   float* xslab = lds;
   constexpr int QPS = CF::L / 4, NTQ = CF::CM / 16;
   const int mt = wave / NTQ, nq = wave % NTQ;
@@ -1083,7 +770,6 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
   const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
   const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
-  const int vbase = (lane >> 4) * VCS + (lane & 15) * VROW;
   const int col = nq * 16 + (lane & 15);
   // both chunks of conv A carry the 1x1 residual conv (3 float4 per lane and k-step), all other convs 2
   BQ<3> ring3[W4_RD];
@@ -1094,85 +780,38 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   auto wlane3 = [&](const float4* w, int cp) {
     return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
   };
-  if constexpr (!VH) {
-    w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
-    zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, 256>(hslab);
-  }
+  w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
+  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, 256>(hslab);
   __syncthreads();                                           // the previous stage is done with the LDS
   TR(trb + 0);
 
   f32x4 m[8], acc[4], res[4];
   auto conv_h = [&](const float4* w, const float4* next) {
-    if constexpr (VH) {
-      w4v_taps<CF::CM, 1>(m, hslab, vbase, wlane(w, CF::CM), ring);
-    } else {
-      w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
-    }
+    w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
     if (next) w4_ring_load<2>(ring, wlane(next, CF::CM));
     w4n1_out(acc, m);
   };
-  auto to_h = [&]() {
-    if constexpr (VH) quad1_to_vform(acc, hslab, nq, lane);
-    else quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane);
-  };
+  auto to_h = [&]() { quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane); };
 
   // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
-  float isc_a = 1.f;
-  if constexpr (VH) {
-    // f16x2 (vbu_taps): skip_write(chunk, phase) stores that phase of chunk 0 (x) / 1 (skip) into the phase slab
-    f32x4 rm[6];
-    const u32x4* wp0 = reinterpret_cast<const u32x4*>(a.r0.wa_bf) + (size_t)nq * VBU_FRAGS * 64 + lane;
-    const u32x4* wp1 = reinterpret_cast<const u32x4*>(a.wa0_c1_bf) + (size_t)nq * VBU_FRAGS * 64 + lane;
-    const char* const vb_a = reinterpret_cast<const char*>(lds) + (lane >> 4) * VB_CG + (4 * (lane & 3) + ((lane & 15) >> 2)) * 16;
-    u32x4 ring_u[VB_RD][6];
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    vbu_ring_load<0>(ring_u, wp0);
-    const float inv_dyn = skip_write(C0{}, C0{});            // (also applies the dynamic input scale to both chunks' tiles)
-    __syncthreads();
-    vbu_taps<0, true>(m, rm, vb_a, wp0, ring_u);
-    vbu_ring_load<1>(ring_u, wp0);
-    __syncthreads();                                         // every wave is done reading the slab
-    skip_write(C0{}, C1{});
-    __syncthreads();
-    vbu_taps<1, true>(m, rm, vb_a, wp0, ring_u);
-    vbu_ring_load<0>(ring_u, wp1);
-    __syncthreads();
-    skip_write(C1{}, C0{});
-    __syncthreads();
-    vbu_taps<0, false>(m, rm, vb_a, wp1, ring_u);
-    vbu_ring_load<1>(ring_u, wp1);
-    __syncthreads();
-    skip_write(C1{}, C1{});
-    __syncthreads();
-    vbu_taps<1, false>(m, rm, vb_a, wp1, ring_u);
-    w4n1_res_out(res, rm, a.br[col], a.isr[col] * inv_dyn);
-    isc_a = a.r0.isa[col] * inv_dyn;
-  } else {
-    {
-      const float br = a.br[col];
+  {
+    const float br = a.br[col];
 #pragma unroll
-      for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
-      w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res, xslab, xbase, wlane3(a.r0.wa, CF::C0P), ring3);
-      w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
-    }
-    __syncthreads();                                            // chunk 0 has been consumed by every wave
-    skip_write(xslab);
-    __syncthreads();
-    w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
+    for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
+    w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res, xslab, xbase, wlane3(a.r0.wa, CF::C0P), ring3);
+    w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
   }
+  __syncthreads();                                            // chunk 0 has been consumed by every wave
+  skip_write(xslab);
+  __syncthreads();
+  w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
   {
     w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
     w4n1_out(acc, m);
     const float tb = a.r0.tb[col];
-    if constexpr (VH) {
-      gn_mish_quad1<CF::CM, CF::L, true>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; }, isc_a);
-    } else {
-      gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
-    }
+    gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
   }
   TR(trb + 1);
-  if constexpr (VH) __syncthreads();                         // chunk 1 is consumed: the H slab aliases it
   to_h();
   __syncthreads();
   TR(trb + 2);
@@ -1209,7 +848,6 @@ __device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, i
   // =================== tail: Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, direct ===================
   // (reads a row-form H slab; at L = 16 it aliases the V-form slabs, which are dead after the barrier)
   __syncthreads();
-  if constexpr (VH) zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, 256>(hslab);
   quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane);
   __syncthreads();
   TR(trb + 7);
@@ -1257,7 +895,7 @@ template <int L, int CM> struct DbGeo {
   static constexpr int PS = 2 * KC * G;                                 // bytes per (piece, slot)
   static constexpr int STEPS = 4 * KC;                                  // (chunk, slot) steps per phase: step = 4 chunk + slot
   static constexpr int FRAGS = 2 * STEPS * 2;                           // weight fragments per n-tile and conv
-  static_assert(8 * PS <= VSLAB_FLOATS * 4, "the phase slab must fit the V slab's space");
+  static_assert(8 * PS <= MX_OFF * 4, "the phase slab must fit below the maxima");
   // channel block of (chunk kc, lane group j): pair index and position in the pair
   __host__ __device__ static constexpr int pair_of(int kc, int j) { return KC == 2 ? j : (j & 1); }
   __host__ __device__ static constexpr int half_of(int kc, int j) { return KC == 2 ? kc : (j >> 1); }
@@ -1349,45 +987,30 @@ __device__ __forceinline__ void vbd_store(char* base, const f32x4 (&P)[4], const
   }
 }
 
-template <class CF, bool FIRST, bool TAIL_MAX>
-__device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, int n0, int lane, int wave, f32x4 (&acc)[2][4],
+template <class CF, bool TAIL_MAX>
+__device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[2][4],
                                               f32x4 (&mid)[2][4], f32x16 (&tout)[1], int trb) {
-  static_assert((CF::L == 32 || CF::L == 64) && CF::CM * CF::L == 2048 && CF::C1 == 0 && CF::RES0 == RES_CONV &&
-                    CF::N_IDENT == 1 && CF::TAIL == TAIL_DOWN, "downs.0 / downs.1");
+  static_assert(CF::L == 32 && CF::CM * CF::L == 2048 && CF::C0 % 32 == 0 && CF::C1 == 0 && CF::RES0 == RES_CONV &&
+                    CF::N_IDENT == 1 && CF::TAIL == TAIL_DOWN, "downs.1");
   using GEO = DbGeo<CF::L, CF::CM>;
   constexpr int QPS = CF::L / 4, QB = GEO::QB;               // quads / lane groups per sample
   float* hslab = lds + CF::XSLAB;                            // row-form H slab of the tail conv
   const int nq = wave % GEO::NTQ, mt0 = 2 * (wave / GEO::NTQ);          // the wave's n-tile and first M tile
   const int col = 16 * nq + (lane & 15);                     // the lane's channel
-  // A row lane & 15 of M tile mt0 + mt = (sample, quad) of the row-form x slab (fp32 conv A of downs.0's first RTB)
-  int xbase[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int ai = (mt0 + mt) * 16 + (lane & 15);
-    xbase[mt] = (ai / QPS) * CF::XSS + 4 * (ai % QPS) * CF::XSTR + (lane >> 4);
-  }
-  BQ<3> ring3[W4_RD];
-  const float* w3 = reinterpret_cast<const float*>(a.r0.wa) + ((size_t)nq * (CF::C0P / 4) * 64 + lane) * 12;
-  // downs.1: conv A of the first RTB (32 -> 64) + the 1x1 residual conv as f16x2 from the row-form x slab (chain_body_d2)
-  using GA = VbGeoL<FIRST ? 32 : CF::C0P, CF::L>;
-  using GR = VrGeoL<FIRST ? 32 : CF::C0P, CF::L>;
+  // conv A of the first RTB (32 -> 64) + the 1x1 residual conv as f16x2 from the row-form x slab (rowform_to_vslab)
+  using GA = VbGeoL<CF::C0P, CF::L>;
+  using GR = VrGeoL<CF::C0P, CF::L>;
   constexpr int VA_OFF = (CF::SPB * CF::XSS * 4 + 255) / 256 * 256, VR_OFF = VA_OFF + GA::BYTES;
-  static_assert(FIRST || VR_OFF + GR::BYTES <= MX_OFF * 4, "x slab + phase slab + raw slab must fit below the maxima");
+  static_assert(VR_OFF + GR::BYTES <= MX_OFF * 4, "x slab + phase slab + raw slab must fit below the maxima");
   const u32x4* const wpa = reinterpret_cast<const u32x4*>(a.r0.wa_bf) + (size_t)nq * GA::FRAGS * 64 + lane;
   const u32x4* const wpr = reinterpret_cast<const u32x4*>(a.wres_bf) + (size_t)nq * (2 * GR::KC) * 64 + lane;
   u32x4 ring_a[VB_RD][2];
-  if constexpr (FIRST) {
-    w4_ring_load<3>(ring3, w3);
-    // the network input, channels-last [n, 64, 4] in HBM (channels 4..7 of the slab are zero)
-    stage_slab<CF::C0, 0, CF::C0P, CF::L, CF::SROWS, 2, CF::XSTR, CF::SPB, CF::XSS>(lds, a.in0, nullptr, n0, a.n);
-  } else {
-    vbd_ring_load<GA, 0>(ring_a, wpa);
-  }
+  vbd_ring_load<GA, 0>(ring_a, wpa);
   __syncthreads();                                           // the x slab is staged
   TR(trb + 0);
 
   f32x4 res[2][4];
-  char* const vb = reinterpret_cast<char*>(lds);             // the bf16x3 phase slab aliases the x and H slabs
+  char* const vb = reinterpret_cast<char*>(lds);             // the f16x2 phase slab aliases the x and H slabs
   const int jg = lane >> 4;
   const char* const vb_a = vb + GEO::pair_of(0, jg) * GEO::G + (GEO::KC == 1 ? GEO::half_of(0, jg) * GEO::X : 0) +
                            (16 * mt0 + (lane & 15)) * 16;
@@ -1478,20 +1101,7 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
 
   // =================== RTB 0 (C0 -> CM): conv A + the 1x1 residual conv ===================
   float inv_in[2] = {1.f, 1.f};
-  if constexpr (FIRST) {
-    // downs.0: on the fp32 MFMA from the row-form x slab (4 input channels; the raw network input has no bounded range)
-    f32x4 m[8];
-    const float br = a.br[col];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int o = 0; o < 4; ++o) res[mt][o] = f32x4{br, br, br, br};
-      w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res[mt], lds, xbase[mt], w3, ring3);
-      if (mt == 0) w4_ring_load<3>(ring3, w3);
-      w4n1_out(acc[mt], m);
-    }
-    gn(std::false_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, nullptr, inv_in, a.r0.act_a);
-  } else {
+  {
     // downs.1: f16x2 (the stage input is residual-stream data: dynamic per-sample scale from the maxima downs.0's tail left)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -2389,213 +1999,6 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// downs.2 + mid blocks (L = 16, 128 channels; 57 % of the network's MACs): the 64 -> 128 conv A of the first RTB on the
-// fp32 MFMA from the row-form x slab (with its 1x1 residual conv riding along), the seven 128 -> 128 convs as bf16x3
-// (vb_taps).  The stage's output is one M tile (4 samples x 4 quads) x 8 n-tiles; wave w owns n-tiles 2 w, 2 w + 1, whose
-// columns are INTERLEAVED over its 32 channels -- column n of tile h is channel 32 w + 2 n + h (the weight packs are
-// permuted accordingly) -- so a lane holds two ADJACENT channels and stores their bf16 pieces as one ds_write_b32 (64
-// distinct banks per wave) instead of two ds_write_b16 into shared dwords.  A GroupNorm group (16 channels) is 8 adjacent
-// lanes x both tiles.
-// ----------------------------------------------------------------------------------------------------------------
-template <bool SCALED, bool ACT, class ADD0, class ADD1>
-__device__ __forceinline__ void gn_mish_pair16(f32x4 (&q0)[4], f32x4 (&q1)[4], const float (&bias)[2], const float (&gamma)[2],
-                                               const float (&beta)[2], const float (&isc)[2], const ActScale& as, ADD0 add0, ADD1 add1) {
-  constexpr float inv_n = 1.f / 256.f;                       // 16 channels x 16 positions
-  float sum0 = 0.f, sum1 = 0.f;
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sum0 += q0[o][r];
-      sum1 += q1[o][r];
-    }
-  const float sum = SCALED ? fmaf(sum0, isc[0], sum1 * isc[1]) : sum0 + sum1;
-  const float mean = (group_colsum<8>(sum) + group_colsum<8>(bias[0] + bias[1]) * 16.f) * inv_n;
-  const float dm0 = mean - bias[0], dm1 = mean - bias[1];
-  float sq = 0.f;
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float d0 = SCALED ? fmaf(q0[o][r], isc[0], -dm0) : q0[o][r] - dm0;
-      const float d1 = SCALED ? fmaf(q1[o][r], isc[1], -dm1) : q1[o][r] - dm1;
-      sq = fmaf(d0, d0, sq);
-      sq = fmaf(d1, d1, sq);
-    }
-  const float rstd = rsqrtf(group_colsum<8>(sq) * inv_n + 1e-5f);
-  GnCoef cf0 = gn_coef(dm0, rstd, gamma[0], beta[0]), cf1 = gn_coef(dm1, rstd, gamma[1], beta[1]);
-  if constexpr (SCALED) { cf0.sa *= isc[0]; cf1.sa *= isc[1]; }
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      q0[o][r] = gn_mish1<ACT>(q0[o][r], cf0, add0(o, r), as);
-      q1[o][r] = gn_mish1<ACT>(q1[o][r], cf1, add1(o, r), as);
-    }
-}
-
-template <class CF>
-__device__ __forceinline__ void chain_body_d2(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[2][4],
-                                              f32x4 (&mid)[2][4], int trb) {
-  static_assert(CF::L == 16 && CF::CM == 128 && CF::C0 == 64 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_NONE &&
-                    CF::MID_AFTER >= 1, "downs.2 + mid blocks");
-  const int c0 = 32 * wave + 2 * (lane & 15);                // the lane's channels c0 (tile 0), c0 + 1 (tile 1)
-  // conv A of the first RTB (64 -> 128) + the 1x1 residual conv, both f16x2: the row-form x slab (previous stage's tail
-  // tile) stays at the start of the LDS through both phases, its phase slab and the residual's raw slab follow it
-  using GA = VbGeo<CF::C0P>;
-  using GR = VrGeo<CF::C0P>;
-  constexpr int VA_OFF = (CF::SPB * CF::XSS * 4 + 255) / 256 * 256, VR_OFF = VA_OFF + GA::BYTES;
-  static_assert(VR_OFF + GR::BYTES <= MX_OFF * 4, "x slab + phase slab + raw slab must fit below the maxima");
-  char* const va_slab = reinterpret_cast<char*>(lds) + VA_OFF;
-  char* const vr_slab = reinterpret_cast<char*>(lds) + VR_OFF;
-  const u32x4* wpa[2];
-  const u32x4* wpr[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    wpa[h] = reinterpret_cast<const u32x4*>(a.r0.wa_bf) + (size_t)(2 * wave + h) * GA::FRAGS * 64 + lane;
-    wpr[h] = reinterpret_cast<const u32x4*>(a.wres_bf) + (size_t)(2 * wave + h) * (2 * GR::KC) * 64 + lane;
-  }
-  u32x4 ring_a[VB_RD][2][2];
-  vb_ring_load<GA, 0>(ring_a, wpa);
-  __syncthreads();                                           // the x slab (previous stage's tail tile) and its maxima are staged
-  TR(trb + 0);
-
-  f32x4 res[2][4];
-  float* const mx = lds + MX_OFF;                            // per-sample partial maxima (dynamic f16x2 input scales)
-  char* const vb = reinterpret_cast<char*>(lds);             // the f16x2 phase slab aliases the x slab
-  // A fragment: row lane & 15 = (sample (lane & 15) >> 2, quad lane & 3), channel-block group lane >> 4
-  const char* const vb_a = vb + (lane >> 4) * VB_CG + (4 * (lane & 3) + ((lane & 15) >> 2)) * 16;
-  // stores: channels c0, c0 + 1 = block 4 wave + ((lane & 15) >> 2), dword lane & 3; sample lane >> 4
-  char* const vb_s = vb + wave * VB_CG + ((lane & 15) >> 2) * VB_CB + (lane >> 4) * 16 + (lane & 3) * 4;
-  // A whole 128 -> 128 conv over the H tile in acc, in two position phases.  On entry every wave is past its reads of the
-  // slab (the caller's barrier); the first ring steps of each phase are issued ahead of the barrier that publishes it.
-  auto conv_hb = [&](const uint4* w) {
-    const u32x4* wp[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) wp[h] = reinterpret_cast<const u32x4*>(w) + (size_t)(2 * wave + h) * VB_FRAGS * 64 + lane;
-    f32x4 mb[2][8];
-    u32x4 ring_b[VB_RD][2][2];
-    TR(trb + 10);
-    vb_ring_load<VbGeo<128>, 0>(ring_b, wp);
-    vb_store_pair<0>(vb_s, [&](int o, int r) { return acc[0][o][r]; }, [&](int o, int r) { return acc[1][o][r]; });
-    TR(trb + 11);
-    __syncthreads();
-    TR(trb + 12);
-    vb_taps<VbGeo<128>, 0>(mb, vb_a, wp, ring_b);
-    TR(trb + 13);
-    vb_ring_load<VbGeo<128>, 1>(ring_b, wp);
-    __syncthreads();                                         // every wave is done reading the phase-0 slab
-    TR(trb + 14);
-    vb_store_pair<1>(vb_s, [&](int o, int r) { return acc[0][o][r]; }, [&](int o, int r) { return acc[1][o][r]; });
-    TR(trb + 15);
-    __syncthreads();
-    TR(trb + 16);
-    vb_taps<VbGeo<128>, 1>(mb, vb_a, wp, ring_b);
-    TR(trb + 17);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) w4n1_out(acc[h], mb[h]);
-  };
-  // GroupNorm + Mish of acc.  Conv A (tb != nullptr): + the time bias, output carried times act_s, the static f16x2 input
-  // scale of conv B (ACT); conv B: + the residual tile.  SCALED: the conv ran as f16x2 -- isc = its inverse weight scales
-  // (conv B's include 1 / act_s), inv_dyn = the inverse of the dynamic input scale (conv A of an identity RTB), per sample.
-  auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc, float inv_dyn,
-                float act_s) {
-    constexpr bool SCALED = decltype(scaled)::value;
-    const float bb[2] = {b[c0], b[c0 + 1]}, gg[2] = {g[c0], g[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
-    const float is[2] = {SCALED ? isc[c0] * inv_dyn : 1.f, SCALED ? isc[c0 + 1] * inv_dyn : 1.f};
-    if (tb) {
-      const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
-      gn_mish_pair16<SCALED, true>(acc[0], acc[1], bb, gg, ee, is, act_scale(act_s), [&](int, int) { return t0; },
-                                   [&](int, int) { return t1; });
-    } else {
-      gn_mish_pair16<SCALED, false>(acc[0], acc[1], bb, gg, ee, is, ActScale{}, [&](int o, int r) { return res[0][o][r]; },
-                                    [&](int o, int r) { return res[1][o][r]; });
-    }
-  };
-  // The lane's two tiles belong to sample lane >> 4: partial |x| maximum of the wave's 32 channels -> mx[sample][wave]
-  // (before a barrier); after it dyn_in() combines the four waves' and scales acc in place (the conv's f16x2 input).
-  auto dyn_out = [&](int region2) {                          // region2 > 0: also kept there for ups.0
-    float m = 0.f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(fabsf(acc[0][o][r]), fabsf(acc[1][o][r])));
-    m = row_max16(m);
-    if ((lane & 15) == 0) {
-      mx[(lane >> 4) * MX_SLOTS + wave] = m;
-      if (region2) mx[region2 * MX_REGION + (lane >> 4) * MX_SLOTS + wave] = m;
-    }
-  };
-  auto dyn_in = [&]() {
-    const float4 p = *reinterpret_cast<const float4*>(mx + (lane >> 4) * MX_SLOTS);
-    const DynScale ds = dyn_scale(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)));
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int o = 0; o < 4; ++o) acc[h][o] *= ds.s;
-    return ds.inv;
-  };
-
-  // =================== RTB 0 (64 -> 128): conv A + the 1x1 residual conv as f16x2 from the row-form x slab ===================
-  float inv_in;
-  {
-    // the stage input is residual-stream data: dynamic per-sample scale from the maxima the previous stage's tail left in mx
-    const float4 p = *reinterpret_cast<const float4*>(mx + (lane >> 4) * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + (lane >> 4) * MX_SLOTS + 4);
-    inv_in = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)))).inv;
-    const char* const va = va_slab + (lane >> 4) * GA::G + (lane & 15) * 16;
-    const char* const vr = vr_slab + (lane >> 4) * GR::G + (lane & 15) * 16;
-    f32x4 mb[2][8];
-    rowform_to_vslab<0, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
-    __syncthreads();
-    vb_taps<GA, 0>(mb, va, wpa, ring_a);
-    vb_ring_load<GA, 1>(ring_a, wpa);
-    vr_taps<CF::C0P>(res, vr, wpr);
-    __syncthreads();                                         // every wave is done reading the phase-0 slab
-    rowform_to_vslab<1, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
-    __syncthreads();
-    vb_taps<GA, 1>(mb, va, wpa, ring_a);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      w4n1_out(acc[h], mb[h]);
-      const float br = a.br[c0 + h], isr = a.isr[c0 + h] * inv_in;
-#pragma unroll
-      for (int o = 0; o < 4; ++o) res[h][o] = res[h][o] * isr + br;
-    }
-  }
-  gn(std::true_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
-  TR(trb + 1);
-  __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
-  conv_hb(a.r0.wb_bf);
-  gn(std::true_type{}, a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, 1.f, 1.f);
-
-  // =================== identity RTBs (a real loop: one copy of the two conv bodies instead of three) ===================
-#pragma unroll 1
-  for (int k = 0; k < CF::N_IDENT; ++k) {
-    const RtbPtrs& R = a.ri[k];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) res[h][i] = acc[h][i];
-    dyn_out(k == CF::MID_AFTER ? 1 : 0);                    // (the input of the RTB after MID_AFTER is the skip tensor)
-    __syncthreads();                                         // the previous conv is done reading the slab
-    const float inv_dyn = dyn_in();
-    conv_hb(R.wa_bf);
-    gn(std::true_type{}, R.ba, R.ga, R.bea, R.tb, R.isa, inv_dyn, R.act_a);
-    __syncthreads();
-    conv_hb(R.wb_bf);
-    gn(std::true_type{}, R.bb, R.gb, R.beb, nullptr, R.isb, 1.f, 1.f);
-    TR(trb + 18);
-    if (CF::MID_AFTER == k + 1) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mid[h][i] = acc[h][i];
-    }
-  }
-  dyn_out(2);                                                // the stage's output: ups.0's conv A takes its maximum from region 2
-}
-
-// ----------------------------------------------------------------------------------------------------------------
 // The whole TemporalUnet forward for 4 samples in ONE workgroup / ONE launch: the five level chains and the final conv
 // hand their activations to each other through LDS (tail tile -> next stage's x slab), the two skip connections wait in
 // registers (32 VGPRs each) for the up path.  HBM traffic per trajectory and forward: 1 KiB in, 1 KiB out.
@@ -2623,7 +2026,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     f32x4 acc[2][4];
     f32x16 t[1];
-    chain_body_db<CH_D1, false, true>(a.c[1], lds, n0, lane, wave, acc, skip1, t, 40);
+    chain_body_db<CH_D1, true>(a.c[1], lds, lane, wave, acc, skip1, t, 40);
     __syncthreads();
     tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
     zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
@@ -2947,35 +2350,6 @@ static size_t push_inverse(std::vector<float>& blob, const std::vector<float>& s
   return off;
 }
 
-// f16x2 pack of a 128 -> 128 k5 conv for vb_taps: per n-tile [phase][step = 4 chunk kc + slot][piece q][lane] x 16 B, lane =
-// (column lane & 15 of the tile, channels 8 (4 (lane >> 4) + kc) + j, j = 0..7 at fp16 index j).  Returns the pack's offset
-// in the blob (in floats; 16-byte aligned); isc_off = offset of the [cout] inverse channel scales.
-static size_t pack_vb(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off, float in_scale) {
-  const std::vector<float> sc = f16_col_scales(w, cout, cin);
-  isc_off = push_inverse(blob, sc, in_scale);                // in_scale: the static scale the conv's input arrives with
-  const size_t base = blob.size();
-  const int tiles = cout / 16, KC = cin / 32;
-  const size_t frags = (size_t)tiles * 2 * 4 * KC * 2;
-  blob.resize(base + (frags + 8) * 64 * 4, 0.f);             // + slack for the ring's over-read past the last tile
-  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
-  for (int t = 0; t < tiles; ++t)
-    for (int ph = 0; ph < 2; ++ph)
-      for (int kc = 0; kc < KC; ++kc)
-        for (int sl = 0; sl < 4; ++sl)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-              const int n = (t / 2) * 32 + 2 * (lane & 15) + (t & 1);   // interleaved tile pair of a wave (chain_body_d2)
-              const int ci = 8 * (KC * (lane >> 4) + kc) + j;           // chunk kc, lane group g = channel block kc + KC g (VbGeo)
-              uint16_t piece[2];
-              f16_split_host(wino_u(w, cin, n, ci, vb_pos(ph, sl)), sc[n], piece);
-              for (int q = 0; q < 2; ++q) {
-                const size_t frag = ((((size_t)t * 2 + ph) * KC + kc) * 4 + sl) * 2 + q;
-                out[(frag * 64 + lane) * 8 + j] = piece[q];
-              }
-            }
-  return base;
-}
-
 // f16x2 pack of a stage's 1x1 residual conv [cout][cin] for vr_taps: per n-tile [chunk kc][piece q][lane] x 16 B, columns and
 // channels as in pack_vb; isc_off = offset of the [cout] inverse channel scales.
 static size_t pack_vr(std::vector<float>& blob, const float* wres, int cout, int cin, size_t& isc_off, bool pair_cols) {
@@ -3033,41 +2407,6 @@ static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int c
                 out[(frag * 64 + lane) * 8 + j] = piece[q];
               }
             }
-  return base;
-}
-
-// f16x2 pack of one 128-channel chunk [c_lo, c_lo + 128) of ups.0's conv A (k5, cout 64, with the 1x1 residual conv wres
-// in the Winograd domain) for vbu_taps: per n-tile [phase][step = 2 chunk kc + slot pair][6 fragments][lane] x 16 B; fragments
-// 0..1 / 2..3 = the pieces of the pair's two slots, 4..5 = the pieces of wres * G[p][2] for the pair's residual position(s)
-// (-2/9 in phase 0, 2/45 and 8/45 for the pairs of phase 1).  Columns are plain (n = 16 tile + (lane & 15)).  sc / scr = the
-// channel scales of the conv / of the residual weights (shared by both chunks).
-static size_t pack_vbu(std::vector<float>& blob, const float* w, const float* wres, int cout, int cin_full, int c_lo,
-                       const std::vector<float>& sc, const std::vector<float>& scr) {
-  while (blob.size() % 4) blob.push_back(0.f);
-  const size_t base = blob.size();
-  const int tiles = cout / 16;
-  const size_t frags = (size_t)tiles * 2 * 2 * 4 * 6;
-  blob.resize(base + (frags + 16) * 64 * 4, 0.f);            // + slack for the ring's over-read past the last tile
-  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
-  for (int t = 0; t < tiles; ++t)
-    for (int ph = 0; ph < 2; ++ph)
-      for (int kc = 0; kc < 4; ++kc)
-        for (int pair = 0; pair < 2; ++pair)
-          for (int grp = 0; grp < 3; ++grp)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int j = 0; j < 8; ++j) {
-                const int n = 16 * t + (lane & 15), ci = c_lo + 8 * (4 * (lane >> 4) + kc) + j;
-                uint16_t piece[2];
-                if (grp < 2)
-                  f16_split_host(wino_u(w, cin_full, n, ci, vb_pos(ph, 2 * pair + grp)), sc[n], piece);
-                else
-                  f16_split_host((float)((double)wres[(size_t)n * cin_full + ci] * kG45[ph == 0 ? 1 : (pair == 0 ? 3 : 5)][2]),
-                                 scr[n], piece);
-                for (int q = 0; q < 2; ++q) {
-                  const size_t frag = (((((size_t)t * 2 + ph) * 4 + kc) * 2 + pair) * 6) + grp * 2 + q;
-                  out[(frag * 64 + lane) * 8 + j] = piece[q];
-                }
-              }
   return base;
 }
 
@@ -3481,20 +2820,25 @@ static const double kUnetFlops =
     rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64;
 
-// fp32 GEMM FLOPs the matrix pipe executes per trajectory (Winograd convs: 8 products per 4 outputs; channel / N padding
-// included).  The C -> C convs of the three down stages + mid and ups.0's conv A run them as bf16x3 (6 bf16 MFMA FLOPs
-// per fp32 FLOP).
+// fp32 GEMM FLOPs the matrix pipe executes per trajectory, by form.  Winograd F(4,5) convs (downs.1, ups.1, final block): 8
+// products per 4 outputs; direct convs (downs.0, downs.2 + mid, ups.0): every tap (downs.0's stride-2 tail at all 64
+// positions, its 4-channel first conv padded to one K = 32 chunk, + one for the residual conv).
 static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // per sample
 static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
 }
-static const double kUnetMfmaFlops =
-    4 * (wino4_flops(8, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 8, 32, 64) + direct_flops(3, 32, 32, 32) +
-    2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) + direct_flops(3, 64, 64, 16) +
-    wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) + 7 * wino4_flops(128, 128) +
-    wino4_flops(256, 64) * 14.0 / 8.0 + 3 * wino4_flops(64, 64) + 2 * direct_flops(2, 64, 64, 16) +   // ups.0 conv A: 8 + 6 (residual, Winograd domain) MFMAs per k-step
+static constexpr double d5(double cin, double cout, double L) { return 2.0 * cout * 5 * cin * L; }
+static const double kF16Flops =
+    2 * (2.0 * 32 * 32 * 64) + 3 * d5(32, 32, 64) + 2.0 * 32 * 3 * 32 * 64 +                          // downs.0
+    2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) +               // downs.1 (but its tail)
+    d5(64, 128, 16) + 2.0 * 128 * 64 * 16 + 7 * d5(128, 128, 16) +                                    // downs.2 + mid
+    d5(256, 64, 16) + 2.0 * 64 * 256 * 16 + 3 * d5(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16;              // ups.0
+static const double kFp32Flops =
+    direct_flops(3, 64, 64, 16) +                                                                      // downs.1's tail
     2 * (wino4_flops(128, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 128, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
-    4 * wino4_flops(32, 32) + direct_flops(1, 32, 32, 64);
+    4 * wino4_flops(32, 32) + direct_flops(1, 32, 32, 64);                                             // ups.1, final block
+static const double kUnetMfmaFlops = kF16Flops + kFp32Flops;
+
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
                              hipStream_t st, mmd_profiler_t prof) {
@@ -3541,11 +2885,7 @@ int mmd_debug_set_trace(void* dev_ptr) {
 
 double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
 double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }
-double mmd_unet_f16x2_flops_per_trajectory(void) {
-  return 4 * 3 * wino4_flops(32, 32) + 2 * 3 * wino4_flops(64, 64) + 7 * wino4_flops(128, 128) + wino4_flops(256, 64) * 14.0 / 8.0 +
-         wino4_flops(64, 128) + direct_flops(1, 64, 128, 16) +   // downs.2's / downs.1's conv A and their 1x1 residual GEMMs
-         2 * wino4_flops(32, 64) + direct_flops(1, 32, 64, 32);
-}
+double mmd_unet_f16x2_flops_per_trajectory(void) { return kF16Flops; }
 
 int mmd_profiler_create(mmd_profiler_t* out, int max_launches, int stride) {
   return mmd_profiler_create_windowed(out, max_launches, stride, 1, 0);

@@ -136,3 +136,17 @@ def oracle_run_inference(case, weights_seed=0, clip_mode="reference"):
     return O.p_sample_loop(sd, tb, xT, hard_conds_for(case["start"], case["goal"]), case["T"], steps, guide=guide,
                            n_guide_steps=20, t_start_guide=ceil(0.5 * case["T"]), noise_std_extra=0.5,
                            n_diffusion_steps_without_noise=1)
+
+
+def chaos_bounds(errs, sens, n_unguided_rows):
+    """Per-row bounds of an end-to-end guided chain.  `sens` is the reference's own response to a relative 1e-6 perturbation
+    of its UNet output (max over 24 draws, stored with the golden rows).  The kernel's deviation from the reference is not
+    exactly that size: on the rows BEFORE guidance starts the chain is well conditioned (errors ~1e-6, linear in the
+    perturbation), so lin = max(1, max err / sens over those rows) measures the kernel's per-step deviation in units of the
+    calibration perturbation, and a chaotic row may be lin times further away than the reference is from its perturbed
+    self -- times SENS_FACTOR for the heavy tail of the amplification -- or within the north-star 1e-3."""
+    lin = 1.0
+    for r in range(min(n_unguided_rows, len(errs))):
+        if sens[r] > 0:
+            lin = max(lin, errs[r] / sens[r])
+    return lin, [max(1e-3, 1.5 * lin * float(v)) for v in sens]
