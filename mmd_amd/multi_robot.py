@@ -119,7 +119,7 @@ class MultiRobotSampler:
             from .multi_agent import count_collisions
             counts = count_collisions(t, paths_all, self.robot0, self.n_local)
             idx, n_free = post.select_best(r.free_mask, self.n_local, counts=counts.view(-1))
-        self.last_n_free = n_free
+        self.last_n_free, self.last_idx = n_free, idx
         tv = t.view(self.n_local, self.n_samples, H, D)
         return tv[torch.arange(self.n_local, device=t.device), idx.long()][..., :2].contiguous()
 

@@ -126,6 +126,64 @@ def test_headline_prior_spot_check_vs_oracle(headline):
         assert rel_l2(out[idx:idx + 1], ref) < 1e-3, (int(idx), rel_l2(out[idx:idx + 1], ref))
 
 
+def test_headline_guided_step_and_guide_vs_oracle(headline):
+    """The guided kernel at the headline size -- the uniform-radius (qx, qy)-only LDS staging with 31 slots x 32 robots in one
+    launch, which the small parity cases (B = 4 .. 16, one robot) never reach -- against the oracle on 8 randomly chosen
+    trajectories from >= 4 robots (1953 soft-constraint points each): one guide evaluation (max-abs 2e-6, g5's bound), the
+    20-iteration guide_gradient_steps (2e-4, the bound of test_guide_20_steps_vs_oracle: 20 norm-clipped iterations) and one
+    teacher-forced guided DDPM step at loop index i = 49 (UNet + posterior mean + 20 guide iterations + noise; the
+    north-star 1e-3).  ref: sample_functions.py:40-107, guides.py:180-226."""
+    import parity_log
+    model, s, starts, goals, paths = headline
+    s.set_other_paths(paths)
+    gp = cases.guide_params("EnvEmpty2D")
+    paths_np = synth.straight_line_paths(starts, goals, H)
+    rng = np.random.Generator(np.random.PCG64(21))
+    robots = rng.choice(R, size=4, replace=False)
+    picks = [(int(r), int(b)) for r in robots for b in rng.choice(B, size=2, replace=False)]
+    assert len(picks) == 8 and len({r for r, _ in picks}) >= 4
+    # a mid-chain looking state: half-amplitude noise with the robots' start / goal rows
+    x = torch.from_numpy(synth.synth_noise(90, (R * B, H, D))) * 0.5
+    x[:, 0] = s.hard_conds[0].cpu().repeat_interleave(B, 0)
+    x[:, -1] = s.hard_conds[H - 1].cpu().repeat_interleave(B, 0)
+    hard = torch.stack((s.hard_conds[0], s.hard_conds[H - 1]), dim=1).contiguous()     # [R, 2, D]
+    # (a) one guide evaluation, (b) 20 guide iterations with hard conditioning
+    g1 = s.guide(x.cuda()).cpu()
+    y20 = x.clone().cuda()
+    s.guide.guide_steps(y20, hard, 3, 20)
+    y20 = y20.cpu()
+    # (c) one guided DDPM step from x at i = 49 with injected noise
+    noise = torch.from_numpy(synth.synth_noise(91, (R * B, H, D)))
+    ys = x.clone().cuda()
+    model.sample_step(ys, s.hard_conds, 49, guide=s.guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                      noise_std_extra_schedule_fn=lambda t: 0.5, n_robots=R, noise=noise.cuda())
+    ys = ys.cpu()
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    tb = O.schedule_tables(T)
+    for r, b in picks:
+        idx = r * B + b
+        grp = cases.soft_group(paths_np, r)
+        assert grp.q.shape[0] == 31 * 63
+        hc = cases.hard_conds_for(starts[r], goals[r])
+        guide = lambda z, grp=grp: O.guide_grad(z, gp, [grp], clip_mode="always")      # noqa: E731
+        xi = x[idx:idx + 1]
+        e1 = float((g1[idx:idx + 1] - guide(xi)).abs().max())
+        parity_log.record("fullsize_guide_single_eval", f"robot{r}_sample{b}", None, e1, bound=2e-6)
+        assert e1 < 2e-6, (r, b, e1)
+        z = xi.clone()
+        for _ in range(20):
+            z = O.apply_hard_conditioning(z + guide(z), hc)
+        e20 = rel_l2(y20[idx:idx + 1], z)
+        parity_log.record("fullsize_guide_20_steps", f"robot{r}_sample{b}", None, e20, bound=2e-4)
+        assert e20 < 2e-4, (r, b, e20)
+        ref = O.ddpm_sample_step(sd, tb, xi.clone(), hc, 49, guide=guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                                 noise=noise[idx:idx + 1], noise_std_extra=0.5)
+        ref = O.apply_hard_conditioning(ref, hc)
+        es = rel_l2(ys[idx:idx + 1], ref)
+        parity_log.record("fullsize_guided_step_teacher_forced", f"robot{r}_sample{b}", 49, es, bound=1e-3)
+        assert es < 1e-3, (r, b, es)
+
+
 def test_guide_zero_weights_is_identity(headline):
     """Idempotence-type property: with every gradient weight at 0 the guide leaves x untouched (only hard conditioning)."""
     import gpu_common

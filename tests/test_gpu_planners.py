@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from mmd_amd import synth                # noqa: E402
 import cases                             # noqa: E402
+from oracle import mmd_oracle as O       # noqa: E402
 import parity_log                        # noqa: E402
 from cases import GOLDEN, H, D, rel_l2   # noqa: E402
 
@@ -500,3 +501,44 @@ def test_torch_ops_match_the_ctypes_path():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(cg, ref) and torch.equal(xg, ref[-1])
+
+
+def test_plan_round_selection_vs_oracle_two_rounds():
+    """MultiRobotSampler.plan_round as a composition (VERDICT r2 #5b): 6 robots on Highways, two planning rounds.  In each
+    round the device-built soft-constraint table equals the oracle's (cbs.py:468-508), and the best-path pick of every
+    robot -- free-first, then fewest robot-robot collisions against the gathered paths, first minimum; all samples if none
+    is free (tasks.py:236-311, cbs.py:446-458) -- equals the oracle's selection on the same sampled batch."""
+    import gpu_common
+    from mmd_amd.multi_robot import MultiRobotSampler
+    N, B, T = 6, 16, 25
+    model = gpu_common.hip_model(T)
+    starts, goals = synth.start_goal_circle(N, 0.45)
+    s = MultiRobotSampler(model, starts, goals, env_id="EnvHighways2D", n_samples=B)
+    gp = cases.guide_params("EnvHighways2D")
+    paths = torch.from_numpy(synth.straight_line_paths(starts, goals, H)).cuda()
+    n_nonfree = 0
+    for rnd in range(2):
+        paths_in = paths.clone()
+        trajs, paths = s.plan_round(paths, seed=300 + rnd)
+        # (a) the constraint table the round sampled with
+        ell = s.guide._constraints()[0].cpu()
+        for r in range(N):
+            grp = O.soft_constraints_from_paths(paths_in.cpu(), r, 0.05 * 2.4, 2e-2)
+            q = ell[r * (N - 1):(r + 1) * (N - 1), 1:, :2].reshape(-1, 2)          # slots x t >= 1
+            assert torch.equal(q, grp.q.view(N - 1, H - 1, 2).reshape(-1, 2)), (rnd, r)
+        # (b) the selection, on the sampled batch
+        tu = s.unnormalize(trajs).cpu()
+        idx = s.last_idx.cpu().tolist()
+        for r in range(N):
+            tr = tu[r * B:(r + 1) * B]
+            _, _, _, free_idxs, _ = O.get_trajs_collision_and_free(tr, gp)
+            free = free_idxs.reshape(-1).tolist()
+            counts = O.count_collisions_with_others(tr[..., :2], paths_in.cpu(), r).tolist()
+            cand = free if free else list(range(B))
+            n_nonfree += B - len(free)
+            want = min(cand, key=lambda b: (counts[b], b))
+            assert idx[r] == want, (rnd, r, idx[r], want, free, counts)
+            assert int(s.last_n_free[r]) == len(free)
+            assert torch.equal(paths[r].cpu(), tr[want, :, :2])
+    assert n_nonfree > 0, "the case must exercise the free / colliding split"
+

@@ -138,3 +138,42 @@ def test_bench_sharding_modes():
         r0, n_local = shard_range(32, world - 1, world)
         assert n_local == 32 // world and r0 + n_local == 32
         assert r0 * 64 == (32 - n_local) * 64                # traj_index_base of the last rank
+
+
+def test_split_cost_constraints_to_tasks_golden_g13():
+    """MPDEnsemble.split_cost_constraints_to_tasks + the per-tile range / transform shift of run_constrained_inference
+    (mpd_ensemble.py:431-507, 515-518) against the reference's own output (g13): tile order, hard-then-soft order inside a
+    tile, every (q, range, radius, is_soft) table exactly -- a mixed list over 3 tiles with a range that starts on a tile
+    boundary and one that straddles it.  The guides are stand-ins that record what add_extra_costs receives."""
+    import types
+    from mmd_amd.planners import MPDEnsemble
+    g = np.load(os.path.join(GOLDEN, "g13_split_constraints.npz"))
+    received = {k: [] for k in range(3)}
+
+    def recorder(k):
+        return types.SimpleNamespace(add_extra_costs=lambda costs, weights, k=k: received[k].extend(zip(costs, weights)))
+    me = types.SimpleNamespace(robot=None, guides={k: recorder(k) for k in range(3)},
+                               transforms={0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0]), 2: torch.tensor([4.0, 0.5])},
+                               weight_grad_cost_constraints=2e-1, weight_grad_cost_soft_constraints=2e-2)
+    me.infer_task_id_from_q_idx = types.MethodType(MPDEnsemble.infer_task_id_from_q_idx, me)
+    me.split_cost_constraints_to_tasks = types.MethodType(MPDEnsemble.split_cost_constraints_to_tasks, me)
+
+    def cc(qs, ranges, radii, soft):
+        return CostConstraint(None, H, q_l=[torch.tensor(q, dtype=torch.float32) for q in qs], traj_range_l=ranges,
+                              radius_l=radii, is_soft=soft)
+    cons = [cc(([0.1, 0.2], [2.3, 0.1]), [(10, 14), (70, 75)], [0.12, 0.10], False),
+            cc(([-0.4, 0.3], [1.7, -0.2], [4.4, 0.6]), [(5, 6), (64, 65), (130, 131)], [0.12, 0.12, 0.12], True),
+            cc(([3.9, 0.4],), [(128, 140)], [0.2], False),
+            cc(([0.9, -0.1], [0.0, 0.0]), [(62, 66), (0, 1)], [0.12, 0.15], True)]
+    split = MPDEnsemble.split_cost_constraints_to_tasks(me, cons)
+    assert list(split.keys()) == g["task_order"].tolist()
+    MPDEnsemble._add_constraints(me, cons)
+    for k in g["task_order"].tolist():
+        assert len(received[k]) == int(g[f"n_{k}"])
+        for j, (c, w) in enumerate(received[k]):
+            assert bool(c.is_soft) == bool(g[f"soft_{k}_{j}"])
+            assert w == (2e-2 if c.is_soft else 2e-1)
+            assert np.array_equal(np.asarray(c.qs, dtype=np.float32), g[f"qs_{k}_{j}"]), (k, j, c.qs)
+            assert np.array_equal(np.asarray(c.traj_ranges, dtype=np.float32), g[f"ranges_{k}_{j}"]), (k, j, c.traj_ranges)
+            assert np.array_equal(np.asarray(c.radii, dtype=np.float32), g[f"radii_{k}_{j}"]), (k, j)
+

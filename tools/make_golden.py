@@ -17,6 +17,7 @@ Fixtures:
   g10_multi_agent.npz  robot-robot collisions of a best-path set + per-sample conflict totals (least_collisions scan)
   g9_post.npz          post-sampling selection: collision/free split, smoothness, path length, SavGol smoothing
   g12_boundary.npz     outer-boundary contract: check_rr_collisions / compute_collision on the shapes CBS / PP pass
+  g13_split_constraints.npz  MPDEnsemble.split_cost_constraints_to_tasks + the per-tile range / transform shift
 """
 import os
 import sys
@@ -480,11 +481,56 @@ def g12():
     np.savez_compressed(os.path.join(OUT, "g12_boundary.npz"), **out)
 
 
+def g13():
+    """MPDEnsemble.split_cost_constraints_to_tasks + the per-tile shift of run_constrained_inference
+    (mpd_ensemble.py:431-507, 515-518), executed on the genuine class through an attribute stand-in (the method only touches
+    self.task / robot / n_support_points / tensor_args; constructing an MPDEnsemble needs the dataset files).  A mixed list:
+    hard + soft constraints over 3 tiles, one range starting exactly on a tile boundary (t = 64), one straddling it
+    (t = 62..66 stays with tile 0: 'we do not break down long constraint intervals').  Stored per tile, in the order the
+    guides receive them: qs, traj_ranges, radii (after the shift) and is_soft."""
+    import types
+    from mmd.planners.single_agent.mpd_ensemble import MPDEnsemble
+    from mp_baselines.planners.costs.cost_functions import CostConstraint
+    from torch_robotics.robots import RobotPlanarDisk
+    from torch_robotics.tasks.tasks_ensemble import PlanningTaskEnsemble
+    with quiet():
+        robot = RobotPlanarDisk(tensor_args=TENSOR_ARGS)
+    task = types.SimpleNamespace(tasks={0: "t0", 1: "t1", 2: "t2"})
+    task.infer_task_id_from_q_idx = types.MethodType(PlanningTaskEnsemble.infer_task_id_from_q_idx, task)
+    me = types.SimpleNamespace(task=task, robot=robot, n_support_points=H, tensor_args=TENSOR_ARGS)
+    transforms = {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0]), 2: torch.tensor([4.0, 0.5])}
+
+    def cc(qs, ranges, radii, soft):
+        return CostConstraint(robot, H, q_l=[torch.tensor(q, dtype=torch.float32) for q in qs], traj_range_l=ranges,
+                              radius_l=radii, is_soft=soft, tensor_args=TENSOR_ARGS)
+    inputs = [
+        (([0.1, 0.2], [2.3, 0.1]), [(10, 14), (70, 75)], [0.12, 0.10], False),
+        (([-0.4, 0.3], [1.7, -0.2], [4.4, 0.6]), [(5, 6), (64, 65), (130, 131)], [0.12, 0.12, 0.12], True),
+        (([3.9, 0.4],), [(128, 140)], [0.2], False),
+        (([0.9, -0.1], [0.0, 0.0]), [(62, 66), (0, 1)], [0.12, 0.15], True),
+    ]
+    cons = [cc(*a) for a in inputs]
+    with quiet():
+        split = MPDEnsemble.split_cost_constraints_to_tasks(me, cons)
+    out = {"task_order": np.array(list(split.keys()), dtype=np.int64)}
+    for task_id, cl in split.items():
+        out[f"n_{task_id}"] = np.int64(len(cl))
+        for k, c in enumerate(cl):
+            c.traj_ranges -= task_id * H                                  # mpd_ensemble.py:517
+            c.qs -= transforms[task_id]                                   # :518
+            out[f"qs_{task_id}_{k}"] = c.qs.numpy().astype(np.float32)
+            out[f"ranges_{task_id}_{k}"] = np.asarray(c.traj_ranges.numpy(), dtype=np.float32)
+            out[f"radii_{task_id}_{k}"] = c.radii.numpy().astype(np.float32)
+            out[f"soft_{task_id}_{k}"] = np.bool_(c.is_soft)
+    print("   g13: tiles", list(split.keys()), "costs per tile", [len(v) for v in split.values()])
+    np.savez_compressed(os.path.join(OUT, "g13_split_constraints.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}[name]()
     print("done")
