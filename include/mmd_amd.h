@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMD_AMD_ABI_VERSION 3
+#define MMD_AMD_ABI_VERSION 4
 #define MMD_STATE_DIM 4
 #define MMD_HORIZON 64
 
@@ -105,6 +105,14 @@ typedef struct mmd_guide_desc {
   float cons_uniform_radius;         /* > 0: every active point of the table has exactly this radius (tables made by
                                       * mmd_soft_constraints_from_paths): the kernel then keeps only (qx, qy) on chip,
                                       * twice the slots per workgroup.  0 = radii vary, general path. */
+  /* Extra objects of the environment (EnvBase.obj_extra_list, env_base.py:76-89: an ObjectField of primitive fields at the
+   * identity pose), evaluated ANALYTICALLY as the reference does -- one more signed-distance field next to the grids of the
+   * fixed objects (df_obj_l = [grid, *obj_extra_list]; cost = max over the fields, distance_fields.py:110-126): spheres
+   * |p - c| - r (MultiSphereField, primitives.py:108-115), boxes as the rounded box of the fixed objects (MultiBoxField,
+   * primitives.py:326-333: corner radius 0.15 x the smaller size), minimum over all of them.  n = 0 / NULL: the env has none (every shipped map: an empty sphere list, sdf = 1). */
+  const float* extra_spheres_dev;    /* [n_extra_spheres][4]: (cx, cy, r, 0) */
+  const float* extra_boxes_dev;      /* [n_extra_boxes][4]: (cx, cy, half size x, half size y) */
+  int32_t n_extra_spheres, n_extra_boxes;
 } mmd_guide_desc;
 
 /* Host helper: time-bucket one robot's constraint groups.  For group g (n_pts[g] points): q [n,2], t_range [n,2]

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmd_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GuideDesc(C.Structure):
@@ -19,6 +19,8 @@ class GuideDesc(C.Structure):
         ("weight_collision", C.c_float), ("weight_smoothness", C.c_float), ("max_grad_norm", C.c_float),
         ("cons_ell_dev", C.c_void_p), ("grp_slot_off_dev", C.c_void_p), ("grp_weight_dev", C.c_void_p),
         ("robot_grp_off_dev", C.c_void_p), ("max_slots_per_robot", C.c_int32), ("cons_uniform_radius", C.c_float),
+        ("extra_spheres_dev", C.c_void_p), ("extra_boxes_dev", C.c_void_p),
+        ("n_extra_spheres", C.c_int32), ("n_extra_boxes", C.c_int32),
     ]
 
 

@@ -232,6 +232,11 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
       const float v = fmaxf(g.margin - c.x, 0.f);
       if (v > best) { best = v; gx = -c.y; gy = -c.z; }
     }
+    if (g.n_xs + g.n_xb > 0) {                             // the env's extra objects: one more field, analytic
+      float ex, ey;
+      const float v = fmaxf(g.margin - extra_sdf(g.xs, g.n_xs, g.xb, g.n_xb, px, py, ex, ey), 0.f);
+      if (v > best) { best = v; gx = -ex; gy = -ey; }
+    }
     const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
     ox = g.w_coll * (sc * gx); oy = g.w_coll * (sc * gy);
   }
@@ -425,6 +430,8 @@ int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
   g.m3 = (float)(4.0 / dt * qc);
   g.max_slots = d->max_slots_per_robot > 0 ? d->max_slots_per_robot : LDS_SLOTS_SMALL;
   g.uniform_r2 = d->cons_uniform_radius > 0.f ? d->cons_uniform_radius * fabsf(d->cons_uniform_radius) : 0.f;
+  g.xs = reinterpret_cast<const float4*>(d->extra_spheres_dev); g.n_xs = d->extra_spheres_dev ? d->n_extra_spheres : 0;
+  g.xb = reinterpret_cast<const float4*>(d->extra_boxes_dev); g.n_xb = d->extra_boxes_dev ? d->n_extra_boxes : 0;
   g.cons = reinterpret_cast<const float4*>(d->cons_ell_dev);
   g.grp_slot_off = d->grp_slot_off_dev; g.grp_weight = d->grp_weight_dev; g.robot_grp_off = d->robot_grp_off_dev;
   if (!g.cons || !g.grp_slot_off || !g.grp_weight) g.robot_grp_off = nullptr;

@@ -22,7 +22,45 @@ struct GuideDev {
   const int* robot_grp_off;
   int max_slots;                     // largest number of constraint slots any robot owns (LDS sizing)
   float uniform_r2;                  // > 0: every active point has radius^2 = this (compact float2 staging); else 0
+  const float4* xs;                  // extra spheres (cx, cy, r, 0)
+  const float4* xb;                  // extra boxes (cx, cy, hx, hy)
+  int n_xs, n_xb;
 };
+
+// signed distance of the env's extra objects at p and its gradient (torch's sub-gradients: the first minimum / maximum);
+// no object at all: sdf = 1 (an empty MultiSphereField, primitives.py:109-110)
+__device__ __forceinline__ float extra_sdf(const float4* __restrict__ xs, int n_xs, const float4* __restrict__ xb, int n_xb,
+                                           float px, float py, float& gx, float& gy) {
+  float best = n_xs + n_xb > 0 ? 1e30f : 1.f;
+  gx = 0.f; gy = 0.f;
+  for (int i = 0; i < n_xs; ++i) {
+    const float4 s = xs[i];
+    const float dx = px - s.x, dy = py - s.y;
+    const float n = sqrtf(dx * dx + dy * dy), d = n - s.z;
+    if (d < best) { best = d; gx = n > 0.f ? dx / n : 0.f; gy = n > 0.f ? dy / n : 0.f; }
+  }
+  for (int i = 0; i < n_xb; ++i) {
+    // MultiBoxField = the rounded box of the fixed objects (primitives.py:326-333): q = |p - c| - half + rad, sdf = min(max q,
+    // 0) + ||relu(q)|| - rad; b = (cx, cy, half x, half y), rad = 0.15 x the smaller SIZE
+    const float4 b = xb[i];
+    const float rad = 0.3f * fminf(b.z, b.w);
+    const float dx = px - b.x, dy = py - b.y, qx = fabsf(dx) - b.z + rad, qy = fabsf(dy) - b.w + rad;
+    const float mq = fmaxf(qx, qy), rx = fmaxf(qx, 0.f), ry = fmaxf(qy, 0.f), n = sqrtf(rx * rx + ry * ry);
+    const float d = fminf(mq, 0.f) + n - rad;
+    if (d < best) {
+      best = d;
+      const float sx = dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f), sy = dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f);
+      if (mq <= 0.f) {                                     // inside the inner box: d = max q - rad
+        gx = qx >= qy ? sx : 0.f;
+        gy = qx >= qy ? 0.f : sy;
+      } else {                                             // outside: d = ||relu(q)|| - rad
+        gx = rx / n * sx;
+        gy = ry / n * sy;
+      }
+    }
+  }
+  return best;
+}
 
 struct StepDev {
   float a_t, b_t, c1, c2;            // sqrt_recip_alphas_cumprod[t], sqrt_recipm1[t], posterior_mean_coef1/2[t]

@@ -19,6 +19,7 @@
 
 #include "../../include/mmd_amd.h"
 #include "common.h"
+#include "guide_dev.h"
 
 #pragma clang fp contract(off)
 
@@ -32,6 +33,9 @@ struct EnvDev {
   const float4* grids;        // [n_maps][n_grids][nx][ny]
   const int* robot_map;       // per-robot map index or null
   float ws_min[2], ws_max[2];
+  const float4* xs;           // the env's extra objects (mmd_guide_desc.extra_spheres_dev / extra_boxes_dev)
+  const float4* xb;
+  int n_xs, n_xb;
 };
 
 static int fill_env(const mmd_guide_desc* d, EnvDev& e) {
@@ -45,6 +49,8 @@ static int fill_env(const mmd_guide_desc* d, EnvDev& e) {
   e.nx = d->grid_nx; e.ny = d->grid_ny; e.n_grids = d->n_grids;
   e.grids = reinterpret_cast<const float4*>(d->sdf_grids_dev);
   e.robot_map = d->robot_map_dev;
+  e.xs = reinterpret_cast<const float4*>(d->extra_spheres_dev); e.n_xs = d->extra_spheres_dev ? d->n_extra_spheres : 0;
+  e.xb = reinterpret_cast<const float4*>(d->extra_boxes_dev); e.n_xb = d->extra_boxes_dev ? d->n_extra_boxes : 0;
   return 0;
 }
 
@@ -58,6 +64,10 @@ __device__ __forceinline__ bool point_collides(const EnvDev& e, const float4* __
     ix = min(max(ix, 0), e.nx - 1);
     iy = min(max(iy, 0), e.ny - 1);
     for (int k = 0; k < e.n_grids; ++k) c = c || grid[((size_t)k * e.nx + ix) * e.ny + iy].x < margin;
+  }
+  if (e.n_xs + e.n_xb > 0) {                                // env.get_df_obj_list(): the fixed grid + obj_extra_list
+    float gx, gy;
+    c = c || extra_sdf(e.xs, e.n_xs, e.xb, e.n_xb, px, py, gx, gy) < margin;
   }
   c = c || (px - e.ws_min[0] < margin) || (py - e.ws_min[1] < margin) || (e.ws_max[0] - px < margin) ||
       (e.ws_max[1] - py < margin);

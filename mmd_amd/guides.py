@@ -40,7 +40,7 @@ class GuideManagerTrajectoriesWithVelocity:
                  env_id="EnvEmpty2D", obstacle_cutoff_margin=0.05, robot_radius=ROBOT_RADIUS,
                  weight_grad_cost_collision=2e-2, weight_grad_cost_smoothness=8e-2, trajectory_duration=5.0,
                  n_support_points=64, sigma_gp=1.0, n_robots=1, robot_env_ids: Optional[Sequence[str]] = None,
-                 extra_objects_only=False, device="cuda", tensor_args=None, **kwargs):
+                 extra_objects_only=False, extra_objects=None, device="cuda", tensor_args=None, **kwargs):
         if not clip_grad or clip_grad_rule != "norm":
             raise NotImplementedError("MPD uses clip_grad=True, clip_grad_rule='norm' (mpd.py:258-265)")
         self.dataset = dataset
@@ -61,9 +61,18 @@ class GuideManagerTrajectoriesWithVelocity:
         from .environments import MAP_BOXES
         self._obstacle_free = all(len(MAP_BOXES[m.replace("ExtraObjects", "")][0]) == 0 for m in maps)
         # use_guide_on_extra_objects_only (mpd.py:216-219): the only collision field is task.get_collision_fields_extra_objects()
-        # = the env's extra ObjectField, which is EMPTY in every shipped map (env_*_extra_objects.py: MultiSphereField([]),
-        # sdf == 1) -- no fixed-object grid and no workspace walls in the guide; GP prior and constraints stay
+        # = the env's extra ObjectField (EMPTY in every shipped map: env_*_extra_objects.py MultiSphereField([]), sdf == 1;
+        # `extra_objects` below otherwise) -- no fixed-object grid and no workspace walls in the guide; GP prior and
+        # constraints stay
         self.extra_objects_only = bool(extra_objects_only)
+        # The env's obj_extra_list (env_base.py:76-89), given as {"spheres": [(cx, cy, r), ...], "boxes": [(cx, cy, size x,
+        # size y), ...]} (MultiSphereField / MultiBoxField arguments; the box is the rounded one of the fixed objects): evaluated analytically by the
+        # kernels, one more field next to the fixed objects' grid.  None / empty = the shipped ExtraObjects maps.
+        xo = extra_objects or {}
+        sph = np.asarray(xo.get("spheres", []), dtype=np.float32).reshape(-1, 3)
+        box = np.asarray(xo.get("boxes", []), dtype=np.float32).reshape(-1, 4)
+        self._xs = torch.from_numpy(np.concatenate([sph, np.zeros((len(sph), 1), np.float32)], 1)).to(self.device) if len(sph) else None
+        self._xb = torch.from_numpy(np.concatenate([box[:, :2], box[:, 2:] / np.float32(2)], 1)).to(self.device) if len(box) else None
         # extra costs, per robot (guides.py:176-178, :228-234)
         self.extra_cost_l: List[List[CostConstraint]] = [[] for _ in range(n_robots)]
         self.extra_costs_grad_weight_l: List[List[float]] = [[] for _ in range(n_robots)]
@@ -120,6 +129,10 @@ class GuideManagerTrajectoriesWithVelocity:
         d.margin, d.dt, d.sigma_gp = self.margin, self.dt, self.sigma_gp
         d.weight_collision, d.weight_smoothness = self.weight_collision, self.weight_smoothness
         d.max_grad_norm = self.max_grad_norm
+        if self._xs is not None:
+            d.extra_spheres_dev, d.n_extra_spheres = self._xs.data_ptr(), self._xs.shape[0]
+        if self._xb is not None:
+            d.extra_boxes_dev, d.n_extra_boxes = self._xb.data_ptr(), self._xb.shape[0]
         cons = self._constraints()
         if cons is not None:
             ell, gso, gw, rgo = cons[:4]

@@ -213,7 +213,7 @@ class MPD:
                  device: str = "cuda", debug: bool = False, seed: int = 18, results_dir: str = "logs",
                  trained_models_dir: str = "", n_samples: int = 64, n_local_inference_noising_steps: int = 3,
                  n_local_inference_denoising_steps: int = 3, model_state_dict=None, model_args=None, env_id=None,
-                 normalizer_limits=None, obstacle_cutoff_margin=0.05, **kwargs):
+                 normalizer_limits=None, obstacle_cutoff_margin=0.05, env_extra_objects=None, **kwargs):
         self.constraints = []
         self.weight_grad_cost_constraints = weight_grad_cost_constraints
         self.weight_grad_cost_soft_constraints = weight_grad_cost_soft_constraints
@@ -244,11 +244,13 @@ class MPD:
             self.dataset, env_id=self.env_id, obstacle_cutoff_margin=obstacle_cutoff_margin,
             weight_grad_cost_collision=weight_grad_cost_collision,
             weight_grad_cost_smoothness=weight_grad_cost_smoothness, trajectory_duration=trajectory_duration,
-            n_support_points=HORIZON, extra_objects_only=use_guide_on_extra_objects_only, device=self.device)
-        # the task's own collision checks (post-processing, compute_collision) always see the full map (tasks.py:141-311)
+            n_support_points=HORIZON, extra_objects_only=use_guide_on_extra_objects_only,
+            extra_objects=env_extra_objects, device=self.device)
+        # the task's own collision checks (post-processing, compute_collision) always see the full map (tasks.py:141-311):
+        # fixed objects + the env's extra objects (env.get_df_obj_list, env_base.py:76-89) + workspace boundaries
         self._task_guide = self.guide if not use_guide_on_extra_objects_only else GuideManagerTrajectoriesWithVelocity(
             self.dataset, env_id=self.env_id, obstacle_cutoff_margin=obstacle_cutoff_margin, n_support_points=HORIZON,
-            device=self.device)
+            extra_objects=env_extra_objects, device=self.device)
         self.task = PlanningTaskFacade(self._task_guide, self.robot)     # CBS reads planner.task (cbs.py:149)
         self.t_start_guide = ceil(start_guide_steps_fraction * self.model.n_diffusion_steps)
         self.n_guide_steps = n_guide_steps

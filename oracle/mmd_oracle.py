@@ -257,6 +257,11 @@ class GuideParams:
     max_grad_norm: float = 1.0                   # guides.py:154
     sigma_gp: float = 1.0                        # mpd.py:237
     sigma_coll: float = 1.0                      # mpd.py:227
+    # the env's extra objects (EnvBase.obj_extra_list, env_base.py:76-89: one ObjectField of primitive fields, identity
+    # pose), evaluated analytically next to the grids of the fixed objects.  None: the env has no obj_extra_list
+    extra_spheres: torch.Tensor = None           # [n,3] (cx, cy, r)          MultiSphereField (primitives.py:108-115)
+    extra_boxes: torch.Tensor = None             # [n,4] (cx, cy, sx, sy)     MultiBoxField (rounded, primitives.py:326-333), sizes
+    extra_only: bool = False                     # use_guide_on_extra_objects_only (mpd.py:216-219): this field alone
 
     @property
     def margin(self):
@@ -297,6 +302,32 @@ def sdf_lookup(p, gp: GuideParams, k=0):
     return sdf[ix, iy], grad[ix, iy]
 
 
+def extra_objects_sdf(p, gp: GuideParams):
+    """ObjectField.compute_signed_distance_impl (primitives.py:554-572, identity pose) over the env's extra primitive fields:
+    min over fields of their own min over spheres (|p - c| - r; an EMPTY MultiSphereField is 1 everywhere, :109-110) /
+    boxes (the rounded box of the fixed objects, radius 0.15 x the smaller size).  Returns (sdf, d sdf / dp) by autograd."""
+    pp = p.detach().clone().requires_grad_(True)
+    fields = []
+    if gp.extra_spheres is not None:
+        if gp.extra_spheres.shape[0] == 0:
+            fields.append(torch.ones_like(pp[..., 0]))
+        else:
+            d = torch.norm(pp.unsqueeze(-2) - gp.extra_spheres[:, :2], dim=-1) - gp.extra_spheres[:, 2]
+            fields.append(torch.min(d, dim=-1)[0])
+    if gp.extra_boxes is not None and gp.extra_boxes.shape[0] > 0:
+        # MultiBoxField = the rounded box of primitives.py:326-333 (radius 0.15 x the smaller size), as the fixed objects
+        sizes = gp.extra_boxes[:, 2:]
+        radius = torch.min(sizes, dim=-1)[0] * 0.15
+        q = torch.abs(pp.unsqueeze(-2) - gp.extra_boxes[:, :2]) - sizes / 2 + radius.unsqueeze(-1)
+        max_q = torch.amax(q, dim=-1)
+        sdfs = torch.minimum(max_q, torch.zeros_like(max_q)) + torch.linalg.norm(torch.relu(q), dim=-1) - radius
+        fields.append(torch.min(sdfs, dim=-1)[0])
+    sdf = torch.min(torch.stack(fields, dim=-1), dim=-1)[0]
+    with torch.enable_grad():
+        g, = torch.autograd.grad(sdf.sum(), pp, allow_unused=True)
+    return sdf.detach(), (torch.zeros_like(p) if g is None else g)
+
+
 def grad_object_collision(xu, gp: GuideParams):
     """d/dx of CostCollision(df_collision_objects) (cost_functions.py:175-193, field_factor.py:24-48 with range
     [1,None]; distance_fields.py:110-135, :342-351): cost_b = sum_{t>=1} max_k relu(margin - sdf_k(p_t))."""
@@ -304,8 +335,11 @@ def grad_object_collision(xu, gp: GuideParams):
     m = gp.margin
     best = torch.zeros_like(p[..., 0])
     gbest = torch.zeros_like(p)
-    for k in range(len(gp.sdf_grids)):
-        s, gs = sdf_lookup(p, gp, k)
+    fields = [] if gp.extra_only else [sdf_lookup(p, gp, k) for k in range(len(gp.sdf_grids))]
+    if gp.extra_spheres is not None or gp.extra_boxes is not None:
+        with torch.enable_grad():
+            fields.append(extra_objects_sdf(p, gp))
+    for s, gs in fields:
         v = torch.relu(m - s)
         take = v > best
         gbest = torch.where(take[..., None], -gs, gbest)
@@ -381,9 +415,10 @@ def guide_grad(x_norm, gp: GuideParams, cons: Sequence[ConstraintGroup] = (), cl
     gradient w.r.t. the UN-normalised trajectory, per-point norm clip, zero rows 0 and H-1, weight, sum, negate.
     The result is added to the NORMALISED x by the caller (sample_functions.py:104) -- reproduced as is."""
     xu = unnormalize(x_norm, gp.norm_mins, gp.norm_maxs, clip_mode=clip_mode)
-    terms = [(grad_object_collision(xu, gp), gp.weight_collision),
-             (grad_ws_boundaries(xu, gp), gp.weight_collision),
-             (grad_gp_prior(xu, gp), gp.weight_smoothness)]
+    terms = [(grad_object_collision(xu, gp), gp.weight_collision)]
+    if not gp.extra_only:                             # (mpd.py:216-219: the extra-objects field is then the ONLY collision cost)
+        terms.append((grad_ws_boundaries(xu, gp), gp.weight_collision))
+    terms.append((grad_gp_prior(xu, gp), gp.weight_smoothness))
     for grp in cons:
         terms.append((grad_constraint(xu, grp), grp.weight))
     total = torch.zeros_like(x_norm)
@@ -635,6 +670,9 @@ def compute_collision(pos, gp: GuideParams, margin=None):
     coll = torch.zeros(pos.shape[:-1], dtype=torch.bool)
     for k in range(len(gp.sdf_grids)):
         coll = coll | (sdf_lookup(pos, gp, k)[0] < margin)
+    if gp.extra_spheres is not None or gp.extra_boxes is not None:      # env.get_df_obj_list(): fixed grid + obj_extra_list
+        with torch.enable_grad():
+            coll = coll | (extra_objects_sdf(pos, gp)[0] < margin)
     ws = torch.cat((pos - gp.ws_min, gp.ws_max - pos), dim=-1)
     return coll | (ws < margin).any(dim=-1)
 

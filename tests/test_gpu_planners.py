@@ -542,3 +542,29 @@ def test_plan_round_selection_vs_oracle_two_rounds():
             assert torch.equal(paths[r].cpu(), tr[want, :, :2])
     assert n_nonfree > 0, "the case must exercise the free / colliding split"
 
+
+def test_extra_objects_guide_and_occupancy_g14():
+    """A map WITH extra objects (env_base.py:76-89, mpd.py:215-233): the HIP guide evaluates the env's extra
+    spheres / boxes analytically next to the fixed-object grid -- full guide and use_guide_on_extra_objects_only against the
+    reference (g14, max-abs 2e-6), the task facade's compute_collision of random points exactly."""
+    import gpu_common
+    from mmd_amd.guides import GuideManagerTrajectoriesWithVelocity
+    from mmd_amd.planners import PlanningTaskFacade, RobotPlanarDiskFacade
+    g = np.load(os.path.join(GOLDEN, "g14_extra_objects.npz"))
+    xo = {"spheres": g["spheres"].tolist(), "boxes": g["boxes"].tolist()}
+    x = (torch.from_numpy(synth.synth_noise(95, (8, H, D))) * 0.6).cuda()
+    full = GuideManagerTrajectoriesWithVelocity(gpu_common.dataset(), env_id="EnvHighways2D", extra_objects=xo, device="cuda")
+    e1 = float((full(x).cpu() - torch.from_numpy(g["guide_full"])).abs().max())
+    only = GuideManagerTrajectoriesWithVelocity(gpu_common.dataset(), env_id="EnvHighways2D", extra_objects=xo,
+                                                extra_objects_only=True, device="cuda")
+    e2 = float((only(x).cpu() - torch.from_numpy(g["guide_extra_only"])).abs().max())
+    parity_log.record("extra_objects_g14", "guide_full", None, e1, bound=2e-6)
+    parity_log.record("extra_objects_g14", "guide_extra_only", None, e2, bound=2e-6)
+    assert e1 < 2e-6 and e2 < 2e-6, (e1, e2)
+    # without the extra objects the same batch gets a different gradient (the objects matter)
+    plain = GuideManagerTrajectoriesWithVelocity(gpu_common.dataset(), env_id="EnvHighways2D", device="cuda")
+    assert float((plain(x).cpu() - torch.from_numpy(g["guide_full"])).abs().max()) > 1e-3
+    task = PlanningTaskFacade(full, RobotPlanarDiskFacade(torch.device("cuda")))
+    coll = task.compute_collision(torch.from_numpy(g["points"]))
+    assert np.array_equal(coll.cpu().numpy().reshape(-1), g["coll_random"].reshape(-1))
+

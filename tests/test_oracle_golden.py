@@ -183,3 +183,23 @@ def test_postprocess_oracle_vs_reference_g9():
     assert np.allclose(O.compute_smoothness(trajs).numpy(), g["smoothness"], rtol=1e-6, atol=1e-6)
     assert np.allclose(O.compute_path_length(trajs).numpy(), g["path_length"], rtol=1e-6, atol=1e-6)
     assert np.allclose(O.smooth_trajs(trajs).numpy(), g["smoothed"], rtol=1e-6, atol=1e-7)
+
+
+def test_g14_extra_objects():
+    """The oracle's analytic extra-object field (EnvBase.obj_extra_list: spheres + boxes next to the fixed-object grid)
+    against the reference on a Highways map WITH extra objects (g14): the full guide, the guide with
+    use_guide_on_extra_objects_only (mpd.py:216-219), and the task's occupancy of random points."""
+    g = np.load(os.path.join(GOLDEN, "g14_extra_objects.npz"))
+    gp = cases.guide_params("EnvHighways2D")
+    gp.extra_spheres = torch.from_numpy(g["spheres"])
+    gp.extra_boxes = torch.from_numpy(g["boxes"])
+    x = torch.from_numpy(synth.synth_noise(95, (8, H, D))) * 0.6
+    assert float((O.guide_grad(x, gp) - torch.from_numpy(g["guide_full"])).abs().max()) < 1e-7
+    gp.extra_only = True
+    assert float((O.guide_grad(x, gp) - torch.from_numpy(g["guide_extra_only"])).abs().max()) < 1e-7
+    gp.extra_only = False
+    coll = O.compute_collision(torch.from_numpy(g["points"]), gp)
+    assert np.array_equal(coll.numpy(), g["coll_random"].reshape(-1))
+    xu = O.unnormalize(x, gp.norm_mins, gp.norm_maxs)
+    assert np.array_equal(O.compute_collision(xu[..., :2].reshape(-1, 2), gp).numpy(), g["coll_points"].reshape(-1))
+

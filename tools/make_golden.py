@@ -18,6 +18,7 @@ Fixtures:
   g9_post.npz          post-sampling selection: collision/free split, smoothness, path length, SavGol smoothing
   g12_boundary.npz     outer-boundary contract: check_rr_collisions / compute_collision on the shapes CBS / PP pass
   g13_split_constraints.npz  MPDEnsemble.split_cost_constraints_to_tasks + the per-tile range / transform shift
+  g14_extra_objects.npz      a map with extra objects (spheres + boxes): guide, extra-objects-only guide, occupancy
 """
 import os
 import sys
@@ -241,6 +242,19 @@ def g6():
     starts, goals = synth.start_goal_circle(6, 0.8)
     save_case("g6_sample_prior_T100.npz", [100, 8, 6, 1, 29, 30], CHAIN_ROWS(100),
               "EnvEmpty2D", 100, 8, starts[1], goals[1], [], 29, 30, use_guide=False)
+
+
+def g6_full():
+    """The FULL 27-row chain of the 32-robot case (g6_sample_empty32_T25, same inputs), so that every one of its 13 guided steps
+    is teacher-forced by test_single_step_teacher_forced_golden (no sensitivity draws: one reference run)."""
+    starts, goals = synth.start_goal_circle(32, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    q, tr, r = soft_points(paths, 5)
+    chain = run_ref_inference("EnvEmpty2D", 25, 4, starts[5], goals[5], [(q, tr, r, True)], 19, 20)
+    ref = np.load(os.path.join(OUT, "g6_sample_empty32_T25.npz"))
+    assert np.array_equal(chain[ref["rows"]], ref["chain_rows"]), "the full chain must contain the stored rows of g6"
+    np.savez_compressed(os.path.join(OUT, "g6_full_empty32_T25.npz"), chain=chain, meta=ref["meta"])
+    print("   g6_full: chain", chain.shape)
 
 
 def g7():
@@ -526,11 +540,66 @@ def g13():
     np.savez_compressed(os.path.join(OUT, "g13_split_constraints.npz"), **out)
 
 
+EXTRA_SPHERES = [(0.35, -0.30, 0.09), (-0.55, 0.15, 0.06)]          # (cx, cy, r)
+EXTRA_BOXES = [(-0.10, 0.55, 0.30, 0.12), (0.62, 0.48, 0.10, 0.22)]    # (cx, cy, size x, size y)
+
+
+def g14():
+    """A map WITH extra objects (EnvBase.obj_extra_list, env_base.py:76-89; every shipped ExtraObjects map has an empty
+    list): EnvHighways2D + an ObjectField of a MultiSphereField and a MultiBoxField.  Stores guide(x) with the full
+    collision fields (mpd.py:220: fixed grid + extra objects in one CollisionObjectDistanceField, workspace walls, GP
+    prior), guide(x) with use_guide_on_extra_objects_only (mpd.py:216-219: the extra-objects field alone + GP prior), and
+    the task's occupancy (compute_collision at the guide margin and get_trajs_collision_and_free) of a batch."""
+    from mp_baselines.planners.costs.cost_functions import CostCollision, CostComposite, CostGPTrajectory
+    from mmd.models.diffusion_models.guides import GuideManagerTrajectoriesWithVelocity
+    from ref_harness import DatasetLike
+    from torch_robotics import environments
+    from torch_robotics.environments.primitives import MultiBoxField, MultiSphereField, ObjectField
+    from torch_robotics.robots import RobotPlanarDisk
+    from torch_robotics.tasks.tasks import PlanningTask
+    sph, box = np.array(EXTRA_SPHERES, np.float32), np.array(EXTRA_BOXES, np.float32)
+    with quiet():
+        extra = ObjectField([MultiSphereField(sph[:, :2], sph[:, 2], tensor_args=TENSOR_ARGS),
+                             MultiBoxField(box[:, :2], box[:, 2:], tensor_args=TENSOR_ARGS)], "extra")
+        env = environments.EnvHighways2D(obj_extra_list=[extra], tensor_args=TENSOR_ARGS)
+        robot = RobotPlanarDisk(tensor_args=TENSOR_ARGS)
+        task = PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.05, tensor_args=TENSOR_ARGS)
+    robot.dt = 5.0 / H
+
+    def guide_for(fields):
+        cost_l = [CostCollision(robot, H, field=f, sigma_coll=1.0, tensor_args=TENSOR_ARGS) for f in fields]
+        w_l = [2e-2] * len(cost_l)
+        cost_l.append(CostGPTrajectory(robot, H, robot.dt, sigma_gp=1.0, tensor_args=TENSOR_ARGS))
+        w_l.append(8e-2)
+        comp = CostComposite(robot, H, cost_l, weights_cost_l=w_l, tensor_args=TENSOR_ARGS)
+        return GuideManagerTrajectoriesWithVelocity(DatasetLike(MINS, MAXS), comp, clip_grad=True,
+                                                    interpolate_trajectories_for_collision=True,
+                                                    num_interpolated_points=ceil(H * 1.5), tensor_args=TENSOR_ARGS)
+    x = torch.from_numpy(synth.synth_noise(95, (8, H, D))) * 0.6
+    with quiet():
+        g_full = guide_for(task.get_collision_fields())(x).numpy()
+        g_extra = guide_for(task.get_collision_fields_extra_objects())(x).numpy()
+    xu = DatasetLike(MINS, MAXS).unnormalize_trajectories(x)
+    with quiet():
+        coll_pts = task.compute_collision(xu[..., :2].reshape(-1, 2))
+        _, coll_idxs, _, free_idxs, _ = task.get_trajs_collision_and_free(xu, return_indices=True)
+    rng = np.random.Generator(np.random.PCG64(96))
+    pts = torch.from_numpy(rng.uniform(-1.0, 1.0, size=(512, 2)).astype(np.float32))
+    with quiet():
+        coll_rand = task.compute_collision(pts)
+    print("   g14: |guide| full / extra-only", float(np.abs(g_full).max()), float(np.abs(g_extra).max()),
+          "colliding points", int(coll_pts.sum()), "/", coll_pts.numel(), "random", int(coll_rand.sum()), "free trajs", free_idxs.numel())
+    np.savez_compressed(os.path.join(OUT, "g14_extra_objects.npz"), spheres=sph, boxes=box, guide_full=g_full,
+                        guide_extra_only=g_extra, coll_points=coll_pts.numpy(), points=pts.numpy(),
+                        coll_random=coll_rand.numpy(), free_idxs=free_idxs.reshape(-1).numpy(),
+                        coll_idxs=coll_idxs.reshape(-1).numpy())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full}[name]()
     print("done")
