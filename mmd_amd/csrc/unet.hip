@@ -1,22 +1,25 @@
 // TemporalUnet forward for gfx950 (MI355X), the whole network in ONE launch (unet_kernel).  Every Conv1d /
 // ConvTranspose1d of the reference network (mmd/models/diffusion_models/temporal_unet.py:121-174,
-// mmd/models/layers/layers.py:261-358) is an fp32 GEMM on the matrix pipe, with GroupNorm + Mish + time-bias / residual
-// fused into the epilogue:
-//   * all 25 stride-1 k=5 convs run as Winograd F(4,5) (8 instead of 20 multiplies per 4 outputs; ~2e-6 relative
-//     difference to the direct sum): 18 of them on v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation), the
-//     seven 128 -> 128 convs of downs.2 + mid blocks (51 % of the MACs) as an exact three-way bf16 split of both
-//     operands on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- as accurate as the fp32 MFMA, 2.7x its rate;
-//   * strided / transposed / 1x1 convs: direct GEMMs (taps = row-shifted views of an LDS slab; v_mfma_f32_32x32x2_f32
-//     for the down / up-sampling convs and the final 1x1, 16x16x4 for the 1x1 residual convs).
+// mmd/models/layers/layers.py:261-358) is an fp32-accurate GEMM on the matrix pipe, with GroupNorm + Mish + time-bias /
+// residual fused into the epilogue:
+//   * f16x2: an fp32 operand is split into two fp16 pieces (round to nearest, twice) and a product is three
+//     v_mfma_f32_16x16x32_f16 (a1*w0 + a0*w1 + a0*w0) with fp32 accumulation -- 1/5 of the fp32 MFMA's pipe time, at
+//     least its accuracy.  Power-of-two scales keep the pieces inside fp16's range: per output channel for weights
+//     (host), static for the inputs of an RTB's second conv (bounded by GroupNorm), dynamic per sample for the
+//     residual stream (dyn_scale); all of them leave through the GroupNorm epilogue's coefficients.
+//   * stage forms: downs.0 wave-private direct f16x2 (wave = sample, no workgroup barriers); downs.1 Winograd F(4,5)
+//     f16x2 in two position phases; downs.2 + mid and ups.0 direct f16x2 on a row-form fp16 slab (rd_taps); ups.1 and
+//     the final block Winograd F(4,5) on v_mfma_f32_16x16x4_f32; the strided tail of downs.1 on v_mfma_f32_32x32x2_f32.
 //
 // Layout.  The trajectory tensor is channels-last [n_traj, 64, 4] fp32 in HBM on both sides (no transposes).  A
-// workgroup (4 waves) owns 4 whole samples for the entire forward: activations live in LDS slabs [sample][L+4][C+1]
-// (zero halo, odd row stride) and in register tiles; the two skip connections wait in registers for the up path;
-// nothing but the input, the output and the weights touches HBM/L2.  In the 16x16x4 C/D layout a lane holds 16
-// consecutive positions of one (sample, channel), so a GroupNorm group (C/8 adjacent channels x all L positions) is a
-// few lanes of one DPP row (x 2 / 4 row blocks at L = 32 / 64): the statistics are in-register + cross-lane reductions.
-// Weights are pre-packed on the host in MFMA B-fragment order (Winograd-transformed in fp64) and fetched straight from
-// L2 through a register ring (no LDS staging: a B element is used once per workgroup).
+// workgroup (4 waves) owns 4 whole samples for the entire forward: activations live in LDS slabs (fp32 row form
+// [sample][L+4][C+1]; fp16 row form [piece][lane group][K chunk][row][8 ch], RdGeo / RwGeo; Winograd phase slabs) and
+// in register tiles; the two skip connections wait in registers for the up path; nothing but the input, the output
+// and the weights touches HBM/L2.  In the 16x16 C/D layouts a lane holds 4 consecutive positions (or Winograd
+// quads) of one channel per tile, so a GroupNorm group is a few lanes of one DPP row (x row blocks): the statistics are
+// in-register + cross-lane reductions.  Weights are pre-packed on the host in MFMA B-fragment order (fp16 pairs,
+// Winograd-transformed in fp64 where that form is used) and fetched straight from L2 through a register ring (no LDS
+// staging: a B element is used once per workgroup).  DESIGN.md section 3.1 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -26,5 +26,7 @@ for n in [int(a) for a in sys.argv[1:]] or [2048]:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     fl, mf = lib.mmd_unet_flops_per_trajectory() * n, lib.mmd_unet_mfma_flops_per_trajectory() * n
-    print(f"n={n:5d}: unet forward {us:8.1f} us  algorithmic {fl / us / 1e6:6.1f} TF  issued {mf / us / 1e6:6.1f} TF "
-          f"({mf / us / 1e6 / 157.3:.3f} of fp32 MFMA peak)  [{os.environ.get('MMD_AMD_LIB', 'default lib')}]", flush=True)
+    hf = lib.mmd_unet_f16x2_flops_per_trajectory() * n
+    busy_us = ((mf - hf) / 157.3e12 + 3.0 * hf / 2516.6e12) * 1e6      # MFMA issue time at the spec clock (bench.py's accounting)
+    print(f"n={n:5d}: unet forward {us:8.1f} us  algorithmic {fl / us / 1e6:6.1f} TF  fp32-equivalent GEMM {mf / us / 1e6:6.1f} TF  "
+          f"matrix pipe busy {busy_us / us:.3f}  [{os.environ.get('MMD_AMD_LIB', 'default lib')}]", flush=True)
