@@ -41,11 +41,14 @@ enum { RES_NONE = 0, RES_IDENT = 1, RES_CONV = 2 };
 // final Conv1dBlock(32->32, k5) + Conv1d(32->4, k1) of the network
 struct FinalArgs {
   float* out;             // eps [n, 64, 4]
-  const float4* wpk;      // Winograd pack of the k5 conv
+  const uint4* w_bf;      // f16x2 pack of the k5 conv (interleaved column pairs)
+  const float* isc;       // [32] inverse channel scales of w_bf
   const float* bias;      // [32]
   const float* gamma;     // [32] GroupNorm weight
   const float* beta;      // [32] GroupNorm bias
-  const float4* w1_pk;    // packed 1x1 conv (B fragments, N padded to 32)
+  float act;              // static power-of-two scale of the block's output activations = the 1x1 conv's f16x2 input
+  const uint4* w1_bf;     // f16x2 pack of the 1x1 conv (one n-tile, columns >= 4 zero)
+  const float* is1;       // [4] inverse channel scales of w1_bf / act
   const float* w1_bias;   // [4]
 };
 
@@ -1866,10 +1869,11 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 // ups.0 in the direct form: cat(mid output, skip2) -> RTB (256 -> 64, with its 1x1 residual conv) -> RTB (64 -> 64) ->
 // Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, all f16x2 on Rd slabs.  Wave w owns the n-tile of
 // channels 16 w + (lane & 15) x all four samples.  x0 / x1: the two 128-channel chunks of the input (downs.2's tiles, in
-// ITS layout: store2(tile) writes one into the 128-channel slab); CFN: the next stage (its row-form fp32 x slab geometry).
-template <class CF, class CFN, class STORE2>
+// ITS layout: store2(tile) writes one into the 128-channel slab); xe / xo: the stage's output (even / odd positions).
+template <class CF, class STORE2>
 __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&x0)[4][2],
-                                               f32x4 (&x1)[4][2], STORE2 store2, char* slab128, int trb) {
+                                               f32x4 (&x1)[4][2], STORE2 store2, char* slab128, f32x4 (&xe)[4][1],
+                                               f32x4 (&xo)[4][1], int trb) {
   static_assert(CF::L == 16 && CF::CM == 64 && CF::C0 == 128 && CF::C1 == 128 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_UP &&
                     CF::N_IDENT == 1, "ups.0");
   using G128 = RdGeo<128>;
@@ -1983,21 +1987,274 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     rd_store1<G64>(vs64, acc, lane);
     __syncthreads();
     TR(trb + 7);
-    f32x4 e[4][1], o[4][1];
-    rd_taps<G64, 1, 1, 2, true, false>(e, res, va64, wt0, wt0, ring);
+    rd_taps<G64, 1, 1, 2, true, false>(xe, res, va64, wt0, wt0, ring);
     rd_ring_load<G64, 1>(ring, wt1);
-    rd_taps<G64, 1, 2, 2, true, false>(o, res, va64, wt1, wt1, ring);
+    rd_taps<G64, 1, 2, 2, true, false>(xo, res, va64, wt1, wt1, ring);
     const float bt = a.bt[col], is0 = a.ist0[col], is1 = a.ist1[col];
-    __syncthreads();                                         // the tail is done reading the slab the next stage's x slab aliases
-    // -> the next stage's row-form x slab [sample][2 + position][CFN::XSTR], positions 2 m + parity, m = 4 g + r
-    float* xb = lds + (2 + 8 * g) * CFN::XSTR + col;
+    // the stage's output stays in registers: xe / xo[sample][0][r] = positions 2 m, 2 m + 1 (m = 4 g + r) of channel col; the
+    // per-sample maxima of the wave's 16 channels go to slot `wave` of mx region 0 (the caller's barrier publishes them)
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm) {
+      float m = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xe[sm][0][r] = fmaf(xe[sm][0][r], is0 * inv[sm], bt);
+        xo[sm][0][r] = fmaf(xo[sm][0][r], is1 * inv[sm], bt);
+        m = fmaxf(m, fmaxf(fabsf(xe[sm][0][r]), fabsf(xo[sm][0][r])));
+      }
+      m = row_max16(m);
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (lane == 0) mx[sm * MX_SLOTS + wave] = m;
+    }
+  }
+}
+
+// ups.1 (cat(x, skip1): 128 -> 32 -> 32 channels at L = 32, Upsample1d) + the final block (Conv1dBlock 32 -> 32 at L = 64, 1x1
+// conv 32 -> 4), wave = sample, all convs direct f16x2 (layers.py:346-358, temporal_unet.py:104-110, 166-172).  Only the
+// first conv needs the other waves: its input arrives distributed by CHANNEL (ups.0's output xe / xo and the skip tensor kept
+// from downs.1: wave w holds channels 16 w + (lane & 15) of all four samples), so the two 64-channel chunks are written into
+// the four samples' slabs across waves, one after the other through the same 10 KB slab (4 workgroup barriers); everything
+// after it -- 3 convs, the transposed tail as two parity passes, the final block and the output store -- reads only what the
+// same wave wrote (wave_lds_fence).  Slabs: RwGeo<64, 32> (conv A chunks), RwGeo<32, 32>, RwGeo<32, 64> (final block).
+template <class CF>
+__device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, float* lds, int n0, int lane, int wave,
+                                               const f32x4 (&xe)[4][1], const f32x4 (&xo)[4][1], const f32x4 (&skip)[2][4],
+                                               int trb) {
+  static_assert(CF::L == 32 && CF::CM == 32 && CF::C0 == 64 && CF::C1 == 64 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
+                    CF::TAIL == TAIL_UP, "ups.1");
+  using GA = RwGeo<64, 32>;
+  using GB = RwGeo<32, 32>;
+  using GF = RwGeo<32, 64>;
+  constexpr int W_BYTES = cmax(GA::BYTES, cmax(GB::BYTES, GF::BYTES)) + 128;
+  static_assert(4 * W_BYTES <= MX_OFF * 4, "four private slabs");
+  char* const lb = reinterpret_cast<char*>(lds);
+  char* const slab = lb + wave * W_BYTES;
+  float* const mx = lds + MX_OFF;
+  const int n = lane & 15, g = lane >> 4, c0 = 2 * n;
+  const bool odd = n & 1;
+  auto wptr = [&](const uint4* w, int frags, int t) { return reinterpret_cast<const u32x4*>(w) + (size_t)t * frags * 64 + lane; };
+  auto swap1 = [](float v) {                                  // the value of the partner lane (n ^ 1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  };
+  const u32x4* wp0[2] = {wptr(a.r0.wa_bf, GA::FRAGS5, 0), wptr(a.r0.wa_bf, GA::FRAGS5, 1)};
+  const u32x4* wp1[2] = {wptr(a.wa0_c1_bf, GA::FRAGS5, 0), wptr(a.wa0_c1_bf, GA::FRAGS5, 1)};
+  const u32x4* wr0[2] = {wptr(a.wres_bf, 2 * GA::KC, 0), wptr(a.wres_bf, 2 * GA::KC, 1)};
+  const u32x4* wr1[2] = {wptr(a.wres_c1_bf, 2 * GA::KC, 0), wptr(a.wres_c1_bf, 2 * GA::KC, 1)};
+  u32x4 ring[RD_RD][2][2];
+  rd_ring_load<GA, 2>(ring, wp0);
+  // ---- the skip tensor's per-sample maxima (skip[mt][o][r]: sample 2 mt + (g >> 1), position 16 (g & 1) + 4 r + o) -> slots
+  //      4 + wave of mx region 0; ups.0 left its output's maxima in slots 0 .. 3
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    float m = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(skip[mt][o][r]));
+    m = row_max16(m);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    if ((lane & 31) == 0) mx[(2 * mt + (lane >> 5)) * MX_SLOTS + 4 + wave] = m;
+  }
+  __syncthreads();                                           // ups.0 is done with its slabs; the maxima are in mx
+  TR(trb + 0);
+  float sc[4];
+#pragma unroll
+  for (int sm = 0; sm < 4; ++sm) sc[sm] = dyn_scale(mx_read(mx, sm)).s;
+  const float inv_in = dyn_scale(mx_read(mx, wave)).inv;
+  // channel col = 16 wave + n of a 64-channel chunk: block 2 wave + (n >> 3) = (lane group wave, chunk n >> 3), the pair (n & ~1,
+  // n | 1) one dword; the lanes of a pair swap halves so that each stores whole dwords
+  char* const cdst = lb + wave * GA::G + (n >> 3) * GA::BX + ((n & 7) >> 1) * 4 + 2 * 16;
+  {
+    // zero halo rows 0, 1, 34, 35 of the own slab's 8 blocks x 2 pieces
+    const int hr = lane & 3;
+    *reinterpret_cast<uint4*>(slab + (lane >> 5) * GA::PS + ((lane >> 3) & 3) * GA::G + ((lane >> 2) & 1) * GA::BX +
+                              (hr < 2 ? hr : 32 + hr) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // chunk 0 = ups.0's output: the even lane stores the even positions 2 (4 g + r) of channels (col, col + 1), the odd lane
+    // the odd positions of (col - 1, col)
+    char* const d0 = cdst + (8 * g + (odd ? 1 : 0)) * 16;
 #pragma unroll
     for (int sm = 0; sm < 4; ++sm)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        xb[sm * CFN::XSS + (2 * r) * CFN::XSTR] = fmaf(e[sm][0][r], is0 * inv[sm], bt);
-        xb[sm * CFN::XSS + (2 * r + 1) * CFN::XSTR] = fmaf(o[sm][0][r], is1 * inv[sm], bt);
+        const float own = (odd ? xo[sm][0][r] : xe[sm][0][r]) * sc[sm];
+        const float recv = swap1((odd ? xe[sm][0][r] : xo[sm][0][r]) * sc[sm]);
+        const F16Pair p = f16_split2(odd ? recv : own, odd ? own : recv);
+        char* d = d0 + sm * W_BYTES + 2 * r * 16;
+        *reinterpret_cast<unsigned*>(d) = p.hi;
+        *reinterpret_cast<unsigned*>(d + GA::PS) = p.lo;
       }
+  }
+  __syncthreads();
+  const char* const vaA = slab + g * GA::G + n * 16;
+  f32x4 acc[2][2], res[2][2];
+  rd_taps<GA, 2, 0, 5, true, true, 2>(acc, res, vaA, wp0, wr0, ring);
+  rd_ring_load<GA, 2>(ring, wp1);
+  __syncthreads();                                           // every wave has consumed chunk 0
+  {
+    // chunk 1 = skip: the even lane stores positions 16 (g & 1) + 4 r + {0, 1}, the odd lane + {2, 3}
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float s = (g >> 1) ? sc[2 * mt + 1] : sc[2 * mt];
+      char* const d1 = cdst + (2 * mt + (g >> 1)) * W_BYTES + (16 * (g & 1) + (odd ? 2 : 0)) * 16;
+#pragma unroll
+      for (int oo = 0; oo < 2; ++oo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float own = (odd ? skip[mt][2 + oo][r] : skip[mt][oo][r]) * s;
+          const float recv = swap1((odd ? skip[mt][oo][r] : skip[mt][2 + oo][r]) * s);
+          const F16Pair p = f16_split2(odd ? recv : own, odd ? own : recv);
+          char* d = d1 + (4 * r + oo) * 16;
+          *reinterpret_cast<unsigned*>(d) = p.hi;
+          *reinterpret_cast<unsigned*>(d + GA::PS) = p.lo;
+        }
+    }
+  }
+  __syncthreads();
+  rd_taps<GA, 2, 0, 5, false, true, 2>(acc, res, vaA, wp1, wr1, ring);
+  // ---- from here on the wave is on its own: 32-channel slab
+  const char* const vaB = slab + g * GB::G + n * 16;
+  char* const vsB = slab + (n >> 2) * GB::G + (2 + 4 * g) * 16 + (n & 3) * 4;
+  u32x4 ring5[5][2][2];
+  auto preload = [&](const uint4* w) {
+    const u32x4* wp[2] = {wptr(w, GB::FRAGS5, 0), wptr(w, GB::FRAGS5, 1)};
+    rd_ring_load<GB, 2, 5>(ring5, wp);
+  };
+  preload(a.r0.wb_bf);
+  const float one = 1.f;
+  auto gn = [&](const float* bs, const float* gm, const float* be, const float* tb, const float* isc, float inv, float act_s) {
+    const float bb[2] = {bs[c0], bs[c0 + 1]}, gg[2] = {gm[c0], gm[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
+    const float is[2] = {isc[c0], isc[c0 + 1]};
+    if (tb) {
+      const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
+      rw_gn_mish<2, 2, 2, 128, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
+    } else {
+      rw_gn_mish<2, 2, 2, 128, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
+    }
+  };
+  auto conv = [&](const uint4* w) {                          // one 32 -> 32 conv over the tile in acc (already scaled)
+    const u32x4* wp[2] = {wptr(w, GB::FRAGS5, 0), wptr(w, GB::FRAGS5, 1)};
+    rw_store2<GB, 2>(vsB, acc);
+    wave_lds_fence();
+    rd_taps<GB, 2, 0, 5, true, false, 2, 5>(acc, res, vaB, wp, wp, ring5);
+    wave_lds_fence();                                        // (the next store must not overtake these reads)
+  };
+  {
+    const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[mt][t] = res[mt][t] * (isr[t] * inv_in) + br[t];
+  }
+  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+  TR(trb + 1);
+  wave_lds_fence();                                          // conv A's reads are done: the slab changes its geometry
+  if (lane < 32) *reinterpret_cast<uint4*>(slab + (lane >> 4) * GB::PS + ((lane >> 2) & 3) * GB::G + ((lane & 3) < 2 ? (lane & 3) : 32 + (lane & 3)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  conv(a.r0.wb_bf);
+  preload(a.ri[0].wa_bf);
+  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one, 1.f);
+  TR(trb + 2);
+  // ---- identity RTB
+  {
+    const RtbPtrs& R = a.ri[0];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[mt][t] = acc[mt][t];
+    const DynScale ds = dyn_scale(rw_absmax<2, 2>(acc));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
+    conv(R.wa_bf);
+    preload(R.wb_bf);
+    gn(R.ba, R.ga, R.bea, R.tb, R.isa, ds.inv, R.act_a);
+    TR(trb + 3);
+    conv(R.wb_bf);
+    gn(R.bb, R.gb, R.beb, nullptr, R.isb, one, 1.f);
+    TR(trb + 4);
+  }
+  // ---- tail: Upsample1d = ConvTranspose1d(k4, s2, p1): out[2 m] = in[m - 1] W3 + in[m] W1, out[2 m + 1] = in[m] W2 + in[m + 1] W0
+  //      -> the final block's input (L = 64) in the 64-row slab
+  const char* const vaF = slab + g * GF::G + n * 16;
+  char* const vsF = slab + (n >> 2) * GF::G + (n & 3) * 4;
+  f32x4 y[4][2];
+  float inv_f;
+  {
+    const DynScale ds = dyn_scale(rw_absmax<2, 2>(acc));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
+    const u32x4* wt0[2] = {wptr(a.wt_bf0, 2 * GB::KC * 2, 0), wptr(a.wt_bf0, 2 * GB::KC * 2, 1)};
+    const u32x4* wt1[2] = {wptr(a.wt_bf1, 2 * GB::KC * 2, 0), wptr(a.wt_bf1, 2 * GB::KC * 2, 1)};
+    u32x4 ring2[2][2][2];
+    rd_ring_load<GB, 2, 2>(ring2, wt0);
+    rw_store2<GB, 2>(vsB, acc);
+    wave_lds_fence();
+    f32x4 e[2][2], o[2][2];
+    rd_taps<GB, 2, 1, 2, true, false, 2, 2>(e, res, vaB, wt0, wt0, ring2);
+    rd_ring_load<GB, 2, 2>(ring2, wt1);
+    rd_taps<GB, 2, 2, 2, true, false, 2, 2>(o, res, vaB, wt1, wt1, ring2);
+    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]};
+    const float is0[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv}, is1[2] = {a.ist1[c0] * ds.inv, a.ist1[c0 + 1] * ds.inv};
+    float m = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e[mt][t][r] = fmaf(e[mt][t][r], is0[t], bt[t]);
+          o[mt][t][r] = fmaf(o[mt][t][r], is1[t], bt[t]);
+          m = fmaxf(m, fmaxf(fabsf(e[mt][t][r]), fabsf(o[mt][t][r])));
+        }
+    m = row_max16(m);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const DynScale df = dyn_scale(m);
+    inv_f = df.inv;
+    wave_lds_fence();                                        // the tail's reads are done: 64-row geometry
+    if (lane < 32) *reinterpret_cast<uint4*>(slab + (lane >> 4) * GF::PS + ((lane >> 2) & 3) * GF::G + ((lane & 3) < 2 ? (lane & 3) : 64 + (lane & 3)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // positions 2 m + parity, m = 16 mt + 4 g + r: rows 2 + 32 mt + 8 g + 2 r + parity
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const F16Pair pe = f16_split2(e[mt][0][r] * df.s, e[mt][1][r] * df.s), po = f16_split2(o[mt][0][r] * df.s, o[mt][1][r] * df.s);
+        char* d = vsF + (2 + 32 * mt + 8 * g + 2 * r) * 16;
+        *reinterpret_cast<unsigned*>(d) = pe.hi;
+        *reinterpret_cast<unsigned*>(d + GF::PS) = pe.lo;
+        *reinterpret_cast<unsigned*>(d + 16) = po.hi;
+        *reinterpret_cast<unsigned*>(d + 16 + GF::PS) = po.lo;
+      }
+  }
+  TR(trb + 5);
+  // ---- final block: Conv1dBlock(32 -> 32, k5) + GroupNorm + Mish, then the 1x1 conv 32 -> 4 (N padded to one n-tile)
+  {
+    const u32x4* wf[2] = {wptr(f.w_bf, GF::FRAGS5, 0), wptr(f.w_bf, GF::FRAGS5, 1)};
+    rd_ring_load<GF, 2, 5>(ring5, wf);
+    const u32x4* w1[1] = {reinterpret_cast<const u32x4*>(f.w1_bf) + lane};
+    u32x4 ring1[1][1][2];
+    rd_ring_load<GF, 1, 1>(ring1, w1);
+    wave_lds_fence();
+    rd_taps<GF, 2, 0, 5, true, false, 4, 5>(y, y, vaF, wf, wf, ring5);
+    const float bb[2] = {f.bias[c0], f.bias[c0 + 1]}, gg[2] = {f.gamma[c0], f.gamma[c0 + 1]}, ee[2] = {f.beta[c0], f.beta[c0 + 1]};
+    const float is[2] = {f.isc[c0], f.isc[c0 + 1]};
+    rw_gn_mish<4, 2, 2, 256, true>(y, bb, gg, ee, is, inv_f, act_scale(f.act), [](int, int, int) { return 0.f; });
+    wave_lds_fence();
+    rw_store2<GF, 4>(vsF + (2 + 4 * g) * 16, y);
+    wave_lds_fence();
+    f32x4 out[4][1];
+    rd_taps<GF, 1, 2, 1, true, false, 4, 1>(out, out, vaF, w1, w1, ring1);
+    if (n < 4 && n0 + wave < a.n) {
+      const float b1 = f.w1_bias[n], s1 = f.is1[n];
+      float* dst = f.out + ((size_t)(n0 + wave) * 64 + 4 * g) * 4 + n;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(16 * mt + r) * 4] = fmaf(out[mt][0][r], s1, b1);
+    }
   }
 }
 
@@ -2039,83 +2296,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 mid_out[4][2];
   chain_body_d2d<CH_D2>(a.c[2], lds, lane, wave, mid_out, skip2, 80);
   TR(130);
-  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64] (chain_body_u0d; the chunks are stored from downs.2's tiles)
+  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64] (chain_body_u0d; the chunks are stored from downs.2's tiles); its output
+  //      stays in registers (even / odd positions of channel 16 wave + (lane & 15))
+  f32x4 xe[4][1], xo[4][1];
   {
     using G128 = RdGeo<128>;
     constexpr int S_OFF = (CH_D2::SPB * CH_D2::XSS * 4 + 255) / 256 * 256;
     char* const slab128 = reinterpret_cast<char*>(lds) + S_OFF;
     char* const vs = slab128 + wave * G128::G + ((lane & 15) >> 2) * G128::BX + (2 + 4 * (lane >> 4)) * 16 + (lane & 3) * 4;
-    chain_body_u0d<CH_U0, CH_U1>(a.c[3], lds, lane, wave, mid_out, skip2,
-                                 [&](const f32x4 (&t)[4][2]) { rd_store2<G128>(vs, t); }, slab128, 136);
-    zero_halo<CH_U1::C0P, CH_U1::L, CH_U1::SROWS, CH_U1::XSTR, CH_U1::XSS, 4>(lds);
+    chain_body_u0d<CH_U0>(a.c[3], lds, lane, wave, mid_out, skip2, [&](const f32x4 (&t)[4][2]) { rd_store2<G128>(vs, t); },
+                          slab128, xe, xo, 136);
   }
   TR(131);
-  // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32]
-  {
-    f32x16 t[2][1];
-    chain_body_w4u<CH_U1>(a.c[4], lds, lane, wave,
-                             [&](float* xs) {
-#pragma unroll
-                               for (int mt = 0; mt < 2; ++mt)
-                                 quad1_to_stage_u<CH_D1::L, CH_D1::CM, CH_U1::XSS, CH_U1::XSTR>(skip1[mt], xs, mt, wave, lane);
-                             },
-                             t, 146);
-    __syncthreads();
-    tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[0], lds, wave, lane, 0);
-    tile_to_stage<32, 1, CH_U1::SW, CH_U1::WN, 2, FIN_SS, FIN_STR>(t[1], lds, wave, lane, 1);
-    zero_halo<32, 64, FIN_SROWS, FIN_STR, FIN_SS, 4>(lds);
-    __syncthreads();
-  }
-  TR(132);
-  // ---- final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]
-  {
-    const FinalArgs& f = a.fin;
-    const int col = lane & 31, hi = lane >> 5;
-    f32x4 q[8];
-    {
-      // wave = sample: one 16-quad M tile x both n-tiles of the 32 channels
-      f32x4 m[16];
-      f32x4 nores[8];
-      BQ<4> ring[W4_RD];
-      const float* w0 = reinterpret_cast<const float*>(f.wpk) + lane * 16;
-      w4_ring_load<4>(ring, w0);
-      w4_taps<32, FIN_STR, 2, false, true>(m, nores, lds, wave * FIN_SS + 4 * (lane & 15) * FIN_STR + (lane >> 4), w0, ring);
-      w4_out(q, m);
-    }
-    {
-      const int c0 = lane & 15, c1 = c0 + 16;
-      const float bb[2] = {f.bias[c0], f.bias[c1]}, gg[2] = {f.gamma[c0], f.gamma[c1]}, ee[2] = {f.beta[c0], f.beta[c1]};
-      gn_mish_quad<32, 64>(q, bb, gg, ee, [](int, int) { return 0.f; });
-    }
-    // wave = sample: the y tile goes over the wave's OWN slab region (stride FIN_SS), so no other wave is affected
-    slab_sync<true>();
-    float* yt = lds + wave * FIN_SS;
-    {
-      float* base = yt + 16 * (lane >> 4) * 33 + (lane & 15);             // rows 16 * block + 4 * quad + o
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) base[(4 * r + o) * 33 + nt * 16] = q[o * 2 + nt][r];
-    }
-    slab_sync<true>();
-    f32x16 acc2[2];
-    int ybase[2];
-    fill<2>(acc2, col < 4 ? f.w1_bias[col] : 0.f);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) ybase[mt] = (mt * 32 + (lane & 31)) * 33 + hi;
-    mfma_taps<1, 32, 33, 2>(acc2, yt, ybase, f.w1_pk + lane);
-    if (col < 4 && n0 + wave < a.n) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          f.out[((size_t)(n0 + wave) * 64 + row) * 4 + col] = acc2[mt][r];
-        }
-    }
-  }
+  // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32], final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]:
+  //      wave = sample (chain_body_u1w)
+  chain_body_u1w<CH_U1>(a.c[4], a.fin, lds, n0, lane, wave, xe, xo, skip1, 146);
   TR(133);
 }
 
@@ -2531,9 +2726,10 @@ struct mmd_unet_s {
   int tb_total = 0;
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
   ConvW down[2], up[2], fin;
-  size_t up_bf[2] = {0, 0}, up_is[2] = {0, 0};   // ups.0's tail: f16x2 parity packs and their inverse scales
+  size_t up_bf[2][2] = {}, up_is[2][2] = {};     // the up stages' tails: f16x2 parity packs and their inverse scales
   size_t down_bf = 0, down_is = 0;               // downs.0's tail: f16x2 pack and its inverse scales
-  size_t fin_w1, fin_b1;
+  size_t fin_w1 = 0, fin_b1 = 0, fin_is1 = 0;    // final 1x1 conv: f16x2 pack (N padded to 16), bias, inverse scales / fin_act
+  float fin_act = 1.f;                           // static scale of the final block's activations
 };
 
 // caller-owned event-pair pool (include/mmd_amd_debug.h); the unet handle itself is immutable after creation
@@ -2609,11 +2805,12 @@ static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb
     a.wt_bf0 = reinterpret_cast<const uint4*>(u->blob + u->down_bf);
     a.ist0 = u->blob + u->down_is;
   }
-  if (tail == &u->up[0]) {
-    a.wt_bf0 = reinterpret_cast<const uint4*>(u->blob + u->up_bf[0]);
-    a.wt_bf1 = reinterpret_cast<const uint4*>(u->blob + u->up_bf[1]);
-    a.ist0 = u->blob + u->up_is[0];
-    a.ist1 = u->blob + u->up_is[1];
+  if (tail == &u->up[0] || tail == &u->up[1]) {
+    const int i = tail == &u->up[1];
+    a.wt_bf0 = reinterpret_cast<const uint4*>(u->blob + u->up_bf[i][0]);
+    a.wt_bf1 = reinterpret_cast<const uint4*>(u->blob + u->up_bf[i][1]);
+    a.ist0 = u->blob + u->up_is[i][0];
+    a.ist1 = u->blob + u->up_is[i][1];
   }
   return a;
 }
@@ -2670,12 +2867,12 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.act_a = 1.f;
     while (blob.size() % 4) blob.push_back(0.f);
     const bool d1 = r <= 3, d2 = r == 4 || r == 5 || r == 10 || r == 11;   // d1: downs.0 / downs.1 (chain_body_db)
-    const int NT = (r >= 6 && r <= 9) || d1 || d2 ? 1 : 2;   // n-tiles per weight slice
-    const int cinp = (R.cin + 7) / 8 * 8;            // the 4-channel network input is padded to 2 k-steps (the ring depth)
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
     const std::vector<int> k5 = {0, 1, 2, 3, 4};
     const bool u0 = r == 6 || r == 7;                  // ups.0 (chain_body_u0d)
     const bool d0 = r == 0 || r == 1;                  // downs.0 (chain_body_d0w): interleaved column pairs like downs.2
+    const bool u1 = r == 8 || r == 9;                  // ups.1 (chain_body_u1w): wave-private, interleaved column pairs
+    const bool pairs = d2 || d0 || u1;
     if (r == 0) {             // downs.0's first conv (4 -> 32): one im2col chunk + the 1x1 residual conv's chunk
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
       const std::vector<float> scr = rd_col_scales(wres, R.cout, R.cin, 1, std::vector<int>{0}, false);
@@ -2683,53 +2880,44 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       W.res_isc = push_inverse(blob, scr);
       W.a.wbf = pack_im2col4(blob, tensors[R.t_w0], R.cout, false, sc);
       W.res_bf = pack_im2col4(blob, wres, R.cout, true, scr);
-    } else if (r == 6 || r == 4) {   // ups.0 / downs.2 conv A of the first RTB: direct f16x2 (rd_taps), the 1x1 residual conv on the
-                              // centre tap; ups.0's input is the two 128-channel chunks of cat(x, skip2)
+    } else if (r == 6 || r == 4 || r == 8) {   // ups.0 / downs.2 / ups.1 conv A of the first RTB: direct f16x2 (rd_taps), the 1x1
+                              // residual conv on the centre tap; the up stages' input is the two chunks of cat(x, skip)
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
       const std::vector<float> scr = rd_col_scales(wres, R.cout, R.cin, 1, std::vector<int>{0}, false);
-      const int chunk = r == 6 ? R.cin / 2 : R.cin;
+      const int chunk = r == 4 ? R.cin : R.cin / 2;
       W.a.isc = push_inverse(blob, sc);
       W.res_isc = push_inverse(blob, scr);
-      W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, chunk, 5, k5, false, /*pair_cols=*/d2, sc);
-      W.res_bf = pack_rd_res(blob, wres, R.cout, R.cin, 0, chunk, d2, scr);
-      if (r == 6) {
-        W.a_c1_bf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, chunk, chunk, 5, k5, false, false, sc);
-        W.res_c1_bf = pack_rd_res(blob, wres, R.cout, R.cin, chunk, chunk, false, scr);
+      W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, chunk, 5, k5, false, pairs, sc);
+      W.res_bf = pack_rd_res(blob, wres, R.cout, R.cin, 0, chunk, pairs, scr);
+      if (r != 4) {
+        W.a_c1_bf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, chunk, chunk, 5, k5, false, pairs, sc);
+        W.res_c1_bf = pack_rd_res(blob, wres, R.cout, R.cin, chunk, chunk, pairs, scr);
       }
-    } else if (r == 8) {      // ups.1: input = cat(x, skip1), staged chunk by chunk: one pack per chunk
-      const int half = R.cin / 2;
-      W.a.wpk = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, half, half, NT, wres);
-      W.a_c1 = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, half, R.cin, half, NT, wres);
     } else if (r == 2) {      // downs.1's first RTB: conv A (32 -> 64) and the 1x1 residual conv as f16x2 (rowform_to_vslab)
       W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f, /*plain_blocks=*/true);
       W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc, /*pair_cols=*/false);
-    } else if ((d2 || u0 || d0) && R.cin == R.cout) {   // conv A of an identity RTB of the direct stages: dynamic input scale
+    } else if ((d2 || u0 || d0 || u1) && R.cin == R.cout) {   // conv A of an identity RTB of the direct stages: dynamic input scale
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
       W.a.isc = push_inverse(blob, sc);
-      W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, 5, k5, false, d2 || d0, sc);
+      W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, 5, k5, false, pairs, sc);
     } else if (d1 && R.cin == R.cout) {
       W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);   // dynamic input scale
     } else {
-      W.a.wpk = blob.size();
-      pack_w4(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, cinp, NT, wres);
+      set_error("mmd_unet_create: no pack for RTB %d", r);
+      delete u;
+      return 1;
     }
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
-    if (d2 || u0 || d0) {     // conv B: direct f16x2, its input scaled by the static act_a
+    if (d2 || u0 || d0 || u1) {   // conv B: direct f16x2, its input scaled by the static act_a
       W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w1], R.cout, R.cout, 5, k5, false);
       W.b.isc = push_inverse(blob, sc, W.act_a);
-      W.b.wbf = pack_rd(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, 5, k5, false, d2 || d0, sc);
-    } else if (d1) {
+      W.b.wbf = pack_rd(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, 5, k5, false, pairs, sc);
+    } else {
       W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
       W.b.wbf = pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc, W.act_a);
-    } else {
-      while (blob.size() % 4) blob.push_back(0.f);
-      W.b.wpk = blob.size();
-      pack_w4(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, R.cout, NT, nullptr);
     }
     W.b.bias = push(blob, tensors[R.t_b1], R.cout);
     W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
@@ -2753,27 +2941,35 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       u->down_bf = pack_rd(blob, tensors[s.t_down[i][0]], c, c, 0, c, 3, k3, false, true, sct);
     }
     const int cu = dims[2 - i];
-    // ConvTranspose1d(k=4, s=2, p=1): out[2m] = in[m-1] W3 + in[m] W1 ; out[2m+1] = in[m] W2 + in[m+1] W0
-    u->up[i].wpk = blob.size();
-    pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{3, 1}, true);
-    pack_b(blob, tensors[s.t_up[i][0]], cu, cu, 4, std::vector<int>{2, 0}, true);
+    // ConvTranspose1d(k=4, s=2, p=1): out[2m] = in[m-1] W3 + in[m] W1 ; out[2m+1] = in[m] W2 + in[m+1] W0, as two direct f16x2
+    // parity passes (chain_body_u0d; chain_body_u1w: interleaved column pairs)
     u->up[i].bias = push(blob, tensors[s.t_up[i][1]], cu);
-    if (i == 0) {             // ups.0's tail as two direct f16x2 parity passes (chain_body_u0d)
+    {
       const std::vector<int> ke = {3, 1}, ko = {2, 0};
       const std::vector<float> sce = rd_col_scales(tensors[s.t_up[i][0]], cu, cu, 4, ke, true);
       const std::vector<float> sco = rd_col_scales(tensors[s.t_up[i][0]], cu, cu, 4, ko, true);
-      u->up_is[0] = push_inverse(blob, sce);
-      u->up_is[1] = push_inverse(blob, sco);
-      u->up_bf[0] = pack_rd(blob, tensors[s.t_up[i][0]], cu, cu, 0, cu, 4, ke, true, false, sce);
-      u->up_bf[1] = pack_rd(blob, tensors[s.t_up[i][0]], cu, cu, 0, cu, 4, ko, true, false, sco);
+      u->up_is[i][0] = push_inverse(blob, sce);
+      u->up_is[i][1] = push_inverse(blob, sco);
+      u->up_bf[i][0] = pack_rd(blob, tensors[s.t_up[i][0]], cu, cu, 0, cu, 4, ke, true, i == 1, sce);
+      u->up_bf[i][1] = pack_rd(blob, tensors[s.t_up[i][0]], cu, cu, 0, cu, 4, ko, true, i == 1, sco);
     }
   }
-  u->fin.wpk = blob.size(); pack_w4(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 32, 2, nullptr);
-  u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
-  u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
-  u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
-  u->fin_w1 = blob.size(); pack_b(blob, tensors[s.t_final[4]], 4, 32, 1, taps1, false);
-  u->fin_b1 = push(blob, tensors[s.t_final[5]], 4);
+  {                           // final block (chain_body_u1w): k5 conv with a dynamic input scale, 1x1 conv behind a static one
+    const std::vector<float> sc = rd_col_scales(tensors[s.t_final[0]], 32, 32, 5, taps5, false);
+    u->fin.isc = push_inverse(blob, sc);
+    u->fin.wbf = pack_rd(blob, tensors[s.t_final[0]], 32, 32, 0, 32, 5, taps5, false, true, sc);
+    u->fin.bias = push(blob, tensors[s.t_final[1]], 32);
+    u->fin.gamma = push(blob, tensors[s.t_final[2]], 32);
+    u->fin.beta = push(blob, tensors[s.t_final[3]], 32);
+    u->fin_act = static_act_scale(tensors[s.t_final[2]], tensors[s.t_final[3]], std::vector<float>(32, 0.f), 32);
+    std::vector<float> sc1 = rd_col_scales(tensors[s.t_final[4]], 4, 32, 1, taps1, false);
+    u->fin_is1 = push_inverse(blob, sc1, u->fin_act);
+    std::vector<float> w1(16 * 32, 0.f);      // N padded to one n-tile
+    memcpy(w1.data(), tensors[s.t_final[4]], sizeof(float) * 4 * 32);
+    sc1.resize(16, 1.f);
+    u->fin_w1 = pack_rd(blob, w1.data(), 16, 32, 0, 32, 1, taps1, false, false, sc1);
+    u->fin_b1 = push(blob, tensors[s.t_final[5]], 4);
+  }
 
   if (hipMalloc(&u->blob, blob.size() * sizeof(float)) != hipSuccess ||
       hipMalloc(&u->ttable, (size_t)u->T * u->tb_total * sizeof(float)) != hipSuccess) {
@@ -2823,9 +3019,9 @@ static const double kUnetFlops =
     rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64;
 
-// fp32 GEMM FLOPs the matrix pipe executes per trajectory, by form.  Winograd F(4,5) convs (downs.1, ups.1, final block): 8
-// products per 4 outputs; direct convs (downs.0, downs.2 + mid, ups.0): every tap (downs.0's stride-2 tail at all 64
-// positions, its 4-channel first conv padded to one K = 32 chunk, + one for the residual conv).
+// fp32 GEMM FLOPs the matrix pipe executes per trajectory, by form.  Winograd F(4,5) convs (downs.1): 8 products per 4
+// outputs; direct convs (everything else): every tap (downs.0's stride-2 tail at all 64 positions, its 4-channel first conv
+// padded to one K = 32 chunk, + one for the residual conv; the final 1x1 conv with N padded to 16).
 static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // per sample
 static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
   return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
@@ -2835,11 +3031,10 @@ static const double kF16Flops =
     2 * (2.0 * 32 * 32 * 64) + 3 * d5(32, 32, 64) + 2.0 * 32 * 3 * 32 * 64 +                          // downs.0
     2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) +               // downs.1 (but its tail)
     d5(64, 128, 16) + 2.0 * 128 * 64 * 16 + 7 * d5(128, 128, 16) +                                    // downs.2 + mid
-    d5(256, 64, 16) + 2.0 * 64 * 256 * 16 + 3 * d5(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16;              // ups.0
-static const double kFp32Flops =
-    direct_flops(3, 64, 64, 16) +                                                                      // downs.1's tail
-    2 * (wino4_flops(128, 32) + 3 * wino4_flops(32, 32)) + direct_flops(1, 128, 32, 32) + 2 * direct_flops(2, 32, 32, 32) +
-    4 * wino4_flops(32, 32) + direct_flops(1, 32, 32, 64);                                             // ups.1, final block
+    d5(256, 64, 16) + 2.0 * 64 * 256 * 16 + 3 * d5(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16 +             // ups.0
+    d5(128, 32, 32) + 2.0 * 32 * 128 * 32 + 3 * d5(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +             // ups.1
+    d5(32, 32, 64) + 2.0 * 16 * 32 * 64;                                                              // final block
+static const double kFp32Flops = direct_flops(3, 64, 64, 16);                                         // downs.1's tail
 static const double kUnetMfmaFlops = kF16Flops + kFp32Flops;
 
 
@@ -2860,9 +3055,12 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.c[3] = args_chain(u, set, kU0, 1, &u->up[0], nullptr, t, n);
   a.c[4] = args_chain(u, set, kU1, 1, &u->up[1], nullptr, t, n);
   a.fin.out = eps;
-  a.fin.wpk = reinterpret_cast<const float4*>(u->blob + u->fin.wpk);
+  a.fin.w_bf = reinterpret_cast<const uint4*>(u->blob + u->fin.wbf);
+  a.fin.isc = u->blob + u->fin.isc;
   a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
-  a.fin.w1_pk = reinterpret_cast<const float4*>(u->blob + u->fin_w1);
+  a.fin.act = u->fin_act;
+  a.fin.w1_bf = reinterpret_cast<const uint4*>(u->blob + u->fin_w1);
+  a.fin.is1 = u->blob + u->fin_is1;
   a.fin.w1_bias = u->blob + u->fin_b1;
   const bool bracket = prof_begin(prof, 0, MMD_PROF_UNET, st);
   hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);

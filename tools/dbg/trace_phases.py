@@ -33,10 +33,11 @@ names = {}
 for base, nm in ((0, "D0"), (40, "D1")):
     for j, w in enumerate(("start (x slab staged)", "convA + res + gn (fp32)", "convB + gn (f16x2)", "id convA + gn", "id convB + gn", "tail conv done")):
         names[base + j] = f"{nm} {w}"
-for base, nm in ((136, "U0"), (146, "U1")):
-    for j, w in enumerate(("start", "rtb0 convA+res done", "gn+write+barrier", "rtb0 convB done", "gn+res", "id convA done", "id convB done", "gn+write -> tail")):
-        names[base + j] = f"{nm} {w}"
-names.update({130: "-> U0 start", 131: "-> U1 start", 132: "-> FIN start", 133: "end"})
+for j, w in enumerate(("start", "rtb0 convA+res done", "gn+write+barrier", "rtb0 convB done", "gn+res", "id convA done", "id convB done", "gn+write -> tail")):
+    names[136 + j] = f"U0 {w}"
+for j, w in enumerate(("maxima + barrier", "convA (2 chunks, 4 barriers) + res + gn", "convB + gn", "id convA + gn", "id convB + gn", "tail + final block's input stored")):
+    names[146 + j] = f"U1 {w}"
+names.update({130: "-> U0 start", 131: "-> U1 start", 133: "final block + output store"})
 # direct f16x2 body of downs.2 + mid (tags 90..93 are overwritten by every conv: the values are the LAST conv's, mid_block2 conv B)
 names.update({80: "D2 start", 81: "D2 rtb0 convA+res+gn", 90: "last conv: start (prev gn done)", 91: "  ring + slab store", 92: "  barrier",
               93: "  MFMAs (5 taps x 4 chunks)", 98: "  GN + Mish (+ dyn max)"})
