@@ -514,7 +514,10 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // four private slabs of downs.0 (46080 B) and the final block fit below it (static_asserts in the stage bodies).
 constexpr int MX_OFF = ((CH_D2::SPB * CH_D2::XSS * 4 + 255) / 256 * 256 + 43008) / 4 + 8;
 static_assert(MX_OFF >= CH_D1::LDS_FLOATS && MX_OFF >= CH_U1::LDS_FLOATS && MX_OFF >= 4 * FIN_SS, "stage slabs");
-constexpr int UNET_LDS_FLOATS = MX_OFF + MX_FLOATS;          // + the per-sample maxima of the dynamic input scales
+// + the per-sample maxima of the dynamic input scales + the second part of downs.2's lane-private residual parking area (the
+// first part is the stage's dead x slab: 5 + 3 float4 per thread)
+constexpr int PARK2_OFF = MX_OFF + MX_FLOATS;
+constexpr int UNET_LDS_FLOATS = PARK2_OFF + 3 * 256 * 4;
 
 // Synchronisation between a slab write and the conv that reads it.  WAVE_PRIVATE (the final block: one M tile = one sample
 // per wave): a wave only ever reads what it wrote -- LDS operations of one wave execute in order, and only the compiler
@@ -1267,20 +1270,30 @@ __device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD][NT][2], const u32x4*
 // channels of the slab; va = slab + the lane's A offset (lane group lane >> 4, row lane & 15); w[tile] = the tile's pack +
 // lane; b = ring pre-loaded with the first RD_RD steps.  RES: the stage's 1x1 residual conv rides on the centre tap's A
 // fragments (res[sample][tile] (+)=, weights wr[tile] = [chunk kc][piece] + lane).  FRESH: start from zero.
-template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES, int MT = 4, int RD = RD_RD>
+template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES, int MT = 4, int RD = RD_RD, bool FULL = false>
 __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][NT], const char* va, const u32x4* const (&w)[NT],
                                         const u32x4* const (&wr)[NT], u32x4 (&b)[RD][NT][2]) {
   constexpr int KC = GEO::KC, STEPS = TAPS * KC, HP = MT / 2;
-  static_assert(KC % RD == 0 || KC == 1, "the ring index must be static inside a tap");
+  static_assert(KC % RD == 0 || KC == 1 || FULL, "the ring index must be static inside a tap");
   static_assert(MT % 2 == 0, "M tiles are processed in pairs");
   // A fragments are double-buffered by M-tile pair (half a step = 2 M tiles x NT n-tiles x 3 MFMAs): 32 registers
   u32x4 a[2][2][2];
   rd_load_a<GEO>(a[0], va, TAP0, 0, 0);
+  // (FULL: the residual conv's weights are requested up front, not at the centre tap)
+  u32x4 brp[FULL && RES ? KC : 1][NT][2];
+  if constexpr (FULL && RES) {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) brp[kc][t][q] = wr[t][(kc * 2 + q) * 64];
+  }
   // one step = (tap, chunk kc); ri = its static ring slot
   auto step = [&](auto zero, int tap, int kc, int ri, auto last_kc) {
     u32x4 br[NT][2];
     const bool with_res = RES && TAP0 + tap == 2;
-    if constexpr (RES) {
+    if constexpr (RES && !FULL) {
       if (with_res) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -1293,7 +1306,7 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
       // the next half step's A fragments (the next M-tile pair; then the next chunk, or chunk 0 of the next tap; past the
       // last step: a valid, unused read)
       // (buffer parity = the half step's index: static, because a rolled tap has an even number of half steps)
-      const int cur = (kc * HP + hp + (KC == 1 ? tap * HP : 0)) & 1;
+      const int cur = (kc * HP + hp + (KC == 1 || FULL ? tap * KC * HP : 0)) & 1;
       if (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, TAP0 + tap, kc, hp + 1);
       else rd_load_a<GEO>(a[cur ^ 1], va, decltype(last_kc)::value ? TAP0 + tap + 1 : TAP0 + tap, decltype(last_kc)::value ? 0 : kc + 1, 0);
       MMD_PIN_LOADS();
@@ -1312,8 +1325,9 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
           for (int sm = 0; sm < 2; ++sm)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-              if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], br[t]);
-              else vb_three<false>(res[2 * hp + sm][t], ac[sm], br[t]);
+              const u32x4(&bw)[2] = FULL ? brp[FULL ? kc : 0][t] : br[t];
+              if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], bw);
+              else vb_three<false>(res[2 * hp + sm][t], ac[sm], bw);
             }
         }
       }
@@ -1322,8 +1336,24 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
     if (nxt < STEPS) rd_load_b<GEO, NT>(b[ri], w, nxt);
     MMD_PIN_LOADS();
   };
-  static_assert(KC == 1 || (KC * HP) % 2 == 0, "A buffer parity must be static across the rolled tap loop");
-  if constexpr (KC == 1) {
+  static_assert(KC == 1 || FULL || (KC * HP) % 2 == 0, "A buffer parity must be static across the rolled tap loop");
+  if constexpr (FULL && KC > 1) {
+    // every step unrolled: ring slot = step % RD for any depth -- a wave-private conv with several chunks (ups.1's conv A) has
+    // no second workgroup wave to hide the weight fetch behind, so it needs the fetch ~5 steps ahead
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const int st = tap * KC + kc;
+        if (FRESH && st == 0) {
+          if (kc + 1 < KC) step(std::true_type{}, tap, kc, st % RD, std::false_type{});
+          else step(std::true_type{}, tap, kc, st % RD, std::true_type{});
+        } else {
+          if (kc + 1 < KC) step(std::false_type{}, tap, kc, st % RD, std::false_type{});
+          else step(std::false_type{}, tap, kc, st % RD, std::true_type{});
+        }
+      }
+  } else if constexpr (KC == 1) {
     // one chunk per tap: the taps are unrolled (TAPS is small), ring slot tap % RD (RD = TAPS: the whole conv's weights are
     // in flight before the first MFMA -- a wave-private conv is too short to hide a weight fetch behind two steps)
 #pragma unroll
@@ -1756,6 +1786,22 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
 // downs.2 + mid blocks in the direct form.  Wave w owns the n-tiles 2 w, 2 w + 1 with INTERLEAVED columns (column n of tile h =
 // channel 32 w + 2 n + h: adjacent channels per lane, dword slab stores) x all four samples; acc[sample][h][r] = position
 // 4 (lane >> 4) + r.  acc: the stage's output; mid: the skip tensor (after RTB MID_AFTER).
+// Lane-private parking of a 32-register tile in LDS ([i][thread] x 16 B: conflict-free b128, no synchronisation -- a thread
+// reads back only what it wrote): the residual tile of an RTB waits there instead of in 32 VGPRs while the block's two convs
+// run (the kernel sits at the 256-register limit of two waves per SIMD; a compiler spill to scratch costs a vmcnt(0) wait
+// behind every weight load in flight).  Parts 0 .. 4 in the stage's dead x slab, 5 .. 7 behind the maxima.
+__device__ __forceinline__ float* park_slot(float* lds, int i) {
+  return (i < 5 ? lds + i * 1024 : lds + PARK2_OFF + (i - 5) * 1024) + threadIdx.x * 4;
+}
+__device__ __forceinline__ void park_tile(float* lds, const f32x4 (&t)[4][2]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(park_slot(lds, i)) = t[i >> 1][i & 1];
+}
+__device__ __forceinline__ void unpark_tile(float* lds, f32x4 (&t)[4][2]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(park_slot(lds, i));
+}
+
 template <class CF>
 __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[4][2],
                                                f32x4 (&mid)[4][2], int trb) {
@@ -1769,6 +1815,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   // input uses its first bytes in the 64-channel geometry)
   constexpr int S_OFF = (CF::SPB * CF::XSS * 4 + 255) / 256 * 256;
   static_assert(S_OFF + G128::BYTES <= MX_OFF * 4, "x slab + Rd slab must fit below the maxima");
+  static_assert(S_OFF >= 5 * 1024 * 4, "the dead x slab holds 5 of the 8 parked float4 per thread");
   char* const slab = reinterpret_cast<char*>(lds) + S_OFF;
   float* const mx = lds + MX_OFF;
   const char* const va128 = slab + g * G128::G + n * 16;     // A fragment: row lane & 15 = position, lane group lane >> 4
@@ -1782,10 +1829,10 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   __syncthreads();                                           // the x slab (previous stage's tail tile) and its maxima are staged
   TR(trb + 0);
 
-  f32x4 res[4][2];
   const float one4[4] = {1.f, 1.f, 1.f, 1.f};
   // GroupNorm + Mish of acc.  Conv A (tb != nullptr): + the time bias, output carried times act_s (conv B's static f16x2
-  // input scale); conv B: + the residual tile.  isc: the conv's inverse weight scales, inv: inverse dynamic input scales
+  // input scale); conv B: + the residual tile, which comes back from its parking area.  isc: the conv's inverse weight scales,
+  // inv: inverse dynamic input scales
   auto gn = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc, const float (&inv)[4],
                 float act_s) {
     const float bb[2] = {b[c0], b[c0 + 1]}, gg[2] = {gm[c0], gm[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
@@ -1794,6 +1841,8 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
       const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
       rd_gn_mish<2, 256, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
     } else {
+      f32x4 res[4][2];
+      unpark_tile(lds, res);
       rd_gn_mish<2, 256, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int sm, int t, int r) { return res[sm][t][r]; });
     }
   };
@@ -1806,7 +1855,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
     TR(trb + 11);
     __syncthreads();
     TR(trb + 12);
-    rd_taps<G128, 2, 0, 5, true, false>(acc, res, va128, wp, wp, ring);
+    rd_taps<G128, 2, 0, 5, true, false>(acc, acc, va128, wp, wp, ring);
     TR(trb + 13);
   };
 
@@ -1817,13 +1866,15 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   rd_zero_halo<G64>(slab);
   rowform_to_rd<CF::C0P, CF::XSS, CF::XSTR>(lds, slab, mx);
   __syncthreads();
-  rd_taps<G64, 2, 0, 5, true, true>(acc, res, va64, wpa, wpr, ring);
   {
+    f32x4 res[4][2];
+    rd_taps<G64, 2, 0, 5, true, true>(acc, res, va64, wpa, wpr, ring);
     const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
 #pragma unroll
     for (int sm = 0; sm < 4; ++sm)
 #pragma unroll
       for (int t = 0; t < 2; ++t) res[sm][t] = res[sm][t] * (isr[t] * inv_in[sm]) + br[t];
+    park_tile(lds, res);                                     // (every wave is past the barrier behind the x slab's last read)
   }
   gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
   TR(trb + 1);
@@ -1836,10 +1887,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 #pragma unroll 1
   for (int k = 0; k < CF::N_IDENT; ++k) {
     const RtbPtrs& R = a.ri[k];
-#pragma unroll
-    for (int sm = 0; sm < 4; ++sm)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) res[sm][t] = acc[sm][t];
+    park_tile(lds, acc);                                     // the block's input = its residual
     rd_dyn_out<2>(acc, mx, wave, lane, k == CF::MID_AFTER ? 1 : 0);   // (the input of the RTB after MID_AFTER is the skip tensor)
     __syncthreads();                                         // the previous conv is done reading the slab
     float inv[4];
@@ -2041,8 +2089,9 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   const u32x4* wp1[2] = {wptr(a.wa0_c1_bf, GA::FRAGS5, 0), wptr(a.wa0_c1_bf, GA::FRAGS5, 1)};
   const u32x4* wr0[2] = {wptr(a.wres_bf, 2 * GA::KC, 0), wptr(a.wres_bf, 2 * GA::KC, 1)};
   const u32x4* wr1[2] = {wptr(a.wres_c1_bf, 2 * GA::KC, 0), wptr(a.wres_c1_bf, 2 * GA::KC, 1)};
-  u32x4 ring[RD_RD][2][2];
-  rd_ring_load<GA, 2>(ring, wp0);
+  constexpr int RDA = 5;                                      // conv A's weight ring: half a chunk ahead
+  u32x4 ring[RDA][2][2];
+  rd_ring_load<GA, 2, RDA>(ring, wp0);
   // ---- the skip tensor's per-sample maxima (skip[mt][o][r]: sample 2 mt + (g >> 1), position 16 (g & 1) + 4 r + o) -> slots
   //      4 + wave of mx region 0; ups.0 left its output's maxima in slots 0 .. 3
 #pragma unroll
@@ -2085,11 +2134,14 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
         *reinterpret_cast<unsigned*>(d + GA::PS) = p.lo;
       }
   }
+  TR(trb + 6);
   __syncthreads();
+  TR(trb + 7);
   const char* const vaA = slab + g * GA::G + n * 16;
   f32x4 acc[2][2], res[2][2];
-  rd_taps<GA, 2, 0, 5, true, true, 2>(acc, res, vaA, wp0, wr0, ring);
-  rd_ring_load<GA, 2>(ring, wp1);
+  rd_taps<GA, 2, 0, 5, true, true, 2, RDA, true>(acc, res, vaA, wp0, wr0, ring);
+  rd_ring_load<GA, 2, RDA>(ring, wp1);
+  TR(trb + 8);
   __syncthreads();                                           // every wave has consumed chunk 0
   {
     // chunk 1 = skip: the even lane stores positions 16 (g & 1) + 4 r + {0, 1}, the odd lane + {2, 3}
@@ -2110,8 +2162,11 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
         }
     }
   }
+  TR(trb + 9);
   __syncthreads();
-  rd_taps<GA, 2, 0, 5, false, true, 2>(acc, res, vaA, wp1, wr1, ring);
+  TR(trb + 10);
+  rd_taps<GA, 2, 0, 5, false, true, 2, RDA, true>(acc, res, vaA, wp1, wr1, ring);
+  TR(trb + 11);
   // ---- from here on the wave is on its own: 32-channel slab
   const char* const vaB = slab + g * GB::G + n * 16;
   char* const vsB = slab + (n >> 2) * GB::G + (2 + 4 * g) * 16 + (n & 3) * 4;
