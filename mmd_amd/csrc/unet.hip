@@ -577,8 +577,14 @@ __host__ __device__ constexpr int vb_pos(int ph, int slot) { return ph == 0 ? (s
 struct F16Pair { unsigned hi, lo; };
 __device__ __forceinline__ F16Pair f16_split2(float v0, float v1) {
   const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);                  // v_cvt_pk_f16_f32 (round to nearest even)
-  const f16x2 l = __builtin_convertvector(f32x2{v0 - (float)h.x, v1 - (float)h.y}, f16x2);
-  return F16Pair{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  // v - h (exact in fp32) as ONE v_fma_mix_f32 each -- h * (-1) + v with the fp16 half read in place -- instead of a
+  // conversion and a subtraction
+  float d0, d1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hb), "v"(v0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hb), "v"(v1));
+  const f16x2 l = __builtin_convertvector(f32x2{d0, d1}, f16x2);
+  return F16Pair{hb, __builtin_bit_cast(unsigned, l)};
 }
 __device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -1260,6 +1266,12 @@ __device__ __forceinline__ void rd_load_a(u32x4 (&a)[2][2], const char* va, int 
       a[sm][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + ((2 * hp + sm) * GEO::RPS + rowoff) * 16);
 }
 constexpr int RD_RD = 2;                    // weight ring depth in steps
+#ifndef MMD_D2_RD
+#define MMD_D2_RD 2
+#endif
+#ifndef MMD_U0_RD
+#define MMD_U0_RD 2
+#endif
 template <class GEO, int NT, int RD = RD_RD>
 __device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD][NT][2], const u32x4* const (&w)[NT]) {
 #pragma unroll
@@ -1366,11 +1378,11 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
         if (decltype(zero)::value && kc == 0) {
-          if (kc + 1 < KC) step(std::true_type{}, tap, kc, kc % RD_RD, std::false_type{});
-          else step(std::true_type{}, tap, kc, kc % RD_RD, std::true_type{});
+          if (kc + 1 < KC) step(std::true_type{}, tap, kc, kc % RD, std::false_type{});
+          else step(std::true_type{}, tap, kc, kc % RD, std::true_type{});
         } else {
-          if (kc + 1 < KC) step(std::false_type{}, tap, kc, kc % RD_RD, std::false_type{});
-          else step(std::false_type{}, tap, kc, kc % RD_RD, std::true_type{});
+          if (kc + 1 < KC) step(std::false_type{}, tap, kc, kc % RD, std::false_type{});
+          else step(std::false_type{}, tap, kc, kc % RD, std::true_type{});
         }
       }
     };
@@ -1822,10 +1834,11 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   const char* const va64 = slab + g * G64::G + n * 16;
   char* const vs = slab + wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4;
   auto wptr = [&](const uint4* w, int frags, int h) { return reinterpret_cast<const u32x4*>(w) + (size_t)(2 * wave + h) * frags * 64 + lane; };
-  u32x4 ring[RD_RD][2][2];
+  constexpr int RDD = MMD_D2_RD;                               // weight ring depth of the 128 -> 128 convs
+  u32x4 ring[RDD][2][2];
   const u32x4* wpa[2] = {wptr(a.r0.wa_bf, G64::FRAGS5, 0), wptr(a.r0.wa_bf, G64::FRAGS5, 1)};
   const u32x4* wpr[2] = {wptr(a.wres_bf, 2 * G64::KC, 0), wptr(a.wres_bf, 2 * G64::KC, 1)};
-  rd_ring_load<G64, 2>(ring, wpa);
+  rd_ring_load<G64, 2, 2>(reinterpret_cast<u32x4(&)[2][2][2]>(ring), wpa);
   __syncthreads();                                           // the x slab (previous stage's tail tile) and its maxima are staged
   TR(trb + 0);
 
@@ -1850,12 +1863,12 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   auto conv = [&](const uint4* w) {
     const u32x4* wp[2] = {wptr(w, G128::FRAGS5, 0), wptr(w, G128::FRAGS5, 1)};
     TR(trb + 10);
-    rd_ring_load<G128, 2>(ring, wp);
+    rd_ring_load<G128, 2, RDD>(ring, wp);
     rd_store2<G128>(vs, acc);
     TR(trb + 11);
     __syncthreads();
     TR(trb + 12);
-    rd_taps<G128, 2, 0, 5, true, false>(acc, acc, va128, wp, wp, ring);
+    rd_taps<G128, 2, 0, 5, true, false, 4, RDD>(acc, acc, va128, wp, wp, ring);
     TR(trb + 13);
   };
 
@@ -1868,7 +1881,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   __syncthreads();
   {
     f32x4 res[4][2];
-    rd_taps<G64, 2, 0, 5, true, true>(acc, res, va64, wpa, wpr, ring);
+    rd_taps<G64, 2, 0, 5, true, true, 4, 2>(acc, res, va64, wpa, wpr, reinterpret_cast<u32x4(&)[2][2][2]>(ring));
     const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
 #pragma unroll
     for (int sm = 0; sm < 4; ++sm)
@@ -1934,12 +1947,14 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   const char* const va64 = slab64 + g * G64::G + n * 16;
   char* const vs64 = slab64 + wave * G64::G + (n >> 3) * G64::BX + (2 + 4 * g) * 16 + ((n & 7) >> 1) * 4;
   auto wptr = [&](const uint4* w, int frags) { return reinterpret_cast<const u32x4*>(w) + (size_t)wave * frags * 64 + lane; };
+  constexpr int RDU = MMD_U0_RD;                               // weight ring depth of conv A's two 128-channel chunks
+  u32x4 ringa[RDU][1][2];
   u32x4 ring[RD_RD][1][2];
   const u32x4* wp0[1] = {wptr(a.r0.wa_bf, G128::FRAGS5)};
   const u32x4* wp1[1] = {wptr(a.wa0_c1_bf, G128::FRAGS5)};
   const u32x4* wr0[1] = {wptr(a.wres_bf, 2 * G128::KC)};
   const u32x4* wr1[1] = {wptr(a.wres_c1_bf, 2 * G128::KC)};
-  rd_ring_load<G128, 1>(ring, wp0);
+  rd_ring_load<G128, 1, RDU>(ringa, wp0);
   __syncthreads();                                           // the previous stage is done with the slab; its maxima are in mx
   TR(trb + 0);
 
@@ -1988,12 +2003,12 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   }
   store2(x0);
   __syncthreads();
-  rd_taps<G128, 1, 0, 5, true, true>(acc, res, va128, wp0, wr0, ring);
-  rd_ring_load<G128, 1>(ring, wp1);
+  rd_taps<G128, 1, 0, 5, true, true, 4, RDU>(acc, res, va128, wp0, wr0, ringa);
+  rd_ring_load<G128, 1, RDU>(ringa, wp1);
   __syncthreads();                                           // every wave is done reading chunk 0
   store2(x1);
   __syncthreads();
-  rd_taps<G128, 1, 0, 5, false, true>(acc, res, va128, wp1, wr1, ring);
+  rd_taps<G128, 1, 0, 5, false, true, 4, RDU>(acc, res, va128, wp1, wr1, ringa);
   {
     const float br = a.br[col], isr = a.isr[col];
 #pragma unroll
