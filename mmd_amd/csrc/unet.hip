@@ -598,6 +598,11 @@ __device__ __forceinline__ void vb_three(f32x4& x, const u32x4 (&a)[2], const u3
   c = mfma_h(a[0], b[1], c);
   c = mfma_h(a[0], b[0], c);
   x = c;
+#ifndef MMD_VB3_LOOSE
+  // keep the triple together: left alone, the scheduler interleaves the streams of a half step round robin, and with only two
+  // streams (ups.0: one n-tile per wave) every MFMA then waits for the one two before it (30 instead of 17 cycles each)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 // Geometry of a phase slab of C channels at L = 16 (16 rows): C / 8 channel blocks; K chunk kc (of KC = C / 32), lane group j
 // = block kc + KC j at byte j * G + kc * X of a (piece, slot) region of PS bytes -- the blocks of one chunk lie G = a
@@ -1291,28 +1296,20 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
   // A fragments are double-buffered by M-tile pair (half a step = 2 M tiles x NT n-tiles x 3 MFMAs): 32 registers
   u32x4 a[2][2][2];
   rd_load_a<GEO>(a[0], va, TAP0, 0, 0);
-  // (FULL: the residual conv's weights are requested up front, not at the centre tap)
-  u32x4 brp[FULL && RES ? KC : 1][NT][2];
-  if constexpr (FULL && RES) {
+  // (the residual conv's weights are requested RES_LOOK steps before the centre tap's step that uses them: loaded there,
+  // every one of its steps would wait for an L2 round trip; all up front, they would cost 32 registers for two taps)
+  static_assert(!RES || FULL, "the residual conv rides on fully unrolled convs only");
+  constexpr int RES_LOOK = 3;
+  u32x4 brp[RES ? KC : 1][NT][2];
+  auto load_br = [&](int kc) {
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) brp[kc][t][q] = wr[t][(kc * 2 + q) * 64];
-  }
+      for (int q = 0; q < 2; ++q) brp[kc][t][q] = wr[t][(kc * 2 + q) * 64];
+  };
   // one step = (tap, chunk kc); ri = its static ring slot
   auto step = [&](auto zero, int tap, int kc, int ri, auto last_kc) {
-    u32x4 br[NT][2];
     const bool with_res = RES && TAP0 + tap == 2;
-    if constexpr (RES && !FULL) {
-      if (with_res) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) br[t][q] = wr[t][(kc * 2 + q) * 64];
-      }
-    }
 #pragma unroll
     for (int hp = 0; hp < HP; ++hp) {
       // the next half step's A fragments (the next M-tile pair; then the next chunk, or chunk 0 of the next tap; past the
@@ -1337,7 +1334,7 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
           for (int sm = 0; sm < 2; ++sm)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-              const u32x4(&bw)[2] = FULL ? brp[FULL ? kc : 0][t] : br[t];
+              const u32x4(&bw)[2] = brp[RES ? kc : 0][t];
               if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], bw);
               else vb_three<false>(res[2 * hp + sm][t], ac[sm], bw);
             }
@@ -1357,6 +1354,11 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
         const int st = tap * KC + kc;
+        if constexpr (RES) {
+          constexpr int C0 = (2 - TAP0) * KC;                // the centre tap's first step
+          static_assert(C0 >= RES_LOOK, "the centre tap must not be among the first steps");
+          if (st + RES_LOOK >= C0 && st + RES_LOOK < C0 + KC) load_br(st + RES_LOOK - C0);
+        }
         if (FRESH && st == 0) {
           if (kc + 1 < KC) step(std::true_type{}, tap, kc, st % RD, std::false_type{});
           else step(std::true_type{}, tap, kc, st % RD, std::true_type{});
@@ -1881,7 +1883,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   __syncthreads();
   {
     f32x4 res[4][2];
-    rd_taps<G64, 2, 0, 5, true, true, 4, 2>(acc, res, va64, wpa, wpr, reinterpret_cast<u32x4(&)[2][2][2]>(ring));
+    rd_taps<G64, 2, 0, 5, true, true, 4, 2, true>(acc, res, va64, wpa, wpr, reinterpret_cast<u32x4(&)[2][2][2]>(ring));
     const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
 #pragma unroll
     for (int sm = 0; sm < 4; ++sm)
@@ -2002,13 +2004,19 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     }
   }
   store2(x0);
+  TR(160);
   __syncthreads();
-  rd_taps<G128, 1, 0, 5, true, true, 4, RDU>(acc, res, va128, wp0, wr0, ringa);
+  TR(161);
+  rd_taps<G128, 1, 0, 5, true, true, 4, RDU, true>(acc, res, va128, wp0, wr0, ringa);
   rd_ring_load<G128, 1, RDU>(ringa, wp1);
+  TR(162);
   __syncthreads();                                           // every wave is done reading chunk 0
   store2(x1);
+  TR(163);
   __syncthreads();
-  rd_taps<G128, 1, 0, 5, false, true, 4, RDU>(acc, res, va128, wp1, wr1, ringa);
+  TR(164);
+  rd_taps<G128, 1, 0, 5, false, true, 4, RDU, true>(acc, res, va128, wp1, wr1, ringa);
+  TR(165);
   {
     const float br = a.br[col], isr = a.isr[col];
 #pragma unroll
