@@ -89,6 +89,24 @@ __device__ __forceinline__ float gn_mish1(float x, const GnCoef& c, float addend
   return fmaf(yl, q, addend);
 }
 
+// GroupNorm-epilogue parameters of a conv for the lane's NT adjacent channels.  They are REQUESTED BEFORE the conv's taps (the
+// stage bodies call epi_load ahead of the weight ring): read inside the epilogue they cost every conv an exposed L2 round trip
+// (~0.5 us, 25 times per forward) -- nothing else is in flight at that point and the statistics need the bias at once.
+template <int NT> struct Epi { float b[NT], g[NT], be[NT], is[NT], tb[NT]; };
+template <int NT>
+__device__ __forceinline__ Epi<NT> epi_load(const float* b, const float* g, const float* be, const float* tb, const float* isc, int c0) {
+  Epi<NT> e;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    e.b[t] = b[c0 + t];
+    e.g[t] = g[c0 + t];
+    e.be[t] = be[c0 + t];
+    e.is[t] = isc ? isc[c0 + t] : 1.f;
+    e.tb[t] = tb ? tb[c0 + t] : 0.f;
+  }
+  return e;
+}
+
 // Dynamic f16x2 input scale of a conv whose input is NOT bounded by a GroupNorm (the input of a ResidualTemporalBlock: the
 // residual stream, which follows the magnitude of the network input): per sample, from the exact maximum M of the conv's
 // input tile, s = 2^(10 - floor(log2 M)), so that every Winograd-transformed value |V| <= 15 M s < 30720 fits fp16 whatever
@@ -1076,17 +1094,17 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
   };
   // GroupNorm + Mish of acc (chain_body_d2's gn, for one channel x two M tiles): conv A (tb != nullptr) + the time bias,
   // output carried times act_s; conv B + the residual tile.  inv_dyn[mt]: inverse dynamic input scale of tile mt's sample.
-  auto gn = [&](auto scaled, const float* b, const float* g, const float* be, const float* tb, const float* isc,
-                const float (&inv_dyn)[2], float act_s) {
-    constexpr bool SCALED = decltype(scaled)::value;
-    const float bb = b[col], gg = g[col], ee = be[col], is = SCALED ? isc[col] : 1.f;
+  auto epi = [&](const float* b, const float* g, const float* be, const float* tb, const float* isc) {
+    return epi_load<1>(b, g, be, tb, isc, col);
+  };
+  auto gn = [&](auto conv_a, const Epi<1>& e, const float (&inv_dyn)[2], float act_s) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      if (tb) {
-        const float t0 = tb[col] * act_s;
-        gn_mish_quad1<CF::CM, CF::L, SCALED, true>(acc[mt], bb, gg, ee, [&](int, int) { return t0; }, is * inv_dyn[mt], act_scale(act_s));
+      if constexpr (decltype(conv_a)::value) {
+        const float t0 = e.tb[0] * act_s;
+        gn_mish_quad1<CF::CM, CF::L, true, true>(acc[mt], e.b[0], e.g[0], e.be[0], [&](int, int) { return t0; }, e.is[0] * inv_dyn[mt], act_scale(act_s));
       } else {
-        gn_mish_quad1<CF::CM, CF::L, SCALED, false>(acc[mt], bb, gg, ee, [&](int o, int r) { return res[mt][o][r]; }, is * inv_dyn[mt]);
+        gn_mish_quad1<CF::CM, CF::L, true, false>(acc[mt], e.b[0], e.g[0], e.be[0], [&](int o, int r) { return res[mt][o][r]; }, e.is[0] * inv_dyn[mt]);
       }
     }
   };
@@ -1133,6 +1151,8 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
     const char* const va = va_slab + jg * GA::G + (16 * mt0 + (lane & 15)) * 16;
     const char* const vr = vr_slab + jg * GR::G + (16 * mt0 + (lane & 15)) * 16;
     f32x4 mb[2][8];
+    const Epi<1> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
+    const float br = a.br[col], isr = a.isr[col];
     rowform_to_vslab<0, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
     __syncthreads();
     vbd_taps<GA, 0>(mb, va, wpa, ring_a);
@@ -1142,19 +1162,21 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
     rowform_to_vslab<1, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
     __syncthreads();
     vbd_taps<GA, 1>(mb, va, wpa, ring_a);
-    const float br = a.br[col], isr = a.isr[col];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       w4n1_out(acc[mt], mb[mt]);
 #pragma unroll
       for (int o = 0; o < 4; ++o) res[mt][o] = res[mt][o] * (isr * inv_in[mt]) + br;
     }
-    gn(std::true_type{}, a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+    gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   }
   TR(trb + 1);
   __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
-  conv_hb(a.r0.wb_bf);
-  gn(std::true_type{}, a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one2, 1.f);
+  {
+    const Epi<1> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+    conv_hb(a.r0.wb_bf);
+    gn(std::false_type{}, e, one2, 1.f);
+  }
   TR(trb + 2);
   // =================== identity RTB ===================
   {
@@ -1167,12 +1189,14 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
     __syncthreads();                                         // the previous conv is done reading the slab
     float inv_dyn[2];
     dyn_in(inv_dyn);
+    const Epi<1> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
     conv_hb(R.wa_bf);
-    gn(std::true_type{}, R.ba, R.ga, R.bea, R.tb, R.isa, inv_dyn, R.act_a);
+    gn(std::true_type{}, ea, inv_dyn, R.act_a);
     TR(trb + 3);
     __syncthreads();
+    const Epi<1> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
     conv_hb(R.wb_bf);
-    gn(std::true_type{}, R.bb, R.gb, R.beb, nullptr, R.isb, one2, 1.f);
+    gn(std::false_type{}, eb, one2, 1.f);
     TR(trb + 4);
     if constexpr (CF::MID_AFTER == 1) {
 #pragma unroll
@@ -1671,6 +1695,8 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
   }
   wave_lds_fence();
   f32x4 acc[4][2], res[4][2];
+  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
+  const float br0[2] = {a.br[c0], a.br[c0 + 1]}, isr0[2] = {a.isr[c0], a.isr[c0 + 1]};
   // ---- RTB 0 conv A (im2col chunk) + the 1x1 residual conv
   {
     u32x4 b[2][2], br[2][2];
@@ -1698,14 +1724,15 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
     }
   }
   const float one = 1.f;
-  auto gn = [&](const float* bs, const float* gm, const float* be, const float* tb, const float* isc, float inv, float act_s) {
-    const float bb[2] = {bs[c0], bs[c0 + 1]}, gg[2] = {gm[c0], gm[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
-    const float is[2] = {isc[c0], isc[c0 + 1]};
-    if (tb) {
-      const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
-      rw_gn_mish<4, 2, 2, 256, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
+  auto epi = [&](const float* bs, const float* gm, const float* be, const float* tb, const float* isc) {
+    return epi_load<2>(bs, gm, be, tb, isc, c0);
+  };
+  auto gn = [&](auto conv_a, const Epi<2>& e, float inv, float act_s) {
+    if constexpr (decltype(conv_a)::value) {
+      const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
+      rw_gn_mish<4, 2, 2, 256, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
     } else {
-      rw_gn_mish<4, 2, 2, 256, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
+      rw_gn_mish<4, 2, 2, 256, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
     }
   };
   // The whole weight set of a conv (5 taps x 2 n-tiles x 2 pieces = 20 KB per wave) is requested BEFORE the epilogue that
@@ -1722,19 +1749,19 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
     rd_taps<GW, 2, 0, 5, true, false, 4, 5>(acc, res, va, wp, wp, ring);
     wave_lds_fence();                                        // (the next store must not overtake these reads)
   };
-  {
-    const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) res[mt][t] = res[mt][t] * (isr[t] * inv_in) + br[t];
-  }
+    for (int t = 0; t < 2; ++t) res[mt][t] = res[mt][t] * (isr0[t] * inv_in) + br0[t];
   preload(a.r0.wb_bf);
-  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+  gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   TR(trb + 1);
-  conv(a.r0.wb_bf);
-  preload(a.ri[0].wa_bf);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one, 1.f);
+  {
+    const Epi<2> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+    conv(a.r0.wb_bf);
+    preload(a.ri[0].wa_bf);
+    gn(std::false_type{}, e, one, 1.f);
+  }
   TR(trb + 2);
   // ---- identity RTB
   {
@@ -1748,12 +1775,14 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
     conv(R.wa_bf);
     preload(R.wb_bf);
-    gn(R.ba, R.ga, R.bea, R.tb, R.isa, ds.inv, R.act_a);
+    gn(std::true_type{}, ea, ds.inv, R.act_a);
     TR(trb + 3);
+    const Epi<2> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
     conv(R.wb_bf);
-    gn(R.bb, R.gb, R.beb, nullptr, R.isb, one, 1.f);
+    gn(std::false_type{}, eb, one, 1.f);
     TR(trb + 4);
   }
   // ---- tail: Downsample1d = Conv1d(k3, s2, p1): y[p] = sum_t x[p + t - 1] W_t at the even p
@@ -1765,12 +1794,12 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
       for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
     const u32x4* wt[2] = {wptr(a.wt_bf0, GW::FRAGS3, 0), wptr(a.wt_bf0, GW::FRAGS3, 1)};
     u32x4 ring3[3][2][2];
+    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv};
     rd_ring_load<GW, 2, 3>(ring3, wt);
     rw_store2<GW, 4>(vs, acc);
     wave_lds_fence();
     f32x4 y[4][2];
     rd_taps<GW, 2, 1, 3, true, false, 4, 3>(y, res, va, wt, wt, ring3);
-    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv};
     float mo = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -1848,17 +1877,17 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   // GroupNorm + Mish of acc.  Conv A (tb != nullptr): + the time bias, output carried times act_s (conv B's static f16x2
   // input scale); conv B: + the residual tile, which comes back from its parking area.  isc: the conv's inverse weight scales,
   // inv: inverse dynamic input scales
-  auto gn = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc, const float (&inv)[4],
-                float act_s) {
-    const float bb[2] = {b[c0], b[c0 + 1]}, gg[2] = {gm[c0], gm[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
-    const float is[2] = {isc[c0], isc[c0 + 1]};
-    if (tb) {
-      const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
-      rd_gn_mish<2, 256, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
+  auto epi = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc) {
+    return epi_load<2>(b, gm, be, tb, isc, c0);
+  };
+  auto gn = [&](auto conv_a, const Epi<2>& e, const float (&inv)[4], float act_s) {
+    if constexpr (decltype(conv_a)::value) {
+      const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
+      rd_gn_mish<2, 256, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
     } else {
       f32x4 res[4][2];
       unpark_tile(lds, res);
-      rd_gn_mish<2, 256, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int sm, int t, int r) { return res[sm][t][r]; });
+      rd_gn_mish<2, 256, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int sm, int t, int r) { return res[sm][t][r]; });
     }
   };
   // one 128 -> 128 conv over the tile in acc (already scaled for f16x2); on entry every wave is past its reads of the slab
@@ -1879,24 +1908,28 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 #pragma unroll
   for (int sm = 0; sm < 4; ++sm) inv_in[sm] = dyn_scale(mx_read(mx, sm)).inv;
   rd_zero_halo<G64>(slab);
+  const Epi<2> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
+  const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
   rowform_to_rd<CF::C0P, CF::XSS, CF::XSTR>(lds, slab, mx);
   __syncthreads();
   {
     f32x4 res[4][2];
     rd_taps<G64, 2, 0, 5, true, true, 4, 2, true>(acc, res, va64, wpa, wpr, reinterpret_cast<u32x4(&)[2][2][2]>(ring));
-    const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
 #pragma unroll
     for (int sm = 0; sm < 4; ++sm)
 #pragma unroll
       for (int t = 0; t < 2; ++t) res[sm][t] = res[sm][t] * (isr[t] * inv_in[sm]) + br[t];
     park_tile(lds, res);                                     // (every wave is past the barrier behind the x slab's last read)
   }
-  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+  gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   TR(trb + 1);
   __syncthreads();                                           // conv A is done reading the 64-channel slab
   rd_zero_halo<G128>(slab);
-  conv(a.r0.wb_bf);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one4, 1.f);
+  {
+    const Epi<2> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+    conv(a.r0.wb_bf);
+    gn(std::false_type{}, e, one4, 1.f);
+  }
 
   // =================== identity RTBs ===================
 #pragma unroll 1
@@ -1913,11 +1946,13 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[sm][t] *= ds.s;
     }
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
     conv(R.wa_bf);
-    gn(R.ba, R.ga, R.bea, R.tb, R.isa, inv, R.act_a);
+    gn(std::true_type{}, ea, inv, R.act_a);
     __syncthreads();
+    const Epi<2> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
     conv(R.wb_bf);
-    gn(R.bb, R.gb, R.beb, nullptr, R.isb, one4, 1.f);
+    gn(std::false_type{}, eb, one4, 1.f);
     TR(trb + 18);
     if (CF::MID_AFTER == k + 1) {
 #pragma unroll
@@ -1962,14 +1997,15 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 
   f32x4 acc[4][1], res[4][1];
   const float one4[4] = {1.f, 1.f, 1.f, 1.f};
-  auto gn = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc, const float (&inv)[4],
-                float act_s) {
-    const float bb[1] = {b[col]}, gg[1] = {gm[col]}, ee[1] = {be[col]}, is[1] = {isc[col]};
-    if (tb) {
-      const float t0 = tb[col] * act_s;
-      rd_gn_mish<1, 128, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int, int) { return t0; });
+  auto epi = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc) {
+    return epi_load<1>(b, gm, be, tb, isc, col);
+  };
+  auto gn = [&](auto conv_a, const Epi<1>& e, const float (&inv)[4], float act_s) {
+    if constexpr (decltype(conv_a)::value) {
+      const float t0 = e.tb[0] * act_s;
+      rd_gn_mish<1, 128, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int, int) { return t0; });
     } else {
-      rd_gn_mish<1, 128, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int sm, int, int r) { return res[sm][0][r]; });
+      rd_gn_mish<1, 128, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int sm, int, int r) { return res[sm][0][r]; });
     }
   };
   // dynamic input scale of a conv on the tile in acc: (maxima -> mx, barrier, then) scale in place; the inverse scales
@@ -2003,6 +2039,8 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
       x1[sm][t] *= ds.s;
     }
   }
+  const Epi<1> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
+  const float br = a.br[col], isr = a.isr[col];
   store2(x0);
   TR(160);
   __syncthreads();
@@ -2017,17 +2055,17 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   TR(164);
   rd_taps<G128, 1, 0, 5, false, true, 4, RDU, true>(acc, res, va128, wp1, wr1, ringa);
   TR(165);
-  {
-    const float br = a.br[col], isr = a.isr[col];
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm) res[sm][0] = res[sm][0] * (isr * inv_in[sm]) + br;
-  }
-  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+  for (int sm = 0; sm < 4; ++sm) res[sm][0] = res[sm][0] * (isr * inv_in[sm]) + br;
+  gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   TR(trb + 1);
   __syncthreads();                                           // chunk 1 is consumed
   rd_zero_halo<G64>(slab64);
-  conv64(a.r0.wb_bf);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one4, 1.f);
+  {
+    const Epi<1> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+    conv64(a.r0.wb_bf);
+    gn(std::false_type{}, e, one4, 1.f);
+  }
   TR(trb + 4);
   // =================== identity RTB ===================
   {
@@ -2038,12 +2076,14 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     __syncthreads();                                         // the previous conv is done reading the slab
     float inv[4];
     dyn_scale_acc(inv);
+    const Epi<1> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
     conv64(R.wa_bf);
-    gn(R.ba, R.ga, R.bea, R.tb, R.isa, inv, R.act_a);
+    gn(std::true_type{}, ea, inv, R.act_a);
     TR(trb + 5);
     __syncthreads();
+    const Epi<1> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
     conv64(R.wb_bf);
-    gn(R.bb, R.gb, R.beb, nullptr, R.isb, one4, 1.f);
+    gn(std::false_type{}, eb, one4, 1.f);
     TR(trb + 6);
   }
   // =================== tail: out[2 m] = in[m - 1] W3 + in[m] W1, out[2 m + 1] = in[m] W2 + in[m + 1] W0 ===================
@@ -2054,6 +2094,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     dyn_scale_acc(inv);
     const u32x4* wt0[1] = {wptr(a.wt_bf0, 2 * G64::KC * 2)};
     const u32x4* wt1[1] = {wptr(a.wt_bf1, 2 * G64::KC * 2)};
+    const float bt = a.bt[col], is0 = a.ist0[col], is1 = a.ist1[col];
     rd_ring_load<G64, 1>(ring, wt0);
     rd_store1<G64>(vs64, acc, lane);
     __syncthreads();
@@ -2061,7 +2102,6 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     rd_taps<G64, 1, 1, 2, true, false>(xe, res, va64, wt0, wt0, ring);
     rd_ring_load<G64, 1>(ring, wt1);
     rd_taps<G64, 1, 2, 2, true, false>(xo, res, va64, wt1, wt1, ring);
-    const float bt = a.bt[col], is0 = a.ist0[col], is1 = a.ist1[col];
     // the stage's output stays in registers: xe / xo[sample][0][r] = positions 2 m, 2 m + 1 (m = 4 g + r) of channel col; the
     // per-sample maxima of the wave's 16 channels go to slot `wave` of mx region 0 (the caller's barrier publishes them)
 #pragma unroll
@@ -2089,9 +2129,13 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 // after it -- 3 convs, the transposed tail as two parity passes, the final block and the output store -- reads only what the
 // same wave wrote (wave_lds_fence).  Slabs: RwGeo<64, 32> (conv A chunks), RwGeo<32, 32>, RwGeo<32, 64> (final block).
 template <class CF>
-__device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, float* lds, int n0, int lane, int wave,
+__device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, float* lds, int n0, int lane_in, int wave,
                                                const f32x4 (&xe)[4][1], const f32x4 (&xo)[4][1], const f32x4 (&skip)[2][4],
                                                int trb) {
+  // (an opaque copy of the lane index: the stage's lane-derived offsets are recomputed here -- a handful of VALU ops -- instead
+  // of being kept alive, i.e. spilled, since the stages that happen to use the same products)
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
   static_assert(CF::L == 32 && CF::CM == 32 && CF::C0 == 64 && CF::C1 == 64 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
                     CF::TAIL == TAIL_UP, "ups.1");
   using GA = RwGeo<64, 32>;
@@ -2188,6 +2232,8 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   TR(trb + 9);
   __syncthreads();
   TR(trb + 10);
+  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
+  const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
   rd_taps<GA, 2, 0, 5, false, true, 2, RDA, true>(acc, res, vaA, wp1, wr1, ring);
   TR(trb + 11);
   // ---- from here on the wave is on its own: 32-channel slab
@@ -2200,14 +2246,15 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   };
   preload(a.r0.wb_bf);
   const float one = 1.f;
-  auto gn = [&](const float* bs, const float* gm, const float* be, const float* tb, const float* isc, float inv, float act_s) {
-    const float bb[2] = {bs[c0], bs[c0 + 1]}, gg[2] = {gm[c0], gm[c0 + 1]}, ee[2] = {be[c0], be[c0 + 1]};
-    const float is[2] = {isc[c0], isc[c0 + 1]};
-    if (tb) {
-      const float t0 = tb[c0] * act_s, t1 = tb[c0 + 1] * act_s;
-      rw_gn_mish<2, 2, 2, 128, true>(acc, bb, gg, ee, is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
+  auto epi = [&](const float* bs, const float* gm, const float* be, const float* tb, const float* isc) {
+    return epi_load<2>(bs, gm, be, tb, isc, c0);
+  };
+  auto gn = [&](auto conv_a, const Epi<2>& e, float inv, float act_s) {
+    if constexpr (decltype(conv_a)::value) {
+      const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
+      rw_gn_mish<2, 2, 2, 128, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
     } else {
-      rw_gn_mish<2, 2, 2, 128, false>(acc, bb, gg, ee, is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
+      rw_gn_mish<2, 2, 2, 128, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
     }
   };
   auto conv = [&](const uint4* w) {                          // one 32 -> 32 conv over the tile in acc (already scaled)
@@ -2217,20 +2264,20 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     rd_taps<GB, 2, 0, 5, true, false, 2, 5>(acc, res, vaB, wp, wp, ring5);
     wave_lds_fence();                                        // (the next store must not overtake these reads)
   };
-  {
-    const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) res[mt][t] = res[mt][t] * (isr[t] * inv_in) + br[t];
-  }
-  gn(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, inv_in, a.r0.act_a);
+    for (int t = 0; t < 2; ++t) res[mt][t] = res[mt][t] * (isr[t] * inv_in) + br[t];
+  gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   TR(trb + 1);
   wave_lds_fence();                                          // conv A's reads are done: the slab changes its geometry
   if (lane < 32) *reinterpret_cast<uint4*>(slab + (lane >> 4) * GB::PS + ((lane >> 2) & 3) * GB::G + ((lane & 3) < 2 ? (lane & 3) : 32 + (lane & 3)) * 16) = make_uint4(0u, 0u, 0u, 0u);
-  conv(a.r0.wb_bf);
-  preload(a.ri[0].wa_bf);
-  gn(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb, one, 1.f);
+  {
+    const Epi<2> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+    conv(a.r0.wb_bf);
+    preload(a.ri[0].wa_bf);
+    gn(std::false_type{}, e, one, 1.f);
+  }
   TR(trb + 2);
   // ---- identity RTB
   {
@@ -2244,12 +2291,14 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
     conv(R.wa_bf);
     preload(R.wb_bf);
-    gn(R.ba, R.ga, R.bea, R.tb, R.isa, ds.inv, R.act_a);
+    gn(std::true_type{}, ea, ds.inv, R.act_a);
     TR(trb + 3);
+    const Epi<2> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
     conv(R.wb_bf);
-    gn(R.bb, R.gb, R.beb, nullptr, R.isb, one, 1.f);
+    gn(std::false_type{}, eb, one, 1.f);
     TR(trb + 4);
   }
   // ---- tail: Upsample1d = ConvTranspose1d(k4, s2, p1): out[2 m] = in[m - 1] W3 + in[m] W1, out[2 m + 1] = in[m] W2 + in[m + 1] W0
@@ -2267,6 +2316,8 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     const u32x4* wt0[2] = {wptr(a.wt_bf0, 2 * GB::KC * 2, 0), wptr(a.wt_bf0, 2 * GB::KC * 2, 1)};
     const u32x4* wt1[2] = {wptr(a.wt_bf1, 2 * GB::KC * 2, 0), wptr(a.wt_bf1, 2 * GB::KC * 2, 1)};
     u32x4 ring2[2][2][2];
+    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]};
+    const float is0[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv}, is1[2] = {a.ist1[c0] * ds.inv, a.ist1[c0 + 1] * ds.inv};
     rd_ring_load<GB, 2, 2>(ring2, wt0);
     rw_store2<GB, 2>(vsB, acc);
     wave_lds_fence();
@@ -2274,8 +2325,6 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     rd_taps<GB, 2, 1, 2, true, false, 2, 2>(e, res, vaB, wt0, wt0, ring2);
     rd_ring_load<GB, 2, 2>(ring2, wt1);
     rd_taps<GB, 2, 2, 2, true, false, 2, 2>(o, res, vaB, wt1, wt1, ring2);
-    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]};
-    const float is0[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv}, is1[2] = {a.ist1[c0] * ds.inv, a.ist1[c0 + 1] * ds.inv};
     float m = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -2315,18 +2364,17 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     const u32x4* w1[1] = {reinterpret_cast<const u32x4*>(f.w1_bf) + lane};
     u32x4 ring1[1][1][2];
     rd_ring_load<GF, 1, 1>(ring1, w1);
+    const Epi<2> ef = epi_load<2>(f.bias, f.gamma, f.beta, nullptr, f.isc, c0);
+    const float b1 = f.w1_bias[n & 3], s1 = f.is1[n & 3];
     wave_lds_fence();
     rd_taps<GF, 2, 0, 5, true, false, 4, 5>(y, y, vaF, wf, wf, ring5);
-    const float bb[2] = {f.bias[c0], f.bias[c0 + 1]}, gg[2] = {f.gamma[c0], f.gamma[c0 + 1]}, ee[2] = {f.beta[c0], f.beta[c0 + 1]};
-    const float is[2] = {f.isc[c0], f.isc[c0 + 1]};
-    rw_gn_mish<4, 2, 2, 256, true>(y, bb, gg, ee, is, inv_f, act_scale(f.act), [](int, int, int) { return 0.f; });
+    rw_gn_mish<4, 2, 2, 256, true>(y, ef.b, ef.g, ef.be, ef.is, inv_f, act_scale(f.act), [](int, int, int) { return 0.f; });
     wave_lds_fence();
     rw_store2<GF, 4>(vsF + (2 + 4 * g) * 16, y);
     wave_lds_fence();
     f32x4 out[4][1];
     rd_taps<GF, 1, 2, 1, true, false, 4, 1>(out, out, vaF, w1, w1, ring1);
     if (n < 4 && n0 + wave < a.n) {
-      const float b1 = f.w1_bias[n], s1 = f.is1[n];
       float* dst = f.out + ((size_t)(n0 + wave) * 64 + 4 * g) * 4 + n;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
