@@ -323,146 +323,15 @@ __device__ __forceinline__ float group_colsum(float v) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Winograd F(4,5) for every stride-1 k=5 conv: four outputs from eight products instead of twenty (points 0, +-1, +-2,
-// +-1/2, inf).  A GEMM row is (sample, quad t) = rows 4t .. 4t+3 of a sample; the 4 samples x L / 4 quads are L / 16 M
-// tiles of v_mfma_f32_16x16x4_f32.  C/D layout of that instruction: lane = 16 * (row / 4) + column, register = row % 4
-// = quad, so a lane holds 16 consecutive positions of one (sample, channel) in 4 outputs x 4 registers (at L = 16: all
-// of them, and a GroupNorm group of 16 channels is exactly one 16-lane DPP row; at L = 32 / 64 two / four row blocks
-// per sample).  Down path / mid / final block: a wave owns one M tile x 32 channels = two 16-column n-tiles x 8
-// positions = 16 accumulators of 4 registers.  Input transform: 8 ds_read_b32 + 26 VALU per 16 MFMAs (K step = 4 channels), weights
-// packed [wave][k-step][lane][8 positions][2 n-tiles] (fp64-transformed, 64 B per lane and k-step).  fp32 throughout;
-// 1.9e-6 relative against an fp64-accumulated forward (tools/dbg/winograd_accuracy.py).
+// Winograd F(4,5) (downs.1's convs): four outputs from eight products instead of twenty (points 0, +-1, +-2, +-1/2, inf).  A
+// GEMM row is (sample, quad t) = rows 4t .. 4t+3 of a sample; in the 16x16 C/D layout lane = 16 * (row / 4) + column,
+// register = row % 4 = quad, so a lane holds 16 consecutive positions of one (sample, channel) in 4 outputs x 4 registers
+// (at L = 32 two row blocks per sample).  Weights are transformed in fp64 on the host (pack_vbd).
 // ----------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int W4_RD = 2;               // weight ring depth in k-steps (4 costs 32 more VGPRs = spills: +4 % time)
-// Weights of one k-step for one lane: NQ float4 = 8 positions x NT n-tiles (index p * NT + nt), plus, for a conv with a
-// fused 1x1 residual conv, one more float4 whose .x / .y are the residual weights of n-tile 0 / 1.
-template <int NQ> struct BQ { float4 q[NQ]; };
-template <int NQ>
-__device__ __forceinline__ BQ<NQ> load_bq(const float* __restrict__ p) {
-  BQ<NQ> b;
-  const float4* p4 = reinterpret_cast<const float4*>(p);
-#pragma unroll
-  for (int j = 0; j < NQ; ++j) b.q[j] = p4[j];
-  return b;
-}
-template <int NQ>
-__device__ __forceinline__ void w4_ring_load(BQ<NQ> (&b)[W4_RD], const float* __restrict__ wp) {
-#pragma unroll
-  for (int j = 0; j < W4_RD; ++j) b[j] = load_bq<NQ>(wp + j * 64 * 4 * NQ);
-  MMD_PIN_LOADS();
-}
-template <int I>
-__device__ __forceinline__ float f4at(const float4& v) {
-  if constexpr (I == 0) return v.x;
-  else if constexpr (I == 1) return v.y;
-  else if constexpr (I == 2) return v.z;
-  else return v.w;
-}
-template <int STR>
-__device__ __forceinline__ void load_d8(float (&d)[8], const float* s) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) d[j] = s[j * STR];
-}
 
-__device__ __forceinline__ void w4_transform(float (&v)[8], const float (&d)[8]) {
-  v[0] = fmaf(5.25f, d[2] - d[4], d[6] - d[0]);
-  v[7] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
-  const float e1 = fmaf(-4.25f, d[4], d[2]) + d[6], o1 = fmaf(-4.25f, d[3], d[1]) + d[5];
-  v[1] = e1 + o1; v[2] = e1 - o1;
-  const float e2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), o2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
-  v[3] = e2 + o2; v[4] = e2 - o2;
-  const float e3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), o3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
-  v[5] = e3 + o3; v[6] = e3 - o3;
-}
-// V = B^T d (8 slab rows -> 8 positions), then 8 * NT MFMAs: m[p * NT + nt] += V_p x U_p[nt].  RES: the stage's 1x1
-// residual conv rides along -- its A operands are the untransformed rows 4t + 2 .. 4t + 5 = d[2..5] already in
-// registers, its weights the last float4 of the fragment: res[o * NT + nt] += d[2 + o] x Wr[nt], no extra LDS read,
-// no separate loop, no exposed weight latency.
-template <int NT, bool RES, bool ZERO, int P = 0>
-__device__ __forceinline__ void w4_mfma_pos(f32x4 (&m)[8 * NT], const float (&v)[8], const BQ<2 * NT + (RES ? 1 : 0)>& b) {
-  if constexpr (P < 8) {
-    if constexpr (NT == 2) {
-      m[P * 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[P], f4at<(P * 2) % 4>(b.q[(P * 2) / 4]), m[P * 2], 0, 0, 0);
-      m[P * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[P], f4at<(P * 2 + 1) % 4>(b.q[(P * 2 + 1) / 4]), m[P * 2 + 1], 0, 0, 0);
-    } else {
-      m[P] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[P], f4at<P % 4>(b.q[P / 4]), m[P], 0, 0, 0);
-    }
-    w4_mfma_pos<NT, RES, ZERO, P + 1>(m, v, b);
-  }
-}
-template <int NT, bool RES, bool ZERO>
-__device__ __forceinline__ void w4_step(f32x4 (&m)[8 * NT], f32x4 (&res)[4 * NT], const float (&d)[8],
-                                        const BQ<2 * NT + (RES ? 1 : 0)>& b) {
-  if constexpr (ZERO) {   // first k-step of a conv: srcC = inline constant 0 instead of clearing the accumulators
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8 * NT; ++i) m[i] = z;
-  }
-  float v[8];
-  w4_transform(v, d);
-  w4_mfma_pos<NT, RES, ZERO>(m, v, b);
-  if constexpr (RES) {
-    const float4 wr = b.q[2 * NT];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      res[o * NT] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[2 + o], wr.x, res[o * NT], 0, 0, 0);
-      if constexpr (NT == 2) res[o * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[2 + o], wr.y, res[o * 2 + 1], 0, 0, 0);
-    }
-  }
-}
-
-// m += conv over CP channels of a slab; abase = lane's offset of (sample, slab row 4 * quad, channel lane >> 4);
-// b = ring pre-loaded with the first W4_RD k-steps of wp.  FRESH: the accumulators start at zero.
-template <int CP, int STR, int NT, bool RES, bool FRESH>
-__device__ __forceinline__ void w4_taps(f32x4 (&m)[8 * NT], f32x4 (&res)[4 * NT], const float* slab, int abase,
-                                        const float* __restrict__ wp, BQ<2 * NT + (RES ? 1 : 0)> (&b)[W4_RD]) {
-  constexpr int KS = CP / 4, RD = W4_RD, NQ = 2 * NT + (RES ? 1 : 0), KSTRIDE = 64 * 4 * NQ;
-  static_assert(KS % RD == 0, "k-steps are unrolled by the ring depth");
-  const float* p = wp;
-  const float* s = slab + abase;
-  float d[2][8];
-  load_d8<STR>(d[0], s);
-  auto iter = [&](auto first) {
-    p += RD * KSTRIDE;
-#pragma unroll
-    for (int j = 0; j < RD; ++j) {
-      load_d8<STR>(d[(j + 1) & 1], s + 4 * (j + 1));   // (past the last k-step this reads the next slab row and is unused)
-      MMD_PIN_LOADS();
-      if (decltype(first)::value && j == 0) w4_step<NT, RES, true>(m, res, d[0], b[0]);
-      else w4_step<NT, RES, false>(m, res, d[j & 1], b[j]);
-      b[j] = load_bq<NQ>(p + j * KSTRIDE);
-      MMD_PIN_LOADS();
-    }
-    s += 4 * RD;
-  };
-  if constexpr (FRESH) {
-    iter(std::true_type{});
-#pragma unroll 1
-    for (int ks = RD; ks < KS; ks += RD) iter(std::false_type{});
-  } else {
-#pragma unroll 1
-    for (int ks = 0; ks < KS; ks += RD) iter(std::false_type{});
-  }
-}
-
-// Y = A^T M: q[o * 2 + nt] = outputs 4t + o of n-tile nt (register = quad t)
-__device__ __forceinline__ void w4_out(f32x4 (&q)[8], const f32x4 (&m)[16]) {
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const f32x4 s1 = m[2 + nt] + m[4 + nt], t1 = m[2 + nt] - m[4 + nt];
-    const f32x4 s2 = m[6 + nt] + m[8 + nt], t2 = m[6 + nt] - m[8 + nt];
-    const f32x4 s3 = m[10 + nt] + m[12 + nt], t3 = m[10 + nt] - m[12 + nt];
-    q[0 + nt] = (m[0 + nt] + s1) + (s2 + s3);
-    q[2 + nt] = t1 + 2.f * t2 + 0.5f * t3;
-    q[4 + nt] = s1 + 4.f * s2 + 0.25f * s3;
-    q[6 + nt] = (t1 + m[14 + nt]) + (8.f * t2 + 0.125f * t3);
-  }
-}
-
-// GroupNorm + Mish on a quad tile x + bias; b/g/be = bias, gamma, beta of the lane's channel in n-tile 0 / 1.  A group is
-// CPG adjacent lanes (channels) of a 16-lane DPP row x all L positions: the lane's own 16, and for L = 32 the 16 of the
-// lanes 16 / 32 / 48 further (QB = 2 / 4 row blocks per sample at L = 32 / 64).
+// sum over a GroupNorm group of a quad tile: CPG adjacent lanes (channels) of a 16-lane DPP row x all L positions -- the
+// lane's own 16 and, for L = 32 / 64, those of the lanes 16 / 32 / 48 further (QB = 2 / 4 row blocks per sample)
 template <int CPG, int QB>
 __device__ __forceinline__ float quad_groupsum(float v) {
   v = group_colsum<CPG>(v);
@@ -470,52 +339,6 @@ __device__ __forceinline__ float quad_groupsum(float v) {
   if constexpr (QB == 4) v += __shfl_xor(v, 32);
   return v;
 }
-// add(i, r) = what is added to element r of q[i] after the Mish (time bias / residual / 0)
-template <int CM, int L, class ADD>
-__device__ __forceinline__ void gn_mish_quad(f32x4 (&q)[8], const float (&bias)[2], const float (&gamma)[2],
-                                             const float (&beta)[2], ADD add) {
-  constexpr int CPG = CM / 8, QB = L / 16;
-  constexpr float inv_n = 1.f / (float)(L * CPG);
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    float sum = 0.f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sum += q[o * 2 + nt][r];
-    const float dm = (quad_groupsum<CPG, QB>(sum) + group_colsum<CPG>(bias[nt]) * (float)L) * inv_n - bias[nt];
-    float sq = 0.f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = q[o * 2 + nt][r] - dm;
-        sq = fmaf(d, d, sq);
-      }
-    const GnCoef cf = gn_coef(dm, rsqrtf(quad_groupsum<CPG, QB>(sq) * inv_n + 1e-5f), gamma[nt], beta[nt]);
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) q[o * 2 + nt][r] = gn_mish1(q[o * 2 + nt][r], cf, add(o * 2 + nt, r));
-  }
-}
-
-// quad tile of a level of length L with CM channels -> slab rows 4t + o (+2 halo) of a stage laid out [sample][row][DSTR].
-// Producer tiling: wave = (M tile, 32-channel slice); lane >> 4 = (sample within the M tile, 16-row block)
-
-// ----------------------------------------------------------------------------------------------------------------
-// fp32 V-form slabs (today: the 64 -> 64 convs of ups.0; the wider L = 16 convs use the bf16x3 form of the same idea
-// below).  At L = 16 the four waves of a workgroup share ONE M tile
-// (16 rows = 4 samples x 4 quads) and differ only in their channel slice, so with the input transform V = B^T d inside
-// the K loop every wave repeated the same 26 VALU ops per k-step.  But at L = 16 a lane of the C/D fragment holds ALL 16
-// positions of one (sample, channel): the producing epilogue computes the transform of its four quads in registers
-// (zero padding included, no neighbour exchange) ONCE and stores the conv input already transformed,
-//     V[channel][row = 4 * sample + quad][8 positions],  channel stride VCS = 16 * 8 + 4 floats.
-// The K loop then needs no VALU at all: the A operands of a k-step (4 channels x 16 rows x 8 positions) are two
-// ds_read_b128 per lane (instead of 8 ds_read_b32 + 26 VALU), bank-conflict free for reads (lane = (row i, channel k):
-// dword address 132 k + 8 i, the b128 lane groups of MI355X_MICROARCH.md section LDS hit 16 distinct 4-bank sets) and
-// for the epilogue's ds_write_b128 (8 consecutive channels of one row: banks 4 c .. 4 c + 3).
-// ----------------------------------------------------------------------------------------------------------------
 
 //                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
 using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
@@ -523,36 +346,20 @@ using CH_D1 = ChainCfg<32, 0, 64, 32, 2, RES_CONV, 1, 1, TAIL_DOWN>;     // down
 using CH_D2 = ChainCfg<64, 0, 128, 16, 2, RES_CONV, 3, 1, TAIL_NONE>;    // downs.2 + mid_block1/2 (skip2 after downs.2)
 using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.0: cat(x, skip2) RTB, RTB, Upsample1d
 using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
-constexpr int FIN_STR = 33, FIN_SROWS = 68, FIN_SS = FIN_SROWS * FIN_STR;
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-// The L = 16 stages (downs.2 + mid, ups.0) work on V-form slabs of up to 128 channels that alias their row-form slabs.
 // LDS of a workgroup: the largest stage is downs.2 / ups.0 -- the row-form fp32 x slab of downs.2's input + the 128-channel Rd
-// slab (2 x 21504 B) behind it; downs.1 (x slab + phase slab + raw slab of its first conv: 62720 B), ups.1 (56448 B), the
-// four private slabs of downs.0 (46080 B) and the final block fit below it (static_asserts in the stage bodies).
+// slab (2 x 21504 B) behind it; downs.1 (x slab + phase slab + raw slab of its first conv) and the four private slabs of the
+// wave-private stages (downs.0, ups.1 + final block) fit below it (static_asserts in the stage bodies).
 constexpr int MX_OFF = ((CH_D2::SPB * CH_D2::XSS * 4 + 255) / 256 * 256 + 43008) / 4 + 8;
-static_assert(MX_OFF >= CH_D1::LDS_FLOATS && MX_OFF >= CH_U1::LDS_FLOATS && MX_OFF >= 4 * FIN_SS, "stage slabs");
+static_assert(MX_OFF >= CH_D1::LDS_FLOATS, "stage slabs");
 // + the per-sample maxima of the dynamic input scales + the second part of downs.2's lane-private residual parking area (the
 // first part is the stage's dead x slab: 5 + 3 float4 per thread)
 constexpr int PARK2_OFF = MX_OFF + MX_FLOATS;
 constexpr int UNET_LDS_FLOATS = PARK2_OFF + 3 * 256 * 4;
 
-// Synchronisation between a slab write and the conv that reads it.  WAVE_PRIVATE (the final block: one M tile = one sample
-// per wave): a wave only ever reads what it wrote -- LDS operations of one wave execute in order, and only the compiler
-// has to be kept from reordering them; no workgroup barrier, i.e. no waiting for the slowest of the four SIMDs.
-template <bool WAVE_PRIVATE>
-__device__ __forceinline__ void slab_sync() {
-  if constexpr (WAVE_PRIVATE) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  } else {
-    __syncthreads();
-  }
-}
-
 // ----------------------------------------------------------------------------------------------------------------
-// fp32 GEMM on the fp16 matrix pipe ("f16x2"): the C -> C convs of the three down stages + mid blocks and ups.0's conv A
-// (70 % of the network's matrix work).  Every fp32 operand is split into TWO fp16 pieces by rounding to nearest,
+// fp32 GEMM on the fp16 matrix pipe ("f16x2"): every conv of the network but downs.1's strided tail.  Every fp32 operand is split into TWO fp16 pieces by rounding to nearest,
 // x0 = RN16(x), x1 = RN16(x - x0) (x - x0 is exact in fp32; |x - x0 - x1| <= 2^-24 |x|, half an fp32 ulp, as long as x1 stays
 // above fp16's denormal step 2^-24), and a product a * w is accumulated as a1 w0 + a0 w1 + a0 w0 (low order first) on
 // v_mfma_f32_16x16x32_f16 with fp32 accumulation; the dropped a1 w1 is <= 2^-24 |a w|.  Measured against fp64 the result is
@@ -725,10 +532,7 @@ __device__ __forceinline__ void vr_taps_m2(f32x4 (&res)[2][4], const char* vr, c
   }
 }
 // ----------------------------------------------------------------------------------------------------------------
-// Up-path stage (ups.0: L = 16 / C = 64, ups.1: L = 32 / C = 32) in F(4,5) form.  C_out is small here: the L / 16 M tiles
-// x C / 16 n-tiles are exactly four (M, N) units, one per wave (8 accumulators), so every wave runs the whole K of its
-// unit and nothing is exchanged between waves.  The input is the channel concat cat(x, skip): chunk 0 arrives in the x
-// slab from the previous stage, chunk 1 is the quad tile kept from the down path and is staged into the same slab.
+// One-n-tile quad tiles (downs.1): output transform, GroupNorm + Mish, store to a row-form slab.
 // ----------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void w4n1_out(f32x4 (&q)[4], const f32x4 (&m)[8]) {
   const f32x4 s1 = m[1] + m[2], t1 = m[1] - m[2];
@@ -768,20 +572,7 @@ __device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float g
 #pragma unroll
     for (int r = 0; r < 4; ++r) q[o][r] = gn_mish1<ACT>(q[o][r], cf, add(o, r), as);
 }
-// one-n-tile quad tile -> slab; producer tiling: wave = (M tile, 16-channel n-tile)
-template <int L, int CM, int DSS, int DSTR>
-__device__ __forceinline__ void quad1_to_stage(const f32x4 (&q)[4], float* dst, int wave, int lane) {
-  constexpr int QB = L / 16, SPT = 4 / QB, NTQ = CM / 16;
-  const int mt = wave / NTQ, nq = wave % NTQ;
-  const int smp = mt * SPT + (lane >> 4) / QB, qb = (lane >> 4) % QB;
-  float* base = dst + smp * DSS + (16 * qb + 2) * DSTR + nq * 16 + (lane & 15);
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR] = q[o][r];
-}
-
-// the same for an explicit unit (M tile mt, n-tile nq)
+// one-n-tile quad tile of unit (M tile mt, n-tile nq) -> row-form slab [sample][2 + position][DSTR]
 template <int L, int CM, int DSS, int DSTR>
 __device__ __forceinline__ void quad1_to_stage_u(const f32x4 (&q)[4], float* dst, int mt, int nq, int lane) {
   constexpr int QB = L / 16, SPT = 4 / QB;
@@ -793,138 +584,17 @@ __device__ __forceinline__ void quad1_to_stage_u(const f32x4 (&q)[4], float* dst
     for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR] = q[o][r];
 }
 
-// SKIPW(xslab): writes the stage's skip tensor (chunk 1 of the channel concat) into the x slab in the form this stage
-// reads (V form at L = 16, row form otherwise); it is called by every wave of the workgroup.
-template <class CF, class SKIPW>
-__device__ __forceinline__ void chain_body_w4u(const ChainArgs& a, float* lds, int lane, int wave, SKIPW skip_write,
-                                               f32x16 (&tout)[2][CF::MT_W], int trb) {
-  static_assert(CF::L == 32 && CF::CM * CF::L == 1024 && CF::C1 == CF::C0 && CF::RES0 == RES_CONV &&
-                    CF::TAIL == TAIL_UP && CF::N_IDENT == 1, "ups.1: 4 waves = (L / 16 M tiles) x (CM / 16 n-tiles)");
-  float* hslab = lds + CF::XSLAB;
-  float* xslab = lds;
-  constexpr int QPS = CF::L / 4, NTQ = CF::CM / 16;
-  const int mt = wave / NTQ, nq = wave % NTQ;
-  const int ai = mt * 16 + (lane & 15);
-  const int as = ai / QPS, at = ai % QPS, ak = lane >> 4;
-  const int xbase = as * CF::XSS + 4 * at * CF::XSTR + ak;
-  const int hbase = as * CF::HSS + 4 * at * CF::HSTR + ak;
-  const int col = nq * 16 + (lane & 15);
-  // both chunks of conv A carry the 1x1 residual conv (3 float4 per lane and k-step), all other convs 2
-  BQ<3> ring3[W4_RD];
-  BQ<2> ring[W4_RD];
-  auto wlane = [&](const float4* w, int cp) {
-    return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 8;
-  };
-  auto wlane3 = [&](const float4* w, int cp) {
-    return reinterpret_cast<const float*>(w) + ((size_t)nq * (cp / 4) * 64 + lane) * 12;
-  };
-  w4_ring_load<3>(ring3, wlane3(a.r0.wa, CF::C0P));
-  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB, 256>(hslab);
-  __syncthreads();                                           // the previous stage is done with the LDS
-  TR(trb + 0);
-
-  f32x4 m[8], acc[4], res[4];
-  auto conv_h = [&](const float4* w, const float4* next) {
-    w4_taps<CF::CM, CF::HSTR, 1, false, true>(m, res, hslab, hbase, wlane(w, CF::CM), ring);
-    if (next) w4_ring_load<2>(ring, wlane(next, CF::CM));
-    w4n1_out(acc, m);
-  };
-  auto to_h = [&]() { quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane); };
-
-  // =================== RTB 0: cat(x, skip) -> CM; the 1x1 residual conv rides in conv A ===================
-  {
-    const float br = a.br[col];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) res[o] = f32x4{br, br, br, br};
-    w4_taps<CF::C0P, CF::XSTR, 1, true, true>(m, res, xslab, xbase, wlane3(a.r0.wa, CF::C0P), ring3);
-    w4_ring_load<3>(ring3, wlane3(a.wa0_c1, CF::C1P));
-  }
-  __syncthreads();                                            // chunk 0 has been consumed by every wave
-  skip_write(xslab);
-  __syncthreads();
-  w4_taps<CF::C1P, CF::XSTR, 1, true, false>(m, res, xslab, xbase, wlane3(a.wa0_c1, CF::C1P), ring3);
-  {
-    w4_ring_load<2>(ring, wlane(a.r0.wb, CF::CM));
-    w4n1_out(acc, m);
-    const float tb = a.r0.tb[col];
-    gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.ba[col], a.r0.ga[col], a.r0.bea[col], [&](int, int) { return tb; });
-  }
-  TR(trb + 1);
-  to_h();
-  __syncthreads();
-  TR(trb + 2);
-  {
-    conv_h(a.r0.wb, a.ri[0].wa);
-    gn_mish_quad1<CF::CM, CF::L>(acc, a.r0.bb[col], a.r0.gb[col], a.r0.beb[col], [&](int o, int r) { return res[o][r]; });
-  }
-  TR(trb + 4);
-
-  // =================== identity RTB ===================
-  {
-    const RtbPtrs& R = a.ri[0];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) res[o] = acc[o];
-    __syncthreads();                                         // the previous conv is done reading the H slab
-    to_h();
-    __syncthreads();
-    {
-      conv_h(R.wa, R.wb);
-      const float tb = R.tb[col];
-      gn_mish_quad1<CF::CM, CF::L>(acc, R.ba[col], R.ga[col], R.bea[col], [&](int, int) { return tb; });
-    }
-    TR(trb + 5);
-    __syncthreads();
-    to_h();
-    __syncthreads();
-    {
-      conv_h(R.wb, nullptr);
-      gn_mish_quad1<CF::CM, CF::L>(acc, R.bb[col], R.gb[col], R.beb[col], [&](int o, int r) { return res[o][r]; });
-    }
-    TR(trb + 6);
-  }
-
-  // =================== tail: Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, direct ===================
-  // (reads a row-form H slab; at L = 16 it aliases the V-form slabs, which are dead after the barrier)
-  __syncthreads();
-  quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc, hslab, mt, nq, lane);
-  __syncthreads();
-  TR(trb + 7);
-  {
-    constexpr int MT_W = CF::MT_W;
-    const int wm = wave / CF::WN, wnt = wave % CF::WN, colt = wnt * 32 + (lane & 31), hi = lane >> 5;
-    int hb[MT_W];
-#pragma unroll
-    for (int t = 0; t < MT_W; ++t) {
-      const int r = t * 32 + (lane & 31);
-      hb[t] = (wm * CF::SW + r / CF::L) * CF::HSS + (r % CF::L) * CF::HSTR + hi;
-    }
-    const float bt = a.bt[colt];
-    constexpr int G = 2 * CF::CM / 8;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {                                // the two output parities
-      f32x16 (&t)[MT_W] = tout[pass];
-      fill<MT_W>(t, bt);
-      int ub[MT_W];
-#pragma unroll
-      for (int i = 0; i < MT_W; ++i) ub[i] = hb[i] + (1 + pass) * CF::HSTR;
-      mfma_taps<2, CF::CM, CF::HSTR, MT_W>(t, hslab, ub, a.wt + ((size_t)pass * (CF::WN * G + 4) + (size_t)wnt * G) * 64 + lane);
-    }
-  }
-}
-
 // ----------------------------------------------------------------------------------------------------------------
-// downs.0 (L = 64, 32 channels) and downs.1 (L = 32, 64 channels) with their three C -> C convs as bf16x3.  The stage's
+// downs.1 (L = 32, 64 channels): its convs in the Winograd F(4,5) f16x2 form, two position phases per conv.  The stage's
 // output is L / 16 M tiles x C / 16 n-tiles = 8 units; a wave owns ONE n-tile and TWO M tiles -- the two accumulator
-// streams of a step, so a weight fragment is used twice (a (1 M tile x 2 n-tiles) wave would stream 2 x the weights and
-// gain nothing over the fp32 MFMA: these convs are weight-stream bound too).  A lane of the C/D fragment then holds one
+// streams of a step, so a weight fragment is used twice.  A lane of the C/D fragment then holds one
 // channel x 16 consecutive positions (a half / a quarter of a sample) in each M tile; for the dword stores of the slab the
 // lanes of a pair (n, n ^ 1) swap one tile by DPP, so that the even lane holds channels (c, c + 1) of the first M tile
 // and the odd lane those of the second, and the two positions either side of the lane's 16 come from lane -+ 16 (the
 // neighbouring part of the sample).  Slab: rows = 16 mt + i (the MFMA row order), L rows x 16 B per 8-channel block;
 // the blocks c, c + 1 of an n-tile lie L * 16 + 32 B apart, block pairs a multiple of 256 B, and the two channel-block
 // groups (lane >> 4) that a 16-lane b128 read group spans are blocks of different pairs at the same position in the pair:
-// reads conflict-free, b32 stores 2-way (free).  K chunk kc (downs.1 has two) = blocks kc, kc + 2, kc + 4, kc + 6; downs.0's one
-// chunk takes its four blocks in the order 0, 2, 1, 3.
+// reads conflict-free, b32 stores 2-way (free).  K chunk kc (of two) = blocks kc, kc + 2, kc + 4, kc + 6.
 // ----------------------------------------------------------------------------------------------------------------
 template <int L, int CM> struct DbGeo {
   static constexpr int KC = CM / 32, NTQ = CM / 16, QB = L / 16;        // K chunks, n-tiles, lane groups per sample
@@ -1031,7 +701,7 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
   static_assert(CF::L == 32 && CF::CM * CF::L == 2048 && CF::C0 % 32 == 0 && CF::C1 == 0 && CF::RES0 == RES_CONV &&
                     CF::N_IDENT == 1 && CF::TAIL == TAIL_DOWN, "downs.1");
   using GEO = DbGeo<CF::L, CF::CM>;
-  constexpr int QPS = CF::L / 4, QB = GEO::QB;               // quads / lane groups per sample
+  constexpr int QB = GEO::QB;                                   // quads / lane groups per sample
   float* hslab = lds + CF::XSLAB;                            // row-form H slab of the tail conv
   const int nq = wave % GEO::NTQ, mt0 = 2 * (wave / GEO::NTQ);          // the wave's n-tile and first M tile
   const int col = 16 * nq + (lane & 15);                     // the lane's channel
@@ -2587,42 +2257,6 @@ static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_f
         }
 }
 
-// Winograd F(4,5) weight transform U = G g (points 0, +-1, +-2, +-1/2, inf) in fp64, packed for w4_taps.  A wave slice
-// is NT 16-column n-tiles; per slice, k-step (4 channels) and lane: NF = 8 * NT floats U_p(c, n) at index p * NT + nt,
-// c = c_lo + 4 * ks + (lane >> 4), n = slice * 16 * NT + nt * 16 + (lane & 15); with a fused 1x1 residual conv (wres, layout
-// [cout][cin_full]) four more floats: Wr(c, n) for nt = 0, 1, then zeros.  Channels >= c_hi (padding up to cinp) are
-// zero; 8 zero k-steps follow the pack (register-ring over-read).  conv weight layout [cout][cin_full][5].
-static void pack_w4(std::vector<float>& blob, const float* w, int cout, int cin_full, int c_lo, int c_hi, int cinp, int NT,
-                    const float* wres, bool pair_cols = false) {
-  static const double G[8][5] = {{-1, 0, 0, 0, 0},
-                                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
-                                 {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
-                                 {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
-                                 {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
-                                 {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
-                                 {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
-                                 {0, 0, 0, 0, 1}};
-  const int NF = 8 * NT + (wres ? 4 : 0), nsl = cout / (16 * NT), KS = cinp / 4;
-  const size_t base = blob.size();
-  blob.resize(base + ((size_t)nsl * KS + 8) * 64 * NF, 0.f);
-  for (int sl = 0; sl < nsl; ++sl)
-    for (int ks = 0; ks < KS; ++ks)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int nt = 0; nt < NT; ++nt) {
-          // pair_cols (NT = 1): slices 2 w, 2 w + 1 interleave over the 32 channels of wave w (chain_body_d2)
-          const int ci = c_lo + 4 * ks + (lane >> 4);
-          const int n = pair_cols ? (sl / 2) * 32 + 2 * (lane & 15) + (sl & 1) : sl * 16 * NT + nt * 16 + (lane & 15);
-          if (ci >= c_hi) continue;
-          float* out = &blob[base + (((size_t)sl * KS + ks) * 64 + lane) * NF];
-          const float* g = w + ((size_t)n * cin_full + ci) * 5;
-          for (int p = 0; p < 8; ++p) {
-            double u = 0.0;
-            for (int k = 0; k < 5; ++k) u += G[p][k] * (double)g[k];
-            out[p * NT + nt] = (float)u;
-          }
-          if (wres) out[8 * NT + nt] = wres[(size_t)n * cin_full + ci];
-        }
-}
 
 // ---- f16x2 packs: U = G g in fp64 -> float, scaled per output channel by a power of two, split into two fp16 pieces ----
 static const double kG45[8][5] = {{-1, 0, 0, 0, 0},
@@ -2983,10 +2617,10 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   int tb_off = 0;
   const std::vector<std::vector<float>> tbmax = time_bias_absmax(tensors, s, n_diffusion_steps);
   for (int r = 0; r < 12; ++r) {
-    // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2.  Every conv gets the one pack its stage body
-    // reads: fp32 Winograd packs (pack_w4) for the up path and the first convs of the down stages (one n-tile per slice
-    // there, with the 1x1 residual conv riding along), bf16x3 packs for downs.0's / downs.1's C -> C convs (pack_vbd),
-    // downs.2 + mid's 128 -> 128 convs (pack_vb, paired columns) and ups.0's conv A (pack_vbu).
+    // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2.  Every conv gets the one f16x2 pack its stage
+    // body reads: direct packs (pack_rd; interleaved column pairs where a wave owns two n-tiles) for downs.0, downs.2 + mid and
+    // the up stages, with the 1x1 residual conv of a stage's first RTB as a one-tap pack of its own; Winograd packs
+    // (pack_vbd / pack_vr) for downs.1.
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     W = RtbW{};
