@@ -8,14 +8,34 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { IDLE = 0, MFMA = 1, VALU = 2, TRANS = 3, PK = 4, RCP = 5, LDSR = 6 };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// -DF16MFMA: the MFMA role issues v_mfma_f32_16x16x32_f16 (the matrix core proper; 16 cycles) instead of v_mfma_f32_16x16x4_f32
+// (32 cycles, fp32 at the vector rate)
+#ifdef F16MFMA
+#define MFMA_OP(acc) __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0)
+#define MFMA_DECL f16x8 ah, bh; for (int q = 0; q < 8; ++q) { ah[q] = (_Float16)(1.0f + threadIdx.x * 1e-3f); bh[q] = (_Float16)0.5f; }
+#else
+#define MFMA_OP(acc) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0)
+#define MFMA_DECL
+#endif
 
 __device__ __forceinline__ void run_mfma(int iters, float* out) {
   f32x4 m[16];
   for (int i = 0; i < 16; ++i) m[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
+  (void)a; (void)b;
+  MFMA_DECL
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) m[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, m[i], 0, 0, 0);
+    for (int i = 0; i < 16; ++i) {
+      m[i] = MFMA_OP(m[i]);
+#ifdef MFMA_NOP
+      // yield the issue port while the matrix pipe is busy: does the other wave's VALU stream get the cycles?
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop %0" ::"n"(MFMA_NOP));
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
   }
   float s = 0.f;
   for (int i = 0; i < 16; ++i) s += m[i][0] + m[i][1] + m[i][2] + m[i][3];
@@ -90,11 +110,13 @@ __device__ __forceinline__ void run_mix(int iters, float* out) {
   float v[16];
   for (int i = 0; i < 16; ++i) { m[i] = f32x4{0.f, 0.f, 0.f, 0.f}; v[i] = threadIdx.x * 1e-3f + i; }
   float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
+  (void)a; (void)b;
+  MFMA_DECL
   const float c = 1.0001f, d = 1e-4f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      m[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, m[i], 0, 0, 0);
+      m[i] = MFMA_OP(m[i]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[(i * NV + j) & 15] = __builtin_fmaf(v[(i * NV + j) & 15], c, d);
@@ -178,7 +200,7 @@ int main() {
              names[role], iters * mult, ca, cb, ca / iters, cb / iters);
     }
   }
-  for (int nv = 2; nv <= 8; nv += 2) {
+  for (int nv = 2; nv <= 8; nv += 2) {   // (nv = 1, 3 with the f16 MFMA: see kmix)
     hipLaunchKernelGGL(kmix, dim3(nb), dim3(512), 0, 0, nv, iters, out, cyc);
     hipLaunchKernelGGL(kmix, dim3(nb), dim3(512), 0, 0, nv, iters, out, cyc);
     hipDeviceSynchronize();
