@@ -107,6 +107,22 @@ __device__ __forceinline__ Epi<NT> epi_load(const float* b, const float* g, cons
   return e;
 }
 
+// The same for two values with packed fp32 arithmetic (v_pk_fma / v_pk_mul / v_pk_add: 2 values per ~1.25 issue slots): six
+// packed + two v_min + four transcendental ops per pair instead of 2 x 9.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <bool ACT = false>
+__device__ __forceinline__ f32x2_t gn_mish2(f32x2_t x, const GnCoef& c, f32x2_t addend, const ActScale& as = ActScale{}) {
+  constexpr float LOG2E = 1.44269504088896341f;
+  const f32x2_t sa = {c.sa, c.sa}, sb = {c.sb, c.sb}, two = {2.f, 2.f};
+  const f32x2_t yl = __builtin_elementwise_fma(x, sa, sb);
+  const f32x2_t e = {__builtin_amdgcn_exp2f(fminf(yl.x, 20.f * LOG2E)), __builtin_amdgcn_exp2f(fminf(yl.y, 20.f * LOG2E))};
+  const f32x2_t n = e * (e + two);
+  const f32x2_t k1 = ACT ? f32x2_t{as.l2e, as.l2e} : f32x2_t{LOG2E, LOG2E}, k2 = ACT ? f32x2_t{as.l2e2, as.l2e2} : f32x2_t{2.f * LOG2E, 2.f * LOG2E};
+  const f32x2_t den = __builtin_elementwise_fma(n, k1, k2);
+  const f32x2_t q = n * f32x2_t{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  return __builtin_elementwise_fma(yl, q, addend);
+}
+
 // Dynamic f16x2 input scale of a conv whose input is NOT bounded by a GroupNorm (the input of a ResidualTemporalBlock: the
 // residual stream, which follows the magnitude of the network input): per sample, from the exact maximum M of the conv's
 // input tile, s = 2^(10 - floor(log2 M)), so that every Winograd-transformed value |V| <= 15 M s < 30720 fits fp16 whatever
@@ -1147,7 +1163,11 @@ __device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[4][NT], const float (&bi
       GnCoef cf = gn_coef(dm[sm][t], rstd, gamma[t], beta[t]);
       cf.sa *= k[sm][t];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[sm][t][r] = gn_mish1<ACT>(acc[sm][t][r], cf, add(sm, t, r), as);
+      for (int r = 0; r < 4; r += 2) {
+        const f32x2_t o = gn_mish2<ACT>(f32x2_t{acc[sm][t][r], acc[sm][t][r + 1]}, cf, f32x2_t{add(sm, t, r), add(sm, t, r + 1)}, as);
+        acc[sm][t][r] = o.x;
+        acc[sm][t][r + 1] = o.y;
+      }
     }
   }
 }
@@ -1285,7 +1305,11 @@ __device__ __forceinline__ void rw_gn_mish(f32x4 (&acc)[MT][NT], const float (&b
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[mt][t][r] = gn_mish1<ACT>(acc[mt][t][r], cf, add(mt, t, r), as);
+      for (int r = 0; r < 4; r += 2) {
+        const f32x2_t o = gn_mish2<ACT>(f32x2_t{acc[mt][t][r], acc[mt][t][r + 1]}, cf, f32x2_t{add(mt, t, r), add(mt, t, r + 1)}, as);
+        acc[mt][t][r] = o.x;
+        acc[mt][t][r + 1] = o.y;
+      }
   }
 }
 template <int MT, int NT>

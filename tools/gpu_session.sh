@@ -1,2 +1,6 @@
 export TMPDIR=/tmp
-for sk in 0 4 8 12 16 24 0; do echo "skew $sk"; MMD_AMD_UNET_SKEW=$sk REPS=40 timeout 300 python tools/unet_forward_loop.py 2048 4096 2>&1 | grep unet | cut -c1-40; done > gpurun_out/s14_skew.txt
+timeout 900 python -m pytest tests -m gpu -x -q -k "unet or forward" > gpurun_out/s15_pytest_unet.log 2>&1; tail -3 gpurun_out/s15_pytest_unet.log
+for i in 1 2 3; do
+MMD_AMD_LIB=$PWD/build_tmp/libmmd_amd_prev.so REPS=40 timeout 300 python tools/unet_forward_loop.py 256 1024 2048 2>&1 | grep unet
+REPS=40 timeout 300 python tools/unet_forward_loop.py 256 1024 2048 2>&1 | grep unet
+done > gpurun_out/s15_ab.txt
