@@ -8,8 +8,10 @@
 //     (host), static for the inputs of an RTB's second conv (bounded by GroupNorm), dynamic per sample for the
 //     residual stream (dyn_scale); all of them leave through the GroupNorm epilogue's coefficients.
 //   * stage forms: downs.0 wave-private direct f16x2 (wave = sample, no workgroup barriers); downs.1 Winograd F(4,5)
-//     f16x2 in two position phases; downs.2 + mid and ups.0 direct f16x2 on a row-form fp16 slab (rd_taps); ups.1 and
-//     the final block Winograd F(4,5) on v_mfma_f32_16x16x4_f32; the strided tail of downs.1 on v_mfma_f32_32x32x2_f32.
+//     f16x2 in two position phases, its strided tail on v_mfma_f32_32x32x2_f32 (the only fp32 MFMAs); downs.2 + mid and
+//     ups.0 direct f16x2 on a row-form fp16 slab (rd_taps); ups.1 + the final block wave-private direct f16x2.
+//   * no register spills (a reload waits for every weight load in flight): downs.2's residual tile is parked
+//     lane-privately in LDS; epilogue parameters and the residual conv's weights are requested ahead of their use.
 //
 // Layout.  The trajectory tensor is channels-last [n_traj, 64, 4] fp32 in HBM on both sides (no transposes).  A
 // workgroup (4 waves) owns 4 whole samples for the entire forward: activations live in LDS slabs (fp32 row form
