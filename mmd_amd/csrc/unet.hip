@@ -956,6 +956,14 @@ __device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, in
 template <int C> struct RdGeo {
   static constexpr int KC = C / 32, RPS = 20, BX = 4 * RPS * 16 + 32, G = (KC * BX + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
   static constexpr int FRAGS5 = 5 * KC * 2;                  // weight fragments per n-tile of a k = 5 conv
+  static constexpr int tile_row(int m) { return m * RPS; }   // first slab row (halo included) of M tile m = sample m
+};
+// The same slab for a stage of length 32 (downs.1): a sample is TWO M tiles (positions 0 .. 15, 16 .. 31) between its 2-row
+// halos, 36 rows per sample; a wave's four M tiles are the two samples of its sample pair.
+template <int C> struct RlGeo {
+  static constexpr int KC = C / 32, RPS = 36, BX = 4 * RPS * 16 + 32, G = (KC * BX + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
+  static constexpr int FRAGS5 = 5 * KC * 2, FRAGS3 = 3 * KC * 2;
+  static constexpr int tile_row(int m) { return (m >> 1) * RPS + (m & 1) * 16; }
 };
 template <class GEO>
 __device__ __forceinline__ void rd_zero_halo(char* slab) {
@@ -963,7 +971,7 @@ __device__ __forceinline__ void rd_zero_halo(char* slab) {
   for (int idx = threadIdx.x; idx < TOT; idx += 256) {
     const int hr = idx & 3, sm = (idx >> 2) & 3, blk = (idx >> 4) % (4 * GEO::KC), q = idx / (64 * GEO::KC);
     *reinterpret_cast<uint4*>(slab + q * GEO::PS + (blk / GEO::KC) * GEO::G + (blk % GEO::KC) * GEO::BX +
-                              (sm * GEO::RPS + (hr < 2 ? hr : 16 + hr)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+                              (sm * GEO::RPS + (hr < 2 ? hr : GEO::RPS - 4 + hr)) * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 template <class GEO, int NT>
@@ -980,7 +988,7 @@ __device__ __forceinline__ void rd_load_a(u32x4 (&a)[2][2], const char* va, int 
   for (int sm = 0; sm < 2; ++sm)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      a[sm][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + ((2 * hp + sm) * GEO::RPS + rowoff) * 16);
+      a[sm][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + (GEO::tile_row(2 * hp + sm) + rowoff) * 16);
 }
 constexpr int RD_RD = 2;                    // weight ring depth in steps
 #ifndef MMD_D2_RD
@@ -1011,7 +1019,8 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
   // (the residual conv's weights are requested RES_LOOK steps before the centre tap's step that uses them: loaded there,
   // every one of its steps would wait for an L2 round trip; all up front, they would cost 32 registers for two taps)
   static_assert(!RES || FULL, "the residual conv rides on fully unrolled convs only");
-  constexpr int RES_LOOK = 3;
+  constexpr int C0 = (2 - TAP0) * KC;                        // the centre tap's first step
+  constexpr int RES_LOOK = C0 < 3 ? C0 : 3;
   u32x4 brp[RES ? KC : 1][NT][2];
   auto load_br = [&](int kc) {
 #pragma unroll
@@ -1058,7 +1067,7 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
     MMD_PIN_LOADS();
   };
   static_assert(KC == 1 || FULL || (KC * HP) % 2 == 0, "A buffer parity must be static across the rolled tap loop");
-  if constexpr (FULL && KC > 1) {
+  if constexpr (FULL) {
     // every step unrolled: ring slot = step % RD for any depth -- a wave-private conv with several chunks (ups.1's conv A) has
     // no second workgroup wave to hide the weight fetch behind, so it needs the fetch ~5 steps ahead
 #pragma unroll
@@ -1067,8 +1076,6 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
       for (int kc = 0; kc < KC; ++kc) {
         const int st = tap * KC + kc;
         if constexpr (RES) {
-          constexpr int C0 = (2 - TAP0) * KC;                // the centre tap's first step
-          static_assert(C0 >= RES_LOOK, "the centre tap must not be among the first steps");
           if (st + RES_LOOK >= C0 && st + RES_LOOK < C0 + KC) load_br(st + RES_LOOK - C0);
         }
         if (FRESH && st == 0) {
@@ -1257,6 +1264,7 @@ __device__ __forceinline__ void rowform_to_rd(const float* xslab, char* slab, co
 template <int C, int L> struct RwGeo {
   static constexpr int KC = C / 32, RPS = 16, ROWS = L + 4, BX = ROWS * 16 + 32, G = (KC * BX + 255) / 256 * 256, PS = 4 * G;
   static constexpr int BYTES = 2 * PS, FRAGS5 = 5 * KC * 2, FRAGS3 = 3 * KC * 2;
+  static constexpr int tile_row(int m) { return m * RPS; }   // M tile m = positions 16 m .. 16 m + 15 of the wave's sample
 };
 __device__ __forceinline__ float wave_sum_rows(float v) {   // v + the same lane of the other three 16-lane rows
   v += __shfl_xor(v, 16);
@@ -1350,9 +1358,9 @@ __device__ __forceinline__ void wave_lds_fence() {           // a wave's own LDS
 // [row][4 channel] input slab), its 1x1 residual conv a second chunk with only the centre tap's slots non-zero.  The raw
 // network input has no bounded range: dynamic scale from the sample's own maximum.  The stride-2 tail is evaluated at every
 // position (3 taps, 72 MFMAs) and the even ones are kept -- stride-2 A reads would be 2-way bank conflicted.
-// xn: the next stage's row-form fp32 x slab (written behind a workgroup barrier: it aliases the waves' slabs); mxn: the
-// per-sample maxima of the tile for the next stage's dynamic scale.
-template <class CF, class CFN>
+// The stage's output goes straight into the next stage's input slab (RlGeo<32>) as f16 pieces under the sample's own dynamic
+// scale, behind a workgroup barrier (it aliases the waves' slabs); the sample's maximum goes to mx.
+template <class CF>
 __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb) {
   static_assert(CF::L == 64 && CF::CM == 32 && CF::C0 == 4 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
                     CF::TAIL == TAIL_DOWN, "downs.0");
@@ -1509,15 +1517,203 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
     mo = row_max16(mo);
     mo = fmaxf(mo, __shfl_xor(mo, 16));
     mo = fmaxf(mo, __shfl_xor(mo, 32));
-    __syncthreads();                                         // every wave is done with its slab: the next stage's x slab aliases them
+    __syncthreads();                                         // every wave is done with its slab: the next stage's slab aliases them
     if (lane < MX_SLOTS) (lds + MX_OFF)[wave * MX_SLOTS + lane] = mo;
-    // -> the next stage's row-form x slab [sample][2 + m][CFN::XSTR], m = p / 2 = 8 mt + 2 g + r / 2, channels 2 n, 2 n + 1
-    float* xb = lds + wave * CFN::XSS + (2 + 2 * g) * CFN::XSTR + c0;
+    // -> the next stage's input slab (RlGeo<32>: rows 36 sample + 2 + m), m = p / 2 = 8 mt + 2 g + r / 2, channels 2 n, 2 n + 1 =
+    //    block n >> 2, dword n & 3, as f16 pieces under the sample's own dynamic scale (the next stage reads it from mx)
+    using GN = RlGeo<32>;
+    const float so = dyn_scale(mo).s;
+    char* const lb = reinterpret_cast<char*>(lds);
+    char* xb = lb + (n >> 2) * GN::G + (wave * GN::RPS + 2 + 2 * g) * 16 + (n & 3) * 4;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const F16Pair f = f16_split2(y[mt][0][2 * h] * so, y[mt][1][2 * h] * so);
+        *reinterpret_cast<unsigned*>(xb + (8 * mt + h) * 16) = f.hi;
+        *reinterpret_cast<unsigned*>(xb + GN::PS + (8 * mt + h) * 16) = f.lo;
+      }
+    if (lane < 32)                                           // halo rows 0, 1, 34, 35 of the sample's 4 blocks x 2 pieces
+      *reinterpret_cast<uint4*>(lb + (lane >> 4) * GN::PS + ((lane >> 2) & 3) * GN::G +
+                                (wave * GN::RPS + ((lane & 3) < 2 ? (lane & 3) : 32 + (lane & 3))) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  TR(trb + 5);
+}
+
+// downs.1 (32 -> 64 -> 64 channels at L = 32, Downsample1d) in the direct form on RlGeo slabs.  Wave w = (n-tile pair np = w &
+// 1: channels 32 np + 2 n + t, interleaved columns; sample pair sp = w >> 1: samples 2 sp, 2 sp + 1), so a weight fragment is
+// used on four M tiles and fetched by two waves; acc[m][t]: M tile m = sample 2 sp + (m >> 1), positions 16 (m & 1) + 4 g + r.
+// A GroupNorm group (8 channels x 32 positions of a sample) is 4 lanes x 2 tiles x the sample's 2 M tiles: wave-internal.
+// The input slab arrives from downs.0's tail (f16 pieces, per-sample scales in mx); the strided tail is evaluated at every
+// position and the even ones go to downs.2's row-form fp32 x slab (CFN geometry) + their per-sample maxima to mx.
+// skip: the stage's skip tensor (output of its second RTB) in the acc layout.
+template <class CF, class CFN>
+__device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&skip)[4][2], int trb) {
+  static_assert(CF::L == 32 && CF::CM == 64 && CF::C0 == 32 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
+                    CF::MID_AFTER == 1 && CF::TAIL == TAIL_DOWN, "downs.1");
+  using GI = RlGeo<32>;
+  using GH = RlGeo<64>;
+  constexpr int H_OFF = GI::BYTES;                           // the 64-channel slab lies behind the input slab
+  static_assert(H_OFF + GH::BYTES <= MX_OFF * 4, "input slab + 64-channel slab");
+  char* const lb = reinterpret_cast<char*>(lds);
+  char* const slabH = lb + H_OFF;
+  float* const mx = lds + MX_OFF;
+  const int n = lane & 15, g = lane >> 4, np = wave & 1, sp = wave >> 1;
+  const int c0 = 32 * np + 2 * n;
+  const char* const vaI = lb + g * GI::G + (2 * sp * GI::RPS + n) * 16;
+  const char* const vaH = slabH + g * GH::G + (2 * sp * GH::RPS + n) * 16;
+  // the lane's channel pair (c0, c0 + 1) = block 4 np + (n >> 2) = (chunk (n >> 2) & 1, lane group 2 np + (n >> 3)), dword n & 3
+  char* const vsH = slabH + (2 * np + (n >> 3)) * GH::G + ((n >> 2) & 1) * GH::BX + (2 * sp * GH::RPS + 2 + 4 * g) * 16 + (n & 3) * 4;
+  auto wptr = [&](const uint4* w, int frags, int h) { return reinterpret_cast<const u32x4*>(w) + (size_t)(2 * np + h) * frags * 64 + lane; };
+  auto epi = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc) {
+    return epi_load<2>(b, gm, be, tb, isc, c0);
+  };
+  f32x4 acc[4][2], res[4][2];
+  u32x4 ring[RD_RD][2][2];
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const F16Pair f = f16_split2(acc[m][0][r], acc[m][1][r]);
+        *reinterpret_cast<unsigned*>(vsH + (GH::tile_row(m) + r) * 16) = f.hi;
+        *reinterpret_cast<unsigned*>(vsH + GH::PS + (GH::tile_row(m) + r) * 16) = f.lo;
+      }
+  };
+  // GroupNorm + Mish of acc, sample by sample (M tiles 2 s, 2 s + 1)
+  auto gn = [&](auto conv_a, const Epi<2>& e, const float (&inv)[2], float act_s) {
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      f32x4(&t)[2][2] = reinterpret_cast<f32x4(&)[2][2]>(acc[2 * sl]);
+      if constexpr (decltype(conv_a)::value) {
+        const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
+        rw_gn_mish<2, 2, 4, 256, true>(t, e.b, e.g, e.be, e.is, inv[sl], act_scale(act_s), [&](int, int tt, int) { return tt ? t1 : t0; });
+      } else {
+        rw_gn_mish<2, 2, 4, 256, false>(t, e.b, e.g, e.be, e.is, inv[sl], ActScale{}, [&](int mt, int tt, int r) { return res[2 * sl + mt][tt][r]; });
+      }
+    }
+  };
+  // per-sample |x| maxima of the tile in v -> all eight slots of the two samples (the two waves of a sample pair fill them)
+  auto maxima_out = [&](const f32x4 (&v)[4][2], auto even_only) {
+    float m2[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      float m = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; r += decltype(even_only)::value ? 2 : 1) m = fmaxf(m, fabsf(v[2 * sl + mt][t][r]));
+      m = row_max16(m);
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m2[sl] = fmaxf(m, __shfl_xor(m, 32));
+    }
+    if (lane < 8) mx[(2 * sp + (lane >> 2)) * MX_SLOTS + np + 2 * (lane & 3)] = (lane >> 2) ? m2[1] : m2[0];
+  };
+  // dynamic input scale of the tile in acc from the maxima in mx: scale in place, the inverse scales per sample of the pair
+  auto scale_in = [&](float (&inv)[2]) {
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const DynScale ds = dyn_scale(mx_read(mx, 2 * sp + sl));
+      inv[sl] = ds.inv;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[2 * sl + mt][t] *= ds.s;
+    }
+  };
+  // one 64 -> 64 conv over the tile in acc (already scaled); on entry every wave is past its reads of the slab
+  auto conv = [&](const uint4* w) {
+    const u32x4* wp[2] = {wptr(w, GH::FRAGS5, 0), wptr(w, GH::FRAGS5, 1)};
+    rd_ring_load<GH, 2>(ring, wp);
+    store_tile();
+    __syncthreads();
+    rd_taps<GH, 2, 0, 5, true, false>(acc, acc, vaH, wp, wp, ring);
+  };
+  const float one2[2] = {1.f, 1.f};
+
+  // =================== RTB 0 (32 -> 64): conv A + the 1x1 residual conv on the centre tap ===================
+  {
+    u32x4 ring5[5][2][2];
+    const u32x4* wpa[2] = {wptr(a.r0.wa_bf, GI::FRAGS5, 0), wptr(a.r0.wa_bf, GI::FRAGS5, 1)};
+    const u32x4* wpr[2] = {wptr(a.wres_bf, 2 * GI::KC, 0), wptr(a.wres_bf, 2 * GI::KC, 1)};
+    rd_ring_load<GI, 2, 5>(ring5, wpa);
+    const Epi<2> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
+    const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
+    __syncthreads();                                         // downs.0's tail has written the input slab and its maxima
+    TR(trb + 0);
+    float inv_in[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) inv_in[sl] = dyn_scale(mx_read(mx, 2 * sp + sl)).inv;
+    rd_zero_halo<GH>(slabH);
+    rd_taps<GI, 2, 0, 5, true, true, 4, 5, true>(acc, res, vaI, wpa, wpr, ring5);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[m][t] = res[m][t] * (isr[t] * inv_in[m >> 1]) + br[t];
+    gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
+  }
+  TR(trb + 1);
+  {
+    const Epi<2> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+    conv(a.r0.wb_bf);                                        // (its slab is not the one conv A reads: no barrier before the store)
+    gn(std::false_type{}, e, one2, 1.f);
+  }
+  TR(trb + 2);
+  // =================== identity RTB ===================
+  {
+    const RtbPtrs& R = a.ri[0];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[m][t] = acc[m][t];
+    maxima_out(acc, std::false_type{});
+    __syncthreads();                                         // the previous conv is done reading the slab
+    float inv[2];
+    scale_in(inv);
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    conv(R.wa_bf);
+    gn(std::true_type{}, ea, inv, R.act_a);
+    TR(trb + 3);
+    __syncthreads();
+    const Epi<2> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
+    conv(R.wb_bf);
+    gn(std::false_type{}, eb, one2, 1.f);
+    TR(trb + 4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) skip[m][t] = acc[m][t];
+  }
+  // =================== tail: Downsample1d = Conv1d(k3, s2, p1): y[p] = sum_t x[p + t - 1] W_t at the even p ===================
+  {
+    maxima_out(acc, std::false_type{});
+    __syncthreads();
+    float inv[2];
+    scale_in(inv);
+    const u32x4* wt[2] = {wptr(a.wt_bf0, GH::FRAGS3, 0), wptr(a.wt_bf0, GH::FRAGS3, 1)};
+    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0], a.ist0[c0 + 1]};
+    rd_ring_load<GH, 2>(ring, wt);
+    store_tile();
+    __syncthreads();
+    f32x4 y[4][2];
+    rd_taps<GH, 2, 1, 3, true, false>(y, y, vaH, wt, wt, ring);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) y[m][t][r] = fmaf(y[m][t][r], ist[t] * inv[m >> 1], bt[t]);
+    __syncthreads();                                         // every wave is done reading the slab the next stage's x slab aliases
+    maxima_out(y, std::true_type{});
+    // -> the next stage's row-form fp32 x slab [sample][2 + q][CFN::XSTR], q = p / 2 = 8 (m & 1) + 2 g + r / 2
+    float* xb = lds + (2 * sp) * CFN::XSS + (2 + 2 * g) * CFN::XSTR + c0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
       for (int h = 0; h < 2; ++h)
-        *reinterpret_cast<float2*>(xb + (8 * mt + h) * CFN::XSTR) = make_float2(y[mt][0][2 * h], y[mt][1][2 * h]);
+        *reinterpret_cast<float2*>(xb + (m >> 1) * CFN::XSS + (8 * (m & 1) + h) * CFN::XSTR) = make_float2(y[m][0][2 * h], y[m][1][2 * h]);
   }
   TR(trb + 5);
 }
@@ -1826,7 +2022,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 // same wave wrote (wave_lds_fence).  Slabs: RwGeo<64, 32> (conv A chunks), RwGeo<32, 32>, RwGeo<32, 64> (final block).
 template <class CF>
 __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, float* lds, int n0, int lane_in, int wave,
-                                               const f32x4 (&xe)[4][1], const f32x4 (&xo)[4][1], const f32x4 (&skip)[2][4],
+                                               const f32x4 (&xe)[4][1], const f32x4 (&xo)[4][1], const f32x4 (&skip)[4][2],
                                                int trb) {
   // (an opaque copy of the lane index: the stage's lane-derived offsets are recomputed here -- a handful of VALU ops -- instead
   // of being kept alive, i.e. spilled, since the stages that happen to use the same products)
@@ -1855,18 +2051,26 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   constexpr int RDA = 5;                                      // conv A's weight ring: half a chunk ahead
   u32x4 ring[RDA][2][2];
   rd_ring_load<GA, 2, RDA>(ring, wp0);
-  // ---- the skip tensor's per-sample maxima (skip[mt][o][r]: sample 2 mt + (g >> 1), position 16 (g & 1) + 4 r + o) -> slots
-  //      4 + wave of mx region 0; ups.0 left its output's maxima in slots 0 .. 3
+  // ---- the skip tensor's per-sample maxima (downs.1's layout: wave = (channel half np, sample pair sp); skip[m][t][r]: sample 2 sp
+  //      + (m >> 1), channel 32 np + 2 n + t, position 16 (m & 1) + 4 g + r) -> slots 4 .. 7 of mx region 0 (the two waves of a
+  //      sample pair fill them); ups.0 left its output's maxima in slots 0 .. 3
+  const int np = wave & 1, sp = wave >> 1;
+  {
+    float m2[2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    float m = 0.f;
+    for (int sl = 0; sl < 2; ++sl) {
+      float m = 0.f;
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(skip[mt][o][r]));
-    m = row_max16(m);
-    m = fmaxf(m, __shfl_xor(m, 16));
-    if ((lane & 31) == 0) mx[(2 * mt + (lane >> 5)) * MX_SLOTS + 4 + wave] = m;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(skip[2 * sl + mt][t][r]));
+      m = row_max16(m);
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m2[sl] = fmaxf(m, __shfl_xor(m, 32));
+    }
+    if (lane < 4) mx[(2 * sp + (lane >> 1)) * MX_SLOTS + 4 + np + 2 * (lane & 1)] = (lane >> 1) ? m2[1] : m2[0];
   }
   __syncthreads();                                           // ups.0 is done with its slabs; the maxima are in mx
   TR(trb + 0);
@@ -1874,6 +2078,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
 #pragma unroll
   for (int sm = 0; sm < 4; ++sm) sc[sm] = dyn_scale(mx_read(mx, sm)).s;
   const float inv_in = dyn_scale(mx_read(mx, wave)).inv;
+  const float sc_lo = dyn_scale(mx_read(mx, 2 * sp)).s, sc_hi = dyn_scale(mx_read(mx, 2 * sp + 1)).s;
   // channel col = 16 wave + n of a 64-channel chunk: block 2 wave + (n >> 3) = (lane group wave, chunk n >> 3), the pair (n & ~1,
   // n | 1) one dword; the lanes of a pair swap halves so that each stores whole dwords
   char* const cdst = lb + wave * GA::G + (n >> 3) * GA::BX + ((n & 7) >> 1) * 4 + 2 * 16;
@@ -1907,25 +2112,21 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   TR(trb + 8);
   __syncthreads();                                           // every wave has consumed chunk 0
   {
-    // chunk 1 = skip: the even lane stores positions 16 (g & 1) + 4 r + {0, 1}, the odd lane + {2, 3}
+    // chunk 1 = skip: the lane's channel pair (32 np + 2 n, + 1) of the 64-channel chunk = block 4 np + (n >> 2) = (chunk (n >> 2) &
+    // 1, lane group 2 np + (n >> 3)), dword n & 3, in the slabs of samples 2 sp, 2 sp + 1
+    char* const sdst = lb + (2 * np + (n >> 3)) * GA::G + ((n >> 2) & 1) * GA::BX + (n & 3) * 4 + (2 + 4 * g) * 16;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const float s = (g >> 1) ? sc[2 * mt + 1] : sc[2 * mt];
-      char* const d1 = cdst + (2 * mt + (g >> 1)) * W_BYTES + (16 * (g & 1) + (odd ? 2 : 0)) * 16;
+    for (int m = 0; m < 4; ++m) {
+      const float sm_s = (m >> 1) ? sc_hi : sc_lo;
 #pragma unroll
-      for (int oo = 0; oo < 2; ++oo)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float own = (odd ? skip[mt][2 + oo][r] : skip[mt][oo][r]) * s;
-          const float recv = swap1((odd ? skip[mt][oo][r] : skip[mt][2 + oo][r]) * s);
-          const F16Pair p = f16_split2(odd ? recv : own, odd ? own : recv);
-          char* d = d1 + (4 * r + oo) * 16;
-          *reinterpret_cast<unsigned*>(d) = p.hi;
-          *reinterpret_cast<unsigned*>(d + GA::PS) = p.lo;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const F16Pair p = f16_split2(skip[m][0][r] * sm_s, skip[m][1][r] * sm_s);
+        char* d = sdst + (2 * sp + (m >> 1)) * W_BYTES + (16 * (m & 1) + r) * 16;
+        *reinterpret_cast<unsigned*>(d) = p.hi;
+        *reinterpret_cast<unsigned*>(d + GA::PS) = p.lo;
+      }
     }
   }
-  TR(trb + 9);
   __syncthreads();
   TR(trb + 10);
   const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
@@ -2100,19 +2301,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * 4;
 
-  f32x4 skip1[2][4], skip2[4][2];
+  f32x4 skip1[4][2], skip2[4][2];
   // ---- downs.0 @ L=64 -> [4][32][32]: wave = sample, direct f16x2 convs on the wave's own slab (chain_body_d0w)
-  chain_body_d0w<CH_D0, CH_D1>(a.c[0], lds, n0, lane, wave, 0);
-  zero_halo<CH_D1::C0P, CH_D1::L, CH_D1::SROWS, CH_D1::XSTR, CH_D1::XSS, 4>(lds);
-  // ---- downs.1 @ L=32 -> [4][16][64], skip1 (lane = channel 16 wave + (lane & 15) in both M tiles)
-  {
-    f32x4 acc[2][4];
-    f32x16 t[1];
-    chain_body_db<CH_D1, true>(a.c[1], lds, lane, wave, acc, skip1, t, 40);
-    __syncthreads();
-    tile_to_stage<16, 1, CH_D1::SW, CH_D1::WN, 1, CH_D2::XSS, CH_D2::XSTR>(t, lds, wave, lane, 0);
-    zero_halo<CH_D2::C0P, CH_D2::L, CH_D2::SROWS, CH_D2::XSTR, CH_D2::XSS, 4>(lds);
-  }
+  chain_body_d0w<CH_D0>(a.c[0], lds, n0, lane, wave, 0);
+  // ---- downs.1 @ L=32 -> [4][16][64], skip1: direct f16x2 convs, wave = (n-tile pair, sample pair) (chain_body_d1d)
+  chain_body_d1d<CH_D1, CH_D2>(a.c[1], lds, lane, wave, skip1, 40);
   // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2: direct f16x2 convs (chain_body_d2d; lane = channels 32 wave + 2
   //      (lane & 15) + h, positions 4 (lane >> 4) + r of all four samples)
   f32x4 mid_out[4][2];
@@ -2513,7 +2706,7 @@ struct mmd_unet_s {
   RtbW rtb[12];              // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2
   ConvW down[2], up[2], fin;
   size_t up_bf[2][2] = {}, up_is[2][2] = {};     // the up stages' tails: f16x2 parity packs and their inverse scales
-  size_t down_bf = 0, down_is = 0;               // downs.0's tail: f16x2 pack and its inverse scales
+  size_t down_bf[2] = {0, 0}, down_is[2] = {0, 0};   // the down stages' tails: f16x2 pack and its inverse scales
   size_t fin_w1 = 0, fin_b1 = 0, fin_is1 = 0;    // final 1x1 conv: f16x2 pack (N padded to 16), bias, inverse scales / fin_act
   float fin_act = 1.f;                           // static scale of the final block's activations
 };
@@ -2586,10 +2779,11 @@ static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb
   a.wres_bf = w0.res_bf ? reinterpret_cast<const uint4*>(u->blob + w0.res_bf) : nullptr;
   a.wres_c1_bf = w0.res_c1_bf ? reinterpret_cast<const uint4*>(u->blob + w0.res_c1_bf) : nullptr;
   for (int k = 0; k < n_ident; ++k) a.ri[k] = rtb_ptrs(u, set[rtb[1 + k]], t);
-  if (tail) { a.wt = reinterpret_cast<const float4*>(u->blob + tail->wpk); a.bt = u->blob + tail->bias; }
-  if (tail == &u->down[0]) {
-    a.wt_bf0 = reinterpret_cast<const uint4*>(u->blob + u->down_bf);
-    a.ist0 = u->blob + u->down_is;
+  if (tail) a.bt = u->blob + tail->bias;
+  if (tail == &u->down[0] || tail == &u->down[1]) {
+    const int i = tail == &u->down[1];
+    a.wt_bf0 = reinterpret_cast<const uint4*>(u->blob + u->down_bf[i]);
+    a.ist0 = u->blob + u->down_is[i];
   }
   if (tail == &u->up[0] || tail == &u->up[1]) {
     const int i = tail == &u->up[1];
@@ -2652,13 +2846,12 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W = RtbW{};
     W.act_a = 1.f;
     while (blob.size() % 4) blob.push_back(0.f);
-    const bool d1 = r <= 3, d2 = r == 4 || r == 5 || r == 10 || r == 11;   // d1: downs.0 / downs.1 (chain_body_db)
+    const bool d1s = r == 2 || r == 3, d2 = r == 4 || r == 5 || r == 10 || r == 11;   // d1s: downs.1 (chain_body_d1d)
     const float* wres = R.res ? tensors[R.t_rw] : nullptr;   // 1x1 residual conv [cout][cin]: fused into conv A's pack
     const std::vector<int> k5 = {0, 1, 2, 3, 4};
-    const bool u0 = r == 6 || r == 7;                  // ups.0 (chain_body_u0d)
     const bool d0 = r == 0 || r == 1;                  // downs.0 (chain_body_d0w): interleaved column pairs like downs.2
     const bool u1 = r == 8 || r == 9;                  // ups.1 (chain_body_u1w): wave-private, interleaved column pairs
-    const bool pairs = d2 || d0 || u1;
+    const bool pairs = d2 || d0 || u1 || d1s;
     if (r == 0) {             // downs.0's first conv (4 -> 32): one im2col chunk + the 1x1 residual conv's chunk
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
       const std::vector<float> scr = rd_col_scales(wres, R.cout, R.cin, 1, std::vector<int>{0}, false);
@@ -2666,28 +2859,24 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
       W.res_isc = push_inverse(blob, scr);
       W.a.wbf = pack_im2col4(blob, tensors[R.t_w0], R.cout, false, sc);
       W.res_bf = pack_im2col4(blob, wres, R.cout, true, scr);
-    } else if (r == 6 || r == 4 || r == 8) {   // ups.0 / downs.2 / ups.1 conv A of the first RTB: direct f16x2 (rd_taps), the 1x1
-                              // residual conv on the centre tap; the up stages' input is the two chunks of cat(x, skip)
+    } else if (r == 6 || r == 4 || r == 8 || r == 2) {   // conv A of a stage's first RTB: direct f16x2 (rd_taps), the 1x1 residual
+                              // conv on the centre tap; the up stages' input is the two chunks of cat(x, skip)
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
       const std::vector<float> scr = rd_col_scales(wres, R.cout, R.cin, 1, std::vector<int>{0}, false);
-      const int chunk = r == 4 ? R.cin : R.cin / 2;
+      const bool whole = r == 4 || r == 2;
+      const int chunk = whole ? R.cin : R.cin / 2;
       W.a.isc = push_inverse(blob, sc);
       W.res_isc = push_inverse(blob, scr);
       W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, chunk, 5, k5, false, pairs, sc);
       W.res_bf = pack_rd_res(blob, wres, R.cout, R.cin, 0, chunk, pairs, scr);
-      if (r != 4) {
+      if (!whole) {
         W.a_c1_bf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, chunk, chunk, 5, k5, false, pairs, sc);
         W.res_c1_bf = pack_rd_res(blob, wres, R.cout, R.cin, chunk, chunk, pairs, scr);
       }
-    } else if (r == 2) {      // downs.1's first RTB: conv A (32 -> 64) and the 1x1 residual conv as f16x2 (rowform_to_vslab)
-      W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f, /*plain_blocks=*/true);
-      W.res_bf = pack_vr(blob, wres, R.cout, R.cin, W.res_isc, /*pair_cols=*/false);
-    } else if ((d2 || u0 || d0 || u1) && R.cin == R.cout) {   // conv A of an identity RTB of the direct stages: dynamic input scale
+    } else if (R.cin == R.cout) {   // conv A of an identity RTB of the direct stages: dynamic input scale
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w0], R.cout, R.cin, 5, k5, false);
       W.a.isc = push_inverse(blob, sc);
       W.a.wbf = pack_rd(blob, tensors[R.t_w0], R.cout, R.cin, 0, R.cin, 5, k5, false, pairs, sc);
-    } else if (d1 && R.cin == R.cout) {
-      W.a.wbf = pack_vbd(blob, tensors[R.t_w0], R.cout, R.cin, W.a.isc, 1.f);   // dynamic input scale
     } else {
       set_error("mmd_unet_create: no pack for RTB %d", r);
       delete u;
@@ -2696,14 +2885,11 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
     W.a.bias = push(blob, tensors[R.t_b0], R.cout);
     W.a.gamma = push(blob, tensors[R.t_g0], R.cout);
     W.a.beta = push(blob, tensors[R.t_be0], R.cout);
-    if (d2 || u0 || d0 || u1) {   // conv B: direct f16x2, its input scaled by the static act_a
+    {                         // conv B: direct f16x2, its input scaled by the static act_a
       W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
       const std::vector<float> sc = rd_col_scales(tensors[R.t_w1], R.cout, R.cout, 5, k5, false);
       W.b.isc = push_inverse(blob, sc, W.act_a);
       W.b.wbf = pack_rd(blob, tensors[R.t_w1], R.cout, R.cout, 0, R.cout, 5, k5, false, pairs, sc);
-    } else {
-      W.act_a = static_act_scale(tensors[R.t_g0], tensors[R.t_be0], tbmax[r], R.cout);
-      W.b.wbf = pack_vbd(blob, tensors[R.t_w1], R.cout, R.cout, W.b.isc, W.act_a);
     }
     W.b.bias = push(blob, tensors[R.t_b1], R.cout);
     W.b.gamma = push(blob, tensors[R.t_g1], R.cout);
@@ -2718,13 +2904,12 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   const int dims[4] = {4, unet_input_dim, unet_input_dim * 2, unet_input_dim * 4};
   for (int i = 0; i < 2; ++i) {
     const int c = dims[i + 1];
-    u->down[i].wpk = blob.size(); pack_b(blob, tensors[s.t_down[i][0]], c, c, 3, taps3, false);
     u->down[i].bias = push(blob, tensors[s.t_down[i][1]], c);
-    if (i == 0) {             // downs.0's tail as a direct f16x2 conv (chain_body_d0w): taps 0..2, interleaved column pairs
+    {                         // Downsample1d as a direct f16x2 conv (taps 0..2, interleaved column pairs), evaluated at every position
       const std::vector<int> k3 = {0, 1, 2};
       const std::vector<float> sct = rd_col_scales(tensors[s.t_down[i][0]], c, c, 3, k3, false);
-      u->down_is = push_inverse(blob, sct);
-      u->down_bf = pack_rd(blob, tensors[s.t_down[i][0]], c, c, 0, c, 3, k3, false, true, sct);
+      u->down_is[i] = push_inverse(blob, sct);
+      u->down_bf[i] = pack_rd(blob, tensors[s.t_down[i][0]], c, c, 0, c, 3, k3, false, true, sct);
     }
     const int cu = dims[2 - i];
     // ConvTranspose1d(k=4, s=2, p=1): out[2m] = in[m-1] W3 + in[m] W1 ; out[2m+1] = in[m] W2 + in[m+1] W0, as two direct f16x2
@@ -2815,12 +3000,12 @@ static constexpr double direct_flops(double taps, double cinp, double coutp, dou
 static constexpr double d5(double cin, double cout, double L) { return 2.0 * cout * 5 * cin * L; }
 static const double kF16Flops =
     2 * (2.0 * 32 * 32 * 64) + 3 * d5(32, 32, 64) + 2.0 * 32 * 3 * 32 * 64 +                          // downs.0
-    2 * (wino4_flops(32, 64) + 3 * wino4_flops(64, 64)) + direct_flops(1, 32, 64, 32) +               // downs.1 (but its tail)
+    d5(32, 64, 32) + 2.0 * 64 * 32 * 32 + 3 * d5(64, 64, 32) + 2.0 * 64 * 3 * 64 * 32 +               // downs.1
     d5(64, 128, 16) + 2.0 * 128 * 64 * 16 + 7 * d5(128, 128, 16) +                                    // downs.2 + mid
     d5(256, 64, 16) + 2.0 * 64 * 256 * 16 + 3 * d5(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16 +             // ups.0
     d5(128, 32, 32) + 2.0 * 32 * 128 * 32 + 3 * d5(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +             // ups.1
     d5(32, 32, 64) + 2.0 * 16 * 32 * 64;                                                              // final block
-static const double kFp32Flops = direct_flops(3, 64, 64, 16);                                         // downs.1's tail
+static const double kFp32Flops = 0.0;                                                                 // (no fp32 MFMA left)
 static const double kUnetMfmaFlops = kF16Flops + kFp32Flops;
 
 

@@ -501,15 +501,18 @@ def apply_hard_conditioning(x, hard_conds):
 
 
 def ddpm_sample_step(sd, tb, x, hard_conds, i, *, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
-                     noise=None, noise_std_extra=1.0, n_levels=3):
+                     noise=None, noise_std_extra=1.0, n_levels=3, eps_rel_perturb=None):
     """ddpm_sample_fn (sample_functions.py:40-86) + p_mean_variance / predict_start_from_noise / q_posterior
     (diffusion_model_base.py:126-160) with predict_epsilon=True, clip_denoised=True.  `i` is the loop index (may be
     negative: t := 0, sample_functions.py:53-54); `noise` [B,H,D] is the injected randn_like draw; `guide` is a
-    callable x_norm -> grad."""
+    callable x_norm -> grad.  `eps_rel_perturb` [B,H,D] (tests only): the UNet output is multiplied by 1 + it -- the probe of
+    how far a guided step moves under a rounding-sized change of eps (the sensitivity the golden chains store as `sens`)."""
     B = x.shape[0]
     t = max(i, 0)
     tt = torch.full((B,), t, dtype=torch.long)
     eps = unet_forward(sd, x, tt, n_levels)
+    if eps_rel_perturb is not None:
+        eps = eps * (1.0 + eps_rel_perturb)
     x_recon = tb["sqrt_recip_alphas_cumprod"][t] * x - tb["sqrt_recipm1_alphas_cumprod"][t] * eps
     x_recon = x_recon.clamp(-1.0, 1.0)
     mean = tb["posterior_mean_coef1"][t] * x_recon + tb["posterior_mean_coef2"][t] * x
