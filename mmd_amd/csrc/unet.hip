@@ -7,20 +7,18 @@
 //     least its accuracy.  Power-of-two scales keep the pieces inside fp16's range: per output channel for weights
 //     (host), static for the inputs of an RTB's second conv (bounded by GroupNorm), dynamic per sample for the
 //     residual stream (dyn_scale); all of them leave through the GroupNorm epilogue's coefficients.
-//   * stage forms: downs.0 wave-private direct f16x2 (wave = sample, no workgroup barriers); downs.1 Winograd F(4,5)
-//     f16x2 in two position phases, its strided tail on v_mfma_f32_32x32x2_f32 (the only fp32 MFMAs); downs.2 + mid and
-//     ups.0 direct f16x2 on a row-form fp16 slab (rd_taps); ups.1 + the final block wave-private direct f16x2.
+//   * every conv is a DIRECT convolution (taps = row-shifted views of an fp16 slab): downs.0 and ups.1 + final block
+//     wave-private (wave = sample, no workgroup barriers inside the stage), downs.1 / downs.2 + mid / ups.0 on workgroup slabs
+//     (a wave owns 1-2 n-tiles x 2-4 samples); strided / transposed tails the same way (every position resp. two parity passes).
 //   * no register spills (a reload waits for every weight load in flight): downs.2's residual tile is parked
 //     lane-privately in LDS; epilogue parameters and the residual conv's weights are requested ahead of their use.
 //
 // Layout.  The trajectory tensor is channels-last [n_traj, 64, 4] fp32 in HBM on both sides (no transposes).  A
 // workgroup (4 waves) owns 4 whole samples for the entire forward: activations live in LDS slabs (fp32 row form
-// [sample][L+4][C+1]; fp16 row form [piece][lane group][K chunk][row][8 ch], RdGeo / RwGeo; Winograd phase slabs) and
+// [sample][L+4][C+2] for downs.2's input; fp16 row form [piece][lane group][K chunk][row][8 ch], RdGeo / RlGeo / RwGeo) and
 // in register tiles; the two skip connections wait in registers for the up path; nothing but the input, the output
-// and the weights touches HBM/L2.  In the 16x16 C/D layouts a lane holds 4 consecutive positions (or Winograd
-// quads) of one channel per tile, so a GroupNorm group is a few lanes of one DPP row (x row blocks): the statistics are
-// in-register + cross-lane reductions.  Weights are pre-packed on the host in MFMA B-fragment order (fp16 pairs,
-// Winograd-transformed in fp64 where that form is used) and fetched straight from L2 through a register ring (no LDS
+// and the weights touches HBM/L2.  In the 16x16 C/D layout a lane holds 4 consecutive positions of one channel per tile, so a GroupNorm group is a few lanes of one DPP row (x row blocks): the statistics are
+// in-register + cross-lane reductions.  Weights are pre-packed on the host in MFMA B-fragment order (fp16 pairs) and fetched straight from L2 through a register ring (no LDS
 // staging: a B element is used once per workgroup).  DESIGN.md section 3.1 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
 
@@ -36,7 +34,6 @@
 
 namespace mmd {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { RES_NONE = 0, RES_IDENT = 1, RES_CONV = 2 };
 
@@ -81,15 +78,6 @@ __device__ __forceinline__ ActScale act_scale(float s) {
   const float inv = __builtin_amdgcn_rcpf(s);            // exact: s is a power of two
   return ActScale{LOG2E * inv, 2.f * LOG2E * inv};
 }
-template <bool ACT = false>
-__device__ __forceinline__ float gn_mish1(float x, const GnCoef& c, float addend, const ActScale& as = ActScale{}) {
-  constexpr float LOG2E = 1.44269504088896341f;
-  const float yl = fmaf(x, c.sa, c.sb);
-  const float e = __builtin_amdgcn_exp2f(fminf(yl, 20.f * LOG2E));
-  const float n = e * (e + 2.f);
-  const float q = n * __builtin_amdgcn_rcpf(ACT ? fmaf(n, as.l2e, as.l2e2) : fmaf(n, LOG2E, 2.f * LOG2E));
-  return fmaf(yl, q, addend);
-}
 
 // GroupNorm-epilogue parameters of a conv for the lane's NT adjacent channels.  They are REQUESTED BEFORE the conv's taps (the
 // stage bodies call epi_load ahead of the weight ring): read inside the epilogue they cost every conv an exposed L2 round trip
@@ -127,7 +115,7 @@ __device__ __forceinline__ f32x2_t gn_mish2(f32x2_t x, const GnCoef& c, f32x2_t 
 
 // Dynamic f16x2 input scale of a conv whose input is NOT bounded by a GroupNorm (the input of a ResidualTemporalBlock: the
 // residual stream, which follows the magnitude of the network input): per sample, from the exact maximum M of the conv's
-// input tile, s = 2^(10 - floor(log2 M)), so that every Winograd-transformed value |V| <= 15 M s < 30720 fits fp16 whatever
+// input tile, s = 2^(10 - floor(log2 M)), so that every value |x| s < 2048 (< 30720 with Winograd's factor 15, rounds 1-2) fits fp16 whatever
 // the input's magnitude, and the values that matter (within 2^-13 of the maximum) keep both pieces normal.  inv = 1 / s.
 struct DynScale { float s, inv; };
 __device__ __forceinline__ DynScale dyn_scale(float M) {
@@ -178,65 +166,6 @@ __device__ unsigned long long* g_trace = nullptr;
 #define TR(tag) do { } while (0)
 #endif
 
-template <int MT_W>
-__device__ __forceinline__ void load_a(float (&a)[4][MT_W], const float* slab, const int (&abase)[MT_W], int aoff) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt) a[q][mt] = slab[abase[mt] + aoff + q * 2];
-}
-
-template <int MT_W>
-__device__ __forceinline__ void mfma_a(f32x16 (&acc)[MT_W], const float (&a)[4][MT_W], const float4 b) {
-  const float bq[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][mt], bq[q], acc[mt], 0, 0, 0);
-}
-
-// A fragments are double-buffered in registers (the LDS reads of k-group g+1 are issued before the 4*MT_W MFMAs of
-// group g), B fragments ride a 4-deep register ring fed straight from L2: a lone wave keeps the matrix pipe busy, so a
-// co-resident wave's epilogue overlaps instead of stalling it.
-template <int NTAPS, int CP, int STR, int MT_W>
-__device__ __forceinline__ void mfma_taps(f32x16 (&acc)[MT_W], const float* slab, const int (&abase)[MT_W],
-                                          const float4* __restrict__ wp) {
-  constexpr int GPT = CP / 8;   // k-groups (of 4 k-pairs) per tap
-  static_assert(GPT % 4 == 0, "k-groups are unrolled by the ring depth");
-  {
-    const float4* p = wp;
-    float4 b0 = p[0], b1 = p[64], b2 = p[128], b3 = p[192];
-    float a0[4][MT_W], a1[4][MT_W];
-    load_a<MT_W>(a0, slab, abase, 0);
-#pragma unroll
-    for (int tap = 0; tap < NTAPS; ++tap) {
-#pragma unroll 1
-      for (int cg = 0; cg < GPT; cg += 4) {
-        p += 256;
-        const int aoff = tap * STR + cg * 8;
-        // offset of the group after this chunk: next chunk of the same tap, or the first group of the next tap
-        const int anext = cg + 4 < GPT ? aoff + 32 : (tap + 1) * STR;
-        load_a<MT_W>(a1, slab, abase, aoff + 8);
-        mfma_a<MT_W>(acc, a0, b0);
-        b0 = p[0];
-        MMD_PIN_LOADS();
-        load_a<MT_W>(a0, slab, abase, aoff + 16);
-        mfma_a<MT_W>(acc, a1, b1);
-        b1 = p[64];
-        MMD_PIN_LOADS();
-        load_a<MT_W>(a1, slab, abase, aoff + 24);
-        mfma_a<MT_W>(acc, a0, b2);
-        b2 = p[128];
-        MMD_PIN_LOADS();
-        load_a<MT_W>(a0, slab, abase, anext);      // (after the last group this reads a valid slab row and is unused)
-        mfma_a<MT_W>(acc, a1, b3);
-        b3 = p[192];
-        MMD_PIN_LOADS();
-      }
-    }
-  }
-}
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {   // v + v[DPP-permuted lane] in one VALU op
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -246,9 +175,9 @@ enum { TAIL_NONE = 0, TAIL_DOWN = 1, TAIL_UP = 2 };
 constexpr int MAX_IDENT = 3;
 
 struct RtbPtrs {
-  const float4* wa; const float* ba; const float* ga; const float* bea; const float* tb;
-  const float4* wb; const float* bb; const float* gb; const float* beb;
-  const uint4* wa_bf; const uint4* wb_bf;   // f16x2 packs of the same convs (C -> C convs of the down stages + mid, ups.0 conv A)
+  const float* ba; const float* ga; const float* bea; const float* tb;   // conv A: bias, GroupNorm weight / bias, time bias [C_out]
+  const float* bb; const float* gb; const float* beb;                    // conv B
+  const uint4* wa_bf; const uint4* wb_bf;   // f16x2 packs of the two convs
   const float* isa; const float* isb;       // [C_out] inverse per-channel weight scales of the f16x2 packs (isb: / act_a)
   float act_a;                              // static power-of-two scale of conv A's output activations = conv B's f16x2 input
 };
@@ -256,16 +185,15 @@ struct RtbPtrs {
 struct ChainArgs {
   const float* in0;                      // [n, L, C0] network input (first chain only)
   RtbPtrs r0;
-  const float4* wa0_c1;                  // conv A pack of the second input chunk (C1 > 0)
-  const uint4* wa0_c1_bf;                // ... its f16x2 form (ups.0: vbu_taps)
-  const float* br;                       // bias of the 1x1 residual conv (its weights ride in the conv A packs)
-  const float* isr;                      // [C_out] inverse scale of the residual weights in the f16x2 packs
-  const uint4* wres_bf;                  // f16x2 pack of the 1x1 residual conv (downs.1 / downs.2 / ups.0 chunk 0)
-  const uint4* wres_c1_bf;               // ... of the second input chunk (ups.0)
-  const uint4* wt_bf0; const uint4* wt_bf1;   // f16x2 packs of the two parity passes of the transposed tail conv (ups.0)
+  const uint4* wa0_c1_bf;                // conv A pack of the second input chunk (up stages: cat(x, skip))
+  const float* br;                       // bias of the 1x1 residual conv
+  const float* isr;                      // [C_out] inverse scale of the residual weights in their f16x2 pack
+  const uint4* wres_bf;                  // f16x2 pack of the 1x1 residual conv (first input chunk)
+  const uint4* wres_c1_bf;               // ... of the second input chunk (up stages)
+  const uint4* wt_bf0; const uint4* wt_bf1;   // f16x2 pack(s) of the tail conv: Downsample1d, or the two parity passes of Upsample1d
   const float* ist0; const float* ist1;       // ... their inverse channel scales
   RtbPtrs ri[MAX_IDENT];
-  const float4* wt; const float* bt;     // tail conv pack(s), bias
+  const float* bt;                       // tail conv bias
   int n;
 };
 
@@ -295,41 +223,6 @@ struct ChainCfg {
   static_assert(N_IDENT <= MAX_IDENT, "too many identity RTBs");
 };
 
-template <int MT_W>
-__device__ __forceinline__ void fill(f32x16 (&acc)[MT_W], float v) {
-#pragma unroll
-  for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = v;
-}
-
-// A register tile written into a slab laid out for another stage: rows (sample, position) and columns keep their meaning,
-// only the strides change.  SRC gives the producing stage's tiling (which wave owns which samples / channel slice).
-template <int L_SRC, int MT_W, int SW_SRC, int WN_SRC, int ROW_MUL, int DSS, int DSTR>
-__device__ __forceinline__ void tile_to_stage(const f32x16 (&t)[MT_W], float* dst, int wave, int lane, int row_add) {
-  static_assert(L_SRC % 8 == 0, "rows r and r + 4 (the two half-waves) must belong to the same sample");
-  const int wm = wave / WN_SRC, col = (wave % WN_SRC) * 32 + (lane & 31), hi = lane >> 5;
-  // one runtime base (sample block of the wave, column, half-wave, row parity), compile-time offsets per register:
-  // every store is a ds_write_b32 with an immediate offset, no per-element address arithmetic
-  float* base = dst + wm * SW_SRC * DSS + (ROW_MUL * 4 * hi + row_add + 2) * DSTR + col;
-#pragma unroll
-  for (int mt = 0; mt < MT_W; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2);          // + 4 * hi, which never crosses a sample
-      base[(row / L_SRC) * DSS + ROW_MUL * (row % L_SRC) * DSTR] = t[mt][r];
-    }
-}
-
-template <int CP, int L, int SROWS, int STR, int SS, int SPB, int NTHR = 256>
-__device__ __forceinline__ void zero_halo(float* slab) {
-  constexpr int TOT = SPB * 4 * CP;
-  for (int idx = threadIdx.x; idx < TOT; idx += NTHR) {
-    const int c = idx % CP, hr = (idx / CP) % 4, s = idx / (CP * 4);
-    slab[s * SS + (hr < 2 ? hr : L + hr) * STR + c] = 0.f;
-  }
-}
-
 // sum over the CPG adjacent lanes (channels) of a GroupNorm group, same value in all of them
 template <int CPG>
 __device__ __forceinline__ float group_colsum(float v) {
@@ -340,23 +233,7 @@ __device__ __forceinline__ float group_colsum(float v) {
   return v;
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// Winograd F(4,5) (downs.1's convs): four outputs from eight products instead of twenty (points 0, +-1, +-2, +-1/2, inf).  A
-// GEMM row is (sample, quad t) = rows 4t .. 4t+3 of a sample; in the 16x16 C/D layout lane = 16 * (row / 4) + column,
-// register = row % 4 = quad, so a lane holds 16 consecutive positions of one (sample, channel) in 4 outputs x 4 registers
-// (at L = 32 two row blocks per sample).  Weights are transformed in fp64 on the host (pack_vbd).
-// ----------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// sum over a GroupNorm group of a quad tile: CPG adjacent lanes (channels) of a 16-lane DPP row x all L positions -- the
-// lane's own 16 and, for L = 32 / 64, those of the lanes 16 / 32 / 48 further (QB = 2 / 4 row blocks per sample)
-template <int CPG, int QB>
-__device__ __forceinline__ float quad_groupsum(float v) {
-  v = group_colsum<CPG>(v);
-  if constexpr (QB >= 2) v += __shfl_xor(v, 16);
-  if constexpr (QB == 4) v += __shfl_xor(v, 32);
-  return v;
-}
 
 //                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
 using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
@@ -367,18 +244,17 @@ using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // LDS of a workgroup: the largest stage is downs.2 / ups.0 -- the row-form fp32 x slab of downs.2's input + the 128-channel Rd
-// slab (2 x 21504 B) behind it; downs.1 (x slab + phase slab + raw slab of its first conv) and the four private slabs of the
-// wave-private stages (downs.0, ups.1 + final block) fit below it (static_asserts in the stage bodies).
+// slab (2 x 21504 B) behind it; downs.1 (input slab + 64-channel slab) and the four private slabs of the wave-private stages
+// (downs.0, ups.1 + final block) fit below it (static_asserts in the stage bodies).
 constexpr int MX_OFF = ((CH_D2::SPB * CH_D2::XSS * 4 + 255) / 256 * 256 + 43008) / 4 + 8;
-static_assert(MX_OFF >= CH_D1::LDS_FLOATS, "stage slabs");
 // + the per-sample maxima of the dynamic input scales + the second part of downs.2's lane-private residual parking area (the
 // first part is the stage's dead x slab: 5 + 3 float4 per thread)
 constexpr int PARK2_OFF = MX_OFF + MX_FLOATS;
 constexpr int UNET_LDS_FLOATS = PARK2_OFF + 3 * 256 * 4;
 
 // ----------------------------------------------------------------------------------------------------------------
-// fp32 GEMM on the fp16 matrix pipe ("f16x2"): every conv of the network but downs.1's strided tail.  Every fp32 operand is split into TWO fp16 pieces by rounding to nearest,
-// x0 = RN16(x), x1 = RN16(x - x0) (x - x0 is exact in fp32; |x - x0 - x1| <= 2^-24 |x|, half an fp32 ulp, as long as x1 stays
+// fp32 GEMM on the fp16 matrix pipe ("f16x2"): every conv of the network.  Every fp32 operand is split into TWO fp16 pieces
+// by rounding to nearest, x0 = RN16(x), x1 = RN16(x - x0) (x - x0 is exact in fp32; |x - x0 - x1| <= 2^-24 |x|, half an fp32 ulp, as long as x1 stays
 // above fp16's denormal step 2^-24), and a product a * w is accumulated as a1 w0 + a0 w1 + a0 w0 (low order first) on
 // v_mfma_f32_16x16x32_f16 with fp32 accumulation; the dropped a1 w1 is <= 2^-24 |a w|.  Measured against fp64 the result is
 // more accurate than the fp32 MFMA chain it replaces and than the three-piece bf16 split of round 2
@@ -387,34 +263,17 @@ constexpr int UNET_LDS_FLOATS = PARK2_OFF + 3 * 256 * 4;
 // MFMAs per K = 32 chunk, 1/5 of the fp32 MFMA's) and 4 instead of 6 bytes per weight.  fp16 has five exponent bits:
 // gfx950's MFMA honours fp16 denormal inputs (probed in the same ubench), so a low piece below 2^-14 keeps an ABSOLUTE
 // precision of 2^-25; the weights of every output channel are scaled on the host by a power of two that puts the channel's
-// largest |U| into [2^14, 2^15) (exact; undone for free inside the GroupNorm epilogue, `isc`), and conv inputs (GroupNorm +
-// Mish outputs, V = B^T d of them) sit around 1, where the low pieces are normal or within 2^-25 of it (error 1.5e-7 down to
-// rms 0.2; 7.7e-7 at rms 0.02, same ubench).  |V| must stay below 65504.
+// largest |w| into [2^14, 2^15) (exact; undone for free inside the GroupNorm epilogue, `isc`), and conv inputs carry a static
+// (conv B) or dynamic per-sample (conv A) power-of-two scale that keeps them below 2048 and their low pieces normal or within
+// 2^-25 of it (ActScale / dyn_scale below).
 // Three MFMAs on ONE accumulator issue back to back without a bubble, while an MFMA that depends on the one two
 // before it waits (ubench: 8 accumulators x 3 in a row 17.2 cycles per MFMA, two alternating accumulators 30): a step
-// runs its accumulator streams one after the other, and consecutive steps go to different accumulators (chunk-major).
-//
-// The V slab (Winograd-transformed conv input) holds the pieces channel-innermost, the A fragment of the K = 32 MFMA:
-//     Vb[piece q][slot s][channel block c / 8][row' = 4 * quad + sample][c % 8]    (fp16)
-// so a lane's A operand (one row, 8 channels) is ONE ds_read_b128.  Bank-conflict freedom, for the lane groups the LDS
-// services a wave's access in (MI355X_MICROARCH.md, LDS): a K = 32 chunk kc is the four channel blocks kc, kc + 4, kc + 8,
-// kc + 12 (lane group lane >> 4 = block kc + 4 (lane >> 4)), which lie VB_CG = a multiple of 256 B apart, so the rows a
-// 16-lane read group takes from two of them fall on disjoint banks; the blocks c, c + 1 (c & 3) of one such group lie
-// 256 + 32 B apart and the rows are ordered quad-major, so the epilogue's ds_write_b32 -- lanes = (4 adjacent channel
-// pairs) x (4 channel blocks c & 3) x (2 samples), one quad per instruction -- hit 32 distinct banks per 32-lane group.
-// A conv runs in two PHASES over the position sets {0, 1, 2, 7} and {3, 4, 5, 6} (slots 0..3 of a phase; neither set shares
-// a partial sum of B^T or A^T with the other): store set 0 -- barrier -- MFMAs -- barrier -- store set 1 -- barrier -- MFMAs; the
-// conv's input tile waits in registers meanwhile (all eight positions at once would need 128 accumulator registers).
-// What bounds these convs is the weight stream, not the matrix pipe: a workgroup has only 16 rows (4 samples x 4 quads)
-// to use a weight fragment on.
-// Weights: per n-tile and conv [phase][step = 4 chunk + slot][piece q] fragments of 64 lanes x 16 B (lane = column lane & 15,
-// channel block kc + 4 (lane >> 4)), streamed through a register ring.
+// runs its accumulator streams one after the other (vb_three keeps a triple together).
 // ----------------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__host__ __device__ constexpr int vb_pos(int ph, int slot) { return ph == 0 ? (slot == 3 ? 7 : slot) : 3 + slot; }
 
 // the two pieces of a pair of values (v0: the even channel) as dwords {v1 piece, v0 piece}: hi = RN16(v), lo = RN16(v - hi)
 struct F16Pair { unsigned hi, lo; };
@@ -447,499 +306,13 @@ __device__ __forceinline__ void vb_three(f32x4& x, const u32x4 (&a)[2], const u3
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-// Geometry of a phase slab of C channels at L = 16 (16 rows): C / 8 channel blocks; K chunk kc (of KC = C / 32), lane group j
-// = block kc + KC j at byte j * G + kc * X of a (piece, slot) region of PS bytes -- the blocks of one chunk lie G = a
-// multiple of 256 B apart (conflict-free b128 reads), those of one lane group X = 256 + 32 B.
-template <int C, int L> struct VbGeoL {        // L rows (4 samples x L / 4 quads) per channel block
-  static constexpr int KC = C / 32, X = L * 16 + 32, G = (KC * X + 255) / 256 * 256, PS = 4 * G, STEPS = 4 * KC;
-  static constexpr int BYTES = 8 * PS, FRAGS = 2 * STEPS * 2;
-};
-#ifndef MMD_VB_RD
-#define MMD_VB_RD 2
-#endif
-constexpr int VB_RD = MMD_VB_RD;           // weight ring depth in steps of the Winograd-form f16x2 convs (downs.1)
-
-// ---- a stage's FIRST conv (conv A of its first RTB) as f16x2: the input arrives as a row-form fp32 slab [sample][L + 4][STR]
-// (2-row zero halo) from the previous stage's strided conv; all 256 threads turn it into the conv's phase slab -- V = B^T d
-// of phase PH's four positions, scaled by the sample's dynamic input scale, two pieces -- and (with phase 0) into the RAW slab
-// of the stage's 1x1 residual conv: the untransformed positions themselves, laid out as four M tiles o = position % 4 with
-// rows (sample, quad), so that the residual GEMM's C/D fragment is the res tile (res[o][quad] of (sample, channel)).  One
-// item = (sample, quad, channel pair): 8 ds_read_b64, ~40 VALU, 8 (+ 8) ds_write_b32 -- once per workgroup, where the
-// in-loop transform of the fp32 form cost every wave 26 VALU + 8 ds_read_b32 per k-step and n-tile.
-template <int PH>
-__device__ __forceinline__ void w4_phase(float (&v)[4], const float (&d)[8]) {   // slots 0..3 of phase PH (w4_transform's rows)
-  if constexpr (PH == 0) {
-    const float e1 = fmaf(-4.25f, d[4], d[2]) + d[6], o1 = fmaf(-4.25f, d[3], d[1]) + d[5];
-    v[0] = fmaf(5.25f, d[2] - d[4], d[6] - d[0]);
-    v[1] = e1 + o1;
-    v[2] = e1 - o1;
-    v[3] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
-  } else {
-    const float e2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), o2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
-    const float e3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), o3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
-    v[0] = e2 + o2;
-    v[1] = e2 - o2;
-    v[2] = e3 + o3;
-    v[3] = e3 - o3;
-  }
-}
-template <int C, int L> struct VrGeoL {        // raw slab of the residual GEMM: 4 position classes o x L rows x 16 B per channel block
-  static constexpr int KC = C / 32, X = 4 * L * 16 + 32, G = (KC * X + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
-};
-template <int PH, int C, int L, int XSS, int XSTR>
-__device__ __forceinline__ void rowform_to_vslab(const float* xslab, char* vphase, char* vraw, const float* mx) {
-  using GEO = VbGeoL<C, L>;
-  using GR = VrGeoL<C, L>;
-  constexpr int CP2 = C / 2, QPS = L / 4, ITEMS = L * CP2;      // (sample, quad) x channel pairs
-  static_assert(ITEMS % 256 == 0 && XSTR % 2 == 0, "items per thread; 8-byte aligned channel pairs");
-#pragma unroll
-  for (int it = 0; it < ITEMS / 256; ++it) {
-    const int idx = it * 256 + threadIdx.x;
-    const int cp = idx % CP2, row = idx / CP2, smp = row / QPS, quad = row % QPS;   // row = QPS * sample + quad = GEMM row
-    const float4 p = *reinterpret_cast<const float4*>(mx + smp * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + smp * MX_SLOTS + 4);
-    const float sc = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)))).s;
-    const float* src = xslab + smp * XSS + 4 * quad * XSTR + 2 * cp;                 // slab row 4 quad = position 4 quad - 2
-    float d[8], e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float2 t = *reinterpret_cast<const float2*>(src + j * XSTR);
-      d[j] = t.x * sc;
-      e[j] = t.y * sc;
-    }
-    const int blk = cp >> 2, jg = blk / GEO::KC, kc = blk % GEO::KC;
-    char* dst = vphase + jg * GEO::G + kc * GEO::X + row * 16 + (cp & 3) * 4;
-    float v[4], w[4];
-    w4_phase<PH>(v, d);
-    w4_phase<PH>(w, e);
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      const F16Pair f = f16_split2(v[sl], w[sl]);
-      *reinterpret_cast<unsigned*>(dst + sl * GEO::PS) = f.hi;
-      *reinterpret_cast<unsigned*>(dst + (4 + sl) * GEO::PS) = f.lo;
-    }
-    if constexpr (PH == 0) {
-      char* dr = vraw + jg * GR::G + kc * GR::X + row * 16 + (cp & 3) * 4;
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {                 // position 4 quad + o = slab row 4 quad + 2 + o -> position class o
-        const F16Pair f = f16_split2(d[2 + o], e[2 + o]);
-        *reinterpret_cast<unsigned*>(dr + o * L * 16) = f.hi;
-        *reinterpret_cast<unsigned*>(dr + GR::PS + o * L * 16) = f.lo;
-      }
-    }
-  }
-}
-// the same GEMM for one n-tile x the two M tiles of an L = 32 stage (downs.1): res[M tile][o]
-template <int C, int L>
-__device__ __forceinline__ void vr_taps_m2(f32x4 (&res)[2][4], const char* vr, const u32x4* w) {
-  using GR = VrGeoL<C, L>;
-#pragma unroll
-  for (int kc = 0; kc < GR::KC; ++kc) {
-    u32x4 b[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) b[q] = w[(kc * 2 + q) * 64];
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        u32x4 a[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) a[q] = *reinterpret_cast<const u32x4*>(vr + q * GR::PS + kc * GR::X + o * L * 16 + mt * 256);
-        if (kc == 0) vb_three<true>(res[mt][o], a, b);
-        else vb_three<false>(res[mt][o], a, b);
-      }
-  }
-}
-// ----------------------------------------------------------------------------------------------------------------
-// One-n-tile quad tiles (downs.1): output transform, GroupNorm + Mish, store to a row-form slab.
-// ----------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void w4n1_out(f32x4 (&q)[4], const f32x4 (&m)[8]) {
-  const f32x4 s1 = m[1] + m[2], t1 = m[1] - m[2];
-  const f32x4 s2 = m[3] + m[4], t2 = m[3] - m[4];
-  const f32x4 s3 = m[5] + m[6], t3 = m[5] - m[6];
-  q[0] = (m[0] + s1) + (s2 + s3);
-  q[1] = t1 + 2.f * t2 + 0.5f * t3;
-  q[2] = s1 + 4.f * s2 + 0.25f * s3;
-  q[3] = (t1 + m[7]) + (8.f * t2 + 0.125f * t3);
-}
-// isc (SCALED): the conv ran as f16x2 on weights scaled per output channel -- q is the true output times 1 / isc; the
-// factor is folded into the statistics and the affine coefficient (two more VALU ops per tile, none per element).
-template <int CM, int L, bool SCALED = false, bool ACT = false, class ADD>
-__device__ __forceinline__ void gn_mish_quad1(f32x4 (&q)[4], float bias, float gamma, float beta, ADD add, float isc = 1.f,
-                                              const ActScale& as = ActScale{}) {
-  constexpr int CPG = CM / 8, QB = L / 16;
-  constexpr float inv_n = 1.f / (float)(L * CPG);
-  float sum = 0.f;
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sum += q[o][r];
-  if constexpr (SCALED) sum *= isc;
-  const float dm = (quad_groupsum<CPG, QB>(sum) + group_colsum<CPG>(bias) * (float)L) * inv_n - bias;
-  float sq = 0.f;
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float d = SCALED ? fmaf(q[o][r], isc, -dm) : q[o][r] - dm;
-      sq = fmaf(d, d, sq);
-    }
-  GnCoef cf = gn_coef(dm, rsqrtf(quad_groupsum<CPG, QB>(sq) * inv_n + 1e-5f), gamma, beta);
-  if constexpr (SCALED) cf.sa *= isc;
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) q[o][r] = gn_mish1<ACT>(q[o][r], cf, add(o, r), as);
-}
-// one-n-tile quad tile of unit (M tile mt, n-tile nq) -> row-form slab [sample][2 + position][DSTR]
-template <int L, int CM, int DSS, int DSTR>
-__device__ __forceinline__ void quad1_to_stage_u(const f32x4 (&q)[4], float* dst, int mt, int nq, int lane) {
-  constexpr int QB = L / 16, SPT = 4 / QB;
-  const int smp = mt * SPT + (lane >> 4) / QB, qb = (lane >> 4) % QB;
-  float* base = dst + smp * DSS + (16 * qb + 2) * DSTR + nq * 16 + (lane & 15);
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) base[(4 * r + o) * DSTR] = q[o][r];
-}
 
 // ----------------------------------------------------------------------------------------------------------------
-// downs.1 (L = 32, 64 channels): its convs in the Winograd F(4,5) f16x2 form, two position phases per conv.  The stage's
-// output is L / 16 M tiles x C / 16 n-tiles = 8 units; a wave owns ONE n-tile and TWO M tiles -- the two accumulator
-// streams of a step, so a weight fragment is used twice.  A lane of the C/D fragment then holds one
-// channel x 16 consecutive positions (a half / a quarter of a sample) in each M tile; for the dword stores of the slab the
-// lanes of a pair (n, n ^ 1) swap one tile by DPP, so that the even lane holds channels (c, c + 1) of the first M tile
-// and the odd lane those of the second, and the two positions either side of the lane's 16 come from lane -+ 16 (the
-// neighbouring part of the sample).  Slab: rows = 16 mt + i (the MFMA row order), L rows x 16 B per 8-channel block;
-// the blocks c, c + 1 of an n-tile lie L * 16 + 32 B apart, block pairs a multiple of 256 B, and the two channel-block
-// groups (lane >> 4) that a 16-lane b128 read group spans are blocks of different pairs at the same position in the pair:
-// reads conflict-free, b32 stores 2-way (free).  K chunk kc (of two) = blocks kc, kc + 2, kc + 4, kc + 6.
-// ----------------------------------------------------------------------------------------------------------------
-template <int L, int CM> struct DbGeo {
-  static constexpr int KC = CM / 32, NTQ = CM / 16, QB = L / 16;        // K chunks, n-tiles, lane groups per sample
-  static constexpr int X = L * 16 + 32;                                 // bytes between the blocks of a pair
-  static constexpr int G = (2 * X + 255) / 256 * 256;                   // bytes between block pairs
-  static constexpr int PS = 2 * KC * G;                                 // bytes per (piece, slot)
-  static constexpr int STEPS = 4 * KC;                                  // (chunk, slot) steps per phase: step = 4 chunk + slot
-  static constexpr int FRAGS = 2 * STEPS * 2;                           // weight fragments per n-tile and conv
-  static_assert(8 * PS <= MX_OFF * 4, "the phase slab must fit below the maxima");
-  // channel block of (chunk kc, lane group j): pair index and position in the pair
-  __host__ __device__ static constexpr int pair_of(int kc, int j) { return KC == 2 ? j : (j & 1); }
-  __host__ __device__ static constexpr int half_of(int kc, int j) { return KC == 2 ? kc : (j >> 1); }
-};
-
-template <class GEO>
-__device__ __forceinline__ void vbd_load_b(u32x4 (&b)[2], const u32x4* w, int ph, int step) {
-  const u32x4* p = w + ((ph * GEO::STEPS + step) * 2) * 64;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) b[q] = p[q * 64];
-}
-// va = slab + the lane's (pair, [position in the pair for one-chunk stages], first M tile's row lane & 15) offset
-template <class GEO>
-__device__ __forceinline__ void vbd_load_a(u32x4 (&a)[2][2], const char* va, int step) {   // step = 4 chunk + slot
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      a[mt][q] = *reinterpret_cast<const u32x4*>(va + (q * 4 + step % 4) * GEO::PS +
-                                                 (GEO::KC == 2 ? (step / 4) * GEO::X : 0) + mt * 256);
-}
-template <class GEO, int PH>
-__device__ __forceinline__ void vbd_ring_load(u32x4 (&b)[VB_RD][2], const u32x4* w) {
-#pragma unroll
-  for (int i = 0; i < VB_RD; ++i) vbd_load_b<GEO>(b[i], w, PH, i);
-  MMD_PIN_LOADS();
-}
-// m[M tile][position] of phase PH's four positions = conv over the slab's channels (the two M tiles of a step share the
-// weight fragment: two accumulator streams, one after the other)
-template <class GEO, int PH>
-__device__ __forceinline__ void vbd_taps(f32x4 (&m)[2][8], const char* va, const u32x4* w, u32x4 (&b)[VB_RD][2]) {
-  u32x4 a[2][2][2];
-  vbd_load_a<GEO>(a[0], va, 0);
-#pragma unroll
-  for (int i = 0; i < GEO::STEPS; ++i) {
-    if (i + 1 < GEO::STEPS) vbd_load_a<GEO>(a[(i + 1) & 1], va, i + 1);
-    MMD_PIN_LOADS();
-    const int pos = vb_pos(PH, i % 4);
-    if (i / 4 == 0) {
-      vb_three<true>(m[0][pos], a[i & 1][0], b[i % VB_RD]);
-      vb_three<true>(m[1][pos], a[i & 1][1], b[i % VB_RD]);
-    } else {
-      vb_three<false>(m[0][pos], a[i & 1][0], b[i % VB_RD]);
-      vb_three<false>(m[1][pos], a[i & 1][1], b[i % VB_RD]);
-    }
-    if (i + VB_RD < GEO::STEPS) vbd_load_b<GEO>(b[i % VB_RD], w, PH, i + VB_RD);
-    MMD_PIN_LOADS();
-  }
-}
-// The lane's two tiles P (own channel), Q (pair partner's channel) of its M tile, with the two positions before / after
-// its 16: phase PH of their V transforms -> the slab (sel orders the pair: even lane P = low channel, odd lane Q).
-template <class GEO, int PH>
-__device__ __forceinline__ void vbd_store(char* base, const f32x4 (&P)[4], const float (&pp)[2], const float (&pn)[2],
-                                          const f32x4 (&Q)[4], const float (&qp)[2], const float (&qn)[2], unsigned sel) {
-  constexpr int PS = GEO::PS;
-  auto put2 = [&](char* p, int slot, float v0, float v1) {   // the two pieces of the pair at slot `slot`
-    const F16Pair f = f16_split2(v0, v1);
-    *reinterpret_cast<unsigned*>(p + slot * PS) = __builtin_amdgcn_perm(f.hi, f.hi, sel);
-    *reinterpret_cast<unsigned*>(p + (4 + slot) * PS) = __builtin_amdgcn_perm(f.lo, f.lo, sel);
-  };
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float d[8], e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pos = 4 * r - 2 + j;
-      d[j] = pos < 0 ? pp[pos + 2] : (pos > 15 ? pn[pos - 16] : P[pos & 3][pos >> 2]);
-      e[j] = pos < 0 ? qp[pos + 2] : (pos > 15 ? qn[pos - 16] : Q[pos & 3][pos >> 2]);
-    }
-    char* p = base + r * 16;
-    if constexpr (PH == 0) {
-      const float de1 = fmaf(-4.25f, d[4], d[2]) + d[6], do1 = fmaf(-4.25f, d[3], d[1]) + d[5];
-      const float ee1 = fmaf(-4.25f, e[4], e[2]) + e[6], eo1 = fmaf(-4.25f, e[3], e[1]) + e[5];
-      put2(p, 0, fmaf(5.25f, d[2] - d[4], d[6] - d[0]), fmaf(5.25f, e[2] - e[4], e[6] - e[0]));
-      put2(p, 1, de1 + do1, ee1 + eo1);
-      put2(p, 2, de1 - do1, ee1 - eo1);
-      put2(p, 3, fmaf(5.25f, d[3] - d[5], d[7] - d[1]), fmaf(5.25f, e[3] - e[5], e[7] - e[1]));
-    } else {
-      const float de2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), do2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
-      const float de3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), do3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
-      const float ee2 = fmaf(0.25f, e[2], fmaf(-1.25f, e[4], e[6])), eo2 = fmaf(0.5f, e[1], fmaf(-2.5f, e[3], 2.f * e[5]));
-      const float ee3 = fmaf(4.f, e[2], fmaf(-5.f, e[4], e[6])), eo3 = fmaf(2.f, e[1], fmaf(-2.5f, e[3], 0.5f * e[5]));
-      put2(p, 0, de2 + do2, ee2 + eo2);
-      put2(p, 1, de2 - do2, ee2 - eo2);
-      put2(p, 2, de3 + do3, ee3 + eo3);
-      put2(p, 3, de3 - do3, ee3 - eo3);
-    }
-    asm volatile("" ::: "memory");
-  }
-}
-
-template <class CF, bool TAIL_MAX>
-__device__ __forceinline__ void chain_body_db(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[2][4],
-                                              f32x4 (&mid)[2][4], f32x16 (&tout)[1], int trb) {
-  static_assert(CF::L == 32 && CF::CM * CF::L == 2048 && CF::C0 % 32 == 0 && CF::C1 == 0 && CF::RES0 == RES_CONV &&
-                    CF::N_IDENT == 1 && CF::TAIL == TAIL_DOWN, "downs.1");
-  using GEO = DbGeo<CF::L, CF::CM>;
-  constexpr int QB = GEO::QB;                                   // quads / lane groups per sample
-  float* hslab = lds + CF::XSLAB;                            // row-form H slab of the tail conv
-  const int nq = wave % GEO::NTQ, mt0 = 2 * (wave / GEO::NTQ);          // the wave's n-tile and first M tile
-  const int col = 16 * nq + (lane & 15);                     // the lane's channel
-  // conv A of the first RTB (32 -> 64) + the 1x1 residual conv as f16x2 from the row-form x slab (rowform_to_vslab)
-  using GA = VbGeoL<CF::C0P, CF::L>;
-  using GR = VrGeoL<CF::C0P, CF::L>;
-  constexpr int VA_OFF = (CF::SPB * CF::XSS * 4 + 255) / 256 * 256, VR_OFF = VA_OFF + GA::BYTES;
-  static_assert(VR_OFF + GR::BYTES <= MX_OFF * 4, "x slab + phase slab + raw slab must fit below the maxima");
-  const u32x4* const wpa = reinterpret_cast<const u32x4*>(a.r0.wa_bf) + (size_t)nq * GA::FRAGS * 64 + lane;
-  const u32x4* const wpr = reinterpret_cast<const u32x4*>(a.wres_bf) + (size_t)nq * (2 * GR::KC) * 64 + lane;
-  u32x4 ring_a[VB_RD][2];
-  vbd_ring_load<GA, 0>(ring_a, wpa);
-  __syncthreads();                                           // the x slab is staged
-  TR(trb + 0);
-
-  f32x4 res[2][4];
-  char* const vb = reinterpret_cast<char*>(lds);             // the f16x2 phase slab aliases the x and H slabs
-  const int jg = lane >> 4;
-  const char* const vb_a = vb + GEO::pair_of(0, jg) * GEO::G + (GEO::KC == 1 ? GEO::half_of(0, jg) * GEO::X : 0) +
-                           (16 * mt0 + (lane & 15)) * 16;
-  const int odd = lane & 1, gs = jg % QB;                    // pair position; the lane group's place in its sample
-  char* const vb_s = vb + nq * GEO::G + ((lane & 15) >> 3) * GEO::X + (16 * (mt0 + odd) + 4 * jg) * 16 + ((lane & 7) >> 1) * 4;
-  const unsigned sel = odd ? 0x01000302u : 0x03020100u;     // odd lanes hold (Q, P) = (high, low): swap the halves
-  auto conv_hb = [&](const uint4* w) {
-    const u32x4* wp = reinterpret_cast<const u32x4*>(w) + (size_t)nq * GEO::FRAGS * 64 + lane;
-    u32x4 ring_b[VB_RD][2];
-    vbd_ring_load<GEO, 0>(ring_b, wp);
-    // pair exchange: P = the lane's own channel in ITS M tile (even lane: the first, odd: the second), Q = the partner's
-    f32x4 P[4], Q[4];
-    float pp[2], pn[2], qp[2], qn[2];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float send = odd ? acc[0][o][r] : acc[1][o][r];
-        Q[o][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));
-        P[o][r] = odd ? acc[1][o][r] : acc[0][o][r];
-      }
-    }
-    {
-      // the two positions before the lane's 16 are the last two of lane - 16, the two after the first two of lane + 16;
-      // outside the sample: the conv's zero padding
-      const bool hp = gs > 0, hn = gs < QB - 1;
-      const float p0 = __shfl_up(P[2][3], 16), p1 = __shfl_up(P[3][3], 16), p2 = __shfl_down(P[0][0], 16), p3 = __shfl_down(P[1][0], 16);
-      const float q0 = __shfl_up(Q[2][3], 16), q1 = __shfl_up(Q[3][3], 16), q2 = __shfl_down(Q[0][0], 16), q3 = __shfl_down(Q[1][0], 16);
-      pp[0] = hp ? p0 : 0.f; pp[1] = hp ? p1 : 0.f; pn[0] = hn ? p2 : 0.f; pn[1] = hn ? p3 : 0.f;
-      qp[0] = hp ? q0 : 0.f; qp[1] = hp ? q1 : 0.f; qn[0] = hn ? q2 : 0.f; qn[1] = hn ? q3 : 0.f;
-    }
-    f32x4 mb[2][8];
-    vbd_store<GEO, 0>(vb_s, P, pp, pn, Q, qp, qn, sel);
-    __syncthreads();
-    vbd_taps<GEO, 0>(mb, vb_a, wp, ring_b);
-    vbd_ring_load<GEO, 1>(ring_b, wp);
-    __syncthreads();                                         // every wave is done reading the phase-0 slab
-    vbd_store<GEO, 1>(vb_s, P, pp, pn, Q, qp, qn, sel);
-    __syncthreads();
-    vbd_taps<GEO, 1>(mb, vb_a, wp, ring_b);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) w4n1_out(acc[mt], mb[mt]);
-  };
-  // GroupNorm + Mish of acc (chain_body_d2's gn, for one channel x two M tiles): conv A (tb != nullptr) + the time bias,
-  // output carried times act_s; conv B + the residual tile.  inv_dyn[mt]: inverse dynamic input scale of tile mt's sample.
-  auto epi = [&](const float* b, const float* g, const float* be, const float* tb, const float* isc) {
-    return epi_load<1>(b, g, be, tb, isc, col);
-  };
-  auto gn = [&](auto conv_a, const Epi<1>& e, const float (&inv_dyn)[2], float act_s) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if constexpr (decltype(conv_a)::value) {
-        const float t0 = e.tb[0] * act_s;
-        gn_mish_quad1<CF::CM, CF::L, true, true>(acc[mt], e.b[0], e.g[0], e.be[0], [&](int, int) { return t0; }, e.is[0] * inv_dyn[mt], act_scale(act_s));
-      } else {
-        gn_mish_quad1<CF::CM, CF::L, true, false>(acc[mt], e.b[0], e.g[0], e.be[0], [&](int o, int r) { return res[mt][o][r]; }, e.is[0] * inv_dyn[mt]);
-      }
-    }
-  };
-  // Dynamic input scale of an identity RTB's conv A: tile mt of the lane belongs to sample smp(mt); the sample's 2048 values
-  // are spread over MX_SLOTS = NTQ x QB (wave, lane group) pairs.
-  float* const mx = lds + MX_OFF;
-  static_assert(GEO::NTQ * QB == MX_SLOTS, "partial maxima per sample");
-  auto smp = [&](int mt) { return (mt0 + mt) * (64 / CF::L) + jg / QB; };
-  auto dyn_out = [&]() {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float m = 0.f;
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(acc[mt][o][r]));
-      m = row_max16(m);
-      if ((lane & 15) == 0) mx[smp(mt) * MX_SLOTS + nq * QB + gs] = m;
-    }
-  };
-  auto dyn_in = [&](float (&inv)[2]) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const float4 p = *reinterpret_cast<const float4*>(mx + smp(mt) * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + smp(mt) * MX_SLOTS + 4);
-      const DynScale ds = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w))));
-#pragma unroll
-      for (int o = 0; o < 4; ++o) acc[mt][o] *= ds.s;
-      inv[mt] = ds.inv;
-    }
-  };
-  const float one2[2] = {1.f, 1.f};
-
-  // =================== RTB 0 (C0 -> CM): conv A + the 1x1 residual conv ===================
-  float inv_in[2] = {1.f, 1.f};
-  {
-    // downs.1: f16x2 (the stage input is residual-stream data: dynamic per-sample scale from the maxima downs.0's tail left)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const float4 p = *reinterpret_cast<const float4*>(mx + smp(mt) * MX_SLOTS), q = *reinterpret_cast<const float4*>(mx + smp(mt) * MX_SLOTS + 4);
-      inv_in[mt] = dyn_scale(fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)))).inv;
-    }
-    char* const va_slab = reinterpret_cast<char*>(lds) + VA_OFF;
-    char* const vr_slab = reinterpret_cast<char*>(lds) + VR_OFF;
-    const char* const va = va_slab + jg * GA::G + (16 * mt0 + (lane & 15)) * 16;
-    const char* const vr = vr_slab + jg * GR::G + (16 * mt0 + (lane & 15)) * 16;
-    f32x4 mb[2][8];
-    const Epi<1> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
-    const float br = a.br[col], isr = a.isr[col];
-    rowform_to_vslab<0, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
-    __syncthreads();
-    vbd_taps<GA, 0>(mb, va, wpa, ring_a);
-    vbd_ring_load<GA, 1>(ring_a, wpa);
-    vr_taps_m2<CF::C0P, CF::L>(res, vr, wpr);
-    __syncthreads();                                         // every wave is done reading the phase-0 slab
-    rowform_to_vslab<1, CF::C0P, CF::L, CF::XSS, CF::XSTR>(lds, va_slab, vr_slab, mx);
-    __syncthreads();
-    vbd_taps<GA, 1>(mb, va, wpa, ring_a);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      w4n1_out(acc[mt], mb[mt]);
-#pragma unroll
-      for (int o = 0; o < 4; ++o) res[mt][o] = res[mt][o] * (isr * inv_in[mt]) + br;
-    }
-    gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
-  }
-  TR(trb + 1);
-  __syncthreads();                                           // conv A is done reading the x slab the phase slab aliases
-  {
-    const Epi<1> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
-    conv_hb(a.r0.wb_bf);
-    gn(std::false_type{}, e, one2, 1.f);
-  }
-  TR(trb + 2);
-  // =================== identity RTB ===================
-  {
-    const RtbPtrs& R = a.ri[0];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) res[mt][i] = acc[mt][i];
-    dyn_out();
-    __syncthreads();                                         // the previous conv is done reading the slab
-    float inv_dyn[2];
-    dyn_in(inv_dyn);
-    const Epi<1> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
-    conv_hb(R.wa_bf);
-    gn(std::true_type{}, ea, inv_dyn, R.act_a);
-    TR(trb + 3);
-    __syncthreads();
-    const Epi<1> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
-    conv_hb(R.wb_bf);
-    gn(std::false_type{}, eb, one2, 1.f);
-    TR(trb + 4);
-    if constexpr (CF::MID_AFTER == 1) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mid[mt][i] = acc[mt][i];
-    }
-  }
-  // =================== tail: Downsample1d = Conv1d(k3, s2, p1), direct on v_mfma_f32_32x32x2_f32, row-form H slab ===================
-  __syncthreads();                                           // the last conv is done reading the phase slab
-  zero_halo<CF::CM, CF::L, CF::SROWS, CF::HSTR, CF::HSS, CF::SPB>(hslab);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) quad1_to_stage_u<CF::L, CF::CM, CF::HSS, CF::HSTR>(acc[mt], hslab, mt0 + mt, nq, lane);
-  __syncthreads();
-  {
-    constexpr int LO = CF::L / 2;
-    const int wm = wave / CF::WN, wn = wave % CF::WN, hi = lane >> 5;
-    fill<1>(tout, a.bt[wn * 32 + (lane & 31)]);
-    const int r = lane & 31;
-    int tb_[1] = {(wm * CF::SW + r / LO) * CF::HSS + (2 * (r % LO) + 1) * CF::HSTR + hi};
-    mfma_taps<3, CF::CM, CF::HSTR, 1>(tout, hslab, tb_, a.wt + ((size_t)wn * (3 * CF::CM / 8)) * 64 + lane);
-    if constexpr (TAIL_MAX) {
-      // the next stage's first conv runs as f16x2 on this tile: per-sample |x| maxima for its dynamic input scale.  The 32
-      // rows of the 32 x 32 C/D fragment are SW samples (registers 0..7 / 8..15 when there are two); a sample is shared by
-      // the WN waves of its channel slices x 4 lane groups (every one of the MX_SLOTS slots is written).
-      static_assert(CF::SW == 1 || CF::SW == 2, "tail tile: one or two samples per wave");
-      float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        m0 = fmaxf(m0, fabsf(tout[0][r8]));
-        m1 = fmaxf(m1, fabsf(tout[0][8 + r8]));
-      }
-      if constexpr (CF::SW == 1) m0 = m1 = fmaxf(m0, m1);
-      m0 = row_max16(m0);
-      m1 = row_max16(m1);
-      if ((lane & 15) == 0) {
-        if constexpr (CF::SW == 2) {
-          static_assert(CF::SW == 1 || CF::WN * 4 == MX_SLOTS, "partial maxima per sample");
-          mx[(wm * 2) * MX_SLOTS + wn * 4 + (lane >> 4)] = m0;
-          mx[(wm * 2 + 1) * MX_SLOTS + wn * 4 + (lane >> 4)] = m1;
-        } else {                                             // one channel slice (WN = 1): its four maxima fill both halves
-          mx[wm * MX_SLOTS + (lane >> 4)] = m0;
-          mx[wm * MX_SLOTS + 4 + (lane >> 4)] = m0;
-        }
-      }
-    }
-  }
-  TR(trb + 5);
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// The L = 16 stages (downs.2 + mid blocks, ups.0) as DIRECT f16x2 convolutions on a row-form slab.  Their convs are bound
-// by the weight stream (a workgroup re-uses a weight fragment on 16 GEMM rows in the Winograd form; the vector-memory path
-// of a CU delivers 64 B/clk), not by the matrix pipe, which at the fp16 rate idles 80 % of a Winograd conv.  The direct
-// form trades 2.5 x the MFMAs (5 taps instead of 8 Winograd positions per 4 outputs) for
+// DIRECT f16x2 convolutions on a row-form slab (downs.1, downs.2 + mid blocks, ups.0; the wave-private stages use the same
+// GEMM loop on per-wave slabs).  In the Winograd F(4,5) form of rounds 1-2 these convs were bound by the weight stream (a
+// workgroup re-uses a weight fragment on 16 GEMM rows; the vector-memory path of a CU delivers 64 B/clk), not by the matrix
+// pipe, which at the fp16 rate idled 80 % of a Winograd conv.  The direct form trades 2.5 x the MFMAs (5 taps instead of 8
+// Winograd positions per 4 outputs) for
 //   * 5 / 8 of the weight bytes, every fragment re-used on 64 GEMM rows (a wave's unit is 1-2 n-tiles x the FOUR M tiles
 //     = samples of the workgroup),
 //   * no position phases: ONE slab store and one barrier pair per conv instead of two stores and four barriers, no input /
@@ -2447,69 +1820,13 @@ static bool build_spec(int uid, int n_levels, Spec& s) {
   return true;
 }
 
-// Pack W(k, n), k = tap_slot * cinp + ci, into MFMA 32x32x2 B-fragment order:
-//   out[((nt*G + g)*64 + lane)*4 + q] = W(2*(4g+q) + (lane>>5), nt*32 + (lane&31))
-// conv weight layout [cout][cin][ks] (transposed == false) or ConvTranspose1d [cin][cout][ks] (transposed == true).
-// c_lo..c_hi selects an input-channel sub-range (one K-chunk of a channel concat); cin is the tensor's full C_in.
-static void pack_b(std::vector<float>& blob, const float* w, int cout, int cin_full, int ks, const std::vector<int>& taps,
-                   bool transposed, int c_lo = 0, int c_hi = -1) {
-  if (c_hi < 0) c_hi = cin_full;
-  const int cin = c_hi - c_lo;
-  const int cinp = (cin + 7) / 8 * 8;
-  const int nt_n = (cout + 31) / 32;
-  const int K = (int)taps.size() * cinp;
-  const int G = K / 8;
-  const size_t base = blob.size();
-  blob.resize(base + ((size_t)nt_n * G + 4) * 64 * 4, 0.f);   // + 4 zero groups: prefetch-ring over-read
-  for (int nt = 0; nt < nt_n; ++nt)
-    for (int g = 0; g < G; ++g)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int q = 0; q < 4; ++q) {
-          const int k = 2 * (4 * g + q) + (lane >> 5);
-          const int n = nt * 32 + (lane & 31);
-          const int tap = taps[k / cinp], ci = k % cinp;
-          float v = 0.f;
-          if (ci < cin && n < cout)
-            v = transposed ? w[((size_t)(c_lo + ci) * cout + n) * ks + tap]
-                           : w[((size_t)n * cin_full + (c_lo + ci)) * ks + tap];
-          blob[base + (((size_t)nt * G + g) * 64 + lane) * 4 + q] = v;
-        }
-}
 
-
-// ---- f16x2 packs: U = G g in fp64 -> float, scaled per output channel by a power of two, split into two fp16 pieces ----
-static const double kG45[8][5] = {{-1, 0, 0, 0, 0},
-                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
-                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
-                                  {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
-                                  {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
-                                  {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
-                                  {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
-                                  {0, 0, 0, 0, 1}};
-static inline float wino_u(const float* w, int cin_full, int n, int ci, int pos) {   // conv weight layout [cout][cin_full][5]
-  const float* g = w + ((size_t)n * cin_full + ci) * 5;
-  double u = 0.0;
-  for (int k = 0; k < 5; ++k) u += kG45[pos][k] * (double)g[k];
-  return (float)u;
-}
 // power of two that puts m into [2^14, 2^15) (fp16's largest binade but one); 1 for m = 0 or non-finite
 static inline float f16_scale_for(float m) {
   if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
   int ex;
   (void)frexpf(m, &ex);                    // m = f * 2^ex, f in [0.5, 1)
   return ldexpf(1.f, 15 - ex);
-}
-// per-output-channel scales of a k5 conv over all 8 Winograd positions and ALL its input channels (the chunks of a channel
-// concat accumulate into the same tile, so they share the scale)
-static std::vector<float> f16_col_scales(const float* w, int cout, int cin_full) {
-  std::vector<float> sc(cout);
-  for (int n = 0; n < cout; ++n) {
-    float m = 0.f;
-    for (int ci = 0; ci < cin_full; ++ci)
-      for (int pos = 0; pos < 8; ++pos) m = fmaxf(m, fabsf(wino_u(w, cin_full, n, ci, pos)));
-    sc[n] = f16_scale_for(m);
-  }
-  return sc;
 }
 // u * scale -> hi = RN16, lo = RN16(u * scale - hi) (the device-side split of f16_split2)
 static inline void f16_split_host(float u, float scale, uint16_t (&piece)[2]) {
@@ -2525,66 +1842,6 @@ static size_t push_inverse(std::vector<float>& blob, const std::vector<float>& s
   for (float v : sc) blob.push_back(1.f / (v * in_scale));   // powers of two: exact
   while (blob.size() % 4) blob.push_back(0.f);
   return off;
-}
-
-// f16x2 pack of a stage's 1x1 residual conv [cout][cin] for vr_taps: per n-tile [chunk kc][piece q][lane] x 16 B, columns and
-// channels as in pack_vb; isc_off = offset of the [cout] inverse channel scales.
-static size_t pack_vr(std::vector<float>& blob, const float* wres, int cout, int cin, size_t& isc_off, bool pair_cols) {
-  std::vector<float> sc(cout);
-  for (int n = 0; n < cout; ++n) {
-    float m = 0.f;
-    for (int ci = 0; ci < cin; ++ci) m = fmaxf(m, fabsf(wres[(size_t)n * cin + ci]));
-    sc[n] = f16_scale_for(m);
-  }
-  isc_off = push_inverse(blob, sc);
-  const size_t base = blob.size();
-  const int tiles = cout / 16, KC = cin / 32;
-  const size_t frags = (size_t)tiles * KC * 2;
-  blob.resize(base + (frags + 8) * 64 * 4, 0.f);
-  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
-  for (int t = 0; t < tiles; ++t)
-    for (int kc = 0; kc < KC; ++kc)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int j = 0; j < 8; ++j) {
-          const int n = pair_cols ? (t / 2) * 32 + 2 * (lane & 15) + (t & 1) : 16 * t + (lane & 15);
-          const int ci = 8 * (KC * (lane >> 4) + kc) + j;
-          uint16_t piece[2];
-          f16_split_host(wres[(size_t)n * cin + ci], sc[n], piece);
-          for (int q = 0; q < 2; ++q) out[((((size_t)t * KC + kc) * 2 + q) * 64 + lane) * 8 + j] = piece[q];
-        }
-  return base;
-}
-
-// f16x2 pack of a C -> C k5 conv of downs.0 / downs.1 for vbd_taps: per n-tile [phase][step = 4 chunk kc + slot][piece q][lane]
-// x 16 B; lane = (column n = 16 tile + (lane & 15), the 8 channels of the block DbGeo assigns to (kc, lane >> 4), j at fp16
-// index j).
-static size_t pack_vbd(std::vector<float>& blob, const float* w, int cout, int cin, size_t& isc_off, float in_scale,
-                       bool plain_blocks = false) {
-  const std::vector<float> sc = f16_col_scales(w, cout, cin);
-  isc_off = push_inverse(blob, sc, in_scale);
-  const size_t base = blob.size();
-  const int tiles = cout / 16, KC = cin / 32;
-  const size_t frags = (size_t)tiles * 2 * 4 * KC * 2;
-  blob.resize(base + (frags + 8) * 64 * 4, 0.f);             // + slack for the ring's over-read past the last tile
-  uint16_t* out = reinterpret_cast<uint16_t*>(blob.data() + base);
-  for (int t = 0; t < tiles; ++t)
-    for (int ph = 0; ph < 2; ++ph)
-      for (int kc = 0; kc < KC; ++kc)
-        for (int sl = 0; sl < 4; ++sl)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-              // channel block of (chunk kc, lane group g): 2 * pair + half (DbGeo::pair_of / half_of)
-              // (plain_blocks: the VbGeoL order of a stage's first conv, block kc + KC g)
-              const int jg = lane >> 4, blk = plain_blocks ? kc + KC * jg : (KC == 2 ? 2 * jg + kc : 2 * (jg & 1) + (jg >> 1));
-              const int n = 16 * t + (lane & 15), ci = 8 * blk + j;
-              uint16_t piece[2];
-              f16_split_host(wino_u(w, cin, n, ci, vb_pos(ph, sl)), sc[n], piece);
-              for (int q = 0; q < 2; ++q) {
-                const size_t frag = ((((size_t)t * 2 + ph) * KC + kc) * 4 + sl) * 2 + q;
-                out[(frag * 64 + lane) * 8 + j] = piece[q];
-              }
-            }
-  return base;
 }
 
 // ---- direct f16x2 packs (rd_taps): per n-tile [tap][chunk kc][piece q][lane] x 16 B; lane = (column n, the 8 channels of
@@ -2680,8 +1937,8 @@ static std::vector<std::vector<float>> time_bias_absmax(const float* const* tens
 }
 // Static f16x2 input scale of a conv B: its input Mish(GroupNorm(.)) + time bias is bounded whatever the data --
 // |x_hat| <= sqrt(N - 1) < 16 for a group of N = 256 values, Mish(y) in [-0.31, max(y, 0)] -- by B = max_c (max(0.31, 16
-// |gamma_c| + |beta_c|) + max_t |tb_c(t)|); the power of two s = 2^(10 - floor(log2 B)) keeps every Winograd-transformed
-// value |V| <= 15 B s < 30720 inside fp16 and the typical ones (|x_hat| ~ 1) far above its denormals.
+// |gamma_c| + |beta_c|) + max_t |tb_c(t)|); the power of two s = 2^(10 - floor(log2 B)) keeps every value below 2048 inside fp16
+// and the typical ones (|x_hat| ~ 1) far above its denormals.
 static float static_act_scale(const float* gamma, const float* beta, const std::vector<float>& tbmax, int c) {
   float B = 0.f;
   for (int i = 0; i < c; ++i) B = fmaxf(B, fmaxf(0.31f, 16.f * fabsf(gamma[i]) + fabsf(beta[i])) + tbmax[i] * 1.001f);
@@ -2691,8 +1948,8 @@ static float static_act_scale(const float* gamma, const float* beta, const std::
   return ldexpf(1.f, 10 - (ex - 1));
 }
 
-struct ConvW { size_t wpk, bias, gamma, beta, wbf, isc; };   // wbf / isc: f16x2 pack and its inverse channel scales
-struct RtbW { ConvW a, b; size_t res_bias, res_isc, res_bf, res_c1_bf; int tb_off; size_t a_c1, a_c1_bf; float act_a; };
+struct ConvW { size_t bias, gamma, beta, wbf, isc; };   // wbf / isc: f16x2 pack and its inverse channel scales
+struct RtbW { ConvW a, b; size_t res_bias, res_isc, res_bf, res_c1_bf; int tb_off; size_t a_c1_bf; float act_a; };
 
 }  // namespace mmd
 
@@ -2752,10 +2009,8 @@ static size_t push(std::vector<float>& blob, const float* p, int64_t n) {
 
 static RtbPtrs rtb_ptrs(const mmd_unet_s* u, const RtbW& w, int t) {
   RtbPtrs p{};
-  p.wa = reinterpret_cast<const float4*>(u->blob + w.a.wpk);
   p.ba = u->blob + w.a.bias; p.ga = u->blob + w.a.gamma; p.bea = u->blob + w.a.beta;
   p.tb = u->ttable + (size_t)t * u->tb_total + w.tb_off;
-  p.wb = reinterpret_cast<const float4*>(u->blob + w.b.wpk);
   p.bb = u->blob + w.b.bias; p.gb = u->blob + w.b.gamma; p.beb = u->blob + w.b.beta;
   p.wa_bf = w.a.wbf ? reinterpret_cast<const uint4*>(u->blob + w.a.wbf) : nullptr;
   p.wb_bf = w.b.wbf ? reinterpret_cast<const uint4*>(u->blob + w.b.wbf) : nullptr;
@@ -2772,7 +2027,6 @@ static ChainArgs args_chain(const mmd_unet_s* u, const RtbW* set, const int* rtb
   a.in0 = in0; a.n = n;
   const RtbW& w0 = set[rtb[0]];
   a.r0 = rtb_ptrs(u, w0, t);
-  a.wa0_c1 = reinterpret_cast<const float4*>(u->blob + w0.a_c1);
   a.wa0_c1_bf = w0.a_c1_bf ? reinterpret_cast<const uint4*>(u->blob + w0.a_c1_bf) : nullptr;
   a.br = u->blob + w0.res_bias;
   a.isr = w0.res_isc ? u->blob + w0.res_isc : nullptr;
@@ -2838,9 +2092,8 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   const std::vector<std::vector<float>> tbmax = time_bias_absmax(tensors, s, n_diffusion_steps);
   for (int r = 0; r < 12; ++r) {
     // state_dict order: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2.  Every conv gets the one f16x2 pack its stage
-    // body reads: direct packs (pack_rd; interleaved column pairs where a wave owns two n-tiles) for downs.0, downs.2 + mid and
-    // the up stages, with the 1x1 residual conv of a stage's first RTB as a one-tap pack of its own; Winograd packs
-    // (pack_vbd / pack_vr) for downs.1.
+    // body reads: direct packs (pack_rd; interleaved column pairs where a wave owns two n-tiles), with the 1x1 residual conv of
+    // a stage's first RTB as a one-tap pack of its own.
     const Rtb& R = s.rtb[r];
     RtbW& W = u->rtb[r];
     W = RtbW{};
@@ -2990,13 +2243,6 @@ static const double kUnetFlops =
     rtb_flops(128, 32, 32) + rtb_flops(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +
     2.0 * 32 * 5 * 32 * 64 + 2.0 * 4 * 32 * 64;
 
-// fp32 GEMM FLOPs the matrix pipe executes per trajectory, by form.  Winograd F(4,5) convs (downs.1): 8 products per 4
-// outputs; direct convs (everything else): every tap (downs.0's stride-2 tail at all 64 positions, its 4-channel first conv
-// padded to one K = 32 chunk, + one for the residual conv; the final 1x1 conv with N padded to 16).
-static constexpr double wino4_flops(double cin, double cout) { return (cin / 4) * 8 * (cout / 16) * 2048.0 / 4; }   // per sample
-static constexpr double direct_flops(double taps, double cinp, double coutp, double Lout) {
-  return taps * (cinp / 2) * (coutp / 32) * (4 * Lout / 32) * 4096.0 / 4;
-}
 static constexpr double d5(double cin, double cout, double L) { return 2.0 * cout * 5 * cin * L; }
 static const double kF16Flops =
     2 * (2.0 * 32 * 32 * 64) + 3 * d5(32, 32, 64) + 2.0 * 32 * 3 * 32 * 64 +                          // downs.0
