@@ -31,7 +31,7 @@ t0 = t[:, :, tags[0]].min()
 print(f"n={n} blocks={nb}; tags {len(tags)}; kernel span {(t[:, :, tags[-1]].max() - t0) / 1e3:.1f} us")
 names = {}
 for base, nm in ((0, "D0"), (40, "D1")):
-    for j, w in enumerate(("start (x slab staged)", "convA + res + gn (fp32)", "convB + gn (f16x2)", "id convA + gn", "id convB + gn", "tail conv done")):
+    for j, w in enumerate(("start (input staged)", "convA + res + gn", "convB + gn", "id convA + gn", "id convB + gn", "tail conv + hand-off")):
         names[base + j] = f"{nm} {w}"
 for j, w in enumerate(("start", "rtb0 convA+res done", "gn+write+barrier", "rtb0 convB done", "gn+res", "id convA done", "id convB done", "gn+write -> tail")):
     names[136 + j] = f"U0 {w}"

@@ -1,3 +1,3 @@
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q -rf > gpurun_out/s19_pytest_all.log 2>&1; tail -4 gpurun_out/s19_pytest_all.log
-REPS=40 timeout 300 python tools/unet_forward_loop.py 256 512 1024 2048 2>&1 | grep unet | cut -c1-45
+for n in 512 2048; do MMD_AMD_LIB=$PWD/build_tmp/libmmd_amd_trace.so timeout 120 python tools/dbg/trace_phases.py $n > gpurun_out/r03_trace_${n}_all_direct.txt 2>&1; done
+bash tools/gpu_profile.sh r03c
