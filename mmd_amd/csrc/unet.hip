@@ -123,6 +123,26 @@ __device__ __forceinline__ DynScale dyn_scale(float M) {
   eb = eb < 64u ? 64u : eb;                                  // M < 2^-63 (all zero): s = 2^73
   return DynScale{__uint_as_float((264u - eb) << 23), __uint_as_float((eb - 10u) << 23)};
 }
+// The lane's value combined with the same lane of the neighbouring 16-lane row (xor 16) / of the other wave half (xor 32):
+// v_permlane16_swap / v_permlane32_swap (gfx950) exchange the odd rows of one operand with the even rows of the other, so with
+// both operands = v the two results are (row 0, row 0, row 2, row 2) and (row 1, row 1, row 3, row 3) -- one VALU
+// instruction instead of a ds_bpermute round trip through the LDS in the dependent chain of every GroupNorm reduction.
+struct RowPair { float a, b; };
+__device__ __forceinline__ RowPair rows_xor16(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return RowPair{__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1])};
+}
+__device__ __forceinline__ RowPair rows_xor32(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return RowPair{__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1])};
+}
+__device__ __forceinline__ float add_xor16(float v) { const RowPair r = rows_xor16(v); return r.a + r.b; }
+__device__ __forceinline__ float add_xor32(float v) { const RowPair r = rows_xor32(v); return r.a + r.b; }
+__device__ __forceinline__ float max_xor16(float v) { const RowPair r = rows_xor16(v); return fmaxf(r.a, r.b); }
+__device__ __forceinline__ float max_xor32(float v) { const RowPair r = rows_xor32(v); return fmaxf(r.a, r.b); }
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_max(float v) {
   return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)));
@@ -515,9 +535,9 @@ __device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[4][NT], const float (&bi
     sum[sm] = group_colsum<8>(v);
   }
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) sum[sm] += __shfl_xor(sum[sm], 16);
+  for (int sm = 0; sm < 4; ++sm) sum[sm] = add_xor16(sum[sm]);
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) sum[sm] += __shfl_xor(sum[sm], 32);
+  for (int sm = 0; sm < 4; ++sm) sum[sm] = add_xor32(sum[sm]);
 #pragma unroll
   for (int sm = 0; sm < 4; ++sm) {
     const float mean = fmaf(sum[sm], inv_n, bmean);
@@ -534,12 +554,12 @@ __device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[4][NT], const float (&bi
     sq[sm] = group_colsum<8>(v);
   }
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) sq[sm] += __shfl_xor(sq[sm], 16);
+  for (int sm = 0; sm < 4; ++sm) sq[sm] = add_xor16(sq[sm]);
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) sq[sm] += __shfl_xor(sq[sm], 32);
+  for (int sm = 0; sm < 4; ++sm) sq[sm] = add_xor32(sq[sm]);
 #pragma unroll
   for (int sm = 0; sm < 4; ++sm) {
-    const float rstd = rsqrtf(fmaf(sq[sm], inv_n, 1e-5f));
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(sq[sm], inv_n, 1e-5f));   // (argument >= 1e-5: no denormal handling needed)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       GnCoef cf = gn_coef(dm[sm][t], rstd, gamma[t], beta[t]);
@@ -565,7 +585,7 @@ __device__ __forceinline__ void rd_dyn_out(const f32x4 (&acc)[4][NT], float* mx,
 #pragma unroll
       for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(acc[sm][t][r]));
     m = row_max16(m);
-    m = fmaxf(m, __shfl_xor(m, 16));
+    m = max_xor16(m);
     if ((lane & 31) == 0) {
       mx[sm * MX_SLOTS + 2 * wave + (lane >> 5)] = m;
       if (region2) mx[region2 * MX_REGION + sm * MX_SLOTS + 2 * wave + (lane >> 5)] = m;
@@ -640,8 +660,8 @@ template <int C, int L> struct RwGeo {
   static constexpr int tile_row(int m) { return m * RPS; }   // M tile m = positions 16 m .. 16 m + 15 of the wave's sample
 };
 __device__ __forceinline__ float wave_sum_rows(float v) {   // v + the same lane of the other three 16-lane rows
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
+  v = add_xor16(v);
+  v = add_xor32(v);
   return v;
 }
 // GroupNorm + Mish of ONE sample's tile acc[M tile][tile] (positions 16 mt + 4 g + r; true value = acc * isc[tile] * inv);
@@ -680,7 +700,7 @@ __device__ __forceinline__ void rw_gn_mish(f32x4 (&acc)[MT][NT], const float (&b
         q = fmaf(d, d, q);
       }
   }
-  const float rstd = rsqrtf(fmaf(gsum(q), inv_n, 1e-5f));
+  const float rstd = __builtin_amdgcn_rsqf(fmaf(gsum(q), inv_n, 1e-5f));
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     GnCoef cf = gn_coef(dm[t], rstd, gamma[t], beta[t]);
@@ -705,8 +725,8 @@ __device__ __forceinline__ float rw_absmax(const f32x4 (&acc)[MT][NT]) {   // th
 #pragma unroll
       for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(acc[mt][t][r]));
   m = row_max16(m);
-  m = fmaxf(m, __shfl_xor(m, 16));
-  return fmaxf(m, __shfl_xor(m, 32));
+  m = max_xor16(m);
+  return max_xor32(m);
 }
 // two-interleaved-n-tile tile of one sample (lane: channels 2 n, 2 n + 1 (+ 32 per further pair); positions 16 mt + 4 g + r)
 // -> the wave's slab; vs = slab + the lane's (block n >> 2, row 2 + 4 g, dword n & 3) offset
@@ -756,8 +776,8 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
     if (valid) v = *reinterpret_cast<const float4*>(a.in0 + ((size_t)(n0 + wave) * 64 + lane) * 4);
     float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     m = row_max16(m);
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = max_xor16(m);
+    m = max_xor32(m);
     const DynScale ds = dyn_scale(m);
     inv_in = ds.inv;
     const F16Pair p0 = f16_split2(v.x * ds.s, v.y * ds.s), p1 = f16_split2(v.z * ds.s, v.w * ds.s);
@@ -888,8 +908,8 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
           mo = fmaxf(mo, fabsf(y[mt][t][r]));
         }
     mo = row_max16(mo);
-    mo = fmaxf(mo, __shfl_xor(mo, 16));
-    mo = fmaxf(mo, __shfl_xor(mo, 32));
+    mo = max_xor16(mo);
+    mo = max_xor32(mo);
     __syncthreads();                                         // every wave is done with its slab: the next stage's slab aliases them
     if (lane < MX_SLOTS) (lds + MX_OFF)[wave * MX_SLOTS + lane] = mo;
     // -> the next stage's input slab (RlGeo<32>: rows 36 sample + 2 + m), m = p / 2 = 8 mt + 2 g + r / 2, channels 2 n, 2 n + 1 =
@@ -979,8 +999,8 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
 #pragma unroll
           for (int r = 0; r < 4; r += decltype(even_only)::value ? 2 : 1) m = fmaxf(m, fabsf(v[2 * sl + mt][t][r]));
       m = row_max16(m);
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m2[sl] = fmaxf(m, __shfl_xor(m, 32));
+      m = max_xor16(m);
+      m2[sl] = max_xor32(m);
     }
     if (lane < 8) mx[(2 * sp + (lane >> 2)) * MX_SLOTS + np + 2 * (lane & 3)] = (lane >> 2) ? m2[1] : m2[0];
   };
@@ -1379,8 +1399,8 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
         m = fmaxf(m, fmaxf(fabsf(xe[sm][0][r]), fabsf(xo[sm][0][r])));
       }
       m = row_max16(m);
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
+      m = max_xor16(m);
+      m = max_xor32(m);
       if (lane == 0) mx[sm * MX_SLOTS + wave] = m;
     }
   }
@@ -1440,8 +1460,8 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
 #pragma unroll
           for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(skip[2 * sl + mt][t][r]));
       m = row_max16(m);
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m2[sl] = fmaxf(m, __shfl_xor(m, 32));
+      m = max_xor16(m);
+      m2[sl] = max_xor32(m);
     }
     if (lane < 4) mx[(2 * sp + (lane >> 1)) * MX_SLOTS + 4 + np + 2 * (lane & 1)] = (lane >> 1) ? m2[1] : m2[0];
   }
@@ -1607,8 +1627,8 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
           m = fmaxf(m, fmaxf(fabsf(e[mt][t][r]), fabsf(o[mt][t][r])));
         }
     m = row_max16(m);
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = max_xor16(m);
+    m = max_xor32(m);
     const DynScale df = dyn_scale(m);
     inv_f = df.inv;
     wave_lds_fence();                                        // the tail's reads are done: 64-row geometry
