@@ -385,10 +385,16 @@ __device__ __forceinline__ void rd_load_a(u32x4 (&a)[2][2], const char* va, int 
 }
 constexpr int RD_RD = 2;                    // weight ring depth in steps
 #ifndef MMD_D2_RD
-#define MMD_D2_RD 2
+#define MMD_D2_RD 3
+#endif
+#ifndef MMD_D1_RD
+#define MMD_D1_RD 3
+#endif
+#ifndef MMD_U0C_RD
+#define MMD_U0C_RD 4
 #endif
 #ifndef MMD_U0_RD
-#define MMD_U0_RD 2
+#define MMD_U0_RD 3
 #endif
 template <class GEO, int NT, int RD = RD_RD>
 __device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD][NT][2], const u32x4* const (&w)[NT]) {
@@ -400,18 +406,16 @@ __device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD][NT][2], const u32x4*
 // channels of the slab; va = slab + the lane's A offset (lane group lane >> 4, row lane & 15); w[tile] = the tile's pack +
 // lane; b = ring pre-loaded with the first RD_RD steps.  RES: the stage's 1x1 residual conv rides on the centre tap's A
 // fragments (res[sample][tile] (+)=, weights wr[tile] = [chunk kc][piece] + lane).  FRESH: start from zero.
-template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES, int MT = 4, int RD = RD_RD, bool FULL = false>
+template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES, int MT = 4, int RD = RD_RD>
 __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][NT], const char* va, const u32x4* const (&w)[NT],
                                         const u32x4* const (&wr)[NT], u32x4 (&b)[RD][NT][2]) {
   constexpr int KC = GEO::KC, STEPS = TAPS * KC, HP = MT / 2;
-  static_assert(KC % RD == 0 || KC == 1 || FULL, "the ring index must be static inside a tap");
   static_assert(MT % 2 == 0, "M tiles are processed in pairs");
   // A fragments are double-buffered by M-tile pair (half a step = 2 M tiles x NT n-tiles x 3 MFMAs): 32 registers
   u32x4 a[2][2][2];
   rd_load_a<GEO>(a[0], va, TAP0, 0, 0);
   // (the residual conv's weights are requested RES_LOOK steps before the centre tap's step that uses them: loaded there,
   // every one of its steps would wait for an L2 round trip; all up front, they would cost 32 registers for two taps)
-  static_assert(!RES || FULL, "the residual conv rides on fully unrolled convs only");
   constexpr int C0 = (2 - TAP0) * KC;                        // the centre tap's first step
   constexpr int RES_LOOK = C0 < 3 ? C0 : 3;
   u32x4 brp[RES ? KC : 1][NT][2];
@@ -421,94 +425,51 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
 #pragma unroll
       for (int q = 0; q < 2; ++q) brp[kc][t][q] = wr[t][(kc * 2 + q) * 64];
   };
-  // one step = (tap, chunk kc); ri = its static ring slot
-  auto step = [&](auto zero, int tap, int kc, int ri, auto last_kc) {
-    const bool with_res = RES && TAP0 + tap == 2;
+  // Every step (tap, chunk kc) is unrolled: the ring slot step % RD and the A buffer parity are static for any depth, the
+  // loop has no branches, and the scheduler sees the whole conv (rolled over the taps, downs.2's convs ran 5 % slower at <= 512
+  // trajectories).
 #pragma unroll
-    for (int hp = 0; hp < HP; ++hp) {
-      // the next half step's A fragments (the next M-tile pair; then the next chunk, or chunk 0 of the next tap; past the
-      // last step: a valid, unused read)
-      // (buffer parity = the half step's index: static, because a rolled tap has an even number of half steps)
-      const int cur = (kc * HP + hp + (KC == 1 || FULL ? tap * KC * HP : 0)) & 1;
-      if (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, TAP0 + tap, kc, hp + 1);
-      else rd_load_a<GEO>(a[cur ^ 1], va, decltype(last_kc)::value ? TAP0 + tap + 1 : TAP0 + tap, decltype(last_kc)::value ? 0 : kc + 1, 0);
-      MMD_PIN_LOADS();
-      const u32x4(&ac)[2][2] = a[cur];
-      const u32x4(&bc)[NT][2] = b[ri];
+  for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-      for (int sm = 0; sm < 2; ++sm)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (decltype(zero)::value) vb_three<true>(acc[2 * hp + sm][t], ac[sm], bc[t]);
-          else vb_three<false>(acc[2 * hp + sm][t], ac[sm], bc[t]);
-        }
+    for (int kc = 0; kc < KC; ++kc) {
+      const int st = tap * KC + kc, ri = st % RD;
+      const bool zero = FRESH && st == 0, last_kc = kc + 1 == KC, with_res = RES && TAP0 + tap == 2;
       if constexpr (RES) {
-        if (with_res) {
-#pragma unroll
-          for (int sm = 0; sm < 2; ++sm)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              const u32x4(&bw)[2] = brp[RES ? kc : 0][t];
-              if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], bw);
-              else vb_three<false>(res[2 * hp + sm][t], ac[sm], bw);
-            }
-        }
+        if (st + RES_LOOK >= C0 && st + RES_LOOK < C0 + KC) load_br(st + RES_LOOK - C0);
       }
-    }
-    const int nxt = tap * KC + kc + RD;
-    if (nxt < STEPS) rd_load_b<GEO, NT>(b[ri], w, nxt);
-    MMD_PIN_LOADS();
-  };
-  static_assert(KC == 1 || FULL || (KC * HP) % 2 == 0, "A buffer parity must be static across the rolled tap loop");
-  if constexpr (FULL) {
-    // every step unrolled: ring slot = step % RD for any depth -- a wave-private conv with several chunks (ups.1's conv A) has
-    // no second workgroup wave to hide the weight fetch behind, so it needs the fetch ~5 steps ahead
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap)
+      for (int hp = 0; hp < HP; ++hp) {
+        // the next half step's A fragments (the next M-tile pair; then the next chunk, or chunk 0 of the next tap; past the
+        // last step: a valid, unused read)
+        const int cur = (st * HP + hp) & 1;
+        if (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, TAP0 + tap, kc, hp + 1);
+        else rd_load_a<GEO>(a[cur ^ 1], va, last_kc ? TAP0 + tap + 1 : TAP0 + tap, last_kc ? 0 : kc + 1, 0);
+        MMD_PIN_LOADS();
+        const u32x4(&ac)[2][2] = a[cur];
+        const u32x4(&bc)[NT][2] = b[ri];
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const int st = tap * KC + kc;
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (zero) vb_three<true>(acc[2 * hp + sm][t], ac[sm], bc[t]);
+            else vb_three<false>(acc[2 * hp + sm][t], ac[sm], bc[t]);
+          }
         if constexpr (RES) {
-          if (st + RES_LOOK >= C0 && st + RES_LOOK < C0 + KC) load_br(st + RES_LOOK - C0);
-        }
-        if (FRESH && st == 0) {
-          if (kc + 1 < KC) step(std::true_type{}, tap, kc, st % RD, std::false_type{});
-          else step(std::true_type{}, tap, kc, st % RD, std::true_type{});
-        } else {
-          if (kc + 1 < KC) step(std::false_type{}, tap, kc, st % RD, std::false_type{});
-          else step(std::false_type{}, tap, kc, st % RD, std::true_type{});
+          if (with_res) {
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                const u32x4(&bw)[2] = brp[kc][t];
+                if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], bw);
+                else vb_three<false>(res[2 * hp + sm][t], ac[sm], bw);
+              }
+          }
         }
       }
-  } else if constexpr (KC == 1) {
-    // one chunk per tap: the taps are unrolled (TAPS is small), ring slot tap % RD (RD = TAPS: the whole conv's weights are
-    // in flight before the first MFMA -- a wave-private conv is too short to hide a weight fetch behind two steps)
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      if (FRESH && tap == 0) step(std::true_type{}, tap, 0, tap % RD, std::true_type{});
-      else step(std::false_type{}, tap, 0, tap % RD, std::true_type{});
+      if (st + RD < STEPS) rd_load_b<GEO, NT>(b[ri], w, st + RD);
+      MMD_PIN_LOADS();
     }
-  } else {
-    auto one_tap = [&](auto zero, int tap) {
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        if (decltype(zero)::value && kc == 0) {
-          if (kc + 1 < KC) step(std::true_type{}, tap, kc, kc % RD, std::false_type{});
-          else step(std::true_type{}, tap, kc, kc % RD, std::true_type{});
-        } else {
-          if (kc + 1 < KC) step(std::false_type{}, tap, kc, kc % RD, std::false_type{});
-          else step(std::false_type{}, tap, kc, kc % RD, std::true_type{});
-        }
-      }
-    };
-    if constexpr (FRESH) {
-      one_tap(std::true_type{}, 0);
-#pragma unroll 1
-      for (int tap = 1; tap < TAPS; ++tap) one_tap(std::false_type{}, tap);
-    } else {
-#pragma unroll 1
-      for (int tap = 0; tap < TAPS; ++tap) one_tap(std::false_type{}, tap);
-    }
-  }
 }
 // GroupNorm + Mish of the direct-layout tile acc[sample][tile] (raw f16x2 conv output: true value = acc * isc[tile] *
 // inv[sample]) + add(sample, tile, r); NG = values per group (16 channels x 16 positions for two interleaved n-tiles at C =
@@ -962,7 +923,8 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     return epi_load<2>(b, gm, be, tb, isc, c0);
   };
   f32x4 acc[4][2], res[4][2];
-  u32x4 ring[RD_RD][2][2];
+  constexpr int RD1 = MMD_D1_RD;                               // weight ring depth of the 64 -> 64 convs
+  u32x4 ring[RD1][2][2];
   auto store_tile = [&]() {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -1019,10 +981,10 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
   // one 64 -> 64 conv over the tile in acc (already scaled); on entry every wave is past its reads of the slab
   auto conv = [&](const uint4* w) {
     const u32x4* wp[2] = {wptr(w, GH::FRAGS5, 0), wptr(w, GH::FRAGS5, 1)};
-    rd_ring_load<GH, 2>(ring, wp);
+    rd_ring_load<GH, 2, RD1>(ring, wp);
     store_tile();
     __syncthreads();
-    rd_taps<GH, 2, 0, 5, true, false>(acc, acc, vaH, wp, wp, ring);
+    rd_taps<GH, 2, 0, 5, true, false, 4, RD1>(acc, acc, vaH, wp, wp, ring);
   };
   const float one2[2] = {1.f, 1.f};
 
@@ -1040,7 +1002,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) inv_in[sl] = dyn_scale(mx_read(mx, 2 * sp + sl)).inv;
     rd_zero_halo<GH>(slabH);
-    rd_taps<GI, 2, 0, 5, true, true, 4, 5, true>(acc, res, vaI, wpa, wpr, ring5);
+    rd_taps<GI, 2, 0, 5, true, true, 4, 5>(acc, res, vaI, wpa, wpr, ring5);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1087,11 +1049,11 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     scale_in(inv);
     const u32x4* wt[2] = {wptr(a.wt_bf0, GH::FRAGS3, 0), wptr(a.wt_bf0, GH::FRAGS3, 1)};
     const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0], a.ist0[c0 + 1]};
-    rd_ring_load<GH, 2>(ring, wt);
+    rd_ring_load<GH, 2, RD1>(ring, wt);
     store_tile();
     __syncthreads();
     f32x4 y[4][2];
-    rd_taps<GH, 2, 1, 3, true, false>(y, y, vaH, wt, wt, ring);
+    rd_taps<GH, 2, 1, 3, true, false, 4, RD1>(y, y, vaH, wt, wt, ring);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1154,7 +1116,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   u32x4 ring[RDD][2][2];
   const u32x4* wpa[2] = {wptr(a.r0.wa_bf, G64::FRAGS5, 0), wptr(a.r0.wa_bf, G64::FRAGS5, 1)};
   const u32x4* wpr[2] = {wptr(a.wres_bf, 2 * G64::KC, 0), wptr(a.wres_bf, 2 * G64::KC, 1)};
-  rd_ring_load<G64, 2, 2>(reinterpret_cast<u32x4(&)[2][2][2]>(ring), wpa);
+  rd_ring_load<G64, 2, 2>(reinterpret_cast<u32x4(&)[2][2][2]>(ring), wpa);   // (conv A + residual streams: depth 2, or it spills)
   __syncthreads();                                           // the x slab (previous stage's tail tile) and its maxima are staged
   TR(trb + 0);
 
@@ -1199,7 +1161,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   __syncthreads();
   {
     f32x4 res[4][2];
-    rd_taps<G64, 2, 0, 5, true, true, 4, 2, true>(acc, res, va64, wpa, wpr, reinterpret_cast<u32x4(&)[2][2][2]>(ring));
+    rd_taps<G64, 2, 0, 5, true, true, 4, 2>(acc, res, va64, wpa, wpr, reinterpret_cast<u32x4(&)[2][2][2]>(ring));
 #pragma unroll
     for (int sm = 0; sm < 4; ++sm)
 #pragma unroll
@@ -1271,7 +1233,8 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   auto wptr = [&](const uint4* w, int frags) { return reinterpret_cast<const u32x4*>(w) + (size_t)wave * frags * 64 + lane; };
   constexpr int RDU = MMD_U0_RD;                               // weight ring depth of conv A's two 128-channel chunks
   u32x4 ringa[RDU][1][2];
-  u32x4 ring[RD_RD][1][2];
+  constexpr int RDC = MMD_U0C_RD;                              // ... of the 64 -> 64 convs and the tail's parity passes
+  u32x4 ring[RDC][1][2];
   const u32x4* wp0[1] = {wptr(a.r0.wa_bf, G128::FRAGS5)};
   const u32x4* wp1[1] = {wptr(a.wa0_c1_bf, G128::FRAGS5)};
   const u32x4* wr0[1] = {wptr(a.wres_bf, 2 * G128::KC)};
@@ -1305,10 +1268,10 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   // one 64 -> 64 conv over the tile in acc (already scaled); on entry every wave is past its reads of the slab
   auto conv64 = [&](const uint4* w) {
     const u32x4* wp[1] = {wptr(w, G64::FRAGS5)};
-    rd_ring_load<G64, 1>(ring, wp);
+    rd_ring_load<G64, 1, RDC>(ring, wp);
     rd_store1<G64>(vs64, acc, lane);
     __syncthreads();
-    rd_taps<G64, 1, 0, 5, true, false>(acc, res, va64, wp, wp, ring);
+    rd_taps<G64, 1, 0, 5, true, false, 4, RDC>(acc, res, va64, wp, wp, ring);
   };
 
   // =================== RTB 0: cat(x0, x1) -> 64 channels; the 1x1 residual conv rides on the centre tap ===================
@@ -1330,7 +1293,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   TR(160);
   __syncthreads();
   TR(161);
-  rd_taps<G128, 1, 0, 5, true, true, 4, RDU, true>(acc, res, va128, wp0, wr0, ringa);
+  rd_taps<G128, 1, 0, 5, true, true, 4, RDU>(acc, res, va128, wp0, wr0, ringa);
   rd_ring_load<G128, 1, RDU>(ringa, wp1);
   TR(162);
   __syncthreads();                                           // every wave is done reading chunk 0
@@ -1338,7 +1301,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   TR(163);
   __syncthreads();
   TR(164);
-  rd_taps<G128, 1, 0, 5, false, true, 4, RDU, true>(acc, res, va128, wp1, wr1, ringa);
+  rd_taps<G128, 1, 0, 5, false, true, 4, RDU>(acc, res, va128, wp1, wr1, ringa);
   TR(165);
 #pragma unroll
   for (int sm = 0; sm < 4; ++sm) res[sm][0] = res[sm][0] * (isr * inv_in[sm]) + br;
@@ -1380,13 +1343,13 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     const u32x4* wt0[1] = {wptr(a.wt_bf0, 2 * G64::KC * 2)};
     const u32x4* wt1[1] = {wptr(a.wt_bf1, 2 * G64::KC * 2)};
     const float bt = a.bt[col], is0 = a.ist0[col], is1 = a.ist1[col];
-    rd_ring_load<G64, 1>(ring, wt0);
+    rd_ring_load<G64, 1, RDC>(ring, wt0);
     rd_store1<G64>(vs64, acc, lane);
     __syncthreads();
     TR(trb + 7);
-    rd_taps<G64, 1, 1, 2, true, false>(xe, res, va64, wt0, wt0, ring);
-    rd_ring_load<G64, 1>(ring, wt1);
-    rd_taps<G64, 1, 2, 2, true, false>(xo, res, va64, wt1, wt1, ring);
+    rd_taps<G64, 1, 1, 2, true, false, 4, RDC>(xe, res, va64, wt0, wt0, ring);
+    rd_ring_load<G64, 1, RDC>(ring, wt1);
+    rd_taps<G64, 1, 2, 2, true, false, 4, RDC>(xo, res, va64, wt1, wt1, ring);
     // the stage's output stays in registers: xe / xo[sample][0][r] = positions 2 m, 2 m + 1 (m = 4 g + r) of channel col; the
     // per-sample maxima of the wave's 16 channels go to slot `wave` of mx region 0 (the caller's barrier publishes them)
 #pragma unroll
@@ -1500,7 +1463,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   TR(trb + 7);
   const char* const vaA = slab + g * GA::G + n * 16;
   f32x4 acc[2][2], res[2][2];
-  rd_taps<GA, 2, 0, 5, true, true, 2, RDA, true>(acc, res, vaA, wp0, wr0, ring);
+  rd_taps<GA, 2, 0, 5, true, true, 2, RDA>(acc, res, vaA, wp0, wr0, ring);
   rd_ring_load<GA, 2, RDA>(ring, wp1);
   TR(trb + 8);
   __syncthreads();                                           // every wave has consumed chunk 0
@@ -1524,7 +1487,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   TR(trb + 10);
   const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
   const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
-  rd_taps<GA, 2, 0, 5, false, true, 2, RDA, true>(acc, res, vaA, wp1, wr1, ring);
+  rd_taps<GA, 2, 0, 5, false, true, 2, RDA>(acc, res, vaA, wp1, wr1, ring);
   TR(trb + 11);
   // ---- from here on the wave is on its own: 32-channel slab
   const char* const vaB = slab + g * GB::G + n * 16;
