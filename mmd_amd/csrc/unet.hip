@@ -217,30 +217,18 @@ struct ChainArgs {
   int n;
 };
 
-template <int C0_, int C1_, int CM_, int L_, int MT_W_, int RES0_, int N_IDENT_, int MID_AFTER_, int TAIL_>
+// Shape of a stage: RTB (C0 [+ C1 concatenated] -> CM channels, 1x1 residual conv), N_IDENT identity RTBs (the skip tensor is
+// the output of RTB number MID_AFTER), an optional strided / transposed tail conv; L = length of the level.  A workgroup owns
+// SPB = 4 samples in every stage.  XSTR / XSS: row and sample stride (floats) of the one row-form fp32 slab left, the stage's
+// input as the previous stage's tail hands it over (downs.1 -> downs.2): [sample][2 + position][channel], even row stride (two
+// channels per 8-byte access), sample stride padded to 16 (mod 32) floats.
+template <int C0_, int C1_, int CM_, int L_, int RES0_, int N_IDENT_, int MID_AFTER_, int TAIL_>
 struct ChainCfg {
-  static constexpr int C0 = C0_, C1 = C1_, CM = CM_, L = L_, MT_W = MT_W_, RES0 = RES0_, N_IDENT = N_IDENT_;
-  static constexpr int MID_AFTER = MID_AFTER_, TAIL = TAIL_;
-  static constexpr int C0P = (C0 + 7) / 8 * 8, C1P = (C1 + 7) / 8 * 8;   // (4-channel input: 2 k-steps of 4 = the weight ring's depth)
-  static constexpr int CXP = C0P > C1P ? C0P : C1P;
-  // (downs.1 / downs.2: their row-form x slab is only read by rowform_to_vslab, two channels per ds_read_b64 -- an even row
-  // stride keeps them 8-byte aligned)
-  static constexpr int XSTR = (C0 % 32 == 0 && C1 == 0) ? CXP + 2 : CXP + 1, HSTR = CM + 1;
-  static constexpr int WN = CM / 32, WM = 4 / WN;
-  static constexpr int RW = 32 * MT_W, SW = RW / L, SPB = WM * SW, SROWS = L + 4;
-  static constexpr bool SHARE = RES0 == RES_IDENT;         // x is staged straight into the H slab
-  // Sample stride.  With L = 16 an A tile spans all four samples (rows s*stride + l*STR, STR odd): pad the stride to
-  // 16 (mod 32) floats so that odd samples fall on the other 16 banks.
-  static constexpr int spad(int n) { return L == 16 ? (16 - n % 32 + 32) % 32 : 0; }
-  static constexpr int XSS = SROWS * XSTR + spad(SROWS * XSTR);
-  static constexpr int HSS = SROWS * HSTR + spad(SROWS * HSTR);
-  static constexpr int XSLAB = SHARE ? 0 : SPB * XSS;
-  static constexpr int HSLAB = SPB * HSS;
-  static constexpr int LDS_FLOATS = XSLAB + HSLAB;
-  static_assert(CM % 32 == 0 && RW % L == 0 && L >= 16, "tile shape");
-  static_assert(!SHARE || (C0 == CM && C1 == 0), "identity residual needs C_in == C_out");
-  static_assert(TAIL != TAIL_DOWN || MT_W == 2, "the downsample tail maps a wave's 64 rows to one 32-row tile");
-  static_assert(N_IDENT <= MAX_IDENT, "too many identity RTBs");
+  static constexpr int C0 = C0_, C1 = C1_, CM = CM_, L = L_, RES0 = RES0_, N_IDENT = N_IDENT_;
+  static constexpr int MID_AFTER = MID_AFTER_, TAIL = TAIL_, SPB = 4;
+  static constexpr int C0P = (C0 + 7) / 8 * 8, XSTR = C0P + 2, SROWS = L + 4;
+  static constexpr int XSS = SROWS * XSTR + (16 - (SROWS * XSTR) % 32 + 32) % 32;
+  static_assert(CM % 32 == 0 && L >= 16 && N_IDENT <= MAX_IDENT, "stage shape");
 };
 
 // sum over the CPG adjacent lanes (channels) of a GroupNorm group, same value in all of them
@@ -255,12 +243,12 @@ __device__ __forceinline__ float group_colsum(float v) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-//                  C0   C1   CM   L  MT_W RES0      N_IDENT MID_AFTER TAIL
-using CH_D0 = ChainCfg<4, 0, 32, 64, 2, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
-using CH_D1 = ChainCfg<32, 0, 64, 32, 2, RES_CONV, 1, 1, TAIL_DOWN>;     // downs.1 (skip1 = output of its 2nd RTB)
-using CH_D2 = ChainCfg<64, 0, 128, 16, 2, RES_CONV, 3, 1, TAIL_NONE>;    // downs.2 + mid_block1/2 (skip2 after downs.2)
-using CH_U0 = ChainCfg<128, 128, 64, 16, 1, RES_CONV, 1, -1, TAIL_UP>;   // ups.0: cat(x, skip2) RTB, RTB, Upsample1d
-using CH_U1 = ChainCfg<64, 64, 32, 32, 1, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
+//                  C0   C1   CM   L   RES0      N_IDENT MID_AFTER TAIL
+using CH_D0 = ChainCfg<4, 0, 32, 64, RES_CONV, 1, -1, TAIL_DOWN>;     // downs.0: RTB, RTB, Downsample1d
+using CH_D1 = ChainCfg<32, 0, 64, 32, RES_CONV, 1, 1, TAIL_DOWN>;     // downs.1 (skip1 = output of its 2nd RTB)
+using CH_D2 = ChainCfg<64, 0, 128, 16, RES_CONV, 3, 1, TAIL_NONE>;    // downs.2 + mid_block1/2 (skip2 after downs.2)
+using CH_U0 = ChainCfg<128, 128, 64, 16, RES_CONV, 1, -1, TAIL_UP>;   // ups.0: cat(x, skip2) RTB, RTB, Upsample1d
+using CH_U1 = ChainCfg<64, 64, 32, 32, RES_CONV, 1, -1, TAIL_UP>;     // ups.1: cat(x, skip1) RTB, RTB, Upsample1d
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // LDS of a workgroup: the largest stage is downs.2 / ups.0 -- the row-form fp32 x slab of downs.2's input + the 128-channel Rd
