@@ -318,6 +318,8 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
             d = float(np.mean([b - a for a, b in iv]))
             guide[name] = {"launch_ms": d * 1e3, "launches_timed": len(iv), "achieved": step_bytes / d / 1e9,
                            "frac": step_bytes / d / 1e9 / PEAK_HBM_GBPS}
+    if not iv_p:
+        guide["unguided"] = {"fused": "steps without guidance run inside the tail of the unet_kernel launch that produces their eps (no step-kernel launch)"}
     gp = pmc_all.get("GUIDE")
     if gp:
         guide["pmc"] = gp

@@ -32,6 +32,8 @@ void set_error(const char* fmt, ...) {
 constexpr int kMaxChunks = 4;
 // MMD_AMD_STREAMS=<n>: A/B override of mmd_sampler_desc.n_streams for tools/gpu_streams.sh, sampled ONCE at load time -- the
 // sampling entry points themselves never touch the environment
+// measurement override (A/B of the fused unguided step), sampled once when the library is loaded
+static const bool kEnvNoFusedStep = [] { const char* e = getenv("MMD_AMD_NO_FUSED_STEP"); return e && atoi(e) != 0; }();
 static const int kEnvStreams = [] {
   const char* e = getenv("MMD_AMD_STREAMS");
   return e ? atoi(e) : 0;
@@ -143,11 +145,10 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   // layer so both queues stay fed.  Robots are independent and the noise is keyed by the global trajectory index, so
   // results are bit-identical to the unsplit run.
   int nch = kEnvStreams > 0 ? kEnvStreams : s->n_streams;   // (measurement override, read once when the library is loaded)
-  // auto: 2 chunks once a chunk alone fills the chip (>= 1024 trajectories = one workgroup per CU): +7 % on the 32-robot
-  // round since downs.2 + mid run weight-stream-bound (bf16x3) -- one chunk's bandwidth-bound stages and step kernels
-  // meet the other's compute-bound ones on a CU, and a chunk's forward no longer ends with CUs idling until its slowest
-  // workgroup is done.  Smaller batches stay whole: two half-empty launches would share CUs that one leaves free (a
-  // 1024-trajectory round: 31.1 ms in two chunks, 23 ms in one).
+  // auto: 2 chunks once a chunk alone fills the chip (>= 1024 trajectories = one workgroup per CU): +6 .. 12 % on the 32-robot
+  // round (profiles/r03b_stream_chunks.txt) -- one chunk's guided step kernel runs beside the other chunk's UNet launch, and a
+  // chunk's forward no longer ends with CUs idling until its slowest workgroup is done.  Smaller batches stay whole: two
+  // half-empty launches would share CUs that one leaves free.
   if (nch <= 0) nch = n >= 2048 ? 2 : 1;
   if (nch > kMaxChunks) nch = kMaxChunks;
   if (nch > n_robots) nch = n_robots;
@@ -171,17 +172,33 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
     StepDev sd{};
     if ((rc = make_step(s, i, guide != nullptr, sd))) break;
     sd.seed = seed; sd.draw = (unsigned int)k;
+    // A step without guidance is fused into the tail of the UNet launch (unet.hip: the wave that holds a trajectory's eps applies
+    // ddpm_sample_fn to it): one launch and one dependent dispatch less per (step, chunk).
+    const bool fused = !sd.do_guide && !kEnvNoFusedStep;
+    const float* noise_k = step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr;
+    float* chain_k = chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr;
     for (int c = 0; c < nch && rc == 0; ++c) {
       const int t0 = r0[c] * samples_per_robot, nc = (r0[c + 1] - r0[c]) * samples_per_robot;
-      rc = mmd_unet_forward_profiled(unet, x_dev + (size_t)t0 * H * D, i < 0 ? 0 : i, eps + (size_t)t0 * H * D, nc,
-                                     workspace_dev, uws, (mmd_profiler_t)s->profiler, cs[c]);
+      if (fused) {
+        FusedStep fs{};
+        fs.enabled = 1;
+        fs.a_t = sd.a_t; fs.b_t = sd.b_t; fs.c1 = sd.c1; fs.c2 = sd.c2; fs.sigma = sd.sigma; fs.noise_std_extra = sd.noise_std_extra;
+        fs.do_noise = sd.do_noise; fs.hard_mask = sd.hard_mask; fs.seed = sd.seed; fs.draw = sd.draw; fs.traj_base = sd.traj_base;
+        fs.traj0 = t0; fs.spr = samples_per_robot;
+        fs.x = reinterpret_cast<float4*>(x_dev); fs.noise = reinterpret_cast<const float4*>(noise_k);
+        fs.chain = reinterpret_cast<float4*>(chain_k); fs.hard = reinterpret_cast<const float4*>(hard_dev);
+        rc = unet_forward_fused(unet, x_dev + (size_t)t0 * H * D, i < 0 ? 0 : i, eps + (size_t)t0 * H * D, nc, workspace_dev, uws,
+                                (mmd_profiler_t)s->profiler, cs[c], fs);
+        prof_skip((mmd_profiler_t)s->profiler, 1);
+      } else {
+        rc = mmd_unet_forward_profiled(unet, x_dev + (size_t)t0 * H * D, i < 0 ? 0 : i, eps + (size_t)t0 * H * D, nc,
+                                       workspace_dev, uws, (mmd_profiler_t)s->profiler, cs[c]);
+      }
     }
-    for (int c = 0; c < nch && rc == 0; ++c) {
+    for (int c = 0; c < nch && rc == 0 && !fused; ++c) {
       const int t0 = r0[c] * samples_per_robot, nc = (r0[c + 1] - r0[c]) * samples_per_robot;
-      const bool br = prof_begin((mmd_profiler_t)s->profiler, 1, sd.do_guide ? MMD_PROF_STEP_GUIDED : MMD_PROF_STEP_PLAIN, cs[c]);
-      launch_step(g, sd, x_dev, eps, step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr,
-                  chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr, hard_dev, t0, nc, samples_per_robot,
-                  cs[c]);
+      const bool br = prof_begin((mmd_profiler_t)s->profiler, 1, MMD_PROF_STEP_GUIDED, cs[c]);
+      launch_step(g, sd, x_dev, eps, noise_k, chain_k, hard_dev, t0, nc, samples_per_robot, cs[c]);
       if (br) prof_end((mmd_profiler_t)s->profiler, cs[c]);
     }
   }

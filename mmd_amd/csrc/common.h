@@ -32,6 +32,7 @@ void set_error(const char* fmt, ...);
 // measurement brackets of include/mmd_amd_debug.h (unet.hip): true = an event was recorded and prof_end must follow
 bool prof_begin(::mmd_profiler_s* prof, int counter, int kind, hipStream_t st);
 void prof_end(::mmd_profiler_s* prof, hipStream_t st);
+void prof_skip(::mmd_profiler_s* prof, int counter);   // a launch that did not happen (fused into another): keeps the counters in step
 
 constexpr int H = 64;   // support points per trajectory
 constexpr int D = 4;    // state dim (x, y, vx, vy)

@@ -25,36 +25,6 @@
 
 namespace mmd {
 
-// ---- Philox4x32-10 + Box-Muller -------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
-    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
-    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0;
-    const unsigned int n1 = (unsigned int)p1;
-    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
-    const unsigned int n3 = (unsigned int)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-
-// counter = (GLOBAL point index lo, draw, GLOBAL point index hi, 0), key = seed: a (robot, sample, t) point draws the same
-// noise whichever rank / stream chunk / batch position it is sampled in
-__device__ __forceinline__ float4 normal4(unsigned long long seed, unsigned int draw, unsigned long long point) {
-  unsigned int c[4] = {(unsigned int)point, draw, (unsigned int)(point >> 32), 0u};
-  philox4x32(c, (unsigned int)seed, (unsigned int)(seed >> 32));
-  const float s = 2.3283064365386963e-10f;   // 2^-32
-  const float u0 = ((float)c[0] + 0.5f) * s, u1 = ((float)c[1] + 0.5f) * s;
-  const float u2 = ((float)c[2] + 0.5f) * s, u3 = ((float)c[3] + 0.5f) * s;
-  const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
-  float s0, c0, s1, c1;
-  sincosf(6.283185307179586f * u1, &s0, &c0);
-  sincosf(6.283185307179586f * u3, &s1, &c1);
-  return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
-}
-
 // clip_grad_by_norm (guides.py:247-253): scale = clip(||g + 1e-6||, 0, max) / ||g + 1e-6||
 // n >= 2e-6 always (the +1e-6), so min(n, max) / n = min(1, max / n): one v_rsq_f32 (1 ulp) instead of the IEEE sqrt and
 // divide sequences (~25 VALU instructions, five times per guide iteration); the factor is exactly 1 whenever the term is
@@ -288,28 +258,7 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
   const size_t idx = (size_t)traj * H + t;
   float4 v = x[idx];
 
-  if (s.do_model) {
-    // p_mean_variance (diffusion_model_base.py:148-160): x0 = a x - b eps; clamp; mean = c1 x0 + c2 x
-    const float4 e = eps[idx];
-    if (s.ddim) {
-      // ddim_sample, eta = 0 (diffusion_model_base.py:245-262): x_start = a x - b eps (not clamped);
-      // x = x_start sqrt(alpha_next) + sqrt(1 - alpha_next) eps   (c1 = 1, c2 = 0 on the last pair: x = x_start)
-      v.x = s.c1 * (s.a_t * v.x - s.b_t * e.x) + s.c2 * e.x;
-      v.y = s.c1 * (s.a_t * v.y - s.b_t * e.y) + s.c2 * e.y;
-      v.z = s.c1 * (s.a_t * v.z - s.b_t * e.z) + s.c2 * e.z;
-      v.w = s.c1 * (s.a_t * v.w - s.b_t * e.w) + s.c2 * e.w;
-    } else {
-      float4 x0;
-      x0.x = fminf(fmaxf(s.a_t * v.x - s.b_t * e.x, -1.f), 1.f);
-      x0.y = fminf(fmaxf(s.a_t * v.y - s.b_t * e.y, -1.f), 1.f);
-      x0.z = fminf(fmaxf(s.a_t * v.z - s.b_t * e.z, -1.f), 1.f);
-      x0.w = fminf(fmaxf(s.a_t * v.w - s.b_t * e.w, -1.f), 1.f);
-      v.x = s.c1 * x0.x + s.c2 * v.x;
-      v.y = s.c1 * x0.y + s.c2 * v.y;
-      v.z = s.c1 * x0.z + s.c2 * v.z;
-      v.w = s.c1 * x0.w + s.c2 * v.w;
-    }
-  }
+  if (s.do_model) v = s.ddim ? ddim_update(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2) : ddpm_posterior_mean(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2);
 
   const float4 hs = hard[robot * 2 + 0], hg = hard[robot * 2 + 1];
   const bool is_start = (s.hard_mask & 1) && t == 0;
@@ -329,14 +278,7 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
     }
   }
 
-  if (s.do_noise) {
-    float4 z = noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx);
-    // x + model_std * noise * noise_std  (sample_functions.py:86)
-    v.x += s.sigma * z.x * s.noise_std_extra;
-    v.y += s.sigma * z.y * s.noise_std_extra;
-    v.z += s.sigma * z.z * s.noise_std_extra;
-    v.w += s.sigma * z.w * s.noise_std_extra;
-  }
+  if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx), s.sigma, s.noise_std_extra);
   if (is_start) v = hs;
   if (is_goal) v = hg;
   x[idx] = v;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/mmd_amd.h"
+#include "common.h"
 
 namespace mmd {
 
@@ -62,6 +63,75 @@ __device__ __forceinline__ float extra_sdf(const float4* __restrict__ xs, int n_
   return best;
 }
 
+// ---- Philox4x32-10 + Box-Muller -------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0;
+    const unsigned int n1 = (unsigned int)p1;
+    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+    const unsigned int n3 = (unsigned int)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// counter = (GLOBAL point index lo, draw, GLOBAL point index hi, 0), key = seed: a (robot, sample, t) point draws the same
+// noise whichever rank / stream chunk / batch position it is sampled in
+__device__ __forceinline__ float4 normal4(unsigned long long seed, unsigned int draw, unsigned long long point) {
+  unsigned int c[4] = {(unsigned int)point, draw, (unsigned int)(point >> 32), 0u};
+  philox4x32(c, (unsigned int)seed, (unsigned int)(seed >> 32));
+  const float s = 2.3283064365386963e-10f;   // 2^-32
+  const float u0 = ((float)c[0] + 0.5f) * s, u1 = ((float)c[1] + 0.5f) * s;
+  const float u2 = ((float)c[2] + 0.5f) * s, u3 = ((float)c[3] + 0.5f) * s;
+  const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+}
+
+// p_mean_variance (diffusion_model_base.py:148-160): x0 = a x - b eps; clamp; mean = c1 x0 + c2 x.  Explicit fmas: the step
+// kernel and the UNet kernel's fused unguided step (unet.hip) must round identically.
+__device__ __forceinline__ float ddpm_mean1(float x, float e, float a, float b, float c1, float c2) {
+  const float x0 = fminf(fmaxf(__builtin_fmaf(a, x, -(b * e)), -1.f), 1.f);
+  return __builtin_fmaf(c1, x0, c2 * x);
+}
+__device__ __forceinline__ float4 ddpm_posterior_mean(float4 v, float4 e, float a, float b, float c1, float c2) {
+  return make_float4(ddpm_mean1(v.x, e.x, a, b, c1, c2), ddpm_mean1(v.y, e.y, a, b, c1, c2), ddpm_mean1(v.z, e.z, a, b, c1, c2),
+                     ddpm_mean1(v.w, e.w, a, b, c1, c2));
+}
+// ddim_sample, eta = 0 (diffusion_model_base.py:245-262): x_start = a x - b eps (not clamped); x = x_start sqrt(alpha_next) +
+// sqrt(1 - alpha_next) eps   (c1 = 1, c2 = 0 on the last pair: x = x_start)
+__device__ __forceinline__ float4 ddim_update(float4 v, float4 e, float a, float b, float c1, float c2) {
+  auto f = [&](float x, float ee) { return __builtin_fmaf(c1, __builtin_fmaf(a, x, -(b * ee)), c2 * ee); };
+  return make_float4(f(v.x, e.x), f(v.y, e.y), f(v.z, e.z), f(v.w, e.w));
+}
+// x + model_std * noise * noise_std  (sample_functions.py:86)
+__device__ __forceinline__ float4 add_step_noise(float4 v, float4 z, float sigma, float noise_std_extra) {
+  return make_float4(__builtin_fmaf(sigma * z.x, noise_std_extra, v.x), __builtin_fmaf(sigma * z.y, noise_std_extra, v.y),
+                     __builtin_fmaf(sigma * z.z, noise_std_extra, v.z), __builtin_fmaf(sigma * z.w, noise_std_extra, v.w));
+}
+
+// An UNGUIDED ddpm_sample_fn step fused into the tail of the UNet launch that produces its eps (unet.hip; mmd_p_sample_loop uses
+// it for every step without guidance: one launch and one dependent-dispatch bubble less per step).  Pointers are those of the full
+// arrays, traj0 = first trajectory of the launch in them.
+struct FusedStep {
+  int enabled;
+  float a_t, b_t, c1, c2, sigma, noise_std_extra;
+  int do_noise, hard_mask;
+  unsigned long long seed;
+  unsigned int draw;
+  long long traj_base;
+  int traj0, spr;
+  float4* x;
+  const float4* noise;
+  float4* chain;
+  const float4* hard;
+};
+
 struct StepDev {
   float a_t, b_t, c1, c2;            // sqrt_recip_alphas_cumprod[t], sqrt_recipm1[t], posterior_mean_coef1/2[t]
   float sigma;                       // exp(0.5 * posterior_log_variance_clipped[t])
@@ -79,6 +149,9 @@ struct StepDev {
 };
 
 int fill_guide(const mmd_guide_desc* d, GuideDev& g);
+// the UNet forward with the unguided step fused into its tail (unet.hip)
+int unet_forward_fused(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, ::mmd_profiler_s* prof,
+                       hipStream_t st, const FusedStep& fs);
 int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
                 const float* hard, int traj0, int n_traj, int spr, hipStream_t st);
 int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed,

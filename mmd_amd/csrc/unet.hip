@@ -31,6 +31,7 @@
 #include "../../include/mmd_amd.h"
 #include "../../include/mmd_amd_debug.h"
 #include "common.h"
+#include "guide_dev.h"
 
 namespace mmd {
 
@@ -1365,7 +1366,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 // after it -- 3 convs, the transposed tail as two parity passes, the final block and the output store -- reads only what the
 // same wave wrote (wave_lds_fence).  Slabs: RwGeo<64, 32> (conv A chunks), RwGeo<32, 32>, RwGeo<32, 64> (final block).
 template <class CF>
-__device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, float* lds, int n0, int lane_in, int wave,
+__device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, const FusedStep& fs, float* lds, int n0, int lane_in, int wave,
                                                const f32x4 (&xe)[4][1], const f32x4 (&xo)[4][1], const f32x4 (&skip)[4][2],
                                                int trb) {
   // (an opaque copy of the lane index: the stage's lane-derived offsets are recomputed here -- a handful of VALU ops -- instead
@@ -1615,7 +1616,32 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     wave_lds_fence();
     f32x4 out[4][1];
     rd_taps<GF, 1, 2, 1, true, false, 4, 1>(out, out, vaF, w1, w1, ring1);
-    if (n < 4 && n0 + wave < a.n) {
+    if (fs.enabled) {
+      // eps[64][4] -> the wave's slab as float4 rows, lane = support point: the unguided ddpm_sample_fn step (sample_functions.py:
+      // 40-86; ddpm_guide_kernel's arithmetic, guide_dev.h) on the wave's trajectory, in place
+      float* const et = reinterpret_cast<float*>(slab);
+      wave_lds_fence();                                      // (the 1x1 conv's reads of the slab are done)
+      if (n < 4) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) et[(16 * mt + 4 * g + r) * 4 + n] = fmaf(out[mt][0][r], s1, b1);
+      }
+      wave_lds_fence();
+      if (n0 + wave < a.n) {
+        const float4 e = *reinterpret_cast<const float4*>(et + lane * 4);
+        const int traj = fs.traj0 + n0 + wave, robot = traj / fs.spr;
+        const size_t idx = (size_t)traj * H + lane;
+        float4 v = ddpm_posterior_mean(fs.x[idx], e, fs.a_t, fs.b_t, fs.c1, fs.c2);
+        if (fs.do_noise)
+          v = add_step_noise(v, fs.noise ? fs.noise[idx] : normal4(fs.seed, fs.draw, (unsigned long long)fs.traj_base * H + idx), fs.sigma,
+                             fs.noise_std_extra);
+        if ((fs.hard_mask & 1) && lane == 0) v = fs.hard[robot * 2 + 0];
+        if ((fs.hard_mask & 2) && lane == H - 1) v = fs.hard[robot * 2 + 1];
+        fs.x[idx] = v;
+        if (fs.chain) fs.chain[idx] = v;
+      }
+    } else if (n < 4 && n0 + wave < a.n) {
       float* dst = f.out + ((size_t)(n0 + wave) * 64 + 4 * g) * 4 + n;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
@@ -1634,6 +1660,7 @@ struct UnetArgs {
   ChainArgs c[5];
   FinalArgs fin;
   int n;
+  FusedStep fs;           // enabled: the unguided DDPM step on the launch's trajectories follows in the same kernel
 };
 
 static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SPB == 4 && CH_U1::SPB == 4,
@@ -1669,7 +1696,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   TR(131);
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32], final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]:
   //      wave = sample (chain_body_u1w)
-  chain_body_u1w<CH_U1>(a.c[4], a.fin, lds, n0, lane, wave, xe, xo, skip1, 146);
+  chain_body_u1w<CH_U1>(a.c[4], a.fin, a.fs, lds, n0, lane, wave, xe, xo, skip1, 146);
   TR(133);
 }
 
@@ -1966,6 +1993,9 @@ void prof_end(mmd_profiler_t prof, hipStream_t st) {
   (void)hipEventRecord(prof->ev[prof->used + 1], st);
   prof->used += 2;
 }
+void prof_skip(mmd_profiler_t prof, int counter) {
+  if (prof) ++prof->seen[counter];
+}
 }  // namespace mmd
 
 namespace mmd {
@@ -2227,7 +2257,7 @@ static const double kUnetMfmaFlops = kF16Flops + kFp32Flops;
 
 
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
-                             hipStream_t st, mmd_profiler_t prof) {
+                             hipStream_t st, mmd_profiler_t prof, const FusedStep* fs = nullptr) {
   MMD_REQUIRE(u && x && eps && ws, "mmd_unet_forward: NULL argument");
   MMD_REQUIRE(n >= 1, "mmd_unet_forward: n_traj must be >= 1");
   MMD_REQUIRE(t >= 0 && t < u->T, "mmd_unet_forward: t=%d outside [0,%d)", t, u->T);
@@ -2237,6 +2267,7 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   const RtbW* set = u->rtb;
   UnetArgs a{};
   a.n = n;
+  if (fs) a.fs = *fs;
   a.c[0] = args_chain(u, set, kD0, 1, &u->down[0], x, t, n);
   a.c[1] = args_chain(u, set, kD1, 1, &u->down[1], nullptr, t, n);
   a.c[2] = args_chain(u, set, kD2, 3, nullptr, nullptr, t, n);
@@ -2256,6 +2287,15 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }
+
+}  // extern "C"
+namespace mmd {
+int unet_forward_fused(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, ::mmd_profiler_s* prof,
+                       hipStream_t st, const FusedStep& fs) {
+  return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, st, prof, &fs);
+}
+}  // namespace mmd
+extern "C" {
 
 int mmd_unet_forward(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, void* stream) {
   return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, (hipStream_t)stream, nullptr);

@@ -1,2 +1,5 @@
 export TMPDIR=/tmp
-for n in 512 2048; do MMD_AMD_LIB=$PWD/build_tmp/libmmd_amd_trace.so timeout 120 python tools/dbg/trace_phases.py $n > gpurun_out/r03_trace_${n}_all_direct.txt 2>&1; done
+for i in 1 2 3; do
+for f in 1 0; do
+echo "no_fused=$f $(MMD_AMD_NO_FUSED_STEP=$f timeout 300 python bench.py --steps 8 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["value"]), "traj/s", round(d["ms_per_step"],2), "ms/round")')"
+done; done > gpurun_out/r03_fused_step_ab.txt
