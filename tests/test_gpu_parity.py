@@ -561,6 +561,34 @@ def test_stream_chunking_is_bit_identical():
         assert torch.equal(out, ref), ns
 
 
+def test_fused_unguided_steps_equal_the_step_api_bitwise():
+    """mmd_p_sample_loop applies the steps WITHOUT guidance inside the UNet launch (FusedStep, unet.hip); mmd_ddpm_step keeps the
+    UNet launch + ddpm_guide_kernel form.  Both run the same explicit-fma helpers (guide_dev.h), so the whole chain of a guided
+    call -- 12 fused steps, then 14 guided ones -- must equal the step-by-step replay BIT FOR BIT (injected noise: the two entry
+    points number their Philox draws differently); B = 5 also covers a workgroup with invalid waves.
+    ref: sample_functions.py:40-86."""
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    T, B, R = 25, 5, 3
+    starts, goals = synth.start_goal_circle(R, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    model = _gc().hip_model(T)
+    hc_all = {0: torch.stack([cases.hard_conds_for(starts[r], goals[r])[0] for r in range(R)]),
+              H - 1: torch.stack([cases.hard_conds_for(starts[r], goals[r])[H - 1] for r in range(R)])}
+    guide = _gc().hip_guide("EnvHighways2D", [[cases.soft_group(paths, r)] for r in range(R)], n_robots=R)
+    xT = torch.from_numpy(synth.synth_noise(80, (R * B, H, D))).cuda()
+    steps = torch.from_numpy(synth.synth_noise(81, (T + 1, R * B, H, D))).cuda()
+    kw = dict(horizon=H, return_chain=True, sample_fn=ddpm_sample_fn, n_guide_steps=20, t_start_guide=13,
+              noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=1, guide=guide, n_samples=B, n_robots=R,
+              warm_start_path_b=xT.clone())
+    chain = model.run_inference(None, hc_all, step_noise=steps, **kw)                  # [T + 2, R B, H, D]
+    x = chain[0].clone()
+    assert torch.equal(x[:, 1:-1], xT[:, 1:-1])
+    for k, i in enumerate(reversed(range(-1, T))):
+        model.sample_step(x, hc_all, i, guide=guide, n_guide_steps=20, t_start_guide=13, noise_std_extra_schedule_fn=lambda t: 0.5,
+                          n_robots=R, noise=steps[k])
+        assert torch.equal(x, chain[k + 1]), (k, i, float((x - chain[k + 1]).abs().max()))
+
+
 def test_philox_noise_statistics():
     """Production path: in-kernel Philox draws (no injected noise) are N(0,1) and reproducible per seed."""
     model = _gc().hip_model(25)
