@@ -282,7 +282,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
     eq_tf = mfma_flops * len(dur) / union_s / 1e12
     roofline = {
         "bound": "mfma",
-        "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; the 25 k=5 convs as fp32-accurate GEMMs: downs.0, downs.2 + mid, ups.0 direct and downs.1 Winograd F(4,5) as an fp16 two-piece split of fp32 (f16x2, 3 MFMAs per product) on v_mfma_f32_16x16x32_f16, ups.1 + final block Winograd F(4,5) on the fp32 MFMA; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
+        "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; every conv a direct convolution as an fp16 two-piece split of fp32 (f16x2, 3 MFMAs per product, fp32 accumulate) on v_mfma_f32_16x16x32_f16; the unguided DDPM steps ride in its tail; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
         "achieved": pipe_busy * PEAK_FP32_MFMA_TFLOPS, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": pipe_busy,
         "frac_definition": "matrix-pipe busy fraction: MFMA issue time of the bracketed launches at spec clock (fp32 MFMAs at "
                            "157.3 TFLOP/s, fp16 MFMAs at 2516.6) / wall time during which at least one of them runs (union of "
@@ -302,8 +302,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
             "algorithmic_rate_tflops": flops * len(dur) / union_s / 1e12,
             "note": "fp32 GEMM FLOPs the kernel performs (in the form each stage uses; an f16x2 conv counted as the fp32 math it "
                     "does) and direct-convolution FLOPs (SURVEY 8d) per second of UNet wall time: both exceed what the fp32 pipe "
-                    "could issue because the f16x2 part runs on the 16x faster pipe (and the Winograd stages need 0.45x the "
-                    "multiplies); they are rates of useful work, not a utilisation"},
+                    "could issue because f16x2 runs on the 16x faster pipe; they are rates of useful work, not a utilisation"},
     }
     pmc_busy = pmc_all.get(DOMINANT_KERNEL, {}).get("mfma_busy_frac")
     if pmc_busy is not None:

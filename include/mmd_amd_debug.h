@@ -37,9 +37,9 @@ int mmd_profiler_read(mmd_profiler_t p, double* mean_ms, int* n_launches);
 
 /* One TemporalUnet forward = one launch of unet_kernel.  Algorithmic FLOPs per trajectory (direct-convolution count:
  * 2 * C_out * taps * C_in * L_out over its convs); the fp32 GEMM FLOPs the kernel actually runs on the matrix
- * pipe per trajectory (the 25 k=5 convs as Winograd F(4,5): 8 products per 4 outputs; channel / N padding included); and
+ * pipe per trajectory (every conv a direct GEMM; channel / N padding and the strided tails' discarded positions included); and
  * the part of the latter that runs as f16x2 on the fp16 pipe (two fp16 pieces per operand, 3 fp16 MFMA FLOPs per fp32
- * FLOP; the rest are fp32 MFMAs). */
+ * FLOP) -- all of it since round 3. */
 double mmd_unet_flops_per_trajectory(void);
 double mmd_unet_mfma_flops_per_trajectory(void);
 double mmd_unet_f16x2_flops_per_trajectory(void);

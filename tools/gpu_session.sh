@@ -1,2 +1,6 @@
 export TMPDIR=/tmp
-for f in 2 0 2 0; do echo "no_fused=$f"; MMD_AMD_NO_FUSED_STEP=$f timeout 300 python tools/dbg/shard_cost.py strong 1 2 4 8 2>&1 | grep "W=" | cut -c1-140; done > gpurun_out/r03_fused_guided_shard.txt; cat gpurun_out/r03_fused_guided_shard.txt
+for i in 1 2; do
+echo "default $(REPS=40 timeout 300 python tools/unet_forward_loop.py 512 2048 2>&1 | grep unet | cut -c1-40 | tr '\n' ' ')"
+for v in f_rategymaxilp f_memoryclause f_nlinealltrue; do
+echo "$v $(MMD_AMD_LIB=$PWD/build_tmp/libmmd_amd_$v.so REPS=40 timeout 300 python tools/unet_forward_loop.py 512 2048 2>&1 | grep unet | cut -c1-40 | tr '\n' ' ')"
+done; done > gpurun_out/s27_flags.txt; cat gpurun_out/s27_flags.txt
