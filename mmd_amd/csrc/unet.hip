@@ -168,11 +168,15 @@ constexpr int MX_FLOATS = 3 * MX_REGION;                     // mid blocks' outp
 // sink them down to their first use (one k-group later: the L2 latency then sits in front of the MFMA again).
 // The machine scheduler gets a full barrier at the same point, or it hoists the VALU consumers of an LDS read up to the
 // read (and with them the s_waitcnt), which exposes the LDS latency once per k-step.
+#ifdef MMD_NO_PIN                        // (tools/ubench/fatwave_conv.hip: the scheduler is steered by sched_group_barrier there)
+#define MMD_PIN_LOADS() do { } while (0)
+#else
 #define MMD_PIN_LOADS()                 \
   do {                                  \
     asm volatile("" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
+#endif
 
 // Phase tracing (side builds with -DMMD_TRACE only; tools/dbg/trace_phases.py): lane 0 of every wave stamps the 100 MHz
 // wall clock at tagged points into a [block][wave][256] table set with mmd_debug_set_trace().
