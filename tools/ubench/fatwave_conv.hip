@@ -10,6 +10,9 @@
 #define MMD_VB3_LOOSE
 #define MMD_NO_PIN
 #endif
+#ifndef VPT
+#define VPT 4                 // VALU instructions asked for after each MFMA triple (HOOK variant)
+#endif
 #include "../../mmd_amd/csrc/unet.hip"
 
 #include <cstdio>
@@ -27,7 +30,66 @@ __device__ __forceinline__ void epilogue(ACC& acc, const Epi<2>& e) {
   rd_gn_mish<2, 256, true>(acc, e.b, e.g, e.be, e.is, one4, act_scale(1.f), [&](int, int t, int) { return t ? t1 : t0; });
 }
 
-#ifndef FAT
+#ifdef DPPTAPS
+// The taps of a k = 5 conv at L = 16 are row-shifted views of the slab: M tile = sample = 16 positions = ONE 16-lane DPP row of
+// the A fragment, so the fragment of tap d is the centre fragment shifted by d lanes inside every row (row_shr / row_shl with
+// zero fill = the zero halo).  One ds_read_b128 per (chunk, M tile, piece) + 16 v_mov_dpp per other tap instead of five reads:
+// LDS -> VGPR traffic / 5 (the conv loop is bound by exactly that traffic competing with the MFMAs for the register file,
+// profiles/r03_ubench_conv_parts.txt).  Steps run chunk-major: (kc, tap).
+template <int D>
+__device__ __forceinline__ u32x4 dpp_rows(const u32x4& v) {
+  if constexpr (D == 0) return v;
+  constexpr int ctrl = D > 0 ? 0x100 + D : 0x110 - D;          // row_shl:D (lane i <- lane i + D) / row_shr:-D
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], ctrl, 0xf, 0xf, true);
+  return r;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <class GEO, int NT, int MT, int RD>
+__device__ __forceinline__ void rd_taps_dpp(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2]) {
+  constexpr int KC = GEO::KC, STEPS = 5 * KC;
+  // centre fragments of chunk kc, per M-tile PAIR: the pair that is not multiplying is re-loaded for the next chunk
+  u32x4 c[MT][2];
+  auto load_c = [&](int m0, int kc) {
+#pragma unroll
+    for (int m = m0; m < m0 + 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) c[m][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + (GEO::tile_row(m) + 2) * 16);
+  };
+  load_c(0, 0);
+  load_c(2, 0);
+  MMD_PIN_LOADS();
+  // order inside a chunk: the five taps of pair 0, then the five taps of pair 1; pair 0's next-chunk fragments are requested
+  // when pair 1 starts, pair 1's when the next chunk's pair 0 starts.  Weight steps: 10 per chunk (pair, tap) -- the B fragment
+  // of a tap is loaded twice per chunk ... no: a weight step is shared by both pairs, so the taps of both pairs run inside it.
+  static_for<0, KC>([&](auto kcc) {
+    constexpr int kc = decltype(kcc)::value;
+    static_for<0, 5>([&](auto tc) {
+      constexpr int tap = decltype(tc)::value, q = kc * 5 + tap, ri = q % RD;
+      constexpr bool zero = q == 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const u32x4 a[2] = {dpp_rows<tap - 2>(c[m][0]), dpp_rows<tap - 2>(c[m][1])};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) vb_three<zero>(acc[m][t], a, b[ri][t]);
+        // after the LAST tap's use of a pair its registers take the next chunk's fragments
+        if constexpr (tap == 4 && kc + 1 < KC) {
+          if (m == 1) { load_c(0, kc + 1); MMD_PIN_LOADS(); }
+          if (m == 3) { load_c(2, kc + 1); MMD_PIN_LOADS(); }
+        }
+      }
+      if constexpr (q + RD < STEPS) rd_load_b<GEO, NT>(b[ri], w, q + RD);   // (the pack would be chunk-major: sequential)
+      MMD_PIN_LOADS();
+    });
+  });
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
   __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
@@ -42,6 +104,110 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
   __syncthreads();
   for (int k = 0; k < nconv; ++k) {
+    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
+    u32x4 ring[3][2][2];
+    // chunk-major step order: sequence index q = 5 kc + tap reads weight step tap KC + kc
+#pragma unroll
+    for (int q = 0; q < 3; ++q) rd_load_b<G128, 2>(ring[q], wp, q);
+    rd_store2<G128>(vs, acc);
+    __syncthreads();
+    rd_taps_dpp<G128, 2, 4, 3>(acc, va, wp, ring);
+    epilogue(acc, e);
+    __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int t = 0; t < 2; ++t) s += acc[i][t][0] + acc[i][t][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+constexpr int SAMPLES_PER_WG = 4;
+#elif defined(PARTS)
+// What bounds the conv?  The base loop with parts switched off (-DPARTS=<mask>): 1 MFMAs, 2 A fragments from the LDS, 4 weight
+// fragments from L2 / L1, 8 epilogue (GroupNorm + Mish), 16 slab store, 32 the two barriers.  Loads that feed no MFMA are folded
+// into the accumulators with one xor each so that they stay.
+template <class GEO, int NT, int MT, int RD>
+__device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2]) {
+  constexpr int KC = GEO::KC, STEPS = 5 * KC, HP = MT / 2;
+  u32x4 a[2][2][2];
+  if (PARTS & 2) rd_load_a<GEO>(a[0], va, 0, 0, 0);
+  else for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 2; ++q) a[i][j][q] = u32x4{1u, 2u, 3u, 4u};
+  MMD_PIN_LOADS();
+#pragma unroll
+  for (int tap = 0; tap < 5; ++tap)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int st = tap * KC + kc, ri = st % RD;
+      const bool zero = st == 0, last_kc = kc + 1 == KC;
+#pragma unroll
+      for (int hp = 0; hp < HP; ++hp) {
+        const int cur = (st * HP + hp) & 1;
+        if (PARTS & 2) {
+          if (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, tap, kc, hp + 1);
+          else rd_load_a<GEO>(a[cur ^ 1], va, last_kc ? tap + 1 : tap, last_kc ? 0 : kc + 1, 0);
+        }
+        MMD_PIN_LOADS();
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (PARTS & 1) {
+              if (zero) vb_three<true>(acc[2 * hp + sm][t], a[cur][sm], b[ri][t]);
+              else vb_three<false>(acc[2 * hp + sm][t], a[cur][sm], b[ri][t]);
+            } else {
+              const unsigned x = a[cur][sm][0][0] ^ a[cur][sm][1][3] ^ b[ri][t][0][1] ^ b[ri][t][1][2];
+              acc[2 * hp + sm][t][0] += __builtin_bit_cast(float, (x & 0x007fffffu) | 0x3f800000u) * 1e-9f;
+            }
+          }
+      }
+      if ((PARTS & 4) && st + RD < STEPS) rd_load_b<GEO, NT>(b[ri], w, st + RD);
+      MMD_PIN_LOADS();
+    }
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
+  __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
+  const int c0 = 32 * wave + 2 * n;
+  char* const slab = reinterpret_cast<char*>(lds);
+  const char* const va = slab + g * G128::G + n * 16;
+  char* const vs = slab + wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4;
+  f32x4 acc[4][2];
+  for (int s = 0; s < 4; ++s) for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
+  rd_zero_halo<G128>(slab);
+  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
+                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  __syncthreads();
+  for (int k = 0; k < nconv; ++k) {
+    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
+    u32x4 ring[3][2][2];
+    rd_ring_load<G128, 2, 3>(ring, wp);
+    if (PARTS & 16) rd_store2<G128>(vs, acc);
+    if (PARTS & 32) __syncthreads();
+    rd_taps_parts<G128, 2, 4, 3>(acc, va, wp, ring);
+    if (PARTS & 8) epilogue(acc, e);
+    if (PARTS & 32) __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int t = 0; t < 2; ++t) s += acc[i][t][0] + acc[i][t][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+constexpr int SAMPLES_PER_WG = 4;
+#elif !defined(FAT)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
+  __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
+  const int c0 = 32 * wave + 2 * n;
+  char* const slab = reinterpret_cast<char*>(lds);
+  const char* const va = slab + g * G128::G + n * 16;
+  char* const vs = slab + wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4;
+  f32x4 acc[4][2];
+  for (int s = 0; s < 4; ++s) for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
+  rd_zero_halo<G128>(slab);
+  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
+                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  __syncthreads();
+  for (int k = 0; k < nconv; ++k) {
+    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
     u32x4 ring[3][2][2];
     rd_ring_load<G128, 2, 3>(ring, wp);
@@ -56,6 +222,286 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 constexpr int SAMPLES_PER_WG = 4;
+#elif defined(MICRO)
+// compile-time loops: every index below is a constant expression, so the epilogue state stays in registers
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// rd_taps with a hook after EVERY MFMA triple (8 per step, 160 per conv), strict program order (sched_barrier after each):
+// hook(m) issues a <= 4-instruction micro-slice of the OTHER half's epilogue into the triple's shadow
+template <class GEO, int NT, int MT, int RD, class HOOKF>
+__device__ __forceinline__ void rd_taps_micro(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2], HOOKF hook) {
+  constexpr int KC = GEO::KC, STEPS = 5 * KC, HP = MT / 2;
+  u32x4 a[2][2][2];
+  rd_load_a<GEO>(a[0], va, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<0, STEPS>([&](auto stc) {
+    constexpr int st = decltype(stc)::value, tap = st / KC, kc = st % KC, ri = st % RD;
+    constexpr bool zero = st == 0, last_kc = kc + 1 == KC;
+    static_for<0, HP>([&](auto hpc) {
+      constexpr int hp = decltype(hpc)::value, cur = (st * HP + hp) & 1;
+      if constexpr (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, tap, kc, hp + 1);
+      else rd_load_a<GEO>(a[cur ^ 1], va, last_kc ? tap + 1 : tap, last_kc ? 0 : kc + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 2 * NT>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, sm = q / NT, t = q % NT;
+        vb_three<zero>(acc[2 * hp + sm][t], a[cur][sm], b[ri][t]);
+        __builtin_amdgcn_sched_barrier(0);
+        hook(std::integral_constant<int, ((st * HP + hp) * 2 + sm) * NT + t>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    if constexpr (st + RD < STEPS) rd_load_b<GEO, NT>(b[ri], w, st + RD);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+struct MicroState {
+  float k[4][2], sum[4], dm[4][2], sq[4], bmean, v, rstd;
+  GnCoef cf[2];
+  f32x2_t yl, e2, n2, q2;
+};
+// micro-slice M (0 .. 159) of rd_gn_mish<2, 256, true> + rd_store2 for the tile in acc; 140 are used
+template <int M>
+__device__ __forceinline__ void epi_micro(f32x4 (&acc)[4][2], const Epi<2>& e, MicroState& S, char* vs) {
+  constexpr float inv_n = 1.f / 256.f, LOG2E = 1.44269504088896341f;
+  if constexpr (M < 8) {                         // A: sums, one tile per slice
+    constexpr int sm = M >> 1, t = M & 1;
+    if constexpr (M == 0) S.bmean = e.b[0] + e.b[1];
+    S.k[sm][t] = e.is[t];
+    const float st = (acc[sm][t][0] + acc[sm][t][1]) + (acc[sm][t][2] + acc[sm][t][3]);
+    S.v = fmaf(st, S.k[sm][t], t ? S.v : 0.f);
+    if constexpr (t == 1) S.sum[sm] = S.v;
+  } else if constexpr (M < 16) {                 // B: reductions of the sums
+    constexpr int sm = (M - 8) >> 1, h = (M - 8) & 1;
+    if constexpr (h == 0) S.sum[sm] = group_colsum<8>(S.sum[sm]);
+    else S.sum[sm] = add_xor32(add_xor16(S.sum[sm]));
+    if constexpr (M == 15) S.bmean = group_colsum<8>(S.bmean) * 16.f * inv_n;
+  } else if constexpr (M < 36) {                 // C: centred squares, 5 slices per sample
+    constexpr int sm = (M - 16) / 5, j = (M - 16) % 5;
+    if constexpr (j == 0) {
+      const float mean = fmaf(S.sum[sm], inv_n, S.bmean);
+      S.dm[sm][0] = mean - e.b[0];
+      S.dm[sm][1] = mean - e.b[1];
+      S.v = 0.f;
+    } else {
+      constexpr int t = (j - 1) >> 1, r0 = ((j - 1) & 1) * 2;
+#pragma unroll
+      for (int r = r0; r < r0 + 2; ++r) {
+        const float d = fmaf(acc[sm][t][r], S.k[sm][t], -S.dm[sm][t]);
+        S.v = fmaf(d, d, S.v);
+      }
+      if constexpr (j == 4) S.sq[sm] = S.v;
+    }
+  } else if constexpr (M < 44) {                 // D: reductions of the squares
+    constexpr int sm = (M - 36) >> 1, h = (M - 36) & 1;
+    if constexpr (h == 0) S.sq[sm] = group_colsum<8>(S.sq[sm]);
+    else S.sq[sm] = add_xor32(add_xor16(S.sq[sm]));
+  } else if constexpr (M < 124) {                // E + F per sample: rstd, 2 x coef, then 4 pairs x 3 slices
+    constexpr int sm = (M - 44) / 20, j = (M - 44) % 20;
+    if constexpr (j == 0) S.rstd = __builtin_amdgcn_rsqf(fmaf(S.sq[sm], inv_n, 1e-5f));
+    else if constexpr (j < 3) {
+      constexpr int t = j - 1;
+      S.cf[t] = gn_coef(S.dm[sm][t], S.rstd, e.g[t], e.be[t]);
+      S.cf[t].sa *= S.k[sm][t];
+    } else if constexpr (j < 15) {
+      constexpr int pr = (j - 3) / 3, ph = (j - 3) % 3, t = pr >> 1, r = (pr & 1) * 2;
+      if constexpr (ph == 0) {
+        S.yl = __builtin_elementwise_fma(f32x2_t{acc[sm][t][r], acc[sm][t][r + 1]}, f32x2_t{S.cf[t].sa, S.cf[t].sa}, f32x2_t{S.cf[t].sb, S.cf[t].sb});
+        S.e2 = f32x2_t{__builtin_amdgcn_exp2f(fminf(S.yl.x, 20.f * LOG2E)), __builtin_amdgcn_exp2f(fminf(S.yl.y, 20.f * LOG2E))};
+      } else if constexpr (ph == 1) {
+        S.n2 = S.e2 * (S.e2 + f32x2_t{2.f, 2.f});
+        const f32x2_t den = __builtin_elementwise_fma(S.n2, f32x2_t{LOG2E, LOG2E}, f32x2_t{2.f * LOG2E, 2.f * LOG2E});
+        S.q2 = f32x2_t{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+      } else {
+        const f32x2_t o = __builtin_elementwise_fma(S.yl, S.n2 * S.q2, f32x2_t{e.tb[t], e.tb[t]});
+        acc[sm][t][r] = o.x;
+        acc[sm][t][r + 1] = o.y;
+      }
+    }
+  } else if constexpr (M < 140) {                // G: split + store, one (sample, r) per slice
+    constexpr int sm = (M - 124) >> 2, r = (M - 124) & 3;
+    const F16Pair f = f16_split2(acc[sm][0][r], acc[sm][1][r]);
+    *reinterpret_cast<unsigned*>(vs + (sm * G128::RPS + r) * 16) = f.hi;
+    *reinterpret_cast<unsigned*>(vs + G128::PS + (sm * G128::RPS + r) * 16) = f.lo;
+  }
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_loop(ConvP p, float* out, int nconv) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
+  const int c0 = 32 * wave + 2 * n;
+  char* const slabA = reinterpret_cast<char*>(lds);
+  char* const slabB = slabA + G128::BYTES;
+  const int va_off = g * G128::G + n * 16, vs_off = wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4;
+  f32x4 accA[4][2], accB[4][2];
+  for (int s = 0; s < 4; ++s) for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) {
+    accA[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
+    accB[s][t][r] = 0.01f * ((threadIdx.x * 5 + s * 2 + t + r + blockIdx.x) % 89) - 0.4f;
+  }
+  rd_zero_halo<G128>(slabA);
+  rd_zero_halo<G128>(slabB);
+  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
+                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  __syncthreads();
+  rd_store2<G128>(slabA + vs_off, accA);
+  __syncthreads();
+  MicroState S;
+  for (int k = 0; k < nconv; ++k) {
+    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
+    {
+      u32x4 ring[3][2][2];
+      rd_ring_load<G128, 2, 3>(ring, wp);
+      rd_taps_micro<G128, 2, 4, 3>(accA, slabA + va_off, wp, ring, [&](auto mc) { epi_micro<decltype(mc)::value>(accB, e, S, slabB + vs_off); });
+      __syncthreads();
+    }
+    {
+      u32x4 ring[3][2][2];
+      rd_ring_load<G128, 2, 3>(ring, wp);
+      rd_taps_micro<G128, 2, 4, 3>(accB, slabB + va_off, wp, ring, [&](auto mc) { epi_micro<decltype(mc)::value>(accA, e, S, slabA + vs_off); });
+      __syncthreads();
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int t = 0; t < 2; ++t) s += accA[i][t][0] + accA[i][t][3] + accB[i][t][1];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+constexpr int SAMPLES_PER_WG = 8;
+#elif defined(HOOK)
+// rd_taps with a per-step hook: step st's code, then hook(st) -- an epilogue slice of the OTHER half -- then a small
+// sched_group_barrier pipeline for this region (8 MFMA triples, a few VALU after each) and a region barrier
+template <class GEO, int NT, int MT, int RD, class HOOKF>
+__device__ __forceinline__ void rd_taps_hook(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2], HOOKF hook) {
+  constexpr int KC = GEO::KC, STEPS = 5 * KC, HP = MT / 2;
+  u32x4 a[2][2][2];
+  rd_load_a<GEO>(a[0], va, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int tap = 0; tap < 5; ++tap)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int st = tap * KC + kc, ri = st % RD;
+      const bool zero = st == 0, last_kc = kc + 1 == KC;
+#pragma unroll
+      for (int hp = 0; hp < HP; ++hp) {
+        const int cur = (st * HP + hp) & 1;
+        if (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, tap, kc, hp + 1);
+        else rd_load_a<GEO>(a[cur ^ 1], va, last_kc ? tap + 1 : tap, last_kc ? 0 : kc + 1, 0);
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (zero) vb_three<true>(acc[2 * hp + sm][t], a[cur][sm], b[ri][t]);
+            else vb_three<false>(acc[2 * hp + sm][t], a[cur][sm], b[ri][t]);
+          }
+      }
+      if (st + RD < STEPS) rd_load_b<GEO, NT>(b[ri], w, st + RD);
+      hook(st);
+      // region pipeline: DS reads first, then 8 x (3 MFMAs, VPT VALU), the VMEM reads last
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPT, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+}
+struct EpiState { float k[4][2], sum[4], dm[4][2], sq[4], bmean; };
+// slice st (0 .. 19) of rd_gn_mish<2, 256, true> + rd_store2 for the tile in acc
+__device__ __forceinline__ void epi_slice(int st, f32x4 (&acc)[4][2], const Epi<2>& e, EpiState& S, char* vs) {
+  constexpr float inv_n = 1.f / 256.f;
+  if (st < 4) {
+    const int sm = st;
+    if (st == 0) S.bmean = group_colsum<8>(e.b[0] + e.b[1]) * 16.f * inv_n;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      S.k[sm][t] = e.is[t];
+      v = fmaf((acc[sm][t][0] + acc[sm][t][1]) + (acc[sm][t][2] + acc[sm][t][3]), S.k[sm][t], v);
+    }
+    S.sum[sm] = add_xor32(add_xor16(group_colsum<8>(v)));
+  } else if (st < 8) {
+    const int sm = st - 4;
+    const float mean = fmaf(S.sum[sm], inv_n, S.bmean);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      S.dm[sm][t] = mean - e.b[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = fmaf(acc[sm][t][r], S.k[sm][t], -S.dm[sm][t]);
+        v = fmaf(d, d, v);
+      }
+    }
+    S.sq[sm] = add_xor32(add_xor16(group_colsum<8>(v)));
+  } else if (st < 16) {
+    const int sm = (st - 8) >> 1, t = (st - 8) & 1;
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(S.sq[sm], inv_n, 1e-5f));
+    GnCoef cf = gn_coef(S.dm[sm][t], rstd, e.g[t], e.be[t]);
+    cf.sa *= S.k[sm][t];
+    const ActScale as = act_scale(1.f);
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      const f32x2_t o = gn_mish2<true>(f32x2_t{acc[sm][t][r], acc[sm][t][r + 1]}, cf, f32x2_t{e.tb[t], e.tb[t]}, as);
+      acc[sm][t][r] = o.x;
+      acc[sm][t][r + 1] = o.y;
+    }
+  } else {
+    const int sm = st - 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const F16Pair f = f16_split2(acc[sm][0][r], acc[sm][1][r]);
+      *reinterpret_cast<unsigned*>(vs + (sm * G128::RPS + r) * 16) = f.hi;
+      *reinterpret_cast<unsigned*>(vs + G128::PS + (sm * G128::RPS + r) * 16) = f.lo;
+    }
+  }
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_loop(ConvP p, float* out, int nconv) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
+  const int c0 = 32 * wave + 2 * n;
+  char* const slabA = reinterpret_cast<char*>(lds);
+  char* const slabB = slabA + G128::BYTES;
+  const int va_off = g * G128::G + n * 16, vs_off = wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4;
+  f32x4 accA[4][2], accB[4][2];
+  for (int s = 0; s < 4; ++s) for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) {
+    accA[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
+    accB[s][t][r] = 0.01f * ((threadIdx.x * 5 + s * 2 + t + r + blockIdx.x) % 89) - 0.4f;
+  }
+  rd_zero_halo<G128>(slabA);
+  rd_zero_halo<G128>(slabB);
+  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
+                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  __syncthreads();
+  rd_store2<G128>(slabA + vs_off, accA);
+  __syncthreads();
+  EpiState S;
+  for (int k = 0; k < nconv; ++k) {
+    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
+    {
+      u32x4 ring[3][2][2];
+      rd_ring_load<G128, 2, 3>(ring, wp);
+      rd_taps_hook<G128, 2, 4, 3>(accA, slabA + va_off, wp, ring, [&](int st) { epi_slice(st, accB, e, S, slabB + vs_off); });
+      __syncthreads();
+    }
+    {
+      u32x4 ring[3][2][2];
+      rd_ring_load<G128, 2, 3>(ring, wp);
+      rd_taps_hook<G128, 2, 4, 3>(accB, slabB + va_off, wp, ring, [&](int st) { epi_slice(st, accA, e, S, slabA + vs_off); });
+      __syncthreads();
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int t = 0; t < 2; ++t) s += accA[i][t][0] + accA[i][t][3] + accB[i][t][1];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+constexpr int SAMPLES_PER_WG = 8;
 #else
 // one scheduling pipeline for a phase: per step (20) and half step (2): 4 DS reads, then 4 x (3 MFMAs, 4 VALU); per step 4 VMEM reads
 __device__ __forceinline__ void phase_pipeline() {
@@ -96,6 +542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   rd_store2<G128>(slabA + vs_off, accA);
   __syncthreads();
   for (int k = 0; k < nconv; ++k) {
+    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
     {   // phase 1: taps of half A; epilogue + slab store of half B (its previous conv)
       u32x4 ring[3][2][2];
@@ -154,7 +601,7 @@ int main() {
 #ifdef FAT
            "fat ",
 #else
-           "base",
+           "base",  // (PARTS builds print base too; the mask is in the file name)
 #endif
            nb, SAMPLES_PER_WG, nconv, ms * 1e3, ms * 1e3 / nconv, ho[3], hipGetErrorString(hipGetLastError()));
   }
