@@ -57,11 +57,11 @@ class PowerSampler(threading.Thread):
     current level, hwmon power1_input / power1_average), or `rocm-smi --showclocks --showpower` when sysfs is not
     there.  Of several cards, the one drawing the most power is reported.  Everything is best effort: no reading -> None."""
 
-    def __init__(self, period=0.02):
+    def __init__(self, period=0.02, drm_root="/sys/class/drm"):
         super().__init__(daemon=True)
         self.period, self.halt, self.samples = period, threading.Event(), {}
         self.cards = []
-        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        for dev in sorted(glob.glob(os.path.join(drm_root, "card[0-9]*", "device"))):
             pw = sorted(glob.glob(dev + "/hwmon/hwmon*/power1_input")) or sorted(glob.glob(dev + "/hwmon/hwmon*/power1_average"))
             if os.path.exists(dev + "/pp_dpm_sclk") and pw:
                 self.cards.append((dev + "/pp_dpm_sclk", pw[0], os.path.join(os.path.dirname(pw[0]), "power1_cap")))

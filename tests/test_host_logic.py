@@ -140,6 +140,32 @@ def test_bench_sharding_modes():
         assert r0 * 64 == (32 - n_local) * 64                # traj_index_base of the last rank
 
 
+def test_bench_power_sampler_reads_sysfs(tmp_path):
+    """bench.py's PowerSampler: current pp_dpm_sclk level (the starred line, also the 'S:' sleep level), hwmon power1_input in
+    microwatts, power1_cap; cards without the files are skipped, the busiest card is the one reported, the first skip_s
+    seconds are dropped."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for card, (sclk, uw) in {"card3": ("S: 95Mhz *\n0: 500Mhz\n1: 2400Mhz\n", 40_000_000),
+                             "card8": ("S: 95Mhz\n0: 500Mhz\n1: 2055Mhz *\n", 1_300_000_000)}.items():
+        hw = tmp_path / card / "device" / "hwmon" / "hwmon4"
+        hw.mkdir(parents=True)
+        (tmp_path / card / "device" / "pp_dpm_sclk").write_text(sclk)
+        (hw / "power1_input").write_text(f"{uw}\n")
+        (hw / "power1_cap").write_text("1400000000\n")
+    (tmp_path / "card9" / "device").mkdir(parents=True)          # a render node without power files
+    w = bench.PowerSampler(period=0.005, drm_root=str(tmp_path))
+    assert len(w.cards) == 2
+    w.start()
+    time.sleep(0.1)
+    out = w.finish(skip_s=0.02)
+    assert out["sclk_mhz"] == 2055.0 and out["package_watts"] == 1300.0 and out["package_cap_watts"] == 1400.0
+    assert out["samples"] >= 3 and "sysfs" in out["source"]
+    assert bench.PowerSampler(drm_root=str(tmp_path / "card9")).cards == []      # nothing there: rocm-smi fallback
+
+
 def test_split_cost_constraints_to_tasks_golden_g13():
     """MPDEnsemble.split_cost_constraints_to_tasks + the per-tile range / transform shift of run_constrained_inference
     (mpd_ensemble.py:431-507, 515-518) against the reference's own output (g13): tile order, hard-then-soft order inside a
