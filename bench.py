@@ -414,6 +414,9 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
     pmc_busy = pmc_all.get(DOMINANT_KERNEL, {}).get("mfma_busy_frac")
     if pmc_busy is not None:
         roofline["mfma_busy_pmc"] = {"value": pmc_busy, "source": "profiles/pmc_latest.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs), rocprofv3 PMC pass (serialises kernels: one launch at a time)"}
+        wb = pmc_all[DOMINANT_KERNEL].get("whole_batch_2048")
+        if wb:          # (a ratio of cycle counts: the clock the socket's power limit allows is already in it)
+            roofline["mfma_busy_pmc"]["whole_batch_2048"] = wb
     # second kernel: the fused DDPM-step + guide kernel, HBM roofline on its algorithmic bytes
     step_bytes = 3.0 * 1024.0 * n_launch                     # x read + eps read + x write per trajectory and step
     guide = {"kernel": "ddpm_guide_kernel: posterior mean + 20 guide iterations (SDF gather, workspace walls, GP prior, 31 x 63 soft-constraint points) + noise + hard conditioning, one wave per trajectory",

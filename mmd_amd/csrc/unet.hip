@@ -9,7 +9,7 @@
 //     residual stream (dyn_scale); all of them leave through the GroupNorm epilogue's coefficients.
 //   * every conv is a DIRECT convolution (taps = row-shifted views of an fp16 slab): downs.0 and ups.1 + final block
 //     wave-private (wave = sample, no workgroup barriers inside the stage), downs.1 / downs.2 + mid / ups.0 on workgroup slabs
-//     (a wave owns 1-2 n-tiles x 2-4 samples); strided / transposed tails the same way (every position resp. two parity passes).
+//     (a wave owns 1-2 n-tiles x 2-4 samples); strided tails read their slab at stride 2, transposed tails = two parity passes.
 //   * no register spills (a reload waits for every weight load in flight): downs.2's residual tile is parked
 //     lane-privately in LDS; epilogue parameters and the residual conv's weights are requested ahead of their use.
 //
@@ -613,6 +613,13 @@ template <int C, int L> struct RwGeo {
   static constexpr int BYTES = 2 * PS, FRAGS5 = 5 * KC * 2, FRAGS3 = 3 * KC * 2;
   static constexpr int tile_row(int m) { return m * RPS; }   // M tile m = positions 16 m .. 16 m + 15 of the wave's sample
 };
+// A slab read at STRIDE 2 (Downsample1d = a k3 conv at the even positions only): M tile m = outputs 16 m .. 16 m + 15 of a
+// sample = slab rows 2 (16 m + n) + tap of it, so the lane offset in `va` is n x 32 B (the caller adds n x 16 to the stride-1
+// va) and the 16 lanes of a row group span 512 B: the b128 reads are 2-way bank conflicts, half as many of them and half the
+// MFMAs and weight loads of the conv evaluated at every position.  SROWS = slab rows from one sample to the next.
+template <class GEO, int SROWS, int TILES_PER_SAMPLE> struct Stride2 : GEO {
+  static constexpr int tile_row(int m) { return (m / TILES_PER_SAMPLE) * SROWS + (m % TILES_PER_SAMPLE) * 32; }
+};
 __device__ __forceinline__ float wave_sum_rows(float v) {   // v + the same lane of the other three 16-lane rows
   v = add_xor16(v);
   v = add_xor32(v);
@@ -703,8 +710,8 @@ __device__ __forceinline__ void wave_lds_fence() {           // a wave's own LDS
 // downs.0 (4 -> 32 -> 32 channels at L = 64, Downsample1d): wave = sample.  The first conv's K is 5 taps x 4 channels = 20
 // of the 32 slots of ONE MFMA chunk (im2col: lane group j holds taps 2 j, 2 j + 1 -- two consecutive 8-byte rows of the
 // [row][4 channel] input slab), its 1x1 residual conv a second chunk with only the centre tap's slots non-zero.  The raw
-// network input has no bounded range: dynamic scale from the sample's own maximum.  The stride-2 tail is evaluated at every
-// position (3 taps, 72 MFMAs) and the even ones are kept -- stride-2 A reads would be 2-way bank conflicted.
+// network input has no bounded range: dynamic scale from the sample's own maximum.  The stride-2 tail reads its slab at stride 2
+// (Stride2: 3 taps on two M tiles, 36 MFMAs; the A reads are 2-way bank conflicted, half as many as at every position).
 // The stage's output goes straight into the next stage's input slab (RlGeo<32>) as f16 pieces under the sample's own dynamic
 // scale, behind a workgroup barrier (it aliases the waves' slabs); the sample's maximum goes to mx.
 template <class CF>
@@ -849,15 +856,16 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
     rd_ring_load<GW, 2, 3>(ring3, wt);
     rw_store2<GW, 4>(vs, acc);
     wave_lds_fence();
-    f32x4 y[4][2];
-    rd_taps<GW, 2, 1, 3, true, false, 4, 3>(y, res, va, wt, wt, ring3);
+    // (outputs q = 16 mt + 4 g + r = the even positions 2 q: two M tiles read at stride 2)
+    f32x4 y[2][2];
+    rd_taps<Stride2<GW, 0, 2>, 2, 1, 3, true, false, 2, 3>(y, y, va + n * 16, wt, wt, ring3);
     float mo = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {
+        for (int r = 0; r < 4; ++r) {
           y[mt][t][r] = fmaf(y[mt][t][r], ist[t], bt[t]);
           mo = fmaxf(mo, fabsf(y[mt][t][r]));
         }
@@ -866,19 +874,19 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
     mo = max_xor32(mo);
     __syncthreads();                                         // every wave is done with its slab: the next stage's slab aliases them
     if (lane < MX_SLOTS) (lds + MX_OFF)[wave * MX_SLOTS + lane] = mo;
-    // -> the next stage's input slab (RlGeo<32>: rows 36 sample + 2 + m), m = p / 2 = 8 mt + 2 g + r / 2, channels 2 n, 2 n + 1 =
-    //    block n >> 2, dword n & 3, as f16 pieces under the sample's own dynamic scale (the next stage reads it from mx)
+    // -> the next stage's input slab (RlGeo<32>: rows 36 sample + 2 + q), channels 2 n, 2 n + 1 = block n >> 2, dword n & 3, as
+    //    f16 pieces under the sample's own dynamic scale (the next stage reads it from mx)
     using GN = RlGeo<32>;
     const float so = dyn_scale(mo).s;
     char* const lb = reinterpret_cast<char*>(lds);
-    char* xb = lb + (n >> 2) * GN::G + (wave * GN::RPS + 2 + 2 * g) * 16 + (n & 3) * 4;
+    char* xb = lb + (n >> 2) * GN::G + (wave * GN::RPS + 2 + 4 * g) * 16 + (n & 3) * 4;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const F16Pair f = f16_split2(y[mt][0][2 * h] * so, y[mt][1][2 * h] * so);
-        *reinterpret_cast<unsigned*>(xb + (8 * mt + h) * 16) = f.hi;
-        *reinterpret_cast<unsigned*>(xb + GN::PS + (8 * mt + h) * 16) = f.lo;
+      for (int r = 0; r < 4; ++r) {
+        const F16Pair f = f16_split2(y[mt][0][r] * so, y[mt][1][r] * so);
+        *reinterpret_cast<unsigned*>(xb + (16 * mt + r) * 16) = f.hi;
+        *reinterpret_cast<unsigned*>(xb + GN::PS + (16 * mt + r) * 16) = f.lo;
       }
     if (lane < 32)                                           // halo rows 0, 1, 34, 35 of the sample's 4 blocks x 2 pieces
       *reinterpret_cast<uint4*>(lb + (lane >> 4) * GN::PS + ((lane >> 2) & 3) * GN::G +
@@ -891,8 +899,8 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
 // 1: channels 32 np + 2 n + t, interleaved columns; sample pair sp = w >> 1: samples 2 sp, 2 sp + 1), so a weight fragment is
 // used on four M tiles and fetched by two waves; acc[m][t]: M tile m = sample 2 sp + (m >> 1), positions 16 (m & 1) + 4 g + r.
 // A GroupNorm group (8 channels x 32 positions of a sample) is 4 lanes x 2 tiles x the sample's 2 M tiles: wave-internal.
-// The input slab arrives from downs.0's tail (f16 pieces, per-sample scales in mx); the strided tail is evaluated at every
-// position and the even ones go to downs.2's row-form fp32 x slab (CFN geometry) + their per-sample maxima to mx.
+// The input slab arrives from downs.0's tail (f16 pieces, per-sample scales in mx); the strided tail reads its slab at stride 2
+// (Stride2) and writes downs.2's row-form fp32 x slab (CFN geometry) + the per-sample maxima to mx.
 // skip: the stage's skip tensor (output of its second RTB) in the acc layout.
 template <class CF, class CFN>
 __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&skip)[4][2], int trb) {
@@ -942,7 +950,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     }
   };
   // per-sample |x| maxima of the tile in v -> all eight slots of the two samples (the two waves of a sample pair fill them)
-  auto maxima_out = [&](const f32x4 (&v)[4][2], auto even_only) {
+  auto maxima_out = [&](const f32x4 (&v)[4][2]) {
     float m2[2];
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
@@ -952,7 +960,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; r += decltype(even_only)::value ? 2 : 1) m = fmaxf(m, fabsf(v[2 * sl + mt][t][r]));
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(v[2 * sl + mt][t][r]));
       m = row_max16(m);
       m = max_xor16(m);
       m2[sl] = max_xor32(m);
@@ -1016,7 +1024,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int t = 0; t < 2; ++t) res[m][t] = acc[m][t];
-    maxima_out(acc, std::false_type{});
+    maxima_out(acc);
     __syncthreads();                                         // the previous conv is done reading the slab
     float inv[2];
     scale_in(inv);
@@ -1036,7 +1044,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
   }
   // =================== tail: Downsample1d = Conv1d(k3, s2, p1): y[p] = sum_t x[p + t - 1] W_t at the even p ===================
   {
-    maxima_out(acc, std::false_type{});
+    maxima_out(acc);
     __syncthreads();
     float inv[2];
     scale_in(inv);
@@ -1045,23 +1053,33 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     rd_ring_load<GH, 2, RD1>(ring, wt);
     store_tile();
     __syncthreads();
-    f32x4 y[4][2];
-    rd_taps<GH, 2, 1, 3, true, false, 4, RD1>(y, y, vaH, wt, wt, ring);
+    // (outputs q = 4 g + r = the even positions 2 q of the pair's two samples: one M tile each, read at stride 2)
+    f32x4 y[2][2];
+    rd_taps<Stride2<GH, GH::RPS, 1>, 2, 1, 3, true, false, 2, RD1>(y, y, vaH + n * 16, wt, wt, ring);
+    float m2[2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int sl = 0; sl < 2; ++sl) {
+      float m = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) y[m][t][r] = fmaf(y[m][t][r], ist[t] * inv[m >> 1], bt[t]);
+        for (int r = 0; r < 4; ++r) {
+          y[sl][t][r] = fmaf(y[sl][t][r], ist[t] * inv[sl], bt[t]);
+          m = fmaxf(m, fabsf(y[sl][t][r]));
+        }
+      m = row_max16(m);
+      m = max_xor16(m);
+      m2[sl] = max_xor32(m);
+    }
     __syncthreads();                                         // every wave is done reading the slab the next stage's x slab aliases
-    maxima_out(y, std::true_type{});
-    // -> the next stage's row-form fp32 x slab [sample][2 + q][CFN::XSTR], q = p / 2 = 8 (m & 1) + 2 g + r / 2
-    float* xb = lds + (2 * sp) * CFN::XSS + (2 + 2 * g) * CFN::XSTR + c0;
+    if (lane < 8) mx[(2 * sp + (lane >> 2)) * MX_SLOTS + np + 2 * (lane & 3)] = (lane >> 2) ? m2[1] : m2[0];
+    // -> the next stage's row-form fp32 x slab [sample][2 + q][CFN::XSTR]
+    float* xb = lds + (2 * sp) * CFN::XSS + (2 + 4 * g) * CFN::XSTR + c0;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        *reinterpret_cast<float2*>(xb + (m >> 1) * CFN::XSS + (8 * (m & 1) + h) * CFN::XSTR) = make_float2(y[m][0][2 * h], y[m][1][2 * h]);
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float2*>(xb + sl * CFN::XSS + r * CFN::XSTR) = make_float2(y[sl][0][r], y[sl][1][r]);
   }
   TR(trb + 5);
 }
@@ -2163,7 +2181,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   for (int i = 0; i < 2; ++i) {
     const int c = dims[i + 1];
     u->down[i].bias = push(blob, tensors[s.t_down[i][1]], c);
-    {                         // Downsample1d as a direct f16x2 conv (taps 0..2, interleaved column pairs), evaluated at every position
+    {                         // Downsample1d as a direct f16x2 conv (taps 0..2, interleaved column pairs) read at stride 2
       const std::vector<int> k3 = {0, 1, 2};
       const std::vector<float> sct = rd_col_scales(tensors[s.t_down[i][0]], c, c, 3, k3, false);
       u->down_is[i] = push_inverse(blob, sct);
@@ -2250,8 +2268,8 @@ static const double kUnetFlops =
 
 static constexpr double d5(double cin, double cout, double L) { return 2.0 * cout * 5 * cin * L; }
 static const double kF16Flops =
-    2 * (2.0 * 32 * 32 * 64) + 3 * d5(32, 32, 64) + 2.0 * 32 * 3 * 32 * 64 +                          // downs.0
-    d5(32, 64, 32) + 2.0 * 64 * 32 * 32 + 3 * d5(64, 64, 32) + 2.0 * 64 * 3 * 64 * 32 +               // downs.1
+    2 * (2.0 * 32 * 32 * 64) + 3 * d5(32, 32, 64) + 2.0 * 32 * 3 * 32 * 32 +                          // downs.0
+    d5(32, 64, 32) + 2.0 * 64 * 32 * 32 + 3 * d5(64, 64, 32) + 2.0 * 64 * 3 * 64 * 16 +               // downs.1
     d5(64, 128, 16) + 2.0 * 128 * 64 * 16 + 7 * d5(128, 128, 16) +                                    // downs.2 + mid
     d5(256, 64, 16) + 2.0 * 64 * 256 * 16 + 3 * d5(64, 64, 16) + 2.0 * 64 * 4 * 64 * 16 +             // ups.0
     d5(128, 32, 32) + 2.0 * 32 * 128 * 32 + 3 * d5(32, 32, 32) + 2.0 * 32 * 4 * 32 * 32 +             // ups.1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """gpurun_out/<tag>_pmc*.txt (tools/gpu_pmc.sh) -> profiles/pmc_latest.json, the committed PMC figures bench.py quotes
-(`roofline.traffic`, `roofline.mfma_busy_pmc`, `roofline_step_kernel.pmc`).  Usage: pmc_to_json.py <unet pmc txt> <n_traj> [<bench pmc txt>]"""
+(`roofline.traffic`, `roofline.mfma_busy_pmc`, `roofline_step_kernel.pmc`).  Usage: pmc_to_json.py <unet pmc txt> <n_traj> [<bench pmc txt> [<unet pmc txt of the whole 2048-trajectory batch>]]"""
 import json
 import re
 import sys
@@ -41,5 +41,9 @@ if len(sys.argv) > 3:
                             "SQ_WAIT_ANY": v.get("SQ_WAIT_ANY"), "SQ_WAIT_INST_ANY": v.get("SQ_WAIT_INST_ANY"),
                             "SQ_ACTIVE_INST_VALU": v.get("SQ_ACTIVE_INST_VALU"),
                             "valu_issue_frac": (v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]) if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_WAVE_CYCLES") else None}
+if len(sys.argv) > 4:
+    w = next(v for kk, v in parse(sys.argv[4]).items() if "unet_kernel" in kk)
+    doc["UNET"]["whole_batch_2048"] = {"mfma_busy_frac": w["SQ_VALU_MFMA_BUSY_CYCLES"] / (w["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+                                       "source": f"same passes over tools/unet_forward_loop.py 2048: {sys.argv[4]}"}
 json.dump(doc, open("profiles/pmc_latest.json", "w"), indent=1)
 print(json.dumps(doc, indent=1))
