@@ -3,7 +3,7 @@
 // SECONDS of wall time on every CU at the kernel's occupancy (two 4-wave workgroups per CU) with random operand bits, while the
 // calling script samples `rocm-smi --showclocks --showpower`; prints the sustained rate.  Classes: mfma16 (v_mfma_f32_16x16x32_f16),
 // mfma32 (v_mfma_f32_32x32x16_f16), lds (ds_read_b128, conflict free), valu (v_pk_fma_f32), l2 (global_load_dwordx4 of a 2 MB
-// buffer), idle (s_sleep).
+// buffer: L2 hits), l1 (the same over 16 KB: L1 hits), idle (s_sleep).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/power_probe.hip -o power_probe;  run: power_probe <class> [seconds]
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -85,15 +85,16 @@ __global__ __launch_bounds__(256, 2) void k_valu(float* out, int iters) {
   for (int i = 1; i < 8; ++i) t += x[i];
   out[blockIdx.x * 256 + threadIdx.x] = t[0] + t[1];
 }
-__global__ __launch_bounds__(256, 2) void k_l2(float* out, const u32x4* buf, int iters) {
-  // a wave reads 1 KB contiguous (global_load_dwordx4), 8 loads in flight, walking a 2 MB buffer
+__global__ __launch_bounds__(256, 2) void k_l2(float* out, const u32x4* buf, int iters, unsigned mask) {
+  // a wave reads 1 KB contiguous (global_load_dwordx4), 8 loads in flight, walking (mask + 1) KB of the buffer: 2 MB = L2 hits
+  // (a CU's 8 waves touch far more than its 32 KB L1 between reuses), 16 KB = L1 hits
   const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   u32x4 acc = {0u, 0u, 0u, 0u};
   unsigned pos = wid * 8;
   for (int it = 0; it < iters; ++it) {
     u32x4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = buf[(((pos + k) & 2047) << 6) + lane];
+    for (int k = 0; k < 8; ++k) v[k] = buf[(((pos + k) & mask) << 6) + lane];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc ^= v[k];
     pos += 8 * 37;
@@ -125,7 +126,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(cls, "mfma32")) { hipLaunchKernelGGL(k_mfma32, dim3(nb), dim3(256), 0, 0, out, iters); per_iter = 4; unit = "v_mfma_f32_32x32x16_f16"; }
     else if (!strcmp(cls, "lds")) { hipLaunchKernelGGL(k_lds, dim3(nb), dim3(256), 0, 0, out, iters); unit = "ds_read_b128"; }
     else if (!strcmp(cls, "valu")) { hipLaunchKernelGGL(k_valu, dim3(nb), dim3(256), 0, 0, out, iters); unit = "v_pk_fma_f32"; }
-    else if (!strcmp(cls, "l2")) { hipLaunchKernelGGL(k_l2, dim3(nb), dim3(256), 0, 0, out, buf, iters / 4); unit = "global_load_dwordx4 (L2 hit)"; }
+    else if (!strcmp(cls, "l2")) { hipLaunchKernelGGL(k_l2, dim3(nb), dim3(256), 0, 0, out, buf, iters / 4, 2047u); unit = "global_load_dwordx4 (L2 hit)"; }
+    else if (!strcmp(cls, "l1")) { hipLaunchKernelGGL(k_l2, dim3(nb), dim3(256), 0, 0, out, buf, iters / 4, 15u); unit = "global_load_dwordx4 (L1 hit)"; }
     else { hipLaunchKernelGGL(k_idle, dim3(nb), dim3(256), 0, 0, out, iters / 16); unit = "s_sleep"; }
   };
   launch();
@@ -139,7 +141,7 @@ int main(int argc, char** argv) {
     launches += 4;
     el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   } while (el < seconds);
-  const double it = !strcmp(cls, "l2") ? iters / 4 : !strcmp(cls, "mfma16") || !strcmp(cls, "mfma32") || !strcmp(cls, "lds") || !strcmp(cls, "valu") ? iters : iters / 16;
+  const double it = !strcmp(cls, "l2") || !strcmp(cls, "l1") ? iters / 4 : !strcmp(cls, "mfma16") || !strcmp(cls, "mfma32") || !strcmp(cls, "lds") || !strcmp(cls, "valu") ? iters : iters / 16;
   const double wave_instr = (double)launches * nb * 4 * it * per_iter;
   printf("%s: %.3f s, %ld launches, %.4g wave-instructions/s of %s (%.2f per CU per ns)\n", cls, el, launches, wave_instr / el, unit,
          wave_instr / el / 256 / 1e9);
