@@ -382,7 +382,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
     eq_tf = mfma_flops * len(dur) / union_s / 1e12
     roofline = {
         "bound": "mfma",
-        "kernel": "unet_kernel: whole TemporalUnet forward for 4 trajectories per workgroup (12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; every conv a direct convolution as an fp16 two-piece split of fp32 (f16x2, 3 MFMAs per product, fp32 accumulate) on v_mfma_f32_16x16x32_f16; the unguided DDPM steps ride in its tail; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
+        "kernel": "unet_kernel<4>: whole TemporalUnet forward for 4 trajectories per workgroup (launches of <= 512 trajectories: unet_kernel<2>, two per workgroup; 12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; every conv a direct convolution as an fp16 two-piece split of fp32 (f16x2, 3 MFMAs per product, fp32 accumulate) on v_mfma_f32_16x16x32_f16; the unguided DDPM steps ride in its tail; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
         "achieved": pipe_busy * PEAK_FP32_MFMA_TFLOPS, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": pipe_busy,
         "frac_definition": "matrix-pipe busy fraction: MFMA issue time of the bracketed launches at spec clock (fp32 MFMAs at "
                            "157.3 TFLOP/s, fp16 MFMAs at 2516.6) / wall time during which at least one of them runs (union of "

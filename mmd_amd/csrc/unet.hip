@@ -468,18 +468,18 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
 // inv[sample]) + add(sample, tile, r); NG = values per group (16 channels x 16 positions for two interleaved n-tiles at C =
 // 128, 8 x 16 for one n-tile at C = 64); the lane's NT channels all belong to one group, which is 8 lanes x the wave's four
 // 16-lane rows (position groups).
-template <int NT, int NG, bool ACT, class ADD>
-__device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[4][NT], const float (&bias)[NT], const float (&gamma)[NT],
-                                           const float (&beta)[NT], const float (&isc)[NT], const float (&inv)[4],
+template <int NT, int NG, bool ACT, class ADD, int NS>
+__device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[NS][NT], const float (&bias)[NT], const float (&gamma)[NT],
+                                           const float (&beta)[NT], const float (&isc)[NT], const float (&inv)[NS],
                                            const ActScale& as, ADD add) {
   constexpr float inv_n = 1.f / (float)NG;
   float bsum = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) bsum += bias[t];
   const float bmean = group_colsum<8>(bsum) * 16.f * inv_n;
-  float k[4][NT], sum[4], dm[4][NT], sq[4];
+  float k[NS][NT], sum[NS], dm[NS][NT], sq[NS];
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) {
+  for (int sm = 0; sm < NS; ++sm) {
     float v = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -489,11 +489,11 @@ __device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[4][NT], const float (&bi
     sum[sm] = group_colsum<8>(v);
   }
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) sum[sm] = add_xor16(sum[sm]);
+  for (int sm = 0; sm < NS; ++sm) sum[sm] = add_xor16(sum[sm]);
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) sum[sm] = add_xor32(sum[sm]);
+  for (int sm = 0; sm < NS; ++sm) sum[sm] = add_xor32(sum[sm]);
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) {
+  for (int sm = 0; sm < NS; ++sm) {
     const float mean = fmaf(sum[sm], inv_n, bmean);
     float v = 0.f;
 #pragma unroll
@@ -508,11 +508,11 @@ __device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[4][NT], const float (&bi
     sq[sm] = group_colsum<8>(v);
   }
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) sq[sm] = add_xor16(sq[sm]);
+  for (int sm = 0; sm < NS; ++sm) sq[sm] = add_xor16(sq[sm]);
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) sq[sm] = add_xor32(sq[sm]);
+  for (int sm = 0; sm < NS; ++sm) sq[sm] = add_xor32(sq[sm]);
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) {
+  for (int sm = 0; sm < NS; ++sm) {
     const float rstd = __builtin_amdgcn_rsqf(fmaf(sq[sm], inv_n, 1e-5f));   // (argument >= 1e-5: no denormal handling needed)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -529,10 +529,10 @@ __device__ __forceinline__ void rd_gn_mish(f32x4 (&acc)[4][NT], const float (&bi
 }
 // per-sample |x| maxima of a direct-layout tile -> mx region 0 (and region2 if > 0): row_max16, one cross-row step,
 // lanes 0 / 32 write the wave's two partials: slots 2 wave + {0, 1} of MX_SLOTS = 8
-template <int NT>
-__device__ __forceinline__ void rd_dyn_out(const f32x4 (&acc)[4][NT], float* mx, int wave, int lane, int region2) {
+template <int NT, int NS>
+__device__ __forceinline__ void rd_dyn_out(const f32x4 (&acc)[NS][NT], float* mx, int wave, int lane, int region2) {
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) {
+  for (int sm = 0; sm < NS; ++sm) {
     float m = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -551,10 +551,10 @@ __device__ __forceinline__ float mx_read(const float* mx, int sm) {
   return fmaxf(fmaxf(fmaxf(p.x, p.y), fmaxf(p.z, p.w)), fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
 }
 // two-interleaved-n-tile tile (lane: channels c0, c0 + 1 = block 4 wave + (n >> 2), dword n & 3; positions 4 g + r) -> slab
-template <class GEO>
-__device__ __forceinline__ void rd_store2(char* vs, const f32x4 (&acc)[4][2]) {   // vs = slab + lane's (block, row 2 + 4 g, dword)
+template <class GEO, int NS>
+__device__ __forceinline__ void rd_store2(char* vs, const f32x4 (&acc)[NS][2]) {   // vs = slab + lane's (block, row 2 + 4 g, dword)
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm)
+  for (int sm = 0; sm < NS; ++sm)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const F16Pair f = f16_split2(acc[sm][0][r], acc[sm][1][r]);
@@ -562,30 +562,31 @@ __device__ __forceinline__ void rd_store2(char* vs, const f32x4 (&acc)[4][2]) { 
       *reinterpret_cast<unsigned*>(vs + GEO::PS + (sm * GEO::RPS + r) * 16) = f.lo;
     }
 }
-// one-n-tile tile (lane: channel c, positions 4 g + r of all four samples): the lanes of a pair (n, n ^ 1) swap two samples,
-// the even lane stores samples 0 / 1 of channels (c, c + 1), the odd lane samples 2 / 3 of (c - 1, c).
+// one-n-tile tile (lane: channel c, positions 4 g + r of the NS samples): the lanes of a pair (n, n ^ 1) swap half the samples,
+// the even lane stores the first NS / 2 samples of channels (c, c + 1), the odd lane the other half of (c - 1, c).
 // vs = slab + the lane's (block of c, row 2 + 4 g, dword (c & 7) >> 1) offset
-template <class GEO>
-__device__ __forceinline__ void rd_store1(char* vs, const f32x4 (&acc)[4][1], int lane) {
+template <class GEO, int NS>
+__device__ __forceinline__ void rd_store1(char* vs, const f32x4 (&acc)[NS][1], int lane) {
+  constexpr int HS = NS / 2;
   const bool odd = lane & 1;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < HS; ++h)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float send = odd ? acc[h][0][r] : acc[2 + h][0][r];
+      const float send = odd ? acc[h][0][r] : acc[HS + h][0][r];
       const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));
-      const float own = odd ? acc[2 + h][0][r] : acc[h][0][r];
+      const float own = odd ? acc[HS + h][0][r] : acc[h][0][r];
       const F16Pair f = f16_split2(odd ? recv : own, odd ? own : recv);        // (low channel, high channel)
-      char* p = vs + ((odd ? 2 + h : h) * GEO::RPS + r) * 16;
+      char* p = vs + ((odd ? HS + h : h) * GEO::RPS + r) * 16;
       *reinterpret_cast<unsigned*>(p) = f.hi;
       *reinterpret_cast<unsigned*>(p + GEO::PS) = f.lo;
     }
 }
 // row-form fp32 slab [sample][20][XSTR] (2-row halo) of C channels -> the Rd slab, times the sample's dynamic scale
-template <int C, int XSS, int XSTR>
+template <int C, int XSS, int XSTR, int NS>
 __device__ __forceinline__ void rowform_to_rd(const float* xslab, char* slab, const float* mx) {
   using GEO = RdGeo<C>;
-  constexpr int CP2 = C / 2, ITEMS = 64 * CP2;               // (sample, position) x channel pairs
+  constexpr int CP2 = C / 2, ITEMS = 16 * NS * CP2;          // (sample, position) x channel pairs
   static_assert(ITEMS % 256 == 0 && XSTR % 2 == 0, "items per thread; 8-byte aligned channel pairs");
 #pragma unroll
   for (int it = 0; it < ITEMS / 256; ++it) {
@@ -714,7 +715,7 @@ __device__ __forceinline__ void wave_lds_fence() {           // a wave's own LDS
 // (Stride2: 3 taps on two M tiles, 36 MFMAs; the A reads are 2-way bank conflicted, half as many as at every position).
 // The stage's output goes straight into the next stage's input slab (RlGeo<32>) as f16 pieces under the sample's own dynamic
 // scale, behind a workgroup barrier (it aliases the waves' slabs); the sample's maximum goes to mx.
-template <class CF>
+template <class CF, int NS>
 __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb) {
   static_assert(CF::L == 64 && CF::CM == 32 && CF::C0 == 4 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
                     CF::TAIL == TAIL_DOWN, "downs.0");
@@ -732,7 +733,7 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
   // ---- stage the sample: lane = position; [row = 2 + position][4 channels] x two pieces, zero rows around it
   float inv_in;
   {
-    const bool valid = n0 + wave < a.n;
+    const bool valid = wave < NS && n0 + wave < a.n;           // (NS < 4: the other waves run on zeros, see unet_kernel)
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) v = *reinterpret_cast<const float4*>(a.in0 + ((size_t)(n0 + wave) * 64 + lane) * 4);
     float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -1094,18 +1095,20 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
 __device__ __forceinline__ float* park_slot(float* lds, int i) {
   return (i < 5 ? lds + i * 1024 : lds + PARK2_OFF + (i - 5) * 1024) + threadIdx.x * 4;
 }
-__device__ __forceinline__ void park_tile(float* lds, const f32x4 (&t)[4][2]) {
+template <int NS>
+__device__ __forceinline__ void park_tile(float* lds, const f32x4 (&t)[NS][2]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(park_slot(lds, i)) = t[i >> 1][i & 1];
+  for (int i = 0; i < 2 * NS; ++i) *reinterpret_cast<f32x4*>(park_slot(lds, i)) = t[i >> 1][i & 1];
 }
-__device__ __forceinline__ void unpark_tile(float* lds, f32x4 (&t)[4][2]) {
+template <int NS>
+__device__ __forceinline__ void unpark_tile(float* lds, f32x4 (&t)[NS][2]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t[i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(park_slot(lds, i));
+  for (int i = 0; i < 2 * NS; ++i) t[i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(park_slot(lds, i));
 }
 
-template <class CF>
-__device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[4][2],
-                                               f32x4 (&mid)[4][2], int trb) {
+template <class CF, int NS>
+__device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[NS][2],
+                                               f32x4 (&mid)[NS][2], int trb) {
   static_assert(CF::L == 16 && CF::CM == 128 && CF::C0 == 64 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_NONE &&
                     CF::MID_AFTER >= 1, "downs.2 + mid blocks");
   using G128 = RdGeo<128>;
@@ -1131,19 +1134,21 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
   __syncthreads();                                           // the x slab (previous stage's tail tile) and its maxima are staged
   TR(trb + 0);
 
-  const float one4[4] = {1.f, 1.f, 1.f, 1.f};
+  float one4[NS];
+#pragma unroll
+  for (int sm = 0; sm < NS; ++sm) one4[sm] = 1.f;
   // GroupNorm + Mish of acc.  Conv A (tb != nullptr): + the time bias, output carried times act_s (conv B's static f16x2
   // input scale); conv B: + the residual tile, which comes back from its parking area.  isc: the conv's inverse weight scales,
   // inv: inverse dynamic input scales
   auto epi = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc) {
     return epi_load<2>(b, gm, be, tb, isc, c0);
   };
-  auto gn = [&](auto conv_a, const Epi<2>& e, const float (&inv)[4], float act_s) {
+  auto gn = [&](auto conv_a, const Epi<2>& e, const float (&inv)[NS], float act_s) {
     if constexpr (decltype(conv_a)::value) {
       const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
       rd_gn_mish<2, 256, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
     } else {
-      f32x4 res[4][2];
+      f32x4 res[NS][2];
       unpark_tile(lds, res);
       rd_gn_mish<2, 256, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int sm, int t, int r) { return res[sm][t][r]; });
     }
@@ -1157,24 +1162,24 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
     TR(trb + 11);
     __syncthreads();
     TR(trb + 12);
-    rd_taps<G128, 2, 0, 5, true, false, 4, RDD>(acc, acc, va128, wp, wp, ring);
+    rd_taps<G128, 2, 0, 5, true, false, NS, RDD>(acc, acc, va128, wp, wp, ring);
     TR(trb + 13);
   };
 
   // =================== RTB 0 (64 -> 128): conv A + the 1x1 residual conv from the row-form x slab ===================
-  float inv_in[4];
+  float inv_in[NS];
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) inv_in[sm] = dyn_scale(mx_read(mx, sm)).inv;
+  for (int sm = 0; sm < NS; ++sm) inv_in[sm] = dyn_scale(mx_read(mx, sm)).inv;
   rd_zero_halo<G64>(slab);
   const Epi<2> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
   const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
-  rowform_to_rd<CF::C0P, CF::XSS, CF::XSTR>(lds, slab, mx);
+  rowform_to_rd<CF::C0P, CF::XSS, CF::XSTR, NS>(lds, slab, mx);
   __syncthreads();
   {
-    f32x4 res[4][2];
-    rd_taps<G64, 2, 0, 5, true, true, 4, 2>(acc, res, va64, wpa, wpr, reinterpret_cast<u32x4(&)[2][2][2]>(ring));
+    f32x4 res[NS][2];
+    rd_taps<G64, 2, 0, 5, true, true, NS, 2>(acc, res, va64, wpa, wpr, reinterpret_cast<u32x4(&)[2][2][2]>(ring));
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm)
+    for (int sm = 0; sm < NS; ++sm)
 #pragma unroll
       for (int t = 0; t < 2; ++t) res[sm][t] = res[sm][t] * (isr[t] * inv_in[sm]) + br[t];
     park_tile(lds, res);                                     // (every wave is past the barrier behind the x slab's last read)
@@ -1196,9 +1201,9 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
     park_tile(lds, acc);                                     // the block's input = its residual
     rd_dyn_out<2>(acc, mx, wave, lane, k == CF::MID_AFTER ? 1 : 0);   // (the input of the RTB after MID_AFTER is the skip tensor)
     __syncthreads();                                         // the previous conv is done reading the slab
-    float inv[4];
+    float inv[NS];
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm) {
+    for (int sm = 0; sm < NS; ++sm) {
       const DynScale ds = dyn_scale(mx_read(mx, sm));
       inv[sm] = ds.inv;
 #pragma unroll
@@ -1214,7 +1219,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
     TR(trb + 18);
     if (CF::MID_AFTER == k + 1) {
 #pragma unroll
-      for (int sm = 0; sm < 4; ++sm)
+      for (int sm = 0; sm < NS; ++sm)
 #pragma unroll
         for (int t = 0; t < 2; ++t) mid[sm][t] = acc[sm][t];
     }
@@ -1226,10 +1231,10 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 // Upsample1d = ConvTranspose1d(k4, s2, p1) as two 2-tap parity passes, all f16x2 on Rd slabs.  Wave w owns the n-tile of
 // channels 16 w + (lane & 15) x all four samples.  x0 / x1: the two 128-channel chunks of the input (downs.2's tiles, in
 // ITS layout: store2(tile) writes one into the 128-channel slab); xe / xo: the stage's output (even / odd positions).
-template <class CF, class STORE2>
-__device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&x0)[4][2],
-                                               f32x4 (&x1)[4][2], STORE2 store2, char* slab128, f32x4 (&xe)[4][1],
-                                               f32x4 (&xo)[4][1], int trb) {
+template <class CF, int NS, class STORE2>
+__device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&x0)[NS][2],
+                                               f32x4 (&x1)[NS][2], STORE2 store2, char* slab128, f32x4 (&xe)[NS][1],
+                                               f32x4 (&xo)[NS][1], int trb) {
   static_assert(CF::L == 16 && CF::CM == 64 && CF::C0 == 128 && CF::C1 == 128 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_UP &&
                     CF::N_IDENT == 1, "ups.0");
   using G128 = RdGeo<128>;
@@ -1254,12 +1259,14 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   __syncthreads();                                           // the previous stage is done with the slab; its maxima are in mx
   TR(trb + 0);
 
-  f32x4 acc[4][1], res[4][1];
-  const float one4[4] = {1.f, 1.f, 1.f, 1.f};
+  f32x4 acc[NS][1], res[NS][1];
+  float one4[NS];
+#pragma unroll
+  for (int sm = 0; sm < NS; ++sm) one4[sm] = 1.f;
   auto epi = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc) {
     return epi_load<1>(b, gm, be, tb, isc, col);
   };
-  auto gn = [&](auto conv_a, const Epi<1>& e, const float (&inv)[4], float act_s) {
+  auto gn = [&](auto conv_a, const Epi<1>& e, const float (&inv)[NS], float act_s) {
     if constexpr (decltype(conv_a)::value) {
       const float t0 = e.tb[0] * act_s;
       rd_gn_mish<1, 128, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int, int) { return t0; });
@@ -1268,9 +1275,9 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     }
   };
   // dynamic input scale of a conv on the tile in acc: (maxima -> mx, barrier, then) scale in place; the inverse scales
-  auto dyn_scale_acc = [&](float (&inv)[4]) {
+  auto dyn_scale_acc = [&](float (&inv)[NS]) {
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm) {
+    for (int sm = 0; sm < NS; ++sm) {
       const DynScale ds = dyn_scale(mx_read(mx, sm));
       inv[sm] = ds.inv;
       acc[sm][0] *= ds.s;
@@ -1282,13 +1289,13 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     rd_ring_load<G64, 1, RDC>(ring, wp);
     rd_store1<G64>(vs64, acc, lane);
     __syncthreads();
-    rd_taps<G64, 1, 0, 5, true, false, 4, RDC>(acc, res, va64, wp, wp, ring);
+    rd_taps<G64, 1, 0, 5, true, false, NS, RDC>(acc, res, va64, wp, wp, ring);
   };
 
   // =================== RTB 0: cat(x0, x1) -> 64 channels; the 1x1 residual conv rides on the centre tap ===================
-  float inv_in[4];
+  float inv_in[NS];
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) {
+  for (int sm = 0; sm < NS; ++sm) {
     // residual-stream input: dynamic scale from the maxima downs.2 left in regions 1 (skip2) and 2 (mid output) of mx
     const DynScale ds = dyn_scale(fmaxf(mx_read(mx + MX_REGION, sm), mx_read(mx + 2 * MX_REGION, sm)));
     inv_in[sm] = ds.inv;
@@ -1304,7 +1311,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   TR(160);
   __syncthreads();
   TR(161);
-  rd_taps<G128, 1, 0, 5, true, true, 4, RDU>(acc, res, va128, wp0, wr0, ringa);
+  rd_taps<G128, 1, 0, 5, true, true, NS, RDU>(acc, res, va128, wp0, wr0, ringa);
   rd_ring_load<G128, 1, RDU>(ringa, wp1);
   TR(162);
   __syncthreads();                                           // every wave is done reading chunk 0
@@ -1312,10 +1319,10 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   TR(163);
   __syncthreads();
   TR(164);
-  rd_taps<G128, 1, 0, 5, false, true, 4, RDU>(acc, res, va128, wp1, wr1, ringa);
+  rd_taps<G128, 1, 0, 5, false, true, NS, RDU>(acc, res, va128, wp1, wr1, ringa);
   TR(165);
 #pragma unroll
-  for (int sm = 0; sm < 4; ++sm) res[sm][0] = res[sm][0] * (isr * inv_in[sm]) + br;
+  for (int sm = 0; sm < NS; ++sm) res[sm][0] = res[sm][0] * (isr * inv_in[sm]) + br;
   gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   TR(trb + 1);
   __syncthreads();                                           // chunk 1 is consumed
@@ -1330,10 +1337,10 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   {
     const RtbPtrs& R = a.ri[0];
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm) res[sm][0] = acc[sm][0];
+    for (int sm = 0; sm < NS; ++sm) res[sm][0] = acc[sm][0];
     rd_dyn_out<1>(acc, mx, wave, lane, 0);
     __syncthreads();                                         // the previous conv is done reading the slab
-    float inv[4];
+    float inv[NS];
     dyn_scale_acc(inv);
     const Epi<1> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
     conv64(R.wa_bf);
@@ -1349,7 +1356,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   {
     rd_dyn_out<1>(acc, mx, wave, lane, 0);
     __syncthreads();
-    float inv[4];
+    float inv[NS];
     dyn_scale_acc(inv);
     const u32x4* wt0[1] = {wptr(a.wt_bf0, 2 * G64::KC * 2)};
     const u32x4* wt1[1] = {wptr(a.wt_bf1, 2 * G64::KC * 2)};
@@ -1358,13 +1365,13 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     rd_store1<G64>(vs64, acc, lane);
     __syncthreads();
     TR(trb + 7);
-    rd_taps<G64, 1, 1, 2, true, false, 4, RDC>(xe, res, va64, wt0, wt0, ring);
+    rd_taps<G64, 1, 1, 2, true, false, NS, RDC>(xe, res, va64, wt0, wt0, ring);
     rd_ring_load<G64, 1, RDC>(ring, wt1);
-    rd_taps<G64, 1, 2, 2, true, false, 4, RDC>(xo, res, va64, wt1, wt1, ring);
+    rd_taps<G64, 1, 2, 2, true, false, NS, RDC>(xo, res, va64, wt1, wt1, ring);
     // the stage's output stays in registers: xe / xo[sample][0][r] = positions 2 m, 2 m + 1 (m = 4 g + r) of channel col; the
     // per-sample maxima of the wave's 16 channels go to slot `wave` of mx region 0 (the caller's barrier publishes them)
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm) {
+    for (int sm = 0; sm < NS; ++sm) {
       float m = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1387,9 +1394,9 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 // the four samples' slabs across waves, one after the other through the same 10 KB slab (4 workgroup barriers); everything
 // after it -- 3 convs, the transposed tail as two parity passes, the final block and the output store -- reads only what the
 // same wave wrote (wave_lds_fence).  Slabs: RwGeo<64, 32> (conv A chunks), RwGeo<32, 32>, RwGeo<32, 64> (final block).
-template <class CF>
+template <class CF, int NS>
 __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, const FusedStep& fs, float* lds, int n0, int lane_in, int wave,
-                                               const f32x4 (&xe)[4][1], const f32x4 (&xo)[4][1], const f32x4 (&skip)[4][2],
+                                               const f32x4 (&xe)[NS][1], const f32x4 (&xo)[NS][1], const f32x4 (&skip)[4][2],
                                                int trb) {
   // (an opaque copy of the lane index: the stage's lane-derived offsets are recomputed here -- a handful of VALU ops -- instead
   // of being kept alive, i.e. spilled, since the stages that happen to use the same products)
@@ -1458,7 +1465,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     // the odd positions of (col - 1, col)
     char* const d0 = cdst + (8 * g + (odd ? 1 : 0)) * 16;
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm)
+    for (int sm = 0; sm < NS; ++sm)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float own = (odd ? xo[sm][0][r] : xe[sm][0][r]) * sc[sm];
@@ -1650,7 +1657,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
           for (int r = 0; r < 4; ++r) et[(16 * mt + 4 * g + r) * 4 + n] = fmaf(out[mt][0][r], s1, b1);
       }
       wave_lds_fence();
-      if (n0 + wave < a.n) {
+      if (wave < NS && n0 + wave < a.n) {
         const float4 e = *reinterpret_cast<const float4*>(et + lane * 4);
         const int traj = fs.traj0 + n0 + wave, robot = traj / fs.spr;
         const size_t idx = (size_t)traj * H + lane;
@@ -1663,7 +1670,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
         fs.x[idx] = v;
         if (fs.chain) fs.chain[idx] = v;
       }
-    } else if (n < 4 && n0 + wave < a.n) {
+    } else if (n < 4 && wave < NS && n0 + wave < a.n) {
       float* dst = f.out + ((size_t)(n0 + wave) * 64 + 4 * g) * 4 + n;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
@@ -1688,37 +1695,44 @@ struct UnetArgs {
 static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SPB == 4 && CH_U1::SPB == 4,
               "every stage must own the same 4 samples");
 
+// NS = trajectories per workgroup.  4: the form everything above is written for.  2 (launched for small batches, which leave
+// most CUs without a workgroup otherwise: twice the workgroups): only samples 0, 1 exist -- the L = 16 stages (downs.2 + mid,
+// ups.0: 3/4 of the matrix work, waves = channel slices x ALL samples) run over two samples, i.e. half the MFMAs, A reads,
+// epilogue and parking per wave for the same weight stream, while the stages whose waves ARE samples or sample pairs (downs.0,
+// downs.1, ups.1 + final block) keep their form with samples 2, 3 fed zeros and never stored.  Per-sample arithmetic is the same
+// instruction sequence either way: the results are bitwise equal.
+template <int NS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel(UnetArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n0 = blockIdx.x * 4;
+  const int n0 = blockIdx.x * NS;
 
-  f32x4 skip1[4][2], skip2[4][2];
+  f32x4 skip1[4][2], skip2[NS][2];
   // ---- downs.0 @ L=64 -> [4][32][32]: wave = sample, direct f16x2 convs on the wave's own slab (chain_body_d0w)
-  chain_body_d0w<CH_D0>(a.c[0], lds, n0, lane, wave, 0);
+  chain_body_d0w<CH_D0, NS>(a.c[0], lds, n0, lane, wave, 0);
   // ---- downs.1 @ L=32 -> [4][16][64], skip1: direct f16x2 convs, wave = (n-tile pair, sample pair) (chain_body_d1d)
   chain_body_d1d<CH_D1, CH_D2>(a.c[1], lds, lane, wave, skip1, 40);
-  // ---- downs.2 + mid blocks @ L=16 -> [4][16][128], skip2: direct f16x2 convs (chain_body_d2d; lane = channels 32 wave + 2
-  //      (lane & 15) + h, positions 4 (lane >> 4) + r of all four samples)
-  f32x4 mid_out[4][2];
-  chain_body_d2d<CH_D2>(a.c[2], lds, lane, wave, mid_out, skip2, 80);
+  // ---- downs.2 + mid blocks @ L=16 -> [NS][16][128], skip2: direct f16x2 convs (chain_body_d2d; lane = channels 32 wave + 2
+  //      (lane & 15) + h, positions 4 (lane >> 4) + r of all NS samples)
+  f32x4 mid_out[NS][2];
+  chain_body_d2d<CH_D2, NS>(a.c[2], lds, lane, wave, mid_out, skip2, 80);
   TR(130);
-  // ---- ups.0 @ L=16: cat(x, skip2) -> [4][32][64] (chain_body_u0d; the chunks are stored from downs.2's tiles); its output
+  // ---- ups.0 @ L=16: cat(x, skip2) -> [NS][32][64] (chain_body_u0d; the chunks are stored from downs.2's tiles); its output
   //      stays in registers (even / odd positions of channel 16 wave + (lane & 15))
-  f32x4 xe[4][1], xo[4][1];
+  f32x4 xe[NS][1], xo[NS][1];
   {
     using G128 = RdGeo<128>;
     constexpr int S_OFF = (CH_D2::SPB * CH_D2::XSS * 4 + 255) / 256 * 256;
     char* const slab128 = reinterpret_cast<char*>(lds) + S_OFF;
     char* const vs = slab128 + wave * G128::G + ((lane & 15) >> 2) * G128::BX + (2 + 4 * (lane >> 4)) * 16 + (lane & 3) * 4;
-    chain_body_u0d<CH_U0>(a.c[3], lds, lane, wave, mid_out, skip2, [&](const f32x4 (&t)[4][2]) { rd_store2<G128>(vs, t); },
-                          slab128, xe, xo, 136);
+    chain_body_u0d<CH_U0, NS>(a.c[3], lds, lane, wave, mid_out, skip2, [&](const f32x4 (&t)[NS][2]) { rd_store2<G128>(vs, t); },
+                              slab128, xe, xo, 136);
   }
   TR(131);
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32], final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]:
   //      wave = sample (chain_body_u1w)
-  chain_body_u1w<CH_U1>(a.c[4], a.fin, a.fs, lds, n0, lane, wave, xe, xo, skip1, 146);
+  chain_body_u1w<CH_U1, NS>(a.c[4], a.fin, a.fs, lds, n0, lane, wave, xe, xo, skip1, 146);
   TR(133);
 }
 
@@ -2278,6 +2292,13 @@ static const double kFp32Flops = 0.0;                                           
 static const double kUnetMfmaFlops = kF16Flops + kFp32Flops;
 
 
+// MMD_AMD_UNET_NS2_MAX=<n>: A/B override of the batch size up to which unet_kernel<2> is launched (0: never), sampled once at
+// load time (tools/unet_forward_loop.py, the trace tools); not an interface
+static const int kTwoPerWorkgroupMax = [] {
+  const char* e = getenv("MMD_AMD_UNET_NS2_MAX");
+  return e ? atoi(e) : 512;
+}();
+
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
                              hipStream_t st, mmd_profiler_t prof, const FusedStep* fs = nullptr) {
   MMD_REQUIRE(u && x && eps && ws, "mmd_unet_forward: NULL argument");
@@ -2304,7 +2325,9 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.fin.is1 = u->blob + u->fin_is1;
   a.fin.w1_bias = u->blob + u->fin_b1;
   const bool bracket = prof_begin(prof, 0, MMD_PROF_UNET, st);
-  hipLaunchKernelGGL(unet_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+  // two trajectories per workgroup while that still leaves at most one workgroup per CU (256 CUs): see unet_kernel
+  if (n <= kTwoPerWorkgroupMax) hipLaunchKernelGGL(unet_kernel<2>, dim3((n + 1) / 2), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(unet_kernel<4>, dim3((n + 3) / 4), dim3(256), 0, st, a);
   if (bracket) prof_end(prof, st);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
