@@ -59,20 +59,25 @@ def test_unet_forward_input_range(scale):
 
 
 def test_unet_forward_batch_independence():
-    """A trajectory's eps does not depend on which workgroup / wave slot it lands in: 2051 trajectories (513 workgroups,
-    the last one ragged) against the same rows evaluated in small batches -- bit-identical."""
+    """A trajectory's eps does not depend on which workgroup / wave slot it lands in, nor on which of the two kernels runs it:
+    2051 trajectories (unet_kernel<4>: 513 workgroups of four, the last one ragged) against the same rows evaluated in small
+    batches (unet_kernel<2>, two trajectories per workgroup, launched up to 512 trajectories; a 1-row batch = a workgroup with
+    one real sample) -- bit-identical."""
     model = _gc().hip_model(100)
     x = torch.from_numpy(synth.synth_noise(91, (2051, H, D))).cuda()
     big = model.model(x, 17)
     for rows in ([0, 1, 2, 3], [5, 1030, 2046], [2047, 2048, 2049, 2050], [2050]):
         small = model.model(x[rows].contiguous(), 17)
         assert torch.equal(big[rows], small), rows
+    # either side of the launch-size threshold between the two kernels (512), full and ragged last workgroups
+    for n in (511, 512, 513, 514):
+        assert torch.equal(model.model(x[:n].contiguous(), 17), big[:n]), n
 
 
 def test_unet_forward_is_batch_independent():
     """A trajectory's eps does not depend on which launch / workgroup it is in (the property the sharded sampler rests on):
-    the forward of a sub-batch, of a ragged batch and of a large batch agree bit for bit row by row, and meet the oracle
-    bound."""
+    the forward of a sub-batch, of a ragged batch and of a large batch agree bit for bit row by row (3- and 64-row batches run
+    unet_kernel<2>, the 1026- and 2050-row ones unet_kernel<4>), and meet the oracle bound."""
     model = _gc().hip_model(100)
     sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
     x = torch.from_numpy(synth.synth_noise(300, (2050, H, D))).cuda()
