@@ -903,8 +903,8 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
 // The input slab arrives from downs.0's tail (f16 pieces, per-sample scales in mx); the strided tail reads its slab at stride 2
 // (Stride2) and writes downs.2's row-form fp32 x slab (CFN geometry) + the per-sample maxima to mx.
 // skip: the stage's skip tensor (output of its second RTB) in the acc layout.
-template <class CF, class CFN>
-__device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&skip)[4][2], int trb) {
+template <class CF, class CFN, int NS>
+__device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&skip)[NS][2], int trb) {
   static_assert(CF::L == 32 && CF::CM == 64 && CF::C0 == 32 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
                     CF::MID_AFTER == 1 && CF::TAIL == TAIL_DOWN, "downs.1");
   using GI = RlGeo<32>;
@@ -914,22 +914,25 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
   char* const lb = reinterpret_cast<char*>(lds);
   char* const slabH = lb + H_OFF;
   float* const mx = lds + MX_OFF;
-  const int n = lane & 15, g = lane >> 4, np = wave & 1, sp = wave >> 1;
+  // SW samples per wave: the pair 2 sp, 2 sp + 1 of a four-sample workgroup, or sample sp of a two-sample one (unet_kernel<2>: all
+  // four waves on real samples, half the M tiles each); a sample = 2 M tiles, so a wave has NS of them
+  constexpr int SW = NS / 2;
+  const int n = lane & 15, g = lane >> 4, np = wave & 1, sp = wave >> 1, s0 = SW * sp;
   const int c0 = 32 * np + 2 * n;
-  const char* const vaI = lb + g * GI::G + (2 * sp * GI::RPS + n) * 16;
-  const char* const vaH = slabH + g * GH::G + (2 * sp * GH::RPS + n) * 16;
+  const char* const vaI = lb + g * GI::G + (s0 * GI::RPS + n) * 16;
+  const char* const vaH = slabH + g * GH::G + (s0 * GH::RPS + n) * 16;
   // the lane's channel pair (c0, c0 + 1) = block 4 np + (n >> 2) = (chunk (n >> 2) & 1, lane group 2 np + (n >> 3)), dword n & 3
-  char* const vsH = slabH + (2 * np + (n >> 3)) * GH::G + ((n >> 2) & 1) * GH::BX + (2 * sp * GH::RPS + 2 + 4 * g) * 16 + (n & 3) * 4;
+  char* const vsH = slabH + (2 * np + (n >> 3)) * GH::G + ((n >> 2) & 1) * GH::BX + (s0 * GH::RPS + 2 + 4 * g) * 16 + (n & 3) * 4;
   auto wptr = [&](const uint4* w, int frags, int h) { return reinterpret_cast<const u32x4*>(w) + (size_t)(2 * np + h) * frags * 64 + lane; };
   auto epi = [&](const float* b, const float* gm, const float* be, const float* tb, const float* isc) {
     return epi_load<2>(b, gm, be, tb, isc, c0);
   };
-  f32x4 acc[4][2], res[4][2];
+  f32x4 acc[NS][2], res[NS][2];
   constexpr int RD1 = MMD_D1_RD;                               // weight ring depth of the 64 -> 64 convs
   u32x4 ring[RD1][2][2];
   auto store_tile = [&]() {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < NS; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const F16Pair f = f16_split2(acc[m][0][r], acc[m][1][r]);
@@ -938,9 +941,9 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
       }
   };
   // GroupNorm + Mish of acc, sample by sample (M tiles 2 s, 2 s + 1)
-  auto gn = [&](auto conv_a, const Epi<2>& e, const float (&inv)[2], float act_s) {
+  auto gn = [&](auto conv_a, const Epi<2>& e, const float (&inv)[SW], float act_s) {
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < SW; ++sl) {
       f32x4(&t)[2][2] = reinterpret_cast<f32x4(&)[2][2]>(acc[2 * sl]);
       if constexpr (decltype(conv_a)::value) {
         const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
@@ -951,10 +954,10 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     }
   };
   // per-sample |x| maxima of the tile in v -> all eight slots of the two samples (the two waves of a sample pair fill them)
-  auto maxima_out = [&](const f32x4 (&v)[4][2]) {
-    float m2[2];
+  auto maxima_out = [&](const f32x4 (&v)[NS][2]) {
+    float m2[2] = {0.f, 0.f};
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < SW; ++sl) {
       float m = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -966,13 +969,13 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
       m = max_xor16(m);
       m2[sl] = max_xor32(m);
     }
-    if (lane < 8) mx[(2 * sp + (lane >> 2)) * MX_SLOTS + np + 2 * (lane & 3)] = (lane >> 2) ? m2[1] : m2[0];
+    if (lane < 4 * SW) mx[(s0 + (lane >> 2)) * MX_SLOTS + np + 2 * (lane & 3)] = (lane >> 2) ? m2[1] : m2[0];
   };
   // dynamic input scale of the tile in acc from the maxima in mx: scale in place, the inverse scales per sample of the pair
-  auto scale_in = [&](float (&inv)[2]) {
+  auto scale_in = [&](float (&inv)[SW]) {
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      const DynScale ds = dyn_scale(mx_read(mx, 2 * sp + sl));
+    for (int sl = 0; sl < SW; ++sl) {
+      const DynScale ds = dyn_scale(mx_read(mx, s0 + sl));
       inv[sl] = ds.inv;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -986,9 +989,11 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     rd_ring_load<GH, 2, RD1>(ring, wp);
     store_tile();
     __syncthreads();
-    rd_taps<GH, 2, 0, 5, true, false, 4, RD1>(acc, acc, vaH, wp, wp, ring);
+    rd_taps<GH, 2, 0, 5, true, false, NS, RD1>(acc, acc, vaH, wp, wp, ring);
   };
-  const float one2[2] = {1.f, 1.f};
+  float one2[SW];
+#pragma unroll
+  for (int sl = 0; sl < SW; ++sl) one2[sl] = 1.f;
 
   // =================== RTB 0 (32 -> 64): conv A + the 1x1 residual conv on the centre tap ===================
   {
@@ -1000,13 +1005,13 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
     __syncthreads();                                         // downs.0's tail has written the input slab and its maxima
     TR(trb + 0);
-    float inv_in[2];
+    float inv_in[SW];
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) inv_in[sl] = dyn_scale(mx_read(mx, 2 * sp + sl)).inv;
+    for (int sl = 0; sl < SW; ++sl) inv_in[sl] = dyn_scale(mx_read(mx, s0 + sl)).inv;
     rd_zero_halo<GH>(slabH);
-    rd_taps<GI, 2, 0, 5, true, true, 4, 5>(acc, res, vaI, wpa, wpr, ring5);
+    rd_taps<GI, 2, 0, 5, true, true, NS, 5>(acc, res, vaI, wpa, wpr, ring5);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < NS; ++m)
 #pragma unroll
       for (int t = 0; t < 2; ++t) res[m][t] = res[m][t] * (isr[t] * inv_in[m >> 1]) + br[t];
     gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
@@ -1022,12 +1027,12 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
   {
     const RtbPtrs& R = a.ri[0];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < NS; ++m)
 #pragma unroll
       for (int t = 0; t < 2; ++t) res[m][t] = acc[m][t];
     maxima_out(acc);
     __syncthreads();                                         // the previous conv is done reading the slab
-    float inv[2];
+    float inv[SW];
     scale_in(inv);
     const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
     conv(R.wa_bf);
@@ -1039,7 +1044,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     gn(std::false_type{}, eb, one2, 1.f);
     TR(trb + 4);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < NS; ++m)
 #pragma unroll
       for (int t = 0; t < 2; ++t) skip[m][t] = acc[m][t];
   }
@@ -1047,19 +1052,20 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
   {
     maxima_out(acc);
     __syncthreads();
-    float inv[2];
+    float inv[SW];
     scale_in(inv);
     const u32x4* wt[2] = {wptr(a.wt_bf0, GH::FRAGS3, 0), wptr(a.wt_bf0, GH::FRAGS3, 1)};
     const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0], a.ist0[c0 + 1]};
     rd_ring_load<GH, 2, RD1>(ring, wt);
     store_tile();
     __syncthreads();
-    // (outputs q = 4 g + r = the even positions 2 q of the pair's two samples: one M tile each, read at stride 2)
+    // (outputs q = 4 g + r = the even positions 2 q of the wave's samples: one M tile each, read at stride 2; the GEMM loop takes
+    // M tiles in pairs: a one-sample wave computes its tile twice)
     f32x4 y[2][2];
-    rd_taps<Stride2<GH, GH::RPS, 1>, 2, 1, 3, true, false, 2, RD1>(y, y, vaH + n * 16, wt, wt, ring);
-    float m2[2];
+    rd_taps<Stride2<GH, SW == 2 ? GH::RPS : 0, 1>, 2, 1, 3, true, false, 2, RD1>(y, y, vaH + n * 16, wt, wt, ring);
+    float m2[2] = {0.f, 0.f};
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < SW; ++sl) {
       float m = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1073,11 +1079,11 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
       m2[sl] = max_xor32(m);
     }
     __syncthreads();                                         // every wave is done reading the slab the next stage's x slab aliases
-    if (lane < 8) mx[(2 * sp + (lane >> 2)) * MX_SLOTS + np + 2 * (lane & 3)] = (lane >> 2) ? m2[1] : m2[0];
+    if (lane < 4 * SW) mx[(s0 + (lane >> 2)) * MX_SLOTS + np + 2 * (lane & 3)] = (lane >> 2) ? m2[1] : m2[0];
     // -> the next stage's row-form fp32 x slab [sample][2 + q][CFN::XSTR]
-    float* xb = lds + (2 * sp) * CFN::XSS + (2 + 4 * g) * CFN::XSTR + c0;
+    float* xb = lds + s0 * CFN::XSS + (2 + 4 * g) * CFN::XSTR + c0;
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
+    for (int sl = 0; sl < SW; ++sl)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         *reinterpret_cast<float2*>(xb + sl * CFN::XSS + r * CFN::XSTR) = make_float2(y[sl][0][r], y[sl][1][r]);
@@ -1396,7 +1402,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 // same wave wrote (wave_lds_fence).  Slabs: RwGeo<64, 32> (conv A chunks), RwGeo<32, 32>, RwGeo<32, 64> (final block).
 template <class CF, int NS>
 __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, const FusedStep& fs, float* lds, int n0, int lane_in, int wave,
-                                               const f32x4 (&xe)[NS][1], const f32x4 (&xo)[NS][1], const f32x4 (&skip)[4][2],
+                                               const f32x4 (&xe)[NS][1], const f32x4 (&xo)[NS][1], const f32x4 (&skip)[NS][2],
                                                int trb) {
   // (an opaque copy of the lane index: the stage's lane-derived offsets are recomputed here -- a handful of VALU ops -- instead
   // of being kept alive, i.e. spilled, since the stages that happen to use the same products)
@@ -1428,11 +1434,13 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   // ---- the skip tensor's per-sample maxima (downs.1's layout: wave = (channel half np, sample pair sp); skip[m][t][r]: sample 2 sp
   //      + (m >> 1), channel 32 np + 2 n + t, position 16 (m & 1) + 4 g + r) -> slots 4 .. 7 of mx region 0 (the two waves of a
   //      sample pair fill them); ups.0 left its output's maxima in slots 0 .. 3
-  const int np = wave & 1, sp = wave >> 1;
+  //      (two trajectories per workgroup: sp = the wave's one sample, NS = 2 M tiles)
+  constexpr int SW = NS / 2;
+  const int np = wave & 1, sp = wave >> 1, s0 = SW * sp;
   {
-    float m2[2];
+    float m2[2] = {0.f, 0.f};
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < SW; ++sl) {
       float m = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -1444,7 +1452,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
       m = max_xor16(m);
       m2[sl] = max_xor32(m);
     }
-    if (lane < 4) mx[(2 * sp + (lane >> 1)) * MX_SLOTS + 4 + np + 2 * (lane & 1)] = (lane >> 1) ? m2[1] : m2[0];
+    if (lane < 2 * SW) mx[(s0 + (lane >> 1)) * MX_SLOTS + 4 + np + 2 * (lane & 1)] = (lane >> 1) ? m2[1] : m2[0];
   }
   __syncthreads();                                           // ups.0 is done with its slabs; the maxima are in mx
   TR(trb + 0);
@@ -1452,7 +1460,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
 #pragma unroll
   for (int sm = 0; sm < 4; ++sm) sc[sm] = dyn_scale(mx_read(mx, sm)).s;
   const float inv_in = dyn_scale(mx_read(mx, wave)).inv;
-  const float sc_lo = dyn_scale(mx_read(mx, 2 * sp)).s, sc_hi = dyn_scale(mx_read(mx, 2 * sp + 1)).s;
+  const float sc_lo = dyn_scale(mx_read(mx, s0)).s, sc_hi = dyn_scale(mx_read(mx, s0 + SW - 1)).s;
   // channel col = 16 wave + n of a 64-channel chunk: block 2 wave + (n >> 3) = (lane group wave, chunk n >> 3), the pair (n & ~1,
   // n | 1) one dword; the lanes of a pair swap halves so that each stores whole dwords
   char* const cdst = lb + wave * GA::G + (n >> 3) * GA::BX + ((n & 7) >> 1) * 4 + 2 * 16;
@@ -1490,12 +1498,12 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     // 1, lane group 2 np + (n >> 3)), dword n & 3, in the slabs of samples 2 sp, 2 sp + 1
     char* const sdst = lb + (2 * np + (n >> 3)) * GA::G + ((n >> 2) & 1) * GA::BX + (n & 3) * 4 + (2 + 4 * g) * 16;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NS; ++m) {
       const float sm_s = (m >> 1) ? sc_hi : sc_lo;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const F16Pair p = f16_split2(skip[m][0][r] * sm_s, skip[m][1][r] * sm_s);
-        char* d = sdst + (2 * sp + (m >> 1)) * W_BYTES + (16 * (m & 1) + r) * 16;
+        char* d = sdst + (s0 + (m >> 1)) * W_BYTES + (16 * (m & 1) + r) * 16;
         *reinterpret_cast<unsigned*>(d) = p.hi;
         *reinterpret_cast<unsigned*>(d + GA::PS) = p.lo;
       }
@@ -1698,8 +1706,9 @@ static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SP
 // NS = trajectories per workgroup.  4: the form everything above is written for.  2 (launched for small batches, which leave
 // most CUs without a workgroup otherwise: twice the workgroups): only samples 0, 1 exist -- the L = 16 stages (downs.2 + mid,
 // ups.0: 3/4 of the matrix work, waves = channel slices x ALL samples) run over two samples, i.e. half the MFMAs, A reads,
-// epilogue and parking per wave for the same weight stream, while the stages whose waves ARE samples or sample pairs (downs.0,
-// downs.1, ups.1 + final block) keep their form with samples 2, 3 fed zeros and never stored.  Per-sample arithmetic is the same
+// epilogue and parking per wave for the same weight stream, and downs.1's waves (n-tile pair x sample PAIR) take one sample each,
+// while the stages whose waves ARE samples (downs.0, ups.1 + final block) keep their form with samples 2, 3 fed zeros and
+// never stored.  Per-sample arithmetic is the same
 // instruction sequence either way: the results are bitwise equal.
 template <int NS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel(UnetArgs a) {
@@ -1708,11 +1717,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * NS;
 
-  f32x4 skip1[4][2], skip2[NS][2];
+  f32x4 skip1[NS][2], skip2[NS][2];
   // ---- downs.0 @ L=64 -> [4][32][32]: wave = sample, direct f16x2 convs on the wave's own slab (chain_body_d0w)
   chain_body_d0w<CH_D0, NS>(a.c[0], lds, n0, lane, wave, 0);
   // ---- downs.1 @ L=32 -> [4][16][64], skip1: direct f16x2 convs, wave = (n-tile pair, sample pair) (chain_body_d1d)
-  chain_body_d1d<CH_D1, CH_D2>(a.c[1], lds, lane, wave, skip1, 40);
+  chain_body_d1d<CH_D1, CH_D2, NS>(a.c[1], lds, lane, wave, skip1, 40);
   // ---- downs.2 + mid blocks @ L=16 -> [NS][16][128], skip2: direct f16x2 convs (chain_body_d2d; lane = channels 32 wave + 2
   //      (lane & 15) + h, positions 4 (lane >> 4) + r of all NS samples)
   f32x4 mid_out[NS][2];
