@@ -43,7 +43,7 @@ PEAK_F16_MFMA_TFLOPS = 2516.6      # dense fp16 / bf16 MFMA peak (1024 FLOP/clk/
 PEAK_HBM_GBPS = 8000.0             # HBM3E spec (6.3 TB/s achievable, same guide)
 DOMINANT_KERNEL = "UNET"           # unet_kernel: the whole TemporalUnet forward in one launch (all 25 convs + GN/Mish)
 HEADLINE_ROBOTS = 32               # BASELINE.json: 32-robot Empty map
-PROF_UNET, PROF_STEP_GUIDED, PROF_STEP_PLAIN = 0, 1, 2     # include/mmd_amd_debug.h
+PROF_UNET, PROF_STEP_GUIDED, PROF_STEP_PLAIN, PROF_UNET_FUSED = 0, 1, 2, 3     # include/mmd_amd_debug.h
 
 
 # unet_kernel runs at the package power limit (profiles/r03_power_probe.txt): a loop of nothing but v_mfma_f32_16x16x32_f16 at
@@ -133,6 +133,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-scaling", action="store_true", help="N>1: time only the headline scaling mode")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit: no GPU touched")
     ap.add_argument("--no-power-probe", action="store_true",
                     help="skip the 1.5 s of whole-batch launches timed with the clock / power sampled (outside the timed region; "
                          "~6000 extra unet_kernel launches that would swamp a rocprofv3 trace of the command)")
@@ -240,8 +241,10 @@ def union_length(intervals):
     return tot
 
 
-def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
-    """Time args.steps planning rounds of one scaling mode; returns (value, ms_per_step, config, roofline objects or None)."""
+def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=None):
+    """Time args.steps planning rounds of one scaling mode with NOTHING attached (pass 1: `value`); with_roofline: the same
+    rounds once more with the launch profiler and the clock / power sampler attached (pass 2: secondary launch statistics) and
+    the whole-batch kernel back to back (power probe).  Returns (value, ms_per_step, config, roofline objects or None)."""
     import ctypes as C
     from mmd_amd import _lib, synth
     from mmd_amd.diffusion_model import GaussianDiffusionModel
@@ -273,38 +276,30 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def timed_rounds(seed0):
+        nonlocal paths_local
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            trajs, paths_local = sampler.plan_round(paths_local, seed=seed0 + k)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert torch.isfinite(trajs).all()
+        return dt
+
     lib = _lib.load()
     n_traj_local = RPG * B
-    # the sampler splits the robots into `chunks` concurrent launch chains (HIP streams) from 2048 trajectories on
-    chunks = max(1, min(2 if n_traj_local >= 2048 else 1, RPG))
+    # the launch shape the library will use: concurrent stream chunks per UNet / step launch (2 from 2048 trajectories on)
+    chunks = lib.mmd_sampler_stream_chunks(sampler.n_streams, RPG, B)
     for w in range(args.warmup):
         _, paths_local = sampler.plan_round(paths_local, seed=1000 + w)
-    # Roofline measurements INSIDE the timed region: every UNet launch and step-kernel launch of two consecutive DDPM steps
-    # out of every twelve (all stream chunks) is bracketed by a HIP event pair on the stream it is launched on
-    # (mmd_amd_debug.h profiler attached to the sampler): ~130 event pairs per 101-step round, < 1 % of it.
-    prof = C.c_void_p()
-    window, stride = 2 * chunks, 6
-    per_call = (T + 1) * chunks
-    max_pairs = 2 * (per_call // (window * stride) + 1) * window * max(args.steps, 1)
-    if with_roofline:
-        _lib.check(lib.mmd_profiler_create_windowed(C.byref(prof), max_pairs, stride, window, per_call))
-        model.profiler = prof
-    watch = PowerSampler() if with_roofline and rank == 0 and not rehearsal else None
-    barrier()
-    if watch:
-        watch.start()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        trajs, paths_local = sampler.plan_round(paths_local, seed=k)
-    barrier()
-    dt = time.perf_counter() - t0
-    power_timed = watch.finish() if watch else None
-    model.profiler = None
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(trajs).all()
+    # ---- pass 1: the timed region.  No profiler, no sampler thread: exactly args.steps rounds between two barriers.
+    dt = timed_rounds(0)
+    ms_per_step = dt / args.steps * 1e3
     value = args.steps * n_traj_local * world / dt
     config = {"workload": f"{scaling}-scaling over {world} GPU(s): "
                           f"{n_robots}-robot EnvEmpty2D circle r=0.8, {RPG} robots/GPU x B={B} samples, H=64, "
@@ -316,7 +311,39 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
               else "single GPU", "noise": "in-kernel Philox4x32-10 keyed by global trajectory index",
               "weights": "random-init (numpy PCG64 seed 0)"}
     if not with_roofline:
-        return value, dt / args.steps * 1e3, config, None, None
+        return value, ms_per_step, config, None, None
+
+    # ---- roofline of the dominant kernel from the timed region alone: MFMA issue time of one round at the spec clock / the
+    # round's wall time.  Every conv runs as f16x2: 3 fp16 MFMA FLOPs per fp32 GEMM FLOP, (T + 1) forwards of every local
+    # trajectory per round, whatever the launch shape.
+    n_fwd = T + 1
+    flops_traj = lib.mmd_unet_flops_per_trajectory()                 # algorithmic (direct-conv, fp32) FLOPs per forward
+    mfma_traj = lib.mmd_unet_mfma_flops_per_trajectory()             # fp32 GEMM FLOPs the kernel runs (padding included)
+    h_traj = lib.mmd_unet_f16x2_flops_per_trajectory()               # ... of which as f16x2 on the fp16 pipe (all of it)
+    assert mfma_traj == h_traj, "an fp32 MFMA path is back: price it at the fp32 MFMA peak"
+    issued_round = 3.0 * h_traj * n_traj_local * n_fwd               # fp16 MFMA FLOPs issued per round (per GPU)
+    issue_ms_round = issued_round / (PEAK_F16_MFMA_TFLOPS * 1e12) * 1e3
+    frac = issue_ms_round / ms_per_step
+    launches_round = n_fwd * chunks
+    n_launch = n_traj_local // chunks                                # trajectories per launch
+    busy_s = issue_ms_round * 1e-3 / launches_round                  # MFMA issue time of ONE launch at spec clock
+
+    # ---- pass 2 (secondary): the same rounds with every UNet launch and step-kernel launch of two consecutive DDPM steps out
+    # of every twelve (all stream chunks) bracketed by a HIP event pair on the stream it is launched on, and the shader clock /
+    # socket power sampled.  The brackets slow the bracketed launches down (they serialise against the other chunk), which is
+    # why none of this enters `value` or `frac`.
+    prof = C.c_void_p()
+    window, stride = 2 * chunks, 6
+    per_call = n_fwd * chunks
+    max_pairs = 2 * (per_call // (window * stride) + 1) * window * max(args.steps, 1)
+    _lib.check(lib.mmd_profiler_create_windowed(C.byref(prof), max_pairs, stride, window, per_call))
+    model.profiler = prof
+    watch = PowerSampler() if rank == 0 and not rehearsal else None
+    if watch:
+        watch.start()
+    dt2 = timed_rounds(10_000)
+    power_timed = watch.finish() if watch else None
+    model.profiler = None
 
     def intervals(kind):
         a = (C.c_double * max_pairs)()
@@ -325,21 +352,28 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
         _lib.check(lib.mmd_profiler_intervals(prof, kind, a, b, max_pairs, C.byref(n)))
         return [(a[i] * 1e-3, b[i] * 1e-3) for i in range(n.value)]       # seconds
 
-    iv_unet, iv_g, iv_p = intervals(PROF_UNET), intervals(PROF_STEP_GUIDED), intervals(PROF_STEP_PLAIN)
+    iv_plain, iv_fused = intervals(PROF_UNET), intervals(PROF_UNET_FUSED)
+    iv_g, iv_p = intervals(PROF_STEP_GUIDED), intervals(PROF_STEP_PLAIN)
     _lib.check(lib.mmd_profiler_destroy(prof))
-    n_launch = n_traj_local // chunks                                            # trajectories per launch
-    flops = lib.mmd_unet_flops_per_trajectory() * n_launch                      # algorithmic (direct-conv) FLOPs per launch
-    mfma_flops = lib.mmd_unet_mfma_flops_per_trajectory() * n_launch            # fp32 GEMM FLOPs the matrix pipe runs
-    h_flops = lib.mmd_unet_f16x2_flops_per_trajectory() * n_launch              # ... of which as f16x2 on the fp16 pipe
-    # matrix-pipe issue time of ONE launch at spec clock: fp32 MFMAs at the fp32 MFMA peak, the f16x2 part as 3 fp16 MFMA
-    # FLOPs per fp32 FLOP at the fp16 MFMA peak (16x)
-    busy_s = (mfma_flops - h_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + 3.0 * h_flops / (PEAK_F16_MFMA_TFLOPS * 1e12)
+    iv_unet = iv_plain + iv_fused
+
+    def mean_ms(iv):
+        return float(np.mean([b - a for a, b in iv])) * 1e3 if iv else None
+
     dur = [b - a for a, b in iv_unet]
-    launch_s = float(np.mean(dur))
     union_s = union_length(iv_unet)                      # wall time during which at least one bracketed UNet launch runs
-    concurrency = sum(dur) / union_s
-    pipe_busy = busy_s * len(dur) / union_s
-    # outside the timed region: the same kernel as ONE launch of all local trajectories, back to back on one stream
+    bracketed = {
+        "note": "pass 2 (same rounds, profiler attached; NOT the timed region): HIP-event intervals of the bracketed launches; "
+                "bracketed launches run slower than unbracketed ones, so union x launches may exceed the round time",
+        "ms_per_step_with_profiler": dt2 / args.steps * 1e3,
+        "unet_launch_ms": {"forward_only": mean_ms(iv_plain), "forward_plus_fused_unguided_step": mean_ms(iv_fused)},
+        "launches_timed": len(dur), "measured_concurrency": sum(dur) / union_s if dur else None,
+        "union_ms_per_launch": union_s / len(dur) * 1e3 if dur else None,
+        "pipe_busy_in_union": busy_s * len(dur) / union_s if dur else None,
+    }
+    # outside the timed region: the same kernel as ONE launch of all local trajectories, back to back on one stream, with the
+    # shader clock / socket power / throttler residencies sampled (and the CPU baseline running beside it in its own process:
+    # it needs the host cores only, and the GPU stays busy for whoever watches it)
     xs = torch.randn(n_traj_local, H, 4, device=dev)
     for _ in range(3):
         unet(xs, 50)
@@ -351,80 +385,78 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
     e1.record()
     torch.cuda.synchronize()
     solo_s, solo_n = e0.elapsed_time(e1) / 20 * 1e-3, 20
-    # ... and for ~1.5 s with the shader clock and the socket power sampled: the kernel sits at the package power limit, so the
-    # clock the matrix pipe really runs at is below the 2.4 GHz the peak is quoted for
-    sustained = None
+    sustained, cpu_result = None, None
     if rank == 0 and not rehearsal and not args.no_power_probe:
-        reps = max(20, int(1.5 / solo_s))
+        job = cpu_job() if cpu_job else None               # subprocess handle (or None)
+        throttle0 = throttle_snapshot()
         watch = PowerSampler()
         watch.start()
+        t_start, reps, batch = time.perf_counter(), 0, max(20, int(0.25 / solo_s))
         e0.record()
-        for _ in range(reps):
-            unet(xs, 50)
+        while True:
+            for _ in range(batch):
+                unet(xs, 50)
+            reps += batch
+            torch.cuda.synchronize()                       # (bounds the launch queue; one sync per ~0.25 s of kernels)
+            el = time.perf_counter() - t_start
+            if (el >= 1.5 and (job is None or job.poll() is not None)) or el > args.cpu_budget_s + 90:
+                break
         e1.record()
         torch.cuda.synchronize()
         sustained = watch.finish(skip_s=0.5)
+        throttle1 = throttle_snapshot()
         if sustained:
-            sustained.update({"launch_ms": e0.elapsed_time(e1) / reps, "launches": reps, "trajectories": n_traj_local})
-        solo_s = e0.elapsed_time(e1) / reps * 1e-3           # (the 20 launches above start from an idle, down-clocked GPU)
-        solo_n = reps
-    # HBM-side traffic per launch: rocprofv3 PMC passes (separate runs, kernel-trace only: tools/gpu_profile.sh), committed as
-    # profiles/pmc_latest.json; traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE half-count correction)
-    traffic, traffic_src, pmc_all = None, None, {}
+            sustained.update({"launch_ms": e0.elapsed_time(e1) / reps, "launches": reps, "trajectories": n_traj_local,
+                              "seconds": time.perf_counter() - t_start})
+            if throttle0 and throttle1:
+                import gpu_throttle
+                sustained["throttle_residency"] = gpu_throttle.residency(throttle0, throttle1)
+                sustained["throttle_active_at_end"] = {k: v for k, v in throttle1.items() if k.startswith("active_")}
+                sustained["power_cap_info"] = throttle1.get("power_cap")
+        solo_s, solo_n = e0.elapsed_time(e1) / reps * 1e-3, reps
+        if job is not None:
+            cpu_result = cpu_job_result(job)
+    elif cpu_job:
+        cpu_result = cpu_job_result(cpu_job())
+    pmc_ref = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
-            pmc_all = json.load(f)
-        pmc = pmc_all.get(DOMINANT_KERNEL)
-        if pmc and pmc.get("trajectories_per_launch", 1024) == n_launch:
-            traffic = (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0
-            traffic_src = f"profiles/pmc_latest.json ({pmc_all.get('source', 'rocprofv3 PMC passes')}); not measured by this run"
-    eq_tf = mfma_flops * len(dur) / union_s / 1e12
+            pmc_ref = json.load(f)
     roofline = {
         "bound": "mfma",
-        "kernel": "unet_kernel<4>: whole TemporalUnet forward for 4 trajectories per workgroup (launches of <= 512 trajectories: unet_kernel<2>, two per workgroup; 12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; every conv a direct convolution as an fp16 two-piece split of fp32 (f16x2, 3 MFMAs per product, fp32 accumulate) on v_mfma_f32_16x16x32_f16; the unguided DDPM steps ride in its tail; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
-        "achieved": pipe_busy * PEAK_FP32_MFMA_TFLOPS, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": pipe_busy,
-        "frac_definition": "matrix-pipe busy fraction: MFMA issue time of the bracketed launches at spec clock (fp32 MFMAs at "
-                           "157.3 TFLOP/s, fp16 MFMAs at 2516.6) / wall time during which at least one of them runs (union of "
-                           "their HIP-event intervals, all stream chunks); `achieved` = frac x peak, i.e. the issued MFMA work "
-                           "in fp32-MFMA-equivalent TFLOP/s (an fp16 MFMA FLOP counts 1/16)",
-        "traffic": traffic, "traffic_source": traffic_src,
-        "hbm_gbps": None if traffic is None else traffic * len(dur) / union_s / 1e9,
-        "launch_ms": launch_s * 1e3, "launches_timed": len(dur), "trajectories_per_launch": n_launch,
-        "stream_chunks": chunks, "measured_concurrency": concurrency, "union_ms_per_launch": union_s / len(dur) * 1e3,
-        "pipe_busy_single_launch_alone": busy_s * chunks / solo_s,
+        "kernel": "unet_kernel<4>: whole TemporalUnet forward for 4 trajectories per workgroup (launches of <= 512 trajectories: unet_kernel<2>, two per workgroup; 12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; every conv a direct convolution as an fp16 two-piece split of fp32 (f16x2, 3 MFMAs per product, fp32 accumulate) on the fp16 matrix pipe; the unguided DDPM steps ride in its tail; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
+        "achieved": frac * PEAK_F16_MFMA_TFLOPS, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": frac,
+        "frac_definition": "fp16 MFMA FLOPs the kernel issues per planning round (3 per fp32 GEMM FLOP of an f16x2 conv x "
+                           "(T + 1) forwards x local trajectories) / 2516.6 TFLOP/s = MFMA issue time per round at the spec "
+                           "clock, / ms_per_step of the timed region (pass 1, nothing attached): the matrix pipe's busy "
+                           "fraction over the WHOLE round, step kernels and launch gaps included; achieved = frac x peak",
+        "mfma_issue_ms_per_round": issue_ms_round, "ms_per_step": ms_per_step, "unet_launches_per_round": launches_round,
+        "mfma_issue_ms_per_launch": busy_s * 1e3, "trajectories_per_launch": n_launch, "stream_chunks": chunks,
+        "useful_frac_of_f16_pipe": flops_traj * n_traj_local * n_fwd / (PEAK_F16_MFMA_TFLOPS * 1e12) / (ms_per_step * 1e-3),
+        "flops_per_trajectory_forward": {"algorithmic_direct_conv_fp32": flops_traj, "fp32_gemm_issued": mfma_traj,
+                                         "fp16_mfma_issued": 3.0 * h_traj},
+        "traffic": None,
+        "traffic_note": "not measured by this run (PMC counters need rocprofv3 passes of their own); the last committed passes are "
+                        "under pmc_reference",
+        "pmc_reference": pmc_ref,
+        "bracketed_launches": bracketed,
         "whole_batch_single_launch": {"trajectories": n_traj_local, "launch_ms": solo_s * 1e3,
+                                      "pipe_busy": busy_s * chunks / solo_s,
                                       "note": f"the same kernel as one launch of all local trajectories, {solo_n} back to back on one stream, outside the timed region"},
-        "mfma_issue_ms_per_launch": busy_s * 1e3,
         "power": {
-            "timed_region": power_timed, "kernel_back_to_back": sustained,
-            "frac_at_measured_clock": None if not (sustained and sustained["sclk_mhz"]) else
-            busy_s * SPEC_SCLK_MHZ / sustained["sclk_mhz"] / (sustained["launch_ms"] * 1e-3) * (n_traj_local / n_launch),
-            "frac_of_power_limited_mfma_rate": None if not sustained else
-            busy_s * (PEAK_F16_MFMA_TFLOPS / POWER_LIMITED_F16_MFMA_TFLOPS) / (sustained["launch_ms"] * 1e-3) * (n_traj_local / n_launch),
-            "note": "unet_kernel is power-bound: back to back it holds the socket at its limit and the shader clock drops below the "
-                    "2.4 GHz of `peak`; frac_at_measured_clock = MFMA issue time at the sampled clock / launch time of the whole-batch "
-                    "launch; frac_of_power_limited_mfma_rate = against the 1981 TFLOP/s a pure v_mfma_f32_16x16x32_f16 loop sustains "
-                    "at the same limit (profiles/r03_power_probe.txt); energy per instruction class and the kernel's budget: DESIGN.md"},
-        "flops_per_launch": {"algorithmic_direct_conv": flops, "fp32_gemm_issued": mfma_flops, "of_which_f16x2": h_flops},
-        "not_utilisation": {
-            "fp32_equivalent_gemm_rate_tflops": eq_tf, "ratio_to_fp32_mfma_peak": eq_tf / PEAK_FP32_MFMA_TFLOPS,
-            "algorithmic_rate_tflops": flops * len(dur) / union_s / 1e12,
-            "note": "fp32 GEMM FLOPs the kernel performs (in the form each stage uses; an f16x2 conv counted as the fp32 math it "
-                    "does) and direct-convolution FLOPs (SURVEY 8d) per second of UNet wall time: both exceed what the fp32 pipe "
-                    "could issue because f16x2 runs on the 16x faster pipe; they are rates of useful work, not a utilisation"},
+            "pass2_rounds": power_timed, "kernel_back_to_back": sustained,
+            "frac_at_measured_clock": None if not (sustained and sustained.get("sclk_mhz")) else
+            busy_s * chunks * SPEC_SCLK_MHZ / sustained["sclk_mhz"] / (sustained["launch_ms"] * 1e-3),
+            "note": "shader clock / socket power (amdgpu sysfs) and the firmware's throttler residencies (amdsmi violation "
+                    "accumulators: ppt_pwr = package power tracker, *_thrm = thermal) while the whole-batch launch runs back to "
+                    "back; frac_at_measured_clock = MFMA issue time at the sampled clock / launch time"},
     }
-    pmc_busy = pmc_all.get(DOMINANT_KERNEL, {}).get("mfma_busy_frac")
-    if pmc_busy is not None:
-        roofline["mfma_busy_pmc"] = {"value": pmc_busy, "source": "profiles/pmc_latest.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs), rocprofv3 PMC pass (serialises kernels: one launch at a time)"}
-        wb = pmc_all[DOMINANT_KERNEL].get("whole_batch_2048")
-        if wb:          # (a ratio of cycle counts: the clock the socket's power limit allows is already in it)
-            roofline["mfma_busy_pmc"]["whole_batch_2048"] = wb
     # second kernel: the fused DDPM-step + guide kernel, HBM roofline on its algorithmic bytes
     step_bytes = 3.0 * 1024.0 * n_launch                     # x read + eps read + x write per trajectory and step
     guide = {"kernel": "ddpm_guide_kernel: posterior mean + 20 guide iterations (SDF gather, workspace walls, GP prior, 31 x 63 soft-constraint points) + noise + hard conditioning, one wave per trajectory",
              "bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_launch": step_bytes,
-             "note": "algorithmic bytes = 3 KiB per trajectory and step; the kernel is bound by the latency of its 20 dependent guide iterations (VALU issue), not by HBM"}
+             "note": "algorithmic bytes = 3 KiB per trajectory and step; the kernel is bound by the latency of its 20 dependent guide iterations (VALU issue), not by HBM; launch times are pass-2 brackets"}
     for name, iv in (("guided", iv_g), ("unguided", iv_p)):
         if iv:
             d = float(np.mean([b - a for a, b in iv]))
@@ -432,14 +464,33 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline):
                            "frac": step_bytes / d / 1e9 / PEAK_HBM_GBPS}
     if not iv_p:
         guide["unguided"] = {"fused": "steps without guidance run inside the tail of the unet_kernel launch that produces their eps (no step-kernel launch)"}
-    gp = pmc_all.get("GUIDE")
-    if gp:
-        guide["pmc"] = gp
-    return value, dt / args.steps * 1e3, config, roofline, guide
+    return value, ms_per_step, config, roofline, (guide, cpu_result)
+
+
+def throttle_snapshot():
+    """amdsmi violation accumulators (tools/gpu_throttle.py), or None when the binding / driver does not provide them."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gpu_throttle
+        return gpu_throttle.snapshot()
+    except Exception:      # noqa: BLE001  (best effort, like PowerSampler)
+        return None
+
+
+def cpu_job_result(job):
+    out, _ = job.communicate(timeout=600)
+    for line in reversed(out.decode().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": "cpu baseline subprocess printed no JSON", "returncode": job.returncode}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:                              # (the subprocess of cpu_job below: host cores only)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        print(json.dumps(cpu_baseline(args.diffusion_steps, args.samples, HEADLINE_ROBOTS, args.cpu_budget_s)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)                                   # does not return
@@ -462,7 +513,16 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    value, ms, config, roofline, guide = run_mode(args, args.scaling, rank, world, dev, rehearsal, with_roofline=True)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+
+    def cpu_job():
+        """The CPU baseline in a process of its own (host cores only), started when the GPU part's timed region is over."""
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--diffusion-steps", str(args.diffusion_steps),
+               "--samples", str(args.samples), "--cpu-budget-s", str(args.cpu_budget_s)]
+        return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+
+    value, ms, config, roofline, (guide, cpu_result) = run_mode(args, args.scaling, rank, world, dev, rehearsal, with_roofline=True,
+                                                                cpu_job=cpu_job if want_cpu else None)
     out = {
         "metric": "guided trajectories/sec (H=64, 100 denoise steps), 32-robot Empty map",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -479,9 +539,8 @@ def main():
         other = "weak" if args.scaling == "strong" else "strong"
         v2, ms2, cfg2, _, _ = run_mode(args, other, rank, world, dev, rehearsal, with_roofline=False)
         out[f"{other}_scaling"] = {"value": v2, "unit": "trajectories/s", "ms_per_step": ms2, "scaling": other, "config": cfg2}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        out["cpu_baseline"] = cpu_baseline(args.diffusion_steps, args.samples, config["n_robots"], args.cpu_budget_s)
+    if want_cpu:
+        out["cpu_baseline"] = cpu_result
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -26,9 +26,10 @@ int mmd_profiler_destroy(mmd_profiler_t p);
  * of a period is bracketed iff (i / window) % stride == 0 -- `window` consecutive launches (e.g. every stream chunk of two
  * consecutive steps) out of every window * stride, so that the overlap of concurrent launches can be read off the intervals. */
 int mmd_profiler_create_windowed(mmd_profiler_t* out, int max_launches, int stride, int window, int period);
-/* Kinds of bracketed launches: the UNet forward, and the fused DDPM-step + guide kernel of a guided / an unguided step (the
- * step kernels of the same steps as the UNet launches are bracketed). */
-enum { MMD_PROF_UNET = 0, MMD_PROF_STEP_GUIDED = 1, MMD_PROF_STEP_PLAIN = 2 };
+/* Kinds of bracketed launches: the UNet forward alone (MMD_PROF_UNET), the UNet forward with an unguided DDPM step fused into
+ * its tail (MMD_PROF_UNET_FUSED: posterior mean + Philox noise + hard conditioning ride in the same launch), and the DDPM-step
+ * kernel of a guided / an unguided step (the step kernels of the same steps as the UNet launches are bracketed). */
+enum { MMD_PROF_UNET = 0, MMD_PROF_STEP_GUIDED = 1, MMD_PROF_STEP_PLAIN = 2, MMD_PROF_UNET_FUSED = 3 };
 /* After synchronising the stream(s), BEFORE mmd_profiler_read: [start, end] of every bracketed launch of `kind` in ms since
  * the first bracket (one clock across streams), up to `cap` intervals. */
 int mmd_profiler_intervals(mmd_profiler_t p, int kind, double* start_ms, double* end_ms, int cap, int* n_out);
@@ -43,6 +44,10 @@ int mmd_profiler_read(mmd_profiler_t p, double* mean_ms, int* n_launches);
 double mmd_unet_flops_per_trajectory(void);
 double mmd_unet_mfma_flops_per_trajectory(void);
 double mmd_unet_f16x2_flops_per_trajectory(void);
+
+/* How many concurrent stream chunks mmd_p_sample_loop splits a batch into for this n_streams setting (the load-time
+ * MMD_AMD_STREAMS override included): what a measurement needs to know the launch shape. */
+int mmd_sampler_stream_chunks(int n_streams, int n_robots, int samples_per_robot);
 
 /* mmd_unet_forward with the profiler attached (what mmd_p_sample_loop does internally when desc.profiler is set). */
 int mmd_unet_forward_profiled(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj,

@@ -106,6 +106,7 @@ _DEBUG_SIGNATURES = {
                                          C.POINTER(C.c_int)]),
     "mmd_profiler_destroy": (C.c_int, [C.c_void_p]),
     "mmd_profiler_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "mmd_sampler_stream_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mmd_unet_flops_per_trajectory": (C.c_double, []),
     "mmd_unet_mfma_flops_per_trajectory": (C.c_double, []),
     "mmd_unet_f16x2_flops_per_trajectory": (C.c_double, []),
@@ -143,6 +144,19 @@ def check(rc):
 def current_stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def launch(name, on, *args):
+    """Call entry point `name`, whose LAST parameter is the stream, on the GPU that owns tensor `on`: that device is made
+    current for the call (the library's own streams, events and kernel launches follow hip's current device) and ITS current
+    stream is passed -- so a call on tensors of cuda:1 while cuda:0 is torch's current device lands on cuda:1, with the
+    model handle / workspace the host layer resolved for cuda:1 (TemporalUnet.handle / .workspace key on the same device)."""
+    import torch
+    dev = on.device
+    if dev.type != "cuda":
+        raise ValueError(f"{name}: tensors must live on a CUDA(HIP) device, got {dev}")
+    with torch.cuda.device(dev):
+        check(getattr(load(), name)(*args, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
 
 def require_gpu(t, name="tensor"):

@@ -99,7 +99,7 @@ def soft_constraints_from_paths(paths: torch.Tensor, robot0: int, n_local: int, 
     gso = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
     gw = torch.empty(n_local, dtype=torch.float32, device=dev)
     rgo = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
-    _lib.check(lib.mmd_soft_constraints_from_paths(_lib.require_gpu(paths, "paths"), n_all, robot0, n_local, H,
+    _lib.launch("mmd_soft_constraints_from_paths", paths, _lib.require_gpu(paths, "paths"), n_all, robot0, n_local, H,
                                                    float(radius), float(weight), ell.data_ptr(), gso.data_ptr(),
-                                                   gw.data_ptr(), rgo.data_ptr(), _lib.current_stream_ptr()))
+                                                   gw.data_ptr(), rgo.data_ptr())
     return ell, gso, gw, rgo, float(radius)

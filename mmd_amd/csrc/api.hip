@@ -30,14 +30,27 @@ void set_error(const char* fmt, ...) {
 }
 
 constexpr int kMaxChunks = 4;
-// MMD_AMD_STREAMS=<n>: A/B override of mmd_sampler_desc.n_streams for tools/gpu_streams.sh, sampled ONCE at load time -- the
-// sampling entry points themselves never touch the environment
-// measurement override (A/B of the fused unguided step), sampled once when the library is loaded
+// Measurement overrides, sampled ONCE when the library is loaded -- the sampling entry points themselves never touch the
+// environment.  MMD_AMD_NO_FUSED_STEP=1: unguided steps run as step-kernel launches instead of inside the UNet launch's tail
+// (A/B of the fused step).  MMD_AMD_STREAMS=<n>: overrides mmd_sampler_desc.n_streams (tools/gpu_streams.sh).
 static const bool kEnvNoFusedStep = [] { const char* e = getenv("MMD_AMD_NO_FUSED_STEP"); return e && atoi(e) != 0; }();
 static const int kEnvStreams = [] {
   const char* e = getenv("MMD_AMD_STREAMS");
   return e ? atoi(e) : 0;
 }();
+
+// Number of concurrent stream chunks mmd_p_sample_loop splits n_robots x samples_per_robot trajectories into.  auto (n_streams
+// <= 0): 2 chunks once a chunk alone fills the chip (>= 1024 trajectories = one workgroup per CU): +6 .. 12 % on the 32-robot
+// round (profiles/r03b_stream_chunks.txt) -- one chunk's guided step kernel runs beside the other chunk's UNet launch, and a
+// chunk's forward no longer ends with CUs idling until its slowest workgroup is done.  Smaller batches stay whole: two
+// half-empty launches would share CUs that one leaves free.
+static int stream_chunks(int n_streams, int n_robots, int samples_per_robot) {
+  int nch = kEnvStreams > 0 ? kEnvStreams : n_streams;
+  if (nch <= 0) nch = (long long)n_robots * samples_per_robot >= 2048 ? 2 : 1;
+  if (nch > kMaxChunks) nch = kMaxChunks;
+  if (nch > n_robots) nch = n_robots;
+  return nch < 1 ? 1 : nch;
+}
 
 
 // side streams of the chunked sampling loop: created once per (thread, device), never destroyed
@@ -93,6 +106,9 @@ using namespace mmd;
 extern "C" {
 
 int mmd_abi_version(void) { return MMD_AMD_ABI_VERSION; }
+int mmd_sampler_stream_chunks(int n_streams, int n_robots, int samples_per_robot) {
+  return stream_chunks(n_streams, n_robots, samples_per_robot);
+}
 const char* mmd_last_error(void) { return g_err; }
 
 // [UNet token][eps of all n trajectories]; stream chunks use slices of the one eps block
@@ -144,14 +160,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   // Split the robots into concurrent chunks: each chunk's kernels go to its own stream, launches interleaved layer by
   // layer so both queues stay fed.  Robots are independent and the noise is keyed by the global trajectory index, so
   // results are bit-identical to the unsplit run.
-  int nch = kEnvStreams > 0 ? kEnvStreams : s->n_streams;   // (measurement override, read once when the library is loaded)
-  // auto: 2 chunks once a chunk alone fills the chip (>= 1024 trajectories = one workgroup per CU): +6 .. 12 % on the 32-robot
-  // round (profiles/r03b_stream_chunks.txt) -- one chunk's guided step kernel runs beside the other chunk's UNet launch, and a
-  // chunk's forward no longer ends with CUs idling until its slowest workgroup is done.  Smaller batches stay whole: two
-  // half-empty launches would share CUs that one leaves free.
-  if (nch <= 0) nch = n >= 2048 ? 2 : 1;
-  if (nch > kMaxChunks) nch = kMaxChunks;
-  if (nch > n_robots) nch = n_robots;
+  int nch = stream_chunks(s->n_streams, n_robots, samples_per_robot);
   Streams* S = nullptr;
   if (nch > 1) {
     S = &streams();
@@ -197,7 +206,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
     }
     for (int c = 0; c < nch && rc == 0 && !fused; ++c) {
       const int t0 = r0[c] * samples_per_robot, nc = (r0[c + 1] - r0[c]) * samples_per_robot;
-      const bool br = prof_begin((mmd_profiler_t)s->profiler, 1, MMD_PROF_STEP_GUIDED, cs[c]);
+      const bool br = prof_begin((mmd_profiler_t)s->profiler, 1, sd.do_guide ? MMD_PROF_STEP_GUIDED : MMD_PROF_STEP_PLAIN, cs[c]);
       launch_step(g, sd, x_dev, eps, noise_k, chain_k, hard_dev, t0, nc, samples_per_robot, cs[c]);
       if (br) prof_end((mmd_profiler_t)s->profiler, cs[c]);
     }

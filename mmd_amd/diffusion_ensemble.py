@@ -29,10 +29,9 @@ def apply_cross_conditioning(x: Dict[int, torch.Tensor], conditions, transforms)
     lib = _lib.load()
     for (m1, m2), (ind1, ind2) in conditions.items():
         rel, boundary = _rel_boundary(transforms, m1, m2, x[m1].shape[2])
-        _lib.check(lib.mmd_cross_condition(_lib.require_gpu(x[m1], "x[m1]"), _lib.require_gpu(x[m2], "x[m2]"),
+        _lib.launch("mmd_cross_condition", x[m1], _lib.require_gpu(x[m1], "x[m1]"), _lib.require_gpu(x[m2], "x[m2]"),
                                            int(ind1) % x[m1].shape[1], int(ind2) % x[m2].shape[1],
-                                           (C.c_float * 4)(*rel), (C.c_float * 4)(*boundary), x[m1].shape[0],
-                                           _lib.current_stream_ptr()))
+                                           (C.c_float * 4)(*rel), (C.c_float * 4)(*boundary), x[m1].shape[0])
     return x
 
 
@@ -105,9 +104,8 @@ class DiffusionsEnsemble:
             cc[c].m1, cc[c].m2, cc[c].ind1, cc[c].ind2 = pos[m1], pos[m2], int(ind1) % H, int(ind2) % H
             cc[c].rel[:], cc[c].boundary[:] = rel, boundary
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        _lib.check(lib.mmd_p_sample_loop_ensemble(tiles, K, cc, len(cross_conds), 1, B, n_diffusion_steps,
-                                                  n_diffusion_steps_without_noise, init_noise, ws.data_ptr(), ws.numel(),
-                                                  _lib.current_stream_ptr()))
+        _lib.launch("mmd_p_sample_loop_ensemble", ws, tiles, K, cc, len(cross_conds), 1, B, n_diffusion_steps,
+                                                  n_diffusion_steps_without_noise, init_noise, ws.data_ptr(), ws.numel())
         if return_chain:
             return x, {m: chains[m].transpose(0, 1) for m in keys}            # [B, steps+1, H, D] like torch.stack(dim=1)
         return x

@@ -161,12 +161,10 @@ class GaussianDiffusionModel:
         ws = self.model.workspace(B_total, device, sampler=True)
         if seed is None:
             seed = next_stream_seed(self.seed)
-        _lib.check(lib.mmd_p_sample_loop(
-            self.model.handle(self.n_diffusion_steps, device), C.byref(s), C.byref(gd) if gd is not None else None,
+        _lib.launch("mmd_p_sample_loop", x, self.model.handle(self.n_diffusion_steps, device), C.byref(s), C.byref(gd) if gd is not None else None,
             x.data_ptr(), hard.data_ptr(), n_robots, B_total // n_robots, n_diffusion_steps,
             n_diffusion_steps_without_noise, init_noise, step_noise.data_ptr() if step_noise is not None else None,
-            C.c_uint64(seed), chain.data_ptr() if chain is not None else None, ws.data_ptr(), ws.numel(),
-            _lib.current_stream_ptr()))
+            C.c_uint64(seed), chain.data_ptr() if chain is not None else None, ws.data_ptr(), ws.numel())
         if return_chain:
             return x, chain.transpose(0, 1)                      # [B, steps+1, H, D] like torch.stack(chain, dim=1)
         return x
@@ -207,11 +205,9 @@ class GaussianDiffusionModel:
         ws = self.model.workspace(B_total, device, sampler=True)
         if seed is None:
             seed = next_stream_seed(self.seed)
-        _lib.check(lib.mmd_ddim_sample(
-            self.model.handle(self.n_diffusion_steps, device), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
+        _lib.launch("mmd_ddim_sample", x, self.model.handle(self.n_diffusion_steps, device), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
             C.byref(gd) if gd is not None else None, x.data_ptr(), hard.data_ptr(), n_robots, B_total // n_robots,
-            init_noise, C.c_uint64(seed), chain.data_ptr() if chain is not None else None, ws.data_ptr(), ws.numel(),
-            _lib.current_stream_ptr()))
+            init_noise, C.c_uint64(seed), chain.data_ptr() if chain is not None else None, ws.data_ptr(), ws.numel())
         if return_chain:
             return x, chain.transpose(0, 1)
         return x
@@ -230,11 +226,10 @@ class GaussianDiffusionModel:
         ws = self.model.workspace(B_total, x.device, sampler=True)
         if seed is None:
             seed = next_stream_seed(self.seed)
-        _lib.check(_lib.load().mmd_ddpm_step(
-            self.model.handle(self.n_diffusion_steps, x.device), C.byref(s), C.byref(gd) if gd is not None else None,
+        _lib.launch("mmd_ddpm_step", x, self.model.handle(self.n_diffusion_steps, x.device), C.byref(s), C.byref(gd) if gd is not None else None,
             _lib.require_gpu(x, "x"), hard.data_ptr(), n_robots, B_total // n_robots, int(i),
             _lib.require_gpu(noise.contiguous(), "noise") if noise is not None else None, C.c_uint64(seed),
-            C.c_uint32(int(i) & 0xFFFFFFFF), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))
+            C.c_uint32(int(i) & 0xFFFFFFFF), ws.data_ptr(), ws.numel())
         return x
 
     @torch.no_grad()
@@ -282,10 +277,9 @@ class GaussianDiffusionModel:
         if x_start.ndim != 3 or x_start.shape[1] % 64 or x_start.shape[2] != self.state_dim:
             raise ValueError(f"q_sample: expected [B, K*64, {self.state_dim}], got {tuple(x_start.shape)}")
         out = torch.empty_like(x_start)
-        _lib.check(_lib.load().mmd_q_sample(
-            out.data_ptr(), _lib.require_gpu(x_start, "x_start"),
+        _lib.launch("mmd_q_sample", x_start, out.data_ptr(), _lib.require_gpu(x_start, "x_start"),
             _lib.require_gpu(noise.contiguous(), "noise") if noise is not None else None,
             float(self.sqrt_alphas_cumprod[t]), float(self.sqrt_one_minus_alphas_cumprod[t]),
             C.c_uint64(next_stream_seed(self.seed)), 0xFFFFFFFE, C.c_int64(int(traj_index_base)),
-            x_start.numel() // (64 * self.state_dim), _lib.current_stream_ptr()))
+            x_start.numel() // (64 * self.state_dim))
         return out

@@ -154,10 +154,9 @@ class GuideManagerTrajectoriesWithVelocity:
         B = x.shape[0] // self.n_robots
         if chain is not None:
             assert chain.shape == (n_steps,) + tuple(x.shape)
-        _lib.check(_lib.load().mmd_guide_steps(C.byref(d), _lib.require_gpu(x, "x"), _lib.require_gpu(hard, "hard"),
+        _lib.launch("mmd_guide_steps", x, C.byref(d), _lib.require_gpu(x, "x"), _lib.require_gpu(hard, "hard"),
                                                hard_mask, self.n_robots, B, n_steps,
-                                               _lib.require_gpu(chain, "chain") if chain is not None else None,
-                                               _lib.current_stream_ptr()))
+                                               _lib.require_gpu(chain, "chain") if chain is not None else None)
         return x
 
     def forward(self, x_normalized):

@@ -15,9 +15,8 @@ def check_rr_collisions(paths, margin=RR_MARGIN, with_midpoints=True):
     n, T = paths.shape[0], paths.shape[1]
     mask = torch.empty((T, n, n), dtype=torch.uint8, device=paths.device)
     mid = torch.empty((T, n, n, 2), dtype=torch.float32, device=paths.device) if with_midpoints else None
-    _lib.check(_lib.load().mmd_rr_collisions(_lib.require_gpu(paths.contiguous(), "paths"), n, T, float(margin),
-                                             mask.data_ptr(), mid.data_ptr() if mid is not None else None,
-                                             _lib.current_stream_ptr()))
+    _lib.launch("mmd_rr_collisions", paths, _lib.require_gpu(paths.contiguous(), "paths"), n, T, float(margin),
+                                             mask.data_ptr(), mid.data_ptr() if mid is not None else None)
     return mask.bool(), mid
 
 
@@ -26,10 +25,9 @@ def count_collisions(trajs, paths_all, robot0, n_local, margin=RR_MARGIN):
     robots -> int32 [n_local, B] number of (t, other robot) collision pairs per sample."""
     B = trajs.shape[0] // n_local
     counts = torch.empty(n_local * B, dtype=torch.int32, device=trajs.device)
-    _lib.check(_lib.load().mmd_count_collisions(_lib.require_gpu(trajs.contiguous(), "trajs"),
+    _lib.launch("mmd_count_collisions", trajs, _lib.require_gpu(trajs.contiguous(), "trajs"),
                                                 _lib.require_gpu(paths_all.contiguous(), "paths_all"), robot0, n_local,
-                                                B, paths_all.shape[0], H, float(margin), counts.data_ptr(),
-                                                _lib.current_stream_ptr()))
+                                                B, paths_all.shape[0], H, float(margin), counts.data_ptr())
     return counts.view(n_local, B)
 
 

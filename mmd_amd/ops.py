@@ -54,8 +54,8 @@ def unet_forward(x: torch.Tensor, t: int, n_timesteps: int, unet: int) -> torch.
     model = _get(unet, "unet")
     out = torch.empty_like(x)
     ws = model.workspace(x.shape[0], x.device)
-    _lib.check(_lib.load().mmd_unet_forward(model.handle(n_timesteps, x.device), x.data_ptr(), int(t), out.data_ptr(), x.shape[0],
-                                            ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))
+    _lib.launch("mmd_unet_forward", x, model.handle(n_timesteps, x.device), x.data_ptr(), int(t), out.data_ptr(), x.shape[0],
+                                            ws.data_ptr(), ws.numel())
     return out
 
 
@@ -71,9 +71,8 @@ def guide_steps(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, n_steps: in
     _check_traj(x)
     g = _get(guide, "guide")
     d = g.desc()
-    _lib.check(_lib.load().mmd_guide_steps(C.byref(d), x.data_ptr(), _lib.require_gpu(hard, "hard"), int(hard_mask),
-                                           g.n_robots, x.shape[0] // g.n_robots, int(n_steps), None,
-                                           _lib.current_stream_ptr()))
+    _lib.launch("mmd_guide_steps", x, C.byref(d), x.data_ptr(), _lib.require_gpu(hard, "hard"), int(hard_mask),
+                                           g.n_robots, x.shape[0] // g.n_robots, int(n_steps), None)
 
 
 # ---- p_sample_loop -------------------------------------------------------------------------------------------------
@@ -98,12 +97,10 @@ def p_sample_loop(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: in
     if step_noise is not None and tuple(step_noise.shape) != (n_total,) + tuple(x.shape):
         raise RuntimeError("mmd_amd::p_sample_loop: step_noise must be [n_steps_total, n_traj, 64, 4]")
     ws = m.model.workspace(x.shape[0], x.device, sampler=True)
-    _lib.check(_lib.load().mmd_p_sample_loop(
-        m.model.handle(m.n_diffusion_steps, x.device), C.byref(s), C.byref(gd) if gd is not None else None, x.data_ptr(),
+    _lib.launch("mmd_p_sample_loop", x, m.model.handle(m.n_diffusion_steps, x.device), C.byref(s), C.byref(gd) if gd is not None else None, x.data_ptr(),
         _lib.require_gpu(hard, "hard"), int(n_robots), x.shape[0] // int(n_robots), int(n_steps), int(n_steps_without_noise),
         int(bool(init_noise)), _lib.require_gpu(step_noise, "step_noise") if step_noise is not None else None,
-        C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), chain.data_ptr() if return_chain else None, ws.data_ptr(), ws.numel(),
-        _lib.current_stream_ptr()))
+        C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), chain.data_ptr() if return_chain else None, ws.data_ptr(), ws.numel())
     return chain
 
 
@@ -131,11 +128,10 @@ def ddim_sample(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: int,
     chain = (torch.empty((len(times),) + tuple(x.shape), dtype=torch.float32, device=x.device) if return_chain
              else torch.empty(0, dtype=torch.float32, device=x.device))
     ws = m.model.workspace(x.shape[0], x.device, sampler=True)
-    _lib.check(_lib.load().mmd_ddim_sample(
-        m.model.handle(m.n_diffusion_steps, x.device), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
+    _lib.launch("mmd_ddim_sample", x, m.model.handle(m.n_diffusion_steps, x.device), C.byref(s), acp.ctypes.data, times.ctypes.data, len(times),
         C.byref(gd) if gd is not None else None, x.data_ptr(), _lib.require_gpu(hard, "hard"), int(n_robots),
         x.shape[0] // int(n_robots), int(bool(init_noise)), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
-        chain.data_ptr() if return_chain else None, ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))
+        chain.data_ptr() if return_chain else None, ws.data_ptr(), ws.numel())
     return chain
 
 

@@ -66,13 +66,11 @@ def postprocess_batch(guide, trajs, n_robots=1, num_interpolation=5, margin=ROBO
     alpha = interpolation_alphas(num_interpolation)
     sav = _savgol_dev(h, dev, window_size, poly_order) if smooth else None
     fp = C.POINTER(C.c_float)
-    _lib.check(_lib.load().mmd_postprocess_trajs(
-        C.byref(desc), _lib.require_gpu(trajs, "trajs"), n_robots, n // n_robots, h, num_interpolation,
+    _lib.launch("mmd_postprocess_trajs", trajs, C.byref(desc), _lib.require_gpu(trajs, "trajs"), n_robots, n // n_robots, h, num_interpolation,
         alpha.ctypes.data_as(fp), float(margin), (C.c_float * 2)(*Q_MIN), (C.c_float * 2)(*Q_MAX), int(bool(all_free)),
         sav.data_ptr() if sav is not None else None, window_size,      # rows of the operator are zero beyond +-window
         r.waypoint_collisions.data_ptr() if r.waypoint_collisions is not None else None, r.free_mask.data_ptr(),
-        r.path_length.data_ptr(), r.smoothness.data_ptr(), r.smoothed.data_ptr() if smooth else None,
-        _lib.current_stream_ptr()))
+        r.path_length.data_ptr(), r.smoothness.data_ptr(), r.smoothed.data_ptr() if smooth else None)
     return r
 
 
@@ -82,11 +80,10 @@ def select_best(free_mask, n_robots, cost_a=None, cost_b=None, counts=None):
     dev = free_mask.device
     idx = torch.empty(n_robots, dtype=torch.int32, device=dev)
     n_free = torch.empty(n_robots, dtype=torch.int32, device=dev)
-    _lib.check(_lib.load().mmd_select_best(
-        free_mask.data_ptr(), cost_a.data_ptr() if cost_a is not None else None,
+    _lib.launch("mmd_select_best", free_mask, free_mask.data_ptr(), cost_a.data_ptr() if cost_a is not None else None,
         cost_b.data_ptr() if cost_b is not None else None,
         counts.contiguous().data_ptr() if counts is not None else None, n_robots, n // n_robots, idx.data_ptr(),
-        n_free.data_ptr(), _lib.current_stream_ptr()))
+        n_free.data_ptr())
     return idx, n_free
 
 
@@ -115,11 +112,10 @@ def compute_collision(points, guide, margin=None, map_index=0):
     flat = pts.reshape(-1, pts.shape[-1])
     out = torch.empty(flat.shape[0], dtype=torch.uint8, device=pts.device)
     desc = guide.desc() if hasattr(guide, "desc") else guide
-    _lib.check(_lib.load().mmd_points_collision(C.byref(desc), _lib.require_gpu(flat, "points"), flat.shape[0],
+    _lib.launch("mmd_points_collision", flat, C.byref(desc), _lib.require_gpu(flat, "points"), flat.shape[0],
                                                 flat.shape[1], map_index,
                                                 float(getattr(guide, "margin", desc.margin) if margin is None else margin),
-                                                out.data_ptr(),
-                                                _lib.current_stream_ptr()))
+                                                out.data_ptr())
     return out.bool().view(pts.shape[:-1])
 
 
@@ -127,8 +123,8 @@ def compute_variance_waypoints(trajs):
     """trajectory/metrics.py:17-27 for a [B,L,4] batch on the GPU."""
     trajs = trajs.contiguous()
     var_t = torch.empty(trajs.shape[1], dtype=torch.float32, device=trajs.device)
-    _lib.check(_lib.load().mmd_variance_waypoints(_lib.require_gpu(trajs, "trajs"), trajs.shape[0], trajs.shape[1],
-                                                  var_t.data_ptr(), _lib.current_stream_ptr()))
+    _lib.launch("mmd_variance_waypoints", trajs, _lib.require_gpu(trajs, "trajs"), trajs.shape[0], trajs.shape[1],
+                                                  var_t.data_ptr())
     return var_t.sum()
 
 

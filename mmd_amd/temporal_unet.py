@@ -16,6 +16,7 @@ from .unet_spec import UNET_DIM_MULTS, unet_param_spec   # noqa: F401
 # the same number of diffusion steps and the same device shares ONE device model: one packed weight blob + one
 # time-embedding table.  The cache holds weak references: the device model is freed when its last user goes away.
 _DEVICE_MODELS = weakref.WeakValueDictionary()
+MAX_WORKSPACES = 8                   # scratch buffers a TemporalUnet keeps: one per (device, stream), least recently used dropped
 N_DEVICE_MODELS_CREATED = 0          # number of mmd_unet_create calls made by this process (tests / constructor reports)
 
 
@@ -119,10 +120,12 @@ class TemporalUnet:
         dev = self._device_index(device)
         nbytes = (lib.mmd_sampler_workspace_bytes if sampler else lib.mmd_unet_workspace_bytes)(self.handle(device=dev), n_traj)
         key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", dev))
-            self._ws[key] = ws
+        self._ws[key] = ws                       # (re-inserted: most recently used last)
+        while len(self._ws) > MAX_WORKSPACES:    # streams come and go: keep the buffers of the most recent ones only
+            self._ws.pop(next(iter(self._ws)))
         return ws
 
     # ---- forward ----------------------------------------------------------------------------------------------
@@ -135,8 +138,8 @@ class TemporalUnet:
         x = x.contiguous()
         out = torch.empty_like(x)
         ws = self.workspace(x.shape[0], x.device)
-        _lib.check(_lib.load().mmd_unet_forward(self.handle(device=x.device), _lib.require_gpu(x, "x"), t, out.data_ptr(), x.shape[0],
-                                                ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()))
+        _lib.launch("mmd_unet_forward", x, self.handle(device=x.device), _lib.require_gpu(x, "x"), t, out.data_ptr(), x.shape[0],
+                                                ws.data_ptr(), ws.numel())
         return out
 
     __call__ = forward

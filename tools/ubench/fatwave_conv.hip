@@ -100,11 +100,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 acc[4][2];
   for (int s = 0; s < 4; ++s) for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
   rd_zero_halo<G128>(slab);
-  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
-                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  int woff[2] = {(2 * wave) * G128::FRAGS5 * 64 + lane, (2 * wave + 1) * G128::FRAGS5 * 64 + lane};
   __syncthreads();
   for (int k = 0; k < nconv; ++k) {
-    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    // (per-conv pointers, as in the kernel: no address hoisting out of the loop; the barrier sits on the OFFSETS so that the
+    // loads stay global_load -- behind an opaque pointer they become flat_load, which also counts on lgkmcnt)
+    asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
+    const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + woff[0], reinterpret_cast<const u32x4*>(p.w) + woff[1]};
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
     u32x4 ring[3][2][2];
     // chunk-major step order: sequence index q = 5 kc + tap reads weight step tap KC + kc
@@ -173,11 +175,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 acc[4][2];
   for (int s = 0; s < 4; ++s) for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
   rd_zero_halo<G128>(slab);
-  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
-                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  int woff[2] = {(2 * wave) * G128::FRAGS5 * 64 + lane, (2 * wave + 1) * G128::FRAGS5 * 64 + lane};
   __syncthreads();
   for (int k = 0; k < nconv; ++k) {
-    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    // (per-conv pointers, as in the kernel: no address hoisting out of the loop; the barrier sits on the OFFSETS so that the
+    // loads stay global_load -- behind an opaque pointer they become flat_load, which also counts on lgkmcnt)
+    asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
+    const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + woff[0], reinterpret_cast<const u32x4*>(p.w) + woff[1]};
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
     u32x4 ring[3][2][2];
     rd_ring_load<G128, 2, 3>(ring, wp);
@@ -192,6 +196,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 constexpr int SAMPLES_PER_WG = 4;
+#elif defined(M32)
+// downs.2's 128 -> 128 conv on v_mfma_f32_32x32x16_f16 (unet.hip: rm_taps / rm_gn_mish / rm_store; M tile = sample pair, N tile =
+// the wave's 32 channels, K step = 16 channels): the same loop as `base`, with parts switched off by -DM32=<mask> like -DPARTS
+// (1 MFMAs, 2 A fragments from the LDS, 4 weight fragments, 8 epilogue, 16 slab store, 32 barriers; 63 = everything).
+template <class GEO, int MT, int RD>
+__device__ __forceinline__ void rm_taps_parts(f32x16 (&acc)[MT], const char* va, const u32x4* w, u32x4 (&b)[RD][2]) {
+  constexpr int KS = RmGeo<GEO>::KS, STEPS = 5 * KS;
+  u32x4 a[2][MT][2];
+  if (M32 & 2) rm_load_a<GEO, MT>(a[0], va, 0, 0);
+  else for (int i = 0; i < 2; ++i) for (int j = 0; j < MT; ++j) for (int q = 0; q < 2; ++q) a[i][j][q] = u32x4{1u, 2u, 3u, 4u};
+  MMD_PIN_LOADS();
+#pragma unroll
+  for (int tap = 0; tap < 5; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int st = tap * KS + ks, ri = st % RD, cur = st & 1;
+      const bool zero = st == 0, last_ks = ks + 1 == KS;
+      if (M32 & 2) rm_load_a<GEO, MT>(a[cur ^ 1], va, last_ks ? tap + 1 : tap, last_ks ? 0 : ks + 1);
+      MMD_PIN_LOADS();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (M32 & 1) {
+          if (zero) vw_three<true>(acc[mt], a[cur][mt], b[ri]);
+          else vw_three<false>(acc[mt], a[cur][mt], b[ri]);
+        } else {
+          const unsigned x = a[cur][mt][0][0] ^ a[cur][mt][1][3] ^ b[ri][0][1] ^ b[ri][1][2];
+          acc[mt][0] += __builtin_bit_cast(float, (x & 0x007fffffu) | 0x3f800000u) * 1e-9f;
+        }
+      }
+      if ((M32 & 4) && st + RD < STEPS) rm_load_b(b[ri], w, st + RD);
+      MMD_PIN_LOADS();
+    }
+}
+#ifndef M32_RD
+#define M32_RD 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
+  __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = 32 * wave + (lane & 31);
+  char* const slab = reinterpret_cast<char*>(lds);
+  const char* const va = slab + rm_lane_a<G128>(lane);
+  int vs[2];
+  rm_lane_s<G128>(vs, wave, lane);
+  f32x16 acc[2];
+  for (int m = 0; m < 2; ++m) for (int i = 0; i < 16; ++i) acc[m][i] = 0.01f * ((threadIdx.x * 7 + m * 3 + i + blockIdx.x) % 97) - 0.5f;
+  rd_zero_halo<G128>(slab);
+  int woff = wave * RmGeo<G128>::FRAGS5 * 64 + lane;
+  __syncthreads();
+  const float one4[4] = {1.f, 1.f, 1.f, 1.f};
+  for (int k = 0; k < nconv; ++k) {
+    asm volatile("" : "+v"(woff));
+    const u32x4* wp = reinterpret_cast<const u32x4*>(p.w) + woff;
+    const Epi<1> e = epi_load<1>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c);
+    u32x4 ring[M32_RD][2];
+    rm_ring_load<M32_RD>(ring, wp);
+    if (M32 & 16) rm_store<G128, 2>(slab, vs, acc);
+    if (M32 & 32) __syncthreads();
+    rm_taps_parts<G128, 2, M32_RD>(acc, va, wp, ring);
+    if (M32 & 8) {
+      const float tb = e.tb[0];
+      rm_gn_mish<2, true>(acc, e.b[0], e.g[0], e.be[0], e.is[0], one4, act_scale(1.f), [&](int, int) { return tb; });
+    }
+    if (M32 & 32) __syncthreads();
+  }
+  float s = 0.f;
+  for (int m = 0; m < 2; ++m) s += acc[m][0] + acc[m][3] + acc[m][9] + acc[m][15];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+constexpr int SAMPLES_PER_WG = 4;
 #elif !defined(FAT)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
   __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
@@ -203,11 +277,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 acc[4][2];
   for (int s = 0; s < 4; ++s) for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
   rd_zero_halo<G128>(slab);
-  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
-                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  int woff[2] = {(2 * wave) * G128::FRAGS5 * 64 + lane, (2 * wave + 1) * G128::FRAGS5 * 64 + lane};
   __syncthreads();
   for (int k = 0; k < nconv; ++k) {
-    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    // (per-conv pointers, as in the kernel: no address hoisting out of the loop; the barrier sits on the OFFSETS so that the
+    // loads stay global_load -- behind an opaque pointer they become flat_load, which also counts on lgkmcnt)
+    asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
+    const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + woff[0], reinterpret_cast<const u32x4*>(p.w) + woff[1]};
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
     u32x4 ring[3][2][2];
     rd_ring_load<G128, 2, 3>(ring, wp);
@@ -343,14 +419,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   rd_zero_halo<G128>(slabA);
   rd_zero_halo<G128>(slabB);
-  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
-                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  int woff[2] = {(2 * wave) * G128::FRAGS5 * 64 + lane, (2 * wave + 1) * G128::FRAGS5 * 64 + lane};
   __syncthreads();
   rd_store2<G128>(slabA + vs_off, accA);
   __syncthreads();
   MicroState S;
   for (int k = 0; k < nconv; ++k) {
-    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    // (per-conv pointers, as in the kernel: no address hoisting out of the loop; the barrier sits on the OFFSETS so that the
+    // loads stay global_load -- behind an opaque pointer they become flat_load, which also counts on lgkmcnt)
+    asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
+    const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + woff[0], reinterpret_cast<const u32x4*>(p.w) + woff[1]};
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
     {
       u32x4 ring[3][2][2];
@@ -475,14 +553,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   rd_zero_halo<G128>(slabA);
   rd_zero_halo<G128>(slabB);
-  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
-                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  int woff[2] = {(2 * wave) * G128::FRAGS5 * 64 + lane, (2 * wave + 1) * G128::FRAGS5 * 64 + lane};
   __syncthreads();
   rd_store2<G128>(slabA + vs_off, accA);
   __syncthreads();
   EpiState S;
   for (int k = 0; k < nconv; ++k) {
-    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    // (per-conv pointers, as in the kernel: no address hoisting out of the loop; the barrier sits on the OFFSETS so that the
+    // loads stay global_load -- behind an opaque pointer they become flat_load, which also counts on lgkmcnt)
+    asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
+    const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + woff[0], reinterpret_cast<const u32x4*>(p.w) + woff[1]};
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
     {
       u32x4 ring[3][2][2];
@@ -536,13 +616,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   rd_zero_halo<G128>(slabA);
   rd_zero_halo<G128>(slabB);
-  const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave) * G128::FRAGS5 * 64 + lane,
-                        reinterpret_cast<const u32x4*>(p.w) + (size_t)(2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+  int woff[2] = {(2 * wave) * G128::FRAGS5 * 64 + lane, (2 * wave + 1) * G128::FRAGS5 * 64 + lane};
   __syncthreads();
   rd_store2<G128>(slabA + vs_off, accA);
   __syncthreads();
   for (int k = 0; k < nconv; ++k) {
-    asm volatile("" : "+v"(wp[0]), "+v"(wp[1]));   // (per-conv pointers, as in the kernel: no address hoisting out of the loop)
+    // (per-conv pointers, as in the kernel: no address hoisting out of the loop; the barrier sits on the OFFSETS so that the
+    // loads stay global_load -- behind an opaque pointer they become flat_load, which also counts on lgkmcnt)
+    asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
+    const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + woff[0], reinterpret_cast<const u32x4*>(p.w) + woff[1]};
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
     {   // phase 1: taps of half A; epilogue + slab store of half B (its previous conv)
       u32x4 ring[3][2][2];

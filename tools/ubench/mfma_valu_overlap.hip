@@ -11,24 +11,37 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // -DF16MFMA: the MFMA role issues v_mfma_f32_16x16x32_f16 (the matrix core proper; 16 cycles) instead of v_mfma_f32_16x16x4_f32
 // (32 cycles, fp32 at the vector rate)
-#ifdef F16MFMA
+// -DF16MFMA32: v_mfma_f32_32x32x16_f16 (8 passes = 32 cycles, 16 accumulator registers; 4 accumulators x 4 per iteration)
+#if defined(F16MFMA32)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define ACC_T f32x16
+#define NACC 4
+#define ACC_ZERO(x) for (int q_ = 0; q_ < 16; ++q_) x[q_] = 0.f
+#define MFMA_OP(acc) __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0)
+#define MFMA_DECL f16x8 ah, bh; for (int q = 0; q < 8; ++q) { ah[q] = (_Float16)(1.0f + threadIdx.x * 1e-3f); bh[q] = (_Float16)0.5f; }
+#elif defined(F16MFMA)
 #define MFMA_OP(acc) __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0)
 #define MFMA_DECL f16x8 ah, bh; for (int q = 0; q < 8; ++q) { ah[q] = (_Float16)(1.0f + threadIdx.x * 1e-3f); bh[q] = (_Float16)0.5f; }
 #else
 #define MFMA_OP(acc) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0)
 #define MFMA_DECL
 #endif
+#ifndef ACC_T
+#define ACC_T f32x4
+#define NACC 16
+#define ACC_ZERO(x) x = f32x4{0.f, 0.f, 0.f, 0.f}
+#endif
 
 __device__ __forceinline__ void run_mfma(int iters, float* out) {
-  f32x4 m[16];
-  for (int i = 0; i < 16; ++i) m[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ACC_T m[NACC];
+  for (int i = 0; i < NACC; ++i) ACC_ZERO(m[i]);
   float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
   (void)a; (void)b;
   MFMA_DECL
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      m[i] = MFMA_OP(m[i]);
+      m[i % NACC] = MFMA_OP(m[i % NACC]);
 #ifdef MFMA_NOP
       // yield the issue port while the matrix pipe is busy: does the other wave's VALU stream get the cycles?
       __builtin_amdgcn_sched_barrier(0);
@@ -38,7 +51,7 @@ __device__ __forceinline__ void run_mfma(int iters, float* out) {
     }
   }
   float s = 0.f;
-  for (int i = 0; i < 16; ++i) s += m[i][0] + m[i][1] + m[i][2] + m[i][3];
+  for (int i = 0; i < NACC; ++i) s += m[i][0] + m[i][1] + m[i][2] + m[i][3];
   out[threadIdx.x] = s;
 }
 __device__ __forceinline__ void run_valu(int iters, float* out) {
@@ -106,9 +119,10 @@ __device__ __forceinline__ void run_ldsr(int iters, float* out) {   // 16 ds_rea
 // MIX: one wave interleaves NV independent v_fma_f32 after every MFMA (does VALU issue in the MFMA's shadow?)
 template <int NV>
 __device__ __forceinline__ void run_mix(int iters, float* out) {
-  f32x4 m[16];
+  ACC_T m[NACC];
   float v[16];
-  for (int i = 0; i < 16; ++i) { m[i] = f32x4{0.f, 0.f, 0.f, 0.f}; v[i] = threadIdx.x * 1e-3f + i; }
+  for (int i = 0; i < NACC; ++i) ACC_ZERO(m[i]);
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 1e-3f + i;
   float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
   (void)a; (void)b;
   MFMA_DECL
@@ -116,7 +130,7 @@ __device__ __forceinline__ void run_mix(int iters, float* out) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      m[i] = MFMA_OP(m[i]);
+      m[i % NACC] = MFMA_OP(m[i % NACC]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[(i * NV + j) & 15] = __builtin_fmaf(v[(i * NV + j) & 15], c, d);
@@ -124,7 +138,8 @@ __device__ __forceinline__ void run_mix(int iters, float* out) {
     }
   }
   float s = 0.f;
-  for (int i = 0; i < 16; ++i) s += m[i][0] + m[i][1] + m[i][2] + m[i][3] + v[i];
+  for (int i = 0; i < NACC; ++i) s += m[i][0] + m[i][1] + m[i][2] + m[i][3];
+  for (int i = 0; i < 16; ++i) s += v[i];
   out[threadIdx.x] = s;
 }
 

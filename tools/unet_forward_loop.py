@@ -1,7 +1,9 @@
 """N back-to-back TemporalUnet forwards of n trajectories (the body of the PMC / A-B passes).  MMD_AMD_LIB selects the
-.so.  Usage: python tools/unet_forward_loop.py [n_traj ...]   -> per n: mean unet_kernel time by HIP events."""
+.so.  Usage: python tools/unet_forward_loop.py [n_traj ...]   -> per n: mean unet_kernel time by HIP events.  REPS=<n>: launches
+per size (30); SECS=<s>: keep launching for about s seconds instead (power / throttle sampling sessions)."""
 import os
 import sys
+import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mmd_amd import _lib, synth
@@ -19,12 +21,21 @@ for n in [int(a) for a in sys.argv[1:]] or [2048]:
         unet(x, 50)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    secs = float(os.environ.get("SECS", "0"))
+    t0, done = time.perf_counter(), 0
     e0.record()
-    for _ in range(reps):
-        unet(x, 50)
+    while True:
+        for _ in range(reps):
+            unet(x, 50)
+        done += reps
+        if secs <= 0:
+            break
+        torch.cuda.synchronize()                 # (bounds the launch queue; one sync per `reps` launches)
+        if time.perf_counter() - t0 >= secs:
+            break
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / reps * 1e3
+    us = e0.elapsed_time(e1) / done * 1e3
     fl, mf = lib.mmd_unet_flops_per_trajectory() * n, lib.mmd_unet_mfma_flops_per_trajectory() * n
     hf = lib.mmd_unet_f16x2_flops_per_trajectory() * n
     busy_us = ((mf - hf) / 157.3e12 + 3.0 * hf / 2516.6e12) * 1e6      # MFMA issue time at the spec clock (bench.py's accounting)
