@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -60,63 +61,77 @@ constexpr int LDS_SLOTS_MAX = 144;
 // max(d2, tiny) and d * m = 0 instead of 0 * inf = NaN.
 __device__ __forceinline__ float rsq_pos(float d2) { return __builtin_amdgcn_rsqf(fmaxf(d2, 1e-30f)); }
 
-template <int UNROLL>
-__device__ __forceinline__ void cons_accumulate(const float4* tab, int n, int t, float px, float py, float& gx,
-                                                float& gy) {
-  float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
-  int s = 0;
-#pragma unroll UNROLL
-  for (; s + 1 < n; s += 2) {
-    const float4 c0 = tab[s * H + t], c1 = tab[(s + 1) * H + t];
-    const float dx0 = px - c0.x, dy0 = py - c0.y, dx1 = px - c1.x, dy1 = py - c1.y;
-    const float d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
-    const float m0 = (d0 > c0.w) ? 0.f : rsq_pos(d0);
-    const float m1 = (d1 > c1.w) ? 0.f : rsq_pos(d1);
-    ax -= dx0 * m0; ay -= dy0 * m0;
-    bx -= dx1 * m1; by -= dy1 * m1;
+// The slot sum of a constraint group is DEFINED as four interleaved partial sums -- accumulator k takes the group's slots k, k + 4,
+// k + 8, ... (slot index relative to the group's first slot) in increasing order, each term one explicit fma -- combined as
+// (A0 + A1) + (A2 + A3).  The one-wave-per-trajectory kernel evaluates that tree with four accumulators; the cooperative kernel
+// (four waves per trajectory, wave k owns accumulator k) produces the very same bits, so a robot's samples do not depend on
+// which of the two a launch size selects (the multi-GPU shards stay bitwise equal to the one-GPU run).  (x, y) pairs run on
+// packed fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma): 8 instead of 12 VALU instructions per slot and lane.
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+struct Acc4 { f32x2g a0, a1, a2, a3; };
+__device__ __forceinline__ Acc4 acc4_zero() {
+  const f32x2g z = {0.f, 0.f};
+  return Acc4{z, z, z, z};
+}
+__device__ __forceinline__ f32x2g acc4_total(const Acc4& r) { return (r.a0 + r.a1) + (r.a2 + r.a3); }
+// a <- a - d m,  d = p - q,  m = [||d||^2 <= R|R|] / ||d||   (one slot, one lane)
+__device__ __forceinline__ f32x2g cons_term(f32x2g a, f32x2g p, f32x2g q, float r2) {
+  const f32x2g d = p - q, sq = d * d;
+  const float d2 = sq.x + sq.y;
+  const float m = (d2 > r2) ? 0.f : rsq_pos(d2);
+  return __builtin_elementwise_fma(-d, f32x2g{m, m}, a);
+}
+// one table entry as (q, R|R|): the general table holds (qx, qy, R, R|R|) (R < 0: empty, R|R| < 0 <= d2), the compact on-chip
+// table (qx, qy) with one radius for every active point and "no point" stored as (1e30, 1e30): dist^2 = inf > R^2
+template <bool COMPACT> struct ConsTab;
+template <> struct ConsTab<false> {
+  const float4* tab;
+  float r2;
+  __device__ __forceinline__ f32x2g add(f32x2g a, f32x2g p, int slot, int t) const {
+    const float4 c = tab[slot * H + t];
+    return cons_term(a, p, f32x2g{c.x, c.y}, c.w);
   }
-  if (s < n) {
-    const float4 c0 = tab[s * H + t];
-    const float dx0 = px - c0.x, dy0 = py - c0.y;
-    const float d0 = dx0 * dx0 + dy0 * dy0;
-    const float m0 = (d0 > c0.w) ? 0.f : rsq_pos(d0);
-    ax -= dx0 * m0; ay -= dy0 * m0;
+};
+template <> struct ConsTab<true> {
+  const float2* tab;
+  float r2;
+  __device__ __forceinline__ f32x2g add(f32x2g a, f32x2g p, int slot, int t) const {
+    const float2 c = tab[slot * H + t];
+    return cons_term(a, p, f32x2g{c.x, c.y}, r2);
   }
-  gx += ax + bx;
-  gy += ay + by;
+};
+// accumulator (rel + i) & 3 += slot (first + i) of `tab` for i in [0, n): rel = the first slot's index relative to its group
+template <class TAB>
+__device__ __forceinline__ void cons_accumulate4(Acc4& acc, const TAB& tab, int first, int n, int rel, int t, f32x2g p) {
+  auto one = [&](int k, int slot) {                          // (k is wave-uniform: scalar branches)
+    if (k == 0) acc.a0 = tab.add(acc.a0, p, slot, t);
+    else if (k == 1) acc.a1 = tab.add(acc.a1, p, slot, t);
+    else if (k == 2) acc.a2 = tab.add(acc.a2, p, slot, t);
+    else acc.a3 = tab.add(acc.a3, p, slot, t);
+  };
+  int i = 0;
+  for (; i < n && ((rel + i) & 3); ++i) one((rel + i) & 3, first + i);   // up to the next multiple of four
+#pragma unroll 2
+  for (; i + 3 < n; i += 4) {
+    acc.a0 = tab.add(acc.a0, p, first + i, t);
+    acc.a1 = tab.add(acc.a1, p, first + i + 1, t);
+    acc.a2 = tab.add(acc.a2, p, first + i + 2, t);
+    acc.a3 = tab.add(acc.a3, p, first + i + 3, t);
+  }
+  for (int k = 0; i < n; ++i, ++k) one(k, first + i);         // the last 1 .. 3 slots: accumulators 0, 1, 2
+}
+// ... the slots of ONE accumulator (wave `k` of the cooperative kernel): first + j for the j in [0, n) with (rel + j) & 3 == k
+template <class TAB>
+__device__ __forceinline__ f32x2g cons_accumulate1(f32x2g a, const TAB& tab, int first, int n, int rel, int k, int t, f32x2g p) {
+#pragma unroll 4
+  for (int j = (k - rel) & 3; j < n; j += 4) a = tab.add(a, p, first + j, t);
+  return a;
 }
 
-// the same sum over a compact on-chip table of (qx, qy) with one radius for every active point; "no point" is stored
-// as (1e30, 1e30): dist^2 = inf > R^2 and dx * 0 = -0, i.e. exactly the 0 the general path adds
-template <int UNROLL>
-__device__ __forceinline__ void cons_accumulate_xy(const float2* tab, int n, int t, float px, float py, float r2,
-                                                   float& gx, float& gy) {
-  float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
-  int s = 0;
-#pragma unroll UNROLL
-  for (; s + 1 < n; s += 2) {
-    const float2 c0 = tab[s * H + t], c1 = tab[(s + 1) * H + t];
-    const float dx0 = px - c0.x, dy0 = py - c0.y, dx1 = px - c1.x, dy1 = py - c1.y;
-    const float d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
-    const float m0 = (d0 > r2) ? 0.f : rsq_pos(d0);
-    const float m1 = (d1 > r2) ? 0.f : rsq_pos(d1);
-    ax -= dx0 * m0; ay -= dy0 * m0;
-    bx -= dx1 * m1; by -= dy1 * m1;
-  }
-  if (s < n) {
-    const float2 c0 = tab[s * H + t];
-    const float dx0 = px - c0.x, dy0 = py - c0.y;
-    const float d0 = dx0 * dx0 + dy0 * dy0;
-    const float m0 = (d0 > r2) ? 0.f : rsq_pos(d0);
-    ax -= dx0 * m0; ay -= dy0 * m0;
-  }
-  gx += ax + bx;
-  gy += ay + by;
-}
-
-template <bool COMPACT>
+// group_sum(grp, p) = the slot sum of constraint group grp at the lane's position p (the canonical four-accumulator tree above)
+template <class GROUPSUM>
 __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t, const float4* __restrict__ grid,
-                                             int grp0, int grp1, const float4* lds_cons, int lds_slot0, int lds_n) {
+                                             int grp0, int grp1, GROUPSUM group_sum) {
   // LimitsNormalizer.unnormalize (normalization.py:157-168), clip applied unconditionally
   float xu[4];
   const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
@@ -173,24 +188,13 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
     gpx = g.w_smooth * (sc * gx); gpy = g.w_smooth * (sc * gy);
     gpz = g.w_smooth * (sc * gz); gpw = g.w_smooth * (sc * gw);
   }
-  // --- CostConstraint groups: LDS-resident slots first, any overflow straight from the L2-resident table
+  // --- CostConstraint groups (cost_functions.py:297-326): per group the slot sum, its own clip and weight
   float cx = 0.f, cy = 0.f;
   for (int grp = grp0; grp < grp1; ++grp) {
-    const int s0 = g.grp_slot_off[grp], s1 = g.grp_slot_off[grp + 1];
-    float gx = 0.f, gy = 0.f;
-    const int l0 = min(max(s0 - lds_slot0, 0), lds_n), l1 = min(max(s1 - lds_slot0, 0), lds_n);   // LDS part
-    if (l1 > l0) {
-      if constexpr (COMPACT)
-        cons_accumulate_xy<4>(reinterpret_cast<const float2*>(lds_cons) + (size_t)l0 * H, l1 - l0, t, px, py, g.uniform_r2,
-                              gx, gy);
-      else
-        cons_accumulate<4>(lds_cons + (size_t)l0 * H, l1 - l0, t, px, py, gx, gy);
-    }
-    const int g0 = lds_n > 0 ? max(s0, lds_slot0 + lds_n) : s0;                                    // global part
-    if (s1 > g0) cons_accumulate<4>(g.cons + (size_t)g0 * H, s1 - g0, t, px, py, gx, gy);
-    const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
+    const f32x2g gs = group_sum(grp, f32x2g{px, py});
+    const float sc = clip_scale(gs.x, gs.y, 0.f, 0.f, g.max_norm);
     const float w = g.grp_weight[grp];
-    cx += w * (sc * gx); cy += w * (sc * gy);
+    cx += w * (sc * gs.x); cy += w * (sc * gs.y);
   }
   // --- CostCollision over the SDF grids: d/dp max_k relu(margin - sdf_k(p))  (t >= 1; field_factor.py range [1,None])
   float ox, oy;
@@ -237,8 +241,8 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
     const int rb0 = traj_b / samples_per_robot;
     const int rb1 = min(traj_b + WPB - 1, s.traj_end - 1) / samples_per_robot;
     if (rb0 == rb1) {
-      lds_slot0 = g.grp_slot_off[g.robot_grp_off[rb0]];
-      lds_n = min(g.grp_slot_off[g.robot_grp_off[rb0 + 1]] - lds_slot0, lds_slots);
+      lds_slot0 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[g.robot_grp_off[rb0]]);
+      lds_n = min(__builtin_amdgcn_readfirstlane(g.grp_slot_off[g.robot_grp_off[rb0 + 1]]) - lds_slot0, lds_slots);
       const float4* src = g.cons + (size_t)lds_slot0 * H;
       if constexpr (COMPACT) {
         float2* dst = reinterpret_cast<float2*>(lds_cons);
@@ -268,9 +272,29 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
     const int map = g.robot_map ? g.robot_map[robot] : 0;
     const float4* grid = g.grids + (size_t)map * g.n_grids * g.nx * g.ny;
     int grp0 = 0, grp1 = 0;
-    if (g.robot_grp_off) { grp0 = g.robot_grp_off[robot]; grp1 = g.robot_grp_off[robot + 1]; }
+    if (g.robot_grp_off) {
+      grp0 = __builtin_amdgcn_readfirstlane(g.robot_grp_off[robot]);
+      grp1 = __builtin_amdgcn_readfirstlane(g.robot_grp_off[robot + 1]);
+    }
+    // the group's slots: LDS-resident ones first, any overflow straight from the L2-resident table
+    auto group_sum = [&](int grp, f32x2g p) {
+      // (group bounds are the same for the whole wave: scalar registers, scalar loop control)
+      const int s0 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp]), s1 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp + 1]);
+      const int l0 = min(max(s0 - lds_slot0, 0), lds_n), l1 = min(max(s1 - lds_slot0, 0), lds_n);   // LDS part
+      Acc4 acc = acc4_zero();
+      if (l1 > l0) {
+        if constexpr (COMPACT)
+          cons_accumulate4(acc, ConsTab<true>{reinterpret_cast<const float2*>(lds_cons), g.uniform_r2}, l0, l1 - l0,
+                           lds_slot0 + l0 - s0, t, p);
+        else
+          cons_accumulate4(acc, ConsTab<false>{lds_cons, 0.f}, l0, l1 - l0, lds_slot0 + l0 - s0, t, p);
+      }
+      const int g0 = lds_n > 0 ? max(s0, lds_slot0 + lds_n) : s0;                                    // global part
+      if (s1 > g0) cons_accumulate4(acc, ConsTab<false>{g.cons, 0.f}, g0, s1 - g0, g0 - s0, t, p);
+      return acc4_total(acc);
+    };
     for (int it = 0; it < s.n_guide_steps; ++it) {
-      const float4 gr = guide_grad<COMPACT>(g, v, t, grid, grp0, grp1, lds_cons, lds_slot0, lds_n);
+      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, group_sum);
       v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w;
       if (is_start) v = hs;
       if (is_goal) v = hg;
@@ -278,6 +302,90 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
     }
   }
 
+  if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx), s.sigma, s.noise_std_extra);
+  if (is_start) v = hs;
+  if (is_goal) v = hg;
+  x[idx] = v;
+  if (chain) chain[idx] = v;
+}
+
+// The same step with FOUR waves per trajectory (small launches: <= 512 trajectories leave most SIMDs without a wave, and a
+// wave's 20 dependent guide iterations of ~600 instructions are pure latency).  Every wave carries the whole trajectory (lane =
+// support point) and computes everything but the constraint sums redundantly -- identical instructions, identical bits, so the
+// four copies of v never diverge; wave k evaluates accumulator k of every group's slot sum (a quarter of the slots), the four
+// partials meet in LDS (one barrier per group and iteration, double-buffered by parity) and every wave combines them in the
+// canonical order.  Wave 0 stores.  Bitwise equal to ddpm_guide_kernel.
+constexpr int COOP_XCH_BYTES = 2 * 4 * H * 8;
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDev s, int lds_slots, float4* __restrict__ x,
+                                                              const float4* __restrict__ eps, const float4* __restrict__ noise,
+                                                              float4* __restrict__ chain, const float4* __restrict__ hard,
+                                                              int samples_per_robot) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds_cons[];
+  const int t = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int traj = s.traj0 + blockIdx.x;                   // (the grid is exactly the launch's trajectories)
+  const int robot = traj / samples_per_robot;
+  float2* const xch = reinterpret_cast<float2*>(reinterpret_cast<char*>(lds_cons) + (size_t)lds_slots * H * (COMPACT ? 8 : 16));
+  int lds_slot0 = 0, lds_n = 0;
+  if (s.do_guide && g.robot_grp_off) {
+    lds_slot0 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[g.robot_grp_off[robot]]);
+    lds_n = min(__builtin_amdgcn_readfirstlane(g.grp_slot_off[g.robot_grp_off[robot + 1]]) - lds_slot0, lds_slots);
+    const float4* src = g.cons + (size_t)lds_slot0 * H;
+    if constexpr (COMPACT) {
+      float2* dst = reinterpret_cast<float2*>(lds_cons);
+      for (int i = threadIdx.x; i < lds_n * H; i += 256) {
+        const float4 c = src[i];
+        dst[i] = c.z < 0.f ? make_float2(1e30f, 1e30f) : make_float2(c.x, c.y);
+      }
+    } else {
+      for (int i = threadIdx.x; i < lds_n * H; i += 256) lds_cons[i] = src[i];
+    }
+  }
+  __syncthreads();
+  const size_t idx = (size_t)traj * H + t;
+  float4 v = x[idx];
+  if (s.do_model) v = s.ddim ? ddim_update(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2) : ddpm_posterior_mean(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2);
+  const float4 hs = hard[robot * 2 + 0], hg = hard[robot * 2 + 1];
+  const bool is_start = (s.hard_mask & 1) && t == 0;
+  const bool is_goal = (s.hard_mask & 2) && t == H - 1;
+  if (s.do_guide) {
+    const int map = g.robot_map ? g.robot_map[robot] : 0;
+    const float4* grid = g.grids + (size_t)map * g.n_grids * g.nx * g.ny;
+    int grp0 = 0, grp1 = 0;
+    if (g.robot_grp_off) {
+      grp0 = __builtin_amdgcn_readfirstlane(g.robot_grp_off[robot]);
+      grp1 = __builtin_amdgcn_readfirstlane(g.robot_grp_off[robot + 1]);
+    }
+    int parity = 0;
+    auto group_sum = [&](int grp, f32x2g p) {
+      const int s0 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp]), s1 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp + 1]);
+      const int l0 = min(max(s0 - lds_slot0, 0), lds_n), l1 = min(max(s1 - lds_slot0, 0), lds_n);
+      f32x2g a = {0.f, 0.f};
+      if (l1 > l0) {
+        if constexpr (COMPACT)
+          a = cons_accumulate1(a, ConsTab<true>{reinterpret_cast<const float2*>(lds_cons), g.uniform_r2}, l0, l1 - l0,
+                               lds_slot0 + l0 - s0, wave, t, p);
+        else
+          a = cons_accumulate1(a, ConsTab<false>{lds_cons, 0.f}, l0, l1 - l0, lds_slot0 + l0 - s0, wave, t, p);
+      }
+      const int g0 = lds_n > 0 ? max(s0, lds_slot0 + lds_n) : s0;
+      if (s1 > g0) a = cons_accumulate1(a, ConsTab<false>{g.cons, 0.f}, g0, s1 - g0, g0 - s0, wave, t, p);
+      float2* const slot = xch + parity * 4 * H;
+      slot[wave * H + t] = make_float2(a.x, a.y);
+      __syncthreads();                                       // (the buffer of the other parity is free again: every wave has
+      parity ^= 1;                                           //  passed the barrier after reading it)
+      const float2 q0 = slot[t], q1 = slot[H + t], q2 = slot[2 * H + t], q3 = slot[3 * H + t];
+      return acc4_total(Acc4{f32x2g{q0.x, q0.y}, f32x2g{q1.x, q1.y}, f32x2g{q2.x, q2.y}, f32x2g{q3.x, q3.y}});
+    };
+    for (int it = 0; it < s.n_guide_steps; ++it) {
+      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, group_sum);
+      v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w;
+      if (is_start) v = hs;
+      if (is_goal) v = hg;
+      if (s.guide_chain && wave == 0) s.guide_chain[(size_t)it * s.guide_chain_stride + idx] = v;
+    }
+  }
+  if (wave != 0) return;
   if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx), s.sigma, s.noise_std_extra);
   if (is_start) v = hs;
   if (is_goal) v = hg;
@@ -380,6 +488,13 @@ int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
   return 0;
 }
 
+// MMD_AMD_GUIDE_COOP_MAX=<n>: A/B override of the launch size up to which a guided step runs four waves per trajectory (0: never),
+// sampled once at load time; not an interface
+static const int kCoopMaxTraj = [] {
+  const char* e = getenv("MMD_AMD_GUIDE_COOP_MAX");
+  return e ? atoi(e) : 512;
+}();
+
 int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
                 const float* hard, int traj0, int n_traj, int spr, hipStream_t st) {
   s.traj0 = traj0;
@@ -393,7 +508,15 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
     hipLaunchKernelGGL(kern, dim3((n_traj + wpb - 1) / wpb), dim3(wpb * 64), (size_t)slots * bytes_per_slot, st, g, s, slots,
                        (float4*)x, (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
   };
-  if (guided && g.max_slots > small && spr % 8 == 0 && traj0 % 8 == 0) {
+  if (guided && n_traj <= kCoopMaxTraj) {
+    // four waves per trajectory (ddpm_guide_coop_kernel): the whole table of the trajectory's robot in LDS up to 60 KiB (+ the
+    // exchange buffer: inside the 64 KiB a launch gets without an opt-in), the rest from L2
+    const int fit = 60 * 1024 / bytes_per_slot;
+    const int slots = g.max_slots < fit ? g.max_slots : fit;
+    auto kern = compact ? ddpm_guide_coop_kernel<true> : ddpm_guide_coop_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(n_traj), dim3(256), (size_t)slots * bytes_per_slot + COOP_XCH_BYTES, st, g, s, slots, (float4*)x,
+                       (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
+  } else if (guided && g.max_slots > small && spr % 8 == 0 && traj0 % 8 == 0) {
     // 8 trajectories of one robot per workgroup (2048 trajectories = 256 workgroups = one per CU); LDS sized to the
     // largest table any robot can have (g.max_slots), the rest of a larger table is read from L2
     const int slots = g.max_slots < big ? g.max_slots : big;

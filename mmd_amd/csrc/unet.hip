@@ -104,6 +104,19 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <bool ACT = false>
 __device__ __forceinline__ f32x2_t gn_mish2(f32x2_t x, const GnCoef& c, f32x2_t addend, const ActScale& as = ActScale{}) {
   constexpr float LOG2E = 1.44269504088896341f;
+#ifdef MMD_GN_SCALAR   // (A/B build: the same arithmetic as plain fp32 VALU ops -- next to another wave's MFMA stream a v_pk_* issues
+                       // once per MFMA, a plain VALU op every ~10 cycles: tools/ubench/mfma_valu_overlap.hip)
+  f32x2_t out;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float yl = fmaf(x[i], c.sa, c.sb);
+    const float e = __builtin_amdgcn_exp2f(fminf(yl, 20.f * LOG2E));
+    const float n = e * (e + 2.f);
+    const float den = fmaf(n, ACT ? as.l2e : LOG2E, ACT ? as.l2e2 : 2.f * LOG2E);
+    out[i] = fmaf(yl, n * __builtin_amdgcn_rcpf(den), addend[i]);
+  }
+  return out;
+#endif
   const f32x2_t sa = {c.sa, c.sa}, sb = {c.sb, c.sb}, two = {2.f, 2.f};
   const f32x2_t yl = __builtin_elementwise_fma(x, sa, sb);
   const f32x2_t e = {__builtin_amdgcn_exp2f(fminf(yl.x, 20.f * LOG2E)), __builtin_amdgcn_exp2f(fminf(yl.y, 20.f * LOG2E))};

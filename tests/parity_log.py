@@ -1,5 +1,5 @@
 """Collects the measured HIP-vs-reference / HIP-vs-oracle errors of the -m gpu parity tests and writes them as one JSON
-artifact at session end (gpurun_out/r03_parity.json on the GPU box; copied to profiles/ and committed): per case and
+artifact at session end (gpurun_out/r04_parity.json on the GPU box; copied to profiles/ and committed): per case and
 chain row the error, the reference's own sensitivity `sens` to a relative 1e-6 UNet perturbation (stored in the golden
 fixtures by tools/make_golden.py), their ratio and the bound that was asserted."""
 import json
@@ -26,7 +26,7 @@ def flush():
         return None
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r03_parity.json")
+    path = os.path.join(out_dir, "r04_parity.json")
     summary = {}
     for r in _RECORDS:
         s = summary.setdefault(r["test"], {"n": 0, "max_err": 0.0, "max_err_over_sens": None})

@@ -1,5 +1,9 @@
 """-m gpu: BASELINE.json's five configs as concrete synthetic inputs, each run end to end through the
-product classes on one GPU and checked through domain properties (+ a teacher-forced oracle step for one robot)."""
+product classes on one GPU and checked through domain properties, plus teacher-forced guided steps against the oracle: at the
+short schedule (T = 25) inside the sampled chain, and at BASELINE's full size (B = 64, T = 100: 384 / 640 / 512 trajectories for
+configs 2, 3 and the per-GPU shard of config 5 -- both sides of the unet_kernel<2> / <4> launch threshold) on >= 4
+trajectories each.  Bound everywhere: the north-star 1e-3, or 1.5 x the oracle's own response to a rounding-sized perturbation
+of eps where that is larger (gpu_common.teacher_forced_guided_step)."""
 from math import ceil
 
 import numpy as np
@@ -25,6 +29,76 @@ def _check_hard_conds(s, trajs):
     assert torch.isfinite(trajs).all()
     assert torch.equal(trajs[:, 0], s.hard_conds[0].repeat_interleave(B, 0))
     assert torch.equal(trajs[:, -1], s.hard_conds[H - 1].repeat_interleave(B, 0))
+
+
+def _chain_step_vs_oracle(tag, sd, tb, chain, k, sl, hc, i, guide, noise):
+    """Chain row k -> k + 1 of the sampled batch slice `sl`, per trajectory, against the oracle restarted from row k."""
+    import parity_log
+    for j in range(sl.start, sl.stop):
+        xi = chain[k, j:j + 1]
+        step = lambda pert=None: O.apply_hard_conditioning(                                   # noqa: E731
+            O.ddpm_sample_step(sd, tb, xi.clone(), hc, i, guide=guide, n_guide_steps=20, t_start_guide=13,
+                               noise=noise[j - sl.start:j - sl.start + 1], noise_std_extra=0.5, eps_rel_perturb=pert), hc)
+        ref = step()
+        err = rel_l2(chain[k + 1, j:j + 1], ref)
+        gen = torch.Generator().manual_seed(2000 + j)
+        sens = max(rel_l2(step(2e-6 * torch.randn(xi.shape, generator=gen)), ref) for _ in range(8))
+        bound = max(1e-3, 1.5 * sens)
+        parity_log.record("config_chain_step_teacher_forced", f"{tag}_traj{j}", i, err, sens=sens, bound=bound)
+        assert err < bound, (tag, j, err, sens)
+
+
+def _picks(n_robots, robot0, n_local, B, seed, n=4):
+    """n (global robot, sample) pairs from >= min(n, n_local) different local robots."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    robots = rng.choice(n_local, size=min(n, n_local), replace=False)
+    return [(robot0 + int(r), int(rng.integers(B))) for r in robots]
+
+
+def test_config2_full_size_guided_step_vs_oracle():
+    """configs[1] at BASELINE size: 6 robots x B = 64 = 384 trajectories (unet_kernel<2>), T = 100, Empty map, no inter-robot
+    term; one guided step at i = 49 (the first guided one) and one at i = 10, 4 trajectories each, vs the oracle."""
+    import gpu_common
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    s = _sampler(6, "EnvEmpty2D", starts, goals, T=100, B=64)
+    s.set_other_paths(None)
+    for i, seeds in ((49, (110, 111)), (10, (112, 113))):
+        gpu_common.teacher_forced_guided_step("config_fullsize_guided_step", f"config2_i{i}", s, 100, starts, goals, "EnvEmpty2D",
+                                              _picks(6, 0, 6, 64, 31 + i), i, seeds)
+
+
+def test_config3_full_size_guided_step_vs_oracle():
+    """configs[2] at BASELINE size: 10 robots x 64 = 640 trajectories (unet_kernel<4>), T = 100, Highways map, every robot
+    soft-constrained by the other nine (9 x 63 points); 4 trajectories of 4 robots vs the oracle."""
+    import gpu_common
+    starts, goals = synth.start_goal_circle(10, 0.45)
+    paths_np = synth.straight_line_paths(starts, goals, H)
+    s = _sampler(10, "EnvHighways2D", starts, goals, T=100, B=64)
+    s.set_other_paths(torch.from_numpy(paths_np).cuda())
+    gpu_common.teacher_forced_guided_step("config_fullsize_guided_step", "config3_i49", s, 100, starts, goals, "EnvHighways2D",
+                                          _picks(10, 0, 10, 64, 41), 49, (114, 115), paths_np=paths_np)
+
+
+def test_config5_full_size_shard_guided_step_vs_oracle():
+    """configs[4] at BASELINE size, the per-GPU shard: rank 5 of 8 owns robots 40 .. 47 of the 64-robot Conveyor instance = 512
+    trajectories (the largest unet_kernel<2> launch), each robot soft-constrained by the other 63 (63 x 63 points); 4 trajectories
+    of 4 local robots vs the oracle, and the shard's sampled rows equal the unsharded run's bitwise in the production noise path
+    at T = 100 (the 1024-trajectory unsharded launch runs unet_kernel<4>: the two kernels agree bit for bit)."""
+    import gpu_common
+    starts, goals = synth.start_goal_boundary(64)
+    paths_np = synth.straight_line_paths(starts, goals, H)
+    paths = torch.from_numpy(paths_np).cuda()
+    shard = _sampler(64, "EnvConveyor2D", starts, goals, T=100, B=64, rank=5, world_size=8)
+    shard.set_other_paths(paths)
+    assert (shard.robot0, shard.n_local) == (40, 8)
+    gpu_common.teacher_forced_guided_step("config_fullsize_guided_step", "config5_rank5_i49", shard, 100, starts, goals,
+                                          "EnvConveyor2D", _picks(64, 40, 8, 64, 51), 49, (116, 117), paths_np=paths_np)
+    b = shard.sample(seed=77)
+    _check_hard_conds(shard, b)
+    pair = _sampler(64, "EnvConveyor2D", starts, goals, T=100, B=64, rank=2, world_size=4)      # robots 32 .. 47: 1024 trajectories
+    pair.set_other_paths(paths)
+    a = pair.sample(seed=77)
+    assert torch.equal(a[8 * 64:], b)
 
 
 def test_config1_single_robot_mpd_b1_t50():
@@ -55,10 +129,8 @@ def test_config2_six_robots_empty_no_interrobot_term():
     r, k = 4, 14                                             # chain row k -> k+1 is loop index i = 24 - k = 10 (guided)
     sl = slice(r * 16, (r + 1) * 16)
     hc = cases.hard_conds_for(starts[r], goals[r])
-    ref = O.ddpm_sample_step(sd, tb, chain[k, sl].clone(), hc, 24 - k, guide=lambda x: O.guide_grad(x, gp, [], clip_mode="always"),
-                             n_guide_steps=20, t_start_guide=13, noise=st[k, sl], noise_std_extra=0.5)
-    ref = O.apply_hard_conditioning(ref, hc)
-    assert rel_l2(chain[k + 1, sl], ref) < 2e-3
+    _chain_step_vs_oracle("config2_T25", sd, tb, chain, k, sl, hc, 24 - k, lambda x: O.guide_grad(x, gp, [], clip_mode="always"),
+                          st[k, sl])
 
 
 def test_config3_ten_robots_highways_with_soft_constraints():
@@ -80,10 +152,8 @@ def test_config3_ten_robots_highways_with_soft_constraints():
     sl = slice(r * 8, (r + 1) * 8)
     hc = cases.hard_conds_for(starts[r], goals[r])
     grp = cases.soft_group(paths_np, r)
-    ref = O.ddpm_sample_step(sd, tb, chain[k, sl].clone(), hc, 24 - k, guide=lambda x: O.guide_grad(x, gp, [grp], clip_mode="always"),
-                             n_guide_steps=20, t_start_guide=13, noise=st[k, sl], noise_std_extra=0.5)
-    ref = O.apply_hard_conditioning(ref, hc)
-    assert rel_l2(chain[k + 1, sl], ref) < 2e-3
+    _chain_step_vs_oracle("config3_T25", sd, tb, chain, k, sl, hc, 24 - k, lambda x: O.guide_grad(x, gp, [grp], clip_mode="always"),
+                          st[k, sl])
     # the device-side pick + conflict mask run on the result
     from mmd_amd.multi_agent import check_rr_collisions
     best = s.best_paths(chain[-1].cuda(), paths)

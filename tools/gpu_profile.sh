@@ -9,7 +9,7 @@ TAG=${1:-r03}
 OUT=gpurun_out
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -25 | tee $OUT/${TAG}_pytest_gpu.log
-cp $OUT/r03_parity.json $OUT/${TAG}_parity.json 2>/dev/null
+cp $OUT/r04_parity.json $OUT/${TAG}_parity.json 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/${TAG}_smoke.log
 # PMC first: bench.py quotes profiles/pmc_latest.json for `traffic` / `mfma_busy_pmc` (copied there after the session)
 REPS=8 tools/gpu_pmc.sh ${TAG}_unet1024 unet_kernel -- python tools/unet_forward_loop.py 1024 > /dev/null

@@ -19,6 +19,8 @@ Fixtures:
   g12_boundary.npz     outer-boundary contract: check_rr_collisions / compute_collision on the shapes CBS / PP pass
   g13_split_constraints.npz  MPDEnsemble.split_cost_constraints_to_tasks + the per-tile range / transform shift
   g14_extra_objects.npz      a map with extra objects (spheres + boxes): guide, extra-objects-only guide, occupancy
+  g15_distribution_*.npz     guided sampling over 32 noise seeds: final rows of every sample, their position mean / covariance per
+                             support point, free / collision split and soft-constraint violation counts (distribution-level parity)
 """
 import os
 import sys
@@ -595,11 +597,65 @@ def g14():
                         coll_idxs=coll_idxs.reshape(-1).numpy())
 
 
+N_DIST_SEEDS = int(os.environ.get("MMD_DIST_SEEDS", "32"))
+
+
+def violation_counts(pos, cons):
+    """pos [n,H,2] un-normalised final positions; cons: the case's (q, t_range, radius, soft) groups.  Per trajectory: number of
+    (constraint point, support point) pairs inside the radius at an active time (t0 <= t < t1, cost_functions.py:305)."""
+    out = np.zeros(pos.shape[0], np.int64)
+    for (q, tr, r, soft) in cons:
+        for k in range(len(q)):
+            t0, t1 = int(tr[k][0]), int(tr[k][1])
+            d = np.linalg.norm(pos[:, t0:t1].astype(np.float64) - np.asarray(q[k], np.float64)[None, None], axis=-1)
+            out += (d < float(r[k])).sum(1)
+    return out
+
+
+def g15():
+    """Distribution-level parity: the guided sampler is chaotic end to end, so beside the per-step teacher-forced
+    statement the reference's OUTPUT DISTRIBUTION is pinned: for the 32-robot north-star shape (empty32_T25) and the Highways
+    case with soft + hard constraints (highways_T100), N_DIST_SEEDS independent noise seeds (x_T and every step's noise from
+    synth.synth_noise(base + 2 j), (base + 2 j + 1)) through the genuine reference; stored: the final normalised rows of every
+    sample, per-support-point mean / covariance of the un-normalised positions over all samples, the reference's own free /
+    collision split (PlanningTask.get_trajs_collision_and_free, tasks.py:236-311) and the soft / hard constraint violation
+    counts per trajectory (guides.py:180-226 is what keeps them low)."""
+    cases = {}
+    starts, goals = synth.start_goal_circle(32, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    q, tr, r = soft_points(paths, 5)
+    cases["empty32_T25"] = ("EnvEmpty2D", 25, 4, starts[5], goals[5], [(q, tr, r, True)], 3000)
+    starts, goals, soft, hard = highways_case()
+    cases["highways_T100"] = ("EnvHighways2D", 100, 8, starts[3], goals[3], [(*soft, True), (*hard, False)], 4000)
+    for name, (env_id, T, B, start, goal, cons, base) in cases.items():
+        finals = []
+        for j in range(N_DIST_SEEDS):
+            chain = run_ref_inference(env_id, T, B, start, goal, cons, base + 2 * j, base + 2 * j + 1)
+            finals.append(chain[-1])
+            print("   g15", name, "seed", j, flush=True)
+        finals = np.concatenate(finals, 0).astype(np.float32)                      # [N * B, H, D] normalised
+        with quiet():
+            guide, robot, task, env = make_guide(env_id, MINS, MAXS)
+        trajs = guide.dataset.unnormalize_trajectories(torch.from_numpy(finals))
+        coll, coll_idxs, free, free_idxs, wp = task.get_trajs_collision_and_free(trajs, return_indices=True)
+        pos = trajs[..., :2].numpy().astype(np.float64)
+        mean = pos.mean(0)                                                         # [H, 2]
+        dev = pos - mean[None]
+        cov = np.einsum("nhi,nhj->hij", dev, dev) / (pos.shape[0] - 1)             # [H, 2, 2]
+        free_mask = np.zeros(finals.shape[0], bool)
+        free_mask[free_idxs.numpy().reshape(-1)] = True
+        viol = violation_counts(trajs[..., :2].numpy(), cons)
+        np.savez_compressed(os.path.join(OUT, f"g15_distribution_{name}.npz"), finals=finals, pos_mean=mean, pos_cov=cov,
+                            free_mask=free_mask, violations=viol, meta=np.array([T, B, N_DIST_SEEDS, base]))
+        print("   g15", name, "free", int(free_mask.sum()), "of", finals.shape[0], "violating", int((viol > 0).sum()),
+              "pairs", int(viol.sum()), flush=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15}[name]()
     print("done")

@@ -127,26 +127,36 @@ constexpr int SAMPLES_PER_WG = 4;
 // What bounds the conv?  The base loop with parts switched off (-DPARTS=<mask>): 1 MFMAs, 2 A fragments from the LDS, 4 weight
 // fragments from L2 / L1, 8 epilogue (GroupNorm + Mish), 16 slab store, 32 the two barriers.  Loads that feed no MFMA are folded
 // into the accumulators with one xor each so that they stay.
+// -DADEPTH=<n> (default 2): the A fragments of a half step are requested n - 1 half steps ahead (n buffers of 16 registers; the
+// kernel double-buffers: is the LDS latency of one half step exposed when eight waves read at once?)
+#ifndef ADEPTH
+#define ADEPTH 2
+#endif
 template <class GEO, int NT, int MT, int RD>
 __device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2]) {
-  constexpr int KC = GEO::KC, STEPS = 5 * KC, HP = MT / 2;
-  u32x4 a[2][2][2];
-  if (PARTS & 2) rd_load_a<GEO>(a[0], va, 0, 0, 0);
-  else for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 2; ++q) a[i][j][q] = u32x4{1u, 2u, 3u, 4u};
+  constexpr int KC = GEO::KC, STEPS = 5 * KC, HP = MT / 2, HS = STEPS * HP;
+  u32x4 a[ADEPTH][2][2];
+  auto load_hs = [&](int slot, int hs) {     // half step hs = (tap, kc, hp); past the end: a valid, unused read
+    const int st = hs / HP, hp = hs % HP, tap = st / KC, kc = st % KC;
+    rd_load_a<GEO>(a[slot], va, tap, kc, hp);
+  };
+  if (PARTS & 2) {
+#pragma unroll
+    for (int i = 0; i + 1 < ADEPTH; ++i) load_hs(i, i);
+  } else {
+    for (int i = 0; i < ADEPTH; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 2; ++q) a[i][j][q] = u32x4{1u + i, 2u + j, 3u + q, 4u};
+  }
   MMD_PIN_LOADS();
 #pragma unroll
   for (int tap = 0; tap < 5; ++tap)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       const int st = tap * KC + kc, ri = st % RD;
-      const bool zero = st == 0, last_kc = kc + 1 == KC;
+      const bool zero = st == 0;
 #pragma unroll
       for (int hp = 0; hp < HP; ++hp) {
-        const int cur = (st * HP + hp) & 1;
-        if (PARTS & 2) {
-          if (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, tap, kc, hp + 1);
-          else rd_load_a<GEO>(a[cur ^ 1], va, last_kc ? tap + 1 : tap, last_kc ? 0 : kc + 1, 0);
-        }
+        const int hs = st * HP + hp, cur = hs % ADEPTH;
+        if (PARTS & 2) load_hs((hs + ADEPTH - 1) % ADEPTH, hs + ADEPTH - 1 < HS ? hs + ADEPTH - 1 : HS - 1);
         MMD_PIN_LOADS();
 #pragma unroll
         for (int sm = 0; sm < 2; ++sm)
@@ -165,6 +175,11 @@ __device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* 
       MMD_PIN_LOADS();
     }
 }
+// -DSKEW=<n>: the SECOND workgroup of a CU (blocks >= 256) starts n x 64 cycles late, so that its MFMA phases meet the first
+// one's epilogues (do the two workgroups of a CU drift into lockstep?)
+#ifndef SKEW
+#define SKEW 0
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
   __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
@@ -177,6 +192,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   rd_zero_halo<G128>(slab);
   int woff[2] = {(2 * wave) * G128::FRAGS5 * 64 + lane, (2 * wave + 1) * G128::FRAGS5 * 64 + lane};
   __syncthreads();
+  if (SKEW && blockIdx.x >= 256) {
+    for (int i = 0; i < SKEW; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   for (int k = 0; k < nconv; ++k) {
     // (per-conv pointers, as in the kernel: no address hoisting out of the loop; the barrier sits on the OFFSETS so that the
     // loads stay global_load -- behind an opaque pointer they become flat_load, which also counts on lgkmcnt)
@@ -205,7 +223,7 @@ __device__ __forceinline__ void rm_taps_parts(f32x16 (&acc)[MT], const char* va,
   constexpr int KS = RmGeo<GEO>::KS, STEPS = 5 * KS;
   u32x4 a[2][MT][2];
   if (M32 & 2) rm_load_a<GEO, MT>(a[0], va, 0, 0);
-  else for (int i = 0; i < 2; ++i) for (int j = 0; j < MT; ++j) for (int q = 0; q < 2; ++q) a[i][j][q] = u32x4{1u, 2u, 3u, 4u};
+  else for (int i = 0; i < 2; ++i) for (int j = 0; j < MT; ++j) for (int q = 0; q < 2; ++q) a[i][j][q] = u32x4{1u + i, 2u + j, 3u + q, 4u};   // (distinct per M tile: no CSE of the chains)
   MMD_PIN_LOADS();
 #pragma unroll
   for (int tap = 0; tap < 5; ++tap)
@@ -215,6 +233,21 @@ __device__ __forceinline__ void rm_taps_parts(f32x16 (&acc)[MT], const char* va,
       const bool zero = st == 0, last_ks = ks + 1 == KS;
       if (M32 & 2) rm_load_a<GEO, MT>(a[cur ^ 1], va, last_ks ? tap + 1 : tap, last_ks ? 0 : ks + 1);
       MMD_PIN_LOADS();
+#ifdef M32IL    // the two M tiles' chains interleaved: no MFMA depends on the one right before it
+      if (M32 & 1) {
+        static_assert(MT == 2, "interleave of two accumulators");
+        f32x16 c0 = acc[0], c1 = acc[1];
+        if (zero) { for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; } }
+        c0 = mfma_w(a[cur][0][1], b[ri][0], c0);
+        c1 = mfma_w(a[cur][1][1], b[ri][0], c1);
+        c0 = mfma_w(a[cur][0][0], b[ri][1], c0);
+        c1 = mfma_w(a[cur][1][0], b[ri][1], c1);
+        c0 = mfma_w(a[cur][0][0], b[ri][0], c0);
+        c1 = mfma_w(a[cur][1][0], b[ri][0], c1);
+        acc[0] = c0; acc[1] = c1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         if (M32 & 1) {
@@ -225,6 +258,7 @@ __device__ __forceinline__ void rm_taps_parts(f32x16 (&acc)[MT], const char* va,
           acc[mt][0] += __builtin_bit_cast(float, (x & 0x007fffffu) | 0x3f800000u) * 1e-9f;
         }
       }
+#endif
       if ((M32 & 4) && st + RD < STEPS) rm_load_b(b[ri], w, st + RD);
       MMD_PIN_LOADS();
     }
