@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build libmmd_amd.so for gfx950 (cross-compiles without a GPU).  Usage: ./build.sh [extra hipcc flags]
-# -fno-slp-vectorize: the SLP vectorizer pairs fp32 ops into v_pk_* and pays for it with v_mov shuffles in the MFMA loops
-# (10 extra VALU ops per Winograd k-step); packed fp32 is not faster here.
+# -fno-slp-vectorize: the SLP vectorizer pairs fp32 ops into v_pk_* wherever it can and pays for it with v_mov shuffles; the
+# kernels use packed fp32 arithmetic only where it is written out (GroupNorm + Mish epilogue, the guide's (x, y) pairs).
 set -e
 cd "$(dirname "$0")"
 mkdir -p mmd_amd/lib

@@ -65,21 +65,34 @@ __device__ __forceinline__ float rsq_pos(float d2) { return __builtin_amdgcn_rsq
 // k + 8, ... (slot index relative to the group's first slot) in increasing order, each term one explicit fma -- combined as
 // (A0 + A1) + (A2 + A3).  The one-wave-per-trajectory kernel evaluates that tree with four accumulators; the cooperative kernel
 // (four waves per trajectory, wave k owns accumulator k) produces the very same bits, so a robot's samples do not depend on
-// which of the two a launch size selects (the multi-GPU shards stay bitwise equal to the one-GPU run).  (x, y) pairs run on
-// packed fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma): 8 instead of 12 VALU instructions per slot and lane.
+// which of the two a launch size selects (the multi-GPU shards stay bitwise equal to the one-GPU run).
 typedef float f32x2g __attribute__((ext_vector_type(2)));
 struct Acc4 { f32x2g a0, a1, a2, a3; };
 __device__ __forceinline__ Acc4 acc4_zero() {
   const f32x2g z = {0.f, 0.f};
   return Acc4{z, z, z, z};
 }
-__device__ __forceinline__ f32x2g acc4_total(const Acc4& r) { return (r.a0 + r.a1) + (r.a2 + r.a3); }
-// a <- a - d m,  d = p - q,  m = [||d||^2 <= R|R|] / ||d||   (one slot, one lane)
+__device__ __forceinline__ f32x2g acc4_total(const Acc4& r) {
+  return f32x2g{(r.a0.x + r.a1.x) + (r.a2.x + r.a3.x), (r.a0.y + r.a1.y) + (r.a2.y + r.a3.y)};
+}
+// a <- a - d m,  d = p - q,  m = [||d||^2 <= R|R|] / ||d||   (one slot, one lane).  Plain fp32 VALU ops with explicit fmas (the same
+// instruction sequence in both kernels).  The packed form (v_pk_add / v_pk_mul / v_pk_fma on the (x, y) pair: 8 instead of 12
+// instructions per slot, -DMMD_GUIDE_PK) was measured and is NOT used: next to another wave's MFMA stream a v_pk_* issues once
+// per MFMA where a plain VALU op issues every ~10 cycles (tools/ubench/mfma_valu_overlap.hip), and the guided step of one stream
+// chunk runs beside the other chunk's UNet launch -- 108 instead of 83 us per launch in the loop, 86.2 k instead of 92.3 k
+// trajectories/s (profiles/r04_guide_packed_ab.txt).
 __device__ __forceinline__ f32x2g cons_term(f32x2g a, f32x2g p, f32x2g q, float r2) {
+#ifdef MMD_GUIDE_PK
   const f32x2g d = p - q, sq = d * d;
   const float d2 = sq.x + sq.y;
   const float m = (d2 > r2) ? 0.f : rsq_pos(d2);
   return __builtin_elementwise_fma(-d, f32x2g{m, m}, a);
+#else
+  const float dx = p.x - q.x, dy = p.y - q.y;
+  const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+  const float m = (d2 > r2) ? 0.f : rsq_pos(d2);
+  return f32x2g{__builtin_fmaf(-dx, m, a.x), __builtin_fmaf(-dy, m, a.y)};
+#endif
 }
 // one table entry as (q, R|R|): the general table holds (qx, qy, R, R|R|) (R < 0: empty, R|R| < 0 <= d2), the compact on-chip
 // table (qx, qy) with one radius for every active point and "no point" stored as (1e30, 1e30): dist^2 = inf > R^2

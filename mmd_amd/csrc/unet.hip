@@ -41,8 +41,8 @@ enum { RES_NONE = 0, RES_IDENT = 1, RES_CONV = 2 };
 // final Conv1dBlock(32->32, k5) + Conv1d(32->4, k1) of the network
 struct FinalArgs {
   float* out;             // eps [n, 64, 4]
-  const uint4* w_bf;      // f16x2 pack of the k5 conv (interleaved column pairs)
-  const float* isc;       // [32] inverse channel scales of w_bf
+  const uint4* w5;        // f16x2 pack of the k5 conv (interleaved column pairs)
+  const float* isc;       // [32] inverse channel scales of w5
   const float* bias;      // [32]
   const float* gamma;     // [32] GroupNorm weight
   const float* beta;      // [32] GroupNorm bias
@@ -129,7 +129,7 @@ __device__ __forceinline__ f32x2_t gn_mish2(f32x2_t x, const GnCoef& c, f32x2_t 
 
 // Dynamic f16x2 input scale of a conv whose input is NOT bounded by a GroupNorm (the input of a ResidualTemporalBlock: the
 // residual stream, which follows the magnitude of the network input): per sample, from the exact maximum M of the conv's
-// input tile, s = 2^(10 - floor(log2 M)), so that every value |x| s < 2048 (< 30720 with Winograd's factor 15, rounds 1-2) fits fp16 whatever
+// input tile, s = 2^(10 - floor(log2 M)), so that every value |x| s < 2048 fits fp16 whatever
 // the input's magnitude, and the values that matter (within 2^-13 of the maximum) keep both pieces normal.  inv = 1 / s.
 struct DynScale { float s, inv; };
 __device__ __forceinline__ DynScale dyn_scale(float M) {
@@ -335,15 +335,9 @@ __device__ __forceinline__ void vb_three(f32x4& x, const u32x4 (&a)[2], const u3
 
 // ----------------------------------------------------------------------------------------------------------------
 // DIRECT f16x2 convolutions on a row-form slab (downs.1, downs.2 + mid blocks, ups.0; the wave-private stages use the same
-// GEMM loop on per-wave slabs).  In the Winograd F(4,5) form of rounds 1-2 these convs were bound by the weight stream (a
-// workgroup re-uses a weight fragment on 16 GEMM rows; the vector-memory path of a CU delivers 64 B/clk), not by the matrix
-// pipe, which at the fp16 rate idled 80 % of a Winograd conv.  The direct form trades 2.5 x the MFMAs (5 taps instead of 8
-// Winograd positions per 4 outputs) for
-//   * 5 / 8 of the weight bytes, every fragment re-used on 64 GEMM rows (a wave's unit is 1-2 n-tiles x the FOUR M tiles
-//     = samples of the workgroup),
-//   * no position phases: ONE slab store and one barrier pair per conv instead of two stores and four barriers, no input /
-//     output transforms (~250 VALU per conv and lane), 8 accumulator streams (32-64 registers),
-//   * direct-convolution accuracy (0.8e-6 instead of 1.9e-6 of the forward against fp64).
+// GEMM loop on per-wave slabs).  Every weight fragment is re-used on 64 GEMM rows (a wave's unit is 1-2 n-tiles x the FOUR M
+// tiles = samples of the workgroup), a conv is ONE slab store and one barrier pair, 8 accumulator streams (32-64 registers).
+// (DESIGN.md section 3.1 has the history: the transform-domain forms of rounds 1-2 were bound by their weight stream.)
 // GEMM: M tile s = sample s, row i = position; the taps of a k = 5 conv are row-shifted views of the slab
 //     Rd[piece][lane group j][chunk kc][row = 20 s + 2 + position][8 channels]   (fp16, 2-row zero halo per sample)
 // (channel block kc + KC j, KC = C / 32: the four blocks of a K = 32 chunk lie G = a multiple of 256 B apart, so a b128 A
@@ -1872,7 +1866,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   TR(trb + 5);
   // ---- final block: Conv1dBlock(32 -> 32, k5) + GroupNorm + Mish, then the 1x1 conv 32 -> 4 (N padded to one n-tile)
   {
-    const u32x4* wf[2] = {wptr(f.w_bf, GF::FRAGS5, 0), wptr(f.w_bf, GF::FRAGS5, 1)};
+    const u32x4* wf[2] = {wptr(f.w5, GF::FRAGS5, 0), wptr(f.w5, GF::FRAGS5, 1)};
     rd_ring_load<GF, 2, 5>(ring5, wf);
     const u32x4* w1[1] = {reinterpret_cast<const u32x4*>(f.w1_bf) + lane};
     u32x4 ring1[1][1][2];
@@ -2560,7 +2554,7 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.c[3] = args_chain(u, set, kU0, 1, &u->up[0], nullptr, t, n);
   a.c[4] = args_chain(u, set, kU1, 1, &u->up[1], nullptr, t, n);
   a.fin.out = eps;
-  a.fin.w_bf = reinterpret_cast<const uint4*>(u->blob + u->fin.wbf);
+  a.fin.w5 = reinterpret_cast<const uint4*>(u->blob + u->fin.wbf);
   a.fin.isc = u->blob + u->fin.isc;
   a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
   a.fin.act = u->fin_act;

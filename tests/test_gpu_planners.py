@@ -65,7 +65,6 @@ def test_ensemble_two_tiles_golden():
         errs = [rel_l2(got[r], ref[r]) for r in range(ref.shape[0])]
         # rows 0 .. T - t_start_guide are unguided (well conditioned): they calibrate the kernel's per-step deviation `lin`
         lin, bounds = chaos_bounds(errs, [float(v) for v in sens], T - ceil(0.5 * T) + 1)
-        import cases
         assert lin < cases.LIN, (m, lin)
         for r in range(ref.shape[0]):
             err, bound = errs[r], bounds[r]
