@@ -374,14 +374,14 @@ __device__ __forceinline__ void rd_load_b(u32x4 (&b)[NT][2], const u32x4* const 
 #pragma unroll
     for (int q = 0; q < 2; ++q) b[t][q] = w[t][(step * 2 + q) * 64];
 }
-// A fragments of one sample PAIR (M tiles 2 hp, 2 hp + 1) at slab-row offset rowoff, chunk kc
-template <class GEO>
-__device__ __forceinline__ void rd_load_a(u32x4 (&a)[2][2], const char* va, int rowoff, int kc, int hp) {
+// A fragments of one sample PAIR (M tiles 2 hp, 2 hp + 1; SM = 1: of the single M tile) at slab-row offset rowoff, chunk kc
+template <class GEO, int SM = 2>
+__device__ __forceinline__ void rd_load_a(u32x4 (&a)[SM][2], const char* va, int rowoff, int kc, int hp) {
 #pragma unroll
-  for (int sm = 0; sm < 2; ++sm)
+  for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      a[sm][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + (GEO::tile_row(2 * hp + sm) + rowoff) * 16);
+      a[sm][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + (GEO::tile_row(SM * hp + sm) + rowoff) * 16);
 }
 constexpr int RD_RD = 2;                    // weight ring depth in steps
 #ifndef MMD_D2_RD
@@ -409,11 +409,12 @@ __device__ __forceinline__ void rd_ring_load(u32x4 (&b)[RD][NT][2], const u32x4*
 template <class GEO, int NT, int TAP0, int TAPS, bool FRESH, bool RES, int MT = 4, int RD = RD_RD>
 __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][NT], const char* va, const u32x4* const (&w)[NT],
                                         const u32x4* const (&wr)[NT], u32x4 (&b)[RD][NT][2]) {
-  constexpr int KC = GEO::KC, STEPS = TAPS * KC, HP = MT / 2;
-  static_assert(MT % 2 == 0, "M tiles are processed in pairs");
+  // M tiles are processed in pairs (SM = 2), or a single one (MT = 1: the half-sample waves of unet_kernel<2> at L = 32)
+  constexpr int KC = GEO::KC, STEPS = TAPS * KC, SM = MT >= 2 ? 2 : 1, HP = MT / SM;
+  static_assert(MT == 1 || MT % 2 == 0, "M tiles are processed in pairs");
   // A fragments are double-buffered by M-tile pair (half a step = 2 M tiles x NT n-tiles x 3 MFMAs): 32 registers
-  u32x4 a[2][2][2];
-  rd_load_a<GEO>(a[0], va, TAP0, 0, 0);
+  u32x4 a[2][SM][2];
+  rd_load_a<GEO, SM>(a[0], va, TAP0, 0, 0);
   // (the residual conv's weights are requested RES_LOOK steps before the centre tap's step that uses them: loaded there,
   // every one of its steps would wait for an L2 round trip; all up front, they would cost 32 registers for two taps)
   constexpr int C0 = (2 - TAP0) * KC;                        // the centre tap's first step
@@ -442,27 +443,27 @@ __device__ __forceinline__ void rd_taps(f32x4 (&acc)[MT][NT], f32x4 (&res)[MT][N
         // the next half step's A fragments (the next M-tile pair; then the next chunk, or chunk 0 of the next tap; past the
         // last step: a valid, unused read)
         const int cur = (st * HP + hp) & 1;
-        if (hp + 1 < HP) rd_load_a<GEO>(a[cur ^ 1], va, TAP0 + tap, kc, hp + 1);
-        else rd_load_a<GEO>(a[cur ^ 1], va, last_kc ? TAP0 + tap + 1 : TAP0 + tap, last_kc ? 0 : kc + 1, 0);
+        if (hp + 1 < HP) rd_load_a<GEO, SM>(a[cur ^ 1], va, TAP0 + tap, kc, hp + 1);
+        else rd_load_a<GEO, SM>(a[cur ^ 1], va, last_kc ? TAP0 + tap + 1 : TAP0 + tap, last_kc ? 0 : kc + 1, 0);
         MMD_PIN_LOADS();
-        const u32x4(&ac)[2][2] = a[cur];
+        const u32x4(&ac)[SM][2] = a[cur];
         const u32x4(&bc)[NT][2] = b[ri];
 #pragma unroll
-        for (int sm = 0; sm < 2; ++sm)
+        for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            if (zero) vb_three<true>(acc[2 * hp + sm][t], ac[sm], bc[t]);
-            else vb_three<false>(acc[2 * hp + sm][t], ac[sm], bc[t]);
+            if (zero) vb_three<true>(acc[SM * hp + sm][t], ac[sm], bc[t]);
+            else vb_three<false>(acc[SM * hp + sm][t], ac[sm], bc[t]);
           }
         if constexpr (RES) {
           if (with_res) {
 #pragma unroll
-            for (int sm = 0; sm < 2; ++sm)
+            for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
               for (int t = 0; t < NT; ++t) {
                 const u32x4(&bw)[2] = brp[kc][t];
-                if (FRESH && kc == 0) vb_three<true>(res[2 * hp + sm][t], ac[sm], bw);
-                else vb_three<false>(res[2 * hp + sm][t], ac[sm], bw);
+                if (FRESH && kc == 0) vb_three<true>(res[SM * hp + sm][t], ac[sm], bw);
+                else vb_three<false>(res[SM * hp + sm][t], ac[sm], bw);
               }
           }
         }
@@ -905,6 +906,109 @@ __device__ __forceinline__ void rw_gn_mish(f32x4 (&acc)[MT][NT], const float (&b
       }
   }
 }
+// The same for the stages whose waves are whole samples in unet_kernel<4> and HALF samples in unet_kernel<2> (downs.0, ups.1 +
+// final block): the statistics of a sample are DEFINED through its two halves (positions [0, L / 2) and [L / 2, L): HT = 1 or 2
+// M tiles each) -- per half the mean of x = acc k + bias over the group and the sum of squared deviations from THAT mean, combined
+// by the pairwise update mean = (m0 + m1) / 2, M2 = (M2_0 + M2_1) + (m1 - m0)^2 N / 4.  A whole-sample wave evaluates both halves
+// itself; two half-sample waves evaluate one each and swap (mean, M2) through LDS -- the same arithmetic, the same bits.
+struct HalfStat { float mean, m2; };
+template <int GL>
+__device__ __forceinline__ float rw_gsum(float v) {          // sum over the GL lanes of a group and the wave's four 16-lane rows
+  v = dpp_add<0xB1>(v);
+  if constexpr (GL >= 4) v = dpp_add<0x4E>(v);
+  if constexpr (GL >= 8) v = dpp_add<0x141>(v);
+  return wave_sum_rows(v);
+}
+// bsum4 = rw_gsum(sum of the lane's biases) (every channel's bias counts once per position: 4 positions per lane row and M tile)
+template <int HT, int NT, int GL, int NG>
+__device__ __forceinline__ HalfStat rw_half_stat(const f32x4 (&acc)[HT][NT], const float (&bias)[NT], const float (&k)[NT], float bsum4) {
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float st = (acc[0][t][0] + acc[0][t][1]) + (acc[0][t][2] + acc[0][t][3]);
+    if constexpr (HT == 2) st += (acc[1][t][0] + acc[1][t][1]) + (acc[1][t][2] + acc[1][t][3]);
+    v = fmaf(st, k[t], v);
+  }
+  HalfStat h;
+  h.mean = (rw_gsum<GL>(v) + bsum4 * (float)(4 * HT)) * (2.f / (float)NG);
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float dm = h.mean - bias[t];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = fmaf(acc[mt][t][r], k[t], -dm);
+        q = fmaf(d, d, q);
+      }
+  }
+  h.m2 = rw_gsum<GL>(q);
+  return h;
+}
+struct GnStat { float mean, rstd; };
+template <int NG>
+__device__ __forceinline__ GnStat gn_combine(const HalfStat& h0, const HalfStat& h1) {
+  const float dlt = h1.mean - h0.mean;
+  const float m2 = fmaf(dlt * dlt, 0.25f * (float)NG, h0.m2 + h1.m2);
+  return GnStat{0.5f * (h0.mean + h1.mean), __builtin_amdgcn_rsqf(fmaf(m2, 1.f / (float)NG, 1e-5f))};
+}
+// GroupNorm affine + Mish + add(mt, t, r) on MT tiles with the sample's statistics st
+template <int MT, int NT, bool ACT, class ADD>
+__device__ __forceinline__ void rw_gn_apply(f32x4 (&acc)[MT][NT], const float (&bias)[NT], const float (&gamma)[NT],
+                                            const float (&beta)[NT], const float (&k)[NT], const GnStat& st, const ActScale& as, ADD add) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    GnCoef cf = gn_coef(st.mean - bias[t], st.rstd, gamma[t], beta[t]);
+    cf.sa *= k[t];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const f32x2_t o = gn_mish2<ACT>(f32x2_t{acc[mt][t][r], acc[mt][t][r + 1]}, cf, f32x2_t{add(mt, t, r), add(mt, t, r + 1)}, as);
+        acc[mt][t][r] = o.x;
+        acc[mt][t][r + 1] = o.y;
+      }
+  }
+}
+// ... of a WHOLE sample held by one wave (MT = 2 HT M tiles)
+template <int MT, int NT, int GL, int NG, bool ACT, class ADD>
+__device__ __forceinline__ void rw_gn_mish_whole(f32x4 (&acc)[MT][NT], const float (&bias)[NT], const float (&gamma)[NT],
+                                                 const float (&beta)[NT], const float (&isc)[NT], float inv, const ActScale& as, ADD add) {
+  constexpr int HT = MT / 2;
+  static_assert(MT == 2 || MT == 4, "two halves of one or two M tiles");
+  float k[NT], bsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    k[t] = isc[t] * inv;
+    bsum += bias[t];
+  }
+  const float bsum4 = rw_gsum<GL>(bsum);
+  const HalfStat h0 = rw_half_stat<HT, NT, GL, NG>(reinterpret_cast<const f32x4(&)[HT][NT]>(acc[0]), bias, k, bsum4);
+  const HalfStat h1 = rw_half_stat<HT, NT, GL, NG>(reinterpret_cast<const f32x4(&)[HT][NT]>(acc[HT]), bias, k, bsum4);
+  rw_gn_apply<MT, NT, ACT>(acc, bias, gamma, beta, k, gn_combine<NG>(h0, h1), as, add);
+}
+// ... of the HALF sample this wave holds (HT M tiles; half index hf); the partner wave's statistics arrive through xch = the
+// sample's exchange area [2 halves][64 lanes] of HalfStat (one workgroup barrier; the caller guarantees another barrier between
+// this read and the next write of the area)
+template <int HT, int NT, int GL, int NG, bool ACT, class ADD>
+__device__ __forceinline__ void rw_gn_mish_half(f32x4 (&acc)[HT][NT], const float (&bias)[NT], const float (&gamma)[NT],
+                                                const float (&beta)[NT], const float (&isc)[NT], float inv, const ActScale& as, ADD add,
+                                                HalfStat* xch, int hf, int lane) {
+  float k[NT], bsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    k[t] = isc[t] * inv;
+    bsum += bias[t];
+  }
+  const float bsum4 = rw_gsum<GL>(bsum);
+  const HalfStat own = rw_half_stat<HT, NT, GL, NG>(acc, bias, k, bsum4);
+  xch[hf * 64 + lane] = own;
+  __syncthreads();
+  const HalfStat other = xch[(hf ^ 1) * 64 + lane];
+  const GnStat st = hf ? gn_combine<NG>(other, own) : gn_combine<NG>(own, other);
+  rw_gn_apply<HT, NT, ACT>(acc, bias, gamma, beta, k, st, as, add);
+}
 template <int MT, int NT>
 __device__ __forceinline__ float rw_absmax(const f32x4 (&acc)[MT][NT]) {   // the sample's |x| maximum, in every lane
   float m = 0.f;
@@ -1017,9 +1121,9 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
   auto gn = [&](auto conv_a, const Epi<2>& e, float inv, float act_s) {
     if constexpr (decltype(conv_a)::value) {
       const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
-      rw_gn_mish<4, 2, 2, 256, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
+      rw_gn_mish_whole<4, 2, 2, 256, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
     } else {
-      rw_gn_mish<4, 2, 2, 256, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
+      rw_gn_mish_whole<4, 2, 2, 256, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
     }
   };
   // The whole weight set of a conv (5 taps x 2 n-tiles x 2 pieces = 20 KB per wave) is requested BEFORE the epilogue that
@@ -1759,9 +1863,9 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   auto gn = [&](auto conv_a, const Epi<2>& e, float inv, float act_s) {
     if constexpr (decltype(conv_a)::value) {
       const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
-      rw_gn_mish<2, 2, 2, 128, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
+      rw_gn_mish_whole<2, 2, 2, 128, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; });
     } else {
-      rw_gn_mish<2, 2, 2, 128, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
+      rw_gn_mish_whole<2, 2, 2, 128, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; });
     }
   };
   auto conv = [&](const uint4* w) {                          // one 32 -> 32 conv over the tile in acc (already scaled)
@@ -1875,7 +1979,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     const float b1 = f.w1_bias[n & 3], s1 = f.is1[n & 3];
     wave_lds_fence();
     rd_taps<GF, 2, 0, 5, true, false, 4, 5>(y, y, vaF, wf, wf, ring5);
-    rw_gn_mish<4, 2, 2, 256, true>(y, ef.b, ef.g, ef.be, ef.is, inv_f, act_scale(f.act), [](int, int, int) { return 0.f; });
+    rw_gn_mish_whole<4, 2, 2, 256, true>(y, ef.b, ef.g, ef.be, ef.is, inv_f, act_scale(f.act), [](int, int, int) { return 0.f; });
     wave_lds_fence();
     rw_store2<GF, 4>(vsF + (2 + 4 * g) * 16, y);
     wave_lds_fence();
