@@ -1228,6 +1228,225 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
   TR(trb + 5);
 }
 
+// Cooperative weight staging of the half-sample stages (unet_kernel<2>): there every wave of the workgroup needs ALL B fragments of
+// a 32 -> 32 conv, and four waves fetching the same 20 KB through the CU's 64 B/clk vector-memory path took ~0.8 us per conv
+// (the issue of the loads itself blocks: profiles/r04_trace_512_half_sample.txt).  Instead the conv's NFRAG fragments (1 KiB
+// each: [lane] x 16 B, contiguous in the pack) go global -> LDS ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: no
+// registers; wave w moves fragments w, w + 4, ...), one conv ahead into the other of two buffers, and the GEMM loop reads its B
+// fragments from LDS through a two-step ring.  The issuing wave waits for its own pieces (vmcnt) before the barrier that
+// publishes the slab the conv reads.
+template <int NFRAG>
+__device__ __forceinline__ void stage_weights(const uint4* w, char* dst, int wave, int lane) {
+  static_assert(NFRAG % 4 == 0, "fragments are dealt to the four waves");
+  const uint4* src = w + lane;
+#pragma unroll
+  for (int i = 0; i < NFRAG / 4; ++i) {
+    const int f = wave + 4 * i;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 64),
+                                     (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void staged_weights_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr int WBUF_BYTES = 20 * 1024;                        // the largest staged conv: 32 -> 32, k = 5, two pieces
+
+// downs.0 for unet_kernel<2> (two trajectories per workgroup): a sample is split between two waves by POSITION -- wave = (sample sp =
+// wave >> 1, half hf = wave & 1: positions 32 hf .. 32 hf + 31 = M tiles 2 hf, 2 hf + 1 of the sample's four), so all four waves
+// work on real data with half the MFMAs and half the epilogue values each (the whole-sample form left two waves on zeros).  The
+// two waves share the sample's slab (a conv's taps reach two rows into the other half: one workgroup barrier between the slab
+// store and the taps), GroupNorm statistics are the two-half combination of rw_half_stat (one exchange through LDS per conv,
+// whose barrier also orders the next slab store behind the partner's taps), dynamic scales take the sample's maximum from the
+// two waves' partials in mx.  Per-sample arithmetic is that of chain_body_d0w: bitwise equal results.
+template <class CF>
+__device__ __forceinline__ void chain_body_d0s(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb) {
+  static_assert(CF::L == 64 && CF::CM == 32 && CF::C0 == 4 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
+                    CF::TAIL == TAIL_DOWN, "downs.0");
+  using GW = RwGeo<32, 64>;
+  constexpr int XIN = 72 * 8;
+  constexpr int W_BYTES = GW::BYTES + 2 * XIN + 128;          // (per SAMPLE here)
+  const int sp = wave >> 1, hf = wave & 1;
+  char* const slab = reinterpret_cast<char*>(lds) + sp * W_BYTES;
+  char* const xin = slab + GW::BYTES;
+  float* const mx = lds + MX_OFF;
+  HalfStat* const xch = reinterpret_cast<HalfStat*>(lds + PARK2_OFF) + sp * 128;   // (downs.2's parking area is idle in this stage)
+  static_assert(2 * 128 * sizeof(HalfStat) <= 3 * 256 * 16, "exchange area inside the parking area");
+  char* const wb0 = reinterpret_cast<char*>(lds) + 2 * W_BYTES;   // two weight buffers behind the two samples' slabs
+  char* const wb1 = wb0 + WBUF_BYTES;
+  static_assert(2 * W_BYTES + 2 * WBUF_BYTES <= MX_OFF * 4, "slabs + weight buffers below the maxima");
+  static_assert(GW::FRAGS5 * 2 * 1024 <= WBUF_BYTES, "a staged conv fits its buffer");
+  stage_weights<2 * GW::FRAGS5>(a.r0.wb_bf, wb0, wave, lane);     // RTB 0's conv B: lands while the sample is staged and conv A runs
+  const int n = lane & 15, g = lane >> 4, c0 = 2 * n;
+  const char* const va = slab + g * GW::G + (n + 32 * hf) * 16;
+  char* const vs = slab + (n >> 2) * GW::G + (2 + 4 * g + 32 * hf) * 16 + (n & 3) * 4;
+  auto wptr = [&](const uint4* w, int frags, int t) { return reinterpret_cast<const u32x4*>(w) + (size_t)t * frags * 64 + lane; };
+  // the sample's maximum of a per-wave partial: both waves publish theirs in the sample's mx slots (4 hf .. 4 hf + 3), barrier
+  auto sample_max = [&](float own) {
+    if (lane < 4) mx[sp * MX_SLOTS + 4 * hf + lane] = own;
+    __syncthreads();
+    return mx_read(mx, sp);
+  };
+  TR(trb + 0);
+  // ---- stage the sample: every wave loads all of it (lane = position: the exact maximum without an exchange) and writes its half
+  float inv_in;
+  {
+    const bool valid = n0 + sp < a.n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *reinterpret_cast<const float4*>(a.in0 + ((size_t)(n0 + sp) * 64 + lane) * 4);
+    float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = row_max16(m);
+    m = max_xor16(m);
+    m = max_xor32(m);
+    const DynScale ds = dyn_scale(m);
+    inv_in = ds.inv;
+    const F16Pair p0 = f16_split2(v.x * ds.s, v.y * ds.s), p1 = f16_split2(v.z * ds.s, v.w * ds.s);
+    if ((lane >> 5) == hf) {
+      *reinterpret_cast<uint2*>(xin + (2 + lane) * 8) = make_uint2(p0.hi, p1.hi);
+      *reinterpret_cast<uint2*>(xin + XIN + (2 + lane) * 8) = make_uint2(p0.lo, p1.lo);
+    }
+    if (hf == 0) {
+      if (lane < 16) {                                         // rows 0, 1, 66 .. 71 of both pieces
+        const int row = (lane & 7) < 2 ? (lane & 7) : 64 + (lane & 7);
+        *reinterpret_cast<uint2*>(xin + (lane >> 3) * XIN + row * 8) = make_uint2(0u, 0u);
+      }
+      if (lane < 32) *reinterpret_cast<uint4*>(slab + (lane >> 4) * GW::PS + ((lane >> 2) & 3) * GW::G + ((lane & 3) < 2 ? (lane & 3) : 64 + (lane & 3)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  f32x4 acc[2][2], res[2][2];
+  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
+  const float br0[2] = {a.br[c0], a.br[c0 + 1]}, isr0[2] = {a.isr[c0], a.isr[c0 + 1]};
+  u32x4 b0[2][2], br[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      b0[t][q] = wptr(a.r0.wa_bf, 2, t)[q * 64];
+      br[t][q] = wptr(a.wres_bf, 2, t)[q * 64];
+    }
+  __syncthreads();
+  // ---- RTB 0 conv A (im2col chunk) + the 1x1 residual conv on the half's two M tiles
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    u32x4 af[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint2* p = reinterpret_cast<const uint2*>(xin + q * XIN + ((2 * hf + i) * 16 + n + 2 * g) * 8);
+      const uint2 lo = p[0], hi = p[1];
+      af[q] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      vb_three<true>(acc[i][t], af, b0[t]);
+      vb_three<true>(res[i][t], af, br[t]);
+    }
+  }
+  const float one = 1.f;
+  auto epi = [&](const float* bs, const float* gm, const float* be, const float* tb, const float* isc) {
+    return epi_load<2>(bs, gm, be, tb, isc, c0);
+  };
+  auto gn = [&](auto conv_a, const Epi<2>& e, float inv, float act_s) {
+    if constexpr (decltype(conv_a)::value) {
+      const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
+      rw_gn_mish_half<2, 2, 2, 256, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; }, xch, hf, lane);
+    } else {
+      rw_gn_mish_half<2, 2, 2, 256, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; }, xch, hf, lane);
+    }
+  };
+  u32x4 ring[2][2][2];
+  // one 32 -> 32 conv over the half tile in acc (already scaled), its weights staged in wb; behind the barrier the NEXT conv's
+  // NEXT_FRAGS fragments start on their way into the other buffer (every wave is past the conv that read it)
+  auto conv = [&](char* wb, auto next_frags, const uint4* w_next, char* wb_next, int tr = -1) {
+    const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(wb) + lane, reinterpret_cast<const u32x4*>(wb) + GW::FRAGS5 * 64 + lane};
+    if (tr >= 0) TR(tr);
+    rw_store2<GW, 2>(vs, acc);
+    if (tr >= 0) TR(tr + 1);
+    staged_weights_landed();
+    __syncthreads();                                         // both halves of the sample and the conv's weights are in LDS
+    if (tr >= 0) TR(tr + 2);
+    if constexpr (decltype(next_frags)::value > 0) stage_weights<decltype(next_frags)::value>(w_next, wb_next, wave, lane);
+    rd_ring_load<GW, 2, 2>(ring, wp);
+    rd_taps<GW, 2, 0, 5, true, false, 2, 2>(acc, res, va, wp, wp, ring);
+    if (tr >= 0) TR(tr + 3);
+  };
+  using F5 = std::integral_constant<int, 2 * GW::FRAGS5>;
+  using F3 = std::integral_constant<int, 2 * GW::FRAGS3>;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) res[mt][t] = res[mt][t] * (isr0[t] * inv_in) + br0[t];
+  gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
+  TR(trb + 1);
+  {
+    const Epi<2> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+    conv(wb0, F5{}, a.ri[0].wa_bf, wb1);
+    gn(std::false_type{}, e, one, 1.f);
+  }
+  TR(trb + 2);
+  // ---- identity RTB
+  {
+    const RtbPtrs& R = a.ri[0];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) res[mt][t] = acc[mt][t];
+    const DynScale ds = dyn_scale(sample_max(rw_absmax<2, 2>(acc)));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    conv(wb1, F5{}, R.wb_bf, wb0, trb + 6);
+    TR(trb + 10);
+    gn(std::true_type{}, ea, ds.inv, R.act_a);
+    TR(trb + 3);
+    const Epi<2> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
+    conv(wb0, F3{}, a.wt_bf0, wb1);
+    gn(std::false_type{}, eb, one, 1.f);
+    TR(trb + 4);
+  }
+  // ---- tail: Downsample1d = Conv1d(k3, s2, p1) at the even positions: the half's 16 outputs = ONE M tile read at stride 2
+  {
+    const DynScale ds = dyn_scale(sample_max(rw_absmax<2, 2>(acc)));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
+    const u32x4* wt[2] = {reinterpret_cast<const u32x4*>(wb1) + lane, reinterpret_cast<const u32x4*>(wb1) + GW::FRAGS3 * 64 + lane};
+    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv};
+    rw_store2<GW, 2>(vs, acc);
+    staged_weights_landed();
+    __syncthreads();
+    f32x4 y[1][2];
+    rd_ring_load<GW, 2, 2>(ring, wt);
+    rd_taps<Stride2<GW, 0, 2>, 2, 1, 3, true, false, 1, 2>(y, y, va + n * 16, wt, wt, ring);
+    float mo = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        y[0][t][r] = fmaf(y[0][t][r], ist[t], bt[t]);
+        mo = fmaxf(mo, fabsf(y[0][t][r]));
+      }
+    mo = row_max16(mo);
+    mo = max_xor16(mo);
+    mo = max_xor32(mo);
+    // (the barrier inside: every wave is done with its slab -- the next stage's slab aliases them -- and the sample's maxima
+    // are published for the next stage's dynamic scale)
+    const float so = dyn_scale(sample_max(mo)).s;
+    using GN = RlGeo<32>;
+    char* const lb = reinterpret_cast<char*>(lds);
+    char* xb = lb + (n >> 2) * GN::G + (sp * GN::RPS + 2 + 16 * hf + 4 * g) * 16 + (n & 3) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const F16Pair f = f16_split2(y[0][0][r] * so, y[0][1][r] * so);
+      *reinterpret_cast<unsigned*>(xb + r * 16) = f.hi;
+      *reinterpret_cast<unsigned*>(xb + GN::PS + r * 16) = f.lo;
+    }
+    if (hf == 0 && lane < 32)                                // halo rows 0, 1, 34, 35 of the sample's 4 blocks x 2 pieces
+      *reinterpret_cast<uint4*>(lb + (lane >> 4) * GN::PS + ((lane >> 2) & 3) * GN::G +
+                                (sp * GN::RPS + ((lane & 3) < 2 ? (lane & 3) : 32 + (lane & 3))) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  TR(trb + 5);
+}
+
 // downs.1 (32 -> 64 -> 64 channels at L = 32, Downsample1d) in the direct form on RlGeo slabs.  Wave w = (n-tile pair np = w &
 // 1: channels 32 np + 2 n + t, interleaved columns; sample pair sp = w >> 1: samples 2 sp, 2 sp + 1), so a weight fragment is
 // used on four M tiles and fetched by two waves; acc[m][t]: M tile m = sample 2 sp + (m >> 1), positions 16 (m & 1) + 4 g + r.
@@ -2020,6 +2239,287 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   }
 }
 
+// ups.1 + final block for unet_kernel<2>: like chain_body_d0s a sample is split between two waves by position (wave = (sample sp =
+// wave >> 1, half hf = wave & 1): ONE M tile of the L = 32 convs, two of the final block's L = 64), the sample's slab is shared,
+// GroupNorm statistics / dynamic scales are exchanged through LDS.  The two input chunks arrive across waves as in
+// chain_body_u1w.  Bitwise equal results.
+template <class CF>
+__device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalArgs& f, const FusedStep& fs, float* lds, int n0, int lane_in, int wave,
+                                               const f32x4 (&xe)[2][1], const f32x4 (&xo)[2][1], const f32x4 (&skip)[2][2], int trb) {
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  static_assert(CF::L == 32 && CF::CM == 32 && CF::C0 == 64 && CF::C1 == 64 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
+                    CF::TAIL == TAIL_UP, "ups.1");
+  using GA = RwGeo<64, 32>;
+  using GB = RwGeo<32, 32>;
+  using GF = RwGeo<32, 64>;
+  constexpr int W_BYTES = cmax(GA::BYTES, cmax(GB::BYTES, GF::BYTES)) + 128;   // (the geometry of chain_body_u1w: per SAMPLE here)
+  char* const lb = reinterpret_cast<char*>(lds);
+  const int sp = wave >> 1, hf = wave & 1;                   // (downs.1's skip layout has the same sample index: np = wave & 1 there)
+  char* const slab = lb + sp * W_BYTES;
+  float* const mx = lds + MX_OFF;
+  HalfStat* const xch = reinterpret_cast<HalfStat*>(lds + PARK2_OFF) + sp * 128;
+  const int n = lane & 15, g = lane >> 4, c0 = 2 * n;
+  const bool odd = n & 1;
+  auto wptr = [&](const uint4* w, int frags, int t) { return reinterpret_cast<const u32x4*>(w) + (size_t)t * frags * 64 + lane; };
+  auto swap1 = [](float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  };
+  auto sample_max = [&](float own) {
+    if (lane < 4) mx[sp * MX_SLOTS + 4 * hf + lane] = own;
+    __syncthreads();
+    return mx_read(mx, sp);
+  };
+  const u32x4* wp0[2] = {wptr(a.r0.wa_bf, GA::FRAGS5, 0), wptr(a.r0.wa_bf, GA::FRAGS5, 1)};
+  const u32x4* wp1[2] = {wptr(a.wa0_c1_bf, GA::FRAGS5, 0), wptr(a.wa0_c1_bf, GA::FRAGS5, 1)};
+  const u32x4* wr0[2] = {wptr(a.wres_bf, 2 * GA::KC, 0), wptr(a.wres_bf, 2 * GA::KC, 1)};
+  const u32x4* wr1[2] = {wptr(a.wres_c1_bf, 2 * GA::KC, 0), wptr(a.wres_c1_bf, 2 * GA::KC, 1)};
+  constexpr int RDA = 5;
+  u32x4 ring[RDA][2][2];
+  rd_ring_load<GA, 2, RDA>(ring, wp0);
+  // ---- the skip tensor's per-sample maxima (downs.1's layout for two trajectories: wave = (channel half np = wave & 1, sample wave >> 1),
+  //      skip[m][t][r]: M tile m of the sample) -> slots 4 .. 7 of mx region 0; ups.0 left its output's maxima in slots 0 .. 3
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(skip[mt][t][r]));
+    m = row_max16(m);
+    m = max_xor16(m);
+    m = max_xor32(m);
+    if (lane < 2) mx[sp * MX_SLOTS + 4 + hf + 2 * lane] = m;
+  }
+  __syncthreads();                                           // ups.0 is done with its slabs; the maxima are in mx
+  TR(trb + 0);
+  // staged weights (stage_weights above): two buffers behind the two samples' slabs; RTB 0's conv B lands while conv A runs
+  char* const wb0 = lb + 2 * W_BYTES;
+  char* const wb1 = wb0 + WBUF_BYTES;
+  static_assert(2 * W_BYTES + 2 * WBUF_BYTES <= MX_OFF * 4, "slabs + weight buffers below the maxima");
+  static_assert(GB::FRAGS5 * 2 * 1024 <= WBUF_BYTES && GF::FRAGS5 * 2 * 1024 <= WBUF_BYTES, "a staged conv fits its buffer");
+  stage_weights<2 * GB::FRAGS5>(a.r0.wb_bf, wb0, wave, lane);
+  float sc[2];
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm) sc[sm] = dyn_scale(mx_read(mx, sm)).s;
+  const float inv_in = dyn_scale(mx_read(mx, sp)).inv;
+  const float sc_own = dyn_scale(mx_read(mx, sp)).s;
+  char* const cdst = lb + wave * GA::G + (n >> 3) * GA::BX + ((n & 7) >> 1) * 4 + 2 * 16;
+  {
+    // zero halo rows 0, 1, 34, 35 of the sample's slab (8 blocks x 2 pieces): one wave per sample
+    if (hf == 0) {
+      const int hr = lane & 3;
+      *reinterpret_cast<uint4*>(slab + (lane >> 5) * GA::PS + ((lane >> 3) & 3) * GA::G + ((lane >> 2) & 1) * GA::BX +
+                                (hr < 2 ? hr : 32 + hr) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // chunk 0 = ups.0's output (wave w holds channels 16 w + n of both samples): as in chain_body_u1w
+    char* const d0 = cdst + (8 * g + (odd ? 1 : 0)) * 16;
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float own = (odd ? xo[sm][0][r] : xe[sm][0][r]) * sc[sm];
+        const float recv = swap1((odd ? xe[sm][0][r] : xo[sm][0][r]) * sc[sm]);
+        const F16Pair p = f16_split2(odd ? recv : own, odd ? own : recv);
+        char* d = d0 + sm * W_BYTES + 2 * r * 16;
+        *reinterpret_cast<unsigned*>(d) = p.hi;
+        *reinterpret_cast<unsigned*>(d + GA::PS) = p.lo;
+      }
+  }
+  TR(trb + 6);
+  __syncthreads();
+  TR(trb + 7);
+  const char* const vaA = slab + g * GA::G + (n + 16 * hf) * 16;
+  f32x4 acc[1][2], res[1][2];
+  rd_taps<GA, 2, 0, 5, true, true, 1, RDA>(acc, res, vaA, wp0, wr0, ring);
+  rd_ring_load<GA, 2, RDA>(ring, wp1);
+  TR(trb + 8);
+  __syncthreads();                                           // every wave has consumed chunk 0
+  {
+    // chunk 1 = skip (downs.1's layout: this wave holds channel pair (32 np + 2 n, + 1), np = wave & 1, of sample sp, both M tiles)
+    const int np = hf;
+    char* const sdst = lb + (2 * np + (n >> 3)) * GA::G + ((n >> 2) & 1) * GA::BX + (n & 3) * 4 + (2 + 4 * g) * 16 + sp * W_BYTES;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const F16Pair p = f16_split2(skip[m][0][r] * sc_own, skip[m][1][r] * sc_own);
+        char* d = sdst + (16 * m + r) * 16;
+        *reinterpret_cast<unsigned*>(d) = p.hi;
+        *reinterpret_cast<unsigned*>(d + GA::PS) = p.lo;
+      }
+  }
+  __syncthreads();
+  TR(trb + 10);
+  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
+  const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
+  rd_taps<GA, 2, 0, 5, false, true, 1, RDA>(acc, res, vaA, wp1, wr1, ring);
+  TR(trb + 11);
+  // ---- 32-channel slab of the sample, shared by its two waves
+  const char* const vaB = slab + g * GB::G + (n + 16 * hf) * 16;
+  char* const vsB = slab + (n >> 2) * GB::G + (2 + 4 * g + 16 * hf) * 16 + (n & 3) * 4;
+  u32x4 ring2[2][2][2];
+  const float one = 1.f;
+  auto epi = [&](const float* bs, const float* gm, const float* be, const float* tb, const float* isc) {
+    return epi_load<2>(bs, gm, be, tb, isc, c0);
+  };
+  auto gn = [&](auto conv_a, const Epi<2>& e, float inv, float act_s) {
+    if constexpr (decltype(conv_a)::value) {
+      const float t0 = e.tb[0] * act_s, t1 = e.tb[1] * act_s;
+      rw_gn_mish_half<1, 2, 2, 128, true>(acc, e.b, e.g, e.be, e.is, inv, act_scale(act_s), [&](int, int t, int) { return t ? t1 : t0; }, xch, hf, lane);
+    } else {
+      rw_gn_mish_half<1, 2, 2, 128, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int mt, int t, int r) { return res[mt][t][r]; }, xch, hf, lane);
+    }
+  };
+  // one 32 -> 32 conv over the half tile in acc (already scaled), its weights staged in wb; `stage_next` puts the next conv's on
+  // their way behind the barrier (every wave is past the conv that read the other buffer)
+  auto conv = [&](char* wb, auto stage_next) {
+    const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(wb) + lane, reinterpret_cast<const u32x4*>(wb) + GB::FRAGS5 * 64 + lane};
+    rw_store2<GB, 1>(vsB, acc);
+    staged_weights_landed();
+    __syncthreads();
+    stage_next();
+    rd_ring_load<GB, 2, 2>(ring2, wp);
+    rd_taps<GB, 2, 0, 5, true, false, 1, 2>(acc, res, vaB, wp, wp, ring2);
+  };
+  constexpr int TF = 2 * (2 * GB::KC * 2);                   // fragments of one parity pass of the transposed tail (both n-tiles)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) res[0][t] = res[0][t] * (isr[t] * inv_in) + br[t];
+  gn(std::true_type{}, e0a, inv_in, a.r0.act_a);             // (its barrier: conv A's reads are done, the slab changes its geometry)
+  TR(trb + 1);
+  if (hf == 0 && lane < 32) *reinterpret_cast<uint4*>(slab + (lane >> 4) * GB::PS + ((lane >> 2) & 3) * GB::G + ((lane & 3) < 2 ? (lane & 3) : 32 + (lane & 3)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  {
+    const Epi<2> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
+    conv(wb0, [&] { stage_weights<2 * GB::FRAGS5>(a.ri[0].wa_bf, wb1, wave, lane); });
+    gn(std::false_type{}, e, one, 1.f);
+  }
+  TR(trb + 2);
+  // ---- identity RTB
+  {
+    const RtbPtrs& R = a.ri[0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) res[0][t] = acc[0][t];
+    const DynScale ds = dyn_scale(sample_max(rw_absmax<1, 2>(acc)));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[0][t] *= ds.s;
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    conv(wb1, [&] { stage_weights<2 * GB::FRAGS5>(R.wb_bf, wb0, wave, lane); });
+    gn(std::true_type{}, ea, ds.inv, R.act_a);
+    TR(trb + 3);
+    const Epi<2> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
+    conv(wb0, [&] {                                          // the tail's two parity passes
+      stage_weights<TF>(a.wt_bf0, wb1, wave, lane);
+      stage_weights<TF>(a.wt_bf1, wb1 + TF * 1024, wave, lane);
+    });
+    gn(std::false_type{}, eb, one, 1.f);
+    TR(trb + 4);
+  }
+  // ---- tail: Upsample1d as two parity passes -> the final block's input (L = 64), the half's rows of the 64-row slab
+  const char* const vaF = slab + g * GF::G + (n + 32 * hf) * 16;
+  char* const vsF = slab + (n >> 2) * GF::G + (n & 3) * 4;
+  f32x4 y[2][2];
+  float inv_f;
+  {
+    const DynScale ds = dyn_scale(sample_max(rw_absmax<1, 2>(acc)));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[0][t] *= ds.s;
+    const u32x4* const t0 = reinterpret_cast<const u32x4*>(wb1) + lane;
+    const u32x4* const t1 = reinterpret_cast<const u32x4*>(wb1 + TF * 1024) + lane;
+    const u32x4* wt0[2] = {t0, t0 + (TF / 2) * 64};
+    const u32x4* wt1[2] = {t1, t1 + (TF / 2) * 64};
+    const float bt[2] = {a.bt[c0], a.bt[c0 + 1]};
+    const float is0[2] = {a.ist0[c0] * ds.inv, a.ist0[c0 + 1] * ds.inv}, is1[2] = {a.ist1[c0] * ds.inv, a.ist1[c0 + 1] * ds.inv};
+    rw_store2<GB, 1>(vsB, acc);
+    staged_weights_landed();
+    __syncthreads();
+    stage_weights<2 * GF::FRAGS5>(f.w5, wb0, wave, lane);    // the final block's k5 conv
+    f32x4 e[1][2], o[1][2];
+    rd_ring_load<GB, 2, 2>(ring2, wt0);
+    rd_taps<GB, 2, 1, 2, true, false, 1, 2>(e, res, vaB, wt0, wt0, ring2);
+    rd_ring_load<GB, 2, 2>(ring2, wt1);
+    rd_taps<GB, 2, 2, 2, true, false, 1, 2>(o, res, vaB, wt1, wt1, ring2);
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e[0][t][r] = fmaf(e[0][t][r], is0[t], bt[t]);
+        o[0][t][r] = fmaf(o[0][t][r], is1[t], bt[t]);
+        m = fmaxf(m, fmaxf(fabsf(e[0][t][r]), fabsf(o[0][t][r])));
+      }
+    m = row_max16(m);
+    m = max_xor16(m);
+    m = max_xor32(m);
+    const DynScale df = dyn_scale(sample_max(m));            // (its barrier: the tail's reads are done, 64-row geometry)
+    inv_f = df.inv;
+    if (hf == 0 && lane < 32) *reinterpret_cast<uint4*>(slab + (lane >> 4) * GF::PS + ((lane >> 2) & 3) * GF::G + ((lane & 3) < 2 ? (lane & 3) : 64 + (lane & 3)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // positions 2 m + parity, m = 16 hf + 4 g + r: rows 2 + 32 hf + 8 g + 2 r + parity
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const F16Pair pe = f16_split2(e[0][0][r] * df.s, e[0][1][r] * df.s), po = f16_split2(o[0][0][r] * df.s, o[0][1][r] * df.s);
+      char* d = vsF + (2 + 32 * hf + 8 * g + 2 * r) * 16;
+      *reinterpret_cast<unsigned*>(d) = pe.hi;
+      *reinterpret_cast<unsigned*>(d + GF::PS) = pe.lo;
+      *reinterpret_cast<unsigned*>(d + 16) = po.hi;
+      *reinterpret_cast<unsigned*>(d + 16 + GF::PS) = po.lo;
+    }
+  }
+  TR(trb + 5);
+  // ---- final block: Conv1dBlock(32 -> 32, k5) + GroupNorm + Mish, then the 1x1 conv 32 -> 4, on the half's two M tiles
+  {
+    const u32x4* wf[2] = {reinterpret_cast<const u32x4*>(wb0) + lane, reinterpret_cast<const u32x4*>(wb0) + GF::FRAGS5 * 64 + lane};
+    const u32x4* w1[1] = {reinterpret_cast<const u32x4*>(f.w1_bf) + lane};
+    u32x4 ring1[1][1][2];
+    rd_ring_load<GF, 1, 1>(ring1, w1);
+    const Epi<2> ef = epi_load<2>(f.bias, f.gamma, f.beta, nullptr, f.isc, c0);
+    const float b1 = f.w1_bias[n & 3], s1 = f.is1[n & 3];
+    staged_weights_landed();
+    __syncthreads();                                         // the final block's input and weights are complete
+    rd_ring_load<GF, 2, 2>(ring2, wf);
+    rd_taps<GF, 2, 0, 5, true, false, 2, 2>(y, y, vaF, wf, wf, ring2);
+    rw_gn_mish_half<2, 2, 2, 256, true>(y, ef.b, ef.g, ef.be, ef.is, inv_f, act_scale(f.act), [](int, int, int) { return 0.f; }, xch, hf, lane);
+    // (the exchange's barrier: the partner is past its taps, the slab may be overwritten; the 1x1 conv reads only the centre
+    // tap = the wave's own rows)
+    rw_store2<GF, 2>(vsF + (2 + 4 * g + 32 * hf) * 16, y);
+    wave_lds_fence();
+    f32x4 out[2][1];
+    rd_taps<GF, 1, 2, 1, true, false, 2, 1>(out, out, vaF, w1, w1, ring1);
+    if (fs.enabled) {
+      // eps[64][4] -> the sample's slab as float4 rows (both waves their halves), then the unguided ddpm_sample_fn step on the
+      // trajectory by the sample's first wave, lane = support point (chain_body_u1w)
+      float* const et = reinterpret_cast<float*>(slab);
+      __syncthreads();                                       // (both waves' 1x1 reads of the slab are done)
+      if (n < 4) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) et[(32 * hf + 16 * mt + 4 * g + r) * 4 + n] = fmaf(out[mt][0][r], s1, b1);
+      }
+      __syncthreads();
+      if (hf == 0 && n0 + sp < a.n) {
+        const float4 e = *reinterpret_cast<const float4*>(et + lane * 4);
+        const int traj = fs.traj0 + n0 + sp, robot = traj / fs.spr;
+        const size_t idx = (size_t)traj * H + lane;
+        float4 v = ddpm_posterior_mean(fs.x[idx], e, fs.a_t, fs.b_t, fs.c1, fs.c2);
+        if (fs.do_noise)
+          v = add_step_noise(v, fs.noise ? fs.noise[idx] : normal4(fs.seed, fs.draw, (unsigned long long)fs.traj_base * H + idx), fs.sigma,
+                             fs.noise_std_extra);
+        if ((fs.hard_mask & 1) && lane == 0) v = fs.hard[robot * 2 + 0];
+        if ((fs.hard_mask & 2) && lane == H - 1) v = fs.hard[robot * 2 + 1];
+        fs.x[idx] = v;
+        if (fs.chain) fs.chain[idx] = v;
+      }
+    } else if (n < 4 && n0 + sp < a.n) {
+      float* dst = f.out + ((size_t)(n0 + sp) * 64 + 32 * hf + 4 * g) * 4 + n;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(16 * mt + r) * 4] = fmaf(out[mt][0][r], s1, b1);
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // The whole TemporalUnet forward for 4 samples in ONE workgroup / ONE launch: the five level chains and the final conv
 // hand their activations to each other through LDS (tail tile -> next stage's x slab), the two skip connections wait in
@@ -2051,7 +2551,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   f32x4 skip1[NS][2], skip2[NS][2];
   // ---- downs.0 @ L=64 -> [4][32][32]: wave = sample, direct f16x2 convs on the wave's own slab (chain_body_d0w)
-  chain_body_d0w<CH_D0, NS>(a.c[0], lds, n0, lane, wave, 0);
+  if constexpr (NS == 2) chain_body_d0s<CH_D0>(a.c[0], lds, n0, lane, wave, 0);
+  else chain_body_d0w<CH_D0, NS>(a.c[0], lds, n0, lane, wave, 0);
   // ---- downs.1 @ L=32 -> [4][16][64], skip1: direct f16x2 convs, wave = (n-tile pair, sample pair) (chain_body_d1d)
   chain_body_d1d<CH_D1, CH_D2, NS>(a.c[1], lds, lane, wave, skip1, 40);
   // ---- downs.2 + mid blocks @ L=16 -> [NS][16][128], skip2: direct f16x2 convs (chain_body_d2d; lane = channels 32 wave + 2
@@ -2073,7 +2574,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   TR(131);
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32], final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]:
   //      wave = sample (chain_body_u1w)
-  chain_body_u1w<CH_U1, NS>(a.c[4], a.fin, a.fs, lds, n0, lane, wave, xe, xo, skip1, 146);
+  if constexpr (NS == 2) chain_body_u1s<CH_U1>(a.c[4], a.fin, a.fs, lds, n0, lane, wave, xe, xo, skip1, 146);
+  else chain_body_u1w<CH_U1, NS>(a.c[4], a.fin, a.fs, lds, n0, lane, wave, xe, xo, skip1, 146);
   TR(133);
 }
 

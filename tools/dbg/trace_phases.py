@@ -41,6 +41,7 @@ for j, w in enumerate(("maxima + barrier", "convA (2 chunks, 4 barriers) + res +
 names.update({152: "U1 x chunk scaled + stored", 153: "  barrier", 154: "  chunk 0 taps + ring", 155: "  barrier + skip chunk stored", 156: "  barrier",
               157: "  chunk 1 taps"})
 names.update({160: "U0 x0 scaled + stored", 161: "  barrier", 162: "  chunk 0 taps + ring", 163: "  barrier + x1 stored", 164: "  barrier", 165: "  chunk 1 taps"})
+names.update({6: "D0 id convA (two per workgroup): start", 7: "  slab store", 8: "  barrier", 9: "  taps (60 MFMAs)", 10: "  weight preload issued"})
 names.update({130: "-> U0 start", 131: "-> U1 start", 133: "final block + output store"})
 # direct f16x2 body of downs.2 + mid (tags 90..93 are overwritten by every conv: the values are the LAST conv's, mid_block2 conv B)
 names.update({80: "D2 start", 81: "D2 rtb0 convA+res+gn", 90: "last conv: start (prev gn done)", 91: "  ring + slab store", 92: "  barrier",
