@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMD_AMD_ABI_VERSION 4
+#define MMD_AMD_ABI_VERSION 5
 #define MMD_STATE_DIM 4
 #define MMD_HORIZON 64
 
@@ -113,6 +113,11 @@ typedef struct mmd_guide_desc {
   const float* extra_spheres_dev;    /* [n_extra_spheres][4]: (cx, cy, r, 0) */
   const float* extra_boxes_dev;      /* [n_extra_boxes][4]: (cx, cy, half size x, half size y) */
   int32_t n_extra_spheres, n_extra_boxes;
+  /* GuideManager.clip_gradient (guides.py:228-259), applied to every cost's per-point gradient: 0 = clip_grad_by_norm with
+   * max_grad_norm (what MPD / MPDEnsemble set, mpd.py:258-265), 1 = clip_grad_by_value: torch.clip(grad, -max_grad_value,
+   * max_grad_value) (the class default 0.1), 2 = clip_grad = False */
+  int32_t clip_grad_rule;
+  float max_grad_value;
 } mmd_guide_desc;
 
 /* Host helper: time-bucket one robot's constraint groups.  For group g (n_pts[g] points): q [n,2], t_range [n,2]
@@ -170,6 +175,10 @@ typedef struct mmd_sampler_desc {
                                              * t (sample_functions.py:83-86 calls it per step); NULL = the constant above */
   void* profiler;                           /* optional mmd_profiler_t (include/mmd_amd_debug.h) that brackets UNet launches
                                              * with HIP events; NULL in production */
+  int32_t scale_grad_by_std;                /* 1: every guide gradient is multiplied by model_var = exp(posterior_log_variance_
+                                             * clipped[t]) before it is added (guide_gradient_steps, sample_functions.py:100-101) */
+  int32_t model_predicts_x0;                /* 1: GaussianDiffusionModel(predict_epsilon=False): the network output IS x_recon
+                                             * (predict_start_from_noise, diffusion_model_base.py:131-141); DDPM sampler only */
 } mmd_sampler_desc;
 
 /* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop: [UNet token (256 B)][eps: n_traj * H * 4 floats].  The chunked

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmd_amd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GuideDesc(C.Structure):
@@ -21,6 +21,7 @@ class GuideDesc(C.Structure):
         ("robot_grp_off_dev", C.c_void_p), ("max_slots_per_robot", C.c_int32), ("cons_uniform_radius", C.c_float),
         ("extra_spheres_dev", C.c_void_p), ("extra_boxes_dev", C.c_void_p),
         ("n_extra_spheres", C.c_int32), ("n_extra_boxes", C.c_int32),
+        ("clip_grad_rule", C.c_int32), ("max_grad_value", C.c_float),
     ]
 
 
@@ -35,6 +36,7 @@ class SamplerDesc(C.Structure):
         ("n_guide_steps", C.c_int32), ("t_start_guide", C.c_int32),
         ("noise_std_extra", C.c_float), ("hard_mask", C.c_int32), ("n_streams", C.c_int32),
         ("traj_index_base", C.c_int64), ("noise_std_extra_by_t", C.POINTER(C.c_float)), ("profiler", C.c_void_p),
+        ("scale_grad_by_std", C.c_int32), ("model_predicts_x0", C.c_int32),
     ]
 
 

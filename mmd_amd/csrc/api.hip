@@ -81,6 +81,9 @@ static int make_step(const mmd_sampler_desc* s, int i, bool guided, StepDev& sd)
   MMD_REQUIRE(t < s->n_diffusion_steps, "loop index %d outside the %d-step schedule", i, s->n_diffusion_steps);
   sd.a_t = s->sqrt_recip_alphas_cumprod[t];
   sd.b_t = s->sqrt_recipm1_alphas_cumprod[t];
+  if (s->model_predicts_x0) { sd.a_t = 0.f; sd.b_t = -1.f; }       // predict_epsilon = False: x_recon = a x - b out = out (diffusion_model_base.py:131-141)
+  // scale_grad_by_std (sample_functions.py:59-61, 100-101): the guide gradient times model_var = exp(posterior_log_variance_clipped[t])
+  sd.grad_scale = s->scale_grad_by_std ? expf(s->posterior_log_variance_clipped[t]) : 1.f;
   sd.c1 = s->posterior_mean_coef1[t];
   sd.c2 = s->posterior_mean_coef2[t];
   sd.sigma = expf(0.5f * s->posterior_log_variance_clipped[t]);   // model_std, sample_functions.py:60
@@ -304,8 +307,10 @@ int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alp
   for (int k = 0; k + 1 < n_times; ++k) {
     const int t = times[k], tn = times[k + 1];
     MMD_REQUIRE(t >= 0 && t < s->n_diffusion_steps && tn < t, "mmd_ddim_sample: times must decrease inside the schedule");
+    MMD_REQUIRE(!s->model_predicts_x0, "mmd_ddim_sample: predict_epsilon = False is implemented for the DDPM sampler only");
     StepDev sd{};
     sd.ddim = 1;
+    sd.grad_scale = 1.f;                                              // (ddim_sample passes no scale_grad_by_std on)
     sd.a_t = s->sqrt_recip_alphas_cumprod[t];
     sd.b_t = s->sqrt_recipm1_alphas_cumprod[t];
     sd.c1 = tn < 0 ? 1.f : sqrtf(alphas_cumprod[tn]);               // x = x_start on the last pair (time_next = -1)

@@ -36,6 +36,22 @@ __device__ __forceinline__ float clip_scale(float gx, float gy, float gz, float 
   return fminf(max_norm * __builtin_amdgcn_rsqf(n2), 1.f);
 }
 
+// GuideManager.clip_gradient (guides.py:228-259) of one cost's per-point gradient: by norm (the planners' setting), by value
+// (torch.clip to +-max_grad_value per component) or not at all (clip_grad = False).  The rule is wave uniform.
+__device__ __forceinline__ void clip_grad(const GuideDev& g, float& gx, float& gy, float& gz, float& gw) {
+  if (g.clip_rule == 0) {
+    const float sc = clip_scale(gx, gy, gz, gw, g.max_norm);
+    gx = sc * gx; gy = sc * gy; gz = sc * gz; gw = sc * gw;
+  } else if (g.clip_rule == 1) {
+    const float m = g.max_value;
+    gx = fminf(fmaxf(gx, -m), m); gy = fminf(fmaxf(gy, -m), m); gz = fminf(fmaxf(gz, -m), m); gw = fminf(fmaxf(gw, -m), m);
+  }
+}
+__device__ __forceinline__ void clip_grad(const GuideDev& g, float& gx, float& gy) {
+  float z = 0.f, w = 0.f;
+  clip_grad(g, gx, gy, z, w);
+}
+
 // wave shift by one lane through DPP (GFX9 wave_shr:1 / wave_shl:1): lane t reads lane t-1 / t+1, no LDS round trip.
 // Lanes shifted in from outside the wave read 0 (bound_ctrl) -- callers mask t == 0 / t == H-1 anyway.
 __device__ __forceinline__ float lane_prev(float v) {
@@ -177,8 +193,8 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
     v = fmaxf(g.margin - d3, 0.f);
     if (v > best) { best = v; gx = 0.f; gy = 1.f; }
     if (!(best > 0.f)) { gx = 0.f; gy = 0.f; }
-    const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
-    wsx = g.w_coll * (sc * gx); wsy = g.w_coll * (sc * gy);
+    clip_grad(g, gx, gy);
+    wsx = g.w_coll * gx; wsy = g.w_coll * gy;
   }
   // --- CostGPTrajectory (cost_functions.py:532-542, gp_factor.py): e_t = s_{t+1} - Phi s_t, w_t = 2 Q^-1 e_t,
   //     g_t = w_{t-1} - Phi^T w_t
@@ -195,19 +211,20 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
       wvy = 2.f * (g.m2 * epy + g.m3 * evy);
     }
     const float lpx = lane_prev(wpx), lpy = lane_prev(wpy), lvx = lane_prev(wvx), lvy = lane_prev(wvy);
-    const float gx = lpx - wpx, gy = lpy - wpy;
-    const float gz = lvx - (g.dt * wpx + wvx), gw = lvy - (g.dt * wpy + wvy);
-    const float sc = clip_scale(gx, gy, gz, gw, g.max_norm);
-    gpx = g.w_smooth * (sc * gx); gpy = g.w_smooth * (sc * gy);
-    gpz = g.w_smooth * (sc * gz); gpw = g.w_smooth * (sc * gw);
+    float gx = lpx - wpx, gy = lpy - wpy;
+    float gz = lvx - (g.dt * wpx + wvx), gw = lvy - (g.dt * wpy + wvy);
+    clip_grad(g, gx, gy, gz, gw);
+    gpx = g.w_smooth * gx; gpy = g.w_smooth * gy;
+    gpz = g.w_smooth * gz; gpw = g.w_smooth * gw;
   }
   // --- CostConstraint groups (cost_functions.py:297-326): per group the slot sum, its own clip and weight
   float cx = 0.f, cy = 0.f;
   for (int grp = grp0; grp < grp1; ++grp) {
     const f32x2g gs = group_sum(grp, f32x2g{px, py});
-    const float sc = clip_scale(gs.x, gs.y, 0.f, 0.f, g.max_norm);
+    float gx = gs.x, gy = gs.y;
+    clip_grad(g, gx, gy);
     const float w = g.grp_weight[grp];
-    cx += w * (sc * gs.x); cy += w * (sc * gs.y);
+    cx += w * gx; cy += w * gy;
   }
   // --- CostCollision over the SDF grids: d/dp max_k relu(margin - sdf_k(p))  (t >= 1; field_factor.py range [1,None])
   float ox, oy;
@@ -224,8 +241,8 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
       const float v = fmaxf(g.margin - extra_sdf(g.xs, g.n_xs, g.xb, g.n_xb, px, py, ex, ey), 0.f);
       if (v > best) { best = v; gx = -ex; gy = -ey; }
     }
-    const float sc = clip_scale(gx, gy, 0.f, 0.f, g.max_norm);
-    ox = g.w_coll * (sc * gx); oy = g.w_coll * (sc * gy);
+    clip_grad(g, gx, gy);
+    ox = g.w_coll * gx; oy = g.w_coll * gy;
   }
   // sum in the reference's cost order (objects, ws boundaries, GP, constraints), zero rows 0 / H-1, negate
   float tx = ((ox + wsx) + gpx) + cx, ty = ((oy + wsy) + gpy) + cy;
@@ -242,6 +259,9 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
                                                          const float4* __restrict__ hard,
                                                          int samples_per_robot) {
   extern __shared__ __attribute__((aligned(16))) float4 lds_cons[];
+#ifdef MMD_GUIDE_PRIO   // (A/B build: the step kernel is on the critical chain of its stream chunk while the other chunk's UNet launch shares the SIMDs)
+  __builtin_amdgcn_s_setprio(MMD_GUIDE_PRIO);
+#endif
   const int t = threadIdx.x & 63;
   const int traj_b = s.traj0 + blockIdx.x * WPB;
   const int traj = traj_b + (threadIdx.x >> 6);
@@ -308,7 +328,9 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
     };
     for (int it = 0; it < s.n_guide_steps; ++it) {
       const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, group_sum);
-      v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w;
+      // (x + model_var * grad with scale_grad_by_std, sample_functions.py:100-104; grad_scale = 1 otherwise: the fma is then the add)
+      v.x = __builtin_fmaf(s.grad_scale, gr.x, v.x); v.y = __builtin_fmaf(s.grad_scale, gr.y, v.y);
+      v.z = __builtin_fmaf(s.grad_scale, gr.z, v.z); v.w = __builtin_fmaf(s.grad_scale, gr.w, v.w);
       if (is_start) v = hs;
       if (is_goal) v = hg;
       if (s.guide_chain) s.guide_chain[(size_t)it * s.guide_chain_stride + idx] = v;
@@ -392,7 +414,9 @@ __global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDe
     };
     for (int it = 0; it < s.n_guide_steps; ++it) {
       const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, group_sum);
-      v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w;
+      // (x + model_var * grad with scale_grad_by_std, sample_functions.py:100-104; grad_scale = 1 otherwise: the fma is then the add)
+      v.x = __builtin_fmaf(s.grad_scale, gr.x, v.x); v.y = __builtin_fmaf(s.grad_scale, gr.y, v.y);
+      v.z = __builtin_fmaf(s.grad_scale, gr.z, v.z); v.w = __builtin_fmaf(s.grad_scale, gr.w, v.w);
       if (is_start) v = hs;
       if (is_goal) v = hg;
       if (s.guide_chain && wave == 0) s.guide_chain[(size_t)it * s.guide_chain_stride + idx] = v;
@@ -487,6 +511,9 @@ int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
   g.robot_map = d->robot_map_dev;
   g.margin = d->margin; g.dt = d->dt; g.w_coll = d->weight_collision; g.w_smooth = d->weight_smoothness;
   g.max_norm = d->max_grad_norm;
+  MMD_REQUIRE(d->clip_grad_rule >= 0 && d->clip_grad_rule <= 2, "guide: clip_grad_rule must be 0 (norm), 1 (value) or 2 (off)");
+  g.clip_rule = d->clip_grad_rule;
+  g.max_value = d->max_grad_value;
   const double dt = d->dt, qc = 1.0 / ((double)d->sigma_gp * d->sigma_gp);
   g.m1 = (float)(12.0 / (dt * dt * dt) * qc);
   g.m2 = (float)(-6.0 / (dt * dt) * qc);
@@ -635,7 +662,7 @@ int mmd_guide_steps(const mmd_guide_desc* d, float* x_dev, const float* hard_dev
   GuideDev g{};
   if (int rc = fill_guide(d, g)) return rc;
   StepDev s{};
-  s.do_guide = 1; s.n_guide_steps = n_steps; s.hard_mask = hard_mask;
+  s.do_guide = 1; s.n_guide_steps = n_steps; s.hard_mask = hard_mask; s.grad_scale = 1.f;
   s.guide_chain = reinterpret_cast<float4*>(chain_dev);
   s.guide_chain_stride = (long long)n_robots * samples_per_robot * H;
   launch_step(g, s, x_dev, nullptr, nullptr, nullptr, hard_dev, 0, n_robots * samples_per_robot, samples_per_robot,

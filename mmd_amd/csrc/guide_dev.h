@@ -16,6 +16,8 @@ struct GuideDev {
   const int* robot_map;
   float ws_min[2], ws_max[2];
   float margin, dt, w_coll, w_smooth, max_norm;
+  int clip_rule;                     // 0: clip_grad_by_norm (max_norm), 1: clip_grad_by_value (max_value), 2: clip_grad = False
+  float max_value;
   float m1, m2, m3;                  // GP prior Q^-1 blocks: 12/dt^3, -6/dt^2, 4/dt  (x 1/sigma^2)
   const float4* cons;                // [n_slots][H]
   const int* grp_slot_off;
@@ -136,6 +138,7 @@ struct StepDev {
   float a_t, b_t, c1, c2;            // sqrt_recip_alphas_cumprod[t], sqrt_recipm1[t], posterior_mean_coef1/2[t]
   float sigma;                       // exp(0.5 * posterior_log_variance_clipped[t])
   float noise_std_extra;
+  float grad_scale;                  // scale_grad_by_std: model_var = exp(posterior_log_variance_clipped[t]), else 1
   int do_model, do_guide, do_noise;  // do_model = 0: guide-only launch (mmd_guide_steps)
   int ddim;                          // 1: DDIM update x <- c1 * (a x - b eps) + c2 * eps, x0 not clamped (mmd_ddim_sample)
   int n_guide_steps;

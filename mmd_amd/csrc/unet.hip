@@ -280,9 +280,9 @@ constexpr int UNET_LDS_FLOATS = PARK2_OFF + 3 * 256 * 4;
 
 // ----------------------------------------------------------------------------------------------------------------
 // fp32 GEMM on the fp16 matrix pipe ("f16x2"): every conv of the network.  Every fp32 operand is split into TWO fp16 pieces
-// by rounding to nearest, x0 = RN16(x), x1 = RN16(x - x0) (x - x0 is exact in fp32; |x - x0 - x1| <= 2^-24 |x|, half an fp32 ulp, as long as x1 stays
-// above fp16's denormal step 2^-24), and a product a * w is accumulated as a1 w0 + a0 w1 + a0 w0 (low order first) on
-// v_mfma_f32_16x16x32_f16 with fp32 accumulation; the dropped a1 w1 is <= 2^-24 |a w|.  Measured against fp64 the result is
+// by rounding to nearest, x0 = RN16(x), x1 = RN16(x - x0) (x - x0 is exact in fp32; each rounding is good to 2^-11 of what it rounds: |x - x0 - x1| <= 2^-22 |x|, measured worst case
+// 2^-23, rms 4.2e-8 -- fp32 rounding itself: 3.4e-8 -- as long as x1 stays above fp16's denormal step 2^-24), and a product a * w is accumulated as a1 w0 + a0 w1 + a0 w0 (low order first) on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation; the dropped a1 w1 is <= 2^-22 |a w|.  Measured against fp64 the result is
 // more accurate than the fp32 MFMA chain it replaces and than the three-piece bf16 split of round 2
 // (tools/ubench/f16x2_emul.hip: rms error 1.5e-7 / 2.9e-7 / 4.0e-7 of rms(D) at K = 128 / 640 / 1280 against 2.1e-7 / 4.4e-7 /
 // 6.4e-7 for the fp32 chain and 1.7e-7 / 3.9e-7 / 5.5e-7 for bf16x3) at HALF the matrix-pipe time of bf16x3 (3 instead of 6

@@ -81,7 +81,8 @@ class DiffusionsEnsemble:
             guide = skw.get("guide")
             hard, mask = model._hard_tensor(hard_conds[m], 1, H, device, D)
             sd = model._sampler_desc(skw.get("n_guide_steps", 1), skw.get("t_start_guide", float("inf")),
-                                     skw.get("noise_std_extra_schedule_fn"), mask)
+                                     skw.get("noise_std_extra_schedule_fn"), mask,
+                                     scale_grad_by_std=skw.get("scale_grad_by_std", False))
             gd = guide.desc() if guide is not None else None
             noise_m = None
             if step_noise is not None:

@@ -38,9 +38,9 @@ def make_timesteps(batch_size, i, device):
 class GaussianDiffusionModel:
     def __init__(self, model=None, variance_schedule="exponential", n_diffusion_steps=100, clip_denoised=True,
                  predict_epsilon=False, loss_type="l2", context_model=None, **kwargs):
-        if not predict_epsilon or not clip_denoised or context_model is not None:
-            raise NotImplementedError("kernels implement predict_epsilon=True, clip_denoised=True, no context "
-                                      "(the configuration of the released MPD checkpoints)")
+        if not clip_denoised or context_model is not None:
+            raise NotImplementedError("kernels implement clip_denoised=True, no context (the configuration of the released MPD "
+                                      "checkpoints; the reference itself asserts on clip_denoised=False, diffusion_model_base.py:156)")
         self.model = model
         self.n_diffusion_steps = n_diffusion_steps
         if hasattr(model, "max_timesteps"):
@@ -83,7 +83,8 @@ class GaussianDiffusionModel:
                 self._noise_tables.pop(next(iter(self._noise_tables)))
         return self._noise_tables[key][1]
 
-    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_fn, hard_mask, n_streams=0, traj_index_base=0):
+    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_fn, hard_mask, n_streams=0, traj_index_base=0,
+                      scale_grad_by_std=False):
         s = _lib.SamplerDesc()
         s.n_diffusion_steps = self.n_diffusion_steps
         fp = C.POINTER(C.c_float)
@@ -100,6 +101,8 @@ class GaussianDiffusionModel:
         s.n_streams = int(n_streams)
         s.traj_index_base = int(traj_index_base)
         s.profiler = self.profiler
+        s.scale_grad_by_std = int(bool(scale_grad_by_std))
+        s.model_predicts_x0 = 0 if self.predict_epsilon else 1
         return s
 
     @staticmethod
@@ -129,7 +132,7 @@ class GaussianDiffusionModel:
                       sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0, warm_start_path_b=None,
                       guide=None, n_guide_steps=1, t_start_guide=float("inf"), noise_std_extra_schedule_fn=None,
                       n_robots=1, step_noise=None, seed=None, device="cuda", n_streams=0, traj_index_base=0,
-                      **sample_kwargs):
+                      scale_grad_by_std=False, **sample_kwargs):
         """diffusion_model_base.py:162-211.  Extensions: `n_robots` (batch = n_robots * n_samples, robot-major),
         `step_noise` [n_steps_total, B, H, D] + `warm_start_path_b` as x_T to inject every Gaussian draw (parity
         tests), `seed` for the in-kernel Philox stream otherwise, `traj_index_base` = global index of this call's first
@@ -145,7 +148,8 @@ class GaussianDiffusionModel:
         device = torch.device(device)
         lib = _lib.load()
         hard, mask = self._hard_tensor(hard_conds, n_robots, H, device, D)
-        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std_extra_schedule_fn, mask, n_streams, traj_index_base)
+        s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std_extra_schedule_fn, mask, n_streams, traj_index_base,
+                               scale_grad_by_std=scale_grad_by_std)
         n_total = n_diffusion_steps + n_diffusion_steps_without_noise
         if warm_start_path_b is not None:
             x = warm_start_path_b.to(device=device, dtype=torch.float32).contiguous().clone()
@@ -185,6 +189,8 @@ class GaussianDiffusionModel:
         `seed` for the Philox draw of x_T otherwise."""
         if context is not None:
             raise NotImplementedError("context")
+        if not self.predict_epsilon:
+            raise NotImplementedError("ddim_sample with predict_epsilon=False (the DDPM sampler implements it)")
         if guide is not None and not isinstance(guide, GuideManagerTrajectoriesWithVelocity):
             raise NotImplementedError("guide must be a mmd_amd GuideManagerTrajectoriesWithVelocity")
         B_total, H, D = shape
@@ -214,14 +220,15 @@ class GaussianDiffusionModel:
 
     @torch.no_grad()
     def sample_step(self, x, hard_conds, i, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
-                    noise_std_extra_schedule_fn=None, n_robots=1, noise=None, seed=None, traj_index_base=0):
+                    noise_std_extra_schedule_fn=None, n_robots=1, noise=None, seed=None, traj_index_base=0,
+                    scale_grad_by_std=False):
         """One `ddpm_sample_fn` call + the `apply_hard_conditioning` that follows it in the loop
         (sample_functions.py:40-86, diffusion_model_base.py:199-203), in place on x; `i` is the loop index
         (negative: t = 0).  This is what DiffusionsEnsemble interleaves across tiles (diffusion_ensemble.py:86-100)."""
         B_total, H, D = x.shape
         hard, mask = self._hard_tensor(hard_conds, n_robots, H, x.device, D)
         s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std_extra_schedule_fn, mask,
-                               traj_index_base=traj_index_base)
+                               traj_index_base=traj_index_base, scale_grad_by_std=scale_grad_by_std)
         gd = guide.desc() if guide is not None else None
         ws = self.model.workspace(B_total, x.device, sampler=True)
         if seed is None:

@@ -36,13 +36,16 @@ def device_sdf_textures(maps, device):
 
 
 class GuideManagerTrajectoriesWithVelocity:
-    def __init__(self, dataset, cost=None, clip_grad=True, clip_grad_rule="norm", max_grad_norm=1.0,
+    def __init__(self, dataset, cost=None, clip_grad=True, clip_grad_rule="norm", max_grad_norm=1.0, max_grad_value=0.1,
                  env_id="EnvEmpty2D", obstacle_cutoff_margin=0.05, robot_radius=ROBOT_RADIUS,
                  weight_grad_cost_collision=2e-2, weight_grad_cost_smoothness=8e-2, trajectory_duration=5.0,
                  n_support_points=64, sigma_gp=1.0, n_robots=1, robot_env_ids: Optional[Sequence[str]] = None,
                  extra_objects_only=False, extra_objects=None, device="cuda", tensor_args=None, **kwargs):
-        if not clip_grad or clip_grad_rule != "norm":
-            raise NotImplementedError("MPD uses clip_grad=True, clip_grad_rule='norm' (mpd.py:258-265)")
+        # GuideManager.clip_gradient (guides.py:228-259).  NB the reference class defaults to clip_grad=False; MPD / MPDEnsemble
+        # construct it with clip_grad=True, rule 'norm' (mpd.py:258-265), which is the default here
+        if clip_grad and clip_grad_rule not in ("norm", "value"):
+            raise NotImplementedError(clip_grad_rule)
+        self.clip_grad, self.clip_grad_rule, self.max_grad_value = bool(clip_grad), clip_grad_rule, float(max_grad_value)
         self.dataset = dataset
         self.device = torch.device(tensor_args["device"] if tensor_args else device)
         self.n_robots = n_robots
@@ -129,6 +132,8 @@ class GuideManagerTrajectoriesWithVelocity:
         d.margin, d.dt, d.sigma_gp = self.margin, self.dt, self.sigma_gp
         d.weight_collision, d.weight_smoothness = self.weight_collision, self.weight_smoothness
         d.max_grad_norm = self.max_grad_norm
+        d.clip_grad_rule = 2 if not self.clip_grad else (1 if self.clip_grad_rule == "value" else 0)
+        d.max_grad_value = self.max_grad_value
         if self._xs is not None:
             d.extra_spheres_dev, d.n_extra_spheres = self._xs.data_ptr(), self._xs.shape[0]
         if self._xb is not None:

@@ -409,8 +409,19 @@ def grad_constraint(xu, grp: ConstraintGroup):
     return g
 
 
+def clip_gradient(g, rule="norm", max_grad_norm=1.0, max_grad_value=0.1):
+    """GuideManager.clip_gradient (guides.py:228-259): rule 'norm' | 'value' | None (clip_grad = False)."""
+    if rule == "norm":
+        return clip_grad_by_norm(g, max_grad_norm)
+    if rule == "value":
+        return torch.clip(g, -max_grad_value, max_grad_value)
+    if rule is None:
+        return g
+    raise NotImplementedError(rule)
+
+
 def guide_grad(x_norm, gp: GuideParams, cons: Sequence[ConstraintGroup] = (), clip_mode="reference",
-               return_terms=False):
+               return_terms=False, clip_rule="norm", max_grad_value=0.1):
     """GuideManagerTrajectoriesWithVelocity.forward (guides.py:180-226), closed form: un-normalise, per-cost
     gradient w.r.t. the UN-normalised trajectory, per-point norm clip, zero rows 0 and H-1, weight, sum, negate.
     The result is added to the NORMALISED x by the caller (sample_functions.py:104) -- reproduced as is."""
@@ -424,7 +435,7 @@ def guide_grad(x_norm, gp: GuideParams, cons: Sequence[ConstraintGroup] = (), cl
     total = torch.zeros_like(x_norm)
     clipped_terms = []
     for g, w in terms:
-        gc = clip_grad_by_norm(g, gp.max_grad_norm)
+        gc = clip_gradient(g, clip_rule, gp.max_grad_norm, max_grad_value).clone()
         gc[..., 0, :] = 0.0
         gc[..., -1, :] = 0.0
         clipped_terms.append(gc)
@@ -501,7 +512,8 @@ def apply_hard_conditioning(x, hard_conds):
 
 
 def ddpm_sample_step(sd, tb, x, hard_conds, i, *, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
-                     noise=None, noise_std_extra=1.0, n_levels=3, eps_rel_perturb=None):
+                     noise=None, noise_std_extra=1.0, n_levels=3, eps_rel_perturb=None, scale_grad_by_std=False,
+                     predict_epsilon=True):
     """ddpm_sample_fn (sample_functions.py:40-86) + p_mean_variance / predict_start_from_noise / q_posterior
     (diffusion_model_base.py:126-160) with predict_epsilon=True, clip_denoised=True.  `i` is the loop index (may be
     negative: t := 0, sample_functions.py:53-54); `noise` [B,H,D] is the injected randn_like draw; `guide` is a
@@ -513,14 +525,18 @@ def ddpm_sample_step(sd, tb, x, hard_conds, i, *, guide=None, n_guide_steps=1, t
     eps = unet_forward(sd, x, tt, n_levels)
     if eps_rel_perturb is not None:
         eps = eps * (1.0 + eps_rel_perturb)
-    x_recon = tb["sqrt_recip_alphas_cumprod"][t] * x - tb["sqrt_recipm1_alphas_cumprod"][t] * eps
+    if predict_epsilon:
+        x_recon = tb["sqrt_recip_alphas_cumprod"][t] * x - tb["sqrt_recipm1_alphas_cumprod"][t] * eps
+    else:
+        x_recon = eps                                                     # the model predicts x0 directly, :131-141
     x_recon = x_recon.clamp(-1.0, 1.0)
     mean = tb["posterior_mean_coef1"][t] * x_recon + tb["posterior_mean_coef2"][t] * x
     model_std = torch.exp(0.5 * tb["posterior_log_variance_clipped"][t])
+    model_var = torch.exp(tb["posterior_log_variance_clipped"][t])
     x = mean
     if guide is not None and i < t_start_guide:
         for _ in range(n_guide_steps):                                    # guide_gradient_steps, :89-107
-            x = x + guide(x)
+            x = x + (model_var * guide(x) if scale_grad_by_std else guide(x))
             x = apply_hard_conditioning(x, hard_conds)
     if noise is None:
         noise = torch.zeros_like(x)
@@ -530,7 +546,8 @@ def ddpm_sample_step(sd, tb, x, hard_conds, i, *, guide=None, n_guide_steps=1, t
 
 
 def p_sample_loop(sd, tb, x_init, hard_conds, n_diffusion_steps, step_noise, *, guide=None, n_guide_steps=20,
-                  t_start_guide=float("inf"), noise_std_extra=0.5, n_diffusion_steps_without_noise=0, n_levels=3):
+                  t_start_guide=float("inf"), noise_std_extra=0.5, n_diffusion_steps_without_noise=0, n_levels=3,
+                  scale_grad_by_std=False, predict_epsilon=True):
     """GaussianDiffusionModel.p_sample_loop (diffusion_model_base.py:162-211), with the torch.randn draws injected:
     x_init [B,H,D] is x_T (or the warm start), step_noise [n_steps,B,H,D] one draw per loop iteration in order.
     Returns chain [n_steps+1, B,H,D] (chain[0] = conditioned x_init, chain[-1] = result)."""
@@ -540,7 +557,7 @@ def p_sample_loop(sd, tb, x_init, hard_conds, n_diffusion_steps, step_noise, *, 
     for i in reversed(range(-n_diffusion_steps_without_noise, n_diffusion_steps)):
         x = ddpm_sample_step(sd, tb, x, hard_conds, i, guide=guide, n_guide_steps=n_guide_steps,
                              t_start_guide=t_start_guide, noise=step_noise[k], noise_std_extra=noise_std_extra,
-                             n_levels=n_levels)
+                             n_levels=n_levels, scale_grad_by_std=scale_grad_by_std, predict_epsilon=predict_epsilon)
         x = apply_hard_conditioning(x, hard_conds)
         chain.append(x)
         k += 1

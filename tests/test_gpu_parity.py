@@ -143,6 +143,58 @@ def test_guide_single_eval_golden():
     assert float((guide(x3).cpu() - torch.from_numpy(g["empty32_B4"])).abs().max()) < 2e-6
 
 
+def test_reference_options_golden():
+    """Options of the reference that MPD / MPDEnsemble leave at their defaults, against the reference itself (g16): gradient
+    clipping by value and switched off (guides.py:228-259), scale_grad_by_std (sample_functions.py:100-101: the guide gradient
+    times the posterior variance -- a well-conditioned chain, so every row is held to the north-star tolerance) and
+    GaussianDiffusionModel(predict_epsilon=False) (diffusion_model_base.py:131-141)."""
+    from mmd_amd.diffusion_model import GaussianDiffusionModel, ddpm_sample_fn
+    from mmd_amd.temporal_unet import TemporalUnet
+    g = np.load(os.path.join(GOLDEN, "g16_options.npz"))
+    T, B, s_x, s_n = (int(v) for v in g["meta"])
+    starts, goals, soft, hard = cases.highways_case()
+    x = (torch.from_numpy(synth.synth_noise(7, (8, H, D))) * 0.6).cuda()
+    gc = _gc()
+    pairs = [gc.to_cost_constraint(grp) for grp in (soft, hard)]
+
+    def guide_with(**kw):
+        from mmd_amd.guides import GuideManagerTrajectoriesWithVelocity
+        gd = GuideManagerTrajectoriesWithVelocity(gc.dataset(), env_id="EnvHighways2D", device="cuda", **kw)
+        gd.add_extra_costs([p[0] for p in pairs], [p[1] for p in pairs])
+        return gd
+    e_val = float((guide_with(clip_grad=True, clip_grad_rule="value", max_grad_value=float(g["max_grad_value"]))(x).cpu()
+                   - torch.from_numpy(g["guide_clip_value"])).abs().max())
+    ref_off = torch.from_numpy(g["guide_clip_off"])
+    e_off = float((guide_with(clip_grad=False)(x).cpu() - ref_off).abs().max() / ref_off.abs().max())
+    parity_log.record("reference_options", "guide_clip_by_value_maxabs", None, e_val, bound=2e-6)
+    parity_log.record("reference_options", "guide_no_clip_rel_maxabs", None, e_off, bound=2e-6)
+    assert e_val < 2e-6 and e_off < 2e-6, (e_val, e_off)
+    xT = torch.from_numpy(synth.synth_noise(s_x, (B, H, D)))
+    steps = torch.from_numpy(synth.synth_noise(s_n, (T + 1, B, H, D)))
+    hc = cases.hard_conds_for(starts[3], goals[3])
+    model = gc.hip_model(T)
+    chain = model.run_inference(None, hc, n_samples=B, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn,
+                                guide=guide_with(), n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                                noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=1,
+                                warm_start_path_b=xT.cuda(), step_noise=steps.cuda(), scale_grad_by_std=True).cpu()
+    ref = torch.from_numpy(g["chain_scale_grad_by_std"])
+    e_std = max(rel_l2(chain[k], ref[k]) for k in range(T + 2))
+    parity_log.record("reference_options", "chain_scale_grad_by_std", None, e_std, bound=TOL_FINAL)
+    assert e_std < TOL_FINAL, e_std
+    unet = TemporalUnet(state_dim=4, n_support_points=64, unet_input_dim=32, dim_mults=(1, 2, 4))
+    unet.load_state_dict(synth.synth_unet_state_dict(0))
+    m0 = GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=False)
+    chain0 = m0.run_inference(None, hc, n_samples=B, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn, guide=None,
+                              noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=1,
+                              warm_start_path_b=xT.cuda(), step_noise=steps.cuda()).cpu()
+    ref0 = torch.from_numpy(g["chain_predict_x0"])
+    e_x0 = max(rel_l2(chain0[k], ref0[k]) for k in range(T + 2))
+    parity_log.record("reference_options", "chain_predict_x0", None, e_x0, bound=TOL_FINAL)
+    assert e_x0 < TOL_FINAL, e_x0
+    with pytest.raises(NotImplementedError):
+        m0.ddim_sample((B, H, D), hc, T)
+
+
 def _raw_guide_grad(guide, x, patch):
     """guide(x) through the C ABI with a patched descriptor (isolates one cost term)."""
     import ctypes as C

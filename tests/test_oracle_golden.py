@@ -231,3 +231,31 @@ def test_g15_distribution_oracle_subset():
     assert cases.mean_z(vo, vr) < cases.Z_MAX
     # (matched pairs do NOT coincide here: with 31 x 63 soft constraints crossing at the centre every trajectory sits on some
     # switching surface, the reference differs from its own perturbed self by 1e-1 on this case's final row -- `sens` of g6)
+
+
+def test_g16_options_oracle():
+    """The oracle's restatement of the options the planners leave at their defaults, against the reference (g16): clip by value /
+    no clip (guides.py:228-259), scale_grad_by_std (sample_functions.py:100-101), predict_epsilon=False
+    (diffusion_model_base.py:131-141)."""
+    g = np.load(os.path.join(GOLDEN, "g16_options.npz"))
+    T, B, s_x, s_n = (int(v) for v in g["meta"])
+    starts, goals, soft, hard = cases.highways_case()
+    gp = cases.guide_params("EnvHighways2D")
+    x = torch.from_numpy(synth.synth_noise(7, (8, H, D))) * 0.6
+    mv = float(g["max_grad_value"])
+    assert float((O.guide_grad(x, gp, [soft, hard], clip_rule="value", max_grad_value=mv) - torch.from_numpy(g["guide_clip_value"])).abs().max()) <= 1e-7
+    assert float((O.guide_grad(x, gp, [soft, hard], clip_rule=None) - torch.from_numpy(g["guide_clip_off"])).abs().max()) <= 2e-5   # (unclipped GP terms ~ 1e2)
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    tb = O.schedule_tables(T)
+    xT = torch.from_numpy(synth.synth_noise(s_x, (B, H, D)))
+    steps = torch.from_numpy(synth.synth_noise(s_n, (T + 1, B, H, D)))
+    hc = cases.hard_conds_for(starts[3], goals[3])
+    chain = O.p_sample_loop(sd, tb, xT, hc, T, steps, guide=lambda y: O.guide_grad(y, gp, [soft, hard]), n_guide_steps=20,
+                            t_start_guide=ceil(0.5 * T), noise_std_extra=0.5, n_diffusion_steps_without_noise=1,
+                            scale_grad_by_std=True)
+    ref = torch.from_numpy(g["chain_scale_grad_by_std"])
+    assert max(rel_l2(chain[k], ref[k]) for k in range(T + 2)) < 1e-4
+    chain0 = O.p_sample_loop(sd, tb, xT, hc, T, steps, guide=None, noise_std_extra=0.5, n_diffusion_steps_without_noise=1,
+                             predict_epsilon=False)
+    ref0 = torch.from_numpy(g["chain_predict_x0"])
+    assert max(rel_l2(chain0[k], ref0[k]) for k in range(T + 2)) < 1e-4

@@ -19,6 +19,8 @@ Fixtures:
   g12_boundary.npz     outer-boundary contract: check_rr_collisions / compute_collision on the shapes CBS / PP pass
   g13_split_constraints.npz  MPDEnsemble.split_cost_constraints_to_tasks + the per-tile range / transform shift
   g14_extra_objects.npz      a map with extra objects (spheres + boxes): guide, extra-objects-only guide, occupancy
+  g16_options.npz            options the planners leave at their defaults: clip_grad_rule 'value' / clip_grad False, scale_grad_by_std,
+                             predict_epsilon False
   g15_distribution_*.npz     guided sampling over 32 noise seeds: final rows of every sample, their position mean / covariance per
                              support point, free / collision split and soft-constraint violation counts (distribution-level parity)
 """
@@ -651,11 +653,59 @@ def g15():
               "pairs", int(viol.sum()), flush=True)
 
 
+def g16():
+    """Reference options MPD / MPDEnsemble never set (missing #5): GuideManager.clip_gradient by value and switched off
+    (guides.py:228-259), guide_gradient_steps' scale_grad_by_std (sample_functions.py:100-101) and GaussianDiffusionModel(
+    predict_epsilon=False) (diffusion_model_base.py:131-141).  Inputs as g5 / g6: Highways guide inputs (seed 7), chains with
+    injected noise (T = 25, B = 4)."""
+    from ref_harness import GaussianDiffusionModel, TemporalUnet
+    out = {}
+    x = torch.from_numpy(synth.synth_noise(7, (8, H, D))) * 0.6
+    starts, goals, soft, hard = highways_case()
+    for key, kw in (("guide_clip_value", dict(clip_grad=True, clip_grad_rule="value")), ("guide_clip_off", dict(clip_grad=False))):
+        with quiet():
+            guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS)
+        guide.clip_grad, guide.clip_grad_rule = kw["clip_grad"], kw.get("clip_grad_rule", "norm")
+        guide.add_extra_costs([make_cost_constraint(robot, *soft, True), make_cost_constraint(robot, *hard, False)], [2e-2, 2e-1])
+        out[key] = guide(x).numpy()
+        out["max_grad_value"] = np.float32(guide.max_grad_value)
+    # scale_grad_by_std through run_inference's **diffusion_kwargs -> sample_fn
+    T, B = 25, 4
+    sd = synth.synth_unet_state_dict(0)
+    xT = synth.synth_noise(41, (B, H, D))
+    steps = synth.synth_noise(42, (T + 1, B, H, D))
+    with quiet():
+        model = make_model(sd, T)
+        guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS)
+    guide.add_extra_costs([make_cost_constraint(robot, *soft, True), make_cost_constraint(robot, *hard, False)], [2e-2, 2e-1])
+    with quiet(), injected_noise([xT] + list(steps)) as q:
+        chain = model.run_inference(None, hard_conds_for(starts[3], goals[3]), n_samples=B, horizon=H, return_chain=True,
+                                    sample_fn=ddpm_sample_fn, guide=guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                                    noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=1,
+                                    scale_grad_by_std=True)
+        assert len(q) == 0
+    out["chain_scale_grad_by_std"] = chain.numpy()
+    # predict_epsilon = False: the network output is x_recon (no guide: the prior chain)
+    unet = TemporalUnet(state_dim=4, n_support_points=64, unet_input_dim=32, dim_mults=(1, 2, 4))
+    m0 = GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=False)
+    m0.load_state_dict({"model." + k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m0.eval()
+    with quiet(), injected_noise([xT] + list(steps)) as q:
+        chain0 = m0.run_inference(None, hard_conds_for(starts[3], goals[3]), n_samples=B, horizon=H, return_chain=True,
+                                  sample_fn=ddpm_sample_fn, guide=None, noise_std_extra_schedule_fn=lambda x: 0.5,
+                                  n_diffusion_steps_without_noise=1)
+        assert len(q) == 0
+    out["chain_predict_x0"] = chain0.numpy()
+    out["meta"] = np.array([T, B, 41, 42])
+    np.savez_compressed(os.path.join(OUT, "g16_options.npz"), **out)
+    print("   g16:", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim > 0})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16}[name]()
     print("done")

@@ -163,8 +163,16 @@ __device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* 
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             if (PARTS & 1) {
+#ifdef AGPR_ACC   // the accumulators in the AGPR half of the register file (inline asm: timing experiment only, no hazard padding)
+              f32x4& c = acc[2 * hp + sm][t];
+              if (zero) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a[cur][sm][1]), "v"(b[ri][t][0]));
+              else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a[cur][sm][1]), "v"(b[ri][t][0]));
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a[cur][sm][0]), "v"(b[ri][t][1]));
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a[cur][sm][0]), "v"(b[ri][t][0]));
+#else
               if (zero) vb_three<true>(acc[2 * hp + sm][t], a[cur][sm], b[ri][t]);
               else vb_three<false>(acc[2 * hp + sm][t], a[cur][sm], b[ri][t]);
+#endif
             } else {
               const unsigned x = a[cur][sm][0][0] ^ a[cur][sm][1][3] ^ b[ri][t][0][1] ^ b[ri][t][1][2];
               acc[2 * hp + sm][t][0] += __builtin_bit_cast(float, (x & 0x007fffffu) | 0x3f800000u) * 1e-9f;
