@@ -108,8 +108,8 @@ typedef struct mmd_guide_desc {
   /* Extra objects of the environment (EnvBase.obj_extra_list, env_base.py:76-89: an ObjectField of primitive fields at the
    * identity pose), evaluated ANALYTICALLY as the reference does -- one more signed-distance field next to the grids of the
    * fixed objects (df_obj_l = [grid, *obj_extra_list]; cost = max over the fields, distance_fields.py:110-126): spheres
-   * |p - c| - r (MultiSphereField, primitives.py:108-115), boxes as the rounded box of the fixed objects (MultiBoxField,
-   * primitives.py:326-333: corner radius 0.15 x the smaller size), minimum over all of them.  n = 0 / NULL: the env has none (every shipped map: an empty sphere list, sdf = 1). */
+   * |p - c| - r (MultiSphereField, primitives.py:108-115), boxes as the rounded box of the fixed objects (MultiBoxField --
+   * an ALIAS of MultiRoundedBoxField, primitives.py:345 -- i.e. primitives.py:326-333: corner radius 0.15 x the smaller size), minimum over all of them.  n = 0 / NULL: the env has none (every shipped map: an empty sphere list, sdf = 1). */
   const float* extra_spheres_dev;    /* [n_extra_spheres][4]: (cx, cy, r, 0) */
   const float* extra_boxes_dev;      /* [n_extra_boxes][4]: (cx, cy, half size x, half size y) */
   int32_t n_extra_spheres, n_extra_boxes;

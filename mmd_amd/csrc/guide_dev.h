@@ -43,7 +43,7 @@ __device__ __forceinline__ float extra_sdf(const float4* __restrict__ xs, int n_
     if (d < best) { best = d; gx = n > 0.f ? dx / n : 0.f; gy = n > 0.f ? dy / n : 0.f; }
   }
   for (int i = 0; i < n_xb; ++i) {
-    // MultiBoxField = the rounded box of the fixed objects (primitives.py:326-333): q = |p - c| - half + rad, sdf = min(max q,
+    // MultiBoxField (an alias of MultiRoundedBoxField, primitives.py:345) = the rounded box of the fixed objects (primitives.py:326-333): q = |p - c| - half + rad, sdf = min(max q,
     // 0) + ||relu(q)|| - rad; b = (cx, cy, half x, half y), rad = 0.15 x the smaller SIZE
     const float4 b = xb[i];
     const float rad = 0.3f * fminf(b.z, b.w);

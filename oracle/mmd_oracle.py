@@ -260,7 +260,7 @@ class GuideParams:
     # the env's extra objects (EnvBase.obj_extra_list, env_base.py:76-89: one ObjectField of primitive fields, identity
     # pose), evaluated analytically next to the grids of the fixed objects.  None: the env has no obj_extra_list
     extra_spheres: torch.Tensor = None           # [n,3] (cx, cy, r)          MultiSphereField (primitives.py:108-115)
-    extra_boxes: torch.Tensor = None             # [n,4] (cx, cy, sx, sy)     MultiBoxField (rounded, primitives.py:326-333), sizes
+    extra_boxes: torch.Tensor = None             # [n,4] (cx, cy, sx, sy)     MultiBoxField (= MultiRoundedBoxField by the alias at primitives.py:345; :326-333), sizes
     extra_only: bool = False                     # use_guide_on_extra_objects_only (mpd.py:216-219): this field alone
 
     @property
@@ -315,7 +315,7 @@ def extra_objects_sdf(p, gp: GuideParams):
             d = torch.norm(pp.unsqueeze(-2) - gp.extra_spheres[:, :2], dim=-1) - gp.extra_spheres[:, 2]
             fields.append(torch.min(d, dim=-1)[0])
     if gp.extra_boxes is not None and gp.extra_boxes.shape[0] > 0:
-        # MultiBoxField = the rounded box of primitives.py:326-333 (radius 0.15 x the smaller size), as the fixed objects
+        # MultiBoxField (alias of MultiRoundedBoxField, primitives.py:345) = the rounded box of :326-333 (radius 0.15 x the smaller size), as the fixed objects
         sizes = gp.extra_boxes[:, 2:]
         radius = torch.min(sizes, dim=-1)[0] * 0.15
         q = torch.abs(pp.unsqueeze(-2) - gp.extra_boxes[:, :2]) - sizes / 2 + radius.unsqueeze(-1)

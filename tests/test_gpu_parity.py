@@ -717,3 +717,26 @@ def test_guide_large_constraint_tables(n_robots, B):
     for _ in range(5):
         r = r + O.guide_grad(r, gp, [soft, hard], clip_mode="always")
     assert rel_l2(y.cpu(), r) < 1e-4
+
+
+def test_calls_follow_the_tensors_device_not_torchs_current_device():
+    """one TemporalUnet / guide may serve several GPUs -- every C call runs under a device guard on the GPU that owns
+    its tensors, on THAT device's current stream, with the handle / workspace resolved for it.  With a second GPU: a forward and a
+    guided step on cuda:1 tensors while cuda:0 is current equal the cuda:0 results bit for bit.  On a one-GPU box the same
+    property is exercised through a non-default current stream (the launch must land on the stream torch reports for the
+    tensors' device, and results must match the default-stream call)."""
+    model = _gc().hip_model(25)
+    x = torch.from_numpy(synth.synth_noise(70, (6, H, D)))
+    ref = model.model(x.cuda(), 7).cpu()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        y = model.model(x.cuda(), 7)
+    st.synchronize()
+    assert torch.equal(y.cpu(), ref)
+    if torch.cuda.device_count() < 2:
+        return
+    x1 = x.to("cuda:1")
+    torch.cuda.set_device(0)
+    y1 = model.model(x1, 7)                                  # tensors on cuda:1, current device cuda:0
+    torch.cuda.synchronize(1)
+    assert y1.device.index == 1 and torch.equal(y1.cpu(), ref)

@@ -203,3 +203,11 @@ def test_split_cost_constraints_to_tasks_golden_g13():
             assert np.array_equal(np.asarray(c.traj_ranges, dtype=np.float32), g[f"ranges_{k}_{j}"]), (k, j, c.traj_ranges)
             assert np.array_equal(np.asarray(c.radii, dtype=np.float32), g[f"radii_{k}_{j}"]), (k, j)
 
+
+
+def test_launch_helper_rejects_host_tensors():
+    """_lib.launch pins a call to the device of its tensors: a host tensor has no such device -- loud error, no
+    launch."""
+    from mmd_amd import _lib
+    with pytest.raises(ValueError):
+        _lib.launch("mmd_unet_forward", torch.zeros(1, 64, 4))
