@@ -611,227 +611,6 @@ __device__ __forceinline__ void rowform_to_rd(const float* xslab, char* slab, co
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// The L = 16 stages on v_mfma_f32_32x32x16_f16 (8 passes: the same FLOP rate as 16x16x32, HALF the A / B operand reads from the
-// register file per FLOP and half the MFMA instructions).  An M tile is a sample PAIR: matrix row r < 16 = position r of sample
-// 2 mt, row r >= 16 = position (r - 20) mod 16 of sample 2 mt + 1 -- rotated by four rows, because the second sample's slab rows
-// start RPS = 20 rows = 320 B after the first's and a ds_read_b128 is served in groups of 16 lanes that mix the two 16-lane rows
-// (rows {0-3, 12-15} with {20-27}: with the rotation the 16 lanes of every group hit 16 different 16-byte bank groups of the same
-// Rd slab the 16x16 forms use; unrotated the second sample's rows collide 2-way with the first's).  An N tile is the wave's 32
-// channels (column n = channel 32 wave + n), a K step 16 channels: lane (row r = lane & 31, h = lane >> 5) reads the 8 channels of
-// block 2 ks + h.  C/D layout: lane (n, h) holds for channel n the matrix rows 8 (i >> 2) + 4 h + (i & 3), i = 0 .. 15, i.e. of
-// the even sample positions 4 h + (i & 3) (i < 4) and 8 + 4 h + (i & 3) (4 <= i < 8), of the odd sample (i >= 8) positions
-// (12 - 12 h) + (i & 3) and 4 + 4 h + (i & 3): both samples own the same two position sets {0-3, 8-11} / {4-7, 12-15}, one per
-// wave half, so every per-sample reduction below (four-value chains per position set, combined by commutative additions) is the
-// same arithmetic for an even and an odd sample -- results stay bitwise independent of the batch position.
-// Weights: per n-tile of 32 columns [tap][K step ks][piece][lane] x 16 B (pack_rm).
-// ----------------------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ f32x16 mfma_w(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-template <bool ZERO>
-__device__ __forceinline__ void vw_three(f32x16& x, const u32x4 (&a)[2], const u32x4 (&b)[2]) {
-  f32x16 c;
-  if constexpr (ZERO) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = 0.f;
-  } else {
-    c = x;
-  }
-  c = mfma_w(a[1], b[0], c);
-  c = mfma_w(a[0], b[1], c);
-  c = mfma_w(a[0], b[0], c);
-  x = c;
-  __builtin_amdgcn_sched_barrier(0);
-}
-template <class GEO> struct RmGeo : GEO {
-  static constexpr int KS = GEO::KC * 2;                     // K steps of 16 channels
-  static constexpr int FRAGS5 = 5 * KS * 2;                  // weight fragments per 32-column n-tile of a k = 5 conv
-  // slab offset of channel block cb = 2 ks + h (the two blocks of a K step are neighbours inside one lane group's region)
-  static constexpr int blk(int cb) { return (cb / GEO::KC) * GEO::G + (cb % GEO::KC) * GEO::BX; }
-};
-// the lane's A offset inside the slab: (row of its matrix row, block half h); M tile mt adds 2 mt RPS rows, K step ks blk(2 ks)
-template <class GEO>
-__device__ __forceinline__ int rm_lane_a(int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const int row = r < 16 ? r : GEO::RPS + ((r - 20) & 15);
-  return row * 16 + h * GEO::BX;
-}
-template <class GEO, int MT>
-__device__ __forceinline__ void rm_load_a(u32x4 (&a)[MT][2], const char* va, int rowoff, int ks) {
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      a[mt][q] = *reinterpret_cast<const u32x4*>(va + q * GEO::PS + RmGeo<GEO>::blk(2 * ks) + (2 * mt * GEO::RPS + rowoff) * 16);
-}
-__device__ __forceinline__ void rm_load_b(u32x4 (&b)[2], const u32x4* w, int step) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) b[q] = w[(step * 2 + q) * 64];
-}
-template <int RD>
-__device__ __forceinline__ void rm_ring_load(u32x4 (&b)[RD][2], const u32x4* w) {
-#pragma unroll
-  for (int i = 0; i < RD; ++i) rm_load_b(b[i], w, i);
-  MMD_PIN_LOADS();
-}
-// acc[mt] (+)= conv over TAPS taps (slab rows TAP0 .. relative to the output position) x the C channels of the slab; va = slab +
-// rm_lane_a; w = the wave's n-tile pack + lane; b = ring pre-loaded with the first RD steps.  RES: the stage's 1x1 residual conv
-// rides on the centre tap's A fragments (wr = [K step][piece] + lane).  FRESH: start from zero.
-template <class GEO, int TAP0, int TAPS, bool FRESH, bool RES, int MT, int RD>
-__device__ __forceinline__ void rm_taps(f32x16 (&acc)[MT], f32x16 (&res)[MT], const char* va, const u32x4* w, const u32x4* wr,
-                                        u32x4 (&b)[RD][2]) {
-  constexpr int KS = RmGeo<GEO>::KS, STEPS = TAPS * KS;
-  u32x4 a[2][MT][2];                                         // double-buffered by step
-  rm_load_a<GEO, MT>(a[0], va, TAP0, 0);
-  constexpr int C0 = (2 - TAP0) * KS;                        // the centre tap's first step
-  constexpr int RES_LOOK = C0 < 6 ? C0 : 6;
-  u32x4 brp[RES ? KS : 1][2];
-#pragma unroll
-  for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int st = tap * KS + ks, ri = st % RD, cur = st & 1;
-      const bool zero = FRESH && st == 0, last_ks = ks + 1 == KS, with_res = RES && TAP0 + tap == 2;
-      if constexpr (RES) {
-        if (st + RES_LOOK >= C0 && st + RES_LOOK < C0 + KS) rm_load_b(brp[st + RES_LOOK - C0], wr, st + RES_LOOK - C0);
-      }
-      // the next step's A fragments (past the last step: a valid, unused read)
-      rm_load_a<GEO, MT>(a[cur ^ 1], va, last_ks ? TAP0 + tap + 1 : TAP0 + tap, last_ks ? 0 : ks + 1);
-      MMD_PIN_LOADS();
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (zero) vw_three<true>(acc[mt], a[cur][mt], b[ri]);
-        else vw_three<false>(acc[mt], a[cur][mt], b[ri]);
-      }
-      if constexpr (RES) {
-        if (with_res) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            if (FRESH && ks == 0) vw_three<true>(res[mt], a[cur][mt], brp[ks]);
-            else vw_three<false>(res[mt], a[cur][mt], brp[ks]);
-          }
-        }
-      }
-      if (st + RD < STEPS) rm_load_b(b[ri], w, st + RD);
-      MMD_PIN_LOADS();
-    }
-}
-// sum over a lane's eight values of sample sl (0: even, 1: odd) of an M tile, f(value, running sum) folded over the four
-// registers of each position set separately and the two chains added: an odd sample's lanes hold the position sets of the even
-// sample's OTHER wave half (in the other register order), and a + b = b + a, so both samples get the same arithmetic.
-template <class F>
-__device__ __forceinline__ float rm_sum8(const f32x16& t, int sl, F f) {
-  float c0 = 0.f, c1 = 0.f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    c0 = f(t[8 * sl + r], c0);
-    c1 = f(t[8 * sl + 4 + r], c1);
-  }
-  return c0 + c1;
-}
-__device__ __forceinline__ float row_sum16(float v) {        // sum over the 16 lanes of a DPP row, in all of them
-  v = dpp_add<0xB1>(v);
-  v = dpp_add<0x4E>(v);
-  v = dpp_add<0x141>(v);
-  v = dpp_add<0x140>(v);
-  return v;
-}
-// GroupNorm + Mish of the 32x32 tiles acc[mt] (raw f16x2 conv output: true value = acc * isc * inv[sample]) + add(mt, i); a
-// group = 16 adjacent channels (one DPP row) x the sample's 16 positions (both wave halves), NG = 256 values; sample = 2 mt + (i >> 3)
-template <int MT, bool ACT, class ADD>
-__device__ __forceinline__ void rm_gn_mish(f32x16 (&acc)[MT], float bias, float gamma, float beta, float isc,
-                                           const float (&inv)[2 * MT], const ActScale& as, ADD add) {
-  constexpr float inv_n = 1.f / 256.f;
-  const float bmean = row_sum16(bias) * 16.f * inv_n;
-  float k[2 * MT], sum[2 * MT], dm[2 * MT], sq[2 * MT];
-#pragma unroll
-  for (int s = 0; s < 2 * MT; ++s) {
-    k[s] = isc * inv[s];
-    sum[s] = row_sum16(rm_sum8(acc[s >> 1], s & 1, [](float x, float c) { return c + x; }) * k[s]);
-  }
-#pragma unroll
-  for (int s = 0; s < 2 * MT; ++s) sum[s] = add_xor32(sum[s]);
-#pragma unroll
-  for (int s = 0; s < 2 * MT; ++s) {
-    const float mean = fmaf(sum[s], inv_n, bmean);
-    dm[s] = mean - bias;
-    const float ks = k[s], d0 = dm[s];
-    sq[s] = row_sum16(rm_sum8(acc[s >> 1], s & 1, [&](float x, float c) {
-      const float d = fmaf(x, ks, -d0);
-      return fmaf(d, d, c);
-    }));
-  }
-#pragma unroll
-  for (int s = 0; s < 2 * MT; ++s) sq[s] = add_xor32(sq[s]);
-#pragma unroll
-  for (int s = 0; s < 2 * MT; ++s) {
-    const float rstd = __builtin_amdgcn_rsqf(fmaf(sq[s], inv_n, 1e-5f));
-    GnCoef cf = gn_coef(dm[s], rstd, gamma, beta);
-    cf.sa *= k[s];
-    f32x16& t = acc[s >> 1];
-#pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-      const int i = 8 * (s & 1) + r;
-      const f32x2_t o = gn_mish2<ACT>(f32x2_t{t[i], t[i + 1]}, cf, f32x2_t{add(s >> 1, i), add(s >> 1, i + 1)}, as);
-      t[i] = o.x;
-      t[i + 1] = o.y;
-    }
-  }
-}
-// per-sample |x| maxima of the tiles -> mx region 0 (and region2 if > 0): slots 2 wave + {0, 1} of MX_SLOTS = 8 (the wave's two
-// halves; the two 16-lane rows of a half are combined first)
-template <int MT>
-__device__ __forceinline__ void rm_dyn_out(const f32x16 (&acc)[MT], float* mx, int wave, int lane, int region2) {
-#pragma unroll
-  for (int s = 0; s < 2 * MT; ++s) {
-    float m = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) m = fmaxf(m, fabsf(acc[s >> 1][8 * (s & 1) + r]));
-    m = row_max16(m);
-    m = max_xor16(m);
-    if ((lane & 31) == 0) {
-      mx[s * MX_SLOTS + 2 * wave + (lane >> 5)] = m;
-      if (region2) mx[region2 * MX_REGION + s * MX_SLOTS + 2 * wave + (lane >> 5)] = m;
-    }
-  }
-}
-// the lane's two store offsets inside the slab for channel c = 32 wave + n of a C-channel Rd slab: vs[0] = even sample, rows 2 + 4 h
-// + r (registers r = 0 .. 3; registers 4 .. 7: eight rows further); vs[1] = odd sample, registers 8 .. 11 at rows 2 + (12 - 12 h) + r
-// (registers 12 .. 15 at the even sample's row offset + RPS + 4 rows)
-template <class GEO>
-__device__ __forceinline__ void rm_lane_s(int (&vs)[2], int wave, int lane) {
-  const int n = lane & 31, h = lane >> 5, c = 32 * wave + n, cb = c >> 3;
-  const int base = (cb / GEO::KC) * GEO::G + (cb % GEO::KC) * GEO::BX + (c & 7) * 2;
-  vs[0] = base + (2 + 4 * h) * 16;
-  vs[1] = base + (GEO::RPS + 2 + 12 - 12 * h) * 16;
-}
-// 32x32 tiles -> the slab, one fp16 per lane and value (a lane owns ONE channel: the two pieces of a pair of its values are split
-// together and stored as halves, ds_write_b16 / ds_write_b16_d16_hi)
-template <class GEO, int MT>
-__device__ __forceinline__ void rm_store(char* slab, const int (&vs)[2], const f32x16 (&acc)[MT]) {
-  auto st2 = [&](char* p0, char* p1, float v0, float v1) {   // v0 -> p0, v1 -> p1 (both pieces)
-    const F16Pair f = f16_split2(v0, v1);
-    *reinterpret_cast<unsigned short*>(p0) = (unsigned short)f.hi;
-    *reinterpret_cast<unsigned short*>(p1) = (unsigned short)(f.hi >> 16);
-    *reinterpret_cast<unsigned short*>(p0 + GEO::PS) = (unsigned short)f.lo;
-    *reinterpret_cast<unsigned short*>(p1 + GEO::PS) = (unsigned short)(f.lo >> 16);
-  };
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    char* const e = slab + vs[0] + 2 * mt * GEO::RPS * 16;
-    char* const o = slab + vs[1] + 2 * mt * GEO::RPS * 16;
-#pragma unroll
-    for (int r = 0; r < 4; r += 2) {
-      st2(e + r * 16, e + (r + 1) * 16, acc[mt][r], acc[mt][r + 1]);
-      st2(e + (8 + r) * 16, e + (9 + r) * 16, acc[mt][4 + r], acc[mt][5 + r]);
-      st2(o + r * 16, o + (r + 1) * 16, acc[mt][8 + r], acc[mt][9 + r]);
-      st2(e + (GEO::RPS + 4 + r) * 16, e + (GEO::RPS + 5 + r) * 16, acc[mt][12 + r], acc[mt][13 + r]);
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
 // WAVE-PRIVATE direct stages (downs.0; one sample per wave): at L = 64 a sample is four M tiles of its own, and with 32
 // channels a wave holds a whole sample (4 M tiles x 2 interleaved n-tiles = 8 accumulators) -- so every conv of the stage
 // reads only what the same wave wrote: no workgroup barrier anywhere inside the stage (LDS operations of one wave execute in
