@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")"
 mkdir -p mmd_amd/lib
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -fno-slp-vectorize \
-  mmd_amd/csrc/unet.hip mmd_amd/csrc/guide.hip mmd_amd/csrc/api.hip mmd_amd/csrc/multi_agent.hip mmd_amd/csrc/postprocess.hip -o mmd_amd/lib/libmmd_amd.so "$@"
+  mmd_amd/csrc/unet.hip mmd_amd/csrc/unet_layers.hip mmd_amd/csrc/guide.hip mmd_amd/csrc/api.hip mmd_amd/csrc/multi_agent.hip mmd_amd/csrc/postprocess.hip -o mmd_amd/lib/libmmd_amd.so "$@"
 echo "built mmd_amd/lib/libmmd_amd.so"

@@ -164,6 +164,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   // layer so both queues stay fed.  Robots are independent and the noise is keyed by the global trajectory index, so
   // results are bit-identical to the unsplit run.
   int nch = stream_chunks(s->n_streams, n_robots, samples_per_robot);
+  if (!unet_fused_step_supported(unet)) nch = 1;   // the layer-by-layer path keeps its activations in the ONE workspace
   Streams* S = nullptr;
   if (nch > 1) {
     S = &streams();
@@ -186,7 +187,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
     sd.seed = seed; sd.draw = (unsigned int)k;
     // A step without guidance is fused into the tail of the UNet launch (unet.hip: the wave that holds a trajectory's eps applies
     // ddpm_sample_fn to it): one launch and one dependent dispatch less per (step, chunk).
-    const bool fused = !sd.do_guide && !kEnvNoFusedStep;
+    const bool fused = !sd.do_guide && !kEnvNoFusedStep && unet_fused_step_supported(unet);
     const float* noise_k = step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr;
     float* chain_k = chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr;
     for (int c = 0; c < nch && rc == 0; ++c) {

@@ -152,7 +152,8 @@ struct StepDev {
 };
 
 int fill_guide(const mmd_guide_desc* d, GuideDev& g);
-// the UNet forward with the unguided step fused into its tail (unet.hip)
+// the UNet forward with the unguided step fused into its tail (unet.hip); only the fused kernel's configuration has it
+bool unet_fused_step_supported(mmd_unet_t u);
 int unet_forward_fused(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, ::mmd_profiler_s* prof,
                        hipStream_t st, const FusedStep& fs);
 int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,

@@ -32,6 +32,7 @@
 #include "../../include/mmd_amd_debug.h"
 #include "common.h"
 #include "guide_dev.h"
+#include "unet_spec.h"
 
 namespace mmd {
 
@@ -2361,15 +2362,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ----------------------------------------------------------------------------------------------------------------
 // time embedding table: TimeEncoder (layers.py:232-258) + every block's cond_mlp (layers.py:337-341) for all integer t
 // ----------------------------------------------------------------------------------------------------------------
-struct TimeArgs {
-  const float* w1; const float* b1;   // [128,32], [128]
-  const float* w3; const float* b3;   // [32,128], [32]
-  const float* cw[12]; const float* cb[12];   // cond_mlp.1 weight [C,32], bias [C]
-  int cout[12]; int off[12];
-  int n_rtb; int total;
-  float* table;                       // [T][total]
-};
-
 __device__ __forceinline__ float mish_exact(float y) {
   float sp = y > 20.f ? y : log1pf(expf(y));
   return y * tanhf(sp);
@@ -2409,73 +2401,11 @@ __global__ void time_table_kernel(TimeArgs a) {
 // host side: parameter spec, weight packing, forward orchestration
 // ----------------------------------------------------------------------------------------------------------------
 
-struct TensorSpec { int64_t numel; };
+// the fused kernel's configuration: unet_input_dim 32, dim_mults (1, 2, 4) (every released checkpoint); anything else build_spec
+// accepts runs layer by layer (unet_layers.hip)
+static inline bool fused_config(int uid, int n_levels) { return uid == 32 && n_levels == 3; }
 
-struct Rtb { int cin, cout; bool res; int t_w0, t_b0, t_g0, t_be0, t_w1, t_b1, t_g1, t_be1, t_cw, t_cb, t_rw, t_rb; };
-
-static void add_rtb(std::vector<int64_t>& sp, std::vector<Rtb>& rtbs, int cin, int cout) {
-  Rtb r{};
-  r.cin = cin; r.cout = cout; r.res = cin != cout;
-  r.t_w0 = sp.size(); sp.push_back((int64_t)cout * cin * 5);
-  r.t_b0 = sp.size(); sp.push_back(cout);
-  r.t_g0 = sp.size(); sp.push_back(cout);
-  r.t_be0 = sp.size(); sp.push_back(cout);
-  r.t_w1 = sp.size(); sp.push_back((int64_t)cout * cout * 5);
-  r.t_b1 = sp.size(); sp.push_back(cout);
-  r.t_g1 = sp.size(); sp.push_back(cout);
-  r.t_be1 = sp.size(); sp.push_back(cout);
-  r.t_cw = sp.size(); sp.push_back((int64_t)cout * 32);
-  r.t_cb = sp.size(); sp.push_back(cout);
-  if (r.res) {
-    r.t_rw = sp.size(); sp.push_back((int64_t)cout * cin);
-    r.t_rb = sp.size(); sp.push_back(cout);
-  }
-  rtbs.push_back(r);
-}
-
-struct Spec {
-  std::vector<int64_t> numel;
-  std::vector<Rtb> rtb;           // downs.0.0, downs.0.1, downs.1.0, ..., ups.0.0, ..., mid1, mid2 (state_dict order)
-  int t_time[4];
-  int t_down[2][2], t_up[2][2];
-  int t_final[6];
-};
-
-// state_dict order of TemporalUnet(dim_mults=(1,2,4)): time_mlp, downs, ups, mid_block1, mid_block2, final_conv
-static bool build_spec(int uid, int n_levels, Spec& s) {
-  if (uid != 32 || n_levels != 3) return false;
-  const int dims[4] = {4, uid, uid * 2, uid * 4};
-  auto& sp = s.numel;
-  s.t_time[0] = sp.size(); sp.push_back(128 * 32);
-  s.t_time[1] = sp.size(); sp.push_back(128);
-  s.t_time[2] = sp.size(); sp.push_back(32 * 128);
-  s.t_time[3] = sp.size(); sp.push_back(32);
-  for (int i = 0; i < 3; ++i) {
-    add_rtb(sp, s.rtb, dims[i], dims[i + 1]);
-    add_rtb(sp, s.rtb, dims[i + 1], dims[i + 1]);
-    if (i < 2) {
-      s.t_down[i][0] = sp.size(); sp.push_back((int64_t)dims[i + 1] * dims[i + 1] * 3);
-      s.t_down[i][1] = sp.size(); sp.push_back(dims[i + 1]);
-    }
-  }
-  for (int i = 0; i < 2; ++i) {   // reversed(in_out[1:]) = (64,128), (32,64): ups.i.0 = RTB(2*dout, din)
-    const int din = dims[2 - i], dout = dims[3 - i];
-    add_rtb(sp, s.rtb, dout * 2, din);
-    add_rtb(sp, s.rtb, din, din);
-    s.t_up[i][0] = sp.size(); sp.push_back((int64_t)din * din * 4);
-    s.t_up[i][1] = sp.size(); sp.push_back(din);
-  }
-  add_rtb(sp, s.rtb, dims[3], dims[3]);
-  add_rtb(sp, s.rtb, dims[3], dims[3]);
-  s.t_final[0] = sp.size(); sp.push_back((int64_t)uid * uid * 5);
-  s.t_final[1] = sp.size(); sp.push_back(uid);
-  s.t_final[2] = sp.size(); sp.push_back(uid);
-  s.t_final[3] = sp.size(); sp.push_back(uid);
-  s.t_final[4] = sp.size(); sp.push_back((int64_t)4 * uid);
-  s.t_final[5] = sp.size(); sp.push_back(4);
-  return true;
-}
-
+void launch_time_table(const TimeArgs& a, int T, hipStream_t st) { hipLaunchKernelGGL(time_table_kernel, dim3(T), dim3(128), 0, st, a); }
 
 // power of two that puts m into [2^14, 2^15) (fp16's largest binade but one); 1 for m = 0 or non-finite
 static inline float f16_scale_for(float m) {
@@ -2612,6 +2542,7 @@ struct RtbW { ConvW a, b; size_t res_bias, res_isc, res_bf, res_c1_bf; int tb_of
 using namespace mmd;
 
 struct mmd_unet_s {
+  mmd::LayeredUnet* layered = nullptr;   // set: a configuration other than the fused kernel's; everything below is unused
   int T = 0;
   float* blob = nullptr;     // packed weights / biases / affine params
   float* ttable = nullptr;   // [T][tb_total]
@@ -2742,6 +2673,18 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
 
   auto* u = new mmd_unet_s();
   u->T = n_diffusion_steps;
+  // MMD_AMD_UNET_LAYERED=1 (read at create): the layer-by-layer path for the fused kernel's own configuration too -- the two
+  // implementations share no device code, tests/test_gpu_dim_mults.py holds one against the other
+  const char* force_layered = getenv("MMD_AMD_UNET_LAYERED");
+  if (!fused_config(unet_input_dim, n_levels) || (force_layered && force_layered[0] == '1')) {
+    // e.g. UNET_DIM_MULTS[1] = (1, 2, 4, 8): layer by layer (unet_layers.hip)
+    if (int rc = layered_create(&u->layered, s, n_diffusion_steps, tensors, st)) {
+      delete u;
+      return rc;
+    }
+    *out = u;
+    return 0;
+  }
   std::vector<float> blob;
   const std::vector<int> taps5 = {0, 1, 2, 3, 4}, taps3 = {0, 1, 2}, taps1 = {0};
   size_t raw_time[4];
@@ -2880,6 +2823,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
 
 int mmd_unet_destroy(mmd_unet_t u) {
   if (!u) return 0;
+  layered_destroy(u->layered);
   if (u->blob) (void)hipFree(u->blob);
   if (u->ttable) (void)hipFree(u->ttable);
   delete u;
@@ -2888,7 +2832,10 @@ int mmd_unet_destroy(mmd_unet_t u) {
 
 // The forward keeps every intermediate in LDS / registers; the workspace argument is kept in the ABI (callers pass the
 // buffer they sized with this function) but only a token size is asked for.
-size_t mmd_unet_workspace_bytes(mmd_unet_t, int n_traj) { return n_traj > 0 ? 256 : 0; }
+size_t mmd_unet_workspace_bytes(mmd_unet_t u, int n_traj) {
+  if (u && u->layered) return layered_workspace_bytes(u->layered, n_traj);   // (that path keeps its activations in the workspace)
+  return n_traj > 0 ? 256 : 0;
+}
 
 // algorithmic FLOPs per trajectory of one forward: sum over its convs of 2 * C_out * taps * C_in * L_out
 static constexpr double rtb_flops(double cin, double cout, double L) {
@@ -2927,6 +2874,13 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   MMD_REQUIRE(n >= 1, "mmd_unet_forward: n_traj must be >= 1");
   MMD_REQUIRE(t >= 0 && t < u->T, "mmd_unet_forward: t=%d outside [0,%d)", t, u->T);
   MMD_REQUIRE(ws_bytes >= mmd_unet_workspace_bytes(u, n), "mmd_unet_forward: workspace too small");
+  if (u->layered) {
+    MMD_REQUIRE(!(fs && fs->enabled), "mmd_unet_forward: the fused unguided step exists in the fused kernel only");
+    const bool bracket = prof_begin(prof, 0, MMD_PROF_UNET, st);
+    const int rc = layered_forward(u->layered, x, t, eps, n, ws, ws_bytes, st);
+    if (bracket) prof_end(prof, st);
+    return rc;
+  }
   // state_dict RTB indices: d00 d01 d10 d11 d20 d21 u00 u01 u10 u11 mid1 mid2 = 0..11
   static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};
   const RtbW* set = u->rtb;
@@ -2957,6 +2911,7 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
 
 }  // extern "C"
 namespace mmd {
+bool unet_fused_step_supported(mmd_unet_t u) { return u && !u->layered; }
 int unet_forward_fused(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, ::mmd_profiler_s* prof,
                        hipStream_t st, const FusedStep& fs) {
   return unet_forward_impl(u, x, t, eps, n, ws, ws_bytes, st, prof, &fs);

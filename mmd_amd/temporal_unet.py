@@ -2,6 +2,7 @@
 hand-written gfx950 kernels (mmd_amd/csrc/unet.hip) behind the C ABI (include/mmd_amd.h: mmd_unet_*)."""
 import ctypes as C
 import hashlib
+import os
 import weakref
 from collections import OrderedDict
 
@@ -45,6 +46,12 @@ class TemporalUnet:
             raise NotImplementedError("kernels are instantiated for H=64, state_dim=4, time_emb_dim=32")
         self.state_dim, self.n_support_points = state_dim, n_support_points
         self.unet_input_dim, self.dim_mults = unet_input_dim, tuple(dim_mults)
+        # UNET_DIM_MULTS (mmd/models/__init__.py:8-11) = {0: (1, 2, 4), 1: (1, 2, 4, 8)}: option 0 with unet_input_dim 32 runs the
+        # fused kernel, every other doubling ladder the layer-by-layer kernels (csrc/unet_layers.hip)
+        if self.dim_mults != (1, 2, 4, 8)[:len(self.dim_mults)] or not self.dim_mults:
+            raise NotImplementedError(f"dim_mults {self.dim_mults}: only a prefix of (1, 2, 4, 8) (each level doubles the channels)")
+        if unet_input_dim % 8 or not 8 <= unet_input_dim <= 64:
+            raise NotImplementedError("unet_input_dim must be a multiple of 8 in [8, 64]")
         self.spec = unet_param_spec(state_dim, unet_input_dim, self.dim_mults)
         self.max_timesteps = max_timesteps
         self._sd = None
@@ -96,7 +103,7 @@ class TemporalUnet:
             have = [t for (t, d) in self._models if d == dev]
             T = max(have) if have else self.max_timesteps
         if (T, dev) not in self._models:
-            key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, dev)
+            key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, dev, os.environ.get("MMD_AMD_UNET_LAYERED", ""))
             dm = _DEVICE_MODELS.get(key)
             if dm is None:
                 lib = _lib.load()

@@ -137,10 +137,16 @@ def _rtb(sd, prefix, x, c):
     return h + res
 
 
-def unet_forward(sd: Dict[str, torch.Tensor], x, t, n_levels=3):
+def unet_levels(sd) -> int:
+    """number of resolution levels = len(dim_mults) (temporal_unet.py:50-72: one `downs` entry per level)."""
+    return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("downs."))
+
+
+def unet_forward(sd: Dict[str, torch.Tensor], x, t, n_levels=None):
     """TemporalUnet.forward with conditioning_type=None, self_attention=False
     (mmd/models/diffusion_models/temporal_unet.py:121-174).  x [B,H,D] fp32, t [B] (any numeric) -> [B,H,D].  With a
-    float64 state dict and x it is the fp64 yardstick of the accuracy tests."""
+    float64 state dict and x it is the fp64 yardstick of the accuracy tests.  n_levels None: read from the state dict."""
+    n_levels = unet_levels(sd) if n_levels is None else n_levels
     c = time_embedding(sd, t.to(x.dtype))
     x = x.transpose(1, 2)                                            # 'b h c -> b c h'
     skips = []
@@ -512,7 +518,7 @@ def apply_hard_conditioning(x, hard_conds):
 
 
 def ddpm_sample_step(sd, tb, x, hard_conds, i, *, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
-                     noise=None, noise_std_extra=1.0, n_levels=3, eps_rel_perturb=None, scale_grad_by_std=False,
+                     noise=None, noise_std_extra=1.0, n_levels=None, eps_rel_perturb=None, scale_grad_by_std=False,
                      predict_epsilon=True):
     """ddpm_sample_fn (sample_functions.py:40-86) + p_mean_variance / predict_start_from_noise / q_posterior
     (diffusion_model_base.py:126-160) with predict_epsilon=True, clip_denoised=True.  `i` is the loop index (may be
@@ -546,7 +552,7 @@ def ddpm_sample_step(sd, tb, x, hard_conds, i, *, guide=None, n_guide_steps=1, t
 
 
 def p_sample_loop(sd, tb, x_init, hard_conds, n_diffusion_steps, step_noise, *, guide=None, n_guide_steps=20,
-                  t_start_guide=float("inf"), noise_std_extra=0.5, n_diffusion_steps_without_noise=0, n_levels=3,
+                  t_start_guide=float("inf"), noise_std_extra=0.5, n_diffusion_steps_without_noise=0, n_levels=None,
                   scale_grad_by_std=False, predict_epsilon=True):
     """GaussianDiffusionModel.p_sample_loop (diffusion_model_base.py:162-211), with the torch.randn draws injected:
     x_init [B,H,D] is x_T (or the warm start), step_noise [n_steps,B,H,D] one draw per loop iteration in order.
@@ -572,7 +578,7 @@ def ddim_times(n_diffusion_steps):
     return list(reversed(times.int().tolist()))
 
 
-def ddim_sample(sd, tb, x_init, hard_conds, n_diffusion_steps, *, guide=None, t_start_guide=float("inf"), n_levels=3):
+def ddim_sample(sd, tb, x_init, hard_conds, n_diffusion_steps, *, guide=None, t_start_guide=float("inf"), n_levels=None):
     """GaussianDiffusionModel.ddim_sample (diffusion_model_base.py:213-290), predict_epsilon=True, eta = 0 (sigma = 0: the
     per-step randn_like draw is multiplied by 0).  x_init [B,H,D] is the injected x_T.  Quirk kept: the guide runs ONE
     gradient step per sampling step -- ddim_sample binds `n_guide_steps` itself and forwards only **sample_kwargs, so

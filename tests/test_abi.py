@@ -34,6 +34,12 @@ def test_unet_spec_matches_library():
     lib = _lib.load()
     spec = unet_param_spec(4, 32, (1, 2, 4))
     assert lib.mmd_unet_num_tensors(32, 3) == len(spec) == 148
-    for i, shape in enumerate(spec.values()):
-        assert lib.mmd_unet_tensor_numel(32, 3, i) == int(np.prod(shape))
-    assert lib.mmd_unet_num_tensors(64, 3) == -1 and b"unsupported" in lib.mmd_last_error()
+    # every doubling ladder the reference's constructor admits at these widths, UNET_DIM_MULTS[1] = (1, 2, 4, 8) among them
+    for uid in (8, 16, 32, 64):
+        for dm in ((1,), (1, 2), (1, 2, 4), (1, 2, 4, 8)):
+            spec = unet_param_spec(4, uid, dm)
+            assert lib.mmd_unet_num_tensors(uid, len(dm)) == len(spec)
+            for i, shape in enumerate(spec.values()):
+                assert lib.mmd_unet_tensor_numel(uid, len(dm), i) == int(np.prod(shape)), (uid, dm, i)
+    for uid, nl in ((12, 3), (128, 3), (32, 5), (32, 0)):
+        assert lib.mmd_unet_num_tensors(uid, nl) == -1 and b"unsupported" in lib.mmd_last_error()

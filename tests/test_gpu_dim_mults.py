@@ -1,0 +1,164 @@
+"""-m gpu: TemporalUnet configurations other than the fused kernel's -- first of all the reference's UNET_DIM_MULTS[1] = (1, 2, 4, 8)
+(mmd/models/__init__.py:8-11, selected by a checkpoint's args.yaml at mpd.py:158) -- which run layer by layer (csrc/unet_layers.hip),
+against the reference (g17) and against the fused kernel on the configuration both serve."""
+import os
+from math import ceil
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmd_amd import synth                # noqa: E402
+import cases                             # noqa: E402
+import parity_log                        # noqa: E402
+from cases import GOLDEN, H, D, rel_l2   # noqa: E402
+
+NETS = (("d32_1248", 32, (1, 2, 4, 8)), ("d16_12", 16, (1, 2)), ("d8_1", 8, (1,)), ("d64_124", 64, (1, 2, 4)))
+TOL_STEP = 1e-3
+
+
+def _unet(uid, dm, seed=0):
+    from mmd_amd.temporal_unet import TemporalUnet
+    u = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=uid, dim_mults=dm)
+    u.load_state_dict(synth.synth_unet_state_dict(seed, unet_input_dim=uid, dim_mults=dm))
+    return u
+
+
+def _model(T, dm=(1, 2, 4, 8)):
+    from mmd_amd.diffusion_model import GaussianDiffusionModel
+    return GaussianDiffusionModel(model=_unet(32, dm), variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True)
+
+
+@pytest.mark.parametrize("tag,uid,dm", NETS, ids=[n[0] for n in NETS])
+def test_layered_unet_forward_golden(tag, uid, dm):
+    g = np.load(os.path.join(GOLDEN, "g17_unet_dim_mults.npz"))
+    unet = _unet(uid, dm)
+    x = torch.from_numpy(synth.synth_noise(int(g["x_seed"]), (4, H, D))).cuda()
+    for t in g["ts"]:
+        out = unet(x, torch.full((4,), int(t), dtype=torch.long, device="cuda")).cpu()
+        err = rel_l2(out, g[f"{tag}.eps_t{t}"])
+        parity_log.record("layered_unet_forward_golden", f"{tag}_t{int(t)}", None, err, bound=2e-5)
+        assert err < 2e-5, (tag, int(t), err)
+
+
+def test_layered_path_equals_fused_kernel_on_option0(monkeypatch):
+    """The two implementations share no device code: the fp32 layer-by-layer kernels forced onto the fused kernel's own
+    configuration (MMD_AMD_UNET_LAYERED=1, read when the device model is created) must give the fused kernel's output within its
+    documented distance from the fp32 reference (2.4e-6 rel-L2, test_unet_forward_accuracy_against_fp64), at a batch that is not
+    a multiple of the fused kernel's workgroup size."""
+    n = 37
+    x = (torch.from_numpy(synth.synth_noise(901, (n, H, D))) * 0.7).cuda()
+    fused = _unet(32, (1, 2, 4))
+    monkeypatch.setenv("MMD_AMD_UNET_LAYERED", "1")
+    layered = _unet(32, (1, 2, 4))
+    layered.handle(25, "cuda")                               # (the switch is read here: when the device model is created)
+    monkeypatch.delenv("MMD_AMD_UNET_LAYERED")
+    fused.handle(25, "cuda")
+    for t in (0, 11, 24):
+        err = rel_l2(layered(x, t).cpu(), fused(x, t).cpu())
+        parity_log.record("layered_vs_fused", f"t{t}", None, err, bound=6e-6)
+        assert err < 6e-6, (t, err)
+    from mmd_amd import _lib
+    lib = _lib.load()
+    assert lib.mmd_unet_workspace_bytes(layered.handle(device="cuda"), n) > lib.mmd_unet_workspace_bytes(fused.handle(device="cuda"), n)
+
+
+def _g17_chain_case():
+    g = np.load(os.path.join(GOLDEN, "g17_unet_dim_mults.npz"))
+    T, B, s_x, s_n = (int(v) for v in g["meta"])
+    starts, goals, soft, hard = cases.highways_case()
+    return g, T, B, s_x, s_n, cases.hard_conds_for(starts[3], goals[3]), soft, hard
+
+
+def test_option1_guided_steps_teacher_forced_vs_reference():
+    """Every ddpm_sample_fn step of the reference's guided Highways chain through the FOUR-level network (g17: T = 25, B = 4; 13
+    steps with 20 guide iterations each), started from the reference's own previous row: one step is well conditioned, so each is
+    held to the north-star tolerance against the reference itself."""
+    import gpu_common
+    g, T, B, s_x, s_n, hc, soft, hard = _g17_chain_case()
+    model = _model(T)
+    guide = gpu_common.hip_guide("EnvHighways2D", [[soft, hard]])
+    steps = torch.from_numpy(synth.synth_noise(s_n, (T + 1, B, H, D)))
+    ref = torch.from_numpy(g["chain"])
+    hcd = {k: v.cuda() for k, v in hc.items()}
+    worst = 0.0
+    for k in range(T + 1):
+        i = T - 1 - k if k < T else 0
+        y = ref[k].clone().cuda()
+        model.sample_step(y, hcd, i, guide=guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                          noise_std_extra_schedule_fn=lambda t: 0.5, noise=(steps[k] if k < T else torch.zeros_like(steps[k])).cuda())
+        err = rel_l2(y.cpu(), ref[k + 1])
+        parity_log.record("option1_teacher_forced_step", f"row{k + 1}", i, err, bound=TOL_STEP)
+        worst = max(worst, err)
+        assert err < TOL_STEP, (k, i, err)
+    assert worst < TOL_STEP
+
+
+def test_option1_chain_vs_reference():
+    """The same chain end to end (run_inference with injected noise).  Its map noise -> trajectory is chaotic once guidance
+    starts (the reference's own response to 1e-6 relative perturbations reaches 0.2 on the last row): rows are held to
+    cases.chaos_bounds, the unguided rows to 1e-3."""
+    import gpu_common
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    g, T, B, s_x, s_n, hc, soft, hard = _g17_chain_case()
+    model = _model(T)
+    guide = gpu_common.hip_guide("EnvHighways2D", [[soft, hard]])
+    xT = torch.from_numpy(synth.synth_noise(s_x, (B, H, D)))
+    steps = torch.from_numpy(synth.synth_noise(s_n, (T + 1, B, H, D)))
+    chain = model.run_inference(None, hc, n_samples=B, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn, guide=guide,
+                                n_guide_steps=20, t_start_guide=ceil(0.5 * T), noise_std_extra_schedule_fn=lambda t: 0.5,
+                                n_diffusion_steps_without_noise=1, warm_start_path_b=xT.cuda(), step_noise=steps.cuda()).cpu()
+    ref = torch.from_numpy(g["chain"])
+    errs = [rel_l2(chain[k], ref[k]) for k in range(T + 2)]
+    n_unguided = T - ceil(0.5 * T) + 1                       # rows 0 .. : x_T and the steps t = T-1 .. t_start_guide
+    lin, bounds = cases.chaos_bounds(errs, list(g["sens"]), n_unguided)
+    for k in range(T + 2):
+        parity_log.record("option1_chain", f"row{k}", None, errs[k], sens=float(g["sens"][k]), bound=bounds[k])
+        assert errs[k] < bounds[k], (k, errs[k], bounds[k])
+    assert max(errs[:n_unguided]) < 1e-3 and lin < cases.LIN, (errs[:n_unguided], lin)
+
+
+def test_option1_multi_robot_sampler_shards_bitwise_and_ignores_stream_chunks():
+    """MultiRobotSampler over a four-level model: the layer-by-layer path keeps its activations in the one workspace, so the
+    sampler must not split the robots over concurrent streams (n_streams = 2 gives the n_streams = 1 bits), and a rank's shard
+    equals its rows of the unsharded run."""
+    from mmd_amd.multi_robot import MultiRobotSampler
+    T, R, B = 25, 6, 4
+    starts, goals = synth.start_goal_circle(R, 0.6)
+    paths = torch.from_numpy(synth.straight_line_paths(starts, goals, H)).cuda()
+    model = _model(T)
+
+    def run(**kw):
+        s = MultiRobotSampler(model, starts, goals, env_id="EnvEmpty2D", n_samples=B, **kw)
+        s.set_other_paths(paths)
+        return s.sample(seed=5).cpu()
+    whole = run(n_streams=1)
+    assert torch.isfinite(whole).all() and whole.shape == (R * B, H, D)
+    assert torch.equal(whole, run(n_streams=2))
+    assert torch.equal(whole[2 * B:4 * B], run(rank=1, world_size=3))
+
+
+def test_option1_planner_from_args_yaml(tmp_path):
+    """mpd.py:117-177 with args.yaml's unet_dim_mults_option = 1: MPD builds the four-level TemporalUnet from the checkpoint and
+    plans through it."""
+    import yaml
+    from mmd_amd.planners import MPD
+    from mmd_amd.schedules import diffusion_buffers
+    model_id = "EnvEmpty2D-RobotPlanarDisk"
+    mdir = tmp_path / "models" / model_id
+    (mdir / "checkpoints").mkdir(parents=True)
+    yaml.safe_dump(dict(variance_schedule="exponential", n_diffusion_steps=25, predict_epsilon=True, unet_input_dim=32,
+                        unet_dim_mults_option=1, use_ema=True, dataset_subdir=model_id, include_velocity=True),
+                   open(mdir / "args.yaml", "w"))
+    sd = {"model." + k: torch.from_numpy(v) for k, v in synth.synth_unet_state_dict(0, dim_mults=(1, 2, 4, 8)).items()}
+    sd.update(diffusion_buffers(25))
+    torch.save(sd, mdir / "checkpoints" / "ema_model_current_state_dict.pth")
+    p = MPD(model_id=model_id, planner_alg="mmd", start_state_pos=torch.tensor([-0.5, 0.1]), goal_state_pos=torch.tensor([0.5, -0.1]),
+            n_samples=8, trained_models_dir=str(tmp_path / "models"), device="cuda")
+    assert p.model.model.dim_mults == (1, 2, 4, 8)
+    res = p(torch.tensor([-0.5, 0.1]), torch.tensor([0.5, -0.1]))
+    tf = res.trajs_iters[-1]
+    assert tuple(tf.shape) == (8, H, D) and torch.isfinite(res.trajs_iters).all()
+    assert torch.allclose(tf[:, 0, :2].cpu(), torch.tensor([-0.5, 0.1]).expand(8, 2), atol=1e-5)

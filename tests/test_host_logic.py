@@ -211,3 +211,17 @@ def test_launch_helper_rejects_host_tensors():
     from mmd_amd import _lib
     with pytest.raises(ValueError):
         _lib.launch("mmd_unet_forward", torch.zeros(1, 64, 4))
+
+
+def test_temporal_unet_accepts_doubling_ladders_only():
+    """UNET_DIM_MULTS (mmd/models/__init__.py:8-11) holds (1, 2, 4) and (1, 2, 4, 8); anything that is not a prefix of the doubling
+    ladder, or a width the kernels are not written for, is refused at construction -- not at the first forward."""
+    from mmd_amd.temporal_unet import TemporalUnet
+    from mmd_amd.unet_spec import UNET_DIM_MULTS
+    for dm in UNET_DIM_MULTS.values():
+        assert TemporalUnet(dim_mults=dm).dim_mults == tuple(dm)
+    for bad in ((1, 3), (2, 4), (1, 2, 4, 8, 16), ()):
+        with pytest.raises(NotImplementedError):
+            TemporalUnet(dim_mults=bad)
+    with pytest.raises(NotImplementedError):
+        TemporalUnet(unet_input_dim=20)

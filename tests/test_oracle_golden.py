@@ -259,3 +259,35 @@ def test_g16_options_oracle():
                              predict_epsilon=False)
     ref0 = torch.from_numpy(g["chain_predict_x0"])
     assert max(rel_l2(chain0[k], ref0[k]) for k in range(T + 2)) < 1e-4
+
+
+G17_NETS = (("d32_1248", 32, (1, 2, 4, 8)), ("d16_12", 16, (1, 2)), ("d8_1", 8, (1,)), ("d64_124", 64, (1, 2, 4)))
+
+
+def test_g17_unet_dim_mults_oracle():
+    """TemporalUnet with the reference's other dim_mults option (mmd/models/__init__.py:8-11: UNET_DIM_MULTS[1] = (1, 2, 4, 8)) and
+    three more shapes the constructor admits, plus a guided chain through the four-level network, against the reference (g17)."""
+    g = np.load(os.path.join(GOLDEN, "g17_unet_dim_mults.npz"))
+    x = torch.from_numpy(synth.synth_noise(int(g["x_seed"]), (4, H, D)))
+    for tag, uid, dm in G17_NETS:
+        sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0, unet_input_dim=uid, dim_mults=dm))
+        assert O.unet_levels(sd) == len(dm)
+        for t in g["ts"]:
+            eps = O.unet_forward(sd, x, torch.full((4,), int(t), dtype=torch.long))
+            assert rel_l2(eps, g[f"{tag}.eps_t{t}"]) < 1e-6, (tag, t)
+    T, B, s_x, s_n = (int(v) for v in g["meta"])
+    starts, goals, soft, hard = cases.highways_case()
+    gp = cases.guide_params("EnvHighways2D")
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0, dim_mults=(1, 2, 4, 8)))
+    tb = O.schedule_tables(T)
+    steps = torch.from_numpy(synth.synth_noise(s_n, (T + 1, B, H, D)))
+    hc = cases.hard_conds_for(starts[3], goals[3])
+    ref = torch.from_numpy(g["chain"])
+    # teacher-forced: every step starts from the reference's own chain row (the chain itself is chaotic: sens up to 0.2)
+    for k in range(T + 1):
+        i = T - 1 - k if k < T else 0          # rows: x_T, then t = T-1 .. 0, then the extra noiseless t = 0 step
+        y = O.ddpm_sample_step(sd, tb, ref[k].clone(), hc, i, guide=lambda z: O.guide_grad(z, gp, [soft, hard]), n_guide_steps=20,
+                               t_start_guide=ceil(0.5 * T), noise=steps[k] if k < T else torch.zeros_like(steps[k]),
+                               noise_std_extra=0.5)
+        y = O.apply_hard_conditioning(y, hc)
+        assert rel_l2(y, ref[k + 1]) < 1e-4, (k, i, rel_l2(y, ref[k + 1]))

@@ -701,11 +701,56 @@ def g16():
     print("   g16:", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim > 0})
 
 
+def g17():
+    """UNET_DIM_MULTS[1] = (1, 2, 4, 8) (mmd/models/__init__.py:8-11, temporal_unet.py:50-119): eps of a four-level TemporalUnet
+    at t in {0, 37, 99} (inputs as g2), of a two-level one (1, 2) with unet_input_dim = 16, and a guided Highways chain (T = 25,
+    B = 4, inputs as g16) through the four-level network with its sensitivity row (1e-6 relative perturbations, 8 draws)."""
+    x = torch.from_numpy(synth.synth_noise(5, (4, H, D)))
+    out = {"x_seed": 5, "ts": np.array([0, 37, 99])}
+    for tag, uid, dm in (("d32_1248", 32, (1, 2, 4, 8)), ("d16_12", 16, (1, 2)), ("d8_1", 8, (1,)), ("d64_124", 64, (1, 2, 4))):
+        sd = synth.synth_unet_state_dict(0, unet_input_dim=uid, dim_mults=dm)
+        with quiet():
+            m = make_model(sd, 100, dim_mults=dm, unet_input_dim=uid)
+        for t in (0, 37, 99):
+            with torch.no_grad():
+                out[f"{tag}.eps_t{t}"] = m.model(x, torch.full((4,), t, dtype=torch.long), None).numpy()
+    T, B = 25, 4
+    dm = (1, 2, 4, 8)
+    sd = synth.synth_unet_state_dict(0, dim_mults=dm)
+    starts, goals, soft, hard = highways_case()
+    xT = synth.synth_noise(41, (B, H, D))
+    steps = synth.synth_noise(42, (T + 1, B, H, D))
+
+    def run(perturb=0.0, seed=0):
+        with quiet():
+            model = make_model(sd, T, dim_mults=dm)
+            guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS)
+        if perturb:
+            gen = torch.Generator().manual_seed(seed)
+            model.model.register_forward_hook(
+                lambda mod, inp, o: o * (1 + perturb * torch.empty(o.shape).normal_(generator=gen)))
+        guide.add_extra_costs([make_cost_constraint(robot, *soft, True), make_cost_constraint(robot, *hard, False)], [2e-2, 2e-1])
+        with quiet(), injected_noise([xT] + list(steps)) as q:
+            chain = model.run_inference(None, hard_conds_for(starts[3], goals[3]), n_samples=B, horizon=H, return_chain=True,
+                                        sample_fn=ddpm_sample_fn, guide=guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                                        noise_std_extra_schedule_fn=lambda x: 0.5, n_diffusion_steps_without_noise=1)
+            assert len(q) == 0
+        return chain.numpy()
+    chain = run()
+    sens = np.zeros(chain.shape[0])
+    for ps in range(1, 9):
+        pert = run(1e-6, ps)
+        sens = np.maximum(sens, [rel_l2(pert[r], chain[r]) for r in range(chain.shape[0])])
+    out["chain"], out["sens"], out["meta"] = chain, sens, np.array([T, B, 41, 42])
+    np.savez_compressed(os.path.join(OUT, "g17_unet_dim_mults.npz"), **out)
+    print("   g17: chain", chain.shape, "final-row sensitivity", f"{sens[-1]:.2e}")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17}[name]()
     print("done")
