@@ -38,8 +38,10 @@ const char* mmd_last_error(void);
  * ---------------------------------------------------------------------------------------------------------- */
 
 /* Number of parameter tensors, and the element count of tensor i, in the reference's state_dict order for
- * TemporalUnet(state_dim=4, n_support_points=64, unet_input_dim, dim_mults=(1,2,4)).
- * Only unet_input_dim == 32 with 3 levels is instantiated in this build; others return an error. */
+ * TemporalUnet(state_dim=4, n_support_points=64, unet_input_dim, dim_mults=(1, 2, 4, 8)[:n_levels]).
+ * unet_input_dim: a multiple of 8 in [8, 64]; n_levels 1 .. 4 (UNET_DIM_MULTS, mmd/models/__init__.py:8-11: option 0 =
+ * 3 levels, option 1 = 4 levels); anything else returns -1.  unet_input_dim == 32 with 3 levels (the released checkpoints)
+ * runs the fused one-launch kernel, every other shape the layer-by-layer kernels (csrc/unet_layers.hip). */
 int mmd_unet_num_tensors(int unet_input_dim, int n_levels);
 int64_t mmd_unet_tensor_numel(int unet_input_dim, int n_levels, int index);
 
@@ -53,8 +55,9 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
                     const float* const* tensors, const int64_t* numels, int n_tensors, void* stream);
 int mmd_unet_destroy(mmd_unet_t unet);
 
-/* Scratch needed by mmd_unet_forward for n_traj trajectories; allocate it with the host framework.  (The forward keeps
- * every activation on chip, so this is a token size; the argument stays in the ABI.) */
+/* Scratch needed by mmd_unet_forward for n_traj trajectories; allocate it with the host framework.  (The fused kernel keeps
+ * every activation on chip: a token size; the layer-by-layer path keeps (5 + n_levels) tensors of n_traj x 64 x unet_input_dim
+ * floats there.) */
 size_t mmd_unet_workspace_bytes(mmd_unet_t unet, int n_traj);
 
 /* eps = model(x, t, context=None)  (temporal_unet.py:121; called from p_mean_variance,

@@ -1,18 +1,24 @@
 // TemporalUnet forward, layer by layer, for the configurations the fused kernel (unet.hip) is not instantiated for -- first of all
 // UNET_DIM_MULTS[1] = (1, 2, 4, 8) (mmd/models/diffusion_models/temporal_unet.py:17-20, selected by a checkpoint's args.yaml at
 // mmd/planners/single_agent/mpd.py:158; the released checkpoints use option 0 and run the fused kernel).  Plain fp32 FMA
-// arithmetic, one launch per Conv1dBlock / conv, activations channels-last [n][L][C] in an HBM workspace: a correct path for a
-// rarely used configuration, NOT a tuned one (about 40 launches and ~0.5-5 ms per forward instead of one launch and 0.2 ms).
+// arithmetic on the vector ALUs, one launch per Conv1dBlock / conv, activations channels-FIRST [n][C][L] in an HBM workspace (the
+// trajectory input and the eps output are [n][L][4] as everywhere else): a correct path for a rarely used configuration, about
+// 50 launches per forward instead of one.
 //
 //   ResidualTemporalBlock (layers.py:323-358): out = Mish(GN(conv5(Mish(GN(conv5(x))) + time bias))) + res(x)
 //   Downsample1d = Conv1d(k3, s2, p1), Upsample1d = ConvTranspose1d(k4, s2, p1) (layers.py:261-279)
 //   final_conv = Conv1dBlock(k5) + Conv1d(k1) (temporal_unet.py:104-110)
 //
-// A workgroup owns one sample of a layer: the input rows are staged in LDS, every thread computes outputs (position, channel) with
-// the weights transposed to [tap][c_in][c_out] at create time (adjacent threads = adjacent output channels read adjacent weights),
-// the conv output stays in LDS for the GroupNorm (8 groups, two-pass statistics, eps 1e-5) + Mish + addend, then goes to HBM.
+// conv5_block_kernel (the 33 Conv1dBlocks = all but a few percent of the arithmetic): a workgroup owns one sample and a slice of
+// whole GroupNorm groups of the output channels (blockIdx.y; small launches are split 2 .. 8 ways so they still fill the chip).  The
+// input rows are staged in LDS as [c_in][L + 8] with four zeros either side (no boundary tests in the loop); a thread holds a
+// register tile of 4 positions x CT channels: per input channel it reads its 8-position window once (two 16-byte LDS reads) and
+// 5 CT weights [tap][c_in][c_out] (adjacent threads = adjacent output channels: coalesced, L2-resident) for 20 CT FMAs.  The conv
+// output goes to LDS for the GroupNorm (8 groups, two-pass statistics, eps 1e-5) + Mish + addend, then to HBM.
+// conv_plain_kernel: the strided / transposed / 1x1 convs without a norm, one thread per output, split over blockIdx.y likewise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -33,34 +39,150 @@ __device__ __forceinline__ float mish_ref(float y) {          // torch.nn.Mish: 
 }
 
 struct ConvArgs {
-  const float* x1; const float* x2;   // input [n][L_in][C1] (+ [n][L_in][C2] concatenated behind it along the channels, or NULL)
+  const float* x1; const float* x2;   // input [n][C1][L_in] (+ [n][C2][L_in] concatenated behind it along the channels, or NULL)
   int c1, c2, l_in, l_out, c_out;
+  int cs;                             // output channels per workgroup (blockIdx.y * cs = first)
+  int in_cl, out_cl;                  // the input / output tensor is channels-last [n][L][C] (the trajectory, eps)
   const float* wt;                    // [taps][c1 + c2][c_out]
   const float* bias;                  // [c_out]
-  const float* gamma; const float* beta;   // GroupNorm affine, or NULL: plain conv
+  const float* gamma; const float* beta;   // GroupNorm affine (conv5_block_kernel)
   const float* add_c;                 // per-channel addend after Mish (time bias), or NULL
-  const float* add_t;                 // [n][l_out][c_out] addend after Mish (residual), or NULL
-  float* y;                           // [n][l_out][c_out]
+  const float* add_t;                 // [n][c_out][l_out] addend after Mish (residual), or NULL
+  float* y;                           // [n][c_out][l_out]
 };
 
+__device__ __forceinline__ float load_in(const ConvArgs& a, size_t n, int c, int l) {
+  if (a.in_cl) return a.x1[(n * a.l_in + l) * a.c1 + c];
+  return c < a.c1 ? a.x1[(n * a.c1 + c) * a.l_in + l] : a.x2[(n * a.c2 + (c - a.c1)) * a.l_in + l];
+}
+
+// Conv1dBlock (layers.py:232-258): Conv1d(k5, p2) -> GroupNorm(8) -> Mish, + per-channel addend, + tensor addend.
+// blockDim = KS * (L / 4) * (cs / CT).  The sum over the input channels is DEFINED as KS = 4 interleaved partial sums (channels
+// ci = r mod 4, taps in order) combined as ((s0 + s1) + (s2 + s3)) + bias: thread group r of a workgroup computes s_r, so the bits
+// do not depend on how a launch is sliced (CT, cs follow the batch size).
+constexpr int KS = 4;
+template <int CT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void conv5_block_kernel(ConvArgs a) {
+  extern __shared__ float lds[];
+  const int cin = a.c1 + a.c2, L = a.l_in, Lp = L + 8, tid = threadIdx.x, nthr = blockDim.x;
+  const size_t n = blockIdx.x;
+  const int c0 = blockIdx.y * a.cs, tile = a.cs * L;
+  float* xs = lds;                               // [cin][Lp]
+  float* part = lds + cin * Lp;                  // [KS][cs][L] partial sums; [0] becomes the conv output
+  float* red = part + KS * tile;                 // [2 * groups of the slice]
+  for (int i = tid; i < cin * Lp; i += nthr) {
+    const int c = i / Lp, l = i % Lp - 4;
+    xs[i] = (l >= 0 && l < L) ? load_in(a, n, c, l) : 0.f;
+  }
+  __syncthreads();
+  {
+    const int lanes = a.cs / CT, nconv = (L / 4) * lanes, ks = tid / nconv, r = tid % nconv, cl = r % lanes, pg = r / lanes;
+    float acc[CT][4];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[j][p] = 0.f;
+    // weight loads through a buffer descriptor: a per-thread byte offset (input channel ks, output channel lane cl) that never
+    // changes + a scalar offset per (iteration, tap, channel tile): no vector address arithmetic in the loop
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wt), 0, 5 * cin * a.c_out * 4, 0x00020000);
+    const int voff = 4 * (ks * a.c_out + cl * CT);                 // the thread's CT output channels are adjacent: one load per tap
+    const int tap = cin * a.c_out;
+    auto load_w = [&](float (&w)[5 * CT], int it) {
+      const int so = c0 + it * KS * a.c_out;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        if constexpr (CT == 1) {
+          w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, voff, 4 * (so + k * tap), 0));
+        } else if constexpr (CT == 2) {
+          // (the b64 / b128 buffer-load builtins of this compiler return the first dword in every component: plain vector loads)
+          const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.wt + so + k * tap) + voff);
+          w[2 * k] = v.x; w[2 * k + 1] = v.y;
+        } else {
+          const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wt + so + k * tap) + voff);
+          w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+      }
+    };
+    auto taps = [&](const float (&w)[5 * CT], int ci) {
+      const float4* xr = reinterpret_cast<const float4*>(xs + ci * Lp + pg * 4);     // positions 4 pg - 4 .. 4 pg + 7
+      const float4 v0 = xr[0], v1 = xr[1], v2 = xr[2];
+      const float xw[8] = {v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y};           // positions 4 pg - 2 .. 4 pg + 5
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[j][p] = fmaf(xw[p + k], w[k * CT + j], acc[j][p]);
+    };
+    // two weight sets in flight alternately: the next input channel's loads are issued before the current one's 20 CT FMAs
+    float w0[5 * CT], w1[5 * CT];
+    const int nci = cin / KS;                            // this thread's input channels: ks, ks + KS, ... (c_in is 4 or a multiple of 8)
+    if (nci > 0) load_w(w0, 0);
+    int it = 0;
+    for (; it + 2 <= nci; it += 2) {
+      load_w(w1, it + 1);
+      taps(w0, ks + it * KS);
+      load_w(w0, it + 2 < nci ? it + 2 : it);
+      taps(w1, ks + (it + 1) * KS);
+    }
+    if (it < nci) taps(w0, ks + it * KS);
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+      *reinterpret_cast<float4*>(part + ks * tile + (cl * CT + j) * L + pg * 4) =
+          make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  }
+  __syncthreads();
+  float* outs = part;
+  for (int o = tid; o < tile; o += nthr)                // (each element is read and written by the same thread)
+    outs[o] = ((part[o] + part[tile + o]) + (part[2 * tile + o] + part[3 * tile + o])) + a.bias[c0 + o / L];
+  __syncthreads();
+  // GroupNorm over (c_out / 8 channels) x L positions per group = one contiguous block of `outs`; a wave per group
+  const int cpg = a.c_out / N_GROUPS, per = cpg * L, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  for (int g = wave; g < a.cs / cpg; g += nwave) {
+    const float* blk = outs + g * per;
+    float s = 0.f;
+    for (int i = lane; i < per; i += 64) s += blk[i];
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)per;
+    float q = 0.f;
+    for (int i = lane; i < per; i += 64) {
+      const float d = blk[i] - mean;
+      q = fmaf(d, d, q);
+    }
+    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
+    if (lane == 0) {
+      red[2 * g] = mean;
+      red[2 * g + 1] = 1.f / sqrtf(q / (float)per + 1e-5f);
+    }
+  }
+  __syncthreads();
+  const size_t base = (n * a.c_out + c0) * L;
+  for (int o = tid; o < tile; o += nthr) {
+    const int c = o / L, co = c0 + c, g = c / cpg;
+    float v = mish_ref((outs[o] - red[2 * g]) * red[2 * g + 1] * a.gamma[co] + a.beta[co]);
+    if (a.add_c) v += a.add_c[co];
+    if (a.add_t) v += a.add_t[base + o];
+    a.y[base + o] = v;
+  }
+}
+
 // MODE 0: Conv1d, K taps, stride S, padding K / 2.  MODE 1: ConvTranspose1d(k4, s2, p1): out[2 m] = in[m - 1] W3 + in[m] W1,
-// out[2 m + 1] = in[m] W2 + in[m + 1] W0 (taps stored in kernel-index order 0 .. 3)
+// out[2 m + 1] = in[m] W2 + in[m + 1] W0 (taps stored in kernel-index order 0 .. 3).  No norm; input staged as [l][c_in].
 template <int MODE, int K, int S>
-__global__ __launch_bounds__(256) void conv_block_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) void conv_plain_kernel(ConvArgs a) {
   extern __shared__ float lds[];
   const int cin = a.c1 + a.c2, tid = threadIdx.x;
   const size_t n = blockIdx.x;
+  const int c0 = blockIdx.y * a.cs;
   float* xin = lds;                              // [l_in][cin]
-  float* out = lds + a.l_in * cin;               // [l_out][c_out]
-  float* red = out + a.l_out * a.c_out;          // [2 * N_GROUPS] group statistics
   for (int i = tid; i < a.l_in * cin; i += 256) {
-    const int l = i / cin, c = i % cin;
-    xin[i] = c < a.c1 ? a.x1[(n * a.l_in + l) * a.c1 + c] : a.x2[(n * a.l_in + l) * a.c2 + (c - a.c1)];
+    const int c = a.in_cl ? i % cin : i / a.l_in, l = a.in_cl ? i / cin : i % a.l_in;
+    xin[l * cin + c] = load_in(a, n, c, l);
   }
   __syncthreads();
-  const int n_out = a.l_out * a.c_out;
-  for (int o = tid; o < n_out; o += 256) {
-    const int lo = o / a.c_out, co = o % a.c_out;
+  for (int o = tid; o < a.l_out * a.cs; o += 256) {
+    // adjacent threads = adjacent output channels (coalesced weights); the store below is strided but small
+    const int lo = o / a.cs, co = c0 + o % a.cs;
     float acc = a.bias[co];
     if (MODE == 0) {
 #pragma unroll
@@ -83,41 +205,8 @@ __global__ __launch_bounds__(256) void conv_block_kernel(ConvArgs a) {
         for (int ci = 0; ci < cin; ++ci) acc = fmaf(xr[ci], wr[(size_t)ci * a.c_out], acc);
       }
     }
-    out[o] = acc;
-  }
-  __syncthreads();
-  if (a.gamma) {
-    // GroupNorm(8, c_out) over (c_out / 8 channels) x l_out positions per group: wave w reduces group w (256 threads = 4 waves: two
-    // groups each), mean first, then the centred second moment
-    const int cpg = a.c_out / N_GROUPS, per = cpg * a.l_out, lane = tid & 63, wave = tid >> 6;
-    for (int g = wave; g < N_GROUPS; g += 4) {
-      float s = 0.f;
-      for (int i = lane; i < per; i += 64) s += out[(i / cpg) * a.c_out + g * cpg + i % cpg];
-      for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-      const float mean = s / (float)per;
-      float q = 0.f;
-      for (int i = lane; i < per; i += 64) {
-        const float d = out[(i / cpg) * a.c_out + g * cpg + i % cpg] - mean;
-        q = fmaf(d, d, q);
-      }
-      for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
-      if (lane == 0) {
-        red[2 * g] = mean;
-        red[2 * g + 1] = 1.f / sqrtf(q / (float)per + 1e-5f);
-      }
-    }
-    __syncthreads();
-  }
-  for (int o = tid; o < n_out; o += 256) {
-    const int co = o % a.c_out;
-    float v = out[o];
-    if (a.gamma) {
-      const int g = co / (a.c_out / N_GROUPS);
-      v = mish_ref((v - red[2 * g]) * red[2 * g + 1] * a.gamma[co] + a.beta[co]);
-    }
-    if (a.add_c) v += a.add_c[co];
-    if (a.add_t) v += a.add_t[n * n_out + o];
-    a.y[n * n_out + o] = v;
+    if (a.out_cl) a.y[(n * a.l_out + lo) * a.c_out + co] = acc;
+    else a.y[(n * a.c_out + co) * a.l_out + lo] = acc;
   }
 }
 
@@ -198,6 +287,9 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
     layered_destroy(u);
     return 1;
   }
+  // widest Conv1dBlock input: ups.0.0 of a four-level net stages 2 x 8 uid x 8 channels x (8 + 8) positions (64 KB at uid 64)
+  for (const void* f : {(const void*)conv5_block_kernel<1>, (const void*)conv5_block_kernel<2>, (const void*)conv5_block_kernel<4>})
+    MMD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   MMD_HIP_CHECK(hipMemcpyAsync(u->blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, st));
   MMD_HIP_CHECK(hipStreamSynchronize(st));
   TimeArgs ta{};
@@ -244,24 +336,46 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   for (int i = 0; i < s.n_levels - 1; ++i) skip[i] = base + (6 + i) * per;   // skip[j] = output of down level j + 1
   const float* B = u->blob;
   const float* tt = u->ttable + (size_t)t * u->tb_total;
-  auto conv = [&](int mode, int k, const float* x1, int c1, const float* x2, int c2, int l_in, int l_out, int c_out,
-                  size_t w, size_t b, const float* gamma, const float* beta, const float* add_c, const float* add_t, float* y) {
-    ConvArgs a{x1, x2, c1, c2, l_in, l_out, c_out, B + w, B + b, gamma, beta, add_c, add_t, y};
-    const size_t shm = ((size_t)l_in * (c1 + c2) + (size_t)l_out * c_out + 2 * N_GROUPS) * sizeof(float);
-    if (mode == 1) hipLaunchKernelGGL((conv_block_kernel<1, 4, 2>), dim3(n), dim3(256), shm, st, a);
-    else if (k == 5) hipLaunchKernelGGL((conv_block_kernel<0, 5, 1>), dim3(n), dim3(256), shm, st, a);
-    else if (k == 3) hipLaunchKernelGGL((conv_block_kernel<0, 3, 2>), dim3(n), dim3(256), shm, st, a);
-    else hipLaunchKernelGGL((conv_block_kernel<0, 1, 1>), dim3(n), dim3(256), shm, st, a);
+  // split a launch's output channels over blockIdx.y until it has >= 3 workgroups per CU (or 8 slices: one GroupNorm group each)
+  auto slices = [&](int c_out, int unit, int max_cs) {
+    int ns = 1;
+    while (ns < N_GROUPS && ((long long)n * ns < 768 || c_out / ns > max_cs) && (c_out / (2 * ns)) % unit == 0) ns *= 2;
+    return ns;
   };
-  // one ResidualTemporalBlock (layers.py:346-358): (x1 | x2) [L][cin] -> out [L][cout]
-  auto rtb = [&](const LRtb& R, const float* x1, int c1, const float* x2, int c2, int L, float* out) {
-    conv(0, 5, x1, c1, x2, c2, L, L, R.cout, R.wa, R.ba, B + R.ga, B + R.bea, tt + R.tb_off, nullptr, tmp);
+  // Conv1dBlock: (x1 | x2) [c][L] -> Mish(GN(conv5)) + add_c[c] + add_t -> y.  A workgroup of KS x nconv threads, nconv =
+  // (L / 4) * (cs / CT) in [16, 64]: the slice width cs (whole GroupNorm groups) follows from that, CT = 2 for the big launches
+  auto block5 = [&](const float* x1, int c1, const float* x2, int c2, int in_cl, int L, int c_out, size_t w, size_t b, size_t gamma,
+                    size_t beta, const float* add_c, const float* add_t, float* y) {
+    const int cpg = c_out / N_GROUPS;
+    int ct = n >= 768 ? 4 : n >= 192 ? 2 : 1, cs = c_out;
+    auto nconv = [&]() { return (L / 4) * (cs / ct); };
+    while (nconv() > 64 && (cs / 2) % cpg == 0) cs /= 2;
+    while (nconv() > 64) ct *= 2;                               // (unet_input_dim 64: one group of a level is 512 outputs)
+    while (ct > 1 && (cs % ct || nconv() < 16)) ct /= 2;
+    ConvArgs a{x1, x2, c1, c2, L, L, c_out, cs, in_cl, 0, B + w, B + b, B + gamma, B + beta, add_c, add_t, y};
+    const size_t shm = ((size_t)(c1 + c2) * (L + 8) + (size_t)KS * cs * L + 2 * N_GROUPS) * sizeof(float);
+    if (ct == 4) hipLaunchKernelGGL(conv5_block_kernel<4>, dim3(n, c_out / cs), dim3(KS * nconv()), shm, st, a);
+    else if (ct == 2) hipLaunchKernelGGL(conv5_block_kernel<2>, dim3(n, c_out / cs), dim3(KS * nconv()), shm, st, a);
+    else hipLaunchKernelGGL(conv5_block_kernel<1>, dim3(n, c_out / cs), dim3(KS * nconv()), shm, st, a);
+  };
+  auto plain = [&](int mode, int k, const float* x1, int c1, const float* x2, int c2, int in_cl, int l_in, int l_out, int c_out,
+                   int out_cl, size_t w, size_t b, float* y) {
+    const int ns = c_out >= 32 ? slices(c_out, 8, 1 << 30) : 1;
+    ConvArgs a{x1, x2, c1, c2, l_in, l_out, c_out, c_out / ns, in_cl, out_cl, B + w, B + b, nullptr, nullptr, nullptr, nullptr, y};
+    const size_t shm = (size_t)l_in * (c1 + c2) * sizeof(float);
+    if (mode == 1) hipLaunchKernelGGL((conv_plain_kernel<1, 4, 2>), dim3(n, ns), dim3(256), shm, st, a);
+    else if (k == 3) hipLaunchKernelGGL((conv_plain_kernel<0, 3, 2>), dim3(n, ns), dim3(256), shm, st, a);
+    else hipLaunchKernelGGL((conv_plain_kernel<0, 1, 1>), dim3(n, ns), dim3(256), shm, st, a);
+  };
+  // one ResidualTemporalBlock (layers.py:346-358): (x1 | x2) [cin][L] -> out [cout][L]
+  auto rtb = [&](const LRtb& R, const float* x1, int c1, const float* x2, int c2, int in_cl, int L, float* out) {
+    block5(x1, c1, x2, c2, in_cl, L, R.cout, R.wa, R.ba, R.ga, R.bea, tt + R.tb_off, nullptr, tmp);
     const float* res = x1;                                   // identity residual (cin == cout: never a concatenated input)
     if (R.res) {
-      conv(0, 1, x1, c1, x2, c2, L, L, R.cout, R.wr, R.br, nullptr, nullptr, nullptr, nullptr, resb);
+      plain(0, 1, x1, c1, x2, c2, in_cl, L, L, R.cout, 0, R.wr, R.br, resb);
       res = resb;
     }
-    conv(0, 5, tmp, R.cout, nullptr, 0, L, L, R.cout, R.wb, R.bb, B + R.gb, B + R.beb, nullptr, res, out);
+    block5(tmp, R.cout, nullptr, 0, 0, L, R.cout, R.wb, R.bb, R.gb, R.beb, nullptr, res, out);
   };
   const int NL = s.n_levels;
   int L = H, cin = 4;
@@ -270,10 +384,10 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   for (int i = 0; i < NL; ++i) {                              // downs (temporal_unet.py:147-156)
     const int c = s.dims[i + 1];
     level_out = i == 0 ? out0 : skip[i - 1];
-    rtb(u->rtb[2 * i], xin, cin, nullptr, 0, L, mid);
-    rtb(u->rtb[2 * i + 1], mid, c, nullptr, 0, L, level_out);
+    rtb(u->rtb[2 * i], xin, cin, nullptr, 0, i == 0, L, mid);          // (level 0 reads the trajectory: channels-last)
+    rtb(u->rtb[2 * i + 1], mid, c, nullptr, 0, 0, L, level_out);
     if (i < NL - 1) {
-      conv(0, 3, level_out, c, nullptr, 0, L, L / 2, c, u->down_w[i], u->down_b[i], nullptr, nullptr, nullptr, nullptr, in[i & 1]);
+      plain(0, 3, level_out, c, nullptr, 0, 0, L, L / 2, c, 0, u->down_w[i], u->down_b[i], in[i & 1]);
       xin = in[i & 1];
       L /= 2;
     }
@@ -281,19 +395,19 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   }
   {                                                          // mid blocks (state_dict order: behind the ups)
     const int m0 = 2 * NL + 2 * (NL - 1), c = s.dims[NL];
-    rtb(u->rtb[m0], level_out, c, nullptr, 0, L, mid);
-    rtb(u->rtb[m0 + 1], mid, c, nullptr, 0, L, in[0]);
+    rtb(u->rtb[m0], level_out, c, nullptr, 0, 0, L, mid);
+    rtb(u->rtb[m0 + 1], mid, c, nullptr, 0, 0, L, in[0]);
   }
   for (int i = 0; i < NL - 1; ++i) {                          // ups: x = cat(x, h.pop()) (temporal_unet.py:164-171)
     const int din = s.dims[NL - 1 - i], dout = s.dims[NL - i];
-    rtb(u->rtb[2 * NL + 2 * i], in[0], dout, skip[NL - 2 - i], dout, L, mid);
-    rtb(u->rtb[2 * NL + 2 * i + 1], mid, din, nullptr, 0, L, in[1]);
-    conv(1, 4, in[1], din, nullptr, 0, L, 2 * L, din, u->up_w[i], u->up_b[i], nullptr, nullptr, nullptr, nullptr, in[0]);
+    rtb(u->rtb[2 * NL + 2 * i], in[0], dout, skip[NL - 2 - i], dout, 0, L, mid);
+    rtb(u->rtb[2 * NL + 2 * i + 1], mid, din, nullptr, 0, 0, L, in[1]);
+    plain(1, 4, in[1], din, nullptr, 0, 0, L, 2 * L, din, 0, u->up_w[i], u->up_b[i], in[0]);
     L *= 2;
   }
   // final_conv (temporal_unet.py:104-110); with one level there are no ups and L is still 64
-  conv(0, 5, in[0], s.uid, nullptr, 0, L, L, s.uid, u->fin_w5, u->fin_b5, B + u->fin_g, B + u->fin_be, nullptr, nullptr, mid);
-  conv(0, 1, mid, s.uid, nullptr, 0, L, L, 4, u->fin_w1, u->fin_b1, nullptr, nullptr, nullptr, nullptr, eps);
+  block5(in[0], s.uid, nullptr, 0, 0, L, s.uid, u->fin_w5, u->fin_b5, u->fin_g, u->fin_be, nullptr, nullptr, mid);
+  plain(0, 1, mid, s.uid, nullptr, 0, 0, L, L, 4, 1, u->fin_w1, u->fin_b1, eps);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -65,6 +65,29 @@ def test_layered_path_equals_fused_kernel_on_option0(monkeypatch):
     assert lib.mmd_unet_workspace_bytes(layered.handle(device="cuda"), n) > lib.mmd_unet_workspace_bytes(fused.handle(device="cuda"), n)
 
 
+@pytest.mark.parametrize("dm", [(1, 2, 4), (1, 2, 4, 8)], ids=["option0", "option1"])
+def test_layered_forward_bits_do_not_depend_on_the_batch(monkeypatch, dm):
+    """The launch shape of the layer kernels follows the batch size (1, 2 or 4 output channels per thread, 2 .. 8 channel slices per
+    sample); the sum over the input channels is DEFINED as four interleaved partial sums combined in a fixed tree, so a trajectory's
+    eps must not change by a bit with the size of the batch it sits in (n = 8: CT 1, n = 200: CT 2, n = 800: CT 4), and for option 0
+    every size must agree with the fused kernel."""
+    monkeypatch.setenv("MMD_AMD_UNET_LAYERED", "1")
+    layered = _unet(32, dm)
+    layered.handle(25, "cuda")
+    monkeypatch.delenv("MMD_AMD_UNET_LAYERED")
+    x = (torch.from_numpy(synth.synth_noise(902, (800, H, D))) * 0.7).cuda()
+    big = layered(x, 7)
+    assert torch.isfinite(big).all()
+    assert torch.equal(layered(x[:200].contiguous(), 7), big[:200])
+    assert torch.equal(layered(x[600:608].contiguous(), 7), big[600:608])
+    if dm == (1, 2, 4):
+        fused = _unet(32, dm)
+        fused.handle(25, "cuda")
+        err = rel_l2(big.cpu(), fused(x, 7).cpu())
+        parity_log.record("layered_vs_fused", "n800_t7", None, err, bound=6e-6)
+        assert err < 6e-6, err
+
+
 def _g17_chain_case():
     g = np.load(os.path.join(GOLDEN, "g17_unet_dim_mults.npz"))
     T, B, s_x, s_n = (int(v) for v in g["meta"])
