@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMD_AMD_ABI_VERSION 5
+#define MMD_AMD_ABI_VERSION 6
 #define MMD_STATE_DIM 4
 #define MMD_HORIZON 64
 
@@ -141,11 +141,13 @@ int mmd_soft_constraints_from_paths(const float* paths_dev, int n_all, int robot
                                     float* grp_weight_dev, int32_t* robot_grp_off_dev, void* stream);
 
 /* n_steps x { x += guide(x); apply_hard_conditioning }  (guide_gradient_steps,
- * mmd/models/diffusion_models/sample_functions.py:89-107).  hard_dev [n_robots][2][4]: normalised start / goal
- * state of each robot; hard_mask bit0 = row 0 is conditioned, bit1 = row H-1 is conditioned.  chain_dev, if not NULL,
+ * mmd/models/diffusion_models/sample_functions.py:89-107).  Hard conditions (apply_hard_conditioning,
+ * sample_functions.py:8-14: the dict {support point: state}): bit t of hard_rows set = support point t of every trajectory
+ * is pinned; hard_dev [n_robots][popcount(hard_rows)][4] holds each robot's pinned states in ascending row order
+ * (MPD's {0: start, H-1: goal} = hard_rows 0x8000000000000001, hard_dev [n_robots][2][4]).  chain_dev, if not NULL,
  * receives the state after EVERY iteration, [n_steps][n_traj, H, 4] (the post-diffusion guide steps of planner_alg
  * 'diffusion_prior_then_guide', mmd/planners/single_agent/mpd.py:429-453, in one launch). */
-int mmd_guide_steps(const mmd_guide_desc* g, float* x_dev, const float* hard_dev, int hard_mask, int n_robots,
+int mmd_guide_steps(const mmd_guide_desc* g, float* x_dev, const float* hard_dev, uint64_t hard_rows, int n_robots,
                     int samples_per_robot, int n_steps, float* chain_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -164,7 +166,7 @@ typedef struct mmd_sampler_desc {
   int32_t n_guide_steps;                    /* 20 (mmd_params.py:38) */
   int32_t t_start_guide;                    /* guide iff loop index i < t_start_guide (sample_functions.py:63) */
   float noise_std_extra;                    /* 0.5 (mpd.py:303) */
-  int32_t hard_mask;                        /* as in mmd_guide_steps */
+  uint64_t hard_rows;                       /* as in mmd_guide_steps */
   int32_t n_streams;                        /* mmd_p_sample_loop splits the robots into this many concurrent HIP
                                              * streams (forked from / joined to `stream`) so one chunk's staging and
                                              * epilogues overlap the other's MFMA phases; 0 = auto (2 from 2048
@@ -181,7 +183,7 @@ typedef struct mmd_sampler_desc {
   int32_t scale_grad_by_std;                /* 1: every guide gradient is multiplied by model_var = exp(posterior_log_variance_
                                              * clipped[t]) before it is added (guide_gradient_steps, sample_functions.py:100-101) */
   int32_t model_predicts_x0;                /* 1: GaussianDiffusionModel(predict_epsilon=False): the network output IS x_recon
-                                             * (predict_start_from_noise, diffusion_model_base.py:131-141); DDPM sampler only */
+                                             * (predict_start_from_noise / predict_noise_from_start, diffusion_model_base.py:114-141) */
 } mmd_sampler_desc;
 
 /* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop: [UNet token (256 B)][eps: n_traj * H * 4 floats].  The chunked

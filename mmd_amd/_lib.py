@@ -5,7 +5,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmd_amd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
+HARD_ROWS_START_GOAL = (1 << 63) | 1     # hard_rows of MPD's {0: start, H-1: goal} (include/mmd_amd.h: bit t = support point t pinned)
+
+
+def signed64(mask):
+    """a 64-bit row mask as the signed int64 a torch custom-op `int` argument carries (the C side sees the same bits)."""
+    mask = int(mask) & 0xFFFFFFFFFFFFFFFF
+    return mask - (1 << 64) if mask >> 63 else mask
+
 
 
 class GuideDesc(C.Structure):
@@ -34,7 +42,7 @@ class SamplerDesc(C.Structure):
         ("posterior_mean_coef2", C.POINTER(C.c_float)),
         ("posterior_log_variance_clipped", C.POINTER(C.c_float)),
         ("n_guide_steps", C.c_int32), ("t_start_guide", C.c_int32),
-        ("noise_std_extra", C.c_float), ("hard_mask", C.c_int32), ("n_streams", C.c_int32),
+        ("noise_std_extra", C.c_float), ("hard_rows", C.c_uint64), ("n_streams", C.c_int32),
         ("traj_index_base", C.c_int64), ("noise_std_extra_by_t", C.POINTER(C.c_float)), ("profiler", C.c_void_p),
         ("scale_grad_by_std", C.c_int32), ("model_predicts_x0", C.c_int32),
     ]
@@ -68,7 +76,7 @@ _SIGNATURES = {
                                        C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "mmd_soft_constraints_from_paths": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mmd_guide_steps": (C.c_int, [C.POINTER(GuideDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+    "mmd_guide_steps": (C.c_int, [C.POINTER(GuideDesc), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),
     "mmd_sampler_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "mmd_ddpm_step": (C.c_int, [C.c_void_p, C.POINTER(SamplerDesc), C.POINTER(GuideDesc), C.c_void_p, C.c_void_p,

@@ -93,7 +93,7 @@ static int make_step(const mmd_sampler_desc* s, int i, bool guided, StepDev& sd)
   sd.do_guide = guided && i < s->t_start_guide ? 1 : 0;           // sample_functions.py:63
   sd.do_noise = t == 0 ? 0 : 1;                                   // noise[t == 0] = 0, sample_functions.py:76
   sd.n_guide_steps = s->n_guide_steps;
-  sd.hard_mask = s->hard_mask;
+  sd.hard_rows = s->hard_rows; sd.n_hard = __builtin_popcountll(s->hard_rows);
   sd.traj_base = (long long)s->traj_index_base;
   return 0;
 }
@@ -157,7 +157,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   GuideDev g{};
   if (guide)
     if (int rc = fill_guide(guide, g)) return rc;
-  launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed,
+  launch_init(x_dev, chain_dev, hard_dev, s->hard_rows, init_noise, (unsigned long long)seed,
               (long long)s->traj_index_base, n, samples_per_robot, st);
 
   // Split the robots into concurrent chunks: each chunk's kernels go to its own stream, launches interleaved layer by
@@ -196,7 +196,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
         FusedStep fs{};
         fs.enabled = 1;
         fs.a_t = sd.a_t; fs.b_t = sd.b_t; fs.c1 = sd.c1; fs.c2 = sd.c2; fs.sigma = sd.sigma; fs.noise_std_extra = sd.noise_std_extra;
-        fs.do_noise = sd.do_noise; fs.hard_mask = sd.hard_mask; fs.seed = sd.seed; fs.draw = sd.draw; fs.traj_base = sd.traj_base;
+        fs.do_noise = sd.do_noise; fs.hard_rows = sd.hard_rows; fs.n_hard = sd.n_hard; fs.seed = sd.seed; fs.draw = sd.draw; fs.traj_base = sd.traj_base;
         fs.traj0 = t0; fs.spr = samples_per_robot;
         fs.x = reinterpret_cast<float4*>(x_dev); fs.noise = reinterpret_cast<const float4*>(noise_k);
         fs.chain = reinterpret_cast<float4*>(chain_k); fs.hard = reinterpret_cast<const float4*>(hard_dev);
@@ -261,7 +261,7 @@ int mmd_p_sample_loop_ensemble(const mmd_ensemble_tile* tiles, int n_tiles, cons
   };
   // x_T per tile (diffusion_ensemble.py:66-81): draw / keep, hard conditioning, then cross conditioning; chain[0]
   for (int m = 0; m < n_tiles; ++m)
-    launch_init(tiles[m].x_dev, tiles[m].chain_dev, tiles[m].hard_dev, tiles[m].sampler->hard_mask, init_noise,
+    launch_init(tiles[m].x_dev, tiles[m].chain_dev, tiles[m].hard_dev, tiles[m].sampler->hard_rows, init_noise,
                 (unsigned long long)tiles[m].seed, (long long)tiles[m].sampler->traj_index_base, n, samples_per_robot, st);
   cross_all(0);
   int k = 0;
@@ -303,24 +303,23 @@ int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alp
   GuideDev g{};
   if (guide)
     if (int rc = fill_guide(guide, g)) return rc;
-  launch_init(x_dev, chain_dev, hard_dev, s->hard_mask, init_noise, (unsigned long long)seed,
+  launch_init(x_dev, chain_dev, hard_dev, s->hard_rows, init_noise, (unsigned long long)seed,
               (long long)s->traj_index_base, n, samples_per_robot, st);
   for (int k = 0; k + 1 < n_times; ++k) {
     const int t = times[k], tn = times[k + 1];
     MMD_REQUIRE(t >= 0 && t < s->n_diffusion_steps && tn < t, "mmd_ddim_sample: times must decrease inside the schedule");
-    MMD_REQUIRE(!s->model_predicts_x0, "mmd_ddim_sample: predict_epsilon = False is implemented for the DDPM sampler only");
     StepDev sd{};
-    sd.ddim = 1;
+    sd.ddim = s->model_predicts_x0 ? 2 : 1;
     sd.grad_scale = 1.f;                                              // (ddim_sample passes no scale_grad_by_std on)
     sd.a_t = s->sqrt_recip_alphas_cumprod[t];
-    sd.b_t = s->sqrt_recipm1_alphas_cumprod[t];
+    sd.b_t = s->model_predicts_x0 ? 1.f / s->sqrt_recipm1_alphas_cumprod[t] : s->sqrt_recipm1_alphas_cumprod[t];
     sd.c1 = tn < 0 ? 1.f : sqrtf(alphas_cumprod[tn]);               // x = x_start on the last pair (time_next = -1)
     sd.c2 = tn < 0 ? 0.f : sqrtf(1.f - alphas_cumprod[tn]);         // sigma = eta * ... = 0
     sd.do_model = 1;
     sd.do_guide = guide && tn >= 0 && tn < s->t_start_guide ? 1 : 0;  // torch.all(t_next < t_start_guide); none after the break
     sd.do_noise = 0;
     sd.n_guide_steps = s->n_guide_steps;
-    sd.hard_mask = s->hard_mask;
+    sd.hard_rows = s->hard_rows; sd.n_hard = __builtin_popcountll(s->hard_rows);
     sd.seed = seed; sd.draw = (unsigned int)k;
     sd.traj_base = (long long)s->traj_index_base;
     if (int rc = mmd_unet_forward_profiled(unet, x_dev, t, eps, n, workspace_dev, uws, (mmd_profiler_t)s->profiler, stream))

@@ -295,11 +295,12 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
   const size_t idx = (size_t)traj * H + t;
   float4 v = x[idx];
 
-  if (s.do_model) v = s.ddim ? ddim_update(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2) : ddpm_posterior_mean(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2);
+  if (s.do_model)
+    v = s.ddim == 2 ? ddim_update_x0(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2)
+        : s.ddim ? ddim_update(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2) : ddpm_posterior_mean(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2);
 
-  const float4 hs = hard[robot * 2 + 0], hg = hard[robot * 2 + 1];
-  const bool is_start = (s.hard_mask & 1) && t == 0;
-  const bool is_goal = (s.hard_mask & 2) && t == H - 1;
+  float4 hv = v;
+  const bool is_hard = hard_row(s.hard_rows, s.n_hard, hard, robot, t, hv);
 
   if (s.do_guide) {
     const int map = g.robot_map ? g.robot_map[robot] : 0;
@@ -331,15 +332,13 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
       // (x + model_var * grad with scale_grad_by_std, sample_functions.py:100-104; grad_scale = 1 otherwise: the fma is then the add)
       v.x = __builtin_fmaf(s.grad_scale, gr.x, v.x); v.y = __builtin_fmaf(s.grad_scale, gr.y, v.y);
       v.z = __builtin_fmaf(s.grad_scale, gr.z, v.z); v.w = __builtin_fmaf(s.grad_scale, gr.w, v.w);
-      if (is_start) v = hs;
-      if (is_goal) v = hg;
+      if (is_hard) v = hv;
       if (s.guide_chain) s.guide_chain[(size_t)it * s.guide_chain_stride + idx] = v;
     }
   }
 
   if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx), s.sigma, s.noise_std_extra);
-  if (is_start) v = hs;
-  if (is_goal) v = hg;
+  if (is_hard) v = hv;
   x[idx] = v;
   if (chain) chain[idx] = v;
 }
@@ -379,10 +378,11 @@ __global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDe
   __syncthreads();
   const size_t idx = (size_t)traj * H + t;
   float4 v = x[idx];
-  if (s.do_model) v = s.ddim ? ddim_update(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2) : ddpm_posterior_mean(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2);
-  const float4 hs = hard[robot * 2 + 0], hg = hard[robot * 2 + 1];
-  const bool is_start = (s.hard_mask & 1) && t == 0;
-  const bool is_goal = (s.hard_mask & 2) && t == H - 1;
+  if (s.do_model)
+    v = s.ddim == 2 ? ddim_update_x0(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2)
+        : s.ddim ? ddim_update(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2) : ddpm_posterior_mean(v, eps[idx], s.a_t, s.b_t, s.c1, s.c2);
+  float4 hv = v;
+  const bool is_hard = hard_row(s.hard_rows, s.n_hard, hard, robot, t, hv);
   if (s.do_guide) {
     const int map = g.robot_map ? g.robot_map[robot] : 0;
     const float4* grid = g.grids + (size_t)map * g.n_grids * g.nx * g.ny;
@@ -417,30 +417,28 @@ __global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDe
       // (x + model_var * grad with scale_grad_by_std, sample_functions.py:100-104; grad_scale = 1 otherwise: the fma is then the add)
       v.x = __builtin_fmaf(s.grad_scale, gr.x, v.x); v.y = __builtin_fmaf(s.grad_scale, gr.y, v.y);
       v.z = __builtin_fmaf(s.grad_scale, gr.z, v.z); v.w = __builtin_fmaf(s.grad_scale, gr.w, v.w);
-      if (is_start) v = hs;
-      if (is_goal) v = hg;
+      if (is_hard) v = hv;
       if (s.guide_chain && wave == 0) s.guide_chain[(size_t)it * s.guide_chain_stride + idx] = v;
     }
   }
   if (wave != 0) return;
   if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx), s.sigma, s.noise_std_extra);
-  if (is_start) v = hs;
-  if (is_goal) v = hg;
+  if (is_hard) v = hv;
   x[idx] = v;
   if (chain) chain[idx] = v;
 }
 
 // x <- conditioned init: optional Philox draw of x_T, apply_hard_conditioning, optional chain[0] write
 __global__ void init_kernel(float4* __restrict__ x, float4* __restrict__ chain, const float4* __restrict__ hard,
-                            int hard_mask, int draw_noise, unsigned long long seed, long long traj_base, int n_traj,
+                            unsigned long long hard_rows, int draw_noise, unsigned long long seed, long long traj_base, int n_traj,
                             int samples_per_robot) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n_traj * H) return;
   const int t = idx % H;
   const int robot = (idx / H) / samples_per_robot;
   float4 v = draw_noise ? normal4(seed, 0xFFFFFFFFu, (unsigned long long)traj_base * H + idx) : x[idx];
-  if ((hard_mask & 1) && t == 0) v = hard[robot * 2];
-  if ((hard_mask & 2) && t == H - 1) v = hard[robot * 2 + 1];
+  float4 hv;
+  if (hard_row(hard_rows, __popcll(hard_rows), hard, robot, t, hv)) v = hv;
   x[idx] = v;
   if (chain) chain[idx] = v;
 }
@@ -590,11 +588,11 @@ void launch_cross(float* x1, float* x2, float* c1, float* c2, int ind1, int ind2
                      make_float4(bnd[0], bnd[1], bnd[2], bnd[3]), n_traj);
 }
 
-int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed,
+int launch_init(float* x, float* chain, const float* hard, unsigned long long hard_rows, int draw, unsigned long long seed,
                 long long traj_base, int n_traj, int spr, hipStream_t st) {
   const size_t n = (size_t)n_traj * H;
   hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float4*)x, (float4*)chain,
-                     (const float4*)hard, hard_mask, draw, seed, traj_base, n_traj, spr);
+                     (const float4*)hard, hard_rows, draw, seed, traj_base, n_traj, spr);
   return 0;
 }
 
@@ -656,13 +654,13 @@ int mmd_soft_constraints_from_paths(const float* paths_dev, int n_all, int robot
   return 0;
 }
 
-int mmd_guide_steps(const mmd_guide_desc* d, float* x_dev, const float* hard_dev, int hard_mask, int n_robots,
+int mmd_guide_steps(const mmd_guide_desc* d, float* x_dev, const float* hard_dev, uint64_t hard_rows, int n_robots,
                     int samples_per_robot, int n_steps, float* chain_dev, void* stream) {
   MMD_REQUIRE(d && x_dev && hard_dev, "mmd_guide_steps: NULL argument");
   GuideDev g{};
   if (int rc = fill_guide(d, g)) return rc;
   StepDev s{};
-  s.do_guide = 1; s.n_guide_steps = n_steps; s.hard_mask = hard_mask; s.grad_scale = 1.f;
+  s.do_guide = 1; s.n_guide_steps = n_steps; s.hard_rows = hard_rows; s.n_hard = __builtin_popcountll(hard_rows); s.grad_scale = 1.f;
   s.guide_chain = reinterpret_cast<float4*>(chain_dev);
   s.guide_chain_stride = (long long)n_robots * samples_per_robot * H;
   launch_step(g, s, x_dev, nullptr, nullptr, nullptr, hard_dev, 0, n_robots * samples_per_robot, samples_per_robot,

@@ -111,6 +111,12 @@ __device__ __forceinline__ float4 ddim_update(float4 v, float4 e, float a, float
   auto f = [&](float x, float ee) { return __builtin_fmaf(c1, __builtin_fmaf(a, x, -(b * ee)), c2 * ee); };
   return make_float4(f(v.x, e.x), f(v.y, e.y), f(v.z, e.z), f(v.w, e.w));
 }
+// the same with GaussianDiffusionModel(predict_epsilon=False): the network output o IS x_start, pred_noise = (a x - o) / b
+// (predict_noise_from_start, diffusion_model_base.py:114-124); b_inv = 1 / b is passed in `b`
+__device__ __forceinline__ float4 ddim_update_x0(float4 v, float4 o, float a, float b_inv, float c1, float c2) {
+  auto f = [&](float x, float oo) { return __builtin_fmaf(c1, oo, c2 * (__builtin_fmaf(a, x, -oo) * b_inv)); };
+  return make_float4(f(v.x, o.x), f(v.y, o.y), f(v.z, o.z), f(v.w, o.w));
+}
 // x + model_std * noise * noise_std  (sample_functions.py:86)
 __device__ __forceinline__ float4 add_step_noise(float4 v, float4 z, float sigma, float noise_std_extra) {
   return make_float4(__builtin_fmaf(sigma * z.x, noise_std_extra, v.x), __builtin_fmaf(sigma * z.y, noise_std_extra, v.y),
@@ -123,7 +129,8 @@ __device__ __forceinline__ float4 add_step_noise(float4 v, float4 z, float sigma
 struct FusedStep {
   int enabled;
   float a_t, b_t, c1, c2, sigma, noise_std_extra;
-  int do_noise, hard_mask;
+  int do_noise, n_hard;
+  unsigned long long hard_rows;
   unsigned long long seed;
   unsigned int draw;
   long long traj_base;
@@ -134,15 +141,26 @@ struct FusedStep {
   const float4* hard;
 };
 
+// apply_hard_conditioning (sample_functions.py:8-14: x[:, t, :] = val for every (t, val) of the hard_conds dict): bit t of `rows` set =
+// support point t of every trajectory of a robot is pinned to hard[robot][slot], slot = number of pinned rows below t (the dict's
+// rows in ascending order; {0, H-1} = the start / goal pair MPD passes).  Returns whether row t is pinned; hv is its value then.
+__device__ __forceinline__ bool hard_row(unsigned long long rows, int n_hard, const float4* hard, int robot, int t, float4& hv) {
+  const bool on = (rows >> t) & 1ull;
+  if (on) hv = hard[robot * n_hard + __popcll(rows & ((1ull << t) - 1ull))];
+  return on;
+}
+
 struct StepDev {
   float a_t, b_t, c1, c2;            // sqrt_recip_alphas_cumprod[t], sqrt_recipm1[t], posterior_mean_coef1/2[t]
   float sigma;                       // exp(0.5 * posterior_log_variance_clipped[t])
   float noise_std_extra;
   float grad_scale;                  // scale_grad_by_std: model_var = exp(posterior_log_variance_clipped[t]), else 1
   int do_model, do_guide, do_noise;  // do_model = 0: guide-only launch (mmd_guide_steps)
-  int ddim;                          // 1: DDIM update x <- c1 * (a x - b eps) + c2 * eps, x0 not clamped (mmd_ddim_sample)
+  int ddim;                          // 1: DDIM update x <- c1 * (a x - b eps) + c2 * eps, x0 not clamped (mmd_ddim_sample); 2: the
+                                     // network predicts x0 (b_t holds 1 / sqrt_recipm1_alphas_cumprod[t])
   int n_guide_steps;
-  int hard_mask;
+  int n_hard;                        // popcount(hard_rows)
+  unsigned long long hard_rows;      // bit t: support point t is hard-conditioned (hard[robot][slot], slot = pinned rows below t)
   unsigned long long seed;
   unsigned int draw;
   int traj0, traj_end;               // this launch covers trajectories [traj0, traj_end) of the full arrays
@@ -158,7 +176,7 @@ int unet_forward_fused(mmd_unet_t u, const float* x, int t, float* eps, int n, v
                        hipStream_t st, const FusedStep& fs);
 int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
                 const float* hard, int traj0, int n_traj, int spr, hipStream_t st);
-int launch_init(float* x, float* chain, const float* hard, int hard_mask, int draw, unsigned long long seed,
+int launch_init(float* x, float* chain, const float* hard, unsigned long long hard_rows, int draw, unsigned long long seed,
                 long long traj_base, int n_traj, int spr, hipStream_t st);
 
 void launch_cross(float* x1, float* x2, float* c1, float* c2, int ind1, int ind2, const float* rel, const float* bnd,

@@ -2004,8 +2004,8 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
         if (fs.do_noise)
           v = add_step_noise(v, fs.noise ? fs.noise[idx] : normal4(fs.seed, fs.draw, (unsigned long long)fs.traj_base * H + idx), fs.sigma,
                              fs.noise_std_extra);
-        if ((fs.hard_mask & 1) && lane == 0) v = fs.hard[robot * 2 + 0];
-        if ((fs.hard_mask & 2) && lane == H - 1) v = fs.hard[robot * 2 + 1];
+        float4 hv;
+        if (hard_row(fs.hard_rows, fs.n_hard, fs.hard, robot, lane, hv)) v = hv;
         fs.x[idx] = v;
         if (fs.chain) fs.chain[idx] = v;
       }
@@ -2285,8 +2285,8 @@ __device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalAr
         if (fs.do_noise)
           v = add_step_noise(v, fs.noise ? fs.noise[idx] : normal4(fs.seed, fs.draw, (unsigned long long)fs.traj_base * H + idx), fs.sigma,
                              fs.noise_std_extra);
-        if ((fs.hard_mask & 1) && lane == 0) v = fs.hard[robot * 2 + 0];
-        if ((fs.hard_mask & 2) && lane == H - 1) v = fs.hard[robot * 2 + 1];
+        float4 hv;
+        if (hard_row(fs.hard_rows, fs.n_hard, fs.hard, robot, lane, hv)) v = hv;
         fs.x[idx] = v;
         if (fs.chain) fs.chain[idx] = v;
       }

@@ -83,7 +83,7 @@ class GaussianDiffusionModel:
                 self._noise_tables.pop(next(iter(self._noise_tables)))
         return self._noise_tables[key][1]
 
-    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_fn, hard_mask, n_streams=0, traj_index_base=0,
+    def _sampler_desc(self, n_guide_steps, t_start_guide, noise_fn, hard_rows, n_streams=0, traj_index_base=0,
                       scale_grad_by_std=False):
         s = _lib.SamplerDesc()
         s.n_diffusion_steps = self.n_diffusion_steps
@@ -97,7 +97,7 @@ class GaussianDiffusionModel:
         table = self._noise_std_table(noise_fn)
         s.noise_std_extra = float(table[0])
         s.noise_std_extra_by_t = table.ctypes.data_as(fp)
-        s.hard_mask = hard_mask
+        s.hard_rows = int(hard_rows) & 0xFFFFFFFFFFFFFFFF      # (torch custom ops carry the mask as a signed int64)
         s.n_streams = int(n_streams)
         s.traj_index_base = int(traj_index_base)
         s.profiler = self.profiler
@@ -107,23 +107,22 @@ class GaussianDiffusionModel:
 
     @staticmethod
     def _hard_tensor(hard_conds, n_robots, horizon, device, D):
-        """{row: [D] | [n_robots, D] | [B_total, D]} -> ([n_robots, 2, D] float32, mask).  Per-sample hard conditions
-        must be constant within a robot (they are: run_inference repeats one state, diffusion_model_base.py:327-329)."""
-        hard = torch.zeros(n_robots, 2, D, dtype=torch.float32, device=device)
+        """apply_hard_conditioning's dict (sample_functions.py:8-14) {row: [D] | [n_robots, D] | [B_total, D]} -> ([n_robots, n_rows, D]
+        float32 in ascending row order, the 64-bit row mask of include/mmd_amd.h).  Per-sample hard conditions must be constant
+        within a robot (they are: run_inference repeats one state, diffusion_model_base.py:327-329)."""
+        rows = sorted(int(r) for r in hard_conds)
+        if rows and not 0 <= rows[0] <= rows[-1] < horizon:
+            raise ValueError(f"hard condition rows {rows} outside [0, {horizon})")
+        hard = torch.zeros(n_robots, max(len(rows), 1), D, dtype=torch.float32, device=device)
         mask = 0
-        for row, val in hard_conds.items():
-            val = torch.as_tensor(val, dtype=torch.float32, device=device)
+        for slot, row in enumerate(rows):
+            val = torch.as_tensor(hard_conds[row], dtype=torch.float32, device=device)
             if val.ndim == 1:
                 val = val[None].expand(n_robots, D)
             elif val.shape[0] != n_robots:
                 per = val.shape[0] // n_robots
                 val = val[::per]
-            if row == 0:
-                hard[:, 0], mask = val, mask | 1
-            elif row == horizon - 1:
-                hard[:, 1], mask = val, mask | 2
-            else:
-                raise NotImplementedError("hard conditions are supported on rows 0 and H-1 (what MPD/MPDEnsemble use)")
+            hard[:, slot], mask = val, mask | (1 << row)
         return hard.contiguous(), mask
 
     # ---- sampling ---------------------------------------------------------------------------------------------
@@ -189,8 +188,6 @@ class GaussianDiffusionModel:
         `seed` for the Philox draw of x_T otherwise."""
         if context is not None:
             raise NotImplementedError("context")
-        if not self.predict_epsilon:
-            raise NotImplementedError("ddim_sample with predict_epsilon=False (the DDPM sampler implements it)")
         if guide is not None and not isinstance(guide, GuideManagerTrajectoriesWithVelocity):
             raise NotImplementedError("guide must be a mmd_amd GuideManagerTrajectoriesWithVelocity")
         B_total, H, D = shape

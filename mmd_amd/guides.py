@@ -151,16 +151,17 @@ class GuideManagerTrajectoriesWithVelocity:
         return d
 
     # ---- guide_gradient_steps / forward -----------------------------------------------------------------------
-    def guide_steps(self, x, hard, hard_mask, n_steps, chain=None):
+    def guide_steps(self, x, hard, hard_rows, n_steps, chain=None):
         """In place: n_steps x { x += guide(x); apply_hard_conditioning } (sample_functions.py:89-107).
-        x [n_robots*B,H,D]; hard [n_robots,2,D] normalised start / goal states; chain (optional) [n_steps, n_robots*B, H, D]
+        x [n_robots*B,H,D]; hard [n_robots, n_rows, D] normalised pinned states in ascending row order, hard_rows the 64-bit mask of
+        those rows (_lib.HARD_ROWS_START_GOAL for the start / goal pair, 0 for none); chain (optional) [n_steps, n_robots*B, H, D]
         receives the state after every iteration."""
         d = self.desc()
         B = x.shape[0] // self.n_robots
         if chain is not None:
             assert chain.shape == (n_steps,) + tuple(x.shape)
         _lib.launch("mmd_guide_steps", x, C.byref(d), _lib.require_gpu(x, "x"), _lib.require_gpu(hard, "hard"),
-                                               hard_mask, self.n_robots, B, n_steps,
+                                               int(hard_rows) & 0xFFFFFFFFFFFFFFFF, self.n_robots, B, n_steps,
                                                _lib.require_gpu(chain, "chain") if chain is not None else None)
         return x
 

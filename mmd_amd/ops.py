@@ -66,18 +66,19 @@ def _(x, t, n_timesteps, unet):
 
 # ---- guide_steps ---------------------------------------------------------------------------------------------------
 @torch.library.custom_op("mmd_amd::guide_steps", mutates_args=("x",), device_types="cuda")
-def guide_steps(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, n_steps: int, guide: int) -> None:
-    """In place: n_steps x { x += guide(x); apply_hard_conditioning } (sample_functions.py:89-107); hard [n_robots,2,4]."""
+def guide_steps(x: torch.Tensor, hard: torch.Tensor, hard_rows: int, n_steps: int, guide: int) -> None:
+    """In place: n_steps x { x += guide(x); apply_hard_conditioning } (sample_functions.py:89-107); hard [n_robots, n_rows, 4] + the 64-bit row
+    mask as a SIGNED int64 (_lib.signed64(_lib.HARD_ROWS_START_GOAL) for the start / goal pair)."""
     _check_traj(x)
     g = _get(guide, "guide")
     d = g.desc()
-    _lib.launch("mmd_guide_steps", x, C.byref(d), x.data_ptr(), _lib.require_gpu(hard, "hard"), int(hard_mask),
+    _lib.launch("mmd_guide_steps", x, C.byref(d), x.data_ptr(), _lib.require_gpu(hard, "hard"), int(hard_rows) & 0xFFFFFFFFFFFFFFFF,
                                            g.n_robots, x.shape[0] // g.n_robots, int(n_steps), None)
 
 
 # ---- p_sample_loop -------------------------------------------------------------------------------------------------
 @torch.library.custom_op("mmd_amd::p_sample_loop", mutates_args=("x",), device_types="cuda")
-def p_sample_loop(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: int, guide: int, n_robots: int,
+def p_sample_loop(x: torch.Tensor, hard: torch.Tensor, hard_rows: int, model: int, guide: int, n_robots: int,
                   n_steps: int, n_steps_without_noise: int, init_noise: bool, step_noise: torch.Tensor | None, seed: int,
                   n_guide_steps: int, t_start_guide: int, noise_std_extra: float, traj_index_base: int,
                   return_chain: bool) -> torch.Tensor:
@@ -89,7 +90,7 @@ def p_sample_loop(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: in
     m = _get(model, "model")
     g = _get(guide, "guide") if guide else None
     n_total = n_steps + n_steps_without_noise
-    s = m._sampler_desc(n_guide_steps, t_start_guide, None, hard_mask, 0, traj_index_base)
+    s = m._sampler_desc(n_guide_steps, t_start_guide, None, hard_rows, 0, traj_index_base)
     s.noise_std_extra, s.noise_std_extra_by_t = float(noise_std_extra), None
     gd = g.desc() if g is not None else None
     chain = (torch.empty((n_total + 1,) + tuple(x.shape), dtype=torch.float32, device=x.device) if return_chain
@@ -105,7 +106,7 @@ def p_sample_loop(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: in
 
 
 @p_sample_loop.register_fake
-def _(x, hard, hard_mask, model, guide, n_robots, n_steps, n_steps_without_noise, init_noise, step_noise, seed,
+def _(x, hard, hard_rows, model, guide, n_robots, n_steps, n_steps_without_noise, init_noise, step_noise, seed,
       n_guide_steps, t_start_guide, noise_std_extra, traj_index_base, return_chain):
     n_total = n_steps + n_steps_without_noise
     return x.new_empty((n_total + 1,) + tuple(x.shape)) if return_chain else x.new_empty(0)
@@ -113,7 +114,7 @@ def _(x, hard, hard_mask, model, guide, n_robots, n_steps, n_steps_without_noise
 
 # ---- ddim_sample ---------------------------------------------------------------------------------------------------
 @torch.library.custom_op("mmd_amd::ddim_sample", mutates_args=("x",), device_types="cuda")
-def ddim_sample(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: int, guide: int, n_robots: int,
+def ddim_sample(x: torch.Tensor, hard: torch.Tensor, hard_rows: int, model: int, guide: int, n_robots: int,
                 n_diffusion_steps: int, init_noise: bool, seed: int, t_start_guide: int, traj_index_base: int,
                 return_chain: bool) -> torch.Tensor:
     """GaussianDiffusionModel.ddim_sample (diffusion_model_base.py:213-290, eta = 0) on x in place; chain [n_times, ...]."""
@@ -121,7 +122,7 @@ def ddim_sample(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: int,
     _check_traj(x)
     m = _get(model, "model")
     g = _get(guide, "guide") if guide else None
-    s = m._sampler_desc(1, t_start_guide, None, hard_mask, 0, traj_index_base)
+    s = m._sampler_desc(1, t_start_guide, None, hard_rows, 0, traj_index_base)
     times = np.asarray(m.ddim_times(n_diffusion_steps), dtype=np.int32)
     acp = np.ascontiguousarray(m._tables["alphas_cumprod"], dtype=np.float32)
     gd = g.desc() if g is not None else None
@@ -136,7 +137,7 @@ def ddim_sample(x: torch.Tensor, hard: torch.Tensor, hard_mask: int, model: int,
 
 
 @ddim_sample.register_fake
-def _(x, hard, hard_mask, model, guide, n_robots, n_diffusion_steps, init_noise, seed, t_start_guide, traj_index_base,
+def _(x, hard, hard_rows, model, guide, n_robots, n_diffusion_steps, init_noise, seed, t_start_guide, traj_index_base,
       return_chain):
     n_times = n_diffusion_steps // 5 + 2
     return x.new_empty((n_times,) + tuple(x.shape)) if return_chain else x.new_empty(0)

@@ -300,9 +300,9 @@ class MPD:
             return chain
         n_post = (self.t_start_guide + self.n_diffusion_steps_without_noise) * self.n_guide_steps
         x = chain[-1].contiguous().clone()
-        hard = torch.stack([self.hard_conds[0], self.hard_conds[HORIZON - 1]])[None].to(x.device).contiguous()
+        hard, mask = self.model._hard_tensor(self.hard_conds, 1, HORIZON, x.device, x.shape[-1])
         extra = torch.empty((n_post,) + tuple(x.shape), dtype=torch.float32, device=x.device)
-        self.guide.guide_steps(x, hard, 3, n_post, chain=extra)        # ONE launch; every iteration lands in `extra`
+        self.guide.guide_steps(x, hard, mask, n_post, chain=extra)        # ONE launch; every iteration lands in `extra`
         return torch.cat((chain, extra))
 
     def run_constrained_inference(self, cost_constraints_l, **kw):

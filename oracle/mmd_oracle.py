@@ -578,9 +578,11 @@ def ddim_times(n_diffusion_steps):
     return list(reversed(times.int().tolist()))
 
 
-def ddim_sample(sd, tb, x_init, hard_conds, n_diffusion_steps, *, guide=None, t_start_guide=float("inf"), n_levels=None):
-    """GaussianDiffusionModel.ddim_sample (diffusion_model_base.py:213-290), predict_epsilon=True, eta = 0 (sigma = 0: the
-    per-step randn_like draw is multiplied by 0).  x_init [B,H,D] is the injected x_T.  Quirk kept: the guide runs ONE
+def ddim_sample(sd, tb, x_init, hard_conds, n_diffusion_steps, *, guide=None, t_start_guide=float("inf"), n_levels=None,
+                predict_epsilon=True):
+    """GaussianDiffusionModel.ddim_sample (diffusion_model_base.py:213-290), eta = 0 (sigma = 0: the per-step randn_like draw
+    is multiplied by 0).  predict_epsilon=False: the network output is x_start and pred_noise = (a x - out) / b
+    (predict_noise_from_start, :114-124).  x_init [B,H,D] is the injected x_T.  Quirk kept: the guide runs ONE
     gradient step per sampling step -- ddim_sample binds `n_guide_steps` itself and forwards only **sample_kwargs, so
     guide_gradient_steps (sample_functions.py:89) runs with its default n_guide_steps=1.  x_start is NOT clamped here.
     Returns chain [n_pairs+1, B,H,D]."""
@@ -590,7 +592,11 @@ def ddim_sample(sd, tb, x_init, hard_conds, n_diffusion_steps, *, guide=None, t_
     B = x.shape[0]
     for time, time_next in zip(times[:-1], times[1:]):
         eps = unet_forward(sd, x, torch.full((B,), time, dtype=torch.long), n_levels)
-        x_start = tb["sqrt_recip_alphas_cumprod"][time] * x - tb["sqrt_recipm1_alphas_cumprod"][time] * eps
+        if predict_epsilon:
+            x_start = tb["sqrt_recip_alphas_cumprod"][time] * x - tb["sqrt_recipm1_alphas_cumprod"][time] * eps
+        else:
+            x_start = eps
+            eps = (tb["sqrt_recip_alphas_cumprod"][time] * x - x_start) / tb["sqrt_recipm1_alphas_cumprod"][time]
         if time_next < 0:
             x = apply_hard_conditioning(x_start, hard_conds)
             chain.append(x)

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from mmd_amd import synth                # noqa: E402
+from mmd_amd import _lib, synth          # noqa: E402
 from oracle import mmd_oracle as O       # noqa: E402
 import cases                             # noqa: E402
 from cases import H, D, rel_l2           # noqa: E402
@@ -150,7 +150,7 @@ def test_headline_guided_step_and_guide_vs_oracle(headline):
     # (a) one guide evaluation, (b) 20 guide iterations with hard conditioning
     g1 = s.guide(x.cuda()).cpu()
     y20 = x.clone().cuda()
-    s.guide.guide_steps(y20, hard, 3, 20)
+    s.guide.guide_steps(y20, hard, _lib.HARD_ROWS_START_GOAL, 20)
     y20 = y20.cpu()
     # (c) one guided DDPM step from x at i = 49 with injected noise
     noise = torch.from_numpy(synth.synth_noise(91, (R * B, H, D)))

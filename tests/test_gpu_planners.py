@@ -8,7 +8,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from mmd_amd import synth                # noqa: E402
+from mmd_amd import _lib, synth          # noqa: E402
+
+SG = _lib.signed64(_lib.HARD_ROWS_START_GOAL)   # the start / goal row mask as a torch custom-op int
 import cases                             # noqa: E402
 from oracle import mmd_oracle as O       # noqa: E402
 import parity_log                        # noqa: E402
@@ -470,26 +472,26 @@ def test_torch_ops_match_the_ctypes_path():
     x = torch.from_numpy(synth.synth_noise(120, (R * B, H, D))).cuda()
     assert torch.equal(torch.ops.mmd_amd.unet_forward(x, 7, T, tu), model.model(x, 7))
     y1, y2 = x.clone(), x.clone()
-    torch.ops.mmd_amd.guide_steps(y1, hard, 3, 5, tg)
-    guide.guide_steps(y2, hard, 3, 5)
+    torch.ops.mmd_amd.guide_steps(y1, hard, SG, 5, tg)
+    guide.guide_steps(y2, hard, _lib.HARD_ROWS_START_GOAL, 5)
     assert torch.equal(y1, y2)
     ref = model.run_inference(None, hc, n_samples=B, n_robots=R, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn,
                               guide=guide, n_guide_steps=20, t_start_guide=13, noise_std_extra_schedule_fn=lambda t: 0.5,
                               n_diffusion_steps_without_noise=1, seed=77)
     xo = torch.empty((R * B, H, D), device="cuda")
-    chain = torch.ops.mmd_amd.p_sample_loop(xo, hard, 3, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
+    chain = torch.ops.mmd_amd.p_sample_loop(xo, hard, SG, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
     assert torch.equal(chain, ref) and torch.equal(xo, ref[-1])
     refd, chd = model.ddim_sample((R * B, H, D), hc, n_diffusion_steps=T, return_chain=True, guide=guide,
                                   t_start_guide=13, n_robots=R, seed=78)
     xd = torch.empty((R * B, H, D), device="cuda")
-    chain_d = torch.ops.mmd_amd.ddim_sample(xd, hard, 3, tm, tg, R, T, True, 78, 13, 0, True)
+    chain_d = torch.ops.mmd_amd.ddim_sample(xd, hard, SG, tm, tg, R, T, True, 78, 13, 0, True)
     assert torch.equal(chain_d, chd.transpose(0, 1)) and torch.equal(xd, refd)
     # a side stream: the op runs on torch's current stream
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         xs = torch.empty((R * B, H, D), device="cuda")
-        cs = torch.ops.mmd_amd.p_sample_loop(xs, hard, 3, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
+        cs = torch.ops.mmd_amd.p_sample_loop(xs, hard, SG, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
     torch.cuda.current_stream().wait_stream(side)
     assert torch.equal(cs, ref)
     # stream capture: the whole 26-step guided loop as one hipGraph, replayed
@@ -497,7 +499,7 @@ def test_torch_ops_match_the_ctypes_path():
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        cg = torch.ops.mmd_amd.p_sample_loop(xg, hard, 3, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
+        cg = torch.ops.mmd_amd.p_sample_loop(xg, hard, SG, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(cg, ref) and torch.equal(xg, ref[-1])

@@ -8,6 +8,8 @@ import pytest
 import torch
 
 from mmd_amd import _lib, synth
+
+SG = _lib.signed64(_lib.HARD_ROWS_START_GOAL)
 from mmd_amd.constraints import CostConstraint
 from mmd_amd.environments import sdf_grid_texture
 from mmd_amd.normalization import LimitsNormalizer, TrajectoryDatasetFacade
@@ -115,8 +117,8 @@ def test_torch_library_ops_are_registered_with_fake_impls():
     schema = str(torch.ops.mmd_amd.p_sample_loop.default._schema)
     assert "Tensor(a0!) x" in schema and "Tensor? step_noise" in schema and "-> Tensor" in schema
     x, h = torch.empty(8, H, 4, device="meta"), torch.empty(1, 2, 4, device="meta")
-    assert torch.ops.mmd_amd.p_sample_loop(x, h, 3, 0, 0, 1, 25, 1, False, None, 0, 20, 13, 0.5, 0, True).shape == (27, 8, H, 4)
-    assert torch.ops.mmd_amd.ddim_sample(x, h, 3, 0, 0, 1, 100, False, 0, 50, 0, True).shape == (22, 8, H, 4)
+    assert torch.ops.mmd_amd.p_sample_loop(x, h, SG, 0, 0, 1, 25, 1, False, None, 0, 20, 13, 0.5, 0, True).shape == (27, 8, H, 4)
+    assert torch.ops.mmd_amd.ddim_sample(x, h, SG, 0, 0, 1, 100, False, 0, 50, 0, True).shape == (22, 8, H, 4)
     assert torch.ops.mmd_amd.unet_forward(x, 3, 25, 0).shape == x.shape
     with pytest.raises(RuntimeError):                       # CPU tensors: no kernel is registered for them
         torch.ops.mmd_amd.unet_forward(torch.zeros(1, H, 4), 0, 25, 0)

@@ -291,3 +291,43 @@ def test_g17_unet_dim_mults_oracle():
                                noise_std_extra=0.5)
         y = O.apply_hard_conditioning(y, hc)
         assert rel_l2(y, ref[k + 1]) < 1e-4, (k, i, rel_l2(y, ref[k + 1]))
+
+
+def _g18_hard_conds(g):
+    starts, goals, soft, hard = cases.highways_case()
+    hc = cases.hard_conds_for(starts[3], goals[3])
+    for row, v in zip(g["via_rows"], g["via_states"]):
+        hc[int(row)] = O.normalize(torch.from_numpy(v), cases.MINS, cases.MAXS)
+    return hc, cases.hard_conds_for(starts[3], goals[3]), soft, hard
+
+
+def test_g18_hard_rows_and_ddim_x0_oracle():
+    """apply_hard_conditioning on rows other than 0 / H-1 (sample_functions.py:8-14) through guided DDPM steps (teacher-forced from
+    the reference's chain rows) and a guided DDIM chain, and DDIM with predict_epsilon=False (diffusion_model_base.py:114-124, :248)."""
+    g = np.load(os.path.join(GOLDEN, "g18_hard_rows_ddim_x0.npz"))
+    hc4, hc2, soft, hard = _g18_hard_conds(g)
+    assert sorted(hc4) == [0, 17, 40, H - 1]
+    gp = cases.guide_params("EnvHighways2D")
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
+    T, B, s_x, s_n = (int(v) for v in g["ddpm_meta"])
+    tb = O.schedule_tables(T)
+    steps = torch.from_numpy(synth.synth_noise(s_n, (T + 1, B, H, D)))
+    ref = torch.from_numpy(g["ddpm_chain"])
+    for row in (17, 40):
+        assert torch.equal(ref[-1][:, row], hc4[row].expand(B, D))
+    for k in range(T + 1):
+        i = T - 1 - k if k < T else 0
+        y = O.ddpm_sample_step(sd, tb, ref[k].clone(), hc4, i, guide=lambda z: O.guide_grad(z, gp, [soft, hard]), n_guide_steps=20,
+                               t_start_guide=ceil(0.5 * T), noise=steps[k] if k < T else torch.zeros_like(steps[k]),
+                               noise_std_extra=0.5)
+        assert rel_l2(O.apply_hard_conditioning(y, hc4), ref[k + 1]) < 1e-4, k
+    T2, B2, s2 = (int(v) for v in g["ddim_meta"])
+    chain = O.ddim_sample(sd, O.schedule_tables(T2), torch.from_numpy(synth.synth_noise(s2, (B2, H, D))), hc4, T2,
+                          guide=lambda z: O.guide_grad(z, gp, [soft, hard]), t_start_guide=ceil(0.5 * T2))
+    assert chain.shape == g["ddim_chain"].shape
+    assert max(rel_l2(chain[k], g["ddim_chain"][k]) for k in range(chain.shape[0])) < 1e-4
+    T3, B3, s3 = (int(v) for v in g["ddim_x0_meta"])
+    chain0 = O.ddim_sample(sd, O.schedule_tables(T3), torch.from_numpy(synth.synth_noise(s3, (B3, H, D))), hc2, T3,
+                           predict_epsilon=False)
+    assert chain0.shape == g["ddim_x0_chain"].shape and np.isfinite(g["ddim_x0_chain"]).all()
+    assert max(rel_l2(chain0[k], g["ddim_x0_chain"][k]) for k in range(chain0.shape[0])) < 1e-4

@@ -746,11 +746,75 @@ def g17():
     print("   g17: chain", chain.shape, "final-row sensitivity", f"{sens[-1]:.2e}")
 
 
+def g18():
+    """Hard conditions on rows other than 0 / H-1 (apply_hard_conditioning takes any {row: state} dict, sample_functions.py:8-14)
+    and DDIM with GaussianDiffusionModel(predict_epsilon=False) (predict_noise_from_start, diffusion_model_base.py:114-124, as
+    ddim_sample uses it at :248).  Highways, agent 3 of the g5 / g6 case, a via state pinned at rows 17 and 40 besides start / goal:
+    a guided DDPM chain (T = 25, B = 4, injected noise) with its sensitivity row, a guided DDIM chain (T = 100, B = 4) with the
+    same four hard rows, and an unguided DDIM chain of an x0-predicting model (T = 50, B = 4, start / goal only)."""
+    from ref_harness import GaussianDiffusionModel, TemporalUnet
+    starts, goals, soft, hard = highways_case()
+    hc = hard_conds_for(starts[3], goals[3])
+    via = {17: np.array([-0.15, 0.3, 0.2, -0.1], np.float32), 40: np.array([0.2, -0.25, 0.0, 0.3], np.float32)}
+    for row, v in via.items():
+        hc[row] = torch.from_numpy(normalize(v).astype(np.float32))
+    out = {"via_rows": np.array(sorted(via)), "via_states": np.stack([via[r] for r in sorted(via)])}
+    sd = synth.synth_unet_state_dict(0)
+    T, B = 25, 4
+    xT = synth.synth_noise(43, (B, H, D))
+    steps = synth.synth_noise(44, (T + 1, B, H, D))
+
+    def run(perturb=0.0, seed=0):
+        with quiet():
+            model = make_model(sd, T)
+            guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS)
+        if perturb:
+            gen = torch.Generator().manual_seed(seed)
+            model.model.register_forward_hook(
+                lambda mod, inp, o: o * (1 + perturb * torch.empty(o.shape).normal_(generator=gen)))
+        guide.add_extra_costs([make_cost_constraint(robot, *soft, True), make_cost_constraint(robot, *hard, False)], [2e-2, 2e-1])
+        with quiet(), injected_noise([xT] + list(steps)) as q:
+            chain = model.run_inference(None, hc, n_samples=B, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn, guide=guide,
+                                        n_guide_steps=20, t_start_guide=ceil(0.5 * T), noise_std_extra_schedule_fn=lambda x: 0.5,
+                                        n_diffusion_steps_without_noise=1)
+            assert len(q) == 0
+        return chain.numpy()
+    chain = run()
+    sens = np.zeros(chain.shape[0])
+    for ps in range(1, 9):
+        pert = run(1e-6, ps)
+        sens = np.maximum(sens, [rel_l2(pert[r], chain[r]) for r in range(chain.shape[0])])
+    out["ddpm_chain"], out["ddpm_sens"], out["ddpm_meta"] = chain, sens, np.array([T, B, 43, 44])
+    # DDIM, four hard rows, guided
+    T2 = 100
+    with quiet():
+        model = make_model(sd, T2)
+        guide, robot, task, env = make_guide("EnvHighways2D", MINS, MAXS)
+    guide.add_extra_costs([make_cost_constraint(robot, *soft, True), make_cost_constraint(robot, *hard, False)], [2e-2, 2e-1])
+    xT2 = synth.synth_noise(45, (B, H, D))
+    with quiet(), injected_noise([xT2] + [np.zeros((B, H, D), np.float32)] * (T2 // 5 + 1)):
+        x, ch = model.ddim_sample((B, H, D), hc, n_diffusion_steps=T2, return_chain=True, guide=guide, t_start_guide=ceil(0.5 * T2),
+                                  n_guide_steps=20)
+    out["ddim_chain"], out["ddim_meta"] = ch.transpose(0, 1).numpy(), np.array([T2, B, 45])
+    # DDIM with an x0-predicting model, unguided
+    T3 = 50
+    unet = TemporalUnet(state_dim=4, n_support_points=64, unet_input_dim=32, dim_mults=(1, 2, 4))
+    m0 = GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T3, predict_epsilon=False)
+    m0.load_state_dict({"model." + k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m0.eval()
+    xT3 = synth.synth_noise(46, (B, H, D))
+    with quiet(), injected_noise([xT3] + [np.zeros((B, H, D), np.float32)] * (T3 // 5 + 1)):
+        x, ch0 = m0.ddim_sample((B, H, D), hard_conds_for(starts[3], goals[3]), n_diffusion_steps=T3, return_chain=True)
+    out["ddim_x0_chain"], out["ddim_x0_meta"] = ch0.transpose(0, 1).numpy(), np.array([T3, B, 46])
+    np.savez_compressed(os.path.join(OUT, "g18_hard_rows_ddim_x0.npz"), **out)
+    print("   g18:", {k: v.shape for k, v in out.items()}, "ddpm final-row sens", f"{sens[-1]:.2e}")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17, "g18": g18}[name]()
     print("done")
