@@ -5,7 +5,7 @@
 # Usage: tools/gpu_profile.sh [tag]   (outputs under gpurun_out/<tag>_*)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04c}
 OUT=gpurun_out
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -25 | tee $OUT/${TAG}_pytest_gpu.log

@@ -5,7 +5,7 @@
 //   fat : 256 workgroups of 8 samples = two halves; per phase the taps of one half and the epilogue + slab store of the other sit
 //         in one basic block and a sched_group_barrier pipeline asks for 3 MFMAs : 4 VALU  (hipcc -DFAT ... -o fat_fat)
 // Prints the time per conv of 8 samples per CU.  Build (both): hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize [-DFAT]
-//   tools/ubench/fatwave_conv.hip mmd_amd/csrc/{guide,api,multi_agent,postprocess}.hip -o build_tmp/fat_{base,fat}
+//   tools/ubench/fatwave_conv.hip mmd_amd/csrc/{unet_layers,guide,api,multi_agent,postprocess}.hip -o build_tmp/fat_{base,fat}
 #ifdef FAT
 #define MMD_VB3_LOOSE
 #define MMD_NO_PIN
