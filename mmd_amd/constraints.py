@@ -39,6 +39,23 @@ class MultiPointConstraint:
         return MultiPointConstraint(list(self.q_l), list(self.t_range_l), list(self.radius_l), self.is_soft)
 
 
+def _points_xy(q_l) -> np.ndarray:
+    """[n, 2] float32 host array of the (x, y) of every constraint point.  CBS hands over hundreds of tiny tensors per call
+    (cbs.py:468-508), usually device tensors: they are stacked where they live and cross to the host in ONE copy (one by one, each
+    `.cpu()` is a device synchronisation: 2 ms of a 5 ms planner call at 568 points)."""
+    if torch.is_tensor(q_l):
+        q = q_l
+    else:
+        q_l = list(q_l)
+        try:                                        # (per-element Python work is what costs: one stack, no per-point calls)
+            q = torch.stack(q_l)
+        except (TypeError, RuntimeError):           # not all tensors, or mixed shapes / devices: the element-wise path
+            return np.stack([np.asarray(torch.as_tensor(q).detach().cpu(), dtype=np.float32).reshape(-1)[:2]
+                             for q in q_l]).astype(np.float32).reshape(-1, 2)
+    q = q.detach().reshape(q.shape[0], -1)
+    return np.ascontiguousarray(q[:, :2].to("cpu", torch.float32).numpy()).reshape(-1, 2)
+
+
 class CostConstraint:
     """Parameter holder with the reference constructor signature (cost_functions.py:282-295).  One instance = one
     guide cost term = one ELL group (own gradient clip and weight)."""
@@ -46,20 +63,19 @@ class CostConstraint:
     def __init__(self, robot=None, n_support_points=H, q_l=None, traj_range_l=None, radius_l=None, is_soft=False,
                  **kwargs):
         self.n_support_points = n_support_points
-        self.qs = np.stack([np.asarray(torch.as_tensor(q).detach().cpu(), dtype=np.float32).reshape(-1)[:2]
-                            for q in q_l]).astype(np.float32).reshape(-1, 2)
+        self.qs = _points_xy(q_l)
         self.traj_ranges = np.asarray(traj_range_l, dtype=np.float32).reshape(-1, 2)
         self.radii = np.asarray(radius_l, dtype=np.float32).reshape(-1)
         self.is_soft = is_soft
 
 
-def pack_constraints(per_robot_groups: Sequence[Sequence[Tuple[CostConstraint, float]]], device):
+def pack_constraints(per_robot_groups: Sequence[Sequence[Tuple[CostConstraint, float]]], device, return_max_slots=False):
     """per_robot_groups[r] = [(CostConstraint, weight), ...].  Returns device tensors
     (ell [n_slots,H,4] f32, grp_slot_off [G+1] i32, grp_weight [G] f32, robot_grp_off [R+1] i32) or None if empty."""
     lib = _lib.load()
     flat = [gw for groups in per_robot_groups for gw in groups]
     if not flat:
-        return None
+        return (None, 0) if return_max_slots else None
     G = len(flat)
     n_pts = (C.c_int32 * G)(*[g.qs.shape[0] for g, _ in flat])
     keep = []
@@ -83,8 +99,12 @@ def pack_constraints(per_robot_groups: Sequence[Sequence[Tuple[CostConstraint, f
     robot_grp_off = np.zeros(len(per_robot_groups) + 1, dtype=np.int32)
     robot_grp_off[1:] = np.cumsum([len(g) for g in per_robot_groups])
     weights = np.array([w for _, w in flat], dtype=np.float32)
-    return (torch.from_numpy(ell).to(device), torch.from_numpy(grp_slot_off).to(device),
-            torch.from_numpy(weights).to(device), torch.from_numpy(robot_grp_off).to(device))
+    out = (torch.from_numpy(ell).to(device), torch.from_numpy(grp_slot_off).to(device),
+           torch.from_numpy(weights).to(device), torch.from_numpy(robot_grp_off).to(device))
+    if return_max_slots:                         # the most slots any one robot owns (sizes the guide kernel's on-chip table)
+        per_robot = grp_slot_off[robot_grp_off[1:]] - grp_slot_off[robot_grp_off[:-1]]
+        return out, int(per_robot.max())
+    return out
 
 
 def soft_constraints_from_paths(paths: torch.Tensor, robot0: int, n_local: int, radius=VERTEX_CONSTRAINT_RADIUS,

@@ -83,6 +83,7 @@ class GuideManagerTrajectoriesWithVelocity:
         self._cons_dirty = True
         self._external_cons = None
         self._max_slots = 0
+        self._norm_limits = None
 
     # ---- extra costs (constraints) ----------------------------------------------------------------------------
     def add_extra_costs(self, extra_costs, extra_costs_grad_weights, robot=0):
@@ -106,19 +107,17 @@ class GuideManagerTrajectoriesWithVelocity:
             return self._external_cons
         if self._cons_dirty:
             groups = [list(zip(c, w)) for c, w in zip(self.extra_cost_l, self.extra_costs_grad_weight_l)]
-            self._cons = pack_constraints(groups, self.device)
+            self._cons, self._max_slots = pack_constraints(groups, self.device, return_max_slots=True)
             self._cons_dirty = False
-            if self._cons is not None:
-                gso, rgo = self._cons[1].cpu(), self._cons[3].cpu()
-                self._max_slots = int(max(int(gso[rgo[r + 1]]) - int(gso[rgo[r]]) for r in range(self.n_robots)))
         return self._cons
 
     # ---- C-ABI descriptor -------------------------------------------------------------------------------------
     def desc(self):
         d = _lib.GuideDesc()
         nz = self.dataset.normalizer
-        d.norm_min[:] = [float(v) for v in nz.mins.cpu()]
-        d.norm_max[:] = [float(v) for v in nz.maxs.cpu()]
+        if self._norm_limits is None:                       # (host floats once: the normaliser's limits do not change)
+            self._norm_limits = ([float(v) for v in nz.mins.cpu()], [float(v) for v in nz.maxs.cpu()])
+        d.norm_min[:], d.norm_max[:] = self._norm_limits
         d.limits_lo[:] = LIMITS[0]
         d.limits_hi[:] = LIMITS[1]
         d.grid_nx, d.grid_ny = self._grids.shape[2], self._grids.shape[3]

@@ -144,24 +144,32 @@ def _fill_output(out, guide, trajs_iters, all_free=False):
     """mpd.py:344-405 / mpd_ensemble.py:385-429 on the device: ONE fused launch (collision / free split, path length,
     smoothness, SavGol) + the per-batch argmin + the waypoint variance of the free set."""
     trajs_final = trajs_iters[-1].contiguous()
+    B, dev = trajs_final.shape[0], trajs_final.device
     r = post.postprocess_batch(guide, trajs_final, all_free=all_free, smooth=True)
-    coll, coll_idxs, free, free_idxs = post.split_free(trajs_final, r.free_mask)
+    idx, _ = post.select_best(r.free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness)
+    # the call's ONE device -> host transfer: free mask, index of the cheapest free sample, the two costs (boolean-mask indexing,
+    # argwhere, .item() would each synchronise: nine round trips = 0.4 ms of a 3.4 ms planner call at T = 25)
+    host = torch.cat((r.free_mask.float(), idx.float(), r.path_length, r.smoothness)).cpu().numpy()
+    fm, ib = host[:B] > 0, int(host[B])
+    free_i, coll_i = np.flatnonzero(fm), np.flatnonzero(~fm)
+    free_idxs = torch.from_numpy(free_i).to(dev).view(-1, 1)          # [n, 1] int64, as torch.argwhere gives them (tasks.py:258-307)
+    coll_idxs = torch.from_numpy(coll_i).to(dev).view(-1, 1)
+    free = trajs_final.index_select(0, free_idxs.view(-1)) if free_i.size else None
+    coll = trajs_final.index_select(0, coll_idxs.view(-1)) if coll_i.size else None
     out.trajs_iters, out.trajs_final = trajs_iters, r.smoothed
     out.trajs_final_coll, out.trajs_final_coll_idxs = coll, coll_idxs
     out.trajs_final_free, out.trajs_final_free_idxs = free, free_idxs
     out.success_free_trajs = free is not None
-    out.fraction_free_trajs = 0.0 if free is None else free.shape[0] / trajs_final.shape[0]
+    out.fraction_free_trajs = 0.0 if free is None else free.shape[0] / B
     if free is not None:
-        fm = r.free_mask.bool()
-        out.cost_smoothness, out.cost_path_length = r.smoothness[fm], r.path_length[fm]
+        out.cost_smoothness = r.smoothness.index_select(0, free_idxs.view(-1))
+        out.cost_path_length = r.path_length.index_select(0, free_idxs.view(-1))
         out.cost_all = out.cost_path_length + out.cost_smoothness
-        idx, _ = post.select_best(r.free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness)
-        ib = int(idx.item())                                   # index in the batch of the cheapest free sample
-        idx_best_free = int((free_idxs.view(-1) == ib).nonzero()[0])
+        idx_best_free = int(np.searchsorted(free_i, ib))          # position of the batch index ib among the free samples
         out.idx_best_traj = free_idxs[idx_best_free]
         out.idx_best_free_traj = idx_best_free
         out.traj_final_free_best = free[idx_best_free]
-        out.cost_best_free_traj = float(out.cost_all[idx_best_free])
+        out.cost_best_free_traj = float(np.float32(host[B + 1 + ib]) + np.float32(host[2 * B + 1 + ib]))
         out.variance_waypoint_trajs_final_free = post.compute_variance_waypoints(free)
     return out
 
