@@ -132,6 +132,51 @@ constexpr int SAMPLES_PER_WG = 4;
 #ifndef ADEPTH
 #define ADEPTH 2
 #endif
+#ifdef SPREAD
+// -DSPREAD: the operand fetches of a half step are NOT issued as a bunch in front of its twelve MFMAs: one A read (ds_read_b128) goes in
+// front of every MFMA triple (the four fragments of the NEXT half step), one weight fragment (global_load_dwordx4) behind every second
+// triple (the ring slot freed by the PREVIOUS step is refilled during this one: the same distance as the kernel's refill after the
+// step).  A single wave per SIMD has nobody to fill the issue cycles a bunch of eight 64-lane memory instructions takes.
+template <class GEO, int NT, int MT, int RD>
+__device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2]) {
+  constexpr int KC = GEO::KC, STEPS = 5 * KC, HP = MT / 2, HS = STEPS * HP;
+  static_assert(NT == 2 && ADEPTH == 2, "spread form: four triples per half step, double-buffered A");
+  u32x4 a[2][2][2];
+  auto a_ptr = [&](int hs, int sm, int q) {
+    const int st = hs / HP, hp = hs % HP, tap = st / KC, kc = st % KC;
+    return reinterpret_cast<const u32x4*>(va + q * GEO::PS + kc * GEO::BX + (GEO::tile_row(2 * hp + sm) + tap) * 16);
+  };
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) a[0][sm][q] = *a_ptr(0, sm, q);
+  MMD_PIN_LOADS();
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int ri = st % RD;
+    const bool zero = st == 0;
+#pragma unroll
+    for (int hp = 0; hp < HP; ++hp) {
+      const int hs = st * HP + hp, cur = hs & 1, nx = hs + 1 < HS ? hs + 1 : HS - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                       // triple j = (sm, t) = (j >> 1, j & 1)
+        if (PARTS & 2) a[cur ^ 1][j >> 1][j & 1] = *a_ptr(nx, j >> 1, j & 1);      // the next half step's fragment (sm, q) = (j >> 1, j & 1)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (zero) vb_three<true>(acc[2 * hp + (j >> 1)][j & 1], a[cur][j >> 1], b[ri][j & 1]);
+        else vb_three<false>(acc[2 * hp + (j >> 1)][j & 1], a[cur][j >> 1], b[ri][j & 1]);
+        // refill the slot of step st - 1 with step st - 1 + RD: fragment (t, q) = the k-th of this step's four load slots
+        const int k = hp * 2 + (j >> 1);                  // 0 .. 3 over the step's eight triples (behind triples 1, 3, 5, 7)
+        if ((PARTS & 4) && (j & 1) && st >= 1 && st - 1 + RD < STEPS && (HP == 2 || true)) {
+          const int rs = (st - 1) % RD, t = k >> 1, q = k & 1;
+          if (HP == 2) b[rs][t][q] = w[t][((st - 1 + RD) * 2 + q) * 64];
+        }
+      }
+    }
+    MMD_PIN_LOADS();
+  }
+}
+#else
 template <class GEO, int NT, int MT, int RD>
 __device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2]) {
   constexpr int KC = GEO::KC, STEPS = 5 * KC, HP = MT / 2, HS = STEPS * HP;
@@ -183,10 +228,16 @@ __device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* 
       MMD_PIN_LOADS();
     }
 }
+#endif   // SPREAD
 // -DSKEW=<n>: the SECOND workgroup of a CU (blocks >= 256) starts n x 64 cycles late, so that its MFMA phases meet the first
 // one's epilogues (do the two workgroups of a CU drift into lockstep?)
 #ifndef SKEW
 #define SKEW 0
+#endif
+// -DUB_RD=<n>: weight ring depth (the kernel: 3); -DUB_NB=256 (main): ONE workgroup per CU, the regime of launches of <= 1024
+// trajectories (a single wave per SIMD: nothing fills the gaps of another wave's operand waits)
+#ifndef UB_RD
+#define UB_RD 3
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
   __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
@@ -209,11 +260,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
     const u32x4* wp[2] = {reinterpret_cast<const u32x4*>(p.w) + woff[0], reinterpret_cast<const u32x4*>(p.w) + woff[1]};
     const Epi<2> e = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
-    u32x4 ring[3][2][2];
-    rd_ring_load<G128, 2, 3>(ring, wp);
+    u32x4 ring[UB_RD][2][2];
+    rd_ring_load<G128, 2, UB_RD>(ring, wp);
     if (PARTS & 16) rd_store2<G128>(vs, acc);
     if (PARTS & 32) __syncthreads();
-    rd_taps_parts<G128, 2, 4, 3>(acc, va, wp, ring);
+    rd_taps_parts<G128, 2, 4, UB_RD>(acc, va, wp, ring);
     if (PARTS & 8) epilogue(acc, e);
     if (PARTS & 32) __syncthreads();
   }
@@ -921,7 +972,11 @@ constexpr int SAMPLES_PER_WG = 8;
 
 int main() {
   using namespace mmd;
+#ifdef UB_NB
+  const int nconv = 64, nb = UB_NB;
+#else
   const int nconv = 64, nb = 2048 / SAMPLES_PER_WG;
+#endif
   const size_t wbytes = (size_t)(8 * G128::FRAGS5 + 8) * 64 * 16;
   std::vector<uint16_t> hw(wbytes / 2);
   std::mt19937 rng(1);
@@ -945,7 +1000,7 @@ int main() {
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<float> ho(8); hipMemcpy(ho.data(), dout, 32, hipMemcpyDeviceToHost);
-    printf("%s: %d workgroups x %d samples, %d convs: %.1f us -> %.2f us per conv of 8 samples per CU  (check %.4f, err %s)\n",
+    printf("%s: %d workgroups x %d samples, %d convs: %.1f us -> %.2f us per conv of the workgroups a CU holds  (check %.4f, err %s)\n",
 #ifdef FAT
            "fat ",
 #else
