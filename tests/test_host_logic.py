@@ -227,3 +227,19 @@ def test_temporal_unet_accepts_doubling_ladders_only():
             TemporalUnet(dim_mults=bad)
     with pytest.raises(NotImplementedError):
         TemporalUnet(unet_input_dim=20)
+
+
+def test_constraint_points_cross_to_the_host_in_one_copy():
+    """CostConstraint takes CBS's list of tiny tensors (cbs.py:468-508): stacked once (no per-point host copies), first two entries of
+    every point, float32; mixed lists fall back to the element-wise path with the same result."""
+    from mmd_amd.constraints import CostConstraint, _points_xy
+    rng = np.random.Generator(np.random.PCG64(3))
+    pts = rng.standard_normal((37, 4)).astype(np.float32)
+    as_tensors = [torch.from_numpy(p.copy()).double() for p in pts]
+    want = pts[:, :2]
+    for q_l in (as_tensors, torch.from_numpy(pts), [p for p in pts], [as_tensors[0], pts[1]] + [list(p) for p in pts[2:]],
+                [t[None] for t in as_tensors]):
+        got = _points_xy(q_l)
+        assert got.dtype == np.float32 and got.shape == (37, 2) and got.flags["C_CONTIGUOUS"] and np.array_equal(got, want)
+    c = CostConstraint(None, 64, q_l=as_tensors, traj_range_l=[(3, 5)] * 37, radius_l=[0.12] * 37, is_soft=True)
+    assert np.array_equal(c.qs, want) and c.traj_ranges.shape == (37, 2) and c.radii.shape == (37,)
