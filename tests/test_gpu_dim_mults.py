@@ -185,3 +185,33 @@ def test_option1_planner_from_args_yaml(tmp_path):
     tf = res.trajs_iters[-1]
     assert tuple(tf.shape) == (8, H, D) and torch.isfinite(res.trajs_iters).all()
     assert torch.allclose(tf[:, 0, :2].cpu(), torch.tensor([-0.5, 0.1]).expand(8, 2), atol=1e-5)
+
+
+def test_option1_ddim_and_ensemble_paths_vs_oracle():
+    """The other sampler entry points over a four-level model: ddim_sample (mmd_ddim_sample) against the oracle's DDIM on the same
+    weights, every chain row (the DDIM chain is deterministic and well conditioned: 1e-4), and the unguided p_sample_loop through the
+    step API == through the loop (the layer-by-layer path has no fused step: both are UNet + step kernel launches)."""
+    from oracle import mmd_oracle as O
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    T, B = 50, 4
+    model = _model(T)
+    starts, goals, soft, hard = cases.highways_case()
+    hc = cases.hard_conds_for(starts[3], goals[3])
+    xT = torch.from_numpy(synth.synth_noise(77, (B, H, D)))
+    x, ch = model.ddim_sample((B, H, D), hc, n_diffusion_steps=T, return_chain=True, x_init=xT)
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0, dim_mults=(1, 2, 4, 8)))
+    ref = O.ddim_sample(sd, O.schedule_tables(T), xT, hc, T)
+    ch = ch.transpose(0, 1).cpu()
+    assert ch.shape == ref.shape
+    err = max(rel_l2(ch[r], ref[r]) for r in range(ref.shape[0]))
+    parity_log.record("option1_ddim_vs_oracle", "worst_row", None, err, bound=1e-4)
+    assert err < 1e-4, err
+    steps = torch.from_numpy(synth.synth_noise(78, (T + 1, B, H, D))).cuda()
+    chain = model.run_inference(None, hc, n_samples=B, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn, guide=None,
+                                noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=1,
+                                warm_start_path_b=xT.cuda(), step_noise=steps)
+    y = chain[0].clone()
+    hcd = {k: v.cuda() for k, v in hc.items()}
+    for k in range(3):
+        model.sample_step(y, hcd, T - 1 - k, guide=None, noise_std_extra_schedule_fn=lambda t: 0.5, noise=steps[k])
+        assert torch.equal(y, chain[k + 1]), k
