@@ -53,6 +53,36 @@ int mmd_sampler_stream_chunks(int n_streams, int n_robots, int samples_per_robot
 int mmd_unet_forward_profiled(mmd_unet_t unet, const float* x_dev, int t, float* eps_dev, int n_traj,
                               void* workspace_dev, size_t workspace_bytes, mmd_profiler_t profiler, void* stream);
 
+/* Bytes of the packed weight / parameter block a TemporalUnet forward reads (the fused kernel's f16x2 packs + biases + GroupNorm
+ * affines + scales; the layer-by-layer path: its fp32 blob): with 2 KiB per trajectory the ALGORITHMIC HBM-side bytes of one
+ * launch, the denominator of bench.py's roofline.traffic / wasted ratio. */
+size_t mmd_unet_weight_bytes(mmd_unet_t unet);
+
+/* Decision trace of ONE guided ddpm_sample_fn step (sample_functions.py:40-107): mmd_ddpm_step on the one-wave step kernel with
+ * the dump compiled in -- the same arithmetic, bit for bit, as every production launch shape -- which additionally writes
+ *   mu_dev          [n_traj][64][4]  (optional) the posterior mean, hard rows pinned: the state the guide iterations start from
+ *   guide_chain_dev [n_guide_steps][n_traj][64][4]  the state after every guide iteration (before the step's noise)
+ *   trace_dev       [n_guide_steps][n_traj][64][MMD_TRACE_WORDS] uint32: the discrete decisions of the iteration at that support
+ *                   point, i.e. everything in GuideManagerTrajectoriesWithVelocity.forward that is not continuous in x:
+ *     word 0      SDF cell index ix * ny + iy of the nearest-cell lookup (grid_map_sdf.py:84-114)
+ *     word 1      bit 0: the object-collision hinge is active (margin - sdf > 0, distance_fields.py:110-135), bits 1-3: the field
+ *                 that wins the max (grid index; 7 = the env's extra objects); bit 4: the workspace-boundary hinge is active,
+ *                 bits 5-6: its arg max (x-min, y-min, x-max, y-max; distance_fields.py:354-367); bits 8 / 9 / 10: the gradient
+ *                 clip (guides.py:228-259) is active on the object / boundary / GP term, bits 11-14: on constraint group 0..3 of the
+ *                 robot; bits 16-19: the un-normalisation clips dimension 0..3 (normalization.py:161-163); bits 20-23: the
+ *                 robot's number of constraint groups
+ *     words 2-9   four 64-bit masks (lo, hi): slot s of constraint group 0..3 is ACTIVE at this support point (||p - q|| <= R
+ *                 inside its time range, cost_functions.py:305-312); slot = the point's rank among the group's points that cover
+ *                 this support point, in list order (mmd_pack_constraints) / the other robot's index (mmd_soft_constraints_from_paths)
+ *     word 10     number of active slots over ALL groups and slots (also those beyond 4 groups x 64 slots)
+ *     word 11     0
+ * tests/test_gpu_flips.py holds the oracle's decisions against these. */
+#define MMD_TRACE_WORDS 12
+int mmd_debug_ddpm_step_trace(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_desc* guide, float* x_dev,
+                              const float* hard_dev, int n_robots, int samples_per_robot, int i, const float* noise_dev,
+                              uint64_t seed, uint32_t draw_index, void* workspace_dev, size_t workspace_bytes,
+                              float* mu_dev, float* guide_chain_dev, uint32_t* trace_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,7 +122,12 @@ _DEBUG_SIGNATURES = {
     "mmd_unet_f16x2_flops_per_trajectory": (C.c_double, []),
     "mmd_unet_forward_profiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_void_p]),
+    "mmd_unet_weight_bytes": (C.c_size_t, [C.c_void_p]),
+    "mmd_debug_ddpm_step_trace": (C.c_int, [C.c_void_p, C.POINTER(SamplerDesc), C.POINTER(GuideDesc), C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
+TRACE_WORDS = 12                        # MMD_TRACE_WORDS of include/mmd_amd_debug.h
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 DEBUG_SYMBOLS = tuple(_DEBUG_SIGNATURES)

@@ -143,6 +143,34 @@ int mmd_ddpm_step(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_de
   return 0;
 }
 
+int mmd_debug_ddpm_step_trace(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_desc* guide, float* x_dev,
+                              const float* hard_dev, int n_robots, int samples_per_robot, int i, const float* noise_dev,
+                              uint64_t seed, uint32_t draw_index, void* workspace_dev, size_t workspace_bytes,
+                              float* mu_dev, float* guide_chain_dev, uint32_t* trace_dev, void* stream) {
+  MMD_REQUIRE(unet && s && guide && x_dev && hard_dev && workspace_dev && guide_chain_dev && trace_dev,
+              "mmd_debug_ddpm_step_trace: NULL argument");
+  const int n = n_robots * samples_per_robot;
+  MMD_REQUIRE(n >= 1, "mmd_debug_ddpm_step_trace: empty batch");
+  MMD_REQUIRE(workspace_bytes >= mmd_sampler_workspace_bytes(unet, n), "mmd_debug_ddpm_step_trace: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* eps = eps_of(workspace_dev, unet, n);
+  StepDev sd{};
+  if (int rc = make_step(s, i, true, sd)) return rc;
+  MMD_REQUIRE(sd.do_guide, "mmd_debug_ddpm_step_trace: step %d is not a guided one (t_start_guide %d)", i, s->t_start_guide);
+  sd.seed = seed; sd.draw = draw_index;
+  sd.guide_chain = reinterpret_cast<float4*>(guide_chain_dev);
+  sd.guide_chain_stride = (long long)n * H;
+  sd.trace = trace_dev;
+  sd.mu_out = reinterpret_cast<float4*>(mu_dev);
+  GuideDev g{};
+  if (int rc = fill_guide(guide, g)) return rc;
+  if (int rc = mmd_unet_forward(unet, x_dev, i < 0 ? 0 : i, eps, n, workspace_dev, mmd_unet_workspace_bytes(unet, n), stream))
+    return rc;
+  launch_step(g, sd, x_dev, eps, noise_dev, nullptr, hard_dev, 0, n, samples_per_robot, st);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guide_desc* guide, float* x_dev,
                       const float* hard_dev, int n_robots, int samples_per_robot, int n_steps,
                       int n_steps_without_noise, int init_noise, const float* step_noise_dev, uint64_t seed,
@@ -312,7 +340,9 @@ int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alp
     sd.ddim = s->model_predicts_x0 ? 2 : 1;
     sd.grad_scale = 1.f;                                              // (ddim_sample passes no scale_grad_by_std on)
     sd.a_t = s->sqrt_recip_alphas_cumprod[t];
-    sd.b_t = s->model_predicts_x0 ? 1.f / s->sqrt_recipm1_alphas_cumprod[t] : s->sqrt_recipm1_alphas_cumprod[t];
+    // (x0-predicting model: b_t carries 1 / sqrt_recipm1; on the last pair x = x_start and pred_noise is never used -- 0 there, so a
+    // schedule whose sqrt_recipm1[t] is 0 or denormal cannot put 0 * inf into the update)
+    sd.b_t = s->model_predicts_x0 ? (tn < 0 ? 0.f : 1.f / s->sqrt_recipm1_alphas_cumprod[t]) : s->sqrt_recipm1_alphas_cumprod[t];
     sd.c1 = tn < 0 ? 1.f : sqrtf(alphas_cumprod[tn]);               // x = x_start on the last pair (time_next = -1)
     sd.c2 = tn < 0 ? 0.f : sqrtf(1.f - alphas_cumprod[tn]);         // sigma = eta * ... = 0
     sd.do_model = 1;

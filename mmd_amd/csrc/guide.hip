@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/mmd_amd.h"
+#include "../../include/mmd_amd_debug.h"
 #include "common.h"
 #include "guide_dev.h"
 
@@ -38,18 +39,24 @@ __device__ __forceinline__ float clip_scale(float gx, float gy, float gz, float 
 
 // GuideManager.clip_gradient (guides.py:228-259) of one cost's per-point gradient: by norm (the planners' setting), by value
 // (torch.clip to +-max_grad_value per component) or not at all (clip_grad = False).  The rule is wave uniform.
-__device__ __forceinline__ void clip_grad(const GuideDev& g, float& gx, float& gy, float& gz, float& gw) {
+// Returns whether the rule was ACTIVE on this point (the norm / a component beyond the limit): used by the trace instantiation
+// only, dead code elsewhere.
+__device__ __forceinline__ bool clip_grad(const GuideDev& g, float& gx, float& gy, float& gz, float& gw) {
   if (g.clip_rule == 0) {
     const float sc = clip_scale(gx, gy, gz, gw, g.max_norm);
     gx = sc * gx; gy = sc * gy; gz = sc * gz; gw = sc * gw;
+    return sc < 1.f;
   } else if (g.clip_rule == 1) {
     const float m = g.max_value;
+    const bool on = fabsf(gx) > m || fabsf(gy) > m || fabsf(gz) > m || fabsf(gw) > m;
     gx = fminf(fmaxf(gx, -m), m); gy = fminf(fmaxf(gy, -m), m); gz = fminf(fmaxf(gz, -m), m); gw = fminf(fmaxf(gw, -m), m);
+    return on;
   }
+  return false;
 }
-__device__ __forceinline__ void clip_grad(const GuideDev& g, float& gx, float& gy) {
+__device__ __forceinline__ bool clip_grad(const GuideDev& g, float& gx, float& gy) {
   float z = 0.f, w = 0.f;
-  clip_grad(g, gx, gy, z, w);
+  return clip_grad(g, gx, gy, z, w);
 }
 
 // wave shift by one lane through DPP (GFX9 wave_shr:1 / wave_shl:1): lane t reads lane t-1 / t+1, no LDS round trip.
@@ -158,15 +165,20 @@ __device__ __forceinline__ f32x2g cons_accumulate1(f32x2g a, const TAB& tab, int
 }
 
 // group_sum(grp, p) = the slot sum of constraint group grp at the lane's position p (the canonical four-accumulator tree above)
-template <class GROUPSUM>
+// DUMP (mmd_debug_ddpm_step_trace only): the iteration's discrete decisions of this support point -> tr[0 .. MMD_TRACE_WORDS)
+// (layout: include/mmd_amd_debug.h).  The constraint masks are re-derived slot by slot from the L2-resident table with
+// cons_term's own expression, so they are the decisions the sums above took.
+template <bool DUMP = false, class GROUPSUM>
 __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t, const float4* __restrict__ grid,
-                                             int grp0, int grp1, GROUPSUM group_sum) {
+                                             int grp0, int grp1, GROUPSUM group_sum, unsigned int* tr = nullptr) {
+  unsigned int flags = 0;
   // LimitsNormalizer.unnormalize (normalization.py:157-168), clip applied unconditionally
   float xu[4];
   const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     float v = fminf(fmaxf(xv[d], -1.f), 1.f);
+    if constexpr (DUMP) flags |= (fabsf(xv[d]) > 1.f ? 1u : 0u) << (16 + d);
     v = (v + 1.f) / 2.f;
     xu[d] = v * g.nscale[d] + g.nmin[d];
   }
@@ -193,7 +205,12 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
     v = fmaxf(g.margin - d3, 0.f);
     if (v > best) { best = v; gx = 0.f; gy = 1.f; }
     if (!(best > 0.f)) { gx = 0.f; gy = 0.f; }
-    clip_grad(g, gx, gy);
+    if constexpr (DUMP) {
+      const unsigned arg = gx < 0.f ? 0u : gy < 0.f ? 1u : gx > 0.f ? 2u : 3u;
+      if (best > 0.f) flags |= 1u << 4 | arg << 5;
+    }
+    const bool clipped = clip_grad(g, gx, gy);
+    if constexpr (DUMP) flags |= (clipped ? 1u : 0u) << 9;
     wsx = g.w_coll * gx; wsy = g.w_coll * gy;
   }
   // --- CostGPTrajectory (cost_functions.py:532-542, gp_factor.py): e_t = s_{t+1} - Phi s_t, w_t = 2 Q^-1 e_t,
@@ -213,7 +230,8 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
     const float lpx = lane_prev(wpx), lpy = lane_prev(wpy), lvx = lane_prev(wvx), lvy = lane_prev(wvy);
     float gx = lpx - wpx, gy = lpy - wpy;
     float gz = lvx - (g.dt * wpx + wvx), gw = lvy - (g.dt * wpy + wvy);
-    clip_grad(g, gx, gy, gz, gw);
+    const bool clipped = clip_grad(g, gx, gy, gz, gw);
+    if constexpr (DUMP) flags |= (clipped ? 1u : 0u) << 10;
     gpx = g.w_smooth * gx; gpy = g.w_smooth * gy;
     gpz = g.w_smooth * gz; gpw = g.w_smooth * gw;
   }
@@ -222,7 +240,27 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
   for (int grp = grp0; grp < grp1; ++grp) {
     const f32x2g gs = group_sum(grp, f32x2g{px, py});
     float gx = gs.x, gy = gs.y;
-    clip_grad(g, gx, gy);
+    const bool clipped = clip_grad(g, gx, gy);
+    if constexpr (DUMP) {
+      const int k = grp - grp0, s0 = g.grp_slot_off[grp], s1 = g.grp_slot_off[grp + 1];
+      unsigned long long mask = 0;
+      unsigned int n_act = 0;
+      for (int sl = s0; sl < s1; ++sl) {
+        const float4 c = g.cons[(size_t)sl * H + t];
+        const float dx = px - c.x, dy = py - c.y;
+        const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+        if (!(d2 > c.w)) {
+          ++n_act;
+          if (sl - s0 < 64) mask |= 1ull << (sl - s0);
+        }
+      }
+      if (k < 4) {
+        tr[2 + 2 * k] = (unsigned int)mask;
+        tr[3 + 2 * k] = (unsigned int)(mask >> 32);
+        flags |= (clipped ? 1u : 0u) << (11 + k);
+      }
+      tr[10] += n_act;
+    }
     const float w = g.grp_weight[grp];
     cx += w * gx; cy += w * gy;
   }
@@ -230,19 +268,28 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
   float ox, oy;
   {
     float best = fmaxf(g.margin - cell0.x, 0.f), gx = 0.f, gy = 0.f;
+    unsigned win = 0;
     if (best > 0.f) { gx = -cell0.y; gy = -cell0.z; }
     for (int k = 1; k < g.n_grids; ++k) {
       const float4 c = grid[((size_t)k * g.nx + ix) * g.ny + iy];
       const float v = fmaxf(g.margin - c.x, 0.f);
-      if (v > best) { best = v; gx = -c.y; gy = -c.z; }
+      if (v > best) { best = v; gx = -c.y; gy = -c.z; win = (unsigned)k; }
     }
     if (g.n_xs + g.n_xb > 0) {                             // the env's extra objects: one more field, analytic
       float ex, ey;
       const float v = fmaxf(g.margin - extra_sdf(g.xs, g.n_xs, g.xb, g.n_xb, px, py, ex, ey), 0.f);
-      if (v > best) { best = v; gx = -ex; gy = -ey; }
+      if (v > best) { best = v; gx = -ex; gy = -ey; win = 7u; }
     }
-    clip_grad(g, gx, gy);
+    const bool clipped = clip_grad(g, gx, gy);
+    if constexpr (DUMP) {
+      if (best > 0.f) flags |= 1u | (win & 7u) << 1;
+      flags |= (clipped ? 1u : 0u) << 8;
+    }
     ox = g.w_coll * gx; oy = g.w_coll * gy;
+  }
+  if constexpr (DUMP) {
+    tr[0] = (unsigned int)(ix * g.ny + iy);
+    tr[1] = flags | (unsigned int)min(grp1 - grp0, 15) << 20;
   }
   // sum in the reference's cost order (objects, ws boundaries, GP, constraints), zero rows 0 / H-1, negate
   float tx = ((ox + wsx) + gpx) + cx, ty = ((oy + wsy) + gpy) + cy;
@@ -252,7 +299,7 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
 }
 
 // One ddpm_sample_fn (sample_functions.py:40-86) + the apply_hard_conditioning after it, for one trajectory per wave.
-template <int WPB, bool COMPACT>
+template <int WPB, bool COMPACT, bool DUMP = false>
 __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDev s, int lds_slots, float4* __restrict__ x,
                                                          const float4* __restrict__ eps,
                                                          const float4* __restrict__ noise, float4* __restrict__ chain,
@@ -301,6 +348,9 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
 
   float4 hv = v;
   const bool is_hard = hard_row(s.hard_rows, s.n_hard, hard, robot, t, hv);
+  if constexpr (DUMP) {
+    if (s.mu_out) s.mu_out[idx] = is_hard ? hv : v;
+  }
 
   if (s.do_guide) {
     const int map = g.robot_map ? g.robot_map[robot] : 0;
@@ -328,7 +378,12 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
       return acc4_total(acc);
     };
     for (int it = 0; it < s.n_guide_steps; ++it) {
-      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, group_sum);
+      unsigned int* tr = nullptr;
+      if constexpr (DUMP) {
+        tr = s.trace + ((size_t)it * s.guide_chain_stride + idx) * MMD_TRACE_WORDS;
+        for (int w = 0; w < MMD_TRACE_WORDS; ++w) tr[w] = 0u;
+      }
+      const float4 gr = guide_grad<DUMP>(g, v, t, grid, grp0, grp1, group_sum, tr);
       // (x + model_var * grad with scale_grad_by_std, sample_functions.py:100-104; grad_scale = 1 otherwise: the fma is then the add)
       v.x = __builtin_fmaf(s.grad_scale, gr.x, v.x); v.y = __builtin_fmaf(s.grad_scale, gr.y, v.y);
       v.z = __builtin_fmaf(s.grad_scale, gr.z, v.z); v.w = __builtin_fmaf(s.grad_scale, gr.w, v.w);
@@ -546,7 +601,12 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
     hipLaunchKernelGGL(kern, dim3((n_traj + wpb - 1) / wpb), dim3(wpb * 64), (size_t)slots * bytes_per_slot, st, g, s, slots,
                        (float4*)x, (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
   };
-  if (guided && n_traj <= kCoopMaxTraj) {
+  if (s.trace) {
+    // measurement hook: the one-wave kernel, every slot from the L2-resident table (the slot sums are canonical: same bits as any
+    // production launch shape), with the decision dump compiled in
+    hipLaunchKernelGGL((ddpm_guide_kernel<4, false, true>), dim3((n_traj + 3) / 4), dim3(256), 0, st, g, s, 0, (float4*)x,
+                       (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
+  } else if (guided && n_traj <= kCoopMaxTraj) {
     // four waves per trajectory (ddpm_guide_coop_kernel): the whole table of the trajectory's robot in LDS up to 60 KiB (+ the
     // exchange buffer: inside the 64 KiB a launch gets without an opt-in), the rest from L2
     const int fit = 60 * 1024 / bytes_per_slot;

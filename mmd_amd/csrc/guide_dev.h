@@ -167,6 +167,11 @@ struct StepDev {
   float4* guide_chain;               // optional [n_guide_steps][n_traj_total][H]: state after every guide iteration
   long long guide_chain_stride;      // float4 elements between consecutive iterations
   long long traj_base;               // global index of trajectory 0 of the arrays (mmd_sampler_desc.traj_index_base)
+  // measurement hook (include/mmd_amd_debug.h, mmd_debug_ddpm_step_trace; NULL in every product call -- only the DUMP
+  // instantiation of the step kernel reads them): the discrete decisions of every guide iteration, MMD_TRACE_WORDS uint32 per
+  // (iteration, trajectory, support point) at the guide_chain stride, and the state the iterations start from
+  unsigned int* trace;
+  float4* mu_out;                    // optional [n_traj_total][H]: posterior mean (hard rows pinned) before the first iteration
 };
 
 int fill_guide(const mmd_guide_desc* d, GuideDev& g);

@@ -2544,6 +2544,7 @@ using namespace mmd;
 struct mmd_unet_s {
   mmd::LayeredUnet* layered = nullptr;   // set: a configuration other than the fused kernel's; everything below is unused
   int T = 0;
+  size_t blob_bytes = 0;     // bytes of `blob` (mmd_unet_weight_bytes)
   float* blob = nullptr;     // packed weights / biases / affine params
   float* ttable = nullptr;   // [T][tb_total]
   int tb_total = 0;
@@ -2805,6 +2806,7 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
   }
   MMD_HIP_CHECK(hipMemcpyAsync(u->blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, st));
   MMD_HIP_CHECK(hipStreamSynchronize(st));   // blob is a local vector
+  u->blob_bytes = blob.size() * sizeof(float);
 
   TimeArgs ta{};
   ta.w1 = u->blob + raw_time[0]; ta.b1 = u->blob + raw_time[1];
@@ -2933,6 +2935,11 @@ int mmd_debug_set_trace(void* dev_ptr) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dev_ptr, sizeof(dev_ptr)) == hipSuccess ? 0 : 1;
 }
 #endif
+
+size_t mmd_unet_weight_bytes(mmd_unet_t u) {
+  if (!u) return 0;
+  return u->layered ? layered_weight_bytes(u->layered) : u->blob_bytes;
+}
 
 double mmd_unet_flops_per_trajectory(void) { return kUnetFlops; }
 double mmd_unet_mfma_flops_per_trajectory(void) { return kUnetMfmaFlops; }

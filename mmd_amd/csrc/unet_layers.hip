@@ -57,9 +57,11 @@ __device__ __forceinline__ float load_in(const ConvArgs& a, size_t n, int c, int
 }
 
 // Conv1dBlock (layers.py:232-258): Conv1d(k5, p2) -> GroupNorm(8) -> Mish, + per-channel addend, + tensor addend.
-// blockDim = KS * (L / 4) * (cs / CT).  The sum over the input channels is DEFINED as KS = 4 interleaved partial sums (channels
-// ci = r mod 4, taps in order) combined as ((s0 + s1) + (s2 + s3)) + bias: thread group r of a workgroup computes s_r, so the bits
-// do not depend on how a launch is sliced (CT, cs follow the batch size).
+// blockDim = KS * NT, NT = min(64, the slice's (L / 4) * (cs / CT) register tiles rounded up to 16): always whole waves, at most
+// 256 threads; a thread loops over the tiles r, r + NT, ... of its thread group (one trip for the power-of-two channel counts, more
+// where a GroupNorm group is 5 or 7 channels wide: unet_input_dim 40 / 56).  The sum over the input channels is DEFINED as KS = 4
+// interleaved partial sums (channels ci = r mod 4, taps in order) combined as ((s0 + s1) + (s2 + s3)) + bias: thread group r of a
+// workgroup computes s_r, so the bits do not depend on how a launch is sliced (CT, cs follow the batch size).
 constexpr int KS = 4;
 template <int CT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void conv5_block_kernel(ConvArgs a) {
@@ -75,8 +77,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     xs[i] = (l >= 0 && l < L) ? load_in(a, n, c, l) : 0.f;
   }
   __syncthreads();
-  {
-    const int lanes = a.cs / CT, nconv = (L / 4) * lanes, ks = tid / nconv, r = tid % nconv, cl = r % lanes, pg = r / lanes;
+  const int lanes = a.cs / CT, items = (L / 4) * lanes, nt = nthr / KS, ks = tid / nt;
+  for (int r = tid % nt; r < items; r += nt) {
+    const int cl = r % lanes, pg = r / lanes;
     float acc[CT][4];
 #pragma unroll
     for (int j = 0; j < CT; ++j)
@@ -235,6 +238,7 @@ struct LayeredUnet {
   Spec spec;
   int T = 0, tb_total = 0;
   float* blob = nullptr;
+  size_t blob_bytes = 0;
   float* ttable = nullptr;
   std::vector<LRtb> rtb;
   size_t down_w[MAX_LEVELS - 1], down_b[MAX_LEVELS - 1], up_w[MAX_LEVELS - 1], up_b[MAX_LEVELS - 1];
@@ -292,6 +296,7 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
     MMD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   MMD_HIP_CHECK(hipMemcpyAsync(u->blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, st));
   MMD_HIP_CHECK(hipStreamSynchronize(st));
+  u->blob_bytes = blob.size() * sizeof(float);
   TimeArgs ta{};
   ta.w1 = u->blob + raw_time[0]; ta.b1 = u->blob + raw_time[1];
   ta.w3 = u->blob + raw_time[2]; ta.b3 = u->blob + raw_time[3];
@@ -318,6 +323,7 @@ void layered_destroy(LayeredUnet* u) {
 // tensor of a block, the output of a level's first block, a 1x1 residual, level 0's output, the (n_levels - 1) skip tensors; the
 // concatenated up-path input is read from its two tensors in place
 static int n_buffers(const LayeredUnet* u) { return 6 + (u->spec.n_levels - 1); }
+size_t layered_weight_bytes(const LayeredUnet* u) { return u->blob_bytes; }
 size_t layered_workspace_bytes(const LayeredUnet* u, int n_traj) {
   return n_traj > 0 ? (size_t)n_buffers(u) * n_traj * u->per_sample * sizeof(float) + 256 : 0;
 }
@@ -345,18 +351,23 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   // Conv1dBlock: (x1 | x2) [c][L] -> Mish(GN(conv5)) + add_c[c] + add_t -> y.  A workgroup of KS x nconv threads, nconv =
   // (L / 4) * (cs / CT) in [16, 64]: the slice width cs (whole GroupNorm groups) follows from that, CT = 2 for the big launches
   auto block5 = [&](const float* x1, int c1, const float* x2, int c2, int in_cl, int L, int c_out, size_t w, size_t b, size_t gamma,
-                    size_t beta, const float* add_c, const float* add_t, float* y) {
+                    size_t beta, const float* add_c, const float* add_t, float* y) -> int {
     const int cpg = c_out / N_GROUPS;
     int ct = n >= 768 ? 4 : n >= 192 ? 2 : 1, cs = c_out;
     auto nconv = [&]() { return (L / 4) * (cs / ct); };
     while (nconv() > 64 && (cs / 2) % cpg == 0) cs /= 2;
-    while (nconv() > 64) ct *= 2;                               // (unet_input_dim 64: one group of a level is 512 outputs)
     while (ct > 1 && (cs % ct || nconv() < 16)) ct /= 2;
+    // threads per partial sum: the slice's register tiles, in whole quarter-waves, at most 64 -- a thread loops over more (a group
+    // of 5 or 7 channels, or one group of 512 outputs at unet_input_dim 64, does not cut into 16 .. 64 tiles)
+    const int nt = nconv() >= 64 ? 64 : (nconv() + 15) / 16 * 16;
+    MMD_REQUIRE((ct == 1 || ct == 2 || ct == 4) && cs % ct == 0 && cs % cpg == 0 && c_out % cs == 0 && (KS * nt) % 64 == 0 && KS * nt <= 256,
+                "layered_forward: no launch shape for a Conv1dBlock of %d channels at length %d", c_out, L);
     ConvArgs a{x1, x2, c1, c2, L, L, c_out, cs, in_cl, 0, B + w, B + b, B + gamma, B + beta, add_c, add_t, y};
     const size_t shm = ((size_t)(c1 + c2) * (L + 8) + (size_t)KS * cs * L + 2 * N_GROUPS) * sizeof(float);
-    if (ct == 4) hipLaunchKernelGGL(conv5_block_kernel<4>, dim3(n, c_out / cs), dim3(KS * nconv()), shm, st, a);
-    else if (ct == 2) hipLaunchKernelGGL(conv5_block_kernel<2>, dim3(n, c_out / cs), dim3(KS * nconv()), shm, st, a);
-    else hipLaunchKernelGGL(conv5_block_kernel<1>, dim3(n, c_out / cs), dim3(KS * nconv()), shm, st, a);
+    if (ct == 4) hipLaunchKernelGGL(conv5_block_kernel<4>, dim3(n, c_out / cs), dim3(KS * nt), shm, st, a);
+    else if (ct == 2) hipLaunchKernelGGL(conv5_block_kernel<2>, dim3(n, c_out / cs), dim3(KS * nt), shm, st, a);
+    else hipLaunchKernelGGL(conv5_block_kernel<1>, dim3(n, c_out / cs), dim3(KS * nt), shm, st, a);
+    return 0;
   };
   auto plain = [&](int mode, int k, const float* x1, int c1, const float* x2, int c2, int in_cl, int l_in, int l_out, int c_out,
                    int out_cl, size_t w, size_t b, float* y) {
@@ -368,14 +379,14 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     else hipLaunchKernelGGL((conv_plain_kernel<0, 1, 1>), dim3(n, ns), dim3(256), shm, st, a);
   };
   // one ResidualTemporalBlock (layers.py:346-358): (x1 | x2) [cin][L] -> out [cout][L]
-  auto rtb = [&](const LRtb& R, const float* x1, int c1, const float* x2, int c2, int in_cl, int L, float* out) {
-    block5(x1, c1, x2, c2, in_cl, L, R.cout, R.wa, R.ba, R.ga, R.bea, tt + R.tb_off, nullptr, tmp);
+  auto rtb = [&](const LRtb& R, const float* x1, int c1, const float* x2, int c2, int in_cl, int L, float* out) -> int {
+    if (int rc = block5(x1, c1, x2, c2, in_cl, L, R.cout, R.wa, R.ba, R.ga, R.bea, tt + R.tb_off, nullptr, tmp)) return rc;
     const float* res = x1;                                   // identity residual (cin == cout: never a concatenated input)
     if (R.res) {
       plain(0, 1, x1, c1, x2, c2, in_cl, L, L, R.cout, 0, R.wr, R.br, resb);
       res = resb;
     }
-    block5(tmp, R.cout, nullptr, 0, 0, L, R.cout, R.wb, R.bb, R.gb, R.beb, nullptr, res, out);
+    return block5(tmp, R.cout, nullptr, 0, 0, L, R.cout, R.wb, R.bb, R.gb, R.beb, nullptr, res, out);
   };
   const int NL = s.n_levels;
   int L = H, cin = 4;
@@ -384,8 +395,8 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   for (int i = 0; i < NL; ++i) {                              // downs (temporal_unet.py:147-156)
     const int c = s.dims[i + 1];
     level_out = i == 0 ? out0 : skip[i - 1];
-    rtb(u->rtb[2 * i], xin, cin, nullptr, 0, i == 0, L, mid);          // (level 0 reads the trajectory: channels-last)
-    rtb(u->rtb[2 * i + 1], mid, c, nullptr, 0, 0, L, level_out);
+    if (int rc = rtb(u->rtb[2 * i], xin, cin, nullptr, 0, i == 0, L, mid)) return rc;   // (level 0 reads the trajectory: channels-last)
+    if (int rc = rtb(u->rtb[2 * i + 1], mid, c, nullptr, 0, 0, L, level_out)) return rc;
     if (i < NL - 1) {
       plain(0, 3, level_out, c, nullptr, 0, 0, L, L / 2, c, 0, u->down_w[i], u->down_b[i], in[i & 1]);
       xin = in[i & 1];
@@ -395,18 +406,18 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   }
   {                                                          // mid blocks (state_dict order: behind the ups)
     const int m0 = 2 * NL + 2 * (NL - 1), c = s.dims[NL];
-    rtb(u->rtb[m0], level_out, c, nullptr, 0, 0, L, mid);
-    rtb(u->rtb[m0 + 1], mid, c, nullptr, 0, 0, L, in[0]);
+    if (int rc = rtb(u->rtb[m0], level_out, c, nullptr, 0, 0, L, mid)) return rc;
+    if (int rc = rtb(u->rtb[m0 + 1], mid, c, nullptr, 0, 0, L, in[0])) return rc;
   }
   for (int i = 0; i < NL - 1; ++i) {                          // ups: x = cat(x, h.pop()) (temporal_unet.py:164-171)
     const int din = s.dims[NL - 1 - i], dout = s.dims[NL - i];
-    rtb(u->rtb[2 * NL + 2 * i], in[0], dout, skip[NL - 2 - i], dout, 0, L, mid);
-    rtb(u->rtb[2 * NL + 2 * i + 1], mid, din, nullptr, 0, 0, L, in[1]);
+    if (int rc = rtb(u->rtb[2 * NL + 2 * i], in[0], dout, skip[NL - 2 - i], dout, 0, L, mid)) return rc;
+    if (int rc = rtb(u->rtb[2 * NL + 2 * i + 1], mid, din, nullptr, 0, 0, L, in[1])) return rc;
     plain(1, 4, in[1], din, nullptr, 0, 0, L, 2 * L, din, 0, u->up_w[i], u->up_b[i], in[0]);
     L *= 2;
   }
   // final_conv (temporal_unet.py:104-110); with one level there are no ups and L is still 64
-  block5(in[0], s.uid, nullptr, 0, 0, L, s.uid, u->fin_w5, u->fin_b5, u->fin_g, u->fin_be, nullptr, nullptr, mid);
+  if (int rc = block5(in[0], s.uid, nullptr, 0, 0, L, s.uid, u->fin_w5, u->fin_b5, u->fin_g, u->fin_be, nullptr, nullptr, mid)) return rc;
   plain(0, 1, mid, s.uid, nullptr, 0, 0, L, L, 4, 1, u->fin_w1, u->fin_b1, eps);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;

@@ -98,6 +98,7 @@ struct LayeredUnet;
 int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* tensors, hipStream_t st);
 void layered_destroy(LayeredUnet* u);
 size_t layered_workspace_bytes(const LayeredUnet* u, int n_traj);
+size_t layered_weight_bytes(const LayeredUnet* u);
 int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int n_traj, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace mmd

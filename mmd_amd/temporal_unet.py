@@ -97,13 +97,16 @@ class TemporalUnet:
         if self._sd is None:
             raise RuntimeError("TemporalUnet has no parameters: call load_state_dict first")
         dev = self._device_index(device)
+        # (MMD_AMD_UNET_LAYERED is read by mmd_unet_create: part of BOTH cache keys, so toggling it on a live TemporalUnet -- the
+        # fused-vs-layered A/B tests do -- really switches paths instead of returning the handle created before)
+        layered = os.environ.get("MMD_AMD_UNET_LAYERED", "")
         if n_timesteps is not None:
             T = int(n_timesteps)
         else:
-            have = [t for (t, d) in self._models if d == dev]
+            have = [t for (t, d, l) in self._models if d == dev and l == layered]
             T = max(have) if have else self.max_timesteps
-        if (T, dev) not in self._models:
-            key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, dev, os.environ.get("MMD_AMD_UNET_LAYERED", ""))
+        if (T, dev, layered) not in self._models:
+            key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, dev, layered)
             dm = _DEVICE_MODELS.get(key)
             if dm is None:
                 lib = _lib.load()
@@ -117,8 +120,8 @@ class TemporalUnet:
                 N_DEVICE_MODELS_CREATED += 1
                 dm = _DeviceModel(h)
                 _DEVICE_MODELS[key] = dm
-            self._models[(T, dev)] = dm
-        return self._models[(T, dev)].handle
+            self._models[(T, dev, layered)] = dm
+        return self._models[(T, dev, layered)].handle
 
     def workspace(self, n_traj, device, sampler=False):
         """Scratch for one call: one buffer per (device, stream), so calls issued on different streams never share the

@@ -451,6 +451,141 @@ def guide_grad(x_norm, gp: GuideParams, cons: Sequence[ConstraintGroup] = (), cl
     return -1.0 * total
 
 
+# --------------------------------------------------------------------------------------------------------------
+# The guide's DISCRETE decisions (tests/test_gpu_flips.py).  Everything in GuideManagerTrajectoriesWithVelocity.forward that is
+# not continuous in x -- the nearest-cell SDF index (grid_map_sdf.py:84-114), the collision hinges and their arg max
+# (distance_fields.py:110-135, :354-367), the active set of every CostConstraint (cost_functions.py:305-312) -- plus the two
+# continuous switches (gradient clip active, guides.py:247-253; un-normalisation clip, normalization.py:161-163) as one record per
+# (trajectory, support point).  guide_decisions() returns the sets guide_grad() takes; guide_grad_forced() evaluates the same guide
+# with the sets GIVEN -- with the HIP kernel's own sets it tells whether a step that differs by more than the tolerance differs
+# through a branch or through arithmetic.
+# --------------------------------------------------------------------------------------------------------------
+
+
+@dataclass
+class GuideSets:
+    cell: torch.Tensor          # [B,H] long   ix * ny + iy of the grid lookup
+    obj_active: torch.Tensor    # [B,H] bool   margin - sdf > 0 for the winning field
+    obj_win: torch.Tensor       # [B,H] long   index of the winning field (7: the env's extra objects)
+    ws_active: torch.Tensor     # [B,H] bool
+    ws_arg: torch.Tensor        # [B,H] long   0: x-min, 1: y-min, 2: x-max, 3: y-max
+    clip: torch.Tensor          # [B,H,3+G] bool  gradient clip active on (objects, boundaries, GP, group 0, ...)
+    unnorm_clip: torch.Tensor   # [B,H,4] bool
+    cons: List[torch.Tensor]    # per group [B,H,S] bool: slot s active (slot_table)
+
+
+def slot_table(grp: ConstraintGroup, H=64):
+    """[S,H] long: the point of `grp` that sits in slot s at support point t (-1: none).  A point covers the integer t with
+    t0 <= t < t1 (cost_functions.py:304-305); slot = its rank among the points covering t, in list order -- the layout of the
+    product's time-bucketed table (mmd_pack_constraints / mmd_soft_constraints_from_paths)."""
+    n = grp.q.shape[0]
+    t0 = torch.ceil(grp.t_range[:, 0]).long().clamp_min(0)
+    t1 = torch.ceil(grp.t_range[:, 1]).long().clamp_max(H)
+    cover = (torch.arange(H)[None, :] >= t0[:, None]) & (torch.arange(H)[None, :] < t1[:, None])     # [n,H]
+    rank = torch.cumsum(cover.long(), dim=0) - 1                                                    # [n,H]
+    S = int(cover.sum(0).max()) if n else 0
+    tab = torch.full((max(S, 1), H), -1, dtype=torch.long)
+    pts, ts = torch.nonzero(cover, as_tuple=True)
+    tab[rank[pts, ts], ts] = pts
+    return tab
+
+
+def _cell_index(p, gp: GuideParams):
+    sdf = gp.sdf_grids[0][0]
+    map_dim = torch.abs(gp.limits_hi - gp.limits_lo)
+    cmap = torch.tensor(sdf.shape, dtype=torch.long)
+    idx = ((p - gp.limits_lo) / map_dim * cmap).floor().to(torch.int)
+    idx = idx.clamp(torch.zeros(2, dtype=torch.int), (cmap - 1).to(torch.int))
+    return idx[..., 0].long() * int(cmap[1]) + idx[..., 1].long()
+
+
+def _constraint_dist(p, grp: ConstraintGroup, tab):
+    """dist [S,B,H] of every (slot, trajectory, support point) and the unit vectors d / ||d|| [S,B,H,2] (zero at d = 0)."""
+    q = grp.q[tab.clamp_min(0)]                                  # [S,H,2]
+    d = p[None] - q[:, None]                                     # [S,B,H,2]
+    dist = torch.linalg.norm(d, dim=-1)
+    unit = torch.where(dist[..., None] > 0, d / dist[..., None].clamp_min(1e-38), torch.zeros_like(d))
+    return dist, unit
+
+
+def guide_decisions(x_norm, gp: GuideParams, cons: Sequence[ConstraintGroup] = (), clip_mode="always") -> GuideSets:
+    """The sets guide_grad(x_norm, gp, cons, clip_mode) takes (norm clipping rule; the env's extra objects are not covered)."""
+    assert gp.extra_spheres is None and gp.extra_boxes is None and not gp.extra_only
+    H = x_norm.shape[-2]
+    xu = unnormalize(x_norm, gp.norm_mins, gp.norm_maxs, clip_mode=clip_mode)
+    p = xu[..., :2]
+    m = gp.margin
+    best = torch.zeros_like(p[..., 0])
+    win = torch.zeros_like(best, dtype=torch.long)
+    for k in range(len(gp.sdf_grids)):
+        v = torch.relu(m - sdf_lookup(p, gp, k)[0])
+        take = v > best
+        win = torch.where(take, torch.full_like(win, k), win)
+        best = torch.where(take, v, best)
+    d = torch.cat((p - gp.ws_min, gp.ws_max - p), dim=-1)
+    vmax, arg = torch.relu(m - d).max(dim=-1)
+    _, terms_raw = _raw_terms(xu, gp, cons)
+    clip = torch.stack([torch.linalg.norm(g + 1e-6, dim=-1) > gp.max_grad_norm for g in terms_raw], dim=-1)
+    masks = []
+    for grp in cons:
+        tab = slot_table(grp, H)
+        dist, _ = _constraint_dist(p, grp, tab)
+        r = grp.radius[tab.clamp_min(0)]                          # [S,H]
+        act = (tab >= 0)[:, None, :] & ~(dist > r[:, None, :])
+        masks.append(act.permute(1, 2, 0).contiguous())
+    return GuideSets(cell=_cell_index(p, gp) if gp.sdf_grids else torch.zeros_like(win), obj_active=best > 0, obj_win=win,
+                     ws_active=vmax > 0, ws_arg=arg, clip=clip,
+                     unnorm_clip=(x_norm.abs() > 1) if clip_mode == "always" else torch.zeros_like(x_norm, dtype=torch.bool),
+                     cons=masks)
+
+
+def _raw_terms(xu, gp: GuideParams, cons):
+    terms = [grad_object_collision(xu, gp), grad_ws_boundaries(xu, gp), grad_gp_prior(xu, gp)]
+    for grp in cons:
+        terms.append(grad_constraint(xu, grp))
+    weights = [gp.weight_collision, gp.weight_collision, gp.weight_smoothness] + [grp.weight for grp in cons]
+    return weights, terms
+
+
+def guide_grad_forced(x_norm, gp: GuideParams, cons: Sequence[ConstraintGroup], sets: GuideSets):
+    """guide_grad with every decision taken from `sets` instead of from x: the clip of the un-normalisation where
+    sets.unnorm_clip says so, the SDF value / gradient of cell sets.cell and field sets.obj_win iff sets.obj_active, the
+    boundary direction sets.ws_arg iff sets.ws_active, the constraint points of sets.cons, the norm clip where sets.clip."""
+    H = x_norm.shape[-2]
+    xc = torch.where(sets.unnorm_clip, torch.clip(x_norm, -1, 1), x_norm)
+    xu = (xc + 1) / 2.0 * (gp.norm_maxs - gp.norm_mins) + gp.norm_mins
+    p = xu[..., :2]
+    terms = []
+    g = torch.zeros_like(xu)
+    if gp.sdf_grids:
+        grads = torch.stack([gr.reshape(-1, 2) for _, gr in gp.sdf_grids], dim=0)       # [K, nx*ny, 2]
+        gsel = grads[sets.obj_win.clamp_max(len(gp.sdf_grids) - 1), sets.cell]             # [B,H,2]
+        g[..., :2] = torch.where(sets.obj_active[..., None], -gsel, torch.zeros_like(gsel))
+    g[..., 0, :] = 0.0
+    terms.append((g, gp.weight_collision))
+    dirs = torch.tensor([[-1.0, 0.0], [0.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+    g = torch.zeros_like(xu)
+    g[..., :2] = dirs[sets.ws_arg] * sets.ws_active[..., None]
+    g[..., 0, :] = 0.0
+    terms.append((g, gp.weight_collision))
+    terms.append((grad_gp_prior(xu, gp), gp.weight_smoothness))
+    for grp, act in zip(cons, sets.cons):
+        tab = slot_table(grp, H)
+        _, unit = _constraint_dist(p, grp, tab)                                          # [S,B,H,2]
+        a = act.permute(2, 0, 1)[: tab.shape[0]] & (tab >= 0)[:, None, :]
+        g = torch.zeros_like(xu)
+        g[..., :2] = -torch.where(a[..., None], unit, torch.zeros_like(unit)).sum(0)
+        terms.append((g, grp.weight))
+    total = torch.zeros_like(x_norm)
+    for k, (g, w) in enumerate(terms):
+        n = torch.linalg.norm(g + 1e-6, dim=-1, keepdims=True)
+        gc = torch.where(sets.clip[..., k:k + 1], gp.max_grad_norm / n * g, g).clone()
+        gc[..., 0, :] = 0.0
+        gc[..., -1, :] = 0.0
+        total = total + w * gc
+    return -1.0 * total
+
+
 def guide_grad_dense_autograd(x_norm, gp: GuideParams, cons: Sequence[ConstraintGroup] = ()):
     """Reference-SHAPED evaluation of the same guide: the dense (n,B,H,2) CostConstraint broadcast
     (cost_functions.py:297-326) and one torch.autograd.grad per cost term (guides.py:207-211).  Used (a) to

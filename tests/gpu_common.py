@@ -57,10 +57,10 @@ def hip_run_inference(case, xT, steps, weights_seed=0):
 def teacher_forced_guided_step(test, tag, s, T, starts, goals, map_name, picks, i, seeds, paths_np=None):
     """ONE guided ddpm_sample_fn step (sample_functions.py:40-107: UNet + posterior mean + 20 guide iterations + noise + hard
     conditioning) of MultiRobotSampler `s` on ALL its local trajectories, started from a mid-chain looking state, against the
-    oracle on the trajectories `picks` = [(global robot, sample)].  Bound per trajectory: the north-star 1e-3, or 1.5 x the
-    oracle's OWN response to a rounding-sized (relative 2e-6) perturbation of eps where that is larger -- 20 norm-clipped
-    iterations over hinge constraints are not continuous in eps, so a trajectory on a switching surface moves by more than 1e-3
-    whatever computes it (tests/test_gpu_fullsize.py uses the same yardstick).  paths_np: all robots' paths for the inter-robot
+    oracle on the trajectories `picks` = [(global robot, sample)].  Bound per trajectory: the north-star 1e-3; a trajectory
+    beyond it must be a BRANCH FLIP -- the kernel's decision trace differs from the oracle's at some guide iteration and the
+    oracle run on the kernel's decisions agrees with the kernel to 1e-4 (GuidedStepJudge) -- with 1.5 x the oracle's own response
+    to a rounding-sized perturbation of eps as the fallback yardstick only.  paths_np: all robots' paths for the inter-robot
     soft constraints (None: no inter-robot term).  Returns the worst error / bound ratio."""
     import cases
     import parity_log
@@ -80,22 +80,149 @@ def teacher_forced_guided_step(test, tag, s, T, starts, goals, map_name, picks, 
     sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
     tb = O.schedule_tables(T)
     gp = cases.guide_params(map_name)
+    judge = GuidedStepJudge(model, s.guide, x, s.hard_conds, i, ceil(0.5 * T), s.n_local, noise, ys)
     worst = 0.0
     for r, b in picks:
         idx = (r - s.robot0) * B + b
         groups = [cases.soft_group(paths_np, r)] if paths_np is not None else []
         hc = cases.hard_conds_for(starts[r], goals[r])
-        guide = lambda z, groups=groups: O.guide_grad(z, gp, groups, clip_mode="always")      # noqa: E731
-        xi = x[idx:idx + 1]
-        step = lambda pert=None: O.apply_hard_conditioning(                                   # noqa: E731
-            O.ddpm_sample_step(sd, tb, xi.clone(), hc, i, guide=guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
-                               noise=noise[idx:idx + 1], noise_std_extra=0.5, eps_rel_perturb=pert), hc)
-        ref = step()
-        err = cases.rel_l2(ys[idx:idx + 1], ref)
-        gen = torch.Generator().manual_seed(1000 + idx)
-        sens = max(cases.rel_l2(step(2e-6 * torch.randn(xi.shape, generator=gen)), ref) for _ in range(8))
-        bound = max(1e-3, 1.5 * sens)
-        parity_log.record(test, f"{tag}_robot{r}_sample{b}", i, err, sens=sens, bound=bound)
-        assert err < bound, (tag, r, b, err, sens)
-        worst = max(worst, err / bound)
+        verdict, err = judge.check(test, f"{tag}_robot{r}_sample{b}", idx, sd, tb, gp, groups, hc, 1000 + idx)
+        if verdict == "within":
+            worst = max(worst, err / 1e-3)
     return worst
+
+
+# ---- branch-flip attribution of a guided step (include/mmd_amd_debug.h: mmd_debug_ddpm_step_trace) -----------
+def hip_step_with_trace(model, x, hard_conds, i, guide, t_start_guide, n_robots=1, noise=None, n_guide_steps=20,
+                        noise_fn=lambda t: 0.5):
+    """model.sample_step through the measurement hook: returns (y, mu, gchain [n_it, n, H, 4], trace [n_it, n, H, 12] int64), all
+    on the CPU; x is left untouched."""
+    import ctypes as C
+    from mmd_amd import _lib
+    y = x.clone().cuda().contiguous()
+    n, H, D = y.shape
+    hard, mask = model._hard_tensor(hard_conds, n_robots, H, y.device, D)
+    s = model._sampler_desc(n_guide_steps, t_start_guide, noise_fn, mask)
+    gd = guide.desc()
+    ws = model.model.workspace(n, y.device, sampler=True)
+    mu = torch.empty_like(y)
+    gchain = torch.empty((n_guide_steps, n, H, D), dtype=torch.float32, device=y.device)
+    trace = torch.zeros((n_guide_steps, n, H, _lib.TRACE_WORDS), dtype=torch.int32, device=y.device)
+    nz = noise.cuda().contiguous() if noise is not None else None
+    _lib.launch("mmd_debug_ddpm_step_trace", y, model.model.handle(model.n_diffusion_steps, y.device), C.byref(s), C.byref(gd),
+                y.data_ptr(), hard.data_ptr(), n_robots, n // n_robots, int(i), nz.data_ptr() if nz is not None else None,
+                C.c_uint64(0), C.c_uint32(int(i) & 0xFFFFFFFF), ws.data_ptr(), ws.numel(), mu.data_ptr(), gchain.data_ptr(),
+                trace.data_ptr())
+    tr = trace.cpu().to(torch.int64) & 0xFFFFFFFF
+    return y.cpu(), mu.cpu(), gchain.cpu(), tr
+
+
+def decode_trace(tr, slots):
+    """tr [n_it, H, 12] (one trajectory) -> one oracle GuideSets per iteration; slots = slots per constraint group."""
+    from oracle import mmd_oracle as O
+    out = []
+    for w in tr:
+        f = w[:, 1]
+        bit = lambda k: ((f >> k) & 1).bool()                                                # noqa: E731
+        cons = []
+        for g, S in enumerate(slots):
+            assert g < 4 and S <= 64, "the trace holds 4 groups x 64 slots"
+            lo, hi = w[:, 2 + 2 * g], w[:, 3 + 2 * g]
+            sidx = torch.arange(S)
+            word = torch.where(sidx[None, :] < 32, lo[:, None], hi[:, None])
+            cons.append((((word >> (sidx % 32)[None, :]) & 1).bool())[None])                 # [1,H,S]
+        clip = torch.stack([bit(8), bit(9), bit(10)] + [bit(11 + g) for g in range(len(slots))], dim=-1)[None]
+        out.append(O.GuideSets(cell=w[None, :, 0], obj_active=bit(0)[None], obj_win=((f >> 1) & 7)[None], ws_active=bit(4)[None],
+                               ws_arg=((f >> 5) & 3)[None], clip=clip,
+                               unnorm_clip=torch.stack([bit(16 + d) for d in range(4)], dim=-1)[None], cons=cons))
+    return out
+
+
+def first_set_difference(a, b, H=64):
+    """(kind, support point, detail) of the first DISCRETE decision in which two GuideSets differ on an interior support point
+    (rows 0 / H-1 carry no gradient; the continuous switches -- clips -- are not flips), or None."""
+    inner = slice(1, H - 1)
+    checks = [("obj_active", a.obj_active, b.obj_active), ("ws_active", a.ws_active, b.ws_active)]
+    both = a.obj_active & b.obj_active
+    checks.append(("sdf_cell", torch.where(both, a.cell, 0), torch.where(both, b.cell, 0)))
+    checks.append(("obj_field", torch.where(both, a.obj_win, 0), torch.where(both, b.obj_win, 0)))
+    bw = a.ws_active & b.ws_active
+    checks.append(("ws_arg", torch.where(bw, a.ws_arg, 0), torch.where(bw, b.ws_arg, 0)))
+    for g, (ma, mb) in enumerate(zip(a.cons, b.cons)):
+        S = min(ma.shape[-1], mb.shape[-1])
+        checks.append((f"constraint_group{g}_active_set", ma[..., :S], mb[..., :S]))
+    for kind, u, v in checks:
+        d = (u != v)[0, inner]
+        if d.any():
+            t = int(torch.nonzero(d.reshape(d.shape[0], -1).any(-1))[0]) + 1
+            return kind, t, int(d.sum())
+    return None
+
+
+class GuidedStepJudge:
+    """Verdict on ONE teacher-forced guided step of a HIP batch against the oracle, per trajectory:
+      err < 1e-3 (the north-star tolerance)                                   -> 'within'
+      else: the kernel's own decision trace is read back (bit-identical re-run of the step through the measurement hook), the
+      first guide iteration whose discrete sets differ from the oracle's is located, and the oracle is re-run with the KERNEL's
+      sets forced on it: if that agrees with the kernel to < 1e-4 the step differs by a branch flip, not by arithmetic
+                                                                               -> 'flip@<iteration>:<kind>'
+      else the old yardstick, max(1e-3, 1.5 x the oracle's own response to a relative `pert` perturbation of eps)
+                                                                               -> 'sens' (or an assertion)."""
+
+    def __init__(self, model, guide, x, hard_conds, i, t_start_guide, n_robots, noise, y_hip):
+        self.model, self.guide, self.x, self.hard_conds, self.i = model, guide, x, hard_conds, i
+        self.tsg, self.n_robots, self.noise, self.y_hip = t_start_guide, n_robots, noise, y_hip
+        self._tr = None
+
+    def trace(self):
+        if self._tr is None:
+            y, mu, gchain, tr = hip_step_with_trace(self.model, self.x, self.hard_conds, self.i, self.guide, self.tsg,
+                                                    self.n_robots, self.noise)
+            assert torch.equal(y, self.y_hip), "the trace instantiation must reproduce the production step bit for bit"
+            self._tr = (mu, gchain, tr)
+        return self._tr
+
+    def check(self, test, tag, idx, sd, tb, gp, groups, hc, sens_seed, pert=2e-6, n_sens=8, lin=1.0):
+        import cases
+        import parity_log
+        from oracle import mmd_oracle as O
+        xi, nz, i = self.x[idx:idx + 1], self.noise[idx:idx + 1], self.i
+        own_sets = []
+
+        def own_guide(z):
+            own_sets.append(O.guide_decisions(z, gp, groups, clip_mode="always"))
+            return O.guide_grad(z, gp, groups, clip_mode="always")
+
+        def step(guide, p=None):
+            return O.apply_hard_conditioning(
+                O.ddpm_sample_step(sd, tb, xi.clone(), hc, i, guide=guide, n_guide_steps=20, t_start_guide=self.tsg, noise=nz,
+                                   noise_std_extra=0.5, eps_rel_perturb=p), hc)
+        ref = step(own_guide)
+        err = cases.rel_l2(self.y_hip[idx:idx + 1], ref)
+        if err < 1e-3:
+            parity_log.record(test, tag, i, err, bound=1e-3)
+            return "within", err
+        # ---- over the tolerance: whose decisions differ, and is that all that differs?
+        mu, gchain, tr = self.trace()
+        slots = [O.slot_table(g).shape[0] for g in groups]
+        hip_sets = decode_trace(tr[:, idx], slots)
+        first = None
+        for k, (a, b) in enumerate(zip(hip_sets, own_sets)):
+            d = first_set_difference(a, b)
+            if d is not None:
+                first = (k,) + d
+                break
+        it = iter(hip_sets)
+        forced = step(lambda z: O.guide_grad_forced(z, gp, groups, next(it)))
+        ferr = cases.rel_l2(self.y_hip[idx:idx + 1], forced)
+        if first is not None and ferr < 1e-4:
+            verdict = f"flip@{first[0]}:{first[1]}:t{first[2]}"
+            parity_log.record(test, tag, i, err, bound=1e-3, flip=verdict, forced_err=ferr)
+            return verdict, err
+        gen = torch.Generator().manual_seed(sens_seed)
+        sens = max(cases.rel_l2(step(lambda z: O.guide_grad(z, gp, groups, clip_mode="always"),
+                                     pert * torch.randn(xi.shape, generator=gen)), ref) for _ in range(n_sens))
+        bound = max(1e-3, 1.5 * lin * sens)
+        parity_log.record(test, tag, i, err, sens=sens, bound=bound, forced_err=ferr, first_difference=str(first))
+        assert err < bound, (test, tag, err, sens, ferr, first)
+        return "sens", err

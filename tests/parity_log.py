@@ -1,5 +1,5 @@
 """Collects the measured HIP-vs-reference / HIP-vs-oracle errors of the -m gpu parity tests and writes them as one JSON
-artifact at session end (gpurun_out/r04_parity.json on the GPU box; copied to profiles/ and committed): per case and
+artifact at session end (gpurun_out/r05_parity.json on the GPU box; copied to profiles/ and committed): per case and
 chain row the error, the reference's own sensitivity `sens` to a relative 1e-6 UNet perturbation (stored in the golden
 fixtures by tools/make_golden.py), their ratio and the bound that was asserted."""
 import json
@@ -9,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _RECORDS = []
 
 
-def record(test, case, row, err, sens=None, bound=None, note=None):
+def record(test, case, row, err, sens=None, bound=None, note=None, **extra):
     r = {"test": test, "case": case, "row": None if row is None else int(row), "err": float(err)}
+    r.update({k: (float(v) if isinstance(v, (int, float)) else v) for k, v in extra.items()})
     if sens is not None:
         r["sens"] = float(sens)
         r["err_over_sens"] = float(err) / float(sens) if float(sens) > 0 else None
@@ -26,11 +27,13 @@ def flush():
         return None
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r04_parity.json")
+    path = os.path.join(out_dir, "r05_parity.json")
     summary = {}
     for r in _RECORDS:
         s = summary.setdefault(r["test"], {"n": 0, "max_err": 0.0, "max_err_over_sens": None})
         s["n"] += 1
+        if r.get("flip"):
+            s["branch_flips"] = s.get("branch_flips", 0) + 1
         s["max_err"] = max(s["max_err"], r["err"])
         if r.get("err_over_sens") is not None:
             s["max_err_over_sens"] = max(s["max_err_over_sens"] or 0.0, r["err_over_sens"])

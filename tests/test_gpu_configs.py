@@ -31,21 +31,13 @@ def _check_hard_conds(s, trajs):
     assert torch.equal(trajs[:, -1], s.hard_conds[H - 1].repeat_interleave(B, 0))
 
 
-def _chain_step_vs_oracle(tag, sd, tb, chain, k, sl, hc, i, guide, noise):
-    """Chain row k -> k + 1 of the sampled batch slice `sl`, per trajectory, against the oracle restarted from row k."""
-    import parity_log
+def _chain_step_vs_oracle(tag, s, sd, tb, chain, k, sl, hc, i, gp, groups, st_k):
+    """Chain row k -> k + 1 of the sampled batch slice `sl` (one robot of sampler `s`), per trajectory, against the oracle
+    restarted from row k: the north-star 1e-3, a step beyond it must be a shown branch flip (gpu_common.GuidedStepJudge)."""
+    import gpu_common
+    jd = gpu_common.GuidedStepJudge(s.model, s.guide, chain[k].clone(), s.hard_conds, i, 13, s.n_local, st_k, chain[k + 1])
     for j in range(sl.start, sl.stop):
-        xi = chain[k, j:j + 1]
-        step = lambda pert=None: O.apply_hard_conditioning(                                   # noqa: E731
-            O.ddpm_sample_step(sd, tb, xi.clone(), hc, i, guide=guide, n_guide_steps=20, t_start_guide=13,
-                               noise=noise[j - sl.start:j - sl.start + 1], noise_std_extra=0.5, eps_rel_perturb=pert), hc)
-        ref = step()
-        err = rel_l2(chain[k + 1, j:j + 1], ref)
-        gen = torch.Generator().manual_seed(2000 + j)
-        sens = max(rel_l2(step(2e-6 * torch.randn(xi.shape, generator=gen)), ref) for _ in range(8))
-        bound = max(1e-3, 1.5 * sens)
-        parity_log.record("config_chain_step_teacher_forced", f"{tag}_traj{j}", i, err, sens=sens, bound=bound)
-        assert err < bound, (tag, j, err, sens)
+        jd.check("config_chain_step_teacher_forced", f"{tag}_traj{j}", j, sd, tb, gp, groups, hc, 2000 + j)
 
 
 def _picks(n_robots, robot0, n_local, B, seed, n=4):
@@ -129,8 +121,7 @@ def test_config2_six_robots_empty_no_interrobot_term():
     r, k = 4, 14                                             # chain row k -> k+1 is loop index i = 24 - k = 10 (guided)
     sl = slice(r * 16, (r + 1) * 16)
     hc = cases.hard_conds_for(starts[r], goals[r])
-    _chain_step_vs_oracle("config2_T25", sd, tb, chain, k, sl, hc, 24 - k, lambda x: O.guide_grad(x, gp, [], clip_mode="always"),
-                          st[k, sl])
+    _chain_step_vs_oracle("config2_T25", s, sd, tb, chain, k, sl, hc, 24 - k, gp, [], st[k])
 
 
 def test_config3_ten_robots_highways_with_soft_constraints():
@@ -152,8 +143,7 @@ def test_config3_ten_robots_highways_with_soft_constraints():
     sl = slice(r * 8, (r + 1) * 8)
     hc = cases.hard_conds_for(starts[r], goals[r])
     grp = cases.soft_group(paths_np, r)
-    _chain_step_vs_oracle("config3_T25", sd, tb, chain, k, sl, hc, 24 - k, lambda x: O.guide_grad(x, gp, [grp], clip_mode="always"),
-                          st[k, sl])
+    _chain_step_vs_oracle("config3_T25", s, sd, tb, chain, k, sl, hc, 24 - k, gp, [grp], st[k])
     # the device-side pick + conflict mask run on the result
     from mmd_amd.multi_agent import check_rr_collisions
     best = s.best_paths(chain[-1].cuda(), paths)

@@ -160,6 +160,8 @@ def test_headline_guided_step_and_guide_vs_oracle(headline):
     ys = ys.cpu()
     sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
     tb = O.schedule_tables(T)
+    import gpu_common
+    judge = gpu_common.GuidedStepJudge(model, s.guide, x, s.hard_conds, 49, ceil(0.5 * T), R, noise, ys)
     for r, b in picks:
         idx = r * B + b
         grp = cases.soft_group(paths_np, r)
@@ -176,21 +178,12 @@ def test_headline_guided_step_and_guide_vs_oracle(headline):
         e20 = rel_l2(y20[idx:idx + 1], z)
         parity_log.record("fullsize_guide_20_steps", f"robot{r}_sample{b}", None, e20, bound=2e-4)
         assert e20 < 2e-4, (r, b, e20)
-        step = lambda pert=None: O.apply_hard_conditioning(                            # noqa: E731
-            O.ddpm_sample_step(sd, tb, xi.clone(), hc, 49, guide=guide, n_guide_steps=20, t_start_guide=ceil(0.5 * T),
-                               noise=noise[idx:idx + 1], noise_std_extra=0.5, eps_rel_perturb=pert), hc)
-        ref = step()
-        es = rel_l2(ys[idx:idx + 1], ref)
         # 20 norm-clipped iterations with hinge constraints are not continuous in eps: a trajectory that sits on a switching
-        # surface moves by more than 1e-3 under a rounding-sized change of the UNet output.  The oracle's own response to a
-        # relative 2e-6 perturbation of eps (the kernel's forward deviates from the fp32 reference by <= 2.4e-6 rel-L2,
-        # test_unet_forward_accuracy_against_fp64), max over 8 draws, is the yardstick there -- as `sens` is for the golden
-        # chains (tests/cases.py::chaos_bounds); everywhere else the north-star 1e-3 stands.
-        gen = torch.Generator().manual_seed(1000 + idx)
-        sens = max(rel_l2(step(2e-6 * torch.randn(xi.shape, generator=gen)), ref) for _ in range(8))
-        bound = max(1e-3, 1.5 * sens)
-        parity_log.record("fullsize_guided_step_teacher_forced", f"robot{r}_sample{b}", 49, es, sens=sens, bound=bound)
-        assert es < bound, (r, b, es, sens)
+        # surface moves by more than 1e-3 under a rounding-sized change of the UNet output.  Such a step must be SHOWN to be a
+        # branch flip (the kernel's decision trace differs from the oracle's and the oracle on the kernel's decisions agrees with
+        # the kernel to 1e-4: gpu_common.GuidedStepJudge); 1.5 x the oracle's own response to a relative 2e-6 perturbation of eps
+        # is the fallback yardstick only.  Everywhere else the north-star 1e-3 stands.
+        judge.check("fullsize_guided_step_teacher_forced", f"robot{r}_sample{b}", idx, sd, tb, gp, [grp], hc, 1000 + idx)
 
 
 def test_guide_zero_weights_is_identity(headline):
