@@ -17,6 +17,12 @@ per rank per round.  UNet weights are synthetic random-init (numpy PCG64), Gauss
 by the global trajectory index, so every rank's rows equal the unsharded run's), inputs are resident in HBM before the
 timed region.
 
+`--workload {headline,config2,config3,config4,config5}` (default: headline) runs the same measurement on BASELINE.json's other
+configs (`config.workload` carries BASELINE.json's own wording): config2 = 6-robot Empty circle without the inter-robot term, config3
+= 10-robot Highways with it, config4 = the 4 robots of the 1x2 Empty-tile ensemble (MPDEnsemble planner calls: two tile models
+composed along the horizon, a trajectory = 128 support points), config5 = the 64-robot Conveyor instance -- 8 robots per GPU under
+`--gpus 8`, one 4096-trajectory instance under `--gpus 1`.  All with B = 64 samples, T = 100 + 1 steps.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -44,6 +50,43 @@ PEAK_HBM_GBPS = 8000.0             # HBM3E spec (6.3 TB/s achievable, same guide
 DOMINANT_KERNEL = "UNET"           # unet_kernel: the whole TemporalUnet forward in one launch (all 25 convs + GN/Mish)
 HEADLINE_ROBOTS = 32               # BASELINE.json: 32-robot Empty map
 PROF_UNET, PROF_STEP_GUIDED, PROF_STEP_PLAIN, PROF_UNET_FUSED = 0, 1, 2, 3     # include/mmd_amd_debug.h
+HEADLINE_METRIC = "guided trajectories/sec (H=64, 100 denoise steps), 32-robot Empty map"
+
+
+def _baseline_configs():
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["configs"]
+    except Exception:      # noqa: BLE001  (the wording is then the table's own)
+        return [None] * 5
+
+
+_CFG = _baseline_configs()
+# the synthetic instances of SURVEY 8d (tests/test_gpu_configs.py holds each against the oracle at this size)
+WORKLOADS = {
+    "headline": dict(robots=32, env="EnvEmpty2D", formation=("circle", 0.8), inter_robot=True, label=None,
+                     ref="mmd/common/multi_agent_utils.py:146-154, env_empty_2d.py:25-54"),
+    "config2": dict(robots=6, env="EnvEmpty2D", formation=("circle", 0.8), inter_robot=False,
+                    label=_CFG[1] or "6-robot Empty circle map, no inter-robot term", ref="env_empty_2d.py:25-54"),
+    "config3": dict(robots=10, env="EnvHighways2D", formation=("circle", 0.45), inter_robot=True,
+                    label=_CFG[2] or "10-robot Highways map with inter-robot soft-constraint guidance",
+                    ref="env_highways_2d.py:38-103, mmd_experiment_configs.py:142-156"),
+    "config4": dict(robots=4, env="EnvEmptyNoWait2D", formation=("tiles_1x2",), inter_robot=False, ensemble=True,
+                    label=_CFG[3] or "MPDEnsemble multi_tile 1x2 Empty grid, 4 robots", ref="inference_multi_agent.py:418-431, mpd_ensemble.py:335-429"),
+    "config5": dict(robots=64, env="EnvConveyor2D", formation=("boundary",), inter_robot=True,
+                    label=_CFG[4] or "64-robot Conveyor map, per-robot batch sharded across 8 GPUs",
+                    ref="env_conveyor_2d.py:37-80, multi_agent_utils.py:157-173"),
+}
+
+
+def workload_starts_goals(w, n_robots):
+    from mmd_amd import synth
+    f = w["formation"]
+    if f[0] == "circle":
+        return synth.start_goal_circle(n_robots, f[1])
+    if f[0] == "boundary":
+        return synth.start_goal_boundary(n_robots)
+    raise ValueError(f)
 
 
 # unet_kernel runs at the package power limit (profiles/r03_power_probe.txt): a loop of nothing but v_mfma_f32_16x16x32_f16 at
@@ -127,7 +170,11 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N>1 headline: strong = the metric's 32-robot instance sharded 32/N robots per GPU; weak = 32 robots "
                          "per GPU of a 32N-robot instance (the other one is timed too and reported alongside)")
-    ap.add_argument("--robots-per-gpu", type=int, default=0, help="override (0 = 32/N for strong, 32 for weak)")
+    ap.add_argument("--workload", choices=tuple(WORKLOADS), default="headline",
+                    help="headline = BASELINE.json's metric (32-robot Empty map); config2..config5 = BASELINE.json's configs[1..4]")
+    ap.add_argument("--robots-per-gpu", type=int, default=0, help="override (0 = robots/N for strong, all robots per GPU for weak)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the dominant kernel that fill roofline.traffic")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,20 +198,23 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(T, B, n_robots, budget_s):
+def cpu_baseline(T, B, workload, budget_s):
     """The oracle's reference-SHAPED path (dense (n,B,H,2) CostConstraint broadcast + one autograd pass per cost term,
-    torch-CPU UNet) for ONE robot of the headline instance, timed on this host's cores on a bounded sample and
+    torch-CPU UNet) for ONE robot of the workload's instance, timed on this host's cores on a bounded sample and
     extrapolated to the full 101-step call.  Robots are planned sequentially by the reference, so trajectories/s of
     one robot's call is the whole-round rate.  The thread count is swept upwards from 8 (an oversubscribed pool is slower
     for these small tensors); the rest of the budget then goes into more steps at the best thread count (spread over the
     guided and the unguided half of the schedule), and that longer sample is what is reported."""
     import cases_for_bench as cb
     from oracle import mmd_oracle as O
-    sd, tb, gp, grp, hc = cb.oracle_headline_robot(T, n_robots)
+    w = WORKLOADS[workload]
+    n_robots = w["robots"]
+    sd, tb, gp, groups, hc = cb.oracle_workload_robot(w, T)
+    tiles = 2 if w.get("ensemble") else 1                         # the ensemble steps its K tile models one after the other
     x = torch.from_numpy(cb.synth.synth_noise(91, (B, H, D))) * 0.5
     x = O.apply_hard_conditioning(x, hc)
     noise = torch.from_numpy(cb.synth.synth_noise(92, (B, H, D)))
-    guide = lambda y: O.guide_grad_dense_autograd(y, gp, [grp])     # noqa: E731
+    guide = lambda y: O.guide_grad_dense_autograd(y, gp, groups)     # noqa: E731
     tsg = ceil(0.5 * T)
 
     def timed(i, g):
@@ -172,7 +222,7 @@ def cpu_baseline(T, B, n_robots, budget_s):
         with torch.no_grad():
             O.ddpm_sample_step(sd, tb, x.clone(), hc, i, guide=g, n_guide_steps=20, t_start_guide=tsg, noise=noise,
                                noise_std_extra=0.5)
-        return time.perf_counter() - t0
+        return (time.perf_counter() - t0) * tiles
 
     n_cpus = os.cpu_count() or 1
     # oversubscribed pools are catastrophically slow for these small tensors (256 threads: 100x slower than 8), so the
@@ -209,7 +259,10 @@ def cpu_baseline(T, B, n_robots, budget_s):
         est = best["est_seconds_per_robot_call"]
     return {"value": B / est, "unit": "trajectories/s", "cores": best["threads"], "kind": "port",
             "cpu_model": cpu_model_name(), "logical_cpus": n_cpus,
-            "sample": f"1 of {n_robots} robots (B={B}, {grp.q.shape[0]} soft-constraint points): {len(tg)} guided + {len(tu)} "
+            "running_beside": "the GPU power probe (a spinning launch loop + a 50 Hz sysfs sampler thread in the parent process) -- "
+                              "a few host threads of the box's cores; ADVICE r4",
+            "sample": f"1 of {n_robots} robots of the {workload} instance (B={B}, {sum(g.q.shape[0] for g in groups)} soft-constraint points"
+                      f"{', x 2 tile models per step' if tiles == 2 else ''}): {len(tg)} guided + {len(tu)} "
                       f"unguided DDPM steps at {best['threads']} threads (the best of a thread sweep that timed 2 + 2 steps per "
                       f"count), {sum(tg) + sum(tu):.1f} s of CPU work, extrapolated to the {n_guided}+{n_unguided}-step call "
                       f"(robots are sequential in the reference)",
@@ -252,21 +305,22 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     from mmd_amd.temporal_unet import TemporalUnet
 
     T, B = args.diffusion_steps, args.samples
+    W = WORKLOADS[args.workload]
     if args.robots_per_gpu:
         RPG = args.robots_per_gpu
     elif scaling == "strong":
-        if HEADLINE_ROBOTS % world:
-            raise SystemExit(f"--scaling strong needs {HEADLINE_ROBOTS} % gpus == 0")
-        RPG = HEADLINE_ROBOTS // world
+        if W["robots"] % world:
+            raise SystemExit(f"--scaling strong needs {W['robots']} % gpus == 0")
+        RPG = W["robots"] // world
     else:
-        RPG = HEADLINE_ROBOTS
+        RPG = W["robots"]
     n_robots = RPG * world
     unet = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=32, dim_mults=(1, 2, 4))
     unet.load_state_dict(synth.synth_unet_state_dict(0))
     model = GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True)
-    starts, goals = synth.start_goal_circle(n_robots, 0.8)
-    sampler = MultiRobotSampler(model, starts, goals, env_id="EnvEmpty2D", n_samples=B, rank=rank, world_size=world,
-                                device=dev)
+    starts, goals = workload_starts_goals(W, n_robots)
+    sampler = MultiRobotSampler(model, starts, goals, env_id=W["env"], n_samples=B, rank=rank, world_size=world,
+                                device=dev, inter_robot=W["inter_robot"])
     # round 0 input: straight-line paths stand in for "previous best paths" 
     paths_local = torch.from_numpy(synth.straight_line_paths(starts, goals, H)[sampler.robot0:sampler.robot0 + RPG]).to(dev)
 
@@ -301,11 +355,11 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     dt = timed_rounds(0)
     ms_per_step = dt / args.steps * 1e3
     value = args.steps * n_traj_local * world / dt
-    config = {"workload": f"{scaling}-scaling over {world} GPU(s): "
-                          f"{n_robots}-robot EnvEmpty2D circle r=0.8, {RPG} robots/GPU x B={B} samples, H=64, "
-                          f"T={T}+1 DDPM steps, 20 guide iterations on {ceil(0.5 * T) + 1} guided steps, "
-                          f"{n_robots - 1} x 63 soft-constraint points per robot",
-              "n_robots": n_robots, "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": H,
+    detail = (f"{scaling}-scaling over {world} GPU(s): {n_robots}-robot {W['env']} {' '.join(str(v) for v in W['formation'])}, "
+              f"{RPG} robots/GPU x B={B} samples, H=64, T={T}+1 DDPM steps, 20 guide iterations on {ceil(0.5 * T) + 1} guided steps, "
+              + (f"{n_robots - 1} x 63 soft-constraint points per robot" if W["inter_robot"] else "no inter-robot term"))
+    config = {"workload": detail if W["label"] is None else W["label"], "workload_detail": detail, "workload_key": args.workload,
+              "reference_shapes": W["ref"], "n_robots": n_robots, "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": H,
               "diffusion_steps": T, "trajectories_per_step": n_traj_local * world,
               "parallelism": f"robots sharded x{world}; 1 all-gather of [{RPG},64,2] fp32 per round" if world > 1
               else "single GPU", "noise": "in-kernel Philox4x32-10 keyed by global trajectory index",
@@ -423,6 +477,21 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc_ref = json.load(f)
+    # ---- HBM-side traffic of the dominant kernel, measured NOW: separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; the SQ
+    # instruction counters) over the two kernels alone at the sampler's launch size, outside the timed region, rank 0 at N = 1 only
+    weight_bytes = float(lib.mmd_unet_weight_bytes(unet.handle(T, dev)))
+    algo_bytes = 2.0 * 1024.0 * n_launch + weight_bytes            # 1 KiB in + 1 KiB out per trajectory, the weight pack once
+    pmc_live, pmc_log = (None, ["skipped (--no-pmc / N > 1 / rehearsal)"])
+    if rank == 0 and world == 1 and not rehearsal and not args.no_pmc:
+        pmc_live, pmc_log = measure_pmc(args.workload, n_launch, T)
+    traffic, traffic_src = None, None
+    u = (pmc_live or {}).get("UNET", {})
+    if "FETCH_SIZE" in u and "WRITE_SIZE" in u:
+        traffic = (2.0 * u["FETCH_SIZE"] + u["WRITE_SIZE"]) * 1024.0
+        traffic_src = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/pmc_kernels.py"
+    elif pmc_ref and pmc_ref.get("UNET", {}).get("FETCH_SIZE_KiB") and pmc_ref["UNET"].get("trajectories_per_launch") == n_launch:
+        traffic = (2.0 * pmc_ref["UNET"]["FETCH_SIZE_KiB"] + pmc_ref["UNET"]["WRITE_SIZE_KiB"]) * 1024.0
+        traffic_src = "NOT this run (the live passes failed: see pmc_log): the last committed passes, profiles/pmc_latest.json"
     roofline = {
         "bound": "mfma",
         "kernel": "unet_kernel<4>: whole TemporalUnet forward for 4 trajectories per workgroup (launches of <= 512 trajectories: unet_kernel<2>, two per workgroup; 12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; every conv a direct convolution as an fp16 two-piece split of fp32 (f16x2, 3 MFMAs per product, fp32 accumulate) on the fp16 matrix pipe; the unguided DDPM steps ride in its tail; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
@@ -436,10 +505,19 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
         "useful_frac_of_f16_pipe": flops_traj * n_traj_local * n_fwd / (PEAK_F16_MFMA_TFLOPS * 1e12) / (ms_per_step * 1e-3),
         "flops_per_trajectory_forward": {"algorithmic_direct_conv_fp32": flops_traj, "fp32_gemm_issued": mfma_traj,
                                          "fp16_mfma_issued": 3.0 * h_traj},
-        "traffic": None,
-        "traffic_note": "not measured by this run (PMC counters need rocprofv3 passes of their own); the last committed passes are "
-                        "under pmc_reference",
-        "pmc_reference": pmc_ref,
+        "traffic": traffic,
+        "traffic_unit": "bytes per launch of the dominant kernel (HBM / fabric side of the L2s)",
+        "traffic_definition": "(2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE tallies the 128-byte requests of wide coalesced "
+                              "reads at 64 bytes (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is taken as reported",
+        "traffic_source": traffic_src, "pmc_log": pmc_log,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "algorithmic_bytes_definition": f"{n_launch} trajectories x (1 KiB in + 1 KiB out) + the packed weight / parameter block once "
+                                        f"({weight_bytes / 1e6:.2f} MB: two fp16 pieces per weight, MFMA fragment order)",
+        "wasted_ratio": None if traffic is None else traffic / algo_bytes,
+        "wasted_note": "the weight block is fetched once per XCD L2 (8 x), not once per launch: the kernel keeps every activation on "
+                       "chip, so what exceeds the algorithmic bytes is the 8 L2s' copies of the weights",
+        "hbm_gbps_in_round": None if traffic is None else traffic * launches_round / (ms_per_step * 1e-3) / 1e9,
+        "pmc_live": pmc_live, "pmc_reference": pmc_ref,
         "bracketed_launches": bracketed,
         "whole_batch_single_launch": {"trajectories": n_traj_local, "launch_ms": solo_s * 1e3,
                                       "pipe_busy": busy_s * chunks / solo_s,
@@ -452,19 +530,162 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
                     "accumulators: ppt_pwr = package power tracker, *_thrm = thermal) while the whole-batch launch runs back to "
                     "back; frac_at_measured_clock = MFMA issue time at the sampled clock / launch time"},
     }
-    # second kernel: the fused DDPM-step + guide kernel, HBM roofline on its algorithmic bytes
+    # second kernel: the fused DDPM-step + guide kernel.  It moves 3 KiB per trajectory and step (0.4 % of the HBM roof):
+    # its bound is the VALU issue port -- a SIMD issues one wave64 VALU instruction per 4 cycles -- so the fraction reported is
+    # 4 cycles x wave-level VALU instructions per launch / (1024 SIMDs x launch cycles), alone (the PMC pass's own dispatches) and
+    # in the loop (pass-2 brackets: beside the other stream chunk's UNet launch, which shares the issue port).
     step_bytes = 3.0 * 1024.0 * n_launch                     # x read + eps read + x write per trajectory and step
-    guide = {"kernel": "ddpm_guide_kernel: posterior mean + 20 guide iterations (SDF gather, workspace walls, GP prior, 31 x 63 soft-constraint points) + noise + hard conditioning, one wave per trajectory",
-             "bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_launch": step_bytes,
-             "note": "algorithmic bytes = 3 KiB per trajectory and step; the kernel is bound by the latency of its 20 dependent guide iterations (VALU issue), not by HBM; launch times are pass-2 brackets"}
+    gq = (pmc_live or {}).get("GUIDE") or {}
+    insts = gq.get("SQ_INSTS_VALU") or ((pmc_ref or {}).get("GUIDE") or {}).get("SQ_INSTS_VALU")
+    insts_src = "this run's PMC pass" if gq.get("SQ_INSTS_VALU") else "profiles/pmc_latest.json (the live pass failed or was skipped)"
+    n_simd = 1024.0
+    sclk_hz = (power_timed or {}).get("sclk_mhz", SPEC_SCLK_MHZ) * 1e6
+
+    def valu_frac(seconds, hz):
+        return None if not (insts and seconds) else 4.0 * insts / (n_simd * seconds * hz)
+    guide = {"kernel": "ddpm_guide_kernel: posterior mean + 20 guide iterations (SDF gather, workspace walls, GP prior, soft-constraint slots) + noise + hard conditioning, one wave per trajectory",
+             "bound": "valu", "peak": 1.0, "unit": "fraction of the VALU issue slots (one wave64 instruction per SIMD and 4 cycles)",
+             "valu_instructions_per_launch": insts, "valu_instructions_source": insts_src, "trajectories_per_launch": n_launch,
+             "hbm": {"bytes_per_launch": step_bytes, "note": "3 KiB per trajectory and step: not what bounds it"},
+             "note": "20 dependent guide iterations of ~600 VALU instructions per wave; one wave per SIMD at 1024 trajectories per launch"}
+    if gq.get("SQ_BUSY_CYCLES") or gq.get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the launch's cycles
+        cyc = gq["GRBM_GUI_ACTIVE"] / 8.0 if gq.get("GRBM_GUI_ACTIVE") else None
+        guide["alone"] = {"launch_cycles": cyc, "frac": None if not (cyc and insts) else 4.0 * insts / (n_simd * cyc),
+                          "valu_busy_of_wave_cycles": (gq["SQ_ACTIVE_INST_VALU"] / gq["SQ_WAVE_CYCLES"]) if gq.get("SQ_ACTIVE_INST_VALU") and gq.get("SQ_WAVE_CYCLES") else None,
+                          "source": "this run's PMC pass over tools/pmc_kernels.py (the kernel with the GPU to itself)"}
     for name, iv in (("guided", iv_g), ("unguided", iv_p)):
         if iv:
             d = float(np.mean([b - a for a, b in iv]))
-            guide[name] = {"launch_ms": d * 1e3, "launches_timed": len(iv), "achieved": step_bytes / d / 1e9,
-                           "frac": step_bytes / d / 1e9 / PEAK_HBM_GBPS}
+            guide[name if name == "unguided" else "in_loop"] = {
+                "launch_ms": d * 1e3, "launches_timed": len(iv), "frac": valu_frac(d, sclk_hz) if name == "guided" else None,
+                "sclk_mhz_used": sclk_hz / 1e6, "hbm_gbps": step_bytes / d / 1e9,
+                "note": "pass-2 brackets: the launch runs beside the other stream chunk's UNet launch"}
+    guide["achieved"] = (guide.get("in_loop") or {}).get("frac")
+    guide["frac"] = guide["achieved"]
     if not iv_p:
         guide["unguided"] = {"fused": "steps without guidance run inside the tail of the unet_kernel launch that produces their eps (no step-kernel launch)"}
     return value, ms_per_step, config, roofline, (guide, cpu_result)
+
+
+PMC_PASSES = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE")
+
+
+def measure_pmc(workload, n_launch, T, timeout_s=150):
+    """rocprofv3 PMC passes over tools/pmc_kernels.py (the UNet forward and the guided step kernel alone, at the sampler's launch
+    size), each counter set in a run of its own with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Returns {kernel family: {counter: mean per dispatch}} + the log of what ran.
+    Best effort: a pass that fails or times out leaves its counters out."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, ["rocprofv3 not found"]
+    out, log = {}, []
+    base = tempfile.mkdtemp(prefix="mmd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", REPS="6")
+    for k, counters in enumerate(PMC_PASSES):
+        d = os.path.join(base, f"p{k}")
+        cmd = [exe, "--pmc", *counters.split(), "--kernel-trace", "-f", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+               os.path.join(ROOT, "tools", "pmc_kernels.py"), workload, str(n_launch), str(T)]
+        try:
+            p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd="/tmp", env=env, start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)                          # (exactly the group this call started)
+                p.communicate()
+                log.append(f"{counters}: timed out after {timeout_s} s")
+                continue
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                log.append(f"{counters}: rc {p.returncode}, {(err or b'').decode(errors='replace')[-200:]}")
+                continue
+            acc = {}
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    name = row.get("Kernel_Name", "")
+                    fam = "UNET" if "unet_kernel" in name else "GUIDE" if "ddpm_guide" in name else None
+                    if fam:
+                        acc.setdefault((fam, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+            for (fam, c), v in acc.items():
+                v = v[len(v) // 3:]                          # (drop the first launches: cold L2 / instruction cache)
+                out.setdefault(fam, {})[c] = sum(v) / len(v)
+                out[fam]["dispatches"] = len(v)
+            log.append(f"{counters}: ok")
+        except Exception as e:      # noqa: BLE001  (a profiling pass must never take the benchmark down)
+            log.append(f"{counters}: {type(e).__name__}: {e}")
+    shutil.rmtree(base, ignore_errors=True)
+    return out, log
+
+
+def run_ensemble(args, rank, world, dev):
+    """config4: the 4 robots of the 1x2 Empty-tile instance, each an MPDEnsemble planner (two tile models composed along the horizon,
+    cross-conditioned at the tile boundary every step, mpd_ensemble.py:335-429, diffusion_ensemble.py:55-106) called once per step --
+    the reference's own granularity: one planner per agent (inference_multi_agent.py:225-237), B = 64 samples a call, a trajectory =
+    2 x 64 support points.  A step = the four planner calls, selection included.  Multi-GPU: robots sharded (no exchange)."""
+    from mmd_amd import _lib, synth
+    from mmd_amd.planners import MPDEnsemble
+    T, B = args.diffusion_steps, args.samples
+    W = WORKLOADS["config4"]
+    if W["robots"] % world:
+        raise SystemExit(f"config4 needs {W['robots']} % gpus == 0")
+    RPG = W["robots"] // world
+    sd = synth.synth_unet_state_dict(0)
+    tr = {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])}
+    planners = []
+    for r in range(rank * RPG, (rank + 1) * RPG):
+        start, goal = torch.tensor([-0.7, -0.6 + 0.4 * r]), torch.tensor([2.7, 0.6 - 0.4 * r])
+        planners.append((MPDEnsemble(model_ids=("EnvEmptyNoWait2D-RobotPlanarDisk",) * 2, transforms=tr, planner_alg="mmd",
+                                     start_state_pos=start, goal_state_pos=goal, n_samples=B, model_state_dicts=[sd, sd],
+                                     model_args=dict(n_diffusion_steps=T), device=dev, seed=18 + r), start, goal))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def rounds(n):
+        out = None
+        for _ in range(n):
+            for p, start, goal in planners:
+                out = p(start, goal)
+        return out
+    rounds(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    out = rounds(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert out.trajs_iters.shape[-2] == 2 * H and torch.isfinite(out.trajs_iters[-1]).all()
+    ms = dt / args.steps * 1e3
+    n_traj = RPG * B * world
+    lib = _lib.load()
+    h_traj = lib.mmd_unet_f16x2_flops_per_trajectory()
+    issued = 3.0 * h_traj * RPG * B * 2 * (T + 1)                    # two tile forwards per composed trajectory and step
+    issue_ms = issued / (PEAK_F16_MFMA_TFLOPS * 1e12) * 1e3
+    detail = (f"{W['robots']} robots x B={B} samples on the 1x2 EnvEmptyNoWait2D tile grid (tile offset 2.0), one MPDEnsemble planner "
+              f"call per robot and step: K=2 tile models, T={T}+1 DDPM steps per tile, 20 guide iterations on {ceil(0.5 * T) + 1} guided "
+              f"steps, cross-conditioning of the tile boundary after every tile step, post-sampling selection; a trajectory = 128 support points")
+    config = {"workload": W["label"], "workload_detail": detail, "workload_key": "config4", "reference_shapes": W["ref"],
+              "n_robots": W["robots"], "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": 2 * H, "diffusion_steps": T,
+              "trajectories_per_step": n_traj, "parallelism": "single GPU" if world == 1 else f"robots sharded x{world}; no exchange",
+              "noise": "in-kernel Philox4x32-10", "weights": "random-init (numpy PCG64 seed 0), the same for both tiles"}
+    roofline = {"bound": "mfma", "kernel": "unet_kernel<2> (64-trajectory launches, one per tile and step)", "peak": PEAK_F16_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": issue_ms / ms, "achieved": issue_ms / ms * PEAK_F16_MFMA_TFLOPS,
+                "frac_definition": "fp16 MFMA FLOPs issued per step (3 per fp32 GEMM FLOP x 2 tiles x (T + 1) forwards x trajectories) / "
+                                   "2516.6 TFLOP/s / ms_per_step: 64-trajectory launches leave 7/8 of the CUs idle, the planner call is "
+                                   "latency bound (profiles/r04c_planner_call.txt)",
+                "mfma_issue_ms_per_round": issue_ms, "ms_per_step": ms, "unet_launches_per_round": RPG * 2 * (T + 1),
+                "trajectories_per_launch": B, "traffic": None,
+                "traffic_note": "PMC passes are wired for the sharded sampler's launches (tools/pmc_kernels.py); not collected for the planner-call workload"}
+    return n_traj * args.steps / dt, ms, config, roofline
 
 
 def throttle_snapshot():
@@ -489,7 +710,7 @@ def main():
     args = parse()
     if args.cpu_baseline_only:                              # (the subprocess of cpu_job below: host cores only)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        print(json.dumps(cpu_baseline(args.diffusion_steps, args.samples, HEADLINE_ROBOTS, args.cpu_budget_s)), flush=True)
+        print(json.dumps(cpu_baseline(args.diffusion_steps, args.samples, args.workload, args.cpu_budget_s)), flush=True)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
@@ -518,13 +739,18 @@ def main():
     def cpu_job():
         """The CPU baseline in a process of its own (host cores only), started when the GPU part's timed region is over."""
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--diffusion-steps", str(args.diffusion_steps),
-               "--samples", str(args.samples), "--cpu-budget-s", str(args.cpu_budget_s)]
+               "--samples", str(args.samples), "--cpu-budget-s", str(args.cpu_budget_s), "--workload", args.workload]
         return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
 
-    value, ms, config, roofline, (guide, cpu_result) = run_mode(args, args.scaling, rank, world, dev, rehearsal, with_roofline=True,
-                                                                cpu_job=cpu_job if want_cpu else None)
+    W = WORKLOADS[args.workload]
+    if W.get("ensemble"):
+        value, ms, config, roofline = run_ensemble(args, rank, world, dev)
+        guide, cpu_result = None, (cpu_job_result(cpu_job()) if want_cpu else None)
+    else:
+        value, ms, config, roofline, (guide, cpu_result) = run_mode(args, args.scaling, rank, world, dev, rehearsal, with_roofline=True,
+                                                                    cpu_job=cpu_job if want_cpu else None)
     out = {
-        "metric": "guided trajectories/sec (H=64, 100 denoise steps), 32-robot Empty map",
+        "metric": HEADLINE_METRIC if W["label"] is None else f"guided trajectories/sec (H=64, {args.diffusion_steps} denoise steps), {W['label']}",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None,
@@ -535,7 +761,7 @@ def main():
     }
     if rehearsal:
         out["rehearsal"] = "all ranks on ONE GPU over gloo (MMD_BENCH_REHEARSAL=1): exercises the N>1 code path, NOT a measurement"
-    if world > 1 and not args.no_second_scaling and not args.robots_per_gpu:
+    if world > 1 and not args.no_second_scaling and not args.robots_per_gpu and not W.get("ensemble"):
         other = "weak" if args.scaling == "strong" else "strong"
         v2, ms2, cfg2, _, _ = run_mode(args, other, rank, world, dev, rehearsal, with_roofline=False)
         out[f"{other}_scaling"] = {"value": v2, "unit": "trajectories/s", "ms_per_step": ms2, "scaling": other, "config": cfg2}

@@ -56,7 +56,7 @@ class MultiRobotSampler:
                  norm_mins=synth.NORM_MINS, norm_maxs=synth.NORM_MAXS, n_guide_steps=20,
                  start_guide_steps_fraction=0.5, n_diffusion_steps_without_noise=1,
                  weight_grad_cost_soft_constraints=2e-2, radius=VERTEX_CONSTRAINT_RADIUS, device="cuda", group=None,
-                 n_streams=0):
+                 n_streams=0, inter_robot=True):
         self.model = model
         self.n_robots = starts.shape[0]
         self.rank, self.world_size, self.group = rank, world_size, group
@@ -78,6 +78,9 @@ class MultiRobotSampler:
         self.n_extra = n_diffusion_steps_without_noise
         self.w_soft, self.radius = weight_grad_cost_soft_constraints, radius
         self.n_streams = n_streams      # mmd_sampler_desc.n_streams (0 = the library's choice: 2 chunks from 2048 trajectories)
+        # False: no inter-robot term (BASELINE config 2: every robot guided by the map, the workspace and the GP prior alone) --
+        # plan_round then needs no exchange step either
+        self.inter_robot = inter_robot
 
     def set_other_paths(self, paths_all):
         """paths_all [N,H,2] un-normalised best paths of ALL robots (this device) or None (no inter-robot term)."""
@@ -125,7 +128,7 @@ class MultiRobotSampler:
 
     def plan_round(self, paths_local, seed=None):
         """all-gather -> constraint table -> guided sampling -> new local best paths."""
-        paths_all = all_gather_paths(paths_local, self.world_size, self.group)
+        paths_all = all_gather_paths(paths_local, self.world_size, self.group) if self.inter_robot else None
         self.set_other_paths(paths_all)
         trajs = self.sample(seed=seed)
         return trajs, self.best_paths(trajs, paths_all)

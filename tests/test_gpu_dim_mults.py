@@ -19,9 +19,9 @@ NETS = (("d32_1248", 32, (1, 2, 4, 8)), ("d16_12", 16, (1, 2)), ("d8_1", 8, (1,)
 TOL_STEP = 1e-3
 
 
-def _unet(uid, dm, seed=0):
+def _unet(uid, dm, seed=0, layered=None):
     from mmd_amd.temporal_unet import TemporalUnet
-    u = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=uid, dim_mults=dm)
+    u = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=uid, dim_mults=dm, layered=layered)
     u.load_state_dict(synth.synth_unet_state_dict(seed, unet_input_dim=uid, dim_mults=dm))
     return u
 
@@ -45,17 +45,18 @@ def test_layered_unet_forward_golden(tag, uid, dm):
 
 def test_layered_path_equals_fused_kernel_on_option0(monkeypatch):
     """The two implementations share no device code: the fp32 layer-by-layer kernels forced onto the fused kernel's own
-    configuration (MMD_AMD_UNET_LAYERED=1, read when the device model is created) must give the fused kernel's output within its
+    configuration (TemporalUnet(layered=True); MMD_AMD_UNET_LAYERED=1 is the default for objects built while it is set) must give the fused kernel's output within its
     documented distance from the fp32 reference (2.4e-6 rel-L2, test_unet_forward_accuracy_against_fp64), at a batch that is not
     a multiple of the fused kernel's workgroup size."""
     n = 37
     x = (torch.from_numpy(synth.synth_noise(901, (n, H, D))) * 0.7).cuda()
-    fused = _unet(32, (1, 2, 4))
-    monkeypatch.setenv("MMD_AMD_UNET_LAYERED", "1")
-    layered = _unet(32, (1, 2, 4))
-    layered.handle(25, "cuda")                               # (the switch is read here: when the device model is created)
-    monkeypatch.delenv("MMD_AMD_UNET_LAYERED")
+    fused = _unet(32, (1, 2, 4), layered=False)
+    layered = _unet(32, (1, 2, 4), layered=True)              # (fixed per object; the environment switch is the default only)
+    layered.handle(25, "cuda")
+    monkeypatch.setenv("MMD_AMD_UNET_LAYERED", "1")           # ... and toggling it later does not move an existing object
     fused.handle(25, "cuda")
+    monkeypatch.delenv("MMD_AMD_UNET_LAYERED")
+    assert layered.handle(device="cuda").value != fused.handle(device="cuda").value
     for t in (0, 11, 24):
         err = rel_l2(layered(x, t).cpu(), fused(x, t).cpu())
         parity_log.record("layered_vs_fused", f"t{t}", None, err, bound=6e-6)
@@ -71,17 +72,15 @@ def test_layered_forward_bits_do_not_depend_on_the_batch(monkeypatch, dm):
     sample); the sum over the input channels is DEFINED as four interleaved partial sums combined in a fixed tree, so a trajectory's
     eps must not change by a bit with the size of the batch it sits in (n = 8: CT 1, n = 200: CT 2, n = 800: CT 4), and for option 0
     every size must agree with the fused kernel."""
-    monkeypatch.setenv("MMD_AMD_UNET_LAYERED", "1")
-    layered = _unet(32, dm)
+    layered = _unet(32, dm, layered=True)
     layered.handle(25, "cuda")
-    monkeypatch.delenv("MMD_AMD_UNET_LAYERED")
     x = (torch.from_numpy(synth.synth_noise(902, (800, H, D))) * 0.7).cuda()
     big = layered(x, 7)
     assert torch.isfinite(big).all()
     assert torch.equal(layered(x[:200].contiguous(), 7), big[:200])
     assert torch.equal(layered(x[600:608].contiguous(), 7), big[600:608])
     if dm == (1, 2, 4):
-        fused = _unet(32, dm)
+        fused = _unet(32, dm, layered=False)
         fused.handle(25, "cuda")
         err = rel_l2(big.cpu(), fused(x, 7).cpu())
         parity_log.record("layered_vs_fused", "n800_t7", None, err, bound=6e-6)
@@ -215,3 +214,24 @@ def test_option1_ddim_and_ensemble_paths_vs_oracle():
     for k in range(3):
         model.sample_step(y, hcd, T - 1 - k, guide=None, noise_std_extra_schedule_fn=lambda t: 0.5, noise=steps[k])
         assert torch.equal(y, chain[k + 1]), k
+
+
+@pytest.mark.parametrize("uid", [24, 40, 48, 56])
+def test_layered_unet_any_group_width_vs_oracle(uid):
+    """unet_input_dim 40 / 56 give GroupNorm groups of 5 / 7 (x 2^level) channels, which do not cut into the 16 .. 64
+    register tiles a workgroup's thread group takes (the launch then had 320 / 448 threads and failed); a thread now loops over its
+    thread group's tiles.  Every accepted width x 3 and 4 levels against the oracle's forward (pinned by g2 / g17), at the three
+    batch sizes that select 1, 2 and 4 output channels per thread -- the bits must not depend on the batch."""
+    from oracle import mmd_oracle as O
+    for dm in ((1, 2, 4), (1, 2, 4, 8)):
+        unet = _unet(uid, dm)
+        sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0, unet_input_dim=uid, dim_mults=dm))
+        x = torch.from_numpy(synth.synth_noise(905, (800, H, D))) * 0.7
+        big = unet(x.cuda(), 11)
+        assert torch.isfinite(big).all()
+        ref = O.unet_forward(sd, x[:6], torch.full((6,), 11, dtype=torch.long))
+        err = rel_l2(big[:6].cpu(), ref)
+        parity_log.record("layered_unet_group_widths", f"uid{uid}_levels{len(dm)}", None, err, bound=2e-5)
+        assert err < 2e-5, (uid, dm, err)
+        assert torch.equal(unet(x[:200].contiguous().cuda(), 11), big[:200])
+        assert torch.equal(unet(x[600:608].contiguous().cuda(), 11), big[600:608])
