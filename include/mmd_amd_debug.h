@@ -60,7 +60,7 @@ size_t mmd_unet_weight_bytes(mmd_unet_t unet);
 
 /* Decision trace of ONE guided ddpm_sample_fn step (sample_functions.py:40-107): mmd_ddpm_step on the one-wave step kernel with
  * the dump compiled in -- the same arithmetic, bit for bit, as every production launch shape -- which additionally writes
- *   mu_dev          [n_traj][64][4]  (optional) the posterior mean, hard rows pinned: the state the guide iterations start from
+ *   mu_dev          [n_traj][64][4]  (optional) the posterior mean as the first guide iteration sees it (hard rows are pinned after an iteration, not before the first)
  *   guide_chain_dev [n_guide_steps][n_traj][64][4]  the state after every guide iteration (before the step's noise)
  *   trace_dev       [n_guide_steps][n_traj][64][MMD_TRACE_WORDS] uint32: the discrete decisions of the iteration at that support
  *                   point, i.e. everything in GuideManagerTrajectoriesWithVelocity.forward that is not continuous in x:

@@ -349,7 +349,9 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
   float4 hv = v;
   const bool is_hard = hard_row(s.hard_rows, s.n_hard, hard, robot, t, hv);
   if constexpr (DUMP) {
-    if (s.mu_out) s.mu_out[idx] = is_hard ? hv : v;
+    // (the posterior mean as the first guide evaluation sees it: rows 0 / H - 1 are pinned AFTER every iteration, not before the
+    // first one -- guide_gradient_steps, sample_functions.py:89-107)
+    if (s.mu_out) s.mu_out[idx] = v;
   }
 
   if (s.do_guide) {

@@ -171,7 +171,7 @@ struct StepDev {
   // instantiation of the step kernel reads them): the discrete decisions of every guide iteration, MMD_TRACE_WORDS uint32 per
   // (iteration, trajectory, support point) at the guide_chain stride, and the state the iterations start from
   unsigned int* trace;
-  float4* mu_out;                    // optional [n_traj_total][H]: posterior mean (hard rows pinned) before the first iteration
+  float4* mu_out;                    // optional [n_traj_total][H]: posterior mean before the first iteration (hard rows not pinned yet)
 };
 
 int fill_guide(const mmd_guide_desc* d, GuideDev& g);

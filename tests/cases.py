@@ -222,3 +222,26 @@ def mean_z(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
     return 0.0 if se == 0 else float(abs(a.mean() - b.mean()) / se)
+
+
+# ---- g19: a network that denoises (the reference's TemporalUnet after a fixed number of Adam steps with the reference's loss) -----
+TRAINED_CASES = ("empty32", "highways")
+
+
+def trained_state_dict():
+    """key -> float32 ndarray in unet_param_spec order (tests/golden/g19_trained_unet.npz: data only)."""
+    from collections import OrderedDict
+    from mmd_amd.unet_spec import unet_param_spec
+    g = np.load(os.path.join(GOLDEN, "g19_trained_unet.npz"))
+    return OrderedDict((k, np.ascontiguousarray(g[k], dtype=np.float32)) for k in unet_param_spec())
+
+
+def trained_case(name):
+    """The two constraint cases of g19 (tools/make_golden.py::g19), T = 25: the 32-robot north-star shape (Empty, robot 5, 31 x 63
+    soft points, B = 4) and Highways robot 3 with soft + hard constraints (B = 8); noise seeds seed0 + 2 s (x_T), + 1 (steps)."""
+    if name == "empty32":
+        starts, goals = synth.start_goal_circle(32, 0.8)
+        paths = synth.straight_line_paths(starts, goals, H)
+        return dict(map="EnvEmpty2D", T=25, B=4, start=starts[5], goal=goals[5], cons=[soft_group(paths, 5)], seed0=400)
+    starts, goals, soft, hard = highways_case()
+    return dict(map="EnvHighways2D", T=25, B=8, start=starts[3], goal=goals[3], cons=[soft, hard], seed0=440)

@@ -6,7 +6,9 @@ write those decisions per guide iteration and support point; the oracle exposes 
 ones (guide_grad_forced).  Proven here:
   * the trace instantiation reproduces the production step bit for bit, whatever launch shape production picks;
   * on EVERY trajectory of a batch -- also those whose step differs from the oracle by more than the north-star 1e-3 -- the oracle
-    run on the kernel's decisions agrees with the kernel to 1e-4: the arithmetic is the reference's, what can differ is a branch;
+    run on the kernel's decisions agrees with the kernel up to the fp32 rounding of the two evaluations (each measured against the same
+    iterations in float64, decisions frozen: the 20 norm-clipped steps amplify rounding 5 .. 350 x): the arithmetic is the
+    reference's, what can differ is a branch;
   * where the step does differ by more than 1e-3 the first differing decision is located (iteration, kind, support point)."""
 from math import ceil
 
@@ -53,14 +55,15 @@ def test_trace_instantiation_equals_production_step_bitwise(B):
 
 def test_oracle_on_the_kernels_decisions_equals_the_kernel_on_every_trajectory():
     """16 + 16 trajectories of two Highways robots (soft constraints of nine other robots + one hard vertex constraint), guided
-    steps i = 12 (the first) and i = 3: per trajectory the plain oracle error, the oracle-on-kernel-decisions error (< 1e-4 for
-    ALL of them) and, where the two decision traces differ, where they first do."""
+    steps i = 12 (the first) and i = 3: per trajectory the plain oracle error, the oracle-on-kernel-decisions error and the fp32
+    rounding of both evaluations along the kernel's decision path (attribute_guided_step).  For ALL of them the oracle on the kernel's
+    decisions agrees with the kernel up to that rounding; where the plain error is larger the first differing decision is named."""
     import gpu_common as gc
     import parity_log
     B = 16
     model, guide, groups, hc, starts, goals = _highways(B)
     sd, tb, gp = O.state_dict_to_torch(synth.synth_unet_state_dict(0)), O.schedule_tables(25), cases.guide_params("EnvHighways2D")
-    n_diff = 0
+    n_diff, worst_ratio = 0, 0.0
     for i, seed in ((12, 310), (3, 312)):
         x = torch.from_numpy(synth.synth_noise(seed, (2 * B, H, D))) * 0.5
         for r in range(2):
@@ -71,27 +74,18 @@ def test_oracle_on_the_kernels_decisions_equals_the_kernel_on_every_trajectory()
             r = idx // B
             hcr = cases.hard_conds_for(starts[r], goals[r])
             slots = [O.slot_table(g).shape[0] for g in groups[r]]
-            hip_sets = gc.decode_trace(tr[:, idx], slots)
-            own = []
-
-            def own_guide(z, r=r):
-                own.append(O.guide_decisions(z, gp, groups[r]))
-                return O.guide_grad(z, gp, groups[r], clip_mode="always")
-            step = lambda gfn: O.apply_hard_conditioning(O.ddpm_sample_step(                                   # noqa: E731
-                sd, tb, x[idx:idx + 1].clone(), hcr, i, guide=gfn, n_guide_steps=20, t_start_guide=13, noise=nz[idx:idx + 1],
-                noise_std_extra=0.5), hcr)
-            ref = step(own_guide)
-            it = iter(hip_sets)
-            forced = step(lambda z, r=r: O.guide_grad_forced(z, gp, groups[r], next(it)))
-            err, ferr = rel_l2(y[idx:idx + 1], ref), rel_l2(y[idx:idx + 1], forced)
-            first = next(((k,) + d for k, d in ((k, gc.first_set_difference(a, b)) for k, (a, b) in enumerate(zip(hip_sets, own)))
-                          if d is not None), None)
+            a = gc.attribute_guided_step(y[idx:idx + 1], mu[idx:idx + 1], gchain[-1, idx:idx + 1], gc.decode_trace(tr[:, idx], slots),
+                                         x[idx:idx + 1], nz[idx:idx + 1], i, 13, sd, tb, gp, groups[r], hcr)
+            first, bound = a["first"], gc.rounding_bound(a)
             n_diff += first is not None
-            parity_log.record("oracle_on_kernel_decisions", f"i{i}_traj{idx}", i, ferr, bound=1e-4, plain_err=err,
+            parity_log.record("oracle_on_kernel_decisions", f"i{i}_traj{idx}", i, a["ferr"], bound=bound, plain_err=a["err"],
+                              fp32_rounding_oracle=a["d_o32"], fp32_rounding_kernel=a["d_hip"],
                               first_difference=None if first is None else f"iteration {first[0]}: {first[1]} at t={first[2]}")
-            assert ferr < 1e-4, (i, idx, err, ferr, first)
-            assert err < 1e-3 or first is not None, (i, idx, err, "over the tolerance with identical decisions")
-            # identical decisions at every iteration: the plain error is arithmetic only
+            assert a["ferr"] < bound, (i, idx, a)
+            # the kernel's own rounding along its path is of the size of the fp32 oracle's (rsq / fma contraction: within 10 x)
+            worst_ratio = max(worst_ratio, a["d_hip"] / max(a["d_o32"], 2e-6))
+            assert a["d_hip"] < 10.0 * max(a["d_o32"], 2e-6), (i, idx, a["d_hip"], a["d_o32"])
+            # identical decisions at every iteration: the plain error is arithmetic only, i.e. the same bound
             if first is None:
-                assert err < 1e-4, (i, idx, err)
-    print(f"{n_diff} of {4 * B} trajectory-steps take a different decision somewhere in their 20 iterations")
+                assert a["err"] < bound, (i, idx, a)
+    print(f"{n_diff} of {4 * B} trajectory-steps take a different decision somewhere in their 20 iterations; kernel / oracle fp32 rounding <= {worst_ratio:.1f}")

@@ -617,13 +617,15 @@ def test_hard_rows_and_ddim_x0_golden():
             sens = max(rel_l2(step(1e-6 * torch.randn(ref[k].shape, generator=gen)), base) for _ in range(16))
             bound = max(bound, 1.5 * cases.LIN * sens)
             n_ill += 1
-            # ... and WHY it is beyond 1e-3: per trajectory against the oracle, a step over the tolerance must be a branch flip (the
-            # kernel's decision trace differs from the oracle's, and the oracle on the kernel's decisions agrees with the kernel)
+            # ... and WHO is beyond 1e-3: per trajectory against the oracle evaluated on THIS host, the kernel's step is within the
+            # tolerance or a shown branch flip (the kernel's decision trace differs from the oracle's, and the oracle on the kernel's
+            # decisions agrees with the kernel).  Round 5 measured all four within 1e-3: the party that moved is the golden row --
+            # the reference run on the CPU that generated the fixture takes another branch than the same arithmetic on this host.
             nz = steps[k] if k < T else torch.zeros_like(steps[k])
             jd = gc.GuidedStepJudge(model, guide, ref[k].clone(), hcd, i, ceil(0.5 * T), 1, nz, y.cpu())
             verdicts = [jd.check("hard_rows_step_attribution", f"row{k + 1}_traj{j}", j, sd_o, tb_o, gp_o, [soft, hard], hc4, 3000 + j)[0]
                         for j in range(B)]
-            assert any(v.startswith("flip") for v in verdicts) and "sens" not in verdicts, verdicts
+            assert "sens" not in verdicts, verdicts
         parity_log.record("hard_rows_teacher_forced_step", f"row{k + 1}", i, err, sens=sens, bound=bound)
         assert err < bound, (k, i, err, sens)
     assert n_ill <= 1, n_ill                       # (25 of the 26 steps hold the plain 1e-3, measured <= 1.2e-5)

@@ -1,0 +1,108 @@
+"""-m gpu: parity on a network that DENOISES (golden g19).  Every fixture before g19 used random-init weights; on
+those the reference itself moves 0.13 .. 0.32 rel-L2 at the final row under a relative 1e-6 perturbation of its UNet output, and it
+was open whether that chaos is the guided sampler's or the random network's.  g19 = the reference's TemporalUnet trained for 2500
+Adam steps with the reference's own loss on synthetic collision-free trajectories (tools/make_golden.py::g19; eps-prediction MSE
+0.07 .. 0.11 on held-out data against ~1 at init), and the reference's guided chains run with it.  Measured: the reference's `sens`
+stays 2.5e-1 (32-robot Empty case) / 1.8e-2 (Highways) at the final row -- the chaos is the sampler's (20 norm-clipped guide
+iterations per step), not the network's.  Held here: every teacher-forced step of both chains within 1e-3 of the reference (or an
+attributed flip / fp32-rounding verdict), the chains under the chaos bound, and the matched-within-1e-3 fraction over 8 noise seeds
+RECORDED next to the reference's own (its perturbed self)."""
+import os
+from math import ceil
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmd_amd import synth                # noqa: E402
+from oracle import mmd_oracle as O       # noqa: E402
+import cases                             # noqa: E402
+import parity_log                        # noqa: E402
+from cases import GOLDEN, H, D, rel_l2   # noqa: E402
+
+
+def _model(T):
+    from mmd_amd.diffusion_model import GaussianDiffusionModel
+    from mmd_amd.temporal_unet import TemporalUnet
+    unet = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=32, dim_mults=(1, 2, 4))
+    unet.load_state_dict(cases.trained_state_dict())
+    return GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True)
+
+
+def test_trained_unet_forward_vs_oracle():
+    """The trained weights through the fused kernel: eps against the oracle's forward (pinned on these weights by the CPU test of the
+    g19 chains) on noised smooth trajectories, the regime the network was trained for."""
+    model = _model(25)
+    sd = O.state_dict_to_torch(cases.trained_state_dict())
+    x = torch.from_numpy(synth.synth_noise(460, (8, H, D))) * 0.4
+    for t in (0, 7, 24):
+        err = rel_l2(model.model(x.cuda(), t).cpu(), O.unet_forward(sd, x, torch.full((8,), t, dtype=torch.long)))
+        parity_log.record("trained_unet_forward", f"t{t}", None, err, bound=2e-5)
+        assert err < 2e-5, (t, err)
+
+
+@pytest.mark.parametrize("name", cases.TRAINED_CASES)
+def test_trained_network_teacher_forced_steps_and_chain(name):
+    import gpu_common as gc
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    g = np.load(os.path.join(GOLDEN, "g19_trained_chains.npz"))
+    case = cases.trained_case(name)
+    T, B, seed0, n_seeds = (int(v) for v in g[f"{name}.meta"])
+    model = _model(T)
+    guide = gc.hip_guide(case["map"], [case["cons"]])
+    hc = cases.hard_conds_for(case["start"], case["goal"])
+    hcd = {k: v.cuda() for k, v in hc.items()}
+    sd, tb, gp = O.state_dict_to_torch(cases.trained_state_dict()), O.schedule_tables(T), cases.guide_params(case["map"])
+    ref, sens = torch.from_numpy(g[f"{name}.chain"]), g[f"{name}.sens"]
+    steps = torch.from_numpy(synth.synth_noise(seed0 + 1, (T + 1, B, H, D)))
+    tsg = ceil(0.5 * T)
+    # ---- every step of the reference's chain, started from the reference's own state
+    verdicts = {}
+    for k in range(T + 1):
+        i = T - 1 - k
+        nz = steps[k] if i >= 0 else torch.zeros_like(steps[k])
+        y = ref[k].clone().cuda()
+        model.sample_step(y, hcd, i, guide=guide, n_guide_steps=20, t_start_guide=tsg, noise_std_extra_schedule_fn=lambda t: 0.5,
+                          noise=nz.cuda())
+        y = y.cpu()
+        if i >= tsg:
+            err = rel_l2(y, ref[k + 1])
+            parity_log.record("trained_teacher_forced_step", f"{name}_row{k + 1}", i, err, bound=2e-5)
+            assert err < 2e-5, (name, k, err)
+            continue
+        jd = gc.GuidedStepJudge(model, guide, ref[k].clone(), hcd, i, tsg, 1, nz, y)
+        for j in range(B):
+            v, e = jd.check("trained_teacher_forced_step", f"{name}_row{k + 1}_traj{j}", j, sd, tb, gp, case["cons"], hc, 5000 + 100 * k + j)
+            verdicts[v.split("@")[0].split(":")[0]] = verdicts.get(v.split("@")[0].split(":")[0], 0) + 1
+    print(f"{name}: guided trajectory-steps by verdict {verdicts}")
+    # ---- end to end, noise seed 0: the chaos bound of the random-init chains (tests/cases.py::chaos_bounds) on trained weights
+    xT = torch.from_numpy(synth.synth_noise(seed0, (B, H, D)))
+    chain = model.run_inference(None, hc, n_samples=B, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn, guide=guide,
+                                n_guide_steps=20, t_start_guide=tsg, noise_std_extra_schedule_fn=lambda t: 0.5,
+                                n_diffusion_steps_without_noise=1, warm_start_path_b=xT.cuda(), step_noise=steps.cuda()).cpu()
+    errs = [rel_l2(chain[r], ref[r]) for r in range(T + 2)]
+    n_unguided = T - tsg + 1
+    lin, bounds = cases.chaos_bounds(errs, list(sens), n_unguided)
+    for r in range(T + 2):
+        parity_log.record("trained_chain", f"{name}_row{r}", None, errs[r], sens=float(sens[r]), bound=bounds[r])
+        assert errs[r] < bounds[r], (name, r, errs[r], bounds[r])
+    assert max(errs[:n_unguided]) < 1e-3 and lin < cases.LIN
+    # ---- matched-within-1e-3 fraction over the 8 noise seeds (final rows), per trajectory
+    finals = torch.from_numpy(g[f"{name}.finals"])
+    matched, per = 0, []
+    for s in range(n_seeds):
+        xs = torch.from_numpy(synth.synth_noise(seed0 + 2 * s, (B, H, D)))
+        st = torch.from_numpy(synth.synth_noise(seed0 + 2 * s + 1, (T + 1, B, H, D)))
+        out = model.run_inference(None, hc, n_samples=B, horizon=H, return_chain=False, sample_fn=ddpm_sample_fn, guide=guide,
+                                  n_guide_steps=20, t_start_guide=tsg, noise_std_extra_schedule_fn=lambda t: 0.5,
+                                  n_diffusion_steps_without_noise=1, warm_start_path_b=xs.cuda(), step_noise=st.cuda()).cpu()
+        for j in range(B):
+            e = rel_l2(out[j], finals[s, j])
+            per.append(e)
+            matched += e < 1e-3
+    parity_log.record("trained_end_to_end_matched", name, None, float(np.median(per)), note=f"{matched} of {len(per)} trajectories within 1e-3 of the reference end to end; "
+                      f"median {np.median(per):.2e}, max {max(per):.2e}; the reference against its 1e-6-perturbed self at the final row: {sens[-1]:.2e}")
+    print(f"{name}: {matched} of {len(per)} trajectories within 1e-3 end to end (median {np.median(per):.2e}); reference self-sensitivity {sens[-1]:.2e}")
+    assert np.isfinite(per).all()

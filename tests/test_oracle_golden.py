@@ -331,3 +331,30 @@ def test_g18_hard_rows_and_ddim_x0_oracle():
                            predict_epsilon=False)
     assert chain0.shape == g["ddim_x0_chain"].shape and np.isfinite(g["ddim_x0_chain"]).all()
     assert max(rel_l2(chain0[k], g["ddim_x0_chain"][k]) for k in range(chain0.shape[0])) < 1e-4
+
+
+@pytest.mark.parametrize("name", cases.TRAINED_CASES)
+def test_g19_trained_network_oracle(name):
+    """The oracle with the TRAINED network's weights (g19: the reference's TemporalUnet after 2500 Adam steps of the reference's
+    loss -- held-out eps MSE 0.07 .. 0.11 against ~1 at random init) against the reference's guided chain: every unguided row within
+    1e-4, every guided row within the reference's own response to relative 1e-6 perturbations of eps (`sens`: still 2e-2 .. 2e-1 at
+    the final row -- the guided sampler is chaotic whatever the network)."""
+    g = np.load(os.path.join(GOLDEN, "g19_trained_chains.npz"))
+    case = cases.trained_case(name)
+    T, B, seed0, n_seeds = (int(v) for v in g[f"{name}.meta"])
+    assert (T, B, seed0) == (case["T"], case["B"], case["seed0"])
+    sd = O.state_dict_to_torch(cases.trained_state_dict())
+    tb = O.schedule_tables(T)
+    gp = cases.guide_params(case["map"])
+    xT = torch.from_numpy(synth.synth_noise(seed0, (B, H, D)))
+    steps = torch.from_numpy(synth.synth_noise(seed0 + 1, (T + 1, B, H, D)))
+    chain = O.p_sample_loop(sd, tb, xT, cases.hard_conds_for(case["start"], case["goal"]), T, steps,
+                            guide=lambda x: O.guide_grad(x, gp, case["cons"]), n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                            noise_std_extra=0.5, n_diffusion_steps_without_noise=1)
+    ref, sens = torch.from_numpy(g[f"{name}.chain"]), g[f"{name}.sens"]
+    n_unguided = T - ceil(0.5 * T) + 1
+    for r in range(T + 2):
+        err = rel_l2(chain[r], ref[r])
+        assert err < (1e-4 if r < n_unguided else max(1e-4, 1.5 * sens[r])), (name, r, err, sens[r])
+    # the network denoises: eps-prediction error on noised smooth trajectories well below the random-init level
+    assert float(g["heldout_eps_mse_t5_t12_t20"].max()) < 0.2

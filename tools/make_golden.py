@@ -21,6 +21,8 @@ Fixtures:
   g14_extra_objects.npz      a map with extra objects (spheres + boxes): guide, extra-objects-only guide, occupancy
   g16_options.npz            options the planners leave at their defaults: clip_grad_rule 'value' / clip_grad False, scale_grad_by_std,
                              predict_epsilon False
+  g19_trained_unet.npz / g19_trained_chains.npz   a TemporalUnet trained briefly with the reference's loss (it denoises), and
+                             the guided chains / sensitivities / multi-seed final rows of two constraint cases run with it
   g15_distribution_*.npz     guided sampling over 32 noise seeds: final rows of every sample, their position mean / covariance per
                              support point, free / collision split and soft-constraint violation counts (distribution-level parity)
 """
@@ -166,11 +168,11 @@ CHAIN_ROWS = lambda T: sorted({0, 1, 2, T // 2, T // 2 + 1, T // 2 + 2, T - 1, T
 
 
 def run_ref_inference(env_id, T, B, start, goal, cons, seed_xT, seed_steps, weights_seed=0, cutoff=0.05,
-                      n_guide_steps=20, use_guide=True, perturb=0.0, perturb_seed=0):
+                      n_guide_steps=20, use_guide=True, perturb=0.0, perturb_seed=0, sd=None):
     """`perturb` > 0 multiplies the reference UNet's output by (1 + perturb * N(0,1)) at every step: an fp32-rounding
     sized disturbance (a different summation order) used to MEASURE how well-conditioned the reference's own map
     noise -> trajectory is for this case (stored next to the golden rows as `sens`)."""
-    sd = synth.synth_unet_state_dict(weights_seed)
+    sd = synth.synth_unet_state_dict(weights_seed) if sd is None else sd
     with quiet():
         model = make_model(sd, T)
         guide, robot, task, env = make_guide(env_id, MINS, MAXS, cutoff_margin=cutoff)
@@ -810,11 +812,110 @@ def g18():
     print("   g18:", {k: v.shape for k, v in out.items()}, "ddpm final-row sens", f"{sens[-1]:.2e}")
 
 
+def synth_training_trajectories(n, seed):
+    """Synthetic collision-free demonstrations on the EMPTY map (there is no dataset offline): smooth-step motion from a
+    random start to a random goal plus two low-frequency sine modes that vanish at both ends, velocities by central differences
+    at dt = trajectory_duration / H (mpd.py:140), zero at the ends (the planners' hard conditions pin zero velocity,
+    trajectories.py:216-239).  Un-normalised [n, H, 4]; bit-reproducible (numpy PCG64)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    u = np.linspace(0.0, 1.0, H)
+    sm = 3 * u ** 2 - 2 * u ** 3
+    start = rng.uniform(-0.85, 0.85, size=(n, 2))
+    goal = rng.uniform(-0.85, 0.85, size=(n, 2))
+    pos = start[:, None, :] + (goal - start)[:, None, :] * sm[None, :, None]
+    for k in (1, 2):
+        a = rng.normal(0.0, 0.12 / k, size=(n, 1, 2))
+        pos = pos + a * np.sin(k * np.pi * u)[None, :, None]
+    pos = np.clip(pos, -0.95, 0.95)
+    vel = np.gradient(pos, 5.0 / H, axis=1)
+    vel[:, 0] = 0.0
+    vel[:, -1] = 0.0
+    return np.concatenate([pos, np.clip(vel, -1.5, 1.5)], axis=-1).astype(np.float32)
+
+
+def train_reference_unet(T=25, n_steps=2500, batch=64, lr=3e-4, n_data=4096):
+    """The reference's own training objective on the reference's own modules: GaussianDiffusionModel.loss -> p_losses
+    (diffusion_model_base.py:435-461: q_sample at a random t, hard conditioning, eps-prediction, l2) as
+    GaussianDiffusionLoss.loss_fn calls it (mmd/losses/gaussian_diffusion_loss.py:9-28), Adam as in mmd/trainer/trainer.py:119, from
+    the synthetic init (seed 0), fixed seeds.  No EMA (the trainer starts it at step 1000): a BRIEFLY trained network, enough to
+    denoise.  Returns the UNet state dict as {key: float32 ndarray} in unet_param_spec order."""
+    sd0 = synth.synth_unet_state_dict(0)
+    with quiet():
+        model = make_model(sd0, T)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    model.train()
+    data = torch.from_numpy(normalize(synth_training_trajectories(n_data, 190)).astype(np.float32))
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    gen = np.random.Generator(np.random.PCG64(191))
+    torch.manual_seed(192)
+    for step in range(n_steps):
+        idx = torch.from_numpy(gen.integers(0, n_data, size=batch))
+        x = data[idx]
+        hard = {0: x[:, 0].clone(), H - 1: x[:, -1].clone()}
+        loss, _ = model.loss(x, None, hard)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if step % 250 == 0 or step == n_steps - 1:
+            print(f"   g19 train step {step}: loss {float(loss.detach()):.4f}", flush=True)
+    model.eval()
+    out = {k[len("model."):]: v.detach().numpy().astype(np.float32).copy() for k, v in model.state_dict().items() if k.startswith("model.")}
+    assert list(out.keys()) == list(sd0.keys())
+    return out, float(loss.detach())
+
+
+def g19():
+    """A network that DENOISES: the reference's TemporalUnet trained for a fixed number of Adam steps with the
+    reference's loss on synthetic collision-free trajectories, then the guided chains of the two constraint cases whose random-init
+    versions are chaotic end to end -- the 32-robot north-star shape (Empty, robot 5, 31 x 63 soft points) and Highways with soft +
+    hard constraints -- at T = 25 (the released checkpoints' step count): the full chain of noise seed 0 with its `sens` rows
+    (the reference against itself under relative 1e-6 perturbations of the UNet output, N_SENS_DRAWS draws), and the final rows of
+    8 noise seeds for the matched-within-1e-3 fraction.  Data only: the state dict, the chains."""
+    T = 25
+    sd, final_loss = train_reference_unet(T)
+    np.savez_compressed(os.path.join(OUT, "g19_trained_unet.npz"), final_loss=np.float32(final_loss), **sd)
+    # how well it denoises: eps-prediction error on held-out synthetic trajectories at t = 5, 12, 20 (a random-init net: ~1)
+    with quiet():
+        model = make_model(sd, T)
+    held = torch.from_numpy(normalize(synth_training_trajectories(256, 193)).astype(np.float32))
+    out = {"T": np.array(T), "final_loss": np.float32(final_loss)}
+    mse = []
+    for t in (5, 12, 20):
+        z = torch.from_numpy(synth.synth_noise(194 + t, tuple(held.shape)))
+        tt = torch.full((held.shape[0],), t, dtype=torch.long)
+        with torch.no_grad():
+            xn = model.q_sample(held, tt, z)
+            mse.append(float(((model.model(xn, tt, None) - z) ** 2).mean()))
+    out["heldout_eps_mse_t5_t12_t20"] = np.array(mse, np.float32)
+    print("   g19 held-out eps MSE at t = 5 / 12 / 20:", mse, flush=True)
+    n_seeds = 8
+    starts32, goals32 = synth.start_goal_circle(32, 0.8)
+    q, tr, r = soft_points(synth.straight_line_paths(starts32, goals32, H), 5)
+    hs, hg, soft, hard = highways_case()
+    cases = {"empty32": ("EnvEmpty2D", 4, starts32[5], goals32[5], [(q, tr, r, True)], 400),
+             "highways": ("EnvHighways2D", 8, hs[3], hg[3], [(*soft, True), (*hard, False)], 440)}
+    for name, (env_id, B, st, go, cons, seed0) in cases.items():
+        chain = run_ref_inference(env_id, T, B, st, go, cons, seed0, seed0 + 1, sd=sd)
+        sens = np.zeros(chain.shape[0])
+        for ps in range(1, N_SENS_DRAWS + 1):
+            pert = run_ref_inference(env_id, T, B, st, go, cons, seed0, seed0 + 1, sd=sd, perturb=1e-6, perturb_seed=ps)
+            sens = np.maximum(sens, [rel_l2(pert[k], chain[k]) for k in range(chain.shape[0])])
+        finals = [chain[-1]]
+        for sdx in range(1, n_seeds):
+            finals.append(run_ref_inference(env_id, T, B, st, go, cons, seed0 + 2 * sdx, seed0 + 2 * sdx + 1, sd=sd)[-1])
+        out[f"{name}.chain"], out[f"{name}.sens"] = chain, sens
+        out[f"{name}.finals"] = np.stack(finals)                       # [n_seeds, B, H, D]; noise seeds seed0 + 2 s, + 1
+        out[f"{name}.meta"] = np.array([T, B, seed0, n_seeds])
+        print(f"   g19 {name}: final-row sens {sens[-1]:.2e}, max over rows {sens.max():.2e}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "g19_trained_chains.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17, "g18": g18}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17, "g18": g18, "g19": g19}[name]()
     print("done")

@@ -583,6 +583,179 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 constexpr int SAMPLES_PER_WG = 4;
+#elif defined(W8)
+// VERDICT r4 #1 / DESIGN 7.1a, the lever nobody had run: ONE 8-wave workgroup of 8 samples per CU instead of two 4-wave
+// workgroups of 4, a wave = (n-tile quad nq = wave & 1: channels 64 nq .. 64 nq + 63, sample pair sp = wave >> 1) with a register
+// tile of 4 n-tiles x 2 samples (the kernel: 2 x 4) -- half the A-fragment LDS reads per MFMA -- and the conv's weights staged
+// ONCE per workgroup into an LDS ring by LDS-DMA (global_load_lds_dwordx4), read from there by the four waves that share them.
+// -DW8=<mask>: 1 MFMAs, 2 A fragments from the LDS, 4 B fragments from the LDS stage, 8 epilogue, 16 slab store, 32 the conv's
+// two barriers, 64 the stage ring is really refilled (LDS-DMA + one barrier per W8_SB steps); without 64 the ring holds static
+// data: the loop's best case.  -DW8_SB=<1|2>: steps per refill barrier (ring = 2 W8_SB steps of 16 KB).
+// -DW8_RING=<n> (with bit 64): the stage is a ring of n single steps instead of two halves; the refill of step st + n - 1 is issued at
+// the top of step st (behind the step's barrier: every wave is past step st - 1, whose slot it takes) and a wave waits only for the
+// DMAs of the step it is about to read -- s_waitcnt vmcnt(2 (n - 2)): two fragments per wave and step stay in flight per younger
+// step -- so a fragment has n - 2 steps (~0.4 us each) to arrive instead of one refill group.
+#ifndef W8_SB
+#define W8_SB 2
+#endif
+#ifdef W8_RING
+#undef W8_SB
+#define W8_SB 1
+#endif
+struct Rd8 {                     // RdGeo<128> for EIGHT samples: [piece][lane group][chunk][row = 20 s + 2 + position][8 ch]
+  static constexpr int KC = 4, RPS = 20, BX = 8 * RPS * 16 + 32, G = (KC * BX + 255) / 256 * 256, PS = 4 * G, BYTES = 2 * PS;
+  static constexpr int tile_row(int m) { return m * RPS; }
+};
+constexpr int W8_STEP_BYTES = 8 * 2 * 1024;                    // one (tap, chunk) step of all 8 n-tiles, two pieces
+#ifdef W8_RING
+constexpr int W8_SLOTS = W8_RING;
+#else
+constexpr int W8_SLOTS = 2 * W8_SB;
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
+  const int nq = wave & 1, sp = wave >> 1;
+  char* const slab = reinterpret_cast<char*>(lds);
+  char* const stage = slab + Rd8::BYTES;
+  const char* const va = slab + g * Rd8::G + n * 16;
+  f32x4 acc[2][4];
+  for (int sm = 0; sm < 2; ++sm) for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) acc[sm][t][r] = 0.01f * ((threadIdx.x * 7 + sm * 3 + t + r + blockIdx.x) % 97) - 0.5f;
+  for (int i = threadIdx.x; i < Rd8::BYTES / 16; i += 512) reinterpret_cast<uint4*>(slab)[i] = make_uint4(0u, 0u, 0u, 0u);
+  // the stage: static pseudo-random fp16 content (all W8_SLOTS steps) unless it is refilled
+  for (int i = threadIdx.x; i < W8_SLOTS * W8_STEP_BYTES / 16; i += 512) reinterpret_cast<uint4*>(stage)[i] = p.w[i];
+  const int c0[2] = {64 * nq + 2 * n, 64 * nq + 32 + 2 * n};
+  __syncthreads();
+  // DMA of the fragments of steps [s0, s0 + W8_SB) into ring half `half`: 16 W8_SB fragments of 1 KiB dealt to the 8 waves
+  auto refill = [&](int s0, int half) {
+#pragma unroll
+    for (int i = 0; i < 2 * W8_SB; ++i) {
+      const int f = wave + 8 * i;                             // fragment within the W8_SB steps
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.w + ((size_t)s0 * 16 + f) * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)(stage + (half * W8_SB * 16 + f) * 1024), 16, 0, 0);
+    }
+  };
+  for (int k = 0; k < nconv; ++k) {
+    const Epi<2> e0 = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0[0]);
+    const Epi<2> e1 = epi_load<2>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0[1]);
+#ifdef W8_RING
+    auto refill1 = [&](int st) {                               // the 16 fragments of step st -> slot st % W8_RING
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = wave + 8 * i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.w + ((size_t)st * 16 + f) * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(stage + ((st % W8_RING) * 16 + f) * 1024), 16, 0, 0);
+      }
+    };
+    if (W8 & 64) {
+#pragma unroll
+      for (int st = 0; st < W8_RING - 1; ++st) refill1(st);
+    }
+#else
+    if (W8 & 64) refill(0, 0);
+#endif
+    if (W8 & 16) {
+      // the lane's channel pairs: tile pair tp of the quad = block 4 (2 nq + tp) + (n >> 2), rows of samples 2 sp, 2 sp + 1
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        char* const vs = slab + (2 * nq + tp) * Rd8::G + (n >> 2) * Rd8::BX + (2 * sp * Rd8::RPS + 2 + 4 * g) * 16 + (n & 3) * 4;
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const F16Pair f = f16_split2(acc[sm][2 * tp][r], acc[sm][2 * tp + 1][r]);
+            *reinterpret_cast<unsigned*>(vs + (sm * Rd8::RPS + r) * 16) = f.hi;
+            *reinterpret_cast<unsigned*>(vs + Rd8::PS + (sm * Rd8::RPS + r) * 16) = f.lo;
+          }
+      }
+    }
+#ifdef W8_RING
+    if (W8 & 64) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (W8_RING - 2)) : "memory");
+#else
+    if (W8 & 64) staged_weights_landed();
+#endif
+    if (W8 & 32) __syncthreads();
+    // ---- taps: 20 steps of 2 samples x 4 n-tiles x 3 MFMAs; A double-buffered by step from the slab, B by step from the stage
+    u32x4 a[2][2][2], b[2][4][2];
+    auto load_a = [&](int buf, int st) {
+      if (W8 & 2) rd_load_a<Rd8, 2>(a[buf], va, st / 4, st % 4, sp);
+    };
+    auto load_b = [&](int buf, int st) {
+      if (W8 & 4) {
+        const char* src = stage + (st % W8_SLOTS) * W8_STEP_BYTES + (4 * nq) * 2048 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) b[buf][t][q] = *reinterpret_cast<const u32x4*>(src + (2 * t + q) * 1024);
+      }
+    };
+    if (!(W8 & 2))
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 2; ++q) a[i][j][q] = u32x4{1u + i, 2u + j, 3u + q, 4u};
+    if (!(W8 & 4))
+      for (int i = 0; i < 2; ++i) for (int t = 0; t < 4; ++t) for (int q = 0; q < 2; ++q) b[i][t][q] = u32x4{5u + i, 6u + t, 7u + q, 8u};
+    load_a(0, 0);
+    load_b(0, 0);
+    MMD_PIN_LOADS();
+#pragma unroll
+    for (int st = 0; st < 20; ++st) {
+      const int cur = st & 1;
+#ifdef W8_RING
+      if (W8 & 64) {
+        if (st > 0) {
+          // step st's fragments (issued W8_RING - 1 steps ago) have landed: at most the W8_RING - 2 younger steps' stay in flight
+          if (st + W8_RING - 2 < 20) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (W8_RING - 2)) : "memory");
+          else staged_weights_landed();
+          __syncthreads();
+        }
+        if (st + W8_RING - 1 < 20) refill1(st + W8_RING - 1);
+      }
+      if (false) {
+#else
+      if ((W8 & 64) && st % W8_SB == 0) {
+#endif
+        // top of a refill group: this wave's DMA of the group has landed, every wave has landed its own and is past the previous
+        // group (barrier): the other ring half is free for the group after this one
+        if (st > 0) {
+          staged_weights_landed();
+          __syncthreads();
+        }
+        if (st + W8_SB < 20) refill(st + W8_SB, ((st / W8_SB) + 1) & 1);
+      }
+      load_a(cur ^ 1, st + 1 < 20 ? st + 1 : 19);
+      load_b(cur ^ 1, st + 1 < 20 ? st + 1 : 19);
+      MMD_PIN_LOADS();
+#pragma unroll
+      for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (W8 & 1) {
+            if (st == 0) vb_three<true>(acc[sm][t], a[cur][sm], b[cur][t]);
+            else vb_three<false>(acc[sm][t], a[cur][sm], b[cur][t]);
+          } else {
+            const unsigned x = a[cur][sm][0][0] ^ a[cur][sm][1][3] ^ b[cur][t][0][1] ^ b[cur][t][1][2];
+            acc[sm][t][0] += __builtin_bit_cast(float, (x & 0x007fffffu) | 0x3f800000u) * 1e-9f;
+          }
+        }
+    }
+    if (W8 & 8) {
+      const float one2[2] = {1.f, 1.f};
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const Epi<2>& e = tp ? e1 : e0;
+        f32x4 tile[2][2] = {{acc[0][2 * tp], acc[0][2 * tp + 1]}, {acc[1][2 * tp], acc[1][2 * tp + 1]}};
+        const float t0 = e.tb[0], t1 = e.tb[1];
+        rd_gn_mish<2, 256, true>(tile, e.b, e.g, e.be, e.is, one2, act_scale(1.f), [&](int, int t, int) { return t ? t1 : t0; });
+        acc[0][2 * tp] = tile[0][0]; acc[0][2 * tp + 1] = tile[0][1]; acc[1][2 * tp] = tile[1][0]; acc[1][2 * tp + 1] = tile[1][1];
+      }
+    }
+    if (W8 & 32) __syncthreads();
+  }
+  float s = 0.f;
+  for (int sm = 0; sm < 2; ++sm) for (int t = 0; t < 4; ++t) s += acc[sm][t][0] + acc[sm][t][3];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+constexpr int SAMPLES_PER_WG = 8;
+#define W8_LAUNCH 1
 #elif !defined(FAT)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
   __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
@@ -984,11 +1157,14 @@ int main() {
   std::vector<float> par(5 * 128);
   for (int i = 0; i < 128; ++i) { par[i] = 0.01f * (i % 7); par[128 + i] = 1.f + 0.01f * (i % 5); par[256 + i] = 0.02f * (i % 3); par[384 + i] = 0.05f; par[512 + i] = 1.f; }
   uint4* dw; float* dpar; float* dout;
-  hipMalloc(&dw, wbytes); hipMalloc(&dpar, par.size() * 4); hipMalloc(&dout, (size_t)nb * 256 * 4);
+  hipMalloc(&dw, wbytes); hipMalloc(&dpar, par.size() * 4); hipMalloc(&dout, (size_t)nb * 512 * 4);
   hipMemcpy(dw, hw.data(), wbytes, hipMemcpyHostToDevice); hipMemcpy(dpar, par.data(), par.size() * 4, hipMemcpyHostToDevice);
   ConvP p{dw, dpar};
 #ifdef FAT
   const size_t shm = 2 * G128::BYTES + 256;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_loop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+#elif defined(W8_LAUNCH)
+  const size_t shm = Rd8::BYTES + W8_SLOTS * W8_STEP_BYTES;
   hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_loop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
 #else
   const size_t shm = 0;
@@ -996,7 +1172,11 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
+#ifdef W8_LAUNCH
+    hipLaunchKernelGGL(conv_loop, dim3(nb), dim3(512), shm, 0, p, dout, nconv);
+#else
     hipLaunchKernelGGL(conv_loop, dim3(nb), dim3(256), shm, 0, p, dout, nconv);
+#endif
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<float> ho(8); hipMemcpy(ho.data(), dout, 32, hipMemcpyDeviceToHost);
