@@ -34,6 +34,8 @@ constexpr int kMaxChunks = 4;
 // environment.  MMD_AMD_NO_FUSED_STEP=1: unguided steps run as step-kernel launches instead of inside the UNet launch's tail
 // (A/B of the fused step).  MMD_AMD_STREAMS=<n>: overrides mmd_sampler_desc.n_streams (tools/gpu_streams.sh).
 static const bool kEnvNoFusedStep = [] { const char* e = getenv("MMD_AMD_NO_FUSED_STEP"); return e && atoi(e) != 0; }();
+// MMD_AMD_PERSIST=0: the leading run of unguided steps goes launch by launch again (A/B of the persistent run, unet.hip)
+static const bool kEnvPersist = [] { const char* e = getenv("MMD_AMD_PERSIST"); return !e || atoi(e) != 0; }();
 static const int kEnvStreams = [] {
   const char* e = getenv("MMD_AMD_STREAMS");
   return e ? atoi(e) : 0;
@@ -188,6 +190,37 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   launch_init(x_dev, chain_dev, hard_dev, s->hard_rows, init_noise, (unsigned long long)seed,
               (long long)s->traj_index_base, n, samples_per_robot, st);
 
+  // The leading run of steps WITHOUT guidance (i >= t_start_guide; every step of a prior-only call) as persistent launches on the
+  // caller's stream: a workgroup iterates the run's steps on its own trajectories (unet.hip: unet_persist_kernel), <= 64 steps a
+  // launch.  Bitwise the launch-per-step result.  Not with a profiler attached (its brackets are per launch).
+  int k_start = 0;
+  if (kEnvPersist && !kEnvNoFusedStep && unet_fused_step_supported(unet) && !s->profiler) {
+    FusedStep run[PERSIST_MAX_STEPS];
+    int i = n_steps - 1, k0 = 0;
+    while (i >= -n_steps_without_noise) {
+      int m = 0;
+      for (; m < PERSIST_MAX_STEPS && i - m >= -n_steps_without_noise; ++m) {
+        StepDev sd{};
+        if (int rc = make_step(s, i - m, guide != nullptr, sd)) return rc;
+        if (sd.do_guide) break;
+        FusedStep& fs = run[m];
+        fs = FusedStep{};
+        fs.enabled = 1;
+        fs.a_t = sd.a_t; fs.b_t = sd.b_t; fs.c1 = sd.c1; fs.c2 = sd.c2; fs.sigma = sd.sigma; fs.noise_std_extra = sd.noise_std_extra;
+        fs.do_noise = sd.do_noise; fs.hard_rows = sd.hard_rows; fs.n_hard = sd.n_hard; fs.seed = seed; fs.draw = (unsigned int)(k0 + m);
+        fs.traj_base = sd.traj_base; fs.traj0 = 0; fs.spr = samples_per_robot;
+        fs.x = reinterpret_cast<float4*>(x_dev);
+        fs.noise = step_noise_dev ? reinterpret_cast<const float4*>(step_noise_dev + (size_t)(k0 + m) * traj_floats) : nullptr;
+        fs.chain = chain_dev ? reinterpret_cast<float4*>(chain_dev + (size_t)(k0 + m + 1) * traj_floats) : nullptr;
+        fs.hard = reinterpret_cast<const float4*>(hard_dev);
+        fs.t_row = i - m < 0 ? 0 : i - m;
+      }
+      if (m == 0 || (m < 2 && k0 == 0)) break;              // (a single step gains nothing over the fused launch)
+      if (int rc = unet_persist_steps(unet, n, workspace_dev, mmd_unet_workspace_bytes(unet, n), st, run, m)) return rc;
+      k0 += m; i -= m;
+    }
+    k_start = k0;
+  }
   // Split the robots into concurrent chunks: each chunk's kernels go to its own stream, launches interleaved layer by
   // layer so both queues stay fed.  Robots are independent and the noise is keyed by the global trajectory index, so
   // results are bit-identical to the unsplit run.
@@ -208,8 +241,8 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
     MMD_HIP_CHECK(hipEventRecord(S->fork, st));
     for (int c = 0; c < nch; ++c) MMD_HIP_CHECK(hipStreamWaitEvent(cs[c], S->fork, 0));
   }
-  int rc = 0, k = 0;
-  for (int i = n_steps - 1; i >= -n_steps_without_noise && rc == 0; --i, ++k) {
+  int rc = 0, k = k_start;                                  // (the loop resumes behind the persistent run)
+  for (int i = n_steps - 1 - k_start; i >= -n_steps_without_noise && rc == 0; --i, ++k) {
     StepDev sd{};
     if ((rc = make_step(s, i, guide != nullptr, sd))) break;
     sd.seed = seed; sd.draw = (unsigned int)k;

@@ -139,7 +139,16 @@ struct FusedStep {
   const float4* noise;
   float4* chain;
   const float4* hard;
+  int t_row;              // persistent run only: the step's row of the time table (t = max(i, 0))
 };
+
+// A persistent run of unguided steps (unet.hip: unet_persist_kernel): one complete FusedStep per step (schedule coefficients, Philox
+// draw index, the step's noise / chain rows, row t of the time table) in a table at the start of the sampler workspace, the run's
+// kernel-argument block behind it.
+constexpr int PERSIST_MAX_STEPS = 64;
+constexpr int PERSIST_ARGS_OFF = 8192;
+constexpr int PERSIST_TABLE_BYTES = 12288;
+static_assert(PERSIST_MAX_STEPS * sizeof(FusedStep) <= PERSIST_ARGS_OFF, "the step table fits its workspace region");
 
 // apply_hard_conditioning (sample_functions.py:8-14: x[:, t, :] = val for every (t, val) of the hard_conds dict): bit t of `rows` set =
 // support point t of every trajectory of a robot is pinned to hard[robot][slot], slot = number of pinned rows below t (the dict's
@@ -179,6 +188,7 @@ int fill_guide(const mmd_guide_desc* d, GuideDev& g);
 bool unet_fused_step_supported(mmd_unet_t u);
 int unet_forward_fused(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, ::mmd_profiler_s* prof,
                        hipStream_t st, const FusedStep& fs);
+int unet_persist_steps(mmd_unet_t u, int n, void* ws, size_t ws_bytes, hipStream_t st, const FusedStep* steps, int n_steps);
 int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
                 const float* hard, int traj0, int n_traj, int spr, hipStream_t st);
 int launch_init(float* x, float* chain, const float* hard, unsigned long long hard_rows, int draw, unsigned long long seed,

@@ -205,6 +205,14 @@ __device__ unsigned long long* g_trace = nullptr;
 #define TR(tag) do { } while (0)
 #endif
 
+// The thread index through an opaque copy, for addresses that depend on nothing but the thread: inside the persistent kernel's step
+// loop they are loop invariant, and hoisted out of the loop they were kept -- spilled to scratch -- across the whole forward (a
+// reload waits for every weight load in flight).  Recomputing them where they are used costs a few VALU instructions.
+__device__ __forceinline__ int opaque_tid() {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  return tid;
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {   // v + v[DPP-permuted lane] in one VALU op
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -362,7 +370,7 @@ template <int C> struct RlGeo {
 template <class GEO>
 __device__ __forceinline__ void rd_zero_halo(char* slab) {
   constexpr int TOT = 2 * 4 * GEO::KC * 4 * 4;               // pieces x lane groups x chunks x samples x halo rows, 16 B each
-  for (int idx = threadIdx.x; idx < TOT; idx += 256) {
+  for (int idx = opaque_tid(); idx < TOT; idx += 256) {
     const int hr = idx & 3, sm = (idx >> 2) & 3, blk = (idx >> 4) % (4 * GEO::KC), q = idx / (64 * GEO::KC);
     *reinterpret_cast<uint4*>(slab + q * GEO::PS + (blk / GEO::KC) * GEO::G + (blk % GEO::KC) * GEO::BX +
                               (sm * GEO::RPS + (hr < 2 ? hr : GEO::RPS - 4 + hr)) * 16) = make_uint4(0u, 0u, 0u, 0u);
@@ -597,9 +605,10 @@ __device__ __forceinline__ void rowform_to_rd(const float* xslab, char* slab, co
   using GEO = RdGeo<C>;
   constexpr int CP2 = C / 2, ITEMS = 16 * NS * CP2;          // (sample, position) x channel pairs
   static_assert(ITEMS % 256 == 0 && XSTR % 2 == 0, "items per thread; 8-byte aligned channel pairs");
+  const int tid = opaque_tid();
 #pragma unroll
   for (int it = 0; it < ITEMS / 256; ++it) {
-    const int idx = it * 256 + threadIdx.x;
+    const int idx = it * 256 + tid;
     const int cp = idx % CP2, sp = idx / CP2, sm = sp >> 4, pos = sp & 15;
     const float sc = dyn_scale(mx_read(mx, sm)).s;
     const float2 t = *reinterpret_cast<const float2*>(xslab + sm * XSS + (2 + pos) * XSTR + 2 * cp);
@@ -828,7 +837,7 @@ __device__ __forceinline__ void wave_lds_fence() {           // a wave's own LDS
 // The stage's output goes straight into the next stage's input slab (RlGeo<32>) as f16 pieces under the sample's own dynamic
 // scale, behind a workgroup barrier (it aliases the waves' slabs); the sample's maximum goes to mx.
 template <class CF, int NS>
-__device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb) {
+__device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb, int tb_off = 0) {
   static_assert(CF::L == 64 && CF::CM == 32 && CF::C0 == 4 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
                     CF::TAIL == TAIL_DOWN, "downs.0");
   using GW = RwGeo<32, 64>;
@@ -866,7 +875,7 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
   }
   wave_lds_fence();
   f32x4 acc[4][2], res[4][2];
-  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
+  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb + tb_off, a.r0.isa, c0);
   const float br0[2] = {a.br[c0], a.br[c0 + 1]}, isr0[2] = {a.isr[c0], a.isr[c0 + 1]};
   // ---- RTB 0 conv A (im2col chunk) + the 1x1 residual conv
   {
@@ -946,7 +955,7 @@ __device__ __forceinline__ void chain_body_d0w(const ChainArgs& a, float* lds, i
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
-    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
     conv(R.wa_bf);
     preload(R.wb_bf);
     gn(std::true_type{}, ea, ds.inv, R.act_a);
@@ -1037,7 +1046,7 @@ constexpr int WBUF_BYTES = 20 * 1024;                        // the largest stag
 // whose barrier also orders the next slab store behind the partner's taps), dynamic scales take the sample's maximum from the
 // two waves' partials in mx.  Per-sample arithmetic is that of chain_body_d0w: bitwise equal results.
 template <class CF>
-__device__ __forceinline__ void chain_body_d0s(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb) {
+__device__ __forceinline__ void chain_body_d0s(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb, int tb_off = 0) {
   static_assert(CF::L == 64 && CF::CM == 32 && CF::C0 == 4 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
                     CF::TAIL == TAIL_DOWN, "downs.0");
   using GW = RwGeo<32, 64>;
@@ -1091,7 +1100,7 @@ __device__ __forceinline__ void chain_body_d0s(const ChainArgs& a, float* lds, i
     }
   }
   f32x4 acc[2][2], res[2][2];
-  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
+  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb + tb_off, a.r0.isa, c0);
   const float br0[2] = {a.br[c0], a.br[c0 + 1]}, isr0[2] = {a.isr[c0], a.isr[c0 + 1]};
   u32x4 b0[2][2], br[2][2];
 #pragma unroll
@@ -1172,7 +1181,7 @@ __device__ __forceinline__ void chain_body_d0s(const ChainArgs& a, float* lds, i
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
-    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
     conv(wb1, F5{}, R.wb_bf, wb0, trb + 6);
     TR(trb + 10);
     gn(std::true_type{}, ea, ds.inv, R.act_a);
@@ -1235,7 +1244,7 @@ __device__ __forceinline__ void chain_body_d0s(const ChainArgs& a, float* lds, i
 // (Stride2) and writes downs.2's row-form fp32 x slab (CFN geometry) + the per-sample maxima to mx.
 // skip: the stage's skip tensor (output of its second RTB) in the acc layout.
 template <class CF, class CFN, int NS>
-__device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&skip)[NS][2], int trb) {
+__device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&skip)[NS][2], int trb, int tb_off = 0) {
   static_assert(CF::L == 32 && CF::CM == 64 && CF::C0 == 32 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
                     CF::MID_AFTER == 1 && CF::TAIL == TAIL_DOWN, "downs.1");
   using GI = RlGeo<32>;
@@ -1332,7 +1341,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     const u32x4* wpa[2] = {wptr(a.r0.wa_bf, GI::FRAGS5, 0), wptr(a.r0.wa_bf, GI::FRAGS5, 1)};
     const u32x4* wpr[2] = {wptr(a.wres_bf, 2 * GI::KC, 0), wptr(a.wres_bf, 2 * GI::KC, 1)};
     rd_ring_load<GI, 2, 5>(ring5, wpa);
-    const Epi<2> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
+    const Epi<2> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb + tb_off, a.r0.isa);
     const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
     __syncthreads();                                         // downs.0's tail has written the input slab and its maxima
     TR(trb + 0);
@@ -1365,7 +1374,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     __syncthreads();                                         // the previous conv is done reading the slab
     float inv[SW];
     scale_in(inv);
-    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
     conv(R.wa_bf);
     gn(std::true_type{}, ea, inv, R.act_a);
     TR(trb + 3);
@@ -1430,7 +1439,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
 // run (the kernel sits at the 256-register limit of two waves per SIMD; a compiler spill to scratch costs a vmcnt(0) wait
 // behind every weight load in flight).  Parts 0 .. 4 in the stage's dead x slab, 5 .. 7 behind the maxima.
 __device__ __forceinline__ float* park_slot(float* lds, int i) {
-  return (i < 5 ? lds + i * 1024 : lds + PARK2_OFF + (i - 5) * 1024) + threadIdx.x * 4;
+  return (i < 5 ? lds + i * 1024 : lds + PARK2_OFF + (i - 5) * 1024) + opaque_tid() * 4;
 }
 template <int NS>
 __device__ __forceinline__ void park_tile(float* lds, const f32x4 (&t)[NS][2]) {
@@ -1445,7 +1454,7 @@ __device__ __forceinline__ void unpark_tile(float* lds, f32x4 (&t)[NS][2]) {
 
 template <class CF, int NS>
 __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&acc)[NS][2],
-                                               f32x4 (&mid)[NS][2], int trb) {
+                                               f32x4 (&mid)[NS][2], int trb, int tb_off = 0) {
   static_assert(CF::L == 16 && CF::CM == 128 && CF::C0 == 64 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_NONE &&
                     CF::MID_AFTER >= 1, "downs.2 + mid blocks");
   using G128 = RdGeo<128>;
@@ -1508,7 +1517,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 #pragma unroll
   for (int sm = 0; sm < NS; ++sm) inv_in[sm] = dyn_scale(mx_read(mx, sm)).inv;
   rd_zero_halo<G64>(slab);
-  const Epi<2> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
+  const Epi<2> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb + tb_off, a.r0.isa);
   const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
   rowform_to_rd<CF::C0P, CF::XSS, CF::XSTR, NS>(lds, slab, mx);
   __syncthreads();
@@ -1546,7 +1555,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[sm][t] *= ds.s;
     }
-    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
     conv(R.wa_bf);
     gn(std::true_type{}, ea, inv, R.act_a);
     __syncthreads();
@@ -1571,7 +1580,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 template <class CF, int NS, class STORE2>
 __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, int lane, int wave, f32x4 (&x0)[NS][2],
                                                f32x4 (&x1)[NS][2], STORE2 store2, char* slab128, f32x4 (&xe)[NS][1],
-                                               f32x4 (&xo)[NS][1], int trb) {
+                                               f32x4 (&xo)[NS][1], int trb, int tb_off = 0) {
   static_assert(CF::L == 16 && CF::CM == 64 && CF::C0 == 128 && CF::C1 == 128 && CF::RES0 == RES_CONV && CF::TAIL == TAIL_UP &&
                     CF::N_IDENT == 1, "ups.0");
   using G128 = RdGeo<128>;
@@ -1642,7 +1651,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
       x1[sm][t] *= ds.s;
     }
   }
-  const Epi<1> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa);
+  const Epi<1> e0a = epi(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb + tb_off, a.r0.isa);
   const float br = a.br[col], isr = a.isr[col];
   store2(x0);
   TR(160);
@@ -1679,7 +1688,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     __syncthreads();                                         // the previous conv is done reading the slab
     float inv[NS];
     dyn_scale_acc(inv);
-    const Epi<1> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    const Epi<1> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
     conv64(R.wa_bf);
     gn(std::true_type{}, ea, inv, R.act_a);
     TR(trb + 5);
@@ -1734,7 +1743,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 template <class CF, int NS>
 __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalArgs& f, const FusedStep& fs, float* lds, int n0, int lane_in, int wave,
                                                const f32x4 (&xe)[NS][1], const f32x4 (&xo)[NS][1], const f32x4 (&skip)[NS][2],
-                                               int trb) {
+                                               int trb, int tb_off = 0) {
   // (an opaque copy of the lane index: the stage's lane-derived offsets are recomputed here -- a handful of VALU ops -- instead
   // of being kept alive, i.e. spilled, since the stages that happen to use the same products)
   int lane = lane_in;
@@ -1842,7 +1851,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
   }
   __syncthreads();
   TR(trb + 10);
-  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
+  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb + tb_off, a.r0.isa, c0);
   const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
   rd_taps<GA, 2, 0, 5, false, true, 2, RDA>(acc, res, vaA, wp1, wr1, ring);
   TR(trb + 11);
@@ -1901,7 +1910,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[mt][t] *= ds.s;
-    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
     conv(R.wa_bf);
     preload(R.wb_bf);
     gn(std::true_type{}, ea, ds.inv, R.act_a);
@@ -2025,7 +2034,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
 // chain_body_u1w.  Bitwise equal results.
 template <class CF>
 __device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalArgs& f, const FusedStep& fs, float* lds, int n0, int lane_in, int wave,
-                                               const f32x4 (&xe)[2][1], const f32x4 (&xo)[2][1], const f32x4 (&skip)[2][2], int trb) {
+                                               const f32x4 (&xe)[2][1], const f32x4 (&xo)[2][1], const f32x4 (&skip)[2][2], int trb, int tb_off = 0) {
   int lane = lane_in;
   asm volatile("" : "+v"(lane));
   static_assert(CF::L == 32 && CF::CM == 32 && CF::C0 == 64 && CF::C1 == 64 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
@@ -2132,7 +2141,7 @@ __device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalAr
   }
   __syncthreads();
   TR(trb + 10);
-  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb, a.r0.isa, c0);
+  const Epi<2> e0a = epi_load<2>(a.r0.ba, a.r0.ga, a.r0.bea, a.r0.tb + tb_off, a.r0.isa, c0);
   const float br[2] = {a.br[c0], a.br[c0 + 1]}, isr[2] = {a.isr[c0], a.isr[c0 + 1]};
   rd_taps<GA, 2, 0, 5, false, true, 1, RDA>(acc, res, vaA, wp1, wr1, ring);
   TR(trb + 11);
@@ -2183,7 +2192,7 @@ __device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalAr
     const DynScale ds = dyn_scale(sample_max(rw_absmax<1, 2>(acc)));
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc[0][t] *= ds.s;
-    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb, R.isa);
+    const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
     conv(wb1, [&] { stage_weights<2 * GB::FRAGS5>(R.wb_bf, wb0, wave, lane); });
     gn(std::true_type{}, ea, ds.inv, R.act_a);
     TR(trb + 3);
@@ -2322,23 +2331,20 @@ static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SP
 // while the stages whose waves ARE samples (downs.0, ups.1 + final block) keep their form with samples 2, 3 fed zeros and
 // never stored.  Per-sample arithmetic is the same
 // instruction sequence either way: the results are bitwise equal.
+// tb_off: added to every RTB's time-bias pointer (floats) -- 0 in unet_kernel, whose host side bakes the step's row of the time
+// table into the pointers; t * tb_total in the persistent kernel, whose pointers are those of row 0
 template <int NS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel(UnetArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n0 = blockIdx.x * NS;
-
+__device__ __forceinline__ void unet_forward_body(const UnetArgs& a, const FusedStep& fs, int tb_off, float* lds, int n0, int lane, int wave) {
   f32x4 skip1[NS][2], skip2[NS][2];
   // ---- downs.0 @ L=64 -> [4][32][32]: wave = sample, direct f16x2 convs on the wave's own slab (chain_body_d0w)
-  if constexpr (NS == 2) chain_body_d0s<CH_D0>(a.c[0], lds, n0, lane, wave, 0);
-  else chain_body_d0w<CH_D0, NS>(a.c[0], lds, n0, lane, wave, 0);
+  if constexpr (NS == 2) chain_body_d0s<CH_D0>(a.c[0], lds, n0, lane, wave, 0, tb_off);
+  else chain_body_d0w<CH_D0, NS>(a.c[0], lds, n0, lane, wave, 0, tb_off);
   // ---- downs.1 @ L=32 -> [4][16][64], skip1: direct f16x2 convs, wave = (n-tile pair, sample pair) (chain_body_d1d)
-  chain_body_d1d<CH_D1, CH_D2, NS>(a.c[1], lds, lane, wave, skip1, 40);
+  chain_body_d1d<CH_D1, CH_D2, NS>(a.c[1], lds, lane, wave, skip1, 40, tb_off);
   // ---- downs.2 + mid blocks @ L=16 -> [NS][16][128], skip2: direct f16x2 convs (chain_body_d2d; lane = channels 32 wave + 2
   //      (lane & 15) + h, positions 4 (lane >> 4) + r of all NS samples)
   f32x4 mid_out[NS][2];
-  chain_body_d2d<CH_D2, NS>(a.c[2], lds, lane, wave, mid_out, skip2, 80);
+  chain_body_d2d<CH_D2, NS>(a.c[2], lds, lane, wave, mid_out, skip2, 80, tb_off);
   TR(130);
   // ---- ups.0 @ L=16: cat(x, skip2) -> [NS][32][64] (chain_body_u0d; the chunks are stored from downs.2's tiles); its output
   //      stays in registers (even / odd positions of channel 16 wave + (lane & 15))
@@ -2349,14 +2355,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char* const slab128 = reinterpret_cast<char*>(lds) + S_OFF;
     char* const vs = slab128 + wave * G128::G + ((lane & 15) >> 2) * G128::BX + (2 + 4 * (lane >> 4)) * 16 + (lane & 3) * 4;
     chain_body_u0d<CH_U0, NS>(a.c[3], lds, lane, wave, mid_out, skip2, [&](const f32x4 (&t)[NS][2]) { rd_store2<G128>(vs, t); },
-                              slab128, xe, xo, 136);
+                              slab128, xe, xo, 136, tb_off);
   }
   TR(131);
   // ---- ups.1 @ L=32: cat(x, skip1) -> [4][64][32], final_conv: Conv1dBlock(32->32) -> 1x1 conv (32->4) -> eps[n,64,4]:
   //      wave = sample (chain_body_u1w)
-  if constexpr (NS == 2) chain_body_u1s<CH_U1>(a.c[4], a.fin, a.fs, lds, n0, lane, wave, xe, xo, skip1, 146);
-  else chain_body_u1w<CH_U1, NS>(a.c[4], a.fin, a.fs, lds, n0, lane, wave, xe, xo, skip1, 146);
+  if constexpr (NS == 2) chain_body_u1s<CH_U1>(a.c[4], a.fin, fs, lds, n0, lane, wave, xe, xo, skip1, 146, tb_off);
+  else chain_body_u1w<CH_U1, NS>(a.c[4], a.fin, fs, lds, n0, lane, wave, xe, xo, skip1, 146, tb_off);
   TR(133);
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel(UnetArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unet_forward_body<NS>(a, a.fs, 0, lds, blockIdx.x * NS, lane, wave);
+}
+
+// A RUN of consecutive unguided DDPM steps in ONE launch (mmd_p_sample_loop: the steps before guidance starts, or every step of a
+// prior-only call): a workgroup iterates the steps of its own NS trajectories -- forward, fused ddpm_sample_fn step (the wave that
+// holds a trajectory's eps writes x in place), the next forward reads what the same workgroup wrote.  No launch boundary between
+// the steps: no dispatch gap, and the workgroups of a CU never wait for the slowest workgroup of the chip.  sc[s]: the step's
+// schedule coefficients and its row of the time table (a.c[*].*.tb point at row 0); chain / injected noise advance by one
+// batch per step.  Same arithmetic as the launch-per-step form: bitwise-equal results.
+// The argument block comes through a pointer into the constant address space, re-derived from an opaque integer every step: as
+// by-value kernel arguments inside a loop the ~300 pointers were hoisted out of it, i.e. kept -- spilled -- across the whole forward
+// (1100 VGPR spills); loaded where they are used (s_load from a uniform address) the loop body compiles like unet_kernel's.
+static_assert(sizeof(UnetArgs) <= PERSIST_TABLE_BYTES - PERSIST_ARGS_OFF, "the argument block fits its workspace region");
+template <int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_persist_kernel(const UnetArgs* ap, const FusedStep* steps,
+                                                                                                     int n_steps, int tb_total) {
+  __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  typedef const __attribute__((address_space(4))) UnetArgs* ConstArgs;
+  typedef const __attribute__((address_space(4))) FusedStep* ConstStep;
+  for (int s = 0; s < n_steps; ++s) {
+    unsigned long long pa = reinterpret_cast<unsigned long long>(ap), ps = reinterpret_cast<unsigned long long>(steps + s);
+    asm volatile("" : "+s"(pa), "+s"(ps));
+    const UnetArgs& a = *(const UnetArgs*)(ConstArgs)pa;
+    const FusedStep& fs = *(const FusedStep*)(ConstStep)ps;     // (read where the fused step uses it: the tail of the forward)
+    // (an opaque copy of the lane index per step: lane-derived slab offsets are loop invariant, and hoisted out of the loop they
+    // would stay live -- spilled -- across the whole forward)
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+    unet_forward_body<NS>(a, fs, fs.t_row * tb_total, lds, blockIdx.x * NS, lane_s, wave);
+    // every wave is done with the LDS of this step, and the trajectories the workgroup wrote are visible to all of its waves
+    // (unet_kernel<2>: a sample's second wave reads what its first wave stored)
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -2836,7 +2885,7 @@ int mmd_unet_destroy(mmd_unet_t u) {
 // buffer they sized with this function) but only a token size is asked for.
 size_t mmd_unet_workspace_bytes(mmd_unet_t u, int n_traj) {
   if (u && u->layered) return layered_workspace_bytes(u->layered, n_traj);   // (that path keeps its activations in the workspace)
-  return n_traj > 0 ? 256 : 0;
+  return n_traj > 0 ? PERSIST_TABLE_BYTES : 0;                                // (the step table of a persistent run of unguided steps)
 }
 
 // algorithmic FLOPs per trajectory of one forward: sum over its convs of 2 * C_out * taps * C_in * L_out
@@ -2913,6 +2962,41 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
 
 }  // extern "C"
 namespace mmd {
+// A run of n_steps <= PERSIST_MAX_STEPS unguided steps of ALL n trajectories in one launch (unet_persist_kernel).  steps: host array of
+// the steps' complete fused-step descriptors (x, hard, seed, traj0 = 0, the step's own coefficients / draw / noise and chain rows /
+// t_row), copied into the workspace's table region in stream order (pageable source: staged by the runtime before the call returns).
+int unet_persist_steps(mmd_unet_t u, int n, void* ws, size_t ws_bytes, hipStream_t st, const FusedStep* steps, int n_steps) {
+  MMD_REQUIRE(u && !u->layered && ws && n >= 1, "unet_persist_steps: bad arguments");
+  MMD_REQUIRE(n_steps >= 1 && n_steps <= PERSIST_MAX_STEPS && ws_bytes >= (size_t)PERSIST_TABLE_BYTES, "unet_persist_steps: step table");
+  for (int s = 0; s < n_steps; ++s) MMD_REQUIRE(steps[s].t_row >= 0 && steps[s].t_row < u->T, "unet_persist_steps: t outside the time table");
+  MMD_HIP_CHECK(hipMemcpyAsync(ws, steps, sizeof(FusedStep) * n_steps, hipMemcpyHostToDevice, st));
+  char* const args_dev = reinterpret_cast<char*>(ws) + PERSIST_ARGS_OFF;
+  static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};
+  const RtbW* set = u->rtb;
+  float* x = reinterpret_cast<float*>(steps[0].x);
+  UnetArgs a{};
+  a.n = n;
+  a.c[0] = args_chain(u, set, kD0, 1, &u->down[0], x, 0, n);
+  a.c[1] = args_chain(u, set, kD1, 1, &u->down[1], nullptr, 0, n);
+  a.c[2] = args_chain(u, set, kD2, 3, nullptr, nullptr, 0, n);
+  a.c[3] = args_chain(u, set, kU0, 1, &u->up[0], nullptr, 0, n);
+  a.c[4] = args_chain(u, set, kU1, 1, &u->up[1], nullptr, 0, n);
+  a.fin.out = nullptr;                                     // (every step is fused: eps never leaves the workgroup)
+  a.fin.w5 = reinterpret_cast<const uint4*>(u->blob + u->fin.wbf);
+  a.fin.isc = u->blob + u->fin.isc;
+  a.fin.bias = u->blob + u->fin.bias; a.fin.gamma = u->blob + u->fin.gamma; a.fin.beta = u->blob + u->fin.beta;
+  a.fin.act = u->fin_act;
+  a.fin.w1_bf = reinterpret_cast<const uint4*>(u->blob + u->fin_w1);
+  a.fin.is1 = u->blob + u->fin_is1;
+  a.fin.w1_bias = u->blob + u->fin_b1;
+  MMD_HIP_CHECK(hipMemcpyAsync(args_dev, &a, sizeof(a), hipMemcpyHostToDevice, st));   // (pageable source: staged before the call returns)
+  const FusedStep* sd = reinterpret_cast<const FusedStep*>(ws);
+  const UnetArgs* ap = reinterpret_cast<const UnetArgs*>(args_dev);
+  if (n <= kTwoPerWorkgroupMax) hipLaunchKernelGGL(unet_persist_kernel<2>, dim3((n + 1) / 2), dim3(256), 0, st, ap, sd, n_steps, u->tb_total);
+  else hipLaunchKernelGGL(unet_persist_kernel<4>, dim3((n + 3) / 4), dim3(256), 0, st, ap, sd, n_steps, u->tb_total);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 bool unet_fused_step_supported(mmd_unet_t u) { return u && !u->layered; }
 int unet_forward_fused(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes, ::mmd_profiler_s* prof,
                        hipStream_t st, const FusedStep& fs) {

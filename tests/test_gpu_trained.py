@@ -68,9 +68,13 @@ def test_trained_network_teacher_forced_steps_and_chain(name):
                           noise=nz.cuda())
         y = y.cpu()
         if i >= tsg:
+            # (an unguided step multiplies the forward's ~1e-6 by sqrt_recip_alphas_cumprod[t] x posterior_mean_coef1[t] wherever the
+            # x0 clamp does not bite -- on a network that denoises it rarely does at t = T - 1: the reference's own response to a
+            # relative 1e-6 perturbation, times LIN, is the yardstick, as for the chains)
             err = rel_l2(y, ref[k + 1])
-            parity_log.record("trained_teacher_forced_step", f"{name}_row{k + 1}", i, err, bound=2e-5)
-            assert err < 2e-5, (name, k, err)
+            bound = max(2e-5, 1.5 * cases.LIN * float(sens[k + 1]))
+            parity_log.record("trained_teacher_forced_step", f"{name}_row{k + 1}", i, err, sens=float(sens[k + 1]), bound=bound)
+            assert err < bound, (name, k, err, bound)
             continue
         jd = gc.GuidedStepJudge(model, guide, ref[k].clone(), hcd, i, tsg, 1, nz, y)
         for j in range(B):
