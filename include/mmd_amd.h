@@ -56,8 +56,8 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
 int mmd_unet_destroy(mmd_unet_t unet);
 
 /* Scratch needed by mmd_unet_forward for n_traj trajectories; allocate it with the host framework.  (The fused kernel keeps
- * every activation on chip: a token size; the layer-by-layer path keeps (5 + n_levels) tensors of n_traj x 64 x unet_input_dim
- * floats there.) */
+ * every activation on chip: 12 KiB, the step table + argument block of a persistent run of unguided steps in mmd_p_sample_loop;
+ * the layer-by-layer path keeps (5 + n_levels) tensors of n_traj x 64 x unet_input_dim floats there.) */
 size_t mmd_unet_workspace_bytes(mmd_unet_t unet, int n_traj);
 
 /* eps = model(x, t, context=None)  (temporal_unet.py:121; called from p_mean_variance,
@@ -186,7 +186,7 @@ typedef struct mmd_sampler_desc {
                                              * (predict_start_from_noise / predict_noise_from_start, diffusion_model_base.py:114-141) */
 } mmd_sampler_desc;
 
-/* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop: [UNet token (256 B)][eps: n_traj * H * 4 floats].  The chunked
+/* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop: [mmd_unet_workspace_bytes][eps: n_traj * H * 4 floats].  The chunked
  * (n_streams > 1) loop uses slices of the same eps block, so this size is exact for every n_streams. */
 size_t mmd_sampler_workspace_bytes(mmd_unet_t unet, int n_traj);
 

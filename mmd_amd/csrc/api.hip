@@ -34,8 +34,11 @@ constexpr int kMaxChunks = 4;
 // environment.  MMD_AMD_NO_FUSED_STEP=1: unguided steps run as step-kernel launches instead of inside the UNet launch's tail
 // (A/B of the fused step).  MMD_AMD_STREAMS=<n>: overrides mmd_sampler_desc.n_streams (tools/gpu_streams.sh).
 static const bool kEnvNoFusedStep = [] { const char* e = getenv("MMD_AMD_NO_FUSED_STEP"); return e && atoi(e) != 0; }();
-// MMD_AMD_PERSIST=0: the leading run of unguided steps goes launch by launch again (A/B of the persistent run, unet.hip)
-static const bool kEnvPersist = [] { const char* e = getenv("MMD_AMD_PERSIST"); return !e || atoi(e) != 0; }();
+// MMD_AMD_PERSIST=1 (sampled once at load; default OFF): the leading run of unguided steps as persistent launches (unet.hip:
+// unet_persist_kernel).  Measured in round 5 and NOT kept as the default (profiles/r05_persist_ab.txt): bitwise-equal results, +1 .. 2 %
+// on the 256 .. 1024-trajectory shards (the launch gaps of 50 steps), -1 .. -4 % on the 2048-trajectory headline (one whole-batch
+// persistent launch replaces the two interleaved stream chunks, which are worth more there).
+static const bool kEnvPersist = [] { const char* e = getenv("MMD_AMD_PERSIST"); return e && atoi(e) != 0; }();
 static const int kEnvStreams = [] {
   const char* e = getenv("MMD_AMD_STREAMS");
   return e ? atoi(e) : 0;
@@ -190,11 +193,15 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   launch_init(x_dev, chain_dev, hard_dev, s->hard_rows, init_noise, (unsigned long long)seed,
               (long long)s->traj_index_base, n, samples_per_robot, st);
 
-  // The leading run of steps WITHOUT guidance (i >= t_start_guide; every step of a prior-only call) as persistent launches on the
-  // caller's stream: a workgroup iterates the run's steps on its own trajectories (unet.hip: unet_persist_kernel), <= 64 steps a
-  // launch.  Bitwise the launch-per-step result.  Not with a profiler attached (its brackets are per launch).
+  // OPT-IN (MMD_AMD_PERSIST=1, see kEnvPersist): the leading run of steps WITHOUT guidance (i >= t_start_guide; every step of a
+  // prior-only call) as persistent launches on the caller's stream: a workgroup iterates the run's steps on its own trajectories
+  // (unet.hip: unet_persist_kernel), <= 64 steps a launch.  Bitwise the launch-per-step result.  Not with a profiler attached (its
+  // brackets are per launch).
   int k_start = 0;
-  if (kEnvPersist && !kEnvNoFusedStep && unet_fused_step_supported(unet) && !s->profiler) {
+  // (its step table travels by hipMemcpyAsync from host memory: not inside a stream capture)
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (kEnvPersist) (void)hipStreamIsCapturing(st, &capturing);
+  if (kEnvPersist && capturing == hipStreamCaptureStatusNone && !kEnvNoFusedStep && unet_fused_step_supported(unet) && !s->profiler) {
     FusedStep run[PERSIST_MAX_STEPS];
     int i = n_steps - 1, k0 = 0;
     while (i >= -n_steps_without_noise) {
