@@ -5,20 +5,25 @@
 # Usage: tools/gpu_profile.sh [tag]   (outputs under gpurun_out/<tag>_*)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
-TAG=${1:-r04c}
+TAG=${1:-r05}
 OUT=gpurun_out
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -25 | tee $OUT/${TAG}_pytest_gpu.log
-cp $OUT/r04_parity.json $OUT/${TAG}_parity.json 2>/dev/null
+cp $OUT/r05_parity.json $OUT/${TAG}_parity.json 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/${TAG}_smoke.log
 # PMC first: bench.py quotes profiles/pmc_latest.json for `traffic` / `mfma_busy_pmc` (copied there after the session)
 REPS=8 tools/gpu_pmc.sh ${TAG}_unet1024 unet_kernel -- python tools/unet_forward_loop.py 1024 > /dev/null
 REPS=8 PMC_SETS="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" tools/gpu_pmc.sh ${TAG}_unet2048 unet_kernel -- python tools/unet_forward_loop.py 2048 > /dev/null
-tools/gpu_pmc.sh ${TAG}_bench "unet_kernel|ddpm_guide" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-power-probe > /dev/null
+tools/gpu_pmc.sh ${TAG}_bench "unet_kernel|ddpm_guide" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-power-probe --no-pmc > /dev/null
 python tools/pmc_to_json.py $OUT/${TAG}_unet1024_pmc.txt 1024 $OUT/${TAG}_bench_pmc.txt $OUT/${TAG}_unet2048_pmc.txt > /dev/null && cp profiles/pmc_latest.json $OUT/${TAG}_pmc_latest.json
 timeout 900 python bench.py --steps 10 --warmup 2 2>$OUT/bench.err | tee $OUT/${TAG}_bench.json | cut -c1-300
+# BASELINE.json's other configs: the same line per workload
+for w in config2 config3 config4 config5; do
+  timeout 600 python bench.py --workload $w --steps 10 --warmup 2 2>>$OUT/bench.err | tee $OUT/${TAG}_bench_$w.json | cut -c1-260
+done
+cp $OUT/${TAG}_bench.json $OUT/${TAG}_bench_headline.json
 rm -rf $OUT/prof; mkdir -p $OUT/prof
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-power-probe > $OUT/${TAG}_bench_prof.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-power-probe --no-pmc > $OUT/${TAG}_bench_prof.json 2> $OUT/prof.err
 python tools/rocpd_summary.py $OUT/prof/bench_results.db > $OUT/${TAG}_rocprofv3_kernel_stats.md && head -16 $OUT/${TAG}_rocprofv3_kernel_stats.md
 rm -rf $OUT/prof/bench_results.db
 timeout 300 python tools/unet_forward_loop.py 256 512 1024 2048 4096 2>&1 | grep "n=" | tee $OUT/${TAG}_unet_sizes.txt

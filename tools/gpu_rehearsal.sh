@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 OUT=gpurun_out; mkdir -p $OUT
-TAG=${1:-r04c}
+TAG=${1:-r05}
 for n in 2 4; do
   MMD_BENCH_REHEARSAL=1 timeout 900 python3 bench.py --gpus $n --steps 2 --warmup 1 2>$OUT/${TAG}_rehearsal_$n.err | tee $OUT/${TAG}_rehearsal_gpus$n.json | cut -c1-500
   tail -2 $OUT/${TAG}_rehearsal_$n.err

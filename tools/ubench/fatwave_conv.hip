@@ -178,7 +178,8 @@ __device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* 
 }
 #else
 template <class GEO, int NT, int MT, int RD>
-__device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2]) {
+__device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* va, const u32x4* const (&w)[NT], u32x4 (&b)[RD][NT][2],
+                                              const char* g_ldsb = nullptr) {
   constexpr int KC = GEO::KC, STEPS = 5 * KC, HP = MT / 2, HS = STEPS * HP;
   u32x4 a[ADEPTH][2][2];
   auto load_hs = [&](int slot, int hs) {     // half step hs = (tap, kc, hp); past the end: a valid, unused read
@@ -224,7 +225,16 @@ __device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* 
             }
           }
       }
+#ifdef LDSB   // (X1: the kernel's 2 x 4 tile, but the B fragments come from a static LDS stage instead of L2: is it the global loads?)
+      if ((PARTS & 4) && st + RD < STEPS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) b[ri][t][q] = *reinterpret_cast<const u32x4*>(g_ldsb + (((st + RD) & 1) * 4 + 2 * t + q) * 1024);
+      }
+#else
       if ((PARTS & 4) && st + RD < STEPS) rd_load_b<GEO, NT>(b[ri], w, st + RD);
+#endif
       MMD_PIN_LOADS();
     }
 }
@@ -240,7 +250,11 @@ __device__ __forceinline__ void rd_taps_parts(f32x4 (&acc)[MT][NT], const char* 
 #define UB_RD 3
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_loop(ConvP p, float* out, int nconv) {
+#ifdef LDSB
+  __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64 + 4 * 8 * 1024 / 4];
+#else
   __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
+#endif
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
   const int c0 = 32 * wave + 2 * n;
   char* const slab = reinterpret_cast<char*>(lds);
@@ -250,6 +264,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int s = 0; s < 4; ++s) for (int t = 0; t < 2; ++t) for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
   rd_zero_halo<G128>(slab);
   int woff[2] = {(2 * wave) * G128::FRAGS5 * 64 + lane, (2 * wave + 1) * G128::FRAGS5 * 64 + lane};
+#ifdef LDSB
+  char* const ldsb = slab + G128::BYTES + 256 + wave * 8 * 1024 + lane * 16;      // the wave's 8 static fragments (2 steps x 2 tiles x 2 pieces)
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(ldsb + i * 1024) = p.w[(wave * 8 + i) * 64 + lane];
+#else
+  const char* const ldsb = nullptr;
+#endif
   __syncthreads();
   if (SKEW && blockIdx.x >= 256) {
     for (int i = 0; i < SKEW; ++i) __builtin_amdgcn_s_sleep(1);
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     rd_ring_load<G128, 2, UB_RD>(ring, wp);
     if (PARTS & 16) rd_store2<G128>(vs, acc);
     if (PARTS & 32) __syncthreads();
-    rd_taps_parts<G128, 2, 4, UB_RD>(acc, va, wp, ring);
+    rd_taps_parts<G128, 2, 4, UB_RD>(acc, va, wp, ring, ldsb);
     if (PARTS & 8) epilogue(acc, e);
     if (PARTS & 32) __syncthreads();
   }
@@ -681,6 +701,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (W8 & 2) rd_load_a<Rd8, 2>(a[buf], va, st / 4, st % 4, sp);
     };
     auto load_b = [&](int buf, int st) {
+#ifdef W8_GLOBB   // (X2: the 4 x 2 tile with its B fragments straight from L2, eight 64-lane global loads per step and wave)
+      if (W8 & 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) b[buf][t][q] = reinterpret_cast<const u32x4*>(p.w)[(((size_t)st * 8 + 4 * nq + t) * 2 + q) * 64 + lane];
+        return;
+      }
+#endif
       if (W8 & 4) {
         const char* src = stage + (st % W8_SLOTS) * W8_STEP_BYTES + (4 * nq) * 2048 + lane * 16;
 #pragma unroll
