@@ -361,8 +361,10 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     config = {"workload": detail if W["label"] is None else W["label"], "workload_detail": detail, "workload_key": args.workload,
               "reference_shapes": W["ref"], "n_robots": n_robots, "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": H,
               "diffusion_steps": T, "trajectories_per_step": n_traj_local * world,
-              "parallelism": f"robots sharded x{world}; 1 all-gather of [{RPG},64,2] fp32 per round" if world > 1
-              else "single GPU", "noise": "in-kernel Philox4x32-10 keyed by global trajectory index",
+              "parallelism": "single GPU" if world == 1 else
+              (f"robots sharded x{world}; 1 all-gather of [{RPG},64,2] fp32 per round" if W["inter_robot"]
+               else f"robots sharded x{world}; no exchange (the workload has no inter-robot term)"),
+              "noise": "in-kernel Philox4x32-10 keyed by global trajectory index",
               "weights": "random-init (numpy PCG64 seed 0)"}
     if not with_roofline:
         return value, ms_per_step, config, None, None
@@ -620,7 +622,7 @@ def measure_pmc(workload, n_launch, T, timeout_s=150):
     return out, log
 
 
-def run_ensemble(args, rank, world, dev):
+def run_ensemble(args, rank, world, dev, rehearsal=False):
     """config4: the 4 robots of the 1x2 Empty-tile instance, each an MPDEnsemble planner (two tile models composed along the horizon,
     cross-conditioned at the tile boundary every step, mpd_ensemble.py:335-429, diffusion_ensemble.py:55-106) called once per step --
     the reference's own granularity: one planner per agent (inference_multi_agent.py:225-237), B = 64 samples a call, a trajectory =
@@ -660,7 +662,7 @@ def run_ensemble(args, rank, world, dev):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert out.trajs_iters.shape[-2] == 2 * H and torch.isfinite(out.trajs_iters[-1]).all()
@@ -744,7 +746,7 @@ def main():
 
     W = WORKLOADS[args.workload]
     if W.get("ensemble"):
-        value, ms, config, roofline = run_ensemble(args, rank, world, dev)
+        value, ms, config, roofline = run_ensemble(args, rank, world, dev, rehearsal)
         guide, cpu_result = None, (cpu_job_result(cpu_job()) if want_cpu else None)
     else:
         value, ms, config, roofline, (guide, cpu_result) = run_mode(args, args.scaling, rank, world, dev, rehearsal, with_roofline=True,
