@@ -246,10 +246,13 @@ def cpu_baseline(T, B, workload, budget_s):
     # the longer sample at the best thread count: guided / unguided steps spread over their halves of the schedule
     torch.set_num_threads(best["threads"])
     tg, tu = [], []
-    gi = list(np.linspace(tsg - 1, 0, 8).astype(int))
-    ui = list(np.linspace(T - 1, tsg, 8).astype(int))
+    n_pairs = 24                                                      # (as many of them as the budget allows: less to extrapolate)
+    gi = list(np.linspace(tsg - 1, 0, n_pairs).astype(int))
+    ui = list(np.linspace(T - 1, tsg, n_pairs).astype(int))
+    order = [int(j) for j in np.argsort([(j * 7) % n_pairs for j in range(n_pairs)])]   # spread over the schedule whatever the count
+    gi, ui = [gi[j] for j in order], [ui[j] for j in order]
     k = 0
-    while time.perf_counter() - t_start < budget_s and k < 8:
+    while time.perf_counter() - t_start < budget_s and k < n_pairs:
         tg.append(timed(int(gi[k]), guide))
         tu.append(timed(int(ui[k]), None))
         k += 1
