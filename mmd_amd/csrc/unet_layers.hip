@@ -25,6 +25,9 @@
 
 #include "../../include/mmd_amd.h"
 #include "common.h"
+#include "f16x2.h"
+#include "gn_mish.h"
+#include <type_traits>
 #include "unet_spec.h"
 
 namespace mmd {
@@ -169,6 +172,315 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   }
 }
 
+// The layer-by-layer path ON THE MATRIX PIPE (round 5): fp32 arithmetic as the two-piece fp16 split of f16x2.h (three
+// v_mfma_f32_16x16x32_f16 per product, fp32 accumulate -- the fused kernel's building blocks), for every layer whose GEMM columns are
+// whole 16-column n-tiles.  KIND 0: Conv1dBlock (conv k5 + GroupNorm + Mish + addends); 1: Conv1d k1 (the 1x1 residual); 2: Conv1d k3
+// stride 2 (Downsample1d); 3: ConvTranspose1d(k4, s2, p1) (Upsample1d) as a k3 conv with 2 c_out columns (column 2 co + parity: out[2 m] =
+// in[m - 1] W3 + in[m] W1, out[2 m + 1] = in[m] W2 + in[m + 1] W0) and an interleaving store.
+// GEMM: M = (sample, output row) -- a workgroup (4 waves) takes SPW = 64 / LR consecutive samples (LR = rows of a sample: l_in, or l_in / 2
+// for the strided conv), so M is always 64 rows = four M tiles and a weight fragment is used on all of them, as in the fused kernel; N = a
+// slice of cs in {16, 32, 64, 128} columns (blockIdx.y; whole GroupNorm groups for KIND 0); K = taps x input channels, in CHUNKS of kch <=
+// 128 channels:
+//   * per chunk the samples' [chunk channels][l_in] fp32 rows go to LDS as fp16 pieces in ROW form [piece][channel block b = KCj g + kc][row
+//     = (l_in + 4) sample + 2 + position][8 channels] (16 bytes per (block, row): an A fragment is one ds_read_b128; two zero rows either
+//     side of a sample are the conv's padding, a tap is a row offset, the stride a row step) under a dynamic PER-SAMPLE power-of-two scale
+//     from the exact maximum of the sample's whole input (dyn_scale); the accumulators live across the chunks;
+//   * weights: host-packed per layer and chunk in B-fragment order [chunk][n-tile][tap][kc][piece][lane] x 16 bytes with per-column
+//     power-of-two scales (pack_rd / rd_col_scales of f16x2.h), streamed from L2 through a register ring of RD steps (RD divides a chunk's
+//     steps: 5 taps, 3 taps, or the k1 conv's chunk always padded to four K chunks);
+//   * a wave takes NTW n-tiles x MTW M tiles (cs <= 32: the waves that share an n-tile split the M tiles);
+//   * KIND 0: the accumulators go -- scaled back per channel and sample, bias added -- to an LDS tile that re-uses the slab, and the
+//     GroupNorm + Mish + addend tail works on it per (sample, group) with conv5_block_kernel's two-pass statistics; the plain convs store
+//     from the accumulators (a lane holds four consecutive positions of one column).
+// A sample's arithmetic does not depend on the batch it sits in, on its place in the workgroup or on the slicing.
+constexpr int MCONV_KCH = 128;                     // input channels staged per chunk (at most)
+constexpr int MCONV_MAX_CHUNKS = 8;                // <= 1024 input channels
+constexpr int OST = 68;                            // row stride of the LDS output tile [channel][64 (sample, position) rows]
+struct MPack { size_t w = 0, isc = 0; int n_chunks = 0, kch = 0; unsigned stride = 0; };   // f16x2 packs of a conv in the blob (w = 0: none)
+struct MConvArgs {
+  ConvArgs c;                         // x1 / x2 / c1 / c2 / l_in / l_out / c_out / cs (columns of the slice) / in_cl / bias / gamma / beta / add_c / add_t / y
+  const uint4* wpk;                   // the layer's packs; chunk j starts at wpk + j stride: n-tiles x taps x kcj chunks x 2 pieces x 64 lanes
+  const float* isc;                   // [columns] inverse weight scales
+  unsigned stride;                    // (every chunk but the last is kch channels wide: one stride)
+  int n_chunks, kch, n;
+};
+template <int KIND> struct MKind;
+template <> struct MKind<0> { static constexpr int K = 5, S = 1, RD = 5, NR = 3; };
+template <> struct MKind<1> { static constexpr int K = 1, S = 1, RD = 4, NR = 3; };
+template <> struct MKind<2> { static constexpr int K = 3, S = 2, RD = 3, NR = 5; };
+template <> struct MKind<3> { static constexpr int K = 3, S = 1, RD = 3, NR = 3; };
+// NTW n-tiles x MTW M tiles per wave: (2, 4) for a slice of 128 columns, (1, 4) for 64, (1, 2) for 32, (1, 1) for 16 -- compile-time, so
+// that the weight ring's slots are registers with exact s_waitcnt counts (with run-time tile counts the compiler drained every load)
+template <int NTW, int MTW, int KIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mconv_kernel(MConvArgs m) {
+  constexpr int K = MKind<KIND>::K, S = MKind<KIND>::S, RD = MKind<KIND>::RD, NR = MKind<KIND>::NR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ConvArgs& a = m.c;
+  const int cin = a.c1 + a.c2, L = a.l_in, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lsh_in = 31 - __builtin_clz(L);                // l_in is 8, 16, 32 or 64
+  const int lsh = lsh_in - (S - 1), LR = 1 << lsh;         // GEMM rows of a sample
+  const int SPW = 64 >> lsh, RS = L + 4, SROWS = SPW * RS;  // samples per workgroup, slab rows per sample / in all
+  const int s0 = blockIdx.x * SPW, c0 = blockIdx.y * a.cs;
+  char* const slab = smem;
+  // LDS: [slab: 2 pieces x (kch / 8) blocks x SROWS x 16 B | KIND 0: the output tile [cs][OST] aliases it] [stat: 2 x groups x samples,
+  // 8 + 8 scales, 8 partial maxima]
+  const int slab_bytes = 2 * (m.kch / 8) * SROWS * 16, outs_bytes = KIND == 0 ? a.cs * OST * 4 : 0;
+  float* const stat = reinterpret_cast<float*>(smem + (slab_bytes > outs_bytes ? slab_bytes : outs_bytes));
+  float* const scale_inv = stat + 2 * N_GROUPS * 8;        // [8] inverse dynamic scale per sample
+  float* const scale_s = scale_inv + 8;                    // [8] dynamic scale per sample
+  float* const pmx = scale_s + 8;                          // [8] partial maxima
+  // ---- per-sample maxima of the WHOLE input -> dynamic scales: a sample's input is one contiguous run per source ([c1][L] of x1, [c2][L]
+  // of x2; channels-last the same run); 4 / SPW waves share a sample (>= 4 samples: a wave takes whole samples)
+  {
+    const int parts = SPW >= 4 ? 1 : 4 / SPW;
+    for (int u = wave; u < SPW * parts; u += 4) {
+      const int sm = u / parts, pt = u - sm * parts, smp = s0 + sm;
+      float mx = 0.f;
+      if (smp < m.n) {
+        auto scan = [&](const float* src, int count4) {    // eight 16-byte loads in flight per lane
+          const float4* const p = reinterpret_cast<const float4*>(src);
+          const int lo = count4 * pt / parts, hi = count4 * (pt + 1) / parts;
+          for (int i0 = lo + lane; i0 < hi; i0 += 512) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = i0 + 64 * q < hi ? p[i0 + 64 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[q].x), fabsf(v[q].y))), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
+          }
+        };
+        scan(a.x1 + (size_t)smp * a.c1 * L, (a.c1 << lsh_in) >> 2);
+        if (a.c2) scan(a.x2 + (size_t)smp * a.c2 * L, (a.c2 << lsh_in) >> 2);
+      }
+      for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      if (lane == 0) pmx[u] = mx;
+    }
+    __syncthreads();
+    if (tid < SPW) {
+      float mx = pmx[tid * parts];
+      for (int q = 1; q < parts; ++q) mx = fmaxf(mx, pmx[tid * parts + q]);
+      const DynScale ds = dyn_scale(mx);
+      scale_s[tid] = ds.s;
+      scale_inv[tid] = ds.inv;
+    }
+    __syncthreads();
+  }
+  // ---- this thread's staging rows (fixed over the chunks): rows tid % 32 + 32 i of the slab -> (sample, position); the element offsets
+  // and the sample's scale (0, and the first element of the batch as the address: a padding row, a row past the slab or past the batch)
+  int st_smp[NR], st_l[NR];
+  float st_sc[NR];
+  bool st_row[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int row = (tid & 31) + 32 * i, sm = row / RS, l = row - sm * RS - 2, smp = s0 + sm;
+    st_row[i] = row < SROWS;
+    const bool in = st_row[i] && smp < m.n && l >= 0 && l < L;
+    st_sc[i] = in ? scale_s[sm] : 0.f;
+    st_smp[i] = in ? smp : 0;
+    st_l[i] = in ? l : 0;
+  }
+  // ---- GEMM over the channel chunks
+  constexpr int WPT = 4 / MTW;                             // waves that share an n-tile (MTW < 4: they split its M tiles)
+  const int nt0 = (wave / WPT) * NTW;                      // first n-tile of the wave
+  const int mt0 = wave % WPT;                              // its M tiles: mt0, mt0 + WPT, ...
+  const int row = lane & 15, g = lane >> 4;
+  int arow[MTW];                                           // slab row of the lane's A row in its M tile i at tap 0: position S lo - K / 2
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int r64 = 16 * (mt0 + i * WPT) + row;            // (sample, output row) of the 64
+    arow[i] = (r64 >> lsh) * RS + S * (r64 & (LR - 1)) + 2 - K / 2;
+  }
+  f32x4 acc[NTW][MTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ch = 0; ch < m.n_chunks; ++ch) {
+    // (the k1 conv's chunk is always four K chunks wide: its four steps are the ring)
+    const int c_lo = ch * m.kch, cc = K == 1 ? m.kch : min(m.kch, cin - c_lo), KCj = (cc + 31) / 32, NB = 4 * KCj;
+    const int PS = NB * SROWS * 16;
+    if (ch) __syncthreads();                               // every wave is done reading the previous chunk
+    // the weight ring's first steps are requested before the staging: their latency passes under it
+    const int steps = K * KCj;                             // (tap, kc), tap-major: a multiple of the ring's RD slots
+    // the wave's B fragments of step st: n-tile nt0 + t, pieces q
+    const u32x4* const wp = reinterpret_cast<const u32x4*>(m.wpk) + (size_t)ch * m.stride + (size_t)(c0 / 16 + nt0) * steps * 128 + lane;
+    const size_t tstride = (size_t)steps * 128;            // one n-tile further
+    u32x4 b[RD][NTW][2];
+    auto load_b = [&](int slot, int st) {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        b[slot][t][0] = wp[t * tstride + (size_t)st * 128];
+        b[slot][t][1] = wp[t * tstride + (size_t)st * 128 + 64];
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < RD; ++j) load_b(j, j);
+    // stage: item = (channel block, slab row): 8 channels of one position, both pieces; a thread has <= 2 blocks x NR rows.  All of a
+    // thread's loads are issued before the first is used (a padding row reads a valid address and is multiplied by its zero scale)
+    {
+      float v[2][NR][8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int blk = (tid >> 5) + 8 * h, c = c_lo + 8 * blk;   // (c1 is a multiple of 8: the block lies in one source)
+        if (blk >= NB) continue;
+        if (a.in_cl) {                                     // the trajectory [n][L][4]: channels 0 .. 3 are one 16-byte load
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const float4 q = c == 0 ? *reinterpret_cast<const float4*>(a.x1 + ((size_t)st_smp[i] * L + st_l[i]) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[h][i][0] = q.x; v[h][i][1] = q.y; v[h][i][2] = q.z; v[h][i][3] = q.w;
+            v[h][i][4] = v[h][i][5] = v[h][i][6] = v[h][i][7] = 0.f;
+          }
+        } else {
+          const bool live = c < cin, first = c < a.c1;
+          const float* const src = first ? a.x1 + (size_t)c * L : a.x2 + (size_t)(c - a.c1) * L;
+          const int cw = first ? a.c1 : a.c2;              // channels of the source: a sample is cw x L elements
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const float* const q = live ? src + (size_t)st_smp[i] * cw * L + st_l[i] : a.x1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[h][i][j] = live ? q[j << lsh_in] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int blk = (tid >> 5) + 8 * h;
+        if (blk >= NB) continue;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          if (!st_row[i]) continue;
+          const float sc = st_sc[i];
+          const F16Pair p0 = f16_split2(v[h][i][0] * sc, v[h][i][1] * sc), p1 = f16_split2(v[h][i][2] * sc, v[h][i][3] * sc),
+                        p2 = f16_split2(v[h][i][4] * sc, v[h][i][5] * sc), p3 = f16_split2(v[h][i][6] * sc, v[h][i][7] * sc);
+          const size_t o = ((size_t)blk * SROWS + (tid & 31) + 32 * i) * 16;
+          *reinterpret_cast<uint4*>(slab + o) = make_uint4(p0.hi, p1.hi, p2.hi, p3.hi);
+          *reinterpret_cast<uint4*>(slab + PS + o) = make_uint4(p0.lo, p1.lo, p2.lo, p3.lo);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      auto group = [&](int base, auto refill) {            // RD steps: slot j holds step base + j and is refilled with step base + j + RD
+#pragma unroll
+        for (int j = 0; j < RD; ++j) {
+          const int st = base + j, tap = st / KCj, kc = st - tap * KCj;
+          const char* const ablk = slab + ((size_t)(KCj * g + kc) * SROWS + tap) * 16;
+          u32x4 af[MTW][2];
+#pragma unroll
+          for (int i = 0; i < MTW; ++i) {
+            af[i][0] = *reinterpret_cast<const u32x4*>(ablk + arow[i] * 16);
+            af[i][1] = *reinterpret_cast<const u32x4*>(ablk + PS + arow[i] * 16);
+          }
+#pragma unroll
+          for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) vb_three<false>(acc[t][i], af[i], b[j][t]);
+          if (decltype(refill)::value) load_b(j, st + RD);
+        }
+      };
+      // (the last group peeled: every load of the loop is unconditional, so the waits count loads instead of draining them)
+      for (int base = 0; base < steps - RD; base += RD) group(base, std::true_type{});
+      group(steps - RD, std::false_type{});
+    }
+  }
+  if (KIND != 0) {
+    // ---- plain convs: column scale x sample scale, + bias, stored from the accumulators (C/D layout: lane = column lane & 15, rows 4 g ..
+    // 4 g + 3 of the M tile = four consecutive output rows of one sample)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = c0 + 16 * (nt0 + t) + row, co = KIND == 3 ? col >> 1 : col;
+      const float kc_ = m.isc[col], bs = a.bias[co];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        const int r64 = 16 * (mt0 + i * WPT) + 4 * g, sm = r64 >> lsh, lo = r64 & (LR - 1), smp = s0 + sm;
+        const float k = kc_ * scale_inv[sm];
+        const float4 v = make_float4(fmaf(acc[t][i][0], k, bs), fmaf(acc[t][i][1], k, bs), fmaf(acc[t][i][2], k, bs), fmaf(acc[t][i][3], k, bs));
+        if (KIND == 3) {
+          // columns 2 co (even lane: out[2 m]) and 2 co + 1 (odd lane: out[2 m + 1]) sit in neighbouring lanes: the even lane stores
+          // out[2 lo .. 2 lo + 3], the odd lane out[2 lo + 4 .. 2 lo + 7]
+          const float ox = __shfl_xor(v.x, 1), oy = __shfl_xor(v.y, 1), oz = __shfl_xor(v.z, 1), ow = __shfl_xor(v.w, 1);
+          const bool odd = lane & 1;
+          const float4 w = odd ? make_float4(oz, v.z, ow, v.w) : make_float4(v.x, ox, v.y, oy);
+          if (smp < m.n) *reinterpret_cast<float4*>(a.y + ((size_t)smp * a.c_out + co) * a.l_out + 2 * lo + (odd ? 4 : 0)) = w;
+        } else if (smp < m.n) {
+          *reinterpret_cast<float4*>(a.y + ((size_t)smp * a.c_out + co) * a.l_out + lo) = v;
+        }
+      }
+    }
+    return;
+  }
+  // ---- the tail's global operands are requested now (a thread's items: 4 consecutive positions of channel c, NIT of them), so that
+  // their latency passes under the exchange and the statistics
+  float* const outs = reinterpret_cast<float*>(smem);      // [cs][OST] conv output (64 rows + 4 of padding: conflict-free column writes)
+  constexpr int NIT = NTW * MTW;                           // = cs / 16
+  float4 addt[NIT];
+  float gm[NIT], bt[NIT], ac[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int o4 = tid + 256 * k, c = o4 >> 4, r64 = (o4 & 15) * 4, smp = s0 + (r64 >> lsh), co = c0 + c;
+    gm[k] = a.gamma[co];
+    bt[k] = a.beta[co];
+    ac[k] = a.add_c ? a.add_c[co] : 0.f;
+    addt[k] = (a.add_t && smp < m.n) ? *reinterpret_cast<const float4*>(a.add_t + ((size_t)smp * a.c_out + co) * L + (r64 & (L - 1)))
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float kc_[NTW], bs_[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    kc_[t] = m.isc[c0 + 16 * (nt0 + t) + row];
+    bs_[t] = a.bias[c0 + 16 * (nt0 + t) + row];
+  }
+  __syncthreads();                                         // the slab is dead: its memory becomes the output tile
+  // ---- accumulators -> outs[c][r64] (C/D layout: lane = column lane & 15, rows 4 g .. 4 g + 3 of the M tile), scaled back, + bias
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int cl = 16 * (nt0 + t) + row;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const int r64 = 16 * (mt0 + i * WPT) + 4 * g;
+      const float k = kc_[t] * scale_inv[r64 >> lsh], bs = bs_[t];
+      *reinterpret_cast<float4*>(outs + cl * OST + r64) =
+          make_float4(fmaf(acc[t][i][0], k, bs), fmaf(acc[t][i][1], k, bs), fmaf(acc[t][i][2], k, bs), fmaf(acc[t][i][3], k, bs));
+    }
+  }
+  __syncthreads();
+  // ---- GroupNorm statistics per (sample, group): cpg channels x L positions (two passes, as conv5_block_kernel)
+  const int cpg = a.c_out / N_GROUPS, ngrp = a.cs / cpg, per = cpg << lsh;
+  for (int w = wave; w < ngrp * SPW; w += 4) {
+    const int gidx = w % ngrp, sm = w / ngrp;
+    const float* blk = outs + gidx * cpg * OST + (sm << lsh);
+    float sum = 0.f;
+    for (int i = lane; i < per; i += 64) sum += blk[(i >> lsh) * OST + (i & (L - 1))];
+    for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)per;
+    float q = 0.f;
+    for (int i = lane; i < per; i += 64) {
+      const float d = blk[(i >> lsh) * OST + (i & (L - 1))] - mean;
+      q = fmaf(d, d, q);
+    }
+    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
+    if (lane == 0) {
+      stat[2 * w] = mean;
+      stat[2 * w + 1] = 1.f / sqrtf(q / (float)per + 1e-5f);
+    }
+  }
+  __syncthreads();
+  // ---- normalise + Mish + addends -> y [n][c_out][L]
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int o4 = tid + 256 * k, c = o4 >> 4, r64 = (o4 & 15) * 4, sm = r64 >> lsh, smp = s0 + sm;
+    if (smp >= m.n) continue;
+    const int w = sm * ngrp + c / cpg;
+    const float4 x = *reinterpret_cast<const float4*>(outs + c * OST + r64);
+    // (the fused kernel's GroupNorm affine + Mish + addend of gn_mish.h: one of the two addends is absent -- the time bias follows an
+    // RTB's first block, the residual its second)
+    const GnCoef cf = gn_coef(stat[2 * w], stat[2 * w + 1], gm[k], bt[k]);
+    const f32x2_t lo = gn_mish2(f32x2_t{x.x, x.y}, cf, f32x2_t{ac[k] + addt[k].x, ac[k] + addt[k].y});
+    const f32x2_t hi = gn_mish2(f32x2_t{x.z, x.w}, cf, f32x2_t{ac[k] + addt[k].z, ac[k] + addt[k].w});
+    const float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
+    *reinterpret_cast<float4*>(a.y + ((size_t)smp * a.c_out + c0 + c) * L + (r64 & (L - 1))) = v;
+  }
+}
+
 // MODE 0: Conv1d, K taps, stride S, padding K / 2.  MODE 1: ConvTranspose1d(k4, s2, p1): out[2 m] = in[m - 1] W3 + in[m] W1,
 // out[2 m + 1] = in[m] W2 + in[m + 1] W0 (taps stored in kernel-index order 0 .. 3).  No norm; input staged as [l][c_in].
 template <int MODE, int K, int S>
@@ -224,13 +536,82 @@ size_t push_wt(std::vector<float>& blob, const float* w, int cout, int cin, int 
             transposed ? w[((size_t)ci * cout + co) * k + kk] : w[((size_t)co * cin + ci) * k + kk];
   return off;
 }
+// smallest slice of a Conv1dBlock on the matrix pipe: 16, 32 or 64 output channels = whole 16-column n-tiles AND whole GroupNorm groups
+// (0: none fits -- unet_input_dim 8's first level, the 24 / 40 / 56 ladders: those blocks stay on conv5_block_kernel)
+int mfma_slice(int c_out) {
+  if (c_out % 16) return 0;
+  const int cpg = c_out / N_GROUPS;
+  for (int cs : {16, 32, 64})
+    if (c_out % cs == 0 && cs % cpg == 0) return cs;
+  return 0;
+}
+// f16x2 packs of a conv given as wk [cols][cin][K] (K taps in slab-row order), one per chunk of kch input channels: kch = the input
+// channels rounded up to whole K chunks of 32, at most MCONV_KCH (the k1 conv: always MCONV_KCH, its four steps are the weight ring);
+// the last chunk zero-padded
+MPack push_mfma(std::vector<float>& blob, const float* wk, int cols, int cin, int K) {
+  MPack p{};
+  const int kch = K == 1 ? MCONV_KCH : std::min(MCONV_KCH, (cin + 31) / 32 * 32);
+  const int n_chunks = (cin + kch - 1) / kch;
+  if (cols % 16 || n_chunks > MCONV_MAX_CHUNKS) return p;
+  const int cp = K == 1 ? n_chunks * kch : (cin + 31) / 32 * 32;
+  std::vector<float> wp((size_t)cols * cp * K, 0.f);
+  for (int co = 0; co < cols; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int k = 0; k < K; ++k) wp[((size_t)co * cp + ci) * K + k] = wk[((size_t)co * cin + ci) * K + k];
+  std::vector<int> taps(K);
+  for (int k = 0; k < K; ++k) taps[k] = k;
+  const std::vector<float> sc = rd_col_scales(wp.data(), cols, cp, K, taps, false);
+  p.isc = push_inverse(blob, sc);
+  p.n_chunks = n_chunks;
+  p.kch = kch;
+  for (int j = 0; j < n_chunks; ++j) {
+    const int c_lo = j * kch, cc = std::min(kch, cp - c_lo);
+    const size_t o = pack_rd(blob, wp.data(), cols, cp, c_lo, cc, K, taps, false, false, sc);
+    if (j == 0) p.w = o;
+    if (j == 1) p.stride = (unsigned)((o - p.w) / 4);      // in 16-byte units; every chunk but the last has the same size
+    if (j > 1 && (o - p.w) / 4 != (size_t)j * p.stride) return MPack{};
+  }
+  return p;
+}
+// Conv1dBlock: the slice must be whole GroupNorm groups
+MPack push_mfma5(std::vector<float>& blob, const float* w, int cout, int cin) { return mfma_slice(cout) ? push_mfma(blob, w, cout, cin, 5) : MPack{}; }
+// ConvTranspose1d(k4, s2, p1) [cin][cout][4] as a k3 conv with columns 2 co + parity over rows (m - 1, m, m + 1):
+// out[2 m] = in[m - 1] W3 + in[m] W1, out[2 m + 1] = in[m] W2 + in[m + 1] W0
+MPack push_mfma_up(std::vector<float>& blob, const float* w, int cout, int cin) {
+  std::vector<float> wk((size_t)2 * cout * cin * 3, 0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci) {
+      const float* k = w + ((size_t)ci * cout + co) * 4;
+      float* e = wk.data() + ((size_t)(2 * co) * cin + ci) * 3;
+      float* o = wk.data() + ((size_t)(2 * co + 1) * cin + ci) * 3;
+      e[0] = k[3]; e[1] = k[1];
+      o[1] = k[2]; o[2] = k[0];
+    }
+  return push_mfma(blob, wk.data(), 2 * cout, cin, 3);
+}
+template <int KIND>
+void launch_mconv(int cs, dim3 grid, size_t shm, hipStream_t st, const MConvArgs& ma) {
+  if (cs == 128) hipLaunchKernelGGL((mconv_kernel<2, 4, KIND>), grid, dim3(256), shm, st, ma);
+  else if (cs == 64) hipLaunchKernelGGL((mconv_kernel<1, 4, KIND>), grid, dim3(256), shm, st, ma);
+  else if (cs == 32) hipLaunchKernelGGL((mconv_kernel<1, 2, KIND>), grid, dim3(256), shm, st, ma);
+  else hipLaunchKernelGGL((mconv_kernel<1, 1, KIND>), grid, dim3(256), shm, st, ma);
+}
+template <int KIND>
+int mconv_set_lds() {
+  for (const void* f : {(const void*)mconv_kernel<2, 4, KIND>, (const void*)mconv_kernel<1, 4, KIND>, (const void*)mconv_kernel<1, 2, KIND>,
+                        (const void*)mconv_kernel<1, 1, KIND>})
+    MMD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  return 0;
+}
 size_t push_v(std::vector<float>& blob, const float* p, int64_t n) {
   const size_t off = blob.size();
   blob.insert(blob.end(), p, p + n);
   return off;
 }
 
-struct LRtb { int cin, cout; size_t wa, ba, ga, bea, wb, bb, gb, beb, wr, br; bool res; int tb_off; };
+// MMD_AMD_LAYERED_VALU=1 (sampled once at load): every layer on the vector-ALU kernels again (A/B of mconv_kernel)
+static const bool kLayeredValu = [] { const char* e = getenv("MMD_AMD_LAYERED_VALU"); return e && atoi(e) != 0; }();
+struct LRtb { int cin, cout; size_t wa, ba, ga, bea, wb, bb, gb, beb, wr, br; bool res; int tb_off; MPack ma, mb, mr; };
 
 }  // namespace
 
@@ -243,6 +624,7 @@ struct LayeredUnet {
   std::vector<LRtb> rtb;
   size_t down_w[MAX_LEVELS - 1], down_b[MAX_LEVELS - 1], up_w[MAX_LEVELS - 1], up_b[MAX_LEVELS - 1];
   size_t fin_w5, fin_b5, fin_g, fin_be, fin_w1, fin_b1;
+  MPack fin_m, down_m[MAX_LEVELS - 1], up_m[MAX_LEVELS - 1];
   int per_sample = 0;                 // floats of the largest activation tensor of a sample (64 x unet_input_dim)
 };
 
@@ -263,7 +645,12 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
     L.ba = push_v(blob, tensors[R.t_b0], R.cout); L.ga = push_v(blob, tensors[R.t_g0], R.cout); L.bea = push_v(blob, tensors[R.t_be0], R.cout);
     L.wb = push_wt(blob, tensors[R.t_w1], R.cout, R.cout, 5, false);
     L.bb = push_v(blob, tensors[R.t_b1], R.cout); L.gb = push_v(blob, tensors[R.t_g1], R.cout); L.beb = push_v(blob, tensors[R.t_be1], R.cout);
-    if (R.res) { L.wr = push_wt(blob, tensors[R.t_rw], R.cout, R.cin, 1, false); L.br = push_v(blob, tensors[R.t_rb], R.cout); }
+    if (R.res) {
+      L.wr = push_wt(blob, tensors[R.t_rw], R.cout, R.cin, 1, false); L.br = push_v(blob, tensors[R.t_rb], R.cout);
+      L.mr = push_mfma(blob, tensors[R.t_rw], R.cout, R.cin, 1);
+    }
+    L.ma = push_mfma5(blob, tensors[R.t_w0], R.cout, R.cin);
+    L.mb = push_mfma5(blob, tensors[R.t_w1], R.cout, R.cout);
     raw_cw[r] = push_v(blob, tensors[R.t_cw], (int64_t)R.cout * 32);
     raw_cb[r] = push_v(blob, tensors[R.t_cb], R.cout);
     L.tb_off = tb;
@@ -275,10 +662,13 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
     const int c = s.dims[i + 1];
     u->down_w[i] = push_wt(blob, tensors[s.t_down[i][0]], c, c, 3, false);
     u->down_b[i] = push_v(blob, tensors[s.t_down[i][1]], c);
+    u->down_m[i] = push_mfma(blob, tensors[s.t_down[i][0]], c, c, 3);
     const int cu = s.dims[s.n_levels - 1 - i];
     u->up_w[i] = push_wt(blob, tensors[s.t_up[i][0]], cu, cu, 4, true);
     u->up_b[i] = push_v(blob, tensors[s.t_up[i][1]], cu);
+    u->up_m[i] = push_mfma_up(blob, tensors[s.t_up[i][0]], cu, cu);
   }
+  u->fin_m = push_mfma5(blob, tensors[s.t_final[0]], s.uid, s.uid);
   u->fin_w5 = push_wt(blob, tensors[s.t_final[0]], s.uid, s.uid, 5, false);
   u->fin_b5 = push_v(blob, tensors[s.t_final[1]], s.uid);
   u->fin_g = push_v(blob, tensors[s.t_final[2]], s.uid);
@@ -294,6 +684,7 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
   // widest Conv1dBlock input: ups.0.0 of a four-level net stages 2 x 8 uid x 8 channels x (8 + 8) positions (64 KB at uid 64)
   for (const void* f : {(const void*)conv5_block_kernel<1>, (const void*)conv5_block_kernel<2>, (const void*)conv5_block_kernel<4>})
     MMD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  if (mconv_set_lds<0>() || mconv_set_lds<1>() || mconv_set_lds<2>() || mconv_set_lds<3>()) return 1;
   MMD_HIP_CHECK(hipMemcpyAsync(u->blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, st));
   MMD_HIP_CHECK(hipStreamSynchronize(st));
   u->blob_bytes = blob.size() * sizeof(float);
@@ -348,11 +739,42 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     while (ns < N_GROUPS && ((long long)n * ns < 768 || c_out / ns > max_cs) && (c_out / (2 * ns)) % unit == 0) ns *= 2;
     return ns;
   };
+  // a layer on the matrix pipe (mconv_kernel): a workgroup = 64 / (rows of a sample) samples x a slice of <= 128 of the GEMM's columns;
+  // narrower slices (down to `unit`: whole n-tiles, for a Conv1dBlock whole GroupNorm groups) while the launch has fewer than 3
+  // workgroups per CU
+  auto mconv_ok = [&](const MPack& mp, int c1, int c2, int in_cl) { return mp.w && !kLayeredValu && (in_cl ? c1 == 4 && !c2 : c1 % 8 == 0); };
+  auto mconv = [&](int kind, const MPack& mp, ConvArgs c, int cols, int unit) -> int {
+    const int rows = kind == 2 ? c.l_in / 2 : c.l_in, spw = 64 / rows, n_wg = (n + spw - 1) / spw;
+    int cs = 0;                                            // the widest slice that leaves >= 768 workgroups, else the narrowest there is
+    for (int w : {128, 64, 32, 16})
+      if (cols % w == 0 && w % unit == 0 && (!cs || (long long)n_wg * (cols / cs) < 768)) cs = w;
+    MMD_REQUIRE(cs && rows >= 8 && rows <= 64, "layered_forward: no slice for a layer of %d columns", cols);
+    MConvArgs ma{};
+    ma.c = c;
+    ma.c.cs = cs;
+    ma.wpk = reinterpret_cast<const uint4*>(B + mp.w);
+    ma.isc = B + mp.isc;
+    ma.stride = mp.stride;
+    ma.n_chunks = mp.n_chunks;
+    ma.kch = mp.kch;
+    ma.n = n;
+    const size_t slab = (size_t)2 * (mp.kch / 8) * spw * (c.l_in + 4) * 16, outs = kind == 0 ? (size_t)cs * OST * 4 : 0;
+    const size_t shm = std::max(slab, outs) + (2 * N_GROUPS * 8 + 8 + 8 + 8) * sizeof(float);
+    const dim3 grid(n_wg, cols / cs);
+    if (kind == 0) launch_mconv<0>(cs, grid, shm, st, ma);
+    else if (kind == 1) launch_mconv<1>(cs, grid, shm, st, ma);
+    else if (kind == 2) launch_mconv<2>(cs, grid, shm, st, ma);
+    else launch_mconv<3>(cs, grid, shm, st, ma);
+    return 0;
+  };
   // Conv1dBlock: (x1 | x2) [c][L] -> Mish(GN(conv5)) + add_c[c] + add_t -> y.  A workgroup of KS x nconv threads, nconv =
   // (L / 4) * (cs / CT) in [16, 64]: the slice width cs (whole GroupNorm groups) follows from that, CT = 2 for the big launches
   auto block5 = [&](const float* x1, int c1, const float* x2, int c2, int in_cl, int L, int c_out, size_t w, size_t b, size_t gamma,
-                    size_t beta, const float* add_c, const float* add_t, float* y) -> int {
+                    size_t beta, const float* add_c, const float* add_t, float* y, const MPack& mp) -> int {
     const int cpg = c_out / N_GROUPS;
+    if (mconv_ok(mp, c1, c2, in_cl))
+      return mconv(0, mp, ConvArgs{x1, x2, c1, c2, L, L, c_out, 0, in_cl, 0, nullptr, B + b, B + gamma, B + beta, add_c, add_t, y}, c_out,
+                   mfma_slice(c_out));
     int ct = n >= 768 ? 4 : n >= 192 ? 2 : 1, cs = c_out;
     auto nconv = [&]() { return (L / 4) * (cs / ct); };
     while (nconv() > 64 && (cs / 2) % cpg == 0) cs /= 2;
@@ -370,23 +792,27 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     return 0;
   };
   auto plain = [&](int mode, int k, const float* x1, int c1, const float* x2, int c2, int in_cl, int l_in, int l_out, int c_out,
-                   int out_cl, size_t w, size_t b, float* y) {
+                   int out_cl, size_t w, size_t b, float* y, const MPack& mp) -> int {
+    if (!out_cl && mconv_ok(mp, c1, c2, in_cl))
+      return mconv(mode == 1 ? 3 : k == 3 ? 2 : 1, mp, ConvArgs{x1, x2, c1, c2, l_in, l_out, c_out, 0, in_cl, 0, nullptr, B + b, nullptr,
+                                                                 nullptr, nullptr, nullptr, y}, mode == 1 ? 2 * c_out : c_out, 16);
     const int ns = c_out >= 32 ? slices(c_out, 8, 1 << 30) : 1;
     ConvArgs a{x1, x2, c1, c2, l_in, l_out, c_out, c_out / ns, in_cl, out_cl, B + w, B + b, nullptr, nullptr, nullptr, nullptr, y};
     const size_t shm = (size_t)l_in * (c1 + c2) * sizeof(float);
     if (mode == 1) hipLaunchKernelGGL((conv_plain_kernel<1, 4, 2>), dim3(n, ns), dim3(256), shm, st, a);
     else if (k == 3) hipLaunchKernelGGL((conv_plain_kernel<0, 3, 2>), dim3(n, ns), dim3(256), shm, st, a);
     else hipLaunchKernelGGL((conv_plain_kernel<0, 1, 1>), dim3(n, ns), dim3(256), shm, st, a);
+    return 0;
   };
   // one ResidualTemporalBlock (layers.py:346-358): (x1 | x2) [cin][L] -> out [cout][L]
   auto rtb = [&](const LRtb& R, const float* x1, int c1, const float* x2, int c2, int in_cl, int L, float* out) -> int {
-    if (int rc = block5(x1, c1, x2, c2, in_cl, L, R.cout, R.wa, R.ba, R.ga, R.bea, tt + R.tb_off, nullptr, tmp)) return rc;
+    if (int rc = block5(x1, c1, x2, c2, in_cl, L, R.cout, R.wa, R.ba, R.ga, R.bea, tt + R.tb_off, nullptr, tmp, R.ma)) return rc;
     const float* res = x1;                                   // identity residual (cin == cout: never a concatenated input)
     if (R.res) {
-      plain(0, 1, x1, c1, x2, c2, in_cl, L, L, R.cout, 0, R.wr, R.br, resb);
+      if (int rc = plain(0, 1, x1, c1, x2, c2, in_cl, L, L, R.cout, 0, R.wr, R.br, resb, R.mr)) return rc;
       res = resb;
     }
-    return block5(tmp, R.cout, nullptr, 0, 0, L, R.cout, R.wb, R.bb, R.gb, R.beb, nullptr, res, out);
+    return block5(tmp, R.cout, nullptr, 0, 0, L, R.cout, R.wb, R.bb, R.gb, R.beb, nullptr, res, out, R.mb);
   };
   const int NL = s.n_levels;
   int L = H, cin = 4;
@@ -398,7 +824,7 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     if (int rc = rtb(u->rtb[2 * i], xin, cin, nullptr, 0, i == 0, L, mid)) return rc;   // (level 0 reads the trajectory: channels-last)
     if (int rc = rtb(u->rtb[2 * i + 1], mid, c, nullptr, 0, 0, L, level_out)) return rc;
     if (i < NL - 1) {
-      plain(0, 3, level_out, c, nullptr, 0, 0, L, L / 2, c, 0, u->down_w[i], u->down_b[i], in[i & 1]);
+      if (int rc = plain(0, 3, level_out, c, nullptr, 0, 0, L, L / 2, c, 0, u->down_w[i], u->down_b[i], in[i & 1], u->down_m[i])) return rc;
       xin = in[i & 1];
       L /= 2;
     }
@@ -413,12 +839,12 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     const int din = s.dims[NL - 1 - i], dout = s.dims[NL - i];
     if (int rc = rtb(u->rtb[2 * NL + 2 * i], in[0], dout, skip[NL - 2 - i], dout, 0, L, mid)) return rc;
     if (int rc = rtb(u->rtb[2 * NL + 2 * i + 1], mid, din, nullptr, 0, 0, L, in[1])) return rc;
-    plain(1, 4, in[1], din, nullptr, 0, 0, L, 2 * L, din, 0, u->up_w[i], u->up_b[i], in[0]);
+    if (int rc = plain(1, 4, in[1], din, nullptr, 0, 0, L, 2 * L, din, 0, u->up_w[i], u->up_b[i], in[0], u->up_m[i])) return rc;
     L *= 2;
   }
   // final_conv (temporal_unet.py:104-110); with one level there are no ups and L is still 64
-  if (int rc = block5(in[0], s.uid, nullptr, 0, 0, L, s.uid, u->fin_w5, u->fin_b5, u->fin_g, u->fin_be, nullptr, nullptr, mid)) return rc;
-  plain(0, 1, mid, s.uid, nullptr, 0, 0, L, L, 4, 1, u->fin_w1, u->fin_b1, eps);
+  if (int rc = block5(in[0], s.uid, nullptr, 0, 0, L, s.uid, u->fin_w5, u->fin_b5, u->fin_g, u->fin_be, nullptr, nullptr, mid, u->fin_m)) return rc;
+  if (int rc = plain(0, 1, mid, s.uid, nullptr, 0, 0, L, L, 4, 1, u->fin_w1, u->fin_b1, eps, MPack{})) return rc;
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }

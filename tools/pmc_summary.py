@@ -13,7 +13,10 @@ with open(path) as f:
             continue
         name = row.get("Kernel_Name", "")
         m = re.search(r"(chain_kernel|rtb_kernel|conv_kernel)<mmd::(?:Rtb|Chain)?Cfg<([^>]*)>", name)
-        key = f"{m.group(1)}<{m.group(2).replace(' ', '')}>" if m else re.sub(r"\(.*", "", name)[:60]
+        plain = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        key = f"{m.group(1)}<{m.group(2).replace(' ', '')}>" if m else re.sub(r"\(.*", "", plain)[:48]
+        if "mconv" in key:                                   # the layered path's kernel: one line per launch shape
+            key += f" grid {row.get('Grid_Size', '?')}"
         acc[key].append(float(row["Counter_Value"]))
 print(f"# {counter}: mean per dispatch (raw counter units as reported by rocprofv3)")
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
