@@ -52,9 +52,13 @@ struct ConvArgs {
   const float* add_c;                 // per-channel addend after Mish (time bias), or NULL
   const float* add_t;                 // [n][c_out][l_out] addend after Mish (residual), or NULL
   float* y;                           // [n][c_out][l_out]
+  int in_bl;                          // x1 is a blocked activation tensor [n][c1 / 8][l_in][8] of the matrix-pipe path (mconv_kernel)
 };
 
+// element offset of (sample, channel c, position l) in a blocked activation tensor of C channels
+__device__ __forceinline__ size_t bl_off(size_t smp, int C, int L, int c, int l) { return ((smp * (C >> 3) + (c >> 3)) * L + l) * 8 + (c & 7); }
 __device__ __forceinline__ float load_in(const ConvArgs& a, size_t n, int c, int l) {
+  if (a.in_bl) return a.x1[bl_off(n, a.c1, a.l_in, c, l)];
   if (a.in_cl) return a.x1[(n * a.l_in + l) * a.c1 + c];
   return c < a.c1 ? a.x1[(n * a.c1 + c) * a.l_in + l] : a.x2[(n * a.c2 + (c - a.c1)) * a.l_in + l];
 }
@@ -173,25 +177,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 }
 
 // The layer-by-layer path ON THE MATRIX PIPE (round 5): fp32 arithmetic as the two-piece fp16 split of f16x2.h (three
-// v_mfma_f32_16x16x32_f16 per product, fp32 accumulate -- the fused kernel's building blocks), for every layer whose GEMM columns are
-// whole 16-column n-tiles.  KIND 0: Conv1dBlock (conv k5 + GroupNorm + Mish + addends); 1: Conv1d k1 (the 1x1 residual); 2: Conv1d k3
-// stride 2 (Downsample1d); 3: ConvTranspose1d(k4, s2, p1) (Upsample1d) as a k3 conv with 2 c_out columns (column 2 co + parity: out[2 m] =
-// in[m - 1] W3 + in[m] W1, out[2 m + 1] = in[m] W2 + in[m + 1] W0) and an interleaving store.
+// v_mfma_f32_16x16x32_f16 per product, fp32 accumulate -- the fused kernel's building blocks), for a network whose every layer has GEMM
+// columns in whole 16-column n-tiles.  KIND 0: Conv1dBlock (conv k5 + GroupNorm + Mish + addends); 1: Conv1d k1 (the 1x1 residual); 2:
+// Conv1d k3 stride 2 (Downsample1d); 3: ConvTranspose1d(k4, s2, p1) (Upsample1d) as a k3 conv with 2 c_out columns (column 2 co + parity:
+// out[2 m] = in[m - 1] W3 + in[m] W1, out[2 m + 1] = in[m] W2 + in[m + 1] W0) and an interleaving store.
+// ACTIVATIONS between the layers are stored BLOCKED, [n][C / 8][L][8 channels]: the 8 channels of a position are 32 contiguous bytes, so
+// the staging below reads whole rows of its LDS layout (two 16-byte loads) and the epilogues write runs of channels (the trajectory in
+// and eps out keep the caller's channels-last layout).
 // GEMM: M = (sample, output row) -- a workgroup (4 waves) takes SPW = 64 / LR consecutive samples (LR = rows of a sample: l_in, or l_in / 2
 // for the strided conv), so M is always 64 rows = four M tiles and a weight fragment is used on all of them, as in the fused kernel; N = a
 // slice of cs in {16, 32, 64, 128} columns (blockIdx.y; whole GroupNorm groups for KIND 0); K = taps x input channels, in CHUNKS of kch <=
 // 128 channels:
-//   * per chunk the samples' [chunk channels][l_in] fp32 rows go to LDS as fp16 pieces in ROW form [piece][channel block b = KCj g + kc][row
-//     = (l_in + 4) sample + 2 + position][8 channels] (16 bytes per (block, row): an A fragment is one ds_read_b128; two zero rows either
-//     side of a sample are the conv's padding, a tap is a row offset, the stride a row step) under a dynamic PER-SAMPLE power-of-two scale
-//     from the exact maximum of the sample's whole input (dyn_scale); the accumulators live across the chunks;
+//   * per chunk the samples' rows go to LDS as fp16 pieces in ROW form [piece][channel block b = KCj g + kc][row = (l_in + 4) sample + 2 +
+//     position][8 channels] (16 bytes per (block, row): an A fragment is one ds_read_b128; two zero rows either side of a sample are the
+//     conv's padding, a tap is a row offset, the stride a row step) under a dynamic power-of-two scale PER SAMPLE AND CHUNK from the exact
+//     maximum of the staged values (dyn_scale; the maximum is taken on the registers the loads land in, through LDS atomics -- no second
+//     pass over the input).  The accumulators live across the chunks in units of the current chunk's scale: a new chunk multiplies them
+//     by the ratio of the two scales (a power of two: exact);
 //   * weights: host-packed per layer and chunk in B-fragment order [chunk][n-tile][tap][kc][piece][lane] x 16 bytes with per-column
 //     power-of-two scales (pack_rd / rd_col_scales of f16x2.h), streamed from L2 through a register ring of RD steps (RD divides a chunk's
 //     steps: 5 taps, 3 taps, or the k1 conv's chunk always padded to four K chunks);
 //   * a wave takes NTW n-tiles x MTW M tiles (cs <= 32: the waves that share an n-tile split the M tiles);
-//   * KIND 0: the accumulators go -- scaled back per channel and sample, bias added -- to an LDS tile that re-uses the slab, and the
-//     GroupNorm + Mish + addend tail works on it per (sample, group) with conv5_block_kernel's two-pass statistics; the plain convs store
-//     from the accumulators (a lane holds four consecutive positions of one column).
+//   * KIND 0: the accumulators go -- scaled back per channel and sample, bias added -- to an LDS tile that re-uses the slab; a thread then
+//     owns 4 rows x cs / 16 adjacent channels of it in registers: the GroupNorm statistics (two passes: mean, then squared deviations) are
+//     sums over those and a FIXED balanced tree over the channel index, then over the rows (lanes, then waves), so the bits do not depend
+//     on the slicing; normalise + Mish + addend as the fused kernel (gn_mish.h).  The plain convs store from the accumulators.
 // A sample's arithmetic does not depend on the batch it sits in, on its place in the workgroup or on the slicing.
 constexpr int MCONV_KCH = 128;                     // input channels staged per chunk (at most)
 constexpr int MCONV_MAX_CHUNKS = 8;                // <= 1024 input channels
@@ -204,11 +214,37 @@ struct MConvArgs {
   unsigned stride;                    // (every chunk but the last is kch channels wide: one stride)
   int n_chunks, kch, n;
 };
+// -DMCONV_TIMING (tools/dbg/mconv_phases.py builds it): wave 0 of every workgroup adds its clock64() phase times to a table indexed by
+// (KIND, log2 l_in - 3, NTW * MTW): staging loads + maxima, conversion, GEMM, exchange, statistics, tail, whole; read and cleared by
+// mmd_debug_mconv_clocks
+#ifdef MCONV_TIMING
+__device__ unsigned long long g_mconv_clk[4][4][9][8];
+#define MCONV_T(i) if (tid == 0) { const long long now_ = clock64(); clk_[i] += now_ - last_; last_ = now_; }
+#else
+#define MCONV_T(i)
+#endif
 template <int KIND> struct MKind;
 template <> struct MKind<0> { static constexpr int K = 5, S = 1, RD = 5, NR = 3; };
 template <> struct MKind<1> { static constexpr int K = 1, S = 1, RD = 4, NR = 3; };
 template <> struct MKind<2> { static constexpr int K = 3, S = 2, RD = 3, NR = 5; };
 template <> struct MKind<3> { static constexpr int K = 3, S = 1, RD = 3, NR = 3; };
+// V adjacent floats (V = 1, 2, 4 or 8) of a blocked tensor from / to global memory (a run inside one 32-byte block: 4 V-byte aligned)
+template <int V> __device__ __forceinline__ void ld_run(float (&d)[V], const float* p) {
+  if constexpr (V == 1) d[0] = p[0];
+  else if constexpr (V == 2) { const float2 q = *reinterpret_cast<const float2*>(p); d[0] = q.x; d[1] = q.y; }
+  else {
+#pragma unroll
+    for (int j = 0; j < V; j += 4) { const float4 q = *reinterpret_cast<const float4*>(p + j); d[j] = q.x; d[j + 1] = q.y; d[j + 2] = q.z; d[j + 3] = q.w; }
+  }
+}
+template <int V> __device__ __forceinline__ void st_run(float* p, const float (&d)[V]) {
+  if constexpr (V == 1) p[0] = d[0];
+  else if constexpr (V == 2) *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+  else {
+#pragma unroll
+    for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(p + j) = make_float4(d[j], d[j + 1], d[j + 2], d[j + 3]);
+  }
+}
 // NTW n-tiles x MTW M tiles per wave: (2, 4) for a slice of 128 columns, (1, 4) for 64, (1, 2) for 32, (1, 1) for 16 -- compile-time, so
 // that the weight ring's slots are registers with exact s_waitcnt counts (with run-time tile counts the compiler drained every load)
 template <int NTW, int MTW, int KIND>
@@ -221,62 +257,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
   const int lsh = lsh_in - (S - 1), LR = 1 << lsh;         // GEMM rows of a sample
   const int SPW = 64 >> lsh, RS = L + 4, SROWS = SPW * RS;  // samples per workgroup, slab rows per sample / in all
   const int s0 = blockIdx.x * SPW, c0 = blockIdx.y * a.cs;
+#ifdef MCONV_TIMING
+  long long clk_[6] = {}, last_ = clock64();
+  const long long first_ = last_;
+#endif
   char* const slab = smem;
-  // LDS: [slab: 2 pieces x (kch / 8) blocks x SROWS x 16 B | KIND 0: the output tile [cs][OST] aliases it] [stat: 2 x groups x samples,
-  // 8 + 8 scales, 8 partial maxima]
+  // LDS: [slab: 2 pieces x (kch / 8) blocks x SROWS x 16 B | KIND 0: the output tile [cs][OST] aliases it] [red: 4 waves x 16 partial sums]
+  // [smax: 2 x 8 per-sample maxima (as uint: non-negative floats order like their bits), alternating between the chunks]
   const int slab_bytes = 2 * (m.kch / 8) * SROWS * 16, outs_bytes = KIND == 0 ? a.cs * OST * 4 : 0;
-  float* const stat = reinterpret_cast<float*>(smem + (slab_bytes > outs_bytes ? slab_bytes : outs_bytes));
-  float* const scale_inv = stat + 2 * N_GROUPS * 8;        // [8] inverse dynamic scale per sample
-  float* const scale_s = scale_inv + 8;                    // [8] dynamic scale per sample
-  float* const pmx = scale_s + 8;                          // [8] partial maxima
-  // ---- per-sample maxima of the WHOLE input -> dynamic scales: a sample's input is one contiguous run per source ([c1][L] of x1, [c2][L]
-  // of x2; channels-last the same run); 4 / SPW waves share a sample (>= 4 samples: a wave takes whole samples)
-  {
-    const int parts = SPW >= 4 ? 1 : 4 / SPW;
-    for (int u = wave; u < SPW * parts; u += 4) {
-      const int sm = u / parts, pt = u - sm * parts, smp = s0 + sm;
-      float mx = 0.f;
-      if (smp < m.n) {
-        auto scan = [&](const float* src, int count4) {    // eight 16-byte loads in flight per lane
-          const float4* const p = reinterpret_cast<const float4*>(src);
-          const int lo = count4 * pt / parts, hi = count4 * (pt + 1) / parts;
-          for (int i0 = lo + lane; i0 < hi; i0 += 512) {
-            float4 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = i0 + 64 * q < hi ? p[i0 + 64 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[q].x), fabsf(v[q].y))), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
-          }
-        };
-        scan(a.x1 + (size_t)smp * a.c1 * L, (a.c1 << lsh_in) >> 2);
-        if (a.c2) scan(a.x2 + (size_t)smp * a.c2 * L, (a.c2 << lsh_in) >> 2);
-      }
-      for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-      if (lane == 0) pmx[u] = mx;
-    }
-    __syncthreads();
-    if (tid < SPW) {
-      float mx = pmx[tid * parts];
-      for (int q = 1; q < parts; ++q) mx = fmaxf(mx, pmx[tid * parts + q]);
-      const DynScale ds = dyn_scale(mx);
-      scale_s[tid] = ds.s;
-      scale_inv[tid] = ds.inv;
-    }
-    __syncthreads();
-  }
-  // ---- this thread's staging rows (fixed over the chunks): rows tid % 32 + 32 i of the slab -> (sample, position); the element offsets
-  // and the sample's scale (0, and the first element of the batch as the address: a padding row, a row past the slab or past the batch)
-  int st_smp[NR], st_l[NR];
-  float st_sc[NR];
-  bool st_row[NR];
+  float* const red = reinterpret_cast<float*>(smem + (slab_bytes > outs_bytes ? slab_bytes : outs_bytes));
+  unsigned* const smax = reinterpret_cast<unsigned*>(red + 64);
+  if (tid < 16) smax[tid] = 0u;
+  // ---- this thread's staging rows (fixed over the chunks): rows tid % 32 + 32 i of the slab -> (sample, position); a padding row, a row
+  // past the slab or past the batch reads the first element of the batch and is not used
+  int st_smp[NR], st_l[NR], st_sm[NR];
+  bool st_row[NR], st_ok[NR];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int row = (tid & 31) + 32 * i, sm = row / RS, l = row - sm * RS - 2, smp = s0 + sm;
     st_row[i] = row < SROWS;
-    const bool in = st_row[i] && smp < m.n && l >= 0 && l < L;
-    st_sc[i] = in ? scale_s[sm] : 0.f;
-    st_smp[i] = in ? smp : 0;
-    st_l[i] = in ? l : 0;
+    st_ok[i] = st_row[i] && smp < m.n && l >= 0 && l < L;
+    st_sm[i] = st_row[i] ? sm : 0;
+    st_smp[i] = st_ok[i] ? smp : 0;
+    st_l[i] = st_ok[i] ? l : 0;
   }
   // ---- GEMM over the channel chunks
   constexpr int WPT = 4 / MTW;                             // waves that share an n-tile (MTW < 4: they split its M tiles)
@@ -284,20 +287,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
   const int mt0 = wave % WPT;                              // its M tiles: mt0, mt0 + WPT, ...
   const int row = lane & 15, g = lane >> 4;
   int arow[MTW];                                           // slab row of the lane's A row in its M tile i at tap 0: position S lo - K / 2
+  int csm[MTW];                                            // sample (of the workgroup) of the lane's four C/D rows 4 g .. 4 g + 3 of M tile i
+  float inv_prev[MTW];                                     // 1 / (the current chunk's scale) of that sample
 #pragma unroll
   for (int i = 0; i < MTW; ++i) {
     const int r64 = 16 * (mt0 + i * WPT) + row;            // (sample, output row) of the 64
     arow[i] = (r64 >> lsh) * RS + S * (r64 & (LR - 1)) + 2 - K / 2;
+    csm[i] = (16 * (mt0 + i * WPT) + 4 * g) >> lsh;
+    inv_prev[i] = 1.f;
   }
   f32x4 acc[NTW][MTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
 #pragma unroll
     for (int i = 0; i < MTW; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                         // smax is zero
   for (int ch = 0; ch < m.n_chunks; ++ch) {
     // (the k1 conv's chunk is always four K chunks wide: its four steps are the ring)
     const int c_lo = ch * m.kch, cc = K == 1 ? m.kch : min(m.kch, cin - c_lo), KCj = (cc + 31) / 32, NB = 4 * KCj;
     const int PS = NB * SROWS * 16;
+    unsigned* const mxs = smax + 8 * (ch & 1);
     if (ch) __syncthreads();                               // every wave is done reading the previous chunk
     // the weight ring's first steps are requested before the staging: their latency passes under it
     const int steps = K * KCj;                             // (tap, kc), tap-major: a multiple of the ring's RD slots
@@ -314,33 +323,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     };
 #pragma unroll
     for (int j = 0; j < RD; ++j) load_b(j, j);
-    // stage: item = (channel block, slab row): 8 channels of one position, both pieces; a thread has <= 2 blocks x NR rows.  All of a
-    // thread's loads are issued before the first is used (a padding row reads a valid address and is multiplied by its zero scale)
+    // stage: item = (channel block, slab row): the 8 channels of one position (32 contiguous bytes of a blocked tensor), both pieces; a
+    // thread has <= 2 blocks x NR rows.  All of a thread's loads are issued before the first is used
     {
-      float v[2][NR][8];
+      float4 v[2][NR][2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int blk = (tid >> 5) + 8 * h, c = c_lo + 8 * blk;   // (c1 is a multiple of 8: the block lies in one source)
         if (blk >= NB) continue;
-        if (a.in_cl) {                                     // the trajectory [n][L][4]: channels 0 .. 3 are one 16-byte load
+        const bool live = a.in_cl ? c == 0 : c < cin, first = c < a.c1;
+        const float* const src = a.in_cl ? a.x1 : first ? a.x1 + (size_t)c * L : a.x2 + (size_t)(c - a.c1) * L;
+        const int cw = first ? a.c1 : a.c2;                // channels of the source: a sample is cw x L elements
 #pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            const float4 q = c == 0 ? *reinterpret_cast<const float4*>(a.x1 + ((size_t)st_smp[i] * L + st_l[i]) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[h][i][0] = q.x; v[h][i][1] = q.y; v[h][i][2] = q.z; v[h][i][3] = q.w;
-            v[h][i][4] = v[h][i][5] = v[h][i][6] = v[h][i][7] = 0.f;
-          }
-        } else {
-          const bool live = c < cin, first = c < a.c1;
-          const float* const src = first ? a.x1 + (size_t)c * L : a.x2 + (size_t)(c - a.c1) * L;
-          const int cw = first ? a.c1 : a.c2;              // channels of the source: a sample is cw x L elements
-#pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            const float* const q = live ? src + (size_t)st_smp[i] * cw * L + st_l[i] : a.x1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[h][i][j] = live ? q[j << lsh_in] : 0.f;
-          }
+        for (int i = 0; i < NR; ++i) {
+          // blocked: ((smp cw / 8 + c / 8) L + l) 8; the trajectory [n][L][4]: channels 0 .. 3 are one 16-byte load
+          const float* const q = !live ? a.x1 : a.in_cl ? src + ((size_t)st_smp[i] * L + st_l[i]) * 4 : src + (size_t)st_smp[i] * cw * L + st_l[i] * 8;
+          v[h][i][0] = live ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[h][i][1] = live && !a.in_cl ? *reinterpret_cast<const float4*>(q + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
+      // the samples' maxima over the chunk
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        float mx = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if ((tid >> 5) + 8 * h >= NB) continue;
+          const float4 p = v[h][i][0], q = v[h][i][1];
+          mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), fabsf(p.w))),
+                               fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)))));
+        }
+        if (st_ok[i] && mx > 0.f) atomicMax(mxs + st_sm[i], __float_as_uint(mx));
+      }
+      __syncthreads();
+      MCONV_T(0)
+      if (tid < 8) smax[8 * ((ch + 1) & 1) + tid] = 0u;    // (the other chunk's maxima: every thread has used them by now)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int blk = (tid >> 5) + 8 * h;
@@ -348,16 +365,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           if (!st_row[i]) continue;
-          const float sc = st_sc[i];
-          const F16Pair p0 = f16_split2(v[h][i][0] * sc, v[h][i][1] * sc), p1 = f16_split2(v[h][i][2] * sc, v[h][i][3] * sc),
-                        p2 = f16_split2(v[h][i][4] * sc, v[h][i][5] * sc), p3 = f16_split2(v[h][i][6] * sc, v[h][i][7] * sc);
+          const float sc = st_ok[i] ? dyn_scale(__uint_as_float(mxs[st_sm[i]])).s : 0.f;
+          const float4 p = st_ok[i] ? v[h][i][0] : make_float4(0.f, 0.f, 0.f, 0.f), q = st_ok[i] ? v[h][i][1] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const F16Pair p0 = f16_split2(p.x * sc, p.y * sc), p1 = f16_split2(p.z * sc, p.w * sc), p2 = f16_split2(q.x * sc, q.y * sc),
+                        p3 = f16_split2(q.z * sc, q.w * sc);
           const size_t o = ((size_t)blk * SROWS + (tid & 31) + 32 * i) * 16;
           *reinterpret_cast<uint4*>(slab + o) = make_uint4(p0.hi, p1.hi, p2.hi, p3.hi);
           *reinterpret_cast<uint4*>(slab + PS + o) = make_uint4(p0.lo, p1.lo, p2.lo, p3.lo);
         }
       }
     }
+    // the accumulators pass into the new chunk's units
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const DynScale ds = dyn_scale(__uint_as_float(mxs[csm[i]]));
+      if (ch) {
+        const float r = ds.s * inv_prev[i];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t][i] *= r;
+      }
+      inv_prev[i] = ds.inv;
+    }
     __syncthreads();
+    MCONV_T(1)
     {
       auto group = [&](int base, auto refill) {            // RD steps: slot j holds step base + j and is refilled with step base + j + RD
 #pragma unroll
@@ -381,47 +411,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
       for (int base = 0; base < steps - RD; base += RD) group(base, std::true_type{});
       group(steps - RD, std::false_type{});
     }
+    MCONV_T(2)
   }
   if (KIND != 0) {
     // ---- plain convs: column scale x sample scale, + bias, stored from the accumulators (C/D layout: lane = column lane & 15, rows 4 g ..
-    // 4 g + 3 of the M tile = four consecutive output rows of one sample)
+    // 4 g + 3 of the M tile = four consecutive output rows of one sample) into the blocked output: the 16 lanes of a row write 64
+    // contiguous bytes (two channel blocks; the transposed conv: one block at the positions 2 m and 2 m + 1)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int col = c0 + 16 * (nt0 + t) + row, co = KIND == 3 ? col >> 1 : col;
       const float kc_ = m.isc[col], bs = a.bias[co];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
-        const int r64 = 16 * (mt0 + i * WPT) + 4 * g, sm = r64 >> lsh, lo = r64 & (LR - 1), smp = s0 + sm;
-        const float k = kc_ * scale_inv[sm];
-        const float4 v = make_float4(fmaf(acc[t][i][0], k, bs), fmaf(acc[t][i][1], k, bs), fmaf(acc[t][i][2], k, bs), fmaf(acc[t][i][3], k, bs));
-        if (KIND == 3) {
-          // columns 2 co (even lane: out[2 m]) and 2 co + 1 (odd lane: out[2 m + 1]) sit in neighbouring lanes: the even lane stores
-          // out[2 lo .. 2 lo + 3], the odd lane out[2 lo + 4 .. 2 lo + 7]
-          const float ox = __shfl_xor(v.x, 1), oy = __shfl_xor(v.y, 1), oz = __shfl_xor(v.z, 1), ow = __shfl_xor(v.w, 1);
-          const bool odd = lane & 1;
-          const float4 w = odd ? make_float4(oz, v.z, ow, v.w) : make_float4(v.x, ox, v.y, oy);
-          if (smp < m.n) *reinterpret_cast<float4*>(a.y + ((size_t)smp * a.c_out + co) * a.l_out + 2 * lo + (odd ? 4 : 0)) = w;
-        } else if (smp < m.n) {
-          *reinterpret_cast<float4*>(a.y + ((size_t)smp * a.c_out + co) * a.l_out + lo) = v;
-        }
+        const int r64 = 16 * (mt0 + i * WPT) + 4 * g, lo = r64 & (LR - 1), smp = s0 + csm[i];
+        const float k = kc_ * inv_prev[i];
+        if (smp >= m.n) continue;
+        float* const dst = a.y + bl_off(smp, a.c_out, a.l_out, co, KIND == 3 ? 2 * lo + (col & 1) : lo);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(KIND == 3 ? 16 : 8) * e] = fmaf(acc[t][i][e], k, bs);
       }
     }
+#ifdef MCONV_TIMING
+    if (tid == 0) {
+      unsigned long long* t = g_mconv_clk[KIND][lsh_in - 3][NTW * MTW];
+      const long long now = clock64();
+      for (int i = 0; i < 3; ++i) atomicAdd(t + i, (unsigned long long)clk_[i]);
+      atomicAdd(t + 5, (unsigned long long)(now - last_));
+      atomicAdd(t + 6, (unsigned long long)(now - first_));
+      atomicAdd(t + 7, 1ull);
+    }
+#endif
     return;
   }
-  // ---- the tail's global operands are requested now (a thread's items: 4 consecutive positions of channel c, NIT of them), so that
-  // their latency passes under the exchange and the statistics
+  // ---- Conv1dBlock tail.  A thread owns rows 4 rq .. 4 rq + 3 (one sample: rq = tid % 16) x the NIT adjacent channels cl NIT .. of the
+  // slice (cl = tid / 16).  Its global operands are requested now, so that their latency passes under the exchange
   float* const outs = reinterpret_cast<float*>(smem);      // [cs][OST] conv output (64 rows + 4 of padding: conflict-free column writes)
   constexpr int NIT = NTW * MTW;                           // = cs / 16
-  float4 addt[NIT];
-  float gm[NIT], bt[NIT], ac[NIT];
+  const int rq = tid & 15, cl = tid >> 4, r0 = 4 * rq, tsm = r0 >> lsh, tl = r0 & (L - 1), tsmp = s0 + tsm, tc = c0 + cl * NIT;
+  float gm[NIT], bt[NIT], ad[4][NIT];                      // gamma, beta; the addend (time bias per channel, or the residual) per (row, channel)
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
-    const int o4 = tid + 256 * k, c = o4 >> 4, r64 = (o4 & 15) * 4, smp = s0 + (r64 >> lsh), co = c0 + c;
-    gm[k] = a.gamma[co];
-    bt[k] = a.beta[co];
-    ac[k] = a.add_c ? a.add_c[co] : 0.f;
-    addt[k] = (a.add_t && smp < m.n) ? *reinterpret_cast<const float4*>(a.add_t + ((size_t)smp * a.c_out + co) * L + (r64 & (L - 1)))
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[k] = a.gamma[tc + k];
+    bt[k] = a.beta[tc + k];
+  }
+  if (a.add_c) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) ad[0][k] = ad[1][k] = ad[2][k] = ad[3][k] = a.add_c[tc + k];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (a.add_t && tsmp < m.n) {
+        ld_run<NIT>(ad[e], a.add_t + bl_off(tsmp, a.c_out, L, tc, tl + e));
+      } else {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) ad[e][k] = 0.f;
+      }
+    }
   }
   float kc_[NTW], bs_[NTW];
 #pragma unroll
@@ -433,52 +478,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
   // ---- accumulators -> outs[c][r64] (C/D layout: lane = column lane & 15, rows 4 g .. 4 g + 3 of the M tile), scaled back, + bias
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
-    const int cl = 16 * (nt0 + t) + row;
+    const int ocl = 16 * (nt0 + t) + row;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
       const int r64 = 16 * (mt0 + i * WPT) + 4 * g;
-      const float k = kc_[t] * scale_inv[r64 >> lsh], bs = bs_[t];
-      *reinterpret_cast<float4*>(outs + cl * OST + r64) =
+      const float k = kc_[t] * inv_prev[i], bs = bs_[t];
+      *reinterpret_cast<float4*>(outs + ocl * OST + r64) =
           make_float4(fmaf(acc[t][i][0], k, bs), fmaf(acc[t][i][1], k, bs), fmaf(acc[t][i][2], k, bs), fmaf(acc[t][i][3], k, bs));
     }
   }
   __syncthreads();
-  // ---- GroupNorm statistics per (sample, group): cpg channels x L positions (two passes, as conv5_block_kernel)
-  const int cpg = a.c_out / N_GROUPS, ngrp = a.cs / cpg, per = cpg << lsh;
-  for (int w = wave; w < ngrp * SPW; w += 4) {
-    const int gidx = w % ngrp, sm = w / ngrp;
-    const float* blk = outs + gidx * cpg * OST + (sm << lsh);
-    float sum = 0.f;
-    for (int i = lane; i < per; i += 64) sum += blk[(i >> lsh) * OST + (i & (L - 1))];
-    for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);
-    const float mean = sum / (float)per;
-    float q = 0.f;
-    for (int i = lane; i < per; i += 64) {
-      const float d = blk[(i >> lsh) * OST + (i & (L - 1))] - mean;
-      q = fmaf(d, d, q);
+  MCONV_T(3)
+  // ---- GroupNorm statistics of (sample, group): cpg channels x L positions.  The sum of a group is DEFINED as: per channel the four rows
+  // of a quad ((x0 + x1) + (x2 + x3)); a balanced tree over the channel index (within the thread, then lanes 16 and 32 apart, then
+  // waves); then a balanced tree over the sample's row quads (lanes 1, 2, 4, 8 apart) -- whatever the slice width
+  float4 x[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) x[k] = *reinterpret_cast<const float4*>(outs + (cl * NIT + k) * OST + r0);
+  const int cpg = a.c_out / N_GROUPS, clu = cpg / NIT;     // channel lanes (16 apart) per group: 2, 4, 8 or 16
+  auto group_sum = [&](float (&s)[NIT]) -> float {
+#pragma unroll
+    for (int w = 1; w < NIT; w *= 2)
+#pragma unroll
+      for (int k = 0; k < NIT; k += 2 * w) s[k] += s[k + w];
+    float v = s[0];
+    v += __shfl_xor(v, 16);
+    if (clu >= 4) v += __shfl_xor(v, 32);
+    if (clu >= 8) {                                        // the group spans 2 or 4 waves
+      if (lane < 16) red[16 * wave + lane] = v;
+      __syncthreads();
+      const int w0 = clu >= 16 ? 0 : wave & 2;
+      v = red[16 * w0 + rq] + red[16 * (w0 + 1) + rq];
+      if (clu >= 16) v = v + (red[32 + rq] + red[48 + rq]);
+      __syncthreads();
     }
-    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
-    if (lane == 0) {
-      stat[2 * w] = mean;
-      stat[2 * w + 1] = 1.f / sqrtf(q / (float)per + 1e-5f);
-    }
-  }
-  __syncthreads();
-  // ---- normalise + Mish + addends -> y [n][c_out][L]
+    v += __shfl_xor(v, 1);
+    if (L >= 16) v += __shfl_xor(v, 2);
+    if (L >= 32) v += __shfl_xor(v, 4);
+    if (L >= 64) v += __shfl_xor(v, 8);
+    return v;
+  };
+  const float per = (float)(cpg << lsh);
+  float s[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) s[k] = (x[k].x + x[k].y) + (x[k].z + x[k].w);
+  const float mean = group_sum(s) / per;
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
-    const int o4 = tid + 256 * k, c = o4 >> 4, r64 = (o4 & 15) * 4, sm = r64 >> lsh, smp = s0 + sm;
-    if (smp >= m.n) continue;
-    const int w = sm * ngrp + c / cpg;
-    const float4 x = *reinterpret_cast<const float4*>(outs + c * OST + r64);
-    // (the fused kernel's GroupNorm affine + Mish + addend of gn_mish.h: one of the two addends is absent -- the time bias follows an
-    // RTB's first block, the residual its second)
-    const GnCoef cf = gn_coef(stat[2 * w], stat[2 * w + 1], gm[k], bt[k]);
-    const f32x2_t lo = gn_mish2(f32x2_t{x.x, x.y}, cf, f32x2_t{ac[k] + addt[k].x, ac[k] + addt[k].y});
-    const f32x2_t hi = gn_mish2(f32x2_t{x.z, x.w}, cf, f32x2_t{ac[k] + addt[k].z, ac[k] + addt[k].w});
-    const float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
-    *reinterpret_cast<float4*>(a.y + ((size_t)smp * a.c_out + c0 + c) * L + (r64 & (L - 1))) = v;
+    const float d0 = x[k].x - mean, d1 = x[k].y - mean, d2 = x[k].z - mean, d3 = x[k].w - mean;
+    s[k] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
   }
+  const float rstd = 1.f / sqrtf(group_sum(s) / per + 1e-5f);
+  MCONV_T(4)
+  // ---- normalise + Mish + addend (the fused kernel's arithmetic, gn_mish.h) -> y, blocked: a row's NIT channels are one run
+  if (tsmp < m.n) {
+    float o[4][NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const GnCoef cf = gn_coef(mean, rstd, gm[k], bt[k]);
+      const f32x2_t lo = gn_mish2(f32x2_t{x[k].x, x[k].y}, cf, f32x2_t{ad[0][k], ad[1][k]});
+      const f32x2_t hi = gn_mish2(f32x2_t{x[k].z, x[k].w}, cf, f32x2_t{ad[2][k], ad[3][k]});
+      o[0][k] = lo.x; o[1][k] = lo.y; o[2][k] = hi.x; o[3][k] = hi.y;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) st_run<NIT>(a.y + bl_off(tsmp, a.c_out, L, tc, tl + e), o[e]);
+  }
+#ifdef MCONV_TIMING
+  if (tid == 0) {
+    unsigned long long* t = g_mconv_clk[KIND][lsh_in - 3][NTW * MTW];
+    const long long now = clock64();
+    for (int i = 0; i < 5; ++i) atomicAdd(t + i, (unsigned long long)clk_[i]);
+    atomicAdd(t + 5, (unsigned long long)(now - last_));
+    atomicAdd(t + 6, (unsigned long long)(now - first_));
+    atomicAdd(t + 7, 1ull);
+  }
+#endif
 }
 
 // MODE 0: Conv1d, K taps, stride S, padding K / 2.  MODE 1: ConvTranspose1d(k4, s2, p1): out[2 m] = in[m - 1] W3 + in[m] W1,
@@ -625,6 +699,7 @@ struct LayeredUnet {
   size_t down_w[MAX_LEVELS - 1], down_b[MAX_LEVELS - 1], up_w[MAX_LEVELS - 1], up_b[MAX_LEVELS - 1];
   size_t fin_w5, fin_b5, fin_g, fin_be, fin_w1, fin_b1;
   MPack fin_m, down_m[MAX_LEVELS - 1], up_m[MAX_LEVELS - 1];
+  bool mfma = false;                  // every layer has f16x2 packs: the matrix-pipe kernels with blocked activations; else the vector-ALU kernels
   int per_sample = 0;                 // floats of the largest activation tensor of a sample (64 x unet_input_dim)
 };
 
@@ -669,6 +744,12 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
     u->up_m[i] = push_mfma_up(blob, tensors[s.t_up[i][0]], cu, cu);
   }
   u->fin_m = push_mfma5(blob, tensors[s.t_final[0]], s.uid, s.uid);
+  u->mfma = !kLayeredValu && u->fin_m.w && s.uid % 8 == 0;
+  for (size_t r = 0; r < u->rtb.size(); ++r) {
+    const LRtb& R = u->rtb[r];
+    u->mfma = u->mfma && R.ma.w && R.mb.w && (!R.res || R.mr.w) && (r == 0 || R.cin % 8 == 0);
+  }
+  for (int i = 0; i < s.n_levels - 1; ++i) u->mfma = u->mfma && u->down_m[i].w && u->up_m[i].w;
   u->fin_w5 = push_wt(blob, tensors[s.t_final[0]], s.uid, s.uid, 5, false);
   u->fin_b5 = push_v(blob, tensors[s.t_final[1]], s.uid);
   u->fin_g = push_v(blob, tensors[s.t_final[2]], s.uid);
@@ -742,7 +823,7 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   // a layer on the matrix pipe (mconv_kernel): a workgroup = 64 / (rows of a sample) samples x a slice of <= 128 of the GEMM's columns;
   // narrower slices (down to `unit`: whole n-tiles, for a Conv1dBlock whole GroupNorm groups) while the launch has fewer than 3
   // workgroups per CU
-  auto mconv_ok = [&](const MPack& mp, int c1, int c2, int in_cl) { return mp.w && !kLayeredValu && (in_cl ? c1 == 4 && !c2 : c1 % 8 == 0); };
+  auto mconv_ok = [&](const MPack& mp, int c1, int c2, int in_cl) { return u->mfma && mp.w && (in_cl ? c1 == 4 && !c2 : c1 % 8 == 0 && c2 % 8 == 0); };
   auto mconv = [&](int kind, const MPack& mp, ConvArgs c, int cols, int unit) -> int {
     const int rows = kind == 2 ? c.l_in / 2 : c.l_in, spw = 64 / rows, n_wg = (n + spw - 1) / spw;
     int cs = 0;                                            // the widest slice that leaves >= 768 workgroups, else the narrowest there is
@@ -772,9 +853,11 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   auto block5 = [&](const float* x1, int c1, const float* x2, int c2, int in_cl, int L, int c_out, size_t w, size_t b, size_t gamma,
                     size_t beta, const float* add_c, const float* add_t, float* y, const MPack& mp) -> int {
     const int cpg = c_out / N_GROUPS;
-    if (mconv_ok(mp, c1, c2, in_cl))
+    if (u->mfma) {
+      MMD_REQUIRE(mconv_ok(mp, c1, c2, in_cl), "layered_forward: a Conv1dBlock of %d -> %d channels has no matrix-pipe form", c1 + c2, c_out);
       return mconv(0, mp, ConvArgs{x1, x2, c1, c2, L, L, c_out, 0, in_cl, 0, nullptr, B + b, B + gamma, B + beta, add_c, add_t, y}, c_out,
                    mfma_slice(c_out));
+    }
     int ct = n >= 768 ? 4 : n >= 192 ? 2 : 1, cs = c_out;
     auto nconv = [&]() { return (L / 4) * (cs / ct); };
     while (nconv() > 64 && (cs / 2) % cpg == 0) cs /= 2;
@@ -793,11 +876,14 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   };
   auto plain = [&](int mode, int k, const float* x1, int c1, const float* x2, int c2, int in_cl, int l_in, int l_out, int c_out,
                    int out_cl, size_t w, size_t b, float* y, const MPack& mp) -> int {
-    if (!out_cl && mconv_ok(mp, c1, c2, in_cl))
+    if (u->mfma && !out_cl) {
+      MMD_REQUIRE(mconv_ok(mp, c1, c2, in_cl), "layered_forward: a conv of %d -> %d channels has no matrix-pipe form", c1 + c2, c_out);
       return mconv(mode == 1 ? 3 : k == 3 ? 2 : 1, mp, ConvArgs{x1, x2, c1, c2, l_in, l_out, c_out, 0, in_cl, 0, nullptr, B + b, nullptr,
                                                                  nullptr, nullptr, nullptr, y}, mode == 1 ? 2 * c_out : c_out, 16);
+    }
     const int ns = c_out >= 32 ? slices(c_out, 8, 1 << 30) : 1;
-    ConvArgs a{x1, x2, c1, c2, l_in, l_out, c_out, c_out / ns, in_cl, out_cl, B + w, B + b, nullptr, nullptr, nullptr, nullptr, y};
+    ConvArgs a{x1, x2, c1, c2, l_in, l_out, c_out, c_out / ns, in_cl, out_cl, B + w, B + b, nullptr, nullptr, nullptr, nullptr, y, u->mfma && !in_cl};
+    MMD_REQUIRE(!a.in_bl || !x2, "layered_forward: a blocked input is one tensor");
     const size_t shm = (size_t)l_in * (c1 + c2) * sizeof(float);
     if (mode == 1) hipLaunchKernelGGL((conv_plain_kernel<1, 4, 2>), dim3(n, ns), dim3(256), shm, st, a);
     else if (k == 3) hipLaunchKernelGGL((conv_plain_kernel<0, 3, 2>), dim3(n, ns), dim3(256), shm, st, a);
@@ -850,3 +936,11 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
 }
 
 }  // namespace mmd
+
+#ifdef MCONV_TIMING
+extern "C" __attribute__((visibility("default"))) int mmd_debug_mconv_clocks(unsigned long long* out) {   // [4][4][9][8], cleared after the read
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mmd::g_mconv_clk), sizeof(mmd::g_mconv_clk)) != hipSuccess) return 1;
+  static unsigned long long zero[4 * 4 * 9 * 8];
+  return hipMemcpyToSymbol(HIP_SYMBOL(mmd::g_mconv_clk), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
