@@ -28,6 +28,9 @@
 #include "f16x2.h"
 #include "gn_mish.h"
 #include <type_traits>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "unet_spec.h"
 
 namespace mmd {
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 // ACTIVATIONS between the layers are stored BLOCKED, [n][C / 8][L][8 channels]: the 8 channels of a position are 32 contiguous bytes, so
 // the staging below reads whole rows of its LDS layout (two 16-byte loads) and the epilogues write runs of channels (the trajectory in
 // and eps out keep the caller's channels-last layout).
-// GEMM: M = (sample, output row) -- a workgroup (4 waves) takes SPW = 64 / LR consecutive samples (LR = rows of a sample: l_in, or l_in / 2
-// for the strided conv), so M is always 64 rows = four M tiles and a weight fragment is used on all of them, as in the fused kernel; N = a
+// GEMM: M = (sample, output row) -- an ITEM is SPW = 64 / LR consecutive samples (LR = rows of a sample: l_in, or l_in / 2 for the strided
+// conv), so M is always 64 rows = four M tiles and a weight fragment is used on all of them, as in the fused kernel; N = a
 // slice of cs in {16, 32, 64, 128} columns (blockIdx.y; whole GroupNorm groups for KIND 0); K = taps x input channels, in CHUNKS of kch <=
 // 128 channels:
 //   * per chunk the samples' rows go to LDS as fp16 pieces in ROW form [piece][channel block b = KCj g + kc][row = (l_in + 4) sample + 2 +
@@ -202,6 +205,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 //     owns 4 rows x cs / 16 adjacent channels of it in registers: the GroupNorm statistics (two passes: mean, then squared deviations) are
 //     sums over those and a FIXED balanced tree over the channel index, then over the rows (lanes, then waves), so the bits do not depend
 //     on the slicing; normalise + Mish + addend as the fused kernel (gn_mish.h).  The plain convs store from the accumulators.
+// A launch has as many workgroups as the chip holds at once; a workgroup (4 waves) takes the items blockIdx.x, + gridDim.x, ... of its slice
+// as a sequence of STAGES (item, chunk), and requests the next stage's rows right behind the current stage's conversion, so that they land
+// under its GEMM and tail (the widest slice, whose registers are the weight ring's, requests them at the stage's start).
 // A sample's arithmetic does not depend on the batch it sits in, on its place in the workgroup or on the slicing.
 constexpr int MCONV_KCH = 128;                     // input channels staged per chunk (at most)
 constexpr int MCONV_MAX_CHUNKS = 8;                // <= 1024 input channels
@@ -247,8 +253,9 @@ template <int V> __device__ __forceinline__ void st_run(float* p, const float (&
 }
 // NTW n-tiles x MTW M tiles per wave: (2, 4) for a slice of 128 columns, (1, 4) for 64, (1, 2) for 32, (1, 1) for 16 -- compile-time, so
 // that the weight ring's slots are registers with exact s_waitcnt counts (with run-time tile counts the compiler drained every load)
-template <int NTW, int MTW, int KIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mconv_kernel(MConvArgs m) {
+// NBH: channel blocks per staging thread (1: chunks of <= 64 channels, three workgroups per CU; 2: up to 128)
+template <int NTW, int MTW, int KIND, int NBH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 && NBH == 1 ? 3 : 2))) void mconv_kernel(MConvArgs m) {
   constexpr int K = MKind<KIND>::K, S = MKind<KIND>::S, RD = MKind<KIND>::RD, NR = MKind<KIND>::NR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ConvArgs& a = m.c;
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
   const int lsh_in = 31 - __builtin_clz(L);                // l_in is 8, 16, 32 or 64
   const int lsh = lsh_in - (S - 1), LR = 1 << lsh;         // GEMM rows of a sample
   const int SPW = 64 >> lsh, RS = L + 4, SROWS = SPW * RS;  // samples per workgroup, slab rows per sample / in all
-  const int s0 = blockIdx.x * SPW, c0 = blockIdx.y * a.cs;
+  const int c0 = blockIdx.y * a.cs, n_items = (m.n + SPW - 1) / SPW;   // an item = SPW consecutive samples; the workgroup takes items blockIdx.x, + gridDim.x, ...
 #ifdef MCONV_TIMING
   long long clk_[6] = {}, last_ = clock64();
   const long long first_ = last_;
@@ -268,19 +275,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
   float* const red = reinterpret_cast<float*>(smem + (slab_bytes > outs_bytes ? slab_bytes : outs_bytes));
   unsigned* const smax = reinterpret_cast<unsigned*>(red + 64);
   if (tid < 16) smax[tid] = 0u;
-  // ---- this thread's staging rows (fixed over the chunks): rows tid % 32 + 32 i of the slab -> (sample, position); a padding row, a row
-  // past the slab or past the batch reads the first element of the batch and is not used
+  // ---- this thread's staging rows of an item: rows tid % 32 + 32 i of the slab -> (sample, position); a padding row, a row past the slab
+  // or past the batch reads the first element of the batch and is not used
   int st_smp[NR], st_l[NR], st_sm[NR];
   bool st_row[NR], st_ok[NR];
+  auto set_rows = [&](int s0) {
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int row = (tid & 31) + 32 * i, sm = row / RS, l = row - sm * RS - 2, smp = s0 + sm;
-    st_row[i] = row < SROWS;
-    st_ok[i] = st_row[i] && smp < m.n && l >= 0 && l < L;
-    st_sm[i] = st_row[i] ? sm : 0;
-    st_smp[i] = st_ok[i] ? smp : 0;
-    st_l[i] = st_ok[i] ? l : 0;
-  }
+    for (int i = 0; i < NR; ++i) {
+      const int row = (tid & 31) + 32 * i, sm = row / RS, l = row - sm * RS - 2, smp = s0 + sm;
+      st_row[i] = row < SROWS;
+      st_ok[i] = st_row[i] && smp < m.n && l >= 0 && l < L;
+      st_sm[i] = st_row[i] ? sm : 0;
+      st_smp[i] = st_ok[i] ? smp : 0;
+      st_l[i] = st_ok[i] ? l : 0;
+    }
+  };
+  // the raw rows of (item, chunk): item = (channel block, slab row): the 8 channels of one position (32 contiguous bytes of a blocked tensor);
+  // a thread has <= 2 blocks x NR rows.  They are REQUESTED one stage ahead -- behind the previous stage's conversion, so that their
+  // latency passes under its GEMM and tail (the weight ring's loads of a stage are issued before, and loads return in order)
+  float4 v[NBH][NR][2];
+  auto chunk_blocks = [&](int ch) {                       // channel blocks of chunk ch (the k1 conv's chunk is always four K chunks wide)
+    const int cc = K == 1 ? m.kch : min(m.kch, cin - ch * m.kch);
+    return 4 * ((cc + 31) / 32);
+  };
+  auto request_rows = [&](int ch) {
+    const int c_lo = ch * m.kch, NB = chunk_blocks(ch);
+#pragma unroll
+    for (int h = 0; h < NBH; ++h) {
+      const int blk = (tid >> 5) + 8 * h, c = c_lo + 8 * blk;   // (c1 is a multiple of 8: the block lies in one source)
+      if (blk >= NB) continue;
+      const bool live = a.in_cl ? c == 0 : c < cin, first = c < a.c1;
+      const float* const src = a.in_cl ? a.x1 : first ? a.x1 + (size_t)c * L : a.x2 + (size_t)(c - a.c1) * L;
+      const int cw = first ? a.c1 : a.c2;                  // channels of the source: a sample is cw x L elements
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        // blocked: ((smp cw / 8 + c / 8) L + l) 8; the trajectory [n][L][4]: channels 0 .. 3 are one 16-byte load
+        const float* const q = !live ? a.x1 : a.in_cl ? src + ((size_t)st_smp[i] * L + st_l[i]) * 4 : src + (size_t)st_smp[i] * cw * L + st_l[i] * 8;
+        v[h][i][0] = live ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[h][i][1] = live && !a.in_cl ? *reinterpret_cast<const float4*>(q + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
   // ---- GEMM over the channel chunks
   constexpr int WPT = 4 / MTW;                             // waves that share an n-tile (MTW < 4: they split its M tiles)
   const int nt0 = (wave / WPT) * NTW;                      // first n-tile of the wave
@@ -297,17 +332,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     inv_prev[i] = 1.f;
   }
   f32x4 acc[NTW][MTW];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t)
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (the widest slice keeps no rows in flight across its GEMM: the registers are the weight ring's -- its stages are GEMM-bound)
+  constexpr bool AHEAD = NTW == 1;
+  int item = blockIdx.x, ch = 0, s0 = item * SPW;
+  set_rows(s0);
+  if (AHEAD) request_rows(0);
   __syncthreads();                                         // smax is zero
-  for (int ch = 0; ch < m.n_chunks; ++ch) {
-    // (the k1 conv's chunk is always four K chunks wide: its four steps are the ring)
-    const int c_lo = ch * m.kch, cc = K == 1 ? m.kch : min(m.kch, cin - c_lo), KCj = (cc + 31) / 32, NB = 4 * KCj;
+  for (unsigned seq = 0;; ++seq) {                         // the stages (item, chunk) of this workgroup
+    const int c_lo = ch * m.kch, NB = chunk_blocks(ch), KCj = NB / 4;
     const int PS = NB * SROWS * 16;
-    unsigned* const mxs = smax + 8 * (ch & 1);
-    if (ch) __syncthreads();                               // every wave is done reading the previous chunk
+    unsigned* const mxs = smax + 8 * (seq & 1);
+    if (seq) __syncthreads();                              // every wave is done reading the previous stage's slab / output tile
+    if (ch == 0) {
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        inv_prev[i] = 1.f;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     // the weight ring's first steps are requested before the staging: their latency passes under it
     const int steps = K * KCj;                             // (tap, kc), tap-major: a multiple of the ring's RD slots
     // the wave's B fragments of step st: n-tile nt0 + t, pieces q
@@ -323,31 +366,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     };
 #pragma unroll
     for (int j = 0; j < RD; ++j) load_b(j, j);
-    // stage: item = (channel block, slab row): the 8 channels of one position (32 contiguous bytes of a blocked tensor), both pieces; a
-    // thread has <= 2 blocks x NR rows.  All of a thread's loads are issued before the first is used
+    if (!AHEAD) request_rows(ch);
     {
-      float4 v[2][NR][2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int blk = (tid >> 5) + 8 * h, c = c_lo + 8 * blk;   // (c1 is a multiple of 8: the block lies in one source)
-        if (blk >= NB) continue;
-        const bool live = a.in_cl ? c == 0 : c < cin, first = c < a.c1;
-        const float* const src = a.in_cl ? a.x1 : first ? a.x1 + (size_t)c * L : a.x2 + (size_t)(c - a.c1) * L;
-        const int cw = first ? a.c1 : a.c2;                // channels of the source: a sample is cw x L elements
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-          // blocked: ((smp cw / 8 + c / 8) L + l) 8; the trajectory [n][L][4]: channels 0 .. 3 are one 16-byte load
-          const float* const q = !live ? a.x1 : a.in_cl ? src + ((size_t)st_smp[i] * L + st_l[i]) * 4 : src + (size_t)st_smp[i] * cw * L + st_l[i] * 8;
-          v[h][i][0] = live ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
-          v[h][i][1] = live && !a.in_cl ? *reinterpret_cast<const float4*>(q + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
       // the samples' maxima over the chunk
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         float mx = 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NBH; ++h) {
           if ((tid >> 5) + 8 * h >= NB) continue;
           const float4 p = v[h][i][0], q = v[h][i][1];
           mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), fabsf(p.w))),
@@ -357,9 +383,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
       }
       __syncthreads();
       MCONV_T(0)
-      if (tid < 8) smax[8 * ((ch + 1) & 1) + tid] = 0u;    // (the other chunk's maxima: every thread has used them by now)
+      if (tid < 8) smax[8 * ((seq + 1) & 1) + tid] = 0u;   // (the other stage's maxima: every thread has used them by now)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NBH; ++h) {
         const int blk = (tid >> 5) + 8 * h;
         if (blk >= NB) continue;
 #pragma unroll
@@ -385,6 +411,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         for (int t = 0; t < NTW; ++t) acc[t][i] *= r;
       }
       inv_prev[i] = ds.inv;
+    }
+    // the next stage's rows are requested now (v is free), to land under this stage's GEMM and tail
+    const bool last_chunk = ch + 1 == m.n_chunks;
+    const int n_item = last_chunk ? item + (int)gridDim.x : item, n_ch = last_chunk ? 0 : ch + 1;
+    const bool more = n_item < n_items;
+    if (more) {
+      if (last_chunk) set_rows(n_item * SPW);
+      if (AHEAD) request_rows(n_ch);
     }
     __syncthreads();
     MCONV_T(1)
@@ -412,145 +446,141 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
       group(steps - RD, std::false_type{});
     }
     MCONV_T(2)
-  }
-  if (KIND != 0) {
-    // ---- plain convs: column scale x sample scale, + bias, stored from the accumulators (C/D layout: lane = column lane & 15, rows 4 g ..
-    // 4 g + 3 of the M tile = four consecutive output rows of one sample) into the blocked output: the 16 lanes of a row write 64
-    // contiguous bytes (two channel blocks; the transposed conv: one block at the positions 2 m and 2 m + 1)
+    if (last_chunk) {
+      if (KIND != 0) {
+        // ---- plain convs: column scale x sample scale, + bias, stored from the accumulators (C/D layout: lane = column lane & 15, rows 4 g ..
+        // 4 g + 3 of the M tile = four consecutive output rows of one sample) into the blocked output: the 16 lanes of a row write 64
+        // contiguous bytes (two channel blocks; the transposed conv: one block at the positions 2 m and 2 m + 1)
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int col = c0 + 16 * (nt0 + t) + row, co = KIND == 3 ? col >> 1 : col;
-      const float kc_ = m.isc[col], bs = a.bias[co];
+        for (int t = 0; t < NTW; ++t) {
+          const int col = c0 + 16 * (nt0 + t) + row, co = KIND == 3 ? col >> 1 : col;
+          const float kc_ = m.isc[col], bs = a.bias[co];
 #pragma unroll
-      for (int i = 0; i < MTW; ++i) {
-        const int r64 = 16 * (mt0 + i * WPT) + 4 * g, lo = r64 & (LR - 1), smp = s0 + csm[i];
-        const float k = kc_ * inv_prev[i];
-        if (smp >= m.n) continue;
-        float* const dst = a.y + bl_off(smp, a.c_out, a.l_out, co, KIND == 3 ? 2 * lo + (col & 1) : lo);
+          for (int i = 0; i < MTW; ++i) {
+            const int r64 = 16 * (mt0 + i * WPT) + 4 * g, lo = r64 & (LR - 1), smp = s0 + csm[i];
+            const float k = kc_ * inv_prev[i];
+            if (smp >= m.n) continue;
+            float* const dst = a.y + bl_off(smp, a.c_out, a.l_out, co, KIND == 3 ? 2 * lo + (col & 1) : lo);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[(KIND == 3 ? 16 : 8) * e] = fmaf(acc[t][i][e], k, bs);
-      }
-    }
-#ifdef MCONV_TIMING
-    if (tid == 0) {
-      unsigned long long* t = g_mconv_clk[KIND][lsh_in - 3][NTW * MTW];
-      const long long now = clock64();
-      for (int i = 0; i < 3; ++i) atomicAdd(t + i, (unsigned long long)clk_[i]);
-      atomicAdd(t + 5, (unsigned long long)(now - last_));
-      atomicAdd(t + 6, (unsigned long long)(now - first_));
-      atomicAdd(t + 7, 1ull);
-    }
-#endif
-    return;
-  }
-  // ---- Conv1dBlock tail.  A thread owns rows 4 rq .. 4 rq + 3 (one sample: rq = tid % 16) x the NIT adjacent channels cl NIT .. of the
-  // slice (cl = tid / 16).  Its global operands are requested now, so that their latency passes under the exchange
-  float* const outs = reinterpret_cast<float*>(smem);      // [cs][OST] conv output (64 rows + 4 of padding: conflict-free column writes)
-  constexpr int NIT = NTW * MTW;                           // = cs / 16
-  const int rq = tid & 15, cl = tid >> 4, r0 = 4 * rq, tsm = r0 >> lsh, tl = r0 & (L - 1), tsmp = s0 + tsm, tc = c0 + cl * NIT;
-  float gm[NIT], bt[NIT], ad[4][NIT];                      // gamma, beta; the addend (time bias per channel, or the residual) per (row, channel)
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    gm[k] = a.gamma[tc + k];
-    bt[k] = a.beta[tc + k];
-  }
-  if (a.add_c) {
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) ad[0][k] = ad[1][k] = ad[2][k] = ad[3][k] = a.add_c[tc + k];
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (a.add_t && tsmp < m.n) {
-        ld_run<NIT>(ad[e], a.add_t + bl_off(tsmp, a.c_out, L, tc, tl + e));
+            for (int e = 0; e < 4; ++e) dst[(KIND == 3 ? 16 : 8) * e] = fmaf(acc[t][i][e], k, bs);
+          }
+        }
+        MCONV_T(5)
       } else {
+        // ---- Conv1dBlock tail.  A thread owns rows 4 rq .. 4 rq + 3 (one sample: rq = tid % 16) x the NIT adjacent channels cl NIT .. of the
+        // slice (cl = tid / 16).  Its global operands are requested now, so that their latency passes under the exchange
+        float* const outs = reinterpret_cast<float*>(smem);      // [cs][OST] conv output (64 rows + 4 of padding: conflict-free column writes)
+        constexpr int NIT = NTW * MTW;                           // = cs / 16
+        const int rq = tid & 15, cl = tid >> 4, r0 = 4 * rq, tsm = r0 >> lsh, tl = r0 & (L - 1), tsmp = s0 + tsm, tc = c0 + cl * NIT;
+        float gm[NIT], bt[NIT], ad[4][NIT];                      // gamma, beta; the addend (time bias per channel, or the residual) per (row, channel)
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) ad[e][k] = 0.f;
+        for (int k = 0; k < NIT; ++k) {
+          gm[k] = a.gamma[tc + k];
+          bt[k] = a.beta[tc + k];
+        }
+        if (a.add_c) {
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) ad[0][k] = ad[1][k] = ad[2][k] = ad[3][k] = a.add_c[tc + k];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (a.add_t && tsmp < m.n) {
+              ld_run<NIT>(ad[e], a.add_t + bl_off(tsmp, a.c_out, L, tc, tl + e));
+            } else {
+#pragma unroll
+              for (int k = 0; k < NIT; ++k) ad[e][k] = 0.f;
+            }
+          }
+        }
+        float kc_[NTW], bs_[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          kc_[t] = m.isc[c0 + 16 * (nt0 + t) + row];
+          bs_[t] = a.bias[c0 + 16 * (nt0 + t) + row];
+        }
+        __syncthreads();                                         // the slab is dead: its memory becomes the output tile
+        // ---- accumulators -> outs[c][r64] (C/D layout: lane = column lane & 15, rows 4 g .. 4 g + 3 of the M tile), scaled back, + bias
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const int ocl = 16 * (nt0 + t) + row;
+#pragma unroll
+          for (int i = 0; i < MTW; ++i) {
+            const int r64 = 16 * (mt0 + i * WPT) + 4 * g;
+            const float k = kc_[t] * inv_prev[i], bs = bs_[t];
+            *reinterpret_cast<float4*>(outs + ocl * OST + r64) =
+                make_float4(fmaf(acc[t][i][0], k, bs), fmaf(acc[t][i][1], k, bs), fmaf(acc[t][i][2], k, bs), fmaf(acc[t][i][3], k, bs));
+          }
+        }
+        __syncthreads();
+        MCONV_T(3)
+        // ---- GroupNorm statistics of (sample, group): cpg channels x L positions.  The sum of a group is DEFINED as: per channel the four rows
+        // of a quad ((x0 + x1) + (x2 + x3)); a balanced tree over the channel index (within the thread, then lanes 16 and 32 apart, then
+        // waves); then a balanced tree over the sample's row quads (lanes 1, 2, 4, 8 apart) -- whatever the slice width
+        float4 x[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) x[k] = *reinterpret_cast<const float4*>(outs + (cl * NIT + k) * OST + r0);
+        const int cpg = a.c_out / N_GROUPS, clu = cpg / NIT;     // channel lanes (16 apart) per group: 2, 4, 8 or 16
+        auto group_sum = [&](float (&s)[NIT]) -> float {
+#pragma unroll
+          for (int w = 1; w < NIT; w *= 2)
+#pragma unroll
+            for (int k = 0; k < NIT; k += 2 * w) s[k] += s[k + w];
+          float v = s[0];
+          v += __shfl_xor(v, 16);
+          if (clu >= 4) v += __shfl_xor(v, 32);
+          if (clu >= 8) {                                        // the group spans 2 or 4 waves
+            if (lane < 16) red[16 * wave + lane] = v;
+            __syncthreads();
+            const int w0 = clu >= 16 ? 0 : wave & 2;
+            v = red[16 * w0 + rq] + red[16 * (w0 + 1) + rq];
+            if (clu >= 16) v = v + (red[32 + rq] + red[48 + rq]);
+            __syncthreads();
+          }
+          v += __shfl_xor(v, 1);
+          if (L >= 16) v += __shfl_xor(v, 2);
+          if (L >= 32) v += __shfl_xor(v, 4);
+          if (L >= 64) v += __shfl_xor(v, 8);
+          return v;
+        };
+        const float per = (float)(cpg << lsh);
+        float s[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) s[k] = (x[k].x + x[k].y) + (x[k].z + x[k].w);
+        const float mean = group_sum(s) / per;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const float d0 = x[k].x - mean, d1 = x[k].y - mean, d2 = x[k].z - mean, d3 = x[k].w - mean;
+          s[k] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        const float rstd = 1.f / sqrtf(group_sum(s) / per + 1e-5f);
+        MCONV_T(4)
+        // ---- normalise + Mish + addend (the fused kernel's arithmetic, gn_mish.h) -> y, blocked: a row's NIT channels are one run
+        if (tsmp < m.n) {
+          float o[4][NIT];
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) {
+            const GnCoef cf = gn_coef(mean, rstd, gm[k], bt[k]);
+            const f32x2_t lo = gn_mish2(f32x2_t{x[k].x, x[k].y}, cf, f32x2_t{ad[0][k], ad[1][k]});
+            const f32x2_t hi = gn_mish2(f32x2_t{x[k].z, x[k].w}, cf, f32x2_t{ad[2][k], ad[3][k]});
+            o[0][k] = lo.x; o[1][k] = lo.y; o[2][k] = hi.x; o[3][k] = hi.y;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st_run<NIT>(a.y + bl_off(tsmp, a.c_out, L, tc, tl + e), o[e]);
+        }
+        MCONV_T(5)
       }
     }
-  }
-  float kc_[NTW], bs_[NTW];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    kc_[t] = m.isc[c0 + 16 * (nt0 + t) + row];
-    bs_[t] = a.bias[c0 + 16 * (nt0 + t) + row];
-  }
-  __syncthreads();                                         // the slab is dead: its memory becomes the output tile
-  // ---- accumulators -> outs[c][r64] (C/D layout: lane = column lane & 15, rows 4 g .. 4 g + 3 of the M tile), scaled back, + bias
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int ocl = 16 * (nt0 + t) + row;
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      const int r64 = 16 * (mt0 + i * WPT) + 4 * g;
-      const float k = kc_[t] * inv_prev[i], bs = bs_[t];
-      *reinterpret_cast<float4*>(outs + ocl * OST + r64) =
-          make_float4(fmaf(acc[t][i][0], k, bs), fmaf(acc[t][i][1], k, bs), fmaf(acc[t][i][2], k, bs), fmaf(acc[t][i][3], k, bs));
-    }
-  }
-  __syncthreads();
-  MCONV_T(3)
-  // ---- GroupNorm statistics of (sample, group): cpg channels x L positions.  The sum of a group is DEFINED as: per channel the four rows
-  // of a quad ((x0 + x1) + (x2 + x3)); a balanced tree over the channel index (within the thread, then lanes 16 and 32 apart, then
-  // waves); then a balanced tree over the sample's row quads (lanes 1, 2, 4, 8 apart) -- whatever the slice width
-  float4 x[NIT];
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) x[k] = *reinterpret_cast<const float4*>(outs + (cl * NIT + k) * OST + r0);
-  const int cpg = a.c_out / N_GROUPS, clu = cpg / NIT;     // channel lanes (16 apart) per group: 2, 4, 8 or 16
-  auto group_sum = [&](float (&s)[NIT]) -> float {
-#pragma unroll
-    for (int w = 1; w < NIT; w *= 2)
-#pragma unroll
-      for (int k = 0; k < NIT; k += 2 * w) s[k] += s[k + w];
-    float v = s[0];
-    v += __shfl_xor(v, 16);
-    if (clu >= 4) v += __shfl_xor(v, 32);
-    if (clu >= 8) {                                        // the group spans 2 or 4 waves
-      if (lane < 16) red[16 * wave + lane] = v;
-      __syncthreads();
-      const int w0 = clu >= 16 ? 0 : wave & 2;
-      v = red[16 * w0 + rq] + red[16 * (w0 + 1) + rq];
-      if (clu >= 16) v = v + (red[32 + rq] + red[48 + rq]);
-      __syncthreads();
-    }
-    v += __shfl_xor(v, 1);
-    if (L >= 16) v += __shfl_xor(v, 2);
-    if (L >= 32) v += __shfl_xor(v, 4);
-    if (L >= 64) v += __shfl_xor(v, 8);
-    return v;
-  };
-  const float per = (float)(cpg << lsh);
-  float s[NIT];
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) s[k] = (x[k].x + x[k].y) + (x[k].z + x[k].w);
-  const float mean = group_sum(s) / per;
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const float d0 = x[k].x - mean, d1 = x[k].y - mean, d2 = x[k].z - mean, d3 = x[k].w - mean;
-    s[k] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-  }
-  const float rstd = 1.f / sqrtf(group_sum(s) / per + 1e-5f);
-  MCONV_T(4)
-  // ---- normalise + Mish + addend (the fused kernel's arithmetic, gn_mish.h) -> y, blocked: a row's NIT channels are one run
-  if (tsmp < m.n) {
-    float o[4][NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const GnCoef cf = gn_coef(mean, rstd, gm[k], bt[k]);
-      const f32x2_t lo = gn_mish2(f32x2_t{x[k].x, x[k].y}, cf, f32x2_t{ad[0][k], ad[1][k]});
-      const f32x2_t hi = gn_mish2(f32x2_t{x[k].z, x[k].w}, cf, f32x2_t{ad[2][k], ad[3][k]});
-      o[0][k] = lo.x; o[1][k] = lo.y; o[2][k] = hi.x; o[3][k] = hi.y;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) st_run<NIT>(a.y + bl_off(tsmp, a.c_out, L, tc, tl + e), o[e]);
+    if (!more) break;
+    item = n_item;
+    ch = n_ch;
+    s0 = item * SPW;
   }
 #ifdef MCONV_TIMING
   if (tid == 0) {
     unsigned long long* t = g_mconv_clk[KIND][lsh_in - 3][NTW * MTW];
-    const long long now = clock64();
-    for (int i = 0; i < 5; ++i) atomicAdd(t + i, (unsigned long long)clk_[i]);
-    atomicAdd(t + 5, (unsigned long long)(now - last_));
-    atomicAdd(t + 6, (unsigned long long)(now - first_));
-    atomicAdd(t + 7, 1ull);
+    for (int i = 0; i < 6; ++i) atomicAdd(t + i, (unsigned long long)clk_[i]);
+    atomicAdd(t + 6, (unsigned long long)(clock64() - first_));
+    atomicAdd(t + 7, (unsigned long long)((n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1));
   }
 #endif
 }
@@ -663,18 +693,30 @@ MPack push_mfma_up(std::vector<float>& blob, const float* w, int cout, int cin) 
     }
   return push_mfma(blob, wk.data(), 2 * cout, cin, 3);
 }
+template <int KIND, int NBH>
+const void* mconv_fn(int cs) {
+  return cs == 128 ? (const void*)mconv_kernel<2, 4, KIND, NBH> : cs == 64 ? (const void*)mconv_kernel<1, 4, KIND, NBH>
+       : cs == 32 ? (const void*)mconv_kernel<1, 2, KIND, NBH> : (const void*)mconv_kernel<1, 1, KIND, NBH>;
+}
 template <int KIND>
-void launch_mconv(int cs, dim3 grid, size_t shm, hipStream_t st, const MConvArgs& ma) {
-  if (cs == 128) hipLaunchKernelGGL((mconv_kernel<2, 4, KIND>), grid, dim3(256), shm, st, ma);
-  else if (cs == 64) hipLaunchKernelGGL((mconv_kernel<1, 4, KIND>), grid, dim3(256), shm, st, ma);
-  else if (cs == 32) hipLaunchKernelGGL((mconv_kernel<1, 2, KIND>), grid, dim3(256), shm, st, ma);
-  else hipLaunchKernelGGL((mconv_kernel<1, 1, KIND>), grid, dim3(256), shm, st, ma);
+const void* mconv_fn(int cs, int kch) { return kch <= 64 ? mconv_fn<KIND, 1>(cs) : mconv_fn<KIND, 2>(cs); }
+constexpr int kNumCUs = 256;                       // MI355X
+// workgroups of `fn` with `shm` bytes of LDS that one CU holds (cached: the launches of a forward ask 47 times)
+int mconv_resident(const void* fn, size_t shm) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, int> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find({fn, shm});
+  if (it != cache.end()) return it->second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, shm) != hipSuccess || nb < 1) nb = 1;
+  cache[{fn, shm}] = nb;
+  return nb;
 }
 template <int KIND>
 int mconv_set_lds() {
-  for (const void* f : {(const void*)mconv_kernel<2, 4, KIND>, (const void*)mconv_kernel<1, 4, KIND>, (const void*)mconv_kernel<1, 2, KIND>,
-                        (const void*)mconv_kernel<1, 1, KIND>})
-    MMD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  for (int cs : {16, 32, 64, 128})
+    for (int kch : {64, 128}) MMD_HIP_CHECK(hipFuncSetAttribute(mconv_fn<KIND>(cs, kch), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   return 0;
 }
 size_t push_v(std::vector<float>& blob, const float* p, int64_t n) {
@@ -840,12 +882,14 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     ma.kch = mp.kch;
     ma.n = n;
     const size_t slab = (size_t)2 * (mp.kch / 8) * spw * (c.l_in + 4) * 16, outs = kind == 0 ? (size_t)cs * OST * 4 : 0;
-    const size_t shm = std::max(slab, outs) + (2 * N_GROUPS * 8 + 8 + 8 + 8) * sizeof(float);
-    const dim3 grid(n_wg, cols / cs);
-    if (kind == 0) launch_mconv<0>(cs, grid, shm, st, ma);
-    else if (kind == 1) launch_mconv<1>(cs, grid, shm, st, ma);
-    else if (kind == 2) launch_mconv<2>(cs, grid, shm, st, ma);
-    else launch_mconv<3>(cs, grid, shm, st, ma);
+    const size_t shm = std::max(slab, outs) + (64 + 16) * sizeof(float);   // + the statistics' exchange + the samples' maxima
+    const void* const fn = kind == 0 ? mconv_fn<0>(cs, mp.kch) : kind == 1 ? mconv_fn<1>(cs, mp.kch) : kind == 2 ? mconv_fn<2>(cs, mp.kch) : mconv_fn<3>(cs, mp.kch);
+    // the items (64 / rows samples each) of a slice go to as many workgroups as the chip holds at once, the same number each (+- 1): a
+    // workgroup requests its next item's rows under the current one's GEMM and tail
+    const int ny = cols / cs, cap = std::max(1, mconv_resident(fn, shm) * kNumCUs / ny), per_wg = (n_wg + cap - 1) / cap;
+    const dim3 grid((n_wg + per_wg - 1) / per_wg, ny);
+    void* args[] = {&ma};
+    MMD_HIP_CHECK(hipLaunchKernel(fn, grid, dim3(256), args, shm, st));
     return 0;
   };
   // Conv1dBlock: (x1 | x2) [c][L] -> Mish(GN(conv5)) + add_c[c] + add_t -> y.  A workgroup of KS x nconv threads, nconv =

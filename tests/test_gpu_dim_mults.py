@@ -68,17 +68,22 @@ def test_layered_path_equals_fused_kernel_on_option0(monkeypatch):
 
 @pytest.mark.parametrize("dm", [(1, 2, 4), (1, 2, 4, 8)], ids=["option0", "option1"])
 def test_layered_forward_bits_do_not_depend_on_the_batch(monkeypatch, dm):
-    """The launch shape of the layer kernels follows the batch size (1, 2 or 4 output channels per thread, 2 .. 8 channel slices per
-    sample); the sum over the input channels is DEFINED as four interleaved partial sums combined in a fixed tree, so a trajectory's
-    eps must not change by a bit with the size of the batch it sits in (n = 8: CT 1, n = 200: CT 2, n = 800: CT 4), and for option 0
-    every size must agree with the fused kernel."""
+    """The launch shape of the layer kernels follows the batch size (matrix-pipe kernel: slices of 16 .. 128 GEMM columns per workgroup, 1 .. 8
+    items per workgroup; vector-ALU kernels: 1, 2 or 4 output channels per thread); every sum is DEFINED as a fixed tree (the K order of the
+    GEMM, the GroupNorm statistics' balanced tree over channels and rows), so a trajectory's eps must not change by a bit with the size of
+    the batch it sits in -- n = 6 (a partial item at every level), 200, 800 and 4099 (the widest slices, several items per workgroup, a
+    partial last item) -- and for option 0 every size must agree with the fused kernel."""
     layered = _unet(32, dm, layered=True)
     layered.handle(25, "cuda")
-    x = (torch.from_numpy(synth.synth_noise(902, (800, H, D))) * 0.7).cuda()
-    big = layered(x, 7)
-    assert torch.isfinite(big).all()
+    x = (torch.from_numpy(synth.synth_noise(902, (4099, H, D))) * 0.7).cuda()
+    huge = layered(x, 7)
+    assert torch.isfinite(huge).all()
+    big = layered(x[:800].contiguous(), 7)
+    assert torch.equal(big, huge[:800])
     assert torch.equal(layered(x[:200].contiguous(), 7), big[:200])
     assert torch.equal(layered(x[600:608].contiguous(), 7), big[600:608])
+    assert torch.equal(layered(x[4093:4099].contiguous(), 7), huge[4093:4099])
+    x = x[:800].contiguous()
     if dm == (1, 2, 4):
         fused = _unet(32, dm, layered=False)
         fused.handle(25, "cuda")
@@ -235,3 +240,21 @@ def test_layered_unet_any_group_width_vs_oracle(uid):
         assert err < 2e-5, (uid, dm, err)
         assert torch.equal(unet(x[:200].contiguous().cuda(), 11), big[:200])
         assert torch.equal(unet(x[600:608].contiguous().cuda(), 11), big[600:608])
+
+
+def test_layered_unet_widest_network_widest_slices_vs_oracle():
+    """unet_input_dim 64 with four levels: 512-channel layers (GroupNorm groups of 64 channels: the statistics of a group span two waves of
+    the matrix-pipe kernel), four input chunks at the deepest up block, and -- at 3100 trajectories -- 128-column slices with several items
+    per workgroup.  Against the oracle's forward on six trajectories, and bitwise against the same trajectories in a batch of six."""
+    from oracle import mmd_oracle as O
+    uid, dm = 64, (1, 2, 4, 8)
+    unet = _unet(uid, dm)
+    sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0, unet_input_dim=uid, dim_mults=dm))
+    x = torch.from_numpy(synth.synth_noise(906, (3100, H, D))) * 0.7
+    big = unet(x.cuda(), 11)
+    assert torch.isfinite(big).all()
+    ref = O.unet_forward(sd, x[1000:1006], torch.full((6,), 11, dtype=torch.long))
+    err = rel_l2(big[1000:1006].cpu(), ref)
+    parity_log.record("layered_unet_widest", "uid64_levels4_n3100", None, err, bound=2e-5)
+    assert err < 2e-5, err
+    assert torch.equal(unet(x[1000:1006].contiguous().cuda(), 11), big[1000:1006])
