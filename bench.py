@@ -173,6 +173,8 @@ def parse():
     ap.add_argument("--workload", choices=tuple(WORKLOADS), default="headline",
                     help="headline = BASELINE.json's metric (32-robot Empty map); config2..config5 = BASELINE.json's configs[1..4]")
     ap.add_argument("--robots-per-gpu", type=int, default=0, help="override (0 = robots/N for strong, all robots per GPU for weak)")
+    ap.add_argument("--sequential-planners", action="store_true",
+                    help="config4: the planner calls of a round one after the other (the reference's loop) instead of concurrently")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the dominant kernel that fill roofline.traffic")
     ap.add_argument("--samples", type=int, default=64)
@@ -631,7 +633,7 @@ def run_ensemble(args, rank, world, dev, rehearsal=False):
     the reference's own granularity: one planner per agent (inference_multi_agent.py:225-237), B = 64 samples a call, a trajectory =
     2 x 64 support points.  A step = the four planner calls, selection included.  Multi-GPU: robots sharded (no exchange)."""
     from mmd_amd import _lib, synth
-    from mmd_amd.planners import MPDEnsemble
+    from mmd_amd.planners import MPDEnsemble, plan_concurrently
     T, B = args.diffusion_steps, args.samples
     W = WORKLOADS["config4"]
     if W["robots"] % world:
@@ -653,10 +655,15 @@ def run_ensemble(args, rank, world, dev, rehearsal=False):
         torch.cuda.synchronize()
 
     def rounds(n):
+        # the four planner calls of a round are independent: issued concurrently, one host thread + one stream each
+        # (planners.plan_concurrently; --sequential-planners: one after the other, the reference's loop)
         out = None
         for _ in range(n):
-            for p, start, goal in planners:
-                out = p(start, goal)
+            if args.sequential_planners:
+                for p, start, goal in planners:
+                    out = p(start, goal)
+            else:
+                out = plan_concurrently(planners)[-1]
         return out
     rounds(args.warmup)
     barrier()
@@ -676,11 +683,13 @@ def run_ensemble(args, rank, world, dev, rehearsal=False):
     issued = 3.0 * h_traj * RPG * B * 2 * (T + 1)                    # two tile forwards per composed trajectory and step
     issue_ms = issued / (PEAK_F16_MFMA_TFLOPS * 1e12) * 1e3
     detail = (f"{W['robots']} robots x B={B} samples on the 1x2 EnvEmptyNoWait2D tile grid (tile offset 2.0), one MPDEnsemble planner "
-              f"call per robot and step: K=2 tile models, T={T}+1 DDPM steps per tile, 20 guide iterations on {ceil(0.5 * T) + 1} guided "
+              f"call per robot and step ({'one after the other' if args.sequential_planners else 'the calls of a step issued concurrently, one stream each'}): "
+              f"K=2 tile models, T={T}+1 DDPM steps per tile, 20 guide iterations on {ceil(0.5 * T) + 1} guided "
               f"steps, cross-conditioning of the tile boundary after every tile step, post-sampling selection; a trajectory = 128 support points")
     config = {"workload": W["label"], "workload_detail": detail, "workload_key": "config4", "reference_shapes": W["ref"],
               "n_robots": W["robots"], "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": 2 * H, "diffusion_steps": T,
               "trajectories_per_step": n_traj, "parallelism": "single GPU" if world == 1 else f"robots sharded x{world}; no exchange",
+              "planner_calls": "sequential" if args.sequential_planners else "concurrent (plan_concurrently)",
               "noise": "in-kernel Philox4x32-10", "weights": "random-init (numpy PCG64 seed 0), the same for both tiles"}
     roofline = {"bound": "mfma", "kernel": "unet_kernel<2> (64-trajectory launches, one per tile and step)", "peak": PEAK_F16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": issue_ms / ms, "achieved": issue_ms / ms * PEAK_F16_MFMA_TFLOPS,

@@ -126,7 +126,8 @@ class DiffusionsEnsemble:
                             cross_conds=None, n_samples=1, return_chain=False, **diffusion_kwargs):
         """diffusion_ensemble.py:265-313."""
         hard_conds = deepcopy(hard_conds)
-        noised = None if n_noising_steps is None else self.models[0].q_sample(seed_trajectory_b, n_noising_steps)
+        noised = None if n_noising_steps is None else self.models[0].q_sample(seed_trajectory_b, n_noising_steps,
+                                                                              seed=diffusion_kwargs.get("seed"))
         x, chains = self.p_sample_loop((n_samples, HORIZON, self.models[0].state_dim), hard_conds, deepcopy(cross_conds),
                                        n_diffusion_steps=n_denoising_steps, return_chain=True,
                                        warm_start_path_b=noised, **diffusion_kwargs)

@@ -1,6 +1,7 @@
 """GaussianDiffusionModel: host mirror of reference mmd/models/diffusion_models/diffusion_model_base.py:48-433
 (sampling side) + sample_functions.py.  The p_sample_loop is ONE C-ABI call (mmd_p_sample_loop) that enqueues the
 UNet kernels and the fused posterior/guide/noise kernel of every step on the current HIP stream."""
+import threading
 import ctypes as C
 from copy import copy
 
@@ -24,10 +25,14 @@ def ddpm_sample_fn(*args, **kwargs):
 _GLOBAL_DRAWS = 0
 
 
+_DRAW_LOCK = threading.Lock()
+
+
 def next_stream_seed(base_seed):
     global _GLOBAL_DRAWS
-    seed = (int(base_seed) << 24) + _GLOBAL_DRAWS
-    _GLOBAL_DRAWS += 1
+    with _DRAW_LOCK:                 # (planner calls may run on several host threads: planners.plan_concurrently)
+        seed = (int(base_seed) << 24) + _GLOBAL_DRAWS
+        _GLOBAL_DRAWS += 1
     return seed & 0xFFFFFFFFFFFFFFFF
 
 
@@ -265,17 +270,18 @@ class GaussianDiffusionModel:
         if n_noising_steps is None:
             noised = None
         else:
-            noised = self.q_sample(seed_trajectory_b, n_noising_steps, noise=q_noise)
+            noised = self.q_sample(seed_trajectory_b, n_noising_steps, noise=q_noise, seed=diffusion_kwargs.get("seed"))
         samples, chain = self.conditional_sample(copy(hard_conds), n_diffusion_steps=n_denoising_steps, context=context,
                                                  batch_size=n_samples * n_robots, return_chain=True,
                                                  warm_start_path_b=noised, n_robots=n_robots, **diffusion_kwargs)
         chain = chain.transpose(0, 1)
         return chain if return_chain else chain[-1]
 
-    def q_sample(self, x_start, t, noise=None, traj_index_base=0):
+    def q_sample(self, x_start, t, noise=None, traj_index_base=0, seed=None):
         """diffusion_model_base.py:425-433 (t: int or a constant [B] tensor).  x_start is [B, K*64, 4]: K = 1 for a
         single model, K tiles chained along the horizon for the ensemble's seed (diffusion_ensemble.py:279-281) -- every
-        one of the B*K*64 points is noised."""
+        one of the B*K*64 points is noised.  `seed`: the call's Philox seed (the draw has its own stream index, so a sampling
+        loop under the same seed does not repeat it); default: the next one of the global stream."""
         t = int(t[0].item()) if torch.is_tensor(t) else int(t)
         x_start = x_start.to(dtype=torch.float32).contiguous()
         if x_start.ndim != 3 or x_start.shape[1] % 64 or x_start.shape[2] != self.state_dim:
@@ -284,6 +290,6 @@ class GaussianDiffusionModel:
         _lib.launch("mmd_q_sample", x_start, out.data_ptr(), _lib.require_gpu(x_start, "x_start"),
             _lib.require_gpu(noise.contiguous(), "noise") if noise is not None else None,
             float(self.sqrt_alphas_cumprod[t]), float(self.sqrt_one_minus_alphas_cumprod[t]),
-            C.c_uint64(next_stream_seed(self.seed)), 0xFFFFFFFE, C.c_int64(int(traj_index_base)),
+            C.c_uint64(next_stream_seed(self.seed) if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF), 0xFFFFFFFE, C.c_int64(int(traj_index_base)),
             x_start.numel() // (64 * self.state_dim))
         return out

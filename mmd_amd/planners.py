@@ -58,17 +58,19 @@ class PathBatchExperience:
 
 
 class _Timer:
-    """TimerCUDA semantics (torch_timer.py:44-53): perf_counter bracketed by device synchronisation."""
+    """TimerCUDA semantics (torch_timer.py:44-53): perf_counter bracketed by synchronisation -- of the CURRENT stream, which is where
+    a planner call puts all of its work (the reference has one stream, so its device-wide synchronize() is the same thing; a
+    device-wide one here would make concurrent planner calls on their own streams, plan_concurrently, wait for each other)."""
 
     def __enter__(self):
         import time
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         self._t0 = time.perf_counter()
         return self
 
     def __exit__(self, *a):
         import time
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         self.elapsed = time.perf_counter() - self._t0
 
 
@@ -489,3 +491,43 @@ class MPDEnsemble:
         out.constraints_l = constraints_l
         self.recent_call_data = out
         return out
+
+
+def plan_concurrently(calls, seeds=None):
+    """Independent planner calls issued CONCURRENTLY, one host thread and one HIP stream per call -- the re-entrancy the C ABI has per
+    stream (no global state, scratch per (device, stream)) put to use where the reference loops: one planner per agent in the first
+    round of CBS / PrioritizedPlanning (inference_multi_agent.py:225-237, cbs.py:316-324), the K calls of a batch of re-plans.  A call
+    of 64 samples fills an eighth of the chip and is bound by the latency of its 101 dependent steps; four of them overlap almost
+    completely (bench.py --workload config4).
+    `calls`: a list of (planner, start_state_pos, goal_state_pos[, constraints_l[, experience]]); every planner at most once (a planner
+    mutates its guide during a call: mpd.py:409,456 -- not re-entrant, as in the reference).
+    `seeds`: one Philox seed per call; default: drawn from the global stream counter in list order, i.e. the seeds a sequential loop
+    over `calls` would have used for single-model planners -- the results do not depend on how the threads interleave.
+    Returns the PlannerOutputs in list order; an exception of any call is re-raised."""
+    from concurrent.futures import ThreadPoolExecutor
+    from .diffusion_model import next_stream_seed
+    calls = [tuple(c) for c in calls]
+    if len({id(c[0]) for c in calls}) != len(calls):
+        raise ValueError("plan_concurrently: a planner appears twice (a planner call is not re-entrant)")
+    if seeds is None:      # (an MPD's model carries the planner's seed, an MPDEnsemble's first tile model)
+        seeds = [next_stream_seed(c[0].models[0].seed if hasattr(c[0], "models") else c[0].model.seed) for c in calls]
+    if len(seeds) != len(calls):
+        raise ValueError("plan_concurrently: one seed per call")
+    if not calls:
+        return []
+    # ("cuda" without an index = the caller's current device; the current device is per host thread, so the workers set it)
+    devs = [torch.cuda.current_device() if c[0].device.index is None else c[0].device.index for c in calls]
+    parents = [torch.cuda.current_stream(d) for d in devs]
+
+    def run(j):
+        planner, rest = calls[j][0], calls[j][1:]
+        torch.cuda.set_device(devs[j])
+        side = torch.cuda.Stream(devs[j])
+        side.wait_stream(parents[j])
+        with torch.cuda.stream(side):
+            out = planner(*rest, seed=int(seeds[j]))
+        side.synchronize()
+        return out
+    with ThreadPoolExecutor(max_workers=len(calls)) as pool:
+        return list(pool.map(run, range(len(calls))))
+

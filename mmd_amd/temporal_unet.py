@@ -3,6 +3,7 @@ hand-written gfx950 kernels (mmd_amd/csrc/unet.hip) behind the C ABI (include/mm
 import ctypes as C
 import hashlib
 import os
+import threading
 import weakref
 from collections import OrderedDict
 
@@ -17,6 +18,7 @@ from .unet_spec import UNET_DIM_MULTS, unet_param_spec   # noqa: F401
 # the same number of diffusion steps and the same device shares ONE device model: one packed weight blob + one
 # time-embedding table.  The cache holds weak references: the device model is freed when its last user goes away.
 _DEVICE_MODELS = weakref.WeakValueDictionary()
+_CREATE_LOCK = threading.Lock()     # device models are created one at a time (concurrent planner calls: planners.plan_concurrently)
 MAX_WORKSPACES = 8                   # scratch buffers a TemporalUnet keeps: one per (device, stream), least recently used dropped
 N_DEVICE_MODELS_CREATED = 0          # number of mmd_unet_create calls made by this process (tests / constructor reports)
 
@@ -97,7 +99,6 @@ class TemporalUnet:
         """Device model (packed weights + time-embedding table for t in [0, n_timesteps)), shared by every TemporalUnet
         of this process that holds the same parameters on the same device.  `device`: where the caller's tensors live
         (default: the current device); one TemporalUnet may serve several devices, each gets its own handle."""
-        global N_DEVICE_MODELS_CREATED
         if self._sd is None:
             raise RuntimeError("TemporalUnet has no parameters: call load_state_dict first")
         dev = self._device_index(device)
@@ -108,31 +109,38 @@ class TemporalUnet:
             have = [t for (t, d, l) in self._models if d == dev and l == layered]
             T = max(have) if have else self.max_timesteps
         if (T, dev, layered) not in self._models:
-            key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, dev, layered)
-            dm = _DEVICE_MODELS.get(key)
-            if dm is None:
-                lib = _lib.load()
-                n = len(self._sd)
-                ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in self._sd.values()])
-                numels = (C.c_int64 * n)(*[v.size for v in self._sd.values()])
-                h = C.c_void_p()
-                # (mmd_unet_create reads MMD_AMD_UNET_LAYERED: set to this object's choice for the call)
-                saved = os.environ.get("MMD_AMD_UNET_LAYERED")
-                os.environ["MMD_AMD_UNET_LAYERED"] = "1" if layered else "0"
-                try:
-                    with torch.cuda.device(dev):
-                        _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), T, ptrs, numels, n,
-                                                       _lib.current_stream_ptr()))
-                finally:
-                    if saved is None:
-                        del os.environ["MMD_AMD_UNET_LAYERED"]
-                    else:
-                        os.environ["MMD_AMD_UNET_LAYERED"] = saved
-                N_DEVICE_MODELS_CREATED += 1
-                dm = _DeviceModel(h)
-                _DEVICE_MODELS[key] = dm
-            self._models[(T, dev, layered)] = dm
+            with _CREATE_LOCK:
+                self._create_locked(T, dev, layered)
         return self._models[(T, dev, layered)].handle
+
+    def _create_locked(self, T, dev, layered):
+        global N_DEVICE_MODELS_CREATED
+        if (T, dev, layered) in self._models:
+            return
+        key = (self._sd_hash, self.unet_input_dim, self.dim_mults, T, dev, layered)
+        dm = _DEVICE_MODELS.get(key)
+        if dm is None:
+            lib = _lib.load()
+            n = len(self._sd)
+            ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in self._sd.values()])
+            numels = (C.c_int64 * n)(*[v.size for v in self._sd.values()])
+            h = C.c_void_p()
+            # (mmd_unet_create reads MMD_AMD_UNET_LAYERED: set to this object's choice for the call)
+            saved = os.environ.get("MMD_AMD_UNET_LAYERED")
+            os.environ["MMD_AMD_UNET_LAYERED"] = "1" if layered else "0"
+            try:
+                with torch.cuda.device(dev):
+                    _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), T, ptrs, numels, n,
+                                                   _lib.current_stream_ptr()))
+            finally:
+                if saved is None:
+                    del os.environ["MMD_AMD_UNET_LAYERED"]
+                else:
+                    os.environ["MMD_AMD_UNET_LAYERED"] = saved
+            N_DEVICE_MODELS_CREATED += 1
+            dm = _DeviceModel(h)
+            _DEVICE_MODELS[key] = dm
+        self._models[(T, dev, layered)] = dm
 
     def workspace(self, n_traj, device, sampler=False):
         """Scratch for one call: one buffer per (device, stream), so calls issued on different streams never share the

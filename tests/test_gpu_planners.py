@@ -570,3 +570,57 @@ def test_extra_objects_guide_and_occupancy_g14():
     coll = task.compute_collision(torch.from_numpy(g["points"]))
     assert np.array_equal(coll.cpu().numpy().reshape(-1), g["coll_random"].reshape(-1))
 
+
+
+def test_plan_concurrently_equals_the_sequential_calls():
+    """planners.plan_concurrently: independent planner calls on one host thread + one stream each.  (a) three MPD planners of the
+    Highways case with constraints: the default seeds are the ones the sequential loop draws, so the outputs are bitwise those of the
+    loop; (b) the four MPDEnsemble planners of BASELINE's config 4 under explicit seeds; (c) re-plans from an experience (the forward
+    noising draws under the call's seed too); a planner listed twice is refused."""
+    from mmd_amd import diffusion_model as dm
+    from mmd_amd.constraints import MultiPointConstraint
+    from mmd_amd.planners import MPD, MPDEnsemble, PathBatchExperience, plan_concurrently
+    starts, goals = synth.start_goal_circle(10, 0.45)
+    paths = synth.straight_line_paths(starts, goals, H)
+
+    def soft_for(r):
+        c = MultiPointConstraint(q_l=[torch.from_numpy(paths[j, t]) for j in range(10) if j != r for t in range(1, H)],
+                                 t_range_l=[(t, t + 1) for j in range(10) if j != r for t in range(1, H)])
+        c.is_soft = True
+        return c
+    robots = (1, 4, 7)
+    ps = [MPD(start_state_pos=torch.from_numpy(starts[r]), goal_state_pos=torch.from_numpy(goals[r]), **_mpd_kwargs(seed=18 + r))
+          for r in robots]
+    calls = [(p, torch.from_numpy(starts[r]), torch.from_numpy(goals[r]), [soft_for(r)]) for p, r in zip(ps, robots)]
+    draws = dm._GLOBAL_DRAWS
+    seq = [c[0](*c[1:]) for c in calls]
+    dm._GLOBAL_DRAWS = draws                                  # the same point of the global stream for the concurrent run
+    con = plan_concurrently(calls)
+    for a, b in zip(seq, con):
+        assert torch.equal(a.trajs_iters, b.trajs_iters) and torch.equal(a.trajs_final, b.trajs_final)
+        assert a.idx_best_traj == b.idx_best_traj and b.t_total > 0
+    assert all(p.guide.extra_cost_l == [[]] for p in ps)
+    assert not torch.equal(con[0].trajs_iters[-1], con[1].trajs_iters[-1])
+    # (c) re-plans seeded by the previous batches
+    seeds = [901, 902, 903]
+    calls2 = [c + (PathBatchExperience(o.trajs_final),) for c, o in zip(calls, seq)]
+    seq2 = [c[0](*c[1:], seed=s) for c, s in zip(calls2, seeds)]
+    con2 = plan_concurrently(calls2, seeds=seeds)
+    for a, b in zip(seq2, con2):
+        assert a.trajs_iters.shape[0] == 5 and torch.equal(a.trajs_iters, b.trajs_iters)
+    with pytest.raises(ValueError):
+        plan_concurrently([calls[0], calls[0]])
+    # (b) config 4's ensemble planners
+    sd = synth.synth_unet_state_dict(0)
+    tr = {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])}
+    ecalls = []
+    for r in range(4):
+        start, goal = torch.tensor([-0.7, -0.6 + 0.4 * r]), torch.tensor([2.7, 0.6 - 0.4 * r])
+        ecalls.append((MPDEnsemble(model_ids=("EnvEmptyNoWait2D-RobotPlanarDisk",) * 2, transforms=tr, planner_alg="mmd",
+                                   start_state_pos=start, goal_state_pos=goal, n_samples=8, model_state_dicts=[sd, sd],
+                                   model_args=dict(n_diffusion_steps=25), device="cuda", seed=18 + r), start, goal))
+    eseeds = [7001, 7002, 7003, 7004]
+    eseq = [c[0](*c[1:], seed=s) for c, s in zip(ecalls, eseeds)]
+    econ = plan_concurrently(ecalls, seeds=eseeds)
+    for a, b in zip(eseq, econ):
+        assert a.trajs_iters.shape[-2] == 2 * H and torch.equal(a.trajs_iters, b.trajs_iters)
