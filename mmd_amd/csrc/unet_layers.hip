@@ -701,6 +701,8 @@ const void* mconv_fn(int cs) {
 template <int KIND>
 const void* mconv_fn(int cs, int kch) { return kch <= 64 ? mconv_fn<KIND, 1>(cs) : mconv_fn<KIND, 2>(cs); }
 constexpr int kNumCUs = 256;                       // MI355X
+// MMD_AMD_MCONV_MAX_CS (A/B, sampled at load): the widest column slice mconv_kernel is launched with (default 128)
+static const int kMconvMaxCs = [] { const char* e = getenv("MMD_AMD_MCONV_MAX_CS"); return e && atoi(e) >= 16 ? atoi(e) : 128; }();
 // workgroups of `fn` with `shm` bytes of LDS that one CU holds (cached: the launches of a forward ask 47 times)
 int mconv_resident(const void* fn, size_t shm) {
   static std::mutex mu;
@@ -870,7 +872,7 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     const int rows = kind == 2 ? c.l_in / 2 : c.l_in, spw = 64 / rows, n_wg = (n + spw - 1) / spw;
     int cs = 0;                                            // the widest slice that leaves >= 768 workgroups, else the narrowest there is
     for (int w : {128, 64, 32, 16})
-      if (cols % w == 0 && w % unit == 0 && (!cs || (long long)n_wg * (cols / cs) < 768)) cs = w;
+      if (w <= kMconvMaxCs && cols % w == 0 && w % unit == 0 && (!cs || (long long)n_wg * (cols / cs) < 768)) cs = w;
     MMD_REQUIRE(cs && rows >= 8 && rows <= 64, "layered_forward: no slice for a layer of %d columns", cols);
     MConvArgs ma{};
     ma.c = c;
