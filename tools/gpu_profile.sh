@@ -1,7 +1,7 @@
 #!/bin/bash
 # Full GPU-box session for a round's records: parity tests, smoke, bench, rocprofv3 kernel stats of the SAME bench command,
 # PMC passes (separate runs, --kernel-trace only) for unet_kernel (a stream chunk's launch size) and for the kernels of a
-# bench round (the guided step kernel), forward times by batch size, per-GPU shard costs, the N > 1 rehearsal.
+# bench round (the guided step kernel), forward times by batch size, per-GPU shard costs, the layer-by-layer path, the N > 1 rehearsal.
 # Usage: tools/gpu_profile.sh [tag]   (outputs under gpurun_out/<tag>_*)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
@@ -29,4 +29,10 @@ rm -rf $OUT/prof/bench_results.db
 timeout 300 python tools/unet_forward_loop.py 256 512 1024 2048 4096 2>&1 | grep "n=" | tee $OUT/${TAG}_unet_sizes.txt
 timeout 300 python tools/dbg/shard_cost.py strong 1 2 4 8 2>&1 | grep "W=" | tee $OUT/${TAG}_shard_cost.txt
 timeout 300 python tools/dbg/shard_cost.py weak 1 2 4 8 2>&1 | grep "W=" | tee -a $OUT/${TAG}_shard_cost.txt
+# the layer-by-layer TemporalUnet path (option 1 / option 0 forced): forward by batch size on the matrix pipe and on the vector ALUs, and
+# a planning round of the headline workload with the option-1 network
+for v in 0 1; do MMD_AMD_LAYERED_VALU=$v timeout 300 python tools/dbg/layered_time.py 64 256 1024 4096 2>&1 | grep "n=" | tee -a $OUT/${TAG}_layered_time.txt; done
+for v in 0 1; do MMD_AMD_LAYERED_VALU=$v timeout 600 python tools/dbg/option1_round.py 3 2>&1 | grep "dim_mults" | tee -a $OUT/${TAG}_option1_round.txt; done
+# config4 with the planner calls one after the other (the default issues them concurrently)
+timeout 600 python bench.py --workload config4 --steps 10 --warmup 2 --sequential-planners --no-pmc --no-power-probe 2>>$OUT/bench.err | tee $OUT/${TAG}_bench_config4_sequential.json | cut -c1-260
 bash tools/gpu_rehearsal.sh ${TAG}
