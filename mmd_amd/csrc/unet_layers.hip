@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
   if (AHEAD) request_rows(0);
   __syncthreads();                                         // smax is zero
   for (unsigned seq = 0;; ++seq) {                         // the stages (item, chunk) of this workgroup
-    const int c_lo = ch * m.kch, NB = chunk_blocks(ch), KCj = NB / 4;
+    const int NB = chunk_blocks(ch), KCj = NB / 4;
     const int PS = NB * SROWS * 16;
     unsigned* const mxs = smax + 8 * (seq & 1);
     if (seq) __syncthreads();                              // every wave is done reading the previous stage's slab / output tile
