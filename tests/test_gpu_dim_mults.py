@@ -71,7 +71,7 @@ def test_layered_forward_bits_do_not_depend_on_the_batch(monkeypatch, dm):
     """The launch shape of the layer kernels follows the batch size (matrix-pipe kernel: slices of 16 .. 128 GEMM columns per workgroup, 1 .. 8
     items per workgroup; vector-ALU kernels: 1, 2 or 4 output channels per thread); every sum is DEFINED as a fixed tree (the K order of the
     GEMM, the GroupNorm statistics' balanced tree over channels and rows), so a trajectory's eps must not change by a bit with the size of
-    the batch it sits in -- n = 6 (a partial item at every level), 200, 800 and 4099 (the widest slices, several items per workgroup, a
+    the batch it sits in -- n = 1, 6, 13 (partial items at every level), 200, 800 and 4099 (the widest slices, several items per workgroup, a
     partial last item) -- and for option 0 every size must agree with the fused kernel."""
     layered = _unet(32, dm, layered=True)
     layered.handle(25, "cuda")
@@ -83,6 +83,8 @@ def test_layered_forward_bits_do_not_depend_on_the_batch(monkeypatch, dm):
     assert torch.equal(layered(x[:200].contiguous(), 7), big[:200])
     assert torch.equal(layered(x[600:608].contiguous(), 7), big[600:608])
     assert torch.equal(layered(x[4093:4099].contiguous(), 7), huge[4093:4099])
+    assert torch.equal(layered(x[5:6].contiguous(), 7), huge[5:6])                 # a batch of one
+    assert torch.equal(layered(x[100:113].contiguous(), 7), huge[100:113])
     x = x[:800].contiguous()
     if dm == (1, 2, 4):
         fused = _unet(32, dm, layered=False)
