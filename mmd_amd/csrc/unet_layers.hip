@@ -219,6 +219,11 @@ struct MConvArgs {
   const float* isc;                   // [columns] inverse weight scales
   unsigned stride;                    // (every chunk but the last is kch channels wide: one stride)
   int n_chunks, kch, n;
+  // KIND 4: the block's second Conv1dBlock (c_out -> c_out, one chunk): its packs and GroupNorm parameters; c.add_c (the time bias)
+  // follows the first conv, c.add_t (the residual) the second
+  const uint4* wpk2;
+  const float* isc2;
+  const float* bias2; const float* gamma2; const float* beta2;
 };
 // -DMCONV_TIMING (tools/dbg/mconv_phases.py builds it): wave 0 of every workgroup adds its clock64() phase times to a table indexed by
 // (KIND, log2 l_in - 3, NTW * MTW): staging loads + maxima, conversion, GEMM, exchange, statistics, tail, whole; read and cleared by
@@ -234,6 +239,7 @@ template <> struct MKind<0> { static constexpr int K = 5, S = 1, RD = 5, NR = 3;
 template <> struct MKind<1> { static constexpr int K = 1, S = 1, RD = 4, NR = 3; };
 template <> struct MKind<2> { static constexpr int K = 3, S = 2, RD = 3, NR = 5; };
 template <> struct MKind<3> { static constexpr int K = 3, S = 1, RD = 3, NR = 3; };
+template <> struct MKind<4> { static constexpr int K = 5, S = 1, RD = 5, NR = 3; };   // a whole ResidualTemporalBlock: two KIND 0 convs
 // V adjacent floats (V = 1, 2, 4 or 8) of a blocked tensor from / to global memory (a run inside one 32-byte block: 4 V-byte aligned)
 template <int V> __device__ __forceinline__ void ld_run(float (&d)[V], const float* p) {
   if constexpr (V == 1) d[0] = p[0];
@@ -255,7 +261,7 @@ template <int V> __device__ __forceinline__ void st_run(float* p, const float (&
 // that the weight ring's slots are registers with exact s_waitcnt counts (with run-time tile counts the compiler drained every load)
 // NBH: channel blocks per staging thread (1: chunks of <= 64 channels, three workgroups per CU; 2: up to 128)
 template <int NTW, int MTW, int KIND, int NBH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 && NBH == 1 ? 3 : 2))) void mconv_kernel(MConvArgs m) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 && NBH == 1 && KIND != 4 ? 3 : 2))) void mconv_kernel(MConvArgs m) {
   constexpr int K = MKind<KIND>::K, S = MKind<KIND>::S, RD = MKind<KIND>::RD, NR = MKind<KIND>::NR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ConvArgs& a = m.c;
@@ -270,11 +276,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
 #endif
   char* const slab = smem;
   // LDS: [slab: 2 pieces x (kch / 8) blocks x SROWS x 16 B | KIND 0: the output tile [cs][OST] aliases it] [red: 4 waves x 16 partial sums]
-  // [smax: 2 x 8 per-sample maxima (as uint: non-negative floats order like their bits), alternating between the chunks]
-  const int slab_bytes = 2 * (m.kch / 8) * SROWS * 16, outs_bytes = KIND == 0 ? a.cs * OST * 4 : 0;
+  // [smax: 2 x 8 per-sample maxima (as uint: non-negative floats order like their bits), alternating between the stages; 8 more for the
+  // hidden tensor of KIND 4]
+  const int slab_ch = KIND == 4 && a.c_out > m.kch ? a.c_out : m.kch;   // (KIND 4: the hidden tensor's c_out channels are a slab too)
+  const int slab_bytes = 2 * (slab_ch / 8) * SROWS * 16, outs_bytes = KIND == 0 || KIND == 4 ? a.cs * OST * 4 : 0;
   float* const red = reinterpret_cast<float*>(smem + (slab_bytes > outs_bytes ? slab_bytes : outs_bytes));
   unsigned* const smax = reinterpret_cast<unsigned*>(red + 64);
-  if (tid < 16) smax[tid] = 0u;
+  if (tid < 24) smax[tid] = 0u;
   // ---- this thread's staging rows of an item: rows tid % 32 + 32 i of the slab -> (sample, position); a padding row, a row past the slab
   // or past the batch reads the first element of the batch and is not used
   int st_smp[NR], st_l[NR], st_sm[NR];
@@ -332,8 +340,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
     inv_prev[i] = 1.f;
   }
   f32x4 acc[NTW][MTW];
+  // the weight ring: B fragments of step st of the wave's n-tiles nt0 + t (wp: the wave's first fragment, tstride: one n-tile further)
+  u32x4 b[RD][NTW][2];
+  auto load_b = [&](const u32x4* wp, size_t tstride, int slot, int st) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      b[slot][t][0] = wp[t * tstride + (size_t)st * 128];
+      b[slot][t][1] = wp[t * tstride + (size_t)st * 128 + 64];
+    }
+  };
+  auto ring_start = [&](const u32x4* wp, size_t tstride) {
+#pragma unroll
+    for (int j = 0; j < RD; ++j) load_b(wp, tstride, j, j);
+  };
+  // the GEMM of one chunk: `steps` = K x KCj steps (tap, kc), tap-major, over the slab's KCj x 4 channel blocks (PS: bytes of a piece)
+  auto gemm = [&](const u32x4* wp, size_t tstride, int steps, int KCj, int PS) {
+    auto group = [&](int base, auto refill) {              // RD steps: slot j holds step base + j and is refilled with step base + j + RD
+#pragma unroll
+      for (int j = 0; j < RD; ++j) {
+        const int st = base + j, tap = st / KCj, kc = st - tap * KCj;
+        const char* const ablk = slab + ((size_t)(KCj * g + kc) * SROWS + tap) * 16;
+        u32x4 af[MTW][2];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+          af[i][0] = *reinterpret_cast<const u32x4*>(ablk + arow[i] * 16);
+          af[i][1] = *reinterpret_cast<const u32x4*>(ablk + PS + arow[i] * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) vb_three<false>(acc[t][i], af[i], b[j][t]);
+        if (decltype(refill)::value) load_b(wp, tstride, j, st + RD);
+      }
+    };
+    // (the last group peeled: every load of the loop is unconditional, so the waits count loads instead of draining them)
+    for (int base = 0; base < steps - RD; base += RD) group(base, std::true_type{});
+    group(steps - RD, std::false_type{});
+  };
   // (the widest slice keeps no rows in flight across its GEMM: the registers are the weight ring's -- its stages are GEMM-bound)
-  constexpr bool AHEAD = NTW == 1;
+  constexpr bool AHEAD = NTW == 1 && KIND != 4;          // (nor does the two-conv block: its rows would be held through both tails)
   int item = blockIdx.x, ch = 0, s0 = item * SPW;
   set_rows(s0);
   if (AHEAD) request_rows(0);
@@ -344,6 +389,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
     unsigned* const mxs = smax + 8 * (seq & 1);
     if (seq) __syncthreads();                              // every wave is done reading the previous stage's slab / output tile
     if (ch == 0) {
+      if (KIND == 4 && tid < 8) smax[16 + tid] = 0u;       // (the maxima of the block's hidden tensor: the previous item is done with them)
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
         inv_prev[i] = 1.f;
@@ -356,16 +402,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
     // the wave's B fragments of step st: n-tile nt0 + t, pieces q
     const u32x4* const wp = reinterpret_cast<const u32x4*>(m.wpk) + (size_t)ch * m.stride + (size_t)(c0 / 16 + nt0) * steps * 128 + lane;
     const size_t tstride = (size_t)steps * 128;            // one n-tile further
-    u32x4 b[RD][NTW][2];
-    auto load_b = [&](int slot, int st) {
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        b[slot][t][0] = wp[t * tstride + (size_t)st * 128];
-        b[slot][t][1] = wp[t * tstride + (size_t)st * 128 + 64];
-      }
-    };
-#pragma unroll
-    for (int j = 0; j < RD; ++j) load_b(j, j);
+    ring_start(wp, tstride);
     if (!AHEAD) request_rows(ch);
     {
       // the samples' maxima over the chunk
@@ -422,32 +459,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
     }
     __syncthreads();
     MCONV_T(1)
-    {
-      auto group = [&](int base, auto refill) {            // RD steps: slot j holds step base + j and is refilled with step base + j + RD
-#pragma unroll
-        for (int j = 0; j < RD; ++j) {
-          const int st = base + j, tap = st / KCj, kc = st - tap * KCj;
-          const char* const ablk = slab + ((size_t)(KCj * g + kc) * SROWS + tap) * 16;
-          u32x4 af[MTW][2];
-#pragma unroll
-          for (int i = 0; i < MTW; ++i) {
-            af[i][0] = *reinterpret_cast<const u32x4*>(ablk + arow[i] * 16);
-            af[i][1] = *reinterpret_cast<const u32x4*>(ablk + PS + arow[i] * 16);
-          }
-#pragma unroll
-          for (int i = 0; i < MTW; ++i)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) vb_three<false>(acc[t][i], af[i], b[j][t]);
-          if (decltype(refill)::value) load_b(j, st + RD);
-        }
-      };
-      // (the last group peeled: every load of the loop is unconditional, so the waits count loads instead of draining them)
-      for (int base = 0; base < steps - RD; base += RD) group(base, std::true_type{});
-      group(steps - RD, std::false_type{});
-    }
+    gemm(wp, tstride, steps, KCj, PS);
     MCONV_T(2)
     if (last_chunk) {
-      if (KIND != 0) {
+      if (KIND != 0 && KIND != 4) {
         // ---- plain convs: column scale x sample scale, + bias, stored from the accumulators (C/D layout: lane = column lane & 15, rows 4 g ..
         // 4 g + 3 of the M tile = four consecutive output rows of one sample) into the blocked output: the 16 lanes of a row write 64
         // contiguous bytes (two channel blocks; the transposed conv: one block at the positions 2 m and 2 m + 1)
@@ -468,58 +483,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
         MCONV_T(5)
       } else {
         // ---- Conv1dBlock tail.  A thread owns rows 4 rq .. 4 rq + 3 (one sample: rq = tid % 16) x the NIT adjacent channels cl NIT .. of the
-        // slice (cl = tid / 16).  Its global operands are requested now, so that their latency passes under the exchange
+        // slice (cl = tid / 16)
         float* const outs = reinterpret_cast<float*>(smem);      // [cs][OST] conv output (64 rows + 4 of padding: conflict-free column writes)
         constexpr int NIT = NTW * MTW;                           // = cs / 16
         const int rq = tid & 15, cl = tid >> 4, r0 = 4 * rq, tsm = r0 >> lsh, tl = r0 & (L - 1), tsmp = s0 + tsm, tc = c0 + cl * NIT;
-        float gm[NIT], bt[NIT], ad[4][NIT];                      // gamma, beta; the addend (time bias per channel, or the residual) per (row, channel)
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-          gm[k] = a.gamma[tc + k];
-          bt[k] = a.beta[tc + k];
-        }
-        if (a.add_c) {
-#pragma unroll
-          for (int k = 0; k < NIT; ++k) ad[0][k] = ad[1][k] = ad[2][k] = ad[3][k] = a.add_c[tc + k];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (a.add_t && tsmp < m.n) {
-              ld_run<NIT>(ad[e], a.add_t + bl_off(tsmp, a.c_out, L, tc, tl + e));
-            } else {
-#pragma unroll
-              for (int k = 0; k < NIT; ++k) ad[e][k] = 0.f;
-            }
-          }
-        }
-        float kc_[NTW], bs_[NTW];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          kc_[t] = m.isc[c0 + 16 * (nt0 + t) + row];
-          bs_[t] = a.bias[c0 + 16 * (nt0 + t) + row];
-        }
-        __syncthreads();                                         // the slab is dead: its memory becomes the output tile
-        // ---- accumulators -> outs[c][r64] (C/D layout: lane = column lane & 15, rows 4 g .. 4 g + 3 of the M tile), scaled back, + bias
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          const int ocl = 16 * (nt0 + t) + row;
-#pragma unroll
-          for (int i = 0; i < MTW; ++i) {
-            const int r64 = 16 * (mt0 + i * WPT) + 4 * g;
-            const float k = kc_[t] * inv_prev[i], bs = bs_[t];
-            *reinterpret_cast<float4*>(outs + ocl * OST + r64) =
-                make_float4(fmaf(acc[t][i][0], k, bs), fmaf(acc[t][i][1], k, bs), fmaf(acc[t][i][2], k, bs), fmaf(acc[t][i][3], k, bs));
-          }
-        }
-        __syncthreads();
-        MCONV_T(3)
-        // ---- GroupNorm statistics of (sample, group): cpg channels x L positions.  The sum of a group is DEFINED as: per channel the four rows
-        // of a quad ((x0 + x1) + (x2 + x3)); a balanced tree over the channel index (within the thread, then lanes 16 and 32 apart, then
-        // waves); then a balanced tree over the sample's row quads (lanes 1, 2, 4, 8 apart) -- whatever the slice width
-        float4 x[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) x[k] = *reinterpret_cast<const float4*>(outs + (cl * NIT + k) * OST + r0);
         const int cpg = a.c_out / N_GROUPS, clu = cpg / NIT;     // channel lanes (16 apart) per group: 2, 4, 8 or 16
+        // the sum of a (sample, group) -- cpg channels x L positions -- is DEFINED as: per channel the four rows of a quad ((x0 + x1) + (x2 +
+        // x3)); a balanced tree over the channel index (within the thread, then lanes 16 and 32 apart, then waves); then a balanced tree
+        // over the sample's row quads (lanes 1, 2, 4, 8 apart) -- whatever the slice width
         auto group_sum = [&](float (&s)[NIT]) -> float {
 #pragma unroll
           for (int w = 1; w < NIT; w *= 2)
@@ -542,21 +513,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
           if (L >= 64) v += __shfl_xor(v, 8);
           return v;
         };
-        const float per = (float)(cpg << lsh);
-        float s[NIT];
+        // accumulators (in units of 1 / inv[i]) -> conv output + bias -> GroupNorm -> Mish -> + addend (per channel, or per element from a
+        // blocked tensor) -> o[row][channel] of the thread's 4 x NIT patch.  The global operands are requested first, so that their latency
+        // passes under the exchange
+        auto block_tail = [&](const float* bias, const float* gamma, const float* beta, const float* isc, const float* add_c,
+                              const float* add_t, const float (&inv)[MTW], float (&o)[4][NIT]) {
+          float gm[NIT], bt[NIT], ad[4][NIT];                    // gamma, beta; the addend per (row, channel)
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) s[k] = (x[k].x + x[k].y) + (x[k].z + x[k].w);
-        const float mean = group_sum(s) / per;
+          for (int k = 0; k < NIT; ++k) {
+            gm[k] = gamma[tc + k];
+            bt[k] = beta[tc + k];
+          }
+          if (add_c) {
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-          const float d0 = x[k].x - mean, d1 = x[k].y - mean, d2 = x[k].z - mean, d3 = x[k].w - mean;
-          s[k] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-        const float rstd = 1.f / sqrtf(group_sum(s) / per + 1e-5f);
-        MCONV_T(4)
-        // ---- normalise + Mish + addend (the fused kernel's arithmetic, gn_mish.h) -> y, blocked: a row's NIT channels are one run
-        if (tsmp < m.n) {
-          float o[4][NIT];
+            for (int k = 0; k < NIT; ++k) ad[0][k] = ad[1][k] = ad[2][k] = ad[3][k] = add_c[tc + k];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (add_t && tsmp < m.n) {
+                ld_run<NIT>(ad[e], add_t + bl_off(tsmp, a.c_out, L, tc, tl + e));
+              } else {
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) ad[e][k] = 0.f;
+              }
+            }
+          }
+          float kc_[NTW], bs_[NTW];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            kc_[t] = isc[c0 + 16 * (nt0 + t) + row];
+            bs_[t] = bias[c0 + 16 * (nt0 + t) + row];
+          }
+          __syncthreads();                                       // the slab is dead: its memory becomes the output tile
+          // accumulators -> outs[c][r64] (C/D layout: lane = column lane & 15, rows 4 g .. 4 g + 3 of the M tile), scaled back, + bias
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            const int ocl = 16 * (nt0 + t) + row;
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+              const int r64 = 16 * (mt0 + i * WPT) + 4 * g;
+              const float k = kc_[t] * inv[i], bs = bs_[t];
+              *reinterpret_cast<float4*>(outs + ocl * OST + r64) =
+                  make_float4(fmaf(acc[t][i][0], k, bs), fmaf(acc[t][i][1], k, bs), fmaf(acc[t][i][2], k, bs), fmaf(acc[t][i][3], k, bs));
+            }
+          }
+          __syncthreads();
+          MCONV_T(3)
+          float4 x[NIT];
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) x[k] = *reinterpret_cast<const float4*>(outs + (cl * NIT + k) * OST + r0);
+          const float per = (float)(cpg << lsh);
+          float s[NIT];
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) s[k] = (x[k].x + x[k].y) + (x[k].z + x[k].w);
+          const float mean = group_sum(s) / per;                 // two passes, as the reference: the mean, then the squared deviations
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) {
+            const float d0 = x[k].x - mean, d1 = x[k].y - mean, d2 = x[k].z - mean, d3 = x[k].w - mean;
+            s[k] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          }
+          const float rstd = 1.f / sqrtf(group_sum(s) / per + 1e-5f);
+          MCONV_T(4)
+          // normalise + Mish + addend (the fused kernel's arithmetic, gn_mish.h)
 #pragma unroll
           for (int k = 0; k < NIT; ++k) {
             const GnCoef cf = gn_coef(mean, rstd, gm[k], bt[k]);
@@ -564,6 +582,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
             const f32x2_t hi = gn_mish2(f32x2_t{x[k].z, x[k].w}, cf, f32x2_t{ad[2][k], ad[3][k]});
             o[0][k] = lo.x; o[1][k] = lo.y; o[2][k] = hi.x; o[3][k] = hi.y;
           }
+        };
+        float o[4][NIT];
+        if (KIND == 0) {
+          block_tail(a.bias, a.gamma, a.beta, m.isc, a.add_c, a.add_t, inv_prev, o);
+        } else {
+          // ---- KIND 4, a whole ResidualTemporalBlock (cs = c_out: one slice).  The first Conv1dBlock's output + time bias stays in the
+          // workgroup: it becomes the second conv's A slab (fp16 pieces under its own per-sample scale: the maximum over the thread patches,
+          // LDS atomics as in the staging) -- the arithmetic of the two-launch form, without the tensor's trip through memory
+          block_tail(a.bias, a.gamma, a.beta, m.isc, a.add_c, nullptr, inv_prev, o);
+          const int KC2 = a.c_out / 32, NB2 = 4 * KC2, PS2 = NB2 * SROWS * 16, steps2 = K * KC2;
+          const u32x4* const wp2 = reinterpret_cast<const u32x4*>(m.wpk2) + (size_t)nt0 * steps2 * 128 + lane;
+          if (NTW == 1) ring_start(wp2, (size_t)steps2 * 128);   // (the widest slice: behind the conversion, its patch is 32 registers)
+          unsigned* const mx2 = smax + 16;
+          float mx = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+              if (tsmp >= m.n) o[e][k] = 0.f;                    // (a sample past the batch: zeros, as the staging gives)
+              mx = fmaxf(mx, fabsf(o[e][k]));
+            }
+          if (mx > 0.f) atomicMax(mx2 + tsm, __float_as_uint(mx));
+          __syncthreads();                                       // the maxima are complete, and every thread has read its patch of the tile
+          {
+            const float sc = dyn_scale(__uint_as_float(mx2[tsm])).s;
+            // the thread's NIT channels of row e: 2 NIT bytes at channel offset tc % 8 of block tc / 8 (tc = cl NIT: c0 = 0)
+            char* const dst = slab + ((size_t)(tc >> 3) * SROWS + tsm * RS + 2 + tl) * 16 + (tc & 7) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              unsigned hi[NIT / 2 > 0 ? NIT / 2 : 1], lo[NIT / 2 > 0 ? NIT / 2 : 1];
+#pragma unroll
+              for (int k = 0; k + 1 < NIT; k += 2) {
+                const F16Pair pr = f16_split2(o[e][k] * sc, o[e][k + 1] * sc);
+                hi[k / 2] = pr.hi;
+                lo[k / 2] = pr.lo;
+              }
+              if constexpr (NIT == 8) {
+                *reinterpret_cast<uint4*>(dst + e * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(dst + PS2 + e * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+              } else if constexpr (NIT == 4) {
+                *reinterpret_cast<uint2*>(dst + e * 16) = make_uint2(hi[0], hi[1]);
+                *reinterpret_cast<uint2*>(dst + PS2 + e * 16) = make_uint2(lo[0], lo[1]);
+              } else {
+                *reinterpret_cast<unsigned*>(dst + e * 16) = hi[0];
+                *reinterpret_cast<unsigned*>(dst + PS2 + e * 16) = lo[0];
+              }
+            }
+            // the padding rows (two either side of a sample) of every block, both pieces
+            for (int i = tid; i < SPW * 4 * NB2 * 2; i += 256) {
+              const int h = i & 3, sm = (i >> 2) % SPW, bq = (i >> 2) / SPW;        // bq = piece * NB2 + block
+              *reinterpret_cast<uint4*>(slab + ((size_t)bq * SROWS + sm * RS + (h < 2 ? h : L + h)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+          }
+          if (NTW != 1) ring_start(wp2, (size_t)steps2 * 128);
+          float inv2[MTW];
+#pragma unroll
+          for (int i = 0; i < MTW; ++i) {
+            inv2[i] = dyn_scale(__uint_as_float(mx2[csm[i]])).inv;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          __syncthreads();                                       // the second conv's slab is complete
+          gemm(wp2, (size_t)steps2 * 128, steps2, KC2, PS2);
+          block_tail(m.bias2, m.gamma2, m.beta2, m.isc2, nullptr, a.add_t, inv2, o);
+        }
+        // -> y, blocked: a row's NIT channels are one run
+        if (tsmp < m.n) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) st_run<NIT>(a.y + bl_off(tsmp, a.c_out, L, tc, tl + e), o[e]);
         }
@@ -743,6 +828,8 @@ struct LayeredUnet {
   size_t down_w[MAX_LEVELS - 1], down_b[MAX_LEVELS - 1], up_w[MAX_LEVELS - 1], up_b[MAX_LEVELS - 1];
   size_t fin_w5, fin_b5, fin_g, fin_be, fin_w1, fin_b1;
   MPack fin_m, down_m[MAX_LEVELS - 1], up_m[MAX_LEVELS - 1];
+  int rtb_fused = 64;                 // MMD_AMD_RTB_FUSED=<channels> (A/B, read at create): the widest ResidualTemporalBlock that runs as ONE launch
+                                      // (0: none -- two Conv1dBlock launches each; default 64: with 128 channels the one-launch form spills)
   bool mfma = false;                  // every layer has f16x2 packs: the matrix-pipe kernels with blocked activations; else the vector-ALU kernels
   int per_sample = 0;                 // floats of the largest activation tensor of a sample (64 x unet_input_dim)
 };
@@ -788,6 +875,7 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
     u->up_m[i] = push_mfma_up(blob, tensors[s.t_up[i][0]], cu, cu);
   }
   u->fin_m = push_mfma5(blob, tensors[s.t_final[0]], s.uid, s.uid);
+  if (const char* e = getenv("MMD_AMD_RTB_FUSED")) u->rtb_fused = atoi(e);
   u->mfma = !kLayeredValu && u->fin_m.w && s.uid % 8 == 0;
   for (size_t r = 0; r < u->rtb.size(); ++r) {
     const LRtb& R = u->rtb[r];
@@ -809,7 +897,7 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
   // widest Conv1dBlock input: ups.0.0 of a four-level net stages 2 x 8 uid x 8 channels x (8 + 8) positions (64 KB at uid 64)
   for (const void* f : {(const void*)conv5_block_kernel<1>, (const void*)conv5_block_kernel<2>, (const void*)conv5_block_kernel<4>})
     MMD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-  if (mconv_set_lds<0>() || mconv_set_lds<1>() || mconv_set_lds<2>() || mconv_set_lds<3>()) return 1;
+  if (mconv_set_lds<0>() || mconv_set_lds<1>() || mconv_set_lds<2>() || mconv_set_lds<3>() || mconv_set_lds<4>()) return 1;
   MMD_HIP_CHECK(hipMemcpyAsync(u->blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, st));
   MMD_HIP_CHECK(hipStreamSynchronize(st));
   u->blob_bytes = blob.size() * sizeof(float);
@@ -868,11 +956,13 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   // narrower slices (down to `unit`: whole n-tiles, for a Conv1dBlock whole GroupNorm groups) while the launch has fewer than 3
   // workgroups per CU
   auto mconv_ok = [&](const MPack& mp, int c1, int c2, int in_cl) { return u->mfma && mp.w && (in_cl ? c1 == 4 && !c2 : c1 % 8 == 0 && c2 % 8 == 0); };
-  auto mconv = [&](int kind, const MPack& mp, ConvArgs c, int cols, int unit) -> int {
+  auto mconv = [&](int kind, const MPack& mp, ConvArgs c, int cols, int unit, const MPack* mp2 = nullptr, size_t b2 = 0, size_t g2 = 0,
+                   size_t be2 = 0) -> int {
     const int rows = kind == 2 ? c.l_in / 2 : c.l_in, spw = 64 / rows, n_wg = (n + spw - 1) / spw;
     int cs = 0;                                            // the widest slice that leaves >= 768 workgroups, else the narrowest there is
     for (int w : {128, 64, 32, 16})
       if (w <= kMconvMaxCs && cols % w == 0 && w % unit == 0 && (!cs || (long long)n_wg * (cols / cs) < 768)) cs = w;
+    if (kind == 4) cs = cols;                              // a whole ResidualTemporalBlock: one slice (32, 64 or 128 channels)
     MMD_REQUIRE(cs && rows >= 8 && rows <= 64, "layered_forward: no slice for a layer of %d columns", cols);
     MConvArgs ma{};
     ma.c = c;
@@ -883,9 +973,18 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     ma.n_chunks = mp.n_chunks;
     ma.kch = mp.kch;
     ma.n = n;
-    const size_t slab = (size_t)2 * (mp.kch / 8) * spw * (c.l_in + 4) * 16, outs = kind == 0 ? (size_t)cs * OST * 4 : 0;
-    const size_t shm = std::max(slab, outs) + (64 + 16) * sizeof(float);   // + the statistics' exchange + the samples' maxima
-    const void* const fn = kind == 0 ? mconv_fn<0>(cs, mp.kch) : kind == 1 ? mconv_fn<1>(cs, mp.kch) : kind == 2 ? mconv_fn<2>(cs, mp.kch) : mconv_fn<3>(cs, mp.kch);
+    if (kind == 4) {
+      MMD_REQUIRE(mp2 && mp2->w && mp2->n_chunks == 1 && (cols == 32 || cols == 64 || cols == 128), "layered_forward: no fused block of %d channels", cols);
+      ma.wpk2 = reinterpret_cast<const uint4*>(B + mp2->w);
+      ma.isc2 = B + mp2->isc;
+      ma.bias2 = B + b2; ma.gamma2 = B + g2; ma.beta2 = B + be2;
+    }
+    // LDS: the widest slab (the staged chunk; KIND 4: also the hidden tensor's c_out channels), or the output tile over it
+    const size_t slab = (size_t)2 * (std::max(mp.kch, kind == 4 ? cols : 0) / 8) * spw * (c.l_in + 4) * 16,
+                 outs = kind == 0 || kind == 4 ? (size_t)cs * OST * 4 : 0;
+    const size_t shm = std::max(slab, outs) + (64 + 24) * sizeof(float);   // + the statistics' exchange + the samples' maxima
+    const void* const fn = kind == 0 ? mconv_fn<0>(cs, mp.kch) : kind == 1 ? mconv_fn<1>(cs, mp.kch) : kind == 2 ? mconv_fn<2>(cs, mp.kch)
+                         : kind == 3 ? mconv_fn<3>(cs, mp.kch) : mconv_fn<4>(cs, mp.kch);
     // the items (64 / rows samples each) of a slice go to as many workgroups as the chip holds at once, the same number each (+- 1): a
     // workgroup requests its next item's rows under the current one's GEMM and tail
     const int ny = cols / cs, cap = std::max(1, mconv_resident(fn, shm) * kNumCUs / ny), per_wg = (n_wg + cap - 1) / cap;
@@ -938,8 +1037,20 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
   };
   // one ResidualTemporalBlock (layers.py:346-358): (x1 | x2) [cin][L] -> out [cout][L]
   auto rtb = [&](const LRtb& R, const float* x1, int c1, const float* x2, int c2, int in_cl, int L, float* out) -> int {
-    if (int rc = block5(x1, c1, x2, c2, in_cl, L, R.cout, R.wa, R.ba, R.ga, R.bea, tt + R.tb_off, nullptr, tmp, R.ma)) return rc;
+    // matrix pipe, 32 / 64 / 128 output channels: the two Conv1dBlocks in ONE launch (mconv_kernel KIND 4: the hidden tensor stays in the
+    // workgroup; same bits as the two launches)
+    const bool fused = u->mfma && R.mb.n_chunks == 1 && (R.cout == 32 || R.cout == 64 || R.cout == 128) && R.cout <= u->rtb_fused;
     const float* res = x1;                                   // identity residual (cin == cout: never a concatenated input)
+    if (fused && R.res) {
+      if (int rc = plain(0, 1, x1, c1, x2, c2, in_cl, L, L, R.cout, 0, R.wr, R.br, resb, R.mr)) return rc;
+      res = resb;
+    }
+    if (fused) {
+      MMD_REQUIRE(mconv_ok(R.ma, c1, c2, in_cl), "layered_forward: a block of %d -> %d channels has no matrix-pipe form", c1 + c2, R.cout);
+      return mconv(4, R.ma, ConvArgs{x1, x2, c1, c2, L, L, R.cout, 0, in_cl, 0, nullptr, B + R.ba, B + R.ga, B + R.bea, tt + R.tb_off, res, out},
+                   R.cout, R.cout, &R.mb, R.bb, R.gb, R.beb);
+    }
+    if (int rc = block5(x1, c1, x2, c2, in_cl, L, R.cout, R.wa, R.ba, R.ga, R.bea, tt + R.tb_off, nullptr, tmp, R.ma)) return rc;
     if (R.res) {
       if (int rc = plain(0, 1, x1, c1, x2, c2, in_cl, L, L, R.cout, 0, R.wr, R.br, resb, R.mr)) return rc;
       res = resb;

@@ -260,3 +260,21 @@ def test_layered_unet_widest_network_widest_slices_vs_oracle():
     parity_log.record("layered_unet_widest", "uid64_levels4_n3100", None, err, bound=2e-5)
     assert err < 2e-5, err
     assert torch.equal(unet(x[1000:1006].contiguous().cuda(), 11), big[1000:1006])
+
+
+def test_one_launch_residual_blocks_equal_the_two_launch_form(monkeypatch):
+    """mconv_kernel KIND 4 runs a ResidualTemporalBlock of <= 64 channels as ONE launch (the hidden tensor becomes the second conv's LDS slab
+    instead of a tensor in memory); the arithmetic is that of the two Conv1dBlock launches, so eps must be bitwise the same.
+    MMD_AMD_RTB_FUSED is read when the device model is created: two models of the same weights with different time-table lengths."""
+    x = (torch.from_numpy(synth.synth_noise(907, (1300, H, D))) * 0.7).cuda()
+    for dm in ((1, 2, 4, 8), (1, 2, 4)):
+        outs = []
+        for fused, T in (("0", 25), ("64", 26), ("128", 27)):
+            monkeypatch.setenv("MMD_AMD_RTB_FUSED", fused)
+            u = _unet(32, dm, layered=True)
+            u.handle(T, "cuda")
+            outs.append(u(x, 7))
+            outs.append(u(x[:5].contiguous(), 7))
+        assert torch.isfinite(outs[0]).all()
+        assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4])
+        assert torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[5]) and torch.equal(outs[1], outs[0][:5])
