@@ -278,3 +278,32 @@ def test_one_launch_residual_blocks_equal_the_two_launch_form(monkeypatch):
         assert torch.isfinite(outs[0]).all()
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4])
         assert torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[5]) and torch.equal(outs[1], outs[0][:5])
+
+
+def test_option1_sampling_loop_captures_into_a_hip_graph():
+    """The layer-by-layer path inside a stream capture: the 26-step guided loop of an option-1 model (39 launches per forward, their grids
+    sized from a cached occupancy query) as ONE hipGraph, replayed, against the eager loop."""
+    import gpu_common
+    from mmd_amd import _lib, ops
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    T, B, R = 25, 8, 2
+    model = _model(T)
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    guide = gpu_common.hip_guide("EnvHighways2D", [[cases.soft_group(paths, r)] for r in range(R)], n_robots=R)
+    hc = {0: torch.stack([cases.hard_conds_for(starts[r], goals[r])[0] for r in range(R)]),
+          H - 1: torch.stack([cases.hard_conds_for(starts[r], goals[r])[H - 1] for r in range(R)])}
+    hard = torch.stack([hc[0], hc[H - 1]], dim=1).cuda().contiguous()
+    tm, tg = ops.register(model), ops.register(guide)
+    sg = _lib.signed64(_lib.HARD_ROWS_START_GOAL)
+    ref = model.run_inference(None, hc, n_samples=B, n_robots=R, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn,
+                              guide=guide, n_guide_steps=20, t_start_guide=13, noise_std_extra_schedule_fn=lambda t: 0.5,
+                              n_diffusion_steps_without_noise=1, seed=77)
+    xg = torch.empty((R * B, H, D), device="cuda")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cg = torch.ops.mmd_amd.p_sample_loop(xg, hard, sg, tm, tg, R, T, 1, True, None, 77, 20, 13, 0.5, 0, True)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref).all() and torch.equal(cg, ref) and torch.equal(xg, ref[-1])
