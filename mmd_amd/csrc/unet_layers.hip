@@ -229,7 +229,7 @@ struct MConvArgs {
 // (KIND, log2 l_in - 3, NTW * MTW): staging loads + maxima, conversion, GEMM, exchange, statistics, tail, whole; read and cleared by
 // mmd_debug_mconv_clocks
 #ifdef MCONV_TIMING
-__device__ unsigned long long g_mconv_clk[4][4][9][8];
+__device__ unsigned long long g_mconv_clk[5][4][9][8];
 #define MCONV_T(i) if (tid == 0) { const long long now_ = clock64(); clk_[i] += now_ - last_; last_ = now_; }
 #else
 #define MCONV_T(i)
@@ -1095,9 +1095,9 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
 }  // namespace mmd
 
 #ifdef MCONV_TIMING
-extern "C" __attribute__((visibility("default"))) int mmd_debug_mconv_clocks(unsigned long long* out) {   // [4][4][9][8], cleared after the read
+extern "C" __attribute__((visibility("default"))) int mmd_debug_mconv_clocks(unsigned long long* out) {   // [5][4][9][8], cleared after the read
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mmd::g_mconv_clk), sizeof(mmd::g_mconv_clk)) != hipSuccess) return 1;
-  static unsigned long long zero[4 * 4 * 9 * 8];
+  static unsigned long long zero[5 * 4 * 9 * 8];
   return hipMemcpyToSymbol(HIP_SYMBOL(mmd::g_mconv_clk), zero, sizeof(zero)) != hipSuccess;
 }
 #endif

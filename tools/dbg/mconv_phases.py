@@ -25,7 +25,7 @@ u.load_state_dict(synth.synth_unet_state_dict(0, dim_mults=(1, 2, 4, 8)))
 x = torch.randn(n, 64, 4, device="cuda")
 lib = _lib.load()
 lib.mmd_debug_mconv_clocks.restype, lib.mmd_debug_mconv_clocks.argtypes = C.c_int, [C.c_void_p]
-clk = np.zeros((4, 4, 9, 8), dtype=np.uint64)
+clk = np.zeros((5, 4, 9, 8), dtype=np.uint64)
 for _ in range(3):
     u(x, 5)
 torch.cuda.synchronize()
@@ -35,9 +35,9 @@ for _ in range(REPS):
     u(x, 5)
 torch.cuda.synchronize()
 assert lib.mmd_debug_mconv_clocks(clk.ctypes.data) == 0
-names = ("scan", "stage", "gemm", "exch", "stats", "tail")
+names = ("loads", "convert", "gemm", "exch", "stats", "tail")   # (KIND 4: exch / stats / tail of both Conv1dBlocks, gemm of the first, the second GEMM under "tail")
 print(f"n = {n}: mean clock64() ticks per workgroup (wave 0) by phase; workgroups per forward")
-for kind in range(4):
+for kind in range(5):
     for li in range(4):
         for nit in range(9):
             t = clk[kind, li, nit].astype(np.float64)
