@@ -243,3 +243,15 @@ def test_constraint_points_cross_to_the_host_in_one_copy():
         assert got.dtype == np.float32 and got.shape == (37, 2) and got.flags["C_CONTIGUOUS"] and np.array_equal(got, want)
     c = CostConstraint(None, 64, q_l=as_tensors, traj_range_l=[(3, 5)] * 37, radius_l=[0.12] * 37, is_soft=True)
     assert np.array_equal(c.qs, want) and c.traj_ranges.shape == (37, 2) and c.radii.shape == (37,)
+
+
+def test_stream_seeds_are_unique_across_host_threads():
+    """planners.plan_concurrently runs planner calls on several host threads; the global draw counter behind next_stream_seed must hand
+    every caller its own value (it is the stand-in for torch's one global RNG stream in the reference)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from mmd_amd import diffusion_model as dm
+    start = dm._GLOBAL_DRAWS
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        seeds = list(pool.map(lambda _: dm.next_stream_seed(18), range(4000)))
+    assert len(set(seeds)) == 4000 and dm._GLOBAL_DRAWS == start + 4000
+    assert {s >> 24 for s in seeds} == {18}
