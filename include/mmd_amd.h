@@ -245,7 +245,10 @@ typedef struct mmd_ensemble_tile {
   float* x_dev;                      /* [n_traj, H, 4]: x_T / warm start on entry (init_noise != 0: drawn), result on exit */
   const float* hard_dev;             /* [n_robots][2][4] */
   const float* step_noise_dev;       /* [n_steps + n_steps_without_noise][n_traj, H, 4] injected draws, or NULL */
-  float* chain_dev;                  /* [n_steps + n_steps_without_noise + 1][n_traj, H, 4], or NULL */
+  float* chain_dev;                  /* [n_steps + n_steps_without_noise + 1][n_traj, H, 4], or NULL.  Rows as the reference's
+                                        chains hold them (it stores the tensor object and stitches in place,
+                                        diffusion_ensemble.py:86-103): row k of tile m >= 1 also carries the boundary rows stitched
+                                        after the earlier tiles' steps of outer step k + 1; the last row is the result */
   uint64_t seed;
 } mmd_ensemble_tile;
 

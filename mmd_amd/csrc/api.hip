@@ -318,20 +318,25 @@ int mmd_p_sample_loop_ensemble(const mmd_ensemble_tile* tiles, int n_tiles, cons
     MMD_REQUIRE(cross[c].m1 >= 0 && cross[c].m1 < n_tiles && cross[c].m2 >= 0 && cross[c].m2 < n_tiles &&
                     cross[c].ind1 >= 0 && cross[c].ind1 < H && cross[c].ind2 >= 0 && cross[c].ind2 < H,
                 "cross condition %d out of range", c);
-  // apply_cross_conditioning (sample_functions.py:17-31) over all pairs; row `crow` of the chains is kept in step
-  auto cross_all = [&](int crow) {
+  // apply_cross_conditioning (sample_functions.py:17-31) over all pairs, after tile `stepped` has taken its step of the outer step
+  // that produces chain row `crow`.  The chains are kept in step the way the reference's are: it appends the tensor OBJECT x[m]
+  // (diffusion_ensemble.py:101-103) and the stitching writes into x[m] in place, so a tile that has not stepped yet in this outer
+  // step (index > stepped) still IS its previous chain row, crow - 1, and that row receives the stitched boundary too (from 3 tiles
+  // on this is visible: re-stitching two not-yet-stepped neighbours is not idempotent in the clamped coordinate).
+  auto cross_all = [&](int crow, int stepped) {
     for (int c = 0; c < n_cross; ++c) {
       const mmd_cross_cond& C = cross[c];
-      float* ch1 = tiles[C.m1].chain_dev ? tiles[C.m1].chain_dev + (size_t)crow * traj_floats : nullptr;
-      float* ch2 = tiles[C.m2].chain_dev ? tiles[C.m2].chain_dev + (size_t)crow * traj_floats : nullptr;
-      launch_cross(tiles[C.m1].x_dev, tiles[C.m2].x_dev, ch1, ch2, C.ind1, C.ind2, C.rel, C.boundary, n, st);
+      auto row = [&](int m) -> float* {
+        return tiles[m].chain_dev ? tiles[m].chain_dev + (size_t)(m > stepped ? crow - 1 : crow) * traj_floats : nullptr;
+      };
+      launch_cross(tiles[C.m1].x_dev, tiles[C.m2].x_dev, row(C.m1), row(C.m2), C.ind1, C.ind2, C.rel, C.boundary, n, st);
     }
   };
   // x_T per tile (diffusion_ensemble.py:66-81): draw / keep, hard conditioning, then cross conditioning; chain[0]
   for (int m = 0; m < n_tiles; ++m)
     launch_init(tiles[m].x_dev, tiles[m].chain_dev, tiles[m].hard_dev, tiles[m].sampler->hard_rows, init_noise,
                 (unsigned long long)tiles[m].seed, (long long)tiles[m].sampler->traj_index_base, n, samples_per_robot, st);
-  cross_all(0);
+  cross_all(0, n_tiles);
   int k = 0;
   for (int i = n_steps - 1; i >= -n_steps_without_noise; --i, ++k) {
     // tiles step IN ORDER inside an outer step and every tile's step is followed by the cross conditioning of all pairs
@@ -349,7 +354,7 @@ int mmd_p_sample_loop_ensemble(const mmd_ensemble_tile* tiles, int n_tiles, cons
       launch_step(g[m], sd, T.x_dev, eps, T.step_noise_dev ? T.step_noise_dev + (size_t)k * traj_floats : nullptr,
                   T.chain_dev ? T.chain_dev + (size_t)(k + 1) * traj_floats : nullptr, T.hard_dev, 0, n,
                   samples_per_robot, st);
-      cross_all(k + 1);
+      cross_all(k + 1, m);
     }
   }
   MMD_HIP_CHECK(hipGetLastError());

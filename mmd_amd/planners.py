@@ -142,6 +142,74 @@ class PlanningTaskFacade:
         return free_idxs.shape[0] / trajs.shape[0]
 
 
+class PlanningTaskEnsembleFacade:
+    """What CBS / PP and MPDEnsemble read from the multi-tile task (PlanningTaskEnsemble,
+    deps/torch_robotics/torch_robotics/tasks/tasks_ensemble.py:39-365): the tile tasks, the tile <-> global transforms,
+    `compute_collision` on global positions (tile inferred from the position, tile-frame occupancy against the tile's OWN map;
+    a point outside every tile stays "in collision", :238-262) and the all-free `get_trajs_collision_and_free` stub (:271-277).
+    The per-tile collision / free split of a planner call (get_traj_unnormalized, :79-88) goes through `tasks[m]`."""
+
+    def __init__(self, task_guides: Dict[int, object], transforms: Dict[int, torch.Tensor], robot):
+        self.robot, self.tensor_args = robot, robot.tensor_args
+        self.tasks = {m: PlanningTaskFacade(g, robot) for m, g in task_guides.items()}
+        self.transforms = {m: torch.as_tensor(t, dtype=torch.float32).cpu() for m, t in transforms.items()}
+
+    def _transform(self, task_id, q):
+        t = self.transforms[task_id].to(q.device)
+        return torch.cat((t, torch.zeros(q.shape[-1] - t.shape[0], device=q.device))) if q.shape[-1] > t.shape[0] else t
+
+    def transform_q(self, task_id: int, q):
+        return q + self._transform(task_id, q)
+
+    def inverse_transform_q(self, task_id: int, q):
+        return q - self._transform(task_id, q)
+
+    def infer_task_id_from_q_idx(self, q_idx):
+        task_id = int(q_idx // HORIZON)
+        return task_id, self.tasks[task_id]
+
+    def infer_task_id_from_q(self, q):
+        """q [n, 1, >=2] global positions -> [n] tile index, -1 outside every tile; where tiles touch the LATER tile wins (:355-363)."""
+        q_pos = self.robot.get_position(torch.as_tensor(q))
+        task_ids = torch.full((q_pos.shape[0],), -1, dtype=torch.long, device=q_pos.device)
+        for i, m in enumerate(self.tasks):
+            lo = self.transform_q(m, self.robot.q_min.to(q_pos.device))          # the tile env's limits (env_base limits = +-1)
+            hi = self.transform_q(m, self.robot.q_max.to(q_pos.device))
+            mask = torch.logical_and(q_pos >= lo, q_pos <= hi).all(dim=-1).reshape(-1)
+            task_ids[mask] = i
+        return task_ids
+
+    def compute_collision(self, x, **kwargs):
+        """x [2+] | [n, 2+] global -> int64 [] -> [1] | [n] (tasks_ensemble.py:227-262); [B, H, 2] with H > 1 fails in the reference
+        too (the tile lookup is per leading row)."""
+        x = torch.as_tensor(x)
+        q = self.robot.get_position(x).to(device=self.robot.device, dtype=torch.float32)
+        shape = q.shape[:-1]
+        if q.ndim > 3:
+            raise NotImplementedError
+        if q.ndim == 3 and q.shape[1] != 1:
+            raise IndexError("PlanningTaskEnsemble.compute_collision: one position per row (tasks_ensemble.py:361-363)")
+        q = q.reshape(-1, 1, q.shape[-1])
+        collisions = torch.ones(q.shape[0], dtype=torch.long, device=q.device)
+        task_ids = self.infer_task_id_from_q(q)
+        for i, m in enumerate(self.tasks):
+            mask = task_ids == i
+            if bool(mask.any()):
+                local = self.inverse_transform_q(m, q[mask])
+                collisions[mask] = self.tasks[m].compute_collision(local.reshape(-1, local.shape[-1]), **kwargs).reshape(-1).long()
+        return collisions.view(shape).to(x.device)
+
+    def get_trajs_collision_and_free(self, trajs, return_indices=False, num_interpolation=5):
+        """tasks_ensemble.py:271-277: "return all valid"."""
+        if return_indices:
+            return (None, torch.tensor([]), trajs, torch.tensor([i for i in range(trajs.shape[0])]),
+                    torch.tensor([False for _ in range(trajs.shape[1])]))
+        return None, trajs
+
+    def compute_fraction_free_trajs(self, trajs, **kwargs):
+        return 1.0
+
+
 def _fill_output(out, guide, trajs_iters, all_free=False):
     """mpd.py:344-405 / mpd_ensemble.py:385-429 on the device: ONE fused launch (collision / free split, path length,
     smoothness, SavGol) + the per-batch argmin + the waypoint variance of the free set."""
@@ -173,6 +241,46 @@ def _fill_output(out, guide, trajs_iters, all_free=False):
         out.traj_final_free_best = free[idx_best_free]
         out.cost_best_free_traj = float(np.float32(host[B + 1 + ib]) + np.float32(host[2 * B + 1 + ib]))
         out.variance_waypoint_trajs_final_free = post.compute_variance_waypoints(free)
+    return out
+
+
+def _fill_output_ensemble(out, task, tile_trajs_final, trajs_iters):
+    """mpd_ensemble.py:385-429 + PlanningTaskEnsemble.get_traj_unnormalized / combine_trajs (tasks_ensemble.py:79-88, 162-225) on
+    the device: every tile's final samples [B, 64, 4] (tile frame) are split against the tile's OWN map (one launch per tile), a
+    sample is free iff it is free in every tile; costs, SavGol and the waypoint variance are those of the concatenated global-frame
+    trajectories [B, K*64, 4] (one launch), the best sample the cheapest free one.  Shapes as combine_trajs leaves them: index
+    tensors are int64 [n] (not [n, 1]), an empty free / colliding set is an empty tensor, and trajs_final_coll indexes the HORIZON
+    axis of the final batch with the colliding sample indices (tasks_ensemble.py:190, `trajs_final[:, idxs]`) as the reference does."""
+    trajs_final = trajs_iters[-1].contiguous()
+    B, dev = trajs_final.shape[0], trajs_final.device
+    free_mask = None
+    for m, tf in tile_trajs_final.items():
+        fm = post.postprocess_batch(task.tasks[m].guide, tf.contiguous(), smooth=False).free_mask
+        free_mask = fm if free_mask is None else free_mask & fm
+    r = post.postprocess_batch(task.tasks[next(iter(task.tasks))].guide, trajs_final, all_free=True, smooth=True)
+    idx, _ = post.select_best(free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness)
+    host = torch.cat((free_mask.float(), idx.float(), r.path_length, r.smoothness)).cpu().numpy()      # the call's one transfer
+    fm, ib = host[:B] > 0, int(host[B])
+    free_i, coll_i = np.flatnonzero(fm), np.flatnonzero(~fm)
+    free_idxs, coll_idxs = torch.from_numpy(free_i).to(dev), torch.from_numpy(coll_i).to(dev)
+    empty = torch.tensor([], dtype=torch.float32, device=dev)
+    out.trajs_iters, out.trajs_final = trajs_iters, r.smoothed
+    out.trajs_final_coll = trajs_final[:, coll_idxs] if coll_i.size else empty
+    out.trajs_final_coll_idxs = coll_idxs
+    out.trajs_final_free = trajs_final.index_select(0, free_idxs) if free_i.size else empty
+    out.trajs_final_free_idxs = free_idxs
+    out.success_free_trajs = 1 if free_i.size else 0
+    out.fraction_free_trajs = free_i.size / B
+    out.collision_intensity_trajs = 1 - out.fraction_free_trajs
+    if free_i.size:
+        out.cost_smoothness = r.smoothness.index_select(0, free_idxs)
+        out.cost_path_length = r.path_length.index_select(0, free_idxs)
+        out.cost_all = out.cost_smoothness + out.cost_path_length
+        best = int(np.searchsorted(free_i, ib))
+        out.idx_best_traj = free_idxs[best]
+        out.traj_final_free_best = out.trajs_final_free[best]
+        out.cost_best_free_traj = out.cost_all[best]
+        out.variance_waypoint_trajs_final_free = post.compute_variance_waypoints(out.trajs_final_free)
     return out
 
 
@@ -371,6 +479,7 @@ class MPDEnsemble:
         mins, maxs = normalizer_limits if normalizer_limits is not None else (synth.NORM_MINS, synth.NORM_MAXS)
         self.transforms = {k: torch.as_tensor(v, dtype=torch.float32).cpu() for k, v in transforms.items()}
         self.models, self.guides, self.datasets, self.sample_kwargs, self.env_ids = {}, {}, [], {}, {}
+        task_guides = {}
         for j, model_id in enumerate(model_ids):
             sd = None if model_state_dicts is None else model_state_dicts[j]
             model, _ = _load_model(model_id, trained_models_dir, sd, model_args, self.device)
@@ -383,7 +492,10 @@ class MPDEnsemble:
                 ds, env_id=self.env_ids[j], obstacle_cutoff_margin=0.01,
                 weight_grad_cost_collision=weight_grad_cost_collision,
                 weight_grad_cost_smoothness=weight_grad_cost_smoothness, trajectory_duration=trajectory_duration,
-                n_support_points=HORIZON, device=self.device)
+                n_support_points=HORIZON, extra_objects_only=use_guide_on_extra_objects_only, device=self.device)
+            # the tile TASK always sees the tile's full map (tasks.py:141-311), whatever the guide is restricted to (:196-199)
+            task_guides[j] = self.guides[j] if not use_guide_on_extra_objects_only else GuideManagerTrajectoriesWithVelocity(
+                ds, env_id=self.env_ids[j], obstacle_cutoff_margin=0.01, n_support_points=HORIZON, device=self.device)
             self.sample_kwargs[j] = dict(
                 guide=None if self.run_prior_then_guidance or self.run_prior_only else self.guides[j],
                 n_guide_steps=n_guide_steps,
@@ -391,7 +503,7 @@ class MPDEnsemble:
                 noise_std_extra_schedule_fn=lambda x: 0.5)
         K = len(model_ids)
         self.robot = RobotPlanarDiskFacade(self.device)
-        self.task = PlanningTaskFacade(self.guides[0], self.robot, all_free=True)   # PlanningTaskEnsemble: tasks_ensemble.py:271-277
+        self.task = PlanningTaskEnsembleFacade(task_guides, self.transforms, self.robot)    # mpd_ensemble.py:256-258, :328
         self.n_support_points = HORIZON
         self.start_state_pos = torch.as_tensor(start_state_pos, dtype=torch.float32).clone()
         self.goal_state_pos = torch.as_tensor(goal_state_pos, dtype=torch.float32).clone()
@@ -477,17 +589,18 @@ class MPDEnsemble:
         with _Timer() as timer:
             chains = (self.run_constrained_inference(cl, **kwargs) if experience is None
                       else self.run_constrained_local_inference(cl, experience, **kwargs))
-        # un-normalise per tile, move to the global frame, concatenate along the horizon (tasks_ensemble.py:162-225)
-        parts = []
+        # un-normalise per tile (the tile-frame final rows go to the tile's own collision check, tasks_ensemble.py:79-88), move to
+        # the global frame, concatenate along the horizon (:162-175)
+        parts, tile_final = [], {}
         for m in sorted(chains):
             tr = self.datasets[m].unnormalize_trajectories(chains[m]).clone()
+            tile_final[m] = tr[-1].clone()
             tr[..., :2] += self.transforms[m].to(tr.device)
             parts.append(tr)
         trajs_iters = torch.cat(parts, dim=-2)                     # [T+2, B, K*64, D]
         out = PlannerOutput()
         out.t_total = timer.elapsed
-        # every sample is free (PlanningTaskEnsemble, tasks_ensemble.py:271-277); costs / SavGol over the K*64 points
-        _fill_output(out, self.guides[0], trajs_iters, all_free=True)
+        _fill_output_ensemble(out, self.task, tile_final, trajs_iters)
         out.constraints_l = constraints_l
         self.recent_call_data = out
         return out

@@ -72,3 +72,46 @@ def straight_line_paths(starts, goals, horizon=64):
     """[N,H,2] float32 straight-line position paths: the synthetic stand-in for 'previous best paths' (SURVEY §8d-3)."""
     a = np.linspace(0.0, 1.0, horizon, dtype=np.float32)[None, :, None]
     return (starts[:, None, :] * (1 - a) + goals[:, None, :] * a).astype(np.float32)
+
+
+# ---- 3-tile corner-turning MPDEnsemble instance (golden g20) -------------------------------------------------------------
+ENSEMBLE3_GRID = (("EnvHighways2D", "EnvDropRegion2D"), ("EnvEmptyNoWait2D", "EnvConveyor2D"))   # global_model_ids[row][col]
+ENSEMBLE3_RADIUS = 0.05 * 2.4                                                                    # mmd_params.py:52
+
+
+def ensemble3_case(direction="fwd", horizon=64):
+    """A multi-tile planning problem shaped like the reference's multi-tile experiments (mmd_experiment_configs.py:180-221: 3-step
+    skeletons that turn a corner over a grid of heterogeneous tile models): skeleton [[0,0],[0,1],[1,1]] ("fwd": one +x hop, then
+    one -y hop) or the same tiles traversed the other way ("rev": +y, then -x, so both relative transforms of
+    apply_cross_conditioning are negative in the clamped coordinate), tile transforms [col * 2, -row * 2] as
+    scripts/inference/inference_multi_agent.py:148-151 builds them, every tile with its own map (an SDF gradient in each).
+    Returns a dict: skeleton, env_ids [K], transforms [K,2], start / goal (GLOBAL frame, inference_multi_agent.py:196-199) and
+    `constraints`: MultiPointConstraint-shaped tuples (q [n,2] global frame, t_range [n,2] over the K*H support points, radius
+    [n], is_soft) -- one hard and one soft constraint whose points fall on different tiles (one soft range straddles a tile
+    boundary and stays with the tile of its first index), for MPDEnsemble.split_cost_constraints_to_tasks
+    (mpd_ensemble.py:431-522) to route."""
+    skeleton = [[0, 0], [0, 1], [1, 1]]
+    # (skeleton step, tile-local point, tile-local time range)
+    hard = [(1, (-0.45, 0.0), (6, 12)), (2, (0.0, 0.45), (12, 18))]
+    soft = [(0, (0.45, 0.0), (20, 21)), (1, (0.0, 0.45), (36, 37)), (2, (-0.45, 0.0), (42, 43)), (0, (0.9, 0.0), (62, 66))]
+    start_local, goal_local = np.array([-0.6, 0.5], np.float32), np.array([0.5, -0.6], np.float32)
+    if direction == "rev":
+        skeleton = skeleton[::-1]
+        start_local, goal_local = goal_local, start_local
+        hard = [(2 - s, q, t) for (s, q, t) in hard]
+        soft = [(2 - s, q, t) for (s, q, t) in soft[:3]] + [(0, (0.0, 0.9), (62, 66))]
+    elif direction != "fwd":
+        raise KeyError(direction)
+    transforms = np.array([[c * 2.0, -r * 2.0] for r, c in skeleton], np.float32)
+    env_ids = [ENSEMBLE3_GRID[r][c] for r, c in skeleton]
+
+    def to_global(items, is_soft):
+        q = np.array([np.asarray(p, np.float32) + transforms[s] for s, p, _ in items], np.float32)
+        tr = np.array([(s * horizon + t0, s * horizon + t1) for s, _, (t0, t1) in items], np.int64)
+        return q, tr, np.full(len(items), ENSEMBLE3_RADIUS, np.float32), is_soft
+    return dict(skeleton=skeleton, env_ids=env_ids, transforms=transforms, start=start_local + transforms[0],
+                goal=goal_local + transforms[-1], constraints=[to_global(hard, False), to_global(soft, True)],
+                # tile UNets: three different random-init weight sets / the briefly trained one of g19 (it denoises, so the
+                # trajectories are smooth and actually meet the constraint points) on every tile
+                weights=(0, 1, 2) if direction == "fwd" else ("g19", "g19", "g19"),
+                seeds=dict(x0=(200, 201, 202), steps=203) if direction == "fwd" else dict(x0=(210, 211, 212), steps=213))

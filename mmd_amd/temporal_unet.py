@@ -159,12 +159,29 @@ class TemporalUnet:
 
     # ---- forward ----------------------------------------------------------------------------------------------
     def forward(self, x, time, context=None):
-        """x [B,H,D] float32 on the GPU; time: int or a [B] tensor with identical entries (as make_timesteps
-        produces, diffusion_model_base.py:27-29); returns eps [B,H,D]."""
+        """x [B,H,D] float32 on the GPU; time: int, or a [B] tensor (temporal_unet.py:121) -- identical entries as make_timesteps
+        produces (diffusion_model_base.py:27-29) are one launch, distinct entries one launch per distinct timestep; returns eps
+        [B,H,D]."""
         if context is not None:
             raise NotImplementedError("context conditioning is not used by MPD/MPDEnsemble")
-        t = int(time[0].item()) if torch.is_tensor(time) else int(time)
         x = x.contiguous()
+        if torch.is_tensor(time) and time.numel() > 1:
+            if time.numel() != x.shape[0]:
+                raise ValueError(f"TemporalUnet.forward: time has {time.numel()} entries for a batch of {x.shape[0]}")
+            tt = time.reshape(-1).to("cpu", torch.int64)
+            uniq = torch.unique(tt)
+            if uniq.numel() > 1:
+                # per-sample timesteps (temporal_unet.py:121, t [B]; the training loss draws them per sample): the kernel takes one
+                # time embedding per launch, so the batch is run per distinct timestep and scattered back.  The sampling path
+                # (make_timesteps) is uniform and never comes here.
+                out = torch.empty_like(x)
+                for t in uniq.tolist():
+                    rows = torch.nonzero(tt == t).reshape(-1).to(x.device)
+                    out.index_copy_(0, rows, self.forward(x.index_select(0, rows), int(t)))
+                return out
+            t = int(uniq[0])
+        else:
+            t = int(time.item()) if torch.is_tensor(time) else int(time)
         out = torch.empty_like(x)
         ws = self.workspace(x.shape[0], x.device)
         _lib.launch("mmd_unet_forward", x, self.handle(device=x.device), _lib.require_gpu(x, "x"), t, out.data_ptr(), x.shape[0],

@@ -771,6 +771,33 @@ def apply_cross_conditioning(x: Dict[int, torch.Tensor], conditions, transforms)
     return x
 
 
+def ensemble_p_sample_loop(sds, tb, x_init: Dict[int, torch.Tensor], hard_conds, cross_conds, transforms, n_diffusion_steps,
+                           step_noise, guides=None, n_guide_steps=20, t_start_guide=float("inf"), noise_std_extra=0.5,
+                           n_diffusion_steps_without_noise=0):
+    """DiffusionsEnsemble.p_sample_loop (mmd/models/diffusion_models/diffusion_ensemble.py:55-106) with injected noise: per outer
+    step the tiles step IN ORDER (ddpm_sample_fn, hard conditioning), each followed by the cross conditioning of ALL pairs.
+    sds / guides: per tile; x_init {m: [B,H,D]}; step_noise [n_steps, K, B,H,D].  Returns (x, chains {m: [n_steps+1, B,H,D]}).
+    The chains are collected the way the reference collects them -- `chains[m].append(x[m])` stores the tensor OBJECT, and
+    apply_cross_conditioning writes into x[m] in place -- so row k of a tile that has not stepped yet in outer step k+1 also carries
+    the boundary rows stitched after the EARLIER tiles' steps of step k+1 (visible from 3 tiles on: re-stitching two not-yet-stepped
+    neighbours is not idempotent when the later tile's first row was fresh from its own step); the dynamics are unaffected, the
+    last row is clean."""
+    keys = list(x_init.keys())
+    x = {m: apply_hard_conditioning(x_init[m].clone(), hard_conds.get(m, {})) for m in keys}
+    x = apply_cross_conditioning(x, cross_conds, transforms)
+    chains = {m: [x[m]] for m in keys}
+    for k, i in enumerate(reversed(range(-n_diffusion_steps_without_noise, n_diffusion_steps))):
+        for j, m in enumerate(keys):
+            guide = guides[m] if guides is not None else None
+            x[m] = ddpm_sample_step(sds[m], tb, x[m], hard_conds.get(m, {}), i, guide=guide, n_guide_steps=n_guide_steps,
+                                    t_start_guide=t_start_guide, noise=step_noise[k, j], noise_std_extra=noise_std_extra)
+            x[m] = apply_hard_conditioning(x[m], hard_conds.get(m, {}))
+            x = apply_cross_conditioning(x, cross_conds, transforms)
+        for m in keys:
+            chains[m].append(x[m])
+    return x, {m: torch.stack(v, dim=0) for m, v in chains.items()}
+
+
 def soft_constraints_from_paths(paths, agent_id, radius, weight, start_times=None):
     """CBS.create_soft_constraints_from_other_agents_paths (mmd/planners/multi_agent/cbs.py:468-508) for equal start
     times: every other robot's position at t (1 <= t <= H-1) constrains this robot at [t, t+1)."""
@@ -890,3 +917,48 @@ def smooth_trajs(trajs, window_size=10, poly_order=2):
     """mmd/common/trajectory_utils.py:31-40 (scipy savgol_filter along the horizon, mode='interp')."""
     from scipy.signal import savgol_filter
     return torch.from_numpy(savgol_filter(trajs.numpy(), window_size, poly_order, axis=1))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# MPDEnsemble.__call__ post-processing (multi-tile planner output)
+# --------------------------------------------------------------------------------------------------------------
+
+
+def ensemble_planner_output(chains_norm: Dict[int, torch.Tensor], gps: Dict[int, GuideParams], transforms, mins, maxs):
+    """mmd/planners/single_agent/mpd_ensemble.py:385-429 + PlanningTaskEnsemble.get_traj_unnormalized / combine_trajs
+    (deps/torch_robotics/torch_robotics/tasks/tasks_ensemble.py:79-88, 162-225): every tile's chain [T+2,B,H,D] is un-normalised
+    and split into colliding / free samples against the tile's OWN map in the tile frame (PlanningTask.get_trajs_collision_and_free,
+    tasks.py:236-311); a sample is free iff no tile reports it; positions move to the global frame and the tiles are concatenated
+    along the horizon; costs, best sample and waypoint variance are those of the concatenated free samples; trajs_final is the
+    SavGol-smoothed last row.  Returned as a dict of the PlannerOutput fields.  (tasks_ensemble.py:190 indexes the HORIZON axis of
+    trajs_final with the colliding sample indices -- `trajs_final[:, idxs]` -- that is reproduced.)"""
+    keys = list(chains_norm.keys())
+    iters, tile_coll = {}, {}
+    for m in keys:
+        tr = unnormalize(chains_norm[m], mins, maxs)
+        _, coll_idxs, _, _, _ = get_trajs_collision_and_free(tr[-1], gps[m])
+        tile_coll[m] = set(int(i) for i in coll_idxs.reshape(-1))
+        tr = tr.clone()
+        tr[..., :2] += torch.as_tensor(transforms[m])
+        iters[m] = tr
+    trajs_iters = torch.cat([iters[m] for m in keys], dim=-2)
+    final = trajs_iters[-1]
+    B = final.shape[0]
+    coll = [b for b in range(B) if any(b in tile_coll[m] for m in keys)]
+    free = [b for b in range(B) if b not in coll]
+    out = dict(trajs_iters=trajs_iters, trajs_final=smooth_trajs(final), tile_coll_idxs={m: sorted(tile_coll[m]) for m in keys},
+               trajs_final_coll_idxs=torch.tensor(coll, dtype=torch.long), trajs_final_free_idxs=torch.tensor(free, dtype=torch.long),
+               trajs_final_coll=final[:, coll] if coll else torch.tensor([]), trajs_final_free=final[free] if free else torch.tensor([]),
+               success_free_trajs=1 if free else 0, fraction_free_trajs=len(free) / B, collision_intensity_trajs=1 - len(free) / B,
+               idx_best_traj=None, traj_final_free_best=None, cost_best_free_traj=None, cost_smoothness=None, cost_path_length=None,
+               cost_all=None, variance_waypoint_trajs_final_free=None)
+    if free:
+        f = out["trajs_final_free"]
+        out["cost_smoothness"], out["cost_path_length"] = compute_smoothness(f), compute_path_length(f)
+        out["cost_all"] = out["cost_smoothness"] + out["cost_path_length"]
+        best = int(torch.argmin(out["cost_all"]))
+        out["idx_best_traj"] = out["trajs_final_free_idxs"][best]
+        out["traj_final_free_best"] = f[best]
+        out["cost_best_free_traj"] = out["cost_all"][best]
+        out["variance_waypoint_trajs_final_free"] = compute_variance_waypoints(f)
+    return out

@@ -245,3 +245,45 @@ def trained_case(name):
         return dict(map="EnvEmpty2D", T=25, B=4, start=starts[5], goal=goals[5], cons=[soft_group(paths, 5)], seed0=400)
     starts, goals, soft, hard = highways_case()
     return dict(map="EnvHighways2D", T=25, B=8, start=starts[3], goal=goals[3], cons=[soft, hard], seed0=440)
+
+
+# ---- g20: 3-tile corner-turning heterogeneous ensemble (synth.ensemble3_case) -----------------------------------------------------
+ENSEMBLE3_DIRECTIONS = ("fwd", "rev")
+
+
+def named_state_dict(w):
+    """tile weights of synth.ensemble3_case: a synth seed, or "g19" = the trained state dict stored as data by golden g19."""
+    return trained_state_dict() if w == "g19" else synth.synth_unet_state_dict(w)
+
+
+def ensemble3_hard_conds(case):
+    """mpd_ensemble.py:286-296: start pinned on row 0 of the first tile, goal on the last row of the last tile, both in the tile
+    frame (tasks_ensemble.inverse_transform_q) and normalised."""
+    K = len(case["env_ids"])
+    s = hard_conds_for(case["start"] - case["transforms"][0], [0, 0])[0]
+    g = hard_conds_for(case["goal"] - case["transforms"][K - 1], [0, 0])[0]
+    hard = {m: {} for m in range(K)}
+    hard[0][0] = s
+    hard[K - 1][H - 1] = g
+    return hard
+
+
+def ensemble3_tile_groups(g, direction, K=3):
+    """The reference's own per-tile constraint tables of golden g20 (after split_cost_constraints_to_tasks + the tile shift) as
+    oracle ConstraintGroups, in the order the tile guides received them; weights mmd_params.py:42-43."""
+    out = {m: [] for m in range(K)}
+    for m in g[f"{direction}.task_order"].tolist():
+        for k in range(int(g[f"{direction}.n_{m}"])):
+            soft = bool(g[f"{direction}.soft_{m}_{k}"])
+            out[m].append(O.ConstraintGroup(q=torch.from_numpy(g[f"{direction}.qs_{m}_{k}"]),
+                                            t_range=torch.from_numpy(g[f"{direction}.ranges_{m}_{k}"]),
+                                            radius=torch.from_numpy(g[f"{direction}.radii_{m}_{k}"]),
+                                            weight=2e-2 if soft else 2e-1))
+    return out
+
+
+def ensemble3_inputs(case, T, B):
+    K = len(case["env_ids"])
+    x0 = {m: torch.from_numpy(synth.synth_noise(case["seeds"]["x0"][m], (B, H, D))) for m in range(K)}
+    steps = torch.from_numpy(synth.synth_noise(case["seeds"]["steps"], (T + 1, K, B, H, D)))
+    return x0, steps

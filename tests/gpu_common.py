@@ -15,10 +15,12 @@ _MODELS = {}
 
 
 def hip_model(T, weights_seed=0):
+    """weights_seed: a synth seed, or "g19" = the trained state dict of golden g19 (cases.named_state_dict)."""
     key = (T, weights_seed)
     if key not in _MODELS:
+        import cases
         unet = TemporalUnet(state_dim=4, n_support_points=64, unet_input_dim=32, dim_mults=(1, 2, 4))
-        unet.load_state_dict(synth.synth_unet_state_dict(weights_seed))
+        unet.load_state_dict(cases.named_state_dict(weights_seed))
         _MODELS[key] = GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T,
                                               predict_epsilon=True)
     return _MODELS[key]
@@ -59,8 +61,7 @@ def teacher_forced_guided_step(test, tag, s, T, starts, goals, map_name, picks, 
     conditioning) of MultiRobotSampler `s` on ALL its local trajectories, started from a mid-chain looking state, against the
     oracle on the trajectories `picks` = [(global robot, sample)].  Bound per trajectory: the north-star 1e-3; a trajectory
     beyond it must be a BRANCH FLIP -- the kernel's decision trace differs from the oracle's at some guide iteration and the
-    oracle run on the kernel's decisions agrees with the kernel to 1e-4 (GuidedStepJudge) -- with 1.5 x the oracle's own response
-    to a rounding-sized perturbation of eps as the fallback yardstick only.  paths_np: all robots' paths for the inter-robot
+    oracle run on the kernel's decisions agrees with the kernel up to fp32 rounding (GuidedStepJudge); anything else fails.  paths_np: all robots' paths for the inter-robot
     soft constraints (None: no inter-robot term).  Returns the worst error / bound ratio."""
     import cases
     import parity_log
@@ -200,8 +201,9 @@ def attribute_guided_step(y_hip, mu_hip, gstate_hip, hip_sets, xi, nz, i, tsg, s
 
 
 def rounding_bound(a):
-    """What two fp32 evaluations of the same decision path may differ by: 3 x (their two distances from exact arithmetic), at least 1e-4."""
-    return max(1e-4, 3.0 * (a["d_hip"] + a["d_o32"]))
+    """What two fp32 evaluations of the same decision path may differ by: 3 x (their two distances from exact arithmetic), at least
+    1e-4 and never more than half the north-star tolerance (VERDICT r5 #7)."""
+    return min(5e-4, max(1e-4, 3.0 * (a["d_hip"] + a["d_o32"])))
 
 
 class GuidedStepJudge:
@@ -213,8 +215,7 @@ class GuidedStepJudge:
         rounding along that path                                              -> 'flip@<iteration>:<kind>:t<support point>'
         the traces are identical and the difference is within the fp32 rounding of the two evaluations (the 20 norm-clipped
         steps amplify rounding 5 .. 350 x with every decision frozen)          -> 'fp32'
-      else the old yardstick, max(1e-3, 1.5 x the oracle's own response to a relative `pert` perturbation of eps)
-                                                                               -> 'sens' (or an assertion)."""
+      else                                                                     -> AssertionError."""
 
     def __init__(self, model, guide, x, hard_conds, i, t_start_guide, n_robots, noise, y_hip):
         self.model, self.guide, self.x, self.hard_conds, self.i = model, guide, x, hard_conds, i
@@ -257,9 +258,8 @@ class GuidedStepJudge:
         if a["first"] is None and err < rounding_bound(a):
             parity_log.record(test, tag, i, err, bound=rounding_bound(a), fp32="identical decisions: fp32 rounding of both evaluations", **extra)
             return "fp32", err
-        gen = torch.Generator().manual_seed(sens_seed)
-        sens = max(cases.rel_l2(step(pert * torch.randn(xi.shape, generator=gen)), ref) for _ in range(n_sens))
-        bound = max(1e-3, 1.5 * lin * sens)
-        parity_log.record(test, tag, i, err, sens=sens, bound=bound, **extra)
-        assert err < bound, (test, tag, err, sens, a["ferr"], a["first"], a["d_hip"], a["d_o32"])
-        return "sens", err
+        # neither: a step beyond the tolerance that is not an attributed flip and not fp32 rounding along identical decisions is a
+        # parity FAILURE (the sensitivity yardstick of rounds 2-5 is gone)
+        parity_log.record(test, tag, i, err, bound=1e-3, unexplained=True, **extra)
+        raise AssertionError((test, tag, "guided step beyond 1e-3 without an attributed flip / fp32 verdict", err, a["ferr"], a["first"],
+                              a["d_hip"], a["d_o32"]))

@@ -56,6 +56,9 @@ def test_guided_sampling_distribution_vs_reference(name):
     parity_log.record("distribution_vs_reference", f"{name}_matched_within_1e-3", None, float((per < 1e-3).mean()),
                       note=f"free {free_hip} / {free_ref} of {n}; violating {int((viol_hip > 0).sum())} / {int((viol_ref > 0).sum())}; "
                            f"pairs {int(viol_hip.sum())} / {int(viol_ref.sum())}; median matched rel-L2 {np.median(per):.2e}")
+    parity_log.track(f"end_to_end_matched_within_1e-3.random_weights.{name}", int((per < 1e-3).sum()), int(n),
+                     note=f"random-init weights, {n} trajectories over {n_seeds} noise seeds; median rel-L2 {np.median(per):.2e} (the chain is "
+                          "chaotic end to end on random weights: the distribution-level z-tests next to this are the parity statement)")
     assert z_mean < cases.Z_MAX and z_cov < cases.Z_MAX, (name, z_mean, z_cov)
     assert z_free < cases.Z_MAX, (name, free_hip, free_ref)
     assert z_viol < cases.Z_MAX and z_pairs < cases.Z_MAX, (name, z_viol, z_pairs)

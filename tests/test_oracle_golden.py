@@ -358,3 +358,85 @@ def test_g19_trained_network_oracle(name):
         assert err < (1e-4 if r < n_unguided else max(1e-4, 1.5 * sens[r])), (name, r, err, sens[r])
     # the network denoises: eps-prediction error on noised smooth trajectories well below the random-init level
     assert float(g["heldout_eps_mse_t5_t12_t20"].max()) < 0.2
+
+
+@pytest.mark.parametrize("direction", cases.ENSEMBLE3_DIRECTIONS)
+def test_g20_ensemble3_oracle(direction):
+    """3-tile corner-turning heterogeneous ensemble (golden g20): +x / -y hops ("fwd") and +y / -x hops ("rev") of
+    apply_cross_conditioning, a map and a weight set per tile, the reference's own per-tile constraint tables.  The oracle's tile
+    loop (diffusion_ensemble.py:55-106) restarted from the reference's rows: EVERY outer step of EVERY tile within 1e-5 of the
+    reference's next row; then free-running from the injected noise (O.ensemble_p_sample_loop), EVERY chain row of every tile within
+    max(1e-5, a tenth of the reference's own response to a 1e-6 perturbation) -- both are torch-CPU fp32."""
+    g = np.load(os.path.join(GOLDEN, "g20_ensemble3.npz"))
+    T, B, K = (int(v) for v in g[f"{direction}.meta"])
+    case = synth.ensemble3_case(direction)
+    sds = [O.state_dict_to_torch(cases.named_state_dict(w)) for w in case["weights"]]
+    tb = O.schedule_tables(T)
+    gps = [cases.guide_params(e, cutoff=0.01) for e in case["env_ids"]]
+    transforms = {m: torch.from_numpy(case["transforms"][m]) for m in range(K)}
+    hard = cases.ensemble3_hard_conds(case)
+    cross = {(m, m + 1): (H - 1, 0) for m in range(K - 1)}
+    cons = cases.ensemble3_tile_groups(g, direction, K)
+    assert sum(len(v) for v in cons.values()) >= 4 and all(len(cons[m]) >= 1 for m in range(K))
+    x0, steps = cases.ensemble3_inputs(case, T, B)
+
+    def tile_step(x, m, i, k):
+        x[m] = O.ddpm_sample_step(sds[m], tb, x[m], hard[m], i, guide=lambda y, m=m: O.guide_grad(y, gps[m], cons[m]),
+                                  n_guide_steps=20, t_start_guide=ceil(0.5 * T), noise=steps[k, m], noise_std_extra=0.5)
+        x[m] = O.apply_hard_conditioning(x[m], hard[m])
+        return O.apply_cross_conditioning(x, cross, transforms)
+
+    # teacher-forced.  (The reference's stored rows of tiles m >= 1 already carry the stitches of the NEXT outer step's earlier
+    # tiles -- see O.ensemble_p_sample_loop -- which re-applied give the same values: restarting from them is exact.)
+    for k, i in enumerate(reversed(range(-1, T))):
+        xs = {m: torch.from_numpy(g[f"{direction}.chain{m}"][k]).clone() for m in range(K)}
+        for m in range(K):
+            xs = tile_step(xs, m, i, k)
+        if k == T:                                       # (rows before the last carry the next step's stitches: compared below)
+            for m in range(K):
+                assert rel_l2(xs[m], g[f"{direction}.chain{m}"][k + 1]) < 1e-5, (direction, m, k, i)
+        else:                                            # tile 0 is clean in every row; tiles m >= 1 except their boundary rows
+            assert rel_l2(xs[0], g[f"{direction}.chain0"][k + 1]) < 1e-5, (direction, k, i)
+            for m in range(1, K):
+                assert rel_l2(xs[m][:, 1:H - 1], g[f"{direction}.chain{m}"][k + 1][:, 1:H - 1]) < 1e-5, (direction, m, k, i)
+    # free-running from the injected noise, chains collected as the reference collects them: every row of every tile
+    guides = {m: (lambda y, m=m: O.guide_grad(y, gps[m], cons[m])) for m in range(K)}
+    x, chains = O.ensemble_p_sample_loop(sds, tb, x0, hard, cross, transforms, T, steps, guides=guides, n_guide_steps=20,
+                                         t_start_guide=ceil(0.5 * T), noise_std_extra=0.5, n_diffusion_steps_without_noise=1)
+    for m in range(K):
+        ref, sens = g[f"{direction}.chain{m}"], g[f"{direction}.sens{m}"]
+        assert np.array_equal(chains[m][0].numpy(), ref[0]), (direction, m, "row 0: noise + hard conditioning + stitching")
+        for r in range(T + 2):
+            err = rel_l2(chains[m][r], ref[r])
+            assert err < max(1e-5, 0.1 * float(sens[r])), (direction, m, r, err, float(sens[r]))
+        assert torch.equal(chains[m][-1], x[m])
+
+
+@pytest.mark.parametrize("direction", cases.ENSEMBLE3_DIRECTIONS)
+def test_g20_ensemble_planner_output_oracle(direction):
+    """MPDEnsemble.__call__'s post-processing (mpd_ensemble.py:385-429, tasks_ensemble.py:79-88,162-225) restated by
+    O.ensemble_planner_output, on the reference's own chains: per-tile collision split in the tile frame against the tile's own
+    map, free = free in every tile, global-frame concatenation, costs / best sample over the concatenated free samples, SavGol."""
+    g = np.load(os.path.join(GOLDEN, "g20_ensemble3.npz"))
+    T, B, K = (int(v) for v in g[f"{direction}.meta"])
+    case = synth.ensemble3_case(direction)
+    gps = {m: cases.guide_params(case["env_ids"][m], cutoff=0.01) for m in range(K)}
+    chains = {m: torch.from_numpy(g[f"{direction}.chain{m}"]) for m in range(K)}
+    out = O.ensemble_planner_output(chains, gps, {m: case["transforms"][m] for m in range(K)}, cases.MINS, cases.MAXS)
+    for m in range(K):
+        assert out["tile_coll_idxs"][m] == g[f"{direction}.tile{m}_coll_idxs"].tolist(), m
+    assert out["trajs_final_free_idxs"].tolist() == g[f"{direction}.free_idxs"].tolist()
+    assert out["trajs_final_coll_idxs"].tolist() == g[f"{direction}.coll_idxs"].tolist()
+    assert out["fraction_free_trajs"] == float(g[f"{direction}.fraction_free"])
+    assert out["trajs_iters"].shape == (T + 2, B, K * H, D)
+    assert np.array_equal(out["trajs_iters"][-1].numpy(), g[f"{direction}.trajs_final_global"])
+    assert np.array_equal(out["trajs_iters"][T // 2 + 1].numpy(), g[f"{direction}.trajs_iters_mid_global"])
+    assert np.allclose(out["trajs_final"].numpy(), g[f"{direction}.smoothed"], atol=1e-6)
+    if len(g[f"{direction}.free_idxs"]):
+        assert int(out["idx_best_traj"]) == int(g[f"{direction}.idx_best_traj"])
+        assert np.allclose(out["cost_smoothness"].numpy(), g[f"{direction}.cost_smoothness"], rtol=1e-6)
+        assert np.allclose(out["cost_path_length"].numpy(), g[f"{direction}.cost_path_length"], rtol=1e-6)
+        assert abs(float(out["cost_best_free_traj"]) - float(g[f"{direction}.cost_best_free_traj"])) < 1e-5
+        assert abs(float(out["variance_waypoint_trajs_final_free"]) - float(g[f"{direction}.variance_waypoint"])) < 1e-5
+    else:
+        assert out["success_free_trajs"] == 0 and out["idx_best_traj"] is None

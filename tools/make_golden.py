@@ -23,6 +23,9 @@ Fixtures:
                              predict_epsilon False
   g19_trained_unet.npz / g19_trained_chains.npz   a TemporalUnet trained briefly with the reference's loss (it denoises), and
                              the guided chains / sensitivities / multi-seed final rows of two constraint cases run with it
+  g20_ensemble3.npz          3-tile corner-turning heterogeneous MPDEnsemble instance (x and y hops, both directions, per-tile maps
+                             and weights, constraint routing, per-tile free / collision split + combine_trajs)
+  g21_ensemble_task.npz      PlanningTaskEnsemble.compute_collision / infer_task_id_from_q on global positions over the three tiles
   g15_distribution_*.npz     guided sampling over 32 noise seeds: final rows of every sample, their position mean / covariance per
                              support point, free / collision split and soft-constraint violation counts (distribution-level parity)
 """
@@ -911,11 +914,185 @@ def g19():
     np.savez_compressed(os.path.join(OUT, "g19_trained_chains.npz"), **out)
 
 
+def _state_dict_named(w):
+    """tile weights of synth.ensemble3_case: a synth seed or "g19" (the trained state dict stored by g19 -- data)."""
+    if w == "g19":
+        from collections import OrderedDict
+        from mmd_amd.unet_spec import unet_param_spec
+        g = np.load(os.path.join(OUT, "g19_trained_unet.npz"))
+        return OrderedDict((k, np.ascontiguousarray(g[k], dtype=np.float32)) for k in unet_param_spec())
+    return synth.synth_unet_state_dict(w)
+
+
+def g20():
+    """3-tile, corner-turning, heterogeneous MPDEnsemble instance (synth.ensemble3_case) through the GENUINE classes:
+      * PlanningTaskEnsemble over three genuine PlanningTasks (tasks_ensemble.py:39-49) with the tile transforms of
+        inference_multi_agent.py:148-151;
+      * MPDEnsemble.split_cost_constraints_to_tasks (mpd_ensemble.py:431-507) on one hard + one soft CostConstraint built as
+        MPDEnsemble.__call__ builds them (:360-372), then the shift of run_constrained_inference (:515-522) into the tile guides;
+      * DiffusionsEnsemble.run_inference (diffusion_ensemble.py:223-263: the einops repeat of the hard conditions, p_sample_loop
+        with apply_cross_conditioning after every tile step, the chain rearrange) with injected noise;
+      * the post-processing of MPDEnsemble.__call__ (:385-429): per tile get_traj_unnormalized + get_stats, combine_trajs
+        (tasks_ensemble.py:162-225: a sample is free iff it is free in EVERY tile's own map), smooth_trajs.
+    Stored per direction ("fwd" / "rev"): every chain row of every tile + `sens` (as g8), the per-tile constraint split after the
+    shift, the combined PlannerOutput fields.  The MPDEnsemble object itself cannot be constructed offline (its __init__ reads the
+    dataset / checkpoint files), so the three methods run on an attribute stand-in that carries exactly what they touch."""
+    import types
+    from mmd.common.trajectory_utils import smooth_trajs
+    from mmd.models.diffusion_models.diffusion_ensemble import DiffusionsEnsemble
+    from mmd.planners.single_agent.mpd_ensemble import MPDEnsemble
+    from torch_robotics.tasks.tasks_ensemble import PlanningTaskEnsemble
+    import ref_harness
+    T, B = 25, 8
+    out = {}
+    for direction in ("fwd", "rev"):
+        case = synth.ensemble3_case(direction)
+        K = len(case["env_ids"])
+        transforms = {j: torch.from_numpy(case["transforms"][j]) for j in range(K)}
+        with quiet():
+            models = {j: make_model(_state_dict_named(case["weights"][j]), T) for j in range(K)}
+            guides, tasks, datasets = {}, {}, []
+            for j in range(K):
+                # fresh (uncached) env / task per tile: EnvEnsemble shifts the tile objects' positions in place (env_ensemble.py:42-45)
+                ref_harness._ENV_CACHE.pop((case["env_ids"][j], 0.01), None)
+                guides[j], robot_j, tasks[j], _ = make_guide(case["env_ids"][j], MINS, MAXS, cutoff_margin=0.01)   # mpd_ensemble.py:139
+                ref_harness._ENV_CACHE.pop((case["env_ids"][j], 0.01), None)
+                datasets.append(guides[j].dataset)
+                if j == 0:
+                    robot = robot_j
+            task_ens = PlanningTaskEnsemble(tasks, transforms, tensor_args=TENSOR_ARGS)
+        me = types.SimpleNamespace(task=task_ens, robot=robot, n_support_points=H, tensor_args=TENSOR_ARGS)
+        # mpd_ensemble.py:286-296
+        start = torch.from_numpy(case["start"])
+        goal = torch.from_numpy(case["goal"])
+        start_local = task_ens.inverse_transform_q(0, start)
+        goal_local = task_ens.inverse_transform_q(K - 1, goal)
+        hard_conds = {0: {0: hard_conds_for(start_local.numpy(), start_local.numpy())[0]}}
+        hard_conds.setdefault(K - 1, {})[-1] = hard_conds_for(goal_local.numpy(), goal_local.numpy())[0]
+        cross_conds = {(i, i + 1): (H - 1, 0) for i in range(K - 1)}                      # :301-303
+        cost_constraints = [make_cost_constraint(robot, q, tr, r, soft) for (q, tr, r, soft) in case["constraints"]]
+        with quiet():
+            split = MPDEnsemble.split_cost_constraints_to_tasks(me, cost_constraints)
+        out[f"{direction}.task_order"] = np.array(list(split.keys()), dtype=np.int64)
+        for task_id, cl in split.items():
+            out[f"{direction}.n_{task_id}"] = np.int64(len(cl))
+            for k, c in enumerate(cl):
+                c.traj_ranges -= task_id * H                                              # :517
+                c.qs -= transforms[task_id]                                               # :518
+                guides[task_id].add_extra_costs([c], [2e-1 if not c.is_soft else 2e-2])   # :519-522, mmd_params.py:42-43
+                out[f"{direction}.qs_{task_id}_{k}"] = c.qs.numpy().astype(np.float32)
+                out[f"{direction}.ranges_{task_id}_{k}"] = np.asarray(c.traj_ranges.numpy(), dtype=np.float32)
+                out[f"{direction}.radii_{task_id}_{k}"] = c.radii.numpy().astype(np.float32)
+                out[f"{direction}.soft_{task_id}_{k}"] = np.bool_(c.is_soft)
+        x0 = [synth.synth_noise(case["seeds"]["x0"][j], (B, H, D)) for j in range(K)]
+        steps = synth.synth_noise(case["seeds"]["steps"], (T + 1, K, B, H, D))
+        draws = list(x0) + [steps[k, j] for k in range(T + 1) for j in range(K)]
+        sample_kwargs = [dict(guide=guides[j], n_guide_steps=20, t_start_guide=ceil(0.5 * T),
+                              noise_std_extra_schedule_fn=lambda x: 0.5) for j in range(K)]     # :236-243 (a list, indexed by tile)
+        ens = DiffusionsEnsemble(models, transforms)
+
+        def run(perturb=0.0, ps=0):
+            handles = []
+            if perturb:
+                gen = torch.Generator().manual_seed(ps)
+                for j in range(K):
+                    handles.append(models[j].model.register_forward_hook(
+                        lambda mod, inp, o: o * (1 + perturb * torch.empty(o.shape).normal_(generator=gen))))
+            with quiet(), injected_noise(draws) as q:
+                chains = ens.run_inference(None, hard_conds, cross_conds=cross_conds, n_samples=B, return_chain=True,
+                                           sample_fn=ddpm_sample_fn, sample_kwargs=sample_kwargs,
+                                           n_diffusion_steps_without_noise=1)                  # :527-535
+                assert len(q) == 0
+            for h in handles:
+                h.remove()
+            return {j: chains[j].clone() for j in range(K)}                                     # [T+2, B, H, D]
+
+        chains = run()
+        sens = {j: np.zeros(T + 2) for j in range(K)}
+        for ps in range(1, N_SENS_DRAWS + 1):
+            pert = run(1e-6, ps)
+            for j in range(K):
+                sens[j] = np.maximum(sens[j], [rel_l2(pert[j][r].numpy(), chains[j][r].numpy()) for r in range(T + 2)])
+        # ---- MPDEnsemble.__call__ :385-429 ----
+        with quiet():
+            results_ensemble = {}
+            for j in range(K):
+                r6 = task_ens.get_traj_unnormalized(j, datasets, chains[j])
+                results_ensemble[j] = task_ens.get_stats(j, *r6, 0.0, save_data=False)
+                out[f"{direction}.tile{j}_coll_idxs"] = np.asarray(r6[3].numpy(), dtype=np.int64).reshape(-1)
+            res = task_ens.combine_trajs(results_ensemble)
+            smoothed = smooth_trajs(res["trajs_iters"][-1])
+        for j in range(K):
+            out[f"{direction}.chain{j}"] = chains[j].numpy()
+            out[f"{direction}.sens{j}"] = sens[j]
+            # how many (sample, constraint point, step) triples are inside a constraint radius on the final row (tile frame)
+            pos = datasets[j].unnormalize_trajectories(chains[j][-1])[..., :2]
+            act = 0
+            for cst in split.get(j, []):
+                for q, tr, rad in zip(cst.qs, cst.traj_ranges, cst.radii):
+                    seg = pos[:, int(tr[0]):int(tr[1]) + 1]
+                    act += int((torch.linalg.norm(seg - q, dim=-1) < rad).sum())
+            print(f"   g20 {direction} tile {j} ({case['env_ids'][j]}): final-row sens {sens[j][-1]:.2e}, max {sens[j].max():.2e}, "
+                  f"constraint hits on the final row {act}, tile coll idxs {out[f'{direction}.tile{j}_coll_idxs'].tolist()}", flush=True)
+            guides[j].reset_extra_costs()
+        out[f"{direction}.trajs_final_global"] = res["trajs_iters"][-1].numpy()
+        out[f"{direction}.trajs_iters_mid_global"] = res["trajs_iters"][T // 2 + 1].numpy()
+        out[f"{direction}.smoothed"] = smoothed.numpy()
+        out[f"{direction}.free_idxs"] = res["trajs_final_free_idxs"].numpy().astype(np.int64).reshape(-1)
+        out[f"{direction}.coll_idxs"] = res["trajs_final_coll_idxs"].numpy().astype(np.int64).reshape(-1)
+        out[f"{direction}.fraction_free"] = np.float64(res["fraction_free_trajs"])
+        if len(out[f"{direction}.free_idxs"]):
+            out[f"{direction}.idx_best_traj"] = np.int64(int(res["idx_best_traj"]))
+            out[f"{direction}.cost_smoothness"] = res["cost_smoothness_trajs_final_free"].numpy()
+            out[f"{direction}.cost_path_length"] = res["cost_path_length_trajs_final_free"].numpy()
+            out[f"{direction}.cost_best_free_traj"] = np.float32(float(res["cost_best_free_traj"]))
+            out[f"{direction}.variance_waypoint"] = np.float32(float(res["variance_waypoint_trajs_final_free"]))
+        out[f"{direction}.meta"] = np.array([T, B, K])
+        print(f"   g20 {direction}: free {out[f'{direction}.free_idxs'].tolist()} coll {out[f'{direction}.coll_idxs'].tolist()}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "g20_ensemble3.npz"), **out)
+
+
+def g21():
+    """Outer-boundary contract of the multi-tile task (what CBS / PP read from an MPDEnsemble planner's `.task`,
+    cbs.py:149-156, multi_agent_utils.py:47,84,89): the GENUINE PlanningTaskEnsemble.compute_collision
+    (tasks_ensemble.py:227-269: tile inferred from the global position, tile-frame occupancy against that tile's own map, points
+    outside every tile stay "in collision") on [n, 2] stacked global positions and on a single [2] position, and
+    infer_task_id_from_q (:340-365), over the three tiles of synth.ensemble3_case("fwd")."""
+    from torch_robotics.tasks.tasks_ensemble import PlanningTaskEnsemble
+    import ref_harness
+    case = synth.ensemble3_case("fwd")
+    K = len(case["env_ids"])
+    transforms = {j: torch.from_numpy(case["transforms"][j]) for j in range(K)}
+    with quiet():
+        tasks = {}
+        for j in range(K):
+            ref_harness._ENV_CACHE.pop((case["env_ids"][j], 0.01), None)
+            tasks[j] = make_task(case["env_ids"][j], 0.01)[2]
+            ref_harness._ENV_CACHE.pop((case["env_ids"][j], 0.01), None)
+        task_ens = PlanningTaskEnsemble(tasks, transforms, tensor_args=TENSOR_ARGS)
+    rng = np.random.Generator(np.random.PCG64(220))
+    local = rng.uniform(-1.0, 1.0, size=(K, 40, 2)).astype(np.float32)
+    pts = np.concatenate([local[j] + case["transforms"][j] for j in range(K)] +
+                         [np.array([[-1.5, 0.0], [0.0, -2.0], [3.5, -2.0], [2.0, 1.2], [1.0, 0.3], [2.4, -1.0], [1.0, -1.0]], np.float32)])
+    pts_t = torch.from_numpy(pts)
+    out = {"points": pts, "task_ids": task_ens.infer_task_id_from_q(pts_t.unsqueeze(1)).numpy()}
+    with quiet():
+        out["collision"] = task_ens.compute_collision(pts_t).numpy()
+        single = []
+        for k in (0, 45, 90, 120, 121, 124):
+            single.append(np.asarray(task_ens.compute_collision(pts_t[k]).numpy()).reshape(-1))
+        out["single_idx"] = np.array([0, 45, 90, 120, 121, 124])
+        out["single_collision"] = np.concatenate(single)
+    print("   g21: task ids", np.unique(out["task_ids"], return_counts=True), "colliding", int(out["collision"].sum()), "of", len(pts),
+          "shape", out["collision"].shape, out["collision"].dtype, "single", out["single_collision"].tolist())
+    np.savez_compressed(os.path.join(OUT, "g21_ensemble_task.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17, "g18": g18, "g19": g19}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17, "g18": g18, "g19": g19, "g20": g20, "g21": g21}[name]()
     print("done")
