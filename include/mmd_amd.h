@@ -8,7 +8,9 @@
  * fp32 / int32 data; everything else is host memory.  `stream` is a hipStream_t passed as void* (NULL = default
  * stream).  Every function returns 0 on success and a non-zero code on failure; mmd_last_error() gives the text.
  * No global state besides the last-error string (thread-local) and lazily created per-(thread, device) side streams;
- * handles are immutable after creation, so entry points are re-entrant per (handle, stream).
+ * handles are immutable after creation, so entry points are re-entrant per (handle, stream).  The library never reads the
+ * environment: every switch, measurement ones included, is a field of a descriptor passed with the call (mmd_unet_options,
+ * mmd_sampler_desc.flags / .n_streams / .guide_coop_max).
  *
  * Trajectory tensors are [n_traj, H, D] fp32 with D = 4 (x, y, vx, vy) and H = 64 support points, in the
  * NORMALISED space of the diffusion model; n_traj = n_robots * samples_per_robot, robot-major.
@@ -23,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MMD_AMD_ABI_VERSION 6
+#define MMD_AMD_ABI_VERSION 7
 #define MMD_STATE_DIM 4
 #define MMD_HORIZON 64
 
@@ -51,8 +53,21 @@ int64_t mmd_unet_tensor_numel(int unet_input_dim, int n_levels, int index);
  * against mmd_unet_tensor_numel.  Also precomputes, on the GPU, the time-embedding projections of every integer
  * diffusion step t in [0, n_diffusion_steps) (TimeEncoder + the 12 cond_mlp heads; t is identical across the
  * batch, mmd/models/diffusion_models/diffusion_model_base.py:27-29). */
+typedef struct mmd_unet_options {     /* creation-time choices, fixed for the life of the handle; NULL / all zero = defaults */
+  uint32_t flags;                     /* MMD_UNET_* below */
+  int32_t rtb_fused;                  /* layer-by-layer path, A/B: the widest ResidualTemporalBlock run as ONE launch (channels);
+                                       * 0 = none, < 0 = default (64) */
+  int32_t mconv_max_cs;               /* layer-by-layer path, A/B: the widest column slice of its matrix-pipe kernel; 0 = default (128) */
+  int32_t two_per_workgroup_max;      /* fused kernel, A/B: batches up to this size run two trajectories per workgroup; 0 = default
+                                       * (512), < 0 = never */
+} mmd_unet_options;
+#define MMD_UNET_LAYERED 1u           /* the layer-by-layer kernels for the fused kernel's own configuration too (the two
+                                       * implementations share no device code: tests hold one against the other) */
+#define MMD_UNET_LAYERED_VALU 2u      /* layer-by-layer path: every layer on the vector-ALU kernels (A/B of its matrix-pipe kernel) */
+
 int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_diffusion_steps,
-                    const float* const* tensors, const int64_t* numels, int n_tensors, void* stream);
+                    const float* const* tensors, const int64_t* numels, int n_tensors, const mmd_unet_options* options,
+                    void* stream);
 int mmd_unet_destroy(mmd_unet_t unet);
 
 /* Scratch needed by mmd_unet_forward for n_traj trajectories; allocate it with the host framework.  (The fused kernel keeps
@@ -184,7 +199,19 @@ typedef struct mmd_sampler_desc {
                                              * clipped[t]) before it is added (guide_gradient_steps, sample_functions.py:100-101) */
   int32_t model_predicts_x0;                /* 1: GaussianDiffusionModel(predict_epsilon=False): the network output IS x_recon
                                              * (predict_start_from_noise / predict_noise_from_start, diffusion_model_base.py:114-141) */
+  uint32_t flags;                           /* MMD_SAMPLER_* below (measurement switches; 0 in production) */
+  int32_t guide_coop_max;                   /* A/B: a guided step of up to this many trajectories per launch runs four waves per
+                                             * trajectory; 0 = default (512), < 0 = never */
+  const uint64_t* robot_seeds_dev;          /* optional DEVICE array [n_robots]: one Philox stream per ROBOT -- robot r's draws are
+                                             * keyed by (robot_seeds[r], draw, index within the robot * H + t) and `seed` /
+                                             * traj_index_base are ignored.  R independent planner calls (cbs.py:316-324,
+                                             * inference_multi_agent.py:225-237: one MPD call per agent) batched into ONE launch
+                                             * sequence then draw exactly the noise of the R separate calls with those seeds.
+                                             * NULL = one stream per call */
 } mmd_sampler_desc;
+#define MMD_SAMPLER_NO_FUSED_STEP 1u        /* unguided steps as separate step-kernel launches instead of the UNet launch's tail */
+#define MMD_SAMPLER_PERSIST 2u              /* the leading run of unguided steps of mmd_p_sample_loop as persistent launches (<= 64
+                                             * steps each; the first 12 KiB of the workspace then hold the step table) */
 
 /* Scratch needed by mmd_ddpm_step / mmd_p_sample_loop: [mmd_unet_workspace_bytes][eps: n_traj * H * 4 floats].  The chunked
  * (n_streams > 1) loop uses slices of the same eps block, so this size is exact for every n_streams. */
@@ -236,7 +263,7 @@ int mmd_cross_condition(float* x1_dev, float* x2_dev, int ind1, int ind2, const 
  * along the horizon.  Per outer step the tiles step IN ORDER (UNet + fused DDPM/guide kernel of tile m on its own
  * x_dev), each followed by apply_cross_conditioning over all (m1, m2) pairs (sample_functions.py:17-31) -- the whole
  * loop is enqueued by this ONE call (no per-step host round trip).  Every tile has its own model handle, sampler
- * (schedule, guide-step counts, hard mask, Philox seed via `seed`), guide, state, chain and injected-noise buffers; all
+ * (schedule, guide-step counts, hard mask, Philox seed via `seed` or sampler->robot_seeds_dev), guide, state, chain and injected-noise buffers; all
  * tiles share n_robots / samples_per_robot and the workspace (sized by mmd_sampler_workspace_bytes of the largest). */
 typedef struct mmd_ensemble_tile {
   mmd_unet_t unet;
@@ -256,6 +283,9 @@ typedef struct mmd_cross_cond {
   int32_t m1, m2, ind1, ind2;        /* row ind1 of tile m1 is stitched to row ind2 of tile m2 */
   float rel[4];                      /* transforms[m2] - transforms[m1], zero padded to the state dim */
   float boundary[4];                 /* rel / ||rel|| with zeros replaced by 1e6 */
+  const float* by_robot_dev;         /* optional DEVICE table [n_robots][2][4] = (rel, boundary) per robot, replacing the two above:
+                                        batched planner calls whose robots traverse different tile skeletons
+                                        (inference_multi_agent.py:418-431: [[0,0],[0,1]] and [[0,1],[0,0]]); NULL = one pair */
 } mmd_cross_cond;
 
 int mmd_p_sample_loop_ensemble(const mmd_ensemble_tile* tiles, int n_tiles, const mmd_cross_cond* cross, int n_cross,

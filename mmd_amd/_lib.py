@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmd_amd.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 HARD_ROWS_START_GOAL = (1 << 63) | 1     # hard_rows of MPD's {0: start, H-1: goal} (include/mmd_amd.h: bit t = support point t pinned)
 
 
@@ -45,7 +45,16 @@ class SamplerDesc(C.Structure):
         ("noise_std_extra", C.c_float), ("hard_rows", C.c_uint64), ("n_streams", C.c_int32),
         ("traj_index_base", C.c_int64), ("noise_std_extra_by_t", C.POINTER(C.c_float)), ("profiler", C.c_void_p),
         ("scale_grad_by_std", C.c_int32), ("model_predicts_x0", C.c_int32),
+        ("flags", C.c_uint32), ("guide_coop_max", C.c_int32), ("robot_seeds_dev", C.c_void_p),
     ]
+
+
+SAMPLER_NO_FUSED_STEP, SAMPLER_PERSIST = 1, 2          # mmd_sampler_desc.flags
+UNET_LAYERED, UNET_LAYERED_VALU = 1, 2                 # mmd_unet_options.flags
+
+
+class UnetOptions(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("rtb_fused", C.c_int32), ("mconv_max_cs", C.c_int32), ("two_per_workgroup_max", C.c_int32)]
 
 
 class EnsembleTile(C.Structure):
@@ -58,7 +67,7 @@ class EnsembleTile(C.Structure):
 
 class CrossCond(C.Structure):
     _fields_ = [("m1", C.c_int32), ("m2", C.c_int32), ("ind1", C.c_int32), ("ind2", C.c_int32),
-                ("rel", C.c_float * 4), ("boundary", C.c_float * 4)]
+                ("rel", C.c_float * 4), ("boundary", C.c_float * 4), ("by_robot_dev", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -67,7 +76,7 @@ _SIGNATURES = {
     "mmd_unet_num_tensors": (C.c_int, [C.c_int, C.c_int]),
     "mmd_unet_tensor_numel": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "mmd_unet_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
-                                  C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+                                  C.POINTER(C.c_int64), C.c_int, C.POINTER(UnetOptions), C.c_void_p]),
     "mmd_unet_destroy": (C.c_int, [C.c_void_p]),
     "mmd_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "mmd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,

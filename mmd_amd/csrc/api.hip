@@ -30,19 +30,14 @@ void set_error(const char* fmt, ...) {
 }
 
 constexpr int kMaxChunks = 4;
-// Measurement overrides, sampled ONCE when the library is loaded -- the sampling entry points themselves never touch the
-// environment.  MMD_AMD_NO_FUSED_STEP=1: unguided steps run as step-kernel launches instead of inside the UNet launch's tail
-// (A/B of the fused step).  MMD_AMD_STREAMS=<n>: overrides mmd_sampler_desc.n_streams (tools/gpu_streams.sh).
-static const bool kEnvNoFusedStep = [] { const char* e = getenv("MMD_AMD_NO_FUSED_STEP"); return e && atoi(e) != 0; }();
-// MMD_AMD_PERSIST=1 (sampled once at load; default OFF): the leading run of unguided steps as persistent launches (unet.hip:
-// unet_persist_kernel).  Measured in round 5 and NOT kept as the default (profiles/r05_persist_ab.txt): bitwise-equal results, +1 .. 2 %
-// on the 256 .. 1024-trajectory shards (the launch gaps of 50 steps), -1 .. -4 % on the 2048-trajectory headline (one whole-batch
-// persistent launch replaces the two interleaved stream chunks, which are worth more there).
-static const bool kEnvPersist = [] { const char* e = getenv("MMD_AMD_PERSIST"); return e && atoi(e) != 0; }();
-static const int kEnvStreams = [] {
-  const char* e = getenv("MMD_AMD_STREAMS");
-  return e ? atoi(e) : 0;
-}();
+// Measurement switches travel in the descriptors (mmd_sampler_desc.flags / .n_streams / .guide_coop_max, mmd_unet_options): the
+// library never reads the environment.
+//   MMD_SAMPLER_NO_FUSED_STEP: unguided steps run as step-kernel launches instead of inside the UNet launch's tail (A/B of the
+//     fused step).
+//   MMD_SAMPLER_PERSIST (default OFF): the leading run of unguided steps as persistent launches (unet.hip: unet_persist_kernel).
+//     Measured in round 5 and NOT kept as the default (profiles/r05_persist_ab.txt): bitwise-equal results, +1 .. 2 % on the
+//     256 .. 1024-trajectory shards (the launch gaps of 50 steps), -1 .. -4 % on the 2048-trajectory headline (one whole-batch
+//     persistent launch replaces the two interleaved stream chunks, which are worth more there).
 
 // Number of concurrent stream chunks mmd_p_sample_loop splits n_robots x samples_per_robot trajectories into.  auto (n_streams
 // <= 0): 2 chunks once a chunk alone fills the chip (>= 1024 trajectories = one workgroup per CU): +6 .. 12 % on the 32-robot
@@ -50,7 +45,7 @@ static const int kEnvStreams = [] {
 // chunk's forward no longer ends with CUs idling until its slowest workgroup is done.  Smaller batches stay whole: two
 // half-empty launches would share CUs that one leaves free.
 static int stream_chunks(int n_streams, int n_robots, int samples_per_robot) {
-  int nch = kEnvStreams > 0 ? kEnvStreams : n_streams;
+  int nch = n_streams;
   if (nch <= 0) nch = (long long)n_robots * samples_per_robot >= 2048 ? 2 : 1;
   if (nch > kMaxChunks) nch = kMaxChunks;
   if (nch > n_robots) nch = n_robots;
@@ -100,6 +95,8 @@ static int make_step(const mmd_sampler_desc* s, int i, bool guided, StepDev& sd)
   sd.n_guide_steps = s->n_guide_steps;
   sd.hard_rows = s->hard_rows; sd.n_hard = __builtin_popcountll(s->hard_rows);
   sd.traj_base = (long long)s->traj_index_base;
+  sd.robot_seeds = reinterpret_cast<const unsigned long long*>(s->robot_seeds_dev);
+  sd.coop_max = s->guide_coop_max;
   return 0;
 }
 
@@ -191,17 +188,18 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
   if (guide)
     if (int rc = fill_guide(guide, g)) return rc;
   launch_init(x_dev, chain_dev, hard_dev, s->hard_rows, init_noise, (unsigned long long)seed,
-              (long long)s->traj_index_base, n, samples_per_robot, st);
+              reinterpret_cast<const unsigned long long*>(s->robot_seeds_dev), (long long)s->traj_index_base, n, samples_per_robot, st);
+  const bool persist = (s->flags & MMD_SAMPLER_PERSIST) != 0, no_fused_step = (s->flags & MMD_SAMPLER_NO_FUSED_STEP) != 0;
 
-  // OPT-IN (MMD_AMD_PERSIST=1, see kEnvPersist): the leading run of steps WITHOUT guidance (i >= t_start_guide; every step of a
+  // OPT-IN (mmd_sampler_desc.flags & MMD_SAMPLER_PERSIST): the leading run of steps WITHOUT guidance (i >= t_start_guide; every step of a
   // prior-only call) as persistent launches on the caller's stream: a workgroup iterates the run's steps on its own trajectories
   // (unet.hip: unet_persist_kernel), <= 64 steps a launch.  Bitwise the launch-per-step result.  Not with a profiler attached (its
   // brackets are per launch).
   int k_start = 0;
   // (its step table travels by hipMemcpyAsync from host memory: not inside a stream capture)
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-  if (kEnvPersist) (void)hipStreamIsCapturing(st, &capturing);
-  if (kEnvPersist && capturing == hipStreamCaptureStatusNone && !kEnvNoFusedStep && unet_fused_step_supported(unet) && !s->profiler) {
+  if (persist) (void)hipStreamIsCapturing(st, &capturing);
+  if (persist && capturing == hipStreamCaptureStatusNone && !no_fused_step && unet_fused_step_supported(unet) && !s->profiler) {
     FusedStep run[PERSIST_MAX_STEPS];
     int i = n_steps - 1, k0 = 0;
     while (i >= -n_steps_without_noise) {
@@ -215,6 +213,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
         fs.enabled = 1;
         fs.a_t = sd.a_t; fs.b_t = sd.b_t; fs.c1 = sd.c1; fs.c2 = sd.c2; fs.sigma = sd.sigma; fs.noise_std_extra = sd.noise_std_extra;
         fs.do_noise = sd.do_noise; fs.hard_rows = sd.hard_rows; fs.n_hard = sd.n_hard; fs.seed = seed; fs.draw = (unsigned int)(k0 + m);
+        fs.robot_seeds = sd.robot_seeds;
         fs.traj_base = sd.traj_base; fs.traj0 = 0; fs.spr = samples_per_robot;
         fs.x = reinterpret_cast<float4*>(x_dev);
         fs.noise = step_noise_dev ? reinterpret_cast<const float4*>(step_noise_dev + (size_t)(k0 + m) * traj_floats) : nullptr;
@@ -255,7 +254,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
     sd.seed = seed; sd.draw = (unsigned int)k;
     // A step without guidance is fused into the tail of the UNet launch (unet.hip: the wave that holds a trajectory's eps applies
     // ddpm_sample_fn to it): one launch and one dependent dispatch less per (step, chunk).
-    const bool fused = !sd.do_guide && !kEnvNoFusedStep && unet_fused_step_supported(unet);
+    const bool fused = !sd.do_guide && !no_fused_step && unet_fused_step_supported(unet);
     const float* noise_k = step_noise_dev ? step_noise_dev + (size_t)k * traj_floats : nullptr;
     float* chain_k = chain_dev ? chain_dev + (size_t)(k + 1) * traj_floats : nullptr;
     for (int c = 0; c < nch && rc == 0; ++c) {
@@ -265,6 +264,7 @@ int mmd_p_sample_loop(mmd_unet_t unet, const mmd_sampler_desc* s, const mmd_guid
         fs.enabled = 1;
         fs.a_t = sd.a_t; fs.b_t = sd.b_t; fs.c1 = sd.c1; fs.c2 = sd.c2; fs.sigma = sd.sigma; fs.noise_std_extra = sd.noise_std_extra;
         fs.do_noise = sd.do_noise; fs.hard_rows = sd.hard_rows; fs.n_hard = sd.n_hard; fs.seed = sd.seed; fs.draw = sd.draw; fs.traj_base = sd.traj_base;
+        fs.robot_seeds = sd.robot_seeds;
         fs.traj0 = t0; fs.spr = samples_per_robot;
         fs.x = reinterpret_cast<float4*>(x_dev); fs.noise = reinterpret_cast<const float4*>(noise_k);
         fs.chain = reinterpret_cast<float4*>(chain_k); fs.hard = reinterpret_cast<const float4*>(hard_dev);
@@ -329,13 +329,15 @@ int mmd_p_sample_loop_ensemble(const mmd_ensemble_tile* tiles, int n_tiles, cons
       auto row = [&](int m) -> float* {
         return tiles[m].chain_dev ? tiles[m].chain_dev + (size_t)(m > stepped ? crow - 1 : crow) * traj_floats : nullptr;
       };
-      launch_cross(tiles[C.m1].x_dev, tiles[C.m2].x_dev, row(C.m1), row(C.m2), C.ind1, C.ind2, C.rel, C.boundary, n, st);
+      launch_cross(tiles[C.m1].x_dev, tiles[C.m2].x_dev, row(C.m1), row(C.m2), C.ind1, C.ind2, C.rel, C.boundary, C.by_robot_dev,
+                   samples_per_robot, n, st);
     }
   };
   // x_T per tile (diffusion_ensemble.py:66-81): draw / keep, hard conditioning, then cross conditioning; chain[0]
   for (int m = 0; m < n_tiles; ++m)
     launch_init(tiles[m].x_dev, tiles[m].chain_dev, tiles[m].hard_dev, tiles[m].sampler->hard_rows, init_noise,
-                (unsigned long long)tiles[m].seed, (long long)tiles[m].sampler->traj_index_base, n, samples_per_robot, st);
+                (unsigned long long)tiles[m].seed, reinterpret_cast<const unsigned long long*>(tiles[m].sampler->robot_seeds_dev),
+                (long long)tiles[m].sampler->traj_index_base, n, samples_per_robot, st);
   cross_all(0, n_tiles);
   int k = 0;
   for (int i = n_steps - 1; i >= -n_steps_without_noise; --i, ++k) {
@@ -377,7 +379,7 @@ int mmd_ddim_sample(mmd_unet_t unet, const mmd_sampler_desc* s, const float* alp
   if (guide)
     if (int rc = fill_guide(guide, g)) return rc;
   launch_init(x_dev, chain_dev, hard_dev, s->hard_rows, init_noise, (unsigned long long)seed,
-              (long long)s->traj_index_base, n, samples_per_robot, st);
+              reinterpret_cast<const unsigned long long*>(s->robot_seeds_dev), (long long)s->traj_index_base, n, samples_per_robot, st);
   for (int k = 0; k + 1 < n_times; ++k) {
     const int t = times[k], tn = times[k + 1];
     MMD_REQUIRE(t >= 0 && t < s->n_diffusion_steps && tn < t, "mmd_ddim_sample: times must decrease inside the schedule");

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
     }
   }
 
-  if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx), s.sigma, s.noise_std_extra);
+  if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : traj_normal4(s.seed, s.robot_seeds, s.draw, s.traj_base, idx, robot, samples_per_robot), s.sigma, s.noise_std_extra);
   if (is_hard) v = hv;
   x[idx] = v;
   if (chain) chain[idx] = v;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDe
     }
   }
   if (wave != 0) return;
-  if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : normal4(s.seed, s.draw, (unsigned long long)s.traj_base * H + idx), s.sigma, s.noise_std_extra);
+  if (s.do_noise) v = add_step_noise(v, noise ? noise[idx] : traj_normal4(s.seed, s.robot_seeds, s.draw, s.traj_base, idx, robot, samples_per_robot), s.sigma, s.noise_std_extra);
   if (is_hard) v = hv;
   x[idx] = v;
   if (chain) chain[idx] = v;
@@ -487,13 +487,13 @@ __global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDe
 
 // x <- conditioned init: optional Philox draw of x_T, apply_hard_conditioning, optional chain[0] write
 __global__ void init_kernel(float4* __restrict__ x, float4* __restrict__ chain, const float4* __restrict__ hard,
-                            unsigned long long hard_rows, int draw_noise, unsigned long long seed, long long traj_base, int n_traj,
-                            int samples_per_robot) {
+                            unsigned long long hard_rows, int draw_noise, unsigned long long seed,
+                            const unsigned long long* __restrict__ robot_seeds, long long traj_base, int n_traj, int samples_per_robot) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n_traj * H) return;
   const int t = idx % H;
   const int robot = (idx / H) / samples_per_robot;
-  float4 v = draw_noise ? normal4(seed, 0xFFFFFFFFu, (unsigned long long)traj_base * H + idx) : x[idx];
+  float4 v = draw_noise ? traj_normal4(seed, robot_seeds, 0xFFFFFFFFu, traj_base, idx, robot, samples_per_robot) : x[idx];
   float4 hv;
   if (hard_row(hard_rows, __popcll(hard_rows), hard, robot, t, hv)) v = hv;
   x[idx] = v;
@@ -513,9 +513,14 @@ __global__ void q_sample_kernel(float4* __restrict__ x, const float4* __restrict
 // apply_cross_conditioning for one (m1, m2) pair (sample_functions.py:28-29); c1 / c2: the chain rows of the current
 // outer step (or NULL), kept equal to x1 / x2
 __global__ void cross_condition_kernel(float4* __restrict__ x1, float4* __restrict__ x2, float4* __restrict__ c1,
-                                       float4* __restrict__ c2, int ind1, int ind2, float4 rel, float4 bnd, int n_traj) {
+                                       float4* __restrict__ c2, int ind1, int ind2, float4 rel, float4 bnd,
+                                       const float4* __restrict__ by_robot, int spr, int n_traj) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_traj) return;
+  if (by_robot) {                         // batched planner calls: every robot has its own tile offsets
+    rel = by_robot[(size_t)(b / spr) * 2];
+    bnd = by_robot[(size_t)(b / spr) * 2 + 1];
+  }
   const float4 v2 = x2[(size_t)b * H + ind2];
   float4 v1;
   v1.x = fminf(v2.x + rel.x, bnd.x); v1.y = fminf(v2.y + rel.y, bnd.y);
@@ -583,12 +588,8 @@ int fill_guide(const mmd_guide_desc* d, GuideDev& g) {
   return 0;
 }
 
-// MMD_AMD_GUIDE_COOP_MAX=<n>: A/B override of the launch size up to which a guided step runs four waves per trajectory (0: never),
-// sampled once at load time; not an interface
-static const int kCoopMaxTraj = [] {
-  const char* e = getenv("MMD_AMD_GUIDE_COOP_MAX");
-  return e ? atoi(e) : 512;
-}();
+// the launch size up to which a guided step runs four waves per trajectory (mmd_sampler_desc.guide_coop_max overrides: A/B)
+constexpr int kCoopMaxTrajDefault = 512;
 
 int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
                 const float* hard, int traj0, int n_traj, int spr, hipStream_t st) {
@@ -608,7 +609,7 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
     // production launch shape), with the decision dump compiled in
     hipLaunchKernelGGL((ddpm_guide_kernel<4, false, true>), dim3((n_traj + 3) / 4), dim3(256), 0, st, g, s, 0, (float4*)x,
                        (const float4*)eps, (const float4*)noise, (float4*)chain, (const float4*)hard, spr);
-  } else if (guided && n_traj <= kCoopMaxTraj) {
+  } else if (guided && n_traj <= (s.coop_max > 0 ? s.coop_max : s.coop_max < 0 ? 0 : kCoopMaxTrajDefault)) {
     // four waves per trajectory (ddpm_guide_coop_kernel): the whole table of the trajectory's robot in LDS up to 60 KiB (+ the
     // exchange buffer: inside the 64 KiB a launch gets without an opt-in), the rest from L2
     const int fit = 60 * 1024 / bytes_per_slot;
@@ -644,17 +645,17 @@ int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const 
 }
 
 void launch_cross(float* x1, float* x2, float* c1, float* c2, int ind1, int ind2, const float* rel, const float* bnd,
-                  int n_traj, hipStream_t st) {
+                  const float* by_robot, int spr, int n_traj, hipStream_t st) {
   hipLaunchKernelGGL(cross_condition_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, st, (float4*)x1, (float4*)x2,
                      (float4*)c1, (float4*)c2, ind1, ind2, make_float4(rel[0], rel[1], rel[2], rel[3]),
-                     make_float4(bnd[0], bnd[1], bnd[2], bnd[3]), n_traj);
+                     make_float4(bnd[0], bnd[1], bnd[2], bnd[3]), (const float4*)by_robot, spr > 0 ? spr : 1, n_traj);
 }
 
 int launch_init(float* x, float* chain, const float* hard, unsigned long long hard_rows, int draw, unsigned long long seed,
-                long long traj_base, int n_traj, int spr, hipStream_t st) {
+                const unsigned long long* robot_seeds, long long traj_base, int n_traj, int spr, hipStream_t st) {
   const size_t n = (size_t)n_traj * H;
   hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float4*)x, (float4*)chain,
-                     (const float4*)hard, hard_rows, draw, seed, traj_base, n_traj, spr);
+                     (const float4*)hard, hard_rows, draw, seed, robot_seeds, traj_base, n_traj, spr);
   return 0;
 }
 
@@ -746,7 +747,7 @@ int mmd_cross_condition(float* x1_dev, float* x2_dev, int ind1, int ind2, const 
                         int n_traj, void* stream) {
   MMD_REQUIRE(x1_dev && x2_dev && rel && boundary, "mmd_cross_condition: NULL argument");
   MMD_REQUIRE(ind1 >= 0 && ind1 < H && ind2 >= 0 && ind2 < H, "row index out of range");
-  launch_cross(x1_dev, x2_dev, nullptr, nullptr, ind1, ind2, rel, boundary, n_traj, (hipStream_t)stream);
+  launch_cross(x1_dev, x2_dev, nullptr, nullptr, ind1, ind2, rel, boundary, nullptr, 1, n_traj, (hipStream_t)stream);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }

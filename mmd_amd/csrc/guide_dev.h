@@ -95,6 +95,16 @@ __device__ __forceinline__ float4 normal4(unsigned long long seed, unsigned int 
   return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
 }
 
+// The Philox stream of one (trajectory, support point) of a sampling call.  Default: ONE stream per call, keyed by the global
+// trajectory index (traj_base + index in the arrays).  robot_seeds != NULL (mmd_sampler_desc.robot_seeds_dev: R independent planner
+// calls batched into one launch sequence): one stream per ROBOT, keyed by the index within the robot -- exactly what R separate calls
+// with those seeds (and traj_index_base 0) draw.  idx = index of the point in the arrays (trajectory * H + t).
+__device__ __forceinline__ float4 traj_normal4(unsigned long long seed, const unsigned long long* robot_seeds, unsigned int draw,
+                                               long long traj_base, size_t idx, int robot, int spr) {
+  if (robot_seeds) return normal4(robot_seeds[robot], draw, (unsigned long long)(idx - (size_t)robot * spr * H));
+  return normal4(seed, draw, (unsigned long long)traj_base * H + idx);
+}
+
 // p_mean_variance (diffusion_model_base.py:148-160): x0 = a x - b eps; clamp; mean = c1 x0 + c2 x.  Explicit fmas: the step
 // kernel and the UNet kernel's fused unguided step (unet.hip) must round identically.
 __device__ __forceinline__ float ddpm_mean1(float x, float e, float a, float b, float c1, float c2) {
@@ -132,6 +142,7 @@ struct FusedStep {
   int do_noise, n_hard;
   unsigned long long hard_rows;
   unsigned long long seed;
+  const unsigned long long* robot_seeds;   // or NULL (traj_normal4)
   unsigned int draw;
   long long traj_base;
   int traj0, spr;
@@ -171,6 +182,8 @@ struct StepDev {
   int n_hard;                        // popcount(hard_rows)
   unsigned long long hard_rows;      // bit t: support point t is hard-conditioned (hard[robot][slot], slot = pinned rows below t)
   unsigned long long seed;
+  const unsigned long long* robot_seeds;   // or NULL: one Philox stream per robot (traj_normal4; mmd_sampler_desc.robot_seeds_dev)
+  int coop_max;                      // the cooperative guide kernel is used up to this many trajectories per launch (0 = default)
   unsigned int draw;
   int traj0, traj_end;               // this launch covers trajectories [traj0, traj_end) of the full arrays
   float4* guide_chain;               // optional [n_guide_steps][n_traj_total][H]: state after every guide iteration
@@ -192,9 +205,10 @@ int unet_persist_steps(mmd_unet_t u, int n, void* ws, size_t ws_bytes, hipStream
 int launch_step(const GuideDev& g, StepDev s, float* x, const float* eps, const float* noise, float* chain,
                 const float* hard, int traj0, int n_traj, int spr, hipStream_t st);
 int launch_init(float* x, float* chain, const float* hard, unsigned long long hard_rows, int draw, unsigned long long seed,
-                long long traj_base, int n_traj, int spr, hipStream_t st);
+                const unsigned long long* robot_seeds, long long traj_base, int n_traj, int spr, hipStream_t st);
 
+// by_robot: optional device table [n_robots][8] = (rel[4], boundary[4]) per robot (mmd_cross_cond.by_robot_dev), spr = samples per robot
 void launch_cross(float* x1, float* x2, float* c1, float* c2, int ind1, int ind2, const float* rel, const float* bnd,
-                  int n_traj, hipStream_t st);
+                  const float* by_robot, int spr, int n_traj, hipStream_t st);
 
 }  // namespace mmd

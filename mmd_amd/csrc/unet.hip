@@ -1890,7 +1890,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
         const size_t idx = (size_t)traj * H + lane;
         float4 v = ddpm_posterior_mean(fs.x[idx], e, fs.a_t, fs.b_t, fs.c1, fs.c2);
         if (fs.do_noise)
-          v = add_step_noise(v, fs.noise ? fs.noise[idx] : normal4(fs.seed, fs.draw, (unsigned long long)fs.traj_base * H + idx), fs.sigma,
+          v = add_step_noise(v, fs.noise ? fs.noise[idx] : traj_normal4(fs.seed, fs.robot_seeds, fs.draw, fs.traj_base, idx, robot, fs.spr), fs.sigma,
                              fs.noise_std_extra);
         float4 hv;
         if (hard_row(fs.hard_rows, fs.n_hard, fs.hard, robot, lane, hv)) v = hv;
@@ -2171,7 +2171,7 @@ __device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalAr
         const size_t idx = (size_t)traj * H + lane;
         float4 v = ddpm_posterior_mean(fs.x[idx], e, fs.a_t, fs.b_t, fs.c1, fs.c2);
         if (fs.do_noise)
-          v = add_step_noise(v, fs.noise ? fs.noise[idx] : normal4(fs.seed, fs.draw, (unsigned long long)fs.traj_base * H + idx), fs.sigma,
+          v = add_step_noise(v, fs.noise ? fs.noise[idx] : traj_normal4(fs.seed, fs.robot_seeds, fs.draw, fs.traj_base, idx, robot, fs.spr), fs.sigma,
                              fs.noise_std_extra);
         float4 hv;
         if (hard_row(fs.hard_rows, fs.n_hard, fs.hard, robot, lane, hv)) v = hv;
@@ -2411,6 +2411,7 @@ using namespace mmd;
 struct mmd_unet_s {
   mmd::LayeredUnet* layered = nullptr;   // set: a configuration other than the fused kernel's; everything below is unused
   int T = 0;
+  int ns2_max = 512;         // unet_kernel<2> (two trajectories per workgroup) up to this batch size (mmd_unet_options.two_per_workgroup_max)
   size_t blob_bytes = 0;     // bytes of `blob` (mmd_unet_weight_bytes)
   float* blob = nullptr;     // packed weights / biases / affine params
   float* ttable = nullptr;   // [T][tb_total]
@@ -2527,7 +2528,8 @@ int64_t mmd_unet_tensor_numel(int unet_input_dim, int n_levels, int index) {
 }
 
 int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_diffusion_steps,
-                    const float* const* tensors, const int64_t* numels, int n_tensors, void* stream) {
+                    const float* const* tensors, const int64_t* numels, int n_tensors, const mmd_unet_options* options,
+                    void* stream) {
   Spec s;
   MMD_REQUIRE(out != nullptr, "mmd_unet_create: out is NULL");
   MMD_REQUIRE(build_spec(unet_input_dim, n_levels, s),
@@ -2541,12 +2543,12 @@ int mmd_unet_create(mmd_unet_t* out, int unet_input_dim, int n_levels, int n_dif
 
   auto* u = new mmd_unet_s();
   u->T = n_diffusion_steps;
-  // MMD_AMD_UNET_LAYERED=1 (read at create): the layer-by-layer path for the fused kernel's own configuration too -- the two
-  // implementations share no device code, tests/test_gpu_dim_mults.py holds one against the other
-  const char* force_layered = getenv("MMD_AMD_UNET_LAYERED");
-  if (!fused_config(unet_input_dim, n_levels) || (force_layered && force_layered[0] == '1')) {
+  if (options && options->two_per_workgroup_max != 0) u->ns2_max = options->two_per_workgroup_max < 0 ? 0 : options->two_per_workgroup_max;
+  // MMD_UNET_LAYERED: the layer-by-layer path for the fused kernel's own configuration too -- the two implementations share no
+  // device code, tests/test_gpu_dim_mults.py holds one against the other
+  if (!fused_config(unet_input_dim, n_levels) || (options && (options->flags & MMD_UNET_LAYERED))) {
     // e.g. UNET_DIM_MULTS[1] = (1, 2, 4, 8): layer by layer (unet_layers.hip)
-    if (int rc = layered_create(&u->layered, s, n_diffusion_steps, tensors, st)) {
+    if (int rc = layered_create(&u->layered, s, n_diffusion_steps, tensors, options, st)) {
       delete u;
       return rc;
     }
@@ -2730,13 +2732,6 @@ static const double kFp32Flops = 0.0;                                           
 static const double kUnetMfmaFlops = kF16Flops + kFp32Flops;
 
 
-// MMD_AMD_UNET_NS2_MAX=<n>: A/B override of the batch size up to which unet_kernel<2> is launched (0: never), sampled once at
-// load time (tools/unet_forward_loop.py, the trace tools); not an interface
-static const int kTwoPerWorkgroupMax = [] {
-  const char* e = getenv("MMD_AMD_UNET_NS2_MAX");
-  return e ? atoi(e) : 512;
-}();
-
 static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, int n, void* ws, size_t ws_bytes,
                              hipStream_t st, mmd_profiler_t prof, const FusedStep* fs = nullptr) {
   MMD_REQUIRE(u && x && eps && ws, "mmd_unet_forward: NULL argument");
@@ -2771,7 +2766,7 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.fin.w1_bias = u->blob + u->fin_b1;
   const bool bracket = prof_begin(prof, 0, fs && fs->enabled ? MMD_PROF_UNET_FUSED : MMD_PROF_UNET, st);
   // two trajectories per workgroup while that still leaves at most one workgroup per CU (256 CUs): see unet_kernel
-  if (n <= kTwoPerWorkgroupMax) hipLaunchKernelGGL(unet_kernel<2>, dim3((n + 1) / 2), dim3(256), 0, st, a);
+  if (n <= u->ns2_max) hipLaunchKernelGGL(unet_kernel<2>, dim3((n + 1) / 2), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(unet_kernel<4>, dim3((n + 3) / 4), dim3(256), 0, st, a);
   if (bracket) prof_end(prof, st);
   MMD_HIP_CHECK(hipGetLastError());
@@ -2810,7 +2805,7 @@ int unet_persist_steps(mmd_unet_t u, int n, void* ws, size_t ws_bytes, hipStream
   MMD_HIP_CHECK(hipMemcpyAsync(args_dev, &a, sizeof(a), hipMemcpyHostToDevice, st));   // (pageable source: staged before the call returns)
   const FusedStep* sd = reinterpret_cast<const FusedStep*>(ws);
   const UnetArgs* ap = reinterpret_cast<const UnetArgs*>(args_dev);
-  if (n <= kTwoPerWorkgroupMax) hipLaunchKernelGGL(unet_persist_kernel<2>, dim3((n + 1) / 2), dim3(256), 0, st, ap, sd, n_steps, u->tb_total);
+  if (n <= u->ns2_max) hipLaunchKernelGGL(unet_persist_kernel<2>, dim3((n + 1) / 2), dim3(256), 0, st, ap, sd, n_steps, u->tb_total);
   else hipLaunchKernelGGL(unet_persist_kernel<4>, dim3((n + 3) / 4), dim3(256), 0, st, ap, sd, n_steps, u->tb_total);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;

@@ -18,6 +18,8 @@
 // conv_plain_kernel: the strided / transposed / 1x1 convs without a norm, one thread per output, split over blockIdx.y likewise.
 #include <hip/hip_runtime.h>
 
+#include <memory>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -786,8 +788,6 @@ const void* mconv_fn(int cs) {
 template <int KIND>
 const void* mconv_fn(int cs, int kch) { return kch <= 64 ? mconv_fn<KIND, 1>(cs) : mconv_fn<KIND, 2>(cs); }
 constexpr int kNumCUs = 256;                       // MI355X
-// MMD_AMD_MCONV_MAX_CS (A/B, sampled at load): the widest column slice mconv_kernel is launched with (default 128)
-static const int kMconvMaxCs = [] { const char* e = getenv("MMD_AMD_MCONV_MAX_CS"); return e && atoi(e) >= 16 ? atoi(e) : 128; }();
 // workgroups of `fn` with `shm` bytes of LDS that one CU holds (cached: the launches of a forward ask 47 times)
 int mconv_resident(const void* fn, size_t shm) {
   static std::mutex mu;
@@ -812,8 +812,6 @@ size_t push_v(std::vector<float>& blob, const float* p, int64_t n) {
   return off;
 }
 
-// MMD_AMD_LAYERED_VALU=1 (sampled once at load): every layer on the vector-ALU kernels again (A/B of mconv_kernel)
-static const bool kLayeredValu = [] { const char* e = getenv("MMD_AMD_LAYERED_VALU"); return e && atoi(e) != 0; }();
 struct LRtb { int cin, cout; size_t wa, ba, ga, bea, wb, bb, gb, beb, wr, br; bool res; int tb_off; MPack ma, mb, mr; };
 
 }  // namespace
@@ -828,14 +826,17 @@ struct LayeredUnet {
   size_t down_w[MAX_LEVELS - 1], down_b[MAX_LEVELS - 1], up_w[MAX_LEVELS - 1], up_b[MAX_LEVELS - 1];
   size_t fin_w5, fin_b5, fin_g, fin_be, fin_w1, fin_b1;
   MPack fin_m, down_m[MAX_LEVELS - 1], up_m[MAX_LEVELS - 1];
-  int rtb_fused = 64;                 // MMD_AMD_RTB_FUSED=<channels> (A/B, read at create): the widest ResidualTemporalBlock that runs as ONE launch
+  int rtb_fused = 64;                 // mmd_unet_options.rtb_fused (A/B): the widest ResidualTemporalBlock that runs as ONE launch
                                       // (0: none -- two Conv1dBlock launches each; default 64: with 128 channels the one-launch form spills)
+  int mconv_max_cs = 128;             // mmd_unet_options.mconv_max_cs (A/B): the widest column slice mconv_kernel is launched with
   bool mfma = false;                  // every layer has f16x2 packs: the matrix-pipe kernels with blocked activations; else the vector-ALU kernels
   int per_sample = 0;                 // floats of the largest activation tensor of a sample (64 x unet_input_dim)
 };
 
-int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* tensors, hipStream_t st) {
-  auto* u = new LayeredUnet();
+int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* tensors, const mmd_unet_options* opt, hipStream_t st) {
+  // (owned until the last step succeeded: no error path below leaks the device allocations or the host object)
+  std::unique_ptr<LayeredUnet, void (*)(LayeredUnet*)> owner(new LayeredUnet(), layered_destroy);
+  LayeredUnet* u = owner.get();
   u->spec = s;
   u->T = T;
   u->per_sample = H * s.uid;
@@ -875,8 +876,10 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
     u->up_m[i] = push_mfma_up(blob, tensors[s.t_up[i][0]], cu, cu);
   }
   u->fin_m = push_mfma5(blob, tensors[s.t_final[0]], s.uid, s.uid);
-  if (const char* e = getenv("MMD_AMD_RTB_FUSED")) u->rtb_fused = atoi(e);
-  u->mfma = !kLayeredValu && u->fin_m.w && s.uid % 8 == 0;
+  if (opt && opt->rtb_fused >= 0) u->rtb_fused = opt->rtb_fused;
+  if (opt && opt->mconv_max_cs >= 16) u->mconv_max_cs = opt->mconv_max_cs;
+  const bool valu_only = opt && (opt->flags & MMD_UNET_LAYERED_VALU);     // every layer on the vector-ALU kernels (A/B of mconv_kernel)
+  u->mfma = !valu_only && u->fin_m.w && s.uid % 8 == 0;
   for (size_t r = 0; r < u->rtb.size(); ++r) {
     const LRtb& R = u->rtb[r];
     u->mfma = u->mfma && R.ma.w && R.mb.w && (!R.res || R.mr.w) && (r == 0 || R.cin % 8 == 0);
@@ -891,7 +894,6 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
   if (hipMalloc(&u->blob, blob.size() * sizeof(float)) != hipSuccess ||
       hipMalloc(&u->ttable, (size_t)T * u->tb_total * sizeof(float)) != hipSuccess) {
     set_error("mmd_unet_create: hipMalloc failed");
-    layered_destroy(u);
     return 1;
   }
   // widest Conv1dBlock input: ups.0.0 of a four-level net stages 2 x 8 uid x 8 channels x (8 + 8) positions (64 KB at uid 64)
@@ -912,7 +914,7 @@ int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* 
   launch_time_table(ta, T, st);
   MMD_HIP_CHECK(hipGetLastError());
   MMD_HIP_CHECK(hipStreamSynchronize(st));
-  *out = u;
+  *out = owner.release();
   return 0;
 }
 
@@ -961,7 +963,7 @@ int layered_forward(const LayeredUnet* u, const float* x, int t, float* eps, int
     const int rows = kind == 2 ? c.l_in / 2 : c.l_in, spw = 64 / rows, n_wg = (n + spw - 1) / spw;
     int cs = 0;                                            // the widest slice that leaves >= 768 workgroups, else the narrowest there is
     for (int w : {128, 64, 32, 16})
-      if (w <= kMconvMaxCs && cols % w == 0 && w % unit == 0 && (!cs || (long long)n_wg * (cols / cs) < 768)) cs = w;
+      if (w <= u->mconv_max_cs && cols % w == 0 && w % unit == 0 && (!cs || (long long)n_wg * (cols / cs) < 768)) cs = w;
     if (kind == 4) cs = cols;                              // a whole ResidualTemporalBlock: one slice (32, 64 or 128 channels)
     MMD_REQUIRE(cs && rows >= 8 && rows <= 64, "layered_forward: no slice for a layer of %d columns", cols);
     MConvArgs ma{};

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "../../include/mmd_amd.h"
+
 namespace mmd {
 
 constexpr int MAX_LEVELS = 4;                  // dim_mults (1, 2, 4, 8)
@@ -95,7 +97,7 @@ void launch_time_table(const TimeArgs& a, int T, hipStream_t st);   // (unet.hip
 
 // The layer-by-layer TemporalUnet (unet_layers.hip): any configuration build_spec accepts; activations in an HBM workspace.
 struct LayeredUnet;
-int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* tensors, hipStream_t st);
+int layered_create(LayeredUnet** out, const Spec& s, int T, const float* const* tensors, const mmd_unet_options* opt, hipStream_t st);
 void layered_destroy(LayeredUnet* u);
 size_t layered_workspace_bytes(const LayeredUnet* u, int n_traj);
 size_t layered_weight_bytes(const LayeredUnet* u);

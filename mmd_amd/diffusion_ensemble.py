@@ -47,9 +47,14 @@ class DiffusionsEnsemble:
     @torch.no_grad()
     def p_sample_loop(self, shape, hard_conds, cross_conds, n_diffusion_steps=None, contexts=None, return_chain=False,
                       sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0, warm_start_path_b=None,
-                      x_init=None, step_noise=None, device="cuda", seed=None, **sample_kwargs):
+                      x_init=None, step_noise=None, device="cuda", seed=None, n_robots=1, robot_seeds=None,
+                      robot_transforms=None, **sample_kwargs):
         """diffusion_ensemble.py:55-106.  `x_init` {m: [B,H,D]} / `step_noise` [n_steps, n_models, B,H,D] inject the
-        Gaussian draws (parity tests); otherwise Philox (`seed` + tile index, or the global stream counter)."""
+        Gaussian draws (parity tests); otherwise Philox (`seed` + tile index, or the global stream counter).
+        Batched form (planners.plan_batched: R independent MPDEnsemble calls as ONE launch sequence): `n_robots` = R, shape[0] =
+        R * samples, hard conditions [R, D] per row, `robot_seeds` [R] (call r's tile j draws with robot_seeds[r] + j, as its own
+        call would) and `robot_transforms` [R] = each call's {tile: transform} (the cross conditioning then takes its relative
+        transform per robot)."""
         if sample_fn is not ddpm_sample_fn:
             raise NotImplementedError("only ddpm_sample_fn")
         if contexts is not None:
@@ -60,12 +65,16 @@ class DiffusionsEnsemble:
         pos = {m: j for j, m in enumerate(keys)}
         device = torch.device(device)
         B, H, D = shape
+        if B % n_robots:
+            raise ValueError(f"batch {B} is not a multiple of n_robots = {n_robots}")
         n_total = n_diffusion_steps + n_diffusion_steps_without_noise
         kw = sample_kwargs["sample_kwargs"]
         x, chains, keep = {}, {}, []
         init_noise = 0
         for m in keys:
             if warm_start_path_b is not None:
+                if robot_transforms is not None:
+                    raise NotImplementedError("warm start of a batched call")
                 x[m] = warm_start_path_b[:, m * HORIZON:(m + 1) * HORIZON, :].to(device=device, dtype=torch.float32).contiguous().clone()
                 x[m][:, :, :2] -= torch.as_tensor(self.transforms[m]).to(x[m].device)
             elif x_init is not None:
@@ -79,17 +88,18 @@ class DiffusionsEnsemble:
         for j, m in enumerate(keys):
             model, skw = self.models[m], kw[m]
             guide = skw.get("guide")
-            hard, mask = model._hard_tensor(hard_conds[m], 1, H, device, D)
+            hard, mask = model._hard_tensor(hard_conds[m], n_robots, H, device, D)
+            seeds_dev = None if robot_seeds is None else model.robot_seed_tensor([int(v) + j for v in robot_seeds], n_robots, device)
             sd = model._sampler_desc(skw.get("n_guide_steps", 1), skw.get("t_start_guide", float("inf")),
                                      skw.get("noise_std_extra_schedule_fn"), mask,
-                                     scale_grad_by_std=skw.get("scale_grad_by_std", False))
+                                     scale_grad_by_std=skw.get("scale_grad_by_std", False), robot_seeds=seeds_dev)
             gd = guide.desc() if guide is not None else None
             noise_m = None
             if step_noise is not None:
                 noise_m = step_noise[:, j].to(device=device, dtype=torch.float32).contiguous()
                 assert noise_m.shape == (n_total,) + tuple(shape)
             chains[m] = torch.empty((n_total + 1,) + tuple(shape), dtype=torch.float32, device=device) if return_chain else None
-            keep.append((hard, sd, gd, noise_m))
+            keep.append((hard, sd, gd, noise_m, seeds_dev))
             t = tiles[j]
             t.unet = model.model.handle(model.n_diffusion_steps, device)
             t.sampler = C.pointer(sd)
@@ -97,15 +107,19 @@ class DiffusionsEnsemble:
             t.x_dev, t.hard_dev = x[m].data_ptr(), hard.data_ptr()
             t.step_noise_dev = noise_m.data_ptr() if noise_m is not None else None
             t.chain_dev = chains[m].data_ptr() if chains[m] is not None else None
-            t.seed = (int(seed) + j) if seed is not None else next_stream_seed(model.seed)
+            t.seed = 0 if robot_seeds is not None else ((int(seed) + j) if seed is not None else next_stream_seed(model.seed))
             ws_bytes = max(ws_bytes, lib.mmd_sampler_workspace_bytes(t.unet, B))
         cc = (_lib.CrossCond * max(len(cross_conds), 1))()
         for c, ((m1, m2), (ind1, ind2)) in enumerate(cross_conds.items()):
             rel, boundary = _rel_boundary(self.transforms, m1, m2, D)
             cc[c].m1, cc[c].m2, cc[c].ind1, cc[c].ind2 = pos[m1], pos[m2], int(ind1) % H, int(ind2) % H
             cc[c].rel[:], cc[c].boundary[:] = rel, boundary
+            if robot_transforms is not None:
+                table = torch.tensor([sum(_rel_boundary(tr, m1, m2, D), []) for tr in robot_transforms], dtype=torch.float32).to(device)
+                keep.append(table)
+                cc[c].by_robot_dev = table.data_ptr()
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        _lib.launch("mmd_p_sample_loop_ensemble", ws, tiles, K, cc, len(cross_conds), 1, B, n_diffusion_steps,
+        _lib.launch("mmd_p_sample_loop_ensemble", ws, tiles, K, cc, len(cross_conds), n_robots, B // n_robots, n_diffusion_steps,
                                                   n_diffusion_steps_without_noise, init_noise, ws.data_ptr(), ws.numel())
         if return_chain:
             return x, {m: chains[m].transpose(0, 1) for m in keys}            # [B, steps+1, H, D] like torch.stack(dim=1)

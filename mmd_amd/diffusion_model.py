@@ -57,6 +57,8 @@ class GaussianDiffusionModel:
         self._tables = {k: np.ascontiguousarray(getattr(self, k).numpy()) for k in SCHEDULE_KEYS}
         self.seed = 0
         self.profiler = None                                       # optional mmd_profiler_t (bench.py), see mmd_amd_debug.h
+        self.sampler_flags = 0                                     # mmd_sampler_desc.flags (_lib.SAMPLER_*: measurement switches)
+        self.guide_coop_max = 0                                    # mmd_sampler_desc.guide_coop_max (0 = the library's default)
         self._noise_tables = {}
 
     # ---- parameters -------------------------------------------------------------------------------------------
@@ -89,7 +91,7 @@ class GaussianDiffusionModel:
         return self._noise_tables[key][1]
 
     def _sampler_desc(self, n_guide_steps, t_start_guide, noise_fn, hard_rows, n_streams=0, traj_index_base=0,
-                      scale_grad_by_std=False):
+                      scale_grad_by_std=False, robot_seeds=None):
         s = _lib.SamplerDesc()
         s.n_diffusion_steps = self.n_diffusion_steps
         fp = C.POINTER(C.c_float)
@@ -108,7 +110,20 @@ class GaussianDiffusionModel:
         s.profiler = self.profiler
         s.scale_grad_by_std = int(bool(scale_grad_by_std))
         s.model_predicts_x0 = 0 if self.predict_epsilon else 1
+        s.flags, s.guide_coop_max = int(self.sampler_flags), int(self.guide_coop_max)
+        if robot_seeds is not None:                              # int64 device tensor [n_robots] (kept alive by the caller)
+            s.robot_seeds_dev = robot_seeds.data_ptr()
         return s
+
+    @staticmethod
+    def robot_seed_tensor(robot_seeds, n_robots, device):
+        """[n_robots] Philox seeds -> the int64 device tensor mmd_sampler_desc.robot_seeds_dev points at (the same 64 bits), or None."""
+        if robot_seeds is None:
+            return None
+        seeds = [_lib.signed64(int(v)) for v in robot_seeds]
+        if len(seeds) != n_robots:
+            raise ValueError(f"robot_seeds: {len(seeds)} seeds for {n_robots} robots")
+        return torch.tensor(seeds, dtype=torch.int64).to(device)
 
     @staticmethod
     def _hard_tensor(hard_conds, n_robots, horizon, device, D):
@@ -136,12 +151,13 @@ class GaussianDiffusionModel:
                       sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=0, warm_start_path_b=None,
                       guide=None, n_guide_steps=1, t_start_guide=float("inf"), noise_std_extra_schedule_fn=None,
                       n_robots=1, step_noise=None, seed=None, device="cuda", n_streams=0, traj_index_base=0,
-                      scale_grad_by_std=False, **sample_kwargs):
+                      scale_grad_by_std=False, robot_seeds=None, **sample_kwargs):
         """diffusion_model_base.py:162-211.  Extensions: `n_robots` (batch = n_robots * n_samples, robot-major),
         `step_noise` [n_steps_total, B, H, D] + `warm_start_path_b` as x_T to inject every Gaussian draw (parity
         tests), `seed` for the in-kernel Philox stream otherwise, `traj_index_base` = global index of this call's first
         trajectory (a rank sampling robots [r0, r1) of a bigger instance passes r0 * n_samples and draws exactly the noise
-        those rows get in the unsharded call)."""
+        those rows get in the unsharded call); `robot_seeds` [n_robots]: one Philox stream per robot -- the batch then draws
+        exactly what n_robots separate one-robot calls with those seeds draw (planners.plan_batched)."""
         if sample_fn is not ddpm_sample_fn:
             raise NotImplementedError("only ddpm_sample_fn is implemented (DDIM: conditional_sample(ddim=True) / ddim_sample)")
         if context is not None:
@@ -152,8 +168,9 @@ class GaussianDiffusionModel:
         device = torch.device(device)
         lib = _lib.load()
         hard, mask = self._hard_tensor(hard_conds, n_robots, H, device, D)
+        seeds_dev = self.robot_seed_tensor(robot_seeds, n_robots, device)
         s = self._sampler_desc(n_guide_steps, t_start_guide, noise_std_extra_schedule_fn, mask, n_streams, traj_index_base,
-                               scale_grad_by_std=scale_grad_by_std)
+                               scale_grad_by_std=scale_grad_by_std, robot_seeds=seeds_dev)
         n_total = n_diffusion_steps + n_diffusion_steps_without_noise
         if warm_start_path_b is not None:
             x = warm_start_path_b.to(device=device, dtype=torch.float32).contiguous().clone()

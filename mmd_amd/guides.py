@@ -57,6 +57,7 @@ class GuideManagerTrajectoriesWithVelocity:
         # collision_margins + cutoff_margin in fp32 (distance_fields.py:117, robot_planar_disk.py:68)
         self.margin = float(np.float32(np.float32(robot_radius * 1.1) + np.float32(obstacle_cutoff_margin)))
         env_ids = list(robot_env_ids) if robot_env_ids is not None else [env_id] * n_robots
+        self.env_id = env_ids[0]
         maps = sorted(set(env_ids))
         self._grids = device_sdf_textures(maps, self.device)                  # [n_maps, n_grids=1, nx, ny, 4], shared
         self._robot_map = torch.tensor([maps.index(e) for e in env_ids], dtype=torch.int32, device=self.device)

@@ -618,12 +618,11 @@ def plan_concurrently(calls, seeds=None):
     over `calls` would have used for single-model planners -- the results do not depend on how the threads interleave.
     Returns the PlannerOutputs in list order; an exception of any call is re-raised."""
     from concurrent.futures import ThreadPoolExecutor
-    from .diffusion_model import next_stream_seed
     calls = [tuple(c) for c in calls]
     if len({id(c[0]) for c in calls}) != len(calls):
         raise ValueError("plan_concurrently: a planner appears twice (a planner call is not re-entrant)")
-    if seeds is None:      # (an MPD's model carries the planner's seed, an MPDEnsemble's first tile model)
-        seeds = [next_stream_seed(c[0].models[0].seed if hasattr(c[0], "models") else c[0].model.seed) for c in calls]
+    if seeds is None:
+        seeds = _default_seeds(calls)
     if len(seeds) != len(calls):
         raise ValueError("plan_concurrently: one seed per call")
     if not calls:
@@ -644,3 +643,246 @@ def plan_concurrently(calls, seeds=None):
     with ThreadPoolExecutor(max_workers=len(calls)) as pool:
         return list(pool.map(run, range(len(calls))))
 
+
+
+# ---- R independent planner calls as ONE launch sequence ----------------------------------------------------------------------------
+def _default_seeds(calls):
+    from .diffusion_model import next_stream_seed
+    # (an MPD's model carries the planner's seed, an MPDEnsemble's first tile model)
+    return [next_stream_seed(c[0].models[0].seed if hasattr(c[0], "models") else c[0].model.seed) for c in calls]
+
+
+def _guide_key(g):
+    return (g.margin, g.weight_collision, g.weight_smoothness, g.dt, g.sigma_gp, g.max_grad_norm, g.clip_grad, g.clip_grad_rule,
+            g.max_grad_value, g.extra_objects_only, g._xs is None and g._xb is None,
+            tuple(float(v) for v in g.dataset.normalizer.mins.cpu()), tuple(float(v) for v in g.dataset.normalizer.maxs.cpu()))
+
+
+def _batch_key(call):
+    """Calls with equal keys can share one launch sequence: same planner class and algorithm, the same device model(s) (weights are
+    content-hashed: equal state dicts share one handle), schedule, batch size, sampler settings and guide parameters.  Maps,
+    start / goal, constraints, tile transforms and seeds may differ per call.  None: the call is run on its own (a re-plan from an
+    experience, `diffusion_prior_then_guide`, a map with extra objects)."""
+    planner = call[0]
+    experience = call[4] if len(call) > 4 else None
+    if experience is not None or planner.run_prior_then_guidance:
+        return None
+    dev = planner.device
+    if isinstance(planner, MPD):
+        g = planner.guide
+        if g._xs is not None or g._xb is not None:
+            return None
+        m = planner.model
+        return ("MPD", str(dev), m.model.handle(m.n_diffusion_steps, dev).value, m.n_diffusion_steps, m.predict_epsilon, planner.num_samples,
+                planner.n_guide_steps, planner.t_start_guide, planner.n_diffusion_steps_without_noise, planner.run_prior_only,
+                _guide_key(g), m.sampler_flags, m.guide_coop_max)
+    if isinstance(planner, MPDEnsemble):
+        ms = planner.models
+        return ("MPDEnsemble", str(dev), tuple(ms[j].model.handle(ms[j].n_diffusion_steps, dev).value for j in ms),
+                ms[0].n_diffusion_steps, ms[0].predict_epsilon, planner.num_samples, planner.n_diffusion_steps_without_noise,
+                planner.run_prior_only, tuple((planner.sample_kwargs[j]["n_guide_steps"], planner.sample_kwargs[j]["t_start_guide"])
+                                              for j in ms), tuple(_guide_key(planner.guides[j]) for j in ms),
+                tuple(sorted(planner.cross_conds.items())))
+    return None
+
+
+_BATCH_GUIDES = {}       # (ids of the planners' guides) -> (weakrefs, combined guide): built once per set of planners
+
+
+def _combined_guide(guides):
+    """ONE GuideManager over R robots (robot r = call r: its own map index, its own constraint groups) with the parameters the R
+    guides share; cached per set of guide objects (the per-robot map table lives on the device)."""
+    import weakref
+    key = tuple(id(g) for g in guides)
+    hit = _BATCH_GUIDES.get(key)
+    if hit is not None and all(r() is g for r, g in zip(hit[0], guides)):
+        return hit[1]
+    g0 = guides[0]
+    cg = GuideManagerTrajectoriesWithVelocity(
+        g0.dataset, clip_grad=g0.clip_grad, clip_grad_rule=g0.clip_grad_rule, max_grad_norm=g0.max_grad_norm,
+        max_grad_value=g0.max_grad_value, n_robots=len(guides), robot_env_ids=[g.env_id for g in guides],
+        weight_grad_cost_collision=g0.weight_collision, weight_grad_cost_smoothness=g0.weight_smoothness,
+        sigma_gp=g0.sigma_gp, extra_objects_only=g0.extra_objects_only, device=g0.device)
+    cg.margin, cg.dt = g0.margin, g0.dt                       # (exactly the values the planners' own guides carry)
+    while len(_BATCH_GUIDES) > 64:
+        _BATCH_GUIDES.pop(next(iter(_BATCH_GUIDES)))
+    _BATCH_GUIDES[key] = ([weakref.ref(g) for g in guides], cg)
+    return cg
+
+
+def _load_constraints(cg, per_robot):
+    """per_robot[r] = [(CostConstraint, weight), ...] -> the combined guide's extra costs (one host pack for all robots)."""
+    cg.reset_extra_costs()
+    for r, pairs in enumerate(per_robot):
+        if pairs:
+            cg.add_extra_costs([c for c, _ in pairs], [w for _, w in pairs], robot=r)
+
+
+def _split_outputs(calls, planners, r, idx, free_mask, trajs_iters_all, B, t_total, ensemble_tasks=None):
+    """The PlannerOutputs of a batched group from ONE post-processing launch + ONE device -> host transfer."""
+    R, dev = len(planners), trajs_iters_all.device
+    host = torch.cat((free_mask.float(), idx.float(), r.path_length, r.smoothness)).cpu().numpy()
+    fm_all, ib_all = host[:R * B] > 0, host[R * B:R * B + R].astype(np.int64)
+    pl_all, sm_all = host[R * B + R:2 * R * B + R], host[2 * R * B + R:]
+    outs = []
+    for k, (call, planner) in enumerate(zip(calls, planners)):
+        sl = slice(k * B, (k + 1) * B)
+        out = PlannerOutput()
+        out.t_total = t_total
+        trajs_iters = trajs_iters_all[:, sl]
+        trajs_final = trajs_iters[-1].contiguous()
+        fm, ib = fm_all[sl], int(ib_all[k])
+        free_i, coll_i = np.flatnonzero(fm), np.flatnonzero(~fm)
+        ens = ensemble_tasks is not None
+        free_idxs = torch.from_numpy(free_i).to(dev) if ens else torch.from_numpy(free_i).to(dev).view(-1, 1)
+        coll_idxs = torch.from_numpy(coll_i).to(dev) if ens else torch.from_numpy(coll_i).to(dev).view(-1, 1)
+        out.trajs_iters, out.trajs_final = trajs_iters, r.smoothed[sl]
+        out.trajs_final_coll_idxs, out.trajs_final_free_idxs = coll_idxs, free_idxs
+        if ens:                                             # shapes of combine_trajs (_fill_output_ensemble)
+            empty = torch.tensor([], dtype=torch.float32, device=dev)
+            out.trajs_final_coll = trajs_final[:, coll_idxs] if coll_i.size else empty
+            out.trajs_final_free = trajs_final.index_select(0, free_idxs) if free_i.size else empty
+            out.success_free_trajs = 1 if free_i.size else 0
+            out.collision_intensity_trajs = 1 - free_i.size / B
+        else:                                               # shapes of MPD.__call__ (_fill_output)
+            out.trajs_final_coll = trajs_final.index_select(0, coll_idxs.view(-1)) if coll_i.size else None
+            out.trajs_final_free = trajs_final.index_select(0, free_idxs.view(-1)) if free_i.size else None
+            out.success_free_trajs = bool(free_i.size)
+        out.fraction_free_trajs = free_i.size / B if ens else (0.0 if not free_i.size else free_i.size / B)
+        if free_i.size:
+            sel = free_idxs.view(-1) + k * B
+            out.cost_smoothness = r.smoothness.index_select(0, sel)
+            out.cost_path_length = r.path_length.index_select(0, sel)
+            best = int(np.searchsorted(free_i, ib))
+            out.idx_best_traj = free_idxs[best]
+            out.traj_final_free_best = out.trajs_final_free[best]
+            if ens:
+                out.cost_all = out.cost_smoothness + out.cost_path_length
+                out.cost_best_free_traj = out.cost_all[best]
+            else:
+                out.cost_all = out.cost_path_length + out.cost_smoothness
+                out.idx_best_free_traj = best
+                out.cost_best_free_traj = float(np.float32(pl_all[k * B + ib]) + np.float32(sm_all[k * B + ib]))
+            out.variance_waypoint_trajs_final_free = post.compute_variance_waypoints(out.trajs_final_free)
+        out.constraints_l = call[3] if len(call) > 3 else None
+        planner.recent_call_data = out
+        outs.append(out)
+    return outs
+
+
+def _check_start_goal(planner, call):
+    if not torch.allclose(torch.as_tensor(call[1]).cpu().float(), planner.start_state_pos):
+        raise ValueError("The start state is different from the one stored in the planner.")
+    if not torch.allclose(torch.as_tensor(call[2]).cpu().float(), planner.goal_state_pos):
+        raise ValueError("The goal state is different from the one stored in the planner.")
+
+
+def _run_mpd_group(calls, seeds):
+    planners = [c[0] for c in calls]
+    p0, R, B = planners[0], len(calls), planners[0].num_samples
+    dev = p0.device
+    for p, c in zip(planners, calls):
+        _check_start_goal(p, c)
+    cg = _combined_guide([p.guide for p in planners])
+    per_robot = []
+    for p, c in zip(planners, calls):
+        cl = p._cost_constraints(c[3] if len(c) > 3 else None)
+        per_robot.append([(cc, p.weight_grad_cost_soft_constraints if cc.is_soft else p.weight_grad_cost_constraints) for cc in cl])
+    _load_constraints(cg, per_robot)
+    hard = {row: torch.stack([p.hard_conds[row] for p in planners]) for row in p0.hard_conds}
+    with _Timer() as timer:
+        try:
+            chain = p0.model.run_inference(
+                None, hard, n_samples=B, n_robots=R, horizon=HORIZON, return_chain=True, sample_fn=ddpm_sample_fn,
+                guide=None if p0.run_prior_only else cg, n_guide_steps=p0.n_guide_steps, t_start_guide=p0.t_start_guide,
+                noise_std_extra_schedule_fn=p0.sample_fn_kwargs["noise_std_extra_schedule_fn"],
+                n_diffusion_steps_without_noise=p0.n_diffusion_steps_without_noise, device=dev, robot_seeds=seeds)
+        finally:
+            cg.reset_extra_costs()
+    trajs_iters = p0.dataset.unnormalize_trajectories(chain)                     # [T+2, R*B, H, D]
+    tg = cg if all(p._task_guide is p.guide for p in planners) else _combined_guide([p._task_guide for p in planners])
+    r = post.postprocess_batch(tg, trajs_iters[-1].contiguous(), n_robots=R, smooth=True)
+    idx, _ = post.select_best(r.free_mask, R, cost_a=r.path_length, cost_b=r.smoothness)
+    return _split_outputs(calls, planners, r, idx, r.free_mask, trajs_iters, B, timer.elapsed)
+
+
+def _run_ensemble_group(calls, seeds):
+    planners = [c[0] for c in calls]
+    p0, R, B = planners[0], len(calls), planners[0].num_samples
+    dev, keys = p0.device, list(p0.models.keys())
+    for p, c in zip(planners, calls):
+        _check_start_goal(p, c)
+    cgs = {j: _combined_guide([p.guides[j] for p in planners]) for j in keys}
+    per_tile = {j: [[] for _ in range(R)] for j in keys}
+    for k, (p, c) in enumerate(zip(planners, calls)):
+        cl = [CostConstraint(p.robot, HORIZON, q_l=cc.get_q_l(), traj_range_l=cc.get_t_range_l(), radius_l=cc.radius_l,
+                             is_soft=cc.is_soft) for cc in ((c[3] if len(c) > 3 else None) or [])]
+        for task_id, tile_cl in p.split_cost_constraints_to_tasks(cl).items():
+            for cc in tile_cl:
+                cc.traj_ranges = cc.traj_ranges - task_id * HORIZON                       # mpd_ensemble.py:517
+                cc.qs = cc.qs - p.transforms[task_id].numpy()                             # :518
+                per_tile[task_id][k].append((cc, p.weight_grad_cost_constraints if not cc.is_soft else p.weight_grad_cost_soft_constraints))
+    for j in keys:
+        _load_constraints(cgs[j], per_tile[j])
+    hard = {j: {row: torch.stack([p.hard_conds[j][row] for p in planners]) for row in p0.hard_conds.get(j, {})} for j in keys}
+    skw = {j: dict(p0.sample_kwargs[j], guide=None if p0.run_prior_only else cgs[j]) for j in keys}
+    with _Timer() as timer:
+        try:
+            _, chains = p0.model.p_sample_loop(
+                (R * B, HORIZON, p0.models[keys[0]].state_dim), hard, dict(p0.cross_conds), n_diffusion_steps=p0.model.n_diffusion_steps,
+                return_chain=True, sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=p0.n_diffusion_steps_without_noise,
+                device=dev, n_robots=R, robot_seeds=seeds, robot_transforms=[p.transforms for p in planners], sample_kwargs=skw)
+        finally:
+            for j in keys:
+                cgs[j].reset_extra_costs()
+    # un-normalise per tile, tile-frame final rows to the tile's own collision check, global frame, concatenate (as MPDEnsemble.__call__)
+    parts, free_mask = [], None
+    for j in keys:
+        tr = p0.datasets[j].unnormalize_trajectories(chains[j].transpose(0, 1)).clone()       # [T+2, R*B, H, D]
+        tgs = _combined_guide([p.task.tasks[j].guide for p in planners])
+        fm = post.postprocess_batch(tgs, tr[-1].contiguous(), n_robots=R, smooth=False).free_mask
+        free_mask = fm if free_mask is None else free_mask & fm
+        offs = torch.stack([p.transforms[j] for p in planners]).to(tr.device).repeat_interleave(B, 0)     # [R*B, 2]
+        tr[..., :2] += offs[None, :, None, :]
+        parts.append(tr)
+    trajs_iters = torch.cat(parts, dim=-2)                                                      # [T+2, R*B, K*64, D]
+    r = post.postprocess_batch(cgs[keys[0]], trajs_iters[-1].contiguous(), n_robots=R, all_free=True, smooth=True)
+    idx, _ = post.select_best(free_mask, R, cost_a=r.path_length, cost_b=r.smoothness)
+    return _split_outputs(calls, planners, r, idx, free_mask, trajs_iters, B, timer.elapsed, ensemble_tasks=True)
+
+
+def plan_batched(calls, seeds=None):
+    """Independent planner calls as ONE launch sequence: the calls that share a device model, schedule and sampler settings (_batch_key)
+    are packed robot-major into one [R * n_samples, H, D] batch -- each with its own start / goal, map index, constraint groups, tile
+    transforms and Philox stream -- and sampled, post-processed and transferred together.  This is the reference's real call
+    granularity put on the chip the way it fits: CBS / PrioritizedPlanning call one planner per agent with 64 samples
+    (inference_multi_agent.py:225-237, cbs.py:316-324, mmd_params.py:33), and a UNet launch of 64 trajectories costs what one of 256
+    does.  Same signature and seeds as plan_concurrently, and BITWISE the same results as the calls made one after the other with those
+    seeds (mmd_sampler_desc.robot_seeds_dev: one Philox stream per robot).  Calls that cannot be packed (a re-plan from an
+    experience, `diffusion_prior_then_guide`, extra objects) run on their own, in list order, with their seed."""
+    calls = [tuple(c) for c in calls]
+    if len({id(c[0]) for c in calls}) != len(calls):
+        raise ValueError("plan_batched: a planner appears twice (a planner call is not re-entrant)")
+    if seeds is None:
+        seeds = _default_seeds(calls)
+    if len(seeds) != len(calls):
+        raise ValueError("plan_batched: one seed per call")
+    groups, order = {}, []
+    for j, c in enumerate(calls):
+        key = _batch_key(c)
+        key = ("single", j) if key is None else key
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(j)
+    outs = [None] * len(calls)
+    for key in order:
+        js = groups[key]
+        if key[0] == "single" or len(js) == 1:
+            for j in js:
+                outs[j] = calls[j][0](*calls[j][1:], seed=int(seeds[j]))
+            continue
+        run = _run_mpd_group if key[0] == "MPD" else _run_ensemble_group
+        for j, out in zip(js, run([calls[j] for j in js], [int(seeds[j]) for j in js])):
+            outs[j] = out
+    return outs

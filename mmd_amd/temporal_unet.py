@@ -40,7 +40,8 @@ class _DeviceModel:
 
 class TemporalUnet:
     def __init__(self, n_support_points=64, state_dim=4, unet_input_dim=32, dim_mults=(1, 2, 4), time_emb_dim=32,
-                 self_attention=False, conditioning_type=None, max_timesteps=1000, layered=None, **kwargs):
+                 self_attention=False, conditioning_type=None, max_timesteps=1000, layered=False, layered_valu=False,
+                 rtb_fused=-1, mconv_max_cs=0, two_per_workgroup_max=0, **kwargs):
         if self_attention or conditioning_type not in (None, "None"):
             raise NotImplementedError("only the configuration MPD/MPDEnsemble instantiate is supported "
                                       "(no self-attention, no context conditioning)")
@@ -57,9 +58,11 @@ class TemporalUnet:
         self.spec = unet_param_spec(state_dim, unet_input_dim, self.dim_mults)
         self.max_timesteps = max_timesteps
         # layered=True: the layer-by-layer kernels also for the fused kernel's own configuration (the A/B of the two implementations,
-        # tests/test_gpu_dim_mults.py).  Fixed for the life of the object -- None takes MMD_AMD_UNET_LAYERED as it is NOW, later
-        # changes of the environment do not switch an existing TemporalUnet's path
-        self.layered = (os.environ.get("MMD_AMD_UNET_LAYERED", "") == "1") if layered is None else bool(layered)
+        # tests/test_gpu_dim_mults.py).  These choices are fixed for the life of the object and travel to mmd_unet_create as its
+        # mmd_unet_options argument (include/mmd_amd.h) -- nothing is read from, or written to, the process environment.
+        self.layered = bool(layered)
+        self.options = (int(bool(layered)) * _lib.UNET_LAYERED | int(bool(layered_valu)) * _lib.UNET_LAYERED_VALU, int(rtb_fused),
+                        int(mconv_max_cs), int(two_per_workgroup_max))
         self._sd = None
         self._sd_hash = None
         self._models = {}               # (n_timesteps, device index) -> _DeviceModel (shared through _DEVICE_MODELS)
@@ -102,7 +105,7 @@ class TemporalUnet:
         if self._sd is None:
             raise RuntimeError("TemporalUnet has no parameters: call load_state_dict first")
         dev = self._device_index(device)
-        layered = self.layered
+        layered = self.options
         if n_timesteps is not None:
             T = int(n_timesteps)
         else:
@@ -125,18 +128,10 @@ class TemporalUnet:
             ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in self._sd.values()])
             numels = (C.c_int64 * n)(*[v.size for v in self._sd.values()])
             h = C.c_void_p()
-            # (mmd_unet_create reads MMD_AMD_UNET_LAYERED: set to this object's choice for the call)
-            saved = os.environ.get("MMD_AMD_UNET_LAYERED")
-            os.environ["MMD_AMD_UNET_LAYERED"] = "1" if layered else "0"
-            try:
-                with torch.cuda.device(dev):
-                    _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), T, ptrs, numels, n,
-                                                   _lib.current_stream_ptr()))
-            finally:
-                if saved is None:
-                    del os.environ["MMD_AMD_UNET_LAYERED"]
-                else:
-                    os.environ["MMD_AMD_UNET_LAYERED"] = saved
+            opt = _lib.UnetOptions(*layered)
+            with torch.cuda.device(dev):
+                _lib.check(lib.mmd_unet_create(C.byref(h), self.unet_input_dim, len(self.dim_mults), T, ptrs, numels, n,
+                                               C.byref(opt), _lib.current_stream_ptr()))
             N_DEVICE_MODELS_CREATED += 1
             dm = _DeviceModel(h)
             _DEVICE_MODELS[key] = dm

@@ -19,9 +19,9 @@ NETS = (("d32_1248", 32, (1, 2, 4, 8)), ("d16_12", 16, (1, 2)), ("d8_1", 8, (1,)
 TOL_STEP = 1e-3
 
 
-def _unet(uid, dm, seed=0, layered=None):
+def _unet(uid, dm, seed=0, layered=False, **options):
     from mmd_amd.temporal_unet import TemporalUnet
-    u = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=uid, dim_mults=dm, layered=layered)
+    u = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=uid, dim_mults=dm, layered=layered, **options)
     u.load_state_dict(synth.synth_unet_state_dict(seed, unet_input_dim=uid, dim_mults=dm))
     return u
 
@@ -43,19 +43,17 @@ def test_layered_unet_forward_golden(tag, uid, dm):
         assert err < 2e-5, (tag, int(t), err)
 
 
-def test_layered_path_equals_fused_kernel_on_option0(monkeypatch):
+def test_layered_path_equals_fused_kernel_on_option0():
     """The two implementations share no device code: the fp32 layer-by-layer kernels forced onto the fused kernel's own
-    configuration (TemporalUnet(layered=True); MMD_AMD_UNET_LAYERED=1 is the default for objects built while it is set) must give the fused kernel's output within its
+    configuration (TemporalUnet(layered=True) -> mmd_unet_options.flags & MMD_UNET_LAYERED) must give the fused kernel's output within its
     documented distance from the fp32 reference (2.4e-6 rel-L2, test_unet_forward_accuracy_against_fp64), at a batch that is not
     a multiple of the fused kernel's workgroup size."""
     n = 37
     x = (torch.from_numpy(synth.synth_noise(901, (n, H, D))) * 0.7).cuda()
     fused = _unet(32, (1, 2, 4), layered=False)
-    layered = _unet(32, (1, 2, 4), layered=True)              # (fixed per object; the environment switch is the default only)
+    layered = _unet(32, (1, 2, 4), layered=True)              # (a creation-time option of the device model, fixed per object)
     layered.handle(25, "cuda")
-    monkeypatch.setenv("MMD_AMD_UNET_LAYERED", "1")           # ... and toggling it later does not move an existing object
     fused.handle(25, "cuda")
-    monkeypatch.delenv("MMD_AMD_UNET_LAYERED")
     assert layered.handle(device="cuda").value != fused.handle(device="cuda").value
     for t in (0, 11, 24):
         err = rel_l2(layered(x, t).cpu(), fused(x, t).cpu())
@@ -262,22 +260,26 @@ def test_layered_unet_widest_network_widest_slices_vs_oracle():
     assert torch.equal(unet(x[1000:1006].contiguous().cuda(), 11), big[1000:1006])
 
 
-def test_one_launch_residual_blocks_equal_the_two_launch_form(monkeypatch):
+def test_one_launch_residual_blocks_equal_the_two_launch_form():
     """mconv_kernel KIND 4 runs a ResidualTemporalBlock of <= 64 channels as ONE launch (the hidden tensor becomes the second conv's LDS slab
     instead of a tensor in memory); the arithmetic is that of the two Conv1dBlock launches, so eps must be bitwise the same.
-    MMD_AMD_RTB_FUSED is read when the device model is created: two models of the same weights with different time-table lengths."""
+    mmd_unet_options.rtb_fused is a creation-time option of the device model (TemporalUnet(rtb_fused=...)); the vector-ALU form of
+    every layer (MMD_UNET_LAYERED_VALU) is held against the matrix-pipe form here too, within the fp32 reference's own distance."""
     x = (torch.from_numpy(synth.synth_noise(907, (1300, H, D))) * 0.7).cuda()
     for dm in ((1, 2, 4, 8), (1, 2, 4)):
         outs = []
-        for fused, T in (("0", 25), ("64", 26), ("128", 27)):
-            monkeypatch.setenv("MMD_AMD_RTB_FUSED", fused)
-            u = _unet(32, dm, layered=True)
+        for fused, T in ((0, 25), (64, 26), (128, 27)):
+            u = _unet(32, dm, layered=True, rtb_fused=fused)
             u.handle(T, "cuda")
             outs.append(u(x, 7))
             outs.append(u(x[:5].contiguous(), 7))
         assert torch.isfinite(outs[0]).all()
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4])
         assert torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[5]) and torch.equal(outs[1], outs[0][:5])
+        valu = _unet(32, dm, layered=True, layered_valu=True)
+        narrow = _unet(32, dm, layered=True, mconv_max_cs=32)
+        assert rel_l2(valu(x, 7).cpu(), outs[0].cpu()) < 6e-6
+        assert rel_l2(narrow(x, 7).cpu(), outs[0].cpu()) < 6e-6
 
 
 def test_option1_sampling_loop_captures_into_a_hip_graph():

@@ -838,52 +838,43 @@ def test_calls_follow_the_tensors_device_not_torchs_current_device():
     assert y1.device.index == 1 and torch.equal(y1.cpu(), ref)
 
 
-_PERSIST_SCRIPT = r'''
-import os, sys
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-import torch
-import cases, gpu_common
-from mmd_amd import synth
-from mmd_amd.diffusion_model import ddpm_sample_fn
-H, D, T = 64, 4, 100
-model = gpu_common.hip_model(T)
-starts, goals = synth.start_goal_circle(6, 0.8)
-paths = synth.straight_line_paths(starts, goals, H)
-out = {}
-for tag, R, B in (("two_per_workgroup", 2, 8), ("four_per_workgroup", 3, 200)):
-    guide = gpu_common.hip_guide("EnvHighways2D", [[cases.soft_group(paths, r)] for r in range(R)], n_robots=R)
-    hc = {0: torch.stack([cases.hard_conds_for(starts[r], goals[r])[0] for r in range(R)]),
-          H - 1: torch.stack([cases.hard_conds_for(starts[r], goals[r])[H - 1] for r in range(R)])}
-    # guided from i = 49 on (50 leading unguided steps), in-kernel Philox noise, the whole chain
-    out[tag] = model.run_inference(None, hc, n_samples=B, n_robots=R, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn, guide=guide,
-                                   n_guide_steps=20, t_start_guide=50, noise_std_extra_schedule_fn=lambda t: 0.5,
-                                   n_diffusion_steps_without_noise=1, seed=91).cpu()
-    # prior only with injected noise: 101 unguided steps = a run of 64 + a run of 37
-    xT = torch.from_numpy(synth.synth_noise(130, (R * B, H, D)))
-    st = torch.from_numpy(synth.synth_noise(131, (T + 1, R * B, H, D))) if R * B <= 64 else None
-    out[tag + "_prior"] = model.run_inference(None, hc, n_samples=B, n_robots=R, horizon=H, return_chain=st is not None, sample_fn=ddpm_sample_fn,
-                                              guide=None, noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=1,
-                                              warm_start_path_b=xT.cuda(), step_noise=None if st is None else st.cuda(), seed=92).cpu()
-torch.save(out, sys.argv[2])
-print("PERSIST_SCRIPT_OK", os.environ.get("MMD_AMD_PERSIST"))
-'''
-
-
-def test_persistent_run_equals_launch_per_step(tmp_path):
-    """MMD_AMD_PERSIST=1 (opt-in, sampled when the library loads: hence two subprocesses): the leading run of unguided steps in ONE
-    launch per <= 64 steps (unet_persist_kernel<2> / <4>: a workgroup iterates the steps of its own trajectories) gives the
-    launch-per-step results bit for bit -- every chain row of a T = 100 guided call (50 leading unguided steps) and a prior-only
-    call (101 steps: two runs), Philox and injected noise."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def test_persistent_run_equals_launch_per_step():
+    """mmd_sampler_desc.flags & MMD_SAMPLER_PERSIST (opt-in; a field of the call's descriptor, so both modes run in this process): the
+    leading run of unguided steps in ONE launch per <= 64 steps (unet_persist_kernel<2> / <4>: a workgroup iterates the steps of its
+    own trajectories) gives the launch-per-step results bit for bit -- every chain row of a T = 100 guided call (50 leading unguided
+    steps) and a prior-only call (101 steps: two runs), Philox and injected noise.  MMD_SAMPLER_NO_FUSED_STEP (unguided steps as
+    separate step-kernel launches) likewise."""
+    import gpu_common
+    from mmd_amd import _lib
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    T = 100
+    model = gpu_common.hip_model(T)
+    starts, goals = synth.start_goal_circle(6, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
     res = {}
-    for flag in ("0", "1"):
-        path = str(tmp_path / f"persist{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root, path], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, MMD_AMD_PERSIST=flag))
-        assert r.returncode == 0 and "PERSIST_SCRIPT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
-        res[flag] = torch.load(path)
-    assert set(res["0"]) == set(res["1"]) and len(res["0"]) == 4
-    for k in res["0"]:
-        assert torch.isfinite(res["0"][k]).all() and torch.equal(res["0"][k], res["1"][k]), k
+    try:
+        for flags in (0, _lib.SAMPLER_PERSIST, _lib.SAMPLER_NO_FUSED_STEP):
+            model.sampler_flags = flags
+            out = {}
+            for tag, R, B in (("two_per_workgroup", 2, 8), ("four_per_workgroup", 3, 200)):
+                guide = gpu_common.hip_guide("EnvHighways2D", [[cases.soft_group(paths, r)] for r in range(R)], n_robots=R)
+                hc = {0: torch.stack([cases.hard_conds_for(starts[r], goals[r])[0] for r in range(R)]),
+                      H - 1: torch.stack([cases.hard_conds_for(starts[r], goals[r])[H - 1] for r in range(R)])}
+                # guided from i = 49 on (50 leading unguided steps), in-kernel Philox noise, the whole chain
+                out[tag] = model.run_inference(None, hc, n_samples=B, n_robots=R, horizon=H, return_chain=True, sample_fn=ddpm_sample_fn,
+                                               guide=guide, n_guide_steps=20, t_start_guide=50, noise_std_extra_schedule_fn=lambda t: 0.5,
+                                               n_diffusion_steps_without_noise=1, seed=91).cpu()
+                # prior only with injected noise: 101 unguided steps = a run of 64 + a run of 37
+                xT = torch.from_numpy(synth.synth_noise(130, (R * B, H, D)))
+                st = torch.from_numpy(synth.synth_noise(131, (T + 1, R * B, H, D))) if R * B <= 64 else None
+                out[tag + "_prior"] = model.run_inference(None, hc, n_samples=B, n_robots=R, horizon=H, return_chain=st is not None,
+                                                          sample_fn=ddpm_sample_fn, guide=None, noise_std_extra_schedule_fn=lambda t: 0.5,
+                                                          n_diffusion_steps_without_noise=1, warm_start_path_b=xT.cuda(),
+                                                          step_noise=None if st is None else st.cuda(), seed=92).cpu()
+            res[flags] = out
+    finally:
+        model.sampler_flags = 0
+    assert len(res[0]) == 4
+    for flags in (_lib.SAMPLER_PERSIST, _lib.SAMPLER_NO_FUSED_STEP):
+        for k in res[0]:
+            assert torch.isfinite(res[0][k]).all() and torch.equal(res[0][k], res[flags][k]), (flags, k)
