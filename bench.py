@@ -174,14 +174,16 @@ def parse():
                     help="headline = BASELINE.json's metric (32-robot Empty map); config2..config5 = BASELINE.json's configs[1..4]")
     ap.add_argument("--robots-per-gpu", type=int, default=0, help="override (0 = robots/N for strong, all robots per GPU for weak)")
     ap.add_argument("--sequential-planners", action="store_true",
-                    help="config4: the planner calls of a round one after the other (the reference's loop) instead of concurrently")
+                    help="config4: the planner calls of a round one after the other (the reference's loop) instead of batched")
+    ap.add_argument("--concurrent-planners", action="store_true",
+                    help="config4: the planner calls of a round on one host thread + stream each (plan_concurrently) instead of batched")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the dominant kernel that fill roofline.traffic")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-scaling", action="store_true", help="N>1: time only the headline scaling mode")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit: no GPU touched")
     ap.add_argument("--no-power-probe", action="store_true",
                     help="skip the 1.5 s of whole-batch launches timed with the clock / power sampled (outside the timed region; "
@@ -232,21 +234,30 @@ def cpu_baseline(T, B, workload, budget_s):
     sweep = [t for t in (8, 16, 32, 64, 128) if t <= n_cpus] or [n_cpus]
     n_guided, n_unguided = tsg + 1, T - tsg                          # i = tsg-1 ... -1 guided; the rest unguided
     results, t_start = [], time.perf_counter()
-    for nt in sweep:
-        if results and time.perf_counter() - t_start > 0.6 * budget_s:
-            break
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(n_cpus))
+
+    def pin(nt):
+        """the process (and the torch pool it starts) on the first nt logical CPUs it may use; returns that list"""
+        cpus = allowed[:nt]
+        if hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, cpus)
         torch.set_num_threads(nt)
+        return cpus
+    for nt in sweep:
+        if results and time.perf_counter() - t_start > 0.4 * budget_s:
+            break
+        pin(nt)
         timed(T - 1, None)                                           # warm-up (thread pool, allocator)
         t_u = min(timed(T - 1 - k, None) for k in range(2))
         t_g = [timed(tsg - 1 - k, guide) for k in range(2)]
         est = n_guided * float(np.mean(t_g)) + n_unguided * t_u
         results.append({"threads": nt, "guided_step_s": float(np.mean(t_g)), "unguided_step_s": t_u,
                         "est_seconds_per_robot_call": est, "trajectories_per_s": B / est})
-        if B / est < 0.7 * max(r["trajectories_per_s"] for r in results):
+        if B / est < max(r["trajectories_per_s"] for r in results):      # past the best thread count: stop climbing
             break
     best = max(results, key=lambda r: r["trajectories_per_s"])
     # the longer sample at the best thread count: guided / unguided steps spread over their halves of the schedule
-    torch.set_num_threads(best["threads"])
+    pinned = pin(best["threads"])
     tg, tu = [], []
     n_pairs = 24                                                      # (as many of them as the budget allows: less to extrapolate)
     gi = list(np.linspace(tsg - 1, 0, n_pairs).astype(int))
@@ -254,7 +265,8 @@ def cpu_baseline(T, B, workload, budget_s):
     order = [int(j) for j in np.argsort([(j * 7) % n_pairs for j in range(n_pairs)])]   # spread over the schedule whatever the count
     gi, ui = [gi[j] for j in order], [ui[j] for j in order]
     k = 0
-    while time.perf_counter() - t_start < budget_s and k < n_pairs:
+    t_sample = time.perf_counter()                                    # (the sample has 60 % of the budget to itself, at least 3 pairs)
+    while (time.perf_counter() - t_sample < 0.6 * budget_s or k < 3) and k < n_pairs:
         tg.append(timed(int(gi[k]), guide))
         tu.append(timed(int(ui[k]), None))
         k += 1
@@ -264,8 +276,8 @@ def cpu_baseline(T, B, workload, budget_s):
         est = best["est_seconds_per_robot_call"]
     return {"value": B / est, "unit": "trajectories/s", "cores": best["threads"], "kind": "port",
             "cpu_model": cpu_model_name(), "logical_cpus": n_cpus,
-            "running_beside": "the GPU power probe (a spinning launch loop + a 50 Hz sysfs sampler thread in the parent process) -- "
-                              "a few host threads of the box's cores; ADVICE r4",
+            "pinned_cpus": f"{pinned[0]}-{pinned[-1]}" if pinned == list(range(pinned[0], pinned[-1] + 1)) else pinned,
+            "host_state": "the GPU process is idle (blocked on this subprocess): every GPU measurement of the run is finished before it starts",
             "sample": f"1 of {n_robots} robots of the {workload} instance (B={B}, {sum(g.q.shape[0] for g in groups)} soft-constraint points"
                       f"{', x 2 tile models per step' if tiles == 2 else ''}): {len(tg)} guided + {len(tu)} "
                       f"unguided DDPM steps at {best['threads']} threads (the best of a thread sweep that timed 2 + 2 steps per "
@@ -433,8 +445,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
         "pipe_busy_in_union": busy_s * len(dur) / union_s if dur else None,
     }
     # outside the timed region: the same kernel as ONE launch of all local trajectories, back to back on one stream, with the
-    # shader clock / socket power / throttler residencies sampled (and the CPU baseline running beside it in its own process:
-    # it needs the host cores only, and the GPU stays busy for whoever watches it)
+    # shader clock / socket power / throttler residencies sampled
     xs = torch.randn(n_traj_local, H, 4, device=dev)
     for _ in range(3):
         unet(xs, 50)
@@ -448,7 +459,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     solo_s, solo_n = e0.elapsed_time(e1) / 20 * 1e-3, 20
     sustained, cpu_result = None, None
     if rank == 0 and not rehearsal and not args.no_power_probe:
-        job = cpu_job() if cpu_job else None               # subprocess handle (or None)
+        job = None                                         # (the CPU baseline runs AFTER every GPU measurement, the host idle: VERDICT r5)
         throttle0 = throttle_snapshot()
         watch = PowerSampler()
         watch.start()
@@ -475,10 +486,6 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
                 sustained["throttle_active_at_end"] = {k: v for k, v in throttle1.items() if k.startswith("active_")}
                 sustained["power_cap_info"] = throttle1.get("power_cap")
         solo_s, solo_n = e0.elapsed_time(e1) / reps * 1e-3, reps
-        if job is not None:
-            cpu_result = cpu_job_result(job)
-    elif cpu_job:
-        cpu_result = cpu_job_result(cpu_job())
     pmc_ref = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
@@ -499,36 +506,33 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     elif pmc_ref and pmc_ref.get("UNET", {}).get("FETCH_SIZE_KiB") and pmc_ref["UNET"].get("trajectories_per_launch") == n_launch:
         traffic = (2.0 * pmc_ref["UNET"]["FETCH_SIZE_KiB"] + pmc_ref["UNET"]["WRITE_SIZE_KiB"]) * 1024.0
         traffic_src = "NOT this run (the live passes failed: see pmc_log): the last committed passes, profiles/pmc_latest.json"
-    roofline = {
-        "bound": "mfma",
-        "kernel": "unet_kernel<4>: whole TemporalUnet forward for 4 trajectories per workgroup (launches of <= 512 trajectories: unet_kernel<2>, two per workgroup; 12 ResidualTemporalBlocks, 2 down / 2 up convs, final block; every conv a direct convolution as an fp16 two-piece split of fp32 (f16x2, 3 MFMAs per product, fp32 accumulate) on the fp16 matrix pipe; the unguided DDPM steps ride in its tail; GroupNorm + Mish + time bias + residuals fused, activations in LDS/registers)",
-        "achieved": frac * PEAK_F16_MFMA_TFLOPS, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": frac,
-        "frac_definition": "fp16 MFMA FLOPs the kernel issues per planning round (3 per fp32 GEMM FLOP of an f16x2 conv x "
-                           "(T + 1) forwards x local trajectories) / 2516.6 TFLOP/s = MFMA issue time per round at the spec "
-                           "clock, / ms_per_step of the timed region (pass 1, nothing attached): the matrix pipe's busy "
-                           "fraction over the WHOLE round, step kernels and launch gaps included; achieved = frac x peak",
-        "mfma_issue_ms_per_round": issue_ms_round, "ms_per_step": ms_per_step, "unet_launches_per_round": launches_round,
-        "mfma_issue_ms_per_launch": busy_s * 1e3, "trajectories_per_launch": n_launch, "stream_chunks": chunks,
-        "useful_frac_of_f16_pipe": flops_traj * n_traj_local * n_fwd / (PEAK_F16_MFMA_TFLOPS * 1e12) / (ms_per_step * 1e-3),
+    # ---- the roofline object (SURVEY 8d / VERDICT r5 #5).  frac = ALGORITHMIC FLOPs / time / peak: the direct-convolution fp32 FLOPs of
+    # the (T + 1) forwards of a round over the round's wall time, against the dense fp16 MFMA peak (the pipe the kernel runs on).
+    # pipe_occupancy is a different question -- how busy the matrix pipe is, counting the THREE fp16 MFMAs the f16x2 split issues per
+    # fp32 product -- and is reported beside it with the hardware counter of the same run.
+    algo_tflops_round = flops_traj * n_traj_local * n_fwd / (ms_per_step * 1e-3) / 1e12
+    busy_pmc = None
+    if u.get("SQ_VALU_MFMA_BUSY_CYCLES") and u.get("GRBM_GUI_ACTIVE"):
+        # per-SIMD MFMA-busy cycles / the launch's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs)
+        busy_pmc = u["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * u["GRBM_GUI_ACTIVE"] / 8.0)
+    detail = {
+        "frac_definition": "algorithmic FLOPs (direct convolution, fp32: mmd_unet_flops_per_trajectory x (T + 1) forwards x local "
+                           "trajectories) per round / ms_per_step of the timed region (pass 1, nothing attached) / 2516.6 TFLOP/s",
+        "pipe_occupancy_definition": "issue_frac = fp16 MFMA FLOPs ISSUED per round (3 per fp32 GEMM FLOP of an f16x2 conv, padding "
+                                     "included) / 2516.6 TFLOP/s / ms_per_step: the matrix pipe's busy fraction over the whole round at "
+                                     "the spec clock; mfma_busy_pmc = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of "
+                                     "this run's PMC pass over the kernel alone at the sampler's launch size",
+        "mfma_issue_ms_per_round": issue_ms_round, "unet_launches_per_round": launches_round, "mfma_issue_ms_per_launch": busy_s * 1e3,
         "flops_per_trajectory_forward": {"algorithmic_direct_conv_fp32": flops_traj, "fp32_gemm_issued": mfma_traj,
                                          "fp16_mfma_issued": 3.0 * h_traj},
-        "traffic": traffic,
         "traffic_unit": "bytes per launch of the dominant kernel (HBM / fabric side of the L2s)",
         "traffic_definition": "(2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE tallies the 128-byte requests of wide coalesced "
                               "reads at 64 bytes (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is taken as reported",
-        "traffic_source": traffic_src, "pmc_log": pmc_log,
-        "algorithmic_bytes_per_launch": algo_bytes,
         "algorithmic_bytes_definition": f"{n_launch} trajectories x (1 KiB in + 1 KiB out) + the packed weight / parameter block once "
                                         f"({weight_bytes / 1e6:.2f} MB: two fp16 pieces per weight, MFMA fragment order)",
-        "wasted_ratio": None if traffic is None else traffic / algo_bytes,
         "wasted_note": "the weight block is fetched once per XCD L2 (8 x), not once per launch: the kernel keeps every activation on "
                        "chip, so what exceeds the algorithmic bytes is the 8 L2s' copies of the weights",
-        "hbm_gbps_in_round": None if traffic is None else traffic * launches_round / (ms_per_step * 1e-3) / 1e9,
-        "pmc_live": pmc_live, "pmc_reference": pmc_ref,
-        "bracketed_launches": bracketed,
-        "whole_batch_single_launch": {"trajectories": n_traj_local, "launch_ms": solo_s * 1e3,
-                                      "pipe_busy": busy_s * chunks / solo_s,
-                                      "note": f"the same kernel as one launch of all local trajectories, {solo_n} back to back on one stream, outside the timed region"},
+        "pmc_log": pmc_log, "pmc_live": pmc_live, "pmc_reference": pmc_ref, "bracketed_launches": bracketed,
         "power": {
             "pass2_rounds": power_timed, "kernel_back_to_back": sustained,
             "frac_at_measured_clock": None if not (sustained and sustained.get("sclk_mhz")) else
@@ -536,6 +540,25 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
             "note": "shader clock / socket power (amdgpu sysfs) and the firmware's throttler residencies (amdsmi violation "
                     "accumulators: ppt_pwr = package power tracker, *_thrm = thermal) while the whole-batch launch runs back to "
                     "back; frac_at_measured_clock = MFMA issue time at the sampled clock / launch time"},
+    }
+    roofline = {
+        "bound": "mfma",
+        "kernel": "unet_kernel<4> (<= 512 trajectories per launch: unet_kernel<2>): the whole TemporalUnet forward in one launch, every conv "
+                  "a direct convolution as an fp16 two-piece split of fp32 on the fp16 matrix pipe, fp32 accumulate",
+        "achieved": algo_tflops_round, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": algo_tflops_round / PEAK_F16_MFMA_TFLOPS,
+        "frac_is": "algorithmic fp32 direct-conv FLOPs of the round / round time / dense fp16 MFMA peak (not the issued f16x2 FLOPs: those are pipe_occupancy)",
+        "pipe_occupancy": {"issue_frac": frac, "mfma_busy_pmc": busy_pmc, "f16_mfma_per_fp32_product": 3},
+        "kernel_alone": {"trajectories": n_traj_local, "launch_ms": solo_s * 1e3, "launches_timed": solo_n,
+                         "frac": flops_traj * n_traj_local / solo_s / 1e12 / PEAK_F16_MFMA_TFLOPS, "issue_frac": busy_s * chunks / solo_s,
+                         "timed_with": "HIP events around back-to-back launches of the whole local batch, outside the timed region"},
+        "in_loop_launch": {"trajectories": n_launch, "stream_chunks": chunks, "avg_launch_ms": mean_ms(iv_unet),
+                           "measured_concurrency": bracketed["measured_concurrency"],
+                           "timed_with": "HIP event pairs on the launching stream (pass 2: the same rounds with the profiler attached)"},
+        "ms_per_step": ms_per_step, "trajectories_per_launch": n_launch, "stream_chunks": chunks,
+        "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes, "wasted_ratio": None if traffic is None else traffic / algo_bytes,
+        "traffic_source": traffic_src,
+        "hbm_gbps_in_round": None if traffic is None else traffic * launches_round / (ms_per_step * 1e-3) / 1e9,
+        "detail": detail,
     }
     # second kernel: the fused DDPM-step + guide kernel.  It moves 3 KiB per trajectory and step (0.4 % of the HBM roof):
     # its bound is the VALU issue port -- a SIMD issues one wave64 VALU instruction per 4 cycles -- so the fraction reported is
@@ -575,7 +598,8 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     return value, ms_per_step, config, roofline, (guide, cpu_result)
 
 
-PMC_PASSES = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE")
+PMC_PASSES = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE",
+              "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE")
 
 
 def measure_pmc(workload, n_launch, T, timeout_s=150):
@@ -633,17 +657,23 @@ def run_ensemble(args, rank, world, dev, rehearsal=False):
     the reference's own granularity: one planner per agent (inference_multi_agent.py:225-237), B = 64 samples a call, a trajectory =
     2 x 64 support points.  A step = the four planner calls, selection included.  Multi-GPU: robots sharded (no exchange)."""
     from mmd_amd import _lib, synth
-    from mmd_amd.planners import MPDEnsemble, plan_concurrently
+    from mmd_amd.planners import MPDEnsemble, plan_batched, plan_concurrently
     T, B = args.diffusion_steps, args.samples
     W = WORKLOADS["config4"]
     if W["robots"] % world:
         raise SystemExit(f"config4 needs {W['robots']} % gpus == 0")
     RPG = W["robots"] // world
     sd = synth.synth_unet_state_dict(0)
-    tr = {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])}
+    # the reference's multi_tile example (inference_multi_agent.py:418-431): skeletons alternate [[0,0],[0,1]] / [[0,1],[0,0]] (tile
+    # transforms [col * 2, -row * 2], :148-151 -- the relative tile transform is +2 for agents 0 and 2, -2 for agents 1 and 3), starts /
+    # goals given in the frame of the first / last tile and moved to the global frame (:196-199)
+    starts_l = torch.tensor([[0, 0.8], [0, 0.3], [0, -0.3], [0, -0.8]])
+    goals_l = torch.tensor([[0, -0.8], [0, -0.3], [0, 0.3], [0, 0.8]])
     planners = []
     for r in range(rank * RPG, (rank + 1) * RPG):
-        start, goal = torch.tensor([-0.7, -0.6 + 0.4 * r]), torch.tensor([2.7, 0.6 - 0.4 * r])
+        sk = [[0, 0], [0, 1]] if r % 2 == 0 else [[0, 1], [0, 0]]
+        tr = {j: torch.tensor([c * 2.0, -row * 2.0]) for j, (row, c) in enumerate(sk)}
+        start, goal = starts_l[r % 4] + tr[0], goals_l[r % 4] + tr[1]
         planners.append((MPDEnsemble(model_ids=("EnvEmptyNoWait2D-RobotPlanarDisk",) * 2, transforms=tr, planner_alg="mmd",
                                      start_state_pos=start, goal_state_pos=goal, n_samples=B, model_state_dicts=[sd, sd],
                                      model_args=dict(n_diffusion_steps=T), device=dev, seed=18 + r), start, goal))
@@ -654,16 +684,21 @@ def run_ensemble(args, rank, world, dev, rehearsal=False):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    mode = "sequential" if args.sequential_planners else "concurrent" if args.concurrent_planners else "batched"
+
     def rounds(n):
-        # the four planner calls of a round are independent: issued concurrently, one host thread + one stream each
-        # (planners.plan_concurrently; --sequential-planners: one after the other, the reference's loop)
+        # the four planner calls of a round are independent.  batched (default): ONE launch sequence for all of them
+        # (planners.plan_batched: a 64-trajectory UNet launch costs what a 256-trajectory one does); --concurrent-planners: one host
+        # thread + one stream per call; --sequential-planners: one after the other, the reference's loop
         out = None
         for _ in range(n):
-            if args.sequential_planners:
+            if mode == "sequential":
                 for p, start, goal in planners:
                     out = p(start, goal)
-            else:
+            elif mode == "concurrent":
                 out = plan_concurrently(planners)[-1]
+            else:
+                out = plan_batched(planners)[-1]
         return out
     rounds(args.warmup)
     barrier()
@@ -683,22 +718,25 @@ def run_ensemble(args, rank, world, dev, rehearsal=False):
     issued = 3.0 * h_traj * RPG * B * 2 * (T + 1)                    # two tile forwards per composed trajectory and step
     issue_ms = issued / (PEAK_F16_MFMA_TFLOPS * 1e12) * 1e3
     detail = (f"{W['robots']} robots x B={B} samples on the 1x2 EnvEmptyNoWait2D tile grid (tile offset 2.0), one MPDEnsemble planner "
-              f"call per robot and step ({'one after the other' if args.sequential_planners else 'the calls of a step issued concurrently, one stream each'}): "
+              f"call per robot and step ({ {'sequential': 'one after the other', 'concurrent': 'the calls of a step issued concurrently, one stream each', 'batched': 'the calls of a step packed into ONE launch sequence (plan_batched), bitwise the sequential calls'}[mode] }): "
               f"K=2 tile models, T={T}+1 DDPM steps per tile, 20 guide iterations on {ceil(0.5 * T) + 1} guided "
               f"steps, cross-conditioning of the tile boundary after every tile step, post-sampling selection; a trajectory = 128 support points")
     config = {"workload": W["label"], "workload_detail": detail, "workload_key": "config4", "reference_shapes": W["ref"],
               "n_robots": W["robots"], "robots_per_gpu": RPG, "samples_per_robot": B, "horizon": 2 * H, "diffusion_steps": T,
               "trajectories_per_step": n_traj, "parallelism": "single GPU" if world == 1 else f"robots sharded x{world}; no exchange",
-              "planner_calls": "sequential" if args.sequential_planners else "concurrent (plan_concurrently)",
+              "planner_calls": {"sequential": "sequential", "concurrent": "concurrent (plan_concurrently)", "batched": "batched (plan_batched)"}[mode],
               "noise": "in-kernel Philox4x32-10", "weights": "random-init (numpy PCG64 seed 0), the same for both tiles"}
-    roofline = {"bound": "mfma", "kernel": "unet_kernel<2> (64-trajectory launches, one per tile and step)", "peak": PEAK_F16_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": issue_ms / ms, "achieved": issue_ms / ms * PEAK_F16_MFMA_TFLOPS,
-                "frac_definition": "fp16 MFMA FLOPs issued per step (3 per fp32 GEMM FLOP x 2 tiles x (T + 1) forwards x trajectories) / "
-                                   "2516.6 TFLOP/s / ms_per_step: 64-trajectory launches leave 7/8 of the CUs idle, the planner call is "
-                                   "latency bound (profiles/r04c_planner_call.txt)",
-                "mfma_issue_ms_per_round": issue_ms, "ms_per_step": ms, "unet_launches_per_round": RPG * 2 * (T + 1),
-                "trajectories_per_launch": B, "traffic": None,
-                "traffic_note": "PMC passes are wired for the sharded sampler's launches (tools/pmc_kernels.py); not collected for the planner-call workload"}
+    per_launch = B * RPG if mode == "batched" else B
+    algo_tflops = lib.mmd_unet_flops_per_trajectory() * RPG * B * 2 * (T + 1) / (ms * 1e-3) / 1e12   # two tile forwards per trajectory and step
+    roofline = {"bound": "mfma", "kernel": f"unet_kernel<2> ({per_launch}-trajectory launches, one per tile and step)", "peak": PEAK_F16_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "achieved": algo_tflops, "frac": algo_tflops / PEAK_F16_MFMA_TFLOPS,
+                "frac_is": "algorithmic fp32 direct-conv FLOPs of the round (2 tile forwards x (T + 1) steps x trajectories) / round time / dense "
+                           "fp16 MFMA peak; a launch of <= 256 trajectories leaves most CUs idle and costs ~83 us whatever its size: the planner "
+                           "call is latency bound (one workgroup's 25 dependent convs), which is why the calls of a round are packed into one launch sequence",
+                "pipe_occupancy": {"issue_frac": issue_ms / ms, "mfma_busy_pmc": None, "f16_mfma_per_fp32_product": 3},
+                "ms_per_step": ms, "unet_launches_per_round": (1 if mode == "batched" else RPG) * 2 * (T + 1),
+                "trajectories_per_launch": per_launch, "traffic": None,
+                "traffic_source": "PMC passes are wired for the sharded sampler's launches (tools/pmc_kernels.py); not collected for the planner-call workload"}
     return n_traj * args.steps / dt, ms, config, roofline
 
 
@@ -759,16 +797,15 @@ def main():
     W = WORKLOADS[args.workload]
     if W.get("ensemble"):
         value, ms, config, roofline = run_ensemble(args, rank, world, dev, rehearsal)
-        guide, cpu_result = None, (cpu_job_result(cpu_job()) if want_cpu else None)
+        guide = None
     else:
-        value, ms, config, roofline, (guide, cpu_result) = run_mode(args, args.scaling, rank, world, dev, rehearsal, with_roofline=True,
-                                                                    cpu_job=cpu_job if want_cpu else None)
+        value, ms, config, roofline, (guide, _) = run_mode(args, args.scaling, rank, world, dev, rehearsal, with_roofline=True)
     out = {
         "metric": HEADLINE_METRIC if W["label"] is None else f"guided trajectories/sec (H=64, {args.diffusion_steps} denoise steps), {W['label']}",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (f16x2 split on the fp16 MFMA pipe: every fp32 product as 3 fp16 MFMAs, fp32 accumulate)", "data": "synthetic",
         "config": config,
         "roofline": roofline,
         "roofline_step_kernel": guide,
@@ -780,8 +817,26 @@ def main():
         v2, ms2, cfg2, _, _ = run_mode(args, other, rank, world, dev, rehearsal, with_roofline=False)
         out[f"{other}_scaling"] = {"value": v2, "unit": "trajectories/s", "ms_per_step": ms2, "scaling": other, "config": cfg2}
     if want_cpu:
-        out["cpu_baseline"] = cpu_result
+        # the CPU baseline LAST: every GPU measurement above is finished and this process only waits for the subprocess
+        torch.cuda.synchronize()
+        out["cpu_baseline"] = cpu_job_result(cpu_job())
     if rank == 0:
+        # the long-form measurement record (definitions, per-pass PMC logs, bracketed launches, power / clock samples) goes to a side
+        # file; the line keeps the numbers
+        detail = {}
+        for key in ("roofline", "roofline_step_kernel"):
+            if isinstance(out.get(key), dict) and "detail" in out[key]:
+                detail[key] = out[key].pop("detail")
+        if isinstance(out.get("cpu_baseline"), dict) and "thread_sweep" in out["cpu_baseline"]:
+            detail["cpu_baseline_thread_sweep"] = out["cpu_baseline"].pop("thread_sweep")
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            path = os.path.join(ROOT, "gpurun_out", f"bench_detail_{args.workload}_n{world}.json")
+            with open(path, "w") as f:
+                json.dump(detail, f, indent=1)
+            out["detail_file"] = os.path.relpath(path, ROOT)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -350,12 +350,27 @@ int mmd_p_sample_loop_ensemble(const mmd_ensemble_tile* tiles, int n_tiles, cons
       if (int rc = make_step(T.sampler, i, T.guide != nullptr, sd)) return rc;
       sd.seed = T.seed; sd.draw = (unsigned int)k;
       float* eps = eps_of(workspace_dev, T.unet, n);
-      if (int rc = mmd_unet_forward_profiled(T.unet, T.x_dev, i < 0 ? 0 : i, eps, n, workspace_dev,
-                                             mmd_unet_workspace_bytes(T.unet, n), (mmd_profiler_t)T.sampler->profiler, st))
-        return rc;
-      launch_step(g[m], sd, T.x_dev, eps, T.step_noise_dev ? T.step_noise_dev + (size_t)k * traj_floats : nullptr,
-                  T.chain_dev ? T.chain_dev + (size_t)(k + 1) * traj_floats : nullptr, T.hard_dev, 0, n,
-                  samples_per_robot, st);
+      const float* noise_k = T.step_noise_dev ? T.step_noise_dev + (size_t)k * traj_floats : nullptr;
+      float* chain_k = T.chain_dev ? T.chain_dev + (size_t)(k + 1) * traj_floats : nullptr;
+      if (!sd.do_guide && !(T.sampler->flags & MMD_SAMPLER_NO_FUSED_STEP) && unet_fused_step_supported(T.unet)) {
+        // a step without guidance rides in the tail of the UNet launch, as in mmd_p_sample_loop (one launch and one dependent
+        // dispatch less per tile step; bitwise the two-launch form)
+        FusedStep fs{};
+        fs.enabled = 1;
+        fs.a_t = sd.a_t; fs.b_t = sd.b_t; fs.c1 = sd.c1; fs.c2 = sd.c2; fs.sigma = sd.sigma; fs.noise_std_extra = sd.noise_std_extra;
+        fs.do_noise = sd.do_noise; fs.hard_rows = sd.hard_rows; fs.n_hard = sd.n_hard; fs.seed = sd.seed; fs.draw = sd.draw;
+        fs.traj_base = sd.traj_base; fs.robot_seeds = sd.robot_seeds; fs.traj0 = 0; fs.spr = samples_per_robot;
+        fs.x = reinterpret_cast<float4*>(T.x_dev); fs.noise = reinterpret_cast<const float4*>(noise_k);
+        fs.chain = reinterpret_cast<float4*>(chain_k); fs.hard = reinterpret_cast<const float4*>(T.hard_dev);
+        if (int rc = unet_forward_fused(T.unet, T.x_dev, i < 0 ? 0 : i, eps, n, workspace_dev, mmd_unet_workspace_bytes(T.unet, n),
+                                        (mmd_profiler_t)T.sampler->profiler, st, fs))
+          return rc;
+      } else {
+        if (int rc = mmd_unet_forward_profiled(T.unet, T.x_dev, i < 0 ? 0 : i, eps, n, workspace_dev,
+                                               mmd_unet_workspace_bytes(T.unet, n), (mmd_profiler_t)T.sampler->profiler, st))
+          return rc;
+        launch_step(g[m], sd, T.x_dev, eps, noise_k, chain_k, T.hard_dev, 0, n, samples_per_robot, st);
+      }
       cross_all(k + 1, m);
     }
   }
