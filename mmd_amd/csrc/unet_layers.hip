@@ -284,6 +284,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 1 &&
   const int slab_bytes = 2 * (slab_ch / 8) * SROWS * 16, outs_bytes = KIND == 0 || KIND == 4 ? a.cs * OST * 4 : 0;
   float* const red = reinterpret_cast<float*>(smem + (slab_bytes > outs_bytes ? slab_bytes : outs_bytes));
   unsigned* const smax = reinterpret_cast<unsigned*>(red + 64);
+  // (the per-sample maxima, the `red` partials and the slab bookkeeping hold at most 8 samples per item: a sample has >= 8 GEMM rows --
+  // H = 64 over at most MAX_LEVELS = 4 levels, the stride-2 conv never runs at the last level -- which mconv() on the host checks
+  // (`rows >= 8`); a launch that breaks it must not scribble past smax)
+  if (SPW > 8) __builtin_trap();
   if (tid < 24) smax[tid] = 0u;
   // ---- this thread's staging rows of an item: rows tid % 32 + 32 i of the slab -> (sample, position); a padding row, a row past the slab
   // or past the batch reads the first element of the batch and is not used

@@ -125,13 +125,36 @@ class DiffusionsEnsemble:
             return x, {m: chains[m].transpose(0, 1) for m in keys}            # [B, steps+1, H, D] like torch.stack(dim=1)
         return x
 
+    def ddim_sample(self, shape, hard_conds, n_diffusion_steps=None, context=None, return_chain=False, t_start_guide=float("inf"),
+                    guide=None, n_guide_steps=1, **sample_kwargs):
+        """diffusion_ensemble.py:109-221 is a copy of the single model's DDIM loop that reads `self.betas` / `self.model` /
+        `self.alphas_cumprod`, none of which a DiffusionsEnsemble has: in the reference the call raises AttributeError at its first
+        statement (run on the genuine class: tests/test_host_logic.py records what was observed), and
+        joint_conditional_sampling(ddim=True) does not even get that far (below).  There is no behaviour to reproduce but the error;
+        single-model DDIM is GaussianDiffusionModel.ddim_sample (mmd_ddim_sample, golden g11 / g18)."""
+        raise AttributeError("'DiffusionsEnsemble' object has no attribute 'betas'")
+
+    def joint_conditional_sampling(self, hard_conds, cross_conds, n_diffusion_steps=None, batch_size=1, ddim=False,
+                                   warm_start_path_b=None, **sample_kwargs):
+        """diffusion_ensemble.py:223-244.  ddim=True fails in the reference with a TypeError: it passes cross_conds as the third
+        positional argument of ddim_sample, which is n_diffusion_steps, next to the keyword of the same name."""
+        shape = (batch_size, HORIZON, self.models[0].state_dim)
+        if n_diffusion_steps is None:
+            raise ValueError("n_diffusion_steps must be provided.")
+        if ddim:
+            if warm_start_path_b is not None:
+                raise ValueError("warm_start_path_b is not supported for ddim sampling.")
+            raise TypeError("DiffusionsEnsemble.ddim_sample() got multiple values for argument 'n_diffusion_steps'")
+        return self.p_sample_loop(shape, hard_conds, cross_conds, n_diffusion_steps=n_diffusion_steps,
+                                  warm_start_path_b=warm_start_path_b, **sample_kwargs)
+
     @torch.no_grad()
     def run_inference(self, contexts=None, hard_conds=None, cross_conds=None, n_samples=1, return_chain=False,
                       **diffusion_kwargs):
         """diffusion_ensemble.py:223-263: dict model -> [T+2, B, H, D] (return_chain) or [B, H, D]."""
         hard_conds = deepcopy(hard_conds)
-        x, chains = self.p_sample_loop((n_samples, HORIZON, self.models[0].state_dim), hard_conds, deepcopy(cross_conds),
-                                       n_diffusion_steps=self.n_diffusion_steps, return_chain=True, **diffusion_kwargs)
+        x, chains = self.joint_conditional_sampling(hard_conds, deepcopy(cross_conds), n_diffusion_steps=self.n_diffusion_steps,
+                                                    batch_size=n_samples, return_chain=True, **diffusion_kwargs)
         chains = {m: c.transpose(0, 1) for m, c in chains.items()}
         return chains if return_chain else {m: c[-1] for m, c in chains.items()}
 
@@ -142,8 +165,8 @@ class DiffusionsEnsemble:
         hard_conds = deepcopy(hard_conds)
         noised = None if n_noising_steps is None else self.models[0].q_sample(seed_trajectory_b, n_noising_steps,
                                                                               seed=diffusion_kwargs.get("seed"))
-        x, chains = self.p_sample_loop((n_samples, HORIZON, self.models[0].state_dim), hard_conds, deepcopy(cross_conds),
-                                       n_diffusion_steps=n_denoising_steps, return_chain=True,
-                                       warm_start_path_b=noised, **diffusion_kwargs)
+        x, chains = self.joint_conditional_sampling(hard_conds, deepcopy(cross_conds), n_diffusion_steps=n_denoising_steps,
+                                                    batch_size=n_samples, return_chain=True, warm_start_path_b=noised,
+                                                    **diffusion_kwargs)
         chains = {m: c.transpose(0, 1) for m, c in chains.items()}
         return chains if return_chain else {m: c[-1] for m, c in chains.items()}

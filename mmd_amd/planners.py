@@ -617,7 +617,6 @@ def plan_concurrently(calls, seeds=None):
     `seeds`: one Philox seed per call; default: drawn from the global stream counter in list order, i.e. the seeds a sequential loop
     over `calls` would have used for single-model planners -- the results do not depend on how the threads interleave.
     Returns the PlannerOutputs in list order; an exception of any call is re-raised."""
-    from concurrent.futures import ThreadPoolExecutor
     calls = [tuple(c) for c in calls]
     if len({id(c[0]) for c in calls}) != len(calls):
         raise ValueError("plan_concurrently: a planner appears twice (a planner call is not re-entrant)")
@@ -634,15 +633,44 @@ def plan_concurrently(calls, seeds=None):
     def run(j):
         planner, rest = calls[j][0], calls[j][1:]
         torch.cuda.set_device(devs[j])
-        side = torch.cuda.Stream(devs[j])
+        side = _worker_stream(devs[j])
         side.wait_stream(parents[j])
         with torch.cuda.stream(side):
             out = planner(*rest, seed=int(seeds[j]))
-        side.synchronize()
+        # the result tensors were allocated on the side stream and are consumed on the caller's: tell the caching allocator (their
+        # blocks must not be recycled for side-stream work while caller-stream work on them is pending), and order the caller's
+        # stream after the side stream
+        for v in vars(out).values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(parents[j])
+        parents[j].wait_stream(side)
+        side.synchronize()                                  # (PlannerOutput.t_total and the host-side fields are final here)
         return out
-    with ThreadPoolExecutor(max_workers=len(calls)) as pool:
-        return list(pool.map(run, range(len(calls))))
+    return list(_worker_pool(len(calls)).map(run, range(len(calls))))
 
+
+_POOL, _POOL_LOCK, _TLS = None, __import__("threading").Lock(), __import__("threading").local()
+
+
+def _worker_pool(n):
+    """ONE persistent pool of host threads for plan_concurrently (the library keeps per-(thread, device) side streams for its chunked
+    loop: a fresh pool per call would leave a set behind every time), grown when a call needs more workers."""
+    global _POOL
+    from concurrent.futures import ThreadPoolExecutor
+    with _POOL_LOCK:
+        if _POOL is None or _POOL._max_workers < n:
+            if _POOL is not None:
+                _POOL.shutdown(wait=True)
+            _POOL = ThreadPoolExecutor(max_workers=max(n, 4), thread_name_prefix="mmd-planner")
+        return _POOL
+
+
+def _worker_stream(dev):
+    """the calling worker thread's own side stream on `dev` (created once per thread and device)."""
+    streams = _TLS.__dict__.setdefault("streams", {})
+    if dev not in streams:
+        streams[dev] = torch.cuda.Stream(dev)
+    return streams[dev]
 
 
 # ---- R independent planner calls as ONE launch sequence ----------------------------------------------------------------------------

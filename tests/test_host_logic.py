@@ -23,6 +23,12 @@ def test_schedule_tables_bit_exact_vs_reference():
         tb = diffusion_buffers(T)
         for k in SCHEDULE_KEYS:
             assert np.array_equal(tb[k].numpy(), g[f"T{T}.{k}"]), (T, k)
+    for T in (25, 100):                                  # variance_schedule='cosine' (helpers.py:16-27)
+        tb = diffusion_buffers(T, "cosine")
+        for k in SCHEDULE_KEYS:
+            assert np.array_equal(tb[k].numpy(), g[f"cosine.T{T}.{k}"]), ("cosine", T, k)
+    with pytest.raises(NotImplementedError):
+        diffusion_buffers(25, "linear")
 
 
 @pytest.mark.parametrize("env_id", ["EnvEmpty2D", "EnvHighways2D", "EnvConveyor2D", "EnvDropRegion2D"])
@@ -255,3 +261,63 @@ def test_stream_seeds_are_unique_across_host_threads():
         seeds = list(pool.map(lambda _: dm.next_stream_seed(18), range(4000)))
     assert len(set(seeds)) == 4000 and dm._GLOBAL_DRAWS == start + 4000
     assert {s >> 24 for s in seeds} == {18}
+
+
+@pytest.mark.parametrize("direction", ("fwd", "rev"))
+def test_split_cost_constraints_to_tasks_golden_g20(direction):
+    """The 3-tile corner-turning instance of golden g20: MPDEnsemble's own routing (split_cost_constraints_to_tasks + the tile shift of
+    _add_constraints, mpd_ensemble.py:431-522) of the instance's hard + soft MultiPointConstraints, built the way __call__ builds them,
+    against the tables the genuine MPDEnsemble produced -- tile order, hard-then-soft order inside a tile, the shifted (q, range,
+    radius, is_soft) rows (a soft range that straddles a tile boundary stays with the tile of its first index), for x AND y tile
+    offsets in both directions."""
+    import types
+    from mmd_amd import synth
+    from mmd_amd.constraints import MultiPointConstraint
+    from mmd_amd.planners import MPDEnsemble
+    g = np.load(os.path.join(GOLDEN, "g20_ensemble3.npz"))
+    case = synth.ensemble3_case(direction)
+    K = len(case["env_ids"])
+    received = {k: [] for k in range(K)}
+
+    def recorder(k):
+        return types.SimpleNamespace(add_extra_costs=lambda costs, weights, k=k: received[k].extend(zip(costs, weights)))
+    me = types.SimpleNamespace(robot=None, guides={k: recorder(k) for k in range(K)},
+                               transforms={k: torch.from_numpy(case["transforms"][k]) for k in range(K)},
+                               weight_grad_cost_constraints=2e-1, weight_grad_cost_soft_constraints=2e-2)
+    me.infer_task_id_from_q_idx = types.MethodType(MPDEnsemble.infer_task_id_from_q_idx, me)
+    me.split_cost_constraints_to_tasks = types.MethodType(MPDEnsemble.split_cost_constraints_to_tasks, me)
+    cl = [MultiPointConstraint(q_l=[torch.from_numpy(q) for q in qs], t_range_l=[tuple(int(v) for v in t) for t in tr],
+                               radius_l=[float(r) for r in rad], is_soft=soft) for (qs, tr, rad, soft) in case["constraints"]]
+    cons = [CostConstraint(None, H, q_l=c.get_q_l(), traj_range_l=c.get_t_range_l(), radius_l=c.radius_l, is_soft=c.is_soft) for c in cl]
+    split = MPDEnsemble.split_cost_constraints_to_tasks(me, cons)
+    assert list(split.keys()) == g[f"{direction}.task_order"].tolist()
+    MPDEnsemble._add_constraints(me, cons)
+    n_total = 0
+    for k in g[f"{direction}.task_order"].tolist():
+        assert len(received[k]) == int(g[f"{direction}.n_{k}"])
+        for j, (c, w) in enumerate(received[k]):
+            n_total += 1
+            assert bool(c.is_soft) == bool(g[f"{direction}.soft_{k}_{j}"]) and w == (2e-2 if c.is_soft else 2e-1)
+            assert np.array_equal(np.asarray(c.qs, dtype=np.float32), g[f"{direction}.qs_{k}_{j}"]), (k, j, c.qs)
+            assert np.array_equal(np.asarray(c.traj_ranges, dtype=np.float32), g[f"{direction}.ranges_{k}_{j}"]), (k, j)
+            assert np.array_equal(np.asarray(c.radii, dtype=np.float32), g[f"{direction}.radii_{k}_{j}"]), (k, j)
+    assert n_total == 5 and all(len(received[k]) >= 1 for k in range(K))
+
+
+def test_ensemble_ddim_fails_the_way_the_reference_does():
+    """DiffusionsEnsemble.ddim_sample (diffusion_ensemble.py:109-221) cannot run in the reference: run on the genuine class in the build
+    container it raised AttributeError("'DiffusionsEnsemble' object has no attribute 'betas'"), and joint_conditional_sampling(ddim=True)
+    / run_inference(ddim=True) raised TypeError("DiffusionsEnsemble.ddim_sample() got multiple values for argument
+    'n_diffusion_steps'").  The mirror raises the same exception types (it must not silently sample something else)."""
+    import types
+    from mmd_amd.diffusion_ensemble import DiffusionsEnsemble
+    m = types.SimpleNamespace(n_diffusion_steps=25, predict_epsilon=True, state_dim=4)
+    ens = DiffusionsEnsemble({0: m, 1: m}, {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])})
+    with pytest.raises(AttributeError, match="betas"):
+        ens.ddim_sample((4, H, 4), {0: {}, 1: {}}, n_diffusion_steps=25)
+    with pytest.raises(TypeError, match="n_diffusion_steps"):
+        ens.joint_conditional_sampling({0: {}, 1: {}}, {(0, 1): (H - 1, 0)}, n_diffusion_steps=25, batch_size=4, ddim=True)
+    with pytest.raises(TypeError, match="n_diffusion_steps"):
+        ens.run_inference(None, {0: {}, 1: {}}, cross_conds={(0, 1): (H - 1, 0)}, n_samples=4, ddim=True, sample_kwargs={0: {}, 1: {}})
+    with pytest.raises(ValueError):
+        ens.joint_conditional_sampling({0: {}, 1: {}}, {}, n_diffusion_steps=None)

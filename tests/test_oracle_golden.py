@@ -19,6 +19,10 @@ def test_g1_schedule_tables_bit_exact():
         tb = O.schedule_tables(T)
         for k in O.SCHEDULE_KEYS:
             assert np.array_equal(tb[k].numpy(), g[f"T{T}.{k}"]), (T, k)
+    for T in (25, 100):
+        tb = O.schedule_tables(T, "cosine")
+        for k in O.SCHEDULE_KEYS:
+            assert np.array_equal(tb[k].numpy(), g[f"cosine.T{T}.{k}"]), ("cosine", T, k)
 
 
 def test_g2_unet_forward():

@@ -85,6 +85,16 @@ def g1():
         for k, v in m.state_dict().items():
             if not k.startswith("model."):
                 out[f"T{T}.{k}"] = v.numpy()
+    # the cosine schedule (helpers.py:16-27; GaussianDiffusionModel(variance_schedule='cosine'), diffusion_model_base.py:70-75)
+    from mmd.models.diffusion_models.diffusion_model_base import GaussianDiffusionModel
+    from mmd.models.diffusion_models.temporal_unet import TemporalUnet
+    for T in (25, 100):
+        with quiet():
+            m = GaussianDiffusionModel(model=TemporalUnet(state_dim=4, n_support_points=64, unet_input_dim=32, dim_mults=(1, 2, 4)),
+                                       variance_schedule="cosine", n_diffusion_steps=T, predict_epsilon=True)
+        for k, v in m.state_dict().items():
+            if not k.startswith("model."):
+                out[f"cosine.T{T}.{k}"] = v.numpy()
     np.savez_compressed(os.path.join(OUT, "g1_schedules.npz"), **out)
 
 
