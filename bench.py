@@ -179,6 +179,7 @@ def parse():
                     help="config4: the planner calls of a round on one host thread + stream each (plan_concurrently) instead of batched")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the dominant kernel that fill roofline.traffic")
+    ap.add_argument("--streams", type=int, default=0, help="mmd_sampler_desc.n_streams of the sharded sampler (0 = the library's choice: 2 chunks from 2048 trajectories, A/B: tools/gpu_streams.sh)")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -337,7 +338,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     model = GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True)
     starts, goals = workload_starts_goals(W, n_robots)
     sampler = MultiRobotSampler(model, starts, goals, env_id=W["env"], n_samples=B, rank=rank, world_size=world,
-                                device=dev, inter_robot=W["inter_robot"])
+                                device=dev, inter_robot=W["inter_robot"], n_streams=args.streams)
     # round 0 input: straight-line paths stand in for "previous best paths" 
     paths_local = torch.from_numpy(synth.straight_line_paths(starts, goals, H)[sampler.robot0:sampler.robot0 + RPG]).to(dev)
 

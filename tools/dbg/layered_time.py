@@ -1,5 +1,5 @@
 """Forward time of the layer-by-layer TemporalUnet path (csrc/unet_layers.hip) by batch size: option 1 = UNET_DIM_MULTS[1] = (1, 2, 4, 8),
-and option 0 forced onto the path (TemporalUnet(layered=True)) beside the fused kernel.  MMD_AMD_LAYERED_VALU=1 (sampled at load): the
+and option 0 forced onto the path (TemporalUnet(layered=True)) beside the fused kernel.  MMD_AMD_LAYERED_VALU=1 (read HERE by this tool and passed to TemporalUnet(layered_valu=...) -> mmd_unet_options; the library reads no environment): the
 vector-ALU Conv1dBlock kernel instead of conv5_mfma_kernel.  Usage: layered_time.py [n ...]"""
 import os
 import sys
@@ -10,7 +10,7 @@ from mmd_amd.temporal_unet import TemporalUnet
 
 
 def net(dm, layered=None):
-    u = TemporalUnet(dim_mults=dm, layered=layered)
+    u = TemporalUnet(dim_mults=dm, layered=bool(layered), layered_valu=os.environ.get('MMD_AMD_LAYERED_VALU', '0') == '1')
     u.load_state_dict(synth.synth_unet_state_dict(0, dim_mults=dm))
     return u
 

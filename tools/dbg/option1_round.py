@@ -1,6 +1,6 @@
 """One planning round of the headline workload (32 robots x 64 samples on the Empty map, T = 100 + 1, all-pairs soft constraints) with the
 reference's OTHER network shape, UNET_DIM_MULTS[1] = (1, 2, 4, 8): the layer-by-layer TemporalUnet path end to end in the sampler.
-MMD_AMD_LAYERED_VALU=1 (sampled at load) = the vector-ALU kernels.  Usage: option1_round.py [rounds]"""
+MMD_AMD_LAYERED_VALU=1 (read HERE by this tool and passed to TemporalUnet(layered_valu=...) -> mmd_unet_options; the library reads no environment) = the vector-ALU kernels.  Usage: option1_round.py [rounds]"""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ from mmd_amd.temporal_unet import TemporalUnet
 H, T, B, N = 64, 100, 64, 32
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for dm in ((1, 2, 4, 8), (1, 2, 4)):
-    unet = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=32, dim_mults=dm)
+    unet = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=32, dim_mults=dm, layered_valu=os.environ.get('MMD_AMD_LAYERED_VALU', '0') == '1')
     unet.load_state_dict(synth.synth_unet_state_dict(0, dim_mults=dm))
     model = GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True)
     starts, goals = synth.start_goal_circle(N, 0.8)

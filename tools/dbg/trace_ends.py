@@ -13,7 +13,7 @@ from mmd_amd.temporal_unet import TemporalUnet
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 lib = _lib.load()
-unet = TemporalUnet()
+unet = TemporalUnet(two_per_workgroup_max=int(os.environ.get('MMD_AMD_UNET_NS2_MAX', '0')))   # (this TOOL's knob, passed on as mmd_unet_options: the library reads no environment)
 unet.load_state_dict(synth.synth_unet_state_dict(0))
 x = torch.randn(n, 64, 4, device="cuda")
 ns2_max = int(os.environ.get("MMD_AMD_UNET_NS2_MAX", "512"))      # unet_kernel<2> (two trajectories per workgroup) up to here

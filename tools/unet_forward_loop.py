@@ -12,7 +12,7 @@ if os.environ.get("MMD_AMD_LIB"):
 from mmd_amd.temporal_unet import TemporalUnet
 
 lib = _lib.load()
-unet = TemporalUnet()
+unet = TemporalUnet(two_per_workgroup_max=int(os.environ.get('MMD_AMD_UNET_NS2_MAX', '0')))   # (this TOOL's knob, passed on as mmd_unet_options: the library reads no environment)
 unet.load_state_dict(synth.synth_unet_state_dict(0))
 reps = int(os.environ.get("REPS", "30"))
 for n in [int(a) for a in sys.argv[1:]] or [2048]:
