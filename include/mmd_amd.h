@@ -340,14 +340,24 @@ int mmd_postprocess_trajs(const mmd_guide_desc* env, const float* trajs_dev, int
 /* Per robot, the index (within its samples_per_robot samples) of the best FREE sample: with counts_dev == NULL the
  * argmin of cost_a (+ cost_b if not NULL) (torch.argmin(cost_all), mpd.py:366-370); with counts_dev the first free
  * sample with the fewest robot-robot collisions (CBS 'least_collisions', cbs.py:446-458).  n_free_dev[r] = number of
- * free samples; when it is 0 the pick is made over all samples instead. */
+ * free samples; when it is 0 the pick is made over all samples instead.  summary_dev (optional, fp32 [n_traj + n_robots]): the free
+ * flags as 0 / 1 followed by the picks -- laid out so that, with path_length_dev / smoothness_dev of mmd_postprocess_trajs placed right
+ * behind it, everything the host needs to assemble a PlannerOutput crosses in ONE device -> host copy. */
 int mmd_select_best(const uint8_t* free_dev, const float* cost_a_dev, const float* cost_b_dev, const int32_t* counts_dev,
-                    int n_robots, int samples_per_robot, int32_t* idx_best_dev, int32_t* n_free_dev, void* stream);
+                    int n_robots, int samples_per_robot, int32_t* idx_best_dev, int32_t* n_free_dev, float* summary_dev,
+                    void* stream);
 
 /* PlanningTask.compute_collision (tasks.py:141-143, :204-232; occupancy of the fixed objects + workspace boundaries)
  * for n_points positions (x, y at points_dev[i * point_stride + {0, 1}]) on map `map_index` of `env`. */
 int mmd_points_collision(const mmd_guide_desc* env, const float* points_dev, int n_points, int point_stride, int map_index,
                          float margin, uint8_t* out_dev, void* stream);
+
+/* LimitsNormalizer.unnormalize (mmd/datasets/normalization.py:157-168; TrajectoryDataset.unnormalize_trajectories, what MPD.__call__
+ * applies to the sampled chain, mpd.py:344-347) for n_points float4 states (x, y, vx, vy): the WHOLE tensor is clipped to [-1, 1] iff any
+ * element lies outside [-1 - eps, 1 + eps] (the reference's data-dependent clip, decided on the device: flag_dev is one uint32 of
+ * scratch), then x_u = (x + 1) / 2 * (maxs - mins) + mins.  mins / maxs: host [4].  out_dev may alias x_dev. */
+int mmd_unnormalize_trajs(const float* x_dev, size_t n_points, const float* mins, const float* maxs, float eps, float* out_dev,
+                          uint32_t* flag_dev, void* stream);
 
 /* compute_variance_waypoints (trajectory/metrics.py:17-27): var_per_waypoint_dev[t] = unbiased variance of all
  * n_traj^2 entries of triu(cdist(p_t, p_t), 1); the metric is their sum over t. */

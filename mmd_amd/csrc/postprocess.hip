@@ -177,10 +177,12 @@ __global__ __launch_bounds__(MAX_BLOCKS * 64) void postprocess_kernel(PostArgs a
 __global__ __launch_bounds__(64) void select_best_kernel(const unsigned char* __restrict__ free_mask,
                                                          const float* __restrict__ cost_a, const float* __restrict__ cost_b,
                                                          const int* __restrict__ counts, int B, int* __restrict__ idx_best,
-                                                         int* __restrict__ n_free) {
+                                                         int* __restrict__ n_free, float* __restrict__ summary) {
   const int r = blockIdx.x, lane = threadIdx.x;
   int nf = 0;
   for (int b = lane; b < B; b += 64) nf += free_mask[(size_t)r * B + b] ? 1 : 0;
+  if (summary)                                                // the host's one transfer: free flags as floats, then the picks
+    for (int b = lane; b < B; b += 64) summary[(size_t)r * B + b] = free_mask[(size_t)r * B + b] ? 1.f : 0.f;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) nf += __shfl_xor(nf, m);
   float best = INFINITY;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(64) void select_best_kernel(const unsigned char* __
   if (lane == 0) {
     idx_best[r] = best_i == 0x7fffffff ? -1 : best_i;
     n_free[r] = nf;
+    if (summary) summary[(size_t)gridDim.x * B + r] = (float)(best_i == 0x7fffffff ? -1 : best_i);
   }
 }
 
@@ -237,6 +240,35 @@ __global__ __launch_bounds__(256) void variance_waypoints_kernel(const float4* _
     const double n = (double)pairs;
     var_t[t] = n > 1.0 ? (float)((s2[0] - s1[0] * s1[0] / n) / (n - 1.0)) : NAN;
   }
+}
+
+// LimitsNormalizer.unnormalize (mmd/datasets/normalization.py:157-168) of a whole chain on the device, with the reference's
+// data-dependent clip -- the WHOLE tensor is clipped to [-1, 1] iff ANY element lies outside [-1 - eps, 1 + eps] -- decided by a
+// reduction kernel into a device flag (no host round trip: the torch form `if x.max() > 1 + eps or x.min() < -1 - eps` costs two
+// reductions and two synchronisations per planner call), then x_u = (x + 1) / 2 * (max - min) + min with torch's separate
+// roundings (no FMA contraction: this file is compiled with fp contract off).
+__global__ __launch_bounds__(256) void range_flag_kernel(const float4* __restrict__ x, size_t n, float eps, uint32_t* __restrict__ flag) {
+  const float hi = 1.f + eps, lo = -1.f - eps;
+  bool out = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = x[i];
+    out = out || v.x > hi || v.y > hi || v.z > hi || v.w > hi || v.x < lo || v.y < lo || v.z < lo || v.w < lo;
+  }
+  if (__ballot(out) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+struct UnnormArgs { float mins[4], range[4]; };
+__global__ __launch_bounds__(256) void unnormalize_kernel(const float4* __restrict__ x, float4* __restrict__ out, size_t n, UnnormArgs a,
+                                                          const uint32_t* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool clip = *flag != 0u;
+  auto f = [&](float v, int d) {
+    if (clip) v = fminf(fmaxf(v, -1.f), 1.f);                // torch.clip(x, -1, 1)
+    v = (v + 1.f) / 2.f;
+    return v * a.range[d] + a.mins[d];
+  };
+  const float4 v = x[i];
+  out[i] = make_float4(f(v.x, 0), f(v.y, 1), f(v.z, 2), f(v.w, 3));
 }
 
 }  // namespace mmd
@@ -286,11 +318,12 @@ int mmd_postprocess_trajs(const mmd_guide_desc* env, const float* trajs_dev, int
 }
 
 int mmd_select_best(const uint8_t* free_dev, const float* cost_a_dev, const float* cost_b_dev, const int32_t* counts_dev,
-                    int n_robots, int samples_per_robot, int32_t* idx_best_dev, int32_t* n_free_dev, void* stream) {
+                    int n_robots, int samples_per_robot, int32_t* idx_best_dev, int32_t* n_free_dev, float* summary_dev,
+                    void* stream) {
   MMD_REQUIRE(free_dev && (cost_a_dev || counts_dev) && idx_best_dev && n_free_dev, "mmd_select_best: NULL argument");
   MMD_REQUIRE(n_robots >= 1 && samples_per_robot >= 1, "mmd_select_best: empty batch");
   hipLaunchKernelGGL(select_best_kernel, dim3(n_robots), dim3(64), 0, (hipStream_t)stream, free_dev, cost_a_dev, cost_b_dev,
-                     counts_dev, samples_per_robot, idx_best_dev, n_free_dev);
+                     counts_dev, samples_per_robot, idx_best_dev, n_free_dev, summary_dev);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -303,6 +336,22 @@ int mmd_points_collision(const mmd_guide_desc* env, const float* points_dev, int
   MMD_REQUIRE(map_index >= 0 && map_index < (env->n_maps > 0 ? env->n_maps : 1), "mmd_points_collision: map index");
   hipLaunchKernelGGL(points_collision_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, e, points_dev,
                      n_points, point_stride, map_index, margin, out_dev);
+  MMD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int mmd_unnormalize_trajs(const float* x_dev, size_t n_points, const float* mins, const float* maxs, float eps, float* out_dev,
+                          uint32_t* flag_dev, void* stream) {
+  MMD_REQUIRE(x_dev && out_dev && mins && maxs && flag_dev, "mmd_unnormalize_trajs: NULL argument");
+  if (n_points == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  MMD_HIP_CHECK(hipMemsetAsync(flag_dev, 0, sizeof(uint32_t), st));
+  const unsigned blocks = (unsigned)((n_points + 1023) / 1024);
+  hipLaunchKernelGGL(range_flag_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, st, (const float4*)x_dev, n_points, eps, flag_dev);
+  UnnormArgs a;
+  for (int d = 0; d < 4; ++d) { a.mins[d] = mins[d]; a.range[d] = maxs[d] - mins[d]; }
+  hipLaunchKernelGGL(unnormalize_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, (const float4*)x_dev,
+                     (float4*)out_dev, n_points, a, (const uint32_t*)flag_dev);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -8,6 +8,7 @@ class LimitsNormalizer:
     def __init__(self, mins, maxs):
         self.mins = torch.as_tensor(mins, dtype=torch.float32)
         self.maxs = torch.as_tensor(maxs, dtype=torch.float32)
+        self._host = None
 
     def to(self, device):
         self.mins, self.maxs = self.mins.to(device), self.maxs.to(device)
@@ -18,6 +19,19 @@ class LimitsNormalizer:
         return 2 * x - 1
 
     def unnormalize(self, x, eps=1e-4):
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 4 and self.mins.numel() == 4:
+            # on the device in two launches, the data-dependent clip decided there (mmd_unnormalize_trajs): the torch form below costs two
+            # reductions and two host synchronisations per planner call
+            import ctypes as C
+            from . import _lib
+            x = x.contiguous()
+            out = torch.empty_like(x)
+            flag = torch.empty(1, dtype=torch.int32, device=x.device)
+            if self._host is None:
+                self._host = ((C.c_float * 4)(*[float(v) for v in self.mins.cpu()]), (C.c_float * 4)(*[float(v) for v in self.maxs.cpu()]))
+            _lib.launch("mmd_unnormalize_trajs", x, x.data_ptr(), x.numel() // 4, self._host[0], self._host[1], float(eps), out.data_ptr(),
+                        flag.data_ptr())
+            return out
         if x.max() > 1 + eps or x.min() < -1 - eps:
             x = torch.clip(x, -1, 1)
         x = (x + 1) / 2.0

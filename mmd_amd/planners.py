@@ -215,15 +215,18 @@ def _fill_output(out, guide, trajs_iters, all_free=False):
     smoothness, SavGol) + the per-batch argmin + the waypoint variance of the free set."""
     trajs_final = trajs_iters[-1].contiguous()
     B, dev = trajs_final.shape[0], trajs_final.device
-    r = post.postprocess_batch(guide, trajs_final, all_free=all_free, smooth=True)
-    idx, _ = post.select_best(r.free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness)
-    # the call's ONE device -> host transfer: free mask, index of the cheapest free sample, the two costs (boolean-mask indexing,
-    # argwhere, .item() would each synchronise: nine round trips = 0.4 ms of a 3.4 ms planner call at T = 25)
-    host = torch.cat((r.free_mask.float(), idx.float(), r.path_length, r.smoothness)).cpu().numpy()
+    summary = post.host_summary(B, 1, dev)
+    r = post.postprocess_batch(guide, trajs_final, all_free=all_free, smooth=True, summary=summary)
+    post.select_best(r.free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness, summary=summary)
+    # the call's ONE device -> host transfer: free mask, index of the cheapest free sample, the two costs, written by the two kernels
+    # into one buffer (boolean-mask indexing, argwhere, .item() would each synchronise: nine round trips = 0.4 ms of a 3.4 ms
+    # planner call at T = 25), and ONE host -> device copy of the two index lists back
+    host = summary.cpu().numpy()
     fm, ib = host[:B] > 0, int(host[B])
     free_i, coll_i = np.flatnonzero(fm), np.flatnonzero(~fm)
-    free_idxs = torch.from_numpy(free_i).to(dev).view(-1, 1)          # [n, 1] int64, as torch.argwhere gives them (tasks.py:258-307)
-    coll_idxs = torch.from_numpy(coll_i).to(dev).view(-1, 1)
+    both = torch.from_numpy(np.concatenate((free_i, coll_i))).to(dev)
+    free_idxs = both[:free_i.size].view(-1, 1)                       # [n, 1] int64, as torch.argwhere gives them (tasks.py:258-307)
+    coll_idxs = both[free_i.size:].view(-1, 1)
     free = trajs_final.index_select(0, free_idxs.view(-1)) if free_i.size else None
     coll = trajs_final.index_select(0, coll_idxs.view(-1)) if coll_i.size else None
     out.trajs_iters, out.trajs_final = trajs_iters, r.smoothed
@@ -257,12 +260,14 @@ def _fill_output_ensemble(out, task, tile_trajs_final, trajs_iters):
     for m, tf in tile_trajs_final.items():
         fm = post.postprocess_batch(task.tasks[m].guide, tf.contiguous(), smooth=False).free_mask
         free_mask = fm if free_mask is None else free_mask & fm
-    r = post.postprocess_batch(task.tasks[next(iter(task.tasks))].guide, trajs_final, all_free=True, smooth=True)
-    idx, _ = post.select_best(free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness)
-    host = torch.cat((free_mask.float(), idx.float(), r.path_length, r.smoothness)).cpu().numpy()      # the call's one transfer
+    summary = post.host_summary(B, 1, dev)
+    r = post.postprocess_batch(task.tasks[next(iter(task.tasks))].guide, trajs_final, all_free=True, smooth=True, summary=summary)
+    post.select_best(free_mask, 1, cost_a=r.path_length, cost_b=r.smoothness, summary=summary)
+    host = summary.cpu().numpy()                                                                        # the call's one transfer
     fm, ib = host[:B] > 0, int(host[B])
     free_i, coll_i = np.flatnonzero(fm), np.flatnonzero(~fm)
-    free_idxs, coll_idxs = torch.from_numpy(free_i).to(dev), torch.from_numpy(coll_i).to(dev)
+    both = torch.from_numpy(np.concatenate((free_i, coll_i))).to(dev)
+    free_idxs, coll_idxs = both[:free_i.size], both[free_i.size:]
     empty = torch.tensor([], dtype=torch.float32, device=dev)
     out.trajs_iters, out.trajs_final = trajs_iters, r.smoothed
     out.trajs_final_coll = trajs_final[:, coll_idxs] if coll_i.size else empty
@@ -746,10 +751,10 @@ def _load_constraints(cg, per_robot):
             cg.add_extra_costs([c for c, _ in pairs], [w for _, w in pairs], robot=r)
 
 
-def _split_outputs(calls, planners, r, idx, free_mask, trajs_iters_all, B, t_total, ensemble_tasks=None):
-    """The PlannerOutputs of a batched group from ONE post-processing launch + ONE device -> host transfer."""
+def _split_outputs(calls, planners, r, summary, trajs_iters_all, B, t_total, ensemble_tasks=None):
+    """The PlannerOutputs of a batched group from ONE post-processing launch + ONE device -> host transfer (post.host_summary)."""
     R, dev = len(planners), trajs_iters_all.device
-    host = torch.cat((free_mask.float(), idx.float(), r.path_length, r.smoothness)).cpu().numpy()
+    host = summary.cpu().numpy()
     fm_all, ib_all = host[:R * B] > 0, host[R * B:R * B + R].astype(np.int64)
     pl_all, sm_all = host[R * B + R:2 * R * B + R], host[2 * R * B + R:]
     outs = []
@@ -829,9 +834,10 @@ def _run_mpd_group(calls, seeds):
             cg.reset_extra_costs()
     trajs_iters = p0.dataset.unnormalize_trajectories(chain)                     # [T+2, R*B, H, D]
     tg = cg if all(p._task_guide is p.guide for p in planners) else _combined_guide([p._task_guide for p in planners])
-    r = post.postprocess_batch(tg, trajs_iters[-1].contiguous(), n_robots=R, smooth=True)
-    idx, _ = post.select_best(r.free_mask, R, cost_a=r.path_length, cost_b=r.smoothness)
-    return _split_outputs(calls, planners, r, idx, r.free_mask, trajs_iters, B, timer.elapsed)
+    summary = post.host_summary(R * B, R, dev)
+    r = post.postprocess_batch(tg, trajs_iters[-1].contiguous(), n_robots=R, smooth=True, summary=summary)
+    post.select_best(r.free_mask, R, cost_a=r.path_length, cost_b=r.smoothness, summary=summary)
+    return _split_outputs(calls, planners, r, summary, trajs_iters, B, timer.elapsed)
 
 
 def _run_ensemble_group(calls, seeds):
@@ -874,9 +880,10 @@ def _run_ensemble_group(calls, seeds):
         tr[..., :2] += offs[None, :, None, :]
         parts.append(tr)
     trajs_iters = torch.cat(parts, dim=-2)                                                      # [T+2, R*B, K*64, D]
-    r = post.postprocess_batch(cgs[keys[0]], trajs_iters[-1].contiguous(), n_robots=R, all_free=True, smooth=True)
-    idx, _ = post.select_best(free_mask, R, cost_a=r.path_length, cost_b=r.smoothness)
-    return _split_outputs(calls, planners, r, idx, free_mask, trajs_iters, B, timer.elapsed, ensemble_tasks=True)
+    summary = post.host_summary(R * B, R, dev)
+    r = post.postprocess_batch(cgs[keys[0]], trajs_iters[-1].contiguous(), n_robots=R, all_free=True, smooth=True, summary=summary)
+    post.select_best(free_mask, R, cost_a=r.path_length, cost_b=r.smoothness, summary=summary)
+    return _split_outputs(calls, planners, r, summary, trajs_iters, B, timer.elapsed, ensemble_tasks=True)
 
 
 def plan_batched(calls, seeds=None):

@@ -46,10 +46,16 @@ class PostprocessResult:
     __slots__ = ("free_mask", "path_length", "smoothness", "smoothed", "waypoint_collisions")
 
 
+def host_summary(n, n_robots, device):
+    """One fp32 buffer [free flags (n) | picks (n_robots) | path lengths (n) | smoothness (n)]: postprocess_batch(summary=...) and
+    select_best(summary=...) fill it, `.cpu()` on it is the planner call's ONE device -> host transfer."""
+    return torch.empty(3 * n + n_robots, dtype=torch.float32, device=device)
+
+
 def postprocess_batch(guide, trajs, n_robots=1, num_interpolation=5, margin=ROBOT_RADIUS, all_free=False, smooth=True,
-                      want_waypoints=False, window_size=10, poly_order=2):
+                      want_waypoints=False, window_size=10, poly_order=2, summary=None):
     """trajs [n_robots*B, K*64, 4] un-normalised on the GPU (K = 1; K tiles for MPDEnsemble); `guide` supplies the resident
-    map (its C-ABI descriptor)."""
+    map (its C-ABI descriptor).  `summary` (host_summary): path lengths / smoothness are written into it."""
     trajs = trajs.contiguous()
     n, h, d = trajs.shape
     if h % H or d != 4 or n % n_robots:
@@ -58,8 +64,11 @@ def postprocess_batch(guide, trajs, n_robots=1, num_interpolation=5, margin=ROBO
     desc = guide.desc() if hasattr(guide, "desc") else guide
     r = PostprocessResult()
     r.free_mask = torch.empty(n, dtype=torch.uint8, device=dev)
-    r.path_length = torch.empty(n, dtype=torch.float32, device=dev)
-    r.smoothness = torch.empty(n, dtype=torch.float32, device=dev)
+    if summary is not None:
+        r.path_length, r.smoothness = summary[n + n_robots:2 * n + n_robots], summary[2 * n + n_robots:]
+    else:
+        r.path_length = torch.empty(n, dtype=torch.float32, device=dev)
+        r.smoothness = torch.empty(n, dtype=torch.float32, device=dev)
     r.smoothed = torch.empty_like(trajs) if smooth else None
     r.waypoint_collisions = (torch.empty((n, (h - 1) * num_interpolation), dtype=torch.uint8, device=dev)
                              if want_waypoints else None)
@@ -74,8 +83,9 @@ def postprocess_batch(guide, trajs, n_robots=1, num_interpolation=5, margin=ROBO
     return r
 
 
-def select_best(free_mask, n_robots, cost_a=None, cost_b=None, counts=None):
-    """Per robot: (index of the best free sample, number of free samples), int32 device tensors (mmd_select_best)."""
+def select_best(free_mask, n_robots, cost_a=None, cost_b=None, counts=None, summary=None):
+    """Per robot: (index of the best free sample, number of free samples), int32 device tensors (mmd_select_best); `summary`
+    (host_summary) receives the free flags and the picks as floats."""
     n = free_mask.shape[0]
     dev = free_mask.device
     idx = torch.empty(n_robots, dtype=torch.int32, device=dev)
@@ -83,7 +93,7 @@ def select_best(free_mask, n_robots, cost_a=None, cost_b=None, counts=None):
     _lib.launch("mmd_select_best", free_mask, free_mask.data_ptr(), cost_a.data_ptr() if cost_a is not None else None,
         cost_b.data_ptr() if cost_b is not None else None,
         counts.contiguous().data_ptr() if counts is not None else None, n_robots, n // n_robots, idx.data_ptr(),
-        n_free.data_ptr())
+        n_free.data_ptr(), summary.data_ptr() if summary is not None else None)
     return idx, n_free
 
 

@@ -624,3 +624,23 @@ def test_plan_concurrently_equals_the_sequential_calls():
     econ = plan_concurrently(ecalls, seeds=eseeds)
     for a, b in zip(eseq, econ):
         assert a.trajs_iters.shape[-2] == 2 * H and torch.equal(a.trajs_iters, b.trajs_iters)
+
+
+def test_unnormalize_on_device_equals_the_torch_form_bitwise():
+    """mmd_unnormalize_trajs (TrajectoryDatasetFacade.unnormalize_trajectories on CUDA tensors) against LimitsNormalizer.unnormalize's torch
+    form (normalization.py:157-168) on the CPU: values inside [-1, 1], values in (1, 1 + 1e-4] (NOT clipped: they stay above the limit),
+    one element beyond 1 + 1e-4 anywhere in the tensor (the WHOLE tensor is clipped), and the lower side; a [T+2, B, H, 4] chain shape."""
+    from mmd_amd.normalization import TrajectoryDatasetFacade
+    ds = TrajectoryDatasetFacade(np.array([-1.0, -1.1, -1.5, -1.7], np.float32), np.array([1.0, 0.9, 1.5, 1.3], np.float32))
+    base = torch.from_numpy(synth.synth_noise(140, (27, 8, H, D))).clamp(-3, 3) / 3.0
+    cases_ = {"inside": base.clone()}
+    v = base.clone(); v[3, 2, 10, 1] = 1.00005; cases_["within_eps"] = v
+    v = base.clone(); v[26, 7, 63, 3] = 1.0002; v[0, 0, 0, 0] = 0.99999; cases_["one_above"] = v
+    v = base.clone(); v[5, 5, 5, 2] = -1.0002; cases_["one_below"] = v
+    v = base.clone() * 2.5; cases_["many_outside"] = v
+    for name, x in cases_.items():
+        ref = ds.unnormalize_trajectories(x.clone())                      # the torch form on the CPU
+        got = ds.unnormalize_trajectories(x.cuda()).cpu()
+        assert torch.equal(got, ref), name
+    assert float(ds.unnormalize_trajectories(cases_["within_eps"].cuda())[3, 2, 10, 1]) > 0.9       # above the limit: not clipped
+    assert float(ds.unnormalize_trajectories(cases_["one_above"].cuda()).max()) <= 1.5
