@@ -1,0 +1,164 @@
+// VERDICT r5 #4 / Weak #6, MEASURED: would splitting a sample's channels over TWO workgroups shorten the latency-bound forward of
+// <= 256 trajectories (83 us whatever the batch: one workgroup's 25 dependent convs, each bound by streaming the conv's whole
+// weight pack through ONE CU -- 320 KB for a 128 -> 128 conv at L = 16, where the GEMM is only 32 rows)?
+//
+// The loop body is downs.2 / mid's 128 -> 128 conv exactly as unet_kernel<2> runs it (this file includes unet.hip: rd_store ->
+// barrier -> rd_taps -> rd_gn_mish), 7 distinct weight packs cycled (downs.2's four convs + mid's... the seven 128 -> 128 convs),
+// two samples per workgroup:
+//   base : one workgroup owns the two samples' 128 output channels (wave = 2 interleaved n-tiles): today's kernel.
+//   pair : TWO workgroups on the same XCD own 64 output channels each of the SAME two samples (wave = 1 n-tile = one whole
+//          GroupNorm(8) group of 16 channels, so no GroupNorm exchange): each streams HALF the weight pack and issues half the
+//          MFMAs; after its epilogue a workgroup publishes its half of the next conv's input slab (the f16x2 pieces, 10 KB) to an
+//          exchange buffer in global memory (L2), raises a per-conv flag (release, agent scope), waits for its partner's flag
+//          (acquire) and copies the partner's half into its own LDS slab.
+//   half : `pair` without the exchange (barriers only): what the halved weight stream alone would buy -- the upper bound.
+//   pairL2: `pair` with a protocol that is only valid while both workgroups sit on the SAME XCD (placement the programming model does
+//          not promise): the publisher waits for its stores to reach the shared L2 (s_waitcnt vmcnt(0), no L2 write-back), raises the
+//          flag with a read-modify-write (executes in the L2); the reader polls with device-scope loads and invalidates its L1
+//          (acquire fence) before copying.  The floor of what an exchange through L2 costs.
+// Prints us per conv.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -w tools/ubench/pair_split.hip
+//   mmd_amd/csrc/{unet_layers,guide,api,multi_agent,postprocess}.hip -o build_tmp/pair_split ; run: build_tmp/pair_split [workgroups of the base arm]
+#include "../../mmd_amd/csrc/unet.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+namespace mmd {
+using G128 = RdGeo<128>;
+constexpr int N_PACKS = 7;                                   // the seven 128 -> 128 convs of downs.2 + mid
+constexpr int PACK_U4 = 8 * G128::FRAGS5 * 64;               // uint4 per conv: 8 n-tiles x 40 fragments x 64 lanes = 320 KB
+constexpr int XCH_U4 = 2 * 2 * G128::KC * 2 * G128::RPS;     // pieces x lane groups of a half x chunks x rows of two samples = 640
+
+struct ConvP { const uint4* w; const float* par; uint4* xbuf; unsigned* flag; };
+
+// MODE 0 base, 1 pair (agent-scope release / acquire), 2 half (pair without the exchange), 3 pairL2 (see main: same-L2 protocol)
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_chain(ConvP p, float* out, int nconv) {
+  constexpr int NT = MODE == 0 ? 2 : 1, NS = 2;
+  __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
+  char* const slab = reinterpret_cast<char*>(lds);
+  const char* const va = slab + g * G128::G + n * 16;
+  // pair arms: consecutive workgroup ids go round the 8 XCDs, so ids i and i ^ 8 share an XCD (and its L2)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, half = MODE == 0 ? 0 : (slot & 1), pair = (slot >> 1) * 8 + xcd;
+  const int nt = 4 * half + wave;                            // pair arms: the wave's n-tile = channels 16 nt .. 16 nt + 15
+  const int c0 = MODE == 0 ? 32 * wave + 2 * n : 16 * nt + n;
+  char* const vs = MODE == 0 ? slab + wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4
+                             : slab + (nt >> 1) * G128::G + (2 * (nt & 1) + (n >> 3)) * G128::BX + (2 + 4 * g) * 16 + ((n & 7) >> 1) * 4;
+  f32x4 acc[NS][NT], res[NS][NT];
+  for (int s = 0; s < NS; ++s) for (int t = 0; t < NT; ++t) for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
+  rd_zero_halo<G128>(slab);
+  float one[NS];
+  for (int s = 0; s < NS; ++s) one[s] = 1.f;
+  __syncthreads();
+  for (int k = 0; k < nconv; ++k) {
+    int woff[NT];
+    for (int t = 0; t < NT; ++t) woff[t] = (k % N_PACKS) * PACK_U4 + (MODE == 0 ? 2 * wave + t : nt) * G128::FRAGS5 * 64 + lane;
+    if constexpr (NT == 2) asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
+    else asm volatile("" : "+v"(woff[0]));
+    const u32x4* wp[NT];
+    for (int t = 0; t < NT; ++t) wp[t] = reinterpret_cast<const u32x4*>(p.w) + woff[t];
+    const Epi<NT> e = epi_load<NT>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
+    u32x4 ring[3][NT][2];
+    rd_ring_load<G128, NT, 3>(ring, wp);
+    if constexpr (MODE == 0) rd_store2<G128, NS>(vs, acc);
+    else rd_store1<G128, NS>(vs, reinterpret_cast<f32x4(&)[NS][1]>(acc), lane);
+    __syncthreads();
+    if constexpr (MODE == 1 || MODE == 3) {
+      // publish my half of the slab (lane groups 2 half, 2 half + 1; both pieces; the rows of the two samples), fetch the partner's
+      const unsigned it = (unsigned)k + 1u;
+      uint4* const mine = p.xbuf + ((size_t)(pair * 2 + (k & 1)) * 2 + half) * XCH_U4;
+      const uint4* const theirs = p.xbuf + ((size_t)(pair * 2 + (k & 1)) * 2 + (half ^ 1)) * XCH_U4;
+      auto slab_at = [&](int idx, int h) {
+        const int b16 = idx / (2 * G128::RPS), row = idx % (2 * G128::RPS), q = b16 >> 3, jj = (b16 >> 2) & 1, kc = b16 & 3;
+        return reinterpret_cast<uint4*>(slab + q * G128::PS + (2 * h + jj) * G128::G + kc * G128::BX + row * 16);
+      };
+      for (int idx = threadIdx.x; idx < XCH_U4; idx += 256) mine[idx] = *slab_at(idx, half);
+      if constexpr (MODE == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (writes the XCD's L2 back: buffer_wbl2)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // the stores have reached the (shared) L2
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        if constexpr (MODE == 1) __hip_atomic_store(p.flag + pair * 2 + half, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else atomicExch(p.flag + pair * 2 + half, it);                                  // a read-modify-write executes in the L2
+        int spins = 0;                                          // (bounded: a placement that breaks the pairing must not hang the box)
+        if constexpr (MODE == 1) {
+          while (__hip_atomic_load(p.flag + pair * 2 + (half ^ 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < it && ++spins < (1 << 20))
+            __builtin_amdgcn_s_sleep(1);
+        } else {
+          while (__hip_atomic_load(p.flag + pair * 2 + (half ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it && ++spins < (1 << 20))
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (spins >= (1 << 20)) atomicAdd(p.flag + 511, 1u);      // the last flag word counts timeouts
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      for (int idx = threadIdx.x; idx < XCH_U4; idx += 256) *slab_at(idx, half ^ 1) = theirs[idx];
+      __syncthreads();
+    }
+    rd_taps<G128, NT, 0, 5, true, false, NS, 3>(acc, res, va, wp, wp, ring);
+    if constexpr (NT == 2) {
+      const float t0 = e.tb[0], t1 = e.tb[1];
+      rd_gn_mish<2, 256, true>(acc, e.b, e.g, e.be, e.is, one, act_scale(1.f), [&](int, int t, int) { return t ? t1 : t0; });
+    } else {
+      // (one n-tile = the 16 channels of ONE GroupNorm group at C = 128; the 8-lane reduction of the 64-channel stages stands in for the
+      // 16-lane one: one DPP step fewer, the same arithmetic otherwise -- a timing stand-in)
+      const float t0 = e.tb[0];
+      rd_gn_mish<1, 128, true>(acc, e.b, e.g, e.be, e.is, one, act_scale(1.f), [&](int, int, int) { return t0; });
+    }
+    __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < NS; ++i) for (int t = 0; t < NT; ++t) s += acc[i][t][0] + acc[i][t][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace mmd
+
+int main(int argc, char** argv) {
+  using namespace mmd;
+  const int nconv = 7 * 16;
+  const size_t wbytes = (size_t)N_PACKS * PACK_U4 * 16 + 4096;
+  std::vector<uint16_t> hw(wbytes / 2);
+  std::mt19937 rng(1);
+  for (auto& v : hw) { const _Float16 f = (_Float16)(((int)(rng() % 2001) - 1000) * 1e-4f); memcpy(&v, &f, 2); }
+  std::vector<float> par(5 * 128);
+  for (int i = 0; i < 128; ++i) { par[i] = 0.01f * (i % 7); par[128 + i] = 1.f + 0.01f * (i % 5); par[256 + i] = 0.02f * (i % 3); par[384 + i] = 0.05f; par[512 + i] = 1.f; }
+  const int max_wg = 512;
+  uint4 *dw, *dx; float *dpar, *dout; unsigned* dflag;
+  hipMalloc(&dw, wbytes); hipMalloc(&dpar, par.size() * 4); hipMalloc(&dout, (size_t)max_wg * 256 * 4);
+  hipMalloc(&dx, (size_t)max_wg * 2 * XCH_U4 * 16); hipMalloc(&dflag, max_wg * 4);
+  hipMemcpy(dw, hw.data(), wbytes, hipMemcpyHostToDevice); hipMemcpy(dpar, par.data(), par.size() * 4, hipMemcpyHostToDevice);
+  ConvP p{dw, dpar, dx, dflag};
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  std::vector<int> sizes;
+  for (int i = 1; i < argc; ++i) sizes.push_back(atoi(argv[i]));
+  if (sizes.empty()) sizes = {8, 32, 64, 128};               // workgroups of the base arm = sample pairs (x 2 = trajectories)
+  for (int nb : sizes) {
+    if (nb % 8 || 2 * nb > max_wg) { printf("skip %d (a multiple of 8, <= %d)\n", nb, max_wg / 2); continue; }
+    for (int mode = 0; mode < 4; ++mode) {
+      float best = 1e9f;
+      float check = 0.f;
+      for (int rep = 0; rep < 5; ++rep) {
+        hipMemset(dflag, 0, max_wg * 4);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        if (mode == 0) hipLaunchKernelGGL(conv_chain<0>, dim3(nb), dim3(256), 0, 0, p, dout, nconv);
+        else if (mode == 1) hipLaunchKernelGGL(conv_chain<1>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
+        else if (mode == 2) hipLaunchKernelGGL(conv_chain<2>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
+        else hipLaunchKernelGGL(conv_chain<3>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
+        hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+        hipMemcpy(&check, dout + 3, 4, hipMemcpyDeviceToHost);
+        unsigned timeouts = 0;
+        hipMemcpy(&timeouts, dflag + 511, 4, hipMemcpyDeviceToHost);
+        if (timeouts) printf("  !! %u flag waits timed out: the timing of this arm is void\n", timeouts);
+      }
+      printf("%4d trajectories  %-6s: %3d workgroups, %d convs (128 -> 128, L = 16): %7.1f us -> %5.2f us per conv   (check %.4f, %s)\n", 2 * nb,
+             mode == 0 ? "base" : mode == 1 ? "pair" : mode == 2 ? "half" : "pairL2", mode == 0 ? nb : 2 * nb, nconv, best * 1e3, best * 1e3 / nconv, check,
+             hipGetErrorString(hipGetLastError()));
+    }
+  }
+  return 0;
+}
