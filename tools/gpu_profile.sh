@@ -5,11 +5,11 @@
 # Usage: tools/gpu_profile.sh [tag]   (outputs under gpurun_out/<tag>_*)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out
 mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -25 | tee $OUT/${TAG}_pytest_gpu.log
-cp $OUT/r05_parity.json $OUT/${TAG}_parity.json 2>/dev/null
+timeout 2400 python -m pytest tests -m gpu -q -rf 2>&1 | tail -25 | tee $OUT/${TAG}_pytest_gpu.log
+cp $OUT/r06_parity.json $OUT/${TAG}_parity.json 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/${TAG}_smoke.log
 # PMC first: bench.py quotes profiles/pmc_latest.json for `traffic` / `mfma_busy_pmc` (copied there after the session)
 REPS=8 tools/gpu_pmc.sh ${TAG}_unet1024 unet_kernel -- python tools/unet_forward_loop.py 1024 > /dev/null
@@ -33,6 +33,10 @@ timeout 300 python tools/dbg/shard_cost.py weak 1 2 4 8 2>&1 | grep "W=" | tee -
 # a planning round of the headline workload with the option-1 network
 for v in 0 1; do MMD_AMD_LAYERED_VALU=$v timeout 300 python tools/dbg/layered_time.py 64 256 1024 4096 2>&1 | grep "n=" | tee -a $OUT/${TAG}_layered_time.txt; done
 for v in 0 1; do MMD_AMD_LAYERED_VALU=$v timeout 600 python tools/dbg/option1_round.py 3 2>&1 | grep "dim_mults" | tee -a $OUT/${TAG}_option1_round.txt; done
-# config4 with the planner calls one after the other (the default issues them concurrently)
-timeout 600 python bench.py --workload config4 --steps 10 --warmup 2 --sequential-planners --no-pmc --no-power-probe 2>>$OUT/bench.err | tee $OUT/${TAG}_bench_config4_sequential.json | cut -c1-260
+# config4 with the planner calls issued concurrently (one stream each) and one after the other (the default packs them into ONE launch sequence)
+timeout 600 python bench.py --workload config4 --steps 10 --warmup 2 --concurrent-planners --no-cpu-baseline --no-pmc --no-power-probe 2>>$OUT/bench.err | tee $OUT/${TAG}_bench_config4_concurrent.json | cut -c1-260
+timeout 600 python bench.py --workload config4 --steps 10 --warmup 2 --sequential-planners --no-cpu-baseline --no-pmc --no-power-probe 2>>$OUT/bench.err | tee $OUT/${TAG}_bench_config4_sequential.json | cut -c1-260
+cp $OUT/bench_detail_*.json $OUT/ 2>/dev/null; for f in $OUT/bench_detail_*_n1.json; do cp $f $OUT/${TAG}_$(basename $f); done
+timeout 300 python tools/dbg/planner_time.py 2>&1 | tail -2 | tee $OUT/${TAG}_planner_time.txt
+timeout 300 python tools/dbg/planner_breakdown.py 2>&1 | tail -1 | tee -a $OUT/${TAG}_planner_time.txt
 bash tools/gpu_rehearsal.sh ${TAG}
