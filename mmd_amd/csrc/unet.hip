@@ -2782,6 +2782,10 @@ int unet_persist_steps(mmd_unet_t u, int n, void* ws, size_t ws_bytes, hipStream
   MMD_REQUIRE(u && !u->layered && ws && n >= 1, "unet_persist_steps: bad arguments");
   MMD_REQUIRE(n_steps >= 1 && n_steps <= PERSIST_MAX_STEPS && ws_bytes >= (size_t)PERSIST_TABLE_BYTES, "unet_persist_steps: step table");
   for (int s = 0; s < n_steps; ++s) MMD_REQUIRE(steps[s].t_row >= 0 && steps[s].t_row < u->T, "unet_persist_steps: t outside the time table");
+  // (`steps` and the argument block below are PAGEABLE host memory: hipMemcpyAsync stages such a source into the runtime's own pinned
+  // buffer before it returns -- the documented behaviour for pageable memory -- so the caller's stack array may be reused for the next
+  // run; it also makes the copy host-synchronous, one reason this opt-in mode does not pay on the headline, and it is not legal inside a
+  // stream capture, which mmd_p_sample_loop checks before it takes this path.  The first 12 KiB of the workspace are clobbered.)
   MMD_HIP_CHECK(hipMemcpyAsync(ws, steps, sizeof(FusedStep) * n_steps, hipMemcpyHostToDevice, st));
   char* const args_dev = reinterpret_cast<char*>(ws) + PERSIST_ARGS_OFF;
   static const int kD0[] = {0, 1}, kD1[] = {2, 3}, kD2[] = {4, 5, 10, 11}, kU0[] = {6, 7}, kU1[] = {8, 9};

@@ -638,23 +638,26 @@ def plan_concurrently(calls, seeds=None):
     def run(j):
         planner, rest = calls[j][0], calls[j][1:]
         torch.cuda.set_device(devs[j])
-        side = _worker_stream(devs[j])
+        side = torch.cuda.Stream(devs[j])              # (from torch's per-device stream pool: see below why not a persistent one)
         side.wait_stream(parents[j])
         with torch.cuda.stream(side):
             out = planner(*rest, seed=int(seeds[j]))
-        # the result tensors were allocated on the side stream and are consumed on the caller's: tell the caching allocator (their
-        # blocks must not be recycled for side-stream work while caller-stream work on them is pending), and order the caller's
-        # stream after the side stream
-        for v in vars(out).values():
-            if torch.is_tensor(v) and v.is_cuda:
-                v.record_stream(parents[j])
+        # The result tensors live in the side stream's pool of the caching allocator and are consumed on the caller's stream.  A block the
+        # caller frees can only be handed out again by an allocation on the same pooled stream, i.e. inside a later plan_concurrently
+        # call -- and every call starts by making its side stream wait for everything queued on the caller's stream (wait_stream above),
+        # so work the caller queued on a result before dropping it is finished before the block is written again; the caller's stream is
+        # ordered after the side stream and the host waits for it (t_total and the host-side fields are final).
+        # Side streams are taken from torch's pool per CALL, not kept per worker: four persistent streams -- created per thread or up
+        # front -- run config 4's round in 46 ms where pool streams taken per call need 30 - 33 (measured, round 6; the hardware-queue
+        # placement of the first pool streams is the suspect).  The WORKER THREADS persist (the library keeps per-(thread, device)
+        # streams for its chunked loop: a fresh set of threads per call would leave a set behind every time).
         parents[j].wait_stream(side)
-        side.synchronize()                                  # (PlannerOutput.t_total and the host-side fields are final here)
+        side.synchronize()
         return out
     return list(_worker_pool(len(calls)).map(run, range(len(calls))))
 
 
-_POOL, _POOL_LOCK, _TLS = None, __import__("threading").Lock(), __import__("threading").local()
+_POOL, _POOL_LOCK = None, __import__("threading").Lock()
 
 
 def _worker_pool(n):
@@ -668,14 +671,6 @@ def _worker_pool(n):
                 _POOL.shutdown(wait=True)
             _POOL = ThreadPoolExecutor(max_workers=max(n, 4), thread_name_prefix="mmd-planner")
         return _POOL
-
-
-def _worker_stream(dev):
-    """the calling worker thread's own side stream on `dev` (created once per thread and device)."""
-    streams = _TLS.__dict__.setdefault("streams", {})
-    if dev not in streams:
-        streams[dev] = torch.cuda.Stream(dev)
-    return streams[dev]
 
 
 # ---- R independent planner calls as ONE launch sequence ----------------------------------------------------------------------------
