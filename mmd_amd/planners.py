@@ -561,26 +561,45 @@ class MPDEnsemble:
         for g in self.guides.values():
             g.reset_extra_costs()
 
+    def _post_guidance(self, chains):
+        """planner_alg 'diffusion_prior_then_guide' (mpd_ensemble.py:540-564, :603-627): after the prior sample every tile runs
+        (t_start_guide + n_diffusion_steps_without_noise) * n_guide_steps guide steps ON ITS OWN -- its guide (extra costs still
+        loaded), its own hard conditions, NO cross conditioning between the tiles -- and the states after every step are appended to
+        the tile's chain.  As in the reference a tile without an entry in `self.hard_conds` (a middle tile of K >= 3: only tiles 0 and
+        K - 1 have one, :293-296) raises KeyError."""
+        if not self.run_prior_then_guidance:
+            return chains
+        out = {}
+        for j, guide in self.guides.items():
+            skw = self.sample_kwargs[j]
+            n_post = (skw["t_start_guide"] + self.n_diffusion_steps_without_noise) * skw["n_guide_steps"]
+            hard_conds = self.hard_conds[j]                              # (KeyError for a tile without hard conditions, as :552)
+            x = chains[j][-1].contiguous().clone()
+            hard, mask = self.models[j]._hard_tensor(hard_conds, 1, HORIZON, x.device, x.shape[-1])
+            extra = torch.empty((n_post,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+            guide.guide_steps(x, hard, mask, n_post, chain=extra)        # ONE launch per tile; every iteration lands in `extra`
+            out[j] = torch.cat((chains[j], extra))
+        return out
+
     def run_constrained_inference(self, cost_constraints_l, **kw):
         self._add_constraints(cost_constraints_l)
         try:
-            return self.model.run_inference(None, self.hard_conds, cross_conds=self.cross_conds,
-                                            n_samples=self.num_samples, return_chain=True, sample_fn=ddpm_sample_fn,
-                                            sample_kwargs=self.sample_kwargs,
-                                            n_diffusion_steps_without_noise=self.n_diffusion_steps_without_noise,
-                                            device=self.device, **kw)
+            return self._post_guidance(self.model.run_inference(
+                None, self.hard_conds, cross_conds=self.cross_conds, n_samples=self.num_samples, return_chain=True,
+                sample_fn=ddpm_sample_fn, sample_kwargs=self.sample_kwargs,
+                n_diffusion_steps_without_noise=self.n_diffusion_steps_without_noise, device=self.device, **kw))
         finally:
             self._reset()
 
     def run_constrained_local_inference(self, cost_constraints_l, experience, **kw):
         self._add_constraints(cost_constraints_l)
         try:
-            return self.model.run_local_inference(
+            return self._post_guidance(self.model.run_local_inference(
                 experience.path_b.to(self.device), self.n_local_inference_noising_steps,
                 self.n_local_inference_denoising_steps, None, self.hard_conds, cross_conds=self.cross_conds,
                 n_samples=self.num_samples, return_chain=True, sample_fn=ddpm_sample_fn,
                 sample_kwargs=self.sample_kwargs,
-                n_diffusion_steps_without_noise=self.n_diffusion_steps_without_noise, device=self.device, **kw)
+                n_diffusion_steps_without_noise=self.n_diffusion_steps_without_noise, device=self.device, **kw))
         finally:
             self._reset()
 

@@ -233,3 +233,58 @@ def test_ensemble_task_boundary_contract_g21():
     assert torch.equal(p.task.inverse_transform_q(2, torch.zeros(2)), torch.tensor([-2.0, 2.0]))
     task_id, task = p.task.infer_task_id_from_q_idx(130)
     assert task_id == 2 and task is p.task.tasks[2]
+
+
+def test_mpd_ensemble_prior_then_guide_post_steps():
+    """planner_alg 'diffusion_prior_then_guide' on an MPDEnsemble (mpd_ensemble.py:540-564): after the UNGUIDED ensemble sample every
+    tile runs (t_start_guide + 1) * n_guide_steps guide steps on its own -- its guide with the routed constraints, its own hard
+    conditions, no stitching -- appended to its chain.  K = 2 (Highways | DropRegion) with a constraint per tile: the appended rows
+    against the oracle's guide steps restarted from the HIP prior sample (every row within 1e-3 -- no noise, the iteration contracts),
+    the prior rows bitwise those of planner_alg 'diffusion_prior' under the same seed; K = 3 raises KeyError as the reference does
+    (its middle tile has no entry in hard_conds)."""
+    from mmd_amd.constraints import MultiPointConstraint
+    from mmd_amd.planners import MPDEnsemble
+    T, B, n_gs = 25, 4, 3
+    tr = {0: torch.tensor([0.0, 0.0]), 1: torch.tensor([2.0, 0.0])}
+    envs = ("EnvHighways2D", "EnvDropRegion2D")
+    start, goal = torch.tensor([-0.6, 0.5]), torch.tensor([2.6, -0.3])
+    kw = dict(model_ids=tuple(e + "-RobotPlanarDisk" for e in envs), transforms=tr, start_state_pos=start, goal_state_pos=goal,
+              model_state_dicts=[cases.named_state_dict("g19")] * 2, model_args=dict(n_diffusion_steps=T), n_samples=B, device="cuda",
+              trained_models_dir="", n_guide_steps=n_gs)
+    cons = [MultiPointConstraint(q_l=[torch.tensor([0.3, 0.2]), torch.tensor([2.1, 0.1])], t_range_l=[(20, 30), (64 + 10, 64 + 20)]),
+            MultiPointConstraint(q_l=[torch.tensor([0.6, 0.0])], t_range_l=[(40, 44)], is_soft=True)]
+    p = MPDEnsemble(planner_alg="diffusion_prior_then_guide", **kw)
+    out = p(start, goal, constraints_l=cons, seed=321)
+    n_post = (ceil(0.5 * T) + 1) * n_gs
+    assert out.trajs_iters.shape == (T + 2 + n_post, B, 2 * H, D) and torch.isfinite(out.trajs_iters).all()
+    prior = MPDEnsemble(planner_alg="diffusion_prior", **kw)(start, goal, constraints_l=cons, seed=321)
+    assert torch.equal(out.trajs_iters[:T + 2], prior.trajs_iters)
+    assert all(g.extra_cost_l == [[]] for g in p.guides.values())
+    # the appended rows per tile against the oracle (normalised tile frame)
+    mins, maxs = cases.MINS, cases.MAXS
+    groups = {0: [cases.hard_group([[0.3, 0.2]], [[20, 30]]), O.ConstraintGroup(q=torch.tensor([[0.6, 0.0]]), t_range=torch.tensor([[40.0, 44.0]]),
+                                                                                 radius=torch.tensor([cases.RADIUS_SOFT]), weight=2e-2)],
+              1: [cases.hard_group([[0.1, 0.1]], [[10, 20]])]}
+    hard = {0: {0: O.normalize(torch.tensor([-0.6, 0.5, 0.0, 0.0]), mins, maxs)}, 1: {H - 1: O.normalize(torch.tensor([0.6, -0.3, 0.0, 0.0]), mins, maxs)}}
+    worst = 0.0
+    for m in (0, 1):
+        gp = cases.guide_params(envs[m], cutoff=0.01)
+        tile = out.trajs_iters[:, :, m * H:(m + 1) * H].cpu().clone()
+        tile[..., :2] -= tr[m]
+        x = O.normalize(tile[T + 1], mins, maxs)                         # the HIP prior sample of this tile, normalised
+        for k in range(n_post):
+            x = O.apply_hard_conditioning(x + O.guide_grad(x, gp, groups[m], clip_mode="always"), hard[m])
+            err = rel_l2(O.unnormalize(x, mins, maxs, clip_mode="always"), tile[T + 2 + k])
+            worst = max(worst, err)
+            assert err < 1e-3, (m, k, err)
+    parity_log.record("ensemble_prior_then_guide_post_steps", "K2", None, worst, bound=1e-3)
+    # K = 3: the middle tile has no hard conditions -> KeyError, as mpd_ensemble.py:552 `self.hard_conds[task_id]`
+    case = synth.ensemble3_case("fwd")
+    p3 = MPDEnsemble(model_ids=tuple(e + "-RobotPlanarDisk" for e in case["env_ids"]),
+                     transforms={m: torch.from_numpy(case["transforms"][m]) for m in range(3)}, planner_alg="diffusion_prior_then_guide",
+                     start_state_pos=torch.from_numpy(case["start"]), goal_state_pos=torch.from_numpy(case["goal"]),
+                     model_state_dicts=[cases.named_state_dict("g19")] * 3, model_args=dict(n_diffusion_steps=T), n_samples=B,
+                     device="cuda", trained_models_dir="", n_guide_steps=2)
+    with pytest.raises(KeyError):
+        p3(torch.from_numpy(case["start"]), torch.from_numpy(case["goal"]))
+    assert all(g.extra_cost_l == [[]] for g in p3.guides.values())
