@@ -1202,13 +1202,27 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
         for (int t = 0; t < 2; ++t) acc[2 * sl + mt][t] *= ds.s;
     }
   };
-  // one 64 -> 64 conv over the tile in acc (already scaled); on entry every wave is past its reads of the slab
-  auto conv = [&](const uint4* w) {
+  // one 64 -> 64 conv over the tile in acc (already scaled); on entry every wave is past its reads of the slab.  PF (one sample per
+  // wave = unet_kernel<2>, the latency-bound launches): the NEXT conv's first ring steps are requested right behind this conv's taps
+  // and travel during the epilogue (chain_body_d2d has the measurement); `frags_next`: the next pack's fragments per n-tile.
+#ifdef MMD_NO_PF
+  constexpr bool PF = false;
+#else
+  constexpr bool PF = SW == 1;
+#endif
+  auto prefetch = [&](const uint4* w, int frags) {
+    if constexpr (PF) {
+      const u32x4* wp[2] = {wptr(w, frags, 0), wptr(w, frags, 1)};
+      rd_ring_load<GH, 2, RD1>(ring, wp);
+    }
+  };
+  auto conv = [&](const uint4* w, const uint4* w_next, int frags_next) {
     const u32x4* wp[2] = {wptr(w, GH::FRAGS5, 0), wptr(w, GH::FRAGS5, 1)};
-    rd_ring_load<GH, 2, RD1>(ring, wp);
+    if constexpr (!PF) rd_ring_load<GH, 2, RD1>(ring, wp);
     store_tile();
     __syncthreads();
     rd_taps<GH, 2, 0, 5, true, false, NS, RD1>(acc, acc, vaH, wp, wp, ring);
+    prefetch(w_next, frags_next);
   };
   float one2[SW];
 #pragma unroll
@@ -1233,12 +1247,13 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     for (int m = 0; m < NS; ++m)
 #pragma unroll
       for (int t = 0; t < 2; ++t) res[m][t] = res[m][t] * (isr[t] * inv_in[m >> 1]) + br[t];
+    prefetch(a.r0.wb_bf, GH::FRAGS5);
     gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   }
   TR(trb + 1);
   {
     const Epi<2> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
-    conv(a.r0.wb_bf);                                        // (its slab is not the one conv A reads: no barrier before the store)
+    conv(a.r0.wb_bf, a.ri[0].wa_bf, GH::FRAGS5);             // (its slab is not the one conv A reads: no barrier before the store)
     gn(std::false_type{}, e, one2, 1.f);
   }
   TR(trb + 2);
@@ -1254,12 +1269,12 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     float inv[SW];
     scale_in(inv);
     const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
-    conv(R.wa_bf);
+    conv(R.wa_bf, R.wb_bf, GH::FRAGS5);
     gn(std::true_type{}, ea, inv, R.act_a);
     TR(trb + 3);
     __syncthreads();
     const Epi<2> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
-    conv(R.wb_bf);
+    conv(R.wb_bf, a.wt_bf0, GH::FRAGS3);                     // (next: the strided tail's 3-tap pack)
     gn(std::false_type{}, eb, one2, 1.f);
     TR(trb + 4);
 #pragma unroll
@@ -1275,7 +1290,7 @@ __device__ __forceinline__ void chain_body_d1d(const ChainArgs& a, float* lds, i
     scale_in(inv);
     const u32x4* wt[2] = {wptr(a.wt_bf0, GH::FRAGS3, 0), wptr(a.wt_bf0, GH::FRAGS3, 1)};
     const float bt[2] = {a.bt[c0], a.bt[c0 + 1]}, ist[2] = {a.ist0[c0], a.ist0[c0 + 1]};
-    rd_ring_load<GH, 2, RD1>(ring, wt);
+    if constexpr (!PF) rd_ring_load<GH, 2, RD1>(ring, wt);
     store_tile();
     __syncthreads();
     // (outputs q = 4 g + r = the even positions 2 q of the wave's samples: one M tile each, read at stride 2; the GEMM loop takes
@@ -1378,16 +1393,32 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
       rd_gn_mish<2, 256, false>(acc, e.b, e.g, e.be, e.is, inv, ActScale{}, [&](int sm, int t, int r) { return res[sm][t][r]; });
     }
   };
-  // one 128 -> 128 conv over the tile in acc (already scaled for f16x2); on entry every wave is past its reads of the slab
-  auto conv = [&](const uint4* w) {
+  // one 128 -> 128 conv over the tile in acc (already scaled for f16x2); on entry every wave is past its reads of the slab.
+  // PF (two trajectories per workgroup: the latency-bound launches of <= 512 trajectories, where nothing else on the CU covers an L2
+  // round trip): the first RDD weight steps of the NEXT conv are requested right behind this conv's taps, so they travel during the
+  // GroupNorm + Mish epilogue and the slab store instead of in front of the first MFMA (tools/ubench/pair_split.hip, arm basePF: 3 - 10 %
+  // of a conv); with four trajectories per workgroup the 48 ring registers would have to live through the epilogue of a 32-register tile.
+#ifdef MMD_NO_PF
+  constexpr bool PF = false;                                  // (A/B side build: profiles/r06_prefetch_ab.txt)
+#else
+  constexpr bool PF = NS == 2;
+#endif
+  auto prefetch = [&](const uint4* w) {
+    if constexpr (PF) {
+      const u32x4* wp[2] = {wptr(w, G128::FRAGS5, 0), wptr(w, G128::FRAGS5, 1)};
+      rd_ring_load<G128, 2, RDD>(ring, wp);
+    }
+  };
+  auto conv = [&](const uint4* w, const uint4* w_next) {
     const u32x4* wp[2] = {wptr(w, G128::FRAGS5, 0), wptr(w, G128::FRAGS5, 1)};
     TR(trb + 10);
-    rd_ring_load<G128, 2, RDD>(ring, wp);
+    if constexpr (!PF) rd_ring_load<G128, 2, RDD>(ring, wp);
     rd_store2<G128>(vs, acc);
     TR(trb + 11);
     __syncthreads();
     TR(trb + 12);
     rd_taps<G128, 2, 0, 5, true, false, NS, RDD>(acc, acc, va128, wp, wp, ring);
+    if (w_next) prefetch(w_next);
     TR(trb + 13);
   };
 
@@ -1409,13 +1440,14 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
       for (int t = 0; t < 2; ++t) res[sm][t] = res[sm][t] * (isr[t] * inv_in[sm]) + br[t];
     park_tile(lds, res);                                     // (every wave is past the barrier behind the x slab's last read)
   }
+  prefetch(a.r0.wb_bf);                                      // (the 64 -> 128 conv's depth-2 ring is consumed: RTB 0's conv B travels now)
   gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   TR(trb + 1);
   __syncthreads();                                           // conv A is done reading the 64-channel slab
   rd_zero_halo<G128>(slab);
   {
     const Epi<2> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
-    conv(a.r0.wb_bf);
+    conv(a.r0.wb_bf, CF::N_IDENT > 0 ? a.ri[0].wa_bf : nullptr);
     gn(std::false_type{}, e, one4, 1.f);
   }
 
@@ -1435,11 +1467,11 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
       for (int t = 0; t < 2; ++t) acc[sm][t] *= ds.s;
     }
     const Epi<2> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
-    conv(R.wa_bf);
+    conv(R.wa_bf, R.wb_bf);
     gn(std::true_type{}, ea, inv, R.act_a);
     __syncthreads();
     const Epi<2> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
-    conv(R.wb_bf);
+    conv(R.wb_bf, k + 1 < CF::N_IDENT ? a.ri[k + 1].wa_bf : nullptr);
     gn(std::false_type{}, eb, one4, 1.f);
     TR(trb + 18);
     if (CF::MID_AFTER == k + 1) {
@@ -1508,13 +1540,27 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
       acc[sm][0] *= ds.s;
     }
   };
-  // one 64 -> 64 conv over the tile in acc (already scaled); on entry every wave is past its reads of the slab
-  auto conv64 = [&](const uint4* w) {
+  // one 64 -> 64 conv over the tile in acc (already scaled); on entry every wave is past its reads of the slab.  PF (two trajectories
+  // per workgroup = unet_kernel<2>): the NEXT pack's first ring steps are requested right behind this conv's taps and travel during the
+  // epilogue (chain_body_d2d has the measurement); `frags_next`: the next pack's fragments per n-tile.
+#ifdef MMD_NO_PF
+  constexpr bool PF = false;
+#else
+  constexpr bool PF = NS == 2;
+#endif
+  auto prefetch64 = [&](const uint4* w, int frags) {
+    if constexpr (PF) {
+      const u32x4* wp[1] = {wptr(w, frags)};
+      rd_ring_load<G64, 1, RDC>(ring, wp);
+    }
+  };
+  auto conv64 = [&](const uint4* w, const uint4* w_next, int frags_next) {
     const u32x4* wp[1] = {wptr(w, G64::FRAGS5)};
-    rd_ring_load<G64, 1, RDC>(ring, wp);
+    if constexpr (!PF) rd_ring_load<G64, 1, RDC>(ring, wp);
     rd_store1<G64>(vs64, acc, lane);
     __syncthreads();
     rd_taps<G64, 1, 0, 5, true, false, NS, RDC>(acc, res, va64, wp, wp, ring);
+    prefetch64(w_next, frags_next);
   };
 
   // =================== RTB 0: cat(x0, x1) -> 64 channels; the 1x1 residual conv rides on the centre tap ===================
@@ -1548,13 +1594,14 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
   TR(165);
 #pragma unroll
   for (int sm = 0; sm < NS; ++sm) res[sm][0] = res[sm][0] * (isr * inv_in[sm]) + br;
+  prefetch64(a.r0.wb_bf, G64::FRAGS5);
   gn(std::true_type{}, e0a, inv_in, a.r0.act_a);
   TR(trb + 1);
   __syncthreads();                                           // chunk 1 is consumed
   rd_zero_halo<G64>(slab64);
   {
     const Epi<1> e = epi(a.r0.bb, a.r0.gb, a.r0.beb, nullptr, a.r0.isb);
-    conv64(a.r0.wb_bf);
+    conv64(a.r0.wb_bf, a.ri[0].wa_bf, G64::FRAGS5);
     gn(std::false_type{}, e, one4, 1.f);
   }
   TR(trb + 4);
@@ -1568,12 +1615,12 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     float inv[NS];
     dyn_scale_acc(inv);
     const Epi<1> ea = epi(R.ba, R.ga, R.bea, R.tb + tb_off, R.isa);
-    conv64(R.wa_bf);
+    conv64(R.wa_bf, R.wb_bf, G64::FRAGS5);
     gn(std::true_type{}, ea, inv, R.act_a);
     TR(trb + 5);
     __syncthreads();
     const Epi<1> eb = epi(R.bb, R.gb, R.beb, nullptr, R.isb);
-    conv64(R.wb_bf);
+    conv64(R.wb_bf, a.wt_bf0, 2 * G64::KC * 2);              // (next: the transposed tail's first parity pack)
     gn(std::false_type{}, eb, one4, 1.f);
     TR(trb + 6);
   }
@@ -1586,7 +1633,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
     const u32x4* wt0[1] = {wptr(a.wt_bf0, 2 * G64::KC * 2)};
     const u32x4* wt1[1] = {wptr(a.wt_bf1, 2 * G64::KC * 2)};
     const float bt = a.bt[col], is0 = a.ist0[col], is1 = a.ist1[col];
-    rd_ring_load<G64, 1, RDC>(ring, wt0);
+    if constexpr (!PF) rd_ring_load<G64, 1, RDC>(ring, wt0);
     rd_store1<G64>(vs64, acc, lane);
     __syncthreads();
     TR(trb + 7);

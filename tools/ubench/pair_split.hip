@@ -33,19 +33,21 @@ constexpr int XCH_U4 = 2 * 2 * G128::KC * 2 * G128::RPS;     // pieces x lane gr
 
 struct ConvP { const uint4* w; const float* par; uint4* xbuf; unsigned* flag; };
 
-// MODE 0 base, 1 pair (agent-scope release / acquire), 2 half (pair without the exchange), 3 pairL2 (see main: same-L2 protocol)
+// MODE 0 base, 1 pair (agent-scope release / acquire), 2 half (pair without the exchange), 3 pairL2 (see main: same-L2 protocol),
+// 4 basePF: base with the NEXT conv's first weight-ring steps requested before the current conv's GroupNorm + Mish epilogue
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_chain(ConvP p, float* out, int nconv) {
-  constexpr int NT = MODE == 0 ? 2 : 1, NS = 2;
+  constexpr int NT = (MODE == 0 || MODE == 4) ? 2 : 1, NS = 2;
+  constexpr bool BASE = MODE == 0 || MODE == 4;
   __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
   char* const slab = reinterpret_cast<char*>(lds);
   const char* const va = slab + g * G128::G + n * 16;
   // pair arms: consecutive workgroup ids go round the 8 XCDs, so ids i and i ^ 8 share an XCD (and its L2)
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, half = MODE == 0 ? 0 : (slot & 1), pair = (slot >> 1) * 8 + xcd;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, half = BASE ? 0 : (slot & 1), pair = (slot >> 1) * 8 + xcd;
   const int nt = 4 * half + wave;                            // pair arms: the wave's n-tile = channels 16 nt .. 16 nt + 15
-  const int c0 = MODE == 0 ? 32 * wave + 2 * n : 16 * nt + n;
-  char* const vs = MODE == 0 ? slab + wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4
+  const int c0 = BASE ? 32 * wave + 2 * n : 16 * nt + n;
+  char* const vs = BASE ? slab + wave * G128::G + (n >> 2) * G128::BX + (2 + 4 * g) * 16 + (n & 3) * 4
                              : slab + (nt >> 1) * G128::G + (2 * (nt & 1) + (n >> 3)) * G128::BX + (2 + 4 * g) * 16 + ((n & 7) >> 1) * 4;
   f32x4 acc[NS][NT], res[NS][NT];
   for (int s = 0; s < NS; ++s) for (int t = 0; t < NT; ++t) for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.01f * ((threadIdx.x * 7 + s * 3 + t + r + blockIdx.x) % 97) - 0.5f;
@@ -53,17 +55,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   float one[NS];
   for (int s = 0; s < NS; ++s) one[s] = 1.f;
   __syncthreads();
-  for (int k = 0; k < nconv; ++k) {
+  u32x4 ring[3][NT][2];
+  auto wptrs = [&](int k, const u32x4* (&wp)[NT]) {
     int woff[NT];
-    for (int t = 0; t < NT; ++t) woff[t] = (k % N_PACKS) * PACK_U4 + (MODE == 0 ? 2 * wave + t : nt) * G128::FRAGS5 * 64 + lane;
+    for (int t = 0; t < NT; ++t) woff[t] = (k % N_PACKS) * PACK_U4 + (BASE ? 2 * wave + t : nt) * G128::FRAGS5 * 64 + lane;
     if constexpr (NT == 2) asm volatile("" : "+v"(woff[0]), "+v"(woff[1]));
     else asm volatile("" : "+v"(woff[0]));
-    const u32x4* wp[NT];
     for (int t = 0; t < NT; ++t) wp[t] = reinterpret_cast<const u32x4*>(p.w) + woff[t];
+  };
+  if constexpr (MODE == 4) {
+    const u32x4* wp0[NT];
+    wptrs(0, wp0);
+    rd_ring_load<G128, NT, 3>(ring, wp0);
+  }
+  for (int k = 0; k < nconv; ++k) {
+    const u32x4* wp[NT];
+    wptrs(k, wp);
     const Epi<NT> e = epi_load<NT>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
-    u32x4 ring[3][NT][2];
-    rd_ring_load<G128, NT, 3>(ring, wp);
-    if constexpr (MODE == 0) rd_store2<G128, NS>(vs, acc);
+    if constexpr (MODE != 4) rd_ring_load<G128, NT, 3>(ring, wp);
+    if constexpr (BASE) rd_store2<G128, NS>(vs, acc);
     else rd_store1<G128, NS>(vs, reinterpret_cast<f32x4(&)[NS][1]>(acc), lane);
     __syncthreads();
     if constexpr (MODE == 1 || MODE == 3) {
@@ -98,6 +108,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       __syncthreads();
     }
     rd_taps<G128, NT, 0, 5, true, false, NS, 3>(acc, res, va, wp, wp, ring);
+    if constexpr (MODE == 4) {                                 // the next conv's first three weight steps travel during the epilogue
+      const u32x4* wpn[NT];
+      wptrs(k + 1, wpn);
+      rd_ring_load<G128, NT, 3>(ring, wpn);
+    }
     if constexpr (NT == 2) {
       const float t0 = e.tb[0], t1 = e.tb[1];
       rd_gn_mish<2, 256, true>(acc, e.b, e.g, e.be, e.is, one, act_scale(1.f), [&](int, int t, int) { return t ? t1 : t0; });
@@ -136,7 +151,7 @@ int main(int argc, char** argv) {
   if (sizes.empty()) sizes = {8, 32, 64, 128};               // workgroups of the base arm = sample pairs (x 2 = trajectories)
   for (int nb : sizes) {
     if (nb % 8 || 2 * nb > max_wg) { printf("skip %d (a multiple of 8, <= %d)\n", nb, max_wg / 2); continue; }
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
       float best = 1e9f;
       float check = 0.f;
       for (int rep = 0; rep < 5; ++rep) {
@@ -146,7 +161,8 @@ int main(int argc, char** argv) {
         if (mode == 0) hipLaunchKernelGGL(conv_chain<0>, dim3(nb), dim3(256), 0, 0, p, dout, nconv);
         else if (mode == 1) hipLaunchKernelGGL(conv_chain<1>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
         else if (mode == 2) hipLaunchKernelGGL(conv_chain<2>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
-        else hipLaunchKernelGGL(conv_chain<3>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
+        else if (mode == 3) hipLaunchKernelGGL(conv_chain<3>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
+        else hipLaunchKernelGGL(conv_chain<4>, dim3(nb), dim3(256), 0, 0, p, dout, nconv);
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best;
@@ -156,7 +172,7 @@ int main(int argc, char** argv) {
         if (timeouts) printf("  !! %u flag waits timed out: the timing of this arm is void\n", timeouts);
       }
       printf("%4d trajectories  %-6s: %3d workgroups, %d convs (128 -> 128, L = 16): %7.1f us -> %5.2f us per conv   (check %.4f, %s)\n", 2 * nb,
-             mode == 0 ? "base" : mode == 1 ? "pair" : mode == 2 ? "half" : "pairL2", mode == 0 ? nb : 2 * nb, nconv, best * 1e3, best * 1e3 / nconv, check,
+             mode == 0 ? "base" : mode == 1 ? "pair" : mode == 2 ? "half" : mode == 3 ? "pairL2" : "basePF", (mode == 0 || mode == 4) ? nb : 2 * nb, nconv, best * 1e3, best * 1e3 / nconv, check,
              hipGetErrorString(hipGetLastError()));
     }
   }
