@@ -160,10 +160,10 @@ class DiffusionsEnsemble:
 
     @torch.no_grad()
     def run_local_inference(self, seed_trajectory_b, n_noising_steps, n_denoising_steps, contexts=None, hard_conds=None,
-                            cross_conds=None, n_samples=1, return_chain=False, **diffusion_kwargs):
-        """diffusion_ensemble.py:265-313."""
+                            cross_conds=None, n_samples=1, return_chain=False, q_noise=None, **diffusion_kwargs):
+        """diffusion_ensemble.py:265-313.  `q_noise` [B, K*64, D]: the injected draw of the forward noising (parity tests)."""
         hard_conds = deepcopy(hard_conds)
-        noised = None if n_noising_steps is None else self.models[0].q_sample(seed_trajectory_b, n_noising_steps,
+        noised = None if n_noising_steps is None else self.models[0].q_sample(seed_trajectory_b, n_noising_steps, noise=q_noise,
                                                                               seed=diffusion_kwargs.get("seed"))
         x, chains = self.joint_conditional_sampling(hard_conds, deepcopy(cross_conds), n_diffusion_steps=n_denoising_steps,
                                                     batch_size=n_samples, return_chain=True, warm_start_path_b=noised,

@@ -798,6 +798,19 @@ def ensemble_p_sample_loop(sds, tb, x_init: Dict[int, torch.Tensor], hard_conds,
     return x, {m: torch.stack(v, dim=0) for m, v in chains.items()}
 
 
+def ensemble_warm_start(tb, seed_trajectory_b, n_noising_steps, q_noise, transforms, horizon=64):
+    """The warm start of DiffusionsEnsemble.run_local_inference (diffusion_ensemble.py:265-300 + p_sample_loop :66-72): the seed batch
+    [B, K*horizon, D] (GLOBAL frame, as the caller hands it over) is forward-noised as a whole (q_sample with ONE draw of the full
+    shape; None: taken as it is), tile m takes rows [m*horizon, (m+1)*horizon) and moves its positions into the tile frame."""
+    noised = seed_trajectory_b if n_noising_steps is None else q_sample(tb, seed_trajectory_b, n_noising_steps, q_noise)
+    x = {}
+    for m in transforms:
+        xm = noised[:, m * horizon:(m + 1) * horizon, :].clone()
+        xm[:, :, :2] -= torch.as_tensor(transforms[m])
+        x[m] = xm
+    return x
+
+
 def soft_constraints_from_paths(paths, agent_id, radius, weight, start_times=None):
     """CBS.create_soft_constraints_from_other_agents_paths (mmd/planners/multi_agent/cbs.py:468-508) for equal start
     times: every other robot's position at t (1 <= t <= H-1) constrains this robot at [t, t+1)."""

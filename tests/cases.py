@@ -287,3 +287,12 @@ def ensemble3_inputs(case, T, B):
     x0 = {m: torch.from_numpy(synth.synth_noise(case["seeds"]["x0"][m], (B, H, D))) for m in range(K)}
     steps = torch.from_numpy(synth.synth_noise(case["seeds"]["steps"], (T + 1, K, B, H, D)))
     return x0, steps
+
+
+def ensemble3_local_inputs(case, g, direction, B, K, n_denoise):
+    """golden g22's inputs: the stored seed batch (data), the q_sample draw and the step noise regenerated from their seeds."""
+    base = case["seeds"]["steps"]
+    seed = torch.from_numpy(g[f"{direction}.seed"])
+    qn = torch.from_numpy(synth.synth_noise(base + 21, (B, K * H, D)))
+    steps = torch.from_numpy(synth.synth_noise(base + 22, (n_denoise + 1, K, B, H, D)))
+    return seed, qn, steps

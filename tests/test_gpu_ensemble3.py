@@ -288,3 +288,50 @@ def test_mpd_ensemble_prior_then_guide_post_steps():
     with pytest.raises(KeyError):
         p3(torch.from_numpy(case["start"]), torch.from_numpy(case["goal"]))
     assert all(g.extra_cost_l == [[]] for g in p3.guides.values())
+
+
+@pytest.mark.parametrize("direction", cases.ENSEMBLE3_DIRECTIONS)
+def test_ensemble3_local_inference_golden_g22(direction):
+    """DiffusionsEnsemble.run_local_inference (the re-plan path: MPDEnsemble with an experience) on the 3-tile instance against the
+    reference (golden g22): row 0 = the whole-seed q_sample + the split into the tile frames (x and y offsets) + conditioning within 1e-6,
+    every later row under the chaos bound; each of the 3 + 1 outer steps teacher-forced from the reference's rows within 1e-3 per tile."""
+    import gpu_common as gc
+    from mmd_amd.diffusion_ensemble import DiffusionsEnsemble, apply_cross_conditioning
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    g = np.load(os.path.join(GOLDEN, "g22_ensemble3_local.npz"))
+    g20 = np.load(os.path.join(GOLDEN, "g20_ensemble3.npz"))
+    T, B, K, n_noise, n_denoise = (int(v) for v in g[f"{direction}.meta"])
+    case = synth.ensemble3_case(direction)
+    models = {m: gc.hip_model(T, "g19") for m in range(K)}
+    cons = cases.ensemble3_tile_groups(g20, direction, K)
+    guides = {m: gc.hip_guide(case["env_ids"][m], [cons[m]], cutoff=0.01) for m in range(K)}
+    transforms = {m: torch.from_numpy(case["transforms"][m]) for m in range(K)}
+    hard = cases.ensemble3_hard_conds(case)
+    cross = {(m, m + 1): (H - 1, 0) for m in range(K - 1)}
+    tsg = ceil(0.5 * T)
+    skw = {m: dict(guide=guides[m], n_guide_steps=20, t_start_guide=tsg, noise_std_extra_schedule_fn=lambda x: 0.5) for m in range(K)}
+    seed, qn, steps = cases.ensemble3_local_inputs(case, g, direction, B, K, n_denoise)
+    ens = DiffusionsEnsemble(models, transforms)
+    chains = ens.run_local_inference(seed.cuda(), n_noise, n_denoise, None, {m: dict(hard[m]) for m in range(K)}, cross_conds=cross,
+                                     n_samples=B, return_chain=True, q_noise=qn.cuda(), sample_fn=ddpm_sample_fn, sample_kwargs=skw,
+                                     n_diffusion_steps_without_noise=1, step_noise=steps.cuda())
+    for m in range(K):
+        ref, sens = g[f"{direction}.chain{m}"], g[f"{direction}.sens{m}"]
+        got = chains[m].cpu()
+        assert got.shape == ref.shape
+        assert rel_l2(got[0], ref[0]) < 1e-6, (m, rel_l2(got[0], ref[0]))
+        for r in range(ref.shape[0]):
+            err, bound = rel_l2(got[r], ref[r]), max(1e-3, 1.5 * cases.LIN * float(sens[r]))
+            parity_log.record(f"ensemble3_{direction}_local_inference_golden", f"tile{m}", r, err, sens=float(sens[r]), bound=bound)
+            assert err < bound, (m, r, err, bound)
+    # teacher-forced outer steps (all guided: i = 2, 1, 0, -1 < t_start_guide)
+    for k, i in enumerate(reversed(range(-1, n_denoise))):
+        xs = {m: torch.from_numpy(g[f"{direction}.chain{m}"][k]).cuda() for m in range(K)}
+        for m in range(K):
+            models[m].sample_step(xs[m], hard[m], i, noise=steps[k, m].cuda(), **skw[m])
+            xs = apply_cross_conditioning(xs, cross, transforms)
+        for m in range(K):
+            rows = slice(0, H) if (m == 0 or k == n_denoise) else slice(1, H - 1)
+            err = rel_l2(xs[m].cpu()[:, rows], g[f"{direction}.chain{m}"][k + 1][:, rows])
+            parity_log.record(f"ensemble3_{direction}_local_outer_step_vs_reference", f"tile{m}", i, err, bound=1e-3)
+            assert err < 1e-3, (m, k, i, err)

@@ -444,3 +444,33 @@ def test_g20_ensemble_planner_output_oracle(direction):
         assert abs(float(out["variance_waypoint_trajs_final_free"]) - float(g[f"{direction}.variance_waypoint"])) < 1e-5
     else:
         assert out["success_free_trajs"] == 0 and out["idx_best_traj"] is None
+
+
+@pytest.mark.parametrize("direction", cases.ENSEMBLE3_DIRECTIONS)
+def test_g22_ensemble3_local_inference_oracle(direction):
+    """DiffusionsEnsemble.run_local_inference on the 3-tile corner-turning instance (golden g22: the re-plan path of MPDEnsemble with an
+    experience): the whole [B, K*64, D] global-frame seed forward-noised by ONE q_sample draw, split into the tile frames (x AND y tile
+    offsets), then 3 + 1 guided steps with the routed constraints of g20 -- every chain row of every tile."""
+    g = np.load(os.path.join(GOLDEN, "g22_ensemble3_local.npz"))
+    g20 = np.load(os.path.join(GOLDEN, "g20_ensemble3.npz"))
+    T, B, K, n_noise, n_denoise = (int(v) for v in g[f"{direction}.meta"])
+    case = synth.ensemble3_case(direction)
+    sds = [O.state_dict_to_torch(cases.named_state_dict("g19"))] * K
+    tb = O.schedule_tables(T)
+    gps = [cases.guide_params(e, cutoff=0.01) for e in case["env_ids"]]
+    transforms = {m: torch.from_numpy(case["transforms"][m]) for m in range(K)}
+    hard = cases.ensemble3_hard_conds(case)
+    cross = {(m, m + 1): (H - 1, 0) for m in range(K - 1)}
+    cons = cases.ensemble3_tile_groups(g20, direction, K)
+    seed, qn, steps = cases.ensemble3_local_inputs(case, g, direction, B, K, n_denoise)
+    x0 = O.ensemble_warm_start(tb, seed, n_noise, qn, transforms)
+    guides = {m: (lambda y, m=m: O.guide_grad(y, gps[m], cons[m])) for m in range(K)}
+    x, chains = O.ensemble_p_sample_loop(sds, tb, x0, hard, cross, transforms, n_denoise, steps, guides=guides, n_guide_steps=20,
+                                         t_start_guide=ceil(0.5 * T), noise_std_extra=0.5, n_diffusion_steps_without_noise=1)
+    for m in range(K):
+        ref, sens = g[f"{direction}.chain{m}"], g[f"{direction}.sens{m}"]
+        assert chains[m].shape == ref.shape == (n_denoise + 2, B, H, D)
+        assert rel_l2(chains[m][0], ref[0]) < 1e-6, (direction, m, "row 0: q_sample + tile split + conditioning")
+        for r in range(n_denoise + 2):
+            err = rel_l2(chains[m][r], ref[r])
+            assert err < max(1e-5, 0.1 * float(sens[r])), (direction, m, r, err, float(sens[r]))

@@ -25,6 +25,8 @@ Fixtures:
                              the guided chains / sensitivities / multi-seed final rows of two constraint cases run with it
   g20_ensemble3.npz          3-tile corner-turning heterogeneous MPDEnsemble instance (x and y hops, both directions, per-tile maps
                              and weights, constraint routing, per-tile free / collision split + combine_trajs)
+  g22_ensemble3_local.npz    DiffusionsEnsemble.run_local_inference (the re-plan path) on the 3-tile instance: whole-seed q_sample, per-tile split
+                             into the tile frames, 3 + 1 guided denoising steps, both directions
   g21_ensemble_task.npz      PlanningTaskEnsemble.compute_collision / infer_task_id_from_q on global positions over the three tiles
   g15_distribution_*.npz     guided sampling over 32 noise seeds: final rows of every sample, their position mean / covariance per
                              support point, free / collision split and soft-constraint violation counts (distribution-level parity)
@@ -1098,11 +1100,100 @@ def g21():
     np.savez_compressed(os.path.join(OUT, "g21_ensemble_task.npz"), **out)
 
 
+def g22():
+    """DiffusionsEnsemble.run_local_inference on the 3-tile corner-turning instance (diffusion_ensemble.py:265-313: the re-plan path of
+    MPDEnsemble with an experience, mpd_ensemble.py:571-600): the seed batch [B, K*64, D] in the GLOBAL frame is forward-noised as a whole
+    by models[0].q_sample (ONE draw of the full shape), split per tile and moved to the tile frames (p_sample_loop :67-72, x and y tile
+    offsets), hard / cross conditioned, then denoised for 3 + 1 steps with the tile guides and the routed constraints of g20.  Both
+    directions; injected noise; every chain row of every tile + `sens`."""
+    import types
+    from mmd.models.diffusion_models.diffusion_ensemble import DiffusionsEnsemble
+    from mmd.planners.single_agent.mpd_ensemble import MPDEnsemble
+    from torch_robotics.tasks.tasks_ensemble import PlanningTaskEnsemble
+    import ref_harness
+    T, B, n_noise, n_denoise = 25, 4, 3, 3
+    out = {}
+    for direction in ("fwd", "rev"):
+        case = synth.ensemble3_case(direction)
+        K = len(case["env_ids"])
+        transforms = {j: torch.from_numpy(case["transforms"][j]) for j in range(K)}
+        with quiet():
+            models = {j: make_model(_state_dict_named("g19"), T) for j in range(K)}
+            guides, tasks = {}, {}
+            for j in range(K):
+                ref_harness._ENV_CACHE.pop((case["env_ids"][j], 0.01), None)
+                guides[j], robot_j, tasks[j], _ = make_guide(case["env_ids"][j], MINS, MAXS, cutoff_margin=0.01)
+                ref_harness._ENV_CACHE.pop((case["env_ids"][j], 0.01), None)
+                if j == 0:
+                    robot = robot_j
+            task_ens = PlanningTaskEnsemble(tasks, transforms, tensor_args=TENSOR_ARGS)
+        me = types.SimpleNamespace(task=task_ens, robot=robot, n_support_points=H, tensor_args=TENSOR_ARGS)
+        start, goal = torch.from_numpy(case["start"]), torch.from_numpy(case["goal"])
+        start_local, goal_local = task_ens.inverse_transform_q(0, start), task_ens.inverse_transform_q(K - 1, goal)
+        hard_conds = {0: {0: hard_conds_for(start_local.numpy(), start_local.numpy())[0]}}
+        hard_conds.setdefault(K - 1, {})[-1] = hard_conds_for(goal_local.numpy(), goal_local.numpy())[0]
+        cross_conds = {(i, i + 1): (H - 1, 0) for i in range(K - 1)}
+        with quiet():
+            split = MPDEnsemble.split_cost_constraints_to_tasks(me, [make_cost_constraint(robot, q, tr, r, soft) for (q, tr, r, soft) in case["constraints"]])
+        for task_id, cl in split.items():
+            for c in cl:
+                c.traj_ranges -= task_id * H
+                c.qs -= transforms[task_id]
+                guides[task_id].add_extra_costs([c], [2e-1 if not c.is_soft else 2e-2])
+        # the seed: a piecewise-linear GLOBAL path start -> tile centres' joints -> goal with zero velocity, + small noise (the caller
+        # passes the previous call's un-normalised, smoothed trajs_final: cbs.py:424 -> mpd_ensemble.py:571)
+        way = [case["start"]] + [0.5 * (case["transforms"][j] + case["transforms"][j + 1]) for j in range(K - 1)] + [case["goal"]]
+        segs = []
+        for j in range(K):
+            a = np.linspace(0.0, 1.0, H, dtype=np.float32)[:, None]
+            segs.append(way[j][None] * (1 - a) + way[j + 1][None] * a)
+        pos = np.concatenate(segs, 0)                                                   # [K*64, 2]
+        seed = np.concatenate([np.repeat(pos[None], B, 0), np.zeros((B, K * H, 2), np.float32)], -1)
+        seed = (seed + 0.02 * synth.synth_noise(case["seeds"]["steps"] + 20, (B, K * H, D))).astype(np.float32)
+        qn = synth.synth_noise(case["seeds"]["steps"] + 21, (B, K * H, D))
+        steps = synth.synth_noise(case["seeds"]["steps"] + 22, (n_denoise + 1, K, B, H, D))
+        draws = [qn] + [steps[k, j] for k in range(n_denoise + 1) for j in range(K)]
+        sample_kwargs = [dict(guide=guides[j], n_guide_steps=20, t_start_guide=ceil(0.5 * T), noise_std_extra_schedule_fn=lambda x: 0.5)
+                         for j in range(K)]
+        ens = DiffusionsEnsemble(models, transforms)
+
+        def run(perturb=0.0, ps=0):
+            handles = []
+            if perturb:
+                gen = torch.Generator().manual_seed(ps)
+                for j in range(K):
+                    handles.append(models[j].model.register_forward_hook(
+                        lambda mod, inp, o: o * (1 + perturb * torch.empty(o.shape).normal_(generator=gen))))
+            with quiet(), injected_noise(draws) as q:
+                chains = ens.run_local_inference(torch.from_numpy(seed), n_noise, n_denoise, None, hard_conds, cross_conds=cross_conds,
+                                                 n_samples=B, return_chain=True, sample_fn=ddpm_sample_fn, sample_kwargs=sample_kwargs,
+                                                 n_diffusion_steps_without_noise=1)
+                assert len(q) == 0
+            for h in handles:
+                h.remove()
+            return {j: chains[j].clone() for j in range(K)}
+
+        chains = run()
+        sens = {j: np.zeros(n_denoise + 2) for j in range(K)}
+        for ps in range(1, N_SENS_DRAWS + 1):
+            pert = run(1e-6, ps)
+            for j in range(K):
+                sens[j] = np.maximum(sens[j], [rel_l2(pert[j][r].numpy(), chains[j][r].numpy()) for r in range(n_denoise + 2)])
+        for j in range(K):
+            out[f"{direction}.chain{j}"] = chains[j].numpy()
+            out[f"{direction}.sens{j}"] = sens[j]
+            guides[j].reset_extra_costs()
+        out[f"{direction}.seed"] = seed
+        out[f"{direction}.meta"] = np.array([T, B, K, n_noise, n_denoise])
+        print(f"   g22 {direction}: chain shapes {[tuple(chains[j].shape) for j in range(K)]}, final-row sens {[float(sens[j][-1]) for j in range(K)]}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "g22_ensemble3_local.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    todo = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     for name in todo:
         print("generating", name, flush=True)
-        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17, "g18": g18, "g19": g19, "g20": g20, "g21": g21}[name]()
+        {"g1": g1, "g2": g2, "g3": g3, "g45": g4_g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g6full": g6_full, "g15": g15, "g16": g16, "g17": g17, "g18": g18, "g19": g19, "g20": g20, "g21": g21, "g22": g22}[name]()
     print("done")
