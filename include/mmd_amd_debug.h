@@ -45,8 +45,8 @@ double mmd_unet_flops_per_trajectory(void);
 double mmd_unet_mfma_flops_per_trajectory(void);
 double mmd_unet_f16x2_flops_per_trajectory(void);
 
-/* How many concurrent stream chunks mmd_p_sample_loop splits a batch into for this n_streams setting (the load-time
- * MMD_AMD_STREAMS override included): what a measurement needs to know the launch shape. */
+/* How many concurrent stream chunks mmd_p_sample_loop splits a batch into for this n_streams setting (0 = the
+ * library's automatic choice): what a measurement needs to know the launch shape. */
 int mmd_sampler_stream_chunks(int n_streams, int n_robots, int samples_per_robot);
 
 /* mmd_unet_forward with the profiler attached (what mmd_p_sample_loop does internally when desc.profiler is set). */

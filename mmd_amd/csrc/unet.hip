@@ -19,7 +19,7 @@
 // in register tiles; the two skip connections wait in registers for the up path; nothing but the input, the output
 // and the weights touches HBM/L2.  In the 16x16 C/D layout a lane holds 4 consecutive positions of one channel per tile, so a GroupNorm group is a few lanes of one DPP row (x row blocks): the statistics are
 // in-register + cross-lane reductions.  Weights are pre-packed on the host in MFMA B-fragment order (fp16 pairs) and fetched straight from L2 through a register ring (no LDS
-// staging: a B element is used once per workgroup).  DESIGN.md section 3.1 has the measurements behind each choice.
+// staging: a B element is used once per workgroup).  HISTORY.md section 3.1 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -225,7 +225,7 @@ constexpr int UNET_LDS_FLOATS = PARK2_OFF + 3 * 256 * 4;
 // DIRECT f16x2 convolutions on a row-form slab (downs.1, downs.2 + mid blocks, ups.0; the wave-private stages use the same
 // GEMM loop on per-wave slabs).  Every weight fragment is re-used on 64 GEMM rows (a wave's unit is 1-2 n-tiles x the FOUR M
 // tiles = samples of the workgroup), a conv is ONE slab store and one barrier pair, 8 accumulator streams (32-64 registers).
-// (DESIGN.md section 3.1 has the history: the transform-domain forms of rounds 1-2 were bound by their weight stream.)
+// (HISTORY.md section 3.1 has the history: the transform-domain forms of rounds 1-2 were bound by their weight stream.)
 // GEMM: M tile s = sample s, row i = position; the taps of a k = 5 conv are row-shifted views of the slab
 //     Rd[piece][lane group j][chunk kc][row = 20 s + 2 + position][8 channels]   (fp16, 2-row zero halo per sample)
 // (channel block kc + KC j, KC = C / 32: the four blocks of a K = 32 chunk lie G = a multiple of 256 B apart, so a b128 A

@@ -1,5 +1,5 @@
 // Would ONE 512-register wave per SIMD that interleaves the MFMAs of one 4-sample half with the GroupNorm + Mish epilogue of the
-// other beat TWO 256-register workgroups per CU running in lockstep?    The loop body is downs.2's
+// other beat TWO 256-register workgroups per CU running in lockstep?  (HISTORY.md section 7, item 1.)  The loop body is downs.2's
 // 128 -> 128 conv exactly as unet_kernel runs it (rd_store2 -> barrier -> rd_taps -> rd_gn_mish, this file includes unet.hip):
 //   base: 512 workgroups of 4 samples, 2 per CU  (hipcc ... -o fat_base)
 //   fat : 256 workgroups of 8 samples = two halves; per phase the taps of one half and the epilogue + slab store of the other sit
