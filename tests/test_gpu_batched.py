@@ -171,3 +171,30 @@ def test_robot_seeds_reproduce_separate_calls_through_every_step_kernel():
                 assert torch.equal(got[r * B:(r + 1) * B], one), (flags, r)
     finally:
         model.sampler_flags = 0
+
+
+def test_robot_seeds_across_stream_chunks():
+    """32 robots x 64 samples = 2048 trajectories: mmd_p_sample_loop splits the robots into two stream chunks (and uses the
+    four-trajectories-per-workgroup UNet kernel); with per-robot Philox streams every robot's rows must still be exactly what its own
+    one-robot call with that seed draws (robots 0, 15, 16 -- the chunk boundary -- and 31 are checked)."""
+    import gpu_common
+    from mmd_amd import _lib
+    from mmd_amd.diffusion_model import ddpm_sample_fn
+    T, R, B = 25, 32, 64
+    model = gpu_common.hip_model(T)
+    assert _lib.load().mmd_sampler_stream_chunks(0, R, B) == 2
+    starts, goals = synth.start_goal_circle(R, 0.8)
+    paths = synth.straight_line_paths(starts, goals, H)
+    hc = {0: torch.stack([cases.hard_conds_for(starts[r], goals[r])[0] for r in range(R)]),
+          H - 1: torch.stack([cases.hard_conds_for(starts[r], goals[r])[H - 1] for r in range(R)])}
+    seeds = [9000 + 7 * r for r in range(R)]
+    kw = dict(horizon=H, return_chain=False, sample_fn=ddpm_sample_fn, n_guide_steps=20, t_start_guide=13,
+              noise_std_extra_schedule_fn=lambda t: 0.5, n_diffusion_steps_without_noise=1)
+    guide = gpu_common.hip_guide("EnvEmpty2D", [[cases.soft_group(paths, r)] for r in range(R)], n_robots=R)
+    got = model.run_inference(None, hc, n_samples=B, n_robots=R, guide=guide, robot_seeds=seeds, **kw)
+    for r in (0, 15, 16, 31):
+        g1 = gpu_common.hip_guide("EnvEmpty2D", [[cases.soft_group(paths, r)]])
+        one = model.run_inference(None, {k: v[r] for k, v in hc.items()}, n_samples=B, n_robots=1, guide=g1, seed=seeds[r], **kw)
+        assert torch.equal(got[r * B:(r + 1) * B], one), r
+    with pytest.raises(ValueError):
+        model.run_inference(None, hc, n_samples=B, n_robots=R, guide=guide, robot_seeds=seeds[:5], **kw)
