@@ -179,7 +179,7 @@ def parse():
                     help="config4: the planner calls of a round on one host thread + stream each (plan_concurrently) instead of batched")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the dominant kernel that fill roofline.traffic")
-    ap.add_argument("--streams", type=int, default=0, help="mmd_sampler_desc.n_streams of the sharded sampler (0 = the library's choice: 2 chunks from 2048 trajectories, A/B: tools/gpu_streams.sh)")
+    ap.add_argument("--streams", type=int, default=0, help="mmd_sampler_desc.n_streams of the sharded sampler (0 = the library's choice: 2 chunks above 512 trajectories, A/B: tools/gpu_streams.sh)")
     ap.add_argument("--guide-coop-max", type=int, default=0, help="mmd_sampler_desc.guide_coop_max (A/B: launches up to this size run the four-waves-per-trajectory guide kernel; 0 = the library's 512)")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=100)
@@ -367,7 +367,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
 
     lib = _lib.load()
     n_traj_local = RPG * B
-    # the launch shape the library will use: concurrent stream chunks per UNet / step launch (2 from 2048 trajectories on)
+    # the launch shape the library will use: concurrent stream chunks per UNet / step launch (2 above 512 trajectories)
     chunks = lib.mmd_sampler_stream_chunks(sampler.n_streams, RPG, B)
     for w in range(args.warmup):
         _, paths_local = sampler.plan_round(paths_local, seed=1000 + w)

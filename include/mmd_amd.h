@@ -184,7 +184,7 @@ typedef struct mmd_sampler_desc {
   uint64_t hard_rows;                       /* as in mmd_guide_steps */
   int32_t n_streams;                        /* mmd_p_sample_loop splits the robots into this many concurrent HIP
                                              * streams (forked from / joined to `stream`) so one chunk's staging and
-                                             * epilogues overlap the other's MFMA phases; 0 = auto (2 from 2048
+                                             * epilogues overlap the other's MFMA phases; 0 = auto (2 above 512
                                              * trajectories, else 1), 1 = off */
   int64_t traj_index_base;                  /* GLOBAL index of this call's trajectory 0 (= first global robot * samples per
                                              * robot).  The in-kernel Philox4x32-10 draws are keyed by (seed, draw, global

@@ -40,13 +40,16 @@ constexpr int kMaxChunks = 4;
 //     persistent launch replaces the two interleaved stream chunks, which are worth more there).
 
 // Number of concurrent stream chunks mmd_p_sample_loop splits n_robots x samples_per_robot trajectories into.  auto (n_streams
-// <= 0): 2 chunks once a chunk alone fills the chip (>= 1024 trajectories = one workgroup per CU): +6 .. 12 % on the 32-robot
-// round (profiles/r03b_stream_chunks.txt) -- one chunk's guided step kernel runs beside the other chunk's UNet launch, and a
-// chunk's forward no longer ends with CUs idling until its slowest workgroup is done.  Smaller batches stay whole: two
-// half-empty launches would share CUs that one leaves free.
+// <= 0): 2 chunks as soon as the batch exceeds 512 trajectories, 1 below.  From 2048 on (a chunk alone fills the chip: one workgroup
+// per CU) one chunk's guided step kernel runs beside the other chunk's UNet launch and a chunk's forward no longer ends with CUs
+// idling until its slowest workgroup is done: +6 .. 12 % on the 32-robot round (profiles/r03b_stream_chunks.txt).  Between 512 and
+// 2048 (round 6, profiles/r06_chunk_sweep.txt) a single launch runs four trajectories per workgroup on a fraction of the CUs (640
+// trajectories = 160 workgroups, 120 us); two chunks of <= 512 run the two-trajectory kernel side by side on twice the CUs:
+// -15 % at 576 / 1280, -13 % at 640 / 1536, -5 % at 1024, -9 % at 2048.  At <= 512 the whole batch already is one
+// two-trajectory launch and a split only adds launches (+8 %).  Results are bit-identical either way.
 static int stream_chunks(int n_streams, int n_robots, int samples_per_robot) {
   int nch = n_streams;
-  if (nch <= 0) nch = (long long)n_robots * samples_per_robot >= 2048 ? 2 : 1;
+  if (nch <= 0) nch = (long long)n_robots * samples_per_robot > 512 ? 2 : 1;
   if (nch > kMaxChunks) nch = kMaxChunks;
   if (nch > n_robots) nch = n_robots;
   return nch < 1 ? 1 : nch;

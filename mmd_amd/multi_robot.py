@@ -77,7 +77,7 @@ class MultiRobotSampler:
         self.t_start_guide = ceil(start_guide_steps_fraction * model.n_diffusion_steps)
         self.n_extra = n_diffusion_steps_without_noise
         self.w_soft, self.radius = weight_grad_cost_soft_constraints, radius
-        self.n_streams = n_streams      # mmd_sampler_desc.n_streams (0 = the library's choice: 2 chunks from 2048 trajectories)
+        self.n_streams = n_streams      # mmd_sampler_desc.n_streams (0 = the library's choice: 2 chunks above 512 trajectories)
         # False: no inter-robot term (BASELINE config 2: every robot guided by the map, the workspace and the GP prior alone) --
         # plan_round then needs no exchange step either
         self.inter_robot = inter_robot
