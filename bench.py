@@ -181,6 +181,7 @@ def parse():
                     help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the dominant kernel that fill roofline.traffic")
     ap.add_argument("--streams", type=int, default=0, help="mmd_sampler_desc.n_streams of the sharded sampler (0 = the library's choice: 2 chunks above 512 trajectories, A/B: tools/gpu_streams.sh)")
     ap.add_argument("--guide-coop-max", type=int, default=0, help="mmd_sampler_desc.guide_coop_max (A/B: launches up to this size run the four-waves-per-trajectory guide kernel; 0 = the library's 512)")
+    ap.add_argument("--ns2-max", type=int, default=0, help="mmd_unet_options.two_per_workgroup_max (A/B: launches up to this size run two trajectories per workgroup; 0 = the library's 512)")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -334,7 +335,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     else:
         RPG = W["robots"]
     n_robots = RPG * world
-    unet = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=32, dim_mults=(1, 2, 4))
+    unet = TemporalUnet(state_dim=4, n_support_points=H, unet_input_dim=32, dim_mults=(1, 2, 4), two_per_workgroup_max=args.ns2_max)
     unet.load_state_dict(synth.synth_unet_state_dict(0))
     model = GaussianDiffusionModel(model=unet, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True)
     model.guide_coop_max = args.guide_coop_max
