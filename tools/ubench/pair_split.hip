@@ -27,6 +27,9 @@
 
 namespace mmd {
 using G128 = RdGeo<128>;
+#ifndef UB_RD
+#define UB_RD 3                                              // weight ring depth in steps (the product kernel: 3)
+#endif
 constexpr int N_PACKS = 7;                                   // the seven 128 -> 128 convs of downs.2 + mid
 constexpr int PACK_U4 = 8 * G128::FRAGS5 * 64;               // uint4 per conv: 8 n-tiles x 40 fragments x 64 lanes = 320 KB
 constexpr int XCH_U4 = 2 * 2 * G128::KC * 2 * G128::RPS;     // pieces x lane groups of a half x chunks x rows of two samples = 640
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   float one[NS];
   for (int s = 0; s < NS; ++s) one[s] = 1.f;
   __syncthreads();
-  u32x4 ring[3][NT][2];
+  u32x4 ring[UB_RD][NT][2];
   auto wptrs = [&](int k, const u32x4* (&wp)[NT]) {
     int woff[NT];
     for (int t = 0; t < NT; ++t) woff[t] = (k % N_PACKS) * PACK_U4 + (BASE ? 2 * wave + t : nt) * G128::FRAGS5 * 64 + lane;
@@ -66,13 +69,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   if constexpr (MODE == 4) {
     const u32x4* wp0[NT];
     wptrs(0, wp0);
-    rd_ring_load<G128, NT, 3>(ring, wp0);
+    rd_ring_load<G128, NT, UB_RD>(ring, wp0);
   }
   for (int k = 0; k < nconv; ++k) {
     const u32x4* wp[NT];
     wptrs(k, wp);
     const Epi<NT> e = epi_load<NT>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
-    if constexpr (MODE != 4) rd_ring_load<G128, NT, 3>(ring, wp);
+    if constexpr (MODE != 4) rd_ring_load<G128, NT, UB_RD>(ring, wp);
     if constexpr (BASE) rd_store2<G128, NS>(vs, acc);
     else rd_store1<G128, NS>(vs, reinterpret_cast<f32x4(&)[NS][1]>(acc), lane);
     __syncthreads();
@@ -107,11 +110,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       for (int idx = threadIdx.x; idx < XCH_U4; idx += 256) *slab_at(idx, half ^ 1) = theirs[idx];
       __syncthreads();
     }
-    rd_taps<G128, NT, 0, 5, true, false, NS, 3>(acc, res, va, wp, wp, ring);
+    rd_taps<G128, NT, 0, 5, true, false, NS, UB_RD>(acc, res, va, wp, wp, ring);
     if constexpr (MODE == 4) {                                 // the next conv's first three weight steps travel during the epilogue
       const u32x4* wpn[NT];
       wptrs(k + 1, wpn);
-      rd_ring_load<G128, NT, 3>(ring, wpn);
+      rd_ring_load<G128, NT, UB_RD>(ring, wpn);
     }
     if constexpr (NT == 2) {
       const float t0 = e.tb[0], t1 = e.tb[1];
