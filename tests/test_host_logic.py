@@ -321,3 +321,41 @@ def test_ensemble_ddim_fails_the_way_the_reference_does():
         ens.run_inference(None, {0: {}, 1: {}}, cross_conds={(0, 1): (H - 1, 0)}, n_samples=4, ddim=True, sample_kwargs={0: {}, 1: {}})
     with pytest.raises(ValueError):
         ens.joint_conditional_sampling({0: {}, 1: {}}, {}, n_diffusion_steps=None)
+
+
+def test_pack_constraints_randomized_vs_oracle_slot_table():
+    """mmd_pack_constraints against the oracle's slot_table (the layout both sides define: a point covers the integer t with
+    ceil(t0) <= t < ceil(t1), its slot = its rank among the points covering t, in list order) on 40 random groups: overlapping, empty,
+    reversed, fractional and out-of-horizon ranges (negative starts, ends beyond H), 1 to 150 points, per-point radii; a group whose only range lies beyond the horizon owns no slot."""
+    from oracle import mmd_oracle as O
+    rng = np.random.Generator(np.random.PCG64(77))
+    groups = []
+    for k in range(40):
+        n = int(rng.integers(1, 150))
+        q = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        t0 = rng.uniform(-6, 70, n)
+        ln = rng.choice([0.0, 0.5, 1.0, 3.0, 9.5, 40.0, -2.0], n) if n else np.zeros(0)
+        if k % 3 == 0:
+            t0, ln = np.floor(t0), np.round(ln)
+        tr = np.stack([t0, t0 + ln], 1).astype(np.float32).reshape(n, 2)
+        r = rng.uniform(0.05, 0.3, n).astype(np.float32)
+        groups.append(CostConstraint(None, H, q_l=torch.from_numpy(q), traj_range_l=tr, radius_l=r))
+    groups = groups + [CostConstraint(None, H, q_l=np.zeros((1, 2), np.float32), traj_range_l=[(70, 90)], radius_l=[0.1])]
+    ell, slots = _pack(groups)
+    off = 0
+    for g, S in zip(groups, slots):
+        grp = O.ConstraintGroup(q=torch.from_numpy(g.qs), t_range=torch.from_numpy(g.traj_ranges), radius=torch.from_numpy(g.radii), weight=1.0)
+        tab = O.slot_table(grp).numpy()                                  # [S', H] point index or -1
+        S_ref = int((tab >= 0).any(1).sum())
+        assert S == S_ref, (S, S_ref)
+        blk = ell[off:off + S]
+        for s in range(S):
+            for t in range(H):
+                p = tab[s, t]
+                if p < 0:
+                    assert blk[s, t, 2] < 0 and blk[s, t, 3] < 0, (s, t)
+                else:
+                    want = (g.qs[p, 0], g.qs[p, 1], g.radii[p], np.float32(g.radii[p] * abs(g.radii[p])))
+                    assert tuple(blk[s, t]) == want, (s, t, tuple(blk[s, t]), want)
+        off += S
+    assert off == ell.shape[0] or (off == 0 and ell.shape[0] == 0)
