@@ -47,6 +47,8 @@ def _points_xy(q_l) -> np.ndarray:
         q = q_l
     else:
         q_l = list(q_l)
+        if not q_l:            # (the reference's torch.stack(q_l) at cost_functions.py:293 fails the same way)
+            raise RuntimeError("CostConstraint: stack expects a non-empty list of constraint points")
         try:                                        # (per-element Python work is what costs: one stack, no per-point calls)
             q = torch.stack(q_l)
         except (TypeError, RuntimeError):           # not all tensors, or mixed shapes / devices: the element-wise path

@@ -323,6 +323,12 @@ def test_ensemble_ddim_fails_the_way_the_reference_does():
         ens.joint_conditional_sampling({0: {}, 1: {}}, {}, n_diffusion_steps=None)
 
 
+def test_empty_constraint_is_refused_like_the_reference():
+    """CostConstraint(q_l=[]) fails in the reference (torch.stack of an empty list, cost_functions.py:293: RuntimeError)."""
+    with pytest.raises(RuntimeError):
+        CostConstraint(None, H, q_l=[], traj_range_l=[], radius_l=[])
+
+
 def test_pack_constraints_randomized_vs_oracle_slot_table():
     """mmd_pack_constraints against the oracle's slot_table (the layout both sides define: a point covers the integer t with
     ceil(t0) <= t < ceil(t1), its slot = its rank among the points covering t, in list order) on 40 random groups: overlapping, empty,
