@@ -353,11 +353,13 @@ int mmd_points_collision(const mmd_guide_desc* env, const float* points_dev, int
                          float margin, uint8_t* out_dev, void* stream);
 
 /* LimitsNormalizer.unnormalize (mmd/datasets/normalization.py:157-168; TrajectoryDataset.unnormalize_trajectories, what MPD.__call__
- * applies to the sampled chain, mpd.py:344-347) for n_points float4 states (x, y, vx, vy): the WHOLE tensor is clipped to [-1, 1] iff any
- * element lies outside [-1 - eps, 1 + eps] (the reference's data-dependent clip, decided on the device: flag_dev is one uint32 of
- * scratch), then x_u = (x + 1) / 2 * (maxs - mins) + mins.  mins / maxs: host [4].  out_dev may alias x_dev. */
-int mmd_unnormalize_trajs(const float* x_dev, size_t n_points, const float* mins, const float* maxs, float eps, float* out_dev,
-                          uint32_t* flag_dev, void* stream);
+ * applies to the sampled chain, mpd.py:344-347) for n_points float4 states (x, y, vx, vy): a tensor is clipped to [-1, 1] as a WHOLE iff any of
+ * its elements lies outside [-1 - eps, 1 + eps] (the reference's data-dependent clip, decided on the device), then x_u = (x + 1) / 2 *
+ * (maxs - mins) + mins.  One call may hold SEVERAL tensors interleaved (the chains of R planner calls batched robot-major, [steps][R][B*H]):
+ * point i belongs to tensor (i % period_points) / segment_points, each tensor gets its own clip decision; period_points = segment_points = 0
+ * means one tensor.  flags_dev: period_points / segment_points uint32 of scratch.  mins / maxs: host [4].  out_dev may alias x_dev. */
+int mmd_unnormalize_trajs(const float* x_dev, size_t n_points, size_t period_points, size_t segment_points, const float* mins,
+                          const float* maxs, float eps, float* out_dev, uint32_t* flags_dev, void* stream);
 
 /* compute_variance_waypoints (trajectory/metrics.py:17-27): var_per_waypoint_dev[t] = unbiased variance of all
  * n_traj^2 entries of triu(cdist(p_t, p_t), 1); the metric is their sum over t. */

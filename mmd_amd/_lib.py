@@ -113,8 +113,8 @@ _SIGNATURES = {
     "mmd_points_collision": (C.c_int, [C.POINTER(GuideDesc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                        C.c_void_p]),
     "mmd_variance_waypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "mmd_unnormalize_trajs": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_void_p,
-                                        C.c_void_p, C.c_void_p]),
+    "mmd_unnormalize_trajs": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmd_cross_condition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.c_int, C.c_void_p]),
 }

@@ -247,21 +247,21 @@ __global__ __launch_bounds__(256) void variance_waypoints_kernel(const float4* _
 // reduction kernel into a device flag (no host round trip: the torch form `if x.max() > 1 + eps or x.min() < -1 - eps` costs two
 // reductions and two synchronisations per planner call), then x_u = (x + 1) / 2 * (max - min) + min with torch's separate
 // roundings (no FMA contraction: this file is compiled with fp contract off).
-__global__ __launch_bounds__(256) void range_flag_kernel(const float4* __restrict__ x, size_t n, float eps, uint32_t* __restrict__ flag) {
+__global__ __launch_bounds__(256) void range_flag_kernel(const float4* __restrict__ x, size_t n, size_t period, size_t segment, float eps,
+                                                         uint32_t* __restrict__ flags) {
   const float hi = 1.f + eps, lo = -1.f - eps;
-  bool out = false;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float4 v = x[i];
-    out = out || v.x > hi || v.y > hi || v.z > hi || v.w > hi || v.x < lo || v.y < lo || v.z < lo || v.w < lo;
+    const bool out = v.x > hi || v.y > hi || v.z > hi || v.w > hi || v.x < lo || v.y < lo || v.z < lo || v.w < lo;
+    if (out) atomicOr(flags + (i % period) / segment, 1u);       // (rare: a tensor that needs the clip has few such elements per wave)
   }
-  if (__ballot(out) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 struct UnnormArgs { float mins[4], range[4]; };
-__global__ __launch_bounds__(256) void unnormalize_kernel(const float4* __restrict__ x, float4* __restrict__ out, size_t n, UnnormArgs a,
-                                                          const uint32_t* __restrict__ flag) {
+__global__ __launch_bounds__(256) void unnormalize_kernel(const float4* __restrict__ x, float4* __restrict__ out, size_t n, size_t period,
+                                                          size_t segment, UnnormArgs a, const uint32_t* __restrict__ flags) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const bool clip = *flag != 0u;
+  const bool clip = flags[(i % period) / segment] != 0u;
   auto f = [&](float v, int d) {
     if (clip) v = fminf(fmaxf(v, -1.f), 1.f);                // torch.clip(x, -1, 1)
     v = (v + 1.f) / 2.f;
@@ -340,18 +340,22 @@ int mmd_points_collision(const mmd_guide_desc* env, const float* points_dev, int
   return 0;
 }
 
-int mmd_unnormalize_trajs(const float* x_dev, size_t n_points, const float* mins, const float* maxs, float eps, float* out_dev,
-                          uint32_t* flag_dev, void* stream) {
-  MMD_REQUIRE(x_dev && out_dev && mins && maxs && flag_dev, "mmd_unnormalize_trajs: NULL argument");
+int mmd_unnormalize_trajs(const float* x_dev, size_t n_points, size_t period_points, size_t segment_points, const float* mins,
+                          const float* maxs, float eps, float* out_dev, uint32_t* flags_dev, void* stream) {
+  MMD_REQUIRE(x_dev && out_dev && mins && maxs && flags_dev, "mmd_unnormalize_trajs: NULL argument");
   if (n_points == 0) return 0;
+  if (period_points == 0) period_points = n_points;
+  if (segment_points == 0) segment_points = period_points;
+  MMD_REQUIRE(period_points % segment_points == 0 && n_points % period_points == 0, "mmd_unnormalize_trajs: n_points %% period %% segment");
   hipStream_t st = (hipStream_t)stream;
-  MMD_HIP_CHECK(hipMemsetAsync(flag_dev, 0, sizeof(uint32_t), st));
+  MMD_HIP_CHECK(hipMemsetAsync(flags_dev, 0, sizeof(uint32_t) * (period_points / segment_points), st));
   const unsigned blocks = (unsigned)((n_points + 1023) / 1024);
-  hipLaunchKernelGGL(range_flag_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, st, (const float4*)x_dev, n_points, eps, flag_dev);
+  hipLaunchKernelGGL(range_flag_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, st, (const float4*)x_dev, n_points, period_points,
+                     segment_points, eps, flags_dev);
   UnnormArgs a;
   for (int d = 0; d < 4; ++d) { a.mins[d] = mins[d]; a.range[d] = maxs[d] - mins[d]; }
   hipLaunchKernelGGL(unnormalize_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, (const float4*)x_dev,
-                     (float4*)out_dev, n_points, a, (const uint32_t*)flag_dev);
+                     (float4*)out_dev, n_points, period_points, segment_points, a, (const uint32_t*)flags_dev);
   MMD_HIP_CHECK(hipGetLastError());
   return 0;
 }

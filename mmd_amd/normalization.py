@@ -18,7 +18,9 @@ class LimitsNormalizer:
         x = (x - self.mins.to(x.device)) / (self.maxs.to(x.device) - self.mins.to(x.device))
         return 2 * x - 1
 
-    def unnormalize(self, x, eps=1e-4):
+    def unnormalize(self, x, eps=1e-4, n_tensors=1):
+        """`n_tensors` > 1: x is [steps, n_tensors * B, H, 4] -- the chains of n_tensors planner calls batched robot-major
+        (planners.plan_batched); every call's chain gets its OWN data-dependent clip decision, as its own call would."""
         if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 4 and self.mins.numel() == 4:
             # on the device in two launches, the data-dependent clip decided there (mmd_unnormalize_trajs): the torch form below costs two
             # reductions and two host synchronisations per planner call
@@ -26,12 +28,21 @@ class LimitsNormalizer:
             from . import _lib
             x = x.contiguous()
             out = torch.empty_like(x)
-            flag = torch.empty(1, dtype=torch.int32, device=x.device)
+            flag = torch.empty(max(int(n_tensors), 1), dtype=torch.int32, device=x.device)
             if self._host is None:
                 self._host = ((C.c_float * 4)(*[float(v) for v in self.mins.cpu()]), (C.c_float * 4)(*[float(v) for v in self.maxs.cpu()]))
-            _lib.launch("mmd_unnormalize_trajs", x, x.data_ptr(), x.numel() // 4, self._host[0], self._host[1], float(eps), out.data_ptr(),
-                        flag.data_ptr())
+            n_points = x.numel() // 4
+            period, segment = 0, 0
+            if n_tensors > 1:
+                if x.dim() != 4 or x.shape[1] % n_tensors:
+                    raise ValueError(f"unnormalize(n_tensors={n_tensors}): expected [steps, n_tensors * B, H, 4], got {tuple(x.shape)}")
+                period = x.shape[1] * x.shape[2]
+                segment = period // n_tensors
+            _lib.launch("mmd_unnormalize_trajs", x, x.data_ptr(), n_points, period, segment, self._host[0], self._host[1], float(eps),
+                        out.data_ptr(), flag.data_ptr())
             return out
+        if n_tensors > 1:
+            return torch.cat([self.unnormalize(c, eps) for c in x.chunk(n_tensors, dim=1)], dim=1)
         if x.max() > 1 + eps or x.min() < -1 - eps:
             x = torch.clip(x, -1, 1)
         x = (x + 1) / 2.0
@@ -48,8 +59,8 @@ class TrajectoryDatasetFacade:
         self.state_dim = state_dim
         self.include_velocity = True
 
-    def unnormalize_trajectories(self, x):
-        return self.normalizer.unnormalize(x)
+    def unnormalize_trajectories(self, x, n_tensors=1):
+        return self.normalizer.unnormalize(x, n_tensors=n_tensors)
 
     def normalize_trajectories(self, x):
         return self.normalizer.normalize(x)

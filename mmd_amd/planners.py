@@ -846,7 +846,7 @@ def _run_mpd_group(calls, seeds):
                 n_diffusion_steps_without_noise=p0.n_diffusion_steps_without_noise, device=dev, robot_seeds=seeds)
         finally:
             cg.reset_extra_costs()
-    trajs_iters = p0.dataset.unnormalize_trajectories(chain)                     # [T+2, R*B, H, D]
+    trajs_iters = p0.dataset.unnormalize_trajectories(chain, n_tensors=R)        # [T+2, R*B, H, D]; every call's own clip decision
     tg = cg if all(p._task_guide is p.guide for p in planners) else _combined_guide([p._task_guide for p in planners])
     summary = post.host_summary(R * B, R, dev)
     r = post.postprocess_batch(tg, trajs_iters[-1].contiguous(), n_robots=R, smooth=True, summary=summary)
@@ -886,7 +886,7 @@ def _run_ensemble_group(calls, seeds):
     # un-normalise per tile, tile-frame final rows to the tile's own collision check, global frame, concatenate (as MPDEnsemble.__call__)
     parts, free_mask = [], None
     for j in keys:
-        tr = p0.datasets[j].unnormalize_trajectories(chains[j].transpose(0, 1)).clone()       # [T+2, R*B, H, D]
+        tr = p0.datasets[j].unnormalize_trajectories(chains[j].transpose(0, 1), n_tensors=R).clone()   # [T+2, R*B, H, D]
         tgs = _combined_guide([p.task.tasks[j].guide for p in planners])
         fm = post.postprocess_batch(tgs, tr[-1].contiguous(), n_robots=R, smooth=False).free_mask
         free_mask = fm if free_mask is None else free_mask & fm

@@ -644,3 +644,9 @@ def test_unnormalize_on_device_equals_the_torch_form_bitwise():
         assert torch.equal(got, ref), name
     assert float(ds.unnormalize_trajectories(cases_["within_eps"].cuda())[3, 2, 10, 1]) > 0.9       # above the limit: not clipped
     assert float(ds.unnormalize_trajectories(cases_["one_above"].cuda()).max()) <= 1.5
+    # the chains of several planner calls batched robot-major (plan_batched): every call keeps its OWN clip decision
+    x = torch.cat([cases_["inside"], cases_["one_above"], cases_["within_eps"], cases_["one_below"]], dim=1)       # [27, 4*8, H, D]
+    ref = torch.cat([ds.unnormalize_trajectories(c.clone()) for c in x.chunk(4, dim=1)], dim=1)
+    assert torch.equal(ds.unnormalize_trajectories(x.cuda(), n_tensors=4).cpu(), ref)
+    assert torch.equal(ds.unnormalize_trajectories(x.clone(), n_tensors=4), ref)                              # the CPU form of the same
+    assert not torch.equal(ds.unnormalize_trajectories(x.cuda()).cpu(), ref)            # one joint decision would clip call 2's 1.00005
