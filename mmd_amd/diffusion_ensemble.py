@@ -73,10 +73,12 @@ class DiffusionsEnsemble:
         init_noise = 0
         for m in keys:
             if warm_start_path_b is not None:
-                if robot_transforms is not None:
-                    raise NotImplementedError("warm start of a batched call")
                 x[m] = warm_start_path_b[:, m * HORIZON:(m + 1) * HORIZON, :].to(device=device, dtype=torch.float32).contiguous().clone()
-                x[m][:, :, :2] -= torch.as_tensor(self.transforms[m]).to(x[m].device)
+                if robot_transforms is None:
+                    x[m][:, :, :2] -= torch.as_tensor(self.transforms[m]).to(x[m].device)
+                else:                                         # every call's seed batch into ITS tile frame
+                    offs = torch.stack([torch.as_tensor(tr[m], dtype=torch.float32) for tr in robot_transforms]).to(device)
+                    x[m][:, :, :2] -= offs.repeat_interleave(B // n_robots, 0)[:, None, :]
             elif x_init is not None:
                 x[m] = x_init[m].to(device=device, dtype=torch.float32).contiguous().clone()
             else:

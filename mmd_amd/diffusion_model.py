@@ -26,6 +26,7 @@ _GLOBAL_DRAWS = 0
 
 
 _DRAW_LOCK = threading.Lock()
+_HARD_CACHE, _HARD_LOCK = {}, threading.Lock()      # GaussianDiffusionModel._hard_tensor
 
 
 def next_stream_seed(base_seed):
@@ -129,10 +130,35 @@ class GaussianDiffusionModel:
     def _hard_tensor(hard_conds, n_robots, horizon, device, D):
         """apply_hard_conditioning's dict (sample_functions.py:8-14) {row: [D] | [n_robots, D] | [B_total, D]} -> ([n_robots, n_rows, D]
         float32 in ascending row order, the 64-bit row mask of include/mmd_amd.h).  Per-sample hard conditions must be constant
-        within a robot (they are: run_inference repeats one state, diffusion_model_base.py:327-329)."""
+        within a robot (they are: run_inference repeats one state, diffusion_model_base.py:327-329).
+        A planner passes the SAME tensor objects call after call (its stored start / goal): the device copy is kept per (objects,
+        their in-place version counters) -- building it is two host -> device copies and four small kernels, 60 us in front of
+        a planner call's first launch."""
         rows = sorted(int(r) for r in hard_conds)
         if rows and not 0 <= rows[0] <= rows[-1] < horizon:
             raise ValueError(f"hard condition rows {rows} outside [0, {horizon})")
+        vals = [hard_conds[r] for r in rows]
+        key = None
+        if all(torch.is_tensor(v) for v in vals):
+            device = torch.device(device)
+            index = device.index if device.index is not None or device.type != "cuda" else torch.cuda.current_device()
+            key = (tuple((r, id(v), v._version) for r, v in zip(rows, vals)), n_robots, horizon, device.type, index, D)
+            with _HARD_LOCK:
+                hit = _HARD_CACHE.get(key)
+            if hit is not None:
+                if hit[1].is_cuda:          # (a later call may run on another stream: the allocator must not recycle it under that stream)
+                    hit[1].record_stream(torch.cuda.current_stream(hit[1].device))
+                return hit[1], hit[2]
+        hard, mask = GaussianDiffusionModel._build_hard_tensor(hard_conds, rows, n_robots, device, D)
+        if key is not None:
+            with _HARD_LOCK:
+                while len(_HARD_CACHE) >= 256:
+                    _HARD_CACHE.pop(next(iter(_HARD_CACHE)))
+                _HARD_CACHE[key] = (vals, hard, mask)            # (holds the value tensors: their ids stay unique while cached)
+        return hard, mask
+
+    @staticmethod
+    def _build_hard_tensor(hard_conds, rows, n_robots, device, D):
         hard = torch.zeros(n_robots, max(len(rows), 1), D, dtype=torch.float32, device=device)
         mask = 0
         for slot, row in enumerate(rows):

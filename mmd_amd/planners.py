@@ -210,6 +210,23 @@ class PlanningTaskEnsembleFacade:
         return 1.0
 
 
+def _same_state(given, stored):
+    """torch.allclose(given, stored) (mpd.py:318-321) on the host in numpy: the two tiny torch calls cost 35 us per planner call."""
+    g = given.detach().cpu().numpy() if torch.is_tensor(given) else np.asarray(given)
+    s = stored.numpy()
+    if g.shape != s.shape:
+        return bool(torch.allclose(torch.as_tensor(given).cpu().float(), stored))      # (broadcasting / shape errors as torch has them)
+    g = g.astype(np.float32, copy=False)
+    return bool(np.all(np.abs(g - s) <= 1e-8 + 1e-5 * np.abs(s)))
+
+
+def _check_states(planner, start_state_pos, goal_state_pos):
+    if not _same_state(start_state_pos, planner.start_state_pos):
+        raise ValueError("The start state is different from the one stored in the planner.")
+    if not _same_state(goal_state_pos, planner.goal_state_pos):
+        raise ValueError("The goal state is different from the one stored in the planner.")
+
+
 def _fill_output(out, guide, trajs_iters, all_free=False):
     """mpd.py:344-405 / mpd_ensemble.py:385-429 on the device: ONE fused launch (collision / free split, path length,
     smoothness, SavGol) + the per-batch argmin + the waypoint variance of the free set."""
@@ -227,16 +244,17 @@ def _fill_output(out, guide, trajs_iters, all_free=False):
     both = torch.from_numpy(np.concatenate((free_i, coll_i))).to(dev)
     free_idxs = both[:free_i.size].view(-1, 1)                       # [n, 1] int64, as torch.argwhere gives them (tasks.py:258-307)
     coll_idxs = both[free_i.size:].view(-1, 1)
-    free = trajs_final.index_select(0, free_idxs.view(-1)) if free_i.size else None
-    coll = trajs_final.index_select(0, coll_idxs.view(-1)) if coll_i.size else None
+    split = trajs_final.index_select(0, both)                        # (free rows first, then the colliding ones: one gather)
+    free = split[:free_i.size] if free_i.size else None
+    coll = split[free_i.size:] if coll_i.size else None
     out.trajs_iters, out.trajs_final = trajs_iters, r.smoothed
     out.trajs_final_coll, out.trajs_final_coll_idxs = coll, coll_idxs
     out.trajs_final_free, out.trajs_final_free_idxs = free, free_idxs
     out.success_free_trajs = free is not None
     out.fraction_free_trajs = 0.0 if free is None else free.shape[0] / B
     if free is not None:
-        out.cost_smoothness = r.smoothness.index_select(0, free_idxs.view(-1))
-        out.cost_path_length = r.path_length.index_select(0, free_idxs.view(-1))
+        costs = summary[B + 1:].view(2, B).index_select(1, free_idxs.view(-1))      # (path lengths | smoothness of the free samples)
+        out.cost_path_length, out.cost_smoothness = costs[0], costs[1]
         out.cost_all = out.cost_path_length + out.cost_smoothness
         idx_best_free = int(np.searchsorted(free_i, ib))          # position of the batch index ib among the free samples
         out.idx_best_traj = free_idxs[idx_best_free]
@@ -395,10 +413,7 @@ class MPD:
                                radius_l=c.radius_l, is_soft=c.is_soft) for c in (constraints_l or [])]
 
     def __call__(self, start_state_pos, goal_state_pos, constraints_l=None, experience=None, *args, **kwargs):
-        if not torch.allclose(torch.as_tensor(start_state_pos).cpu().float(), self.start_state_pos):
-            raise ValueError("The start state is different from the one stored in the planner.")
-        if not torch.allclose(torch.as_tensor(goal_state_pos).cpu().float(), self.goal_state_pos):
-            raise ValueError("The goal state is different from the one stored in the planner.")
+        _check_states(self, start_state_pos, goal_state_pos)
         cost_constraints_l = self._cost_constraints(constraints_l)
         with _Timer() as timer:
             if experience is None:
@@ -604,10 +619,7 @@ class MPDEnsemble:
             self._reset()
 
     def __call__(self, start_state_pos, goal_state_pos, constraints_l=None, experience=None, *args, **kwargs):
-        if not torch.allclose(torch.as_tensor(start_state_pos).cpu().float(), self.start_state_pos):
-            raise ValueError("The start state is different from the one stored in the planner.")
-        if not torch.allclose(torch.as_tensor(goal_state_pos).cpu().float(), self.goal_state_pos):
-            raise ValueError("The goal state is different from the one stored in the planner.")
+        _check_states(self, start_state_pos, goal_state_pos)
         cl = [CostConstraint(self.robot, HORIZON, q_l=c.get_q_l(), traj_range_l=c.get_t_range_l(), radius_l=c.radius_l,
                              is_soft=c.is_soft) for c in (constraints_l or [])]
         with _Timer() as timer:
@@ -708,12 +720,14 @@ def _guide_key(g):
 def _batch_key(call):
     """Calls with equal keys can share one launch sequence: same planner class and algorithm, the same device model(s) (weights are
     content-hashed: equal state dicts share one handle), schedule, batch size, sampler settings and guide parameters.  Maps,
-    start / goal, constraints, tile transforms and seeds may differ per call.  None: the call is run on its own (a re-plan from an
-    experience, `diffusion_prior_then_guide`, a map with extra objects)."""
+    start / goal, constraints, tile transforms, seeds and the experience's seed batch may differ per call.  None: the call is run on
+    its own (`diffusion_prior_then_guide`, a map with extra objects)."""
     planner = call[0]
     experience = call[4] if len(call) > 4 else None
-    if experience is not None or planner.run_prior_then_guidance:
+    if planner.run_prior_then_guidance:
         return None
+    # re-plans from an experience (run_local_inference: the same loop from a forward-noised seed batch) pack with each other
+    local = None if experience is None else (planner.n_local_inference_noising_steps, planner.n_local_inference_denoising_steps)
     dev = planner.device
     if isinstance(planner, MPD):
         g = planner.guide
@@ -722,14 +736,14 @@ def _batch_key(call):
         m = planner.model
         return ("MPD", str(dev), m.model.handle(m.n_diffusion_steps, dev).value, m.n_diffusion_steps, m.predict_epsilon, planner.num_samples,
                 planner.n_guide_steps, planner.t_start_guide, planner.n_diffusion_steps_without_noise, planner.run_prior_only,
-                _guide_key(g), m.sampler_flags, m.guide_coop_max)
+                _guide_key(g), m.sampler_flags, m.guide_coop_max, local)
     if isinstance(planner, MPDEnsemble):
         ms = planner.models
         return ("MPDEnsemble", str(dev), tuple(ms[j].model.handle(ms[j].n_diffusion_steps, dev).value for j in ms),
                 ms[0].n_diffusion_steps, ms[0].predict_epsilon, planner.num_samples, planner.n_diffusion_steps_without_noise,
                 planner.run_prior_only, tuple((planner.sample_kwargs[j]["n_guide_steps"], planner.sample_kwargs[j]["t_start_guide"])
                                               for j in ms), tuple(_guide_key(planner.guides[j]) for j in ms),
-                tuple(sorted(planner.cross_conds.items())))
+                tuple(sorted(planner.cross_conds.items())), local)
     return None
 
 
@@ -818,10 +832,7 @@ def _split_outputs(calls, planners, r, summary, trajs_iters_all, B, t_total, ens
 
 
 def _check_start_goal(planner, call):
-    if not torch.allclose(torch.as_tensor(call[1]).cpu().float(), planner.start_state_pos):
-        raise ValueError("The start state is different from the one stored in the planner.")
-    if not torch.allclose(torch.as_tensor(call[2]).cpu().float(), planner.goal_state_pos):
-        raise ValueError("The goal state is different from the one stored in the planner.")
+    _check_states(planner, call[1], call[2])
 
 
 def _run_mpd_group(calls, seeds):
@@ -837,13 +848,23 @@ def _run_mpd_group(calls, seeds):
         per_robot.append([(cc, p.weight_grad_cost_soft_constraints if cc.is_soft else p.weight_grad_cost_constraints) for cc in cl])
     _load_constraints(cg, per_robot)
     hard = {row: torch.stack([p.hard_conds[row] for p in planners]) for row in p0.hard_conds}
+    experiences = [c[4] if len(c) > 4 else None for c in calls]                  # (all or none: _batch_key)
+    kw = dict(n_samples=B, n_robots=R, horizon=HORIZON, return_chain=True, sample_fn=ddpm_sample_fn,
+              guide=None if p0.run_prior_only else cg, n_guide_steps=p0.n_guide_steps, t_start_guide=p0.t_start_guide,
+              noise_std_extra_schedule_fn=p0.sample_fn_kwargs["noise_std_extra_schedule_fn"],
+              n_diffusion_steps_without_noise=p0.n_diffusion_steps_without_noise, device=dev, robot_seeds=seeds)
     with _Timer() as timer:
         try:
-            chain = p0.model.run_inference(
-                None, hard, n_samples=B, n_robots=R, horizon=HORIZON, return_chain=True, sample_fn=ddpm_sample_fn,
-                guide=None if p0.run_prior_only else cg, n_guide_steps=p0.n_guide_steps, t_start_guide=p0.t_start_guide,
-                noise_std_extra_schedule_fn=p0.sample_fn_kwargs["noise_std_extra_schedule_fn"],
-                n_diffusion_steps_without_noise=p0.n_diffusion_steps_without_noise, device=dev, robot_seeds=seeds)
+            if experiences[0] is None:
+                chain = p0.model.run_inference(None, hard, **kw)
+            else:
+                # every call's seed batch forward-noised with the call's own Philox stream (q_sample under `seed`, as its own call does),
+                # then ONE denoising loop over all of them
+                noised = torch.cat([p.model.q_sample(e.path_b.to(dev), p.n_local_inference_noising_steps, seed=s)
+                                    for p, e, s in zip(planners, experiences, seeds)])
+                kw.pop("n_samples"), kw.pop("return_chain")
+                chain = p0.model.conditional_sample(dict(hard), n_diffusion_steps=p0.n_local_inference_denoising_steps, batch_size=R * B,
+                                                    return_chain=True, warm_start_path_b=noised, **kw)[1].transpose(0, 1)
         finally:
             cg.reset_extra_costs()
     trajs_iters = p0.dataset.unnormalize_trajectories(chain, n_tensors=R)        # [T+2, R*B, H, D]; every call's own clip decision
@@ -874,12 +895,19 @@ def _run_ensemble_group(calls, seeds):
         _load_constraints(cgs[j], per_tile[j])
     hard = {j: {row: torch.stack([p.hard_conds[j][row] for p in planners]) for row in p0.hard_conds.get(j, {})} for j in keys}
     skw = {j: dict(p0.sample_kwargs[j], guide=None if p0.run_prior_only else cgs[j]) for j in keys}
+    experiences = [c[4] if len(c) > 4 else None for c in calls]                  # (all or none: _batch_key)
     with _Timer() as timer:
         try:
+            noised, n_steps = None, p0.model.n_diffusion_steps
+            if experiences[0] is not None:                   # DiffusionsEnsemble.run_local_inference per call, then ONE denoising loop
+                noised = torch.cat([p.models[keys[0]].q_sample(e.path_b.to(dev), p.n_local_inference_noising_steps, seed=s)
+                                    for p, e, s in zip(planners, experiences, seeds)])
+                n_steps = p0.n_local_inference_denoising_steps
             _, chains = p0.model.p_sample_loop(
-                (R * B, HORIZON, p0.models[keys[0]].state_dim), hard, dict(p0.cross_conds), n_diffusion_steps=p0.model.n_diffusion_steps,
+                (R * B, HORIZON, p0.models[keys[0]].state_dim), hard, dict(p0.cross_conds), n_diffusion_steps=n_steps,
                 return_chain=True, sample_fn=ddpm_sample_fn, n_diffusion_steps_without_noise=p0.n_diffusion_steps_without_noise,
-                device=dev, n_robots=R, robot_seeds=seeds, robot_transforms=[p.transforms for p in planners], sample_kwargs=skw)
+                warm_start_path_b=noised, device=dev, n_robots=R, robot_seeds=seeds, robot_transforms=[p.transforms for p in planners],
+                sample_kwargs=skw)
         finally:
             for j in keys:
                 cgs[j].reset_extra_costs()
@@ -907,8 +935,9 @@ def plan_batched(calls, seeds=None):
     granularity put on the chip the way it fits: CBS / PrioritizedPlanning call one planner per agent with 64 samples
     (inference_multi_agent.py:225-237, cbs.py:316-324, mmd_params.py:33), and a UNet launch of 64 trajectories costs what one of 256
     does.  Same signature and seeds as plan_concurrently, and BITWISE the same results as the calls made one after the other with those
-    seeds (mmd_sampler_desc.robot_seeds_dev: one Philox stream per robot).  Calls that cannot be packed (a re-plan from an
-    experience, `diffusion_prior_then_guide`, extra objects) run on their own, in list order, with their seed."""
+    seeds (mmd_sampler_desc.robot_seeds_dev: one Philox stream per robot).  Re-plans from an experience -- the two children of a CBS
+    expansion re-plan two different agents independently (cbs.py:397-432) -- pack with each other.  Calls that cannot be packed
+    (`diffusion_prior_then_guide`, extra objects) run on their own, in list order, with their seed."""
     calls = [tuple(c) for c in calls]
     if len({id(c[0]) for c in calls}) != len(calls):
         raise ValueError("plan_batched: a planner appears twice (a planner call is not re-entrant)")

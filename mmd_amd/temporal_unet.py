@@ -143,7 +143,7 @@ class TemporalUnet:
         lib = _lib.load()
         dev = self._device_index(device)
         nbytes = (lib.mmd_sampler_workspace_bytes if sampler else lib.mmd_unet_workspace_bytes)(self.handle(device=dev), n_traj)
-        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        key = (dev, _lib.raw_stream(dev))
         ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", dev))

@@ -75,7 +75,7 @@ def test_plan_batched_equals_the_sequential_calls():
     calls2 = calls + [(other, torch.from_numpy(starts[5]), torch.from_numpy(goals[5])),
                       (ptg, torch.from_numpy(starts[6]), torch.from_numpy(goals[6]), [hard])] + \
         [(p, torch.from_numpy(starts[r]), torch.from_numpy(goals[r])) for p, r in zip(prior, (0, 3))]
-    calls2[1] = calls[1] + (PathBatchExperience(seq[1].trajs_final),)                                          # a re-plan: on its own
+    calls2[1] = calls[1] + (PathBatchExperience(seq[1].trajs_final),)                                          # a re-plan: its own group
     seeds = [900 + j for j in range(len(calls2))]
     seq2 = [c[0](*c[1:], seed=s) for c, s in zip(calls2, seeds)]
     bat2 = plan_batched(calls2, seeds=seeds)
@@ -86,6 +86,36 @@ def test_plan_batched_equals_the_sequential_calls():
         plan_batched([calls[0], calls[0]])
     with pytest.raises(ValueError):
         plan_batched([(ps[0], torch.from_numpy(goals[1]), torch.from_numpy(goals[1]))] + calls[1:])
+
+
+def test_plan_batched_replans_from_experiences():
+    """The two children of a CBS expansion re-plan two different agents from their previous batches (cbs.py:397-432, xCBS / xECBS:
+    experience = the agent's last trajs_final) -- three such re-plans on different maps, each with its own hard + soft constraints and
+    its own experience, as ONE launch sequence: the forward noising under the call's own Philox stream, one denoising loop, every
+    PlannerOutput field bitwise the sequential call's; an MPD whose local-inference step counts differ forms its own group."""
+    from mmd_amd.constraints import MultiPointConstraint
+    from mmd_amd.planners import PathBatchExperience, plan_batched
+    starts, goals = synth.start_goal_circle(10, 0.45)
+    paths = synth.straight_line_paths(starts, goals, H)
+    envs, robots = ("EnvHighways2D", "EnvConveyor2D", "EnvEmpty2D", "EnvDropRegion2D"), (2, 5, 9, 0)
+    ps = [_mpd(e, starts[r], goals[r], 50 + r) for e, r in zip(envs[:3], robots[:3])]
+    ps.append(_mpd(envs[3], starts[0], goals[0], 50, n_local_inference_noising_steps=5, n_local_inference_denoising_steps=4))
+    first = [p(torch.from_numpy(starts[r]), torch.from_numpy(goals[r]), seed=100 + r) for p, r in zip(ps, robots)]
+
+    def cons(r, t0):
+        soft = MultiPointConstraint(q_l=[torch.from_numpy(paths[j, t]) for j in range(10) if j != r for t in range(1, H, 3)],
+                                    t_range_l=[(t, t + 1) for j in range(10) if j != r for t in range(1, H, 3)], is_soft=True)
+        return [MultiPointConstraint(q_l=[torch.from_numpy(paths[r, t0 + 2])], t_range_l=[(t0, t0 + 5)]), soft]
+    calls = [(p, torch.from_numpy(starts[r]), torch.from_numpy(goals[r]), cons(r, 10 + 7 * k), PathBatchExperience(o.trajs_final))
+             for k, (p, r, o) in enumerate(zip(ps, robots, first))]
+    seeds = [3100, 3101, 3102, 3103]
+    seq = [c[0](*c[1:], seed=s) for c, s in zip(calls, seeds)]
+    bat = plan_batched(calls, seeds=seeds)
+    for a, b in zip(seq, bat):
+        _same_output(a, b)
+    assert [o.trajs_iters.shape[0] for o in bat] == [5, 5, 5, 6]            # n_denoising + 1 no-noise step + the seed row
+    assert not torch.equal(bat[0].trajs_iters[0], first[0].trajs_final)     # (row 0 is the forward-noised seed batch)
+    assert all(p.guide.extra_cost_l == [[]] for p in ps)
 
 
 def _config4_planners(B=8, T=25):
@@ -142,6 +172,16 @@ def test_plan_batched_ensembles_equal_the_sequential_calls():
         assert a.trajs_iters.shape[-2] == 3 * H
         _same_output(a, b, ensemble=True)
     assert any(len(o.trajs_final_coll_idxs) for o in bat3)        # (the per-tile collision split bites on these maps)
+    # (c) re-plans from experiences (the previous trajs_final, global frame, K * 64 points): config 4's four calls with alternating
+    # tile transforms -- each seed batch goes into ITS call's tile frames -- and the two 3-tile calls
+    from mmd_amd.planners import PathBatchExperience
+    for cs, prev, sds in ((calls, seq, (7101, 7102, 7103, 7104)), (calls3, seq3, (821, 822))):
+        cs = [c[:3] + ((c[3] if len(c) > 3 else None), PathBatchExperience(o.trajs_final)) for c, o in zip(cs, prev)]
+        seq_x = [c[0](*c[1:], seed=s) for c, s in zip(cs, sds)]
+        bat_x = plan_batched(cs, seeds=sds)
+        for a, b in zip(seq_x, bat_x):
+            assert a.trajs_iters.shape[0] == 5
+            _same_output(a, b, ensemble=True)
 
 
 def test_robot_seeds_reproduce_separate_calls_through_every_step_kernel():
