@@ -14,7 +14,7 @@ from mmd_amd.constraints import CostConstraint
 from mmd_amd.environments import sdf_grid_texture
 from mmd_amd.normalization import LimitsNormalizer, TrajectoryDatasetFacade
 from mmd_amd.schedules import SCHEDULE_KEYS, diffusion_buffers
-from cases import GOLDEN, H
+from cases import GOLDEN, H, D
 
 
 def test_schedule_tables_bit_exact_vs_reference():
@@ -365,3 +365,37 @@ def test_pack_constraints_randomized_vs_oracle_slot_table():
                     assert tuple(blk[s, t]) == want, (s, t, tuple(blk[s, t]), want)
         off += S
     assert off == ell.shape[0] or (off == 0 and ell.shape[0] == 0)
+
+
+def test_planner_call_host_shortcuts_keep_the_reference_semantics():
+    """The host-side shortcuts of a planner call (profiles/r06_replan_call.txt) against the forms they replace: the (t0, t1) list
+    conversion, the start / goal check (torch.allclose, mpd.py:318-321) and the cached hard-condition tensor (apply_hard_conditioning's
+    dict, sample_functions.py:8-14) -- same values, and an in-place change of a stored state is seen."""
+    from mmd_amd.constraints import _ranges
+    from mmd_amd.diffusion_model import GaussianDiffusionModel
+    from mmd_amd.planners import _same_state
+    for tr in ([(t, t + 1) for t in range(9)], [(1.5, 2), (3, 4.25)], [[1, 2], [3, 4]], np.array([[1, 2], [3, 4]]),
+               [(torch.tensor(1), torch.tensor(2))], torch.tensor([[0.0, 5.0]])):
+        assert np.array_equal(_ranges(tr), np.asarray(tr, dtype=np.float32).reshape(-1, 2))
+        assert _ranges(tr).dtype == np.float32
+    assert _ranges([]).shape == (0, 2)
+    stored = torch.tensor([0.3, -0.7])
+    for given in (stored.clone(), stored.double(), stored + 5e-6, stored + 1e-3, [0.3, -0.7], np.array([0.3, -0.7]),
+                  torch.tensor([[0.3, -0.7]]), torch.tensor([0.3])):
+        want = bool(torch.allclose(torch.as_tensor(given).cpu().float(), stored))
+        assert _same_state(given, stored) == want, given
+    start, goal = torch.tensor([0.1, 0.2, 0.0, 0.0]), torch.tensor([0.5, -0.2, 0.0, 0.0])
+    hc = {0: start, H - 1: goal}
+    a, mask = GaussianDiffusionModel._hard_tensor(hc, 2, H, "cpu", D)
+    assert mask == (1 | 1 << (H - 1)) and torch.equal(a, torch.stack([torch.stack([start, goal])] * 2))
+    b, _ = GaussianDiffusionModel._hard_tensor(dict(hc), 2, H, "cpu", D)            # a copy of the dict, the same tensor objects: the cached one
+    assert b is a
+    c, _ = GaussianDiffusionModel._hard_tensor(hc, 3, H, "cpu", D)
+    assert c.shape == (3, 2, D)
+    goal[0] = 0.25                                                                  # in place: the version counter moves, the cache misses
+    d, _ = GaussianDiffusionModel._hard_tensor(hc, 2, H, "cpu", D)
+    assert d is not a and float(d[1, 1, 0]) == 0.25 and float(a[1, 1, 0]) == 0.5
+    e, mask_e = GaussianDiffusionModel._hard_tensor({5: [0.0, 1.0, 2.0, 3.0]}, 1, H, "cpu", D)       # not tensors: built, not cached
+    assert mask_e == 1 << 5 and e.shape == (1, 1, D)
+    with pytest.raises(ValueError):
+        GaussianDiffusionModel._hard_tensor({H: start}, 1, H, "cpu", D)
