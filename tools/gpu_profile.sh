@@ -39,4 +39,5 @@ timeout 600 python bench.py --workload config4 --steps 10 --warmup 2 --sequentia
 cp $OUT/bench_detail_*.json $OUT/ 2>/dev/null; for f in $OUT/bench_detail_*_n1.json; do cp $f $OUT/${TAG}_$(basename $f); done
 timeout 300 python tools/dbg/planner_time.py 2>&1 | tail -2 | tee $OUT/${TAG}_planner_time.txt
 timeout 300 python tools/dbg/planner_breakdown.py 2>&1 | tail -1 | tee -a $OUT/${TAG}_planner_time.txt
+timeout 300 python tools/dbg/replan_time.py 2>&1 | grep "re-plan" | tee -a $OUT/${TAG}_planner_time.txt
 bash tools/gpu_rehearsal.sh ${TAG}
