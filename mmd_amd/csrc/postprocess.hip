@@ -253,9 +253,9 @@ __global__ __launch_bounds__(256) void range_flag_kernel(const float4* __restric
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float4 v = x[i];
     const bool out = v.x > hi || v.y > hi || v.z > hi || v.w > hi || v.x < lo || v.y < lo || v.z < lo || v.w < lo;
-    // a plain store of the one value a flag ever takes (a wave's lanes with the same flag coalesce into one write; an atomic per element
+    // a relaxed store (a plain global_store) of the one value a flag ever takes (a wave's lanes with the same flag coalesce into one write; an atomic per element
     // serialises on a DDPM chain, whose x_T rows are a third out of range: +0.35 ms per planner call, measured)
-    if (out) flags[(i % period) / segment] = 1u;
+    if (out) __hip_atomic_store(flags + (i % period) / segment, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 struct UnnormArgs { float mins[4], range[4]; };
