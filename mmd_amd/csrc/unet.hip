@@ -465,6 +465,19 @@ template <class GEO, int NS>
 __device__ __forceinline__ void rd_store1(char* vs, const f32x4 (&acc)[NS][1], int lane) {
   constexpr int HS = NS / 2;
   const bool odd = lane & 1;
+  if constexpr (NS == 1) {
+    // one sample: BOTH lanes of a pair store the same dword (c, c + 1) -- no divergent branch around the store: with the store under
+    // `if (even lane)` the results were wrong on the hardware (the cross-lane read apparently ends up inside the branch, where the odd
+    // lanes are disabled and read as 0); the duplicate same-value LDS write is free
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float own = acc[0][0][r];
+      const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own), 0xB1, 0xf, 0xf, true));
+      const F16Pair f = f16_split2(odd ? recv : own, odd ? own : recv);        // (low channel, high channel)
+      *reinterpret_cast<unsigned*>(vs + r * 16) = f.hi;
+      *reinterpret_cast<unsigned*>(vs + GEO::PS + r * 16) = f.lo;
+    }
+  }
 #pragma unroll
   for (int h = 0; h < HS; ++h)
 #pragma unroll
@@ -924,7 +937,7 @@ constexpr int WBUF_BYTES = 20 * 1024;                        // the largest stag
 // store and the taps), GroupNorm statistics are the two-half combination of rw_half_stat (one exchange through LDS per conv,
 // whose barrier also orders the next slab store behind the partner's taps), dynamic scales take the sample's maximum from the
 // two waves' partials in mx.  Per-sample arithmetic is that of chain_body_d0w: bitwise equal results.
-template <class CF>
+template <class CF, int NV = 2>     // NV: the workgroup's REAL samples (unet_kernel<1>: sample 1 is fed zeros and never stored)
 __device__ __forceinline__ void chain_body_d0s(const ChainArgs& a, float* lds, int n0, int lane, int wave, int trb, int tb_off = 0) {
   static_assert(CF::L == 64 && CF::CM == 32 && CF::C0 == 4 && CF::C1 == 0 && CF::RES0 == RES_CONV && CF::N_IDENT == 1 &&
                     CF::TAIL == TAIL_DOWN, "downs.0");
@@ -956,7 +969,7 @@ __device__ __forceinline__ void chain_body_d0s(const ChainArgs& a, float* lds, i
   // ---- stage the sample: every wave loads all of it (lane = position: the exact maximum without an exchange) and writes its half
   float inv_in;
   {
-    const bool valid = n0 + sp < a.n;
+    const bool valid = sp < NV && n0 + sp < a.n;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) v = *reinterpret_cast<const float4*>(a.in0 + ((size_t)(n0 + sp) * 64 + lane) * 4);
     float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -1401,7 +1414,7 @@ __device__ __forceinline__ void chain_body_d2d(const ChainArgs& a, float* lds, i
 #ifdef MMD_NO_PF
   constexpr bool PF = false;                                  // (A/B side build: profiles/r06_prefetch_ab.txt)
 #else
-  constexpr bool PF = NS == 2;
+  constexpr bool PF = NS <= 2;
 #endif
   auto prefetch = [&](const uint4* w) {
     if constexpr (PF) {
@@ -1546,7 +1559,7 @@ __device__ __forceinline__ void chain_body_u0d(const ChainArgs& a, float* lds, i
 #ifdef MMD_NO_PF
   constexpr bool PF = false;
 #else
-  constexpr bool PF = NS == 2;
+  constexpr bool PF = NS <= 2;
 #endif
   auto prefetch64 = [&](const uint4* w, int frags) {
     if constexpr (PF) {
@@ -1958,7 +1971,7 @@ __device__ __forceinline__ void chain_body_u1w(const ChainArgs& a, const FinalAr
 // wave >> 1, half hf = wave & 1): ONE M tile of the L = 32 convs, two of the final block's L = 64), the sample's slab is shared,
 // GroupNorm statistics / dynamic scales are exchanged through LDS.  The two input chunks arrive across waves as in
 // chain_body_u1w.  Bitwise equal results.
-template <class CF>
+template <class CF, int NV = 2>
 __device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalArgs& f, const FusedStep& fs, float* lds, int n0, int lane_in, int wave,
                                                const f32x4 (&xe)[2][1], const f32x4 (&xo)[2][1], const f32x4 (&skip)[2][2], int trb, int tb_off = 0) {
   int lane = lane_in;
@@ -2212,7 +2225,7 @@ __device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalAr
           for (int r = 0; r < 4; ++r) et[(32 * hf + 16 * mt + 4 * g + r) * 4 + n] = fmaf(out[mt][0][r], s1, b1);
       }
       __syncthreads();
-      if (hf == 0 && n0 + sp < a.n) {
+      if (hf == 0 && sp < NV && n0 + sp < a.n) {
         const float4 e = *reinterpret_cast<const float4*>(et + lane * 4);
         const int traj = fs.traj0 + n0 + sp, robot = traj / fs.spr;
         const size_t idx = (size_t)traj * H + lane;
@@ -2225,7 +2238,7 @@ __device__ __forceinline__ void chain_body_u1s(const ChainArgs& a, const FinalAr
         fs.x[idx] = v;
         if (fs.chain) fs.chain[idx] = v;
       }
-    } else if (n < 4 && n0 + sp < a.n) {
+    } else if (n < 4 && sp < NV && n0 + sp < a.n) {
       float* dst = f.out + ((size_t)(n0 + sp) * 64 + 32 * hf + 4 * g) * 4 + n;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -2259,6 +2272,34 @@ static_assert(CH_D0::SPB == 4 && CH_D1::SPB == 4 && CH_D2::SPB == 4 && CH_U0::SP
 // instruction sequence either way: the results are bitwise equal.
 // tb_off: added to every RTB's time-bias pointer (floats) -- 0 in unet_kernel, whose host side bakes the step's row of the time
 // table into the pointers; t * tb_total in the persistent kernel, whose pointers are those of row 0
+// One trajectory per workgroup (unet_kernel<1>, launches of <= ns1_max = 256 trajectories -- one workgroup per CU at most; ONE planner
+// call has 64): the L = 16 stages
+// (downs.2 + mid, ups.0: their waves are channel slices x all samples) run ONE M tile per conv -- the conv's time there is the weight
+// stream plus what the samples' MFMAs, A-fragment reads and epilogues add to it: 3.15 -> 2.7 us per 128 -> 128 conv at <= 64 workgroups
+// (tools/ubench/pair_split.hip, arms basePF / base1PF) -- while the stages whose waves are sample halves or n-tile pairs x samples
+// (downs.0, downs.1, ups.1 + final block) keep the two-trajectory form with sample 1 fed zeros and never stored.  A sample's
+// arithmetic is the same instruction sequence: bitwise the results of unet_kernel<2> / <4>.
+__device__ __forceinline__ void unet_forward_body1(const UnetArgs& a, const FusedStep& fs, int tb_off, float* lds, int n0, int lane, int wave) {
+  f32x4 skip1[2][2], skip2[1][2], mid_out[1][2], xe[2][1], xo[2][1];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xe[1][0][r] = xo[1][0][r] = 0.f;
+  chain_body_d0s<CH_D0, 1>(a.c[0], lds, n0, lane, wave, 0, tb_off);
+  chain_body_d1d<CH_D1, CH_D2, 2>(a.c[1], lds, lane, wave, skip1, 40, tb_off);
+  chain_body_d2d<CH_D2, 1>(a.c[2], lds, lane, wave, mid_out, skip2, 80, tb_off);
+  TR(130);
+  {
+    using G128 = RdGeo<128>;
+    constexpr int S_OFF = (CH_D2::SPB * CH_D2::XSS * 4 + 255) / 256 * 256;
+    char* const slab128 = reinterpret_cast<char*>(lds) + S_OFF;
+    char* const vs = slab128 + wave * G128::G + ((lane & 15) >> 2) * G128::BX + (2 + 4 * (lane >> 4)) * 16 + (lane & 3) * 4;
+    chain_body_u0d<CH_U0, 1>(a.c[3], lds, lane, wave, mid_out, skip2, [&](const f32x4 (&t)[1][2]) { rd_store2<G128>(vs, t); }, slab128,
+                             reinterpret_cast<f32x4(&)[1][1]>(xe), reinterpret_cast<f32x4(&)[1][1]>(xo), 136, tb_off);
+  }
+  TR(131);
+  chain_body_u1s<CH_U1, 1>(a.c[4], a.fin, fs, lds, n0, lane, wave, xe, xo, skip1, 146, tb_off);
+  TR(133);
+}
+
 template <int NS>
 __device__ __forceinline__ void unet_forward_body(const UnetArgs& a, const FusedStep& fs, int tb_off, float* lds, int n0, int lane, int wave) {
   f32x4 skip1[NS][2], skip2[NS][2];
@@ -2292,11 +2333,17 @@ __device__ __forceinline__ void unet_forward_body(const UnetArgs& a, const Fused
 }
 
 template <int NS>
+__device__ __forceinline__ void unet_forward_any(const UnetArgs& a, const FusedStep& fs, int tb_off, float* lds, int n0, int lane, int wave) {
+  if constexpr (NS == 1) unet_forward_body1(a, fs, tb_off, lds, n0, lane, wave);
+  else unet_forward_body<NS>(a, fs, tb_off, lds, n0, lane, wave);
+}
+
+template <int NS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void unet_kernel(UnetArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[UNET_LDS_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unet_forward_body<NS>(a, a.fs, 0, lds, blockIdx.x * NS, lane, wave);
+  unet_forward_any<NS>(a, a.fs, 0, lds, blockIdx.x * NS, lane, wave);
 }
 
 // A RUN of consecutive unguided DDPM steps in ONE launch (mmd_p_sample_loop: the steps before guidance starts, or every step of a
@@ -2459,6 +2506,10 @@ struct mmd_unet_s {
   mmd::LayeredUnet* layered = nullptr;   // set: a configuration other than the fused kernel's; everything below is unused
   int T = 0;
   int ns2_max = 512;         // unet_kernel<2> (two trajectories per workgroup) up to this batch size (mmd_unet_options.two_per_workgroup_max)
+#ifndef MMD_NS1_MAX
+#define MMD_NS1_MAX 256
+#endif
+  int ns1_max = MMD_NS1_MAX; // unet_kernel<1> (one trajectory per workgroup) up to this batch size (-DMMD_NS1_MAX=0: the A/B side build)
   size_t blob_bytes = 0;     // bytes of `blob` (mmd_unet_weight_bytes)
   float* blob = nullptr;     // packed weights / biases / affine params
   float* ttable = nullptr;   // [T][tb_total]
@@ -2813,7 +2864,8 @@ static int unet_forward_impl(mmd_unet_t u, const float* x, int t, float* eps, in
   a.fin.w1_bias = u->blob + u->fin_b1;
   const bool bracket = prof_begin(prof, 0, fs && fs->enabled ? MMD_PROF_UNET_FUSED : MMD_PROF_UNET, st);
   // two trajectories per workgroup while that still leaves at most one workgroup per CU (256 CUs): see unet_kernel
-  if (n <= u->ns2_max) hipLaunchKernelGGL(unet_kernel<2>, dim3((n + 1) / 2), dim3(256), 0, st, a);
+  if (n <= u->ns1_max && n <= u->ns2_max) hipLaunchKernelGGL(unet_kernel<1>, dim3(n), dim3(256), 0, st, a);
+  else if (n <= u->ns2_max) hipLaunchKernelGGL(unet_kernel<2>, dim3((n + 1) / 2), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(unet_kernel<4>, dim3((n + 3) / 4), dim3(256), 0, st, a);
   if (bracket) prof_end(prof, st);
   MMD_HIP_CHECK(hipGetLastError());

@@ -80,31 +80,31 @@ def test_unet_forward_input_range(scale):
 
 
 def test_unet_forward_batch_independence():
-    """A trajectory's eps does not depend on which workgroup / wave slot it lands in, nor on which of the two kernels runs it:
+    """A trajectory's eps does not depend on which workgroup / wave slot it lands in, nor on which of the three kernels runs it:
     2051 trajectories (unet_kernel<4>: 513 workgroups of four, the last one ragged) against the same rows evaluated in small
-    batches (unet_kernel<2>, two trajectories per workgroup, launched up to 512 trajectories; a 1-row batch = a workgroup with
-    one real sample) -- bit-identical."""
+    batches (unet_kernel<1>, one trajectory per workgroup, launches of up to 256; unet_kernel<2>, two per workgroup, up to 512)
+    -- bit-identical."""
     model = _gc().hip_model(100)
     x = torch.from_numpy(synth.synth_noise(91, (2051, H, D))).cuda()
     big = model.model(x, 17)
     for rows in ([0, 1, 2, 3], [5, 1030, 2046], [2047, 2048, 2049, 2050], [2050]):
         small = model.model(x[rows].contiguous(), 17)
         assert torch.equal(big[rows], small), rows
-    # either side of the launch-size threshold between the two kernels (512), full and ragged last workgroups
-    for n in (511, 512, 513, 514):
+    # either side of the launch-size thresholds between the kernels (256, 512), full and ragged last workgroups
+    for n in (255, 256, 257, 258, 300, 511, 512, 513, 514):
         assert torch.equal(model.model(x[:n].contiguous(), 17), big[:n]), n
 
 
 def test_unet_forward_is_batch_independent():
     """A trajectory's eps does not depend on which launch / workgroup it is in (the property the sharded sampler rests on):
     the forward of a sub-batch, of a ragged batch and of a large batch agree bit for bit row by row (3- and 64-row batches run
-    unet_kernel<2>, the 1026- and 2050-row ones unet_kernel<4>), and meet the oracle bound."""
+    unet_kernel<1>, the 401-row one unet_kernel<2>, the 1026- and 2050-row ones unet_kernel<4>), and meet the oracle bound."""
     model = _gc().hip_model(100)
     sd = O.state_dict_to_torch(synth.synth_unet_state_dict(0))
     x = torch.from_numpy(synth.synth_noise(300, (2050, H, D))).cuda()
     full = model.model(x, 41)
     assert torch.isfinite(full).all()
-    for lo, n in ((0, 3), (5, 64), (1024, 1026), (2047, 3)):
+    for lo, n in ((0, 3), (5, 64), (700, 401), (1024, 1026), (2047, 3)):
         part = model.model(x[lo:lo + n].contiguous(), 41)
         assert torch.equal(part, full[lo:lo + n]), (lo, n)
     ref = O.unet_forward(sd, x[:64].cpu(), torch.full((64,), 41, dtype=torch.long))
@@ -877,7 +877,7 @@ def test_persistent_run_equals_launch_per_step():
         for flags in (0, _lib.SAMPLER_PERSIST, _lib.SAMPLER_NO_FUSED_STEP):
             model.sampler_flags = flags
             out = {}
-            for tag, R, B in (("two_per_workgroup", 2, 8), ("four_per_workgroup", 3, 200)):
+            for tag, R, B in (("one_per_workgroup", 2, 8), ("two_per_workgroup", 3, 100), ("four_per_workgroup", 3, 200)):
                 guide = gpu_common.hip_guide("EnvHighways2D", [[cases.soft_group(paths, r)] for r in range(R)], n_robots=R)
                 hc = {0: torch.stack([cases.hard_conds_for(starts[r], goals[r])[0] for r in range(R)]),
                       H - 1: torch.stack([cases.hard_conds_for(starts[r], goals[r])[H - 1] for r in range(R)])}
@@ -895,7 +895,7 @@ def test_persistent_run_equals_launch_per_step():
             res[flags] = out
     finally:
         model.sampler_flags = 0
-    assert len(res[0]) == 4
+    assert len(res[0]) == 6
     for flags in (_lib.SAMPLER_PERSIST, _lib.SAMPLER_NO_FUSED_STEP):
         for k in res[0]:
             assert torch.isfinite(res[0][k]).all() and torch.equal(res[0][k], res[flags][k]), (flags, k)

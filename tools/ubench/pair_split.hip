@@ -38,10 +38,13 @@ struct ConvP { const uint4* w; const float* par; uint4* xbuf; unsigned* flag; };
 
 // MODE 0 base, 1 pair (agent-scope release / acquire), 2 half (pair without the exchange), 3 pairL2 (see main: same-L2 protocol),
 // 4 basePF: base with the NEXT conv's first weight-ring steps requested before the current conv's GroupNorm + Mish epilogue
+// 5 base1 / 6 base1PF: base / basePF with ONE sample per workgroup (is the conv's time the weight stream alone, or do the second sample's
+//   MFMAs, A-fragment reads and epilogue sit on the critical path too?)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_chain(ConvP p, float* out, int nconv) {
-  constexpr int NT = (MODE == 0 || MODE == 4) ? 2 : 1, NS = 2;
-  constexpr bool BASE = MODE == 0 || MODE == 4;
+  constexpr bool BASE = MODE == 0 || MODE >= 4;
+  constexpr bool PFM = MODE == 4 || MODE == 6;
+  constexpr int NT = BASE ? 2 : 1, NS = MODE >= 5 ? 1 : 2;
   __shared__ __attribute__((aligned(16))) float lds[G128::BYTES / 4 + 64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, g = lane >> 4;
   char* const slab = reinterpret_cast<char*>(lds);
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     else asm volatile("" : "+v"(woff[0]));
     for (int t = 0; t < NT; ++t) wp[t] = reinterpret_cast<const u32x4*>(p.w) + woff[t];
   };
-  if constexpr (MODE == 4) {
+  if constexpr (PFM) {
     const u32x4* wp0[NT];
     wptrs(0, wp0);
     rd_ring_load<G128, NT, UB_RD>(ring, wp0);
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const u32x4* wp[NT];
     wptrs(k, wp);
     const Epi<NT> e = epi_load<NT>(p.par, p.par + 128, p.par + 256, p.par + 384, p.par + 512, c0);
-    if constexpr (MODE != 4) rd_ring_load<G128, NT, UB_RD>(ring, wp);
+    if constexpr (!PFM) rd_ring_load<G128, NT, UB_RD>(ring, wp);
     if constexpr (BASE) rd_store2<G128, NS>(vs, acc);
     else rd_store1<G128, NS>(vs, reinterpret_cast<f32x4(&)[NS][1]>(acc), lane);
     __syncthreads();
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       __syncthreads();
     }
     rd_taps<G128, NT, 0, 5, true, false, NS, UB_RD>(acc, res, va, wp, wp, ring);
-    if constexpr (MODE == 4) {                                 // the next conv's first three weight steps travel during the epilogue
+    if constexpr (PFM) {                                 // the next conv's first three weight steps travel during the epilogue
       const u32x4* wpn[NT];
       wptrs(k + 1, wpn);
       rd_ring_load<G128, NT, UB_RD>(ring, wpn);
@@ -154,7 +157,7 @@ int main(int argc, char** argv) {
   if (sizes.empty()) sizes = {8, 32, 64, 128};               // workgroups of the base arm = sample pairs (x 2 = trajectories)
   for (int nb : sizes) {
     if (nb % 8 || 2 * nb > max_wg) { printf("skip %d (a multiple of 8, <= %d)\n", nb, max_wg / 2); continue; }
-    for (int mode = 0; mode < 5; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
       float best = 1e9f;
       float check = 0.f;
       for (int rep = 0; rep < 5; ++rep) {
@@ -165,7 +168,9 @@ int main(int argc, char** argv) {
         else if (mode == 1) hipLaunchKernelGGL(conv_chain<1>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
         else if (mode == 2) hipLaunchKernelGGL(conv_chain<2>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
         else if (mode == 3) hipLaunchKernelGGL(conv_chain<3>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
-        else hipLaunchKernelGGL(conv_chain<4>, dim3(nb), dim3(256), 0, 0, p, dout, nconv);
+        else if (mode == 4) hipLaunchKernelGGL(conv_chain<4>, dim3(nb), dim3(256), 0, 0, p, dout, nconv);
+        else if (mode == 5) hipLaunchKernelGGL(conv_chain<5>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
+        else hipLaunchKernelGGL(conv_chain<6>, dim3(2 * nb), dim3(256), 0, 0, p, dout, nconv);
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best;
@@ -175,7 +180,7 @@ int main(int argc, char** argv) {
         if (timeouts) printf("  !! %u flag waits timed out: the timing of this arm is void\n", timeouts);
       }
       printf("%4d trajectories  %-6s: %3d workgroups, %d convs (128 -> 128, L = 16): %7.1f us -> %5.2f us per conv   (check %.4f, %s)\n", 2 * nb,
-             mode == 0 ? "base" : mode == 1 ? "pair" : mode == 2 ? "half" : mode == 3 ? "pairL2" : "basePF", (mode == 0 || mode == 4) ? nb : 2 * nb, nconv, best * 1e3, best * 1e3 / nconv, check,
+             mode == 0 ? "base" : mode == 1 ? "pair" : mode == 2 ? "half" : mode == 3 ? "pairL2" : mode == 4 ? "basePF" : mode == 5 ? "base1" : "base1PF", (mode == 0 || mode == 4) ? nb : 2 * nb, nconv, best * 1e3, best * 1e3 / nconv, check,
              hipGetErrorString(hipGetLastError()));
     }
   }
