@@ -547,7 +547,7 @@ def run_mode(args, scaling, rank, world, dev, rehearsal, with_roofline, cpu_job=
     }
     roofline = {
         "bound": "mfma",
-        "kernel": "unet_kernel<4> (<= 512 trajectories per launch: unet_kernel<2>): the whole TemporalUnet forward in one launch, every conv "
+        "kernel": "unet_kernel<4> (<= 512 trajectories per launch: unet_kernel<2>, <= 256: unet_kernel<1>): the whole TemporalUnet forward in one launch, every conv "
                   "a direct convolution as an fp16 two-piece split of fp32 on the fp16 matrix pipe, fp32 accumulate",
         "achieved": algo_tflops_round, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": algo_tflops_round / PEAK_F16_MFMA_TFLOPS,
         "frac_is": "algorithmic fp32 direct-conv FLOPs of the round / round time / dense fp16 MFMA peak (not the issued f16x2 FLOPs: those are pipe_occupancy)",
@@ -732,10 +732,10 @@ def run_ensemble(args, rank, world, dev, rehearsal=False):
               "noise": "in-kernel Philox4x32-10", "weights": "random-init (numpy PCG64 seed 0), the same for both tiles"}
     per_launch = B * RPG if mode == "batched" else B
     algo_tflops = lib.mmd_unet_flops_per_trajectory() * RPG * B * 2 * (T + 1) / (ms * 1e-3) / 1e12   # two tile forwards per trajectory and step
-    roofline = {"bound": "mfma", "kernel": f"unet_kernel<2> ({per_launch}-trajectory launches, one per tile and step)", "peak": PEAK_F16_MFMA_TFLOPS,
+    roofline = {"bound": "mfma", "kernel": f"unet_kernel<1> ({per_launch}-trajectory launches, one per tile and step)", "peak": PEAK_F16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "achieved": algo_tflops, "frac": algo_tflops / PEAK_F16_MFMA_TFLOPS,
                 "frac_is": "algorithmic fp32 direct-conv FLOPs of the round (2 tile forwards x (T + 1) steps x trajectories) / round time / dense "
-                           "fp16 MFMA peak; a launch of <= 256 trajectories leaves most CUs idle and costs ~83 us whatever its size: the planner "
+                           "fp16 MFMA peak; a launch of <= 256 trajectories (one per workgroup) costs 72 - 75 us whatever its size: the planner "
                            "call is latency bound (one workgroup's 25 dependent convs), which is why the calls of a round are packed into one launch sequence",
                 "pipe_occupancy": {"issue_frac": issue_ms / ms, "mfma_busy_pmc": None, "f16_mfma_per_fp32_product": 3},
                 "ms_per_step": ms, "unet_launches_per_round": (1 if mode == "batched" else RPG) * 2 * (T + 1),
