@@ -164,13 +164,47 @@ __device__ __forceinline__ f32x2g cons_accumulate1(f32x2g a, const TAB& tab, int
   return a;
 }
 
+// A robot's first two constraint groups' bounds and weights, read ONCE per launch: inside the 20 guide iterations every group evaluation
+// otherwise starts with three dependent loads from the (L2-resident) group tables -- the iterations store x / chain rows, so the compiler
+// cannot keep them -- in front of its first slot (a robot has one or two groups: soft constraints from the other robots, hard ones from a
+// conflict).  Wave-uniform values, selected by wave-uniform branches.
+struct GroupMeta {
+  int s0[2], s1[2];
+  float w[2];
+  int grp0, n;
+  __device__ __forceinline__ void load(const GuideDev& g, int g0, int g1) {
+    grp0 = g0;
+    n = min(g1 - g0, 2);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      s0[k] = s1[k] = 0;
+      w[k] = 0.f;
+      if (k < n) {
+        s0[k] = __builtin_amdgcn_readfirstlane(g.grp_slot_off[g0 + k]);
+        s1[k] = __builtin_amdgcn_readfirstlane(g.grp_slot_off[g0 + k + 1]);
+        w[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g.grp_weight[g0 + k])));
+      }
+    }
+  }
+  __device__ __forceinline__ void bounds(const GuideDev& g, int grp, int& a, int& b) const {
+    const int k = grp - grp0;
+    if (k == 0 && n > 0) { a = s0[0]; b = s1[0]; }
+    else if (k == 1 && n > 1) { a = s0[1]; b = s1[1]; }
+    else { a = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp]); b = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp + 1]); }
+  }
+  __device__ __forceinline__ float weight(const GuideDev& g, int grp) const {
+    const int k = grp - grp0;
+    return (k == 0 && n > 0) ? w[0] : (k == 1 && n > 1) ? w[1] : g.grp_weight[grp];
+  }
+};
+
 // group_sum(grp, p) = the slot sum of constraint group grp at the lane's position p (the canonical four-accumulator tree above)
 // DUMP (mmd_debug_ddpm_step_trace only): the iteration's discrete decisions of this support point -> tr[0 .. MMD_TRACE_WORDS)
 // (layout: include/mmd_amd_debug.h).  The constraint masks are re-derived slot by slot from the L2-resident table with
 // cons_term's own expression, so they are the decisions the sums above took.
-template <bool DUMP = false, class GROUPSUM>
+template <bool DUMP = false, class GROUPSUM, class GROUPW>
 __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t, const float4* __restrict__ grid,
-                                             int grp0, int grp1, GROUPSUM group_sum, unsigned int* tr = nullptr) {
+                                             int grp0, int grp1, GROUPSUM group_sum, GROUPW group_weight, unsigned int* tr = nullptr) {
   unsigned int flags = 0;
   // LimitsNormalizer.unnormalize (normalization.py:157-168), clip applied unconditionally
   float xu[4];
@@ -261,7 +295,7 @@ __device__ __forceinline__ float4 guide_grad(const GuideDev& g, float4 xn, int t
       }
       tr[10] += n_act;
     }
-    const float w = g.grp_weight[grp];
+    const float w = group_weight(grp);
     cx += w * gx; cy += w * gy;
   }
   // --- CostCollision over the SDF grids: d/dp max_k relu(margin - sdf_k(p))  (t >= 1; field_factor.py range [1,None])
@@ -362,10 +396,14 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
       grp0 = __builtin_amdgcn_readfirstlane(g.robot_grp_off[robot]);
       grp1 = __builtin_amdgcn_readfirstlane(g.robot_grp_off[robot + 1]);
     }
+    GroupMeta gm;
+    gm.load(g, grp0, grp1);
+    auto group_weight = [&](int grp) { return gm.weight(g, grp); };
     // the group's slots: LDS-resident ones first, any overflow straight from the L2-resident table
     auto group_sum = [&](int grp, f32x2g p) {
       // (group bounds are the same for the whole wave: scalar registers, scalar loop control)
-      const int s0 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp]), s1 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp + 1]);
+      int s0, s1;
+      gm.bounds(g, grp, s0, s1);
       const int l0 = min(max(s0 - lds_slot0, 0), lds_n), l1 = min(max(s1 - lds_slot0, 0), lds_n);   // LDS part
       Acc4 acc = acc4_zero();
       if (l1 > l0) {
@@ -385,7 +423,7 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
         tr = s.trace + ((size_t)it * s.guide_chain_stride + idx) * MMD_TRACE_WORDS;
         for (int w = 0; w < MMD_TRACE_WORDS; ++w) tr[w] = 0u;
       }
-      const float4 gr = guide_grad<DUMP>(g, v, t, grid, grp0, grp1, group_sum, tr);
+      const float4 gr = guide_grad<DUMP>(g, v, t, grid, grp0, grp1, group_sum, group_weight, tr);
       // (x + model_var * grad with scale_grad_by_std, sample_functions.py:100-104; grad_scale = 1 otherwise: the fma is then the add)
       v.x = __builtin_fmaf(s.grad_scale, gr.x, v.x); v.y = __builtin_fmaf(s.grad_scale, gr.y, v.y);
       v.z = __builtin_fmaf(s.grad_scale, gr.z, v.z); v.w = __builtin_fmaf(s.grad_scale, gr.w, v.w);
@@ -449,8 +487,12 @@ __global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDe
       grp1 = __builtin_amdgcn_readfirstlane(g.robot_grp_off[robot + 1]);
     }
     int parity = 0;
+    GroupMeta gm;
+    gm.load(g, grp0, grp1);
+    auto group_weight = [&](int grp) { return gm.weight(g, grp); };
     auto group_sum = [&](int grp, f32x2g p) {
-      const int s0 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp]), s1 = __builtin_amdgcn_readfirstlane(g.grp_slot_off[grp + 1]);
+      int s0, s1;
+      gm.bounds(g, grp, s0, s1);
       const int l0 = min(max(s0 - lds_slot0, 0), lds_n), l1 = min(max(s1 - lds_slot0, 0), lds_n);
       f32x2g a = {0.f, 0.f};
       if (l1 > l0) {
@@ -470,7 +512,7 @@ __global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDe
       return acc4_total(Acc4{f32x2g{q0.x, q0.y}, f32x2g{q1.x, q1.y}, f32x2g{q2.x, q2.y}, f32x2g{q3.x, q3.y}});
     };
     for (int it = 0; it < s.n_guide_steps; ++it) {
-      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, group_sum);
+      const float4 gr = guide_grad(g, v, t, grid, grp0, grp1, group_sum, group_weight);
       // (x + model_var * grad with scale_grad_by_std, sample_functions.py:100-104; grad_scale = 1 otherwise: the fma is then the add)
       v.x = __builtin_fmaf(s.grad_scale, gr.x, v.x); v.y = __builtin_fmaf(s.grad_scale, gr.y, v.y);
       v.z = __builtin_fmaf(s.grad_scale, gr.z, v.z); v.w = __builtin_fmaf(s.grad_scale, gr.w, v.w);
