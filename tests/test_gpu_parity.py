@@ -451,6 +451,43 @@ def test_guide_cooperative_kernel_equals_one_wave_kernel_bitwise(n_all):
     assert rel_l2(start.cpu(), ref) < 2e-4
 
 
+def test_guide_four_constraint_groups_per_robot():
+    """A robot with FOUR constraint groups (soft slots from the other robots, two hard vertex groups with different weights, a second soft
+    set) next to a robot with one: the kernels keep the first two groups' bounds and weights in registers for the 20 iterations and read
+    the table for the others -- both paths against the oracle, and the cooperative (16 trajectories) and one-wave (2 x 512) kernels
+    bitwise against each other.  ref: cost_functions.py:297-326 (one CostConstraint = one term with its own clip and weight)."""
+    starts, goals = synth.start_goal_circle(10, 0.45)
+    paths = synth.straight_line_paths(starts, goals, H)
+    groups0 = [cases.soft_group(paths, 0), cases.hard_group([[0.1, 0.2], [-0.2, 0.1]], [[20, 27], [30, 41]]),
+               cases.hard_group([[0.0, 0.0]], [[5, 60]], weight=0.11), cases.soft_group(paths[::-1].copy(), 3, weight=5e-2)]
+    cons = [groups0, [cases.soft_group(paths, 1)]]
+    hard = torch.stack([torch.stack([cases.hard_conds_for(starts[r], goals[r])[k] for k in (0, H - 1)]) for r in (0, 1)]).cuda().contiguous()
+    small = torch.from_numpy(synth.synth_noise(62, (2, 8, H, D))) * 0.5
+    big = torch.from_numpy(synth.synth_noise(63, (2, 512, H, D))) * 0.5
+    for r in (0, 1):                                          # (the loop pins rows 0 / H - 1 AFTER every iteration: start from pinned states)
+        small[r] = O.apply_hard_conditioning(small[r], cases.hard_conds_for(starts[r], goals[r]))
+    big[:, :8] = small
+    g = _gc().hip_guide("EnvHighways2D", cons, n_robots=2)
+    ys, yb = small.reshape(16, H, D).clone().cuda(), big.reshape(1024, H, D).clone().cuda()
+    g.guide_steps(ys, hard, _lib.HARD_ROWS_START_GOAL, 20)
+    g.guide_steps(yb, hard, _lib.HARD_ROWS_START_GOAL, 20)
+    assert torch.isfinite(ys).all() and torch.equal(ys.view(2, 8, H, D), yb.view(2, 512, H, D)[:, :8])
+    gp = cases.guide_params("EnvHighways2D")
+    for r in (0, 1):
+        hc = cases.hard_conds_for(starts[r], goals[r])
+        ref = small[r].clone()
+        for _ in range(20):
+            ref = O.apply_hard_conditioning(ref + O.guide_grad(ref, gp, cons[r], clip_mode="always"), hc)
+        assert rel_l2(ys.view(2, 8, H, D)[r].cpu(), ref) < 2e-4, r
+    # one evaluation, term by term exact to rounding: every group contributes (dropping any one of robot 0's groups changes the result)
+    x0 = small[0].clone()
+    full = _gc().hip_guide("EnvHighways2D", [groups0])(x0.cuda()).cpu()
+    assert (full - O.guide_grad(x0, gp, groups0, clip_mode="always")).abs().max() < 2e-6
+    for k in range(4):
+        part = _gc().hip_guide("EnvHighways2D", [groups0[:k] + groups0[k + 1:]])(x0.cuda()).cpu()
+        assert not torch.equal(part, full), k
+
+
 def test_soft_constraints_from_paths_kernel():
     """device-built all-pairs ELL == host-packed ELL for every local robot."""
     from mmd_amd.constraints import soft_constraints_from_paths
