@@ -16,7 +16,8 @@ unet = TemporalUnet(two_per_workgroup_max=int(os.environ.get('MMD_AMD_UNET_NS2_M
 unet.load_state_dict(synth.synth_unet_state_dict(0))
 x = torch.randn(n, 64, 4, device="cuda")
 ns2_max = int(os.environ.get("MMD_AMD_UNET_NS2_MAX", "512"))      # unet_kernel<2> (two trajectories per workgroup) up to here
-nb = (n + 1) // 2 if n <= ns2_max else (n + 3) // 4
+ns1_max = int(os.environ.get("MMD_NS1_MAX", "256"))               # unet_kernel<1> (one per workgroup) up to here: the side build's -DMMD_NS1_MAX
+nb = n if n <= min(ns1_max, ns2_max) else (n + 1) // 2 if n <= ns2_max else (n + 3) // 4
 trace = torch.zeros(nb * 4 * 256, dtype=torch.int64, device="cuda")
 for _ in range(3):
     unet(x, 50)
