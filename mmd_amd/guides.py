@@ -83,6 +83,7 @@ class GuideManagerTrajectoriesWithVelocity:
         self._cons = None
         self._cons_dirty = True
         self._external_cons = None
+        self._soft_paths = None
         self._max_slots = 0
         self._norm_limits = None
 
@@ -97,6 +98,23 @@ class GuideManagerTrajectoriesWithVelocity:
         self.extra_costs_grad_weight_l = [[] for _ in range(self.n_robots)]
         self._cons_dirty = True
         self._external_cons = None
+        self._soft_paths = None
+
+    def set_soft_paths(self, paths_all, self_index, radius=None, weight=2e-2):
+        """The soft constraints from the OTHER agents' current best paths (cbs.py:468-508 for equal start times: every point t >= 1 of
+        every other agent, range (t, t + 1), the vertex-constraint radius) handed over as ONE device tensor `paths_all` [N, 64, 2]
+        (un-normalised positions of all agents, this one at `self_index`) instead of a MultiPointConstraint of N - 1 times 63 tiny
+        tensors: the group is built on the device (mmd_soft_constraints_from_paths) and takes its place AFTER the groups added through
+        add_extra_costs -- the order CBS passes them in (cbs.py:407-413: the agent's hard constraints, then the soft ones).  Bitwise
+        the result of the list form.  One-robot guides only."""
+        from .constraints import VERTEX_CONSTRAINT_RADIUS
+        if self.n_robots != 1:
+            raise NotImplementedError("set_soft_paths: a guide of one robot (MultiRobotSampler.set_other_paths is the many-robot form)")
+        paths_all = paths_all.to(device=self.device, dtype=torch.float32).contiguous()
+        if paths_all.dim() != 3 or paths_all.shape[1] != 64 or paths_all.shape[2] != 2 or not 0 <= int(self_index) < paths_all.shape[0]:
+            raise ValueError(f"set_soft_paths: paths_all [N, 64, 2] and 0 <= self_index < N, got {tuple(paths_all.shape)}, {self_index}")
+        self._soft_paths = (paths_all, int(self_index), float(VERTEX_CONSTRAINT_RADIUS if radius is None else radius), float(weight))
+        self._cons_dirty = True
 
     def set_packed_constraints(self, cons):
         """Use device-built constraint tensors (constraints.soft_constraints_from_paths) instead of host-packed ones."""
@@ -109,6 +127,18 @@ class GuideManagerTrajectoriesWithVelocity:
         if self._cons_dirty:
             groups = [list(zip(c, w)) for c, w in zip(self.extra_cost_l, self.extra_costs_grad_weight_l)]
             self._cons, self._max_slots = pack_constraints(groups, self.device, return_max_slots=True)
+            if self._soft_paths is not None and self._soft_paths[0].shape[0] > 1:
+                from .constraints import soft_constraints_from_paths
+                paths_all, idx, radius, weight = self._soft_paths
+                soft = soft_constraints_from_paths(paths_all, idx, 1, radius, weight)        # (ell, gso, gw, rgo, radius): one group
+                if self._cons is None:
+                    self._cons, self._max_slots = soft, soft[0].shape[0]                     # (one radius: only (qx, qy) staged on chip)
+                else:
+                    ell_h, gso_h, gw_h, rgo_h = self._cons
+                    n_h = self._max_slots                                                    # one robot: the host groups' slots
+                    self._cons = (torch.cat((ell_h[:n_h], soft[0])), torch.cat((gso_h, soft[1][1:] + gso_h[-1:])),
+                                  torch.cat((gw_h, soft[2])), rgo_h + (soft[1] > 0).to(torch.int32))
+                    self._max_slots = n_h + soft[0].shape[0]
             self._cons_dirty = False
         return self._cons
 

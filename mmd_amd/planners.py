@@ -412,9 +412,14 @@ class MPD:
         return [CostConstraint(self.robot, self.n_support_points, q_l=c.get_q_l(), traj_range_l=c.get_t_range_l(),
                                radius_l=c.radius_l, is_soft=c.is_soft) for c in (constraints_l or [])]
 
-    def __call__(self, start_state_pos, goal_state_pos, constraints_l=None, experience=None, *args, **kwargs):
+    def __call__(self, start_state_pos, goal_state_pos, constraints_l=None, experience=None, *args, soft_paths=None, **kwargs):
+        """`soft_paths` (an extension; None = the reference's call): (paths_all [N, 64, 2] device tensor, this agent's index) -- the soft
+        constraints from the other agents' current best paths (cbs.py:468-508) as one tensor instead of a MultiPointConstraint of
+        (N - 1) x 63 tiny tensors in `constraints_l`; built on the device, placed after the groups of `constraints_l`, weighted with
+        weight_grad_cost_soft_constraints: bitwise the list form's result without its 0.14 ms of host conversion per call."""
         _check_states(self, start_state_pos, goal_state_pos)
         cost_constraints_l = self._cost_constraints(constraints_l)
+        self._soft_paths = soft_paths
         with _Timer() as timer:
             if experience is None:
                 chain = self.run_constrained_inference(cost_constraints_l, **kwargs)
@@ -431,6 +436,9 @@ class MPD:
         self.guide.add_extra_costs(cost_constraints_l,
                                    [self.weight_grad_cost_soft_constraints if c.is_soft else
                                     self.weight_grad_cost_constraints for c in cost_constraints_l])
+        soft_paths, self._soft_paths = getattr(self, "_soft_paths", None), None
+        if soft_paths is not None:
+            self.guide.set_soft_paths(soft_paths[0], soft_paths[1], weight=self.weight_grad_cost_soft_constraints)
 
     def _post_guidance(self, chain):
         """planner_alg 'diffusion_prior_then_guide' (mpd.py:429-453): extra guide steps after the prior sample."""
@@ -444,8 +452,8 @@ class MPD:
         return torch.cat((chain, extra))
 
     def run_constrained_inference(self, cost_constraints_l, **kw):
-        self._add_constraints(cost_constraints_l)
         try:
+            self._add_constraints(cost_constraints_l)
             chain = self.model.run_inference(
                 self.context, self.hard_conds, n_samples=self.num_samples, horizon=self.n_support_points,
                 return_chain=True, sample_fn=ddpm_sample_fn, **self.sample_fn_kwargs,
@@ -456,8 +464,8 @@ class MPD:
         return chain
 
     def run_constrained_local_inference(self, cost_constraints_l, experience, **kw):
-        self._add_constraints(cost_constraints_l)
         try:
+            self._add_constraints(cost_constraints_l)
             chain = self.model.run_local_inference(
                 experience.path_b.to(self.device), self.n_local_inference_noising_steps,
                 self.n_local_inference_denoising_steps, self.context, self.hard_conds, n_samples=self.num_samples,

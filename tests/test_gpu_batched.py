@@ -238,3 +238,36 @@ def test_robot_seeds_across_stream_chunks():
         assert torch.equal(got[r * B:(r + 1) * B], one), r
     with pytest.raises(ValueError):
         model.run_inference(None, hc, n_samples=B, n_robots=R, guide=guide, robot_seeds=seeds[:5], **kw)
+
+
+def test_soft_paths_tensor_equals_the_constraint_list():
+    """MPD.__call__(..., soft_paths=(paths_all, agent)) -- the other agents' best paths as ONE device tensor, the soft group built on the
+    device and placed after the hard groups -- against the reference's form of the same call: a MultiPointConstraint of 9 x 63 tiny
+    tensors appended to constraints_l as cbs.py:407-413 / :468-508 build it.  Bitwise, with and without hard constraints, for a fresh
+    plan and for a re-plan from an experience; and the guide is left clean."""
+    from mmd_amd.constraints import MultiPointConstraint
+    from mmd_amd.planners import PathBatchExperience
+    starts, goals = synth.start_goal_circle(10, 0.45)
+    paths = synth.straight_line_paths(starts, goals, H)
+    r = 3
+    p = _mpd("EnvHighways2D", starts[r], goals[r], 21)
+    s, g = torch.from_numpy(starts[r]), torch.from_numpy(goals[r])
+    paths_dev = torch.from_numpy(paths).cuda()
+    soft = MultiPointConstraint(q_l=[paths_dev[j, t] for j in range(10) if j != r for t in range(1, H)],
+                                t_range_l=[(t, t + 1) for j in range(10) if j != r for t in range(1, H)], is_soft=True)
+    hard = [MultiPointConstraint(q_l=[torch.tensor([0.1, 0.2])], t_range_l=[(20, 27)]),
+            MultiPointConstraint(q_l=[torch.tensor([-0.2, 0.1]), torch.tensor([0.0, 0.05])], t_range_l=[(30, 33), (40, 47)])]
+    first = p(s, g, seed=400)
+    exp = PathBatchExperience(first.trajs_final)
+    for k, (h, e) in enumerate(((hard, None), ([], None), (hard[:1], exp), (None, exp))):
+        a = p(s, g, list(h or []) + [soft], e, seed=410 + k)
+        b = p(s, g, h, e, soft_paths=(paths_dev, r), seed=410 + k)
+        for name in ("trajs_iters", "trajs_final", "trajs_final_free_idxs", "trajs_final_coll_idxs"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (k, name)
+        assert (a.idx_best_traj is None) == (b.idx_best_traj is None) and (a.idx_best_traj is None or int(a.idx_best_traj) == int(b.idx_best_traj))
+        assert p.guide.extra_cost_l == [[]] and p.guide._soft_paths is None
+    # the soft group does something: without it the call differs
+    assert not torch.equal(p(s, g, hard, seed=410).trajs_final, p(s, g, hard, soft_paths=(paths_dev, r), seed=410).trajs_final)
+    with pytest.raises(ValueError):
+        p(s, g, hard, soft_paths=(paths_dev[:, :32], r))
+    assert p.guide.extra_cost_l == [[]] and p.guide._soft_paths is None
