@@ -343,6 +343,9 @@ __global__ __launch_bounds__(WPB * 64) void ddpm_guide_kernel(GuideDev g, StepDe
 #ifdef MMD_GUIDE_PRIO   // (A/B build: the step kernel is on the critical chain of its stream chunk while the other chunk's UNet launch shares the SIMDs)
   __builtin_amdgcn_s_setprio(MMD_GUIDE_PRIO);
 #endif
+#ifdef MMD_GUIDE_PLAIN   // (A/B side build: the configuration every planner runs -- clip by norm, no extra objects, at most one grid -- folded in)
+  g.clip_rule = 0; g.n_xs = 0; g.n_xb = 0; g.n_grids = g.n_grids > 0 ? 1 : 0;
+#endif
   const int t = threadIdx.x & 63;
   const int traj_b = s.traj0 + blockIdx.x * WPB;
   const int traj = traj_b + (threadIdx.x >> 6);
@@ -451,6 +454,9 @@ __global__ __launch_bounds__(256) void ddpm_guide_coop_kernel(GuideDev g, StepDe
                                                               float4* __restrict__ chain, const float4* __restrict__ hard,
                                                               int samples_per_robot) {
   extern __shared__ __attribute__((aligned(16))) float4 lds_cons[];
+#ifdef MMD_GUIDE_PLAIN   // (A/B side build: the configuration every planner runs -- clip by norm, no extra objects, at most one grid -- folded in)
+  g.clip_rule = 0; g.n_xs = 0; g.n_xb = 0; g.n_grids = g.n_grids > 0 ? 1 : 0;
+#endif
   const int t = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int traj = s.traj0 + blockIdx.x;                   // (the grid is exactly the launch's trajectories)
   const int robot = traj / samples_per_robot;
